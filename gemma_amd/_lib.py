@@ -1,0 +1,95 @@
+"""ctypes binding of include/gemma_hip.h.  There is no CPU fallback: if the shared library is
+missing this module raises, and every entry point returns GEMMA_HIP_ENODEV without a gfx950 GPU."""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libgemma_hip.so")
+
+# every symbol include/gemma_hip.h declares
+SYMBOLS = [
+    "gemma_hip_init", "gemma_hip_shutdown", "gemma_hip_abi_version", "gemma_hip_strerror",
+    "gemma_hip_last_error", "gemma_hip_device_info", "gemma_hip_dgemm", "gemma_hip_dgemm_d",
+    "gemma_hip_kin_begin", "gemma_hip_kin_add", "gemma_hip_kin_add_d", "gemma_hip_kin_end",
+    "gemma_hip_kin_end_d", "gemma_hip_center", "gemma_hip_center_d", "gemma_hip_eigh",
+    "gemma_hip_eigh_d", "gemma_hip_calc_utx", "gemma_hip_lmm_setup", "gemma_hip_lmm_setup_d",
+    "gemma_hip_lmm_null", "gemma_hip_lmm_set_indicator", "gemma_hip_lmm_batch", "gemma_hip_lmm_batch_d",
+    "gemma_hip_lmm_assoc_d", "gemma_hip_lmm_finish", "gemma_hip_profile_enable",
+    "gemma_hip_profile_read",
+]
+
+OK, EINVAL, ENODEV, ENOMEM, ERUNTIME, ESTATE, ENOCONV = range(7)
+GENO_F64_SNP_MAJOR, GENO_PLINK_2BIT, GENO_F64_IDV_MAJOR = 0, 1, 2
+STAGE_INGEST, STAGE_UTX_GEMM, STAGE_ASSOC, STAGE_KIN_GEMM, STAGE_EIGH = range(5)
+
+
+class SumStat(C.Structure):
+    _fields_ = [(k, C.c_double) for k in
+                ("beta", "se", "lambda_remle", "lambda_mle", "p_wald", "p_lrt", "p_score", "logl_H1")]
+
+
+class LmmCfg(C.Structure):
+    _fields_ = [("a_mode", C.c_int), ("n", C.c_size_t), ("n_cvt", C.c_size_t), ("l_min", C.c_double),
+                ("l_max", C.c_double), ("n_region", C.c_size_t), ("l_mle_null", C.c_double),
+                ("logl_mle_H0", C.c_double), ("plink_nan_rule", C.c_int)]
+
+
+class GemmaHipError(RuntimeError):
+    def __init__(self, code, where, detail):
+        self.code = code
+        super().__init__("%s: error %d (%s)" % (where, code, detail))
+
+
+_lib = None
+
+
+def lib():
+    """Load gemma_amd/libgemma_hip.so (built by gemma_amd.build / __graft_entry__.build)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("gemma_amd/libgemma_hip.so is missing -- run `python -m gemma_amd.build` "
+                          "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+    L = C.CDLL(LIB_PATH)
+    vp, dp, sz, ci, cd = C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_double
+    L.gemma_hip_init.argtypes = [ci, ci]
+    L.gemma_hip_shutdown.restype = None
+    L.gemma_hip_strerror.restype = C.c_char_p
+    L.gemma_hip_strerror.argtypes = [ci]
+    L.gemma_hip_last_error.restype = C.c_char_p
+    L.gemma_hip_device_info.argtypes = [C.c_char_p, sz, C.POINTER(ci), C.POINTER(sz)]
+    gemm = [C.c_char, C.c_char, sz, sz, sz, cd, dp, sz, dp, sz, cd, dp, sz]
+    L.gemma_hip_dgemm.argtypes = gemm
+    L.gemma_hip_dgemm_d.argtypes = gemm + [vp]
+    L.gemma_hip_kin_begin.argtypes = [sz, ci]
+    L.gemma_hip_kin_add.argtypes = [ci, vp, sz, sz]
+    L.gemma_hip_kin_add_d.argtypes = [ci, vp, sz, sz, vp]
+    L.gemma_hip_kin_end.argtypes = [dp, C.POINTER(sz)]
+    L.gemma_hip_kin_end_d.argtypes = [dp, C.POINTER(sz), vp]
+    L.gemma_hip_center.argtypes = [dp, sz]
+    L.gemma_hip_center_d.argtypes = [dp, sz, vp]
+    L.gemma_hip_eigh.argtypes = [dp, sz, dp, dp, C.POINTER(cd)]
+    L.gemma_hip_eigh_d.argtypes = [dp, sz, dp, dp, C.POINTER(cd), vp]
+    L.gemma_hip_calc_utx.argtypes = [dp, dp, sz, sz, dp]
+    L.gemma_hip_lmm_setup.argtypes = [C.POINTER(LmmCfg), dp, dp, dp, dp]
+    L.gemma_hip_lmm_setup_d.argtypes = [C.POINTER(LmmCfg), dp, dp, dp, dp, vp]
+    L.gemma_hip_lmm_null.argtypes = [sz, sz, dp, dp, dp, cd, cd, sz, cd, dp]
+    L.gemma_hip_lmm_set_indicator.argtypes = [vp, sz]
+    L.gemma_hip_lmm_batch.argtypes = [ci, vp, sz, sz, vp]
+    L.gemma_hip_lmm_batch_d.argtypes = [ci, vp, sz, sz, vp, vp]
+    L.gemma_hip_lmm_assoc_d.argtypes = [dp, sz, sz, vp, vp]
+    L.gemma_hip_lmm_finish.argtypes = [C.POINTER(cd), C.POINTER(cd)]
+    L.gemma_hip_profile_enable.argtypes = [ci]
+    L.gemma_hip_profile_read.argtypes = [ci, C.POINTER(cd), C.POINTER(C.c_long), ci]
+    for s in SYMBOLS:
+        getattr(L, s)  # AttributeError if the library does not export what the header declares
+    _lib = L
+    return L
+
+
+def check(rc, where):
+    if rc != OK:
+        L = lib()
+        detail = L.gemma_hip_last_error().decode() or L.gemma_hip_strerror(rc).decode()
+        raise GemmaHipError(rc, where, detail)

@@ -1,0 +1,346 @@
+"""Host-side mirror of the GEMMA interfaces on the kinship + univariate-LMM path, over the C ABI.
+
+Names, argument meaning and error behaviour follow the reference (file:line relative to the
+GEMMA tree) so that the parity tests read like the reference's own tests:
+
+    fast_dgemm            src/fastblas.h:34-36
+    CenterMatrix          src/mathfunc.cpp:147-177
+    EigenDecomp_Zeroed    src/lapack.cpp:260-291
+    CalcUtX               src/mathfunc.cpp:504-506
+    CalcKin / BimbamKin / PlinkKin   src/param.cpp:1300-1321, src/gemma_io.cpp:1418-1738
+    CalcLambdaNull / CalcPve         src/lmm.cpp:2143-2205
+    class LMM  (CopyFromParam fields, Analyze*, WriteFiles)   src/lmm.h:49-125
+
+Arrays may be numpy arrays (host entry points; the library stages through HBM) or torch CUDA
+tensors (device entry points on torch's current stream: torch is only the allocator/stream here).
+All compute happens in gemma_amd/libgemma_hip.so; nothing in this module has a CPU fallback.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+
+SUMSTAT_DTYPE = np.dtype([(k, "f8") for k in
+                          ("beta", "se", "lambda_remle", "lambda_mle", "p_wald", "p_lrt", "p_score",
+                           "logl_H1")])
+LMM_BATCH_SIZE = 20000  # src/lmm.h:33
+K_BATCH_SIZE = 20000  # src/param.h:32
+
+
+def _is_torch(x):
+    return type(x).__module__.startswith("torch")
+
+
+def _np64(a, name):
+    if not isinstance(a, np.ndarray) or a.dtype != np.float64:
+        raise TypeError("%s must be a float64 numpy array" % name)
+    if a.ndim == 2 and a.strides[1] != 8:
+        raise ValueError("%s must be row-major with unit column stride" % name)
+    return a
+
+
+def _ld(a):
+    return a.shape[1] if a.ndim == 2 and a.shape[0] <= 1 else (a.strides[0] // 8 if a.ndim == 2 else a.shape[0])
+
+
+def _ptr(a):
+    return C.c_void_p(a.ctypes.data)
+
+
+def _stream():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _tld(t):
+    if t.dim() != 2 or t.stride(1) != 1:
+        raise ValueError("device matrices must be 2-D row-major")
+    return t.stride(0) if t.shape[0] > 1 else t.shape[1]
+
+
+def init(device=-1, verbose=0):
+    L.check(L.lib().gemma_hip_init(device, verbose), "gemma_hip_init")
+
+
+def device_info():
+    name = C.create_string_buffer(256)
+    cu = C.c_int()
+    mem = C.c_size_t()
+    L.check(L.lib().gemma_hip_device_info(name, 256, C.byref(cu), C.byref(mem)), "device_info")
+    return name.value.decode(), cu.value, mem.value
+
+
+def profile_enable(on=True):
+    L.check(L.lib().gemma_hip_profile_enable(1 if on else 0), "profile_enable")
+
+
+def profile_read(stage, reset=False):
+    ms = C.c_double()
+    n = C.c_long()
+    L.check(L.lib().gemma_hip_profile_read(stage, C.byref(ms), C.byref(n), 1 if reset else 0), "profile_read")
+    return ms.value, n.value
+
+
+# ----------------------------------------------------------------------------- B2
+def fast_dgemm(TransA, TransB, alpha, A, B, beta, Cm):
+    """C = alpha*op(A)*op(B) + beta*C (row-major).  Shape mismatch -> GemmaHipError(EINVAL), the
+    reference's fail_msg("Range error in dgemm") (src/fastblas.cpp:207)."""
+    ta, tb = TransA.upper()[0], TransB.upper()[0]
+    M, N = Cm.shape
+    if ta not in "NT" or tb not in "NT":
+        raise L.GemmaHipError(L.EINVAL, "fast_dgemm", "bad transpose flag")
+    Ka = A.shape[0] if ta == "T" else A.shape[1]
+    Ma = A.shape[1] if ta == "T" else A.shape[0]
+    Kb = B.shape[1] if tb == "T" else B.shape[0]
+    Nb = B.shape[0] if tb == "T" else B.shape[1]
+    if Ma != M or Nb != N or Ka != Kb:
+        raise L.GemmaHipError(L.EINVAL, "fast_dgemm", "Range error in dgemm")
+    if _is_torch(Cm):
+        rc = L.lib().gemma_hip_dgemm_d(ta.encode(), tb.encode(), M, N, Ka, alpha, C.c_void_p(A.data_ptr()),
+                                       _tld(A), C.c_void_p(B.data_ptr()), _tld(B), beta,
+                                       C.c_void_p(Cm.data_ptr()), _tld(Cm), _stream())
+    else:
+        _np64(A, "A"); _np64(B, "B"); _np64(Cm, "C")
+        rc = L.lib().gemma_hip_dgemm(ta.encode(), tb.encode(), M, N, Ka, alpha, _ptr(A), _ld(A), _ptr(B),
+                                     _ld(B), beta, _ptr(Cm), _ld(Cm))
+    L.check(rc, "fast_dgemm")
+    return Cm
+
+
+fast_eigen_dgemm = fast_dgemm  # src/fastblas.h:37-39 (historical alias)
+
+
+# ----------------------------------------------------------------------------- B3
+def CenterMatrix(G):
+    """In place, src/mathfunc.cpp:147-177."""
+    n = G.shape[0]
+    if _is_torch(G):
+        L.check(L.lib().gemma_hip_center_d(C.c_void_p(G.data_ptr()), n, _stream()), "CenterMatrix")
+    else:
+        _np64(G, "G")
+        if not G.flags.c_contiguous:
+            raise ValueError("G must be contiguous")
+        L.check(L.lib().gemma_hip_center(_ptr(G), n), "CenterMatrix")
+    return G
+
+
+def EigenDecomp_Zeroed(G, U, eval_):
+    """G is destroyed; U gets eigenvectors in columns, eval_ ascending with values < 1e-10 zeroed.
+    Returns trace_G = mean(eval) (src/lapack.cpp:260-291)."""
+    n = G.shape[0]
+    tr = C.c_double()
+    if _is_torch(G):
+        rc = L.lib().gemma_hip_eigh_d(C.c_void_p(G.data_ptr()), n, C.c_void_p(U.data_ptr()),
+                                      C.c_void_p(eval_.data_ptr()), C.byref(tr), _stream())
+    else:
+        _np64(G, "G"); _np64(U, "U"); _np64(eval_, "eval")
+        rc = L.lib().gemma_hip_eigh(_ptr(G), n, _ptr(U), _ptr(eval_), C.byref(tr))
+    L.check(rc, "EigenDecomp_Zeroed")
+    return tr.value
+
+
+def CalcUtX(U, X):
+    """UtX = U^T X (src/mathfunc.cpp:504-506).  X: n x m (or n,) numpy."""
+    X2 = np.ascontiguousarray(X.reshape(X.shape[0], -1), dtype=np.float64)
+    n, m = X2.shape
+    out = np.zeros((n, m))
+    L.check(L.lib().gemma_hip_calc_utx(_ptr(_np64(U, "U")), _ptr(X2), n, m, _ptr(out)), "CalcUtX")
+    return out.reshape(X.shape)
+
+
+# ----------------------------------------------------------------------------- B1
+def kin_begin(n_total, k_mode=1):
+    L.check(L.lib().gemma_hip_kin_begin(n_total, k_mode), "kin_begin")
+
+
+def kin_add(geno, geno_kind, l=None, ld=None):
+    if _is_torch(geno):
+        l = geno.shape[0] if l is None else l
+        if geno_kind == L.GENO_F64_IDV_MAJOR and l is None:
+            l = geno.shape[1]
+        ld = _tld(geno) if ld is None else ld
+        rc = L.lib().gemma_hip_kin_add_d(geno_kind, C.c_void_p(geno.data_ptr()), l, ld, _stream())
+    else:
+        if geno_kind == L.GENO_F64_IDV_MAJOR:
+            l = geno.shape[1] if l is None else l
+        else:
+            l = geno.shape[0] if l is None else l
+        ld = (geno.strides[0] // geno.itemsize) if ld is None else ld
+        rc = L.lib().gemma_hip_kin_add(geno_kind, _ptr(geno), l, ld)
+    L.check(rc, "kin_add")
+
+
+def kin_end(K=None):
+    ns = C.c_size_t()
+    if K is not None and _is_torch(K):
+        L.check(L.lib().gemma_hip_kin_end_d(C.c_void_p(K.data_ptr()), C.byref(ns), _stream()), "kin_end")
+    else:
+        L.check(L.lib().gemma_hip_kin_end(_ptr(K) if K is not None else None, C.byref(ns)), "kin_end")
+    return ns.value
+
+
+def CalcKin(geno, geno_kind, n_total, k_mode=1, batch=K_BATCH_SIZE):
+    """PARAM::CalcKin -> BimbamKin / PlinkKin: streams `geno` (SNP-major rows) in blocks of
+    K_BATCH_SIZE SNPs and returns the n_total x n_total kinship matrix (numpy)."""
+    kin_begin(n_total, k_mode)
+    p = geno.shape[0]
+    for s0 in range(0, p, batch):
+        kin_add(geno[s0:s0 + batch], geno_kind)
+    K = np.zeros((n_total, n_total))
+    kin_end(K)
+    return K
+
+
+# ----------------------------------------------------------------------------- null model
+def CalcLambdaNull(eval_, UtW, Uty, l_min=1e-5, l_max=1e5, n_region=10, trace_G=1.0):
+    """Returns dict(l_mle_null, logl_mle_H0, l_remle_null, logl_remle_H0, pve, pve_se, vg, ve):
+    src/gemma.cpp:2711-2750."""
+    UtW = np.ascontiguousarray(UtW, dtype=np.float64).reshape(len(eval_), -1)
+    out = np.zeros(8)
+    n, c = UtW.shape
+    L.check(L.lib().gemma_hip_lmm_null(n, c, _ptr(_np64(np.ascontiguousarray(eval_), "eval")), _ptr(UtW),
+                                       _ptr(np.ascontiguousarray(Uty, dtype=np.float64)), l_min, l_max,
+                                       n_region, trace_G, _ptr(out)), "CalcLambdaNull")
+    keys = ("l_mle_null", "logl_mle_H0", "l_remle_null", "logl_remle_H0", "pve", "pve_se", "vg_remle",
+            "ve_remle")
+    return dict(zip(keys, out.tolist()))
+
+
+# ----------------------------------------------------------------------------- B4
+class LMM:
+    """Mirror of class LMM (src/lmm.h:49-125): the fields CopyFromParam fills (src/lmm.cpp:56-90)
+    and the Analyze* drivers.  sumStat is a numpy record array with SUMSTAT's fields."""
+
+    def __init__(self, a_mode=1, l_min=1e-5, l_max=1e5, n_region=10, l_mle_null=0.0, logl_mle_H0=0.0):
+        self.a_mode = a_mode
+        self.l_min, self.l_max, self.n_region = l_min, l_max, n_region
+        self.l_mle_null, self.logl_mle_H0 = l_mle_null, logl_mle_H0
+        self.ni_test = 0
+        self.n_cvt = 0
+        self.time_UtX = 0.0
+        self.time_opt = 0.0
+        self.sumStat = np.zeros(0, dtype=SUMSTAT_DTYPE)
+        self._active = False
+
+    # -- state handling ---------------------------------------------------------------
+    def _cfg(self, n, c, plink):
+        cfg = L.LmmCfg()
+        cfg.a_mode = self.a_mode
+        cfg.n, cfg.n_cvt = n, c
+        cfg.l_min, cfg.l_max, cfg.n_region = self.l_min, self.l_max, self.n_region
+        cfg.l_mle_null, cfg.logl_mle_H0 = self.l_mle_null, self.logl_mle_H0
+        cfg.plink_nan_rule = 1 if plink else 0
+        return cfg
+
+    def setup(self, U, eval_, UtW, Uty, plink=False):
+        n = U.shape[0]
+        if _is_torch(U):
+            c = UtW.shape[1] if UtW.dim() == 2 else 1
+            cfg = self._cfg(n, c, plink)
+            self._keep = (U, eval_, UtW, Uty)  # borrowed by the library until finish()
+            rc = L.lib().gemma_hip_lmm_setup_d(C.byref(cfg), C.c_void_p(U.data_ptr()),
+                                               C.c_void_p(eval_.data_ptr()), C.c_void_p(UtW.data_ptr()),
+                                               C.c_void_p(Uty.data_ptr()), _stream())
+        else:
+            UtW = np.ascontiguousarray(UtW, dtype=np.float64).reshape(n, -1)
+            c = UtW.shape[1]
+            cfg = self._cfg(n, c, plink)
+            rc = L.lib().gemma_hip_lmm_setup(C.byref(cfg), _ptr(_np64(np.ascontiguousarray(U), "U")),
+                                             _ptr(np.ascontiguousarray(eval_, dtype=np.float64)), _ptr(UtW),
+                                             _ptr(np.ascontiguousarray(Uty, dtype=np.float64)))
+        L.check(rc, "LMM.setup")
+        self.ni_test, self.n_cvt = n, c
+        self._active = True
+
+    def set_indicator(self, indicator_idv):
+        ind = np.ascontiguousarray(indicator_idv, dtype=np.int32)
+        L.check(L.lib().gemma_hip_lmm_set_indicator(_ptr(ind), ind.size), "LMM.set_indicator")
+
+    def batch(self, geno, geno_kind, out=None, l=None, ld=None):
+        """One block of SNPs -> SUMSTAT records (numpy in/out, or torch device tensors in/out)."""
+        if _is_torch(geno):
+            import torch
+            l = geno.shape[0] if l is None else l
+            ld = _tld(geno) if ld is None else ld
+            if out is None:
+                out = torch.empty((l, 8), dtype=torch.float64, device=geno.device)
+            rc = L.lib().gemma_hip_lmm_batch_d(geno_kind, C.c_void_p(geno.data_ptr()), l, ld,
+                                               C.c_void_p(out.data_ptr()), _stream())
+            L.check(rc, "LMM.batch")
+            return out
+        if geno_kind == L.GENO_F64_IDV_MAJOR:
+            l = geno.shape[1] if l is None else l
+        else:
+            l = geno.shape[0] if l is None else l
+        ld = (geno.strides[0] // geno.itemsize) if ld is None else ld
+        if out is None:
+            out = np.zeros(l, dtype=SUMSTAT_DTYPE)
+        L.check(L.lib().gemma_hip_lmm_batch(geno_kind, _ptr(geno), l, ld, _ptr(out)), "LMM.batch")
+        return out
+
+    def assoc(self, UtX, out=None):
+        """Per-SNP stage only, on a device-resident SNP-major UtX (torch)."""
+        import torch
+        l = UtX.shape[0]
+        if out is None:
+            out = torch.empty((l, 8), dtype=torch.float64, device=UtX.device)
+        L.check(L.lib().gemma_hip_lmm_assoc_d(C.c_void_p(UtX.data_ptr()), l, _tld(UtX),
+                                              C.c_void_p(out.data_ptr()), _stream()), "LMM.assoc")
+        return out
+
+    def finish(self):
+        a, b = C.c_double(), C.c_double()
+        L.check(L.lib().gemma_hip_lmm_finish(C.byref(a), C.byref(b)), "LMM.finish")
+        self.time_UtX, self.time_opt = a.value, b.value
+        self._active = False
+        self._keep = None
+
+    # -- drivers ----------------------------------------------------------------------
+    def Analyze(self, U, eval_, UtW, Uty, geno, geno_kind=L.GENO_F64_SNP_MAJOR, plink=False,
+                indicator_idv=None, batch=LMM_BATCH_SIZE):
+        """LMM::Analyze (src/lmm.cpp:1474-1658): stream SNP-major `geno` in blocks of LMM_BATCH_SIZE;
+        results are appended in SNP order to self.sumStat."""
+        self.setup(U, eval_, UtW, Uty, plink=plink)
+        try:
+            if indicator_idv is not None:
+                self.set_indicator(indicator_idv)
+            outs = []
+            for s0 in range(0, geno.shape[0], batch):
+                outs.append(self.batch(geno[s0:s0 + batch], geno_kind))
+            self.sumStat = np.concatenate(outs) if outs else np.zeros(0, dtype=SUMSTAT_DTYPE)
+        finally:
+            self.finish()
+        return self.sumStat
+
+    def AnalyzeBimbam(self, U, eval_, UtW, Uty, X_snpmajor_nan):
+        """src/lmm.cpp:1660-1706 with the file reader factored out: X is SNP-major over the analysed
+        individuals, NaN = "NA"."""
+        return self.Analyze(U, eval_, UtW, Uty, np.ascontiguousarray(X_snpmajor_nan, dtype=np.float64),
+                            L.GENO_F64_SNP_MAJOR, plink=False)
+
+    def AnalyzePlink(self, U, eval_, UtW, Uty, bed_rows, indicator_idv):
+        """src/lmm.cpp:1710-1903: bed_rows = the .bed payload of the analysed SNPs (uint8, one row of
+        ceil(ni_total/4) bytes per SNP); non-analysed individuals are dropped on device."""
+        return self.Analyze(U, eval_, UtW, Uty, np.ascontiguousarray(bed_rows, dtype=np.uint8),
+                            L.GENO_PLINK_2BIT, plink=True, indicator_idv=indicator_idv)
+
+    def WriteFiles(self, path, snp_info):
+        """LMM::WriteFiles (src/lmm.cpp:101-225): `.assoc.txt`.  snp_info: iterable of dicts with
+        chr, rs, ps, n_miss, allele1, allele0, af for every analysed SNP, in order."""
+        m = self.a_mode
+        head = "chr\trs\tps\tn_miss\tallele1\tallele0\taf\t"
+        cols = {1: ["beta", "se", "logl_H1", "l_remle", "p_wald"],
+                2: ["logl_H1", "l_mle", "p_lrt"],
+                3: ["beta", "se", "p_score"],
+                4: ["beta", "se", "logl_H1", "l_remle", "l_mle", "p_wald", "p_lrt", "p_score"],
+                9: ["beta", "se", "l_mle", "p_lrt"]}[m]
+        field = {"l_remle": "lambda_remle", "l_mle": "lambda_mle"}
+        with open(path, "w") as f:
+            f.write(head + "\t".join(cols) + "\n")
+            for info, st in zip(snp_info, self.sumStat):
+                f.write("%s\t%s\t%s\t%d\t%s\t%s\t%.3f" % (info["chr"], info["rs"], info["ps"], info["n_miss"],
+                                                          info["allele1"], info["allele0"], info["af"]))
+                for cname in cols:
+                    f.write("\t%.6e" % st[field.get(cname, cname)])
+                f.write("\n")

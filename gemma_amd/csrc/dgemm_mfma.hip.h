@@ -1,0 +1,305 @@
+// fp64 MFMA GEMM for gfx950 (MI355X): C(MxN) = alpha * op(A) * op(B) + beta * C, row-major.
+//
+// Replaces the cblas_dgemm behind fast_dgemm / fast_eigen_dgemm (GEMMA src/fastblas.cpp:175-209).
+// Hot call sites: U^T X per SNP batch (src/lmm.cpp:1521,1847), K += Xb Xb^T (src/gemma_io.cpp:1554,
+// 1711), CalcUtX (src/mathfunc.cpp:504-506).
+//
+// Design (CDNA4):
+//  * v_mfma_f64_16x16x4_f64: one 16x16 output block per instruction, K = 4, 64 cycles/SIMD
+//    (78.6 TFLOP/s chip peak).  A/B operands are ONE f64 per lane (A[i=l&15][k=l>>4],
+//    B[k=l>>4][j=l&15]); the 16x16 f64 result is 4 f64 per lane: col = l&15, row = (l>>4)+4*r.
+//  * 128x128 block tile, 256 threads = 4 wavefronts in a 2x2 grid, each wave owns 64x64
+//    (4x4 MFMA blocks = 64 f64 accumulators per lane = 128 VGPR), BK = 16.
+//    LDS demand is tiny next to the 64-cycle MFMA (8 ds_read_b64 per 16 MFMAs), so the tile
+//    is sized for L2->LDS traffic (16 flop/B) and occupancy (2 blocks/CU, 73.7 KB LDS each).
+//  * global -> registers -> LDS double buffering: the loads for K-tile t+1 are issued before the
+//    MFMAs of tile t and written to the other LDS buffer after them; one barrier per K-tile.
+//  * LDS image follows the operand's memory order so the 16-byte global loads and the
+//    ds_write_b128 are both contiguous:  [k][m] operands ("T" for A, "N" for B) are kept as
+//    [16][144] (144 = 128 + 16: the two k-rows a 32-lane ds_read_b64 group touches land on
+//    disjoint bank halves), [m][k] operands as [128][18] (row stride 18 doubles walks all 32
+//    8-byte banks).
+//  * blockIdx -> tile: XCD-aware (block b runs on XCD b % 8): every XCD gets a contiguous run of
+//    tiles, rastered in groups of 8 tile-rows so the ~64 blocks an XCD runs at once form an
+//    8x8 patch sharing A/B panels in that XCD's 4 MiB L2.
+//  * SYRK mode (kinship): only tiles with tile_n >= tile_m are launched (triangular grid).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace gemma_hip {
+
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+typedef double f64x2 __attribute__((ext_vector_type(2)));
+
+constexpr int GEMM_BM = 128, GEMM_BN = 128, GEMM_BK = 16;
+constexpr int GEMM_LD_KM = 144; // [k][m] image: row stride in doubles
+constexpr int GEMM_LD_MK = 18;  // [m][k] image: row stride in doubles
+constexpr int GEMM_TILE_DOUBLES = 2304; // 16*144 == 128*18
+constexpr int GEMM_THREADS = 256;
+
+struct GemmArgs {
+  const double *A;
+  const double *B;
+  double *C;
+  long M, N, K;
+  long lda, ldb, ldc;
+  double alpha, beta;
+  int tiles_m, tiles_n;
+  int syrk_upper;  // 1: launch only tiles with tn >= tm
+  int square_a;    // 1: use A*A elementwise as the A operand (grid-lambda x^2 sums)
+};
+
+// 16-byte global load of two consecutive doubles with element-wise bounds; `vec_ok` says the
+// address is 16-byte aligned and both elements are in range.
+__device__ __forceinline__ f64x2 ld2(const double *p, bool ok0, bool ok1, bool vec_ok) {
+  f64x2 v;
+  if (vec_ok) {
+    v = *reinterpret_cast<const f64x2 *>(p);
+  } else {
+    v.x = ok0 ? p[0] : 0.0;
+    v.y = ok1 ? p[1] : 0.0;
+  }
+  return v;
+}
+
+// Operand tile loader.  KM = true: operand stored [k][m] (m contiguous, leading dim ld);
+// KM = false: stored [m][k] (k contiguous).  Loads the BK x 128 tile at (k0, m0) into 4 f64x2.
+template <bool KM>
+__device__ __forceinline__ void load_tile(const double *__restrict__ P, long ld, long m0, long k0,
+                                          long Mdim, long Kdim, bool aligned, int t, f64x2 r[4]) {
+  if (KM) {
+    const int mm = 2 * (t & 63);
+    const int kb = t >> 6;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const long k = k0 + kb + 4 * j;
+      const long m = m0 + mm;
+      const bool kin = k < Kdim;
+      const bool ok0 = kin && (m < Mdim), ok1 = kin && (m + 1 < Mdim);
+      const double *p = P + k * ld + m;
+      if (ok0 || ok1)
+        r[j] = ld2(p, ok0, ok1, aligned && ok1);
+      else
+        r[j] = f64x2{0.0, 0.0};
+    }
+  } else {
+    const int kk = 2 * (t & 7);
+    const int mb = t >> 3;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const long m = m0 + mb + 32 * j;
+      const long k = k0 + kk;
+      const bool min_ = m < Mdim;
+      const bool ok0 = min_ && (k < Kdim), ok1 = min_ && (k + 1 < Kdim);
+      const double *p = P + m * ld + k;
+      if (ok0 || ok1)
+        r[j] = ld2(p, ok0, ok1, aligned && ok1);
+      else
+        r[j] = f64x2{0.0, 0.0};
+    }
+  }
+}
+
+template <bool KM>
+__device__ __forceinline__ void store_tile(double *__restrict__ S, int t, const f64x2 r[4]) {
+  if (KM) {
+    const int mm = 2 * (t & 63);
+    const int kb = t >> 6;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      *reinterpret_cast<f64x2 *>(S + (kb + 4 * j) * GEMM_LD_KM + mm) = r[j];
+  } else {
+    const int kk = 2 * (t & 7);
+    const int mb = t >> 3;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      *reinterpret_cast<f64x2 *>(S + (mb + 32 * j) * GEMM_LD_MK + kk) = r[j];
+  }
+}
+
+template <bool KM>
+__device__ __forceinline__ double frag(const double *__restrict__ S, int m, int k) {
+  return KM ? S[k * GEMM_LD_KM + m] : S[m * GEMM_LD_MK + k];
+}
+
+// block id -> (tm, tn)
+__device__ __forceinline__ void tile_of_block(const GemmArgs &g, int &tm, int &tn) {
+  const int nwg = gridDim.x;
+  const int b = blockIdx.x;
+  // bijective XCD remap: XCD x (= b % 8) gets a contiguous logical range
+  const int q = nwg >> 3, r = nwg & 7, x = b & 7, o = b >> 3;
+  const int L = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + o;
+  if (g.syrk_upper) {
+    // logical index L over the upper triangle, row-major: row tm has (T - tm) tiles
+    const int T = g.tiles_m;
+    const double Td = (double)(2 * T + 1);
+    int i = (int)((Td - sqrt(Td * Td - 8.0 * (double)L)) * 0.5);
+    if (i < 0) i = 0;
+    if (i > T - 1) i = T - 1;
+    // fix up float error
+    while (i > 0 && (long)i * (2 * T - i + 1) / 2 > L) --i;
+    while ((long)(i + 1) * (2 * T - i) / 2 <= L) ++i;
+    tm = i;
+    tn = i + (L - (int)((long)i * (2 * T - i + 1) / 2));
+  } else {
+    const int GM = 8;
+    const int per_group = GM * g.tiles_n;
+    const int grp = L / per_group;
+    const int first_m = grp * GM;
+    const int gsz = min(g.tiles_m - first_m, GM);
+    const int in = L - grp * per_group;
+    tm = first_m + in % gsz;
+    tn = in / gsz;
+  }
+}
+
+template <bool A_KM, bool B_KN>
+__global__ __launch_bounds__(GEMM_THREADS, 2) void dgemm_mfma_kernel(GemmArgs g) {
+  __shared__ __attribute__((aligned(16))) double lds[4 * GEMM_TILE_DOUBLES];
+  double *As0 = lds, *As1 = lds + GEMM_TILE_DOUBLES;
+  double *Bs0 = lds + 2 * GEMM_TILE_DOUBLES, *Bs1 = lds + 3 * GEMM_TILE_DOUBLES;
+
+  int tm, tn;
+  tile_of_block(g, tm, tn);
+  const long m0 = (long)tm * GEMM_BM, n0 = (long)tn * GEMM_BN;
+  const int t = threadIdx.x;
+  const int lane = t & 63, wave = t >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l15 = lane & 15, l4 = lane >> 4;
+
+  const bool a_al = ((reinterpret_cast<uintptr_t>(g.A) & 15) == 0) && ((g.lda & 1) == 0);
+  const bool b_al = ((reinterpret_cast<uintptr_t>(g.B) & 15) == 0) && ((g.ldb & 1) == 0);
+
+  f64x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f64x4{0.0, 0.0, 0.0, 0.0};
+
+  f64x2 ra[4], rb[4];
+  const long nk = (g.K + GEMM_BK - 1) / GEMM_BK;
+
+  load_tile<A_KM>(g.A, g.lda, m0, 0, g.M, g.K, a_al, t, ra);
+  load_tile<B_KN>(g.B, g.ldb, n0, 0, g.N, g.K, b_al, t, rb);
+  if (g.square_a) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) ra[j] = ra[j] * ra[j];
+  }
+  store_tile<A_KM>(As0, t, ra);
+  store_tile<B_KN>(Bs0, t, rb);
+  __syncthreads();
+
+  for (long kt = 0; kt < nk; ++kt) {
+    const double *As = (kt & 1) ? As1 : As0;
+    const double *Bs = (kt & 1) ? Bs1 : Bs0;
+    const bool more = (kt + 1) < nk;
+    if (more) {
+      load_tile<A_KM>(g.A, g.lda, m0, (kt + 1) * GEMM_BK, g.M, g.K, a_al, t, ra);
+      load_tile<B_KN>(g.B, g.ldb, n0, (kt + 1) * GEMM_BK, g.N, g.K, b_al, t, rb);
+    }
+#pragma unroll
+    for (int kk = 0; kk < GEMM_BK / 4; ++kk) {
+      double a[4], b[4];
+      const int k = kk * 4 + l4;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a[i] = frag<A_KM>(As, wm * 64 + i * 16 + l15, k);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) b[j] = frag<B_KN>(Bs, wn * 64 + j * 16 + l15, k);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    if (more) {
+      if (g.square_a) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) ra[j] = ra[j] * ra[j];
+      }
+      store_tile<A_KM>((kt & 1) ? As0 : As1, t, ra);
+      store_tile<B_KN>((kt & 1) ? Bs0 : Bs1, t, rb);
+    }
+    __syncthreads();
+  }
+
+  // epilogue: lane holds rows (l>>4)+4r, col l&15 of each 16x16 block
+  const double alpha = g.alpha, beta = g.beta;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const long col = n0 + wn * 64 + j * 16 + l15;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const long row = m0 + wm * 64 + i * 16 + l4 + 4 * r;
+        if (row < g.M && col < g.N) {
+          double *c = g.C + row * g.ldc + col;
+          double v = alpha * acc[i][j][r];
+          if (beta != 0.0) v += beta * (*c);
+          *c = v;
+        }
+      }
+    }
+  }
+}
+
+// mirror the strict upper triangle into the lower one and scale everything (kinship epilogue:
+// K *= 1/ns_test, GEMMA src/gemma_io.cpp:1570, and the symmetric fill of :1724-1729)
+__global__ void symm_fill_scale_kernel(double *K, long n, long ld, double scale) {
+  __shared__ double tile[32][33];
+  // blocks cover the upper-triangular 32x32 tile pairs (bx >= by)
+  const int bx = blockIdx.x, by = blockIdx.y;
+  if (bx < by) return;
+  const int tx = threadIdx.x, ty = threadIdx.y; // 32 x 8
+  for (int r = ty; r < 32; r += 8) {
+    const long i = (long)by * 32 + r, j = (long)bx * 32 + tx;
+    double v = 0.0;
+    if (i < n && j < n) {
+      v = K[i * ld + j] * scale;
+      if (j >= i) K[i * ld + j] = v;
+    }
+    tile[r][tx] = v;
+  }
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8) {
+    // element (j, i) of the lower triangle <- tile[i_local][j_local]
+    const long j = (long)bx * 32 + r, i = (long)by * 32 + tx;
+    if (i < n && j < n && j > i) K[j * ld + i] = tile[tx][r];
+  }
+}
+
+template <bool A_KM, bool B_KN>
+static inline hipError_t launch_dgemm_t(const GemmArgs &g, hipStream_t s) {
+  int nblocks;
+  if (g.syrk_upper)
+    nblocks = g.tiles_m * (g.tiles_m + 1) / 2;
+  else
+    nblocks = g.tiles_m * g.tiles_n;
+  hipLaunchKernelGGL((dgemm_mfma_kernel<A_KM, B_KN>), dim3(nblocks), dim3(GEMM_THREADS), 0, s, g);
+  return hipGetLastError();
+}
+
+// ta/tb in {'N','T'} with the cblas row-major meaning
+static inline hipError_t launch_dgemm(char ta, char tb, long M, long N, long K, double alpha,
+                                      const double *A, long lda, const double *B, long ldb,
+                                      double beta, double *C, long ldc, bool syrk_upper,
+                                      bool square_a, hipStream_t s) {
+  GemmArgs g;
+  g.A = A; g.B = B; g.C = C;
+  g.M = M; g.N = N; g.K = K;
+  g.lda = lda; g.ldb = ldb; g.ldc = ldc;
+  g.alpha = alpha; g.beta = beta;
+  g.tiles_m = (int)((M + GEMM_BM - 1) / GEMM_BM);
+  g.tiles_n = (int)((N + GEMM_BN - 1) / GEMM_BN);
+  g.syrk_upper = syrk_upper ? 1 : 0;
+  g.square_a = square_a ? 1 : 0;
+  const bool tA = (ta == 'T' || ta == 't'), tB = (tb == 'T' || tb == 't');
+  // op(A) = A^T  <=> A stored [k][m]  (KM image);  op(B) = B <=> B stored [k][n] (KN image)
+  if (tA && !tB) return launch_dgemm_t<true, true>(g, s);
+  if (tA && tB) return launch_dgemm_t<true, false>(g, s);
+  if (!tA && !tB) return launch_dgemm_t<false, true>(g, s);
+  return launch_dgemm_t<false, false>(g, s);
+}
+
+} // namespace gemma_hip

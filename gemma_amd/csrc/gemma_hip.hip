@@ -1,0 +1,772 @@
+// C ABI of the MI355X kinship + univariate-LMM path (see include/gemma_hip.h).
+// Host-side glue only: device memory, streams, launches, staging copies.  All arithmetic of the
+// hot path lives in the kernels of dgemm_mfma.hip.h / lmm_assoc.hip.h / ingest.hip.h / eigh.hip.h.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/gemma_hip.h"
+#include "dgemm_mfma.hip.h"
+#include "eigh.hip.h"
+#include "ingest.hip.h"
+#include "lmm_assoc.hip.h"
+
+using namespace gemma_hip;
+
+namespace {
+
+struct DevBuf {
+  void *p = nullptr;
+  size_t cap = 0;
+  int reserve(size_t bytes) {
+    if (bytes <= cap) return GEMMA_HIP_OK;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+    if (hipMalloc(&p, bytes) != hipSuccess) {
+      (void)hipGetLastError();
+      return GEMMA_HIP_ENOMEM;
+    }
+    cap = bytes;
+    return GEMMA_HIP_OK;
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+  template <class T> T *as() { return reinterpret_cast<T *>(p); }
+};
+
+struct StageProf {
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
+  double acc_ms = 0.0;
+  long launches = 0;
+};
+
+struct Ctx {
+  bool inited = false;
+  int device = -1;
+  int verbose = 0;
+  std::string last_error;
+  hipDeviceProp_t prop;
+  bool profiling = false;
+  StageProf prof[GEMMA_STAGE_COUNT];
+
+  // kinship state
+  bool kin_active = false;
+  size_t kin_n = 0;
+  int kin_mode = 1;
+  size_t kin_ns = 0;
+  DevBuf kin_K, kin_X, kin_stage;
+
+  // lmm state
+  bool lmm_active = false;
+  gemma_lmm_cfg cfg;
+  const double *U = nullptr, *eval = nullptr, *Uty = nullptr; // device
+  DevBuf own_U, own_eval, own_Uty, own_UtW, UtWt, idx_map;
+  size_t ni_total = 0; // PLINK rows cover this many individuals (0 = n)
+  bool have_map = false;
+  DevBuf X, UtX, stage_in, stage_out, carry;
+  int carry_flip = 0;
+  AssocArgs assoc_proto;
+
+  // misc scratch
+  DevBuf scratch;
+} g_ctx;
+
+int fail(int code, const char *fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_ctx.last_error = buf;
+  if (g_ctx.verbose) fprintf(stderr, "gemma_hip: %s\n", buf);
+  return code;
+}
+
+#define HIPCHK(expr)                                                                        \
+  do {                                                                                      \
+    hipError_t e_ = (expr);                                                                 \
+    if (e_ != hipSuccess)                                                                   \
+      return fail(GEMMA_HIP_ERUNTIME, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
+                  __FILE__, __LINE__);                                                      \
+  } while (0)
+
+#define NEED_INIT()                                                                              \
+  do {                                                                                           \
+    if (!g_ctx.inited) {                                                                         \
+      int rc_ = gemma_hip_init(-1, 0);                                                           \
+      if (rc_ != GEMMA_HIP_OK) return rc_;                                                       \
+    }                                                                                            \
+  } while (0)
+
+struct ProfScope {
+  int stage;
+  hipStream_t s;
+  hipEvent_t a = nullptr, b = nullptr;
+  ProfScope(int st, hipStream_t stream) : stage(st), s(stream) {
+    if (g_ctx.profiling) {
+      if (hipEventCreate(&a) == hipSuccess && hipEventCreate(&b) == hipSuccess)
+        (void)hipEventRecord(a, s);
+      else
+        a = b = nullptr;
+    }
+  }
+  ~ProfScope() {
+    if (a && b) {
+      (void)hipEventRecord(b, s);
+      g_ctx.prof[stage].ev.emplace_back(a, b);
+    }
+  }
+};
+
+int prof_collect(int stage) {
+  StageProf &p = g_ctx.prof[stage];
+  for (auto &pr : p.ev) {
+    (void)hipEventSynchronize(pr.second);
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) {
+      p.acc_ms += ms;
+      p.launches += 1;
+    }
+    (void)hipEventDestroy(pr.first);
+    (void)hipEventDestroy(pr.second);
+  }
+  p.ev.clear();
+  return GEMMA_HIP_OK;
+}
+
+inline hipStream_t S(void *s) { return reinterpret_cast<hipStream_t>(s); }
+
+} // namespace
+
+// ------------------------------------------------------------------------------ lifetime
+extern "C" int gemma_hip_abi_version(void) { return GEMMA_HIP_ABI_VERSION; }
+
+extern "C" const char *gemma_hip_strerror(int code) {
+  switch (code) {
+  case GEMMA_HIP_OK: return "ok";
+  case GEMMA_HIP_EINVAL: return "invalid argument (range error)";
+  case GEMMA_HIP_ENODEV: return "no usable gfx950 device";
+  case GEMMA_HIP_ENOMEM: return "device memory allocation failed";
+  case GEMMA_HIP_ERUNTIME: return "HIP runtime error";
+  case GEMMA_HIP_ESTATE: return "call sequence violated";
+  case GEMMA_HIP_ENOCONV: return "eigensolver did not converge";
+  default: return "unknown error";
+  }
+}
+
+extern "C" const char *gemma_hip_last_error(void) { return g_ctx.last_error.c_str(); }
+
+extern "C" int gemma_hip_init(int device, int verbose) {
+  g_ctx.verbose = verbose;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+    (void)hipGetLastError();
+    return fail(GEMMA_HIP_ENODEV, "no HIP device visible (this library has no CPU fallback)");
+  }
+  if (device >= 0) {
+    if (device >= ndev) return fail(GEMMA_HIP_ENODEV, "device %d out of range (%d visible)", device, ndev);
+    HIPCHK(hipSetDevice(device));
+  }
+  int cur = 0;
+  HIPCHK(hipGetDevice(&cur));
+  HIPCHK(hipGetDeviceProperties(&g_ctx.prop, cur));
+  if (strncmp(g_ctx.prop.gcnArchName, "gfx950", 6) != 0)
+    return fail(GEMMA_HIP_ENODEV, "device %d is %s; this build targets gfx950 only", cur,
+                g_ctx.prop.gcnArchName);
+  g_ctx.device = cur;
+  g_ctx.inited = true;
+  if (verbose)
+    fprintf(stderr, "gemma_hip: device %d %s (%s), %d CUs, %.1f GB\n", cur, g_ctx.prop.name,
+            g_ctx.prop.gcnArchName, g_ctx.prop.multiProcessorCount,
+            (double)g_ctx.prop.totalGlobalMem / 1e9);
+  return GEMMA_HIP_OK;
+}
+
+extern "C" void gemma_hip_shutdown(void) {
+  if (!g_ctx.inited) return;
+  (void)hipDeviceSynchronize();
+  for (int s = 0; s < GEMMA_STAGE_COUNT; ++s) prof_collect(s);
+  g_ctx.kin_K.release(); g_ctx.kin_X.release(); g_ctx.kin_stage.release();
+  g_ctx.own_U.release(); g_ctx.own_eval.release(); g_ctx.own_Uty.release(); g_ctx.own_UtW.release();
+  g_ctx.UtWt.release(); g_ctx.idx_map.release(); g_ctx.X.release(); g_ctx.UtX.release();
+  g_ctx.stage_in.release(); g_ctx.stage_out.release(); g_ctx.carry.release(); g_ctx.scratch.release();
+  g_ctx.kin_active = g_ctx.lmm_active = false;
+  g_ctx.inited = false;
+}
+
+extern "C" int gemma_hip_device_info(char *name, size_t len, int *n_cu, size_t *hbm_bytes) {
+  NEED_INIT();
+  if (name && len) {
+    snprintf(name, len, "%s (%s)", g_ctx.prop.name, g_ctx.prop.gcnArchName);
+  }
+  if (n_cu) *n_cu = g_ctx.prop.multiProcessorCount;
+  if (hbm_bytes) *hbm_bytes = g_ctx.prop.totalGlobalMem;
+  return GEMMA_HIP_OK;
+}
+
+extern "C" int gemma_hip_profile_enable(int on) {
+  g_ctx.profiling = (on != 0);
+  return GEMMA_HIP_OK;
+}
+
+extern "C" int gemma_hip_profile_read(int stage, double *total_ms, long *launches, int reset) {
+  NEED_INIT();
+  if (stage < 0 || stage >= GEMMA_STAGE_COUNT) return fail(GEMMA_HIP_EINVAL, "bad stage %d", stage);
+  prof_collect(stage);
+  if (total_ms) *total_ms = g_ctx.prof[stage].acc_ms;
+  if (launches) *launches = g_ctx.prof[stage].launches;
+  if (reset) {
+    g_ctx.prof[stage].acc_ms = 0.0;
+    g_ctx.prof[stage].launches = 0;
+  }
+  return GEMMA_HIP_OK;
+}
+
+// ------------------------------------------------------------------------------ GEMM
+static int check_gemm(char ta, char tb, size_t M, size_t N, size_t K, size_t lda, size_t ldb,
+                      size_t ldc) {
+  const bool tA = (ta == 'T' || ta == 't'), tB = (tb == 'T' || tb == 't');
+  if (!tA && ta != 'N' && ta != 'n') return fail(GEMMA_HIP_EINVAL, "dgemm: bad TransA '%c'", ta);
+  if (!tB && tb != 'N' && tb != 'n') return fail(GEMMA_HIP_EINVAL, "dgemm: bad TransB '%c'", tb);
+  const size_t a_cols = tA ? M : K, b_cols = tB ? K : N;
+  if (lda < a_cols || ldb < b_cols || ldc < N)
+    return fail(GEMMA_HIP_EINVAL, "Range error in dgemm (lda=%zu ldb=%zu ldc=%zu for M=%zu N=%zu K=%zu)",
+                lda, ldb, ldc, M, N, K);
+  return GEMMA_HIP_OK;
+}
+
+extern "C" int gemma_hip_dgemm_d(char ta, char tb, size_t M, size_t N, size_t K, double alpha,
+                                 const double *A, size_t lda, const double *B, size_t ldb,
+                                 double beta, double *C, size_t ldc, void *stream) {
+  NEED_INIT();
+  int rc = check_gemm(ta, tb, M, N, K, lda, ldb, ldc);
+  if (rc) return rc;
+  if (M == 0 || N == 0) return GEMMA_HIP_OK;
+  ProfScope ps(GEMMA_STAGE_UTX_GEMM, S(stream));
+  HIPCHK(launch_dgemm(ta, tb, (long)M, (long)N, (long)K, alpha, A, (long)lda, B, (long)ldb, beta, C,
+                      (long)ldc, false, false, S(stream)));
+  return GEMMA_HIP_OK;
+}
+
+extern "C" int gemma_hip_dgemm(char ta, char tb, size_t M, size_t N, size_t K, double alpha,
+                               const double *A, size_t lda, const double *B, size_t ldb,
+                               double beta, double *C, size_t ldc) {
+  NEED_INIT();
+  int rc = check_gemm(ta, tb, M, N, K, lda, ldb, ldc);
+  if (rc) return rc;
+  if (M == 0 || N == 0) return GEMMA_HIP_OK;
+  const bool tA = (ta == 'T' || ta == 't'), tB = (tb == 'T' || tb == 't');
+  const size_t a_rows = tA ? K : M, b_rows = tB ? N : K;
+  const size_t a_bytes = a_rows * lda * 8, b_bytes = b_rows * ldb * 8, c_bytes = M * ldc * 8;
+  DevBuf dA, dB, dC;
+  if (dA.reserve(a_bytes ? a_bytes : 8) || dB.reserve(b_bytes ? b_bytes : 8) || dC.reserve(c_bytes)) {
+    dA.release(); dB.release(); dC.release();
+    return fail(GEMMA_HIP_ENOMEM, "dgemm: cannot allocate %zu bytes", a_bytes + b_bytes + c_bytes);
+  }
+  // the last row of a strided host view may be shorter than ld: copy row-wise via 2D copies
+  auto h2d = [&](void *d, const double *h, size_t rows, size_t cols, size_t ld) -> hipError_t {
+    if (rows == 0 || cols == 0) return hipSuccess;
+    return hipMemcpy2D(d, ld * 8, h, ld * 8, cols * 8, rows, hipMemcpyHostToDevice);
+  };
+  hipError_t e = h2d(dA.p, A, a_rows, tA ? M : K, lda);
+  if (e == hipSuccess) e = h2d(dB.p, B, b_rows, tB ? K : N, ldb);
+  if (e == hipSuccess && beta != 0.0) e = h2d(dC.p, C, M, N, ldc);
+  if (e == hipSuccess)
+    e = launch_dgemm(ta, tb, (long)M, (long)N, (long)K, alpha, dA.as<double>(), (long)lda,
+                     dB.as<double>(), (long)ldb, beta, dC.as<double>(), (long)ldc, false, false, 0);
+  if (e == hipSuccess) e = hipMemcpy2D(C, ldc * 8, dC.p, ldc * 8, N * 8, M, hipMemcpyDeviceToHost);
+  dA.release(); dB.release(); dC.release();
+  if (e != hipSuccess) return fail(GEMMA_HIP_ERUNTIME, "dgemm: %s", hipGetErrorString(e));
+  return GEMMA_HIP_OK;
+}
+
+// ------------------------------------------------------------------------------ kinship
+extern "C" int gemma_hip_kin_begin(size_t n_total, int k_mode) {
+  NEED_INIT();
+  if (n_total == 0) return fail(GEMMA_HIP_EINVAL, "kin_begin: n_total == 0");
+  if (k_mode != 1 && k_mode != 2) return fail(GEMMA_HIP_EINVAL, "kin_begin: k_mode %d", k_mode);
+  if (g_ctx.kin_K.reserve(n_total * n_total * 8))
+    return fail(GEMMA_HIP_ENOMEM, "kin_begin: cannot allocate K (%zu bytes)", n_total * n_total * 8);
+  HIPCHK(hipMemsetAsync(g_ctx.kin_K.p, 0, n_total * n_total * 8, 0));
+  g_ctx.kin_active = true;
+  g_ctx.kin_n = n_total;
+  g_ctx.kin_mode = k_mode;
+  g_ctx.kin_ns = 0;
+  return GEMMA_HIP_OK;
+}
+
+static size_t min_ld_for(int kind, size_t n_items_per_row, size_t l) {
+  switch (kind) {
+  case GEMMA_GENO_F64_SNP_MAJOR: return n_items_per_row;
+  case GEMMA_GENO_PLINK_2BIT: return (n_items_per_row + 3) / 4;
+  case GEMMA_GENO_F64_IDV_MAJOR: return l;
+  default: return (size_t)-1;
+  }
+}
+
+extern "C" int gemma_hip_kin_add_d(int kind, const void *geno, size_t l, size_t ld, void *stream) {
+  NEED_INIT();
+  if (!g_ctx.kin_active) return fail(GEMMA_HIP_ESTATE, "kin_add before kin_begin");
+  if (l == 0) return GEMMA_HIP_OK;
+  const size_t n = g_ctx.kin_n;
+  const size_t need = min_ld_for(kind, n, l);
+  if (need == (size_t)-1) return fail(GEMMA_HIP_EINVAL, "kin_add: unknown geno_kind %d", kind);
+  if (!geno || ld < need) return fail(GEMMA_HIP_EINVAL, "kin_add: ld=%zu < %zu", ld, need);
+  hipStream_t s = S(stream);
+  const size_t ldx = (n + 1) & ~(size_t)1;
+  if (g_ctx.kin_X.reserve(l * ldx * 8))
+    return fail(GEMMA_HIP_ENOMEM, "kin_add: cannot allocate %zu bytes", l * ldx * 8);
+  double *X = g_ctx.kin_X.as<double>();
+  {
+    ProfScope ps(GEMMA_STAGE_INGEST, s);
+    if (kind == GEMMA_GENO_F64_IDV_MAJOR) {
+      dim3 grid((unsigned)((l + 31) / 32), (unsigned)((n + 31) / 32));
+      hipLaunchKernelGGL(transpose_kernel, grid, dim3(32, 8), 0, s,
+                         reinterpret_cast<const double *>(geno), (long)n, (long)l, (long)ld, X, (long)ldx);
+    } else {
+      IngestArgs a;
+      a.src = geno; a.ld = (long)ld; a.l = (long)l; a.idx_map = nullptr; a.n = (int)n;
+      a.dst = X; a.ldo = (long)ldx; a.k_mode = g_ctx.kin_mode;
+      const unsigned grid = (unsigned)((l + 3) / 4);
+      if (kind == GEMMA_GENO_PLINK_2BIT)
+        hipLaunchKernelGGL(ingest_kin_kernel<true>, dim3(grid), dim3(256), 0, s, a);
+      else
+        hipLaunchKernelGGL(ingest_kin_kernel<false>, dim3(grid), dim3(256), 0, s, a);
+    }
+    HIPCHK(hipGetLastError());
+  }
+  {
+    // K(upper tiles) += X^T X : A = X as [k = snp][m = individual]  -> ('T','N')
+    ProfScope ps(GEMMA_STAGE_KIN_GEMM, s);
+    HIPCHK(launch_dgemm('T', 'N', (long)n, (long)n, (long)l, 1.0, X, (long)ldx, X, (long)ldx, 1.0,
+                        g_ctx.kin_K.as<double>(), (long)n, true, false, s));
+  }
+  g_ctx.kin_ns += l;
+  return GEMMA_HIP_OK;
+}
+
+extern "C" int gemma_hip_kin_add(int kind, const void *geno, size_t l, size_t ld) {
+  NEED_INIT();
+  if (!g_ctx.kin_active) return fail(GEMMA_HIP_ESTATE, "kin_add before kin_begin");
+  if (l == 0) return GEMMA_HIP_OK;
+  const size_t n = g_ctx.kin_n;
+  const size_t need = min_ld_for(kind, n, l);
+  if (need == (size_t)-1) return fail(GEMMA_HIP_EINVAL, "kin_add: unknown geno_kind %d", kind);
+  if (!geno || ld < need) return fail(GEMMA_HIP_EINVAL, "kin_add: ld=%zu < %zu", ld, need);
+  const size_t rows = (kind == GEMMA_GENO_F64_IDV_MAJOR) ? n : l;
+  const size_t esz = (kind == GEMMA_GENO_PLINK_2BIT) ? 1 : 8;
+  const size_t bytes = rows * ld * esz;
+  if (g_ctx.kin_stage.reserve(bytes)) return fail(GEMMA_HIP_ENOMEM, "kin_add: staging %zu bytes", bytes);
+  // last row may be shorter than ld in the caller's buffer
+  const size_t width = need * esz;
+  HIPCHK(hipMemcpy2D(g_ctx.kin_stage.p, ld * esz, geno, ld * esz, width, rows, hipMemcpyHostToDevice));
+  return gemma_hip_kin_add_d(kind, g_ctx.kin_stage.p, l, ld, nullptr);
+}
+
+extern "C" int gemma_hip_kin_end_d(double *K_d, size_t *ns_used, void *stream) {
+  NEED_INIT();
+  if (!g_ctx.kin_active) return fail(GEMMA_HIP_ESTATE, "kin_end before kin_begin");
+  const size_t n = g_ctx.kin_n;
+  hipStream_t s = S(stream);
+  if (ns_used) *ns_used = g_ctx.kin_ns;
+  const double scale = g_ctx.kin_ns ? 1.0 / (double)g_ctx.kin_ns : 1.0;
+  const unsigned nb = (unsigned)((n + 31) / 32);
+  hipLaunchKernelGGL(symm_fill_scale_kernel, dim3(nb, nb), dim3(32, 8), 0, s, g_ctx.kin_K.as<double>(),
+                     (long)n, (long)n, scale);
+  HIPCHK(hipGetLastError());
+  if (K_d) HIPCHK(hipMemcpyAsync(K_d, g_ctx.kin_K.p, n * n * 8, hipMemcpyDeviceToDevice, s));
+  HIPCHK(hipStreamSynchronize(s));
+  g_ctx.kin_active = false;
+  g_ctx.kin_X.release();
+  g_ctx.kin_stage.release();
+  g_ctx.kin_K.release();
+  return GEMMA_HIP_OK;
+}
+
+extern "C" int gemma_hip_kin_end(double *K, size_t *ns_used) {
+  NEED_INIT();
+  if (!g_ctx.kin_active) return fail(GEMMA_HIP_ESTATE, "kin_end before kin_begin");
+  const size_t n = g_ctx.kin_n;
+  if (ns_used) *ns_used = g_ctx.kin_ns;
+  const double scale = g_ctx.kin_ns ? 1.0 / (double)g_ctx.kin_ns : 1.0;
+  const unsigned nb = (unsigned)((n + 31) / 32);
+  hipLaunchKernelGGL(symm_fill_scale_kernel, dim3(nb, nb), dim3(32, 8), 0, 0, g_ctx.kin_K.as<double>(),
+                     (long)n, (long)n, scale);
+  HIPCHK(hipGetLastError());
+  if (K) HIPCHK(hipMemcpy(K, g_ctx.kin_K.p, n * n * 8, hipMemcpyDeviceToHost));
+  g_ctx.kin_active = false;
+  g_ctx.kin_X.release();
+  g_ctx.kin_stage.release();
+  g_ctx.kin_K.release();
+  return GEMMA_HIP_OK;
+}
+
+// ------------------------------------------------------------------------------ centring / eigen
+extern "C" int gemma_hip_center_d(double *G, size_t n, void *stream) {
+  NEED_INIT();
+  if (!G || n == 0) return fail(GEMMA_HIP_EINVAL, "center: empty matrix");
+  hipStream_t s = S(stream);
+  if (g_ctx.scratch.reserve((n + 1) * 8)) return fail(GEMMA_HIP_ENOMEM, "center: scratch");
+  double *Gw = g_ctx.scratch.as<double>();
+  double *d = Gw + n;
+  hipLaunchKernelGGL(rowsum_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s, G, (long)n, (long)n, Gw);
+  hipLaunchKernelGGL(total_kernel, dim3(1), dim3(1024), 0, s, Gw, (long)n, d);
+  hipLaunchKernelGGL(center_update_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)n), dim3(256), 0, s,
+                     G, (long)n, (long)n, Gw, d);
+  HIPCHK(hipGetLastError());
+  return GEMMA_HIP_OK;
+}
+
+extern "C" int gemma_hip_center(double *G, size_t n) {
+  NEED_INIT();
+  if (!G || n == 0) return fail(GEMMA_HIP_EINVAL, "center: empty matrix");
+  DevBuf d;
+  if (d.reserve(n * n * 8)) return fail(GEMMA_HIP_ENOMEM, "center: %zu bytes", n * n * 8);
+  hipError_t e = hipMemcpy(d.p, G, n * n * 8, hipMemcpyHostToDevice);
+  int rc = GEMMA_HIP_OK;
+  if (e == hipSuccess) rc = gemma_hip_center_d(d.as<double>(), n, nullptr);
+  if (e == hipSuccess && rc == GEMMA_HIP_OK) e = hipMemcpy(G, d.p, n * n * 8, hipMemcpyDeviceToHost);
+  d.release();
+  if (e != hipSuccess) return fail(GEMMA_HIP_ERUNTIME, "center: %s", hipGetErrorString(e));
+  return rc;
+}
+
+extern "C" int gemma_hip_eigh_d(double *G, size_t n, double *U, double *eval, double *trace_G,
+                                void *stream) {
+  NEED_INIT();
+  if (!G || !U || !eval || n == 0) return fail(GEMMA_HIP_EINVAL, "eigh: null/empty argument");
+  hipStream_t s = S(stream);
+  ProfScope ps(GEMMA_STAGE_EIGH, s);
+  std::string msg;
+  int rc = eigh_device(G, (long)n, U, eval, s, msg);
+  if (rc != GEMMA_HIP_OK) return fail(rc, "eigh: %s", msg.c_str());
+  // EigenDecomp_Zeroed: eval < 1e-10 -> 0, trace = mean(eval)
+  if (g_ctx.scratch.reserve(8)) return fail(GEMMA_HIP_ENOMEM, "eigh: scratch");
+  hipLaunchKernelGGL(zero_small_eval_kernel, dim3(1), dim3(1024), 0, s, eval, (long)n,
+                     g_ctx.scratch.as<double>());
+  HIPCHK(hipGetLastError());
+  double tr = 0.0;
+  HIPCHK(hipMemcpyAsync(&tr, g_ctx.scratch.p, 8, hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  if (trace_G) *trace_G = tr;
+  return GEMMA_HIP_OK;
+}
+
+extern "C" int gemma_hip_eigh(double *G, size_t n, double *U, double *eval, double *trace_G) {
+  NEED_INIT();
+  if (!G || !U || !eval || n == 0) return fail(GEMMA_HIP_EINVAL, "eigh: null/empty argument");
+  DevBuf dG, dU, dE;
+  if (dG.reserve(n * n * 8) || dU.reserve(n * n * 8) || dE.reserve(n * 8)) {
+    dG.release(); dU.release(); dE.release();
+    return fail(GEMMA_HIP_ENOMEM, "eigh: cannot allocate 2 x %zu bytes", n * n * 8);
+  }
+  int rc = GEMMA_HIP_OK;
+  hipError_t e = hipMemcpy(dG.p, G, n * n * 8, hipMemcpyHostToDevice);
+  if (e == hipSuccess) rc = gemma_hip_eigh_d(dG.as<double>(), n, dU.as<double>(), dE.as<double>(), trace_G, nullptr);
+  if (e == hipSuccess && rc == GEMMA_HIP_OK) e = hipMemcpy(U, dU.p, n * n * 8, hipMemcpyDeviceToHost);
+  if (e == hipSuccess && rc == GEMMA_HIP_OK) e = hipMemcpy(eval, dE.p, n * 8, hipMemcpyDeviceToHost);
+  dG.release(); dU.release(); dE.release();
+  if (e != hipSuccess) return fail(GEMMA_HIP_ERUNTIME, "eigh: %s", hipGetErrorString(e));
+  return rc;
+}
+
+extern "C" int gemma_hip_calc_utx(const double *U, const double *X, size_t n, size_t m, double *UtX) {
+  // UtX (n x m) = U^T X : fast_dgemm("T","N",1.0,U,X,0.0,UtX), src/mathfunc.cpp:505
+  return gemma_hip_dgemm('T', 'N', n, m, n, 1.0, U, n, X, m, 0.0, UtX, m);
+}
+
+// ------------------------------------------------------------------------------ LMM
+static int lmm_common_setup(const gemma_lmm_cfg *cfg) {
+  if (!cfg) return fail(GEMMA_HIP_EINVAL, "lmm_setup: null cfg");
+  if (cfg->n == 0 || cfg->n_cvt == 0) return fail(GEMMA_HIP_EINVAL, "lmm_setup: n=%zu n_cvt=%zu", cfg->n, cfg->n_cvt);
+  if (cfg->n_cvt > 4)
+    return fail(GEMMA_HIP_EINVAL, "lmm_setup: n_cvt=%zu not supported by this build (1..4)", cfg->n_cvt);
+  if (!(cfg->a_mode == 1 || cfg->a_mode == 2 || cfg->a_mode == 3 || cfg->a_mode == 4 || cfg->a_mode == 9))
+    return fail(GEMMA_HIP_EINVAL, "lmm_setup: a_mode %d", cfg->a_mode);
+  if (!(cfg->l_max > cfg->l_min) || cfg->n_region == 0 || cfg->n_region > (size_t)ASSOC_MAX_REGION)
+    return fail(GEMMA_HIP_EINVAL, "lmm_setup: l_min/l_max/n_region");
+  if (cfg->n <= cfg->n_cvt + 1) return fail(GEMMA_HIP_EINVAL, "lmm_setup: n <= n_cvt + 1");
+  if (cfg->n > 0x7fffffffUL) return fail(GEMMA_HIP_EINVAL, "lmm_setup: n too large");
+  g_ctx.cfg = *cfg;
+  AssocArgs &a = g_ctx.assoc_proto;
+  memset(&a, 0, sizeof a);
+  a.n = (int)cfg->n;
+  a.a_mode = cfg->a_mode;
+  a.n_region = (int)cfg->n_region;
+  a.plink_nan_rule = cfg->plink_nan_rule;
+  a.l_min = cfg->l_min;
+  a.l_max = cfg->l_max;
+  a.l_mle_null = cfg->l_mle_null;
+  a.logl_mle_H0 = cfg->logl_mle_H0;
+  const double df = (double)cfg->n - (double)cfg->n_cvt - 1.0;
+  a.lnbeta_half_df = lgamma(df / 2.0) + lgamma(0.5) - lgamma(df / 2.0 + 0.5);
+  // lambda grid exactly as src/lmm.cpp:1964-1969
+  const double lambda_interval = log(cfg->l_max / cfg->l_min) / (double)cfg->n_region;
+  for (size_t i = 0; i <= cfg->n_region; ++i) a.lam_grid[i] = cfg->l_min * exp(lambda_interval * (double)i);
+  if (g_ctx.carry.reserve(4 * 8)) return fail(GEMMA_HIP_ENOMEM, "lmm_setup: carry");
+  HIPCHK(hipMemset(g_ctx.carry.p, 0, 4 * 8));
+  g_ctx.carry_flip = 0;
+  g_ctx.have_map = false;
+  g_ctx.ni_total = 0;
+  return GEMMA_HIP_OK;
+}
+
+// UtW (n x c row-major) -> UtWt (c x n)
+static int make_utwt(const double *UtW_d, hipStream_t s) {
+  const size_t n = g_ctx.cfg.n, c = g_ctx.cfg.n_cvt;
+  if (g_ctx.UtWt.reserve(c * n * 8)) return fail(GEMMA_HIP_ENOMEM, "lmm_setup: UtWt");
+  dim3 grid((unsigned)((c + 31) / 32), (unsigned)((n + 31) / 32));
+  hipLaunchKernelGGL(transpose_kernel, grid, dim3(32, 8), 0, s, UtW_d, (long)n, (long)c, (long)c,
+                     g_ctx.UtWt.as<double>(), (long)n);
+  HIPCHK(hipGetLastError());
+  return GEMMA_HIP_OK;
+}
+
+extern "C" int gemma_hip_lmm_setup_d(const gemma_lmm_cfg *cfg, const double *U_d, const double *eval_d,
+                                     const double *UtW_d, const double *Uty_d, void *stream) {
+  NEED_INIT();
+  if (!U_d || !eval_d || !UtW_d || !Uty_d) return fail(GEMMA_HIP_EINVAL, "lmm_setup: null pointer");
+  int rc = lmm_common_setup(cfg);
+  if (rc) return rc;
+  g_ctx.U = U_d;
+  g_ctx.eval = eval_d;
+  g_ctx.Uty = Uty_d;
+  rc = make_utwt(UtW_d, S(stream));
+  if (rc) return rc;
+  g_ctx.lmm_active = true;
+  return GEMMA_HIP_OK;
+}
+
+extern "C" int gemma_hip_lmm_setup(const gemma_lmm_cfg *cfg, const double *U, const double *eval,
+                                   const double *UtW, const double *Uty) {
+  NEED_INIT();
+  if (!U || !eval || !UtW || !Uty) return fail(GEMMA_HIP_EINVAL, "lmm_setup: null pointer");
+  int rc = lmm_common_setup(cfg);
+  if (rc) return rc;
+  const size_t n = cfg->n, c = cfg->n_cvt;
+  if (g_ctx.own_U.reserve(n * n * 8) || g_ctx.own_eval.reserve(n * 8) || g_ctx.own_Uty.reserve(n * 8) ||
+      g_ctx.own_UtW.reserve(n * c * 8))
+    return fail(GEMMA_HIP_ENOMEM, "lmm_setup: cannot allocate U (%zu bytes)", n * n * 8);
+  HIPCHK(hipMemcpy(g_ctx.own_U.p, U, n * n * 8, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(g_ctx.own_eval.p, eval, n * 8, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(g_ctx.own_Uty.p, Uty, n * 8, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(g_ctx.own_UtW.p, UtW, n * c * 8, hipMemcpyHostToDevice));
+  g_ctx.U = g_ctx.own_U.as<double>();
+  g_ctx.eval = g_ctx.own_eval.as<double>();
+  g_ctx.Uty = g_ctx.own_Uty.as<double>();
+  rc = make_utwt(g_ctx.own_UtW.as<double>(), 0);
+  if (rc) return rc;
+  HIPCHK(hipDeviceSynchronize());
+  g_ctx.lmm_active = true;
+  return GEMMA_HIP_OK;
+}
+
+extern "C" int gemma_hip_lmm_set_indicator(const int *indicator_idv, size_t ni_total) {
+  NEED_INIT();
+  if (!g_ctx.lmm_active) return fail(GEMMA_HIP_ESTATE, "lmm_set_indicator before lmm_setup");
+  if (!indicator_idv || ni_total == 0) {
+    g_ctx.have_map = false;
+    g_ctx.ni_total = 0;
+    return GEMMA_HIP_OK;
+  }
+  std::vector<int> map;
+  map.reserve(g_ctx.cfg.n);
+  for (size_t i = 0; i < ni_total; ++i)
+    if (indicator_idv[i] != 0) map.push_back((int)i);
+  if (map.size() != g_ctx.cfg.n)
+    return fail(GEMMA_HIP_EINVAL, "lmm_set_indicator: %zu analysed individuals, cfg.n = %zu", map.size(),
+                g_ctx.cfg.n);
+  if (g_ctx.idx_map.reserve(map.size() * sizeof(int))) return fail(GEMMA_HIP_ENOMEM, "idx_map");
+  HIPCHK(hipMemcpy(g_ctx.idx_map.p, map.data(), map.size() * sizeof(int), hipMemcpyHostToDevice));
+  g_ctx.have_map = true;
+  g_ctx.ni_total = ni_total;
+  return GEMMA_HIP_OK;
+}
+
+static int launch_assoc(const double *UtX, size_t l, size_t ld, gemma_sumstat *out_d, hipStream_t s) {
+  AssocArgs a = g_ctx.assoc_proto;
+  a.UtX = UtX;
+  a.ld = (long)ld;
+  a.l = (long)l;
+  a.eval = g_ctx.eval;
+  a.Uty = g_ctx.Uty;
+  a.UtWt = g_ctx.UtWt.as<double>();
+  a.out = reinterpret_cast<SumStat *>(out_d);
+  const unsigned grid = (unsigned)((l + 3) / 4);
+  {
+    ProfScope ps(GEMMA_STAGE_ASSOC, s);
+    switch (g_ctx.cfg.n_cvt) {
+    case 1: hipLaunchKernelGGL(lmm_assoc_kernel<1>, dim3(grid), dim3(256), 0, s, a); break;
+    case 2: hipLaunchKernelGGL(lmm_assoc_kernel<2>, dim3(grid), dim3(256), 0, s, a); break;
+    case 3: hipLaunchKernelGGL(lmm_assoc_kernel<3>, dim3(grid), dim3(256), 0, s, a); break;
+    case 4: hipLaunchKernelGGL(lmm_assoc_kernel<4>, dim3(grid), dim3(256), 0, s, a); break;
+    default: return fail(GEMMA_HIP_EINVAL, "assoc: n_cvt");
+    }
+    HIPCHK(hipGetLastError());
+    if (g_ctx.cfg.plink_nan_rule && g_ctx.cfg.a_mode == 1) {
+      double *cin = g_ctx.carry.as<double>() + 2 * g_ctx.carry_flip;
+      double *cout = g_ctx.carry.as<double>() + 2 * (1 - g_ctx.carry_flip);
+      hipLaunchKernelGGL(plink_carry_kernel, dim3((unsigned)((l + 255) / 256)), dim3(256), 0, s,
+                         reinterpret_cast<SumStatRaw *>(out_d), (long)l, cin, cout);
+      HIPCHK(hipGetLastError());
+      g_ctx.carry_flip = 1 - g_ctx.carry_flip;
+    }
+  }
+  return GEMMA_HIP_OK;
+}
+
+extern "C" int gemma_hip_lmm_assoc_d(const double *UtX_d, size_t l, size_t ld_utx, gemma_sumstat *out_d,
+                                     void *stream) {
+  NEED_INIT();
+  if (!g_ctx.lmm_active) return fail(GEMMA_HIP_ESTATE, "lmm_assoc before lmm_setup");
+  if (l == 0) return GEMMA_HIP_OK;
+  if (!UtX_d || !out_d || ld_utx < g_ctx.cfg.n) return fail(GEMMA_HIP_EINVAL, "lmm_assoc: bad UtX/ld");
+  return launch_assoc(UtX_d, l, ld_utx, out_d, S(stream));
+}
+
+extern "C" int gemma_hip_lmm_batch_d(int kind, const void *geno, size_t l, size_t ld, gemma_sumstat *out_d,
+                                     void *stream) {
+  NEED_INIT();
+  if (!g_ctx.lmm_active) return fail(GEMMA_HIP_ESTATE, "lmm_batch before lmm_setup");
+  if (l == 0) return GEMMA_HIP_OK;
+  const size_t n = g_ctx.cfg.n;
+  const size_t per_row = (kind == GEMMA_GENO_PLINK_2BIT && g_ctx.have_map) ? g_ctx.ni_total : n;
+  const size_t need = min_ld_for(kind, per_row, l);
+  if (need == (size_t)-1) return fail(GEMMA_HIP_EINVAL, "lmm_batch: unknown geno_kind %d", kind);
+  if (!geno || !out_d || ld < need) return fail(GEMMA_HIP_EINVAL, "lmm_batch: ld=%zu < %zu", ld, need);
+  hipStream_t s = S(stream);
+  const size_t ldx = (n + 1) & ~(size_t)1;
+  if (g_ctx.X.reserve(l * ldx * 8) || g_ctx.UtX.reserve(l * ldx * 8))
+    return fail(GEMMA_HIP_ENOMEM, "lmm_batch: cannot allocate 2 x %zu bytes", l * ldx * 8);
+  double *X = g_ctx.X.as<double>(), *UtX = g_ctx.UtX.as<double>();
+  {
+    ProfScope ps(GEMMA_STAGE_INGEST, s);
+    if (kind == GEMMA_GENO_F64_IDV_MAJOR) {
+      dim3 grid((unsigned)((l + 31) / 32), (unsigned)((n + 31) / 32));
+      hipLaunchKernelGGL(transpose_kernel, grid, dim3(32, 8), 0, s, reinterpret_cast<const double *>(geno),
+                         (long)n, (long)l, (long)ld, X, (long)ldx);
+    } else {
+      IngestArgs a;
+      a.src = geno; a.ld = (long)ld; a.l = (long)l;
+      a.idx_map = g_ctx.have_map ? g_ctx.idx_map.as<int>() : nullptr;
+      a.n = (int)n; a.dst = X; a.ldo = (long)ldx; a.k_mode = 0;
+      const unsigned grid = (unsigned)((l + 3) / 4);
+      if (kind == GEMMA_GENO_PLINK_2BIT)
+        hipLaunchKernelGGL(ingest_lmm_kernel<true>, dim3(grid), dim3(256), 0, s, a);
+      else
+        hipLaunchKernelGGL(ingest_lmm_kernel<false>, dim3(grid), dim3(256), 0, s, a);
+    }
+    HIPCHK(hipGetLastError());
+  }
+  {
+    // UtX (l x n, SNP-major) = X (l x n) * U (n x n): row s is (U^T x_s)^T, i.e. the column the
+    // reference's fast_dgemm("T","N",U,Xlarge) (src/lmm.cpp:1521) produces for SNP s.
+    ProfScope ps(GEMMA_STAGE_UTX_GEMM, s);
+    HIPCHK(launch_dgemm('N', 'N', (long)l, (long)n, (long)n, 1.0, X, (long)ldx, g_ctx.U, (long)n, 0.0, UtX,
+                        (long)ldx, false, false, s));
+  }
+  return launch_assoc(UtX, l, ldx, out_d, s);
+}
+
+extern "C" int gemma_hip_lmm_batch(int kind, const void *geno, size_t l, size_t ld, gemma_sumstat *out) {
+  NEED_INIT();
+  if (!g_ctx.lmm_active) return fail(GEMMA_HIP_ESTATE, "lmm_batch before lmm_setup");
+  if (l == 0) return GEMMA_HIP_OK;
+  const size_t n = g_ctx.cfg.n;
+  const size_t per_row = (kind == GEMMA_GENO_PLINK_2BIT && g_ctx.have_map) ? g_ctx.ni_total : n;
+  const size_t need = min_ld_for(kind, per_row, l);
+  if (need == (size_t)-1) return fail(GEMMA_HIP_EINVAL, "lmm_batch: unknown geno_kind %d", kind);
+  if (!geno || !out || ld < need) return fail(GEMMA_HIP_EINVAL, "lmm_batch: ld=%zu < %zu", ld, need);
+  const size_t rows = (kind == GEMMA_GENO_F64_IDV_MAJOR) ? n : l;
+  const size_t esz = (kind == GEMMA_GENO_PLINK_2BIT) ? 1 : 8;
+  if (g_ctx.stage_in.reserve(rows * ld * esz) || g_ctx.stage_out.reserve(l * sizeof(gemma_sumstat)))
+    return fail(GEMMA_HIP_ENOMEM, "lmm_batch: staging %zu bytes", rows * ld * esz);
+  HIPCHK(hipMemcpy2D(g_ctx.stage_in.p, ld * esz, geno, ld * esz, need * esz, rows, hipMemcpyHostToDevice));
+  int rc = gemma_hip_lmm_batch_d(kind, g_ctx.stage_in.p, l, ld, g_ctx.stage_out.as<gemma_sumstat>(), nullptr);
+  if (rc) return rc;
+  HIPCHK(hipMemcpy(out, g_ctx.stage_out.p, l * sizeof(gemma_sumstat), hipMemcpyDeviceToHost));
+  return GEMMA_HIP_OK;
+}
+
+// Null model on device.  out[8] = { l_mle_null, logl_mle_H0, l_remle_null, logl_remle_H0,
+// pve, pve_se, vg_remle, ve_remle } -- the quantities src/gemma.cpp:2711-2750 derives before
+// the per-SNP loop (CalcLambda 'L'/'R' with calc_null, CalcPve src/lmm.cpp:2183-2205, and the
+// vg/ve part of CalcLmmVgVeBeta :2253-2259).
+extern "C" int gemma_hip_lmm_null(size_t n, size_t n_cvt, const double *eval, const double *UtW,
+                                  const double *Uty, double l_min, double l_max, size_t n_region,
+                                  double trace_G, double *out8) {
+  NEED_INIT();
+  if (!eval || !UtW || !Uty || !out8 || n == 0 || n_cvt == 0 || n_cvt > 5)
+    return fail(GEMMA_HIP_EINVAL, "lmm_null: bad arguments (n_cvt 1..5)");
+  if (!(l_max > l_min) || n_region == 0 || n_region > (size_t)ASSOC_MAX_REGION || n <= n_cvt)
+    return fail(GEMMA_HIP_EINVAL, "lmm_null: l_min/l_max/n_region/n");
+  DevBuf dE, dW, dWt, dY, dO;
+  auto cleanup = [&]() { dE.release(); dW.release(); dWt.release(); dY.release(); dO.release(); };
+  if (dE.reserve(n * 8) || dW.reserve(n * n_cvt * 8) || dWt.reserve(n * n_cvt * 8) || dY.reserve(n * 8) ||
+      dO.reserve(sizeof(NullOut))) {
+    cleanup();
+    return fail(GEMMA_HIP_ENOMEM, "lmm_null: allocation");
+  }
+  hipError_t e = hipMemcpy(dE.p, eval, n * 8, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(dW.p, UtW, n * n_cvt * 8, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(dY.p, Uty, n * 8, hipMemcpyHostToDevice);
+  if (e == hipSuccess) {
+    dim3 grid((unsigned)((n_cvt + 31) / 32), (unsigned)((n + 31) / 32));
+    hipLaunchKernelGGL(transpose_kernel, grid, dim3(32, 8), 0, 0, dW.as<double>(), (long)n, (long)n_cvt,
+                       (long)n_cvt, dWt.as<double>(), (long)n);
+    AssocArgs a;
+    memset(&a, 0, sizeof a);
+    a.n = (int)n; a.n_region = (int)n_region; a.l_min = l_min; a.l_max = l_max;
+    a.eval = dE.as<double>(); a.Uty = dY.as<double>(); a.UtWt = dWt.as<double>();
+    const double lambda_interval = log(l_max / l_min) / (double)n_region;
+    for (size_t i = 0; i <= n_region; ++i) a.lam_grid[i] = l_min * exp(lambda_interval * (double)i);
+    NullOut *o = dO.as<NullOut>();
+    switch (n_cvt) {
+    case 1: hipLaunchKernelGGL(lmm_null_kernel<0>, dim3(1), dim3(64), 0, 0, a, o); break;
+    case 2: hipLaunchKernelGGL(lmm_null_kernel<1>, dim3(1), dim3(64), 0, 0, a, o); break;
+    case 3: hipLaunchKernelGGL(lmm_null_kernel<2>, dim3(1), dim3(64), 0, 0, a, o); break;
+    case 4: hipLaunchKernelGGL(lmm_null_kernel<3>, dim3(1), dim3(64), 0, 0, a, o); break;
+    case 5: hipLaunchKernelGGL(lmm_null_kernel<4>, dim3(1), dim3(64), 0, 0, a, o); break;
+    }
+    e = hipGetLastError();
+  }
+  NullOut h;
+  if (e == hipSuccess) e = hipMemcpy(&h, dO.p, sizeof h, hipMemcpyDeviceToHost);
+  cleanup();
+  if (e != hipSuccess) return fail(GEMMA_HIP_ERUNTIME, "lmm_null: %s", hipGetErrorString(e));
+  out8[0] = h.l_mle; out8[1] = h.logl_mle; out8[2] = h.l_remle; out8[3] = h.logl_remle;
+  // CalcPve, src/lmm.cpp:2197-2200 (safe_sqrt semantics of src/mathfunc.cpp:122-131)
+  double arg = -1.0 / h.dev2_remle, d1 = arg;
+  if (arg < 0.001) d1 = fabs(arg);
+  const double se = (d1 < 0.0) ? NAN : sqrt(d1);
+  out8[4] = trace_G * h.l_remle / (trace_G * h.l_remle + 1.0);
+  out8[5] = trace_G / ((trace_G * h.l_remle + 1.0) * (trace_G * h.l_remle + 1.0)) * se;
+  out8[7] = h.Pyy_remle / (double)(n - n_cvt); // ve, src/lmm.cpp:2258
+  out8[6] = out8[7] * h.l_remle;               // vg
+  return GEMMA_HIP_OK;
+}
+
+extern "C" int gemma_hip_lmm_finish(double *time_UtX_min, double *time_opt_min) {
+  NEED_INIT();
+  if (!g_ctx.lmm_active) return fail(GEMMA_HIP_ESTATE, "lmm_finish before lmm_setup");
+  HIPCHK(hipDeviceSynchronize());
+  prof_collect(GEMMA_STAGE_UTX_GEMM);
+  prof_collect(GEMMA_STAGE_ASSOC);
+  if (time_UtX_min) *time_UtX_min = g_ctx.prof[GEMMA_STAGE_UTX_GEMM].acc_ms / 60000.0;
+  if (time_opt_min) *time_opt_min = g_ctx.prof[GEMMA_STAGE_ASSOC].acc_ms / 60000.0;
+  g_ctx.own_U.release(); g_ctx.own_eval.release(); g_ctx.own_Uty.release(); g_ctx.own_UtW.release();
+  g_ctx.UtWt.release(); g_ctx.idx_map.release(); g_ctx.X.release(); g_ctx.UtX.release();
+  g_ctx.stage_in.release(); g_ctx.stage_out.release();
+  g_ctx.U = g_ctx.eval = g_ctx.Uty = nullptr;
+  g_ctx.lmm_active = false;
+  return GEMMA_HIP_OK;
+}

@@ -1,0 +1,702 @@
+// Per-SNP association stage of the univariate LMM on gfx950: one wavefront owns one SNP.
+//
+// Replaces the serial loop body of batch_compute, GEMMA src/lmm.cpp:1526-1562 (BIMBAM) /
+// :1853-1888 (PLINK): CalcUab (:1258), CalcRLScore (:1170), CalcLambda (:1945) with
+// LogRL_/LogL_ f/dev1/dev12 (:484-1125) and CalcPab/PPab/PPPab (:283-482), CalcRLWald (:1127),
+// gsl_cdf_fdist_Q / gsl_cdf_chisq_Q (:1161,1206,1553).
+//
+// Shape of the computation: every likelihood/derivative evaluation is a set of weighted inner
+// products  S_k[a,b] = sum_i u_a[i] u_b[i] / (lambda*delta_i + 1)^k  (k = 1..3) over the n rotated
+// individuals, followed by an O(c^3) scalar recursion.  A wavefront streams its SNP's U^T x row
+// (coalesced, 8 B/lane; delta, U^T y, U^T W are shared by all SNPs and stay L2-resident), keeps
+// all S_k in registers, butterfly-reduces across the 64 lanes, and then runs the reference's
+// exact control flow (grid scan -> Brent -> Newton -> boundary checks) redundantly in every lane
+// so that branches are wave-uniform.  No LDS, no barriers, no atomics: results are bit-identical
+// for a SNP wherever it is scheduled (needed for the sharded == unsharded guarantee).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <float.h>
+
+namespace gemma_hip {
+
+struct SumStat {
+  double beta, se, lambda_remle, lambda_mle, p_wald, p_lrt, p_score, logl_H1;
+};
+
+constexpr int ASSOC_MAX_REGION = 64;
+
+struct AssocArgs {
+  const double *UtX;   // l x ld, SNP-major
+  long ld;
+  long l;
+  const double *eval;  // n
+  const double *Uty;   // n
+  const double *UtWt;  // c x n (covariate-major copy of UtW)
+  SumStat *out;
+  int n;
+  int a_mode;
+  int n_region;
+  int plink_nan_rule;
+  double l_min, l_max;
+  double l_mle_null, logl_mle_H0;
+  double lnbeta_half_df;  // ln B(df/2, 1/2), df = n - c - 1 (host lgamma)
+  double lam_grid[ASSOC_MAX_REGION + 1]; // l_min*exp(i*log(l_max/l_min)/n_region), host libm
+};
+
+// ------------------------------------------------------------------ wave helpers
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+__device__ __forceinline__ double uniform(double v) {
+  // every lane already holds the same value; tell the compiler (SGPR broadcast)
+  union { double d; int i[2]; } u;
+  u.d = v;
+  u.i[0] = __builtin_amdgcn_readfirstlane(u.i[0]);
+  u.i[1] = __builtin_amdgcn_readfirstlane(u.i[1]);
+  return u.d;
+}
+
+// GetabIndex, GEMMA src/param.cpp:1400-1415 (1-based, symmetric)
+template <int C>
+__host__ __device__ constexpr int ab_index(int a, int b) {
+  const int cols = C + 2;
+  const int a1 = (b <= a) ? b : a;
+  const int b1 = (b <= a) ? a : b;
+  return (2 * cols - a1 + 2) * (a1 - 1) / 2 + b1 - a1;
+}
+
+// safe_sqrt, GEMMA src/mathfunc.cpp:122-131 (the reference's `fabs(d < 0.001)` is `d < 0.001`)
+__device__ __forceinline__ double safe_sqrt_dev(double d) {
+  double d1 = d;
+  if (d < 0.001) d1 = fabs(d);
+  if (d1 < 0.0) return NAN;
+  return sqrt(d1);
+}
+
+// ------------------------------------------------------------------ special functions
+// continued fraction of the regularised incomplete beta function (modified Lentz; the
+// algorithm of GSL cdf/beta_inc.c beta_cont_frac: <= 512 double steps, same stopping rules)
+__device__ inline double beta_cont_frac_dev(double a, double b, double x, double epsabs) {
+  const double cutoff = 2.0 * DBL_MIN;
+  double num = 1.0;
+  double den = 1.0 - (a + b) * x / (a + 1.0);
+  if (fabs(den) < cutoff) den = NAN;
+  den = 1.0 / den;
+  double cf = den;
+  int it = 0;
+  for (; it < 512; ++it) {
+    const int k = it + 1;
+    double coeff = k * (b - k) * x / (((a - 1.0) + 2 * k) * (a + 2 * k));
+    den = 1.0 + coeff * den;
+    num = 1.0 + coeff / num;
+    if (fabs(den) < cutoff) den = NAN;
+    if (fabs(num) < cutoff) num = NAN;
+    den = 1.0 / den;
+    double delta = den * num;
+    cf *= delta;
+    coeff = -(a + k) * (a + b + k) * x / ((a + 2 * k) * (a + 2 * k + 1.0));
+    den = 1.0 + coeff * den;
+    num = 1.0 + coeff / num;
+    if (fabs(den) < cutoff) den = NAN;
+    if (fabs(num) < cutoff) num = NAN;
+    den = 1.0 / den;
+    delta = den * num;
+    cf *= delta;
+    if (fabs(delta - 1.0) < 2.0 * DBL_EPSILON) break;
+    if (cf * fabs(delta - 1.0) < epsabs) break;
+  }
+  if (it >= 512) return NAN;
+  return cf;
+}
+
+// A*I_x(a,b)+Y with ln B(a,b) supplied (GSL cdf/beta_inc.c beta_inc_AXPY). On this path one of
+// (a,b) is always 1/2 (nu1 = 1), which is what the two asymptotic branches assume.
+__device__ inline double beta_inc_axpy_dev(double A, double Y, double a, double b, double x,
+                                           double ln_beta) {
+  if (x == 0.0) return A * 0 + Y;
+  if (x == 1.0) return A * 1 + Y;
+  if (a > 1e5 && b < 10 && x > a / (a + b) && b == 0.5) {
+    const double N = a + (b - 1.0) / 2.0;
+    return A * erfc(sqrt(-N * log(x))) + Y; // Q(1/2, z) = erfc(sqrt z)
+  }
+  if (b > 1e5 && a < 10 && x < b / (a + b) && a == 0.5) {
+    const double N = b + (a - 1.0) / 2.0;
+    return A * erf(sqrt(-N * log1p(-x))) + Y; // P(1/2, z) = erf(sqrt z)
+  }
+  const double ln_pre = -ln_beta + a * log(x) + b * log1p(-x);
+  const double prefactor = exp(ln_pre);
+  if (x < (a + 1.0) / (a + b + 2.0)) {
+    const double epsabs = fabs(Y / (A * prefactor / a)) * DBL_EPSILON;
+    const double cf = beta_cont_frac_dev(a, b, x, epsabs);
+    return A * (prefactor * cf / a) + Y;
+  } else {
+    const double epsabs = fabs((A + Y) / (A * prefactor / b)) * DBL_EPSILON;
+    const double cf = beta_cont_frac_dev(b, a, 1.0 - x, epsabs);
+    const double term = prefactor * cf / b;
+    if (A == -Y) return -A * term;
+    return A * (1 - term) + Y;
+  }
+}
+
+// gsl_cdf_fdist_Q(x, 1, df)  (GSL cdf/fdist.c), ln B(1/2, df/2) precomputed on the host
+__device__ inline double fdist_Q1_dev(double x, double df, double lnbeta_half_df) {
+  const double r = df; // nu2/nu1
+  if (x < r) {
+    const double u = x / (r + x);
+    return beta_inc_axpy_dev(-1.0, 1.0, 0.5, df / 2.0, u, lnbeta_half_df);
+  } else {
+    const double u = r / (r + x);
+    return beta_inc_axpy_dev(1.0, 0.0, df / 2.0, 0.5, u, lnbeta_half_df);
+  }
+}
+
+// gsl_cdf_chisq_Q(x, 1) = gsl_cdf_gamma_Q(x, 1/2, 2)  (GSL cdf/gamma.c)
+__device__ inline double chisq_Q1_dev(double x) {
+  if (x <= 0.0) return 1.0;
+  const double y = x / 2.0;
+  if (y < 0.5) return 1.0 - erf(sqrt(y));
+  return erfc(sqrt(y));
+}
+
+// ------------------------------------------------------------------ row-0 sums
+template <int C>
+struct Row0 {
+  static constexpr int NI = (C + 3) * (C + 2) / 2;
+  double s1[NI], s2[NI], s3[NI];
+  double tr1, tr2, logdet;
+};
+
+// One pass over the SNP's rotated genotype row.  ORDER = highest power of H needed (1..3);
+// ORDER = 0 means H == 1 (the "Iab" call of LogRL_f, src/lmm.cpp:839-840).
+template <int C, int ORDER, bool LOGDET>
+__device__ __forceinline__ void row0_pass(const AssocArgs &g, const double *__restrict__ x,
+                                          double lambda, int lane, Row0<C> &R) {
+  constexpr int NI = Row0<C>::NI;
+#pragma unroll
+  for (int q = 0; q < NI; ++q) R.s1[q] = R.s2[q] = R.s3[q] = 0.0;
+  double tr1 = 0.0, tr2 = 0.0, ld = 0.0;
+  const int n = g.n;
+#pragma unroll 2
+  for (int i = lane; i < n; i += 64) {
+    double u[C + 2];
+#pragma unroll
+    for (int a = 0; a < C; ++a) u[a] = g.UtWt[(long)a * n + i];
+    u[C] = x[i];
+    u[C + 1] = g.Uty[i];
+    double h1 = 1.0, h2 = 1.0, h3 = 1.0;
+    if (ORDER >= 1) {
+      const double v = g.eval[i] * lambda + 1.0;
+      h1 = 1.0 / v;
+      if (ORDER >= 2) h2 = h1 * h1;
+      if (ORDER >= 3) h3 = h2 * h1;
+      if (LOGDET) ld += log(fabs(v));
+      tr1 += h1;
+      if (ORDER >= 3) tr2 += h2;
+    }
+#pragma unroll
+    for (int a = 1; a <= C + 2; ++a) {
+#pragma unroll
+      for (int b = a; b <= C + 2; ++b) {
+        constexpr int dummy = 0;
+        (void)dummy;
+        const int q = ab_index<C>(a, b);
+        const double pr = u[b - 1] * u[a - 1];
+        R.s1[q] += h1 * pr;
+        if (ORDER >= 2) R.s2[q] += h2 * pr;
+        if (ORDER >= 3) R.s3[q] += h3 * pr;
+      }
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < NI; ++q) {
+    R.s1[q] = wave_sum(R.s1[q]);
+    if (ORDER >= 2) R.s2[q] = wave_sum(R.s2[q]);
+    if (ORDER >= 3) R.s3[q] = wave_sum(R.s3[q]);
+  }
+  R.tr1 = wave_sum(tr1);
+  R.tr2 = (ORDER >= 3) ? wave_sum(tr2) : 0.0;
+  R.logdet = LOGDET ? wave_sum(ld) : 0.0;
+}
+
+// The projection recursion of CalcPab / CalcPPab / CalcPPPab (src/lmm.cpp:326-349, :385-407,
+// :445-474) from row-0 sums.  Only what the callers read is returned:
+//   ww1[p], ww2[p], ww3[p] : P_{p}[w_{p+1} w_{p+1}] of each order (p = 0..C), the pivots
+//   after projecting out the first p variables -- these are Pab(i, index_ww(i+1)) in :844-849,:920-925
+//   yy[k][p] : (P^k)_p [y y] for p = C (after W) and p = C+1 (after W and x); xx, xy at p = C.
+template <int C>
+struct Proj {
+  double ww1[C + 1], ww2[C + 1], ww3[C + 1];
+  double yy1[2], yy2[2], yy3[2]; // [0]: row C, [1]: row C+1
+  double xx1, xy1;               // row C, order 1
+};
+
+template <int C, int ORDER>
+__device__ __forceinline__ void project(const Row0<C> &R, Proj<C> &P) {
+  constexpr int NI = Row0<C>::NI;
+  double p1[NI], p2[NI], p3[NI];
+#pragma unroll
+  for (int q = 0; q < NI; ++q) {
+    p1[q] = R.s1[q];
+    p2[q] = (ORDER >= 2) ? R.s2[q] : 0.0;
+    p3[q] = (ORDER >= 3) ? R.s3[q] : 0.0;
+  }
+  constexpr int iyy = ab_index<C>(C + 2, C + 2);
+  constexpr int ixx = ab_index<C>(C + 1, C + 1);
+  constexpr int ixy = ab_index<C>(C + 2, C + 1);
+#pragma unroll
+  for (int p = 1; p <= C + 1; ++p) {
+    // state before this step = row p-1
+    const int iww = ab_index<C>(p, p);
+    P.ww1[p - 1] = p1[iww];
+    P.ww2[p - 1] = p2[iww];
+    P.ww3[p - 1] = p3[iww];
+    if (p == C + 1) {
+      P.yy1[0] = p1[iyy];
+      P.yy2[0] = p2[iyy];
+      P.yy3[0] = p3[iyy];
+      P.xx1 = p1[ixx];
+      P.xy1 = p1[ixy];
+    }
+    const double ps_ww = p1[iww], ps2_ww = p2[iww], ps3_ww = p3[iww];
+    double n1[NI], n2[NI], n3[NI];
+#pragma unroll
+    for (int q = 0; q < NI; ++q) { n1[q] = p1[q]; n2[q] = p2[q]; n3[q] = p3[q]; }
+#pragma unroll
+    for (int a = p + 1; a <= C + 2; ++a) {
+#pragma unroll
+      for (int b = a; b <= C + 2; ++b) {
+        const int iab = ab_index<C>(a, b), iaw = ab_index<C>(a, p), ibw = ab_index<C>(b, p);
+        const double ps_ab = p1[iab], ps_aw = p1[iaw], ps_bw = p1[ibw];
+        if (ps_ww != 0) {
+          n1[iab] = ps_ab - ps_aw * ps_bw / ps_ww;
+          if (ORDER >= 2) {
+            const double ps2_ab = p2[iab], ps2_aw = p2[iaw], ps2_bw = p2[ibw];
+            double r2 = ps2_ab + ps_aw * ps_bw * ps2_ww / (ps_ww * ps_ww);
+            r2 -= (ps_aw * ps2_bw + ps_bw * ps2_aw) / ps_ww;
+            n2[iab] = r2;
+            if (ORDER >= 3) {
+              const double ps3_ab = p3[iab], ps3_aw = p3[iaw], ps3_bw = p3[ibw];
+              double r3 = ps3_ab - ps_aw * ps_bw * ps2_ww * ps2_ww / (ps_ww * ps_ww * ps_ww);
+              r3 -= (ps_aw * ps3_bw + ps_bw * ps3_aw + ps2_aw * ps2_bw) / ps_ww;
+              r3 += (ps_aw * ps2_bw * ps2_ww + ps_bw * ps2_aw * ps2_ww + ps_aw * ps_bw * ps3_ww) /
+                    (ps_ww * ps_ww);
+              n3[iab] = r3;
+            }
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < NI; ++q) { p1[q] = n1[q]; p2[q] = n2[q]; p3[q] = n3[q]; }
+  }
+  P.yy1[1] = p1[iyy];
+  P.yy2[1] = p2[iyy];
+  P.yy3[1] = p3[iyy];
+}
+
+// ------------------------------------------------------------------ likelihood pieces
+// Everything below is the alternative model: calc_null = false, nc_total = C + 1.
+template <int C>
+struct SnpCtx {
+  const AssocArgs *g;
+  const double *x;
+  int lane;
+  double logdet_iw; // sum_i log(Iab(i, ww_{i+1})), i < C+1  (H == 1; SNP constant)
+};
+
+// LogRL_dev1 / LogRL_dev12 (src/lmm.cpp:866-943, :1035-1125) and LogL_dev1 / LogL_dev12
+// (:544-640, :719-797).  ORDER 2 -> dev1 only; ORDER 3 -> dev1 and dev2.
+template <int C, bool REML, int ORDER>
+__device__ __forceinline__ void deriv(const SnpCtx<C> &s, double l, double &dev1, double &dev2) {
+  Row0<C> R;
+  row0_pass<C, ORDER, false>(*s.g, s.x, l, s.lane, R);
+  Proj<C> P;
+  project<C, ORDER>(R, P);
+  const double n = (double)s.g->n;
+  const double P_yy = P.yy1[1], PP_yy = P.yy2[1], PPP_yy = P.yy3[1];
+  const double yPKPy = (P_yy - PP_yy) / l;
+  if (REML) {
+    const double df = n - (double)C - 1.0;
+    double trace_P = R.tr1, trace_PP = R.tr2;
+#pragma unroll
+    for (int i = 0; i < C + 1; ++i) {
+      trace_P -= P.ww2[i] / P.ww1[i];
+      if (ORDER >= 3)
+        trace_PP += P.ww2[i] * P.ww2[i] / (P.ww1[i] * P.ww1[i]) - 2.0 * P.ww3[i] / P.ww1[i];
+    }
+    const double trace_PK = (df - trace_P) / l;
+    dev1 = -0.5 * trace_PK + 0.5 * df * yPKPy / P_yy;
+    if (ORDER >= 3) {
+      const double trace_PKPK = (df + trace_PP - 2.0 * trace_P) / (l * l);
+      const double yPKPKPy = (P_yy + PPP_yy - 2.0 * PP_yy) / (l * l);
+      dev2 = 0.5 * trace_PKPK - 0.5 * df * (2.0 * yPKPKPy * P_yy - yPKPy * yPKPy) / (P_yy * P_yy);
+    }
+  } else {
+    const double trace_HiK = (n - R.tr1) / l;
+    dev1 = -0.5 * trace_HiK + 0.5 * n * yPKPy / P_yy;
+    if (ORDER >= 3) {
+      const double trace_HiKHiK = (n + R.tr2 - 2 * R.tr1) / (l * l);
+      const double yPKPKPy = (P_yy + PPP_yy - 2.0 * PP_yy) / (l * l);
+      dev2 = 0.5 * trace_HiKHiK - 0.5 * n * (2.0 * yPKPKPy * P_yy - yPKPy * yPKPy) / (P_yy * P_yy);
+    }
+  }
+  dev1 = uniform(dev1);
+  if (ORDER >= 3) dev2 = uniform(dev2);
+}
+
+// LogRL_f (src/lmm.cpp:799-864) / LogL_f (:484-542).  If `P_out` != nullptr the order-1
+// projections at this lambda are handed back (CalcRLWald reuses them when lambda matches).
+template <int C, bool REML>
+__device__ __forceinline__ double logf(const SnpCtx<C> &s, double l) {
+  Row0<C> R;
+  row0_pass<C, 1, true>(*s.g, s.x, l, s.lane, R);
+  Proj<C> P;
+  project<C, 1>(R, P);
+  const double n = (double)s.g->n;
+  double P_yy = P.yy1[1];
+  if (P_yy >= 0.0 && P_yy < 1e-8) P_yy = 1e-8; // P_YY_MIN, src/lmm.cpp:52,527,854
+  double f;
+  if (REML) {
+    const double df = n - (double)C - 1.0;
+    double logdet_hiw = -s.logdet_iw;
+#pragma unroll
+    for (int i = 0; i < C + 1; ++i) logdet_hiw += log(P.ww1[i]);
+    const double cst = 0.5 * df * (log(df) - log(2 * M_PI) - 1.0);
+    f = cst - 0.5 * R.logdet - 0.5 * logdet_hiw - 0.5 * df * log(P_yy);
+  } else {
+    const double cst = 0.5 * n * (log(n) - log(2 * M_PI) - 1.0);
+    f = cst - 0.5 * R.logdet - 0.5 * n * log(P_yy);
+  }
+  return uniform(f);
+}
+
+// CalcRLWald (src/lmm.cpp:1127-1167) / CalcRLScore (:1170-1211)
+template <int C, bool SCORE>
+__device__ __forceinline__ void wald_score(const SnpCtx<C> &s, double l, double &beta, double &se,
+                                           double &pval) {
+  Row0<C> R;
+  row0_pass<C, 1, false>(*s.g, s.x, l, s.lane, R);
+  Proj<C> P;
+  project<C, 1>(R, P);
+  const int df = s.g->n - C - 1;
+  const double P_yy = P.yy1[0], P_xx = P.xx1, P_xy = P.xy1, Px_yy = P.yy1[1];
+  beta = uniform(P_xy / P_xx);
+  const double tau = (double)df / Px_yy;
+  se = uniform(safe_sqrt_dev(1.0 / (tau * P_xx)));
+  double stat;
+  if (SCORE)
+    stat = (double)s.g->n * P_xy * P_xy / (P_yy * P_xx);
+  else
+    stat = (P_yy - Px_yy) * tau;
+  stat = uniform(stat);
+  pval = uniform(fdist_Q1_dev(stat, (double)df, s.g->lnbeta_half_df));
+}
+
+// ------------------------------------------------------------------ root finders
+// GSL roots/brent.c (brent_init / brent_iterate), restated; state lives in registers.
+struct Brent {
+  double a, b, c, d, e, fa, fb, fc;
+  double root, x_lower, x_upper;
+};
+enum { RS_SUCCESS = 0, RS_CONTINUE = -2, RS_EINVAL = 4, RS_EBADFUNC = 9, RS_EZERODIV = 12 };
+
+template <int C, bool REML>
+__device__ __forceinline__ double dev1_of(const SnpCtx<C> &s, double l) {
+  double d1, d2;
+  deriv<C, REML, 2>(s, l, d1, d2);
+  return d1;
+}
+
+__device__ __forceinline__ bool finite_d(double v) { return fabs(v) <= DBL_MAX; }
+
+template <int C, bool REML>
+__device__ inline int brent_set(Brent &s, const SnpCtx<C> &cx, double x_lower, double x_upper,
+                                double f_lower, double f_upper) {
+  // f_lower/f_upper: the reference re-evaluates dev1 at both ends (gsl_root_fsolver_set ->
+  // brent_init); the function is pure, so the grid-scan values are the same numbers.
+  if (x_lower > x_upper) return RS_EINVAL;
+  s.root = 0.5 * (x_lower + x_upper);
+  s.x_lower = x_lower;
+  s.x_upper = x_upper;
+  if (!finite_d(f_lower)) return RS_EBADFUNC;
+  if (!finite_d(f_upper)) return RS_EBADFUNC;
+  s.a = x_lower; s.fa = f_lower;
+  s.b = x_upper; s.fb = f_upper;
+  s.c = x_upper; s.fc = f_upper;
+  s.d = x_upper - x_lower;
+  s.e = x_upper - x_lower;
+  if ((f_lower < 0.0 && f_upper < 0.0) || (f_lower > 0.0 && f_upper > 0.0)) return RS_EINVAL;
+  return RS_SUCCESS;
+}
+
+template <int C, bool REML>
+__device__ inline int brent_iterate(Brent &s, const SnpCtx<C> &cx) {
+  double tol, m;
+  bool ac_equal = false;
+  double a = s.a, b = s.b, c = s.c, fa = s.fa, fb = s.fb, fc = s.fc, d = s.d, e = s.e;
+  if ((fb < 0 && fc < 0) || (fb > 0 && fc > 0)) {
+    ac_equal = true;
+    c = a; fc = fa; d = b - a; e = b - a;
+  }
+  if (fabs(fc) < fabs(fb)) {
+    ac_equal = true;
+    a = b; b = c; c = a;
+    fa = fb; fb = fc; fc = fa;
+  }
+  tol = 0.5 * DBL_EPSILON * fabs(b);
+  m = 0.5 * (c - b);
+  if (fb == 0) {
+    s.root = b; s.x_lower = b; s.x_upper = b;
+    return RS_SUCCESS;
+  }
+  if (fabs(m) <= tol) {
+    s.root = b;
+    if (b < c) { s.x_lower = b; s.x_upper = c; } else { s.x_lower = c; s.x_upper = b; }
+    return RS_SUCCESS;
+  }
+  if (fabs(e) < tol || fabs(fa) <= fabs(fb)) {
+    d = m; e = m;
+  } else {
+    double p, q, r;
+    const double sv = fb / fa;
+    if (ac_equal) {
+      p = 2 * m * sv;
+      q = 1 - sv;
+    } else {
+      q = fa / fc;
+      r = fb / fc;
+      p = sv * (2 * m * q * (q - r) - (b - a) * (r - 1));
+      q = (q - 1) * (r - 1) * (sv - 1);
+    }
+    if (p > 0) q = -q; else p = -p;
+    const double lim1 = 3 * m * q - fabs(tol * q), lim2 = fabs(e * q);
+    if (2 * p < (lim1 < lim2 ? lim1 : lim2)) {
+      e = d; d = p / q;
+    } else {
+      d = m; e = m;
+    }
+  }
+  a = b; fa = fb;
+  if (fabs(d) > tol) b += d; else b += (m > 0 ? +tol : -tol);
+  fb = dev1_of<C, REML>(cx, b);
+  if (!finite_d(fb)) return RS_EBADFUNC;
+  s.a = a; s.b = b; s.c = c; s.d = d; s.e = e; s.fa = fa; s.fb = fb; s.fc = fc;
+  s.root = b;
+  if ((fb < 0 && fc < 0) || (fb > 0 && fc > 0)) c = a;
+  if (b < c) { s.x_lower = b; s.x_upper = c; } else { s.x_lower = c; s.x_upper = b; }
+  return RS_SUCCESS;
+}
+
+// gsl_root_test_interval(lo, hi, 0, 1e-1) and gsl_root_test_delta(x1, x0, 0, 1e-5) (GSL
+// roots/convergence.c) as used at src/lmm.cpp:2050,2073
+__device__ __forceinline__ int test_interval_dev(double lo, double hi, double epsrel) {
+  if (lo > hi) return RS_EINVAL;
+  double min_abs;
+  if ((lo > 0.0 && hi > 0.0) || (lo < 0.0 && hi < 0.0))
+    min_abs = fmin(fabs(lo), fabs(hi));
+  else
+    min_abs = 0;
+  return (fabs(hi - lo) < epsrel * min_abs) ? RS_SUCCESS : RS_CONTINUE;
+}
+__device__ __forceinline__ int test_delta_dev(double x1, double x0, double epsrel) {
+  return (fabs(x1 - x0) < epsrel * fabs(x1) || x1 == x0) ? RS_SUCCESS : RS_CONTINUE;
+}
+
+// CalcLambda, src/lmm.cpp:1945-2140.  Brackets are processed as soon as the grid scan finds
+// them (the evaluations are pure, so interleaving scan and polish gives the reference's
+// sequence of results); `return NaN` and `break` semantics of :2057-2060,:2087-2094 are kept.
+template <int C, bool REML>
+__device__ inline void calc_lambda(const SnpCtx<C> &cx, double &lambda, double &logf_out) {
+  const AssocArgs &g = *cx.g;
+  const double l_min = g.l_min, l_max = g.l_max;
+  double lam = NAN, lf = NAN;
+  bool any = false, first = true, stop = false, failed = false;
+  double l = 0.0, l_temp = 0.0;
+  double d_lo = dev1_of<C, REML>(cx, g.lam_grid[0]);
+  for (int i = 0; i < g.n_region; ++i) {
+    const double lambda_l0 = g.lam_grid[i], lambda_h0 = g.lam_grid[i + 1];
+    const double d_hi = dev1_of<C, REML>(cx, lambda_h0);
+    const bool bracket = (d_lo * d_hi <= 0);
+    if (bracket) any = true;
+    if (bracket && !stop && !failed) {
+      Brent bs;
+      bs.a = bs.b = bs.c = bs.d = bs.e = bs.fa = bs.fb = bs.fc = 0.0;
+      bs.root = bs.x_lower = bs.x_upper = 0.0;
+      (void)brent_set<C, REML>(bs, cx, lambda_l0, lambda_h0, d_lo, d_hi);
+      int status;
+      int iter = 0;
+      double lambda_l, lambda_h;
+      do {
+        iter++;
+        status = brent_iterate<C, REML>(bs, cx);
+        if (status != RS_SUCCESS && status != RS_CONTINUE) break;
+        l = bs.root;
+        lambda_l = bs.x_lower;
+        lambda_h = bs.x_upper;
+        status = test_interval_dev(lambda_l, lambda_h, 1e-1);
+        if (status != RS_SUCCESS && status != RS_CONTINUE) break;
+      } while (status == RS_CONTINUE && iter < 100);
+      if (status == RS_CONTINUE) {
+        stop = true; // :2057-2060 leaves the bracket loop
+      } else {
+        // Newton, GSL roots/newton.c: set() evaluates (f, df) at the start
+        int iter2 = 0;
+        double root = l, nf, ndf;
+        deriv<C, REML, 3>(cx, root, nf, ndf);
+        do {
+          iter2++;
+          if (ndf == 0.0) {
+            status = RS_EZERODIV;
+          } else {
+            const double root_new = root - (nf / ndf);
+            root = root_new;
+            deriv<C, REML, 3>(cx, root_new, nf, ndf);
+            status = (!finite_d(nf) || !finite_d(ndf)) ? RS_EBADFUNC : RS_SUCCESS;
+          }
+          if (status != RS_SUCCESS && status != RS_CONTINUE) break;
+          l_temp = l;
+          l = root;
+          status = test_delta_dev(l, l_temp, 1e-5);
+        } while (status == RS_CONTINUE && iter2 < 100 && l > l_min && l < l_max);
+        if (status != RS_SUCCESS) {
+          failed = true; // :2087-2094: lambda = logf = NaN, return
+        } else {
+          l = l_temp; // :2096 -- the previous Newton iterate is reported
+          if (l < l_min) l = l_min;
+          if (l > l_max) l = l_max;
+          const double logf_l = logf<C, REML>(cx, l);
+          if (first) {
+            lf = logf_l; lam = l;
+          } else if (lf < logf_l) {
+            lf = logf_l; lam = l;
+          }
+          first = false;
+        }
+      }
+    }
+    d_lo = d_hi;
+  }
+  if (failed) {
+    lambda = NAN;
+    logf_out = NAN;
+    return;
+  }
+  const double logf_l = logf<C, REML>(cx, l_min);
+  const double logf_h = logf<C, REML>(cx, l_max);
+  if (!any) { // :1985-2000
+    if (logf_l >= logf_h) { lam = l_min; lf = logf_l; } else { lam = l_max; lf = logf_h; }
+  } else { // :2121-2136
+    if (logf_l > lf) { lam = l_min; lf = logf_l; }
+    if (logf_h > lf) { lam = l_max; lf = logf_h; }
+  }
+  lambda = lam;
+  logf_out = lf;
+}
+
+// ------------------------------------------------------------------ kernel
+template <int C>
+__global__ __launch_bounds__(256) void lmm_assoc_kernel(AssocArgs g) {
+  const int lane = threadIdx.x & 63;
+  const long snp = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (snp >= g.l) return;
+  SnpCtx<C> cx;
+  cx.g = &g;
+  cx.x = g.UtX + snp * g.ld;
+  cx.lane = lane;
+  cx.logdet_iw = 0.0;
+  const int a_mode = g.a_mode;
+
+  double lambda_mle = 0.0, lambda_remle = 0.0, beta = 0.0, se = 0.0, p_wald = 0.0;
+  double p_lrt = 0.0, p_score = 0.0, logl_H1 = 0.0;
+  bool wald_skipped = false;
+
+  if (a_mode == 3 || a_mode == 4 || a_mode == 9) // "3 is before 1", src/lmm.cpp:1540-1543
+    wald_score<C, true>(cx, g.l_mle_null, beta, se, p_score);
+
+  if (a_mode == 1 || a_mode == 4) {
+    { // Iab: CalcPab with H == 1 (src/lmm.cpp:839-850); constant for the SNP
+      Row0<C> R;
+      row0_pass<C, 0, false>(g, cx.x, 0.0, lane, R);
+      Proj<C> P;
+      project<C, 1>(R, P);
+      double s = 0.0;
+#pragma unroll
+      for (int i = 0; i < C + 1; ++i) s += log(P.ww1[i]);
+      cx.logdet_iw = uniform(s);
+    }
+    calc_lambda<C, true>(cx, lambda_remle, logl_H1);
+    if (!g.plink_nan_rule || !isnan(logl_H1)) // src/lmm.cpp:1870
+      wald_score<C, false>(cx, lambda_remle, beta, se, p_wald);
+    else
+      wald_skipped = true;
+  }
+  if (a_mode == 2 || a_mode == 4 || a_mode == 9) {
+    calc_lambda<C, false>(cx, lambda_mle, logl_H1);
+    p_lrt = chisq_Q1_dev(2.0 * (logl_H1 - g.logl_mle_H0));
+    if (isnan(logl_H1)) p_lrt = NAN;
+  }
+  if (g.plink_nan_rule && isnan(logl_H1)) p_wald = p_lrt = logl_H1; // src/lmm.cpp:1882-1884
+  if (wald_skipped && a_mode == 1) {
+    // AnalyzePlink keeps beta/se of the PREVIOUS SNP here (function-scope variables,
+    // src/lmm.cpp:1725); the host fix-up in gemma_hip_lmm_batch* fills these two from the
+    // preceding SNP. A signalling pattern marks them: quiet NaN payload.
+    beta = NAN;
+    se = NAN;
+  }
+  if (lane == 0) {
+    SumStat o;
+    o.beta = beta; o.se = se; o.lambda_remle = lambda_remle; o.lambda_mle = lambda_mle;
+    o.p_wald = p_wald; o.p_lrt = p_lrt; o.p_score = p_score; o.logl_H1 = logl_H1;
+    g.out[snp] = o;
+  }
+}
+
+// ------------------------------------------------------------------ null model
+// CalcLambda(func, eval, UtW, Uty, ...) with calc_null = true (GEMMA src/lmm.cpp:2143-2180,
+// called at src/gemma.cpp:2711,2734), CalcPve's LogRL_dev2 (:2197) and CalcLmmVgVeBeta's P_yy
+// (:2253-2258).  Projecting out w_1..w_c (nc_total = c, df = n - c) is the alternative-model code
+// with CP = c - 1 covariates and the last covariate in the role of x.
+struct NullOut {
+  double l_mle, logl_mle, l_remle, logl_remle, dev2_remle, Pyy_remle, Pyy_mle;
+};
+
+template <int CP>
+__global__ __launch_bounds__(64) void lmm_null_kernel(AssocArgs g, NullOut *out) {
+  const int lane = threadIdx.x & 63;
+  SnpCtx<CP> cx;
+  cx.g = &g;
+  cx.x = g.UtWt + (long)CP * g.n; // last covariate column
+  cx.lane = lane;
+  {
+    Row0<CP> R;
+    row0_pass<CP, 0, false>(g, cx.x, 0.0, lane, R);
+    Proj<CP> P;
+    project<CP, 1>(R, P);
+    double s = 0.0;
+#pragma unroll
+    for (int i = 0; i < CP + 1; ++i) s += log(P.ww1[i]);
+    cx.logdet_iw = uniform(s);
+  }
+  NullOut o;
+  calc_lambda<CP, false>(cx, o.l_mle, o.logl_mle);
+  calc_lambda<CP, true>(cx, o.l_remle, o.logl_remle);
+  double d1, d2;
+  deriv<CP, true, 3>(cx, o.l_remle, d1, d2);
+  o.dev2_remle = d2;
+  {
+    Row0<CP> R;
+    Proj<CP> P;
+    row0_pass<CP, 1, false>(g, cx.x, o.l_remle, lane, R);
+    project<CP, 1>(R, P);
+    o.Pyy_remle = uniform(P.yy1[1]);
+    row0_pass<CP, 1, false>(g, cx.x, o.l_mle, lane, R);
+    project<CP, 1>(R, P);
+    o.Pyy_mle = uniform(P.yy1[1]);
+  }
+  if (lane == 0) *out = o;
+}
+
+} // namespace gemma_hip

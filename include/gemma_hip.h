@@ -1,0 +1,169 @@
+/*
+ * gemma_hip.h -- C ABI of the MI355X (gfx950) implementation of GEMMA's
+ * kinship + univariate-LMM hot path.
+ *
+ * GEMMA has no plugin/FFI layer; the boundary is cut at the internal C++
+ * waists listed in SURVEY.md section 8(b).  Every entry point below names the
+ * reference interface it replaces (file:line relative to the GEMMA tree).
+ * INTEGRATION.md shows the few lines a GEMMA maintainer adds at each site.
+ *
+ * Conventions
+ *  - plain pointers and sizes only; all matrices are row-major with an explicit
+ *    leading dimension (maps 1:1 onto gsl_matrix{data,tda});
+ *  - every function returns 0 on success or a GEMMA_HIP_E* code;
+ *    gemma_hip_last_error() holds the detail text of the last failure;
+ *  - entry points without suffix take HOST pointers (the library stages through
+ *    device memory and never frees caller memory); the `_d` twins take DEVICE
+ *    pointers plus a hipStream_t (passed as void*, NULL = the null stream) and
+ *    are asynchronous on that stream;
+ *  - one calling host thread (GEMMA is single-threaded); one process per GPU.
+ *    Multi-GPU = one process per device, SNP blocks sharded by the caller and
+ *    (U, eval, UtW, Uty) broadcast once into every rank's buffers (RCCL) before
+ *    gemma_hip_lmm_setup_d;
+ *  - there is NO CPU fallback: without a usable gfx950 device every call
+ *    returns GEMMA_HIP_ENODEV.
+ */
+#ifndef GEMMA_HIP_H
+#define GEMMA_HIP_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GEMMA_HIP_ABI_VERSION 1
+
+enum {
+  GEMMA_HIP_OK = 0,
+  GEMMA_HIP_EINVAL = 1,   /* bad argument / shape ("Range error in dgemm", src/fastblas.cpp:207) */
+  GEMMA_HIP_ENODEV = 2,   /* no gfx950 device / not initialised */
+  GEMMA_HIP_ENOMEM = 3,   /* device allocation failed */
+  GEMMA_HIP_ERUNTIME = 4, /* HIP runtime / kernel failure */
+  GEMMA_HIP_ESTATE = 5,   /* call sequence violated (e.g. lmm_batch before lmm_setup) */
+  GEMMA_HIP_ENOCONV = 6   /* eigensolver did not converge (INFO != 0, src/lapack.cpp:213,224) */
+};
+
+/* == class SUMSTAT, src/param.h:54-66 (8 doubles per analysed SNP, in SNP order) */
+typedef struct {
+  double beta, se, lambda_remle, lambda_mle, p_wald, p_lrt, p_score, logl_H1;
+} gemma_sumstat;
+
+/* genotype block encodings accepted by kin_add / lmm_batch */
+enum {
+  /* fp64, SNP-major: l rows of ld doubles (ld >= n); NaN = missing.  Rows hold exactly
+   * the individuals the consumer works on (analysed ones for lmm_batch, all for kin_add). */
+  GEMMA_GENO_F64_SNP_MAJOR = 0,
+  /* PLINK .bed payload, SNP-major: l rows of ld bytes (ld >= ceil(ni_total/4)), 4 individuals
+   * per byte, low bits first, codes 00->2 01->missing(bit0=1,bit1=0) 10->1 11->0 exactly as
+   * src/lmm.cpp:1797-1812.  Individuals are dropped on device with the indicator given to
+   * gemma_hip_lmm_set_indicator (lmm_batch only; kin_add always uses all ni_total). */
+  GEMMA_GENO_PLINK_2BIT = 1,
+  /* fp64, individual-major: n rows of ld doubles, SNP j = strided column j (ld >= l) -- the
+   * reference's own Xlarge layout (src/lmm.cpp:1502,1635; src/gemma_io.cpp:1439,1546).
+   * Missing values must already be imputed by the caller (as the reference does before the
+   * copy into Xlarge); for kin_add the columns must already be centred/scaled. */
+  GEMMA_GENO_F64_IDV_MAJOR = 2
+};
+
+/* ---- lifetime ---------------------------------------------------------- */
+int gemma_hip_init(int device /* -1: keep the current HIP device */, int verbose);
+void gemma_hip_shutdown(void);
+int gemma_hip_abi_version(void);
+const char *gemma_hip_strerror(int code);
+const char *gemma_hip_last_error(void);
+/* name[len], number of CUs, HBM bytes of the device in use */
+int gemma_hip_device_info(char *name, size_t len, int *n_cu, size_t *hbm_bytes);
+
+/* ---- B2: GEMM ---------------------------------------------------------- */
+/* replaces fast_dgemm / fast_eigen_dgemm, src/fastblas.h:34-39 (-> cblas_dgemm,
+ * src/fastblas.cpp:202-204) and the raw fast_cblas_dgemm, src/fastblas.cpp:66-170:
+ * C(MxN) = alpha*op(A)*op(B) + beta*C, row-major, ta/tb in {'N','T'}.
+ * fp64 MFMA (v_mfma_f64_16x16x4_f64), LDS-tiled. */
+int gemma_hip_dgemm(char ta, char tb, size_t M, size_t N, size_t K, double alpha, const double *A,
+                    size_t lda, const double *B, size_t ldb, double beta, double *C, size_t ldc);
+int gemma_hip_dgemm_d(char ta, char tb, size_t M, size_t N, size_t K, double alpha,
+                      const double *A_d, size_t lda, const double *B_d, size_t ldb, double beta,
+                      double *C_d, size_t ldc, void *stream);
+
+/* ---- B1: streaming kinship --------------------------------------------- */
+/* replaces the body of BimbamKin / PlinkKin, src/gemma_io.cpp:1418-1597 / :1599-1738, called
+ * from PARAM::CalcKin src/param.cpp:1300-1321: per SNP over all n_total individuals mean over
+ * non-missing, impute, centre, (k_mode 2: scale by 1/sqrt(var), var as :1511-1514),
+ * K += Xb Xb^T per block, finally K /= ns_used (:1570) and symmetric fill (:1724-1729). */
+int gemma_hip_kin_begin(size_t n_total, int k_mode /* 1 centred, 2 standardised */);
+int gemma_hip_kin_add(int geno_kind, const void *geno, size_t l, size_t ld);
+int gemma_hip_kin_add_d(int geno_kind, const void *geno_d, size_t l, size_t ld, void *stream);
+int gemma_hip_kin_end(double *K /* n_total^2, row-major, full symmetric */, size_t *ns_used);
+int gemma_hip_kin_end_d(double *K_d, size_t *ns_used, void *stream);
+
+/* ---- B3: centring + eigendecomposition --------------------------------- */
+/* CenterMatrix(gsl_matrix*), src/mathfunc.cpp:147-177 (in place) */
+int gemma_hip_center(double *G, size_t n);
+int gemma_hip_center_d(double *G_d, size_t n, void *stream);
+/* EigenDecomp_Zeroed, src/lapack.cpp:260-291 (-> lapack_eigen_symmv/dsyevr_, :149-236):
+ * G (destroyed) -> U (row-major, eigenvector k = column k), eval ascending with values
+ * < 1e-10 set to 0; *trace_G = mean(eval) (the function's return value, :277). */
+int gemma_hip_eigh(double *G, size_t n, double *U, double *eval, double *trace_G);
+int gemma_hip_eigh_d(double *G_d, size_t n, double *U_d, double *eval_d, double *trace_G,
+                     void *stream);
+/* CalcUtX(U,X,UtX), src/mathfunc.cpp:504-506: UtX (n x m) = U^T X (X n x m row-major) */
+int gemma_hip_calc_utx(const double *U, const double *X, size_t n, size_t m, double *UtX);
+
+/* ---- B4: per-batch association ------------------------------------------ */
+/* the state batch_compute (src/lmm.cpp:1513-1564) reads from class LMM, src/lmm.h:53-74 */
+typedef struct {
+  int a_mode;          /* 1 Wald, 2 LRT, 3 score, 4 all, 9 (src/gemma.h:39-43) */
+  size_t n;            /* ni_test */
+  size_t n_cvt;        /* covariates incl. intercept (>= 1) */
+  double l_min, l_max; /* 1e-5, 1e5 (src/param.cpp:94-107) */
+  size_t n_region;     /* 10 */
+  double l_mle_null;   /* null-model ML lambda (score test, src/lmm.cpp:1542) */
+  double logl_mle_H0;  /* null-model ML log-likelihood (LRT, src/lmm.cpp:1553) */
+  int plink_nan_rule;  /* 1: AnalyzePlink's handling of a failed lambda search (src/lmm.cpp:1870-1884) */
+} gemma_lmm_cfg;
+
+/* Null model (calc_null = true): CalcLambda('L'/'R', eval, UtW, Uty, ...) src/lmm.cpp:2143-2180 as
+ * called at src/gemma.cpp:2711,2734, plus CalcPve (src/lmm.cpp:2183-2205) and the vg/ve part of
+ * CalcLmmVgVeBeta (:2253-2259).  Host pointers.  out8 = { l_mle_null, logl_mle_H0, l_remle_null,
+ * logl_remle_H0, pve, pve_se, vg_remle, ve_remle }. */
+int gemma_hip_lmm_null(size_t n, size_t n_cvt, const double *eval, const double *UtW,
+                       const double *Uty, double l_min, double l_max, size_t n_region,
+                       double trace_G, double *out8);
+
+/* uploads U (n x n row-major, eigenvectors in columns), eval, UtW (n x n_cvt row-major), Uty */
+int gemma_hip_lmm_setup(const gemma_lmm_cfg *cfg, const double *U, const double *eval,
+                        const double *UtW, const double *Uty);
+/* same with device-resident inputs (borrowed until lmm_finish): the multi-GPU path, after the
+ * single RCCL broadcast of (U, eval, UtW, Uty) */
+int gemma_hip_lmm_setup_d(const gemma_lmm_cfg *cfg, const double *U_d, const double *eval_d,
+                          const double *UtW_d, const double *Uty_d, void *stream);
+/* for GEMMA_GENO_PLINK_2BIT: indicator_idv over ni_total individuals (sum == cfg.n);
+ * NULL/0 resets to "all individuals analysed" */
+int gemma_hip_lmm_set_indicator(const int *indicator_idv, size_t ni_total);
+/* one block of l SNPs: mean-impute (src/lmm.cpp:1590-1618 / :1819-1827), UtX = U^T X (:1521),
+ * then per SNP CalcUab, CalcRLScore, CalcLambda('R')+CalcRLWald, CalcLambda('L')+LRT (:1526-1562).
+ * out[l] in SNP order. l is not limited to LMM_BATCH_SIZE. */
+int gemma_hip_lmm_batch(int geno_kind, const void *geno, size_t l, size_t ld, gemma_sumstat *out);
+int gemma_hip_lmm_batch_d(int geno_kind, const void *geno_d, size_t l, size_t ld,
+                          gemma_sumstat *out_d, void *stream);
+/* the second half of lmm_batch on a caller-supplied UtX (SNP-major l x ld_utx, device):
+ * what remains of batch_compute after the fast_dgemm at src/lmm.cpp:1521 */
+int gemma_hip_lmm_assoc_d(const double *UtX_d, size_t l, size_t ld_utx, gemma_sumstat *out_d,
+                          void *stream);
+/* releases the LMM state; reports GPU time spent in the UtX GEMM and in the per-SNP stage in
+ * minutes, the unit of LMM::time_UtX / time_opt (src/lmm.cpp:1523,1556) */
+int gemma_hip_lmm_finish(double *time_UtX_min, double *time_opt_min);
+
+/* ---- measurement -------------------------------------------------------- */
+enum { GEMMA_STAGE_INGEST = 0, GEMMA_STAGE_UTX_GEMM = 1, GEMMA_STAGE_ASSOC = 2,
+       GEMMA_STAGE_KIN_GEMM = 3, GEMMA_STAGE_EIGH = 4, GEMMA_STAGE_COUNT = 5 };
+/* when on, every kernel of a stage is bracketed by hipEvents on its launch stream */
+int gemma_hip_profile_enable(int on);
+/* synchronises, then returns accumulated GPU milliseconds and launch count; reset != 0 clears */
+int gemma_hip_profile_read(int stage, double *total_ms, long *launches, int reset);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GEMMA_HIP_H */
