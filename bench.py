@@ -1,0 +1,284 @@
+#!/usr/bin/env python
+"""bench.py -- SNPs/s of `-lmm 1` (Wald) at n = 20 000 on N x MI355X  (BASELINE.json metric).
+
+A step = one pass of the hot path over one block of B SNPs (B = LMM_BATCH_SIZE = 20000, the
+reference's own batch, src/lmm.h:33) with the block's PLINK 2-bit genotypes already resident in
+HBM: ingest (2-bit decode + mean imputation) -> UtX = X U (fp64 MFMA GEMM) -> per-SNP lambda
+search + Wald test -> 64 B/SNP SUMSTAT left in HBM.  Nothing is skipped or cached between steps
+(every step gets its own genotype block).
+
+Untimed setup on rank 0: synthetic genotypes -> kinship K (this library's SYRK path) -> centring
+-> eigendecomposition -> U^T W, U^T y -> null model; then ONE broadcast of (U, eval, UtW, Uty) to
+the other ranks (torch.distributed, backend nccl = RCCL).  Ranks then work on disjoint SNP blocks
+with no collective in the timed region (weak scaling: B SNPs per rank per step).
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
+  roofline     -- the dominant kernel (UtX GEMM): algorithmic flops / hipEvent-measured duration
+  cpu_baseline -- the oracle (kind "port": OpenBLAS dgemm through numpy + the serial C per-SNP
+                  loop of oracle/) timed on this box's host cores on a bounded SNP sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FP64_MFMA_PEAK_TFLOPS = 78.6  # MI355X fp64 matrix peak (AMD CDNA4 datasheet; v_mfma_f64_16x16x4 = 64 clk)
+HBM_PEAK_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=4)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--n", type=int, default=20000, help="analysed individuals")
+    ap.add_argument("--batch", type=int, default=20000, help="SNPs per step and per rank")
+    ap.add_argument("--kin-snps", type=int, default=20000, help="SNPs used for the kinship matrix (setup)")
+    ap.add_argument("--eigen", default="auto", choices=["auto", "gemma", "torch"])
+    ap.add_argument("--cpu-sample", type=int, default=2048, help="SNPs in the CPU baseline sample (0 = skip)")
+    ap.add_argument("--a-mode", type=int, default=1)
+    ap.add_argument("--seed", type=int, default=20000)
+    return ap.parse_args()
+
+
+def synth_block(torch, n, l, gen, dev, miss=0.01, fst=0.05):
+    """l SNPs x n individuals, Balding-Nichols two-population genotypes, 1 % missing, packed as PLINK
+    2-bit rows (codes: 2 -> 00, 1 -> 10, 0 -> 11, missing -> 01; low bits first)."""
+    maf = torch.empty(l, device=dev).uniform_(0.05, 0.5, generator=gen)
+    a = maf * (1 - fst) / fst
+    b = (1 - maf) * (1 - fst) / fst
+    # Beta(a,b) via two gammas (torch._standard_gamma takes no generator: seeded globally)
+    ga = torch._standard_gamma(a.repeat(2, 1))
+    gb = torch._standard_gamma(b.repeat(2, 1))
+    psub = ga / (ga + gb)  # 2 x l
+    half = n // 2
+    pfreq = torch.cat([psub[0].unsqueeze(1).expand(l, half), psub[1].unsqueeze(1).expand(l, n - half)], dim=1)
+    u1 = torch.rand((l, n), device=dev, generator=gen)
+    u2 = torch.rand((l, n), device=dev, generator=gen)
+    g = (u1 < pfreq).to(torch.uint8) + (u2 < pfreq).to(torch.uint8)  # 0/1/2
+    del u1, u2, pfreq
+    code = torch.where(g == 2, torch.zeros_like(g), torch.where(g == 1, torch.full_like(g, 2), torch.full_like(g, 3)))
+    m = torch.rand((l, n), device=dev, generator=gen) < miss
+    code = torch.where(m, torch.ones_like(code), code)
+    nb = (n + 3) // 4
+    pad = torch.zeros((l, nb * 4), dtype=torch.uint8, device=dev)
+    pad[:, :n] = code
+    packed = pad[:, 0::4] | (pad[:, 1::4] << 2) | (pad[:, 2::4] << 4) | (pad[:, 3::4] << 6)
+    return packed.contiguous()
+
+
+def main():
+    args = parse()
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from gemma_amd import api
+    from gemma_amd import _lib as L
+    from gemma_amd import dist as gdist
+
+    api.init(local, verbose=0)
+    name, n_cu, hbm = api.device_info()
+    n, B = args.n, args.batch
+    torch.manual_seed(args.seed + rank)
+    gen = torch.Generator(device=dev).manual_seed(args.seed + 1000 * rank)
+
+    # ------------------------------------------------------------------ setup (untimed)
+    t_setup = time.time()
+    U = torch.empty((n, n), dtype=torch.float64, device=dev)
+    ev = torch.empty(n, dtype=torch.float64, device=dev)
+    UtW = torch.empty((n, 1), dtype=torch.float64, device=dev)
+    Uty = torch.empty(n, dtype=torch.float64, device=dev)
+    setup_info = {}
+    null = torch.zeros(2, dtype=torch.float64, device=dev)
+    if rank == 0:
+        t0 = time.time()
+        K = torch.empty((n, n), dtype=torch.float64, device=dev)
+        api.profile_enable(True)
+        api.kin_begin(n, 1)
+        y = torch.zeros(n, dtype=torch.float64, device=dev)
+        done = 0
+        while done < args.kin_snps:
+            l = min(B, args.kin_snps - done)
+            blk = synth_block(torch, n, l, gen, dev)
+            api.kin_add(blk, L.GENO_PLINK_2BIT)
+            if done == 0:  # phenotype: 50 causal SNPs of the first block + noise
+                codes = (blk[:50].unsqueeze(2) >> torch.tensor([0, 2, 4, 6], device=dev, dtype=torch.uint8)) & 3
+                codes = codes.reshape(50, -1)[:, :n]
+                gv = torch.where(codes == 0, 2.0, torch.where(codes == 2, 1.0, 0.0)).to(torch.float64)
+                beta = torch.randn(50, dtype=torch.float64, device=dev, generator=gen) * 0.15
+                y += gv.T @ beta
+            done += l
+            del blk
+        api.kin_end(K)
+        torch.cuda.synchronize()
+        kin_ms, kin_n = api.profile_read(L.STAGE_KIN_GEMM, reset=True)
+        setup_info["kinship_s"] = round(time.time() - t0, 3)
+        setup_info["kinship_gemm_tflops"] = round(2.0 * n * n * args.kin_snps / (kin_ms * 1e-3) / 1e12, 2) if kin_ms else None
+        y += torch.randn(n, dtype=torch.float64, device=dev, generator=gen) * y.std().clamp_min(1e-3)
+        api.CenterMatrix(K)
+        t0 = time.time()
+        eig = args.eigen
+        if eig in ("auto", "gemma"):
+            try:
+                Kc = K.clone()
+                api.EigenDecomp_Zeroed(Kc, U, ev)
+                eig = "gemma_hip_eigh"
+                del Kc
+            except L.GemmaHipError:
+                if eig == "gemma":
+                    raise
+                eig = "torch"
+        if eig == "torch":
+            w, V = torch.linalg.eigh(K)
+            U.copy_(V)
+            ev.copy_(torch.where(w < 1e-10, torch.zeros_like(w), w))
+            eig = "torch.linalg.eigh (setup only; library eigensolver unavailable)"
+            del w, V
+        torch.cuda.synchronize()
+        setup_info["eigen"] = eig
+        setup_info["eigen_s"] = round(time.time() - t0, 3)
+        del K
+        # UtW = U^T 1, Uty = U^T y through the library's GEMM (CalcUtX, src/mathfunc.cpp:504-506)
+        ones = torch.ones((n, 1), dtype=torch.float64, device=dev)
+        api.fast_dgemm("T", "N", 1.0, U, ones, 0.0, UtW)
+        ycol = y.reshape(n, 1).contiguous()
+        Utyc = torch.empty((n, 1), dtype=torch.float64, device=dev)
+        api.fast_dgemm("T", "N", 1.0, U, ycol, 0.0, Utyc)
+        Uty.copy_(Utyc[:, 0])
+        torch.cuda.synchronize()
+        nm = api.CalcLambdaNull(ev.cpu().numpy(), UtW.cpu().numpy(), Uty.cpu().numpy(), trace_G=float(ev.mean()))
+        null[0], null[1] = nm["l_mle_null"], nm["logl_mle_H0"]
+        setup_info["null"] = {k: nm[k] for k in ("l_remle_null", "pve")}
+        api.profile_read(L.STAGE_UTX_GEMM, reset=True)
+    t0 = time.time()
+    gdist.broadcast_state([U, ev, UtW, Uty, null])  # the single RCCL broadcast
+    torch.cuda.synchronize()
+    setup_info["broadcast_s"] = round(time.time() - t0, 3)
+
+    blocks = [synth_block(torch, n, B, gen, dev) for _ in range(args.steps + args.warmup)]
+    out = torch.empty((B, 8), dtype=torch.float64, device=dev)
+    lmm = api.LMM(a_mode=args.a_mode, l_mle_null=float(null[0]), logl_mle_H0=float(null[1]))
+    lmm.setup(U, ev, UtW, Uty, plink=True)
+    torch.cuda.synchronize()
+    setup_info["setup_total_s"] = round(time.time() - t_setup, 1)
+
+    # ------------------------------------------------------------------ warmup + timed steps
+    api.profile_enable(False)
+    for i in range(args.warmup):
+        lmm.batch(blocks[i], L.GENO_PLINK_2BIT, out=out)
+    torch.cuda.synchronize()
+    api.profile_enable(True)
+    for st in range(L.STAGE_EIGH + 1):
+        api.profile_read(st, reset=True)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        lmm.batch(blocks[args.warmup + i], L.GENO_PLINK_2BIT, out=out)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt[0])
+    gemm_ms, gemm_n = api.profile_read(L.STAGE_UTX_GEMM)
+    assoc_ms, assoc_n = api.profile_read(L.STAGE_ASSOC)
+    ing_ms, ing_n = api.profile_read(L.STAGE_INGEST)
+    res = out.cpu().numpy()
+    n_nan = int(np.isnan(res[:, 4]).sum())
+
+    if rank == 0:
+        total_snps = B * args.steps * world
+        value = total_snps / elapsed
+        gemm_avg_s = gemm_ms * 1e-3 / max(1, gemm_n)
+        flops_per_launch = 2.0 * B * n * n  # 2 n^2 flop per SNP
+        achieved = flops_per_launch / gemm_avg_s / 1e12
+        assoc_avg_s = assoc_ms * 1e-3 / max(1, assoc_n)
+        line = {
+            "metric": "SNPs/s (-lmm 1 Wald) at n=20k on 1/2/4/8 MI355X; U^T x HBM GB/s vs roofline",
+            "value": round(value, 1), "unit": "SNPs/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": "configs[2]: synthetic n=%d, -lmm %d, %d SNPs per step per GPU (PLINK 2-bit, "
+                                   "1%% missing, Balding-Nichols Fst 0.05), c=1" % (n, args.a_mode, B),
+                       "n": n, "snps_per_step": B, "kinship_snps": args.kin_snps, "parallelism": "snp-shard x%d" % world,
+                       "device": name, "cus": n_cu, "setup": setup_info, "nan_p_wald": n_nan},
+            "roofline": {"kernel": "dgemm_mfma_kernel (UtX = X*U)", "bound": "mfma", "achieved": round(achieved, 2),
+                         "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / FP64_MFMA_PEAK_TFLOPS, 4),
+                         "traffic": None, "launches": gemm_n, "avg_launch_ms": round(gemm_avg_s * 1e3, 3)},
+            "roofline_assoc": {"kernel": "lmm_assoc_kernel (lambda search + Wald)", "bound": "hbm",
+                               "achieved": round(8.0 * n * B / assoc_avg_s / 1e9, 2) if assoc_avg_s else None,
+                               "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": round(8.0 * n * B / assoc_avg_s / 1e9 / HBM_PEAK_GBS, 5) if assoc_avg_s else None,
+                               "avg_launch_ms": round(assoc_avg_s * 1e3, 3)},
+            "stage_ms_per_step": {"ingest": round(ing_ms / max(1, args.steps), 3), "utx_gemm": round(gemm_ms / max(1, args.steps), 3),
+                                  "assoc": round(assoc_ms / max(1, args.steps), 3)},
+        }
+        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(pmc):
+            try:
+                pj = json.load(open(pmc))
+                if pj.get("n") == n and pj.get("batch") == B:
+                    line["roofline"]["traffic"] = pj.get("utx_gemm_hbm_bytes_per_launch")
+            except Exception:
+                pass
+        if world == 1 and args.cpu_sample > 0:
+            line["cpu_baseline"] = cpu_baseline(args, np, torch, blocks[args.warmup + args.steps - 1], U, ev, UtW, Uty, res, n, B)
+        print(json.dumps(line), flush=True)
+    lmm.finish()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(args, np, torch, block, U, ev, UtW, Uty, gpu_res, n, B):
+    """Oracle ("port" of the reference's CPU path) on a bounded sample of the same block: OpenBLAS dgemm
+    (numpy) on all host cores for U^T X, then the serial per-SNP loop (src/lmm.cpp:1526-1562)."""
+    from oracle import oracle as O
+    S = min(args.cpu_sample, B)
+    raw = block[:S].cpu().numpy()
+    X = O.bed_decode(raw, n)
+    Uh, evh = U.cpu().numpy(), ev.cpu().numpy()
+    UtWh, Utyh = UtW.cpu().numpy(), Uty.cpu().numpy()
+    cores = os.cpu_count() or 1
+    t0 = time.perf_counter()
+    Xi = O.impute_mean(X)
+    UtX = np.ascontiguousarray(Xi @ Uh)
+    t1 = time.perf_counter()
+    ref = O.lmm_batch_UtX(args.a_mode, evh, UtWh, Utyh, UtX, plink_nan_rule=1)
+    t2 = time.perf_counter()
+    # parity of the timed GPU block against the checker, on the sample
+    worst = 0.0
+    for k, col in (("beta", 0), ("se", 1), ("p_wald", 4), ("logl_H1", 7)):
+        r = ref[k]
+        g = gpu_res[:S, col]
+        ok = np.isfinite(r)
+        worst = max(worst, float(np.max(np.abs(g[ok] - r[ok]) / np.abs(r[ok]))))
+    # the reference amortises the GEMM over 20000-SNP batches: scale the GEMM leg by its flop rate
+    gemm_rate = 2.0 * n * n * S / (t1 - t0)
+    return {"value": round(S / (t2 - t0), 2), "unit": "SNPs/s", "cores": cores, "kind": "port",
+            "sample": "%d SNPs of the last timed block: numpy/OpenBLAS dgemm on %d threads (%.1f GFLOP/s) %.2f s + "
+                      "serial per-SNP loop on 1 thread %.2f s" % (S, cores, gemm_rate / 1e9, t1 - t0, t2 - t1),
+            "gpu_vs_oracle_max_rel_err": worst}
+
+
+if __name__ == "__main__":
+    main()

@@ -15,7 +15,7 @@ SYMBOLS = [
     "gemma_hip_eigh_d", "gemma_hip_calc_utx", "gemma_hip_lmm_setup", "gemma_hip_lmm_setup_d",
     "gemma_hip_lmm_null", "gemma_hip_lmm_set_indicator", "gemma_hip_lmm_batch", "gemma_hip_lmm_batch_d",
     "gemma_hip_lmm_assoc_d", "gemma_hip_lmm_finish", "gemma_hip_profile_enable",
-    "gemma_hip_profile_read",
+    "gemma_hip_profile_read", "gemma_hip_dbg_tridiag", "gemma_hip_dbg_stedc",
 ]
 
 OK, EINVAL, ENODEV, ENOMEM, ERUNTIME, ESTATE, ENOCONV = range(7)
@@ -51,6 +51,13 @@ def lib():
     if not os.path.exists(LIB_PATH):
         raise ImportError("gemma_amd/libgemma_hip.so is missing -- run `python -m gemma_amd.build` "
                           "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+    # One HIP runtime per process: when torch is present (it only supplies device memory, streams and
+    # torch.distributed here) it must be imported BEFORE this library so that both resolve to the
+    # libamdhip64 torch ships; loading /opt/rocm's runtime first leaves torch without a device.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(LIB_PATH)
     vp, dp, sz, ci, cd = C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_double
     L.gemma_hip_init.argtypes = [ci, ci]
@@ -82,6 +89,8 @@ def lib():
     L.gemma_hip_lmm_finish.argtypes = [C.POINTER(cd), C.POINTER(cd)]
     L.gemma_hip_profile_enable.argtypes = [ci]
     L.gemma_hip_profile_read.argtypes = [ci, C.POINTER(cd), C.POINTER(C.c_long), ci]
+    L.gemma_hip_dbg_tridiag.argtypes = [dp, sz, dp, dp, dp, dp]
+    L.gemma_hip_dbg_stedc.argtypes = [dp, dp, sz, dp, dp]
     for s in SYMBOLS:
         getattr(L, s)  # AttributeError if the library does not export what the header declares
     _lib = L

@@ -479,6 +479,72 @@ extern "C" int gemma_hip_eigh(double *G, size_t n, double *U, double *eval, doub
   return rc;
 }
 
+// ---- diagnostics for the eigensolver stages (used by tests/test_gpu_eigh.py) ----
+// Householder tridiagonalisation only: G (host, n x n) -> d[n], e[n-1], tau[n], VT (n x n, row j = u_j)
+extern "C" int gemma_hip_dbg_tridiag(const double *G, size_t n, double *d, double *e, double *tau, double *VT) {
+  NEED_INIT();
+  EigWs ws;
+  DevBuf dG;
+  const size_t nn = n * n;
+  if (dG.reserve(nn * 8)) return fail(GEMMA_HIP_ENOMEM, "dbg_tridiag");
+  bool ok = ws.get(ws.VT, nn) && ws.get(ws.WT, (size_t)EIG_NB * n) && ws.get(ws.xcol, n) && ws.get(ws.p, n) &&
+            ws.get(ws.ab, 2 * EIG_NB) && ws.get(ws.d, n) && ws.get(ws.e, n) && ws.get(ws.tau, n);
+  std::string msg;
+  int rc = ok ? 0 : GEMMA_HIP_ENOMEM;
+  if (!rc && hipMemcpy(dG.p, G, nn * 8, hipMemcpyHostToDevice) != hipSuccess) rc = GEMMA_HIP_ERUNTIME;
+  if (!rc) rc = eig_tridiagonalize(dG.as<double>(), (long)n, ws, 0, msg);
+  if (!rc && hipDeviceSynchronize() != hipSuccess) rc = GEMMA_HIP_ERUNTIME;
+  if (!rc) {
+    (void)hipMemcpy(d, ws.d, n * 8, hipMemcpyDeviceToHost);
+    if (n > 1) (void)hipMemcpy(e, ws.e, (n - 1) * 8, hipMemcpyDeviceToHost);
+    (void)hipMemcpy(tau, ws.tau, n * 8, hipMemcpyDeviceToHost);
+    if (VT) (void)hipMemcpy(VT, ws.VT, nn * 8, hipMemcpyDeviceToHost);
+  }
+  ws.release();
+  dG.release();
+  if (rc) return fail(rc, "dbg_tridiag: %s", msg.c_str());
+  return GEMMA_HIP_OK;
+}
+
+// divide-and-conquer on a symmetric tridiagonal (host d[n], e[n-1]) -> w[n] ascending, ZT (n x n, row k =
+// eigenvector k)
+extern "C" int gemma_hip_dbg_stedc(const double *d, const double *e, size_t n, double *w, double *ZT) {
+  NEED_INIT();
+  EigWs ws;
+  const size_t nn = n * n;
+  double *QA = nullptr, *QB = nullptr;
+  bool ok = ws.get(QA, nn) && ws.get(QB, nn) && ws.get(ws.d, n) && ws.get(ws.e, n) && ws.get(ws.Delta, nn) &&
+            ws.get(ws.Wk, nn) && ws.get(ws.zbuf, n) && ws.get(ws.dl, n) && ws.get(ws.w, n) && ws.get(ws.lam, n) &&
+            ws.get(ws.zhat, n) && ws.get(ws.dphys, n) && ws.get(ws.ibuf, 2 * n + 64) && ws.get(ws.info, 1) &&
+            ws.get(ws.rot, n);
+  std::string msg;
+  int rc = ok ? 0 : GEMMA_HIP_ENOMEM;
+  std::vector<double> hd(d, d + n), he(e, e + (n > 1 ? n - 1 : 0)), dphys;
+  if (he.empty()) he.push_back(0.0);
+  double *Z = nullptr;
+  if (!rc && n == 1) {
+    w[0] = d[0];
+    ZT[0] = 1.0;
+    ws.release();
+    return GEMMA_HIP_OK;
+  }
+  if (!rc) rc = eig_stedc((long)n, hd, he, QA, QB, ws, 0, &Z, dphys, msg);
+  if (!rc) {
+    std::vector<int> perm(n);
+    for (size_t i = 0; i < n; ++i) perm[i] = (int)i;
+    std::stable_sort(perm.begin(), perm.end(), [&](int a, int c) { return dphys[a] < dphys[c]; });
+    std::vector<double> tmp(nn);
+    if (hipMemcpy(tmp.data(), Z, nn * 8, hipMemcpyDeviceToHost) != hipSuccess) rc = GEMMA_HIP_ERUNTIME;
+    for (size_t t = 0; t < n && !rc; ++t) {
+      w[t] = dphys[perm[t]];
+      memcpy(ZT + t * n, tmp.data() + (size_t)perm[t] * n, n * 8);
+    }
+  }
+  ws.release();
+  if (rc) return fail(rc, "dbg_stedc: %s", msg.c_str());
+  return GEMMA_HIP_OK;
+}
+
 extern "C" int gemma_hip_calc_utx(const double *U, const double *X, size_t n, size_t m, double *UtX) {
   // UtX (n x m) = U^T X : fast_dgemm("T","N",1.0,U,X,0.0,UtX), src/mathfunc.cpp:505
   return gemma_hip_dgemm('T', 'N', n, m, n, 1.0, U, n, X, m, 0.0, UtX, m);

@@ -164,18 +164,21 @@ __global__ __launch_bounds__(1024) void total_kernel(const double *Gw, long n, d
     *d = t;
   }
 }
-// G[i][j] += -(Gw[i] + Gw[j])/n + d/n^2   (dsyr2 + dsyr of the reference, both triangles)
+// G[i][j] += -(Gw[i] + Gw[j])/n + d/n^2 on the UPPER triangle (dsyr2 + dsyr with CblasUpper), then
+// the lower triangle is overwritten by the mirror -- exactly src/mathfunc.cpp:160-171, so a K that
+// is not bit-symmetric (cXX.txt at 10 digits) gives the reference's result.
 __global__ __launch_bounds__(256) void center_update_kernel(double *G, long n, long ld,
                                                             const double *Gw, const double *d) {
   const long j = (long)blockIdx.x * 256 + threadIdx.x;
   const long i = blockIdx.y;
-  if (j >= n) return;
+  if (j >= n || j < i) return;
   const double alpha = -1.0 / (double)n;
   const double beta = (*d) / ((double)n * (double)n);
   double v = G[i * ld + j];
   v += alpha * Gw[i] + alpha * Gw[j];
   v += beta;
   G[i * ld + j] = v;
+  if (j != i) G[j * ld + i] = v;
 }
 
 // eigenvalue post-processing of EigenDecomp_Zeroed (GEMMA src/lapack.cpp:266-277)

@@ -163,6 +163,12 @@ int gemma_hip_profile_enable(int on);
 /* synchronises, then returns accumulated GPU milliseconds and launch count; reset != 0 clears */
 int gemma_hip_profile_read(int stage, double *total_ms, long *launches, int reset);
 
+/* ---- diagnostics: the stages of gemma_hip_eigh in isolation (host pointers; tests only) ---- */
+/* Householder tridiagonalisation: d[n], e[n-1], tau[n], VT (n x n, row j = reflector u_j; may be NULL) */
+int gemma_hip_dbg_tridiag(const double *G, size_t n, double *d, double *e, double *tau, double *VT);
+/* divide and conquer on a symmetric tridiagonal: w[n] ascending, ZT (n x n, row k = eigenvector k) */
+int gemma_hip_dbg_stedc(const double *d, const double *e, size_t n, double *w, double *ZT);
+
 #ifdef __cplusplus
 }
 #endif

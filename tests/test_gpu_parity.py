@@ -1,0 +1,344 @@
+"""Parity of the HIP path (through the C ABI) against the oracle -- runs on the MI355X box.
+
+Tolerances (BASELINE.json north_star / SURVEY.md section 8c, App. A.5):
+  beta, se, logl_H1, p_*  : <= 1e-6 relative
+  lambda                  : <= 1e-6 relative on >= 98 % of SNPs, <= 1e-3 on all (see _cmp_stats)
+  K, centred K, GEMM      : <= 1e-12 relative (Frobenius / max-abs scaled)
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-6
+LAM_RTOL = 1e-3
+
+
+def _cmp_stats(got, ref, mode, tag=""):
+    """beta/se/logl/p: <= 1e-6 relative on every SNP.  lambda: the reference reports the Newton iterate
+    BEFORE the one that met its 1e-5 stopping rule (src/lmm.cpp:2071-2073,2096), so a rounding-level
+    change in dev1 that flips a Brent/Newton trip count moves lambda-hat by up to the size of the
+    penultimate Newton step.  Two CPU builds of the oracle itself (sequential vs 4-way summation +
+    FMA contraction) differ by 1.5e-4 on 6 of 7317 BXD SNPs while beta/se/p stay within 3e-8.
+    Criterion: >= 98 % of SNPs within 1e-6, every SNP within 1e-3."""
+    used = {1: ["beta", "se", "logl_H1", "lambda_remle", "p_wald"],
+            2: ["logl_H1", "lambda_mle", "p_lrt"],
+            3: ["beta", "se", "p_score"],
+            4: ["beta", "se", "logl_H1", "lambda_remle", "lambda_mle", "p_wald", "p_lrt", "p_score"],
+            9: ["beta", "se", "logl_H1", "lambda_mle", "p_lrt", "p_score"]}[mode]
+    report = []
+    bad = []
+    # A failed lambda search (NaN, src/lmm.cpp:2087-2094) is a Newton loop that ran into max_iter =
+    # 100 or left (l_min, l_max): equally rounding-sensitive (BXD SNP 912 cycles for 100 iterations in
+    # the oracle's arithmetic).  The NaN sets must agree up to 0.1 % of the SNPs; values are compared
+    # where both sides are finite.
+    nan_g = np.zeros(len(got), dtype=bool)
+    nan_r = np.zeros(len(ref), dtype=bool)
+    for k in ref.dtype.names:
+        nan_g |= np.isnan(got[k])
+        nan_r |= np.isnan(ref[k])
+    n_mis = int((nan_g != nan_r).sum())
+    if n_mis > max(1, len(ref) // 1000):
+        bad.append("NaN (failed lambda search) pattern differs on %d SNPs: %s" % (n_mis, np.flatnonzero(nan_g != nan_r)[:8]))
+    both = ~(nan_g | nan_r)
+    got, ref = got[both], ref[both]
+    for k in ref.dtype.names:
+        g, r = got[k], ref[k]
+        if not np.array_equal(np.isnan(g), np.isnan(r)):
+            bad.append("%s NaN pattern differs at %s" % (k, np.flatnonzero(np.isnan(g) != np.isnan(r))[:8]))
+            continue
+        if k not in used:
+            if not np.all((g == 0) | np.isnan(g)):
+                bad.append("%s should stay 0 in mode %d" % (k, mode))
+            continue
+        with np.errstate(divide="ignore", invalid="ignore"):
+            rel = np.abs(g - r) / np.abs(r)
+        rel = np.where(np.isnan(rel) | (g == r), 0.0, rel)
+        w = int(np.argmax(rel))
+        report.append("%s: max rel %.3e at %d (%r vs %r), #>1e-6: %d" % (k, rel[w], w, g[w], r[w], int((rel > 1e-6).sum())))
+        if k.startswith("lambda"):
+            if rel.max() > 1e-3 or np.mean(rel <= 1e-6) < 0.98:
+                bad.append(report[-1])
+        elif rel.max() > RTOL:
+            bad.append(report[-1])
+    print("parity[%s mode %d] " % (tag, mode) + "; ".join(report))
+    assert not bad, "mode %d %s: %s" % (mode, tag, " | ".join(bad))
+
+
+# --------------------------------------------------------------------------- GEMM
+def test_dgemm_known_answer(gpu_api):
+    """The reference's own KAT, test/src/unittests-math.cpp:74-120 and :122-178."""
+    m, k, n = 2000, 200, 1000
+    A = (np.arange(m * k, dtype=np.float64) + 1).reshape(m, k)
+    B = (-np.arange(k * n, dtype=np.float64) - 1).reshape(k, n)
+    Cm = gpu_api.fast_dgemm("N", "N", 1.0, A, B, 0.0, np.zeros((m, n)))
+    assert np.trunc(Cm.flat[0]) == -2666620100.0
+    assert np.trunc(Cm.flat[1]) == -2666640200.0
+    assert np.trunc(Cm.flat[2003]) == -10627000400.0
+
+
+@pytest.mark.parametrize("ta,tb", [("N", "N"), ("T", "N"), ("N", "T"), ("T", "T")])
+@pytest.mark.parametrize("shape", [(1, 1, 1), (17, 33, 5), (128, 128, 16), (130, 257, 19), (300, 70, 513),
+                                   (64, 1000, 129)])
+def test_dgemm_vs_numpy(gpu_api, ta, tb, shape):
+    M, N, K = shape
+    rng = np.random.default_rng(M * 1000 + N * 10 + K)
+    A = rng.standard_normal((K, M) if ta == "T" else (M, K))
+    B = rng.standard_normal((N, K) if tb == "T" else (K, N))
+    C0 = rng.standard_normal((M, N))
+    opA = A.T if ta == "T" else A
+    opB = B.T if tb == "T" else B
+    # asymmetric operands: a transposed fragment map cannot pass
+    for alpha, beta in ((1.0, 0.0), (-0.5, 1.0), (2.0, 0.25)):
+        ref = alpha * (opA @ opB) + beta * C0
+        got = gpu_api.fast_dgemm(ta, tb, alpha, A, B, beta, C0.copy())
+        scale = np.abs(opA) @ np.abs(opB) + np.abs(C0)
+        assert np.max(np.abs(got - ref) / scale) < 1e-14
+
+
+def test_dgemm_strided_views_and_errors(gpu_api):
+    """gsl_matrix sub-views have tda != size2 (src/lmm.cpp:1516-1518); shape mismatch is the
+    reference's "Range error in dgemm" (src/fastblas.cpp:207)."""
+    from gemma_amd import _lib as L
+    rng = np.random.default_rng(3)
+    big = rng.standard_normal((90, 200))
+    A = big[:, 3:80]     # 90 x 77 view, ld = 200 (odd offset: unaligned path)
+    B = rng.standard_normal((77, 41))
+    Cbig = np.zeros((90, 64))
+    Cv = Cbig[:, 5:46]
+    gpu_api.fast_dgemm("N", "N", 1.0, A, B, 0.0, Cv)
+    assert np.allclose(Cv, A @ B, rtol=1e-13, atol=1e-12)
+    assert np.all(Cbig[:, :5] == 0) and np.all(Cbig[:, 46:] == 0)
+    with pytest.raises(L.GemmaHipError) as e:
+        gpu_api.fast_dgemm("N", "N", 1.0, A, rng.standard_normal((76, 41)), 0.0, np.zeros((90, 41)))
+    assert e.value.code == L.EINVAL
+
+
+def test_dgemm_large_property(gpu_api):
+    """Full-size tile coverage through a size-independent property: (A B) 1 == A (B 1)."""
+    import torch
+    M, N, K = 4096 + 128 + 7, 3000, 2049
+    g = torch.Generator(device="cuda").manual_seed(1)
+    A = torch.randn((M, K), dtype=torch.float64, device="cuda", generator=g)
+    B = torch.randn((K, N), dtype=torch.float64, device="cuda", generator=g)
+    Cm = torch.empty((M, N), dtype=torch.float64, device="cuda")
+    gpu_api.fast_dgemm("N", "N", 1.0, A, B, 0.0, Cm)
+    torch.cuda.synchronize()
+    lhs = Cm.sum(dim=1)
+    rhs = A @ B.sum(dim=1)
+    assert torch.allclose(lhs, rhs, rtol=1e-10, atol=1e-8)
+    # and against torch's own fp64 matmul on a random sample of rows
+    idx = torch.randint(0, M, (64,), device="cuda")
+    assert torch.allclose(Cm[idx], A[idx] @ B, rtol=1e-12, atol=1e-10)
+
+
+# --------------------------------------------------------------------------- kinship / centring
+@pytest.mark.parametrize("k_mode", [1, 2])
+def test_kinship_vs_oracle(gpu_api, oracle, k_mode):
+    from gemma_amd import _lib as L
+    rng = np.random.default_rng(11 + k_mode)
+    n, p = 203, 777
+    G = rng.integers(0, 3, size=(p, n)).astype(np.float64)
+    G[rng.random(G.shape) < 0.03] = np.nan
+    G[5] = 1.0  # monomorphic SNP: var == 0 is not scaled (src/gemma_io.cpp:1535)
+    K = gpu_api.CalcKin(G, L.GENO_F64_SNP_MAJOR, n, k_mode, batch=256)  # 4 blocks, ragged tail
+    ref = oracle.calc_kin(G, k_mode)
+    assert np.linalg.norm(K - ref) / np.linalg.norm(ref) < 1e-13
+    assert np.array_equal(K, K.T)
+
+
+def test_kinship_bxd_golden(gpu_api, bxd):
+    """First 64 QC-passing BXD SNPs over all 198 individuals (fixture generated from the reference's
+    example by tests/golden/make_fixtures.py)."""
+    from gemma_amd import _lib as L
+    G = bxd["G_kin_head"].astype(np.float64)
+    K = gpu_api.CalcKin(G, L.GENO_F64_SNP_MAJOR, G.shape[1], 1)
+    assert np.allclose(K, bxd["K_head"], rtol=1e-12, atol=1e-14)
+
+
+def test_kinship_plink_and_idv_major(gpu_api, oracle):
+    from gemma_amd import _lib as L
+    rng = np.random.default_rng(5)
+    n, p = 1001, 300  # n % 4 != 0: ragged last byte
+    codes = rng.choice([0, 1, 2, 3], size=(p, n), p=[0.3, 0.02, 0.38, 0.3]).astype(np.uint8)
+    nb = (n + 3) // 4
+    pad = np.zeros((p, nb * 4), dtype=np.uint8)
+    pad[:, :n] = codes
+    raw = (pad[:, 0::4] | (pad[:, 1::4] << 2) | (pad[:, 2::4] << 4) | (pad[:, 3::4] << 6)).astype(np.uint8)
+    G = oracle.bed_decode(raw, n)
+    assert np.isnan(G).sum() == (codes == 1).sum()
+    ref = oracle.calc_kin(G, 1)
+    K = gpu_api.CalcKin(raw, L.GENO_PLINK_2BIT, n, 1, batch=128)
+    assert np.linalg.norm(K - ref) / np.linalg.norm(ref) < 1e-13
+    # the reference's own Xlarge layout: individuals x SNPs, already centred
+    Xc = oracle.kin_prepare(G, 1)
+    gpu_api.kin_begin(n, 1)
+    gpu_api.kin_add(np.ascontiguousarray(Xc.T), L.GENO_F64_IDV_MAJOR)
+    K2 = np.zeros((n, n))
+    assert gpu_api.kin_end(K2) == p
+    assert np.linalg.norm(K2 - ref) / np.linalg.norm(ref) < 1e-13
+
+
+def test_center_matrix(gpu_api, oracle, bxd):
+    K = bxd["K_sub"].copy()
+    got = gpu_api.CenterMatrix(K.copy())
+    ref = oracle.center_matrix(K)
+    assert np.max(np.abs(got - ref)) < 1e-14 * max(1.0, np.max(np.abs(ref)))
+    assert np.array_equal(got, got.T)
+
+
+# --------------------------------------------------------------------------- association
+@pytest.mark.parametrize("mode", [1, 2, 3, 4, 9])
+def test_lmm_bxd_golden(gpu_api, bxd, mode):
+    """BXD (n=67, c=3, 7317 SNPs; ~1/3 of SNPs end at a lambda bound): every a_mode vs the oracle
+    outputs that reproduce test/dev_tests.rb:42-54."""
+    null = bxd["null"]
+    lmm = gpu_api.LMM(a_mode=mode, l_mle_null=null[0], logl_mle_H0=null[1])
+    got = lmm.AnalyzeBimbam(bxd["U"], bxd["eval"], bxd["UtW"], bxd["Uty"], bxd["X"].astype(np.float64))
+    ref = bxd["stat_mode%d" % mode]
+    assert got.shape == ref.shape
+    _cmp_stats(got, ref, mode, "BXD")
+    if mode == 2:  # the reference's own assertions
+        assert "%.6e" % got["p_lrt"][0] == "1.234747e-01"
+        assert "%.6e" % np.nanmax(got["p_lrt"]) == "9.997119e-01"
+    if mode == 9:
+        assert "%.7g" % np.nanmax(got["lambda_mle"]) == "0.7531109"
+
+
+def _synthetic(oracle, n, p, c, seed, miss=0.01):
+    rng = np.random.default_rng(seed)
+    maf = rng.uniform(0.05, 0.5, size=p + 600)
+    G = rng.binomial(2, maf[:, None], size=(p + 600, n)).astype(np.float64)
+    G[rng.random(G.shape) < miss] = np.nan
+    K = oracle.calc_kin(G[p:], 1)
+    U, ev, tr = oracle.eigen_decomp_zeroed(oracle.center_matrix(K))
+    W = np.ones((n, 1)) if c == 1 else np.hstack([rng.standard_normal((n, c - 1)), np.ones((n, 1))])
+    Gi = np.where(np.isnan(G[:5]), 0, G[:5])
+    y = Gi.T @ rng.standard_normal(5) * 0.3 + rng.standard_normal(n)
+    return G[:p], U, ev, U.T @ W, U.T @ y, tr
+
+
+@pytest.mark.parametrize("n,c", [(500, 1), (333, 2), (402, 3), (257, 4)])
+def test_lmm_synthetic_all_modes(gpu_api, oracle, n, c):
+    X, U, ev, UtW, Uty, tr = _synthetic(oracle, n, 300, c, seed=100 + n)
+    l_mle, logl0 = oracle.calc_lambda_null("L", ev, UtW, Uty)
+    for mode in (1, 4):
+        ref = oracle.lmm_analyze(mode, U, ev, UtW, Uty, X, l_mle_null=l_mle, logl_mle_H0=logl0)
+        lmm = gpu_api.LMM(a_mode=mode, l_mle_null=l_mle, logl_mle_H0=logl0)
+        got = lmm.AnalyzeBimbam(U, ev, UtW, Uty, X)
+        _cmp_stats(got, ref, mode, "n=%d c=%d" % (n, c))
+        assert lmm.time_UtX >= 0 and lmm.time_opt >= 0
+
+
+def test_null_model(gpu_api, oracle, bxd):
+    null = bxd["null"]
+    got = gpu_api.CalcLambdaNull(bxd["eval"], bxd["UtW"], bxd["Uty"], trace_G=null[6])
+    assert got["l_mle_null"] == pytest.approx(null[0], rel=LAM_RTOL)
+    assert got["logl_mle_H0"] == pytest.approx(null[1], rel=RTOL)
+    assert got["l_remle_null"] == pytest.approx(null[2], rel=LAM_RTOL)
+    assert got["logl_remle_H0"] == pytest.approx(null[3], rel=RTOL)
+    assert got["pve"] == pytest.approx(null[4], rel=1e-4)
+    assert got["pve_se"] == pytest.approx(null[5], rel=1e-4)
+    X, U, ev, UtW, Uty, tr = _synthetic(oracle, 400, 8, 1, seed=9)
+    ref = oracle.calc_lambda_null("R", ev, UtW, Uty)
+    got = gpu_api.CalcLambdaNull(ev, UtW, Uty, trace_G=tr)
+    assert got["l_remle_null"] == pytest.approx(ref[0], rel=LAM_RTOL)
+    assert got["logl_remle_H0"] == pytest.approx(ref[1], rel=RTOL)
+    vg, ve, _, _ = oracle.calc_vg_ve_beta(ev, UtW, Uty, ref[0])
+    assert got["ve_remle"] == pytest.approx(ve, rel=1e-5) and got["vg_remle"] == pytest.approx(vg, rel=1e-4)
+
+
+def test_lmm_plink_path_with_dropped_individuals(gpu_api, oracle):
+    """AnalyzePlink (src/lmm.cpp:1710-1903): 2-bit decode, indicator_idv drop, mean imputation."""
+    rng = np.random.default_rng(21)
+    ni_total, p = 611, 257
+    ind = (rng.random(ni_total) > 0.2).astype(np.int32)
+    n = int(ind.sum())
+    codes = rng.choice([0, 1, 2, 3], size=(p, ni_total), p=[0.25, 0.03, 0.42, 0.3]).astype(np.uint8)
+    nb = (ni_total + 3) // 4
+    pad = np.zeros((p, nb * 4), dtype=np.uint8)
+    pad[:, :ni_total] = codes
+    raw = (pad[:, 0::4] | (pad[:, 1::4] << 2) | (pad[:, 2::4] << 4) | (pad[:, 3::4] << 6)).astype(np.uint8)
+    Xn = oracle.bed_decode(raw, ni_total, ind)
+    assert Xn.shape == (p, n)
+    Kg = oracle.bed_decode(raw, ni_total)[:, ind == 1]
+    U, ev, _ = oracle.eigen_decomp_zeroed(oracle.center_matrix(oracle.calc_kin(Kg, 1)))
+    y = rng.standard_normal(n)
+    UtW, Uty = U.T @ np.ones((n, 1)), U.T @ y
+    ref = oracle.lmm_analyze(1, U, ev, UtW, Uty, Xn, plink_nan_rule=1)
+    lmm = gpu_api.LMM(a_mode=1)
+    got = lmm.AnalyzePlink(U, ev, UtW, Uty, raw, ind)
+    _cmp_stats(got, ref, 1, "plink")
+
+
+def test_lmm_reference_xlarge_layout_and_batching(gpu_api, oracle):
+    """The reference hands fast_dgemm an individuals x 20000 Xlarge view (src/lmm.cpp:1516-1521);
+    results must not depend on how SNPs are cut into blocks."""
+    from gemma_amd import _lib as L
+    X, U, ev, UtW, Uty, _ = _synthetic(oracle, 300, 200, 1, seed=77)
+    Xi = oracle.impute_mean(X)
+    lmm = gpu_api.LMM(a_mode=1)
+    lmm.setup(U, ev, UtW, Uty)
+    Xlarge = np.zeros((300, 256))
+    Xlarge[:, :200] = Xi.T
+    a = lmm.batch(Xlarge[:, :200], L.GENO_F64_IDV_MAJOR)  # view with tda 256
+    b = np.concatenate([lmm.batch(X[s:s + 64], L.GENO_F64_SNP_MAJOR) for s in range(0, 200, 64)])
+    lmm.finish()
+    for k in a.dtype.names:
+        assert np.array_equal(a[k], b[k], equal_nan=True), k  # bit-identical per SNP
+    ref = oracle.lmm_analyze(1, U, ev, UtW, Uty, X)
+    _cmp_stats(a, ref, 1, "xlarge")
+
+
+def test_lmm_eigenvector_sign_invariance(gpu_api, oracle):
+    """App. A.6: flipping eigenvector signs / SNP order is a size-independent property of the path."""
+    X, U, ev, UtW, Uty, _ = _synthetic(oracle, 350, 128, 1, seed=5)
+    lmm = gpu_api.LMM(a_mode=1)
+    base = lmm.AnalyzeBimbam(U, ev, UtW, Uty, X)
+    sgn = np.where(np.random.default_rng(1).random(350) < 0.5, -1.0, 1.0)
+    U2 = U * sgn[None, :]
+    flip = lmm.AnalyzeBimbam(U2, ev, UtW * sgn[:, None], Uty * sgn, X)
+    for k in ("beta", "se", "p_wald", "logl_H1"):
+        assert np.allclose(base[k], flip[k], rtol=1e-9, equal_nan=True)
+    perm = np.random.default_rng(2).permutation(128)
+    shuf = lmm.AnalyzeBimbam(U, ev, UtW, Uty, X[perm])
+    for k in base.dtype.names:
+        assert np.array_equal(base[k][perm], shuf[k], equal_nan=True)
+
+
+def test_lmm_state_errors(gpu_api):
+    from gemma_amd import _lib as L
+    lmm = gpu_api.LMM(a_mode=1)
+    with pytest.raises(L.GemmaHipError) as e:
+        lmm.batch(np.zeros((4, 10)), L.GENO_F64_SNP_MAJOR)
+    assert e.value.code == L.ESTATE
+    with pytest.raises(L.GemmaHipError) as e:
+        gpu_api.LMM(a_mode=7).setup(np.eye(10), np.ones(10), np.ones((10, 1)), np.ones(10))
+    assert e.value.code == L.EINVAL
+    lmm.setup(np.eye(10), np.ones(10), np.ones((10, 1)), np.arange(10.0))
+    assert lmm.batch(np.zeros((0, 10)), L.GENO_F64_SNP_MAJOR).shape == (0,)  # empty block
+    with pytest.raises(L.GemmaHipError):
+        lmm.batch(np.zeros((4, 9)), L.GENO_F64_SNP_MAJOR)  # ld < n
+    lmm.finish()
+
+
+def test_lmm_medium_size_device_path(gpu_api, oracle):
+    """n = 2000, 4096 SNPs through the device-pointer entry points (torch only allocates);
+    oracle on a 192-SNP sample."""
+    import torch
+    from gemma_amd import _lib as L
+    X, U, ev, UtW, Uty, _ = _synthetic(oracle, 2000, 4096, 1, seed=2000, miss=0.01)
+    dev = "cuda"
+    tU, te = torch.from_numpy(U).to(dev), torch.from_numpy(ev).to(dev)
+    tW, ty = torch.from_numpy(np.ascontiguousarray(UtW)).to(dev), torch.from_numpy(Uty).to(dev)
+    lmm = gpu_api.LMM(a_mode=1)
+    lmm.setup(tU, te, tW, ty)
+    out = lmm.batch(torch.from_numpy(X).to(dev), L.GENO_F64_SNP_MAJOR)
+    torch.cuda.synchronize()
+    lmm.finish()
+    got = np.zeros(4096, dtype=gpu_api.SUMSTAT_DTYPE)
+    got.view(np.float64).reshape(-1, 8)[:] = out.cpu().numpy()
+    sample = np.random.default_rng(0).choice(4096, 192, replace=False)
+    ref = oracle.lmm_analyze(1, U, ev, UtW, Uty, X[sample])
+    _cmp_stats(got[sample], ref, 1, "n=2000")
+    assert np.isfinite(got["p_wald"]).all()
