@@ -1,0 +1,302 @@
+// gemma_host.hpp -- C++ host-side mirror of the GEMMA interfaces on the kinship + univariate-LMM
+// path, implemented over the C ABI of include/gemma_hip.h (header-only, C++11, no GSL needed).
+//
+// Same names, argument order and error behaviour as the reference so that a GEMMA source file can
+// switch with a namespace alias; each function cites what it mirrors (file:line in the GEMMA tree).
+// `Matrix` / `Vector` are layout-compatible views of gsl_matrix / gsl_vector data: row-major with
+// leading dimension tda, vector stride in elements.
+//
+// Errors: GEMMA prints a message and raises SIGINT through fail_msg / enforce_msg (src/debug.h:113-164) or
+// sets cPar.error and returns false.  Here void functions throw gemma_amd::HipError (code + text) and the
+// bool readers return false after printing the message, exactly where the reference returns false.
+#ifndef GEMMA_HOST_HPP
+#define GEMMA_HOST_HPP
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <iomanip>
+#include <iostream>
+#include <limits>
+#include <sstream>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "gemma_hip.h"
+
+namespace gemma_amd {
+
+constexpr size_t LMM_BATCH_SIZE = 20000; // src/lmm.h:33
+constexpr size_t K_BATCH_SIZE = 20000;   // src/param.h:32
+
+struct HipError : std::runtime_error {
+  int code;
+  HipError(int c, const std::string &where)
+      : std::runtime_error(where + ": " + gemma_hip_strerror(c) + " -- " + gemma_hip_last_error()), code(c) {}
+};
+inline void enforce_hip(int rc, const char *where) {
+  if (rc != GEMMA_HIP_OK) throw HipError(rc, where);
+}
+
+struct Matrix { // gsl_matrix view
+  size_t size1, size2, tda;
+  double *data;
+};
+struct Vector { // gsl_vector view
+  size_t size, stride;
+  double *data;
+};
+inline Matrix matrix_view(double *p, size_t r, size_t c) { return Matrix{r, c, c, p}; }
+inline Vector vector_view(double *p, size_t n) { return Vector{n, 1, p}; }
+
+// class SUMSTAT, src/param.h:54-66
+struct SUMSTAT {
+  double beta, se, lambda_remle, lambda_mle, p_wald, p_lrt, p_score, logl_H1;
+};
+// class SNPINFO, src/param.h:38-52 (fields WriteFiles prints)
+struct SNPINFO {
+  std::string chr, rs_number;
+  double cM;
+  long int base_position;
+  std::string a_minor, a_major;
+  size_t n_miss;
+  double missingness, maf;
+  size_t n_idv, n_nb, file_position;
+};
+
+// fast_dgemm, src/fastblas.cpp:216-230: C = alpha*op(A)*op(B) + beta*C; "Range error in dgemm" on mismatch
+inline void fast_dgemm(const char *TransA, const char *TransB, const double alpha, const Matrix *A,
+                       const Matrix *B, const double beta, Matrix *C) {
+  const bool tA = (*TransA == 'T' || *TransA == 't'), tB = (*TransB == 'T' || *TransB == 't');
+  const size_t M = C->size1, N = C->size2;
+  const size_t K = tA ? A->size1 : A->size2;
+  const size_t Ma = tA ? A->size2 : A->size1, Kb = tB ? B->size2 : B->size1, Nb = tB ? B->size1 : B->size2;
+  if (Ma != M || Nb != N || Kb != K) throw HipError(GEMMA_HIP_EINVAL, "Range error in dgemm");
+  enforce_hip(gemma_hip_dgemm(*TransA, *TransB, M, N, K, alpha, A->data, A->tda, B->data, B->tda, beta, C->data,
+                              C->tda),
+              "fast_dgemm");
+}
+inline void fast_eigen_dgemm(const char *TransA, const char *TransB, const double alpha, const Matrix *A,
+                             const Matrix *B, const double beta, Matrix *C) {
+  fast_dgemm(TransA, TransB, alpha, A, B, beta, C); // src/fastblas.cpp:232-236
+}
+
+// CenterMatrix, src/mathfunc.cpp:147-177
+inline void CenterMatrix(Matrix *G) {
+  if (G->tda != G->size2 || G->size1 != G->size2) throw HipError(GEMMA_HIP_EINVAL, "CenterMatrix: contiguous square G");
+  enforce_hip(gemma_hip_center(G->data, G->size1), "CenterMatrix");
+}
+
+// EigenDecomp_Zeroed, src/lapack.cpp:260-291: G destroyed, returns trace_G = mean(eval)
+inline double EigenDecomp_Zeroed(Matrix *G, Matrix *U, Vector *eval, const size_t /*flag_largematrix*/) {
+  if (G->tda != G->size2 || U->tda != U->size2 || eval->stride != 1 || G->size1 != G->size2 ||
+      U->size1 != G->size1 || eval->size != G->size1)
+    throw HipError(GEMMA_HIP_EINVAL, "EigenDecomp_Zeroed: shapes");
+  double trace = 0.0;
+  enforce_hip(gemma_hip_eigh(G->data, G->size1, U->data, eval->data, &trace), "EigenDecomp_Zeroed");
+  return trace;
+}
+
+// CalcUtX(U, X, UtX), src/mathfunc.cpp:504-506
+inline void CalcUtX(const Matrix *U, const Matrix *X, Matrix *UtX) { fast_dgemm("T", "N", 1.0, U, X, 0.0, UtX); }
+
+// PlinkKin, src/gemma_io.cpp:1599-1738: the device decodes, imputes, centres/scales and accumulates
+inline bool PlinkKin(const std::string &file_bed, std::vector<int> &indicator_snp, const int k_mode,
+                     const int /*display_pace*/, Matrix *matrix_kin) {
+  std::ifstream infile(file_bed.c_str(), std::ios::binary);
+  if (!infile) {
+    std::cout << "error reading bed file:" << file_bed << std::endl;
+    return false;
+  }
+  const size_t ni_total = matrix_kin->size1;
+  const size_t n_bit = (ni_total + 3) / 4;
+  if (matrix_kin->tda != matrix_kin->size2) return false;
+  enforce_hip(gemma_hip_kin_begin(ni_total, k_mode), "PlinkKin");
+  std::vector<unsigned char> block(K_BATCH_SIZE * n_bit);
+  size_t l = 0;
+  for (size_t t = 0; t < indicator_snp.size(); ++t) {
+    if (indicator_snp[t] == 0) continue;
+    infile.seekg((std::streamoff)(t * n_bit + 3)); // 3 magic bytes, skipped unchecked like the reference
+    infile.read(reinterpret_cast<char *>(&block[l * n_bit]), (std::streamsize)n_bit);
+    if (++l == K_BATCH_SIZE) {
+      enforce_hip(gemma_hip_kin_add(GEMMA_GENO_PLINK_2BIT, block.data(), l, n_bit), "PlinkKin");
+      l = 0;
+    }
+  }
+  if (l) enforce_hip(gemma_hip_kin_add(GEMMA_GENO_PLINK_2BIT, block.data(), l, n_bit), "PlinkKin");
+  size_t ns = 0;
+  enforce_hip(gemma_hip_kin_end(matrix_kin->data, &ns), "PlinkKin");
+  return true;
+}
+
+// BimbamKin, src/gemma_io.cpp:1418-1597 (plain-text mean genotype file; "NA" = missing)
+inline bool BimbamKin(const std::string file_geno, std::vector<int> &indicator_snp, const int k_mode,
+                      const int /*display_pace*/, Matrix *matrix_kin) {
+  std::ifstream infile(file_geno.c_str());
+  if (!infile) {
+    std::cout << "error reading genotype file:" << file_geno << std::endl;
+    return false;
+  }
+  const size_t ni_total = matrix_kin->size1;
+  enforce_hip(gemma_hip_kin_begin(ni_total, k_mode), "BimbamKin");
+  const size_t bsz = 2048;
+  std::vector<double> block(bsz * ni_total);
+  size_t l = 0;
+  std::string line;
+  for (size_t t = 0; t < indicator_snp.size(); ++t) {
+    if (!std::getline(infile, line)) break;
+    if (indicator_snp[t] == 0) continue;
+    char *save = nullptr;
+    char *tok = strtok_r(&line[0], " ,\t", &save); // rs
+    tok = strtok_r(nullptr, " ,\t", &save);          // allele
+    tok = strtok_r(nullptr, " ,\t", &save);          // allele
+    for (size_t i = 0; i < ni_total; ++i) {
+      tok = strtok_r(nullptr, " ,\t", &save);
+      if (!tok) return false;
+      block[l * ni_total + i] = (strncmp(tok, "NA", 2) == 0) ? std::numeric_limits<double>::quiet_NaN() : atof(tok);
+    }
+    if (++l == bsz) {
+      enforce_hip(gemma_hip_kin_add(GEMMA_GENO_F64_SNP_MAJOR, block.data(), l, ni_total), "BimbamKin");
+      l = 0;
+    }
+  }
+  if (l) enforce_hip(gemma_hip_kin_add(GEMMA_GENO_F64_SNP_MAJOR, block.data(), l, ni_total), "BimbamKin");
+  size_t ns = 0;
+  enforce_hip(gemma_hip_kin_end(matrix_kin->data, &ns), "BimbamKin");
+  return true;
+}
+
+// null model: CalcLambda(func, eval, UtW, Uty, ...) src/lmm.cpp:2143-2180 + CalcPve :2183-2205
+struct NullModel {
+  double l_mle_null, logl_mle_H0, l_remle_null, logl_remle_H0, pve_null, pve_se_null, vg_remle_null, ve_remle_null;
+};
+inline NullModel CalcLambdaNull(const Vector *eval, const Matrix *UtW, const Vector *Uty, double l_min, double l_max,
+                                size_t n_region, double trace_G) {
+  if (UtW->tda != UtW->size2 || eval->stride != 1 || Uty->stride != 1)
+    throw HipError(GEMMA_HIP_EINVAL, "CalcLambdaNull: contiguous inputs");
+  double o[8];
+  enforce_hip(gemma_hip_lmm_null(UtW->size1, UtW->size2, eval->data, UtW->data, Uty->data, l_min, l_max, n_region,
+                                 trace_G, o),
+              "CalcLambda (null)");
+  return NullModel{o[0], o[1], o[2], o[3], o[4], o[5], o[6], o[7]};
+}
+
+// class LMM, src/lmm.h:49-125 -- the members CopyFromParam fills (src/lmm.cpp:56-90) and the drivers
+class LMM {
+public:
+  int a_mode = 1;
+  size_t d_pace = 100000;
+  std::string file_bfile, file_geno, file_out, path_out = "./output/";
+  double l_min = 1e-5, l_max = 1e5;
+  size_t n_region = 10;
+  double l_mle_null = 0.0, logl_mle_H0 = 0.0;
+  size_t ni_total = 0, ni_test = 0, n_cvt = 1;
+  double time_UtX = 0.0, time_opt = 0.0;
+  std::vector<int> indicator_idv, indicator_snp;
+  std::vector<SNPINFO> snpInfo;
+  std::vector<SUMSTAT> sumStat;
+
+  // AnalyzePlink, src/lmm.cpp:1710-1903: raw .bed rows go to the device (decode, drop, impute there)
+  void AnalyzePlink(const Matrix *U, const Vector *eval, const Matrix *UtW, const Vector *Uty) {
+    const std::string file_bed = file_bfile + ".bed";
+    std::ifstream infile(file_bed.c_str(), std::ios::binary);
+    if (!infile) throw std::runtime_error("error reading genotype (.bed) file");
+    setup(U, eval, UtW, Uty, 1);
+    enforce_hip(gemma_hip_lmm_set_indicator(indicator_idv.data(), indicator_idv.size()), "AnalyzePlink");
+    const size_t n_bit = (ni_total + 3) / 4;
+    std::vector<unsigned char> block(LMM_BATCH_SIZE * n_bit);
+    std::vector<gemma_sumstat> out(LMM_BATCH_SIZE);
+    size_t l = 0;
+    for (size_t t = 0; t < indicator_snp.size(); ++t) {
+      if (indicator_snp[t] == 0) continue;
+      infile.seekg((std::streamoff)(t * n_bit + 3));
+      infile.read(reinterpret_cast<char *>(&block[l * n_bit]), (std::streamsize)n_bit);
+      if (++l == LMM_BATCH_SIZE) {
+        batch_compute(GEMMA_GENO_PLINK_2BIT, block.data(), l, n_bit, out);
+        l = 0;
+      }
+    }
+    batch_compute(GEMMA_GENO_PLINK_2BIT, block.data(), l, n_bit, out);
+    finish();
+  }
+
+  // LMM::Analyze with a caller-supplied SNP-major block source (the fetch_snp closure of src/lmm.cpp:1675-1700
+  // factored out): X rows = analysed SNPs over the ni_test analysed individuals, NaN = missing
+  void AnalyzeRows(const Matrix *U, const Vector *eval, const Matrix *UtW, const Vector *Uty, const double *X,
+                   size_t n_snps, size_t ld) {
+    setup(U, eval, UtW, Uty, 0);
+    std::vector<gemma_sumstat> out(LMM_BATCH_SIZE);
+    for (size_t s0 = 0; s0 < n_snps; s0 += LMM_BATCH_SIZE) {
+      const size_t l = std::min(LMM_BATCH_SIZE, n_snps - s0);
+      batch_compute(GEMMA_GENO_F64_SNP_MAJOR, X + s0 * ld, l, ld, out);
+    }
+    finish();
+  }
+
+  // WriteFiles, src/lmm.cpp:101-225
+  void WriteFiles() {
+    const std::string file_str = path_out + "/" + file_out + ".assoc.txt";
+    std::ofstream outfile(file_str.c_str(), std::ofstream::out);
+    if (!outfile) {
+      std::cout << "error writing file: " << file_str << std::endl;
+      return;
+    }
+    outfile << "chr\trs\tps\tn_miss\tallele1\tallele0\taf\t";
+    switch (a_mode) {
+    case 1: outfile << "beta\tse\tlogl_H1\tl_remle\tp_wald" << std::endl; break;
+    case 2: outfile << "logl_H1\tl_mle\tp_lrt" << std::endl; break;
+    case 3: outfile << "beta\tse\tp_score" << std::endl; break;
+    case 4: outfile << "beta\tse\tlogl_H1\tl_remle\tl_mle\tp_wald\tp_lrt\tp_score" << std::endl; break;
+    case 9: outfile << "beta\tse\tl_mle\tp_lrt" << std::endl; break;
+    }
+    size_t t = 0;
+    for (size_t i = 0; i < snpInfo.size(); ++i) {
+      if (indicator_snp[i] == 0) continue;
+      const SNPINFO &s = snpInfo[i];
+      const SUMSTAT &st = sumStat[t];
+      outfile << s.chr << "\t" << s.rs_number << "\t" << s.base_position << "\t" << s.n_miss << "\t" << s.a_minor
+              << "\t" << s.a_major << "\t" << std::fixed << std::setprecision(3) << s.maf << "\t";
+      outfile << std::scientific << std::setprecision(6);
+      switch (a_mode) {
+      case 1: outfile << st.beta << "\t" << st.se << "\t" << st.logl_H1 << "\t" << st.lambda_remle << "\t" << st.p_wald << std::endl; break;
+      case 2: outfile << st.logl_H1 << "\t" << st.lambda_mle << "\t" << st.p_lrt << std::endl; break;
+      case 3: outfile << st.beta << "\t" << st.se << "\t" << st.p_score << std::endl; break;
+      case 4:
+        outfile << st.beta << "\t" << st.se << "\t" << st.logl_H1 << "\t" << st.lambda_remle << "\t" << st.lambda_mle
+                << "\t" << st.p_wald << "\t" << st.p_lrt << "\t" << st.p_score << std::endl;
+        break;
+      case 9: outfile << st.beta << "\t" << st.se << "\t" << st.lambda_mle << "\t" << st.p_lrt << std::endl; break;
+      }
+      t++;
+    }
+  }
+
+private:
+  void setup(const Matrix *U, const Vector *eval, const Matrix *UtW, const Vector *Uty, int plink) {
+    if (U->tda != U->size2 || UtW->tda != UtW->size2 || eval->stride != 1 || Uty->stride != 1)
+      throw HipError(GEMMA_HIP_EINVAL, "LMM: contiguous U/UtW/eval/Uty required");
+    ni_test = U->size1;
+    n_cvt = UtW->size2;
+    gemma_lmm_cfg cfg;
+    cfg.a_mode = a_mode; cfg.n = ni_test; cfg.n_cvt = n_cvt; cfg.l_min = l_min; cfg.l_max = l_max;
+    cfg.n_region = n_region; cfg.l_mle_null = l_mle_null; cfg.logl_mle_H0 = logl_mle_H0; cfg.plink_nan_rule = plink;
+    enforce_hip(gemma_hip_lmm_setup(&cfg, U->data, eval->data, UtW->data, Uty->data), "LMM::Analyze");
+    sumStat.clear();
+  }
+  // batch_compute, src/lmm.cpp:1513-1564
+  void batch_compute(int kind, const void *geno, size_t l, size_t ld, std::vector<gemma_sumstat> &out) {
+    if (l == 0) return;
+    enforce_hip(gemma_hip_lmm_batch(kind, geno, l, ld, out.data()), "batch_compute");
+    for (size_t i = 0; i < l; ++i) {
+      SUMSTAT s = {out[i].beta, out[i].se, out[i].lambda_remle, out[i].lambda_mle,
+                   out[i].p_wald, out[i].p_lrt, out[i].p_score, out[i].logl_H1};
+      sumStat.push_back(s);
+    }
+  }
+  void finish() { enforce_hip(gemma_hip_lmm_finish(&time_UtX, &time_opt), "LMM::Analyze"); }
+};
+
+} // namespace gemma_amd
+#endif
