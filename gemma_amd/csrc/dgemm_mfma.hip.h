@@ -26,6 +26,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 namespace gemma_hip {
 
@@ -45,9 +46,12 @@ struct GemmArgs {
   long M, N, K;
   long lda, ldb, ldc;
   double alpha, beta;
-  int tiles_m, tiles_n;
-  int syrk_upper;  // 1: launch only tiles with tn >= tm
+  int tiles_m, tiles_n; // extent of the launched tile sub-grid
+  int tm0, tn0;         // its origin in the full tile grid
+  int syrk_upper;  // 1: launch only tiles with tn >= tm (sub-grid must start at (0,0))
   int square_a;    // 1: use A*A elementwise as the A operand (grid-lambda x^2 sums)
+  int ablate;      // timing experiments only (GEMMA_HIP_GEMM_ABLATE): 1 = no global loads / LDS stores after
+                   // the first K-tile, 2 = no barrier, 4 = fragments read once (results are then wrong)
 };
 
 // 16-byte global load of two consecutive doubles with element-wise bounds; `vec_ok` says the
@@ -65,15 +69,31 @@ __device__ __forceinline__ f64x2 ld2(const double *p, bool ok0, bool ok1, bool v
 
 // Operand tile loader.  KM = true: operand stored [k][m] (m contiguous, leading dim ld);
 // KM = false: stored [m][k] (k contiguous).  Loads the BK x 128 tile at (k0, m0) into 4 f64x2.
-template <bool KM>
+template <bool KM, int NT>
 __device__ __forceinline__ void load_tile(const double *__restrict__ P, long ld, long m0, long k0,
-                                          long Mdim, long Kdim, bool aligned, int t, f64x2 r[4]) {
+                                          long Mdim, long Kdim, bool aligned, int t, f64x2 *r,
+                                          bool full) {
+  constexpr int NLD = 1024 / NT;  // 16-byte loads per thread per operand tile
+  constexpr int KSTEP = NT / 64;  // [k][m] image: k rows covered per pass
+  constexpr int MSTEP = NT / 8;   // [m][k] image: m rows covered per pass
+  if (full) { // interior tile, aligned operand: no predicates at all (block-uniform branch)
+    if (KM) {
+      const double *p = P + (k0 + (t >> 6)) * ld + m0 + 2 * (t & 63);
+#pragma unroll
+      for (int j = 0; j < NLD; ++j) r[j] = *reinterpret_cast<const f64x2 *>(p + (long)(KSTEP * j) * ld);
+    } else {
+      const double *p = P + (m0 + (t >> 3)) * ld + k0 + 2 * (t & 7);
+#pragma unroll
+      for (int j = 0; j < NLD; ++j) r[j] = *reinterpret_cast<const f64x2 *>(p + (long)(MSTEP * j) * ld);
+    }
+    return;
+  }
   if (KM) {
     const int mm = 2 * (t & 63);
     const int kb = t >> 6;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const long k = k0 + kb + 4 * j;
+    for (int j = 0; j < NLD; ++j) {
+      const long k = k0 + kb + KSTEP * j;
       const long m = m0 + mm;
       const bool kin = k < Kdim;
       const bool ok0 = kin && (m < Mdim), ok1 = kin && (m + 1 < Mdim);
@@ -87,8 +107,8 @@ __device__ __forceinline__ void load_tile(const double *__restrict__ P, long ld,
     const int kk = 2 * (t & 7);
     const int mb = t >> 3;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const long m = m0 + mb + 32 * j;
+    for (int j = 0; j < NLD; ++j) {
+      const long m = m0 + mb + MSTEP * j;
       const long k = k0 + kk;
       const bool min_ = m < Mdim;
       const bool ok0 = min_ && (k < Kdim), ok1 = min_ && (k + 1 < Kdim);
@@ -101,20 +121,21 @@ __device__ __forceinline__ void load_tile(const double *__restrict__ P, long ld,
   }
 }
 
-template <bool KM>
-__device__ __forceinline__ void store_tile(double *__restrict__ S, int t, const f64x2 r[4]) {
+template <bool KM, int NT>
+__device__ __forceinline__ void store_tile(double *__restrict__ S, int t, const f64x2 *r) {
+  constexpr int NLD = 1024 / NT;
   if (KM) {
     const int mm = 2 * (t & 63);
     const int kb = t >> 6;
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
-      *reinterpret_cast<f64x2 *>(S + (kb + 4 * j) * GEMM_LD_KM + mm) = r[j];
+    for (int j = 0; j < NLD; ++j)
+      *reinterpret_cast<f64x2 *>(S + (kb + (NT / 64) * j) * GEMM_LD_KM + mm) = r[j];
   } else {
     const int kk = 2 * (t & 7);
     const int mb = t >> 3;
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
-      *reinterpret_cast<f64x2 *>(S + (mb + 32 * j) * GEMM_LD_MK + kk) = r[j];
+    for (int j = 0; j < NLD; ++j)
+      *reinterpret_cast<f64x2 *>(S + (mb + (NT / 8) * j) * GEMM_LD_MK + kk) = r[j];
   }
 }
 
@@ -152,10 +173,19 @@ __device__ __forceinline__ void tile_of_block(const GemmArgs &g, int &tm, int &t
     tm = first_m + in % gsz;
     tn = in / gsz;
   }
+  tm += g.tm0;
+  tn += g.tn0;
 }
 
-template <bool A_KM, bool B_KN>
-__global__ __launch_bounds__(GEMM_THREADS, 2) void dgemm_mfma_kernel(GemmArgs g) {
+// FULL = true: every launched tile is a complete 128x128 tile of 16-byte aligned operands and K is a
+// multiple of 16 -- no predicate anywhere (the hot instantiation).  FULL = false: ragged tiles / K tail /
+// unaligned views, element-wise bounds on every access.
+template <bool A_KM, bool B_KN, int NW, bool FULL>
+__global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : 2)) void dgemm_mfma_kernel(GemmArgs g) {
+  constexpr int NT = NW * 64;
+  constexpr int NLD = 1024 / NT;
+  constexpr int WN = NW / 2;        // waves along N (2 along M)
+  constexpr int TN = 4 / (WN / 2);  // 16-wide MFMA blocks per wave along N: 4 (64 cols) or 2 (32 cols)
   __shared__ __attribute__((aligned(16))) double lds[4 * GEMM_TILE_DOUBLES];
   double *As0 = lds, *As1 = lds + GEMM_TILE_DOUBLES;
   double *Bs0 = lds + 2 * GEMM_TILE_DOUBLES, *Bs1 = lds + 3 * GEMM_TILE_DOUBLES;
@@ -165,62 +195,69 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void dgemm_mfma_kernel(GemmArgs g)
   const long m0 = (long)tm * GEMM_BM, n0 = (long)tn * GEMM_BN;
   const int t = threadIdx.x;
   const int lane = t & 63, wave = t >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / WN, wn = wave % WN;
   const int l15 = lane & 15, l4 = lane >> 4;
+  const int wcol = wn * (16 * TN);
 
-  const bool a_al = ((reinterpret_cast<uintptr_t>(g.A) & 15) == 0) && ((g.lda & 1) == 0);
-  const bool b_al = ((reinterpret_cast<uintptr_t>(g.B) & 15) == 0) && ((g.ldb & 1) == 0);
+  const bool a_al = FULL || (((reinterpret_cast<uintptr_t>(g.A) & 15) == 0) && ((g.lda & 1) == 0));
+  const bool b_al = FULL || (((reinterpret_cast<uintptr_t>(g.B) & 15) == 0) && ((g.ldb & 1) == 0));
 
-  f64x4 acc[4][4];
+  f64x4 acc[4][TN];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f64x4{0.0, 0.0, 0.0, 0.0};
+    for (int j = 0; j < TN; ++j) acc[i][j] = f64x4{0.0, 0.0, 0.0, 0.0};
 
-  f64x2 ra[4], rb[4];
+  f64x2 ra[NLD], rb[NLD];
   const long nk = (g.K + GEMM_BK - 1) / GEMM_BK;
+  const long nk_full = g.K / GEMM_BK; // K-tiles without a ragged tail
+  const bool a_full = FULL || (a_al && (m0 + GEMM_BM <= g.M));
+  const bool b_full = FULL || (b_al && (n0 + GEMM_BN <= g.N));
 
-  load_tile<A_KM>(g.A, g.lda, m0, 0, g.M, g.K, a_al, t, ra);
-  load_tile<B_KN>(g.B, g.ldb, n0, 0, g.N, g.K, b_al, t, rb);
+  load_tile<A_KM, NT>(g.A, g.lda, m0, 0, g.M, g.K, a_al, t, ra, a_full && nk_full > 0);
+  load_tile<B_KN, NT>(g.B, g.ldb, n0, 0, g.N, g.K, b_al, t, rb, b_full && nk_full > 0);
   if (g.square_a) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) ra[j] = ra[j] * ra[j];
+    for (int j = 0; j < NLD; ++j) ra[j] = ra[j] * ra[j];
   }
-  store_tile<A_KM>(As0, t, ra);
-  store_tile<B_KN>(Bs0, t, rb);
+  store_tile<A_KM, NT>(As0, t, ra);
+  store_tile<B_KN, NT>(Bs0, t, rb);
   __syncthreads();
 
   for (long kt = 0; kt < nk; ++kt) {
     const double *As = (kt & 1) ? As1 : As0;
     const double *Bs = (kt & 1) ? Bs1 : Bs0;
-    const bool more = (kt + 1) < nk;
+    const bool more = ((kt + 1) < nk) && !(g.ablate & 1);
     if (more) {
-      load_tile<A_KM>(g.A, g.lda, m0, (kt + 1) * GEMM_BK, g.M, g.K, a_al, t, ra);
-      load_tile<B_KN>(g.B, g.ldb, n0, (kt + 1) * GEMM_BK, g.N, g.K, b_al, t, rb);
+      const bool kfull = FULL || ((kt + 1) < nk_full);
+      load_tile<A_KM, NT>(g.A, g.lda, m0, (kt + 1) * GEMM_BK, g.M, g.K, a_al, t, ra, a_full && kfull);
+      load_tile<B_KN, NT>(g.B, g.ldb, n0, (kt + 1) * GEMM_BK, g.N, g.K, b_al, t, rb, b_full && kfull);
     }
 #pragma unroll
     for (int kk = 0; kk < GEMM_BK / 4; ++kk) {
-      double a[4], b[4];
+      double a[4], b[TN];
       const int k = kk * 4 + l4;
 #pragma unroll
       for (int i = 0; i < 4; ++i) a[i] = frag<A_KM>(As, wm * 64 + i * 16 + l15, k);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) b[j] = frag<B_KN>(Bs, wn * 64 + j * 16 + l15, k);
+      for (int j = 0; j < TN; ++j) b[j] = frag<B_KN>(Bs, wcol + j * 16 + l15, k);
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < TN; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
-    }
-    if (more) {
-      if (g.square_a) {
+      if (kk == GEMM_BK / 4 - 2 && more) {
+        // the next K-tile (issued before this tile's MFMAs) goes to the other LDS buffer while the last
+        // 2 x 16 MFMAs of this tile are still in flight: only the barrier is left at the tile boundary
+        if (g.square_a) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) ra[j] = ra[j] * ra[j];
+          for (int j = 0; j < NLD; ++j) ra[j] = ra[j] * ra[j];
+        }
+        store_tile<A_KM, NT>((kt & 1) ? As0 : As1, t, ra);
+        store_tile<B_KN, NT>((kt & 1) ? Bs0 : Bs1, t, rb);
       }
-      store_tile<A_KM>((kt & 1) ? As0 : As1, t, ra);
-      store_tile<B_KN>((kt & 1) ? Bs0 : Bs1, t, rb);
     }
-    __syncthreads();
+    if (!(g.ablate & 2)) __syncthreads();
   }
 
   // epilogue: lane holds rows (l>>4)+4r, col l&15 of each 16x16 block
@@ -228,12 +265,12 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void dgemm_mfma_kernel(GemmArgs g)
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const long col = n0 + wn * 64 + j * 16 + l15;
+    for (int j = 0; j < TN; ++j) {
+      const long col = n0 + wcol + j * 16 + l15;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const long row = m0 + wm * 64 + i * 16 + l4 + 4 * r;
-        if (row < g.M && col < g.N) {
+        if (FULL || (row < g.M && col < g.N)) {
           double *c = g.C + row * g.ldc + col;
           double v = alpha * acc[i][j][r];
           if (beta != 0.0) v += beta * (*c);
@@ -269,15 +306,60 @@ __global__ void symm_fill_scale_kernel(double *K, long n, long ld, double scale)
   }
 }
 
-template <bool A_KM, bool B_KN>
-static inline hipError_t launch_dgemm_t(const GemmArgs &g, hipStream_t s) {
+// wavefronts per 128x128 block: 8 (2x4 waves of 64x32, 4 waves/SIMD at 2 blocks/CU) or 4 (2x2 of 64x64)
+static inline int gemm_waves() {
+  static int nw = 0;
+  if (nw == 0) {
+    const char *e = getenv("GEMMA_HIP_GEMM_WAVES");
+    nw = (e && e[0] == '4') ? 4 : 8;
+  }
+  return nw;
+}
+
+template <bool A_KM, bool B_KN, bool FULL>
+static inline hipError_t launch_dgemm_grid(const GemmArgs &g, hipStream_t s) {
   int nblocks;
   if (g.syrk_upper)
     nblocks = g.tiles_m * (g.tiles_m + 1) / 2;
   else
     nblocks = g.tiles_m * g.tiles_n;
-  hipLaunchKernelGGL((dgemm_mfma_kernel<A_KM, B_KN>), dim3(nblocks), dim3(GEMM_THREADS), 0, s, g);
+  if (nblocks <= 0) return hipSuccess;
+  if (gemm_waves() == 8)
+    hipLaunchKernelGGL((dgemm_mfma_kernel<A_KM, B_KN, 8, FULL>), dim3(nblocks), dim3(512), 0, s, g);
+  else
+    hipLaunchKernelGGL((dgemm_mfma_kernel<A_KM, B_KN, 4, FULL>), dim3(nblocks), dim3(256), 0, s, g);
   return hipGetLastError();
+}
+
+template <bool A_KM, bool B_KN>
+static inline hipError_t launch_dgemm_t(GemmArgs g, hipStream_t s) {
+  const int Tm = (int)((g.M + GEMM_BM - 1) / GEMM_BM), Tn = (int)((g.N + GEMM_BN - 1) / GEMM_BN);
+  const int Fm = (int)(g.M / GEMM_BM), Fn = (int)(g.N / GEMM_BN); // complete tiles per dimension
+  const bool aligned = ((reinterpret_cast<uintptr_t>(g.A) & 15) == 0) && ((g.lda & 1) == 0) &&
+                       ((reinterpret_cast<uintptr_t>(g.B) & 15) == 0) && ((g.ldb & 1) == 0);
+  const bool fast = aligned && (g.K % GEMM_BK == 0) && g.K > 0 && Fm > 0 && Fn > 0;
+  hipError_t e;
+  if (!fast) { // everything through the bounds-checked instantiation
+    g.tiles_m = Tm; g.tiles_n = Tn; g.tm0 = 0; g.tn0 = 0;
+    return launch_dgemm_grid<A_KM, B_KN, false>(g, s);
+  }
+  // complete tiles: predicate-free kernel (SYRK: the upper triangle of the Fm x Fm complete tiles)
+  g.tiles_m = Fm; g.tiles_n = Fn; g.tm0 = 0; g.tn0 = 0;
+  e = launch_dgemm_grid<A_KM, B_KN, true>(g, s);
+  if (e != hipSuccess) return e;
+  const int syrk = g.syrk_upper;
+  g.syrk_upper = 0;
+  if (Tn > Fn) { // ragged right strip: all tile rows (SYRK: tm <= Tn-1 is every row)
+    g.tiles_m = Tm; g.tiles_n = 1; g.tm0 = 0; g.tn0 = Fn;
+    e = launch_dgemm_grid<A_KM, B_KN, false>(g, s);
+    if (e != hipSuccess) return e;
+  }
+  if (Tm > Fm && !syrk) { // ragged bottom strip (complete columns only; the corner went with the right strip)
+    g.tiles_m = 1; g.tiles_n = Fn; g.tm0 = Fm; g.tn0 = 0;
+    e = launch_dgemm_grid<A_KM, B_KN, false>(g, s);
+    if (e != hipSuccess) return e;
+  }
+  return hipSuccess;
 }
 
 // ta/tb in {'N','T'} with the cblas row-major meaning
@@ -290,10 +372,18 @@ static inline hipError_t launch_dgemm(char ta, char tb, long M, long N, long K, 
   g.M = M; g.N = N; g.K = K;
   g.lda = lda; g.ldb = ldb; g.ldc = ldc;
   g.alpha = alpha; g.beta = beta;
-  g.tiles_m = (int)((M + GEMM_BM - 1) / GEMM_BM);
-  g.tiles_n = (int)((N + GEMM_BN - 1) / GEMM_BN);
+  g.tiles_m = g.tiles_n = 0;
+  g.tm0 = g.tn0 = 0;
   g.syrk_upper = syrk_upper ? 1 : 0;
   g.square_a = square_a ? 1 : 0;
+  {
+    static int abl = -1;
+    if (abl < 0) {
+      const char *e = getenv("GEMMA_HIP_GEMM_ABLATE");
+      abl = e ? atoi(e) : 0;
+    }
+    g.ablate = abl;
+  }
   const bool tA = (ta == 'T' || ta == 't'), tB = (tb == 'T' || tb == 't');
   // op(A) = A^T  <=> A stored [k][m]  (KM image);  op(B) = B <=> B stored [k][n] (KN image)
   if (tA && !tB) return launch_dgemm_t<true, true>(g, s);

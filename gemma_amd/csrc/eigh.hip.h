@@ -24,7 +24,9 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
+#include <cstdlib>
 #include <cstdio>
 #include <string>
 #include <vector>
@@ -62,127 +64,206 @@ __device__ __forceinline__ double eig_bsum1024(double v, double *red /* >= 17 do
 }
 
 // ---------------------------------------------------------------- 1. tridiagonalisation
-// Column j of the current panel (panel starts at j0, k = j - j0 earlier columns in it):
-//   x = A[j][j:] - sum_q ( V_q[j:] W_q[j] + W_q[j:] V_q[j] ),  d_j = x[0],
-//   Householder reflector from x[1:]  (LAPACK dlarfg):  u_j -> row j of VT, tau_j, e_j = beta.
-__global__ __launch_bounds__(1024) void td_column_kernel(const double *__restrict__ A, long n, long j,
-                                                         long j0, double *__restrict__ VT,
-                                                         const double *__restrict__ WT,
-                                                         double *__restrict__ xcol, double *d, double *e,
-                                                         double *tau) {
+// Column j of the current panel (panel starts at j0, k = j - j0 earlier columns in it), four launches,
+// every one of them spread over the whole chip:
+//   td_col   : x = A[j][j:] - sum_q ( V_q[j:] W_q[j] + W_q[j:] V_q[j] )           -> xcol, partial |x|^2
+//   td_symv  : reflector scalars (LAPACK dlarfg: beta, tau, scale) from the partials, u_j -> row j of VT,
+//              p = A[j+1:, j+1:] u  (one wavefront per row, 16-byte loads), W_q.u and V_q.u
+//   td_w1    : w' = tau (p - V (W^T u) - W (V^T u))                                 -> wtmp, partial w'.u
+//   td_w2    : w = w' - (tau/2)(w'.u) u                                              -> row k of WT
+constexpr int TD_CHUNK = 256;
+
+// deterministic sum of `cnt` partials, result in every thread of the block (first wavefront reduces)
+__device__ __forceinline__ double td_sum_parts(const double *__restrict__ parts, int cnt, double *sh) {
+  if (threadIdx.x < 64) {
+    double s = 0.0;
+    for (int i = threadIdx.x; i < cnt; i += 64) s += parts[i];
+    s = eig_wsum(s);
+    if (threadIdx.x == 0) *sh = s;
+  }
+  __syncthreads();
+  return *sh;
+}
+
+struct TdScalars {
+  double scale, tau, beta;
+  bool has_e;
+};
+// LAPACK dlarfg on x[1:] (alpha = x[1], xnorm^2 given)
+__device__ __forceinline__ TdScalars td_reflector(const double *__restrict__ xcol, long n, long j, double xnorm2) {
+  TdScalars r;
+  r.scale = 0.0;
+  r.tau = 0.0;
+  r.beta = 0.0;
+  r.has_e = (j + 1 < n);
+  if (r.has_e) {
+    const double alpha = xcol[j + 1];
+    if (xnorm2 == 0.0) {
+      r.beta = alpha;
+    } else {
+      double beta = sqrt(alpha * alpha + xnorm2);
+      if (alpha > 0.0) beta = -beta;
+      r.tau = (beta - alpha) / beta;
+      r.scale = 1.0 / (alpha - beta);
+      r.beta = beta;
+    }
+  }
+  return r;
+}
+
+__global__ __launch_bounds__(TD_CHUNK) void td_col_kernel(const double *__restrict__ A, long n, long j, long j0,
+                                                          const double *__restrict__ VT,
+                                                          const double *__restrict__ WT,
+                                                          double *__restrict__ xcol, double *__restrict__ ssbuf) {
   __shared__ double sv[EIG_NB], sw[EIG_NB];
-  __shared__ double red[17];
-  __shared__ double s_scale;
+  __shared__ double red[4];
   const int t = threadIdx.x;
   const int k = (int)(j - j0);
-  for (int q = t; q < k; q += 1024) {
+  for (int q = t; q < k; q += TD_CHUNK) {
     sv[q] = VT[(j0 + q) * n + j];
     sw[q] = WT[(long)q * n + j];
   }
   __syncthreads();
+  const long r = j + (long)blockIdx.x * TD_CHUNK + t;
   double ss = 0.0;
-  for (long r = j + t; r < n; r += 1024) {
+  if (r < n) {
     double x = A[j * n + r];
     for (int q = 0; q < k; ++q) x -= VT[(j0 + q) * n + r] * sw[q] + WT[(long)q * n + r] * sv[q];
     xcol[r] = x;
-    if (r >= j + 2) ss += x * x;
+    if (r >= j + 2) ss = x * x;
   }
-  const double xnorm2 = eig_bsum1024(ss, red); // barriers inside also publish xcol within the block
-  if (t == 0) {
-    d[j] = xcol[j];
-    double scale = 0.0, tj = 0.0;
-    if (j + 1 < n) {
-      const double alpha = xcol[j + 1];
-      if (xnorm2 == 0.0) {
-        e[j] = alpha;
-      } else {
-        double beta = sqrt(alpha * alpha + xnorm2);
-        if (alpha > 0.0) beta = -beta;
-        tj = (beta - alpha) / beta;
-        scale = 1.0 / (alpha - beta);
-        e[j] = beta;
-      }
-    }
-    tau[j] = tj;
-    s_scale = scale;
-  }
+  ss = eig_wsum(ss);
+  if ((t & 63) == 0) red[t >> 6] = ss;
   __syncthreads();
-  const double scale = s_scale;
-  for (long r = t; r < n; r += 1024) {
-    double v = 0.0;
-    if (r == j + 1)
-      v = 1.0;
-    else if (r > j + 1)
-      v = xcol[r] * scale;
-    VT[j * n + r] = v;
-  }
+  if (t == 0) ssbuf[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
-// blocks [0, nsymv): p[r] = sum_{c > j} A[r][c] u[c]  (one wavefront per row r > j);
-// blocks [nsymv, nsymv + 2k): ab[2q] = W_q . u, ab[2q+1] = V_q . u
+// grid: [0, nsymv) SYMV rows (4 per block) | [nsymv, nsymv+2k) panel dots | then ceil(n/256) writers of VT row j
 __global__ __launch_bounds__(256) void td_symv_kernel(const double *__restrict__ A, long n, long j, long j0,
-                                                      const double *__restrict__ VT,
-                                                      const double *__restrict__ WT, double *__restrict__ p,
-                                                      double *__restrict__ ab, int nsymv) {
-  const double *__restrict__ u = VT + j * n;
+                                                      double *__restrict__ VT, const double *__restrict__ WT,
+                                                      const double *__restrict__ xcol,
+                                                      const double *__restrict__ ssbuf, int nparts,
+                                                      double *__restrict__ p, double *__restrict__ ab, int nsymv,
+                                                      int k, double *d, double *e, double *tau) {
+  __shared__ double sh;
+  __shared__ double red[4];
+  const double xnorm2 = td_sum_parts(ssbuf, nparts, &sh);
+  const TdScalars sc = td_reflector(xcol, n, j, xnorm2);
+  const double scale = sc.scale;
   const int lane = threadIdx.x & 63;
-  if ((int)blockIdx.x < nsymv) {
-    const long r = j + 1 + (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const long j1 = j + 1;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    d[j] = xcol[j];
+    if (sc.has_e) e[j] = sc.beta;
+    tau[j] = sc.tau;
+  }
+  const int b = (int)blockIdx.x;
+  if (b < nsymv) {
+    const long r = j1 + (long)b * 4 + (threadIdx.x >> 6);
     if (r >= n) return;
     const double *__restrict__ row = A + r * n;
     double s0 = 0.0, s1 = 0.0;
-    long c = j + 1 + lane;
-    for (; c + 64 < n; c += 128) {
-      s0 += row[c] * u[c];
-      s1 += row[c + 64] * u[c + 64];
+    long c = j1;
+    const bool vec = ((n & 1) == 0) && ((reinterpret_cast<uintptr_t>(A) & 15) == 0) &&
+                     ((reinterpret_cast<uintptr_t>(xcol) & 15) == 0);
+    if (vec) {
+      if (c & 1) { // leading odd element is u[j+1] == 1
+        if (lane == 0) s0 += row[c];
+        c++;
+      }
+      long cc = c + 2 * lane;
+      for (; cc + 128 + 1 < n; cc += 256) {
+        const f64x2 a0 = *reinterpret_cast<const f64x2 *>(row + cc);
+        const f64x2 a1 = *reinterpret_cast<const f64x2 *>(row + cc + 128);
+        const f64x2 x0 = *reinterpret_cast<const f64x2 *>(xcol + cc);
+        const f64x2 x1 = *reinterpret_cast<const f64x2 *>(xcol + cc + 128);
+        const double u00 = (cc == j1) ? 1.0 : x0.x * scale, u01 = x0.y * scale;
+        s0 += a0.x * u00 + a0.y * u01;
+        s1 += a1.x * (x1.x * scale) + a1.y * (x1.y * scale);
+      }
+      for (; cc + 1 < n; cc += 128) {
+        const f64x2 a0 = *reinterpret_cast<const f64x2 *>(row + cc);
+        const f64x2 x0 = *reinterpret_cast<const f64x2 *>(xcol + cc);
+        const double u00 = (cc == j1) ? 1.0 : x0.x * scale, u01 = x0.y * scale;
+        s0 += a0.x * u00 + a0.y * u01;
+      }
+    } else {
+      for (long cc = c + lane; cc < n; cc += 64) {
+        const double u = (cc == j1) ? 1.0 : xcol[cc] * scale;
+        s0 += row[cc] * u;
+      }
     }
-    if (c < n) s0 += row[c] * u[c];
     const double s = eig_wsum(s0 + s1);
     if (lane == 0) p[r] = s;
-  } else {
-    __shared__ double red[4];
-    const int idx = (int)blockIdx.x - nsymv;
+  } else if (b < nsymv + 2 * k) {
+    const int idx = b - nsymv;
     const int q = idx >> 1;
-    const double *__restrict__ vec = (idx & 1) ? (VT + (j0 + q) * n) : (WT + (long)q * n);
+    const double *__restrict__ vecp = (idx & 1) ? (VT + (j0 + q) * n) : (WT + (long)q * n);
     double s = 0.0;
-    for (long c = j + 1 + threadIdx.x; c < n; c += 256) s += vec[c] * u[c];
+    for (long c = j1 + threadIdx.x; c < n; c += 256) {
+      const double u = (c == j1) ? 1.0 : xcol[c] * scale;
+      s += vecp[c] * u;
+    }
     s = eig_wsum(s);
     if (lane == 0) red[threadIdx.x >> 6] = s;
     __syncthreads();
     if (threadIdx.x == 0) ab[idx] = (red[0] + red[1]) + (red[2] + red[3]);
+  } else {
+    const long r = (long)(b - nsymv - 2 * k) * 256 + threadIdx.x;
+    if (r < n) {
+      double v = 0.0;
+      if (r == j1)
+        v = 1.0;
+      else if (r > j1)
+        v = xcol[r] * scale;
+      VT[j * n + r] = v;
+    }
   }
 }
 
-// w = tau (p - V (W^T u) - W (V^T u));  w -= (tau/2)(w.u) u;  row k of WT <- w (zeros for r <= j)
-__global__ __launch_bounds__(1024) void td_w_kernel(long n, long j, long j0, const double *__restrict__ VT,
-                                                    double *__restrict__ WT, const double *__restrict__ p,
-                                                    const double *__restrict__ ab, const double *tau) {
+__global__ __launch_bounds__(TD_CHUNK) void td_w1_kernel(long n, long j, long j0, const double *__restrict__ VT,
+                                                         const double *__restrict__ WT,
+                                                         const double *__restrict__ p,
+                                                         const double *__restrict__ ab, const double *tau,
+                                                         double *__restrict__ wtmp, double *__restrict__ dotbuf) {
   __shared__ double sa[EIG_NB], sb[EIG_NB];
-  __shared__ double red[17];
+  __shared__ double red[4];
   const int t = threadIdx.x;
   const int k = (int)(j - j0);
-  for (int q = t; q < k; q += 1024) {
+  for (int q = t; q < k; q += TD_CHUNK) {
     sa[q] = ab[2 * q];
     sb[q] = ab[2 * q + 1];
   }
   __syncthreads();
   const double tj = tau[j];
-  const double *__restrict__ u = VT + j * n;
-  double *__restrict__ wrow = WT + (long)k * n;
+  const long r = j + 1 + (long)blockIdx.x * TD_CHUNK + t;
   double dot = 0.0;
-  for (long r = t; r < n; r += 1024) {
-    double w = 0.0;
-    if (r > j) {
-      w = p[r];
-      for (int q = 0; q < k; ++q) w -= VT[(j0 + q) * n + r] * sa[q] + WT[(long)q * n + r] * sb[q];
-      w *= tj;
-      dot += w * u[r];
-    }
-    wrow[r] = w;
+  if (r < n) {
+    double w = p[r];
+    for (int q = 0; q < k; ++q) w -= VT[(j0 + q) * n + r] * sa[q] + WT[(long)q * n + r] * sb[q];
+    w *= tj;
+    wtmp[r] = w;
+    dot = w * VT[j * n + r];
   }
-  dot = eig_bsum1024(dot, red);
-  const double alpha2 = -0.5 * tj * dot;
-  for (long r = j + 1 + t; r < n; r += 1024) wrow[r] += alpha2 * u[r];
+  dot = eig_wsum(dot);
+  if ((t & 63) == 0) red[t >> 6] = dot;
+  __syncthreads();
+  if (t == 0) dotbuf[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__global__ __launch_bounds__(TD_CHUNK) void td_w2_kernel(long n, long j, long j0, const double *__restrict__ VT,
+                                                         double *__restrict__ WT, const double *__restrict__ wtmp,
+                                                         const double *__restrict__ dotbuf, int nparts,
+                                                         const double *tau) {
+  __shared__ double sh;
+  const double dot = td_sum_parts(dotbuf, nparts, &sh);
+  const double alpha2 = -0.5 * tau[j] * dot;
+  const long r = (long)blockIdx.x * TD_CHUNK + threadIdx.x;
+  if (r < n) {
+    double w = 0.0;
+    if (r > j) w = wtmp[r] + alpha2 * VT[j * n + r];
+    WT[(long)(j - j0) * n + r] = w;
+  }
 }
 
 // ---------------------------------------------------------------- 2. divide and conquer
@@ -452,6 +533,7 @@ __global__ void eig_scale_kernel(double *v, long n, double s) {
 struct EigWs {
   long n = 0;
   double *VT = nullptr, *WT = nullptr, *xcol = nullptr, *p = nullptr, *ab = nullptr;
+  double *ssbuf = nullptr, *dotbuf = nullptr, *wtmp = nullptr;
   double *d = nullptr, *e = nullptr, *tau = nullptr;
   double *Delta = nullptr, *Wk = nullptr, *QB = nullptr;
   double *P = nullptr, *P2 = nullptr, *S = nullptr, *T = nullptr;
@@ -491,15 +573,20 @@ static inline int eig_tridiagonalize(double *A, long n, EigWs &ws, hipStream_t s
     const long kp = std::min<long>(EIG_NB, n - j0);
     for (long k = 0; k < kp; ++k) {
       const long j = j0 + k;
-      hipLaunchKernelGGL(td_column_kernel, dim3(1), dim3(1024), 0, s, A, n, j, j0, ws.VT, ws.WT, ws.xcol, ws.d,
-                         ws.e, ws.tau);
       const long m = n - j - 1;
-      if (m > 0) {
-        const int nsymv = (int)((m + 3) / 4);
-        hipLaunchKernelGGL(td_symv_kernel, dim3(nsymv + 2 * (int)k), dim3(256), 0, s, A, n, j, j0, ws.VT, ws.WT,
-                           ws.p, ws.ab, nsymv);
-      }
-      hipLaunchKernelGGL(td_w_kernel, dim3(1), dim3(1024), 0, s, n, j, j0, ws.VT, ws.WT, ws.p, ws.ab, ws.tau);
+      const int nparts = (int)((n - j + TD_CHUNK - 1) / TD_CHUNK);
+      hipLaunchKernelGGL(td_col_kernel, dim3(nparts), dim3(TD_CHUNK), 0, s, A, n, j, j0, ws.VT, ws.WT, ws.xcol,
+                         ws.ssbuf);
+      const int nsymv = (int)((m + 3) / 4);
+      const int nrow = (int)((n + 255) / 256);
+      hipLaunchKernelGGL(td_symv_kernel, dim3(nsymv + 2 * (int)k + nrow), dim3(256), 0, s, A, n, j, j0, ws.VT, ws.WT,
+                         ws.xcol, ws.ssbuf, nparts, ws.p, ws.ab, nsymv, (int)k, ws.d, ws.e, ws.tau);
+      const int nparts2 = (int)((m + TD_CHUNK - 1) / TD_CHUNK);
+      if (m > 0)
+        hipLaunchKernelGGL(td_w1_kernel, dim3(nparts2), dim3(TD_CHUNK), 0, s, n, j, j0, ws.VT, ws.WT, ws.p, ws.ab,
+                           ws.tau, ws.wtmp, ws.dotbuf);
+      hipLaunchKernelGGL(td_w2_kernel, dim3((unsigned)((n + TD_CHUNK - 1) / TD_CHUNK)), dim3(TD_CHUNK), 0, s, n, j,
+                         j0, ws.VT, ws.WT, ws.wtmp, ws.dotbuf, nparts2, ws.tau);
     }
     EIG_HIP(hipGetLastError());
     const long t0 = j0 + kp;
@@ -725,8 +812,9 @@ static inline int eigh_device(double *G, long n, double *U, double *eval, hipStr
   EigWs ws;
   ws.n = n;
   const size_t nn = (size_t)n * n;
-  bool ok = ws.get(ws.VT, nn) && ws.get(ws.WT, (size_t)EIG_NB * n) && ws.get(ws.xcol, n) && ws.get(ws.p, n) &&
-            ws.get(ws.ab, 2 * EIG_NB) && ws.get(ws.d, n) && ws.get(ws.e, n) && ws.get(ws.tau, n) &&
+  bool ok = ws.get(ws.VT, nn) && ws.get(ws.WT, (size_t)EIG_NB * n) && ws.get(ws.xcol, n + 2) && ws.get(ws.p, n) &&
+            ws.get(ws.ab, 2 * EIG_NB) && ws.get(ws.ssbuf, n / TD_CHUNK + 2) && ws.get(ws.dotbuf, n / TD_CHUNK + 2) &&
+            ws.get(ws.wtmp, n) && ws.get(ws.d, n) && ws.get(ws.e, n) && ws.get(ws.tau, n) &&
             ws.get(ws.Delta, nn) && ws.get(ws.Wk, nn) && ws.get(ws.P, (size_t)n * EIG_NB) &&
             ws.get(ws.P2, (size_t)n * EIG_NB) && ws.get(ws.S, (size_t)EIG_NB * EIG_NB) &&
             ws.get(ws.T, (size_t)EIG_NB * EIG_NB) && ws.get(ws.zbuf, n) && ws.get(ws.dl, n) && ws.get(ws.w, n) &&
@@ -740,6 +828,13 @@ static inline int eigh_device(double *G, long n, double *U, double *eval, hipStr
   int rc = 0;
   std::vector<double> hd(n), he(std::max<long>(n - 1, 1)), dphys;
   double *Z = nullptr;
+  const char *tenv = getenv("GEMMA_HIP_EIGH_TIMING");
+  const bool timing = tenv && tenv[0] == '1';
+  auto now = [&]() {
+    (void)hipStreamSynchronize(s);
+    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+  };
+  double t0 = timing ? now() : 0.0, t1 = 0.0, t2 = 0.0, t3 = 0.0;
   do {
     if (n == 1) {
       hipError_t e1 = hipMemcpyAsync(eval, G, 8, hipMemcpyDeviceToDevice, s);
@@ -773,14 +868,17 @@ static inline int eigh_device(double *G, long n, double *U, double *eval, hipStr
       rc = 1;
       break;
     }
+    if (timing) t1 = now();
     const double scale = (tnorm > 0.0) ? tnorm : 1.0;
     for (long i = 0; i < n; ++i) hd[i] /= scale;
     for (long i = 0; i + 1 < n; ++i) he[i] /= scale;
     // G (dead after the reduction) and U serve as the two eigenvector-row buffers
     rc = eig_stedc(n, hd, he, G, U, ws, s, &Z, dphys, msg);
     if (rc) break;
+    if (timing) t2 = now();
     rc = eig_backtransform(Z, n, ws, s, msg);
     if (rc) break;
+    if (timing) t3 = now();
     std::vector<int> perm(n);
     for (long i = 0; i < n; ++i) perm[i] = (int)i;
     std::stable_sort(perm.begin(), perm.end(), [&](int a, int c) { return dphys[a] < dphys[c]; });
@@ -804,6 +902,9 @@ static inline int eigh_device(double *G, long n, double *U, double *eval, hipStr
     }
   } while (0);
   (void)hipStreamSynchronize(s);
+  if (timing && rc == 0 && n > 1)
+    fprintf(stderr, "gemma_hip_eigh n=%ld: tridiagonalisation %.3f s, divide&conquer %.3f s, back-transform %.3f s, "
+                    "sort+transpose %.3f s\n", n, t1 - t0, t2 - t1, t3 - t2, now() - t3);
   ws.release();
   return rc;
 }

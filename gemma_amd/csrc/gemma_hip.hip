@@ -6,6 +6,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -487,8 +488,9 @@ extern "C" int gemma_hip_dbg_tridiag(const double *G, size_t n, double *d, doubl
   DevBuf dG;
   const size_t nn = n * n;
   if (dG.reserve(nn * 8)) return fail(GEMMA_HIP_ENOMEM, "dbg_tridiag");
-  bool ok = ws.get(ws.VT, nn) && ws.get(ws.WT, (size_t)EIG_NB * n) && ws.get(ws.xcol, n) && ws.get(ws.p, n) &&
-            ws.get(ws.ab, 2 * EIG_NB) && ws.get(ws.d, n) && ws.get(ws.e, n) && ws.get(ws.tau, n);
+  bool ok = ws.get(ws.VT, nn) && ws.get(ws.WT, (size_t)EIG_NB * n) && ws.get(ws.xcol, n + 2) && ws.get(ws.p, n) &&
+            ws.get(ws.ab, 2 * EIG_NB) && ws.get(ws.ssbuf, n / TD_CHUNK + 2) && ws.get(ws.dotbuf, n / TD_CHUNK + 2) &&
+            ws.get(ws.wtmp, n) && ws.get(ws.d, n) && ws.get(ws.e, n) && ws.get(ws.tau, n);
   std::string msg;
   int rc = ok ? 0 : GEMMA_HIP_ENOMEM;
   if (!rc && hipMemcpy(dG.p, G, nn * 8, hipMemcpyHostToDevice) != hipSuccess) rc = GEMMA_HIP_ERUNTIME;
@@ -554,8 +556,8 @@ extern "C" int gemma_hip_calc_utx(const double *U, const double *X, size_t n, si
 static int lmm_common_setup(const gemma_lmm_cfg *cfg) {
   if (!cfg) return fail(GEMMA_HIP_EINVAL, "lmm_setup: null cfg");
   if (cfg->n == 0 || cfg->n_cvt == 0) return fail(GEMMA_HIP_EINVAL, "lmm_setup: n=%zu n_cvt=%zu", cfg->n, cfg->n_cvt);
-  if (cfg->n_cvt > 4)
-    return fail(GEMMA_HIP_EINVAL, "lmm_setup: n_cvt=%zu not supported by this build (1..4)", cfg->n_cvt);
+  if (cfg->n_cvt > (size_t)GEN_CMAX)
+    return fail(GEMMA_HIP_EINVAL, "lmm_setup: n_cvt=%zu not supported by this build (1..%d)", cfg->n_cvt, GEN_CMAX);
   if (!(cfg->a_mode == 1 || cfg->a_mode == 2 || cfg->a_mode == 3 || cfg->a_mode == 4 || cfg->a_mode == 9))
     return fail(GEMMA_HIP_EINVAL, "lmm_setup: a_mode %d", cfg->a_mode);
   if (!(cfg->l_max > cfg->l_min) || cfg->n_region == 0 || cfg->n_region > (size_t)ASSOC_MAX_REGION)
@@ -670,12 +672,17 @@ static int launch_assoc(const double *UtX, size_t l, size_t ld, gemma_sumstat *o
   const unsigned grid = (unsigned)((l + 3) / 4);
   {
     ProfScope ps(GEMMA_STAGE_ASSOC, s);
-    switch (g_ctx.cfg.n_cvt) {
+    // GEMMA_HIP_FORCE_GENERIC=1 routes every covariate count through the multi-pass kernel (tests)
+    const char *fg = getenv("GEMMA_HIP_FORCE_GENERIC");
+    const size_t sel = (fg && fg[0] == '1') ? 99 : g_ctx.cfg.n_cvt;
+    switch (sel) {
     case 1: hipLaunchKernelGGL(lmm_assoc_kernel<1>, dim3(grid), dim3(256), 0, s, a); break;
     case 2: hipLaunchKernelGGL(lmm_assoc_kernel<2>, dim3(grid), dim3(256), 0, s, a); break;
     case 3: hipLaunchKernelGGL(lmm_assoc_kernel<3>, dim3(grid), dim3(256), 0, s, a); break;
     case 4: hipLaunchKernelGGL(lmm_assoc_kernel<4>, dim3(grid), dim3(256), 0, s, a); break;
-    default: return fail(GEMMA_HIP_EINVAL, "assoc: n_cvt");
+    default: // more covariates: register-tiled multi-pass path
+      hipLaunchKernelGGL(lmm_assoc_generic_kernel, dim3(grid), dim3(256), 0, s, a, (int)g_ctx.cfg.n_cvt);
+      break;
     }
     HIPCHK(hipGetLastError());
     if (g_ctx.cfg.plink_nan_rule && g_ctx.cfg.a_mode == 1) {
@@ -771,8 +778,8 @@ extern "C" int gemma_hip_lmm_null(size_t n, size_t n_cvt, const double *eval, co
                                   const double *Uty, double l_min, double l_max, size_t n_region,
                                   double trace_G, double *out8) {
   NEED_INIT();
-  if (!eval || !UtW || !Uty || !out8 || n == 0 || n_cvt == 0 || n_cvt > 5)
-    return fail(GEMMA_HIP_EINVAL, "lmm_null: bad arguments (n_cvt 1..5)");
+  if (!eval || !UtW || !Uty || !out8 || n == 0 || n_cvt == 0 || n_cvt > (size_t)GEN_CMAX + 1)
+    return fail(GEMMA_HIP_EINVAL, "lmm_null: bad arguments (n_cvt 1..%d)", GEN_CMAX + 1);
   if (!(l_max > l_min) || n_region == 0 || n_region > (size_t)ASSOC_MAX_REGION || n <= n_cvt)
     return fail(GEMMA_HIP_EINVAL, "lmm_null: l_min/l_max/n_region/n");
   DevBuf dE, dW, dWt, dY, dO;
@@ -802,6 +809,7 @@ extern "C" int gemma_hip_lmm_null(size_t n, size_t n_cvt, const double *eval, co
     case 3: hipLaunchKernelGGL(lmm_null_kernel<2>, dim3(1), dim3(64), 0, 0, a, o); break;
     case 4: hipLaunchKernelGGL(lmm_null_kernel<3>, dim3(1), dim3(64), 0, 0, a, o); break;
     case 5: hipLaunchKernelGGL(lmm_null_kernel<4>, dim3(1), dim3(64), 0, 0, a, o); break;
+    default: hipLaunchKernelGGL(lmm_null_generic_kernel, dim3(1), dim3(64), 0, 0, a, (int)n_cvt - 1, o); break;
     }
     e = hipGetLastError();
   }

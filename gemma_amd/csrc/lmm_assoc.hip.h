@@ -297,36 +297,229 @@ __device__ __forceinline__ void project(const Row0<C> &R, Proj<C> &P) {
   P.yy3[1] = p3[iyy];
 }
 
-// ------------------------------------------------------------------ likelihood pieces
-// Everything below is the alternative model: calc_null = false, nc_total = C + 1.
+// ------------------------------------------------------------------ models
+// What the likelihood code needs from one evaluation at a given lambda (alternative model:
+// calc_null = false, nc_total = c + 1).
+struct Agg {
+  double tr1, tr2, logdet;      // sum H, sum H^2, sum log|lambda*delta + 1|
+  double trace_P, trace_PP;     // tr1 - sum_i ww2_i/ww1_i ; tr2 + sum_i (ww2_i^2/ww1_i^2 - 2 ww3_i/ww1_i)
+  double slog;                  // sum_i log(ww1_i), i < c+1    (log|W^T H^-1 W| pivots)
+  double yy1_c, xx1, xy1;       // P_c[yy], P_c[xx], P_c[xy]     (row c: after the covariates)
+  double yy1, yy2, yy3;         // (P^k)_{c+1}[yy], k = 1..3    (row c+1: after covariates and x)
+};
+
+// number of covariates fixed at compile time: everything in registers (c = 1..4)
 template <int C>
+struct FixedC {
+  __device__ __forceinline__ int c() const { return C; }
+  template <int ORDER, bool LOGDET>
+  __device__ __forceinline__ void eval(const AssocArgs &g, const double *x, double l, int lane, Agg &A) const {
+    Row0<C> R;
+    row0_pass<C, ORDER, LOGDET>(g, x, l, lane, R);
+    Proj<C> P;
+    project<C, (ORDER == 0 ? 1 : ORDER)>(R, P);
+    A.tr1 = R.tr1;
+    A.tr2 = R.tr2;
+    A.logdet = R.logdet;
+    double tp = R.tr1, tpp = R.tr2, sl = 0.0;
+#pragma unroll
+    for (int i = 0; i < C + 1; ++i) {
+      if (ORDER >= 2) tp -= P.ww2[i] / P.ww1[i];
+      if (ORDER >= 3) tpp += P.ww2[i] * P.ww2[i] / (P.ww1[i] * P.ww1[i]) - 2.0 * P.ww3[i] / P.ww1[i];
+      if (ORDER <= 1) sl += log(P.ww1[i]);
+    }
+    A.trace_P = tp;
+    A.trace_PP = tpp;
+    A.slog = sl;
+    A.yy1_c = P.yy1[0];
+    A.xx1 = P.xx1;
+    A.xy1 = P.xy1;
+    A.yy1 = P.yy1[1];
+    A.yy2 = P.yy2[1];
+    A.yy3 = P.yy3[1];
+  }
+};
+
+// any number of covariates (c <= GEN_CMAX): the (c+2) x (c+2) product table is covered by 4 x 4 register
+// tiles, one streaming pass per tile pair; row-0 sums and the projection recursion live in per-wave LDS.
+constexpr int GEN_CMAX = 16;
+constexpr int GEN_NI = (GEN_CMAX + 3) * (GEN_CMAX + 2) / 2;
+constexpr int GEN_LDS_PER_WAVE = 6 * GEN_NI;
+
+__device__ __forceinline__ int ab_index_rt(int a, int b, int c) {
+  const int cols = c + 2;
+  const int a1 = (b <= a) ? b : a;
+  const int b1 = (b <= a) ? a : b;
+  return (2 * cols - a1 + 2) * (a1 - 1) / 2 + b1 - a1;
+}
+
+struct GenericC {
+  int cc;
+  double *L; // this wave's LDS scratch, GEN_LDS_PER_WAVE doubles
+  __device__ __forceinline__ int c() const { return cc; }
+
+  template <int ORDER, bool LOGDET>
+  __device__ void eval(const AssocArgs &g, const double *__restrict__ x, double lambda, int lane, Agg &A) const {
+    const int c = cc, nv = c + 2, n = g.n;
+    constexpr int EO = (ORDER == 0) ? 1 : ORDER;
+    double *s1 = L, *s2 = L + GEN_NI, *s3 = L + 2 * GEN_NI;
+    double tr1 = 0.0, tr2 = 0.0, ld = 0.0;
+    const int nblk = (nv + 3) >> 2;
+    for (int bi = 0; bi < nblk; ++bi) {
+      for (int bj = bi; bj < nblk; ++bj) {
+        const double *pa[4], *pb[4];
+        bool va[4], vb[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int v = 4 * bi + k, w = 4 * bj + k;
+          va[k] = v < nv;
+          vb[k] = w < nv;
+          const int v0 = va[k] ? v : 0, w0 = vb[k] ? w : 0;
+          pa[k] = (v0 < c) ? g.UtWt + (long)v0 * n : (v0 == c ? x : g.Uty);
+          pb[k] = (w0 < c) ? g.UtWt + (long)w0 * n : (w0 == c ? x : g.Uty);
+        }
+        double a1[4][4], a2[4][4], a3[4][4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+          for (int m = 0; m < 4; ++m) a1[k][m] = a2[k][m] = a3[k][m] = 0.0;
+        const bool first = (bi == 0 && bj == 0);
+        for (int i = lane; i < n; i += 64) {
+          double h1 = 1.0, h2 = 1.0, h3 = 1.0;
+          if (ORDER >= 1) {
+            const double v = g.eval[i] * lambda + 1.0;
+            h1 = 1.0 / v;
+            if (ORDER >= 2) h2 = h1 * h1;
+            if (ORDER >= 3) h3 = h2 * h1;
+            if (first) {
+              if (LOGDET) ld += log(fabs(v));
+              tr1 += h1;
+              if (ORDER >= 3) tr2 += h2;
+            }
+          }
+          double ua[4], ub[4];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            ua[k] = va[k] ? pa[k][i] : 0.0;
+            ub[k] = vb[k] ? pb[k][i] : 0.0;
+          }
+#pragma unroll
+          for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+              const double pr = ub[m] * ua[k];
+              a1[k][m] += h1 * pr;
+              if (ORDER >= 2) a2[k][m] += h2 * pr;
+              if (ORDER >= 3) a3[k][m] += h3 * pr;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+          for (int m = 0; m < 4; ++m) {
+            const int a = 4 * bi + k + 1, b = 4 * bj + m + 1;
+            const double r1 = wave_sum(a1[k][m]);
+            const double r2 = (ORDER >= 2) ? wave_sum(a2[k][m]) : 0.0;
+            const double r3 = (ORDER >= 3) ? wave_sum(a3[k][m]) : 0.0;
+            if (a <= b && b <= nv && lane == 0) {
+              const int idx = ab_index_rt(a, b, c);
+              s1[idx] = r1;
+              if (EO >= 2) s2[idx] = r2;
+              if (EO >= 3) s3[idx] = r3;
+            }
+          }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    A.tr1 = wave_sum(tr1);
+    A.tr2 = (ORDER >= 3) ? wave_sum(tr2) : 0.0;
+    A.logdet = LOGDET ? wave_sum(ld) : 0.0;
+    // projection recursion (src/lmm.cpp:326-349, :385-407, :445-474), one lane per (a,b) pair
+    double *cur1 = s1, *cur2 = s2, *cur3 = s3;
+    double *nx1 = L + 3 * GEN_NI, *nx2 = L + 4 * GEN_NI, *nx3 = L + 5 * GEN_NI;
+    const int iyy = ab_index_rt(c + 2, c + 2, c), ixx = ab_index_rt(c + 1, c + 1, c),
+              ixy = ab_index_rt(c + 2, c + 1, c);
+    double tp = A.tr1, tpp = A.tr2, sl = 0.0;
+    for (int p = 1; p <= c + 1; ++p) {
+      const int iww = ab_index_rt(p, p, c);
+      const double ps_ww = cur1[iww];
+      const double ps2_ww = (EO >= 2) ? cur2[iww] : 0.0;
+      const double ps3_ww = (EO >= 3) ? cur3[iww] : 0.0;
+      if (ORDER >= 2) tp -= ps2_ww / ps_ww;
+      if (ORDER >= 3) tpp += ps2_ww * ps2_ww / (ps_ww * ps_ww) - 2.0 * ps3_ww / ps_ww;
+      if (ORDER <= 1) sl += log(ps_ww);
+      if (p == c + 1) {
+        A.yy1_c = cur1[iyy];
+        A.xx1 = cur1[ixx];
+        A.xy1 = cur1[ixy];
+      }
+      int cnt = 0;
+      for (int a = p + 1; a <= nv; ++a) {
+        for (int b = a; b <= nv; ++b, ++cnt) {
+          if ((cnt & 63) != lane) continue;
+          const int iab = ab_index_rt(a, b, c), iaw = ab_index_rt(a, p, c), ibw = ab_index_rt(b, p, c);
+          const double ps_ab = cur1[iab], ps_aw = cur1[iaw], ps_bw = cur1[ibw];
+          double r1 = ps_ab, r2 = 0.0, r3 = 0.0;
+          if (EO >= 2) r2 = cur2[iab];
+          if (EO >= 3) r3 = cur3[iab];
+          if (ps_ww != 0) {
+            r1 = ps_ab - ps_aw * ps_bw / ps_ww;
+            if (EO >= 2) {
+              const double ps2_ab = cur2[iab], ps2_aw = cur2[iaw], ps2_bw = cur2[ibw];
+              r2 = ps2_ab + ps_aw * ps_bw * ps2_ww / (ps_ww * ps_ww);
+              r2 -= (ps_aw * ps2_bw + ps_bw * ps2_aw) / ps_ww;
+              if (EO >= 3) {
+                const double ps3_ab = cur3[iab], ps3_aw = cur3[iaw], ps3_bw = cur3[ibw];
+                r3 = ps3_ab - ps_aw * ps_bw * ps2_ww * ps2_ww / (ps_ww * ps_ww * ps_ww);
+                r3 -= (ps_aw * ps3_bw + ps_bw * ps3_aw + ps2_aw * ps2_bw) / ps_ww;
+                r3 += (ps_aw * ps2_bw * ps2_ww + ps_bw * ps2_aw * ps2_ww + ps_aw * ps_bw * ps3_ww) /
+                      (ps_ww * ps_ww);
+              }
+            }
+          }
+          nx1[iab] = r1;
+          if (EO >= 2) nx2[iab] = r2;
+          if (EO >= 3) nx3[iab] = r3;
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+      double *t;
+      t = cur1; cur1 = nx1; nx1 = t;
+      t = cur2; cur2 = nx2; nx2 = t;
+      t = cur3; cur3 = nx3; nx3 = t;
+    }
+    A.trace_P = tp;
+    A.trace_PP = tpp;
+    A.slog = sl;
+    A.yy1 = cur1[iyy];
+    A.yy2 = (EO >= 2) ? cur2[iyy] : 0.0;
+    A.yy3 = (EO >= 3) ? cur3[iyy] : 0.0;
+    __builtin_amdgcn_wave_barrier();
+  }
+};
+
+// ------------------------------------------------------------------ likelihood pieces
+template <class M>
 struct SnpCtx {
   const AssocArgs *g;
   const double *x;
   int lane;
-  double logdet_iw; // sum_i log(Iab(i, ww_{i+1})), i < C+1  (H == 1; SNP constant)
+  M m;
+  double logdet_iw; // sum_i log(Iab(i, ww_{i+1})), i < c+1  (H == 1; SNP constant)
 };
 
 // LogRL_dev1 / LogRL_dev12 (src/lmm.cpp:866-943, :1035-1125) and LogL_dev1 / LogL_dev12
 // (:544-640, :719-797).  ORDER 2 -> dev1 only; ORDER 3 -> dev1 and dev2.
-template <int C, bool REML, int ORDER>
-__device__ __forceinline__ void deriv(const SnpCtx<C> &s, double l, double &dev1, double &dev2) {
-  Row0<C> R;
-  row0_pass<C, ORDER, false>(*s.g, s.x, l, s.lane, R);
-  Proj<C> P;
-  project<C, ORDER>(R, P);
+template <class M, bool REML, int ORDER>
+__device__ __forceinline__ void deriv(const SnpCtx<M> &s, double l, double &dev1, double &dev2) {
+  Agg A;
+  s.m.template eval<ORDER, false>(*s.g, s.x, l, s.lane, A);
   const double n = (double)s.g->n;
-  const double P_yy = P.yy1[1], PP_yy = P.yy2[1], PPP_yy = P.yy3[1];
+  const double P_yy = A.yy1, PP_yy = A.yy2, PPP_yy = A.yy3;
   const double yPKPy = (P_yy - PP_yy) / l;
   if (REML) {
-    const double df = n - (double)C - 1.0;
-    double trace_P = R.tr1, trace_PP = R.tr2;
-#pragma unroll
-    for (int i = 0; i < C + 1; ++i) {
-      trace_P -= P.ww2[i] / P.ww1[i];
-      if (ORDER >= 3)
-        trace_PP += P.ww2[i] * P.ww2[i] / (P.ww1[i] * P.ww1[i]) - 2.0 * P.ww3[i] / P.ww1[i];
-    }
+    const double df = n - (double)s.m.c() - 1.0;
+    const double trace_P = A.trace_P, trace_PP = A.trace_PP;
     const double trace_PK = (df - trace_P) / l;
     dev1 = -0.5 * trace_PK + 0.5 * df * yPKPy / P_yy;
     if (ORDER >= 3) {
@@ -335,10 +528,10 @@ __device__ __forceinline__ void deriv(const SnpCtx<C> &s, double l, double &dev1
       dev2 = 0.5 * trace_PKPK - 0.5 * df * (2.0 * yPKPKPy * P_yy - yPKPy * yPKPy) / (P_yy * P_yy);
     }
   } else {
-    const double trace_HiK = (n - R.tr1) / l;
+    const double trace_HiK = (n - A.tr1) / l;
     dev1 = -0.5 * trace_HiK + 0.5 * n * yPKPy / P_yy;
     if (ORDER >= 3) {
-      const double trace_HiKHiK = (n + R.tr2 - 2 * R.tr1) / (l * l);
+      const double trace_HiKHiK = (n + A.tr2 - 2 * A.tr1) / (l * l);
       const double yPKPKPy = (P_yy + PPP_yy - 2.0 * PP_yy) / (l * l);
       dev2 = 0.5 * trace_HiKHiK - 0.5 * n * (2.0 * yPKPKPy * P_yy - yPKPy * yPKPy) / (P_yy * P_yy);
     }
@@ -347,42 +540,35 @@ __device__ __forceinline__ void deriv(const SnpCtx<C> &s, double l, double &dev1
   if (ORDER >= 3) dev2 = uniform(dev2);
 }
 
-// LogRL_f (src/lmm.cpp:799-864) / LogL_f (:484-542).  If `P_out` != nullptr the order-1
-// projections at this lambda are handed back (CalcRLWald reuses them when lambda matches).
-template <int C, bool REML>
-__device__ __forceinline__ double logf(const SnpCtx<C> &s, double l) {
-  Row0<C> R;
-  row0_pass<C, 1, true>(*s.g, s.x, l, s.lane, R);
-  Proj<C> P;
-  project<C, 1>(R, P);
+// LogRL_f (src/lmm.cpp:799-864) / LogL_f (:484-542)
+template <class M, bool REML>
+__device__ __forceinline__ double logf(const SnpCtx<M> &s, double l) {
+  Agg A;
+  s.m.template eval<1, true>(*s.g, s.x, l, s.lane, A);
   const double n = (double)s.g->n;
-  double P_yy = P.yy1[1];
+  double P_yy = A.yy1;
   if (P_yy >= 0.0 && P_yy < 1e-8) P_yy = 1e-8; // P_YY_MIN, src/lmm.cpp:52,527,854
   double f;
   if (REML) {
-    const double df = n - (double)C - 1.0;
-    double logdet_hiw = -s.logdet_iw;
-#pragma unroll
-    for (int i = 0; i < C + 1; ++i) logdet_hiw += log(P.ww1[i]);
+    const double df = n - (double)s.m.c() - 1.0;
+    const double logdet_hiw = A.slog - s.logdet_iw;
     const double cst = 0.5 * df * (log(df) - log(2 * M_PI) - 1.0);
-    f = cst - 0.5 * R.logdet - 0.5 * logdet_hiw - 0.5 * df * log(P_yy);
+    f = cst - 0.5 * A.logdet - 0.5 * logdet_hiw - 0.5 * df * log(P_yy);
   } else {
     const double cst = 0.5 * n * (log(n) - log(2 * M_PI) - 1.0);
-    f = cst - 0.5 * R.logdet - 0.5 * n * log(P_yy);
+    f = cst - 0.5 * A.logdet - 0.5 * n * log(P_yy);
   }
   return uniform(f);
 }
 
 // CalcRLWald (src/lmm.cpp:1127-1167) / CalcRLScore (:1170-1211)
-template <int C, bool SCORE>
-__device__ __forceinline__ void wald_score(const SnpCtx<C> &s, double l, double &beta, double &se,
+template <class M, bool SCORE>
+__device__ __forceinline__ void wald_score(const SnpCtx<M> &s, double l, double &beta, double &se,
                                            double &pval) {
-  Row0<C> R;
-  row0_pass<C, 1, false>(*s.g, s.x, l, s.lane, R);
-  Proj<C> P;
-  project<C, 1>(R, P);
-  const int df = s.g->n - C - 1;
-  const double P_yy = P.yy1[0], P_xx = P.xx1, P_xy = P.xy1, Px_yy = P.yy1[1];
+  Agg A;
+  s.m.template eval<1, false>(*s.g, s.x, l, s.lane, A);
+  const int df = s.g->n - s.m.c() - 1;
+  const double P_yy = A.yy1_c, P_xx = A.xx1, P_xy = A.xy1, Px_yy = A.yy1;
   beta = uniform(P_xy / P_xx);
   const double tau = (double)df / Px_yy;
   se = uniform(safe_sqrt_dev(1.0 / (tau * P_xx)));
@@ -403,18 +589,16 @@ struct Brent {
 };
 enum { RS_SUCCESS = 0, RS_CONTINUE = -2, RS_EINVAL = 4, RS_EBADFUNC = 9, RS_EZERODIV = 12 };
 
-template <int C, bool REML>
-__device__ __forceinline__ double dev1_of(const SnpCtx<C> &s, double l) {
+template <class M, bool REML>
+__device__ __forceinline__ double dev1_of(const SnpCtx<M> &s, double l) {
   double d1, d2;
-  deriv<C, REML, 2>(s, l, d1, d2);
+  deriv<M, REML, 2>(s, l, d1, d2);
   return d1;
 }
 
 __device__ __forceinline__ bool finite_d(double v) { return fabs(v) <= DBL_MAX; }
 
-template <int C, bool REML>
-__device__ inline int brent_set(Brent &s, const SnpCtx<C> &cx, double x_lower, double x_upper,
-                                double f_lower, double f_upper) {
+__device__ inline int brent_set(Brent &s, double x_lower, double x_upper, double f_lower, double f_upper) {
   // f_lower/f_upper: the reference re-evaluates dev1 at both ends (gsl_root_fsolver_set ->
   // brent_init); the function is pure, so the grid-scan values are the same numbers.
   if (x_lower > x_upper) return RS_EINVAL;
@@ -432,8 +616,8 @@ __device__ inline int brent_set(Brent &s, const SnpCtx<C> &cx, double x_lower, d
   return RS_SUCCESS;
 }
 
-template <int C, bool REML>
-__device__ inline int brent_iterate(Brent &s, const SnpCtx<C> &cx) {
+template <class M, bool REML>
+__device__ inline int brent_iterate(Brent &s, const SnpCtx<M> &cx) {
   double tol, m;
   bool ac_equal = false;
   double a = s.a, b = s.b, c = s.c, fa = s.fa, fb = s.fb, fc = s.fc, d = s.d, e = s.e;
@@ -481,7 +665,7 @@ __device__ inline int brent_iterate(Brent &s, const SnpCtx<C> &cx) {
   }
   a = b; fa = fb;
   if (fabs(d) > tol) b += d; else b += (m > 0 ? +tol : -tol);
-  fb = dev1_of<C, REML>(cx, b);
+  fb = dev1_of<M, REML>(cx, b);
   if (!finite_d(fb)) return RS_EBADFUNC;
   s.a = a; s.b = b; s.c = c; s.d = d; s.e = e; s.fa = fa; s.fb = fb; s.fc = fc;
   s.root = b;
@@ -508,30 +692,30 @@ __device__ __forceinline__ int test_delta_dev(double x1, double x0, double epsre
 // CalcLambda, src/lmm.cpp:1945-2140.  Brackets are processed as soon as the grid scan finds
 // them (the evaluations are pure, so interleaving scan and polish gives the reference's
 // sequence of results); `return NaN` and `break` semantics of :2057-2060,:2087-2094 are kept.
-template <int C, bool REML>
-__device__ inline void calc_lambda(const SnpCtx<C> &cx, double &lambda, double &logf_out) {
+template <class M, bool REML>
+__device__ inline void calc_lambda(const SnpCtx<M> &cx, double &lambda, double &logf_out) {
   const AssocArgs &g = *cx.g;
   const double l_min = g.l_min, l_max = g.l_max;
   double lam = NAN, lf = NAN;
   bool any = false, first = true, stop = false, failed = false;
   double l = 0.0, l_temp = 0.0;
-  double d_lo = dev1_of<C, REML>(cx, g.lam_grid[0]);
+  double d_lo = dev1_of<M, REML>(cx, g.lam_grid[0]);
   for (int i = 0; i < g.n_region; ++i) {
     const double lambda_l0 = g.lam_grid[i], lambda_h0 = g.lam_grid[i + 1];
-    const double d_hi = dev1_of<C, REML>(cx, lambda_h0);
+    const double d_hi = dev1_of<M, REML>(cx, lambda_h0);
     const bool bracket = (d_lo * d_hi <= 0);
     if (bracket) any = true;
     if (bracket && !stop && !failed) {
       Brent bs;
       bs.a = bs.b = bs.c = bs.d = bs.e = bs.fa = bs.fb = bs.fc = 0.0;
       bs.root = bs.x_lower = bs.x_upper = 0.0;
-      (void)brent_set<C, REML>(bs, cx, lambda_l0, lambda_h0, d_lo, d_hi);
+      (void)brent_set(bs, lambda_l0, lambda_h0, d_lo, d_hi);
       int status;
       int iter = 0;
       double lambda_l, lambda_h;
       do {
         iter++;
-        status = brent_iterate<C, REML>(bs, cx);
+        status = brent_iterate<M, REML>(bs, cx);
         if (status != RS_SUCCESS && status != RS_CONTINUE) break;
         l = bs.root;
         lambda_l = bs.x_lower;
@@ -545,7 +729,7 @@ __device__ inline void calc_lambda(const SnpCtx<C> &cx, double &lambda, double &
         // Newton, GSL roots/newton.c: set() evaluates (f, df) at the start
         int iter2 = 0;
         double root = l, nf, ndf;
-        deriv<C, REML, 3>(cx, root, nf, ndf);
+        deriv<M, REML, 3>(cx, root, nf, ndf);
         do {
           iter2++;
           if (ndf == 0.0) {
@@ -553,7 +737,7 @@ __device__ inline void calc_lambda(const SnpCtx<C> &cx, double &lambda, double &
           } else {
             const double root_new = root - (nf / ndf);
             root = root_new;
-            deriv<C, REML, 3>(cx, root_new, nf, ndf);
+            deriv<M, REML, 3>(cx, root_new, nf, ndf);
             status = (!finite_d(nf) || !finite_d(ndf)) ? RS_EBADFUNC : RS_SUCCESS;
           }
           if (status != RS_SUCCESS && status != RS_CONTINUE) break;
@@ -567,7 +751,7 @@ __device__ inline void calc_lambda(const SnpCtx<C> &cx, double &lambda, double &
           l = l_temp; // :2096 -- the previous Newton iterate is reported
           if (l < l_min) l = l_min;
           if (l > l_max) l = l_max;
-          const double logf_l = logf<C, REML>(cx, l);
+          const double logf_l = logf<M, REML>(cx, l);
           if (first) {
             lf = logf_l; lam = l;
           } else if (lf < logf_l) {
@@ -584,8 +768,8 @@ __device__ inline void calc_lambda(const SnpCtx<C> &cx, double &lambda, double &
     logf_out = NAN;
     return;
   }
-  const double logf_l = logf<C, REML>(cx, l_min);
-  const double logf_h = logf<C, REML>(cx, l_max);
+  const double logf_l = logf<M, REML>(cx, l_min);
+  const double logf_h = logf<M, REML>(cx, l_max);
   if (!any) { // :1985-2000
     if (logf_l >= logf_h) { lam = l_min; lf = logf_l; } else { lam = l_max; lf = logf_h; }
   } else { // :2121-2136
@@ -596,16 +780,23 @@ __device__ inline void calc_lambda(const SnpCtx<C> &cx, double &lambda, double &
   logf_out = lf;
 }
 
-// ------------------------------------------------------------------ kernel
-template <int C>
-__global__ __launch_bounds__(256) void lmm_assoc_kernel(AssocArgs g) {
-  const int lane = threadIdx.x & 63;
-  const long snp = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (snp >= g.l) return;
-  SnpCtx<C> cx;
+// sum_i log(Iab(i, ww_{i+1})): CalcPab with H == 1 (src/lmm.cpp:839-850); constant for the SNP
+template <class M>
+__device__ __forceinline__ double logdet_iw_of(const SnpCtx<M> &cx) {
+  Agg A;
+  cx.m.template eval<0, false>(*cx.g, cx.x, 0.0, cx.lane, A);
+  return uniform(A.slog);
+}
+
+// ------------------------------------------------------------------ kernels
+// the body of batch_compute's loop (src/lmm.cpp:1526-1562 / :1853-1888) for one SNP
+template <class M>
+__device__ __forceinline__ void assoc_one_snp(const AssocArgs &g, const M &model, long snp, int lane) {
+  SnpCtx<M> cx;
   cx.g = &g;
   cx.x = g.UtX + snp * g.ld;
   cx.lane = lane;
+  cx.m = model;
   cx.logdet_iw = 0.0;
   const int a_mode = g.a_mode;
 
@@ -614,35 +805,25 @@ __global__ __launch_bounds__(256) void lmm_assoc_kernel(AssocArgs g) {
   bool wald_skipped = false;
 
   if (a_mode == 3 || a_mode == 4 || a_mode == 9) // "3 is before 1", src/lmm.cpp:1540-1543
-    wald_score<C, true>(cx, g.l_mle_null, beta, se, p_score);
+    wald_score<M, true>(cx, g.l_mle_null, beta, se, p_score);
 
   if (a_mode == 1 || a_mode == 4) {
-    { // Iab: CalcPab with H == 1 (src/lmm.cpp:839-850); constant for the SNP
-      Row0<C> R;
-      row0_pass<C, 0, false>(g, cx.x, 0.0, lane, R);
-      Proj<C> P;
-      project<C, 1>(R, P);
-      double s = 0.0;
-#pragma unroll
-      for (int i = 0; i < C + 1; ++i) s += log(P.ww1[i]);
-      cx.logdet_iw = uniform(s);
-    }
-    calc_lambda<C, true>(cx, lambda_remle, logl_H1);
+    cx.logdet_iw = logdet_iw_of(cx);
+    calc_lambda<M, true>(cx, lambda_remle, logl_H1);
     if (!g.plink_nan_rule || !isnan(logl_H1)) // src/lmm.cpp:1870
-      wald_score<C, false>(cx, lambda_remle, beta, se, p_wald);
+      wald_score<M, false>(cx, lambda_remle, beta, se, p_wald);
     else
       wald_skipped = true;
   }
   if (a_mode == 2 || a_mode == 4 || a_mode == 9) {
-    calc_lambda<C, false>(cx, lambda_mle, logl_H1);
+    calc_lambda<M, false>(cx, lambda_mle, logl_H1);
     p_lrt = chisq_Q1_dev(2.0 * (logl_H1 - g.logl_mle_H0));
     if (isnan(logl_H1)) p_lrt = NAN;
   }
   if (g.plink_nan_rule && isnan(logl_H1)) p_wald = p_lrt = logl_H1; // src/lmm.cpp:1882-1884
   if (wald_skipped && a_mode == 1) {
     // AnalyzePlink keeps beta/se of the PREVIOUS SNP here (function-scope variables,
-    // src/lmm.cpp:1725); the host fix-up in gemma_hip_lmm_batch* fills these two from the
-    // preceding SNP. A signalling pattern marks them: quiet NaN payload.
+    // src/lmm.cpp:1725); plink_carry_kernel fills these two from the preceding SNP.
     beta = NAN;
     se = NAN;
   }
@@ -654,49 +835,67 @@ __global__ __launch_bounds__(256) void lmm_assoc_kernel(AssocArgs g) {
   }
 }
 
+template <int C>
+__global__ __launch_bounds__(256) void lmm_assoc_kernel(AssocArgs g) {
+  const int lane = threadIdx.x & 63;
+  const long snp = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (snp >= g.l) return;
+  assoc_one_snp(g, FixedC<C>(), snp, lane);
+}
+
+__global__ __launch_bounds__(256) void lmm_assoc_generic_kernel(AssocArgs g, int c) {
+  __shared__ double lds[4 * GEN_LDS_PER_WAVE];
+  const int lane = threadIdx.x & 63;
+  const long snp = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (snp >= g.l) return;
+  GenericC m;
+  m.cc = c;
+  m.L = lds + (threadIdx.x >> 6) * GEN_LDS_PER_WAVE;
+  assoc_one_snp(g, m, snp, lane);
+}
+
 // ------------------------------------------------------------------ null model
 // CalcLambda(func, eval, UtW, Uty, ...) with calc_null = true (GEMMA src/lmm.cpp:2143-2180,
 // called at src/gemma.cpp:2711,2734), CalcPve's LogRL_dev2 (:2197) and CalcLmmVgVeBeta's P_yy
 // (:2253-2258).  Projecting out w_1..w_c (nc_total = c, df = n - c) is the alternative-model code
-// with CP = c - 1 covariates and the last covariate in the role of x.
+// with c - 1 covariates and the last covariate in the role of x.
 struct NullOut {
   double l_mle, logl_mle, l_remle, logl_remle, dev2_remle, Pyy_remle, Pyy_mle;
 };
 
+template <class M>
+__device__ __forceinline__ void null_model(const AssocArgs &g, const M &model, int cp, int lane, NullOut *out) {
+  SnpCtx<M> cx;
+  cx.g = &g;
+  cx.x = g.UtWt + (long)cp * g.n; // last covariate column
+  cx.lane = lane;
+  cx.m = model;
+  cx.logdet_iw = logdet_iw_of(cx);
+  NullOut o;
+  calc_lambda<M, false>(cx, o.l_mle, o.logl_mle);
+  calc_lambda<M, true>(cx, o.l_remle, o.logl_remle);
+  double d1, d2;
+  deriv<M, true, 3>(cx, o.l_remle, d1, d2);
+  o.dev2_remle = d2;
+  Agg A;
+  cx.m.template eval<1, false>(g, cx.x, o.l_remle, lane, A);
+  o.Pyy_remle = uniform(A.yy1);
+  cx.m.template eval<1, false>(g, cx.x, o.l_mle, lane, A);
+  o.Pyy_mle = uniform(A.yy1);
+  if (lane == 0) *out = o;
+}
+
 template <int CP>
 __global__ __launch_bounds__(64) void lmm_null_kernel(AssocArgs g, NullOut *out) {
-  const int lane = threadIdx.x & 63;
-  SnpCtx<CP> cx;
-  cx.g = &g;
-  cx.x = g.UtWt + (long)CP * g.n; // last covariate column
-  cx.lane = lane;
-  {
-    Row0<CP> R;
-    row0_pass<CP, 0, false>(g, cx.x, 0.0, lane, R);
-    Proj<CP> P;
-    project<CP, 1>(R, P);
-    double s = 0.0;
-#pragma unroll
-    for (int i = 0; i < CP + 1; ++i) s += log(P.ww1[i]);
-    cx.logdet_iw = uniform(s);
-  }
-  NullOut o;
-  calc_lambda<CP, false>(cx, o.l_mle, o.logl_mle);
-  calc_lambda<CP, true>(cx, o.l_remle, o.logl_remle);
-  double d1, d2;
-  deriv<CP, true, 3>(cx, o.l_remle, d1, d2);
-  o.dev2_remle = d2;
-  {
-    Row0<CP> R;
-    Proj<CP> P;
-    row0_pass<CP, 1, false>(g, cx.x, o.l_remle, lane, R);
-    project<CP, 1>(R, P);
-    o.Pyy_remle = uniform(P.yy1[1]);
-    row0_pass<CP, 1, false>(g, cx.x, o.l_mle, lane, R);
-    project<CP, 1>(R, P);
-    o.Pyy_mle = uniform(P.yy1[1]);
-  }
-  if (lane == 0) *out = o;
+  null_model(g, FixedC<CP>(), CP, threadIdx.x & 63, out);
+}
+
+__global__ __launch_bounds__(64) void lmm_null_generic_kernel(AssocArgs g, int cp, NullOut *out) {
+  __shared__ double lds[GEN_LDS_PER_WAVE];
+  GenericC m;
+  m.cc = cp;
+  m.L = lds;
+  null_model(g, m, cp, threadIdx.x & 63, out);
 }
 
 } // namespace gemma_hip

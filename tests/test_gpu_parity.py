@@ -230,6 +230,38 @@ def test_lmm_synthetic_all_modes(gpu_api, oracle, n, c):
         assert lmm.time_UtX >= 0 and lmm.time_opt >= 0
 
 
+@pytest.mark.parametrize("n,c", [(310, 5), (288, 7), (350, 11), (400, 16)])
+def test_lmm_many_covariates(gpu_api, oracle, n, c):
+    """c > 4 goes through the register-tiled multi-pass kernel (per-wave LDS recursion)."""
+    X, U, ev, UtW, Uty, tr = _synthetic(oracle, n, 160, c, seed=500 + c)
+    l_mle, logl0 = oracle.calc_lambda_null("L", ev, UtW, Uty)
+    ref = oracle.lmm_analyze(4, U, ev, UtW, Uty, X, l_mle_null=l_mle, logl_mle_H0=logl0)
+    lmm = gpu_api.LMM(a_mode=4, l_mle_null=l_mle, logl_mle_H0=logl0)
+    got = lmm.AnalyzeBimbam(U, ev, UtW, Uty, X)
+    _cmp_stats(got, ref, 4, "n=%d c=%d" % (n, c))
+    nm = gpu_api.CalcLambdaNull(ev, UtW, Uty, trace_G=tr)
+    assert nm["l_mle_null"] == pytest.approx(l_mle, rel=LAM_RTOL) and nm["logl_mle_H0"] == pytest.approx(logl0, rel=RTOL)
+
+
+def test_generic_kernel_on_bxd(gpu_api, bxd, monkeypatch):
+    """The multi-pass kernel forced onto the c = 3 BXD golden case: same bar as the register kernel."""
+    monkeypatch.setenv("GEMMA_HIP_FORCE_GENERIC", "1")
+    null = bxd["null"]
+    X = bxd["X"].astype(np.float64)[:2000]
+    for mode in (1, 2):
+        lmm = gpu_api.LMM(a_mode=mode, l_mle_null=null[0], logl_mle_H0=null[1])
+        got = lmm.AnalyzeBimbam(bxd["U"], bxd["eval"], bxd["UtW"], bxd["Uty"], X)
+        _cmp_stats(got, bxd["stat_mode%d" % mode][:2000], mode, "BXD-generic")
+
+
+def test_too_many_covariates_is_rejected(gpu_api):
+    from gemma_amd import _lib as L
+    n, c = 64, 17
+    with pytest.raises(L.GemmaHipError) as e:
+        gpu_api.LMM(a_mode=1).setup(np.eye(n), np.ones(n), np.ones((n, c)), np.ones(n))
+    assert e.value.code == L.EINVAL
+
+
 def test_null_model(gpu_api, oracle, bxd):
     null = bxd["null"]
     got = gpu_api.CalcLambdaNull(bxd["eval"], bxd["UtW"], bxd["Uty"], trace_G=null[6])
