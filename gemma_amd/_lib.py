@@ -11,7 +11,7 @@ SYMBOLS = [
     "gemma_hip_init", "gemma_hip_shutdown", "gemma_hip_abi_version", "gemma_hip_strerror",
     "gemma_hip_last_error", "gemma_hip_device_info", "gemma_hip_dgemm", "gemma_hip_dgemm_d",
     "gemma_hip_kin_begin", "gemma_hip_kin_add", "gemma_hip_kin_add_d", "gemma_hip_kin_end",
-    "gemma_hip_kin_end_d", "gemma_hip_center", "gemma_hip_center_d", "gemma_hip_eigh",
+    "gemma_hip_kin_end_d", "gemma_hip_kin_loco_d", "gemma_hip_snp_qc", "gemma_hip_center", "gemma_hip_center_d", "gemma_hip_eigh",
     "gemma_hip_eigh_d", "gemma_hip_calc_utx", "gemma_hip_lmm_setup", "gemma_hip_lmm_setup_d",
     "gemma_hip_lmm_null", "gemma_hip_lmm_set_indicator", "gemma_hip_lmm_batch", "gemma_hip_lmm_batch_d",
     "gemma_hip_lmm_assoc_d", "gemma_hip_lmm_finish", "gemma_hip_profile_enable",
@@ -32,6 +32,11 @@ class LmmCfg(C.Structure):
     _fields_ = [("a_mode", C.c_int), ("n", C.c_size_t), ("n_cvt", C.c_size_t), ("l_min", C.c_double),
                 ("l_max", C.c_double), ("n_region", C.c_size_t), ("l_mle_null", C.c_double),
                 ("logl_mle_H0", C.c_double), ("plink_nan_rule", C.c_int)]
+
+
+class QcCfg(C.Structure):
+    _fields_ = [("maf_level", C.c_double), ("miss_level", C.c_double), ("hwe_level", C.c_double),
+                ("r2_level", C.c_double)]
 
 
 class GemmaHipError(RuntimeError):
@@ -74,6 +79,8 @@ def lib():
     L.gemma_hip_kin_add_d.argtypes = [ci, vp, sz, sz, vp]
     L.gemma_hip_kin_end.argtypes = [dp, C.POINTER(sz)]
     L.gemma_hip_kin_end_d.argtypes = [dp, C.POINTER(sz), vp]
+    L.gemma_hip_kin_loco_d.argtypes = [dp, sz, dp, sz, sz, vp]
+    L.gemma_hip_snp_qc.argtypes = [ci, vp, sz, sz, vp, sz, dp, sz, sz, C.POINTER(QcCfg), vp, dp, vp]
     L.gemma_hip_center.argtypes = [dp, sz]
     L.gemma_hip_center_d.argtypes = [dp, sz, vp]
     L.gemma_hip_eigh.argtypes = [dp, sz, dp, dp, C.POINTER(cd)]

@@ -192,6 +192,59 @@ def CalcKin(geno, geno_kind, n_total, k_mode=1, batch=K_BATCH_SIZE):
     return K
 
 
+def SnpQC(geno, geno_kind, indicator_idv, W, maf_level=0.01, miss_level=0.05, hwe_level=0.0, r2_level=0.9999):
+    """First-pass SNP filters of ReadFile_geno / ReadFile_bed (src/gemma_io.cpp:639-873 / :876-1064) on device.
+    geno: SNP-major rows over ALL individuals (fp64 with NaN, or .bed bytes); W: covariates of the analysed
+    individuals.  Returns (indicator_snp, maf, n_miss)."""
+    ind = None if indicator_idv is None else np.ascontiguousarray(indicator_idv, dtype=np.int32)
+    W = np.ascontiguousarray(W, dtype=np.float64).reshape(len(W), -1)
+    n, c = W.shape
+    l = geno.shape[0]
+    ni_total = n if ind is None else ind.size
+    cfg = L.QcCfg(maf_level, miss_level, hwe_level, r2_level)
+    out_i = np.zeros(l, dtype=np.int32)
+    out_maf = np.zeros(l)
+    out_nm = np.zeros(l, dtype=np.uint64)
+    L.check(L.lib().gemma_hip_snp_qc(geno_kind, _ptr(geno), l, geno.strides[0] // geno.itemsize,
+                                     _ptr(ind) if ind is not None else None, ni_total, _ptr(W), n, c, C.byref(cfg),
+                                     _ptr(out_i), _ptr(out_maf), _ptr(out_nm)), "SnpQC")
+    return out_i, out_maf, out_nm.astype(np.int64)
+
+
+def CalcKinLOCO(geno, geno_kind, n_total, chr_of_snp, k_mode=1, batch=K_BATCH_SIZE):
+    """-loco for every chromosome at once (torch device tensors inside): the all-SNP kinship plus one
+    per-chromosome kinship, combined on device as (ns K - ns_c K_c)/(ns - ns_c).  Returns {chr: K_loco numpy}."""
+    import torch
+    chr_of_snp = np.asarray(chr_of_snp)
+    dev = torch.device("cuda", torch.cuda.current_device())
+    Kall = torch.empty((n_total, n_total), dtype=torch.float64, device=dev)
+    kin_begin(n_total, k_mode)
+    for s0 in range(0, geno.shape[0], batch):
+        kin_add(geno[s0:s0 + batch], geno_kind)
+    ns_all = kin_end(Kall)
+    out = {}
+    for ch in sorted(set(chr_of_snp.tolist())):
+        sel = np.flatnonzero(chr_of_snp == ch)
+        Kc = torch.empty_like(Kall)
+        kin_begin(n_total, k_mode)
+        g = np.ascontiguousarray(geno[sel])
+        for s0 in range(0, g.shape[0], batch):
+            kin_add(g[s0:s0 + batch], geno_kind)
+        ns_c = kin_end(Kc)
+        L.check(L.lib().gemma_hip_kin_loco_d(C.c_void_p(Kall.data_ptr()), ns_all, C.c_void_p(Kc.data_ptr()), ns_c,
+                                             n_total, _stream()), "CalcKinLOCO")
+        torch.cuda.synchronize()
+        out[ch] = Kc.cpu().numpy()
+    return out
+
+
+def WriteMatrix10(M):
+    """The text hand-off `-gk` -> `-lmm`: PARAM::WriteMatrix at precision(10) (src/param.cpp:1886-1911) read back
+    by ReadFile_kin (src/gemma_io.cpp:1186-1243).  Returns the matrix as the second GEMMA run would see it."""
+    flat = np.array([float("%.10g" % v) for v in np.asarray(M, dtype=np.float64).ravel()])
+    return flat.reshape(np.asarray(M).shape)
+
+
 # ----------------------------------------------------------------------------- null model
 def CalcLambdaNull(eval_, UtW, Uty, l_min=1e-5, l_max=1e5, n_region=10, trace_G=1.0):
     """Returns dict(l_mle_null, logl_mle_H0, l_remle_null, logl_remle_H0, pve, pve_se, vg, ve):

@@ -16,6 +16,7 @@
 #include "eigh.hip.h"
 #include "ingest.hip.h"
 #include "lmm_assoc.hip.h"
+#include "qc.hip.h"
 
 using namespace gemma_hip;
 
@@ -550,6 +551,80 @@ extern "C" int gemma_hip_dbg_stedc(const double *d, const double *e, size_t n, d
 extern "C" int gemma_hip_calc_utx(const double *U, const double *X, size_t n, size_t m, double *UtX) {
   // UtX (n x m) = U^T X : fast_dgemm("T","N",1.0,U,X,0.0,UtX), src/mathfunc.cpp:505
   return gemma_hip_dgemm('T', 'N', n, m, n, 1.0, U, n, X, m, 0.0, UtX, m);
+}
+
+// ------------------------------------------------------------------------------ first-pass QC
+extern "C" int gemma_hip_snp_qc(int kind, const void *geno, size_t l, size_t ld, const int *indicator_idv,
+                                size_t ni_total, const double *W, size_t n, size_t n_cvt, const gemma_qc_cfg *cfg,
+                                int *indicator_snp, double *maf, size_t *n_miss) {
+  NEED_INIT();
+  if (!geno || !W || !cfg || !indicator_snp || n == 0 || n_cvt == 0 || ni_total < n)
+    return fail(GEMMA_HIP_EINVAL, "snp_qc: bad arguments");
+  if (kind != GEMMA_GENO_F64_SNP_MAJOR && kind != GEMMA_GENO_PLINK_2BIT)
+    return fail(GEMMA_HIP_EINVAL, "snp_qc: geno_kind %d not supported here", kind);
+  const size_t need = (kind == GEMMA_GENO_PLINK_2BIT) ? (ni_total + 3) / 4 : ni_total;
+  if (ld < need) return fail(GEMMA_HIP_EINVAL, "snp_qc: ld=%zu < %zu", ld, need);
+  if (l == 0) return GEMMA_HIP_OK;
+  std::vector<int> map;
+  if (indicator_idv) {
+    for (size_t i = 0; i < ni_total; ++i)
+      if (indicator_idv[i] != 0) map.push_back((int)i);
+    if (map.size() != n) return fail(GEMMA_HIP_EINVAL, "snp_qc: %zu analysed individuals, n = %zu", map.size(), n);
+  } else if (ni_total != n) {
+    return fail(GEMMA_HIP_EINVAL, "snp_qc: no indicator but ni_total != n");
+  }
+  // W^T W and its inverse (host, c x c), W^T (device, covariate-major)
+  const int c = (int)n_cvt;
+  std::vector<double> WtW((size_t)c * c, 0.0), Wt((size_t)c * n);
+  for (size_t i = 0; i < n; ++i)
+    for (int a = 0; a < c; ++a) {
+      Wt[(size_t)a * n + i] = W[i * c + a];
+      for (int b = 0; b < c; ++b) WtW[(size_t)a * c + b] += W[i * c + a] * W[i * c + b];
+    }
+  if (!invert_small(WtW, c)) return fail(GEMMA_HIP_EINVAL, "snp_qc: W^T W is singular");
+  const size_t esz = (kind == GEMMA_GENO_PLINK_2BIT) ? 1 : 8;
+  const size_t ncol = QC_NSTAT + n_cvt;
+  DevBuf dG, dM, dW, dO;
+  auto cleanup = [&]() { dG.release(); dM.release(); dW.release(); dO.release(); };
+  if (dG.reserve(l * ld * esz) || dM.reserve(n * sizeof(int)) || dW.reserve(Wt.size() * 8) || dO.reserve(l * ncol * 8)) {
+    cleanup();
+    return fail(GEMMA_HIP_ENOMEM, "snp_qc: allocation");
+  }
+  hipError_t e = hipMemcpy2D(dG.p, ld * esz, geno, ld * esz, need * esz, l, hipMemcpyHostToDevice);
+  if (e == hipSuccess && indicator_idv) e = hipMemcpy(dM.p, map.data(), n * sizeof(int), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(dW.p, Wt.data(), Wt.size() * 8, hipMemcpyHostToDevice);
+  std::vector<double> stats(l * ncol);
+  if (e == hipSuccess) {
+    QcArgs a;
+    a.src = dG.p; a.ld = (long)ld; a.l = (long)l; a.idx_map = indicator_idv ? dM.as<int>() : nullptr;
+    a.n = (int)n; a.c = c; a.Wt = dW.as<double>(); a.out = dO.as<double>();
+    const unsigned grid = (unsigned)((l + 3) / 4);
+    ProfScope ps(GEMMA_STAGE_INGEST, 0);
+    if (kind == GEMMA_GENO_PLINK_2BIT)
+      hipLaunchKernelGGL(snp_qc_kernel<true>, dim3(grid), dim3(256), 0, 0, a);
+    else
+      hipLaunchKernelGGL(snp_qc_kernel<false>, dim3(grid), dim3(256), 0, 0, a);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipMemcpy(stats.data(), dO.p, stats.size() * 8, hipMemcpyDeviceToHost);
+  cleanup();
+  if (e != hipSuccess) return fail(GEMMA_HIP_ERUNTIME, "snp_qc: %s", hipGetErrorString(e));
+  QcCfgHost q = {cfg->maf_level, cfg->miss_level, cfg->hwe_level, cfg->r2_level};
+  snp_qc_finish(stats.data(), l, (int)n, c, WtW.data(), kind == GEMMA_GENO_PLINK_2BIT, q, indicator_snp, maf, n_miss);
+  return GEMMA_HIP_OK;
+}
+
+// K_loco = (ns_all * K_all - ns_chr * K_chr) / (ns_all - ns_chr)  (LOCO: the kinship of all SNPs not on a
+// chromosome from the all-SNP kinship and the chromosome's own; in place on K_chr_d)
+extern "C" int gemma_hip_kin_loco_d(const double *K_all_d, size_t ns_all, double *K_chr_d, size_t ns_chr, size_t n,
+                                    void *stream) {
+  NEED_INIT();
+  if (!K_all_d || !K_chr_d || n == 0 || ns_all <= ns_chr) return fail(GEMMA_HIP_EINVAL, "kin_loco: bad arguments");
+  const long total = (long)n * (long)n;
+  hipLaunchKernelGGL(loco_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, S(stream), K_all_d, (double)ns_all,
+                     K_chr_d, (double)ns_chr, total);
+  HIPCHK(hipGetLastError());
+  return GEMMA_HIP_OK;
 }
 
 // ------------------------------------------------------------------------------ LMM

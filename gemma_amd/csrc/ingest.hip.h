@@ -181,6 +181,12 @@ __global__ __launch_bounds__(256) void center_update_kernel(double *G, long n, l
   if (j != i) G[j * ld + i] = v;
 }
 
+// leave-one-chromosome-out kinship from the all-SNP and the per-chromosome matrices (in place on Kc)
+__global__ void loco_kernel(const double *__restrict__ Ka, double nsa, double *__restrict__ Kc, double nsc, long total) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < total) Kc[i] = (nsa * Ka[i] - nsc * Kc[i]) / (nsa - nsc);
+}
+
 // eigenvalue post-processing of EigenDecomp_Zeroed (GEMMA src/lapack.cpp:266-277)
 __global__ void zero_small_eval_kernel(double *eval, long n, double *trace) {
   __shared__ double part[16];

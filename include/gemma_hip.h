@@ -97,6 +97,30 @@ int gemma_hip_kin_add_d(int geno_kind, const void *geno_d, size_t l, size_t ld, 
 int gemma_hip_kin_end(double *K /* n_total^2, row-major, full symmetric */, size_t *ns_used);
 int gemma_hip_kin_end_d(double *K_d, size_t *ns_used, void *stream);
 
+/* leave-one-chromosome-out kinship (-loco, src/param.cpp:52-66,497-500): given the kinship of ALL
+ * analysed SNPs (ns_all of them) and of the SNPs on one chromosome (ns_chr), both from kin_begin/add/end_d,
+ * overwrite K_chr_d with the kinship of the remaining SNPs: (ns_all K_all - ns_chr K_chr)/(ns_all - ns_chr). */
+int gemma_hip_kin_loco_d(const double *K_all_d, size_t ns_all, double *K_chr_d, size_t ns_chr, size_t n,
+                         void *stream);
+
+/* ---- first-pass SNP QC ------------------------------------ */
+/* The per-SNP filters of ReadFile_geno (src/gemma_io.cpp:753-853; kind F64_SNP_MAJOR, rows over all ni_total
+ * individuals, NaN = "NA") and ReadFile_bed (:942-1049; kind PLINK_2BIT), statistics over the analysed
+ * individuals only: missingness > miss_level, maf outside [maf_level, 1-maf_level] (skipped when maf_level == -1),
+ * non-polymorphic, HWE exact test p < hwe_level (0 = off), r2 with the covariates > r2_level (only when
+ * n_cvt > 1).  W is the n x n_cvt covariate matrix of the analysed individuals (host, row-major).
+ * indicator_idv may be NULL when ni_total == n.  Outputs (host): indicator_snp[l], maf[l], n_miss[l]
+ * (the latter two may be NULL). */
+typedef struct {
+  double maf_level;  /* 0.01  (src/param.cpp:94-107) */
+  double miss_level; /* 0.05 */
+  double hwe_level;  /* 0 */
+  double r2_level;   /* 0.9999 */
+} gemma_qc_cfg;
+int gemma_hip_snp_qc(int geno_kind, const void *geno, size_t l, size_t ld, const int *indicator_idv,
+                     size_t ni_total, const double *W, size_t n, size_t n_cvt, const gemma_qc_cfg *cfg,
+                     int *indicator_snp, double *maf, size_t *n_miss);
+
 /* ---- B3: centring + eigendecomposition --------------------------------- */
 /* CenterMatrix(gsl_matrix*), src/mathfunc.cpp:147-177 (in place) */
 int gemma_hip_center(double *G, size_t n);

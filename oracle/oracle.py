@@ -294,6 +294,36 @@ def read_bimbam_geno(path):
     return rs, np.array(rows, dtype=np.float64)
 
 
+def calc_hwe(n_hom1, n_hom2, n_ab):
+    """CalcHWE, src/mathfunc.cpp:546-627 (Wigginton et al. 2005 exact test)."""
+    if n_hom1 + n_hom2 + n_ab == 0:
+        return 1.0
+    n_aa, n_bb = min(n_hom1, n_hom2), max(n_hom1, n_hom2)
+    rare = 2 * n_aa + n_ab
+    geno = n_ab + n_bb + n_aa
+    het = np.zeros(rare + 1)
+    mid = (rare * (2 * geno - rare)) // (2 * geno)
+    if (rare & 1) ^ (mid & 1):
+        mid += 1
+    homr, homc = (rare - mid) // 2, geno - mid - (rare - mid) // 2
+    het[mid] = 1.0
+    tot = 1.0
+    h = mid
+    while h > 1:
+        het[h - 2] = het[h] * h * (h - 1.0) / (4.0 * (homr + 1.0) * (homc + 1.0))
+        tot += het[h - 2]
+        homr += 1; homc += 1; h -= 2
+    homr, homc = (rare - mid) // 2, geno - mid - (rare - mid) // 2
+    h = mid
+    while h <= rare - 2:
+        het[h + 2] = het[h] * 4.0 * homr * homc / ((h + 2.0) * (h + 1.0))
+        tot += het[h + 2]
+        homr -= 1; homc -= 1; h += 2
+    het /= tot
+    p = het[het <= het[n_ab]].sum()
+    return min(p, 1.0)
+
+
 def qc_snps(G_all, indicator_idv, W, maf_level=0.01, miss_level=0.05, r2_level=0.9999):
     """First-pass SNP filters of ReadFile_geno, src/gemma_io.cpp:753-853 (hwe off by default),
     statistics over analysed individuals. G_all: p x ni_total with NaN. Returns (indicator_snp, maf,
@@ -359,8 +389,8 @@ def bed_decode(raw_rows, ni_total, indicator=None):
     return out
 
 
-def qc_snps_bed(G_test, W, maf_level=0.01, miss_level=0.05, r2_level=0.9999):
-    """ReadFile_bed filters, src/gemma_io.cpp:942-1049 (hwe off): G_test is p x ni_test with NaN."""
+def qc_snps_bed(G_test, W, maf_level=0.01, miss_level=0.05, r2_level=0.9999, hwe_level=0.0):
+    """ReadFile_bed filters, src/gemma_io.cpp:942-1049: G_test is p x ni_test with NaN."""
     p, ni_test = G_test.shape
     WtWi = np.linalg.inv(W.T @ W)
     ind = np.zeros(p, dtype=np.int32)
@@ -376,6 +406,8 @@ def qc_snps_bed(G_test, W, maf_level=0.01, miss_level=0.05, r2_level=0.9999):
             continue
         n0 = int((obs == 0).sum()); n1 = int((obs == 1).sum()); n2 = int((obs == 2).sum())
         if (n0 + n1) == 0 or (n1 + n2) == 0 or (n2 + n0) == 0:  # :1017-1020
+            continue
+        if hwe_level != 0 and maf_level != -1 and calc_hwe(n0, n2, n1) < hwe_level:  # :1022-1027
             continue
         x = np.where(miss, maf * 2.0, g)
         Wtx = W.T @ x

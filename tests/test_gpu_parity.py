@@ -179,6 +179,59 @@ def test_kinship_plink_and_idv_major(gpu_api, oracle):
     assert np.linalg.norm(K2 - ref) / np.linalg.norm(ref) < 1e-13
 
 
+def test_snp_qc_bimbam_and_plink(gpu_api, oracle):
+    """First-pass SNP filters against the oracle's restatement of ReadFile_geno / ReadFile_bed:
+    missingness, maf, polymorphism, HWE, r2 with covariates -- identical indicator_snp, maf, n_miss."""
+    from gemma_amd import _lib as L
+    rng = np.random.default_rng(8)
+    ni_total, p = 300, 500
+    ind = (rng.random(ni_total) > 0.25).astype(np.int32)
+    n = int(ind.sum())
+    maf = rng.uniform(0.0, 0.5, p)
+    G = rng.binomial(2, maf[:, None], size=(p, ni_total)).astype(np.float64)
+    G[rng.random(G.shape) < rng.uniform(0, 0.1, (p, 1))] = np.nan  # per-SNP missingness up to 10 %
+    G[3] = 1.0                                # monomorphic
+    G[4, ind == 1] = np.nan                   # everything missing among the analysed
+    W = np.hstack([rng.standard_normal((n, 2)), np.ones((n, 1))])
+    G[7, ind == 1] = W[:, 0] * 0.5 + 1.0      # collinear with a covariate -> r2 filter (dosages)
+    ref_i, ref_maf, ref_nm = oracle.qc_snps(G, ind, W)
+    got_i, got_maf, got_nm = gpu_api.SnpQC(G, L.GENO_F64_SNP_MAJOR, ind, W)
+    assert np.array_equal(got_i, ref_i) and 0 < ref_i.sum() < p
+    ok = ~np.isnan(ref_maf)
+    assert np.allclose(got_maf[ok], ref_maf[ok], rtol=1e-14) and np.array_equal(got_nm, ref_nm)
+    assert ref_i[3] == 0 and ref_i[7] == 0
+    # PLINK twin incl. the HWE filter
+    codes = rng.choice([0, 1, 2, 3], size=(p, ni_total), p=[0.3, 0.03, 0.37, 0.3]).astype(np.uint8)
+    codes[10] = np.where(codes[10] == 2, 0, codes[10])  # no heterozygotes: fails HWE
+    nb = (ni_total + 3) // 4
+    pad = np.zeros((p, nb * 4), dtype=np.uint8)
+    pad[:, :ni_total] = codes
+    raw = (pad[:, 0::4] | (pad[:, 1::4] << 2) | (pad[:, 2::4] << 4) | (pad[:, 3::4] << 6)).astype(np.uint8)
+    Gt = oracle.bed_decode(raw, ni_total, ind)
+    for hwe in (0.0, 1e-3):
+        ref = oracle.qc_snps_bed(Gt, W, hwe_level=hwe)
+        got, _, _ = gpu_api.SnpQC(raw, L.GENO_PLINK_2BIT, ind, W, hwe_level=hwe)
+        assert np.array_equal(got, ref)
+    assert ref[10] == 0
+
+
+def test_loco_kinship_and_text_handoff(gpu_api, oracle):
+    """-loco (SURVEY 8f-2): K of all SNPs not on a chromosome == the oracle's kinship of exactly those SNPs;
+    and the 10-significant-digit cXX.txt hand-off emulation."""
+    from gemma_amd import _lib as L
+    rng = np.random.default_rng(12)
+    n, p = 150, 900
+    G = rng.integers(0, 3, size=(p, n)).astype(np.float64)
+    G[rng.random(G.shape) < 0.02] = np.nan
+    chrom = rng.integers(1, 5, size=p)
+    loco = gpu_api.CalcKinLOCO(G, L.GENO_F64_SNP_MAJOR, n, chrom)
+    for ch, K in loco.items():
+        ref = oracle.calc_kin(G[chrom != ch], 1)
+        assert np.linalg.norm(K - ref) / np.linalg.norm(ref) < 1e-12
+    K = gpu_api.CalcKin(G, L.GENO_F64_SNP_MAJOR, n, 1)
+    assert np.array_equal(gpu_api.WriteMatrix10(K), oracle.round10(K))
+
+
 def test_center_matrix(gpu_api, oracle, bxd):
     K = bxd["K_sub"].copy()
     got = gpu_api.CenterMatrix(K.copy())
