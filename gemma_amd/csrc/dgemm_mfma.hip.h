@@ -331,6 +331,31 @@ static inline hipError_t launch_dgemm_grid(const GemmArgs &g, hipStream_t s) {
   return hipGetLastError();
 }
 
+// Optional side stream for the ragged edge strips: they are tiny launches (<= 2 x 157 blocks at n = 20000)
+// that would otherwise run alone after the main grid; on a second stream they fill the main grid's tail.
+struct GemmAux {
+  hipStream_t stream = nullptr;
+  hipEvent_t ready = nullptr, done = nullptr;
+};
+static GemmAux g_gemm_aux;
+static inline void gemm_aux_init() {
+  if (g_gemm_aux.stream) return;
+  if (hipStreamCreateWithFlags(&g_gemm_aux.stream, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreateWithFlags(&g_gemm_aux.ready, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&g_gemm_aux.done, hipEventDisableTiming) != hipSuccess) {
+    (void)hipGetLastError();
+    g_gemm_aux = GemmAux();
+  }
+}
+static inline void gemm_aux_destroy() {
+  if (g_gemm_aux.stream) {
+    (void)hipStreamDestroy(g_gemm_aux.stream);
+    (void)hipEventDestroy(g_gemm_aux.ready);
+    (void)hipEventDestroy(g_gemm_aux.done);
+  }
+  g_gemm_aux = GemmAux();
+}
+
 template <bool A_KM, bool B_KN>
 static inline hipError_t launch_dgemm_t(GemmArgs g, hipStream_t s) {
   const int Tm = (int)((g.M + GEMM_BM - 1) / GEMM_BM), Tn = (int)((g.N + GEMM_BN - 1) / GEMM_BN);
@@ -343,21 +368,41 @@ static inline hipError_t launch_dgemm_t(GemmArgs g, hipStream_t s) {
     g.tiles_m = Tm; g.tiles_n = Tn; g.tm0 = 0; g.tn0 = 0;
     return launch_dgemm_grid<A_KM, B_KN, false>(g, s);
   }
+  const int syrk = g.syrk_upper;
+  const bool strips = (Tn > Fn) || (Tm > Fm && !syrk);
+  const bool side = strips && g_gemm_aux.stream != nullptr && Fm * Fn >= 512;
+  hipStream_t es = side ? g_gemm_aux.stream : s; // stream of the edge strips
+  if (side) {
+    if ((e = hipEventRecord(g_gemm_aux.ready, s)) != hipSuccess) return e;
+    if ((e = hipStreamWaitEvent(es, g_gemm_aux.ready, 0)) != hipSuccess) return e;
+  }
+  GemmArgs ge = g;
+  ge.syrk_upper = 0;
+  if (side) { // strips first on the side stream, the big grid on the caller's stream
+    if (Tn > Fn) { // ragged right strip: all tile rows (SYRK: tm <= Tn-1 is every row)
+      ge.tiles_m = Tm; ge.tiles_n = 1; ge.tm0 = 0; ge.tn0 = Fn;
+      if ((e = launch_dgemm_grid<A_KM, B_KN, false>(ge, es)) != hipSuccess) return e;
+    }
+    if (Tm > Fm && !syrk) { // ragged bottom strip (complete columns only; the corner went with the right strip)
+      ge.tiles_m = 1; ge.tiles_n = Fn; ge.tm0 = Fm; ge.tn0 = 0;
+      if ((e = launch_dgemm_grid<A_KM, B_KN, false>(ge, es)) != hipSuccess) return e;
+    }
+  }
   // complete tiles: predicate-free kernel (SYRK: the upper triangle of the Fm x Fm complete tiles)
   g.tiles_m = Fm; g.tiles_n = Fn; g.tm0 = 0; g.tn0 = 0;
   e = launch_dgemm_grid<A_KM, B_KN, true>(g, s);
   if (e != hipSuccess) return e;
-  const int syrk = g.syrk_upper;
-  g.syrk_upper = 0;
-  if (Tn > Fn) { // ragged right strip: all tile rows (SYRK: tm <= Tn-1 is every row)
-    g.tiles_m = Tm; g.tiles_n = 1; g.tm0 = 0; g.tn0 = Fn;
-    e = launch_dgemm_grid<A_KM, B_KN, false>(g, s);
-    if (e != hipSuccess) return e;
+  if (side) {
+    if ((e = hipEventRecord(g_gemm_aux.done, es)) != hipSuccess) return e;
+    return hipStreamWaitEvent(s, g_gemm_aux.done, 0);
   }
-  if (Tm > Fm && !syrk) { // ragged bottom strip (complete columns only; the corner went with the right strip)
-    g.tiles_m = 1; g.tiles_n = Fn; g.tm0 = Fm; g.tn0 = 0;
-    e = launch_dgemm_grid<A_KM, B_KN, false>(g, s);
-    if (e != hipSuccess) return e;
+  if (Tn > Fn) {
+    ge.tiles_m = Tm; ge.tiles_n = 1; ge.tm0 = 0; ge.tn0 = Fn;
+    if ((e = launch_dgemm_grid<A_KM, B_KN, false>(ge, s)) != hipSuccess) return e;
+  }
+  if (Tm > Fm && !syrk) {
+    ge.tiles_m = 1; ge.tiles_n = Fn; ge.tm0 = Fm; ge.tn0 = 0;
+    if ((e = launch_dgemm_grid<A_KM, B_KN, false>(ge, s)) != hipSuccess) return e;
   }
   return hipSuccess;
 }

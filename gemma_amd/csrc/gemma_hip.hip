@@ -186,6 +186,7 @@ extern "C" int gemma_hip_init(int device, int verbose) {
                 g_ctx.prop.gcnArchName);
   g_ctx.device = cur;
   g_ctx.inited = true;
+  gemm_aux_init();
   if (verbose)
     fprintf(stderr, "gemma_hip: device %d %s (%s), %d CUs, %.1f GB\n", cur, g_ctx.prop.name,
             g_ctx.prop.gcnArchName, g_ctx.prop.multiProcessorCount,
@@ -202,6 +203,7 @@ extern "C" void gemma_hip_shutdown(void) {
   g_ctx.UtWt.release(); g_ctx.idx_map.release(); g_ctx.X.release(); g_ctx.UtX.release();
   g_ctx.stage_in.release(); g_ctx.stage_out.release(); g_ctx.carry.release(); g_ctx.scratch.release();
   g_ctx.kin_active = g_ctx.lmm_active = false;
+  gemm_aux_destroy();
   g_ctx.inited = false;
 }
 

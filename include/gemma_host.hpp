@@ -168,6 +168,81 @@ inline bool BimbamKin(const std::string file_geno, std::vector<int> &indicator_s
   return true;
 }
 
+// PARAM::WriteMatrix / WriteVector, src/param.cpp:1886-1935: tab-separated text, precision(10)
+inline bool WriteMatrix(const Matrix *M, const std::string &file_str) {
+  std::ofstream outfile(file_str.c_str(), std::ofstream::out);
+  if (!outfile) {
+    std::cout << "error writing file: " << file_str << std::endl;
+    return false;
+  }
+  outfile.precision(10);
+  for (size_t i = 0; i < M->size1; ++i) {
+    for (size_t j = 0; j < M->size2; ++j) outfile << (j ? "\t" : "") << M->data[i * M->tda + j];
+    outfile << std::endl;
+  }
+  return true;
+}
+inline bool WriteVector(const Vector *v, const std::string &file_str) {
+  std::ofstream outfile(file_str.c_str(), std::ofstream::out);
+  if (!outfile) {
+    std::cout << "error writing file: " << file_str << std::endl;
+    return false;
+  }
+  outfile.precision(10);
+  for (size_t i = 0; i < v->size; ++i) outfile << v->data[i * v->stride] << std::endl;
+  return true;
+}
+
+// ReadFile_kin (k_mode == 1), src/gemma_io.cpp:1186-1243: dense ni_total x ni_total text; rows/columns of
+// non-analysed individuals are dropped.  error is set exactly where the reference fails.
+inline void ReadFile_kin(const std::string &file_kin, std::vector<int> &indicator_idv, bool &error, Matrix *G) {
+  std::ifstream infile(file_kin.c_str());
+  if (!infile) {
+    std::cout << "error! fail to open kinship file: " << file_kin << std::endl;
+    error = true;
+    return;
+  }
+  const size_t ni_total = indicator_idv.size();
+  for (size_t i = 0; i < G->size1; ++i)
+    for (size_t j = 0; j < G->size2; ++j) G->data[i * G->tda + j] = 0.0;
+  std::string line;
+  size_t i_test = 0, i_total = 0;
+  while (std::getline(infile, line)) {
+    if (i_total == ni_total) {
+      std::cout << "number of rows in the kinship file is larger than the number of phenotypes" << std::endl;
+      error = true;
+      return;
+    }
+    if (indicator_idv[i_total] == 0) {
+      i_total++;
+      continue;
+    }
+    size_t j_total = 0, j_test = 0;
+    char *save = nullptr;
+    for (char *tok = strtok_r(&line[0], " ,\t", &save); tok; tok = strtok_r(nullptr, " ,\t", &save)) {
+      if (j_total == ni_total) {
+        error = true;
+        return;
+      }
+      const double d = atof(tok);
+      if (indicator_idv[j_total] == 1) G->data[i_test * G->tda + j_test++] = d;
+      j_total++;
+    }
+    if (j_total != ni_total) {
+      std::cout << "number of columns in the kinship file does not match the number of individuals for row = "
+                << i_total << std::endl;
+      error = true;
+      return;
+    }
+    i_total++;
+    i_test++;
+  }
+  if (i_total != ni_total) {
+    std::cout << "number of rows in the kinship file does not match the number of individuals." << std::endl;
+    error = true;
+  }
+}
+
 // null model: CalcLambda(func, eval, UtW, Uty, ...) src/lmm.cpp:2143-2180 + CalcPve :2183-2205
 struct NullModel {
   double l_mle_null, logl_mle_H0, l_remle_null, logl_remle_H0, pve_null, pve_se_null, vg_remle_null, ve_remle_null;

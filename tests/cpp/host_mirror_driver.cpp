@@ -43,18 +43,15 @@ int main(int argc, char **argv) {
     Matrix K = matrix_view(Kbuf.data(), ni_total, ni_total);
     if (!PlinkKin(prefix + ".bed", indicator_snp, 1, 0, &K)) return 3;
 
-    // -lmm: sub-select analysed individuals (ReadFile_kin, src/gemma_io.cpp:1205-1243), centre, eigen
+    // the two-run hand-off: cXX.txt at 10 significant digits (src/gemma.cpp:1919), read back with the
+    // non-analysed individuals dropped (ReadFile_kin, src/gemma_io.cpp:1205-1243); then centre, eigen
+    const std::string cxx = std::string(argv[6]) + "/" + argv[7] + ".cXX.txt";
+    if (!WriteMatrix(&K, cxx)) return 3;
     std::vector<double> Gbuf(ni_test * ni_test), Ubuf(ni_test * ni_test), evalbuf(ni_test);
-    for (size_t i = 0, it = 0; i < ni_total; ++i) {
-      if (!indicator_idv[i]) continue;
-      for (size_t j = 0, jt = 0; j < ni_total; ++j) {
-        if (!indicator_idv[j]) continue;
-        Gbuf[it * ni_test + jt] = Kbuf[i * ni_total + j];
-        ++jt;
-      }
-      ++it;
-    }
     Matrix G = matrix_view(Gbuf.data(), ni_test, ni_test), U = matrix_view(Ubuf.data(), ni_test, ni_test);
+    bool error = false;
+    ReadFile_kin(cxx, indicator_idv, error, &G);
+    if (error) return 3;
     Vector eval = vector_view(evalbuf.data(), ni_test);
     CenterMatrix(&G);
     const double trace_G = EigenDecomp_Zeroed(&G, &U, &eval, 0);

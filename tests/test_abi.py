@@ -67,3 +67,18 @@ def test_shard_range_covers_everything():
             assert got[0][0] == 0 and got[-1][1] == p
             for a, b in zip(got, got[1:]):
                 assert a[1] == b[0]
+
+
+def test_cpp_host_mirror_compiles():
+    """include/gemma_host.hpp (the C++ mirror of fast_dgemm / PlinkKin / class LMM ...) and its test driver
+    build against the library with plain g++ (no GPU, no GSL)."""
+    import subprocess
+    import tempfile
+    so = _built()
+    with tempfile.TemporaryDirectory() as td:
+        subprocess.check_call(["g++", "-std=c++11", "-O1", "-Wall", "-I" + os.path.join(ROOT, "include"),
+                               os.path.join(ROOT, "tests", "cpp", "host_mirror_driver.cpp"),
+                               "-L" + os.path.dirname(so), "-lgemma_hip", "-Wl,-rpath," + os.path.dirname(so),
+                               "-o", os.path.join(td, "drv")])
+        r = subprocess.run([os.path.join(td, "drv")], capture_output=True)
+        assert r.returncode == 2  # usage error, before any GPU call

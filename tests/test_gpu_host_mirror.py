@@ -46,8 +46,10 @@ def test_cpp_host_mirror_plink_end_to_end(tmp_path, oracle, mode):
     out = subprocess.run([exe, prefix, str(ni_total), str(ns), prefix + ".pheno", str(mode), str(tmp_path), "res"],
                          capture_output=True, text=True)
     assert out.returncode == 0, out.stderr + out.stdout
-    # oracle: the same BatchRun sequence (in-process K, no 10-digit hand-off)
-    K = oracle.calc_kin(G_all, 1)
+    # oracle: the same two-run sequence, K through the 10-significant-digit cXX.txt
+    K = oracle.round10(oracle.calc_kin(G_all, 1))
+    Kfile = np.loadtxt(tmp_path / "res.cXX.txt")
+    assert Kfile.shape == (ni_total, ni_total) and np.allclose(Kfile, K, rtol=2e-10, atol=1e-12)
     W = np.ones((int(ind.sum()), 1))
     st, null, _ = oracle.run_lmm(mode, G_all, ind, np.ones(ns, dtype=np.int32), y_all, W, K)
     lines = open(tmp_path / "res.assoc.txt").read().strip().split("\n")

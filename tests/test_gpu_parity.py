@@ -391,6 +391,50 @@ def test_lmm_eigenvector_sign_invariance(gpu_api, oracle):
         assert np.array_equal(base[k][perm], shuf[k], equal_nan=True)
 
 
+def _nan_aware_close(got, ref, rtol):
+    for k in ref.dtype.names:
+        g, r = got[k], ref[k]
+        assert np.array_equal(np.isnan(g), np.isnan(r)), (k, g, r)
+        ok = ~np.isnan(r)
+        assert np.allclose(g[ok], r[ok], rtol=rtol, atol=1e-300), (k, g[ok], r[ok])
+
+
+@pytest.mark.parametrize("n", [5, 63, 64, 65, 129, 1001])
+def test_lmm_degenerate_snps_and_odd_sizes(gpu_api, oracle, n):
+    """Edge cases of the per-SNP loop (src/lmm.cpp:1590-1618): an all-missing SNP (mean = 0/0 -> NaN
+    everywhere), a monomorphic SNP (x collinear with the intercept: P_xx == 0), a SNP with one observed
+    call, single-SNP blocks, n below / at / just above one wavefront, odd n (ragged 16-byte rows)."""
+    from gemma_amd import _lib as L
+    rng = np.random.default_rng(n)
+    p = 12
+    G = rng.integers(0, 3, size=(p, n)).astype(np.float64)
+    G[0] = np.nan
+    G[1] = 2.0
+    G[2] = np.nan
+    G[2, n // 2] = 1.0
+    G[3, ::2] = np.nan
+    Kg = rng.integers(0, 3, size=(3 * n + 20, n)).astype(np.float64)
+    U, ev, _ = oracle.eigen_decomp_zeroed(oracle.center_matrix(oracle.calc_kin(Kg, 1)))
+    y = rng.standard_normal(n)
+    UtW, Uty = U.T @ np.ones((n, 1)), U.T @ y
+    l_mle, logl0 = oracle.calc_lambda_null("L", ev, UtW, Uty)
+    for mode in (1, 4):
+        ref = oracle.lmm_analyze(mode, U, ev, UtW, Uty, G, l_mle_null=l_mle, logl_mle_H0=logl0)
+        lmm = gpu_api.LMM(a_mode=mode, l_mle_null=l_mle, logl_mle_H0=logl0)
+        lmm.setup(U, ev, UtW, Uty)
+        got = np.concatenate([lmm.batch(G[s:s + 1], L.GENO_F64_SNP_MAJOR) for s in range(p)])  # l = 1 blocks
+        lmm.finish()
+        assert np.isnan(got["beta"][0]) and np.isnan(ref["beta"][0])  # all-missing SNP
+        # rows 1 (monomorphic) and 2 (a single observed call) are collinear with the intercept: P_xx is pure
+        # rounding noise and every statistic is 0/0-like in the reference too -- only required not to crash;
+        # row 0 (all missing) must be NaN on both sides; all other rows to the usual bar
+        well = np.ones(p, dtype=bool)
+        well[[0, 1, 2]] = False
+        _nan_aware_close(got[well], ref[well], 1e-3 if n < 10 else 2e-5)
+        for k in ("beta", "se", "p_wald", "logl_H1"):
+            assert np.isnan(got[k][0]) and np.isnan(ref[k][0])
+
+
 def test_lmm_state_errors(gpu_api):
     from gemma_amd import _lib as L
     lmm = gpu_api.LMM(a_mode=1)
