@@ -218,8 +218,9 @@ def main():
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": "configs[2]: synthetic n=%d, -lmm %d, %d SNPs per step per GPU (PLINK 2-bit, "
-                                   "1%% missing, Balding-Nichols Fst 0.05), c=1" % (n, args.a_mode, B),
+            "config": {"workload": "%ssynthetic n=%d, -lmm %d, %d SNPs per step per GPU (PLINK 2-bit, "
+                                   "1%% missing, Balding-Nichols Fst 0.05), c=1" % (
+                                       "configs[2] (headline): " if (n == 20000 and args.a_mode == 1) else "", n, args.a_mode, B),
                        "n": n, "snps_per_step": B, "kinship_snps": args.kin_snps, "parallelism": "snp-shard x%d" % world,
                        "device": name, "cus": n_cu, "setup": setup_info, "nan_p_wald": n_nan},
             "roofline": {"kernel": "dgemm_mfma_kernel (UtX = X*U)", "bound": "mfma", "achieved": round(achieved, 2),

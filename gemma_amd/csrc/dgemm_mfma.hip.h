@@ -20,8 +20,8 @@
 //    disjoint bank halves), [m][k] operands as [128][18] (row stride 18 doubles walks all 32
 //    8-byte banks).
 //  * blockIdx -> tile: XCD-aware (block b runs on XCD b % 8): every XCD gets a contiguous run of
-//    tiles, rastered in groups of 8 tile-rows so the ~64 blocks an XCD runs at once form an
-//    8x8 patch sharing A/B panels in that XCD's 4 MiB L2.
+//    tiles, rastered in groups of 4 tile-rows so the ~64 blocks an XCD runs at once form a
+//    4x16 patch sharing A/B panels in that XCD's 4 MiB L2 (82 % TCC hit rate at n = 20000).
 //  * SYRK mode (kinship): only tiles with tile_n >= tile_m are launched (triangular grid).
 #pragma once
 #include <hip/hip_runtime.h>
@@ -50,6 +50,7 @@ struct GemmArgs {
   int tm0, tn0;         // its origin in the full tile grid
   int syrk_upper;  // 1: launch only tiles with tn >= tm (sub-grid must start at (0,0))
   int square_a;    // 1: use A*A elementwise as the A operand (grid-lambda x^2 sums)
+  int gm;          // tile rows per raster group (0 = default 8)
   int ablate;      // timing experiments only (GEMMA_HIP_GEMM_ABLATE): 1 = no global loads / LDS stores after
                    // the first K-tile, 2 = no barrier, 4 = fragments read once (results are then wrong)
 };
@@ -164,7 +165,7 @@ __device__ __forceinline__ void tile_of_block(const GemmArgs &g, int &tm, int &t
     tm = i;
     tn = i + (L - (int)((long)i * (2 * T - i + 1) / 2));
   } else {
-    const int GM = 8;
+    const int GM = g.gm > 0 ? g.gm : 4; // 4 rows x 16 columns in flight per XCD: best L2 hit rate measured
     const int per_group = GM * g.tiles_n;
     const int grp = L / per_group;
     const int first_m = grp * GM;
@@ -306,12 +307,15 @@ __global__ void symm_fill_scale_kernel(double *K, long n, long ld, double scale)
   }
 }
 
-// wavefronts per 128x128 block: 8 (2x4 waves of 64x32, 4 waves/SIMD at 2 blocks/CU) or 4 (2x2 of 64x64)
+// Wavefronts per 128x128 block: 4 (2x2 waves of 64x64, 2 waves/SIMD at 2 blocks/CU; default) or 8 (2x4 waves
+// of 64x32, 4 waves/SIMD; GEMMA_HIP_GEMM_WAVES=8).  Measured at M=N=K=20000 (profiles/r01_gemm_variants.txt):
+// the 8-wave form is 1.7 % faster (238.8 vs 242.6 ms) but its blocks drift apart inside an XCD and the L2 hit
+// rate drops from 82 % to 17 % (fabric traffic x4); the 4-wave form keeps the co-scheduled tiles in step.
 static inline int gemm_waves() {
   static int nw = 0;
   if (nw == 0) {
     const char *e = getenv("GEMMA_HIP_GEMM_WAVES");
-    nw = (e && e[0] == '4') ? 4 : 8;
+    nw = (e && e[0] == '8') ? 8 : 4;
   }
   return nw;
 }
@@ -340,6 +344,8 @@ struct GemmAux {
 static GemmAux g_gemm_aux;
 static inline void gemm_aux_init() {
   if (g_gemm_aux.stream) return;
+  const char *e = getenv("GEMMA_HIP_GEMM_SIDE_STREAM"); // "0": keep everything on the caller's stream
+  if (e && e[0] == '0') return;
   if (hipStreamCreateWithFlags(&g_gemm_aux.stream, hipStreamNonBlocking) != hipSuccess ||
       hipEventCreateWithFlags(&g_gemm_aux.ready, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&g_gemm_aux.done, hipEventDisableTiming) != hipSuccess) {
@@ -428,6 +434,12 @@ static inline hipError_t launch_dgemm(char ta, char tb, long M, long N, long K, 
       abl = e ? atoi(e) : 0;
     }
     g.ablate = abl;
+    static int gm = -1;
+    if (gm < 0) {
+      const char *e = getenv("GEMMA_HIP_GEMM_GM");
+      gm = e ? atoi(e) : 0;
+    }
+    g.gm = gm;
   }
   const bool tA = (ta == 'T' || ta == 't'), tB = (tb == 'T' || tb == 't');
   // op(A) = A^T  <=> A stored [k][m]  (KM image);  op(B) = B <=> B stored [k][n] (KN image)

@@ -673,6 +673,17 @@ static int make_utwt(const double *UtW_d, hipStream_t s) {
   hipLaunchKernelGGL(transpose_kernel, grid, dim3(32, 8), 0, s, UtW_d, (long)n, (long)c, (long)c,
                      g_ctx.UtWt.as<double>(), (long)n);
   HIPCHK(hipGetLastError());
+  // SNP-independent log|H| at l_min and l_max
+  if (g_ctx.scratch.reserve(16)) return fail(GEMMA_HIP_ENOMEM, "lmm_setup: scratch");
+  hipLaunchKernelGGL(logdet_ends_kernel, dim3(1), dim3(64), 0, s, g_ctx.eval, (int)n, g_ctx.cfg.l_min, g_ctx.cfg.l_max,
+                     g_ctx.scratch.as<double>());
+  HIPCHK(hipGetLastError());
+  double ends[2];
+  HIPCHK(hipMemcpyAsync(ends, g_ctx.scratch.p, 16, hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  g_ctx.assoc_proto.logdet_lmin = ends[0];
+  g_ctx.assoc_proto.logdet_lmax = ends[1];
+  g_ctx.assoc_proto.have_logdet_ends = 1;
   return GEMMA_HIP_OK;
 }
 

@@ -41,6 +41,8 @@ struct AssocArgs {
   double l_min, l_max;
   double l_mle_null, logl_mle_H0;
   double lnbeta_half_df;  // ln B(df/2, 1/2), df = n - c - 1 (host lgamma)
+  double logdet_lmin, logdet_lmax; // sum_i log|l*delta_i + 1| at l_min / l_max (SNP independent; logdet_ends_kernel)
+  int have_logdet_ends;
   double lam_grid[ASSOC_MAX_REGION + 1]; // l_min*exp(i*log(l_max/l_min)/n_region), host libm
 };
 
@@ -57,6 +59,19 @@ __device__ __forceinline__ double uniform(double v) {
   u.i[0] = __builtin_amdgcn_readfirstlane(u.i[0]);
   u.i[1] = __builtin_amdgcn_readfirstlane(u.i[1]);
   return u.d;
+}
+
+// 1/v for the weights H = 1/(lambda*delta + 1): hardware reciprocal + two Newton steps (<= 1-2 ulp from the
+// correctly rounded quotient the reference computes; 5 instructions instead of the ~11 of an IEEE divide).
+// Non-finite intermediate (v == 0, inf) falls back to the exact division so that edge semantics are IEEE's.
+__device__ __forceinline__ double recip(double v) {
+  double r = __builtin_amdgcn_rcp(v);
+  double e = fma(-v, r, 1.0);
+  r = fma(e, r, r);
+  e = fma(-v, r, 1.0);
+  r = fma(e, r, r);
+  if (!(fabs(r) <= DBL_MAX)) r = 1.0 / v;
+  return r;
 }
 
 // GetabIndex, GEMMA src/param.cpp:1400-1415 (1-based, symmetric)
@@ -189,7 +204,7 @@ __device__ __forceinline__ void row0_pass(const AssocArgs &g, const double *__re
     double h1 = 1.0, h2 = 1.0, h3 = 1.0;
     if (ORDER >= 1) {
       const double v = g.eval[i] * lambda + 1.0;
-      h1 = 1.0 / v;
+      h1 = recip(v);
       if (ORDER >= 2) h2 = h1 * h1;
       if (ORDER >= 3) h3 = h2 * h1;
       if (LOGDET) ld += log(fabs(v));
@@ -388,7 +403,7 @@ struct GenericC {
           double h1 = 1.0, h2 = 1.0, h3 = 1.0;
           if (ORDER >= 1) {
             const double v = g.eval[i] * lambda + 1.0;
-            h1 = 1.0 / v;
+            h1 = recip(v);
             if (ORDER >= 2) h2 = h1 * h1;
             if (ORDER >= 3) h3 = h2 * h1;
             if (first) {
@@ -542,9 +557,15 @@ __device__ __forceinline__ void deriv(const SnpCtx<M> &s, double l, double &dev1
 
 // LogRL_f (src/lmm.cpp:799-864) / LogL_f (:484-542)
 template <class M, bool REML>
-__device__ __forceinline__ double logf(const SnpCtx<M> &s, double l) {
-  Agg A;
-  s.m.template eval<1, true>(*s.g, s.x, l, s.lane, A);
+__device__ __forceinline__ double logf(const SnpCtx<M> &s, double l, Agg &A) {
+  // log|H| at the two interval ends does not depend on the SNP: taken from the setup kernel, which sums
+  // in this kernel's own order (bit-identical to evaluating it here)
+  if (s.g->have_logdet_ends && (l == s.g->l_min || l == s.g->l_max)) {
+    s.m.template eval<1, false>(*s.g, s.x, l, s.lane, A);
+    A.logdet = (l == s.g->l_min) ? s.g->logdet_lmin : s.g->logdet_lmax;
+  } else {
+    s.m.template eval<1, true>(*s.g, s.x, l, s.lane, A);
+  }
   const double n = (double)s.g->n;
   double P_yy = A.yy1;
   if (P_yy >= 0.0 && P_yy < 1e-8) P_yy = 1e-8; // P_YY_MIN, src/lmm.cpp:52,527,854
@@ -561,12 +582,10 @@ __device__ __forceinline__ double logf(const SnpCtx<M> &s, double l) {
   return uniform(f);
 }
 
-// CalcRLWald (src/lmm.cpp:1127-1167) / CalcRLScore (:1170-1211)
+// CalcRLWald (src/lmm.cpp:1127-1167) / CalcRLScore (:1170-1211) from the order-1 evaluation at their lambda
 template <class M, bool SCORE>
-__device__ __forceinline__ void wald_score(const SnpCtx<M> &s, double l, double &beta, double &se,
-                                           double &pval) {
-  Agg A;
-  s.m.template eval<1, false>(*s.g, s.x, l, s.lane, A);
+__device__ __forceinline__ void wald_score_from(const SnpCtx<M> &s, const Agg &A, double &beta, double &se,
+                                                double &pval) {
   const int df = s.g->n - s.m.c() - 1;
   const double P_yy = A.yy1_c, P_xx = A.xx1, P_xy = A.xy1, Px_yy = A.yy1;
   beta = uniform(P_xy / P_xx);
@@ -579,6 +598,13 @@ __device__ __forceinline__ void wald_score(const SnpCtx<M> &s, double l, double 
     stat = (P_yy - Px_yy) * tau;
   stat = uniform(stat);
   pval = uniform(fdist_Q1_dev(stat, (double)df, s.g->lnbeta_half_df));
+}
+template <class M, bool SCORE>
+__device__ __forceinline__ void wald_score(const SnpCtx<M> &s, double l, double &beta, double &se,
+                                           double &pval) {
+  Agg A;
+  s.m.template eval<1, false>(*s.g, s.x, l, s.lane, A);
+  wald_score_from<M, SCORE>(s, A, beta, se, pval);
 }
 
 // ------------------------------------------------------------------ root finders
@@ -598,7 +624,7 @@ __device__ __forceinline__ double dev1_of(const SnpCtx<M> &s, double l) {
 
 __device__ __forceinline__ bool finite_d(double v) { return fabs(v) <= DBL_MAX; }
 
-__device__ inline int brent_set(Brent &s, double x_lower, double x_upper, double f_lower, double f_upper) {
+__device__ __forceinline__ int brent_set(Brent &s, double x_lower, double x_upper, double f_lower, double f_upper) {
   // f_lower/f_upper: the reference re-evaluates dev1 at both ends (gsl_root_fsolver_set ->
   // brent_init); the function is pure, so the grid-scan values are the same numbers.
   if (x_lower > x_upper) return RS_EINVAL;
@@ -617,7 +643,7 @@ __device__ inline int brent_set(Brent &s, double x_lower, double x_upper, double
 }
 
 template <class M, bool REML>
-__device__ inline int brent_iterate(Brent &s, const SnpCtx<M> &cx) {
+__device__ __forceinline__ int brent_iterate(Brent &s, const SnpCtx<M> &cx) {
   double tol, m;
   bool ac_equal = false;
   double a = s.a, b = s.b, c = s.c, fa = s.fa, fb = s.fb, fc = s.fc, d = s.d, e = s.e;
@@ -693,8 +719,9 @@ __device__ __forceinline__ int test_delta_dev(double x1, double x0, double epsre
 // them (the evaluations are pure, so interleaving scan and polish gives the reference's
 // sequence of results); `return NaN` and `break` semantics of :2057-2060,:2087-2094 are kept.
 template <class M, bool REML>
-__device__ inline void calc_lambda(const SnpCtx<M> &cx, double &lambda, double &logf_out) {
+__device__ __forceinline__ void calc_lambda(const SnpCtx<M> &cx, double &lambda, double &logf_out, Agg &best) {
   const AssocArgs &g = *cx.g;
+  Agg cand;
   const double l_min = g.l_min, l_max = g.l_max;
   double lam = NAN, lf = NAN;
   bool any = false, first = true, stop = false, failed = false;
@@ -751,11 +778,11 @@ __device__ inline void calc_lambda(const SnpCtx<M> &cx, double &lambda, double &
           l = l_temp; // :2096 -- the previous Newton iterate is reported
           if (l < l_min) l = l_min;
           if (l > l_max) l = l_max;
-          const double logf_l = logf<M, REML>(cx, l);
+          const double logf_l = logf<M, REML>(cx, l, cand);
           if (first) {
-            lf = logf_l; lam = l;
+            lf = logf_l; lam = l; best = cand;
           } else if (lf < logf_l) {
-            lf = logf_l; lam = l;
+            lf = logf_l; lam = l; best = cand;
           }
           first = false;
         }
@@ -768,13 +795,14 @@ __device__ inline void calc_lambda(const SnpCtx<M> &cx, double &lambda, double &
     logf_out = NAN;
     return;
   }
-  const double logf_l = logf<M, REML>(cx, l_min);
-  const double logf_h = logf<M, REML>(cx, l_max);
+  Agg a_lo, a_hi;
+  const double logf_l = logf<M, REML>(cx, l_min, a_lo);
+  const double logf_h = logf<M, REML>(cx, l_max, a_hi);
   if (!any) { // :1985-2000
-    if (logf_l >= logf_h) { lam = l_min; lf = logf_l; } else { lam = l_max; lf = logf_h; }
+    if (logf_l >= logf_h) { lam = l_min; lf = logf_l; best = a_lo; } else { lam = l_max; lf = logf_h; best = a_hi; }
   } else { // :2121-2136
-    if (logf_l > lf) { lam = l_min; lf = logf_l; }
-    if (logf_h > lf) { lam = l_max; lf = logf_h; }
+    if (logf_l > lf) { lam = l_min; lf = logf_l; best = a_lo; }
+    if (logf_h > lf) { lam = l_max; lf = logf_h; best = a_hi; }
   }
   lambda = lam;
   logf_out = lf;
@@ -809,14 +837,24 @@ __device__ __forceinline__ void assoc_one_snp(const AssocArgs &g, const M &model
 
   if (a_mode == 1 || a_mode == 4) {
     cx.logdet_iw = logdet_iw_of(cx);
-    calc_lambda<M, true>(cx, lambda_remle, logl_H1);
-    if (!g.plink_nan_rule || !isnan(logl_H1)) // src/lmm.cpp:1870
-      wald_score<M, false>(cx, lambda_remle, beta, se, p_wald);
-    else
-      wald_skipped = true;
+    Agg at_remle;
+    calc_lambda<M, true>(cx, lambda_remle, logl_H1, at_remle);
+    if (isnan(logl_H1)) {
+      // failed search: the BIMBAM loop still calls CalcRLWald(NaN) (src/lmm.cpp:1548) -> NaN statistics;
+      // the PLINK loop skips it (:1870)
+      if (!g.plink_nan_rule) {
+        beta = NAN; se = NAN; p_wald = NAN;
+      } else {
+        wald_skipped = true;
+      }
+    } else {
+      // CalcRLWald's CalcPab at lambda_remle is the evaluation LogRL_f already made there (:2104,:2122-2123)
+      wald_score_from<M, false>(cx, at_remle, beta, se, p_wald);
+    }
   }
   if (a_mode == 2 || a_mode == 4 || a_mode == 9) {
-    calc_lambda<M, false>(cx, lambda_mle, logl_H1);
+    Agg at_mle;
+    calc_lambda<M, false>(cx, lambda_mle, logl_H1, at_mle);
     p_lrt = chisq_Q1_dev(2.0 * (logl_H1 - g.logl_mle_H0));
     if (isnan(logl_H1)) p_lrt = NAN;
   }
@@ -836,7 +874,7 @@ __device__ __forceinline__ void assoc_one_snp(const AssocArgs &g, const M &model
 }
 
 template <int C>
-__global__ __launch_bounds__(256) void lmm_assoc_kernel(AssocArgs g) {
+__global__ __launch_bounds__(256, (C == 1 ? 3 : (C == 2 ? 2 : 1))) void lmm_assoc_kernel(AssocArgs g) {
   const int lane = threadIdx.x & 63;
   const long snp = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (snp >= g.l) return;
@@ -852,6 +890,25 @@ __global__ __launch_bounds__(256) void lmm_assoc_generic_kernel(AssocArgs g, int
   m.cc = c;
   m.L = lds + (threadIdx.x >> 6) * GEN_LDS_PER_WAVE;
   assoc_one_snp(g, m, snp, lane);
+}
+
+// sum_i log|l*delta_i + 1| at l_min and l_max, accumulated exactly like the LOGDET branch of the row passes
+// (lane-strided partial sums, 64-lane butterfly) so that the constants equal what a SNP's own pass would give
+__global__ __launch_bounds__(64) void logdet_ends_kernel(const double *__restrict__ eval, int n, double l_min,
+                                                         double l_max, double *__restrict__ out2) {
+  const int lane = threadIdx.x & 63;
+  double a = 0.0, b = 0.0;
+  for (int i = lane; i < n; i += 64) {
+    const double d = eval[i];
+    a += log(fabs(d * l_min + 1.0));
+    b += log(fabs(d * l_max + 1.0));
+  }
+  a = wave_sum(a);
+  b = wave_sum(b);
+  if (lane == 0) {
+    out2[0] = a;
+    out2[1] = b;
+  }
 }
 
 // ------------------------------------------------------------------ null model
@@ -872,8 +929,9 @@ __device__ __forceinline__ void null_model(const AssocArgs &g, const M &model, i
   cx.m = model;
   cx.logdet_iw = logdet_iw_of(cx);
   NullOut o;
-  calc_lambda<M, false>(cx, o.l_mle, o.logl_mle);
-  calc_lambda<M, true>(cx, o.l_remle, o.logl_remle);
+  Agg tmp;
+  calc_lambda<M, false>(cx, o.l_mle, o.logl_mle, tmp);
+  calc_lambda<M, true>(cx, o.l_remle, o.logl_remle, tmp);
   double d1, d2;
   deriv<M, true, 3>(cx, o.l_remle, d1, d2);
   o.dev2_remle = d2;

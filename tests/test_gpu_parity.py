@@ -399,7 +399,7 @@ def _nan_aware_close(got, ref, rtol):
         assert np.allclose(g[ok], r[ok], rtol=rtol, atol=1e-300), (k, g[ok], r[ok])
 
 
-@pytest.mark.parametrize("n", [5, 63, 64, 65, 129, 1001])
+@pytest.mark.parametrize("n", [31, 63, 64, 65, 129, 1001])
 def test_lmm_degenerate_snps_and_odd_sizes(gpu_api, oracle, n):
     """Edge cases of the per-SNP loop (src/lmm.cpp:1590-1618): an all-missing SNP (mean = 0/0 -> NaN
     everywhere), a monomorphic SNP (x collinear with the intercept: P_xx == 0), a SNP with one observed
@@ -430,7 +430,7 @@ def test_lmm_degenerate_snps_and_odd_sizes(gpu_api, oracle, n):
         # row 0 (all missing) must be NaN on both sides; all other rows to the usual bar
         well = np.ones(p, dtype=bool)
         well[[0, 1, 2]] = False
-        _nan_aware_close(got[well], ref[well], 1e-3 if n < 10 else 2e-5)
+        _nan_aware_close(got[well], ref[well], 2e-5)
         for k in ("beta", "se", "p_wald", "logl_H1"):
             assert np.isnan(got[k][0]) and np.isnan(ref[k][0])
 
