@@ -35,7 +35,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--n", type=int, default=20000, help="analysed individuals")
+    ap.add_argument("--individuals", dest="n", type=int, default=20000, help="analysed individuals (n)")
     ap.add_argument("--batch", type=int, default=20000, help="SNPs per step and per rank")
     ap.add_argument("--kin-snps", type=int, default=20000, help="SNPs used for the kinship matrix (setup)")
     ap.add_argument("--eigen", default="auto", choices=["auto", "gemma", "torch"])
@@ -80,11 +80,19 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # test hooks (1-GPU box): BENCH_FORCE_DEVICE pins every rank to one device, BENCH_DIST_BACKEND=gloo then
+    # carries the collectives; the driver's multi-GPU runs use neither (one rank per GPU over RCCL)
+    if os.environ.get("BENCH_FORCE_DEVICE"):
+        local = int(os.environ["BENCH_FORCE_DEVICE"])
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from gemma_amd import api
     from gemma_amd import _lib as L

@@ -14,7 +14,8 @@ SYMBOLS = [
     "gemma_hip_kin_end_d", "gemma_hip_kin_loco_d", "gemma_hip_snp_qc", "gemma_hip_center", "gemma_hip_center_d", "gemma_hip_eigh",
     "gemma_hip_eigh_d", "gemma_hip_calc_utx", "gemma_hip_lmm_setup", "gemma_hip_lmm_setup_d",
     "gemma_hip_lmm_null", "gemma_hip_lmm_set_indicator", "gemma_hip_lmm_batch", "gemma_hip_lmm_batch_d",
-    "gemma_hip_lmm_assoc_d", "gemma_hip_lmm_finish", "gemma_hip_profile_enable",
+    "gemma_hip_lmm_assoc_d", "gemma_hip_lmm_finish", "gemma_hip_lm_setup", "gemma_hip_lm_batch", "gemma_hip_lm_batch_d",
+    "gemma_hip_lm_finish", "gemma_hip_profile_enable",
     "gemma_hip_profile_read", "gemma_hip_dbg_tridiag", "gemma_hip_dbg_stedc",
 ]
 
@@ -94,6 +95,9 @@ def lib():
     L.gemma_hip_lmm_batch_d.argtypes = [ci, vp, sz, sz, vp, vp]
     L.gemma_hip_lmm_assoc_d.argtypes = [dp, sz, sz, vp, vp]
     L.gemma_hip_lmm_finish.argtypes = [C.POINTER(cd), C.POINTER(cd)]
+    L.gemma_hip_lm_setup.argtypes = [ci, sz, sz, dp, dp]
+    L.gemma_hip_lm_batch.argtypes = [ci, vp, sz, sz, vp]
+    L.gemma_hip_lm_batch_d.argtypes = [ci, vp, sz, sz, vp, vp]
     L.gemma_hip_profile_enable.argtypes = [ci]
     L.gemma_hip_profile_read.argtypes = [ci, C.POINTER(cd), C.POINTER(C.c_long), ci]
     L.gemma_hip_dbg_tridiag.argtypes = [dp, sz, dp, dp, dp, dp]

@@ -397,3 +397,32 @@ class LMM:
                 for cname in cols:
                     f.write("\t%.6e" % st[field.get(cname, cname)])
                 f.write("\n")
+
+
+class LM:
+    """Mirror of class LM (src/lm.h) for `-lm 1..4` (a_mode 51..54): ordinary per-SNP regression, no kinship."""
+
+    def __init__(self, a_mode=51):
+        self.a_mode = a_mode
+        self.sumStat = np.zeros(0, dtype=SUMSTAT_DTYPE)
+
+    def Analyze(self, W, y, geno, geno_kind=L.GENO_F64_SNP_MAJOR, indicator_idv=None, batch=LMM_BATCH_SIZE):
+        """LM::AnalyzeBimbam / AnalyzePlink (src/lm.cpp:382-640) over SNP-major `geno`."""
+        y = np.ascontiguousarray(y, dtype=np.float64)
+        W = np.ascontiguousarray(W, dtype=np.float64).reshape(len(y), -1)
+        L.check(L.lib().gemma_hip_lm_setup(self.a_mode, W.shape[0], W.shape[1], _ptr(W), _ptr(y)), "LM.setup")
+        try:
+            if indicator_idv is not None:
+                ind = np.ascontiguousarray(indicator_idv, dtype=np.int32)
+                L.check(L.lib().gemma_hip_lmm_set_indicator(_ptr(ind), ind.size), "LM.set_indicator")
+            outs = []
+            for s0 in range(0, geno.shape[0], batch):
+                blk = geno[s0:s0 + batch]
+                out = np.zeros(blk.shape[0], dtype=SUMSTAT_DTYPE)
+                L.check(L.lib().gemma_hip_lm_batch(geno_kind, _ptr(blk), blk.shape[0], blk.strides[0] // blk.itemsize,
+                                                   _ptr(out)), "LM.batch")
+                outs.append(out)
+            self.sumStat = np.concatenate(outs) if outs else np.zeros(0, dtype=SUMSTAT_DTYPE)
+        finally:
+            L.check(L.lib().gemma_hip_lm_finish(), "LM.finish")
+        return self.sumStat

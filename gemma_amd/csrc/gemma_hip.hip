@@ -15,6 +15,7 @@
 #include "dgemm_mfma.hip.h"
 #include "eigh.hip.h"
 #include "ingest.hip.h"
+#include "lm_assoc.hip.h"
 #include "lmm_assoc.hip.h"
 #include "qc.hip.h"
 
@@ -77,6 +78,11 @@ struct Ctx {
   DevBuf X, UtX, stage_in, stage_out, carry;
   int carry_flip = 0;
   AssocArgs assoc_proto;
+
+  // linear model (-lm) state
+  bool lm_active = false;
+  LmArgs lm_proto;
+  DevBuf lm_Wt, lm_y, lm_small;
 
   // misc scratch
   DevBuf scratch;
@@ -728,7 +734,7 @@ extern "C" int gemma_hip_lmm_setup(const gemma_lmm_cfg *cfg, const double *U, co
 
 extern "C" int gemma_hip_lmm_set_indicator(const int *indicator_idv, size_t ni_total) {
   NEED_INIT();
-  if (!g_ctx.lmm_active) return fail(GEMMA_HIP_ESTATE, "lmm_set_indicator before lmm_setup");
+  if (!g_ctx.lmm_active && !g_ctx.lm_active) return fail(GEMMA_HIP_ESTATE, "lmm_set_indicator before lmm_setup / lm_setup");
   if (!indicator_idv || ni_total == 0) {
     g_ctx.have_map = false;
     g_ctx.ni_total = 0;
@@ -855,6 +861,130 @@ extern "C" int gemma_hip_lmm_batch(int kind, const void *geno, size_t l, size_t 
   int rc = gemma_hip_lmm_batch_d(kind, g_ctx.stage_in.p, l, ld, g_ctx.stage_out.as<gemma_sumstat>(), nullptr);
   if (rc) return rc;
   HIPCHK(hipMemcpy(out, g_ctx.stage_out.p, l * sizeof(gemma_sumstat), hipMemcpyDeviceToHost));
+  return GEMMA_HIP_OK;
+}
+
+// ------------------------------------------------------------------------------ linear model (-lm)
+extern "C" int gemma_hip_lm_setup(int a_mode, size_t n, size_t n_cvt, const double *W, const double *y) {
+  NEED_INIT();
+  if (g_ctx.lmm_active) return fail(GEMMA_HIP_ESTATE, "lm_setup while an LMM run is active");
+  if (a_mode < 51 || a_mode > 54) return fail(GEMMA_HIP_EINVAL, "lm_setup: a_mode %d (51..54)", a_mode);
+  if (!W || !y || n == 0 || n_cvt == 0 || n_cvt > (size_t)LM_CMAX || n <= n_cvt + 1 || n > 0x7fffffffUL)
+    return fail(GEMMA_HIP_EINVAL, "lm_setup: bad arguments (n_cvt 1..%d)", LM_CMAX);
+  const int c = (int)n_cvt;
+  std::vector<double> WtW((size_t)c * c, 0.0), Wt((size_t)c * n), Wty(c, 0.0);
+  double yy = 0.0;
+  for (size_t i = 0; i < n; ++i) {
+    yy += y[i] * y[i];
+    for (int a = 0; a < c; ++a) {
+      Wt[(size_t)a * n + i] = W[i * c + a];
+      Wty[a] += W[i * c + a] * y[i];
+      for (int b = 0; b < c; ++b) WtW[(size_t)a * c + b] += W[i * c + a] * W[i * c + b];
+    }
+  }
+  if (!invert_small(WtW, c)) return fail(GEMMA_HIP_EINVAL, "lm_setup: W^T W is singular");
+  double d = 0.0; // CalcvPv(WtWi, Wty, y, yPwy), src/lm.cpp:247-263
+  for (int a = 0; a < c; ++a) {
+    double t = 0.0;
+    for (int b = 0; b < c; ++b) t += WtW[(size_t)a * c + b] * Wty[b];
+    d += t * Wty[a];
+  }
+  if (g_ctx.lm_Wt.reserve(Wt.size() * 8) || g_ctx.lm_y.reserve(n * 8) || g_ctx.lm_small.reserve(((size_t)c * c + c) * 8))
+    return fail(GEMMA_HIP_ENOMEM, "lm_setup: allocation");
+  HIPCHK(hipMemcpy(g_ctx.lm_Wt.p, Wt.data(), Wt.size() * 8, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(g_ctx.lm_y.p, y, n * 8, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(g_ctx.lm_small.p, WtW.data(), (size_t)c * c * 8, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(g_ctx.lm_small.as<double>() + (size_t)c * c, Wty.data(), c * 8, hipMemcpyHostToDevice));
+  LmArgs &a = g_ctx.lm_proto;
+  memset(&a, 0, sizeof a);
+  a.Wt = g_ctx.lm_Wt.as<double>();
+  a.y = g_ctx.lm_y.as<double>();
+  a.WtWi = g_ctx.lm_small.as<double>();
+  a.Wty = g_ctx.lm_small.as<double>() + (size_t)c * c;
+  a.yPwy = yy - d;
+  a.n = (int)n;
+  a.c = c;
+  a.test_mode = a_mode - 50;
+  const double df = (double)n - (double)c - 1.0;
+  a.lnbeta_half_df = lgamma(df / 2.0) + lgamma(0.5) - lgamma(df / 2.0 + 0.5);
+  g_ctx.cfg.n = n; // shared with the ingest / indicator code
+  g_ctx.cfg.n_cvt = n_cvt;
+  g_ctx.have_map = false;
+  g_ctx.ni_total = 0;
+  g_ctx.lm_active = true;
+  return GEMMA_HIP_OK;
+}
+
+extern "C" int gemma_hip_lm_batch_d(int kind, const void *geno, size_t l, size_t ld, gemma_sumstat *out_d, void *stream) {
+  NEED_INIT();
+  if (!g_ctx.lm_active) return fail(GEMMA_HIP_ESTATE, "lm_batch before lm_setup");
+  if (l == 0) return GEMMA_HIP_OK;
+  const size_t n = g_ctx.cfg.n;
+  const size_t per_row = (kind == GEMMA_GENO_PLINK_2BIT && g_ctx.have_map) ? g_ctx.ni_total : n;
+  const size_t need = min_ld_for(kind, per_row, l);
+  if (need == (size_t)-1) return fail(GEMMA_HIP_EINVAL, "lm_batch: unknown geno_kind %d", kind);
+  if (!geno || !out_d || ld < need) return fail(GEMMA_HIP_EINVAL, "lm_batch: ld=%zu < %zu", ld, need);
+  hipStream_t s = S(stream);
+  const size_t ldx = (n + 1) & ~(size_t)1;
+  if (g_ctx.X.reserve(l * ldx * 8)) return fail(GEMMA_HIP_ENOMEM, "lm_batch: cannot allocate %zu bytes", l * ldx * 8);
+  double *X = g_ctx.X.as<double>();
+  {
+    ProfScope ps(GEMMA_STAGE_INGEST, s);
+    if (kind == GEMMA_GENO_F64_IDV_MAJOR) {
+      dim3 grid((unsigned)((l + 31) / 32), (unsigned)((n + 31) / 32));
+      hipLaunchKernelGGL(transpose_kernel, grid, dim3(32, 8), 0, s, reinterpret_cast<const double *>(geno), (long)n,
+                         (long)l, (long)ld, X, (long)ldx);
+    } else {
+      IngestArgs a;
+      a.src = geno; a.ld = (long)ld; a.l = (long)l;
+      a.idx_map = g_ctx.have_map ? g_ctx.idx_map.as<int>() : nullptr;
+      a.n = (int)n; a.dst = X; a.ldo = (long)ldx; a.k_mode = 0;
+      const unsigned grid = (unsigned)((l + 3) / 4);
+      if (kind == GEMMA_GENO_PLINK_2BIT)
+        hipLaunchKernelGGL(ingest_lmm_kernel<true>, dim3(grid), dim3(256), 0, s, a);
+      else
+        hipLaunchKernelGGL(ingest_lmm_kernel<false>, dim3(grid), dim3(256), 0, s, a);
+    }
+    HIPCHK(hipGetLastError());
+  }
+  LmArgs a = g_ctx.lm_proto;
+  a.X = X; a.ld = (long)ldx; a.l = (long)l;
+  a.out = reinterpret_cast<SumStat *>(out_d);
+  {
+    ProfScope ps(GEMMA_STAGE_ASSOC, s);
+    hipLaunchKernelGGL(lm_assoc_kernel, dim3((unsigned)((l + 3) / 4)), dim3(256), 0, s, a);
+    HIPCHK(hipGetLastError());
+  }
+  return GEMMA_HIP_OK;
+}
+
+extern "C" int gemma_hip_lm_batch(int kind, const void *geno, size_t l, size_t ld, gemma_sumstat *out) {
+  NEED_INIT();
+  if (!g_ctx.lm_active) return fail(GEMMA_HIP_ESTATE, "lm_batch before lm_setup");
+  if (l == 0) return GEMMA_HIP_OK;
+  const size_t n = g_ctx.cfg.n;
+  const size_t per_row = (kind == GEMMA_GENO_PLINK_2BIT && g_ctx.have_map) ? g_ctx.ni_total : n;
+  const size_t need = min_ld_for(kind, per_row, l);
+  if (need == (size_t)-1) return fail(GEMMA_HIP_EINVAL, "lm_batch: unknown geno_kind %d", kind);
+  if (!geno || !out || ld < need) return fail(GEMMA_HIP_EINVAL, "lm_batch: ld=%zu < %zu", ld, need);
+  const size_t rows = (kind == GEMMA_GENO_F64_IDV_MAJOR) ? n : l;
+  const size_t esz = (kind == GEMMA_GENO_PLINK_2BIT) ? 1 : 8;
+  if (g_ctx.stage_in.reserve(rows * ld * esz) || g_ctx.stage_out.reserve(l * sizeof(gemma_sumstat)))
+    return fail(GEMMA_HIP_ENOMEM, "lm_batch: staging %zu bytes", rows * ld * esz);
+  HIPCHK(hipMemcpy2D(g_ctx.stage_in.p, ld * esz, geno, ld * esz, need * esz, rows, hipMemcpyHostToDevice));
+  int rc = gemma_hip_lm_batch_d(kind, g_ctx.stage_in.p, l, ld, g_ctx.stage_out.as<gemma_sumstat>(), nullptr);
+  if (rc) return rc;
+  HIPCHK(hipMemcpy(out, g_ctx.stage_out.p, l * sizeof(gemma_sumstat), hipMemcpyDeviceToHost));
+  return GEMMA_HIP_OK;
+}
+
+extern "C" int gemma_hip_lm_finish(void) {
+  NEED_INIT();
+  if (!g_ctx.lm_active) return fail(GEMMA_HIP_ESTATE, "lm_finish before lm_setup");
+  HIPCHK(hipDeviceSynchronize());
+  g_ctx.lm_Wt.release(); g_ctx.lm_y.release(); g_ctx.lm_small.release();
+  g_ctx.X.release(); g_ctx.stage_in.release(); g_ctx.stage_out.release(); g_ctx.idx_map.release();
+  g_ctx.lm_active = false;
   return GEMMA_HIP_OK;
 }
 

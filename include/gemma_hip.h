@@ -179,6 +179,17 @@ int gemma_hip_lmm_assoc_d(const double *UtX_d, size_t l, size_t ld_utx, gemma_su
  * minutes, the unit of LMM::time_UtX / time_opt (src/lmm.cpp:1523,1556) */
 int gemma_hip_lmm_finish(double *time_UtX_min, double *time_opt_min);
 
+/* ---- linear model without a random effect (-lm 1..4) ----------------------- */
+/* LM::AnalyzeBimbam / AnalyzePlink, src/lm.cpp:382-640 (CalcvPv :224-263, LmCalcP :266-287): per SNP ordinary
+ * regression of y on (W, x); a_mode 51 Wald, 52 LRT, 53 score, 54 all (src/gemma.h:39-43).  W (n x n_cvt) and y are
+ * host arrays over the analysed individuals.  Blocks use the same genotype encodings, indicator
+ * (gemma_hip_lmm_set_indicator) and mean imputation as lmm_batch; SUMSTAT carries beta, se (score se for a_mode 53),
+ * p_wald, p_lrt, p_score, the lambdas are 0 and logl_H1 is -0.0 as in the reference. */
+int gemma_hip_lm_setup(int a_mode, size_t n, size_t n_cvt, const double *W, const double *y);
+int gemma_hip_lm_batch(int geno_kind, const void *geno, size_t l, size_t ld, gemma_sumstat *out);
+int gemma_hip_lm_batch_d(int geno_kind, const void *geno_d, size_t l, size_t ld, gemma_sumstat *out_d, void *stream);
+int gemma_hip_lm_finish(void);
+
 /* ---- measurement -------------------------------------------------------- */
 enum { GEMMA_STAGE_INGEST = 0, GEMMA_STAGE_UTX_GEMM = 1, GEMMA_STAGE_ASSOC = 2,
        GEMMA_STAGE_KIN_GEMM = 3, GEMMA_STAGE_EIGH = 4, GEMMA_STAGE_COUNT = 5 };

@@ -902,6 +902,80 @@ void orc_lmm_batch(int a_mode, size_t n, size_t c, const double *eval, const dou
   free(Uab);
 }
 
+/* ---------------- linear model (-lm) -------------------------------- */
+/* LmCalcP, src/lm.cpp:266-287 */
+static void lm_calc_p(int test_mode, double yPwy, double xPwy, double xPwx, double df, size_t n_size,
+                      double *beta, double *se, double *p_wald, double *p_lrt, double *p_score) {
+  double yPxy = yPwy - xPwy * xPwy / xPwx;
+  double se_wald, se_score;
+  *beta = xPwy / xPwx;
+  se_wald = sqrt(yPxy / (df * xPwx));
+  se_score = sqrt(yPwy / ((double)n_size * xPwx));
+  *p_wald = orc_cdf_fdist_Q(*beta * *beta / (se_wald * se_wald), 1.0, df);
+  *p_score = orc_cdf_fdist_Q(*beta * *beta / (se_score * se_score), 1.0, df);
+  {
+    double xl = (double)n_size * (log(yPwy) - log(yPxy));
+    *p_lrt = isnan(xl) ? NAN : orc_cdf_chisq_Q1(xl);
+  }
+  *se = (test_mode == 3) ? se_score : se_wald;
+}
+
+/* The per-SNP body of LM::AnalyzeBimbam / AnalyzePlink, src/lm.cpp:382-640, with CalcvPv (:224-263):
+ * X is SNP-major l x n, already mean-imputed; W n x c row-major; WtWi c x c; a_mode 51..54. */
+void orc_lm_batch(int a_mode, size_t n, size_t c, const double *W, const double *WtWi, const double *y,
+                  const double *X, size_t l, orc_sumstat *out) {
+  double Wty[ORC_MAXC], Wtx[ORC_MAXC], t[ORC_MAXC];
+  double yPwy = 0.0, d;
+  double df = (double)n - (double)c - 1.0;
+  for (size_t a = 0; a < c; ++a) {
+    double s = 0.0;
+    for (size_t i = 0; i < n; ++i) s += W[i * c + a] * y[i];
+    Wty[a] = s;
+  }
+  for (size_t i = 0; i < n; ++i) yPwy += y[i] * y[i];
+  d = 0.0;
+  for (size_t a = 0; a < c; ++a) {
+    double s = 0.0;
+    for (size_t b = 0; b < c; ++b) s += WtWi[a * c + b] * Wty[b];
+    d += s * Wty[a];
+  }
+  yPwy -= d;
+  for (size_t s_ = 0; s_ < l; ++s_) {
+    const double *x = X + s_ * n;
+    double xPwx = 0.0, xPwy = 0.0;
+    for (size_t a = 0; a < c; ++a) {
+      double s = 0.0;
+      for (size_t i = 0; i < n; ++i) s += W[i * c + a] * x[i];
+      Wtx[a] = s;
+    }
+    for (size_t i = 0; i < n; ++i) {
+      xPwx += x[i] * x[i];
+      xPwy += x[i] * y[i];
+    }
+    for (size_t a = 0; a < c; ++a) {
+      double s = 0.0;
+      for (size_t b = 0; b < c; ++b) s += WtWi[a * c + b] * Wtx[b];
+      t[a] = s;
+    }
+    d = 0.0;
+    for (size_t a = 0; a < c; ++a) d += t[a] * Wtx[a];
+    xPwx -= d;
+    d = 0.0;
+    for (size_t a = 0; a < c; ++a) d += t[a] * Wty[a];
+    xPwy -= d;
+    double beta, se, p_wald, p_lrt, p_score;
+    lm_calc_p(a_mode - 50, yPwy, xPwy, xPwx, df, n, &beta, &se, &p_wald, &p_lrt, &p_score);
+    out[s_].beta = beta;
+    out[s_].se = se;
+    out[s_].lambda_remle = 0.0;
+    out[s_].lambda_mle = 0.0;
+    out[s_].p_wald = p_wald;
+    out[s_].p_lrt = p_lrt;
+    out[s_].p_score = p_score;
+    out[s_].logl_H1 = -0.0;
+  }
+}
+
 /* ---------------- genotype preparation ----------------------------- */
 /* src/lmm.cpp:1590-1618 (BIMBAM) / :1779-1827 (PLINK): mean-impute only.
  * X is SNP-major l x n with NaN for missing, modified in place.          */

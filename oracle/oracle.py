@@ -62,6 +62,7 @@ def lib():
         L.orc_lmm_batch.argtypes = [C.c_int, C.c_size_t, C.c_size_t, dp, dp, dp, dp, C.c_size_t,
                                     C.c_double, C.c_double, C.c_size_t, C.c_double, C.c_double, C.c_int,
                                     dp, C.POINTER(SumStat), C.POINTER(C.c_long)]
+        L.orc_lm_batch.argtypes = [C.c_int, C.c_size_t, C.c_size_t, dp, dp, dp, dp, C.c_size_t, C.POINTER(SumStat)]
         L.orc_impute_mean.argtypes = [dp, C.c_size_t, C.c_size_t]
         L.orc_kin_prepare.argtypes = [dp, C.c_size_t, C.c_size_t, C.c_int]
         L.orc_bed_decode.restype = C.c_size_t
@@ -180,6 +181,17 @@ def lmm_batch_UtX(a_mode, ev, UtW, Uty, UtX_snpmajor, l_mle_null=0.0, logl_mle_H
                         out.ctypes.data_as(C.POINTER(SumStat)),
                         diag.ctypes.data_as(C.POINTER(C.c_long)) if want_diag else None)
     return (out, diag) if want_diag else out
+
+
+def lm_analyze(a_mode, W, y, X_snpmajor_nan):
+    """LM::AnalyzeBimbam / AnalyzePlink (src/lm.cpp:382-640): ordinary regression per SNP, a_mode 51..54."""
+    W = _c64(W).reshape(len(y), -1); y = _c64(y)
+    n, c = W.shape
+    WtWi = np.ascontiguousarray(np.linalg.inv(W.T @ W))
+    X = impute_mean(X_snpmajor_nan)
+    out = np.zeros(X.shape[0], dtype=SUMSTAT_DTYPE)
+    lib().orc_lm_batch(a_mode, n, c, _dp(W), _dp(WtWi), _dp(y), _dp(X), X.shape[0], out.ctypes.data_as(C.POINTER(SumStat)))
+    return out
 
 
 def impute_mean(X_snpmajor):

@@ -232,6 +232,33 @@ def test_loco_kinship_and_text_handoff(gpu_api, oracle):
     assert np.array_equal(gpu_api.WriteMatrix10(K), oracle.round10(K))
 
 
+@pytest.mark.parametrize("mode", [51, 52, 53, 54])
+def test_linear_model(gpu_api, oracle, mode):
+    """-lm (src/lm.cpp:382-640) through both genotype encodings vs the oracle, which is itself pinned
+    by an independent OLS t-test (tests/test_oracle_golden.py::test_lm_against_ols)."""
+    from gemma_amd import _lib as L
+    rng = np.random.default_rng(mode)
+    ni_total, p = 421, 300
+    ind = (rng.random(ni_total) > 0.2).astype(np.int32)
+    n = int(ind.sum())
+    codes = rng.choice([0, 1, 2, 3], size=(p, ni_total), p=[0.3, 0.02, 0.38, 0.3]).astype(np.uint8)
+    nb = (ni_total + 3) // 4
+    pad = np.zeros((p, nb * 4), dtype=np.uint8)
+    pad[:, :ni_total] = codes
+    raw = (pad[:, 0::4] | (pad[:, 1::4] << 2) | (pad[:, 2::4] << 4) | (pad[:, 3::4] << 6)).astype(np.uint8)
+    X = oracle.bed_decode(raw, ni_total, ind)
+    W = np.hstack([rng.standard_normal((n, 2)), np.ones((n, 1))])
+    y = rng.standard_normal(n) + 0.8 * np.nan_to_num(X[3])
+    ref = oracle.lm_analyze(mode, W, y, X)
+    got_b = gpu_api.LM(mode).Analyze(W, y, X, L.GENO_F64_SNP_MAJOR)
+    got_p = gpu_api.LM(mode).Analyze(W, y, raw, L.GENO_PLINK_2BIT, indicator_idv=ind, batch=128)
+    for got in (got_b, got_p):
+        for k in ("beta", "se", "p_wald", "p_lrt", "p_score"):
+            assert np.allclose(got[k], ref[k], rtol=1e-9, atol=1e-300, equal_nan=True), k
+        assert np.all(got["lambda_remle"] == 0) and np.all(got["lambda_mle"] == 0) and np.all(got["logl_H1"] == 0)
+    assert ref["p_wald"][3] < 1e-6 and np.median(ref["p_wald"]) > 0.05
+
+
 def test_center_matrix(gpu_api, oracle, bxd):
     K = bxd["K_sub"].copy()
     got = gpu_api.CenterMatrix(K.copy())

@@ -108,3 +108,27 @@ def test_plink_decode_and_missing(oracle):
         exp = {0: 2.0, 2: 1.0, 3: 0.0}.get(v, np.nan)
         got = G[3, 20 + j]
         assert (np.isnan(got) and np.isnan(exp)) or got == exp
+
+
+def test_lm_against_ols(oracle):
+    """-lm restatement (src/lm.cpp:224-287,382-640) against an independent OLS fit: Wald p == two-sided t-test.
+    (The reference's own -lm golden, test/dev_tests.rb:13-24, needs the missing mouse_hs1940 genotype blob.)"""
+    from scipy import stats
+    rng = np.random.default_rng(1)
+    n, c = 200, 3
+    W = np.hstack([rng.standard_normal((n, 2)), np.ones((n, 1))])
+    X = rng.integers(0, 3, size=(6, n)).astype(float)
+    X[0, :7] = np.nan
+    y = rng.standard_normal(n) + 0.3 * np.nan_to_num(X[1])
+    out = oracle.lm_analyze(51, W, y, X)
+    Xi = oracle.impute_mean(X)
+    for s in range(6):
+        A = np.hstack([W, Xi[s][:, None]])
+        b = np.linalg.lstsq(A, y, rcond=None)[0]
+        r = y - A @ b
+        df = n - c - 1
+        cov = (r @ r / df) * np.linalg.inv(A.T @ A)
+        t = b[-1] / np.sqrt(cov[-1, -1])
+        assert out["beta"][s] == pytest.approx(b[-1], rel=1e-11)
+        assert out["se"][s] == pytest.approx(np.sqrt(cov[-1, -1]), rel=1e-11)
+        assert out["p_wald"][s] == pytest.approx(2 * stats.t.sf(abs(t), df), rel=1e-10)
