@@ -32,6 +32,7 @@ namespace gemma_hip {
 
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 typedef double f64x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int GEMM_BM = 128, GEMM_BN = 128, GEMM_BK = 16;
 constexpr int GEMM_LD_KM = 144; // [k][m] image: row stride in doubles
@@ -282,6 +283,331 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : 2)) void dgemm_mfma_kernel(
   }
 }
 
+// Software-pipelined form of the FULL 4-wave kernel (complete, aligned tiles only).
+//
+// Why: with 2 blocks per CU the two wavefronts sharing a SIMD arbitrate fairly for the MFMA pipe, so the one that is
+// behind runs alone while the leader waits on LDS and the pair converges to lock-step -- after that both wait on their
+// ds_reads at the same time and the pipe drains once per K-step (measured: 11 % of the MFMA cycles idle with global
+// loads and the barrier ablated away).  Here a wave never waits on LDS: the fragments of K-step s+1 (8 ds_read_b64,
+// two register sets) are issued before the 16 MFMAs of step s, the staged tile t+1 is written to the other LDS buffer
+// in the middle of step 2, the barrier sits between steps 2 and 3, and step 3 already reads tile t+1's first
+// fragments.  The global loads of tile t+2 are issued right after that barrier, 3.5 K-steps (>= 3600 cycles of this
+// wave's own MFMA issue) ahead of the ds_write that consumes them.
+#define GEMMA_SB() __builtin_amdgcn_sched_barrier(0)
+template <bool A_KM, bool B_KN>
+__global__ __launch_bounds__(256, 2) void dgemm_mfma_pipe_kernel(GemmArgs g) {
+  constexpr int NT = 256;
+  constexpr int NLD = 4;
+  __shared__ __attribute__((aligned(16))) double lds[4 * GEMM_TILE_DOUBLES];
+  double *const As0 = lds, *const As1 = lds + GEMM_TILE_DOUBLES;
+  double *const Bs0 = lds + 2 * GEMM_TILE_DOUBLES, *const Bs1 = lds + 3 * GEMM_TILE_DOUBLES;
+
+  int tm, tn;
+  tile_of_block(g, tm, tn);
+  const long m0 = (long)tm * GEMM_BM, n0 = (long)tn * GEMM_BN;
+  const int t = threadIdx.x;
+  const int lane = t & 63, wave = t >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l15 = lane & 15, l4 = lane >> 4;
+
+  // per-lane fragment offsets (doubles) for K-step 0, block i = 0 / j = 0
+  const int a_off = A_KM ? l4 * GEMM_LD_KM + wm * 64 + l15 : (wm * 64 + l15) * GEMM_LD_MK + l4;
+  const int b_off = B_KN ? l4 * GEMM_LD_KM + wn * 64 + l15 : (wn * 64 + l15) * GEMM_LD_MK + l4;
+  constexpr int a_i = A_KM ? 16 : 16 * GEMM_LD_MK, a_kk = A_KM ? 4 * GEMM_LD_KM : 4;
+  constexpr int b_j = B_KN ? 16 : 16 * GEMM_LD_MK, b_kk = B_KN ? 4 * GEMM_LD_KM : 4;
+
+  f64x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f64x4{0.0, 0.0, 0.0, 0.0};
+
+  f64x2 ra[NLD], rb[NLD];
+  const long nk = g.K / GEMM_BK;
+  const bool sq = g.square_a != 0;
+  // timing experiments (GEMMA_HIP_GEMM_ABLATE, results wrong): 1 no global loads, 16 no LDS stores, 2 no barrier
+  const bool ab_ld = (g.ablate & 1) != 0, ab_st = (g.ablate & 16) != 0, ab_bar = (g.ablate & 2) != 0;
+  if (g.ablate & 32) { // experiment: fixed issue priority by hardware wave slot parity (HW_ID.WAVE_ID)
+    const unsigned wid = __builtin_amdgcn_s_getreg((3 << 11) | 4);
+    if (wid & 1) __builtin_amdgcn_s_setprio(3);
+  }
+
+#define GEMMA_GLOAD(KT)                                                                         \
+  do {                                                                                          \
+    load_tile<A_KM, NT>(g.A, g.lda, m0, (long)(KT) * GEMM_BK, g.M, g.K, true, t, ra, true);     \
+    load_tile<B_KN, NT>(g.B, g.ldb, n0, (long)(KT) * GEMM_BK, g.N, g.K, true, t, rb, true);     \
+  } while (0)
+#define GEMMA_LSTORE(AD, BD)                                                                    \
+  do {                                                                                          \
+    if (sq) {                                                                                   \
+      _Pragma("unroll") for (int j_ = 0; j_ < NLD; ++j_) ra[j_] = ra[j_] * ra[j_];              \
+    }                                                                                           \
+    store_tile<A_KM, NT>(AD, t, ra);                                                            \
+    store_tile<B_KN, NT>(BD, t, rb);                                                            \
+  } while (0)
+#define GEMMA_FRAGS(AS, BS, KK, FA, FB)                                                         \
+  do {                                                                                          \
+    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) FA[i_] = (AS)[a_off + i_ * a_i + (KK) * a_kk]; \
+    _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_) FB[j_] = (BS)[b_off + j_ * b_j + (KK) * b_kk]; \
+  } while (0)
+#define GEMMA_MFMA_ROWS(FA, FB, I0, I1)                                                         \
+  do {                                                                                          \
+    _Pragma("unroll") for (int i_ = (I0); i_ < (I1); ++i_)                                      \
+      _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_)                                          \
+        acc[i_][j_] = __builtin_amdgcn_mfma_f64_16x16x4f64(FA[i_], FB[j_], acc[i_][j_], 0, 0, 0); \
+  } while (0)
+
+  GEMMA_GLOAD(0);
+  GEMMA_LSTORE(As0, Bs0);
+  __syncthreads();
+  if (nk > 1 && !ab_ld) GEMMA_GLOAD(1);
+
+  double xa[4], xb[4], ya[4], yb[4];
+  GEMMA_FRAGS(As0, Bs0, 0, xa, xb);
+
+  for (long kt = 0; kt < nk; ++kt) {
+    const bool odd = (kt & 1) != 0;
+    const double *Ac = odd ? As1 : As0, *Bc = odd ? Bs1 : Bs0;
+    double *An = odd ? As0 : As1, *Bn = odd ? Bs0 : Bs1;
+    const bool more = (kt + 1) < nk;
+    // K-step 0
+    GEMMA_FRAGS(Ac, Bc, 1, ya, yb);
+    GEMMA_SB();
+    GEMMA_MFMA_ROWS(xa, xb, 0, 4);
+    GEMMA_SB();
+    // K-step 1
+    GEMMA_FRAGS(Ac, Bc, 2, xa, xb);
+    GEMMA_SB();
+    GEMMA_MFMA_ROWS(ya, yb, 0, 4);
+    GEMMA_SB();
+    // K-step 2: tile t+1 goes to the other LDS buffer behind the first 8 MFMAs; barrier behind the last 8
+    GEMMA_FRAGS(Ac, Bc, 3, ya, yb);
+    GEMMA_SB();
+    GEMMA_MFMA_ROWS(xa, xb, 0, 2);
+    GEMMA_SB();
+    if (more && !ab_st) GEMMA_LSTORE(An, Bn);
+    GEMMA_SB();
+    GEMMA_MFMA_ROWS(xa, xb, 2, 4);
+    GEMMA_SB();
+    if (!ab_bar) __syncthreads();
+    if ((kt + 2) < nk && !ab_ld) GEMMA_GLOAD(kt + 2);
+    // K-step 3: first fragments of tile t+1 behind this tile's last 16 MFMAs
+    if (more) GEMMA_FRAGS(An, Bn, 0, xa, xb);
+    GEMMA_SB();
+    GEMMA_MFMA_ROWS(ya, yb, 0, 4);
+    GEMMA_SB();
+  }
+#undef GEMMA_GLOAD
+#undef GEMMA_LSTORE
+#undef GEMMA_FRAGS
+#undef GEMMA_MFMA_ROWS
+
+  const double alpha = g.alpha, beta = g.beta;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const long col = n0 + wn * 64 + j * 16 + l15;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const long row = m0 + wm * 64 + i * 16 + l4 + 4 * r;
+        double *c = g.C + row * g.ldc + col;
+        double v = alpha * acc[i][j][r];
+        if (beta != 0.0) v += beta * (*c);
+        *c = v;
+      }
+    }
+  }
+}
+
+// Direct-to-LDS, issue-interleaved form of the interior kernel (complete, aligned tiles only).
+//
+// Issue is in order per wave, so every instruction that sits between two MFMAs of one wave delays the second MFMA
+// once the run of such instructions outlasts the 64-cycle shadow of the first (measured: one wave per SIMD reaches
+// only 88 % of the MFMA rate on a clustered schedule even with loads and barrier ablated away, and each removed
+// group of loads / LDS stores buys 2-3 %).  So:
+//  * operands go global -> LDS with global_load_lds_dwordx4 (1 KiB per wave instruction): no staging VGPRs, no
+//    ds_write pass, 8 instructions per wave per K-tile;
+//  * the instruction order is pinned (sched_barrier after every MFMA): at most one ds_read and one LDS-DMA issue
+//    follow any MFMA.  MFMA slots of one K-tile (M0..M63):
+//      M0-7   ds_read fragments of K-step 1     M16-23 K-step 2     M32-39 K-step 3
+//      after M51: s_waitcnt vmcnt(0) (tile t+1 has landed, issued >= 56 MFMAs earlier) + barrier
+//      M52-59 ds_read the first fragments of tile t+1, issue the 8 LDS-DMA pieces of tile t+2
+//  * LDS images are lane-linear per wave instruction, as LDS-DMA requires:
+//      [k][m] operands: one k-row (128 doubles = 1 KiB) per instruction, rows still 144 doubles apart;
+//      [m][k] operands: 8 rows x 16 doubles per instruction, unpadded, with the 16-byte chunk index XOR-ed by
+//      (m >> 1) & 7 on the SOURCE address and on the fragment read (conflict-free ds_read_b64 half-waves).
+typedef const __attribute__((address_space(1))) void *gemma_gptr_t;
+typedef __attribute__((address_space(3))) void *gemma_lptr_t;
+
+template <bool A_KM, bool B_KN>
+__global__ __launch_bounds__(256, 2) void dgemm_mfma_glds_kernel(GemmArgs g) {
+  __shared__ __attribute__((aligned(1024))) double lds[4 * GEMM_TILE_DOUBLES];
+  int tm, tn;
+  tile_of_block(g, tm, tn);
+  const long m0 = (long)tm * GEMM_BM, n0 = (long)tn * GEMM_BN;
+  const int t = threadIdx.x;
+  const int lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l15 = lane & 15, l4 = lane >> 4;
+
+  // fragment offsets (doubles) inside an image, per K-step; block i / j adds a_i / b_j
+  int a_l[4], b_l[4];
+  constexpr int a_i = A_KM ? 16 : 256, b_j = B_KN ? 16 : 256;
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) {
+    const int swz = ((((kk << 1) | (l4 >> 1)) ^ (l15 >> 1)) << 1) | (l4 & 1); // swizzled k position, [m][k] images
+    a_l[kk] = A_KM ? (kk * 4 + l4) * GEMM_LD_KM + wm * 64 + l15 : (wm * 64 + l15) * 16 + swz;
+    b_l[kk] = B_KN ? (kk * 4 + l4) * GEMM_LD_KM + wn * 64 + l15 : (wn * 64 + l15) * 16 + swz;
+  }
+
+  // LDS-DMA pieces: wave w moves pieces p = 4w + j (j = 0..3) of each operand tile.
+  //   [k][m]: piece p = k-row p;  source row stride ld, lane offset 16 B * lane;  LDS p * 144 doubles
+  //   [m][k]: piece p = rows 8p..8p+7;  lane -> row 8p + (lane >> 3), chunk (lane & 7) ^ ((row >> 1) & 7);  LDS p * 128
+  const char *ga[4], *gb[4];
+  unsigned va[2], vb[2]; // per-lane source byte offsets for even / odd j
+  constexpr int pa = A_KM ? GEMM_LD_KM : 128, pb = B_KN ? GEMM_LD_KM : 128; // LDS doubles per piece
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const long p = 4 * wave + j;
+    ga[j] = reinterpret_cast<const char *>(A_KM ? g.A + p * g.lda + m0 : g.A + (m0 + 8 * p) * g.lda);
+    gb[j] = reinterpret_cast<const char *>(B_KN ? g.B + p * g.ldb + n0 : g.B + (n0 + 8 * p) * g.ldb);
+  }
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    const int chunk = (lane & 7) ^ (4 * e + (lane >> 4));
+    va[e] = A_KM ? (unsigned)lane * 16u : (unsigned)(((long)(lane >> 3) * g.lda + 2 * chunk) * 8);
+    vb[e] = B_KN ? (unsigned)lane * 16u : (unsigned)(((long)(lane >> 3) * g.ldb + 2 * chunk) * 8);
+  }
+  const long da = (A_KM ? (long)GEMM_BK * g.lda : (long)GEMM_BK) * 8; // source byte advance per K-tile
+  const long db = (B_KN ? (long)GEMM_BK * g.ldb : (long)GEMM_BK) * 8;
+
+  f64x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f64x4{0.0, 0.0, 0.0, 0.0};
+
+  const long nk = g.K / GEMM_BK;
+  double xa[4], xb[4], ya[4], yb[4];
+
+// one LDS-DMA piece q (0..3: A pieces, 4..7: B pieces) of the tile the source pointers stand on, into (AD, BD)
+#define GEMMA_DMA(q, AD, BD)                                                                                   \
+  do {                                                                                                         \
+    if ((q) < 4)                                                                                               \
+      __builtin_amdgcn_global_load_lds((gemma_gptr_t)(ga[(q)&3] + va[(q)&1]),                                  \
+                                       (gemma_lptr_t)((AD) + (4 * wave + ((q)&3)) * pa), 16, 0, 0);            \
+    else                                                                                                       \
+      __builtin_amdgcn_global_load_lds((gemma_gptr_t)(gb[(q)&3] + vb[(q)&1]),                                  \
+                                       (gemma_lptr_t)((BD) + (4 * wave + ((q)&3)) * pb), 16, 0, 0);            \
+  } while (0)
+#define GEMMA_ADVANCE()                                                                                        \
+  do {                                                                                                         \
+    _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_) { ga[j_] += da; gb[j_] += db; }                           \
+  } while (0)
+// fragment q (0..3: A blocks, 4..7: B blocks) of K-step KK
+#define GEMMA_FRAG(q, AS, BS, KK, FA, FB)                                                                      \
+  do {                                                                                                         \
+    if ((q) < 4) FA[(q)&3] = (AS)[a_l[KK] + ((q)&3) * a_i];                                                    \
+    else FB[(q)&3] = (BS)[b_l[KK] + ((q)&3) * b_j];                                                            \
+  } while (0)
+#define GEMMA_MF(q, FA, FB)                                                                                    \
+  acc[(q) >> 2][(q)&3] = __builtin_amdgcn_mfma_f64_16x16x4f64(FA[(q) >> 2], FB[(q)&3], acc[(q) >> 2][(q)&3], 0, 0, 0)
+// 16 MFMAs of one K-step on (FA, FB) with the 8 fragment reads of the next K-step behind the first 8
+#define GEMMA_STEP(FA, FB, AS, BS, KK, GA, GB)                                                                 \
+  do {                                                                                                         \
+    _Pragma("unroll") for (int q_ = 0; q_ < 16; ++q_) {                                                        \
+      GEMMA_MF(q_, FA, FB);                                                                                    \
+      if (q_ < 8) GEMMA_FRAG(q_, AS, BS, KK, GA, GB);                                                          \
+      GEMMA_SB();                                                                                              \
+    }                                                                                                          \
+  } while (0)
+// one K-tile; MORE: tile t+1 exists (its first fragments are read at the end); LOAD2: tile t+2 exists (DMA it)
+#define GEMMA_KTILE(AC, BC, AN, BN, MORE, LOAD2)                                                               \
+  do {                                                                                                         \
+    GEMMA_STEP(xa, xb, AC, BC, 1, ya, yb);                                                                     \
+    GEMMA_STEP(ya, yb, AC, BC, 2, xa, xb);                                                                     \
+    GEMMA_STEP(xa, xb, AC, BC, 3, ya, yb);                                                                     \
+    _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) {                                                         \
+      GEMMA_MF(q_, ya, yb);                                                                                    \
+      GEMMA_SB();                                                                                              \
+    }                                                                                                          \
+    __syncthreads();                                                                                           \
+    GEMMA_SB();                                                                                                \
+    _Pragma("unroll") for (int q_ = 4; q_ < 16; ++q_) {                                                        \
+      GEMMA_MF(q_, ya, yb);                                                                                    \
+      if (q_ < 12) {                                                                                           \
+        if (MORE) GEMMA_FRAG(q_ - 4, AN, BN, 0, xa, xb);                                                       \
+        if (LOAD2) GEMMA_DMA(q_ - 4, AC, BC);                                                                  \
+      }                                                                                                        \
+      GEMMA_SB();                                                                                              \
+    }                                                                                                          \
+  } while (0)
+
+  double *const As0 = lds, *const As1 = lds + GEMM_TILE_DOUBLES;
+  double *const Bs0 = lds + 2 * GEMM_TILE_DOUBLES, *const Bs1 = lds + 3 * GEMM_TILE_DOUBLES;
+#pragma unroll
+  for (int q = 0; q < 8; ++q) GEMMA_DMA(q, As0, Bs0);
+  if (nk > 1) {
+    GEMMA_ADVANCE();
+#pragma unroll
+    for (int q = 0; q < 8; ++q) GEMMA_DMA(q, As1, Bs1);
+    GEMMA_ADVANCE();
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); // tile 0 has landed, tile 1 may still be in flight
+    __builtin_amdgcn_s_barrier();
+  } else {
+    __syncthreads();
+  }
+  GEMMA_SB();
+#pragma unroll
+  for (int q = 0; q < 8; ++q) GEMMA_FRAG(q, As0, Bs0, 0, xa, xb);
+
+  long kt = 0;
+  for (; kt + 2 < nk; ++kt) { // steady state
+    const bool odd = (kt & 1) != 0;
+    double *Ac = odd ? As1 : As0, *Bc = odd ? Bs1 : Bs0;
+    double *An = odd ? As0 : As1, *Bn = odd ? Bs0 : Bs1;
+    GEMMA_KTILE(Ac, Bc, An, Bn, true, true);
+    GEMMA_ADVANCE();
+  }
+  if (nk >= 2) { // K-tile nk-2: nothing left to load
+    const bool odd = (nk & 1) != 0;
+    double *Ac = odd ? As1 : As0, *Bc = odd ? Bs1 : Bs0;
+    double *An = odd ? As0 : As1, *Bn = odd ? Bs0 : Bs1;
+    GEMMA_KTILE(Ac, Bc, An, Bn, true, false);
+  }
+  { // K-tile nk-1
+    const bool odd = (nk & 1) == 0;
+    double *Ac = odd ? As1 : As0, *Bc = odd ? Bs1 : Bs0;
+    double *An = odd ? As0 : As1, *Bn = odd ? Bs0 : Bs1;
+    GEMMA_KTILE(Ac, Bc, An, Bn, false, false);
+  }
+#undef GEMMA_DMA
+#undef GEMMA_ADVANCE
+#undef GEMMA_FRAG
+#undef GEMMA_MF
+#undef GEMMA_STEP
+#undef GEMMA_KTILE
+
+  const double alpha = g.alpha, beta = g.beta;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const long col = n0 + wn * 64 + j * 16 + l15;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const long row = m0 + wm * 64 + i * 16 + l4 + 4 * r;
+        double *c = g.C + row * g.ldc + col;
+        double v = alpha * acc[i][j][r];
+        if (beta != 0.0) v += beta * (*c);
+        *c = v;
+      }
+    }
+  }
+}
+
 // mirror the strict upper triangle into the lower one and scale everything (kinship epilogue:
 // K *= 1/ns_test, GEMMA src/gemma_io.cpp:1570, and the symmetric fill of :1724-1729)
 __global__ void symm_fill_scale_kernel(double *K, long n, long ld, double scale) {
@@ -320,6 +646,16 @@ static inline int gemm_waves() {
   return nw;
 }
 
+// GEMMA_HIP_GEMM_PIPE=0/1/2: interior kernel = classic / software-pipelined / pipelined + interleaved issue
+static inline int gemm_pipe() {
+  static int v = -1;
+  if (v < 0) {
+    const char *e = getenv("GEMMA_HIP_GEMM_PIPE");
+    v = e ? atoi(e) : 0;
+  }
+  return v;
+}
+
 template <bool A_KM, bool B_KN, bool FULL>
 static inline hipError_t launch_dgemm_grid(const GemmArgs &g, hipStream_t s) {
   int nblocks;
@@ -328,7 +664,17 @@ static inline hipError_t launch_dgemm_grid(const GemmArgs &g, hipStream_t s) {
   else
     nblocks = g.tiles_m * g.tiles_n;
   if (nblocks <= 0) return hipSuccess;
-  if (gemm_waves() == 8)
+  if (FULL && gemm_pipe() == 2 && !g.square_a) {
+    hipLaunchKernelGGL((dgemm_mfma_glds_kernel<A_KM, B_KN>), dim3(nblocks), dim3(256), 0, s, g);
+  } else if (FULL && gemm_pipe()) {
+    static int xlds = -1; // experiment: extra dynamic LDS to force 1 block per CU
+    if (xlds < 0) {
+      const char *e = getenv("GEMMA_HIP_GEMM_XLDS");
+      xlds = e ? atoi(e) : 0;
+    }
+    hipLaunchKernelGGL((dgemm_mfma_pipe_kernel<A_KM, B_KN>), dim3(nblocks), dim3(256), xlds, s, g);
+  }
+  else if (gemm_waves() == 8)
     hipLaunchKernelGGL((dgemm_mfma_kernel<A_KM, B_KN, 8, FULL>), dim3(nblocks), dim3(512), 0, s, g);
   else
     hipLaunchKernelGGL((dgemm_mfma_kernel<A_KM, B_KN, 4, FULL>), dim3(nblocks), dim3(256), 0, s, g);
