@@ -231,7 +231,7 @@ def main():
                                        "configs[2] (headline): " if (n == 20000 and args.a_mode == 1) else "", n, args.a_mode, B),
                        "n": n, "snps_per_step": B, "kinship_snps": args.kin_snps, "parallelism": "snp-shard x%d" % world,
                        "device": name, "cus": n_cu, "setup": setup_info, "nan_p_wald": n_nan},
-            "roofline": {"kernel": "dgemm_mfma_kernel (UtX = X*U)", "bound": "mfma", "achieved": round(achieved, 2),
+            "roofline": {"kernel": "dgemm_mfma_glds_kernel (UtX = X*U)", "bound": "mfma", "achieved": round(achieved, 2),
                          "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / FP64_MFMA_PEAK_TFLOPS, 4),
                          "traffic": None, "launches": gemm_n, "avg_launch_ms": round(gemm_avg_s * 1e3, 3)},
             "roofline_assoc": {"kernel": "lmm_assoc_kernel (lambda search + Wald)", "bound": "hbm",

@@ -52,6 +52,7 @@ struct GemmArgs {
   int syrk_upper;  // 1: launch only tiles with tn >= tm (sub-grid must start at (0,0))
   int square_a;    // 1: use A*A elementwise as the A operand (grid-lambda x^2 sums)
   int gm;          // tile rows per raster group (0 = default 8)
+  int clamp;       // glds kernel: shift ragged last tiles back inside the matrix (needs beta == 0)
   int ablate;      // timing experiments only (GEMMA_HIP_GEMM_ABLATE): 1 = no global loads / LDS stores after
                    // the first K-tile, 2 = no barrier, 4 = fragments read once (results are then wrong)
 };
@@ -445,7 +446,12 @@ __global__ __launch_bounds__(256, 2) void dgemm_mfma_glds_kernel(GemmArgs g) {
   __shared__ __attribute__((aligned(1024))) double lds[4 * GEMM_TILE_DOUBLES];
   int tm, tn;
   tile_of_block(g, tm, tn);
-  const long m0 = (long)tm * GEMM_BM, n0 = (long)tn * GEMM_BN;
+  long m0 = (long)tm * GEMM_BM, n0 = (long)tn * GEMM_BN;
+  if (g.clamp) { // ragged last tile row / column: shift the tile back inside (beta == 0: the overlap is rewritten
+                 // with bit-identical values, every element sums its k products in the same order in any tile)
+    m0 = min(m0, g.M - GEMM_BM);
+    n0 = min(n0, g.N - GEMM_BN);
+  }
   const int t = threadIdx.x;
   const int lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -465,20 +471,17 @@ __global__ __launch_bounds__(256, 2) void dgemm_mfma_glds_kernel(GemmArgs g) {
   // LDS-DMA pieces: wave w moves pieces p = 4w + j (j = 0..3) of each operand tile.
   //   [k][m]: piece p = k-row p;  source row stride ld, lane offset 16 B * lane;  LDS p * 144 doubles
   //   [m][k]: piece p = rows 8p..8p+7;  lane -> row 8p + (lane >> 3), chunk (lane & 7) ^ ((row >> 1) & 7);  LDS p * 128
-  const char *ga[4], *gb[4];
-  unsigned va[2], vb[2]; // per-lane source byte offsets for even / odd j
+  // One running per-lane source pointer per piece (16 VGPRs), advanced one per MFMA slot.
+  const char *pA[4], *pB[4];
   constexpr int pa = A_KM ? GEMM_LD_KM : 128, pb = B_KN ? GEMM_LD_KM : 128; // LDS doubles per piece
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const long p = 4 * wave + j;
-    ga[j] = reinterpret_cast<const char *>(A_KM ? g.A + p * g.lda + m0 : g.A + (m0 + 8 * p) * g.lda);
-    gb[j] = reinterpret_cast<const char *>(B_KN ? g.B + p * g.ldb + n0 : g.B + (n0 + 8 * p) * g.ldb);
-  }
-#pragma unroll
-  for (int e = 0; e < 2; ++e) {
-    const int chunk = (lane & 7) ^ (4 * e + (lane >> 4));
-    va[e] = A_KM ? (unsigned)lane * 16u : (unsigned)(((long)(lane >> 3) * g.lda + 2 * chunk) * 8);
-    vb[e] = B_KN ? (unsigned)lane * 16u : (unsigned)(((long)(lane >> 3) * g.ldb + 2 * chunk) * 8);
+    const int chunk = (lane & 7) ^ (4 * (j & 1) + (lane >> 4));
+    pA[j] = reinterpret_cast<const char *>(A_KM ? g.A + p * g.lda + m0 + 2 * lane
+                                                : g.A + (m0 + 8 * p + (lane >> 3)) * g.lda + 2 * chunk);
+    pB[j] = reinterpret_cast<const char *>(B_KN ? g.B + p * g.ldb + n0 + 2 * lane
+                                                : g.B + (n0 + 8 * p + (lane >> 3)) * g.ldb + 2 * chunk);
   }
   const long da = (A_KM ? (long)GEMM_BK * g.lda : (long)GEMM_BK) * 8; // source byte advance per K-tile
   const long db = (B_KN ? (long)GEMM_BK * g.ldb : (long)GEMM_BK) * 8;
@@ -496,39 +499,47 @@ __global__ __launch_bounds__(256, 2) void dgemm_mfma_glds_kernel(GemmArgs g) {
 #define GEMMA_DMA(q, AD, BD)                                                                                   \
   do {                                                                                                         \
     if ((q) < 4)                                                                                               \
-      __builtin_amdgcn_global_load_lds((gemma_gptr_t)(ga[(q)&3] + va[(q)&1]),                                  \
+      __builtin_amdgcn_global_load_lds((gemma_gptr_t)pA[(q)&3],                                                \
                                        (gemma_lptr_t)((AD) + (4 * wave + ((q)&3)) * pa), 16, 0, 0);            \
     else                                                                                                       \
-      __builtin_amdgcn_global_load_lds((gemma_gptr_t)(gb[(q)&3] + vb[(q)&1]),                                  \
+      __builtin_amdgcn_global_load_lds((gemma_gptr_t)pB[(q)&3],                                                \
                                        (gemma_lptr_t)((BD) + (4 * wave + ((q)&3)) * pb), 16, 0, 0);            \
   } while (0)
-#define GEMMA_ADVANCE()                                                                                        \
+#define GEMMA_ADV(q)                                                                                           \
   do {                                                                                                         \
-    _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_) { ga[j_] += da; gb[j_] += db; }                           \
+    if ((q) < 4) pA[(q)&3] += da;                                                                              \
+    else pB[(q)&3] += db;                                                                                      \
   } while (0)
-// fragment q (0..3: A blocks, 4..7: B blocks) of K-step KK
-#define GEMMA_FRAG(q, AS, BS, KK, FA, FB)                                                                      \
+// fragment pair q (0,1: A blocks 0-1 / 2-3;  2,3: B blocks 0-1 / 2-3) of K-step KK: one ds_read2[st64]_b64
+#define GEMMA_FRAG2(q, AS, BS, KK, FA, FB)                                                                     \
   do {                                                                                                         \
-    if ((q) < 4) FA[(q)&3] = (AS)[a_l[KK] + ((q)&3) * a_i];                                                    \
-    else FB[(q)&3] = (BS)[b_l[KK] + ((q)&3) * b_j];                                                            \
+    if ((q) < 2) {                                                                                             \
+      FA[2 * (q)] = (AS)[a_l[KK] + (2 * (q)) * a_i];                                                           \
+      FA[2 * (q) + 1] = (AS)[a_l[KK] + (2 * (q) + 1) * a_i];                                                   \
+    } else {                                                                                                   \
+      FB[2 * ((q)-2)] = (BS)[b_l[KK] + (2 * ((q)-2)) * b_j];                                                   \
+      FB[2 * ((q)-2) + 1] = (BS)[b_l[KK] + (2 * ((q)-2) + 1) * b_j];                                           \
+    }                                                                                                          \
   } while (0)
 #define GEMMA_MF(q, FA, FB)                                                                                    \
   acc[(q) >> 2][(q)&3] = __builtin_amdgcn_mfma_f64_16x16x4f64(FA[(q) >> 2], FB[(q)&3], acc[(q) >> 2][(q)&3], 0, 0, 0)
-// 16 MFMAs of one K-step on (FA, FB) with the 8 fragment reads of the next K-step behind the first 8
-#define GEMMA_STEP(FA, FB, AS, BS, KK, GA, GB)                                                                 \
+// 16 MFMAs of one K-step on (FA, FB); the fragments of the next K-step behind MFMAs 0-3; ADV: pointer advances
+// behind MFMAs 8-15
+#define GEMMA_STEP(FA, FB, AS, BS, KK, GA, GB, ADV)                                                            \
   do {                                                                                                         \
     _Pragma("unroll") for (int q_ = 0; q_ < 16; ++q_) {                                                        \
       GEMMA_MF(q_, FA, FB);                                                                                    \
-      if (q_ < 8) GEMMA_FRAG(q_, AS, BS, KK, GA, GB);                                                          \
+      if (q_ < 4) GEMMA_FRAG2(q_, AS, BS, KK, GA, GB);                                                         \
+      if ((ADV) && q_ >= 8) GEMMA_ADV(q_ - 8);                                                                 \
       GEMMA_SB();                                                                                              \
     }                                                                                                          \
   } while (0)
 // one K-tile; MORE: tile t+1 exists (its first fragments are read at the end); LOAD2: tile t+2 exists (DMA it)
 #define GEMMA_KTILE(AC, BC, AN, BN, MORE, LOAD2)                                                               \
   do {                                                                                                         \
-    GEMMA_STEP(xa, xb, AC, BC, 1, ya, yb);                                                                     \
-    GEMMA_STEP(ya, yb, AC, BC, 2, xa, xb);                                                                     \
-    GEMMA_STEP(xa, xb, AC, BC, 3, ya, yb);                                                                     \
+    GEMMA_STEP(xa, xb, AC, BC, 1, ya, yb, false);                                                              \
+    GEMMA_STEP(ya, yb, AC, BC, 2, xa, xb, false);                                                              \
+    GEMMA_STEP(xa, xb, AC, BC, 3, ya, yb, LOAD2);                                                              \
     _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) {                                                         \
       GEMMA_MF(q_, ya, yb);                                                                                    \
       GEMMA_SB();                                                                                              \
@@ -537,9 +548,10 @@ __global__ __launch_bounds__(256, 2) void dgemm_mfma_glds_kernel(GemmArgs g) {
     GEMMA_SB();                                                                                                \
     _Pragma("unroll") for (int q_ = 4; q_ < 16; ++q_) {                                                        \
       GEMMA_MF(q_, ya, yb);                                                                                    \
-      if (q_ < 12) {                                                                                           \
-        if (MORE) GEMMA_FRAG(q_ - 4, AN, BN, 0, xa, xb);                                                       \
-        if (LOAD2) GEMMA_DMA(q_ - 4, AC, BC);                                                                  \
+      if (q_ < 8) {                                                                                            \
+        if (MORE) GEMMA_FRAG2(q_ - 4, AN, BN, 0, xa, xb);                                                      \
+      } else {                                                                                                 \
+        if (LOAD2) GEMMA_DMA(q_ - 8, AC, BC);                                                                  \
       }                                                                                                        \
       GEMMA_SB();                                                                                              \
     }                                                                                                          \
@@ -550,10 +562,10 @@ __global__ __launch_bounds__(256, 2) void dgemm_mfma_glds_kernel(GemmArgs g) {
 #pragma unroll
   for (int q = 0; q < 8; ++q) GEMMA_DMA(q, As0, Bs0);
   if (nk > 1) {
-    GEMMA_ADVANCE();
+#pragma unroll
+    for (int q = 0; q < 8; ++q) GEMMA_ADV(q);
 #pragma unroll
     for (int q = 0; q < 8; ++q) GEMMA_DMA(q, As1, Bs1);
-    GEMMA_ADVANCE();
     asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); // tile 0 has landed, tile 1 may still be in flight
     __builtin_amdgcn_s_barrier();
   } else {
@@ -561,15 +573,15 @@ __global__ __launch_bounds__(256, 2) void dgemm_mfma_glds_kernel(GemmArgs g) {
   }
   GEMMA_SB();
 #pragma unroll
-  for (int q = 0; q < 8; ++q) GEMMA_FRAG(q, As0, Bs0, 0, xa, xb);
+  for (int q = 0; q < 4; ++q) GEMMA_FRAG2(q, As0, Bs0, 0, xa, xb);
 
+  // the source pointers stand on tile kt+1 when K-tile kt starts; its third K-step moves them to tile kt+2
   long kt = 0;
   for (; kt + 2 < nk; ++kt) { // steady state
     const bool odd = (kt & 1) != 0;
     double *Ac = odd ? As1 : As0, *Bc = odd ? Bs1 : Bs0;
     double *An = odd ? As0 : As1, *Bn = odd ? Bs0 : Bs1;
     GEMMA_KTILE(Ac, Bc, An, Bn, true, true);
-    GEMMA_ADVANCE();
   }
   if (nk >= 2) { // K-tile nk-2: nothing left to load
     const bool odd = (nk & 1) != 0;
@@ -584,8 +596,8 @@ __global__ __launch_bounds__(256, 2) void dgemm_mfma_glds_kernel(GemmArgs g) {
     GEMMA_KTILE(Ac, Bc, An, Bn, false, false);
   }
 #undef GEMMA_DMA
-#undef GEMMA_ADVANCE
-#undef GEMMA_FRAG
+#undef GEMMA_ADV
+#undef GEMMA_FRAG2
 #undef GEMMA_MF
 #undef GEMMA_STEP
 #undef GEMMA_KTILE
@@ -646,14 +658,24 @@ static inline int gemm_waves() {
   return nw;
 }
 
-// GEMMA_HIP_GEMM_PIPE=0/1/2: interior kernel = classic / software-pipelined / pipelined + interleaved issue
+// GEMMA_HIP_GEMM_PIPE=0/1/2: interior kernel = register-staged / + software-pipelined fragments / direct-to-LDS with
+// pinned interleaved issue (default; 243 -> 238 -> 219 ms at M = N = K = 20000)
 static inline int gemm_pipe() {
   static int v = -1;
   if (v < 0) {
     const char *e = getenv("GEMMA_HIP_GEMM_PIPE");
-    v = e ? atoi(e) : 0;
+    v = e ? atoi(e) : 2;
   }
   return v;
+}
+
+static inline bool gemm_clamp() { // GEMMA_HIP_GEMM_CLAMP=0: ragged strips through the bounds-checked kernel
+  static int v = -1;
+  if (v < 0) {
+    const char *e = getenv("GEMMA_HIP_GEMM_CLAMP");
+    v = (e && e[0] == '0') ? 0 : 1;
+  }
+  return v == 1;
 }
 
 template <bool A_KM, bool B_KN, bool FULL>
@@ -665,7 +687,12 @@ static inline hipError_t launch_dgemm_grid(const GemmArgs &g, hipStream_t s) {
     nblocks = g.tiles_m * g.tiles_n;
   if (nblocks <= 0) return hipSuccess;
   if (FULL && gemm_pipe() == 2 && !g.square_a) {
-    hipLaunchKernelGGL((dgemm_mfma_glds_kernel<A_KM, B_KN>), dim3(nblocks), dim3(256), 0, s, g);
+    static int xl = -1; // experiment: extra dynamic LDS to force 1 block per CU
+    if (xl < 0) {
+      const char *e = getenv("GEMMA_HIP_GEMM_XLDS");
+      xl = e ? atoi(e) : 0;
+    }
+    hipLaunchKernelGGL((dgemm_mfma_glds_kernel<A_KM, B_KN>), dim3(nblocks), dim3(256), xl, s, g);
   } else if (FULL && gemm_pipe()) {
     static int xlds = -1; // experiment: extra dynamic LDS to force 1 block per CU
     if (xlds < 0) {
@@ -721,6 +748,15 @@ static inline hipError_t launch_dgemm_t(GemmArgs g, hipStream_t s) {
     return launch_dgemm_grid<A_KM, B_KN, false>(g, s);
   }
   const int syrk = g.syrk_upper;
+  g.clamp = 0;
+  // beta == 0: ragged last tile rows / columns are shifted back inside the matrix and ride in the same launch
+  // (bit-identical rewrites of the overlap); the [k][m] operand of a shifted tile must stay 16-byte aligned
+  if (gemm_pipe() >= 2 && !syrk && !g.square_a && g.beta == 0.0 && (Tm > Fm || Tn > Fn) && gemm_clamp() &&
+      (!A_KM || (g.M & 1) == 0) && (!B_KN || (g.N & 1) == 0)) {
+    g.clamp = 1;
+    g.tiles_m = Tm; g.tiles_n = Tn; g.tm0 = 0; g.tn0 = 0;
+    return launch_dgemm_grid<A_KM, B_KN, true>(g, s);
+  }
   const bool strips = (Tn > Fn) || (Tm > Fm && !syrk);
   const bool side = strips && g_gemm_aux.stream != nullptr && Fm * Fn >= 512;
   hipStream_t es = side ? g_gemm_aux.stream : s; // stream of the edge strips
@@ -772,6 +808,7 @@ static inline hipError_t launch_dgemm(char ta, char tb, long M, long N, long K, 
   g.tiles_m = g.tiles_n = 0;
   g.tm0 = g.tn0 = 0;
   g.syrk_upper = syrk_upper ? 1 : 0;
+  g.clamp = 0;
   g.square_a = square_a ? 1 : 0;
   {
     static int abl = -1;
