@@ -17,6 +17,7 @@
 #include "ingest.hip.h"
 #include "lm_assoc.hip.h"
 #include "lmm_assoc.hip.h"
+#include "lmm_grid.hip.h"
 #include "qc.hip.h"
 
 using namespace gemma_hip;
@@ -76,6 +77,8 @@ struct Ctx {
   size_t ni_total = 0; // PLINK rows cover this many individuals (0 = n)
   bool have_map = false;
   DevBuf X, UtX, stage_in, stage_out, carry;
+  DevBuf grid_R, grid_F, grid_T; // fixed-lambda table (lmm_grid.hip.h)
+  GridGeom grid_geom;
   int carry_flip = 0;
   AssocArgs assoc_proto;
 
@@ -671,6 +674,68 @@ static int lmm_common_setup(const gemma_lmm_cfg *cfg) {
   return GEMMA_HIP_OK;
 }
 
+// Fixed-lambda table, SNP-independent part (lmm_grid.hip.h): weight matrix in MFMA operand order and the sums over
+// the covariate / phenotype pairs.  Built for the register kernels (c <= 4) and the default n_region = 10 (23
+// weights); anything else keeps streaming every evaluation.  GEMMA_HIP_ASSOC_GRID=0 switches the table off.
+static bool grid_blocks(size_t c, int nq, int *nbx, int *nba) {
+  *nbx = (nq + 15) / 16;
+  *nba = ((int)(c + 1) * nq + 15) / 16;
+  return c >= 1 && c <= 4 && nq == 23;
+}
+static int make_grid(hipStream_t s) {
+  AssocArgs &a = g_ctx.assoc_proto;
+  a.have_grid = 0;
+  a.grid_T = nullptr;
+  a.grid_F = nullptr;
+  const char *e = getenv("GEMMA_HIP_ASSOC_GRID");
+  if (e && e[0] == '0') return GEMMA_HIP_OK;
+  const size_t n = g_ctx.cfg.n, c = g_ctx.cfg.n_cvt;
+  GridGeom gg;
+  gg.nq = 1 + 2 * ((int)g_ctx.cfg.n_region + 1);
+  if (!grid_blocks(c, gg.nq, &gg.nbx, &gg.nba)) return GEMMA_HIP_OK;
+  gg.nc = (int)((n + 15) / 16);
+  const size_t nb = (size_t)(gg.nbx + gg.nba);
+  const size_t r_elems = (size_t)gg.nc * nb * 256;
+  if (g_ctx.grid_R.reserve(r_elems * 8) || g_ctx.grid_F.reserve((size_t)gg.nq * GRID_FIX_LD * 8))
+    return fail(GEMMA_HIP_ENOMEM, "lmm_setup: fixed-lambda table");
+  AssocArgs k = a;
+  k.eval = g_ctx.eval;
+  k.Uty = g_ctx.Uty;
+  k.UtWt = g_ctx.UtWt.as<double>();
+  hipLaunchKernelGGL(grid_weights_kernel, dim3((unsigned)((r_elems + 255) / 256)), dim3(256), 0, s, k, gg, (int)c,
+                     g_ctx.grid_R.as<double>());
+  HIPCHK(hipGetLastError());
+  hipLaunchKernelGGL(grid_fixed_kernel, dim3((unsigned)gg.nq), dim3(256), 0, s, k, (int)c, g_ctx.grid_F.as<double>());
+  HIPCHK(hipGetLastError());
+  g_ctx.grid_geom = gg;
+  a.grid_F = g_ctx.grid_F.as<double>();
+  a.grid_ld = (int)(nb * 16);
+  a.grid_nq = gg.nq;
+  a.grid_xa0 = gg.nbx * 16;
+  a.have_grid = 1;
+  return GEMMA_HIP_OK;
+}
+
+// the per-batch part: T = [X.X | X] * R for the l SNP rows of UtX
+static int launch_grid_table(const double *UtX, size_t l, size_t ld, hipStream_t s) {
+  const GridGeom &gg = g_ctx.grid_geom;
+  const size_t nb = (size_t)(gg.nbx + gg.nba);
+  if (g_ctx.grid_T.reserve(l * nb * 16 * 8)) return fail(GEMMA_HIP_ENOMEM, "lmm_assoc: fixed-lambda table");
+  const unsigned grid = (unsigned)((l + 15) / 16);
+  const double *R = g_ctx.grid_R.as<double>();
+  double *T = g_ctx.grid_T.as<double>();
+  const int n = (int)g_ctx.cfg.n;
+  switch (gg.nba) {
+  case 3: hipLaunchKernelGGL((grid_table_kernel<2, 3>), dim3(grid), dim3(256), 0, s, UtX, (long)ld, (long)l, n, gg.nc, R, T); break;
+  case 5: hipLaunchKernelGGL((grid_table_kernel<2, 5>), dim3(grid), dim3(256), 0, s, UtX, (long)ld, (long)l, n, gg.nc, R, T); break;
+  case 6: hipLaunchKernelGGL((grid_table_kernel<2, 6>), dim3(grid), dim3(256), 0, s, UtX, (long)ld, (long)l, n, gg.nc, R, T); break;
+  case 8: hipLaunchKernelGGL((grid_table_kernel<2, 8>), dim3(grid), dim3(256), 0, s, UtX, (long)ld, (long)l, n, gg.nc, R, T); break;
+  default: return fail(GEMMA_HIP_ERUNTIME, "lmm_assoc: no fixed-lambda table kernel for %d column blocks", gg.nba);
+  }
+  HIPCHK(hipGetLastError());
+  return GEMMA_HIP_OK;
+}
+
 // UtW (n x c row-major) -> UtWt (c x n)
 static int make_utwt(const double *UtW_d, hipStream_t s) {
   const size_t n = g_ctx.cfg.n, c = g_ctx.cfg.n_cvt;
@@ -690,7 +755,7 @@ static int make_utwt(const double *UtW_d, hipStream_t s) {
   g_ctx.assoc_proto.logdet_lmin = ends[0];
   g_ctx.assoc_proto.logdet_lmax = ends[1];
   g_ctx.assoc_proto.have_logdet_ends = 1;
-  return GEMMA_HIP_OK;
+  return make_grid(s);
 }
 
 extern "C" int gemma_hip_lmm_setup_d(const gemma_lmm_cfg *cfg, const double *U_d, const double *eval_d,
@@ -769,6 +834,13 @@ static int launch_assoc(const double *UtX, size_t l, size_t ld, gemma_sumstat *o
     // GEMMA_HIP_FORCE_GENERIC=1 routes every covariate count through the multi-pass kernel (tests)
     const char *fg = getenv("GEMMA_HIP_FORCE_GENERIC");
     const size_t sel = (fg && fg[0] == '1') ? 99 : g_ctx.cfg.n_cvt;
+    a.grid_T = nullptr;
+    if (a.have_grid && sel <= 4 && (ld & 1) == 0 && (reinterpret_cast<uintptr_t>(UtX) & 15) == 0 &&
+        a.a_mode != 3) { // mode 3 (score only) never searches lambda
+      int rc = launch_grid_table(UtX, l, ld, s);
+      if (rc) return rc;
+      a.grid_T = g_ctx.grid_T.as<double>();
+    }
     switch (sel) {
     case 1: hipLaunchKernelGGL(lmm_assoc_kernel<1>, dim3(grid), dim3(256), 0, s, a); break;
     case 2: hipLaunchKernelGGL(lmm_assoc_kernel<2>, dim3(grid), dim3(256), 0, s, a); break;
@@ -1058,6 +1130,7 @@ extern "C" int gemma_hip_lmm_finish(double *time_UtX_min, double *time_opt_min) 
   g_ctx.own_U.release(); g_ctx.own_eval.release(); g_ctx.own_Uty.release(); g_ctx.own_UtW.release();
   g_ctx.UtWt.release(); g_ctx.idx_map.release(); g_ctx.X.release(); g_ctx.UtX.release();
   g_ctx.stage_in.release(); g_ctx.stage_out.release();
+  g_ctx.grid_R.release(); g_ctx.grid_F.release(); g_ctx.grid_T.release();
   g_ctx.U = g_ctx.eval = g_ctx.Uty = nullptr;
   g_ctx.lmm_active = false;
   return GEMMA_HIP_OK;

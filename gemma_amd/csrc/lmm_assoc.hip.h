@@ -43,6 +43,12 @@ struct AssocArgs {
   double lnbeta_half_df;  // ln B(df/2, 1/2), df = n - c - 1 (host lgamma)
   double logdet_lmin, logdet_lmax; // sum_i log|l*delta_i + 1| at l_min / l_max (SNP independent; logdet_ends_kernel)
   int have_logdet_ends;
+  // fixed-lambda table (lmm_grid.hip.h): per SNP the x-dependent sums at the grid lambdas, plus the SNP-independent
+  // sums; columns of T: [q] = sum x^2 w_q,  [grid_xa0 + a * grid_nq + q] = sum x u_a w_q (a < c: U^T W column, a = c: U^T y)
+  const double *grid_T; // l x grid_ld (this batch), nullptr when the table path is off
+  const double *grid_F; // grid_nq x 16: pair sums among (w_1..w_c, y) in upper-triangle order, [15] = sum w_q
+  int grid_ld, grid_nq, grid_xa0;
+  int have_grid;
   double lam_grid[ASSOC_MAX_REGION + 1]; // l_min*exp(i*log(l_max/l_min)/n_region), host libm
 };
 
@@ -326,11 +332,10 @@ struct Agg {
 // number of covariates fixed at compile time: everything in registers (c = 1..4)
 template <int C>
 struct FixedC {
+  static constexpr bool HAS_GRID = true;
   __device__ __forceinline__ int c() const { return C; }
-  template <int ORDER, bool LOGDET>
-  __device__ __forceinline__ void eval(const AssocArgs &g, const double *x, double l, int lane, Agg &A) const {
-    Row0<C> R;
-    row0_pass<C, ORDER, LOGDET>(g, x, l, lane, R);
+  template <int ORDER>
+  __device__ __forceinline__ void finish(const Row0<C> &R, Agg &A) const {
     Proj<C> P;
     project<C, (ORDER == 0 ? 1 : ORDER)>(R, P);
     A.tr1 = R.tr1;
@@ -353,6 +358,53 @@ struct FixedC {
     A.yy2 = P.yy2[1];
     A.yy3 = P.yy3[1];
   }
+  template <int ORDER, bool LOGDET>
+  __device__ __forceinline__ void eval(const AssocArgs &g, const double *x, double l, int lane, Agg &A) const {
+    Row0<C> R;
+    row0_pass<C, ORDER, LOGDET>(g, x, l, lane, R);
+    finish<ORDER>(R, A);
+  }
+  // The same evaluation at grid lambda gi (gi < 0: H = 1, the Iab call) from the fixed-lambda table: the row-0
+  // sums are assembled from the SNP's table row (pairs with x) and the SNP-independent sums; ORDER <= 2.
+  template <int ORDER>
+  __device__ __forceinline__ void eval_grid(const AssocArgs &g, const double *__restrict__ trow, int gi, Agg &A) const {
+    Row0<C> R;
+    const int q1 = (gi < 0) ? 0 : 1 + 2 * gi, q2 = q1 + 1;
+    const double *__restrict__ F1 = g.grid_F + (long)q1 * 16;
+    const double *__restrict__ F2 = g.grid_F + (long)q2 * 16;
+    const int nq = g.grid_nq, xa0 = g.grid_xa0;
+#pragma unroll
+    for (int a = 1; a <= C + 2; ++a) {
+#pragma unroll
+      for (int b = a; b <= C + 2; ++b) {
+        const int q = ab_index<C>(a, b);
+        // variables 1..C: covariates (fixed index a-1), C+1: x, C+2: y (fixed index C)
+        const bool ax = (a == C + 1), bx = (b == C + 1);
+        const int fa = (a == C + 2) ? C : a - 1, fb = (b == C + 2) ? C : b - 1;
+        double v1, v2 = 0.0;
+        if (ax && bx) {
+          v1 = trow[q1];
+          if (ORDER >= 2) v2 = trow[q2];
+        } else if (ax || bx) {
+          const int f = ax ? fb : fa;
+          v1 = trow[xa0 + f * nq + q1];
+          if (ORDER >= 2) v2 = trow[xa0 + f * nq + q2];
+        } else {
+          // upper-triangle index of (fa, fb), fa <= fb, over C + 1 fixed variables
+          const int pidx = fa * (C + 1) - fa * (fa - 1) / 2 + (fb - fa);
+          v1 = F1[pidx];
+          if (ORDER >= 2) v2 = F2[pidx];
+        }
+        R.s1[q] = v1;
+        R.s2[q] = v2;
+        R.s3[q] = 0.0;
+      }
+    }
+    R.tr1 = (gi < 0) ? 0.0 : F1[15];
+    R.tr2 = 0.0;
+    R.logdet = 0.0;
+    finish<ORDER>(R, A);
+  }
 };
 
 // any number of covariates (c <= GEN_CMAX): the (c+2) x (c+2) product table is covered by 4 x 4 register
@@ -369,6 +421,7 @@ __device__ __forceinline__ int ab_index_rt(int a, int b, int c) {
 }
 
 struct GenericC {
+  static constexpr bool HAS_GRID = false;
   int cc;
   double *L; // this wave's LDS scratch, GEN_LDS_PER_WAVE doubles
   __device__ __forceinline__ int c() const { return cc; }
@@ -521,14 +574,13 @@ struct SnpCtx {
   int lane;
   M m;
   double logdet_iw; // sum_i log(Iab(i, ww_{i+1})), i < c+1  (H == 1; SNP constant)
+  const double *trow; // this SNP's row of the fixed-lambda table, nullptr: stream every evaluation
 };
 
 // LogRL_dev1 / LogRL_dev12 (src/lmm.cpp:866-943, :1035-1125) and LogL_dev1 / LogL_dev12
 // (:544-640, :719-797).  ORDER 2 -> dev1 only; ORDER 3 -> dev1 and dev2.
 template <class M, bool REML, int ORDER>
-__device__ __forceinline__ void deriv(const SnpCtx<M> &s, double l, double &dev1, double &dev2) {
-  Agg A;
-  s.m.template eval<ORDER, false>(*s.g, s.x, l, s.lane, A);
+__device__ __forceinline__ void deriv_from(const SnpCtx<M> &s, double l, const Agg &A, double &dev1, double &dev2) {
   const double n = (double)s.g->n;
   const double P_yy = A.yy1, PP_yy = A.yy2, PPP_yy = A.yy3;
   const double yPKPy = (P_yy - PP_yy) / l;
@@ -554,6 +606,28 @@ __device__ __forceinline__ void deriv(const SnpCtx<M> &s, double l, double &dev1
   dev1 = uniform(dev1);
   if (ORDER >= 3) dev2 = uniform(dev2);
 }
+template <class M, bool REML, int ORDER>
+__device__ __forceinline__ void deriv(const SnpCtx<M> &s, double l, double &dev1, double &dev2) {
+  Agg A;
+  s.m.template eval<ORDER, false>(*s.g, s.x, l, s.lane, A);
+  deriv_from<M, REML, ORDER>(s, l, A, dev1, dev2);
+}
+// first derivative at grid lambda gi: from the fixed-lambda table when this SNP has a row in it
+template <class M, bool REML>
+__device__ __forceinline__ double dev1_grid(const SnpCtx<M> &s, int gi) {
+  double d1, d2 = 0.0;
+  const double l = s.g->lam_grid[gi];
+  if constexpr (M::HAS_GRID) {
+    if (s.trow) {
+      Agg A;
+      s.m.template eval_grid<2>(*s.g, s.trow, gi, A);
+      deriv_from<M, REML, 2>(s, l, A, d1, d2);
+      return d1;
+    }
+  }
+  deriv<M, REML, 2>(s, l, d1, d2);
+  return d1;
+}
 
 // LogRL_f (src/lmm.cpp:799-864) / LogL_f (:484-542)
 template <class M, bool REML>
@@ -561,7 +635,14 @@ __device__ __forceinline__ double logf(const SnpCtx<M> &s, double l, Agg &A) {
   // log|H| at the two interval ends does not depend on the SNP: taken from the setup kernel, which sums
   // in this kernel's own order (bit-identical to evaluating it here)
   if (s.g->have_logdet_ends && (l == s.g->l_min || l == s.g->l_max)) {
-    s.m.template eval<1, false>(*s.g, s.x, l, s.lane, A);
+    bool done = false;
+    if constexpr (M::HAS_GRID) {
+      if (s.trow) { // l_min / l_max are grid points 0 / n_region
+        s.m.template eval_grid<1>(*s.g, s.trow, (l == s.g->l_min) ? 0 : s.g->n_region, A);
+        done = true;
+      }
+    }
+    if (!done) s.m.template eval<1, false>(*s.g, s.x, l, s.lane, A);
     A.logdet = (l == s.g->l_min) ? s.g->logdet_lmin : s.g->logdet_lmax;
   } else {
     s.m.template eval<1, true>(*s.g, s.x, l, s.lane, A);
@@ -726,10 +807,10 @@ __device__ __forceinline__ void calc_lambda(const SnpCtx<M> &cx, double &lambda,
   double lam = NAN, lf = NAN;
   bool any = false, first = true, stop = false, failed = false;
   double l = 0.0, l_temp = 0.0;
-  double d_lo = dev1_of<M, REML>(cx, g.lam_grid[0]);
+  double d_lo = dev1_grid<M, REML>(cx, 0);
   for (int i = 0; i < g.n_region; ++i) {
     const double lambda_l0 = g.lam_grid[i], lambda_h0 = g.lam_grid[i + 1];
-    const double d_hi = dev1_of<M, REML>(cx, lambda_h0);
+    const double d_hi = dev1_grid<M, REML>(cx, i + 1);
     const bool bracket = (d_lo * d_hi <= 0);
     if (bracket) any = true;
     if (bracket && !stop && !failed) {
@@ -812,7 +893,14 @@ __device__ __forceinline__ void calc_lambda(const SnpCtx<M> &cx, double &lambda,
 template <class M>
 __device__ __forceinline__ double logdet_iw_of(const SnpCtx<M> &cx) {
   Agg A;
-  cx.m.template eval<0, false>(*cx.g, cx.x, 0.0, cx.lane, A);
+  bool done = false;
+  if constexpr (M::HAS_GRID) {
+    if (cx.trow) {
+      cx.m.template eval_grid<0>(*cx.g, cx.trow, -1, A);
+      done = true;
+    }
+  }
+  if (!done) cx.m.template eval<0, false>(*cx.g, cx.x, 0.0, cx.lane, A);
   return uniform(A.slog);
 }
 
@@ -826,6 +914,7 @@ __device__ __forceinline__ void assoc_one_snp(const AssocArgs &g, const M &model
   cx.lane = lane;
   cx.m = model;
   cx.logdet_iw = 0.0;
+  cx.trow = (g.have_grid && g.grid_T) ? g.grid_T + snp * g.grid_ld : nullptr;
   const int a_mode = g.a_mode;
 
   double lambda_mle = 0.0, lambda_remle = 0.0, beta = 0.0, se = 0.0, p_wald = 0.0;
@@ -876,7 +965,7 @@ __device__ __forceinline__ void assoc_one_snp(const AssocArgs &g, const M &model
 template <int C>
 __global__ __launch_bounds__(256, (C == 1 ? 3 : (C == 2 ? 2 : 1))) void lmm_assoc_kernel(AssocArgs g) {
   const int lane = threadIdx.x & 63;
-  const long snp = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const long snp = (long)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   if (snp >= g.l) return;
   assoc_one_snp(g, FixedC<C>(), snp, lane);
 }
@@ -927,6 +1016,7 @@ __device__ __forceinline__ void null_model(const AssocArgs &g, const M &model, i
   cx.x = g.UtWt + (long)cp * g.n; // last covariate column
   cx.lane = lane;
   cx.m = model;
+  cx.trow = nullptr;
   cx.logdet_iw = logdet_iw_of(cx);
   NullOut o;
   Agg tmp;
