@@ -310,6 +310,37 @@ def test_lmm_synthetic_all_modes(gpu_api, oracle, n, c):
         assert lmm.time_UtX >= 0 and lmm.time_opt >= 0
 
 
+@pytest.mark.parametrize("n,c", [(500, 1), (301, 2), (257, 4)])
+def test_fixed_lambda_table_vs_streaming(gpu_api, oracle, n, c, monkeypatch):
+    """The MFMA table of the SNP-independent lambdas (lmm_grid.hip.h, default) against the same kernel streaming
+    every evaluation (GEMMA_HIP_ASSOC_GRID=0): both on the GPU, both against the oracle; n not a multiple of 16
+    exercises the masked last K chunk of the table product."""
+    X, U, ev, UtW, Uty, tr = _synthetic(oracle, n, 260, c, seed=900 + n)
+    l_mle, logl0 = oracle.calc_lambda_null("L", ev, UtW, Uty)
+    ref = oracle.lmm_analyze(4, U, ev, UtW, Uty, X, l_mle_null=l_mle, logl_mle_H0=logl0)
+    res = {}
+    for grid in ("1", "0"):
+        monkeypatch.setenv("GEMMA_HIP_ASSOC_GRID", grid)
+        lmm = gpu_api.LMM(a_mode=4, l_mle_null=l_mle, logl_mle_H0=logl0)
+        res[grid] = lmm.AnalyzeBimbam(U, ev, UtW, Uty, X)
+        _cmp_stats(res[grid], ref, 4, "n=%d c=%d table=%s" % (n, c, grid))
+    for k in ("beta", "se", "p_wald", "p_lrt", "logl_H1"):
+        a, b = res["1"][k], res["0"][k]
+        ok = ~(np.isnan(a) | np.isnan(b))
+        np.testing.assert_allclose(a[ok], b[ok], rtol=1e-7, err_msg=k)
+
+
+@pytest.mark.parametrize("n_region", [7, 16])
+def test_lmm_other_region_counts_stream(gpu_api, oracle, n_region):
+    """-region != 10: no table kernel is built for that weight count, every evaluation streams (FixedC path)."""
+    X, U, ev, UtW, Uty, tr = _synthetic(oracle, 300, 200, 2, seed=77 + n_region)
+    l_mle, logl0 = oracle.calc_lambda_null("L", ev, UtW, Uty)
+    ref = oracle.lmm_analyze(4, U, ev, UtW, Uty, X, l_mle_null=l_mle, logl_mle_H0=logl0, n_region=n_region)
+    lmm = gpu_api.LMM(a_mode=4, n_region=n_region, l_mle_null=l_mle, logl_mle_H0=logl0)
+    got = lmm.AnalyzeBimbam(U, ev, UtW, Uty, X)
+    _cmp_stats(got, ref, 4, "n_region=%d" % n_region)
+
+
 @pytest.mark.parametrize("n,c", [(310, 5), (288, 7), (350, 11), (400, 16)])
 def test_lmm_many_covariates(gpu_api, oracle, n, c):
     """c > 4 goes through the register-tiled multi-pass kernel (per-wave LDS recursion)."""
