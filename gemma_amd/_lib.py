@@ -16,7 +16,7 @@ SYMBOLS = [
     "gemma_hip_lmm_null", "gemma_hip_lmm_set_indicator", "gemma_hip_lmm_batch", "gemma_hip_lmm_batch_d",
     "gemma_hip_lmm_assoc_d", "gemma_hip_lmm_finish", "gemma_hip_lm_setup", "gemma_hip_lm_batch", "gemma_hip_lm_batch_d",
     "gemma_hip_lm_finish", "gemma_hip_profile_enable",
-    "gemma_hip_profile_read", "gemma_hip_dbg_tridiag", "gemma_hip_dbg_stedc",
+    "gemma_hip_profile_read", "gemma_hip_dbg_tridiag", "gemma_hip_dbg_stedc", "gemma_hip_dbg_utx",
 ]
 
 OK, EINVAL, ENODEV, ENOMEM, ERUNTIME, ESTATE, ENOCONV = range(7)
@@ -102,6 +102,7 @@ def lib():
     L.gemma_hip_profile_read.argtypes = [ci, C.POINTER(cd), C.POINTER(C.c_long), ci]
     L.gemma_hip_dbg_tridiag.argtypes = [dp, sz, dp, dp, dp, dp]
     L.gemma_hip_dbg_stedc.argtypes = [dp, dp, sz, dp, dp]
+    L.gemma_hip_dbg_utx.argtypes = [C.c_int, vp, sz, sz, C.c_int, dp]
     for s in SYMBOLS:
         getattr(L, s)  # AttributeError if the library does not export what the header declares
     _lib = L

@@ -342,6 +342,17 @@ class LMM:
                                               C.c_void_p(out.data_ptr()), _stream()), "LMM.assoc")
         return out
 
+    def dbg_utx(self, geno, geno_kind, path):
+        """The U^T x stage alone (after setup): (l x n) array, row s = (U^T x_s)^T.  path 0: fp64 MFMA GEMM,
+        path 1: exact int8-digit product (PLINK 2-bit input only)."""
+        geno = np.ascontiguousarray(geno)
+        l, ld = geno.shape[0], geno.shape[1]
+        if geno_kind == L.GENO_F64_IDV_MAJOR:
+            l = geno.shape[1]
+        out = np.empty((l, self.ni_test), dtype=np.float64)
+        L.check(L.lib().gemma_hip_dbg_utx(geno_kind, _ptr(geno), l, ld, path, _ptr(out)), "LMM.dbg_utx")
+        return out
+
     def finish(self):
         a, b = C.c_double(), C.c_double()
         L.check(L.lib().gemma_hip_lmm_finish(C.byref(a), C.byref(b)), "LMM.finish")

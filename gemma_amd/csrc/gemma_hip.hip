@@ -18,6 +18,7 @@
 #include "lm_assoc.hip.h"
 #include "lmm_assoc.hip.h"
 #include "lmm_grid.hip.h"
+#include "i8gemm.hip.h"
 #include "qc.hip.h"
 
 using namespace gemma_hip;
@@ -78,6 +79,9 @@ struct Ctx {
   bool have_map = false;
   DevBuf X, UtX, stage_in, stage_out, carry;
   DevBuf grid_R, grid_F, grid_T; // fixed-lambda table (lmm_grid.hip.h)
+  DevBuf i8_Bt, i8_ej, i8_cmax, i8_A, i8_C, i8_mean; // exact int8-digit U^T x (i8gemm.hip.h)
+  bool i8_ready = false;
+  size_t i8_ldk = 0, i8_npad = 0;
   GridGeom grid_geom;
   int carry_flip = 0;
   AssocArgs assoc_proto;
@@ -671,6 +675,7 @@ static int lmm_common_setup(const gemma_lmm_cfg *cfg) {
   g_ctx.carry_flip = 0;
   g_ctx.have_map = false;
   g_ctx.ni_total = 0;
+  g_ctx.i8_ready = false; // digits belong to the previous U
   return GEMMA_HIP_OK;
 }
 
@@ -872,21 +877,109 @@ extern "C" int gemma_hip_lmm_assoc_d(const double *UtX_d, size_t l, size_t ld_ut
   return launch_assoc(UtX_d, l, ld_utx, out_d, S(stream));
 }
 
-extern "C" int gemma_hip_lmm_batch_d(int kind, const void *geno, size_t l, size_t ld, gemma_sumstat *out_d,
-                                     void *stream) {
-  NEED_INIT();
-  if (!g_ctx.lmm_active) return fail(GEMMA_HIP_ESTATE, "lmm_batch before lmm_setup");
-  if (l == 0) return GEMMA_HIP_OK;
+// GEMMA_HIP_UTX_I8: 1 = PLINK batches go through the exact int8-digit product, 0 = always the fp64 MFMA GEMM
+static int utx_i8_mode() {
+  const char *e = getenv("GEMMA_HIP_UTX_I8");
+  return e ? atoi(e) : 0;
+}
+
+static size_t round_up(size_t v, size_t m) { return (v + m - 1) / m * m; }
+
+// one-time: per-column exponents of U and its 7 balanced base-256 digit matrices, transposed (K contiguous)
+static int i8_prepare_u(hipStream_t s) {
+  if (g_ctx.i8_ready) return GEMMA_HIP_OK;
   const size_t n = g_ctx.cfg.n;
-  const size_t per_row = (kind == GEMMA_GENO_PLINK_2BIT && g_ctx.have_map) ? g_ctx.ni_total : n;
-  const size_t need = min_ld_for(kind, per_row, l);
-  if (need == (size_t)-1) return fail(GEMMA_HIP_EINVAL, "lmm_batch: unknown geno_kind %d", kind);
-  if (!geno || !out_d || ld < need) return fail(GEMMA_HIP_EINVAL, "lmm_batch: ld=%zu < %zu", ld, need);
-  hipStream_t s = S(stream);
+  const size_t ldk = round_up(n, I8_BK), npad = round_up(n, I8_BN);
+  if (g_ctx.i8_Bt.reserve((size_t)I8_DIGITS * npad * ldk) || g_ctx.i8_ej.reserve(n * sizeof(int)) ||
+      g_ctx.i8_cmax.reserve(n * 8))
+    return fail(GEMMA_HIP_ENOMEM, "lmm_batch: int8 digits of U (%zu bytes)", (size_t)I8_DIGITS * npad * ldk);
+  HIPCHK(hipMemsetAsync(g_ctx.i8_Bt.p, 0, (size_t)I8_DIGITS * npad * ldk, s));
+  HIPCHK(hipMemsetAsync(g_ctx.i8_cmax.p, 0, n * 8, s));
+  hipLaunchKernelGGL(u_colmax_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)((n + 1023) / 1024)), dim3(256), 0, s,
+                     g_ctx.U, (long)n, (long)n, g_ctx.i8_cmax.as<unsigned long long>());
+  HIPCHK(hipGetLastError());
+  hipLaunchKernelGGL(u_exponent_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s,
+                     g_ctx.i8_cmax.as<unsigned long long>(), (long)n, g_ctx.i8_ej.as<int>());
+  HIPCHK(hipGetLastError());
+  hipLaunchKernelGGL(u_digits_kernel, dim3((unsigned)((n + 31) / 32), (unsigned)((n + 31) / 32)), dim3(256), 0, s,
+                     g_ctx.U, (long)n, (long)n, g_ctx.i8_ej.as<int>(), g_ctx.i8_Bt.as<int8_t>(), (long)ldk,
+                     (long)(npad * ldk));
+  HIPCHK(hipGetLastError());
+  g_ctx.i8_ldk = ldk;
+  g_ctx.i8_npad = npad;
+  g_ctx.i8_ready = true;
+  return GEMMA_HIP_OK;
+}
+
+// UtX (l x ldx, SNP-major) of a PLINK batch through the int8-digit product
+static int utx_plink_i8(const void *geno, size_t l, size_t ld, double *UtX, size_t ldx, hipStream_t s) {
+  int rc = i8_prepare_u(s);
+  if (rc) return rc;
+  const size_t n = g_ctx.cfg.n, ldk = g_ctx.i8_ldk, npad = g_ctx.i8_npad;
+  const size_t lpad = round_up(l, I8_BM), mrows = 2 * lpad;
+  const size_t c_elems = (size_t)I8_DIGITS * mrows * npad;
+  if (g_ctx.i8_A.reserve(mrows * ldk) || g_ctx.i8_C.reserve(c_elems * 4) || g_ctx.i8_mean.reserve(l * 8))
+    return fail(GEMMA_HIP_ENOMEM, "lmm_batch: int8 product buffers (%zu bytes)", mrows * ldk + c_elems * 4);
+  {
+    ProfScope ps(GEMMA_STAGE_INGEST, s);
+    if (lpad != l) HIPCHK(hipMemsetAsync(g_ctx.i8_A.p, 0, mrows * ldk, s)); // padding rows
+    IngestI8Args a;
+    a.src = reinterpret_cast<const unsigned char *>(geno); a.ld = (long)ld; a.l = (long)l;
+    a.idx_map = g_ctx.have_map ? g_ctx.idx_map.as<int>() : nullptr;
+    a.n = (int)n; a.A = g_ctx.i8_A.as<int8_t>(); a.ldk = (long)ldk; a.m_row0 = (long)lpad;
+    a.mean = g_ctx.i8_mean.as<double>();
+    hipLaunchKernelGGL(ingest_i8_kernel, dim3((unsigned)((l + 3) / 4)), dim3(256), 0, s, a);
+    HIPCHK(hipGetLastError());
+  }
+  {
+    ProfScope ps(GEMMA_STAGE_UTX_GEMM, s);
+    static bool attr_set = false;
+    if (!attr_set) {
+      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(i8gemm_kernel),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
+      attr_set = true;
+    }
+    I8GemmArgs g;
+    g.A = g_ctx.i8_A.as<int8_t>();
+    g.Bt = g_ctx.i8_Bt.as<int8_t>();
+    g.C = g_ctx.i8_C.as<int>();
+    g.ldk = (long)ldk; g.ldc = (long)npad;
+    g.strideB = (long)(npad * ldk); g.strideC = (long)(mrows * npad);
+    g.tiles_m = (int)(mrows / I8_BM); g.tiles_n = (int)(npad / I8_BN);
+    g.nk = (int)(ldk / I8_BK);
+    {
+      static int gm = -1;
+      if (gm < 0) {
+        const char *e = getenv("GEMMA_HIP_I8_GM");
+        gm = e ? atoi(e) : 0;
+      }
+      g.gm = gm;
+    }
+    hipLaunchKernelGGL(i8gemm_kernel, dim3((unsigned)(g.tiles_m * g.tiles_n), I8_DIGITS), dim3(512), 131072, s, g);
+    HIPCHK(hipGetLastError());
+    hipLaunchKernelGGL(i8_combine_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)l), dim3(256), 0, s,
+                       g_ctx.i8_C.as<int>(), (long)npad, (long)(mrows * npad), (long)lpad, g_ctx.i8_mean.as<double>(),
+                       g_ctx.i8_ej.as<int>(), (long)l, (long)n, UtX, (long)ldx);
+    HIPCHK(hipGetLastError());
+  }
+  return GEMMA_HIP_OK;
+}
+
+// UtX (l x ldx, SNP-major) = mean-imputed X (l x n) * U (n x n): row s is (U^T x_s)^T, i.e. the column the
+// reference's fast_dgemm("T","N",U,Xlarge) (src/lmm.cpp:1521) produces for SNP s.  path < 0: by GEMMA_HIP_UTX_I8.
+static int compute_utx(int kind, const void *geno, size_t l, size_t ld, int path, double **UtX_out, size_t *ldx_out,
+                       hipStream_t s) {
+  const size_t n = g_ctx.cfg.n;
   const size_t ldx = (n + 1) & ~(size_t)1;
-  if (g_ctx.X.reserve(l * ldx * 8) || g_ctx.UtX.reserve(l * ldx * 8))
+  const bool i8 = (kind == GEMMA_GENO_PLINK_2BIT) && (path < 0 ? utx_i8_mode() == 1 : path == 1);
+  if (path == 1 && kind != GEMMA_GENO_PLINK_2BIT) return fail(GEMMA_HIP_EINVAL, "int8 U^T x path needs PLINK 2-bit input");
+  if (g_ctx.UtX.reserve(l * ldx * 8) || (!i8 && g_ctx.X.reserve(l * ldx * 8)))
     return fail(GEMMA_HIP_ENOMEM, "lmm_batch: cannot allocate 2 x %zu bytes", l * ldx * 8);
-  double *X = g_ctx.X.as<double>(), *UtX = g_ctx.UtX.as<double>();
+  double *UtX = g_ctx.UtX.as<double>();
+  *UtX_out = UtX;
+  *ldx_out = ldx;
+  if (i8) return utx_plink_i8(geno, l, ld, UtX, ldx, s);
+  double *X = g_ctx.X.as<double>();
   {
     ProfScope ps(GEMMA_STAGE_INGEST, s);
     if (kind == GEMMA_GENO_F64_IDV_MAJOR) {
@@ -907,13 +1000,54 @@ extern "C" int gemma_hip_lmm_batch_d(int kind, const void *geno, size_t l, size_
     HIPCHK(hipGetLastError());
   }
   {
-    // UtX (l x n, SNP-major) = X (l x n) * U (n x n): row s is (U^T x_s)^T, i.e. the column the
-    // reference's fast_dgemm("T","N",U,Xlarge) (src/lmm.cpp:1521) produces for SNP s.
     ProfScope ps(GEMMA_STAGE_UTX_GEMM, s);
     HIPCHK(launch_dgemm('N', 'N', (long)l, (long)n, (long)n, 1.0, X, (long)ldx, g_ctx.U, (long)n, 0.0, UtX,
                         (long)ldx, false, false, s));
   }
+  return GEMMA_HIP_OK;
+}
+
+static int check_batch_args(const char *who, int kind, const void *geno, size_t l, size_t ld, const void *out) {
+  const size_t n = g_ctx.cfg.n;
+  const size_t per_row = (kind == GEMMA_GENO_PLINK_2BIT && g_ctx.have_map) ? g_ctx.ni_total : n;
+  const size_t need = min_ld_for(kind, per_row, l);
+  if (need == (size_t)-1) return fail(GEMMA_HIP_EINVAL, "%s: unknown geno_kind %d", who, kind);
+  if (!geno || !out || ld < need) return fail(GEMMA_HIP_EINVAL, "%s: ld=%zu < %zu", who, ld, need);
+  return GEMMA_HIP_OK;
+}
+
+extern "C" int gemma_hip_lmm_batch_d(int kind, const void *geno, size_t l, size_t ld, gemma_sumstat *out_d,
+                                     void *stream) {
+  NEED_INIT();
+  if (!g_ctx.lmm_active) return fail(GEMMA_HIP_ESTATE, "lmm_batch before lmm_setup");
+  if (l == 0) return GEMMA_HIP_OK;
+  int rc = check_batch_args("lmm_batch", kind, geno, l, ld, out_d);
+  if (rc) return rc;
+  hipStream_t s = S(stream);
+  double *UtX;
+  size_t ldx;
+  rc = compute_utx(kind, geno, l, ld, -1, &UtX, &ldx, s);
+  if (rc) return rc;
   return launch_assoc(UtX, l, ldx, out_d, s);
+}
+
+extern "C" int gemma_hip_dbg_utx(int kind, const void *geno, size_t l, size_t ld, int path, double *UtX_host) {
+  NEED_INIT();
+  if (!g_ctx.lmm_active) return fail(GEMMA_HIP_ESTATE, "dbg_utx before lmm_setup");
+  if (l == 0) return GEMMA_HIP_OK;
+  int rc = check_batch_args("dbg_utx", kind, geno, l, ld, UtX_host);
+  if (rc) return rc;
+  const size_t n = g_ctx.cfg.n;
+  const size_t rows = (kind == GEMMA_GENO_F64_IDV_MAJOR) ? n : l;
+  const size_t esz = (kind == GEMMA_GENO_PLINK_2BIT) ? 1 : 8;
+  if (g_ctx.stage_in.reserve(rows * ld * esz)) return fail(GEMMA_HIP_ENOMEM, "dbg_utx: staging");
+  HIPCHK(hipMemcpy(g_ctx.stage_in.p, geno, rows * ld * esz, hipMemcpyHostToDevice));
+  double *UtX;
+  size_t ldx;
+  rc = compute_utx(kind, g_ctx.stage_in.p, l, ld, path ? 1 : 0, &UtX, &ldx, 0);
+  if (rc) return rc;
+  HIPCHK(hipMemcpy2D(UtX_host, n * 8, UtX, ldx * 8, n * 8, l, hipMemcpyDeviceToHost));
+  return GEMMA_HIP_OK;
 }
 
 extern "C" int gemma_hip_lmm_batch(int kind, const void *geno, size_t l, size_t ld, gemma_sumstat *out) {
@@ -1131,6 +1265,9 @@ extern "C" int gemma_hip_lmm_finish(double *time_UtX_min, double *time_opt_min) 
   g_ctx.UtWt.release(); g_ctx.idx_map.release(); g_ctx.X.release(); g_ctx.UtX.release();
   g_ctx.stage_in.release(); g_ctx.stage_out.release();
   g_ctx.grid_R.release(); g_ctx.grid_F.release(); g_ctx.grid_T.release();
+  g_ctx.i8_Bt.release(); g_ctx.i8_ej.release(); g_ctx.i8_cmax.release(); g_ctx.i8_A.release(); g_ctx.i8_C.release();
+  g_ctx.i8_mean.release();
+  g_ctx.i8_ready = false;
   g_ctx.U = g_ctx.eval = g_ctx.Uty = nullptr;
   g_ctx.lmm_active = false;
   return GEMMA_HIP_OK;

@@ -414,6 +414,66 @@ def test_lmm_plink_path_with_dropped_individuals(gpu_api, oracle):
     _cmp_stats(got, ref, 1, "plink")
 
 
+def _plink_case(oracle, rng, ni_total, p, drop=0.2, miss=0.03):
+    ind = (rng.random(ni_total) > drop).astype(np.int32)
+    codes = rng.choice([0, 1, 2, 3], size=(p, ni_total), p=[0.25, miss, 0.42 - miss + 0.03, 0.3]).astype(np.uint8)
+    nb = (ni_total + 3) // 4
+    pad = np.zeros((p, nb * 4), dtype=np.uint8)
+    pad[:, :ni_total] = codes
+    raw = (pad[:, 0::4] | (pad[:, 1::4] << 2) | (pad[:, 2::4] << 4) | (pad[:, 3::4] << 6)).astype(np.uint8)
+    return ind, raw
+
+
+@pytest.mark.parametrize("ni_total,p", [(611, 257), (300, 40), (1301, 700)])
+def test_utx_int8_digit_product_matches_fp64(gpu_api, oracle, ni_total, p):
+    """csrc/i8gemm.hip.h: U^T x of PLINK rows as 14 exact int8 products (7 balanced base-256 digits of U x
+    {genotype, missing mask}) against the fp64 MFMA GEMM and against the float128-free exact reference
+    (integer-left-factor dot products in numpy longdouble)."""
+    from gemma_amd import _lib as L
+    rng = np.random.default_rng(5 + ni_total)
+    ind, raw = _plink_case(oracle, rng, ni_total, p)
+    n = int(ind.sum())
+    Xn = oracle.bed_decode(raw, ni_total, ind)
+    Kg = oracle.bed_decode(raw, ni_total)[:, ind == 1]
+    U, ev, _ = oracle.eigen_decomp_zeroed(oracle.center_matrix(oracle.calc_kin(Kg, 1)))
+    y = rng.standard_normal(n)
+    lmm = gpu_api.LMM(a_mode=1)
+    lmm.setup(U, ev, U.T @ np.ones((n, 1)), U.T @ y, plink=True)
+    lmm.set_indicator(ind)
+    try:
+        a = lmm.dbg_utx(raw, L.GENO_PLINK_2BIT, 0)
+        b = lmm.dbg_utx(raw, L.GENO_PLINK_2BIT, 1)
+    finally:
+        lmm.finish()
+    Xi = oracle.impute_mean(Xn)
+    exact = (Xi.astype(np.longdouble) @ U.astype(np.longdouble)).astype(np.float64)
+    scale = np.abs(Xi) @ np.abs(U)  # the backward-error yardstick of a dot product
+    err64 = np.max(np.abs(a - exact) / scale)
+    err8 = np.max(np.abs(b - exact) / scale)
+    print("U^T x: fp64 GEMM err %.2e, int8-digit err %.2e (units of sum|x||u|)" % (err64, err8))
+    assert err64 < 64 * 2.3e-16
+    assert err8 < 8 * 2.3e-16  # assembled from exact integer sums: a few roundings, not a 600-term chain
+
+
+def test_lmm_plink_through_int8_digit_product(gpu_api, oracle, monkeypatch):
+    """The whole PLINK association path with GEMMA_HIP_UTX_I8=1 against the oracle."""
+    import gemma_amd._lib as L
+    rng = np.random.default_rng(23)
+    ni_total, p = 700, 300
+    ind, raw = _plink_case(oracle, rng, ni_total, p)
+    n = int(ind.sum())
+    Xn = oracle.bed_decode(raw, ni_total, ind)
+    Kg = oracle.bed_decode(raw, ni_total)[:, ind == 1]
+    U, ev, _ = oracle.eigen_decomp_zeroed(oracle.center_matrix(oracle.calc_kin(Kg, 1)))
+    y = rng.standard_normal(n)
+    UtW, Uty = U.T @ np.ones((n, 1)), U.T @ y
+    ref = oracle.lmm_analyze(1, U, ev, UtW, Uty, Xn, plink_nan_rule=1)
+    monkeypatch.setenv("GEMMA_HIP_UTX_I8", "1")
+    lmm = gpu_api.LMM(a_mode=1)
+    got = lmm.AnalyzePlink(U, ev, UtW, Uty, raw, ind)
+    _cmp_stats(got, ref, 1, "plink-int8")
+
+
 def test_lmm_reference_xlarge_layout_and_batching(gpu_api, oracle):
     """The reference hands fast_dgemm an individuals x 20000 Xlarge view (src/lmm.cpp:1516-1521);
     results must not depend on how SNPs are cut into blocks."""
