@@ -915,19 +915,24 @@ static int i8_prepare_u(hipStream_t s) {
 static int utx_plink_i8(const void *geno, size_t l, size_t ld, double *UtX, size_t ldx, hipStream_t s) {
   int rc = i8_prepare_u(s);
   if (rc) return rc;
+  // GEMMA_HIP_I8_KERNEL: 1 (default) packed left factor g | m << 4, 128 x 256 tiles, 3 LDS stages;
+  //                      0 separate G and M rows, 256 x 256 tiles, 2 stages
+  const char *ek = getenv("GEMMA_HIP_I8_KERNEL");
+  const bool packed = !(ek && ek[0] == '0');
   const size_t n = g_ctx.cfg.n, ldk = g_ctx.i8_ldk, npad = g_ctx.i8_npad;
-  const size_t lpad = round_up(l, I8_BM), mrows = 2 * lpad;
+  const size_t lpad = round_up(l, I8_BM), mrows = 2 * lpad, arows = packed ? lpad : mrows;
   const size_t c_elems = (size_t)I8_DIGITS * mrows * npad;
-  if (g_ctx.i8_A.reserve(mrows * ldk) || g_ctx.i8_C.reserve(c_elems * 4) || g_ctx.i8_mean.reserve(l * 8))
-    return fail(GEMMA_HIP_ENOMEM, "lmm_batch: int8 product buffers (%zu bytes)", mrows * ldk + c_elems * 4);
+  if (g_ctx.i8_A.reserve(arows * ldk) || g_ctx.i8_C.reserve(c_elems * 4) || g_ctx.i8_mean.reserve(l * 8))
+    return fail(GEMMA_HIP_ENOMEM, "lmm_batch: int8 product buffers (%zu bytes)", arows * ldk + c_elems * 4);
   {
     ProfScope ps(GEMMA_STAGE_INGEST, s);
-    if (lpad != l) HIPCHK(hipMemsetAsync(g_ctx.i8_A.p, 0, mrows * ldk, s)); // padding rows
+    if (lpad != l) HIPCHK(hipMemsetAsync(g_ctx.i8_A.p, 0, arows * ldk, s)); // padding rows
     IngestI8Args a;
     a.src = reinterpret_cast<const unsigned char *>(geno); a.ld = (long)ld; a.l = (long)l;
     a.idx_map = g_ctx.have_map ? g_ctx.idx_map.as<int>() : nullptr;
     a.n = (int)n; a.A = g_ctx.i8_A.as<int8_t>(); a.ldk = (long)ldk; a.m_row0 = (long)lpad;
     a.mean = g_ctx.i8_mean.as<double>();
+    a.packed = packed ? 1 : 0;
     hipLaunchKernelGGL(ingest_i8_kernel, dim3((unsigned)((l + 3) / 4)), dim3(256), 0, s, a);
     HIPCHK(hipGetLastError());
   }
@@ -937,29 +942,44 @@ static int utx_plink_i8(const void *geno, size_t l, size_t ld, double *UtX, size
     if (!attr_set) {
       HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(i8gemm_kernel),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
+      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(i8gemm_packed_kernel),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 3 * I8P_STAGE));
       attr_set = true;
     }
-    I8GemmArgs g;
-    g.A = g_ctx.i8_A.as<int8_t>();
-    g.Bt = g_ctx.i8_Bt.as<int8_t>();
-    g.C = g_ctx.i8_C.as<int>();
-    g.ldk = (long)ldk; g.ldc = (long)npad;
-    g.strideB = (long)(npad * ldk); g.strideC = (long)(mrows * npad);
-    g.tiles_m = (int)(mrows / I8_BM); g.tiles_n = (int)(npad / I8_BN);
-    g.nk = (int)(ldk / I8_BK);
-    {
-      static int gm = -1;
-      if (gm < 0) {
-        const char *e = getenv("GEMMA_HIP_I8_GM");
-        gm = e ? atoi(e) : 0;
-      }
-      g.gm = gm;
+    static int gm = -1;
+    if (gm < 0) {
+      const char *e = getenv("GEMMA_HIP_I8_GM");
+      gm = e ? atoi(e) : 0;
     }
-    hipLaunchKernelGGL(i8gemm_kernel, dim3((unsigned)(g.tiles_m * g.tiles_n), I8_DIGITS), dim3(512), 131072, s, g);
+    if (packed) {
+      I8PackArgs g;
+      g.A = g_ctx.i8_A.as<int8_t>();
+      g.Bt = g_ctx.i8_Bt.as<int8_t>();
+      g.C = g_ctx.i8_C.as<int>();
+      g.ldk = (long)ldk; g.ldc = (long)npad;
+      g.strideB = (long)(npad * ldk); g.strideC = (long)(mrows * npad);
+      g.m_row0 = (long)lpad;
+      g.tiles_m = (int)(lpad / I8P_BM); g.tiles_n = (int)(npad / I8_BN);
+      g.nk = (int)(ldk / I8_BK);
+      g.gm = gm;
+      hipLaunchKernelGGL(i8gemm_packed_kernel, dim3((unsigned)(g.tiles_m * g.tiles_n), I8_DIGITS), dim3(512),
+                         3 * I8P_STAGE, s, g);
+    } else {
+      I8GemmArgs g;
+      g.A = g_ctx.i8_A.as<int8_t>();
+      g.Bt = g_ctx.i8_Bt.as<int8_t>();
+      g.C = g_ctx.i8_C.as<int>();
+      g.ldk = (long)ldk; g.ldc = (long)npad;
+      g.strideB = (long)(npad * ldk); g.strideC = (long)(mrows * npad);
+      g.tiles_m = (int)(mrows / I8_BM); g.tiles_n = (int)(npad / I8_BN);
+      g.nk = (int)(ldk / I8_BK);
+      g.gm = gm;
+      hipLaunchKernelGGL(i8gemm_kernel, dim3((unsigned)(g.tiles_m * g.tiles_n), I8_DIGITS), dim3(512), 131072, s, g);
+    }
     HIPCHK(hipGetLastError());
     hipLaunchKernelGGL(i8_combine_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)l), dim3(256), 0, s,
                        g_ctx.i8_C.as<int>(), (long)npad, (long)(mrows * npad), (long)lpad, g_ctx.i8_mean.as<double>(),
-                       g_ctx.i8_ej.as<int>(), (long)l, (long)n, UtX, (long)ldx);
+                       g_ctx.i8_ej.as<int>(), (long)l, (long)n, UtX, (long)ldx, packed ? 0.0625 : 1.0);
     HIPCHK(hipGetLastError());
   }
   return GEMMA_HIP_OK;

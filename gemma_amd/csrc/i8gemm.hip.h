@@ -151,6 +151,204 @@ __global__ __launch_bounds__(512, 2) void i8gemm_kernel(I8GemmArgs g) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// Second form: ONE packed left factor per SNP row, byte = g | (m << 4).  A wave reads an A fragment from LDS once and
+// masks it into the genotype operand (a & 0x03) and the missing-mask operand (a & 0x10, i.e. 16 m: the M results
+// come out multiplied by 16, still < 2^27) -- the G and M products share every global / LDS byte of both operands,
+// so LDS traffic per MFMA drops by a third and the left factor is read once.
+//   tile 128 SNP rows x 256 columns x 128 K bytes; 8 wavefronts (2 x 4), wave tile 64 x 64 for G and for M
+//   (2 x 2 x 2 blocks of 32 x 32 = 128 int32 accumulators); three LDS stages of 48 KiB (A 16 KiB + B 32 KiB), LDS-DMA
+//   two K-tiles ahead with a counted vmcnt and a raw s_barrier; pinned issue order: one ds_read_b128 / LDS-DMA piece /
+//   pair of v_and behind each MFMA, fragments one K-step ahead, the barrier after MFMA 25 of 32 so that the next
+//   tile's first fragments are already there when this tile ends.
+struct I8PackArgs {
+  const int8_t *A;   // lpad x ldk packed bytes
+  const int8_t *Bt;  // digit d: N x ldk
+  int *C;            // digit d: (2 lpad) x ldc; rows [0, lpad) = G products, [lpad, 2 lpad) = 16 x M products
+  long ldk, ldc;
+  long strideB, strideC;
+  long m_row0;       // lpad
+  int tiles_m, tiles_n;
+  int nk;
+  int gm;
+};
+constexpr int I8P_BM = 128;
+constexpr int I8P_STAGE = 49152;
+
+__global__ __launch_bounds__(512, 2) void i8gemm_packed_kernel(I8PackArgs g) {
+  extern __shared__ __attribute__((aligned(1024))) int8_t i8lds[];
+  int tm, tn;
+  {
+    const int nwg = gridDim.x, b = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, x = b & 7, o = b >> 3;
+    const int L = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + o;
+    const int GM = g.gm > 0 ? g.gm : 8;
+    const int per_group = GM * g.tiles_n;
+    const int grp = L / per_group;
+    const int first_m = grp * GM;
+    const int gsz = min(g.tiles_m - first_m, GM);
+    const int in = L - grp * per_group;
+    tm = first_m + in % gsz;
+    tn = in / gsz;
+  }
+  const int digit = blockIdx.y;
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wm = wave >> 2, wn = wave & 3; // rows wm*64, cols wn*64
+  const int r32 = lane & 31, h = lane >> 5;
+
+  // LDS-DMA: a stage is 48 pieces of 1 KiB (0-15: A rows 8p.., 16-47: B rows 8(p-16)..); wave w moves pieces 6w..6w+5
+  const int8_t *src[6];
+  int dst[6];
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    const int p = 6 * wave + j;
+    const bool isA = p < 16;
+    const int row = 8 * (isA ? p : p - 16) + (lane >> 3);
+    const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+    const int8_t *base = isA ? g.A + ((long)tm * I8P_BM + row) * g.ldk
+                             : g.Bt + (long)digit * g.strideB + ((long)tn * I8_BN + row) * g.ldk;
+    src[j] = base + 16 * chunk;
+    dst[j] = p * 1024;
+  }
+  // fragment byte offsets inside a stage, K-step ks: logical chunk 2 ks + h
+  int fa[4], fb[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    const int sw = ((2 * ks + h) ^ ((r32 >> 1) & 7)) << 4;
+    fa[ks] = (wm * 64 + r32) * 128 + sw;
+    fb[ks] = 16384 + (wn * 64 + r32) * 128 + sw;
+  }
+
+  i32x16 accg[2][2], accm[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { accg[i][j][r] = 0; accm[i][j][r] = 0; }
+
+  // two fragment register sets (X, Y): raw A (2 blocks), masked G / M operands, B (2 blocks)
+  i32x4 xa[2], xg[2], xm[2], xb[2], ya[2], yg[2], ym[2], yb[2];
+  const i32x4 mask_g = {0x03030303, 0x03030303, 0x03030303, 0x03030303};
+  const i32x4 mask_m = {0x10101010, 0x10101010, 0x10101010, 0x10101010};
+
+#define I8P_DMA(j, SOFF)                                                                                          \
+  do {                                                                                                            \
+    __builtin_amdgcn_global_load_lds((gemma_gptr_t)src[j], (gemma_lptr_t)(i8lds + (SOFF) + dst[j]), 16, 0, 0);    \
+    src[j] += I8_BK;                                                                                              \
+  } while (0)
+// fragment read q of K-step KS from stage offset SOFF: q 0,1 = A blocks, 2,3 = B blocks
+#define I8P_READ(q, SOFF, KS, RA, RB)                                                                             \
+  do {                                                                                                            \
+    if ((q) < 2) RA[(q)&1] = *reinterpret_cast<const i32x4 *>(i8lds + (SOFF) + fa[KS] + ((q)&1) * 4096);         \
+    else RB[(q)&1] = *reinterpret_cast<const i32x4 *>(i8lds + (SOFF) + fb[KS] + ((q)&1) * 4096);                  \
+  } while (0)
+#define I8P_MASK(i, RA, RG, RM)                                                                                   \
+  do {                                                                                                            \
+    RG[i] = RA[i] & mask_g;                                                                                       \
+    RM[i] = RA[i] & mask_m;                                                                                       \
+  } while (0)
+// MFMA q of a K-step: block (i, j) = (q >> 2, (q >> 1) & 1), q & 1: 0 = G, 1 = M
+#define I8P_MF(q, RG, RM, RB)                                                                                     \
+  do {                                                                                                            \
+    if (((q)&1) == 0)                                                                                             \
+      accg[(q) >> 2][((q) >> 1) & 1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(RG[(q) >> 2], RB[((q) >> 1) & 1],    \
+                                                                             accg[(q) >> 2][((q) >> 1) & 1], 0, 0, 0); \
+    else                                                                                                          \
+      accm[(q) >> 2][((q) >> 1) & 1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(RM[(q) >> 2], RB[((q) >> 1) & 1],    \
+                                                                             accm[(q) >> 2][((q) >> 1) & 1], 0, 0, 0); \
+  } while (0)
+// one K-step on set (CG, CM, CB): MFMAs 0-7; reads of K-step NKS of stage NS into (NA, NB) behind MFMAs 0-3, their
+// masks behind MFMAs 5-6; LDS-DMA pieces D0..D0+2 into stage DS behind MFMAs 4-6 when DMA is set
+#define I8P_STEP(CG, CM, CB, NS, NKS, NA, NG, NM, NB, DMA, D0, DS)                                                \
+  do {                                                                                                            \
+    _Pragma("unroll") for (int q_ = 0; q_ < 8; ++q_) {                                                            \
+      I8P_MF(q_, CG, CM, CB);                                                                                     \
+      if (q_ < 4) I8P_READ(q_, NS, NKS, NA, NB);                                                                  \
+      if ((DMA) && q_ >= 4 && q_ < 7) I8P_DMA((D0) + q_ - 4, DS);                                                 \
+      if (q_ == 5) I8P_MASK(0, NA, NG, NM);                                                                       \
+      if (q_ == 6) I8P_MASK(1, NA, NG, NM);                                                                       \
+      GEMMA_SB();                                                                                                 \
+    }                                                                                                             \
+  } while (0)
+// one K-tile from stage SC; MORE: tile t+1 exists in stage SN; LOAD2: tile t+2 exists and goes to stage SD
+#define I8P_KTILE(SC, SN, SD, MORE, LOAD2)                                                                        \
+  do {                                                                                                            \
+    I8P_STEP(xg, xm, xb, SC, 1, ya, yg, ym, yb, LOAD2, 0, SD);                                                    \
+    I8P_STEP(yg, ym, yb, SC, 2, xa, xg, xm, xb, LOAD2, 3, SD);                                                    \
+    I8P_STEP(xg, xm, xb, SC, 3, ya, yg, ym, yb, false, 0, SD);                                                    \
+    I8P_MF(0, yg, ym, yb); GEMMA_SB();                                                                            \
+    I8P_MF(1, yg, ym, yb); GEMMA_SB();                                                                            \
+    if (LOAD2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                                                   \
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                         \
+    __builtin_amdgcn_s_barrier();                                                                                 \
+    GEMMA_SB();                                                                                                   \
+    _Pragma("unroll") for (int q_ = 2; q_ < 8; ++q_) {                                                            \
+      I8P_MF(q_, yg, ym, yb);                                                                                     \
+      if (MORE) {                                                                                                 \
+        if (q_ == 2) I8P_READ(0, SN, 0, xa, xb);                                                                  \
+        if (q_ == 3) I8P_READ(1, SN, 0, xa, xb);                                                                  \
+        if (q_ == 4) I8P_READ(2, SN, 0, xa, xb);                                                                  \
+        if (q_ == 5) I8P_READ(3, SN, 0, xa, xb);                                                                  \
+        if (q_ == 6) I8P_MASK(0, xa, xg, xm);                                                                     \
+        if (q_ == 7) I8P_MASK(1, xa, xg, xm);                                                                     \
+      }                                                                                                           \
+      GEMMA_SB();                                                                                                 \
+    }                                                                                                             \
+  } while (0)
+
+  const int nk = g.nk;
+  // prologue: tiles 0 and 1 in flight, tile 0 landed
+#pragma unroll
+  for (int j = 0; j < 6; ++j) I8P_DMA(j, 0);
+  if (nk > 1) {
+#pragma unroll
+    for (int j = 0; j < 6; ++j) I8P_DMA(j, I8P_STAGE);
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __builtin_amdgcn_s_barrier();
+  GEMMA_SB();
+#pragma unroll
+  for (int q = 0; q < 4; ++q) I8P_READ(q, 0, 0, xa, xb);
+  I8P_MASK(0, xa, xg, xm);
+  I8P_MASK(1, xa, xg, xm);
+
+  int sc = 0, sn = I8P_STAGE, sd = 2 * I8P_STAGE; // stage byte offsets: current, next, DMA target
+  int kt = 0;
+  for (; kt + 2 < nk; ++kt) {
+    I8P_KTILE(sc, sn, sd, true, true);
+    const int tmp = sc; sc = sn; sn = sd; sd = tmp;
+  }
+  if (nk >= 2) {
+    I8P_KTILE(sc, sn, sd, true, false);
+    const int tmp = sc; sc = sn; sn = sd; sd = tmp;
+  }
+  I8P_KTILE(sc, sn, sd, false, false);
+#undef I8P_DMA
+#undef I8P_READ
+#undef I8P_MASK
+#undef I8P_MF
+#undef I8P_STEP
+#undef I8P_KTILE
+
+  int *Cg = g.C + (long)digit * g.strideC;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const long col = (long)tn * I8_BN + wn * 64 + j * 32 + r32;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const long row = (long)tm * I8P_BM + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        Cg[row * g.ldc + col] = accg[i][j][r];
+        Cg[(g.m_row0 + row) * g.ldc + col] = accm[i][j][r];
+      }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // U -> per-column exponent and the 7 balanced base-256 digit matrices, transposed ([j][k], K contiguous)
 __global__ __launch_bounds__(256) void u_colmax_kernel(const double *__restrict__ U, long n, long ld,
                                                        unsigned long long *__restrict__ colmax_bits) {
@@ -213,6 +411,7 @@ struct IngestI8Args {
   long ldk;
   long m_row0;
   double *mean;
+  int packed; // 1: one row per SNP, byte = g | (m << 4)
 };
 __global__ __launch_bounds__(256) void ingest_i8_kernel(IngestI8Args g) {
   const int lane = threadIdx.x & 63;
@@ -225,11 +424,18 @@ __global__ __launch_bounds__(256) void ingest_i8_kernel(IngestI8Args g) {
     const int p = g.idx_map ? g.idx_map[i] : i;
     bool miss;
     const double v = plink_value((bs[p >> 2] >> (2 * (p & 3))) & 3u, miss);
-    gr[i] = miss ? (int8_t)0 : (int8_t)(int)v;
-    mr[i] = miss ? (int8_t)1 : (int8_t)0;
+    if (g.packed) {
+      gr[i] = miss ? (int8_t)16 : (int8_t)(int)v;
+    } else {
+      gr[i] = miss ? (int8_t)0 : (int8_t)(int)v;
+      mr[i] = miss ? (int8_t)1 : (int8_t)0;
+    }
     if (!miss) { tot += v; cnt += 1.0; }
   }
-  for (long i = g.n + lane; i < g.ldk; i += 64) { gr[i] = 0; mr[i] = 0; } // K padding
+  for (long i = g.n + lane; i < g.ldk; i += 64) { // K padding
+    gr[i] = 0;
+    if (!g.packed) mr[i] = 0;
+  }
   tot = wsum(tot);
   cnt = wsum(cnt);
   if (lane == 0) g.mean[s] = tot / cnt; // x_total / (ni_test - n_miss), as ingest_lmm_kernel
@@ -238,7 +444,8 @@ __global__ __launch_bounds__(256) void ingest_i8_kernel(IngestI8Args g) {
 // UtX[s][j] = 2^(e_j - 54) * sum_d 256^d (CG_d[s][j] + mean_s * CM_d[s][j])
 __global__ __launch_bounds__(256) void i8_combine_kernel(const int *__restrict__ C, long ldc, long strideC, long m_row0,
                                                          const double *__restrict__ mean, const int *__restrict__ ej,
-                                                         long l, long n, double *__restrict__ UtX, long ldx) {
+                                                         long l, long n, double *__restrict__ UtX, long ldx,
+                                                         double m_scale) {
   const long j = (long)blockIdx.x * 256 + threadIdx.x;
   const long s = blockIdx.y;
   if (j >= n || s >= l) return;
@@ -248,7 +455,7 @@ __global__ __launch_bounds__(256) void i8_combine_kernel(const int *__restrict__
     tg = tg * 256.0 + (double)C[(long)d * strideC + s * ldc + j];
     tmk = tmk * 256.0 + (double)C[(long)d * strideC + (m_row0 + s) * ldc + j];
   }
-  UtX[s * ldx + j] = ldexp(fma(mean[s], tmk, tg), ej[j] - I8_SCALE_BITS);
+  UtX[s * ldx + j] = ldexp(fma(mean[s] * m_scale, tmk, tg), ej[j] - I8_SCALE_BITS); // m_scale: 1 or 1/16 (exact)
 }
 
 } // namespace gemma_hip
