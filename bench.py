@@ -27,6 +27,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FP64_MFMA_PEAK_TFLOPS = 78.6  # MI355X fp64 matrix peak (AMD CDNA4 datasheet; v_mfma_f64_16x16x4 = 64 clk)
+INT8_MFMA_PEAK_TOPS = 5000.0  # dense int8 = 2 x the 2.5 PFLOP/s bf16 dense peak (MI355X_MICROARCH.md: "i8 ~ 2x bf16
+                              # (2xK)"; micro-benchmark ceiling there 4404 TOP/s for 32x32x32)
 HBM_PEAK_GBS = 8000.0
 
 
@@ -41,6 +43,7 @@ def parse():
     ap.add_argument("--eigen", default="auto", choices=["auto", "gemma", "torch"])
     ap.add_argument("--cpu-sample", type=int, default=2048, help="SNPs in the CPU baseline sample (0 = skip)")
     ap.add_argument("--a-mode", type=int, default=1)
+    ap.add_argument("--fp64-steps", type=int, default=2, help="extra untimed-region steps through the fp64 GEMM path (0 = skip)")
     ap.add_argument("--seed", type=int, default=20000)
     return ap.parse_args()
 
@@ -190,7 +193,7 @@ def main():
         lmm.batch(blocks[i], L.GENO_PLINK_2BIT, out=out)
     torch.cuda.synchronize()
     api.profile_enable(True)
-    for st in range(L.STAGE_EIGH + 1):
+    for st in range(L.STAGE_UTX_POST + 1):
         api.profile_read(st, reset=True)
     if world > 1:
         dist.barrier()
@@ -208,46 +211,88 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt[0])
     gemm_ms, gemm_n = api.profile_read(L.STAGE_UTX_GEMM)
+    post_ms, post_n = api.profile_read(L.STAGE_UTX_POST)
     assoc_ms, assoc_n = api.profile_read(L.STAGE_ASSOC)
     ing_ms, ing_n = api.profile_read(L.STAGE_INGEST)
     res = out.cpu().numpy()
     n_nan = int(np.isnan(res[:, 4]).sum())
+    i8_path = os.environ.get("GEMMA_HIP_UTX_I8", "1") != "0"
+
+    # the fp64 MFMA GEMM path on the same blocks, outside the contract's timed region (single GPU only)
+    fp64_path = None
+    if world == 1 and i8_path and args.fp64_steps > 0:
+        os.environ["GEMMA_HIP_UTX_I8"] = "0"
+        lmm.batch(blocks[0], L.GENO_PLINK_2BIT, out=out)
+        torch.cuda.synchronize()
+        api.profile_read(L.STAGE_UTX_GEMM, reset=True)
+        t1 = time.perf_counter()
+        for i in range(args.fp64_steps):
+            lmm.batch(blocks[(args.warmup + i) % len(blocks)], L.GENO_PLINK_2BIT, out=out)
+        torch.cuda.synchronize()
+        el64 = time.perf_counter() - t1
+        g64_ms, g64_n = api.profile_read(L.STAGE_UTX_GEMM)
+        os.environ["GEMMA_HIP_UTX_I8"] = "1"
+        g64_s = g64_ms * 1e-3 / max(1, g64_n)
+        tf = 2.0 * B * n * n / g64_s / 1e12
+        fp64_path = {"value": round(B * args.fp64_steps / el64, 1), "unit": "SNPs/s", "steps": args.fp64_steps,
+                     "ms_per_step": round(el64 / args.fp64_steps * 1e3, 3),
+                     "roofline": {"kernel": "dgemm_mfma_glds_kernel (UtX = X*U, fp64)", "bound": "mfma",
+                                  "achieved": round(tf, 2), "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                  "frac": round(tf / FP64_MFMA_PEAK_TFLOPS, 4), "avg_launch_ms": round(g64_s * 1e3, 3)}}
 
     if rank == 0:
         total_snps = B * args.steps * world
         value = total_snps / elapsed
         gemm_avg_s = gemm_ms * 1e-3 / max(1, gemm_n)
-        flops_per_launch = 2.0 * B * n * n  # 2 n^2 flop per SNP
-        achieved = flops_per_launch / gemm_avg_s / 1e12
         assoc_avg_s = assoc_ms * 1e-3 / max(1, assoc_n)
+        if i8_path:
+            # 7 digits x {genotype, missing mask}: 14 int8 products of 2 n^2 ops per SNP (2 n^2 per SNP)
+            ops_per_launch = 14.0 * 2.0 * B * n * n
+            achieved = ops_per_launch / gemm_avg_s / 1e12
+            roof = {"kernel": "i8gemm_packed_kernel (14 exact int8-digit products = UtX)", "bound": "mfma",
+                    "achieved": round(achieved, 1), "peak": INT8_MFMA_PEAK_TOPS, "unit": "TOP/s",
+                    "frac": round(achieved / INT8_MFMA_PEAK_TOPS, 4), "traffic": None, "launches": gemm_n,
+                    "avg_launch_ms": round(gemm_avg_s * 1e3, 3)}
+        else:
+            flops_per_launch = 2.0 * B * n * n  # 2 n^2 flop per SNP
+            achieved = flops_per_launch / gemm_avg_s / 1e12
+            roof = {"kernel": "dgemm_mfma_glds_kernel (UtX = X*U)", "bound": "mfma", "achieved": round(achieved, 2),
+                    "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / FP64_MFMA_PEAK_TFLOPS, 4),
+                    "traffic": None, "launches": gemm_n, "avg_launch_ms": round(gemm_avg_s * 1e3, 3)}
         line = {
             "metric": "SNPs/s (-lmm 1 Wald) at n=20k on 1/2/4/8 MI355X; U^T x HBM GB/s vs roofline",
             "value": round(value, 1), "unit": "SNPs/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64 (U^T x as exact int8-digit MFMA products, int32 accumulate)" if i8_path else "f64",
             "data": "synthetic",
             "config": {"workload": "%ssynthetic n=%d, -lmm %d, %d SNPs per step per GPU (PLINK 2-bit, "
                                    "1%% missing, Balding-Nichols Fst 0.05), c=1" % (
                                        "configs[2] (headline): " if (n == 20000 and args.a_mode == 1) else "", n, args.a_mode, B),
                        "n": n, "snps_per_step": B, "kinship_snps": args.kin_snps, "parallelism": "snp-shard x%d" % world,
-                       "device": name, "cus": n_cu, "setup": setup_info, "nan_p_wald": n_nan},
-            "roofline": {"kernel": "dgemm_mfma_glds_kernel (UtX = X*U)", "bound": "mfma", "achieved": round(achieved, 2),
-                         "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / FP64_MFMA_PEAK_TFLOPS, 4),
-                         "traffic": None, "launches": gemm_n, "avg_launch_ms": round(gemm_avg_s * 1e3, 3)},
+                       "device": name, "cus": n_cu, "utx_path": "int8-digit" if i8_path else "fp64-gemm",
+                       "setup": setup_info, "nan_p_wald": n_nan},
+            "roofline": roof,
             "roofline_assoc": {"kernel": "lmm_assoc_kernel (lambda search + Wald)", "bound": "hbm",
                                "achieved": round(8.0 * n * B / assoc_avg_s / 1e9, 2) if assoc_avg_s else None,
                                "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": round(8.0 * n * B / assoc_avg_s / 1e9 / HBM_PEAK_GBS, 5) if assoc_avg_s else None,
                                "avg_launch_ms": round(assoc_avg_s * 1e3, 3)},
             "stage_ms_per_step": {"ingest": round(ing_ms / max(1, args.steps), 3), "utx_gemm": round(gemm_ms / max(1, args.steps), 3),
+                                  "utx_post": round(post_ms / max(1, args.steps), 3),
                                   "assoc": round(assoc_ms / max(1, args.steps), 3)},
         }
+        if fp64_path:
+            line["fp64_gemm_path"] = fp64_path
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc):
             try:
                 pj = json.load(open(pmc))
                 if pj.get("n") == n and pj.get("batch") == B:
-                    line["roofline"]["traffic"] = pj.get("utx_gemm_hbm_bytes_per_launch")
+                    line["roofline"]["traffic"] = pj.get("i8gemm_hbm_bytes_per_launch" if i8_path
+                                                         else "utx_gemm_hbm_bytes_per_launch")
+                    if fp64_path:
+                        fp64_path["roofline"]["traffic"] = pj.get("utx_gemm_hbm_bytes_per_launch")
             except Exception:
                 pass
         if world == 1 and args.cpu_sample > 0:

@@ -21,7 +21,7 @@ SYMBOLS = [
 
 OK, EINVAL, ENODEV, ENOMEM, ERUNTIME, ESTATE, ENOCONV = range(7)
 GENO_F64_SNP_MAJOR, GENO_PLINK_2BIT, GENO_F64_IDV_MAJOR = 0, 1, 2
-STAGE_INGEST, STAGE_UTX_GEMM, STAGE_ASSOC, STAGE_KIN_GEMM, STAGE_EIGH = range(5)
+STAGE_INGEST, STAGE_UTX_GEMM, STAGE_ASSOC, STAGE_KIN_GEMM, STAGE_EIGH, STAGE_UTX_POST = range(6)
 
 
 class SumStat(C.Structure):

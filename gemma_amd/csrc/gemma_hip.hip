@@ -877,10 +877,11 @@ extern "C" int gemma_hip_lmm_assoc_d(const double *UtX_d, size_t l, size_t ld_ut
   return launch_assoc(UtX_d, l, ld_utx, out_d, S(stream));
 }
 
-// GEMMA_HIP_UTX_I8: 1 = PLINK batches go through the exact int8-digit product, 0 = always the fp64 MFMA GEMM
+// GEMMA_HIP_UTX_I8: 1 (default) = PLINK batches go through the exact int8-digit product (i8gemm.hip.h),
+// 0 = always the fp64 MFMA GEMM.  Real-valued (BIMBAM dosage) input always takes the fp64 GEMM.
 static int utx_i8_mode() {
   const char *e = getenv("GEMMA_HIP_UTX_I8");
-  return e ? atoi(e) : 0;
+  return e ? atoi(e) : 1;
 }
 
 static size_t round_up(size_t v, size_t m) { return (v + m - 1) / m * m; }
@@ -942,7 +943,17 @@ static int utx_plink_i8(const void *geno, size_t l, size_t ld, double *UtX, size
     if (!attr_set) {
       HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(i8gemm_kernel),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
-      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(i8gemm_packed_kernel),
+      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(i8gemm_packed_kernel<0>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 3 * I8P_STAGE));
+      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(i8gemm_packed_kernel<1>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 3 * I8P_STAGE));
+      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(i8gemm_packed_kernel<2>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 3 * I8P_STAGE));
+      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(i8gemm_packed_kernel<3>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 3 * I8P_STAGE));
+      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(i8gemm_packed_kernel<7>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 3 * I8P_STAGE));
+      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(i8gemm_packed_kernel<8>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 3 * I8P_STAGE));
       attr_set = true;
     }
@@ -962,8 +973,17 @@ static int utx_plink_i8(const void *geno, size_t l, size_t ld, double *UtX, size
       g.tiles_m = (int)(lpad / I8P_BM); g.tiles_n = (int)(npad / I8_BN);
       g.nk = (int)(ldk / I8_BK);
       g.gm = gm;
-      hipLaunchKernelGGL(i8gemm_packed_kernel, dim3((unsigned)(g.tiles_m * g.tiles_n), I8_DIGITS), dim3(512),
-                         3 * I8P_STAGE, s, g);
+      const char *ea = getenv("GEMMA_HIP_I8_ABLATE"); // timing experiments (wrong results)
+      const int abl = ea ? atoi(ea) : 0;
+      const dim3 grid((unsigned)(g.tiles_m * g.tiles_n), I8_DIGITS);
+      switch (abl) {
+      case 1: hipLaunchKernelGGL(i8gemm_packed_kernel<1>, grid, dim3(512), 3 * I8P_STAGE, s, g); break;
+      case 2: hipLaunchKernelGGL(i8gemm_packed_kernel<2>, grid, dim3(512), 3 * I8P_STAGE, s, g); break;
+      case 3: hipLaunchKernelGGL(i8gemm_packed_kernel<3>, grid, dim3(512), 3 * I8P_STAGE, s, g); break;
+      case 7: hipLaunchKernelGGL(i8gemm_packed_kernel<7>, grid, dim3(512), 3 * I8P_STAGE, s, g); break;
+      case 8: hipLaunchKernelGGL(i8gemm_packed_kernel<8>, grid, dim3(512), 3 * I8P_STAGE, s, g); break;
+      default: hipLaunchKernelGGL(i8gemm_packed_kernel<0>, grid, dim3(512), 3 * I8P_STAGE, s, g); break;
+      }
     } else {
       I8GemmArgs g;
       g.A = g_ctx.i8_A.as<int8_t>();
@@ -977,6 +997,9 @@ static int utx_plink_i8(const void *geno, size_t l, size_t ld, double *UtX, size
       hipLaunchKernelGGL(i8gemm_kernel, dim3((unsigned)(g.tiles_m * g.tiles_n), I8_DIGITS), dim3(512), 131072, s, g);
     }
     HIPCHK(hipGetLastError());
+  }
+  {
+    ProfScope ps(GEMMA_STAGE_UTX_POST, s);
     hipLaunchKernelGGL(i8_combine_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)l), dim3(256), 0, s,
                        g_ctx.i8_C.as<int>(), (long)npad, (long)(mrows * npad), (long)lpad, g_ctx.i8_mean.as<double>(),
                        g_ctx.i8_ej.as<int>(), (long)l, (long)n, UtX, (long)ldx, packed ? 0.0625 : 1.0);
@@ -1278,8 +1301,10 @@ extern "C" int gemma_hip_lmm_finish(double *time_UtX_min, double *time_opt_min) 
   if (!g_ctx.lmm_active) return fail(GEMMA_HIP_ESTATE, "lmm_finish before lmm_setup");
   HIPCHK(hipDeviceSynchronize());
   prof_collect(GEMMA_STAGE_UTX_GEMM);
+  prof_collect(GEMMA_STAGE_UTX_POST);
   prof_collect(GEMMA_STAGE_ASSOC);
-  if (time_UtX_min) *time_UtX_min = g_ctx.prof[GEMMA_STAGE_UTX_GEMM].acc_ms / 60000.0;
+  if (time_UtX_min)
+    *time_UtX_min = (g_ctx.prof[GEMMA_STAGE_UTX_GEMM].acc_ms + g_ctx.prof[GEMMA_STAGE_UTX_POST].acc_ms) / 60000.0;
   if (time_opt_min) *time_opt_min = g_ctx.prof[GEMMA_STAGE_ASSOC].acc_ms / 60000.0;
   g_ctx.own_U.release(); g_ctx.own_eval.release(); g_ctx.own_Uty.release(); g_ctx.own_UtW.release();
   g_ctx.UtWt.release(); g_ctx.idx_map.release(); g_ctx.X.release(); g_ctx.UtX.release();

@@ -172,8 +172,14 @@ struct I8PackArgs {
   int gm;
 };
 constexpr int I8P_BM = 128;
+#ifndef GEMMA_I8_STAGGER
+#define GEMMA_I8_STAGGER 0
+#endif
 constexpr int I8P_STAGE = 49152;
 
+// ABL: timing experiments only (results wrong): 1 no LDS-DMA inside the loop, 2 no barrier, 4 no operand masks,
+// 8 LDS-DMA keeps re-reading the first K-tile (cache-hot source)
+template <int ABL>
 __global__ __launch_bounds__(512, 2) void i8gemm_packed_kernel(I8PackArgs g) {
   extern __shared__ __attribute__((aligned(1024))) int8_t i8lds[];
   int tm, tn;
@@ -235,7 +241,7 @@ __global__ __launch_bounds__(512, 2) void i8gemm_packed_kernel(I8PackArgs g) {
 #define I8P_DMA(j, SOFF)                                                                                          \
   do {                                                                                                            \
     __builtin_amdgcn_global_load_lds((gemma_gptr_t)src[j], (gemma_lptr_t)(i8lds + (SOFF) + dst[j]), 16, 0, 0);    \
-    src[j] += I8_BK;                                                                                              \
+    if (!(ABL & 8)) src[j] += I8_BK;                                                                              \
   } while (0)
 // fragment read q of K-step KS from stage offset SOFF: q 0,1 = A blocks, 2,3 = B blocks
 #define I8P_READ(q, SOFF, KS, RA, RB)                                                                             \
@@ -245,8 +251,13 @@ __global__ __launch_bounds__(512, 2) void i8gemm_packed_kernel(I8PackArgs g) {
   } while (0)
 #define I8P_MASK(i, RA, RG, RM)                                                                                   \
   do {                                                                                                            \
-    RG[i] = RA[i] & mask_g;                                                                                       \
-    RM[i] = RA[i] & mask_m;                                                                                       \
+    if (ABL & 4) {                                                                                                \
+      RG[i] = RA[i];                                                                                              \
+      RM[i] = RA[i];                                                                                              \
+    } else {                                                                                                      \
+      RG[i] = RA[i] & mask_g;                                                                                     \
+      RM[i] = RA[i] & mask_m;                                                                                     \
+    }                                                                                                             \
   } while (0)
 // MFMA q of a K-step: block (i, j) = (q >> 2, (q >> 1) & 1), q & 1: 0 = G, 1 = M
 #define I8P_MF(q, RG, RM, RB)                                                                                     \
@@ -265,7 +276,9 @@ __global__ __launch_bounds__(512, 2) void i8gemm_packed_kernel(I8PackArgs g) {
     _Pragma("unroll") for (int q_ = 0; q_ < 8; ++q_) {                                                            \
       I8P_MF(q_, CG, CM, CB);                                                                                     \
       if (q_ < 4) I8P_READ(q_, NS, NKS, NA, NB);                                                                  \
-      if ((DMA) && q_ >= 4 && q_ < 7) I8P_DMA((D0) + q_ - 4, DS);                                                 \
+      if (!(ABL & 1) && q_ >= 4 && q_ < 7) {                                                                      \
+        if (DMA) I8P_DMA((D0) + q_ - 4, DS);                                                                      \
+      }                                                                                                           \
       if (q_ == 5) I8P_MASK(0, NA, NG, NM);                                                                       \
       if (q_ == 6) I8P_MASK(1, NA, NG, NM);                                                                       \
       GEMMA_SB();                                                                                                 \
@@ -274,14 +287,19 @@ __global__ __launch_bounds__(512, 2) void i8gemm_packed_kernel(I8PackArgs g) {
 // one K-tile from stage SC; MORE: tile t+1 exists in stage SN; LOAD2: tile t+2 exists and goes to stage SD
 #define I8P_KTILE(SC, SN, SD, MORE, LOAD2)                                                                        \
   do {                                                                                                            \
-    I8P_STEP(xg, xm, xb, SC, 1, ya, yg, ym, yb, LOAD2, 0, SD);                                                    \
-    I8P_STEP(yg, ym, yb, SC, 2, xa, xg, xm, xb, LOAD2, 3, SD);                                                    \
-    I8P_STEP(xg, xm, xb, SC, 3, ya, yg, ym, yb, false, 0, SD);                                                    \
+    I8P_STEP(xg, xm, xb, SC, 1, ya, yg, ym, yb, (LOAD2) && early, 0, SD);                                         \
+    I8P_STEP(yg, ym, yb, SC, 2, xa, xg, xm, xb, (LOAD2) && early, 3, SD);                                         \
+    I8P_STEP(xg, xm, xb, SC, 3, ya, yg, ym, yb, (LOAD2) && !early, 0, SD);                                        \
     I8P_MF(0, yg, ym, yb); GEMMA_SB();                                                                            \
     I8P_MF(1, yg, ym, yb); GEMMA_SB();                                                                            \
-    if (LOAD2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                                                   \
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                         \
-    __builtin_amdgcn_s_barrier();                                                                                 \
+    /* tile t+1 must have landed; still in flight: this tile's own pieces (6 early / 3 late so far) */            \
+    if ((LOAD2) && !(ABL & 1)) {                                                                                  \
+      if (early) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                                                 \
+      else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");                                                       \
+    } else {                                                                                                      \
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                            \
+    }                                                                                                             \
+    if (!(ABL & 2)) __builtin_amdgcn_s_barrier();                                                                 \
     GEMMA_SB();                                                                                                   \
     _Pragma("unroll") for (int q_ = 2; q_ < 8; ++q_) {                                                            \
       I8P_MF(q_, yg, ym, yb);                                                                                     \
@@ -293,10 +311,14 @@ __global__ __launch_bounds__(512, 2) void i8gemm_packed_kernel(I8PackArgs g) {
         if (q_ == 6) I8P_MASK(0, xa, xg, xm);                                                                     \
         if (q_ == 7) I8P_MASK(1, xa, xg, xm);                                                                     \
       }                                                                                                           \
+      if ((LOAD2) && !early && !(ABL & 1) && q_ >= 2 && q_ < 5) I8P_DMA(3 + q_ - 2, SD);                          \
       GEMMA_SB();                                                                                                 \
     }                                                                                                             \
   } while (0)
 
+  // the two wavefronts sharing a SIMD (w and w + 4) issue their LDS-DMA pieces in different halves of the K-tile: an
+  // LDS-DMA issue outlasts the 32-cycle MFMA shadow, so the partner's MFMAs have to cover it
+  const bool early = (GEMMA_I8_STAGGER == 0) || wave < 4;
   const int nk = g.nk;
   // prologue: tiles 0 and 1 in flight, tile 0 landed
 #pragma unroll

@@ -192,7 +192,9 @@ int gemma_hip_lm_finish(void);
 
 /* ---- measurement -------------------------------------------------------- */
 enum { GEMMA_STAGE_INGEST = 0, GEMMA_STAGE_UTX_GEMM = 1, GEMMA_STAGE_ASSOC = 2,
-       GEMMA_STAGE_KIN_GEMM = 3, GEMMA_STAGE_EIGH = 4, GEMMA_STAGE_COUNT = 5 };
+       GEMMA_STAGE_KIN_GEMM = 3, GEMMA_STAGE_EIGH = 4,
+       GEMMA_STAGE_UTX_POST = 5, /* int8-digit path only: int32 digit sums -> fp64 U^T x */
+       GEMMA_STAGE_COUNT = 6 };
 /* when on, every kernel of a stage is bracketed by hipEvents on its launch stream */
 int gemma_hip_profile_enable(int on);
 /* synchronises, then returns accumulated GPU milliseconds and launch count; reset != 0 clears */

@@ -455,8 +455,10 @@ def test_utx_int8_digit_product_matches_fp64(gpu_api, oracle, ni_total, p):
     assert err8 < 8 * 2.3e-16  # assembled from exact integer sums: a few roundings, not a 600-term chain
 
 
-def test_lmm_plink_through_int8_digit_product(gpu_api, oracle, monkeypatch):
-    """The whole PLINK association path with GEMMA_HIP_UTX_I8=1 against the oracle."""
+@pytest.mark.parametrize("i8", ["1", "0"])
+def test_lmm_plink_through_int8_digit_product(gpu_api, oracle, monkeypatch, i8):
+    """The whole PLINK association path through the int8-digit product (default) and through the fp64 GEMM
+    (GEMMA_HIP_UTX_I8=0) against the oracle."""
     import gemma_amd._lib as L
     rng = np.random.default_rng(23)
     ni_total, p = 700, 300
@@ -468,10 +470,10 @@ def test_lmm_plink_through_int8_digit_product(gpu_api, oracle, monkeypatch):
     y = rng.standard_normal(n)
     UtW, Uty = U.T @ np.ones((n, 1)), U.T @ y
     ref = oracle.lmm_analyze(1, U, ev, UtW, Uty, Xn, plink_nan_rule=1)
-    monkeypatch.setenv("GEMMA_HIP_UTX_I8", "1")
+    monkeypatch.setenv("GEMMA_HIP_UTX_I8", i8)
     lmm = gpu_api.LMM(a_mode=1)
     got = lmm.AnalyzePlink(U, ev, UtW, Uty, raw, ind)
-    _cmp_stats(got, ref, 1, "plink-int8")
+    _cmp_stats(got, ref, 1, "plink-int8=%s" % i8)
 
 
 def test_lmm_reference_xlarge_layout_and_batching(gpu_api, oracle):
