@@ -4,24 +4,21 @@
 // Hot call sites: U^T X per SNP batch (src/lmm.cpp:1521,1847), K += Xb Xb^T (src/gemma_io.cpp:1554,
 // 1711), CalcUtX (src/mathfunc.cpp:504-506).
 //
-// Design (CDNA4):
+// Design (CDNA4), details in DESIGN.md 3.1:
 //  * v_mfma_f64_16x16x4_f64: one 16x16 output block per instruction, K = 4, 64 cycles/SIMD
 //    (78.6 TFLOP/s chip peak).  A/B operands are ONE f64 per lane (A[i=l&15][k=l>>4],
 //    B[k=l>>4][j=l&15]); the 16x16 f64 result is 4 f64 per lane: col = l&15, row = (l>>4)+4*r.
 //  * 128x128 block tile, 256 threads = 4 wavefronts in a 2x2 grid, each wave owns 64x64
-//    (4x4 MFMA blocks = 64 f64 accumulators per lane = 128 VGPR), BK = 16.
-//    LDS demand is tiny next to the 64-cycle MFMA (8 ds_read_b64 per 16 MFMAs), so the tile
-//    is sized for L2->LDS traffic (16 flop/B) and occupancy (2 blocks/CU, 73.7 KB LDS each).
-//  * global -> registers -> LDS double buffering: the loads for K-tile t+1 are issued before the
-//    MFMAs of tile t and written to the other LDS buffer after them; one barrier per K-tile.
-//  * LDS image follows the operand's memory order so the 16-byte global loads and the
-//    ds_write_b128 are both contiguous:  [k][m] operands ("T" for A, "N" for B) are kept as
-//    [16][144] (144 = 128 + 16: the two k-rows a 32-lane ds_read_b64 group touches land on
-//    disjoint bank halves), [m][k] operands as [128][18] (row stride 18 doubles walks all 32
-//    8-byte banks).
+//    (4x4 MFMA blocks = 64 f64 accumulators per lane = 128 VGPR), BK = 16, 2 blocks/CU.
+//  * Three interior kernels, selected by GEMMA_HIP_GEMM_PIPE:
+//      dgemm_mfma_glds_kernel (default): global -> LDS by global_load_lds_dwordx4, pinned issue order
+//        (one ds_read / LDS-DMA piece behind each MFMA), 218 ms at M = N = K = 20000 (73 TFLOP/s);
+//      dgemm_mfma_pipe_kernel: register-staged, fragments software-pipelined one K-step ahead (238 ms);
+//      dgemm_mfma_kernel<.., FULL>: register-staged, compiler-scheduled (243 ms); its FULL = false form is
+//        the bounds-checked kernel for ragged strips (when beta != 0), K tails and unaligned views.
 //  * blockIdx -> tile: XCD-aware (block b runs on XCD b % 8): every XCD gets a contiguous run of
 //    tiles, rastered in groups of 4 tile-rows so the ~64 blocks an XCD runs at once form a
-//    4x16 patch sharing A/B panels in that XCD's 4 MiB L2 (82 % TCC hit rate at n = 20000).
+//    4x16 patch sharing A/B panels in that XCD's 4 MiB L2 (80 % TCC hit rate at n = 20000).
 //  * SYRK mode (kinship): only tiles with tile_n >= tile_m are launched (triangular grid).
 #pragma once
 #include <hip/hip_runtime.h>
