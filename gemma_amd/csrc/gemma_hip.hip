@@ -920,9 +920,12 @@ static int utx_plink_i8(const void *geno, size_t l, size_t ld, double *UtX, size
   //                      0 separate G and M rows, 256 x 256 tiles, 2 stages
   const char *ek = getenv("GEMMA_HIP_I8_KERNEL");
   const bool packed = !(ek && ek[0] == '0');
+  // two digits per int32 output plane while 256 * C_hi + C_lo cannot overflow: n * 2 * 128 * 257 < 2^31
+  const char *ef = getenv("GEMMA_HIP_I8_FUSE");
+  const int fuse = (packed && !(ef && ef[0] == '0') && (double)g_ctx.cfg.n * 2.0 * 128.0 * 257.0 < 2147483648.0) ? 1 : 0;
   const size_t n = g_ctx.cfg.n, ldk = g_ctx.i8_ldk, npad = g_ctx.i8_npad;
   const size_t lpad = round_up(l, I8_BM), mrows = 2 * lpad, arows = packed ? lpad : mrows;
-  const size_t c_elems = (size_t)I8_DIGITS * mrows * npad;
+  const size_t c_elems = (size_t)(fuse ? 4 : I8_DIGITS) * mrows * npad;
   if (g_ctx.i8_A.reserve(arows * ldk) || g_ctx.i8_C.reserve(c_elems * 4) || g_ctx.i8_mean.reserve(l * 8))
     return fail(GEMMA_HIP_ENOMEM, "lmm_batch: int8 product buffers (%zu bytes)", arows * ldk + c_elems * 4);
   {
@@ -973,9 +976,10 @@ static int utx_plink_i8(const void *geno, size_t l, size_t ld, double *UtX, size
       g.tiles_m = (int)(lpad / I8P_BM); g.tiles_n = (int)(npad / I8_BN);
       g.nk = (int)(ldk / I8_BK);
       g.gm = gm;
+      g.fuse = fuse;
       const char *ea = getenv("GEMMA_HIP_I8_ABLATE"); // timing experiments (wrong results)
       const int abl = ea ? atoi(ea) : 0;
-      const dim3 grid((unsigned)(g.tiles_m * g.tiles_n), I8_DIGITS);
+      const dim3 grid((unsigned)(g.tiles_m * g.tiles_n), fuse ? 4 : I8_DIGITS);
       switch (abl) {
       case 1: hipLaunchKernelGGL(i8gemm_packed_kernel<1>, grid, dim3(512), 3 * I8P_STAGE, s, g); break;
       case 2: hipLaunchKernelGGL(i8gemm_packed_kernel<2>, grid, dim3(512), 3 * I8P_STAGE, s, g); break;
@@ -1002,7 +1006,7 @@ static int utx_plink_i8(const void *geno, size_t l, size_t ld, double *UtX, size
     ProfScope ps(GEMMA_STAGE_UTX_POST, s);
     hipLaunchKernelGGL(i8_combine_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)l), dim3(256), 0, s,
                        g_ctx.i8_C.as<int>(), (long)npad, (long)(mrows * npad), (long)lpad, g_ctx.i8_mean.as<double>(),
-                       g_ctx.i8_ej.as<int>(), (long)l, (long)n, UtX, (long)ldx, packed ? 0.0625 : 1.0);
+                       g_ctx.i8_ej.as<int>(), (long)l, (long)n, UtX, (long)ldx, 1.0, fuse);
     HIPCHK(hipGetLastError());
   }
   return GEMMA_HIP_OK;

@@ -152,9 +152,11 @@ __global__ __launch_bounds__(512, 2) void i8gemm_kernel(I8GemmArgs g) {
 
 // ---------------------------------------------------------------------------------------------------------------
 // Second form: ONE packed left factor per SNP row, byte = g | (m << 4).  A wave reads an A fragment from LDS once and
-// masks it into the genotype operand (a & 0x03) and the missing-mask operand (a & 0x10, i.e. 16 m: the M results
-// come out multiplied by 16, still < 2^27) -- the G and M products share every global / LDS byte of both operands,
-// so LDS traffic per MFMA drops by a third and the left factor is read once.
+// masks it into the genotype operand (a & 0x03) and the missing-mask operand ((a >> 4) & 0x01) -- the G and M
+// products share every global / LDS byte of both operands, so LDS traffic per MFMA drops by a third and the left
+// factor is read once.  Two digits of U are fused per output plane where 256 * C_{d+1} + C_d still fits int32
+// (n <= 32640): the K loop runs for the upper digit, the accumulators are shifted left by 8, and it runs again for
+// the lower digit -- 4 int32 planes leave the kernel instead of 7.
 //   tile 128 SNP rows x 256 columns x 128 K bytes; 8 wavefronts (2 x 4), wave tile 64 x 64 for G and for M
 //   (2 x 2 x 2 blocks of 32 x 32 = 128 int32 accumulators); three LDS stages of 48 KiB (A 16 KiB + B 32 KiB), LDS-DMA
 //   two K-tiles ahead with a counted vmcnt and a raw s_barrier; pinned issue order: one ds_read_b128 / LDS-DMA piece /
@@ -163,13 +165,14 @@ __global__ __launch_bounds__(512, 2) void i8gemm_kernel(I8GemmArgs g) {
 struct I8PackArgs {
   const int8_t *A;   // lpad x ldk packed bytes
   const int8_t *Bt;  // digit d: N x ldk
-  int *C;            // digit d: (2 lpad) x ldc; rows [0, lpad) = G products, [lpad, 2 lpad) = 16 x M products
+  int *C;            // plane q: (2 lpad) x ldc; rows [0, lpad) = G products, [lpad, 2 lpad) = M products
   long ldk, ldc;
   long strideB, strideC;
   long m_row0;       // lpad
   int tiles_m, tiles_n;
   int nk;
   int gm;
+  int fuse;          // 1: 4 output planes {0}, {2,1}, {4,3}, {6,5} (needs n * 2 * 128 * 257 < 2^31), 0: 7 planes
 };
 constexpr int I8P_BM = 128;
 #ifndef GEMMA_I8_STAGGER
@@ -196,7 +199,11 @@ __global__ __launch_bounds__(512, 2) void i8gemm_packed_kernel(I8PackArgs g) {
     tm = first_m + in % gsz;
     tn = in / gsz;
   }
-  const int digit = blockIdx.y;
+  // output plane q: fused pairs of digits when g.fuse (256 * C_{d+1} + C_d still fits int32): planes
+  // {0}, {2,1}, {4,3}, {6,5}; otherwise one digit per plane
+  const int plane = blockIdx.y;
+  const int d_first = g.fuse ? (plane == 0 ? 0 : 2 * plane) : plane; // most significant digit of the plane
+  const int nd = (g.fuse && plane > 0) ? 2 : 1;
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int wm = wave >> 2, wn = wave & 3; // rows wm*64, cols wn*64
@@ -205,17 +212,19 @@ __global__ __launch_bounds__(512, 2) void i8gemm_packed_kernel(I8PackArgs g) {
   // LDS-DMA: a stage is 48 pieces of 1 KiB (0-15: A rows 8p.., 16-47: B rows 8(p-16)..); wave w moves pieces 6w..6w+5
   const int8_t *src[6];
   int dst[6];
-#pragma unroll
-  for (int j = 0; j < 6; ++j) {
-    const int p = 6 * wave + j;
-    const bool isA = p < 16;
-    const int row = 8 * (isA ? p : p - 16) + (lane >> 3);
-    const int chunk = (lane & 7) ^ ((row >> 1) & 7);
-    const int8_t *base = isA ? g.A + ((long)tm * I8P_BM + row) * g.ldk
-                             : g.Bt + (long)digit * g.strideB + ((long)tn * I8_BN + row) * g.ldk;
-    src[j] = base + 16 * chunk;
-    dst[j] = p * 1024;
-  }
+#define I8P_INIT_SRC(DIGIT)                                                                                       \
+  do {                                                                                                            \
+    _Pragma("unroll") for (int j = 0; j < 6; ++j) {                                                               \
+      const int p = 6 * wave + j;                                                                                 \
+      const bool isA = p < 16;                                                                                    \
+      const int row = 8 * (isA ? p : p - 16) + (lane >> 3);                                                       \
+      const int chunk = (lane & 7) ^ ((row >> 1) & 7);                                                            \
+      const int8_t *base = isA ? g.A + ((long)tm * I8P_BM + row) * g.ldk                                          \
+                               : g.Bt + (long)(DIGIT) * g.strideB + ((long)tn * I8_BN + row) * g.ldk;             \
+      src[j] = base + 16 * chunk;                                                                                 \
+      dst[j] = p * 1024;                                                                                          \
+    }                                                                                                             \
+  } while (0)
   // fragment byte offsets inside a stage, K-step ks: logical chunk 2 ks + h
   int fa[4], fb[4];
 #pragma unroll
@@ -236,7 +245,7 @@ __global__ __launch_bounds__(512, 2) void i8gemm_packed_kernel(I8PackArgs g) {
   // two fragment register sets (X, Y): raw A (2 blocks), masked G / M operands, B (2 blocks)
   i32x4 xa[2], xg[2], xm[2], xb[2], ya[2], yg[2], ym[2], yb[2];
   const i32x4 mask_g = {0x03030303, 0x03030303, 0x03030303, 0x03030303};
-  const i32x4 mask_m = {0x10101010, 0x10101010, 0x10101010, 0x10101010};
+  const i32x4 mask_m = {0x01010101, 0x01010101, 0x01010101, 0x01010101};
 
 #define I8P_DMA(j, SOFF)                                                                                          \
   do {                                                                                                            \
@@ -256,7 +265,7 @@ __global__ __launch_bounds__(512, 2) void i8gemm_packed_kernel(I8PackArgs g) {
       RM[i] = RA[i];                                                                                              \
     } else {                                                                                                      \
       RG[i] = RA[i] & mask_g;                                                                                     \
-      RM[i] = RA[i] & mask_m;                                                                                     \
+      RM[i] = (RA[i] >> 4) & mask_m;                                                                              \
     }                                                                                                             \
   } while (0)
 // MFMA q of a K-step: block (i, j) = (q >> 2, (q >> 1) & 1), q & 1: 0 = G, 1 = M
@@ -320,34 +329,47 @@ __global__ __launch_bounds__(512, 2) void i8gemm_packed_kernel(I8PackArgs g) {
   // LDS-DMA issue outlasts the 32-cycle MFMA shadow, so the partner's MFMAs have to cover it
   const bool early = (GEMMA_I8_STAGGER == 0) || wave < 4;
   const int nk = g.nk;
-  // prologue: tiles 0 and 1 in flight, tile 0 landed
+  for (int dd = 0; dd < nd; ++dd) {
+    if (dd > 0) { // second digit of a fused pair: acc = 256 * C_hi, then accumulate C_lo on top
 #pragma unroll
-  for (int j = 0; j < 6; ++j) I8P_DMA(j, 0);
-  if (nk > 1) {
+      for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 6; ++j) I8P_DMA(j, I8P_STAGE);
-    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-  } else {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  }
-  __builtin_amdgcn_s_barrier();
-  GEMMA_SB();
+        for (int j = 0; j < 2; ++j)
 #pragma unroll
-  for (int q = 0; q < 4; ++q) I8P_READ(q, 0, 0, xa, xb);
-  I8P_MASK(0, xa, xg, xm);
-  I8P_MASK(1, xa, xg, xm);
+          for (int r = 0; r < 16; ++r) { accg[i][j][r] <<= 8; accm[i][j][r] <<= 8; }
+    }
+    I8P_INIT_SRC(d_first - dd);
+    // prologue: tiles 0 and 1 in flight, tile 0 landed (every LDS read of the previous digit completed before its
+    // last barrier, so the stages are free)
+#pragma unroll
+    for (int j = 0; j < 6; ++j) I8P_DMA(j, 0);
+    if (nk > 1) {
+#pragma unroll
+      for (int j = 0; j < 6; ++j) I8P_DMA(j, I8P_STAGE);
+      asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    GEMMA_SB();
+#pragma unroll
+    for (int q = 0; q < 4; ++q) I8P_READ(q, 0, 0, xa, xb);
+    I8P_MASK(0, xa, xg, xm);
+    I8P_MASK(1, xa, xg, xm);
 
-  int sc = 0, sn = I8P_STAGE, sd = 2 * I8P_STAGE; // stage byte offsets: current, next, DMA target
-  int kt = 0;
-  for (; kt + 2 < nk; ++kt) {
-    I8P_KTILE(sc, sn, sd, true, true);
-    const int tmp = sc; sc = sn; sn = sd; sd = tmp;
+    int sc = 0, sn = I8P_STAGE, sd = 2 * I8P_STAGE; // stage byte offsets: current, next, DMA target
+    int kt = 0;
+    for (; kt + 2 < nk; ++kt) {
+      I8P_KTILE(sc, sn, sd, true, true);
+      const int tmp = sc; sc = sn; sn = sd; sd = tmp;
+    }
+    if (nk >= 2) {
+      I8P_KTILE(sc, sn, sd, true, false);
+      const int tmp = sc; sc = sn; sn = sd; sd = tmp;
+    }
+    I8P_KTILE(sc, sn, sd, false, false);
   }
-  if (nk >= 2) {
-    I8P_KTILE(sc, sn, sd, true, false);
-    const int tmp = sc; sc = sn; sn = sd; sd = tmp;
-  }
-  I8P_KTILE(sc, sn, sd, false, false);
+#undef I8P_INIT_SRC
 #undef I8P_DMA
 #undef I8P_READ
 #undef I8P_MASK
@@ -355,7 +377,7 @@ __global__ __launch_bounds__(512, 2) void i8gemm_packed_kernel(I8PackArgs g) {
 #undef I8P_STEP
 #undef I8P_KTILE
 
-  int *Cg = g.C + (long)digit * g.strideC;
+  int *Cg = g.C + (long)plane * g.strideC;
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -463,21 +485,31 @@ __global__ __launch_bounds__(256) void ingest_i8_kernel(IngestI8Args g) {
   if (lane == 0) g.mean[s] = tot / cnt; // x_total / (ni_test - n_miss), as ingest_lmm_kernel
 }
 
-// UtX[s][j] = 2^(e_j - 54) * sum_d 256^d (CG_d[s][j] + mean_s * CM_d[s][j])
+// UtX[s][j] = 2^(e_j - 54) * sum_d 256^d (CG_d[s][j] + mean_s * CM_d[s][j]);  planes: 7 single digits (fuse = 0) or
+// {0}, {2,1}, {4,3}, {6,5} with 256 * C_{d+1} + C_d per plane (fuse = 1)
 __global__ __launch_bounds__(256) void i8_combine_kernel(const int *__restrict__ C, long ldc, long strideC, long m_row0,
                                                          const double *__restrict__ mean, const int *__restrict__ ej,
                                                          long l, long n, double *__restrict__ UtX, long ldx,
-                                                         double m_scale) {
+                                                         double m_scale, int fuse) {
   const long j = (long)blockIdx.x * 256 + threadIdx.x;
   const long s = blockIdx.y;
   if (j >= n || s >= l) return;
   double tg = 0.0, tmk = 0.0;
+  if (fuse) {
 #pragma unroll
-  for (int d = I8_DIGITS - 1; d >= 0; --d) {
-    tg = tg * 256.0 + (double)C[(long)d * strideC + s * ldc + j];
-    tmk = tmk * 256.0 + (double)C[(long)d * strideC + (m_row0 + s) * ldc + j];
+    for (int q = 3; q >= 0; --q) {
+      const double w = (q == 0) ? 256.0 : 65536.0; // plane q sits 2 digits above plane q-1, plane 1 one above plane 0
+      tg = tg * w + (double)C[(long)q * strideC + s * ldc + j];
+      tmk = tmk * w + (double)C[(long)q * strideC + (m_row0 + s) * ldc + j];
+    }
+  } else {
+#pragma unroll
+    for (int d = I8_DIGITS - 1; d >= 0; --d) {
+      tg = tg * 256.0 + (double)C[(long)d * strideC + s * ldc + j];
+      tmk = tmk * 256.0 + (double)C[(long)d * strideC + (m_row0 + s) * ldc + j];
+    }
   }
-  UtX[s * ldx + j] = ldexp(fma(mean[s] * m_scale, tmk, tg), ej[j] - I8_SCALE_BITS); // m_scale: 1 or 1/16 (exact)
+  UtX[s * ldx + j] = ldexp(fma(mean[s] * m_scale, tmk, tg), ej[j] - I8_SCALE_BITS); // m_scale: exact power of two
 }
 
 } // namespace gemma_hip
