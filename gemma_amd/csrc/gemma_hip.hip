@@ -847,7 +847,19 @@ static int launch_assoc(const double *UtX, size_t l, size_t ld, gemma_sumstat *o
       a.grid_T = g_ctx.grid_T.as<double>();
     }
     switch (sel) {
-    case 1: hipLaunchKernelGGL(lmm_assoc_kernel<1>, dim3(grid), dim3(256), 0, s, a); break;
+    case 1: {
+      // streaming-loop unroll / wavefronts per SIMD of the c = 1 kernel; measured at n = 20000 (ms per 20000 SNPs):
+      // 2/3: 14.3, 4/3: 14.1, 8/3: 13.9, 2/4: 12.9, 4/4: 12.8 (default), 4/2: 14.2
+      const char *ev = getenv("GEMMA_HIP_ASSOC_VARIANT");
+      const int var = ev ? atoi(ev) : 44;
+      if (var == 43) hipLaunchKernelGGL((lmm_assoc1_variant_kernel<4, 3>), dim3(grid), dim3(256), 0, s, a);
+      else if (var == 83) hipLaunchKernelGGL((lmm_assoc1_variant_kernel<8, 3>), dim3(grid), dim3(256), 0, s, a);
+      else if (var == 24) hipLaunchKernelGGL((lmm_assoc1_variant_kernel<2, 4>), dim3(grid), dim3(256), 0, s, a);
+      else if (var == 23) hipLaunchKernelGGL(lmm_assoc_kernel<1>, dim3(grid), dim3(256), 0, s, a);
+      else if (var == 42) hipLaunchKernelGGL((lmm_assoc1_variant_kernel<4, 2>), dim3(grid), dim3(256), 0, s, a);
+      else hipLaunchKernelGGL((lmm_assoc1_variant_kernel<4, 4>), dim3(grid), dim3(256), 0, s, a);
+      break;
+    }
     case 2: hipLaunchKernelGGL(lmm_assoc_kernel<2>, dim3(grid), dim3(256), 0, s, a); break;
     case 3: hipLaunchKernelGGL(lmm_assoc_kernel<3>, dim3(grid), dim3(256), 0, s, a); break;
     case 4: hipLaunchKernelGGL(lmm_assoc_kernel<4>, dim3(grid), dim3(256), 0, s, a); break;

@@ -192,7 +192,7 @@ struct Row0 {
 
 // One pass over the SNP's rotated genotype row.  ORDER = highest power of H needed (1..3);
 // ORDER = 0 means H == 1 (the "Iab" call of LogRL_f, src/lmm.cpp:839-840).
-template <int C, int ORDER, bool LOGDET>
+template <int C, int ORDER, bool LOGDET, int UNR = 2>
 __device__ __forceinline__ void row0_pass(const AssocArgs &g, const double *__restrict__ x,
                                           double lambda, int lane, Row0<C> &R) {
   constexpr int NI = Row0<C>::NI;
@@ -200,7 +200,7 @@ __device__ __forceinline__ void row0_pass(const AssocArgs &g, const double *__re
   for (int q = 0; q < NI; ++q) R.s1[q] = R.s2[q] = R.s3[q] = 0.0;
   double tr1 = 0.0, tr2 = 0.0, ld = 0.0;
   const int n = g.n;
-#pragma unroll 2
+#pragma unroll UNR
   for (int i = lane; i < n; i += 64) {
     double u[C + 2];
 #pragma unroll
@@ -330,7 +330,7 @@ struct Agg {
 };
 
 // number of covariates fixed at compile time: everything in registers (c = 1..4)
-template <int C>
+template <int C, int UNR = 2>
 struct FixedC {
   static constexpr bool HAS_GRID = true;
   __device__ __forceinline__ int c() const { return C; }
@@ -361,7 +361,7 @@ struct FixedC {
   template <int ORDER, bool LOGDET>
   __device__ __forceinline__ void eval(const AssocArgs &g, const double *x, double l, int lane, Agg &A) const {
     Row0<C> R;
-    row0_pass<C, ORDER, LOGDET>(g, x, l, lane, R);
+    row0_pass<C, ORDER, LOGDET, UNR>(g, x, l, lane, R);
     finish<ORDER>(R, A);
   }
   // The same evaluation at grid lambda gi (gi < 0: H = 1, the Iab call) from the fixed-lambda table: the row-0
@@ -968,6 +968,14 @@ __global__ __launch_bounds__(256, (C == 1 ? 3 : (C == 2 ? 2 : 1))) void lmm_asso
   const long snp = (long)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   if (snp >= g.l) return;
   assoc_one_snp(g, FixedC<C>(), snp, lane);
+}
+// tuning variants of the c = 1 kernel: streaming-loop unroll UNR, WPS wavefronts per SIMD (GEMMA_HIP_ASSOC_VARIANT)
+template <int UNR, int WPS>
+__global__ __launch_bounds__(256, WPS) void lmm_assoc1_variant_kernel(AssocArgs g) {
+  const int lane = threadIdx.x & 63;
+  const long snp = (long)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  if (snp >= g.l) return;
+  assoc_one_snp(g, FixedC<1, UNR>(), snp, lane);
 }
 
 __global__ __launch_bounds__(256) void lmm_assoc_generic_kernel(AssocArgs g, int c) {
