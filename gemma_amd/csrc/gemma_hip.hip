@@ -889,8 +889,9 @@ extern "C" int gemma_hip_lmm_assoc_d(const double *UtX_d, size_t l, size_t ld_ut
   return launch_assoc(UtX_d, l, ld_utx, out_d, S(stream));
 }
 
-// GEMMA_HIP_UTX_I8: 1 (default) = PLINK batches go through the exact int8-digit product (i8gemm.hip.h),
-// 0 = always the fp64 MFMA GEMM.  Real-valued (BIMBAM dosage) input always takes the fp64 GEMM.
+// GEMMA_HIP_UTX_I8: 1 (default) = hard-call batches (PLINK 2-bit; fp64 input whose rows hold only 0/1/2 and one
+// missing / imputed value) go through the exact int8-digit product (i8gemm.hip.h), 0 = always the fp64 MFMA GEMM.
+// Real-valued dosages always take the fp64 GEMM.
 static int utx_i8_mode() {
   const char *e = getenv("GEMMA_HIP_UTX_I8");
   return e ? atoi(e) : 1;
@@ -924,104 +925,107 @@ static int i8_prepare_u(hipStream_t s) {
   return GEMMA_HIP_OK;
 }
 
-// UtX (l x ldx, SNP-major) of a PLINK batch through the int8-digit product
-static int utx_plink_i8(const void *geno, size_t l, size_t ld, double *UtX, size_t ldx, hipStream_t s) {
+// ---- exact int8-digit U^T x (i8gemm.hip.h): buffers, the product on an already packed left factor, ingest variants
+struct I8Dims {
+  size_t n, ldk, npad, lpad, mrows;
+  int fuse;
+};
+static int i8_begin(size_t l, I8Dims *d, hipStream_t s) {
   int rc = i8_prepare_u(s);
   if (rc) return rc;
-  // GEMMA_HIP_I8_KERNEL: 1 (default) packed left factor g | m << 4, 128 x 256 tiles, 3 LDS stages;
-  //                      0 separate G and M rows, 256 x 256 tiles, 2 stages
-  const char *ek = getenv("GEMMA_HIP_I8_KERNEL");
-  const bool packed = !(ek && ek[0] == '0');
+  d->n = g_ctx.cfg.n; d->ldk = g_ctx.i8_ldk; d->npad = g_ctx.i8_npad;
+  d->lpad = round_up(l, I8P_BM); d->mrows = 2 * d->lpad;
   // two digits per int32 output plane while 256 * C_hi + C_lo cannot overflow: n * 2 * 128 * 257 < 2^31
   const char *ef = getenv("GEMMA_HIP_I8_FUSE");
-  const int fuse = (packed && !(ef && ef[0] == '0') && (double)g_ctx.cfg.n * 2.0 * 128.0 * 257.0 < 2147483648.0) ? 1 : 0;
-  const size_t n = g_ctx.cfg.n, ldk = g_ctx.i8_ldk, npad = g_ctx.i8_npad;
-  const size_t lpad = round_up(l, I8_BM), mrows = 2 * lpad, arows = packed ? lpad : mrows;
-  const size_t c_elems = (size_t)(fuse ? 4 : I8_DIGITS) * mrows * npad;
-  if (g_ctx.i8_A.reserve(arows * ldk) || g_ctx.i8_C.reserve(c_elems * 4) || g_ctx.i8_mean.reserve(l * 8))
-    return fail(GEMMA_HIP_ENOMEM, "lmm_batch: int8 product buffers (%zu bytes)", arows * ldk + c_elems * 4);
-  {
-    ProfScope ps(GEMMA_STAGE_INGEST, s);
-    if (lpad != l) HIPCHK(hipMemsetAsync(g_ctx.i8_A.p, 0, arows * ldk, s)); // padding rows
-    IngestI8Args a;
-    a.src = reinterpret_cast<const unsigned char *>(geno); a.ld = (long)ld; a.l = (long)l;
-    a.idx_map = g_ctx.have_map ? g_ctx.idx_map.as<int>() : nullptr;
-    a.n = (int)n; a.A = g_ctx.i8_A.as<int8_t>(); a.ldk = (long)ldk; a.m_row0 = (long)lpad;
-    a.mean = g_ctx.i8_mean.as<double>();
-    a.packed = packed ? 1 : 0;
-    hipLaunchKernelGGL(ingest_i8_kernel, dim3((unsigned)((l + 3) / 4)), dim3(256), 0, s, a);
-    HIPCHK(hipGetLastError());
-  }
+  d->fuse = (!(ef && ef[0] == '0') && (double)d->n * 2.0 * 128.0 * 257.0 < 2147483648.0) ? 1 : 0;
+  const size_t c_elems = (size_t)(d->fuse ? 4 : I8_DIGITS) * d->mrows * d->npad;
+  if (g_ctx.i8_A.reserve(d->lpad * d->ldk) || g_ctx.i8_C.reserve(c_elems * 4) || g_ctx.i8_mean.reserve(l * 8))
+    return fail(GEMMA_HIP_ENOMEM, "lmm_batch: int8 product buffers (%zu bytes)", d->lpad * d->ldk + c_elems * 4);
+  if (d->lpad != l) HIPCHK(hipMemsetAsync(g_ctx.i8_A.p, 0, d->lpad * d->ldk, s)); // padding rows
+  return GEMMA_HIP_OK;
+}
+
+// UtX (l x ldx) from the packed left factor in g_ctx.i8_A and the per-SNP means in g_ctx.i8_mean
+static int i8_product(size_t l, const I8Dims &d, double *UtX, size_t ldx, hipStream_t s) {
   {
     ProfScope ps(GEMMA_STAGE_UTX_GEMM, s);
     static bool attr_set = false;
     if (!attr_set) {
-      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(i8gemm_kernel),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
-      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(i8gemm_packed_kernel<0>),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, 3 * I8P_STAGE));
-      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(i8gemm_packed_kernel<1>),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, 3 * I8P_STAGE));
-      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(i8gemm_packed_kernel<2>),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, 3 * I8P_STAGE));
-      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(i8gemm_packed_kernel<3>),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, 3 * I8P_STAGE));
-      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(i8gemm_packed_kernel<7>),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, 3 * I8P_STAGE));
-      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(i8gemm_packed_kernel<8>),
+      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(i8gemm_packed_kernel),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 3 * I8P_STAGE));
       attr_set = true;
     }
-    static int gm = -1;
-    if (gm < 0) {
-      const char *e = getenv("GEMMA_HIP_I8_GM");
-      gm = e ? atoi(e) : 0;
-    }
-    if (packed) {
-      I8PackArgs g;
-      g.A = g_ctx.i8_A.as<int8_t>();
-      g.Bt = g_ctx.i8_Bt.as<int8_t>();
-      g.C = g_ctx.i8_C.as<int>();
-      g.ldk = (long)ldk; g.ldc = (long)npad;
-      g.strideB = (long)(npad * ldk); g.strideC = (long)(mrows * npad);
-      g.m_row0 = (long)lpad;
-      g.tiles_m = (int)(lpad / I8P_BM); g.tiles_n = (int)(npad / I8_BN);
-      g.nk = (int)(ldk / I8_BK);
-      g.gm = gm;
-      g.fuse = fuse;
-      const char *ea = getenv("GEMMA_HIP_I8_ABLATE"); // timing experiments (wrong results)
-      const int abl = ea ? atoi(ea) : 0;
-      const dim3 grid((unsigned)(g.tiles_m * g.tiles_n), fuse ? 4 : I8_DIGITS);
-      switch (abl) {
-      case 1: hipLaunchKernelGGL(i8gemm_packed_kernel<1>, grid, dim3(512), 3 * I8P_STAGE, s, g); break;
-      case 2: hipLaunchKernelGGL(i8gemm_packed_kernel<2>, grid, dim3(512), 3 * I8P_STAGE, s, g); break;
-      case 3: hipLaunchKernelGGL(i8gemm_packed_kernel<3>, grid, dim3(512), 3 * I8P_STAGE, s, g); break;
-      case 7: hipLaunchKernelGGL(i8gemm_packed_kernel<7>, grid, dim3(512), 3 * I8P_STAGE, s, g); break;
-      case 8: hipLaunchKernelGGL(i8gemm_packed_kernel<8>, grid, dim3(512), 3 * I8P_STAGE, s, g); break;
-      default: hipLaunchKernelGGL(i8gemm_packed_kernel<0>, grid, dim3(512), 3 * I8P_STAGE, s, g); break;
-      }
-    } else {
-      I8GemmArgs g;
-      g.A = g_ctx.i8_A.as<int8_t>();
-      g.Bt = g_ctx.i8_Bt.as<int8_t>();
-      g.C = g_ctx.i8_C.as<int>();
-      g.ldk = (long)ldk; g.ldc = (long)npad;
-      g.strideB = (long)(npad * ldk); g.strideC = (long)(mrows * npad);
-      g.tiles_m = (int)(mrows / I8_BM); g.tiles_n = (int)(npad / I8_BN);
-      g.nk = (int)(ldk / I8_BK);
-      g.gm = gm;
-      hipLaunchKernelGGL(i8gemm_kernel, dim3((unsigned)(g.tiles_m * g.tiles_n), I8_DIGITS), dim3(512), 131072, s, g);
-    }
+    I8PackArgs g;
+    g.A = g_ctx.i8_A.as<int8_t>();
+    g.Bt = g_ctx.i8_Bt.as<int8_t>();
+    g.C = g_ctx.i8_C.as<int>();
+    g.ldk = (long)d.ldk; g.ldc = (long)d.npad;
+    g.strideB = (long)(d.npad * d.ldk); g.strideC = (long)(d.mrows * d.npad);
+    g.m_row0 = (long)d.lpad;
+    g.tiles_m = (int)(d.lpad / I8P_BM); g.tiles_n = (int)(d.npad / I8_BN);
+    g.nk = (int)(d.ldk / I8_BK);
+    const char *e = getenv("GEMMA_HIP_I8_GM");
+    g.gm = e ? atoi(e) : 0;
+    g.fuse = d.fuse;
+    const dim3 grid((unsigned)(g.tiles_m * g.tiles_n), d.fuse ? 4 : I8_DIGITS);
+    hipLaunchKernelGGL(i8gemm_packed_kernel, grid, dim3(512), 3 * I8P_STAGE, s, g);
     HIPCHK(hipGetLastError());
   }
   {
     ProfScope ps(GEMMA_STAGE_UTX_POST, s);
-    hipLaunchKernelGGL(i8_combine_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)l), dim3(256), 0, s,
-                       g_ctx.i8_C.as<int>(), (long)npad, (long)(mrows * npad), (long)lpad, g_ctx.i8_mean.as<double>(),
-                       g_ctx.i8_ej.as<int>(), (long)l, (long)n, UtX, (long)ldx, 1.0, fuse);
+    hipLaunchKernelGGL(i8_combine_kernel, dim3((unsigned)((d.n + 255) / 256), (unsigned)l), dim3(256), 0, s,
+                       g_ctx.i8_C.as<int>(), (long)d.npad, (long)(d.mrows * d.npad), (long)d.lpad,
+                       g_ctx.i8_mean.as<double>(), g_ctx.i8_ej.as<int>(), (long)l, (long)d.n, UtX, (long)ldx, 1.0, d.fuse);
     HIPCHK(hipGetLastError());
   }
   return GEMMA_HIP_OK;
+}
+
+// PLINK 2-bit batch
+static int utx_plink_i8(const void *geno, size_t l, size_t ld, double *UtX, size_t ldx, hipStream_t s) {
+  I8Dims d;
+  int rc = i8_begin(l, &d, s);
+  if (rc) return rc;
+  {
+    ProfScope ps(GEMMA_STAGE_INGEST, s);
+    IngestI8Args a;
+    a.src = reinterpret_cast<const unsigned char *>(geno); a.ld = (long)ld; a.l = (long)l;
+    a.idx_map = g_ctx.have_map ? g_ctx.idx_map.as<int>() : nullptr;
+    a.n = (int)d.n; a.A = g_ctx.i8_A.as<int8_t>(); a.ldk = (long)d.ldk;
+    a.mean = g_ctx.i8_mean.as<double>();
+    hipLaunchKernelGGL(ingest_i8_kernel, dim3((unsigned)((l + 3) / 4)), dim3(256), 0, s, a);
+    HIPCHK(hipGetLastError());
+  }
+  return i8_product(l, d, UtX, ldx, s);
+}
+
+// fp64 SNP-major rows (src: l x ld): if every row is a hard-call row (i8gemm.hip.h, pack_f64_kernel) the batch goes
+// through the int8-digit product and *done = true; otherwise nothing is computed and the caller takes the fp64 GEMM.
+// One stream synchronisation per batch (the verdict is read back).
+static int utx_f64_try_i8(const double *src, size_t l, size_t ld, bool nan_missing, double *UtX, size_t ldx,
+                          hipStream_t s, bool *done) {
+  *done = false;
+  I8Dims d;
+  int rc = i8_begin(l, &d, s);
+  if (rc) return rc;
+  if (g_ctx.scratch.reserve(16)) return fail(GEMMA_HIP_ENOMEM, "lmm_batch: scratch");
+  int one = 1;
+  HIPCHK(hipMemcpyAsync(g_ctx.scratch.p, &one, sizeof one, hipMemcpyHostToDevice, s));
+  {
+    ProfScope ps(GEMMA_STAGE_INGEST, s);
+    PackF64Args a;
+    a.src = src; a.ld = (long)ld; a.l = (long)l; a.n = (int)d.n; a.nan_missing = nan_missing ? 1 : 0;
+    a.A = g_ctx.i8_A.as<int8_t>(); a.ldk = (long)d.ldk; a.mean = g_ctx.i8_mean.as<double>();
+    a.all_hard = g_ctx.scratch.as<int>();
+    hipLaunchKernelGGL(pack_f64_kernel, dim3((unsigned)((l + 3) / 4)), dim3(256), 0, s, a);
+    HIPCHK(hipGetLastError());
+  }
+  int verdict = 0;
+  HIPCHK(hipMemcpyAsync(&verdict, g_ctx.scratch.p, sizeof verdict, hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  if (!verdict) return GEMMA_HIP_OK;
+  *done = true;
+  return i8_product(l, d, UtX, ldx, s);
 }
 
 // UtX (l x ldx, SNP-major) = mean-imputed X (l x n) * U (n x n): row s is (U^T x_s)^T, i.e. the column the
@@ -1030,32 +1034,45 @@ static int compute_utx(int kind, const void *geno, size_t l, size_t ld, int path
                        hipStream_t s) {
   const size_t n = g_ctx.cfg.n;
   const size_t ldx = (n + 1) & ~(size_t)1;
-  const bool i8 = (kind == GEMMA_GENO_PLINK_2BIT) && (path < 0 ? utx_i8_mode() == 1 : path == 1);
-  if (path == 1 && kind != GEMMA_GENO_PLINK_2BIT) return fail(GEMMA_HIP_EINVAL, "int8 U^T x path needs PLINK 2-bit input");
-  if (g_ctx.UtX.reserve(l * ldx * 8) || (!i8 && g_ctx.X.reserve(l * ldx * 8)))
+  const bool want_i8 = (path < 0 ? utx_i8_mode() == 1 : path == 1);
+  if (path == 1 && kind != GEMMA_GENO_PLINK_2BIT) return fail(GEMMA_HIP_EINVAL, "dbg_utx: path 1 needs PLINK 2-bit input");
+  const bool plink_i8 = want_i8 && kind == GEMMA_GENO_PLINK_2BIT;
+  if (g_ctx.UtX.reserve(l * ldx * 8) || (!plink_i8 && g_ctx.X.reserve(l * ldx * 8)))
     return fail(GEMMA_HIP_ENOMEM, "lmm_batch: cannot allocate 2 x %zu bytes", l * ldx * 8);
   double *UtX = g_ctx.UtX.as<double>();
   *UtX_out = UtX;
   *ldx_out = ldx;
-  if (i8) return utx_plink_i8(geno, l, ld, UtX, ldx, s);
+  if (plink_i8) return utx_plink_i8(geno, l, ld, UtX, ldx, s);
   double *X = g_ctx.X.as<double>();
-  {
-    ProfScope ps(GEMMA_STAGE_INGEST, s);
-    if (kind == GEMMA_GENO_F64_IDV_MAJOR) {
+  bool done = false;
+  if (kind == GEMMA_GENO_F64_IDV_MAJOR) {
+    { // the reference's Xlarge (individuals x SNPs, already mean-imputed) -> SNP-major
+      ProfScope ps(GEMMA_STAGE_INGEST, s);
       dim3 grid((unsigned)((l + 31) / 32), (unsigned)((n + 31) / 32));
       hipLaunchKernelGGL(transpose_kernel, grid, dim3(32, 8), 0, s, reinterpret_cast<const double *>(geno),
                          (long)n, (long)l, (long)ld, X, (long)ldx);
-    } else {
-      IngestArgs a;
-      a.src = geno; a.ld = (long)ld; a.l = (long)l;
-      a.idx_map = g_ctx.have_map ? g_ctx.idx_map.as<int>() : nullptr;
-      a.n = (int)n; a.dst = X; a.ldo = (long)ldx; a.k_mode = 0;
-      const unsigned grid = (unsigned)((l + 3) / 4);
-      if (kind == GEMMA_GENO_PLINK_2BIT)
-        hipLaunchKernelGGL(ingest_lmm_kernel<true>, dim3(grid), dim3(256), 0, s, a);
-      else
-        hipLaunchKernelGGL(ingest_lmm_kernel<false>, dim3(grid), dim3(256), 0, s, a);
+      HIPCHK(hipGetLastError());
     }
+    if (want_i8) { // hard calls with one imputed value per SNP take the exact int8-digit product as well
+      int rc = utx_f64_try_i8(X, l, ldx, false, UtX, ldx, s, &done);
+      if (rc) return rc;
+    }
+  } else if (kind == GEMMA_GENO_F64_SNP_MAJOR && want_i8) {
+    int rc = utx_f64_try_i8(reinterpret_cast<const double *>(geno), l, ld, true, UtX, ldx, s, &done);
+    if (rc) return rc;
+  }
+  if (done) return GEMMA_HIP_OK;
+  if (kind != GEMMA_GENO_F64_IDV_MAJOR) {
+    ProfScope ps(GEMMA_STAGE_INGEST, s);
+    IngestArgs a;
+    a.src = geno; a.ld = (long)ld; a.l = (long)l;
+    a.idx_map = g_ctx.have_map ? g_ctx.idx_map.as<int>() : nullptr;
+    a.n = (int)n; a.dst = X; a.ldo = (long)ldx; a.k_mode = 0;
+    const unsigned grid = (unsigned)((l + 3) / 4);
+    if (kind == GEMMA_GENO_PLINK_2BIT)
+      hipLaunchKernelGGL(ingest_lmm_kernel<true>, dim3(grid), dim3(256), 0, s, a);
+    else
+      hipLaunchKernelGGL(ingest_lmm_kernel<false>, dim3(grid), dim3(256), 0, s, a);
     HIPCHK(hipGetLastError());
   }
   {

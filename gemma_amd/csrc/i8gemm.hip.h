@@ -11,10 +11,10 @@
 // fp64 product.  The fp64 result is assembled once per element (Horner over the digits, <= 2 roundings), which is
 // closer to the exact dot product than an fp64 GEMM's 20000-term rounding chain.
 //
-// Kernel: 256 x 256 x 128-byte tiles, 512 threads = 8 wavefronts (2 x 4), wave tile 128 x 64 = 4 x 2 MFMA blocks
-// (128 int32 accumulators), operands global -> LDS by global_load_lds_dwordx4 into two 64 KiB stages; both LDS
-// images are [row][128 bytes of K] with the 16-byte chunk index XOR-ed by (row >> 1) & 7 on the source address and
-// on the ds_read_b128 fragment reads (conflict-free).  One block per CU.
+// Kernel (i8gemm_packed_kernel below): 128 SNP rows x 256 columns x 128 K-bytes per tile, 512 threads = 8 wavefronts,
+// operands global -> LDS by global_load_lds_dwordx4 into three 48 KiB stages; both LDS images are [row][128 bytes of K]
+// with the 16-byte chunk index XOR-ed by (row >> 1) & 7 on the source address and on the ds_read_b128 fragment reads
+// (conflict-free).  One block per CU.  History and ablations: profiles/r01_i8gemm_variants.txt.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <float.h>
@@ -32,126 +32,8 @@ constexpr int I8_BM = 256, I8_BN = 256, I8_BK = 128;
 constexpr int I8_DIGITS = 7;
 constexpr int I8_SCALE_BITS = 54;
 
-struct I8GemmArgs {
-  const int8_t *A;   // M x ldk, K contiguous (rows: SNPs g, then SNP masks m)
-  const int8_t *Bt;  // digit d: N x ldk, K contiguous (row j = column j of U), digits strideB bytes apart
-  int *C;            // digit d: M x ldc int32, digits strideC elements apart
-  long ldk, ldc;
-  long strideB, strideC;
-  int tiles_m, tiles_n;
-  int nk;            // K tiles of 128 bytes
-  int gm;            // raster group height (tile rows)
-};
-
-__device__ __forceinline__ void i8_tile_of_block(const I8GemmArgs &g, int &tm, int &tn) {
-  const int nwg = gridDim.x, b = blockIdx.x;
-  const int q = nwg >> 3, r = nwg & 7, x = b & 7, o = b >> 3;
-  const int L = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + o; // XCD x gets a contiguous range
-  const int GM = g.gm > 0 ? g.gm : 4;
-  const int per_group = GM * g.tiles_n;
-  const int grp = L / per_group;
-  const int first_m = grp * GM;
-  const int gsz = min(g.tiles_m - first_m, GM);
-  const int in = L - grp * per_group;
-  tm = first_m + in % gsz;
-  tn = in / gsz;
-}
-
-__global__ __launch_bounds__(512, 2) void i8gemm_kernel(I8GemmArgs g) {
-  extern __shared__ __attribute__((aligned(1024))) int8_t i8lds[]; // 2 stages x (A 32 KiB + B 32 KiB)
-  int tm, tn;
-  i8_tile_of_block(g, tm, tn);
-  const int digit = blockIdx.y;
-  const int t = threadIdx.x, lane = t & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-  const int wm = wave >> 2, wn = wave & 3; // 2 x 4 waves: rows wm*128, cols wn*64
-  const int r32 = lane & 31, h = lane >> 5;
-
-  const int8_t *Ag = g.A + (long)tm * I8_BM * g.ldk;
-  const int8_t *Bg = g.Bt + (long)digit * g.strideB + (long)tn * I8_BN * g.ldk;
-  int *Cg = g.C + (long)digit * g.strideC;
-
-  // LDS-DMA: 32 pieces of 1 KiB per operand tile (piece p = rows 8p..8p+7); wave w moves pieces 4w..4w+3 of each.
-  // lane -> row 8p + (lane >> 3), physical chunk lane & 7 holds logical chunk (lane & 7) ^ ((row >> 1) & 7)
-  const int8_t *pA[4], *pB[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int p = 4 * wave + j;
-    const int row = 8 * p + (lane >> 3);
-    const int chunk = (lane & 7) ^ ((row >> 1) & 7);
-    pA[j] = Ag + (long)row * g.ldk + 16 * chunk;
-    pB[j] = Bg + (long)row * g.ldk + 16 * chunk;
-  }
-  // fragment byte offsets inside an operand image: block i of K-step ks: row = base + 32 i + r32, logical chunk 2 ks + h
-  int fa[4], fb[4];
-#pragma unroll
-  for (int ks = 0; ks < 4; ++ks) {
-    const int sw = ((2 * ks + h) ^ ((r32 >> 1) & 7)) << 4;
-    fa[ks] = (wm * 128 + r32) * 128 + sw;
-    fb[ks] = (wn * 64 + r32) * 128 + sw;
-  }
-
-  i32x16 acc[4][2];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0;
-
-#define GEMMA_I8_DMA(STAGE)                                                                                  \
-  do {                                                                                                       \
-    _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_) {                                                       \
-      __builtin_amdgcn_global_load_lds((gemma_gptr_t)pA[j_],                                                 \
-                                       (gemma_lptr_t)(i8lds + (STAGE)*65536 + (4 * wave + j_) * 1024), 16, 0, 0); \
-      __builtin_amdgcn_global_load_lds((gemma_gptr_t)pB[j_],                                                 \
-                                       (gemma_lptr_t)(i8lds + (STAGE)*65536 + 32768 + (4 * wave + j_) * 1024), 16, 0, 0); \
-      pA[j_] += I8_BK;                                                                                       \
-      pB[j_] += I8_BK;                                                                                       \
-    }                                                                                                        \
-  } while (0)
-
-  GEMMA_I8_DMA(0);
-  __syncthreads();
-  for (int kt = 0; kt < g.nk; ++kt) {
-    const int st = kt & 1;
-    if (kt + 1 < g.nk) {
-      if (st) GEMMA_I8_DMA(0); else GEMMA_I8_DMA(1);
-    }
-    const int8_t *As = i8lds + st * 65536, *Bs = As + 32768;
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      i32x4 a[4], b[2];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const i32x4 *>(As + fa[ks] + i * 32 * 128);
-#pragma unroll
-      for (int j = 0; j < 2; ++j) b[j] = *reinterpret_cast<const i32x4 *>(Bs + fb[ks] + j * 32 * 128);
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[i], b[j], acc[i][j], 0, 0, 0);
-    }
-    __syncthreads();
-  }
-#undef GEMMA_I8_DMA
-
-  // C/D map of the 32x32 forms: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const long col = (long)tn * I8_BN + wn * 64 + j * 32 + r32;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const long row = (long)tm * I8_BM + wm * 128 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        Cg[row * g.ldc + col] = acc[i][j][r];
-      }
-    }
-}
-
 // ---------------------------------------------------------------------------------------------------------------
-// Second form: ONE packed left factor per SNP row, byte = g | (m << 4).  A wave reads an A fragment from LDS once and
+// ONE packed left factor per SNP row, byte = g | (m << 4).  A wave reads an A fragment from LDS once and
 // masks it into the genotype operand (a & 0x03) and the missing-mask operand ((a >> 4) & 0x01) -- the G and M
 // products share every global / LDS byte of both operands, so LDS traffic per MFMA drops by a third and the left
 // factor is read once.  Two digits of U are fused per output plane where 256 * C_{d+1} + C_d still fits int32
@@ -175,14 +57,8 @@ struct I8PackArgs {
   int fuse;          // 1: 4 output planes {0}, {2,1}, {4,3}, {6,5} (needs n * 2 * 128 * 257 < 2^31), 0: 7 planes
 };
 constexpr int I8P_BM = 128;
-#ifndef GEMMA_I8_STAGGER
-#define GEMMA_I8_STAGGER 0
-#endif
 constexpr int I8P_STAGE = 49152;
 
-// ABL: timing experiments only (results wrong): 1 no LDS-DMA inside the loop, 2 no barrier, 4 no operand masks,
-// 8 LDS-DMA keeps re-reading the first K-tile (cache-hot source)
-template <int ABL>
 __global__ __launch_bounds__(512, 2) void i8gemm_packed_kernel(I8PackArgs g) {
   extern __shared__ __attribute__((aligned(1024))) int8_t i8lds[];
   int tm, tn;
@@ -250,7 +126,7 @@ __global__ __launch_bounds__(512, 2) void i8gemm_packed_kernel(I8PackArgs g) {
 #define I8P_DMA(j, SOFF)                                                                                          \
   do {                                                                                                            \
     __builtin_amdgcn_global_load_lds((gemma_gptr_t)src[j], (gemma_lptr_t)(i8lds + (SOFF) + dst[j]), 16, 0, 0);    \
-    if (!(ABL & 8)) src[j] += I8_BK;                                                                              \
+    src[j] += I8_BK;                                                                                              \
   } while (0)
 // fragment read q of K-step KS from stage offset SOFF: q 0,1 = A blocks, 2,3 = B blocks
 #define I8P_READ(q, SOFF, KS, RA, RB)                                                                             \
@@ -260,13 +136,8 @@ __global__ __launch_bounds__(512, 2) void i8gemm_packed_kernel(I8PackArgs g) {
   } while (0)
 #define I8P_MASK(i, RA, RG, RM)                                                                                   \
   do {                                                                                                            \
-    if (ABL & 4) {                                                                                                \
-      RG[i] = RA[i];                                                                                              \
-      RM[i] = RA[i];                                                                                              \
-    } else {                                                                                                      \
-      RG[i] = RA[i] & mask_g;                                                                                     \
-      RM[i] = (RA[i] >> 4) & mask_m;                                                                              \
-    }                                                                                                             \
+    RG[i] = RA[i] & mask_g;                                                                                       \
+    RM[i] = (RA[i] >> 4) & mask_m;                                                                                \
   } while (0)
 // MFMA q of a K-step: block (i, j) = (q >> 2, (q >> 1) & 1), q & 1: 0 = G, 1 = M
 #define I8P_MF(q, RG, RM, RB)                                                                                     \
@@ -285,9 +156,7 @@ __global__ __launch_bounds__(512, 2) void i8gemm_packed_kernel(I8PackArgs g) {
     _Pragma("unroll") for (int q_ = 0; q_ < 8; ++q_) {                                                            \
       I8P_MF(q_, CG, CM, CB);                                                                                     \
       if (q_ < 4) I8P_READ(q_, NS, NKS, NA, NB);                                                                  \
-      if (!(ABL & 1) && q_ >= 4 && q_ < 7) {                                                                      \
-        if (DMA) I8P_DMA((D0) + q_ - 4, DS);                                                                      \
-      }                                                                                                           \
+      if ((DMA) && q_ >= 4 && q_ < 7) I8P_DMA((D0) + q_ - 4, DS);                                                 \
       if (q_ == 5) I8P_MASK(0, NA, NG, NM);                                                                       \
       if (q_ == 6) I8P_MASK(1, NA, NG, NM);                                                                       \
       GEMMA_SB();                                                                                                 \
@@ -296,19 +165,15 @@ __global__ __launch_bounds__(512, 2) void i8gemm_packed_kernel(I8PackArgs g) {
 // one K-tile from stage SC; MORE: tile t+1 exists in stage SN; LOAD2: tile t+2 exists and goes to stage SD
 #define I8P_KTILE(SC, SN, SD, MORE, LOAD2)                                                                        \
   do {                                                                                                            \
-    I8P_STEP(xg, xm, xb, SC, 1, ya, yg, ym, yb, (LOAD2) && early, 0, SD);                                         \
-    I8P_STEP(yg, ym, yb, SC, 2, xa, xg, xm, xb, (LOAD2) && early, 3, SD);                                         \
-    I8P_STEP(xg, xm, xb, SC, 3, ya, yg, ym, yb, (LOAD2) && !early, 0, SD);                                        \
+    I8P_STEP(xg, xm, xb, SC, 1, ya, yg, ym, yb, LOAD2, 0, SD);                                                    \
+    I8P_STEP(yg, ym, yb, SC, 2, xa, xg, xm, xb, LOAD2, 3, SD);                                                    \
+    I8P_STEP(xg, xm, xb, SC, 3, ya, yg, ym, yb, false, 0, SD);                                                    \
     I8P_MF(0, yg, ym, yb); GEMMA_SB();                                                                            \
     I8P_MF(1, yg, ym, yb); GEMMA_SB();                                                                            \
-    /* tile t+1 must have landed; still in flight: this tile's own pieces (6 early / 3 late so far) */            \
-    if ((LOAD2) && !(ABL & 1)) {                                                                                  \
-      if (early) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                                                 \
-      else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");                                                       \
-    } else {                                                                                                      \
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                            \
-    }                                                                                                             \
-    if (!(ABL & 2)) __builtin_amdgcn_s_barrier();                                                                 \
+    /* tile t+1 must have landed; still in flight: the 6 pieces of tile t+2 issued during this tile */            \
+    if (LOAD2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                                                   \
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                         \
+    __builtin_amdgcn_s_barrier();                                                                                 \
     GEMMA_SB();                                                                                                   \
     _Pragma("unroll") for (int q_ = 2; q_ < 8; ++q_) {                                                            \
       I8P_MF(q_, yg, ym, yb);                                                                                     \
@@ -320,14 +185,10 @@ __global__ __launch_bounds__(512, 2) void i8gemm_packed_kernel(I8PackArgs g) {
         if (q_ == 6) I8P_MASK(0, xa, xg, xm);                                                                     \
         if (q_ == 7) I8P_MASK(1, xa, xg, xm);                                                                     \
       }                                                                                                           \
-      if ((LOAD2) && !early && !(ABL & 1) && q_ >= 2 && q_ < 5) I8P_DMA(3 + q_ - 2, SD);                          \
       GEMMA_SB();                                                                                                 \
     }                                                                                                             \
   } while (0)
 
-  // the two wavefronts sharing a SIMD (w and w + 4) issue their LDS-DMA pieces in different halves of the K-tile: an
-  // LDS-DMA issue outlasts the 32-cycle MFMA shadow, so the partner's MFMAs have to cover it
-  const bool early = (GEMMA_I8_STAGGER == 0) || wave < 4;
   const int nk = g.nk;
   for (int dd = 0; dd < nd; ++dd) {
     if (dd > 0) { // second digit of a fused pair: acc = 256 * C_hi, then accumulate C_lo on top
@@ -445,44 +306,101 @@ __global__ __launch_bounds__(256) void u_digits_kernel(const double *__restrict_
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// PLINK rows -> G rows [0, l), M rows [m_row0, m_row0 + l) of the int8 left factor, and mean_s
+// PLINK rows -> packed left factor rows (byte = g | m << 4) and mean_s
 struct IngestI8Args {
   const unsigned char *src;
   long ld, l;
   const int *idx_map;
   int n;
-  int8_t *A;
+  int8_t *A;  // l x ldk, byte = g | (m << 4)
   long ldk;
-  long m_row0;
   double *mean;
-  int packed; // 1: one row per SNP, byte = g | (m << 4)
 };
 __global__ __launch_bounds__(256) void ingest_i8_kernel(IngestI8Args g) {
   const int lane = threadIdx.x & 63;
   const long s = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (s >= g.l) return;
   const unsigned char *bs = g.src + s * g.ld;
-  int8_t *gr = g.A + s * g.ldk, *mr = g.A + (g.m_row0 + s) * g.ldk;
+  int8_t *gr = g.A + s * g.ldk;
   double tot = 0.0, cnt = 0.0;
   for (int i = lane; i < g.n; i += 64) {
     const int p = g.idx_map ? g.idx_map[i] : i;
     bool miss;
     const double v = plink_value((bs[p >> 2] >> (2 * (p & 3))) & 3u, miss);
-    if (g.packed) {
-      gr[i] = miss ? (int8_t)16 : (int8_t)(int)v;
-    } else {
-      gr[i] = miss ? (int8_t)0 : (int8_t)(int)v;
-      mr[i] = miss ? (int8_t)1 : (int8_t)0;
-    }
+    gr[i] = miss ? (int8_t)16 : (int8_t)(int)v;
     if (!miss) { tot += v; cnt += 1.0; }
   }
-  for (long i = g.n + lane; i < g.ldk; i += 64) { // K padding
-    gr[i] = 0;
-    if (!g.packed) mr[i] = 0;
-  }
+  for (long i = g.n + lane; i < g.ldk; i += 64) gr[i] = 0; // K padding
   tot = wsum(tot);
   cnt = wsum(cnt);
   if (lane == 0) g.mean[s] = tot / cnt; // x_total / (ni_test - n_miss), as ingest_lmm_kernel
+}
+
+// fp64 SNP-major rows (BIMBAM / the reference's Xlarge after transposition) -> packed left factor, when the row is a
+// hard-call row: every value is 0, 1 or 2 except one repeated "other" value.  nan_missing = 1: the other value must be
+// NaN (missing; mean_s = sum / count of the calls, as ingest_lmm_kernel); nan_missing = 0: the input is already
+// mean-imputed (src/lmm.cpp:1590-1618) and the other value must be ONE finite number v (mean_s = v, bit for bit).
+// Any row that is not of that form clears *all_hard (the batch then takes the fp64 GEMM).
+struct PackF64Args {
+  const double *src; // l x ld
+  long ld, l;
+  int n;
+  int nan_missing;
+  int8_t *A;
+  long ldk;
+  double *mean;
+  int *all_hard;
+};
+__global__ __launch_bounds__(256) void pack_f64_kernel(PackF64Args g) {
+  const int lane = threadIdx.x & 63;
+  const long s = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (s >= g.l) return;
+  const double *xs = g.src + s * g.ld;
+  int8_t *gr = g.A + s * g.ldk;
+  double tot = 0.0, cnt = 0.0, vfirst = 0.0;
+  int n_nan = 0, have = 0, bad = 0;
+  for (int i = lane; i < g.n; i += 64) {
+    const double v = xs[i];
+    int8_t b;
+    if (v == 0.0 || v == 1.0 || v == 2.0) {
+      b = (int8_t)(int)v;
+      tot += v;
+      cnt += 1.0;
+    } else {
+      b = 16;
+      if (isnan(v)) {
+        ++n_nan;
+      } else if (!have) {
+        vfirst = v;
+        have = 1;
+      } else if (v != vfirst) {
+        bad = 1;
+      }
+    }
+    gr[i] = b;
+  }
+  for (long i = g.n + lane; i < g.ldk; i += 64) gr[i] = 0;
+  tot = wsum(tot);
+  cnt = wsum(cnt);
+  // one finite "other" value for the whole row: take the lowest lane that saw one
+  const unsigned long long hv = __ballot(have != 0);
+  double v0 = 0.0;
+  if (hv) {
+    const int src_lane = __ffsll((long long)hv) - 1;
+    v0 = __shfl(vfirst, src_lane, 64);
+    if (have && vfirst != v0) bad = 1;
+  }
+  const bool any_nan = __ballot(n_nan != 0) != 0;
+  bool row_bad = __ballot(bad != 0) != 0;
+  if (g.nan_missing) {
+    if (hv) row_bad = true; // a finite non-call value: dosage data
+  } else {
+    if (any_nan) row_bad = true;
+  }
+  if (lane == 0) {
+    g.mean[s] = g.nan_missing ? tot / cnt : v0;
+    if (row_bad) atomicAnd(g.all_hard, 0);
+  }
 }
 
 // UtX[s][j] = 2^(e_j - 54) * sum_d 256^d (CG_d[s][j] + mean_s * CM_d[s][j]);  planes: 7 single digits (fuse = 0) or

@@ -168,9 +168,10 @@ int gemma_hip_lmm_set_indicator(const int *indicator_idv, size_t ni_total);
 /* one block of l SNPs: mean-impute (src/lmm.cpp:1590-1618 / :1819-1827), UtX = U^T X (:1521),
  * then per SNP CalcUab, CalcRLScore, CalcLambda('R')+CalcRLWald, CalcLambda('L')+LRT (:1526-1562).
  * out[l] in SNP order. l is not limited to LMM_BATCH_SIZE.
- * U^T X: fp64 MFMA GEMM for real-valued input; for GEMMA_GENO_PLINK_2BIT (hard calls) the same product as 14 exact
- * int8 MFMA products of {genotype, missing mask} with 7 base-256 digits of U (closer to the exact dot products than
- * the fp64 GEMM; environment GEMMA_HIP_UTX_I8=0 selects the fp64 GEMM for PLINK input as well). */
+ * U^T X: fp64 MFMA GEMM for real-valued input; for hard calls (GEMMA_GENO_PLINK_2BIT, or fp64 rows holding only
+ * 0/1/2 and one missing / imputed value -- detected per batch) the same product as 14 exact int8 MFMA products of
+ * {genotype, missing mask} with 7 base-256 digits of U (closer to the exact dot products than the fp64 GEMM;
+ * environment GEMMA_HIP_UTX_I8=0 selects the fp64 GEMM always). */
 int gemma_hip_lmm_batch(int geno_kind, const void *geno, size_t l, size_t ld, gemma_sumstat *out);
 int gemma_hip_lmm_batch_d(int geno_kind, const void *geno_d, size_t l, size_t ld,
                           gemma_sumstat *out_d, void *stream);

@@ -268,6 +268,16 @@ def test_center_matrix(gpu_api, oracle, bxd):
 
 
 # --------------------------------------------------------------------------- association
+def test_lmm_bxd_golden_fp64_gemm_path(gpu_api, bxd, monkeypatch):
+    """BXD genotypes are hard calls, so the default run below takes the int8-digit product; this one forces the fp64
+    MFMA GEMM on the same data."""
+    monkeypatch.setenv("GEMMA_HIP_UTX_I8", "0")
+    null = bxd["null"]
+    lmm = gpu_api.LMM(a_mode=4, l_mle_null=null[0], logl_mle_H0=null[1])
+    got = lmm.AnalyzeBimbam(bxd["U"], bxd["eval"], bxd["UtW"], bxd["Uty"], bxd["X"].astype(np.float64))
+    _cmp_stats(got, bxd["stat_mode4"], 4, "BXD-fp64-gemm")
+
+
 @pytest.mark.parametrize("mode", [1, 2, 3, 4, 9])
 def test_lmm_bxd_golden(gpu_api, bxd, mode):
     """BXD (n=67, c=3, 7317 SNPs; ~1/3 of SNPs end at a lambda bound): every a_mode vs the oracle
@@ -474,6 +484,45 @@ def test_lmm_plink_through_int8_digit_product(gpu_api, oracle, monkeypatch, i8):
     lmm = gpu_api.LMM(a_mode=1)
     got = lmm.AnalyzePlink(U, ev, UtW, Uty, raw, ind)
     _cmp_stats(got, ref, 1, "plink-int8=%s" % i8)
+
+
+def test_hard_call_detection_picks_the_product(gpu_api, oracle, monkeypatch):
+    """fp64 input: rows holding only 0/1/2 + one missing (NaN) or imputed value take the exact int8-digit product,
+    dosages take the fp64 GEMM; both agree with the oracle and with each other (GEMMA_HIP_UTX_I8=0)."""
+    from gemma_amd import _lib as L
+    X, U, ev, UtW, Uty, _ = _synthetic(oracle, 330, 150, 2, seed=4242, miss=0.03)
+    ref = oracle.lmm_analyze(1, U, ev, UtW, Uty, X)
+
+    def run(geno, kind):
+        lmm = gpu_api.LMM(a_mode=1)
+        lmm.setup(U, ev, UtW, Uty)
+        gpu_api.profile_enable(True)
+        gpu_api.profile_read(L.STAGE_UTX_POST, reset=True)
+        out = lmm.batch(geno, kind)
+        _, n_post = gpu_api.profile_read(L.STAGE_UTX_POST)
+        gpu_api.profile_enable(False)
+        lmm.finish()
+        return out, n_post
+
+    a, na = run(X, L.GENO_F64_SNP_MAJOR)                       # hard calls with NaN
+    assert na == 1
+    _cmp_stats(a, ref, 1, "bimbam-hardcall")
+    Xi = oracle.impute_mean(X)
+    b, nb = run(np.ascontiguousarray(Xi.T), L.GENO_F64_IDV_MAJOR)  # the reference's mean-imputed Xlarge
+    assert nb == 1
+    _cmp_stats(b, ref, 1, "xlarge-hardcall")
+    Xd = X.copy()
+    Xd[3, 5] = 0.37                                            # one dosage value: the whole batch takes the fp64 GEMM
+    c, nc = run(Xd, L.GENO_F64_SNP_MAJOR)
+    assert nc == 0
+    _cmp_stats(c, oracle.lmm_analyze(1, U, ev, UtW, Uty, Xd), 1, "bimbam-dosage")
+    monkeypatch.setenv("GEMMA_HIP_UTX_I8", "0")
+    d, nd = run(X, L.GENO_F64_SNP_MAJOR)
+    assert nd == 0
+    _cmp_stats(d, ref, 1, "bimbam-hardcall-fp64")
+    for k in ("beta", "se", "p_wald"):
+        ok = ~(np.isnan(a[k]) | np.isnan(d[k]))
+        np.testing.assert_allclose(a[k][ok], d[k][ok], rtol=1e-8, err_msg=k)
 
 
 def test_lmm_reference_xlarge_layout_and_batching(gpu_api, oracle):
