@@ -32,5 +32,14 @@ torch.cuda.synchronize()
 ms, k = api.profile_read(L.STAGE_UTX_GEMM)
 mi, ki = api.profile_read(L.STAGE_INGEST)
 sw = " ".join("%s=%s" % (k_[10:], v) for k_, v in sorted(os.environ.items()) if k_.startswith("GEMMA_HIP_"))
-print("[%s] n=%d B=%d: U^T x %.2f ms/batch (ingest %.2f ms)" % (sw or "defaults", n, B, ms / reps, mi / reps))
+mp, _ = api.profile_read(L.STAGE_UTX_POST)
+api.profile_enable(False)
+# agreement of the two products on the first 128 SNPs (host round trip through the debug entry point)
+sub = raw[:128].cpu().numpy()
+a = lmm.dbg_utx(sub, L.GENO_PLINK_2BIT, 0)
+b = lmm.dbg_utx(sub, L.GENO_PLINK_2BIT, 1)
+import numpy as np
+rel = float(np.max(np.abs(a - b)) / np.max(np.abs(a)))
+print("[%s] n=%d B=%d: U^T x %.2f ms/batch + combine %.2f ms (ingest %.2f ms); fp64 vs int8-digit max diff / max |UtX| = %.1e" % (
+    sw or "defaults", n, B, ms / reps, mp / reps, mi / reps, rel))
 lmm.finish()
