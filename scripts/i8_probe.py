@@ -17,6 +17,13 @@ nb = (n + 3) // 4
 # 2-bit codes with ~1 % missing (code 1)
 codes = torch.randint(0, 100, (B, nb * 4), device="cuda", generator=g)
 codes = torch.where(codes < 1, 1, torch.where(codes < 30, 0, torch.where(codes < 70, 2, 3))).to(torch.uint8)
+mode = os.environ.get("PROBE_GENO", "")
+if mode == "zeros":      # every call homozygous 0: the genotype operand is all zero
+    codes.fill_(3)
+elif mode == "nomiss":   # no missing calls: the mask operand is all zero
+    codes = torch.where(codes == 1, 3, codes).to(torch.uint8)
+if os.environ.get("PROBE_U", "") == "pow2":  # U entries exact powers of two: 6 of the 7 digits are zero
+    U = torch.sign(U) * torch.exp2(torch.floor(torch.log2(U.abs())))
 raw = (codes[:, 0::4] | (codes[:, 1::4] << 2) | (codes[:, 2::4] << 4) | (codes[:, 3::4] << 6)).contiguous()
 lmm = api.LMM(a_mode=3)  # score test only: the per-SNP stage is one pass, the probe is about U^T x
 lmm.setup(U, ev, UtW, Uty, plink=True)
@@ -31,7 +38,7 @@ for _ in range(reps):
 torch.cuda.synchronize()
 ms, k = api.profile_read(L.STAGE_UTX_GEMM)
 mi, ki = api.profile_read(L.STAGE_INGEST)
-sw = " ".join("%s=%s" % (k_[10:], v) for k_, v in sorted(os.environ.items()) if k_.startswith("GEMMA_HIP_"))
+sw = " ".join("%s=%s" % (k_.replace("GEMMA_HIP_", ""), v) for k_, v in sorted(os.environ.items()) if k_.startswith("GEMMA_HIP_") or k_.startswith("PROBE_"))
 mp, _ = api.profile_read(L.STAGE_UTX_POST)
 api.profile_enable(False)
 # agreement of the two products on the first 128 SNPs (host round trip through the debug entry point)
