@@ -383,6 +383,24 @@ class LMM:
         return self.Analyze(U, eval_, UtW, Uty, np.ascontiguousarray(X_snpmajor_nan, dtype=np.float64),
                             L.GENO_F64_SNP_MAJOR, plink=False)
 
+    def AnalyzeGene(self, U, eval_, UtW, Utx, Y, batch=LMM_BATCH_SIZE):
+        """LMM::AnalyzeGene (src/lmm.cpp:1365-1471): Y (genes x n) holds one phenotype per row, Utx = U^T x is the
+        fixed tested variable; every row gets its own null fit (l_H0, logl_H0)."""
+        Y = np.ascontiguousarray(Y, dtype=np.float64)
+        self.setup(U, eval_, UtW, Utx)
+        try:
+            outs = []
+            for s0 in range(0, Y.shape[0], batch):
+                blk = Y[s0:s0 + batch]
+                out = np.zeros(blk.shape[0], dtype=SUMSTAT_DTYPE)
+                L.check(L.lib().gemma_hip_lmm_gene_batch(_ptr(blk), blk.shape[0], blk.shape[1], _ptr(out)),
+                        "LMM.AnalyzeGene")
+                outs.append(out)
+        finally:
+            self.finish()
+        self.sumStat = np.concatenate(outs) if outs else np.zeros(0, dtype=SUMSTAT_DTYPE)
+        return self.sumStat
+
     def AnalyzePlink(self, U, eval_, UtW, Uty, bed_rows, indicator_idv):
         """src/lmm.cpp:1710-1903: bed_rows = the .bed payload of the analysed SNPs (uint8, one row of
         ceil(ni_total/4) bytes per SNP); non-analysed individuals are dropped on device."""

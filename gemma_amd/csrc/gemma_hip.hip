@@ -1107,6 +1107,59 @@ extern "C" int gemma_hip_lmm_batch_d(int kind, const void *geno, size_t l, size_
   return launch_assoc(UtX, l, ldx, out_d, s);
 }
 
+// LMM::AnalyzeGene (src/lmm.cpp:1365-1471): rows are phenotypes (gene expression over the analysed individuals), the
+// tested variable is the fixed vector handed to lmm_setup in the Uty slot (U^T x).  Y_d: l x ld fp64, device.
+extern "C" int gemma_hip_lmm_gene_batch_d(const double *Y_d, size_t l, size_t ld, gemma_sumstat *out_d, void *stream) {
+  NEED_INIT();
+  if (!g_ctx.lmm_active) return fail(GEMMA_HIP_ESTATE, "lmm_gene_batch before lmm_setup");
+  if (l == 0) return GEMMA_HIP_OK;
+  const size_t n = g_ctx.cfg.n, c = g_ctx.cfg.n_cvt;
+  if (!Y_d || !out_d || ld < n) return fail(GEMMA_HIP_EINVAL, "lmm_gene_batch: ld=%zu < n=%zu", ld, n);
+  hipStream_t s = S(stream);
+  const size_t ldx = (n + 1) & ~(size_t)1;
+  if (g_ctx.UtX.reserve(l * ldx * 8)) return fail(GEMMA_HIP_ENOMEM, "lmm_gene_batch: %zu bytes", l * ldx * 8);
+  double *UtY = g_ctx.UtX.as<double>();
+  {
+    ProfScope ps(GEMMA_STAGE_UTX_GEMM, s); // U^T y_g for every row (:1415)
+    HIPCHK(launch_dgemm('N', 'N', (long)l, (long)n, (long)n, 1.0, Y_d, (long)ld, g_ctx.U, (long)n, 0.0, UtY, (long)ldx,
+                        false, false, s));
+  }
+  AssocArgs a = g_ctx.assoc_proto;
+  a.UtX = UtY; a.ld = (long)ldx; a.l = (long)l;
+  a.eval = g_ctx.eval; a.Uty = g_ctx.Uty; a.UtWt = g_ctx.UtWt.as<double>();
+  a.out = reinterpret_cast<SumStat *>(out_d);
+  a.grid_T = nullptr;
+  a.have_grid = 0;
+  const unsigned grid = (unsigned)((l + 3) / 4);
+  {
+    ProfScope ps(GEMMA_STAGE_ASSOC, s);
+    switch (c) {
+    case 1: hipLaunchKernelGGL(lmm_gene_kernel<1>, dim3(grid), dim3(256), 0, s, a); break;
+    case 2: hipLaunchKernelGGL(lmm_gene_kernel<2>, dim3(grid), dim3(256), 0, s, a); break;
+    case 3: hipLaunchKernelGGL(lmm_gene_kernel<3>, dim3(grid), dim3(256), 0, s, a); break;
+    case 4: hipLaunchKernelGGL(lmm_gene_kernel<4>, dim3(grid), dim3(256), 0, s, a); break;
+    default: hipLaunchKernelGGL(lmm_gene_generic_kernel, dim3(grid), dim3(256), 0, s, a, (int)c); break;
+    }
+    HIPCHK(hipGetLastError());
+  }
+  return GEMMA_HIP_OK;
+}
+
+extern "C" int gemma_hip_lmm_gene_batch(const double *Y, size_t l, size_t ld, gemma_sumstat *out) {
+  NEED_INIT();
+  if (!g_ctx.lmm_active) return fail(GEMMA_HIP_ESTATE, "lmm_gene_batch before lmm_setup");
+  if (l == 0) return GEMMA_HIP_OK;
+  const size_t n = g_ctx.cfg.n;
+  if (!Y || !out || ld < n) return fail(GEMMA_HIP_EINVAL, "lmm_gene_batch: ld=%zu < n=%zu", ld, n);
+  if (g_ctx.stage_in.reserve(l * ld * 8) || g_ctx.stage_out.reserve(l * sizeof(gemma_sumstat)))
+    return fail(GEMMA_HIP_ENOMEM, "lmm_gene_batch: staging %zu bytes", l * ld * 8);
+  HIPCHK(hipMemcpy(g_ctx.stage_in.p, Y, l * ld * 8, hipMemcpyHostToDevice));
+  int rc = gemma_hip_lmm_gene_batch_d(g_ctx.stage_in.as<double>(), l, ld, g_ctx.stage_out.as<gemma_sumstat>(), nullptr);
+  if (rc) return rc;
+  HIPCHK(hipMemcpy(out, g_ctx.stage_out.p, l * sizeof(gemma_sumstat), hipMemcpyDeviceToHost));
+  return GEMMA_HIP_OK;
+}
+
 extern "C" int gemma_hip_dbg_utx(int kind, const void *geno, size_t l, size_t ld, int path, double *UtX_host) {
   NEED_INIT();
   if (!g_ctx.lmm_active) return fail(GEMMA_HIP_ESTATE, "dbg_utx before lmm_setup");

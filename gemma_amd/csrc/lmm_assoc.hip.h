@@ -194,7 +194,7 @@ struct Row0 {
 // ORDER = 0 means H == 1 (the "Iab" call of LogRL_f, src/lmm.cpp:839-840).
 template <int C, int ORDER, bool LOGDET, int UNR = 2>
 __device__ __forceinline__ void row0_pass(const AssocArgs &g, const double *__restrict__ x,
-                                          double lambda, int lane, Row0<C> &R) {
+                                          const double *__restrict__ y, double lambda, int lane, Row0<C> &R) {
   constexpr int NI = Row0<C>::NI;
 #pragma unroll
   for (int q = 0; q < NI; ++q) R.s1[q] = R.s2[q] = R.s3[q] = 0.0;
@@ -206,7 +206,7 @@ __device__ __forceinline__ void row0_pass(const AssocArgs &g, const double *__re
 #pragma unroll
     for (int a = 0; a < C; ++a) u[a] = g.UtWt[(long)a * n + i];
     u[C] = x[i];
-    u[C + 1] = g.Uty[i];
+    u[C + 1] = y[i];
     double h1 = 1.0, h2 = 1.0, h3 = 1.0;
     if (ORDER >= 1) {
       const double v = g.eval[i] * lambda + 1.0;
@@ -359,9 +359,10 @@ struct FixedC {
     A.yy3 = P.yy3[1];
   }
   template <int ORDER, bool LOGDET>
-  __device__ __forceinline__ void eval(const AssocArgs &g, const double *x, double l, int lane, Agg &A) const {
+  __device__ __forceinline__ void eval(const AssocArgs &g, const double *x, const double *y, double l, int lane,
+                                       Agg &A) const {
     Row0<C> R;
-    row0_pass<C, ORDER, LOGDET, UNR>(g, x, l, lane, R);
+    row0_pass<C, ORDER, LOGDET, UNR>(g, x, y, l, lane, R);
     finish<ORDER>(R, A);
   }
   // The same evaluation at grid lambda gi (gi < 0: H = 1, the Iab call) from the fixed-lambda table: the row-0
@@ -427,7 +428,8 @@ struct GenericC {
   __device__ __forceinline__ int c() const { return cc; }
 
   template <int ORDER, bool LOGDET>
-  __device__ void eval(const AssocArgs &g, const double *__restrict__ x, double lambda, int lane, Agg &A) const {
+  __device__ void eval(const AssocArgs &g, const double *__restrict__ x, const double *__restrict__ y, double lambda,
+                       int lane, Agg &A) const {
     const int c = cc, nv = c + 2, n = g.n;
     constexpr int EO = (ORDER == 0) ? 1 : ORDER;
     double *s1 = L, *s2 = L + GEN_NI, *s3 = L + 2 * GEN_NI;
@@ -443,8 +445,8 @@ struct GenericC {
           va[k] = v < nv;
           vb[k] = w < nv;
           const int v0 = va[k] ? v : 0, w0 = vb[k] ? w : 0;
-          pa[k] = (v0 < c) ? g.UtWt + (long)v0 * n : (v0 == c ? x : g.Uty);
-          pb[k] = (w0 < c) ? g.UtWt + (long)w0 * n : (w0 == c ? x : g.Uty);
+          pa[k] = (v0 < c) ? g.UtWt + (long)v0 * n : (v0 == c ? x : y);
+          pb[k] = (w0 < c) ? g.UtWt + (long)w0 * n : (w0 == c ? x : y);
         }
         double a1[4][4], a2[4][4], a3[4][4];
 #pragma unroll
@@ -570,7 +572,8 @@ struct GenericC {
 template <class M>
 struct SnpCtx {
   const AssocArgs *g;
-  const double *x;
+  const double *x; // vector in the "x" slot (the tested variable): the SNP's U^T x row
+  const double *y; // vector in the "y" slot: U^T y (AnalyzeGene: the gene's row, with x = the fixed U^T x)
   int lane;
   M m;
   double logdet_iw; // sum_i log(Iab(i, ww_{i+1})), i < c+1  (H == 1; SNP constant)
@@ -609,7 +612,7 @@ __device__ __forceinline__ void deriv_from(const SnpCtx<M> &s, double l, const A
 template <class M, bool REML, int ORDER>
 __device__ __forceinline__ void deriv(const SnpCtx<M> &s, double l, double &dev1, double &dev2) {
   Agg A;
-  s.m.template eval<ORDER, false>(*s.g, s.x, l, s.lane, A);
+  s.m.template eval<ORDER, false>(*s.g, s.x, s.y, l, s.lane, A);
   deriv_from<M, REML, ORDER>(s, l, A, dev1, dev2);
 }
 // first derivative at grid lambda gi: from the fixed-lambda table when this SNP has a row in it
@@ -642,10 +645,10 @@ __device__ __forceinline__ double logf(const SnpCtx<M> &s, double l, Agg &A) {
         done = true;
       }
     }
-    if (!done) s.m.template eval<1, false>(*s.g, s.x, l, s.lane, A);
+    if (!done) s.m.template eval<1, false>(*s.g, s.x, s.y, l, s.lane, A);
     A.logdet = (l == s.g->l_min) ? s.g->logdet_lmin : s.g->logdet_lmax;
   } else {
-    s.m.template eval<1, true>(*s.g, s.x, l, s.lane, A);
+    s.m.template eval<1, true>(*s.g, s.x, s.y, l, s.lane, A);
   }
   const double n = (double)s.g->n;
   double P_yy = A.yy1;
@@ -684,7 +687,7 @@ template <class M, bool SCORE>
 __device__ __forceinline__ void wald_score(const SnpCtx<M> &s, double l, double &beta, double &se,
                                            double &pval) {
   Agg A;
-  s.m.template eval<1, false>(*s.g, s.x, l, s.lane, A);
+  s.m.template eval<1, false>(*s.g, s.x, s.y, l, s.lane, A);
   wald_score_from<M, SCORE>(s, A, beta, se, pval);
 }
 
@@ -900,7 +903,7 @@ __device__ __forceinline__ double logdet_iw_of(const SnpCtx<M> &cx) {
       done = true;
     }
   }
-  if (!done) cx.m.template eval<0, false>(*cx.g, cx.x, 0.0, cx.lane, A);
+  if (!done) cx.m.template eval<0, false>(*cx.g, cx.x, cx.y, 0.0, cx.lane, A);
   return uniform(A.slog);
 }
 
@@ -911,6 +914,7 @@ __device__ __forceinline__ void assoc_one_snp(const AssocArgs &g, const M &model
   SnpCtx<M> cx;
   cx.g = &g;
   cx.x = g.UtX + snp * g.ld;
+  cx.y = g.Uty;
   cx.lane = lane;
   cx.m = model;
   cx.logdet_iw = 0.0;
@@ -989,6 +993,87 @@ __global__ __launch_bounds__(256) void lmm_assoc_generic_kernel(AssocArgs g, int
   assoc_one_snp(g, m, snp, lane);
 }
 
+// ------------------------------------------------------------------ AnalyzeGene (src/lmm.cpp:1365-1471)
+// The roles are swapped: every row is a PHENOTYPE (a gene's expression over the analysed individuals, rotated:
+// U^T y_g), the tested variable x is one fixed vector (g.Uty holds U^T x here).  Per row, as the reference:
+//   a_mode 2/3/4/9: null ML search on (W, y_g)  -> l_H0, logl_H0   (:1424-1427; its FUNC_PARAM says calc_null = false
+//                   with the x columns of Uab zero -- the x projection step is skipped (ps_ww == 0) and the ML formulas
+//                   carry no df, so this IS the null model's ML fit; evaluated here as the c-1 covariate model + "x" = w_c)
+//   a_mode 3/4/9:   CalcRLScore at l_H0 (the row's own null lambda, :1434-1436)
+//   a_mode 1/4:     CalcLambda('R') + CalcRLWald;   a_mode 2/4/9: CalcLambda('L'), p_lrt against logl_H0
+// MN: the model type with one covariate fewer (null fit).
+template <class M, class MN>
+__device__ __forceinline__ void gene_one_row(const AssocArgs &g, const M &model, const MN &null_model, long row, int lane) {
+  const double *yrow = g.UtX + row * g.ld;
+  const int a_mode = g.a_mode;
+  double lambda_mle = 0.0, lambda_remle = 0.0, beta = 0.0, se = 0.0, p_wald = 0.0;
+  double p_lrt = 0.0, p_score = 0.0, logl_H1 = 0.0, l_H0 = 0.0, logl_H0 = 0.0;
+  if (a_mode == 2 || a_mode == 3 || a_mode == 4 || a_mode == 9) {
+    SnpCtx<MN> cn;
+    cn.g = &g;
+    cn.x = g.UtWt + (long)null_model.c() * g.n; // last covariate in the "x" slot
+    cn.y = yrow;
+    cn.lane = lane;
+    cn.m = null_model;
+    cn.logdet_iw = 0.0;
+    cn.trow = nullptr;
+    Agg tmp;
+    calc_lambda<MN, false>(cn, l_H0, logl_H0, tmp);
+  }
+  SnpCtx<M> cx;
+  cx.g = &g;
+  cx.x = g.Uty; // the fixed tested variable
+  cx.y = yrow;
+  cx.lane = lane;
+  cx.m = model;
+  cx.logdet_iw = 0.0;
+  cx.trow = nullptr;
+  if (a_mode == 3 || a_mode == 4 || a_mode == 9) wald_score<M, true>(cx, l_H0, beta, se, p_score);
+  if (a_mode == 1 || a_mode == 4) {
+    cx.logdet_iw = logdet_iw_of(cx);
+    Agg at_remle;
+    calc_lambda<M, true>(cx, lambda_remle, logl_H1, at_remle);
+    if (isnan(logl_H1)) { // CalcRLWald(NaN) (:1440)
+      beta = NAN; se = NAN; p_wald = NAN;
+    } else {
+      wald_score_from<M, false>(cx, at_remle, beta, se, p_wald);
+    }
+  }
+  if (a_mode == 2 || a_mode == 4 || a_mode == 9) {
+    Agg at_mle;
+    calc_lambda<M, false>(cx, lambda_mle, logl_H1, at_mle);
+    p_lrt = chisq_Q1_dev(2.0 * (logl_H1 - logl_H0));
+    if (isnan(logl_H1) || isnan(logl_H0)) p_lrt = NAN;
+  }
+  if (lane == 0) {
+    SumStat o;
+    o.beta = beta; o.se = se; o.lambda_remle = lambda_remle; o.lambda_mle = lambda_mle;
+    o.p_wald = p_wald; o.p_lrt = p_lrt; o.p_score = p_score; o.logl_H1 = logl_H1;
+    g.out[row] = o;
+  }
+}
+
+template <int C>
+__global__ __launch_bounds__(256, (C <= 2 ? 2 : 1)) void lmm_gene_kernel(AssocArgs g) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  if (row >= g.l) return;
+  gene_one_row(g, FixedC<C>(), FixedC<C - 1>(), row, lane);
+}
+
+__global__ __launch_bounds__(256) void lmm_gene_generic_kernel(AssocArgs g, int c) {
+  __shared__ double lds[4 * GEN_LDS_PER_WAVE];
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= g.l) return;
+  GenericC m, mn;
+  m.cc = c;
+  m.L = lds + (threadIdx.x >> 6) * GEN_LDS_PER_WAVE;
+  mn.cc = c - 1;
+  mn.L = m.L; // the two fits run one after the other
+  gene_one_row(g, m, mn, row, lane);
+}
+
 // sum_i log|l*delta_i + 1| at l_min and l_max, accumulated exactly like the LOGDET branch of the row passes
 // (lane-strided partial sums, 64-lane butterfly) so that the constants equal what a SNP's own pass would give
 __global__ __launch_bounds__(64) void logdet_ends_kernel(const double *__restrict__ eval, int n, double l_min,
@@ -1022,6 +1107,7 @@ __device__ __forceinline__ void null_model(const AssocArgs &g, const M &model, i
   SnpCtx<M> cx;
   cx.g = &g;
   cx.x = g.UtWt + (long)cp * g.n; // last covariate column
+  cx.y = g.Uty;
   cx.lane = lane;
   cx.m = model;
   cx.trow = nullptr;
@@ -1034,9 +1120,9 @@ __device__ __forceinline__ void null_model(const AssocArgs &g, const M &model, i
   deriv<M, true, 3>(cx, o.l_remle, d1, d2);
   o.dev2_remle = d2;
   Agg A;
-  cx.m.template eval<1, false>(g, cx.x, o.l_remle, lane, A);
+  cx.m.template eval<1, false>(g, cx.x, cx.y, o.l_remle, lane, A);
   o.Pyy_remle = uniform(A.yy1);
-  cx.m.template eval<1, false>(g, cx.x, o.l_mle, lane, A);
+  cx.m.template eval<1, false>(g, cx.x, cx.y, o.l_mle, lane, A);
   o.Pyy_mle = uniform(A.yy1);
   if (lane == 0) *out = o;
 }

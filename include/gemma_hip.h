@@ -175,6 +175,13 @@ int gemma_hip_lmm_set_indicator(const int *indicator_idv, size_t ni_total);
 int gemma_hip_lmm_batch(int geno_kind, const void *geno, size_t l, size_t ld, gemma_sumstat *out);
 int gemma_hip_lmm_batch_d(int geno_kind, const void *geno_d, size_t l, size_t ld,
                           gemma_sumstat *out_d, void *stream);
+/* LMM::AnalyzeGene (src/lmm.cpp:1365-1471; `-gene`): every row of Y (l x ld, row-major, ld >= cfg.n) is a PHENOTYPE
+ * (a gene's expression over the analysed individuals); the tested variable is the one fixed vector whose rotation
+ * U^T x was handed to gemma_hip_lmm_setup in the Uty slot.  Per row: U^T y_g (:1415), the row's own null ML fit
+ * (l_H0, logl_H0, :1424-1427), CalcRLScore at l_H0, CalcLambda('R')+CalcRLWald, CalcLambda('L')+LRT against logl_H0
+ * (:1434-1450).  l_mle_null / logl_mle_H0 of the cfg are not used. */
+int gemma_hip_lmm_gene_batch(const double *Y, size_t l, size_t ld, gemma_sumstat *out);
+int gemma_hip_lmm_gene_batch_d(const double *Y_d, size_t l, size_t ld, gemma_sumstat *out_d, void *stream);
 /* the second half of lmm_batch on a caller-supplied UtX (SNP-major l x ld_utx, device):
  * what remains of batch_compute after the fast_dgemm at src/lmm.cpp:1521 */
 int gemma_hip_lmm_assoc_d(const double *UtX_d, size_t l, size_t ld_utx, gemma_sumstat *out_d,

@@ -310,6 +310,24 @@ public:
     finish();
   }
 
+  // AnalyzeGene, src/lmm.cpp:1365-1471 (the file reader factored out): Y rows = one phenotype (gene) each over the
+  // ni_test analysed individuals, Utx = the rotated fixed tested variable; every row gets its own null fit
+  void AnalyzeGeneRows(const Matrix *U, const Vector *eval, const Matrix *UtW, const Vector *Utx, const double *Y,
+                       size_t n_genes, size_t ld) {
+    setup(U, eval, UtW, Utx, 0);
+    std::vector<gemma_sumstat> out(LMM_BATCH_SIZE);
+    for (size_t s0 = 0; s0 < n_genes; s0 += LMM_BATCH_SIZE) {
+      const size_t l = std::min(LMM_BATCH_SIZE, n_genes - s0);
+      enforce_hip(gemma_hip_lmm_gene_batch(Y + s0 * ld, l, ld, out.data()), "AnalyzeGene");
+      for (size_t i = 0; i < l; ++i) {
+        SUMSTAT SNPs = {out[i].beta, out[i].se, out[i].lambda_remle, out[i].lambda_mle,
+                        out[i].p_wald, out[i].p_lrt, out[i].p_score, out[i].logl_H1};
+        sumStat.push_back(SNPs);
+      }
+    }
+    finish();
+  }
+
   // WriteFiles, src/lmm.cpp:101-225
   void WriteFiles() {
     const std::string file_str = path_out + "/" + file_out + ".assoc.txt";

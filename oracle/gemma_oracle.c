@@ -902,6 +902,50 @@ void orc_lmm_batch(int a_mode, size_t n, size_t c, const double *eval, const dou
   free(Uab);
 }
 
+/* ---------------- AnalyzeGene --------------------------------------- */
+/* LMM::AnalyzeGene, src/lmm.cpp:1365-1471: every row of UtY (l x n, SNP-major style) is a rotated PHENOTYPE U^T y_g,
+ * Utx is the one fixed tested variable.  Per row: Uab from (UtW, Uty_g) with the x columns zero; param0 carries
+ * calc_null = FALSE (:1422) -- the x step of the Pab recursion is then skipped because ps_ww == 0 (:342) -- and
+ * CalcLambda('L') gives l_H0, logl_H0 (:1424-1427); then the x columns are filled (:1429) and the usual score (at
+ * l_H0) / REML+Wald / ML+LRT (against logl_H0) follow (:1432-1450).  Restated with the same FUNC_PARAM quirk.      */
+void orc_gene_batch(int a_mode, size_t n, size_t c, const double *eval, const double *UtW, const double *Utx,
+                    const double *UtY, size_t l, double l_min, double l_max, size_t n_region, orc_sumstat *out) {
+  size_t n_index = (c + 3) * (c + 2) / 2;
+  double *Uab = (double *)calloc(n * n_index, sizeof(double));
+  orc_func_param p = {0, n, c, eval, Uab};
+  param_alloc(&p, n, c);
+  for (size_t g = 0; g < l; ++g) {
+    const double *Uty = UtY + g * n;
+    double lambda_mle = 0.0, lambda_remle = 0.0, beta = 0.0, se = 0.0, p_wald = 0.0;
+    double p_lrt = 0.0, p_score = 0.0, logl_H1 = 0.0, logl_H0 = 0.0, l_H0 = 0.0;
+    memset(Uab, 0, n * n_index * sizeof(double)); /* gsl_matrix_set_zero(Uab), :1419 */
+    orc_CalcUab_null(n, c, UtW, Uty, Uab);         /* :1421 */
+    if (a_mode == 2 || a_mode == 3 || a_mode == 4 || a_mode == 9) /* :1424 */
+      orc_CalcLambda('L', &p, l_min, l_max, n_region, &l_H0, &logl_H0, 0);
+    orc_CalcUab_snp(n, c, UtW, Uty, Utx, Uab); /* :1429 */
+    if (a_mode == 3 || a_mode == 4 || a_mode == 9) wald_or_score(1, l_H0, &p, n, &beta, &se, &p_score);
+    if (a_mode == 1 || a_mode == 4) {
+      orc_CalcLambda('R', &p, l_min, l_max, n_region, &lambda_remle, &logl_H1, 0);
+      wald_or_score(0, lambda_remle, &p, n, &beta, &se, &p_wald);
+    }
+    if (a_mode == 2 || a_mode == 4 || a_mode == 9) {
+      orc_CalcLambda('L', &p, l_min, l_max, n_region, &lambda_mle, &logl_H1, 0);
+      p_lrt = orc_cdf_chisq_Q1(2.0 * (logl_H1 - logl_H0));
+      if (isnan(logl_H1) || isnan(logl_H0)) p_lrt = NAN;
+    }
+    out[g].beta = beta;
+    out[g].se = se;
+    out[g].lambda_remle = lambda_remle;
+    out[g].lambda_mle = lambda_mle;
+    out[g].p_wald = p_wald;
+    out[g].p_lrt = p_lrt;
+    out[g].p_score = p_score;
+    out[g].logl_H1 = logl_H1;
+  }
+  free(p.Hi);
+  free(Uab);
+}
+
 /* ---------------- linear model (-lm) -------------------------------- */
 /* LmCalcP, src/lm.cpp:266-287 */
 static void lm_calc_p(int test_mode, double yPwy, double xPwy, double xPwx, double df, size_t n_size,

@@ -63,6 +63,9 @@ def lib():
                                     C.c_double, C.c_double, C.c_size_t, C.c_double, C.c_double, C.c_int,
                                     dp, C.POINTER(SumStat), C.POINTER(C.c_long)]
         L.orc_lm_batch.argtypes = [C.c_int, C.c_size_t, C.c_size_t, dp, dp, dp, dp, C.c_size_t, C.POINTER(SumStat)]
+        L.orc_gene_batch.argtypes = [C.c_int, C.c_size_t, C.c_size_t, dp, dp, dp, dp, C.c_size_t, C.c_double, C.c_double,
+                                     C.c_size_t, C.POINTER(SumStat)]
+        L.orc_gene_batch.restype = None
         L.orc_impute_mean.argtypes = [dp, C.c_size_t, C.c_size_t]
         L.orc_kin_prepare.argtypes = [dp, C.c_size_t, C.c_size_t, C.c_int]
         L.orc_bed_decode.restype = C.c_size_t
@@ -181,6 +184,18 @@ def lmm_batch_UtX(a_mode, ev, UtW, Uty, UtX_snpmajor, l_mle_null=0.0, logl_mle_H
                         out.ctypes.data_as(C.POINTER(SumStat)),
                         diag.ctypes.data_as(C.POINTER(C.c_long)) if want_diag else None)
     return (out, diag) if want_diag else out
+
+
+def gene_analyze(a_mode, U, ev, UtW, Utx, Y, l_min=1e-5, l_max=1e5, n_region=10):
+    """LMM::AnalyzeGene, src/lmm.cpp:1365-1471: rows of Y (genes x n) are phenotypes, Utx the fixed tested variable."""
+    ev = _c64(ev); UtW = _c64(UtW); Utx = _c64(Utx)
+    n, c = UtW.shape
+    UtY = np.ascontiguousarray(_c64(Y) @ _c64(U))  # row g = (U^T y_g)^T, gsl_blas_dgemv(CblasTrans, U, y) at :1415
+    l = UtY.shape[0]
+    out = np.zeros(l, dtype=SUMSTAT_DTYPE)
+    lib().orc_gene_batch(a_mode, n, c, _dp(ev), _dp(UtW), _dp(Utx), _dp(UtY), l, l_min, l_max, n_region,
+                         out.ctypes.data_as(C.POINTER(SumStat)))
+    return out
 
 
 def lm_analyze(a_mode, W, y, X_snpmajor_nan):

@@ -544,6 +544,22 @@ def test_lmm_reference_xlarge_layout_and_batching(gpu_api, oracle):
     _cmp_stats(a, ref, 1, "xlarge")
 
 
+@pytest.mark.parametrize("n,c", [(260, 1), (301, 3), (288, 6)])
+def test_analyze_gene(gpu_api, oracle, n, c):
+    """LMM::AnalyzeGene (src/lmm.cpp:1365-1471): rows are phenotypes, x is fixed; per-row null fit, score at the row's
+    own l_H0, Wald, LRT against the row's logl_H0 -- every a_mode against the oracle restatement."""
+    X, U, ev, UtW, Uty, _ = _synthetic(oracle, n, 8, c, seed=3100 + n)
+    rng = np.random.default_rng(n)
+    x = oracle.impute_mean(X)[0]                     # one genotype vector as the tested variable
+    G = 140
+    Y = rng.standard_normal((G, n)) + np.outer(rng.standard_normal(G) * 0.4, x - x.mean())
+    Utx = U.T @ x
+    for mode in (1, 2, 3, 4, 9):
+        ref = oracle.gene_analyze(mode, U, ev, UtW, Utx, Y)
+        got = gpu_api.LMM(a_mode=mode).AnalyzeGene(U, ev, UtW, Utx, Y, batch=64)
+        _cmp_stats(got, ref, mode, "gene n=%d c=%d" % (n, c))
+
+
 def test_lmm_eigenvector_sign_invariance(gpu_api, oracle):
     """App. A.6: flipping eigenvector signs / SNP order is a size-independent property of the path."""
     X, U, ev, UtW, Uty, _ = _synthetic(oracle, 350, 128, 1, seed=5)

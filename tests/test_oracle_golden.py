@@ -132,3 +132,26 @@ def test_lm_against_ols(oracle):
         assert out["beta"][s] == pytest.approx(b[-1], rel=1e-11)
         assert out["se"][s] == pytest.approx(np.sqrt(cov[-1, -1]), rel=1e-11)
         assert out["p_wald"][s] == pytest.approx(2 * stats.t.sf(abs(t), df), rel=1e-10)
+
+
+def test_gene_restatement_against_the_snp_path(oracle):
+    """AnalyzeGene (src/lmm.cpp:1365-1471) only swaps roles: for every row y_g the alternative model is the one the SNP
+    path fits with phenotype y_g and the fixed x as the single SNP, and (l_H0, logl_H0) is the null ML fit of (W, y_g).
+    The restatement (with the reference's calc_null = false / zero-x-columns FUNC_PARAM) must reproduce both."""
+    rng = np.random.default_rng(12)
+    n, c, G = 120, 2, 9
+    A = rng.standard_normal((n, n))
+    K = A @ A.T / n
+    U, ev, _ = oracle.eigen_decomp_zeroed(oracle.center_matrix(K))
+    W = np.hstack([rng.standard_normal((n, c - 1)), np.ones((n, 1))])
+    x = rng.integers(0, 3, size=n).astype(float)
+    Y = rng.standard_normal((G, n)) + 0.5 * np.outer(rng.standard_normal(G), x)
+    UtW, Utx = U.T @ W, U.T @ x
+    out = oracle.gene_analyze(4, U, ev, UtW, Utx, Y)
+    UtY = np.ascontiguousarray(Y @ U)  # the same rotated rows gene_analyze works on (lambda-hat is rounding sensitive)
+    for g in range(G):
+        Uty = UtY[g].copy()
+        l0, logl0 = oracle.calc_lambda_null("L", ev, UtW, Uty)
+        ref = oracle.lmm_batch_UtX(4, ev, UtW, Uty, Utx[None, :].copy(), l_mle_null=l0, logl_mle_H0=logl0)[0]
+        for k in ("beta", "se", "lambda_remle", "lambda_mle", "p_wald", "p_lrt", "p_score", "logl_H1"):
+            assert out[k][g] == pytest.approx(ref[k], rel=1e-9), (g, k)
