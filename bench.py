@@ -252,7 +252,9 @@ def main():
             roof = {"kernel": "i8gemm_packed_kernel (14 exact int8-digit products = UtX)", "bound": "mfma",
                     "achieved": round(achieved, 1), "peak": INT8_MFMA_PEAK_TOPS, "unit": "TOP/s",
                     "frac": round(achieved / INT8_MFMA_PEAK_TOPS, 4), "traffic": None, "launches": gemm_n,
-                    "avg_launch_ms": round(gemm_avg_s * 1e3, 3)}
+                    "avg_launch_ms": round(gemm_avg_s * 1e3, 3),
+                    # the same launch priced as the fp64 product it replaces (2 n^2 flop per SNP)
+                    "equiv_fp64_tflops": round(2.0 * B * n * n / gemm_avg_s / 1e12, 1)}
         else:
             flops_per_launch = 2.0 * B * n * n  # 2 n^2 flop per SNP
             achieved = flops_per_launch / gemm_avg_s / 1e12
