@@ -1,0 +1,2 @@
+#!/bin/bash
+python __graft_entry__.py smoke 2>&1 | tail -3
