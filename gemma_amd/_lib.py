@@ -16,7 +16,8 @@ SYMBOLS = [
     "gemma_hip_lmm_null", "gemma_hip_lmm_set_indicator", "gemma_hip_lmm_batch", "gemma_hip_lmm_batch_d",
     "gemma_hip_lmm_assoc_d", "gemma_hip_lmm_finish", "gemma_hip_lm_setup", "gemma_hip_lm_batch", "gemma_hip_lm_batch_d",
     "gemma_hip_lm_finish", "gemma_hip_profile_enable",
-    "gemma_hip_profile_read", "gemma_hip_dbg_tridiag", "gemma_hip_dbg_stedc", "gemma_hip_dbg_utx", "gemma_hip_lmm_gene_batch", "gemma_hip_lmm_gene_batch_d",
+    "gemma_hip_profile_read", "gemma_hip_dbg_tridiag", "gemma_hip_dbg_stedc", "gemma_hip_dbg_utx", "gemma_hip_lmm_gene_batch", "gemma_hip_lmm_gene_batch_d", "gemma_hip_lmm_set_env",
+    "gemma_hip_lmm_gxe_batch", "gemma_hip_lmm_gxe_batch_d",
 ]
 
 OK, EINVAL, ENODEV, ENOMEM, ERUNTIME, ESTATE, ENOCONV = range(7)
@@ -95,6 +96,9 @@ def lib():
     L.gemma_hip_lmm_batch_d.argtypes = [ci, vp, sz, sz, vp, vp]
     L.gemma_hip_lmm_assoc_d.argtypes = [dp, sz, sz, vp, vp]
     L.gemma_hip_lmm_gene_batch.argtypes = [dp, sz, sz, vp]
+    L.gemma_hip_lmm_set_env.argtypes = [dp]
+    L.gemma_hip_lmm_gxe_batch.argtypes = [ci, vp, sz, sz, vp]
+    L.gemma_hip_lmm_gxe_batch_d.argtypes = [ci, vp, sz, sz, vp, vp]
     L.gemma_hip_lmm_gene_batch_d.argtypes = [dp, sz, sz, vp, vp]
     L.gemma_hip_lmm_finish.argtypes = [C.POINTER(cd), C.POINTER(cd)]
     L.gemma_hip_lm_setup.argtypes = [ci, sz, sz, dp, dp]

@@ -401,6 +401,30 @@ class LMM:
         self.sumStat = np.concatenate(outs) if outs else np.zeros(0, dtype=SUMSTAT_DTYPE)
         return self.sumStat
 
+    def AnalyzeGXE(self, U, eval_, UtW, Uty, env, geno, geno_kind=L.GENO_F64_SNP_MAJOR, indicator_idv=None,
+                   batch=LMM_BATCH_SIZE):
+        """LMM::AnalyzeBimbamGXE / AnalyzePlinkGXE (src/lmm.cpp:2283-2608): covariates [W, env, x_s], tested variable
+        x_s . env; env is over the analysed individuals."""
+        plink = geno_kind == L.GENO_PLINK_2BIT
+        self.setup(U, eval_, UtW, Uty, plink=plink)
+        try:
+            if indicator_idv is not None:
+                self.set_indicator(indicator_idv)
+            env = np.ascontiguousarray(env, dtype=np.float64)
+            L.check(L.lib().gemma_hip_lmm_set_env(_ptr(env)), "LMM.set_env")
+            geno = np.ascontiguousarray(geno)
+            outs = []
+            for s0 in range(0, geno.shape[0], batch):
+                blk = geno[s0:s0 + batch]
+                out = np.zeros(blk.shape[0], dtype=SUMSTAT_DTYPE)
+                L.check(L.lib().gemma_hip_lmm_gxe_batch(geno_kind, _ptr(blk), blk.shape[0], blk.shape[1], _ptr(out)),
+                        "LMM.AnalyzeGXE")
+                outs.append(out)
+        finally:
+            self.finish()
+        self.sumStat = np.concatenate(outs) if outs else np.zeros(0, dtype=SUMSTAT_DTYPE)
+        return self.sumStat
+
     def AnalyzePlink(self, U, eval_, UtW, Uty, bed_rows, indicator_idv):
         """src/lmm.cpp:1710-1903: bed_rows = the .bed payload of the analysed SNPs (uint8, one row of
         ceil(ni_total/4) bytes per SNP); non-analysed individuals are dropped on device."""

@@ -79,6 +79,9 @@ struct Ctx {
   bool have_map = false;
   DevBuf X, UtX, stage_in, stage_out, carry;
   DevBuf grid_R, grid_F, grid_T; // fixed-lambda table (lmm_grid.hip.h)
+  DevBuf gxe_env, gxe_UtWt, gxe_Z, gxe_UtZ, gxe_flip; // GXE variants
+  bool gxe_ready = false;
+  double gxe_lnbeta = 0.0;
   DevBuf i8_Bt, i8_ej, i8_cmax, i8_A, i8_C, i8_mean; // exact int8-digit U^T x (i8gemm.hip.h)
   bool i8_ready = false;
   size_t i8_ldk = 0, i8_npad = 0;
@@ -676,6 +679,7 @@ static int lmm_common_setup(const gemma_lmm_cfg *cfg) {
   g_ctx.have_map = false;
   g_ctx.ni_total = 0;
   g_ctx.i8_ready = false; // digits belong to the previous U
+  g_ctx.gxe_ready = false;
   return GEMMA_HIP_OK;
 }
 
@@ -1160,6 +1164,106 @@ extern "C" int gemma_hip_lmm_gene_batch(const double *Y, size_t l, size_t ld, ge
   return GEMMA_HIP_OK;
 }
 
+// ---- GXE variants: LMM::AnalyzeBimbamGXE / AnalyzePlinkGXE, src/lmm.cpp:2283-2608
+// env over the analysed individuals (after lmm_setup): U^T env becomes the (c+1)-th shared covariate row (:2307-2309)
+extern "C" int gemma_hip_lmm_set_env(const double *env) {
+  NEED_INIT();
+  if (!g_ctx.lmm_active) return fail(GEMMA_HIP_ESTATE, "lmm_set_env before lmm_setup");
+  if (!env) return fail(GEMMA_HIP_EINVAL, "lmm_set_env: null pointer");
+  const size_t n = g_ctx.cfg.n, c = g_ctx.cfg.n_cvt;
+  if (c + 2 > (size_t)GEN_CMAX)
+    return fail(GEMMA_HIP_EINVAL, "lmm_set_env: n_cvt + 2 = %zu covariates not supported (<= %d)", c + 2, GEN_CMAX);
+  if (n <= c + 3) return fail(GEMMA_HIP_EINVAL, "lmm_set_env: n <= n_cvt + 3");
+  if (g_ctx.gxe_env.reserve(n * 8) || g_ctx.gxe_UtWt.reserve((c + 1) * n * 8))
+    return fail(GEMMA_HIP_ENOMEM, "lmm_set_env: buffers");
+  HIPCHK(hipMemcpy(g_ctx.gxe_env.p, env, n * 8, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(g_ctx.gxe_UtWt.p, g_ctx.UtWt.p, c * n * 8, hipMemcpyDeviceToDevice));
+  // U^T env (gsl_blas_dgemv(CblasTrans, U, env), :2308): (n x 1) = U^T (n x n) * env (n x 1)
+  HIPCHK(launch_dgemm('T', 'N', (long)n, 1, (long)n, 1.0, g_ctx.U, (long)n, g_ctx.gxe_env.as<double>(), 1, 0.0,
+                      g_ctx.gxe_UtWt.as<double>() + c * n, 1, false, false, 0));
+  HIPCHK(hipDeviceSynchronize());
+  const double df = (double)n - (double)(c + 2) - 1.0;
+  g_ctx.gxe_lnbeta = lgamma(df / 2.0) + lgamma(0.5) - lgamma(df / 2.0 + 0.5);
+  g_ctx.gxe_ready = true;
+  return GEMMA_HIP_OK;
+}
+
+extern "C" int gemma_hip_lmm_gxe_batch_d(int kind, const void *geno, size_t l, size_t ld, gemma_sumstat *out_d,
+                                         void *stream) {
+  NEED_INIT();
+  if (!g_ctx.lmm_active || !g_ctx.gxe_ready) return fail(GEMMA_HIP_ESTATE, "lmm_gxe_batch before lmm_setup + lmm_set_env");
+  if (l == 0) return GEMMA_HIP_OK;
+  if (kind == GEMMA_GENO_F64_IDV_MAJOR) return fail(GEMMA_HIP_EINVAL, "lmm_gxe_batch: SNP-major input only");
+  int rc = check_batch_args("lmm_gxe_batch", kind, geno, l, ld, out_d);
+  if (rc) return rc;
+  hipStream_t s = S(stream);
+  const size_t n = g_ctx.cfg.n, c = g_ctx.cfg.n_cvt;
+  const size_t ldx = (n + 1) & ~(size_t)1;
+  if (g_ctx.X.reserve(l * ldx * 8) || g_ctx.UtX.reserve(l * ldx * 8) || g_ctx.gxe_Z.reserve(l * ldx * 8) ||
+      g_ctx.gxe_UtZ.reserve(l * ldx * 8) || g_ctx.gxe_flip.reserve(l * sizeof(int)))
+    return fail(GEMMA_HIP_ENOMEM, "lmm_gxe_batch: cannot allocate 4 x %zu bytes", l * ldx * 8);
+  double *X = g_ctx.X.as<double>(), *UtX = g_ctx.UtX.as<double>();
+  double *Z = g_ctx.gxe_Z.as<double>(), *UtZ = g_ctx.gxe_UtZ.as<double>();
+  {
+    ProfScope ps(GEMMA_STAGE_INGEST, s);
+    IngestGxeArgs a;
+    a.src = geno; a.ld = (long)ld; a.l = (long)l;
+    a.idx_map = g_ctx.have_map ? g_ctx.idx_map.as<int>() : nullptr;
+    a.n = (int)n; a.env = g_ctx.gxe_env.as<double>(); a.X = X; a.Z = Z; a.ldo = (long)ldx;
+    a.flip = g_ctx.gxe_flip.as<int>();
+    const unsigned grid = (unsigned)((l + 3) / 4);
+    if (kind == GEMMA_GENO_PLINK_2BIT)
+      hipLaunchKernelGGL(ingest_gxe_kernel<true>, dim3(grid), dim3(256), 0, s, a);
+    else
+      hipLaunchKernelGGL(ingest_gxe_kernel<false>, dim3(grid), dim3(256), 0, s, a);
+    HIPCHK(hipGetLastError());
+  }
+  {
+    ProfScope ps(GEMMA_STAGE_UTX_GEMM, s); // U^T x_s (:2364) and U^T (x_s . env) (:2366); z is real-valued: fp64 GEMMs
+    HIPCHK(launch_dgemm('N', 'N', (long)l, (long)n, (long)n, 1.0, X, (long)ldx, g_ctx.U, (long)n, 0.0, UtX, (long)ldx,
+                        false, false, s));
+    HIPCHK(launch_dgemm('N', 'N', (long)l, (long)n, (long)n, 1.0, Z, (long)ldx, g_ctx.U, (long)n, 0.0, UtZ, (long)ldx,
+                        false, false, s));
+  }
+  AssocArgs a = g_ctx.assoc_proto;
+  a.UtX = UtX; a.UtZ = UtZ; a.flip = g_ctx.gxe_flip.as<int>();
+  a.ld = (long)ldx; a.l = (long)l;
+  a.eval = g_ctx.eval; a.Uty = g_ctx.Uty; a.UtWt = g_ctx.gxe_UtWt.as<double>();
+  a.out = reinterpret_cast<SumStat *>(out_d);
+  a.lnbeta_half_df = g_ctx.gxe_lnbeta; // df = n - (c + 2) - 1
+  a.grid_T = nullptr;
+  a.have_grid = 0;
+  a.have_logdet_ends = g_ctx.assoc_proto.have_logdet_ends;
+  const unsigned grid = (unsigned)((l + 3) / 4);
+  {
+    ProfScope ps(GEMMA_STAGE_ASSOC, s);
+    switch (c + 2) {
+    case 3: hipLaunchKernelGGL(lmm_gxe_kernel<3>, dim3(grid), dim3(256), 0, s, a); break;
+    case 4: hipLaunchKernelGGL(lmm_gxe_kernel<4>, dim3(grid), dim3(256), 0, s, a); break;
+    default: hipLaunchKernelGGL(lmm_gxe_generic_kernel, dim3(grid), dim3(256), 0, s, a, (int)(c + 2)); break;
+    }
+    HIPCHK(hipGetLastError());
+  }
+  return GEMMA_HIP_OK;
+}
+
+extern "C" int gemma_hip_lmm_gxe_batch(int kind, const void *geno, size_t l, size_t ld, gemma_sumstat *out) {
+  NEED_INIT();
+  if (!g_ctx.lmm_active || !g_ctx.gxe_ready) return fail(GEMMA_HIP_ESTATE, "lmm_gxe_batch before lmm_setup + lmm_set_env");
+  if (l == 0) return GEMMA_HIP_OK;
+  if (kind == GEMMA_GENO_F64_IDV_MAJOR) return fail(GEMMA_HIP_EINVAL, "lmm_gxe_batch: SNP-major input only");
+  int rc = check_batch_args("lmm_gxe_batch", kind, geno, l, ld, out);
+  if (rc) return rc;
+  const size_t esz = (kind == GEMMA_GENO_PLINK_2BIT) ? 1 : 8;
+  if (g_ctx.stage_in.reserve(l * ld * esz) || g_ctx.stage_out.reserve(l * sizeof(gemma_sumstat)))
+    return fail(GEMMA_HIP_ENOMEM, "lmm_gxe_batch: staging %zu bytes", l * ld * esz);
+  HIPCHK(hipMemcpy(g_ctx.stage_in.p, geno, l * ld * esz, hipMemcpyHostToDevice));
+  rc = gemma_hip_lmm_gxe_batch_d(kind, g_ctx.stage_in.p, l, ld, g_ctx.stage_out.as<gemma_sumstat>(), nullptr);
+  if (rc) return rc;
+  HIPCHK(hipMemcpy(out, g_ctx.stage_out.p, l * sizeof(gemma_sumstat), hipMemcpyDeviceToHost));
+  return GEMMA_HIP_OK;
+}
+
 extern "C" int gemma_hip_dbg_utx(int kind, const void *geno, size_t l, size_t ld, int path, double *UtX_host) {
   NEED_INIT();
   if (!g_ctx.lmm_active) return fail(GEMMA_HIP_ESTATE, "dbg_utx before lmm_setup");
@@ -1399,6 +1503,9 @@ extern "C" int gemma_hip_lmm_finish(double *time_UtX_min, double *time_opt_min) 
   g_ctx.i8_Bt.release(); g_ctx.i8_ej.release(); g_ctx.i8_cmax.release(); g_ctx.i8_A.release(); g_ctx.i8_C.release();
   g_ctx.i8_mean.release();
   g_ctx.i8_ready = false;
+  g_ctx.gxe_env.release(); g_ctx.gxe_UtWt.release(); g_ctx.gxe_Z.release(); g_ctx.gxe_UtZ.release();
+  g_ctx.gxe_flip.release();
+  g_ctx.gxe_ready = false;
   g_ctx.U = g_ctx.eval = g_ctx.Uty = nullptr;
   g_ctx.lmm_active = false;
   return GEMMA_HIP_OK;

@@ -71,6 +71,62 @@ __global__ __launch_bounds__(256) void ingest_lmm_kernel(IngestArgs g) {
   }
 }
 
+// GXE ingest (GEMMA src/lmm.cpp:2316-2361 BIMBAM, :2487-2536 PLINK): mean-impute, recode 2 - x when x_mean > 1,
+// and also write z = x . env; flip[s] records the recoding (beta changes sign, :2403 / :2584).
+struct IngestGxeArgs {
+  const void *src;
+  long ld, l;
+  const int *idx_map;
+  int n;
+  const double *env; // n
+  double *X, *Z;     // l x ldo each
+  long ldo;
+  int *flip;
+};
+template <bool PLINK>
+__global__ __launch_bounds__(256) void ingest_gxe_kernel(IngestGxeArgs g) {
+  const int lane = threadIdx.x & 63;
+  const long s = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (s >= g.l) return;
+  const int n = g.n;
+  double tot = 0.0, cnt = 0.0;
+  const double *xs = reinterpret_cast<const double *>(g.src) + s * g.ld;
+  const unsigned char *bs = reinterpret_cast<const unsigned char *>(g.src) + s * g.ld;
+  for (int i = lane; i < n; i += 64) {
+    double v;
+    bool miss;
+    if (PLINK) {
+      const int p = g.idx_map ? g.idx_map[i] : i;
+      v = plink_value((bs[p >> 2] >> (2 * (p & 3))) & 3u, miss);
+    } else {
+      v = xs[i];
+      miss = isnan(v);
+    }
+    if (!miss) { tot += v; cnt += 1.0; }
+  }
+  tot = wsum(tot);
+  cnt = wsum(cnt);
+  const double mean = tot / cnt;
+  const bool flip = mean > 1;
+  double *dx = g.X + s * g.ldo, *dz = g.Z + s * g.ldo;
+  for (int i = lane; i < n; i += 64) {
+    double v;
+    bool miss;
+    if (PLINK) {
+      const int p = g.idx_map ? g.idx_map[i] : i;
+      v = plink_value((bs[p >> 2] >> (2 * (p & 3))) & 3u, miss);
+    } else {
+      v = xs[i];
+      miss = isnan(v);
+    }
+    if (miss) v = mean;
+    if (flip) v = 2 - v;
+    dx[i] = v;
+    dz[i] = v * g.env[i];
+  }
+  if (lane == 0) g.flip[s] = flip ? 1 : 0;
+}
+
 // Kinship ingest over ALL individuals: mean over non-missing, impute, centre, optional
 // 1/sqrt(var) with var = (sum g^2 + mean^2*n_miss)/n - mean^2
 // (GEMMA src/gemma_io.cpp:1487-1538 BimbamKin, :1651-1704 PlinkKin).

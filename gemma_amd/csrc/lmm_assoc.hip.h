@@ -28,6 +28,8 @@ constexpr int ASSOC_MAX_REGION = 64;
 
 struct AssocArgs {
   const double *UtX;   // l x ld, SNP-major
+  const double *UtZ;   // GXE only: l x ld rows U^T (x_s . env)
+  const int *flip;     // GXE only: l flags, genotypes recoded 2 - x
   long ld;
   long l;
   const double *eval;  // n
@@ -192,9 +194,10 @@ struct Row0 {
 
 // One pass over the SNP's rotated genotype row.  ORDER = highest power of H needed (1..3);
 // ORDER = 0 means H == 1 (the "Iab" call of LogRL_f, src/lmm.cpp:839-840).
-template <int C, int ORDER, bool LOGDET, int UNR = 2>
+template <int C, int ORDER, bool LOGDET, int UNR = 2, bool WL = false>
 __device__ __forceinline__ void row0_pass(const AssocArgs &g, const double *__restrict__ x,
-                                          const double *__restrict__ y, double lambda, int lane, Row0<C> &R) {
+                                          const double *__restrict__ y, const double *__restrict__ wl, double lambda,
+                                          int lane, Row0<C> &R) {
   constexpr int NI = Row0<C>::NI;
 #pragma unroll
   for (int q = 0; q < NI; ++q) R.s1[q] = R.s2[q] = R.s3[q] = 0.0;
@@ -204,7 +207,7 @@ __device__ __forceinline__ void row0_pass(const AssocArgs &g, const double *__re
   for (int i = lane; i < n; i += 64) {
     double u[C + 2];
 #pragma unroll
-    for (int a = 0; a < C; ++a) u[a] = g.UtWt[(long)a * n + i];
+    for (int a = 0; a < C; ++a) u[a] = (WL && a == C - 1) ? wl[i] : g.UtWt[(long)a * n + i];
     u[C] = x[i];
     u[C + 1] = y[i];
     double h1 = 1.0, h2 = 1.0, h3 = 1.0;
@@ -330,9 +333,12 @@ struct Agg {
 };
 
 // number of covariates fixed at compile time: everything in registers (c = 1..4)
-template <int C, int UNR = 2>
+// WL: the LAST covariate is a per-SNP vector (wlast) instead of row C-1 of UtWt (the GXE variants, where the SNP
+// itself is a covariate and the tested variable is SNP x environment)
+template <int C, int UNR = 2, bool WL = false>
 struct FixedC {
-  static constexpr bool HAS_GRID = true;
+  static constexpr bool HAS_GRID = !WL;
+  const double *wlast = nullptr;
   __device__ __forceinline__ int c() const { return C; }
   template <int ORDER>
   __device__ __forceinline__ void finish(const Row0<C> &R, Agg &A) const {
@@ -362,7 +368,7 @@ struct FixedC {
   __device__ __forceinline__ void eval(const AssocArgs &g, const double *x, const double *y, double l, int lane,
                                        Agg &A) const {
     Row0<C> R;
-    row0_pass<C, ORDER, LOGDET, UNR>(g, x, y, l, lane, R);
+    row0_pass<C, ORDER, LOGDET, UNR, WL>(g, x, y, wlast, l, lane, R);
     finish<ORDER>(R, A);
   }
   // The same evaluation at grid lambda gi (gi < 0: H = 1, the Iab call) from the fixed-lambda table: the row-0
@@ -425,6 +431,7 @@ struct GenericC {
   static constexpr bool HAS_GRID = false;
   int cc;
   double *L; // this wave's LDS scratch, GEN_LDS_PER_WAVE doubles
+  const double *wlast = nullptr; // non-null: the last covariate is this per-SNP vector (GXE)
   __device__ __forceinline__ int c() const { return cc; }
 
   template <int ORDER, bool LOGDET>
@@ -445,8 +452,8 @@ struct GenericC {
           va[k] = v < nv;
           vb[k] = w < nv;
           const int v0 = va[k] ? v : 0, w0 = vb[k] ? w : 0;
-          pa[k] = (v0 < c) ? g.UtWt + (long)v0 * n : (v0 == c ? x : y);
-          pb[k] = (w0 < c) ? g.UtWt + (long)w0 * n : (w0 == c ? x : y);
+          pa[k] = (v0 < c) ? ((wlast && v0 == c - 1) ? wlast : g.UtWt + (long)v0 * n) : (v0 == c ? x : y);
+          pb[k] = (w0 < c) ? ((wlast && w0 == c - 1) ? wlast : g.UtWt + (long)w0 * n) : (w0 == c ? x : y);
         }
         double a1[4][4], a2[4][4], a3[4][4];
 #pragma unroll
@@ -1072,6 +1079,91 @@ __global__ __launch_bounds__(256) void lmm_gene_generic_kernel(AssocArgs g, int 
   mn.cc = c - 1;
   mn.L = m.L; // the two fits run one after the other
   gene_one_row(g, m, mn, row, lane);
+}
+
+// ------------------------------------------------------------------ GXE (src/lmm.cpp:2283-2608)
+// AnalyzeBimbamGXE / AnalyzePlinkGXE: the covariates of SNP s are [W, env, x_s] (c + 2 of them) and the tested variable
+// is x_s . env.  Here g.UtWt holds c + 1 shared rows (U^T W columns, then U^T env), g.UtX the rows U^T x_s (the LAST
+// covariate), g.UtZ the rows U^T (x_s . env) (the x slot), g.flip the rows whose genotypes were recoded 2 - x
+// (x_mean > 1, :2352-2354 / :2530-2532: beta changes sign, :2403 / :2584).  Per SNP, as the reference:
+//   a_mode 2/4:   CalcLambda('L') on the c + 2 covariates alone (calc_null = true, :2384-2387) -> logl_H0
+//                 (a_mode 9 does NOT compute it: logl_H0 stays 0 there, as in the reference)
+//   a_mode 3/4/9: CalcRLScore at the GLOBAL l_mle_null (:2396)
+//   a_mode 1/4:   CalcLambda('R') + CalcRLWald;  a_mode 2/4/9: CalcLambda('L'), p_lrt against logl_H0
+// M: c + 2 covariates with the per-SNP last one; MN: c + 1 shared covariates with x_s in the x slot (the null fit).
+template <class M, class MN>
+__device__ __forceinline__ void gxe_one_snp(const AssocArgs &g, M model, const MN &null_model, long snp, int lane) {
+  const double *xrow = g.UtX + snp * g.ld, *zrow = g.UtZ + snp * g.ld;
+  const int a_mode = g.a_mode;
+  double lambda_mle = 0.0, lambda_remle = 0.0, beta = 0.0, se = 0.0, p_wald = 0.0;
+  double p_lrt = 0.0, p_score = 0.0, logl_H1 = 0.0, logl_H0 = 0.0;
+  if (a_mode == 2 || a_mode == 4) {
+    SnpCtx<MN> cn;
+    cn.g = &g;
+    cn.x = xrow; // the SNP is the last covariate of the null model
+    cn.y = g.Uty;
+    cn.lane = lane;
+    cn.m = null_model;
+    cn.logdet_iw = 0.0;
+    cn.trow = nullptr;
+    Agg tmp;
+    calc_lambda<MN, false>(cn, lambda_mle, logl_H0, tmp);
+  }
+  model.wlast = xrow;
+  SnpCtx<M> cx;
+  cx.g = &g;
+  cx.x = zrow;
+  cx.y = g.Uty;
+  cx.lane = lane;
+  cx.m = model;
+  cx.logdet_iw = 0.0;
+  cx.trow = nullptr;
+  if (a_mode == 3 || a_mode == 4 || a_mode == 9) wald_score<M, true>(cx, g.l_mle_null, beta, se, p_score);
+  if (a_mode == 1 || a_mode == 4) {
+    cx.logdet_iw = logdet_iw_of(cx);
+    Agg at_remle;
+    calc_lambda<M, true>(cx, lambda_remle, logl_H1, at_remle);
+    if (isnan(logl_H1)) {
+      beta = NAN; se = NAN; p_wald = NAN;
+    } else {
+      wald_score_from<M, false>(cx, at_remle, beta, se, p_wald);
+    }
+  }
+  if (a_mode == 2 || a_mode == 4 || a_mode == 9) {
+    Agg at_mle;
+    calc_lambda<M, false>(cx, lambda_mle, logl_H1, at_mle);
+    p_lrt = chisq_Q1_dev(2.0 * (logl_H1 - logl_H0));
+    if (isnan(logl_H1) || isnan(logl_H0)) p_lrt = NAN;
+  }
+  if (g.flip[snp]) beta *= -1;
+  if (lane == 0) {
+    SumStat o;
+    o.beta = beta; o.se = se; o.lambda_remle = lambda_remle; o.lambda_mle = lambda_mle;
+    o.p_wald = p_wald; o.p_lrt = p_lrt; o.p_score = p_score; o.logl_H1 = logl_H1;
+    g.out[snp] = o;
+  }
+}
+
+// CT = c + 2 (covariates of the alternative model), register kernel for CT <= 4
+template <int CT>
+__global__ __launch_bounds__(256, (CT <= 3 ? 2 : 1)) void lmm_gxe_kernel(AssocArgs g) {
+  const int lane = threadIdx.x & 63;
+  const long snp = (long)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  if (snp >= g.l) return;
+  gxe_one_snp(g, FixedC<CT, 2, true>(), FixedC<CT - 1>(), snp, lane);
+}
+
+__global__ __launch_bounds__(256) void lmm_gxe_generic_kernel(AssocArgs g, int ct) {
+  __shared__ double lds[4 * GEN_LDS_PER_WAVE];
+  const int lane = threadIdx.x & 63;
+  const long snp = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (snp >= g.l) return;
+  GenericC m, mn;
+  m.cc = ct;
+  m.L = lds + (threadIdx.x >> 6) * GEN_LDS_PER_WAVE;
+  mn.cc = ct - 1;
+  mn.L = m.L;
+  gxe_one_snp(g, m, mn, snp, lane);
 }
 
 // sum_i log|l*delta_i + 1| at l_min and l_max, accumulated exactly like the LOGDET branch of the row passes

@@ -182,6 +182,14 @@ int gemma_hip_lmm_batch_d(int geno_kind, const void *geno_d, size_t l, size_t ld
  * (:1434-1450).  l_mle_null / logl_mle_H0 of the cfg are not used. */
 int gemma_hip_lmm_gene_batch(const double *Y, size_t l, size_t ld, gemma_sumstat *out);
 int gemma_hip_lmm_gene_batch_d(const double *Y_d, size_t l, size_t ld, gemma_sumstat *out_d, void *stream);
+/* GXE variants, LMM::AnalyzeBimbamGXE / AnalyzePlinkGXE (src/lmm.cpp:2283-2608; `-gxe`): the covariates of SNP s are
+ * [W, env, x_s] and the tested variable is x_s . env.  After lmm_setup: set_env(env over the cfg.n analysed individuals)
+ * rotates env (:2308); gxe_batch takes SNP-major blocks (GEMMA_GENO_F64_SNP_MAJOR or GEMMA_GENO_PLINK_2BIT with the
+ * lmm_set_indicator mapping), mean-imputes, recodes 2 - x when x_mean > 1 (beta changes sign, :2352-2354,:2403), and per
+ * SNP runs the c+2-covariate null ML fit (a_mode 2/4), CalcRLScore at cfg.l_mle_null, REML + Wald, ML + LRT (:2376-2400). */
+int gemma_hip_lmm_set_env(const double *env);
+int gemma_hip_lmm_gxe_batch(int geno_kind, const void *geno, size_t l, size_t ld, gemma_sumstat *out);
+int gemma_hip_lmm_gxe_batch_d(int geno_kind, const void *geno_d, size_t l, size_t ld, gemma_sumstat *out_d, void *stream);
 /* the second half of lmm_batch on a caller-supplied UtX (SNP-major l x ld_utx, device):
  * what remains of batch_compute after the fast_dgemm at src/lmm.cpp:1521 */
 int gemma_hip_lmm_assoc_d(const double *UtX_d, size_t l, size_t ld_utx, gemma_sumstat *out_d,

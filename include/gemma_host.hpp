@@ -328,6 +328,27 @@ public:
     finish();
   }
 
+  // AnalyzeBimbamGXE, src/lmm.cpp:2283-2425 (the file reader factored out): X rows = analysed SNPs over the ni_test
+  // analysed individuals (NaN = missing), env over the same individuals
+  void AnalyzeGXERows(const Matrix *U, const Vector *eval, const Matrix *UtW, const Vector *Uty, const Vector *env,
+                      const double *X, size_t n_snps, size_t ld) {
+    setup(U, eval, UtW, Uty, 0);
+    std::vector<double> e(env->size);
+    for (size_t i = 0; i < env->size; ++i) e[i] = env->data[i * env->stride];
+    enforce_hip(gemma_hip_lmm_set_env(e.data()), "AnalyzeGXE");
+    std::vector<gemma_sumstat> out(LMM_BATCH_SIZE);
+    for (size_t s0 = 0; s0 < n_snps; s0 += LMM_BATCH_SIZE) {
+      const size_t l = std::min(LMM_BATCH_SIZE, n_snps - s0);
+      enforce_hip(gemma_hip_lmm_gxe_batch(GEMMA_GENO_F64_SNP_MAJOR, X + s0 * ld, l, ld, out.data()), "AnalyzeGXE");
+      for (size_t i = 0; i < l; ++i) {
+        SUMSTAT SNPs = {out[i].beta, out[i].se, out[i].lambda_remle, out[i].lambda_mle,
+                        out[i].p_wald, out[i].p_lrt, out[i].p_score, out[i].logl_H1};
+        sumStat.push_back(SNPs);
+      }
+    }
+    finish();
+  }
+
   // WriteFiles, src/lmm.cpp:101-225
   void WriteFiles() {
     const std::string file_str = path_out + "/" + file_out + ".assoc.txt";

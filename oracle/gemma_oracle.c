@@ -946,6 +946,61 @@ void orc_gene_batch(int a_mode, size_t n, size_t c, const double *eval, const do
   free(Uab);
 }
 
+/* ---------------- GXE ----------------------------------------------- */
+/* LMM::AnalyzeBimbamGXE :2283-2425 / AnalyzePlinkGXE :2427-2608, the per-SNP part (:2362-2408 / :2540-2589) on rotated
+ * inputs: UtWe = [U^T W | U^T env] (n x (c+1) row-major), UtX rows = U^T x_s (x_s mean-imputed and recoded 2 - x when
+ * x_mean > 1), UtZ rows = U^T (x_s . env), flip[s] = recoded.  Per SNP the covariate matrix UtW_expand = [UtWe | UtX_s]
+ * has c + 2 columns; FUNC_PARAM.n_cvt = c + 2.  logl_H0 comes from CalcLambda('L') with calc_null = TRUE and is computed
+ * for a_mode 2 and 4 ONLY (:2384) -- a_mode 9 compares against logl_H0 = 0, as the reference does.                  */
+void orc_gxe_batch(int a_mode, size_t n, size_t c, const double *eval, const double *UtWe, const double *Uty,
+                   const double *UtX, const double *UtZ, const int *flip, size_t l, double l_min, double l_max,
+                   size_t n_region, double l_mle_null, orc_sumstat *out) {
+  const size_t ce = c + 2;
+  size_t n_index = (ce + 3) * (ce + 2) / 2;
+  double *Uab = (double *)calloc(n * n_index, sizeof(double));
+  double *UtW_expand = (double *)malloc(n * ce * sizeof(double));
+  for (size_t i = 0; i < n; ++i)
+    for (size_t a = 0; a < c + 1; ++a) UtW_expand[i * ce + a] = UtWe[i * (c + 1) + a];
+  orc_func_param p = {0, n, ce, eval, Uab};
+  param_alloc(&p, n, ce);
+  for (size_t s = 0; s < l; ++s) {
+    const double *Utx = UtX + s * n, *Utz = UtZ + s * n;
+    for (size_t i = 0; i < n; ++i) UtW_expand[i * ce + (c + 1)] = Utx[i]; /* :2364 */
+    double lambda_mle = 0.0, lambda_remle = 0.0, beta = 0.0, se = 0.0, p_wald = 0.0;
+    double p_lrt = 0.0, p_score = 0.0, logl_H1 = 0.0, logl_H0 = 0.0;
+    memset(Uab, 0, n * n_index * sizeof(double)); /* :2369 */
+    orc_CalcUab_null(n, ce, UtW_expand, Uty, Uab); /* :2370 */
+    if (a_mode == 2 || a_mode == 4) {              /* :2372-2375 */
+      p.calc_null = 1;
+      orc_CalcLambda('L', &p, l_min, l_max, n_region, &lambda_mle, &logl_H0, 0);
+    }
+    orc_CalcUab_snp(n, ce, UtW_expand, Uty, Utz, Uab); /* :2377 */
+    p.calc_null = 0;
+    if (a_mode == 3 || a_mode == 4 || a_mode == 9) wald_or_score(1, l_mle_null, &p, n, &beta, &se, &p_score);
+    if (a_mode == 1 || a_mode == 4) {
+      orc_CalcLambda('R', &p, l_min, l_max, n_region, &lambda_remle, &logl_H1, 0);
+      wald_or_score(0, lambda_remle, &p, n, &beta, &se, &p_wald);
+    }
+    if (a_mode == 2 || a_mode == 4 || a_mode == 9) {
+      orc_CalcLambda('L', &p, l_min, l_max, n_region, &lambda_mle, &logl_H1, 0);
+      p_lrt = orc_cdf_chisq_Q1(2.0 * (logl_H1 - logl_H0));
+      if (isnan(logl_H1) || isnan(logl_H0)) p_lrt = NAN;
+    }
+    if (flip[s]) beta *= -1; /* :2403 */
+    out[s].beta = beta;
+    out[s].se = se;
+    out[s].lambda_remle = lambda_remle;
+    out[s].lambda_mle = lambda_mle;
+    out[s].p_wald = p_wald;
+    out[s].p_lrt = p_lrt;
+    out[s].p_score = p_score;
+    out[s].logl_H1 = logl_H1;
+  }
+  free(p.Hi);
+  free(UtW_expand);
+  free(Uab);
+}
+
 /* ---------------- linear model (-lm) -------------------------------- */
 /* LmCalcP, src/lm.cpp:266-287 */
 static void lm_calc_p(int test_mode, double yPwy, double xPwy, double xPwx, double df, size_t n_size,

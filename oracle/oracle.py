@@ -66,6 +66,9 @@ def lib():
         L.orc_gene_batch.argtypes = [C.c_int, C.c_size_t, C.c_size_t, dp, dp, dp, dp, C.c_size_t, C.c_double, C.c_double,
                                      C.c_size_t, C.POINTER(SumStat)]
         L.orc_gene_batch.restype = None
+        L.orc_gxe_batch.argtypes = [C.c_int, C.c_size_t, C.c_size_t, dp, dp, dp, dp, dp, C.POINTER(C.c_int), C.c_size_t,
+                                    C.c_double, C.c_double, C.c_size_t, C.c_double, C.POINTER(SumStat)]
+        L.orc_gxe_batch.restype = None
         L.orc_impute_mean.argtypes = [dp, C.c_size_t, C.c_size_t]
         L.orc_kin_prepare.argtypes = [dp, C.c_size_t, C.c_size_t, C.c_int]
         L.orc_bed_decode.restype = C.c_size_t
@@ -195,6 +198,27 @@ def gene_analyze(a_mode, U, ev, UtW, Utx, Y, l_min=1e-5, l_max=1e5, n_region=10)
     out = np.zeros(l, dtype=SUMSTAT_DTYPE)
     lib().orc_gene_batch(a_mode, n, c, _dp(ev), _dp(UtW), _dp(Utx), _dp(UtY), l, l_min, l_max, n_region,
                          out.ctypes.data_as(C.POINTER(SumStat)))
+    return out
+
+
+def gxe_analyze(a_mode, U, ev, UtW, Uty, env, X_snpmajor_nan, l_mle_null=0.0, l_min=1e-5, l_max=1e5, n_region=10):
+    """LMM::AnalyzeBimbamGXE / AnalyzePlinkGXE, src/lmm.cpp:2283-2608: covariates [W, env, x_s], tested x_s . env.
+    Feeder part here (:2316-2366): mean imputation, recode 2 - x when x_mean > 1, the two rotations."""
+    U = _c64(U); ev = _c64(ev); UtW = _c64(UtW); Uty = _c64(Uty); env = _c64(env)
+    n, c = UtW.shape
+    X = impute_mean(X_snpmajor_nan)
+    with np.errstate(invalid="ignore"):
+        xm = np.nanmean(_c64(X_snpmajor_nan), axis=1)
+    flip = np.ascontiguousarray((xm > 1).astype(np.int32))
+    X = np.where(flip[:, None] == 1, 2.0 - X, X)
+    UtX = np.ascontiguousarray(X @ U)
+    UtZ = np.ascontiguousarray((X * env[None, :]) @ U)
+    UtWe = np.ascontiguousarray(np.hstack([UtW, (U.T @ env)[:, None]]))
+    l = X.shape[0]
+    out = np.zeros(l, dtype=SUMSTAT_DTYPE)
+    lib().orc_gxe_batch(a_mode, n, c, _dp(ev), _dp(UtWe), _dp(Uty), _dp(UtX), _dp(UtZ),
+                        flip.ctypes.data_as(C.POINTER(C.c_int)), l, l_min, l_max, n_region, l_mle_null,
+                        out.ctypes.data_as(C.POINTER(SumStat)))
     return out
 
 

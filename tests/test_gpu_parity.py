@@ -560,6 +560,42 @@ def test_analyze_gene(gpu_api, oracle, n, c):
         _cmp_stats(got, ref, mode, "gene n=%d c=%d" % (n, c))
 
 
+@pytest.mark.parametrize("n,c", [(280, 1), (300, 2), (310, 4)])
+def test_analyze_gxe(gpu_api, oracle, n, c):
+    """GXE variants (src/lmm.cpp:2283-2608): covariates [W, env, x_s], tested x_s . env, recoding 2 - x when the SNP mean
+    exceeds 1 (beta changes sign), per-SNP null fit for a_mode 2/4 (logl_H0 stays 0 for a_mode 9, as the reference) --
+    c + 2 = 3, 4 run the register kernel, 6 the multi-pass one; BIMBAM-style fp64 input."""
+    X, U, ev, UtW, Uty, _ = _synthetic(oracle, n, 120, c, seed=5100 + n)
+    rng = np.random.default_rng(n)
+    X[::3] = np.where(np.isnan(X[::3]), np.nan, 2.0 - X[::3])  # make a third of the SNPs "mean > 1"
+    env = rng.standard_normal(n)
+    l_mle, logl0 = oracle.calc_lambda_null("L", ev, UtW, Uty)
+    for mode in (1, 2, 3, 4, 9):
+        ref = oracle.gxe_analyze(mode, U, ev, UtW, Uty, env, X, l_mle_null=l_mle)
+        got = gpu_api.LMM(a_mode=mode, l_mle_null=l_mle, logl_mle_H0=logl0).AnalyzeGXE(U, ev, UtW, Uty, env, X, batch=50)
+        _cmp_stats(got, ref, mode, "gxe n=%d c=%d" % (n, c))
+
+
+def test_analyze_gxe_plink(gpu_api, oracle):
+    """AnalyzePlinkGXE: 2-bit rows, dropped individuals, env over the analysed ones."""
+    from gemma_amd import _lib as L
+    rng = np.random.default_rng(61)
+    ni_total, p = 520, 90
+    ind, raw = _plink_case(oracle, rng, ni_total, p)
+    n = int(ind.sum())
+    Xn = oracle.bed_decode(raw, ni_total, ind)
+    Kg = oracle.bed_decode(raw, ni_total)[:, ind == 1]
+    U, ev, _ = oracle.eigen_decomp_zeroed(oracle.center_matrix(oracle.calc_kin(Kg, 1)))
+    y = rng.standard_normal(n)
+    env = rng.standard_normal(n)
+    UtW, Uty = U.T @ np.ones((n, 1)), U.T @ y
+    l_mle, logl0 = oracle.calc_lambda_null("L", ev, UtW, Uty)
+    ref = oracle.gxe_analyze(4, U, ev, UtW, Uty, env, Xn, l_mle_null=l_mle)
+    got = gpu_api.LMM(a_mode=4, l_mle_null=l_mle, logl_mle_H0=logl0).AnalyzeGXE(
+        U, ev, UtW, Uty, env, raw, geno_kind=L.GENO_PLINK_2BIT, indicator_idv=ind)
+    _cmp_stats(got, ref, 4, "gxe-plink")
+
+
 def test_lmm_eigenvector_sign_invariance(gpu_api, oracle):
     """App. A.6: flipping eigenvector signs / SNP order is a size-independent property of the path."""
     X, U, ev, UtW, Uty, _ = _synthetic(oracle, 350, 128, 1, seed=5)

@@ -155,3 +155,33 @@ def test_gene_restatement_against_the_snp_path(oracle):
         ref = oracle.lmm_batch_UtX(4, ev, UtW, Uty, Utx[None, :].copy(), l_mle_null=l0, logl_mle_H0=logl0)[0]
         for k in ("beta", "se", "lambda_remle", "lambda_mle", "p_wald", "p_lrt", "p_score", "logl_H1"):
             assert out[k][g] == pytest.approx(ref[k], rel=1e-9), (g, k)
+
+
+def test_gxe_restatement_against_the_snp_path(oracle):
+    """GXE (src/lmm.cpp:2283-2608) is the SNP path with per-SNP covariates [W, env, x_s] and tested variable x_s . env;
+    logl_H0 is the null ML fit of those c + 2 covariates.  The restatement must reproduce the pinned SNP path run with
+    that covariate matrix, SNP by SNP (beta with the 2 - x recoding sign)."""
+    rng = np.random.default_rng(5)
+    n, c, p = 110, 1, 7
+    A = rng.standard_normal((n, n))
+    U, ev, _ = oracle.eigen_decomp_zeroed(oracle.center_matrix(A @ A.T / n))
+    W = np.ones((n, c))
+    X = rng.integers(0, 3, size=(p, n)).astype(float)
+    X[1] = 2 - (rng.random(n) < 0.15)          # a SNP with mean > 1 (gets recoded)
+    X[2, :5] = np.nan
+    env = rng.standard_normal(n)
+    y = rng.standard_normal(n) + 0.3 * env
+    UtW, Uty = U.T @ W, U.T @ y
+    l0, _ = oracle.calc_lambda_null("L", ev, UtW, Uty)
+    out = oracle.gxe_analyze(4, U, ev, UtW, Uty, env, X, l_mle_null=l0)
+    Xi = oracle.impute_mean(X)
+    for s in range(p):
+        flip = np.nanmean(X[s]) > 1
+        x = 2 - Xi[s] if flip else Xi[s]
+        Xrot = np.ascontiguousarray(np.vstack([x, x * env]) @ U)  # rows: U^T x_s, U^T (x_s . env)
+        UtWe = np.ascontiguousarray(np.hstack([UtW, (U.T @ env)[:, None], Xrot[0][:, None]]))
+        lH0, loglH0 = oracle.calc_lambda_null("L", ev, UtWe, Uty)
+        ref = oracle.lmm_batch_UtX(4, ev, UtWe, Uty, Xrot[1:2].copy(), l_mle_null=l0, logl_mle_H0=loglH0)[0]
+        for k in ("se", "p_wald", "p_lrt", "p_score", "logl_H1"):
+            assert out[k][s] == pytest.approx(ref[k], rel=1e-7), (s, k)
+        assert out["beta"][s] == pytest.approx(-ref["beta"] if flip else ref["beta"], rel=1e-7), s
