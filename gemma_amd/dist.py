@@ -48,3 +48,20 @@ def gather_sumstat(local, p_total, group=None):
         lo, hi = shard_range(p_total, r, world)
         out.append(part[: hi - lo])
     return torch.cat(out, dim=0)
+
+
+def allreduce_kinship(K_local, ns_local, group=None):
+    """SNP-sharded kinship: every rank holds K_r = X_r X_r^T / ns_r over ITS SNPs (what kin_end returns)
+    and ns_r; ONE all-reduce of the n^2 unscaled sums (plus the SNP counts) gives K = sum_r ns_r K_r / sum_r ns_r =
+    X X^T / ns on every rank -- the matrix PARAM::CalcKin (src/param.cpp:1300-1321) produces, up to summation order.
+    In place on K_local (torch tensor); returns (K, ns_total)."""
+    import torch
+    import torch.distributed as dist
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return K_local, int(ns_local)
+    K_local.mul_(float(ns_local))
+    ns = torch.tensor([float(ns_local)], dtype=torch.float64, device=K_local.device)
+    dist.all_reduce(K_local, op=dist.ReduceOp.SUM, group=group)
+    dist.all_reduce(ns, op=dist.ReduceOp.SUM, group=group)
+    K_local.div_(float(ns[0]))
+    return K_local, int(ns[0])

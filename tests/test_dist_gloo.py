@@ -74,3 +74,36 @@ def test_two_rank_sharding_equals_single_rank(tmp_path, p_total, oracle, bxd):
     ref = ref.view(np.float64).reshape(-1, 8)
     assert got.shape == ref.shape
     assert np.array_equal(got, ref, equal_nan=True)  # bit-identical per SNP, in SNP order
+
+
+def _kin_worker(rank, world, port, p_total, outdir):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    from gemma_amd import dist as gdist
+    from oracle import oracle as O
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    d = np.load(os.path.join(ROOT, "tests", "golden", "bxd.npz"))
+    X = d["X"].astype(np.float64)[:p_total]
+    lo, hi = gdist.shard_range(p_total, rank, world)
+    K_r = torch.from_numpy(O.calc_kin(X[lo:hi], 1))  # stand-in for kin_begin / kin_add / kin_end on this rank's SNPs
+    K, ns = gdist.allreduce_kinship(K_r, hi - lo)
+    assert ns == p_total
+    np.save(os.path.join(outdir, "K_rank%d.npy" % rank), K.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_kinship_allreduce(tmp_path, oracle, bxd):
+    """SNP-sharded kinship: partial X_r X_r^T on each rank, ONE all-reduce, every rank ends with X X^T / ns."""
+    import torch.multiprocessing as mp
+    p_total = 1001  # uneven shards: 501 + 500
+    port = _free_port()
+    mp.spawn(_kin_worker, args=(2, port, p_total, str(tmp_path)), nprocs=2, join=True)
+    ref = oracle.calc_kin(bxd["X"].astype(np.float64)[:p_total], 1)
+    K0, K1 = np.load(tmp_path / "K_rank0.npy"), np.load(tmp_path / "K_rank1.npy")
+    assert np.array_equal(K0, K1)
+    np.testing.assert_allclose(K0, ref, rtol=1e-12, atol=1e-14)
