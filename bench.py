@@ -291,6 +291,7 @@ def main():
             try:
                 pj = json.load(open(pmc))
                 if pj.get("n") == n and pj.get("batch") == B:
+                    line["roofline_assoc"]["traffic"] = pj.get("assoc_hbm_bytes_per_launch")
                     line["roofline"]["traffic"] = pj.get("i8gemm_hbm_bytes_per_launch" if i8_path
                                                          else "utx_gemm_hbm_bytes_per_launch")
                     if fp64_path:
