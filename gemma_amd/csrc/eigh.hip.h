@@ -221,6 +221,127 @@ __global__ __launch_bounds__(256) void td_symv_kernel(const double *__restrict__
   }
 }
 
+// Symmetric form of p = A[j+1:, j+1:] u: only the LOWER triangle is read (half the HBM traffic of the row-per-wave
+// form above, which is what bounds the tridiagonalisation).  A block owns a strip of 64 rows (blockIdx.y) and one segment
+// of 1024 columns (blockIdx.x) of the lower triangle, in sub-tiles of 64 x 64: thread (rg = t >> 5, cl = t & 31) loads
+// A[64 I + 8 rg + k][c0 + 2 cl .. + 1], k = 0..7, as 16-byte pieces and feeds BOTH products of the element:
+//   row part  rowacc[k]  += A[r][c] u[c]          (c <= r)   -> rowP[seg][r]   after a 32-lane butterfly at the end
+//   col part  colacc[..] += A[r][c] u[r]          (c <  r)   -> colP[I][c]     after an 8-way LDS sum per sub-tile
+// td_symv_reduce_kernel then forms p[r] = sum_seg rowP[seg][r] + sum_{I' >= strip(r)} colP[I'][r] in a fixed order (no
+// atomics: the result does not depend on scheduling).  Needs n even (16-byte row alignment).
+constexpr int TS_STRIP = 64, TS_SEG = 1024, TS_WIDE = 256;
+__global__ __launch_bounds__(256) void td_symv_sym_kernel(const double *__restrict__ A, long n, long j,
+                                                          const double *__restrict__ xcol,
+                                                          const double *__restrict__ ssbuf, int nparts,
+                                                          double *__restrict__ rowP, double *__restrict__ colP) {
+  __shared__ double sh;
+  __shared__ double cbuf[2][8][TS_WIDE];
+  const long j1 = j + 1;
+  const long I = (long)blockIdx.y + j1 / TS_STRIP;      // strip index (absolute)
+  const long seg = (long)blockIdx.x + j1 / TS_SEG;      // column segment (absolute)
+  const long r0 = I * TS_STRIP;
+  if (r0 >= n) return;
+  const long cend_strip = std::min<long>(r0 + TS_STRIP, n); // columns <= last row of the strip
+  const long cseg0 = seg * TS_SEG;
+  if (cseg0 >= cend_strip) return;
+  const double xnorm2 = td_sum_parts(ssbuf, nparts, &sh);
+  const TdScalars sc = td_reflector(xcol, n, j, xnorm2);
+  const double scale = sc.scale;
+  const int t = threadIdx.x, cl = t & 31, rg = t >> 5;
+  double ur[8], rowacc[8];
+  long rr[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    rr[k] = r0 + rg * 8 + k;
+    const bool ok = rr[k] >= j1 && rr[k] < n;
+    ur[k] = ok ? ((rr[k] == j1) ? 1.0 : xcol[rr[k]] * scale) : 0.0;
+    if (!ok) rr[k] = -1;
+    rowacc[k] = 0.0;
+  }
+  const long c_lo = std::max<long>(cseg0, (j1 / TS_WIDE) * TS_WIDE), c_hi = std::min<long>(cseg0 + TS_SEG, cend_strip);
+  int par = 0;
+  for (long c0 = c_lo; c0 < c_hi; c0 += TS_WIDE, par ^= 1) {
+    // 4 sub-tiles of 64 columns per pass: 32 independent 16-byte loads per thread in flight, one barrier per pass
+    f64x2 a[4][8];
+    const bool interior = (c0 + TS_WIDE <= r0) && (c0 >= j1); // strictly below the diagonal and inside the window
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const long c = c0 + 64 * q + 2 * cl;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const long r = rr[k];
+        a[q][k] = (r >= 0 && c < n && c <= r0 + 63) ? *reinterpret_cast<const f64x2 *>(A + r * n + c) : f64x2{0.0, 0.0};
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const long c = c0 + 64 * q + 2 * cl;
+      const double u0 = (c >= j1 && c < n) ? ((c == j1) ? 1.0 : xcol[c] * scale) : 0.0;
+      const double u1 = (c + 1 >= j1 && c + 1 < n) ? ((c + 1 == j1) ? 1.0 : xcol[c + 1] * scale) : 0.0;
+      double ca0 = 0.0, ca1 = 0.0;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const long r = rr[k];
+        if (interior) {
+          rowacc[k] += a[q][k].x * u0 + a[q][k].y * u1;
+          ca0 += a[q][k].x * ur[k];
+          ca1 += a[q][k].y * ur[k];
+        } else if (r >= 0) {
+          const bool in0 = c >= j1, in1 = (c + 1 >= j1) && (c + 1 < n);
+          if (in0 && c <= r) rowacc[k] += a[q][k].x * u0;
+          if (in1 && c + 1 <= r) rowacc[k] += a[q][k].y * u1;
+          if (in0 && c < r) ca0 += a[q][k].x * ur[k];
+          if (in1 && c + 1 < r) ca1 += a[q][k].y * ur[k];
+        }
+      }
+      cbuf[par][rg][64 * q + 2 * cl] = ca0;
+      cbuf[par][rg][64 * q + 2 * cl + 1] = ca1;
+    }
+    __syncthreads();
+    {
+      const long cc = c0 + t;
+      if (cc >= j1 && cc < cend_strip) {
+        double v = 0.0;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v += cbuf[par][q][t];
+        colP[I * n + cc] = v;
+      }
+    }
+  }
+  // row sums: butterfly over the 32 column lanes of each half-wave
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    double v = rowacc[k];
+#pragma unroll
+    for (int off = 16; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    if (cl == 0 && rr[k] >= 0) rowP[seg * n + rr[k]] = v;
+  }
+}
+
+// p[r] = sum_seg rowP[seg][r] + sum_{I' >= strip(r)} colP[I'][r], r in [j+1, n): 64 rows per block, four threads per
+// row take every fourth partial (independent loads), fixed-order combine
+__global__ __launch_bounds__(256) void td_symv_reduce_kernel(long n, long j, const double *__restrict__ rowP,
+                                                             const double *__restrict__ colP, double *__restrict__ p) {
+  __shared__ double part[4][64];
+  const long j1 = j + 1;
+  const int rl = threadIdx.x & 63, pt = threadIdx.x >> 6;
+  const long r = j1 + (long)blockIdx.x * 64 + rl;
+  double s0 = 0.0, s1 = 0.0;
+  if (r < n) {
+    const long nstrip = (n + TS_STRIP - 1) / TS_STRIP;
+    for (long sg = j1 / TS_SEG + pt; sg <= r / TS_SEG; sg += 4) s0 += rowP[sg * n + r];
+    long I = r / TS_STRIP + pt;
+    for (; I + 4 < nstrip; I += 8) {
+      s0 += colP[I * n + r];
+      s1 += colP[(I + 4) * n + r];
+    }
+    if (I < nstrip) s0 += colP[I * n + r];
+  }
+  part[pt][rl] = s0 + s1;
+  __syncthreads();
+  if (pt == 0 && r < n) p[r] = (part[0][rl] + part[1][rl]) + (part[2][rl] + part[3][rl]);
+}
+
 __global__ __launch_bounds__(TD_CHUNK) void td_w1_kernel(long n, long j, long j0, const double *__restrict__ VT,
                                                          const double *__restrict__ WT,
                                                          const double *__restrict__ p,
@@ -534,6 +655,7 @@ struct EigWs {
   long n = 0;
   double *VT = nullptr, *WT = nullptr, *xcol = nullptr, *p = nullptr, *ab = nullptr;
   double *ssbuf = nullptr, *dotbuf = nullptr, *wtmp = nullptr;
+  double *rowP = nullptr, *colP = nullptr; // symmetric SYMV partials (nullptr: row-per-wave SYMV)
   double *d = nullptr, *e = nullptr, *tau = nullptr;
   double *Delta = nullptr, *Wk = nullptr, *QB = nullptr;
   double *P = nullptr, *P2 = nullptr, *S = nullptr, *T = nullptr;
@@ -577,8 +699,24 @@ static inline int eig_tridiagonalize(double *A, long n, EigWs &ws, hipStream_t s
       const int nparts = (int)((n - j + TD_CHUNK - 1) / TD_CHUNK);
       hipLaunchKernelGGL(td_col_kernel, dim3(nparts), dim3(TD_CHUNK), 0, s, A, n, j, j0, ws.VT, ws.WT, ws.xcol,
                          ws.ssbuf);
-      const int nsymv = (int)((m + 3) / 4);
+      // short tails: the row-per-wave form has less overhead (GEMMA_HIP_EIGH_SYMV_MIN overrides the switch-over, tests)
+      static long sym_min = -1;
+      if (sym_min < 0) {
+        const char *e = getenv("GEMMA_HIP_EIGH_SYMV_MIN");
+        sym_min = e ? atol(e) : 12288;
+      }
+      const bool sym = ws.rowP != nullptr && m >= sym_min;
+      const int nsymv = sym ? 0 : (int)((m + 3) / 4);
       const int nrow = (int)((n + 255) / 256);
+      if (sym) {
+        const long j1 = j + 1;
+        const unsigned gx = (unsigned)((n - 1) / TS_SEG - j1 / TS_SEG + 1);
+        const unsigned gy = (unsigned)((n - 1) / TS_STRIP - j1 / TS_STRIP + 1);
+        hipLaunchKernelGGL(td_symv_sym_kernel, dim3(gx, gy), dim3(256), 0, s, A, n, j, ws.xcol, ws.ssbuf, nparts,
+                           ws.rowP, ws.colP);
+        hipLaunchKernelGGL(td_symv_reduce_kernel, dim3((unsigned)((m + 63) / 64)), dim3(256), 0, s, n, j, ws.rowP,
+                           ws.colP, ws.p);
+      }
       hipLaunchKernelGGL(td_symv_kernel, dim3(nsymv + 2 * (int)k + nrow), dim3(256), 0, s, A, n, j, j0, ws.VT, ws.WT,
                          ws.xcol, ws.ssbuf, nparts, ws.p, ws.ab, nsymv, (int)k, ws.d, ws.e, ws.tau);
       const int nparts2 = (int)((m + TD_CHUNK - 1) / TD_CHUNK);
@@ -820,6 +958,14 @@ static inline int eigh_device(double *G, long n, double *U, double *eval, hipStr
             ws.get(ws.T, (size_t)EIG_NB * EIG_NB) && ws.get(ws.zbuf, n) && ws.get(ws.dl, n) && ws.get(ws.w, n) &&
             ws.get(ws.lam, n) && ws.get(ws.zhat, n) && ws.get(ws.dphys, n) && ws.get(ws.ibuf, 2 * (size_t)n + 64) &&
             ws.get(ws.info, 1) && ws.get(ws.rot, n);
+  {
+    // symmetric (lower-triangle) SYMV partials; GEMMA_HIP_EIGH_SYMV=0 keeps the row-per-wave form
+    const char *e = getenv("GEMMA_HIP_EIGH_SYMV");
+    if (ok && (n & 1) == 0 && !(e && e[0] == '0')) {
+      const size_t nseg = (size_t)(n + TS_SEG - 1) / TS_SEG, nstrip = (size_t)(n + TS_STRIP - 1) / TS_STRIP;
+      ok = ws.get(ws.rowP, nseg * (size_t)n) && ws.get(ws.colP, nstrip * (size_t)n);
+    }
+  }
   if (!ok) {
     ws.release();
     msg = "cannot allocate the eigensolver workspace (about 3 n^2 doubles)";

@@ -1,0 +1,27 @@
+"""Times gemma_hip_eigh on a random kinship-like matrix (n = 20000 unless given); GEMMA_HIP_EIGH_TIMING=1 prints stages."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from gemma_amd import api
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 20000
+api.init(0)
+g = torch.Generator(device="cuda").manual_seed(3)
+X = torch.randn((n, n // 2), dtype=torch.float64, device="cuda", generator=g)
+A = X @ X.T / (n // 2)
+del X
+A = (A + A.T) / 2
+A0 = A.clone() if n <= 8192 else None
+U = torch.empty_like(A)
+w = torch.empty(n, dtype=torch.float64, device="cuda")
+torch.cuda.synchronize()
+t0 = time.time()
+api.EigenDecomp_Zeroed(A, U, w)
+torch.cuda.synchronize()
+dt = time.time() - t0
+msg = "eigh n=%d: %.2f s" % (n, dt)
+if A0 is not None:
+    nrm = torch.linalg.matrix_norm(A0, 2)
+    res = torch.linalg.matrix_norm(A0 @ U - U * w[None, :]) / (nrm * n * 2.2e-16)
+    orth = torch.linalg.matrix_norm(U.T @ U - torch.eye(n, dtype=torch.float64, device="cuda")) / (n * 2.2e-16)
+    msg += ", resid %.2f orth %.2f (n*eps)" % (float(res), float(orth))
+print(msg)

@@ -69,6 +69,27 @@ def test_tridiagonalisation_stage(gpu_api, n):
     assert np.max(np.abs(np.linalg.eigvalsh(T) - np.linalg.eigvalsh(A))) / nrm < 50 * n * EPS
 
 
+@pytest.mark.parametrize("n", [64, 130, 200, 1030, 2200])
+def test_symmetric_symv_path(gpu_api, n, monkeypatch):
+    """The lower-triangle SYMV (td_symv_sym_kernel: 64-row strips x 1024-column segments, fixed-order partial sums) forced
+    on from the first column (it normally takes over for trailing sizes >= 2048): strips and segments that are ragged,
+    straddle the diagonal or start inside a 64-column sub-tile; same bar as the row-per-wave form (even n only)."""
+    from gemma_amd import _lib as L
+    monkeypatch.setenv("GEMMA_HIP_EIGH_SYMV_MIN", "1")
+    A = _sym(n, 900 + n)
+    d, e, tau, VT = np.zeros(n), np.zeros(max(n - 1, 1)), np.zeros(n), np.zeros((n, n))
+    L.check(L.lib().gemma_hip_dbg_tridiag(_p(A), n, _p(d), _p(e), _p(tau), _p(VT)), "dbg_tridiag")
+    T = np.diag(d) + np.diag(e[: n - 1], 1) + np.diag(e[: n - 1], -1)
+    nrm = np.linalg.norm(A, 2)
+    assert np.max(np.abs(np.linalg.eigvalsh(T) - np.linalg.eigvalsh(A))) / nrm < 50 * n * EPS
+    if n <= 1100:
+        Q = np.eye(n)
+        for j in range(n):
+            Q = Q @ (np.eye(n) - tau[j] * np.outer(VT[j], VT[j]))
+        assert np.linalg.norm(Q.T @ Q - np.eye(n)) < 50 * n * EPS
+        assert np.linalg.norm(Q @ T @ Q.T - A) / nrm < 50 * n * EPS
+
+
 @pytest.mark.parametrize("n,kind", [(2, "random"), (3, "random"), (64, "random"), (65, "random"), (150, "random"),
                                     (300, "laplace"), (300, "neardiag"), (257, "wilkinson"), (700, "random"),
                                     (1000, "graded")])
