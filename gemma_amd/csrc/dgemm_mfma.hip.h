@@ -325,10 +325,6 @@ __global__ __launch_bounds__(256, 2) void dgemm_mfma_pipe_kernel(GemmArgs g) {
   const bool sq = g.square_a != 0;
   // timing experiments (GEMMA_HIP_GEMM_ABLATE, results wrong): 1 no global loads, 16 no LDS stores, 2 no barrier
   const bool ab_ld = (g.ablate & 1) != 0, ab_st = (g.ablate & 16) != 0, ab_bar = (g.ablate & 2) != 0;
-  if (g.ablate & 32) { // experiment: fixed issue priority by hardware wave slot parity (HW_ID.WAVE_ID)
-    const unsigned wid = __builtin_amdgcn_s_getreg((3 << 11) | 4);
-    if (wid & 1) __builtin_amdgcn_s_setprio(3);
-  }
 
 #define GEMMA_GLOAD(KT)                                                                         \
   do {                                                                                          \
@@ -683,21 +679,10 @@ static inline hipError_t launch_dgemm_grid(const GemmArgs &g, hipStream_t s) {
   else
     nblocks = g.tiles_m * g.tiles_n;
   if (nblocks <= 0) return hipSuccess;
-  if (FULL && gemm_pipe() == 2 && !g.square_a) {
-    static int xl = -1; // experiment: extra dynamic LDS to force 1 block per CU
-    if (xl < 0) {
-      const char *e = getenv("GEMMA_HIP_GEMM_XLDS");
-      xl = e ? atoi(e) : 0;
-    }
-    hipLaunchKernelGGL((dgemm_mfma_glds_kernel<A_KM, B_KN>), dim3(nblocks), dim3(256), xl, s, g);
-  } else if (FULL && gemm_pipe()) {
-    static int xlds = -1; // experiment: extra dynamic LDS to force 1 block per CU
-    if (xlds < 0) {
-      const char *e = getenv("GEMMA_HIP_GEMM_XLDS");
-      xlds = e ? atoi(e) : 0;
-    }
-    hipLaunchKernelGGL((dgemm_mfma_pipe_kernel<A_KM, B_KN>), dim3(nblocks), dim3(256), xlds, s, g);
-  }
+  if (FULL && gemm_pipe() == 2 && !g.square_a)
+    hipLaunchKernelGGL((dgemm_mfma_glds_kernel<A_KM, B_KN>), dim3(nblocks), dim3(256), 0, s, g);
+  else if (FULL && gemm_pipe())
+    hipLaunchKernelGGL((dgemm_mfma_pipe_kernel<A_KM, B_KN>), dim3(nblocks), dim3(256), 0, s, g);
   else if (gemm_waves() == 8)
     hipLaunchKernelGGL((dgemm_mfma_kernel<A_KM, B_KN, 8, FULL>), dim3(nblocks), dim3(512), 0, s, g);
   else

@@ -691,6 +691,10 @@ struct EigWs {
 // A (n x n, both triangles) -> d, e, tau, reflectors in ws.VT (row j = u_j).  A is destroyed.
 static inline int eig_tridiagonalize(double *A, long n, EigWs &ws, hipStream_t s, std::string &msg) {
   EIG_HIP(hipMemsetAsync(ws.VT, 0, (size_t)n * n * 8, s));
+  // symmetric SYMV for trailing sizes >= sym_min: below that the row-per-wave form has less overhead
+  // (GEMMA_HIP_EIGH_SYMV_MIN overrides the switch-over; read per call so that tests can force the path)
+  const char *esm = getenv("GEMMA_HIP_EIGH_SYMV_MIN");
+  const long sym_min = esm ? atol(esm) : 12288;
   for (long j0 = 0; j0 < n; j0 += EIG_NB) {
     const long kp = std::min<long>(EIG_NB, n - j0);
     for (long k = 0; k < kp; ++k) {
@@ -699,12 +703,6 @@ static inline int eig_tridiagonalize(double *A, long n, EigWs &ws, hipStream_t s
       const int nparts = (int)((n - j + TD_CHUNK - 1) / TD_CHUNK);
       hipLaunchKernelGGL(td_col_kernel, dim3(nparts), dim3(TD_CHUNK), 0, s, A, n, j, j0, ws.VT, ws.WT, ws.xcol,
                          ws.ssbuf);
-      // short tails: the row-per-wave form has less overhead (GEMMA_HIP_EIGH_SYMV_MIN overrides the switch-over, tests)
-      static long sym_min = -1;
-      if (sym_min < 0) {
-        const char *e = getenv("GEMMA_HIP_EIGH_SYMV_MIN");
-        sym_min = e ? atol(e) : 12288;
-      }
       const bool sym = ws.rowP != nullptr && m >= sym_min;
       const int nsymv = sym ? 0 : (int)((m + 3) / 4);
       const int nrow = (int)((n + 255) / 256);
