@@ -723,8 +723,25 @@ static inline hipError_t launch_dgemm_t(GemmArgs g, hipStream_t s) {
   const int Fm = (int)(g.M / GEMM_BM), Fn = (int)(g.N / GEMM_BN); // complete tiles per dimension
   const bool aligned = ((reinterpret_cast<uintptr_t>(g.A) & 15) == 0) && ((g.lda & 1) == 0) &&
                        ((reinterpret_cast<uintptr_t>(g.B) & 15) == 0) && ((g.ldb & 1) == 0);
-  const bool fast = aligned && (g.K % GEMM_BK == 0) && g.K > 0 && Fm > 0 && Fn > 0;
   hipError_t e;
+  // K tail: the first floor(K / 16) * 16 of K through the fast kernels, the remaining < 16 accumulated on top by the
+  // bounds-checked one (the eigensolver's divide & conquer merges have arbitrary K)
+  if (aligned && g.K > 4 * GEMM_BK && (g.K % GEMM_BK) != 0 && Fm > 0 && Fn > 0 && !g.square_a) {
+    const long K0 = (g.K / GEMM_BK) * GEMM_BK, K1 = g.K - K0;
+    GemmArgs g0 = g;
+    g0.K = K0;
+    if ((e = launch_dgemm_t<A_KM, B_KN>(g0, s)) != hipSuccess) return e;
+    GemmArgs g1 = g;
+    g1.K = K1;
+    g1.A = A_KM ? g.A + K0 * g.lda : g.A + K0;
+    g1.B = B_KN ? g.B + K0 * g.ldb : g.B + K0;
+    g1.beta = 1.0;
+    g1.clamp = 0;
+    g1.tiles_m = Tm; g1.tiles_n = Tn; g1.tm0 = 0; g1.tn0 = 0;
+    if (g.syrk_upper) g1.tiles_n = Tm;
+    return launch_dgemm_grid<A_KM, B_KN, false>(g1, s);
+  }
+  const bool fast = aligned && (g.K % GEMM_BK == 0) && g.K > 0 && Fm > 0 && Fn > 0;
   if (!fast) { // everything through the bounds-checked instantiation
     g.tiles_m = Tm; g.tiles_n = Tn; g.tm0 = 0; g.tn0 = 0;
     return launch_dgemm_grid<A_KM, B_KN, false>(g, s);
