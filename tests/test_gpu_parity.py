@@ -669,7 +669,19 @@ def test_lmm_state_errors(gpu_api):
     assert lmm.batch(np.zeros((0, 10)), L.GENO_F64_SNP_MAJOR).shape == (0,)  # empty block
     with pytest.raises(L.GemmaHipError):
         lmm.batch(np.zeros((4, 9)), L.GENO_F64_SNP_MAJOR)  # ld < n
+    # the widened entry points keep the same discipline
+    import ctypes as C
+    out = np.zeros(4, dtype=gpu_api.SUMSTAT_DTYPE)
+    rows = np.zeros((4, 10))
+    rc = L.lib().gemma_hip_lmm_gxe_batch(L.GENO_F64_SNP_MAJOR, rows.ctypes.data_as(C.c_void_p), 4, 10,
+                                         out.ctypes.data_as(C.c_void_p))
+    assert rc == L.ESTATE  # gxe_batch before set_env
+    rc = L.lib().gemma_hip_lmm_gene_batch(rows.ctypes.data_as(C.POINTER(C.c_double)), 4, 9, out.ctypes.data_as(C.c_void_p))
+    assert rc == L.EINVAL  # ld < n
+    assert L.lib().gemma_hip_lmm_set_env(None) == L.EINVAL
     lmm.finish()
+    rc = L.lib().gemma_hip_lmm_gene_batch(rows.ctypes.data_as(C.POINTER(C.c_double)), 4, 10, out.ctypes.data_as(C.c_void_p))
+    assert rc == L.ESTATE  # after finish
 
 
 def test_lmm_medium_size_device_path(gpu_api, oracle):
