@@ -984,7 +984,8 @@ static int i8_product(size_t l, const I8Dims &d, double *UtX, size_t ldx, hipStr
   }
   {
     ProfScope ps(GEMMA_STAGE_UTX_POST, s);
-    hipLaunchKernelGGL(i8_combine_kernel, dim3((unsigned)((d.n + 255) / 256), (unsigned)l), dim3(256), 0, s,
+    hipLaunchKernelGGL(i8_combine_kernel, dim3((unsigned)((d.n + 255) / 256), (unsigned)std::min<size_t>(l, 65535)),
+                       dim3(256), 0, s,
                        g_ctx.i8_C.as<int>(), (long)d.npad, (long)(d.mrows * d.npad), (long)d.lpad,
                        g_ctx.i8_mean.as<double>(), g_ctx.i8_ej.as<int>(), (long)l, (long)d.n, UtX, (long)ldx, 1.0, d.fuse);
     HIPCHK(hipGetLastError());

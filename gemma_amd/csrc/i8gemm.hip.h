@@ -410,8 +410,8 @@ __global__ __launch_bounds__(256) void i8_combine_kernel(const int *__restrict__
                                                          long l, long n, double *__restrict__ UtX, long ldx,
                                                          double m_scale, int fuse) {
   const long j = (long)blockIdx.x * 256 + threadIdx.x;
-  const long s = blockIdx.y;
-  if (j >= n || s >= l) return;
+  if (j >= n) return;
+  for (long s = blockIdx.y; s < l; s += gridDim.y) { // gridDim.y is capped at 65535 rows per sweep
   double tg = 0.0, tmk = 0.0;
   if (fuse) {
 #pragma unroll
@@ -428,6 +428,7 @@ __global__ __launch_bounds__(256) void i8_combine_kernel(const int *__restrict__
     }
   }
   UtX[s * ldx + j] = ldexp(fma(mean[s] * m_scale, tmk, tg), ej[j] - I8_SCALE_BITS); // m_scale: exact power of two
+  }
 }
 
 } // namespace gemma_hip

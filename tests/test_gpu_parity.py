@@ -465,6 +465,28 @@ def test_utx_int8_digit_product_matches_fp64(gpu_api, oracle, ni_total, p):
     assert err8 < 8 * 2.3e-16  # assembled from exact integer sums: a few roundings, not a 600-term chain
 
 
+def test_utx_int8_more_rows_than_a_grid_dimension(gpu_api, oracle):
+    """70 000 SNPs in one block: more rows than a HIP grid's y extent (65 535) -- the digit-combine pass sweeps."""
+    from gemma_amd import _lib as L
+    rng = np.random.default_rng(77)
+    ni_total, p = 96, 70000
+    ind = np.ones(ni_total, dtype=np.int32)
+    codes = rng.choice([0, 1, 2, 3], size=(p, ni_total), p=[0.25, 0.02, 0.43, 0.3]).astype(np.uint8)
+    raw = (codes[:, 0::4] | (codes[:, 1::4] << 2) | (codes[:, 2::4] << 4) | (codes[:, 3::4] << 6)).astype(np.uint8)
+    A = rng.standard_normal((ni_total, ni_total))
+    U, ev, _ = oracle.eigen_decomp_zeroed(oracle.center_matrix(A @ A.T / ni_total))
+    lmm = gpu_api.LMM(a_mode=1)
+    lmm.setup(U, ev, U.T @ np.ones((ni_total, 1)), U.T @ rng.standard_normal(ni_total), plink=True)
+    lmm.set_indicator(ind)
+    try:
+        a = lmm.dbg_utx(raw, L.GENO_PLINK_2BIT, 0)
+        b = lmm.dbg_utx(raw, L.GENO_PLINK_2BIT, 1)
+    finally:
+        lmm.finish()
+    assert a.shape == (p, ni_total)
+    np.testing.assert_allclose(b, a, rtol=0, atol=1e-13 * np.abs(a).max())
+
+
 @pytest.mark.parametrize("i8", ["1", "0"])
 def test_lmm_plink_through_int8_digit_product(gpu_api, oracle, monkeypatch, i8):
     """The whole PLINK association path through the int8-digit product (default) and through the fp64 GEMM
