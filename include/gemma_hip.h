@@ -171,7 +171,8 @@ int gemma_hip_lmm_set_indicator(const int *indicator_idv, size_t ni_total);
  * U^T X: fp64 MFMA GEMM for real-valued input; for hard calls (GEMMA_GENO_PLINK_2BIT, or fp64 rows holding only
  * 0/1/2 and one missing / imputed value -- detected per batch) the same product as 14 exact int8 MFMA products of
  * {genotype, missing mask} with 7 base-256 digits of U (closer to the exact dot products than the fp64 GEMM;
- * environment GEMMA_HIP_UTX_I8=0 selects the fp64 GEMM always). */
+ * environment GEMMA_HIP_UTX_I8=0 selects the fp64 GEMM always).  The _d form is asynchronous on its stream for
+ * GEMMA_GENO_PLINK_2BIT; for fp64 input it synchronises the stream once per call (the hard-call verdict is read back). */
 int gemma_hip_lmm_batch(int geno_kind, const void *geno, size_t l, size_t ld, gemma_sumstat *out);
 int gemma_hip_lmm_batch_d(int geno_kind, const void *geno_d, size_t l, size_t ld,
                           gemma_sumstat *out_d, void *stream);
