@@ -144,7 +144,8 @@ __global__ __launch_bounds__(256) void td_symv_kernel(const double *__restrict__
                                                       const double *__restrict__ xcol,
                                                       const double *__restrict__ ssbuf, int nparts,
                                                       double *__restrict__ p, double *__restrict__ ab, int nsymv,
-                                                      int k, double *d, double *e, double *tau) {
+                                                      int k, double *d, double *e, double *tau,
+                                                      double *__restrict__ Spanel) {
   __shared__ double sh;
   __shared__ double red[4];
   const double xnorm2 = td_sum_parts(ssbuf, nparts, &sh);
@@ -207,7 +208,12 @@ __global__ __launch_bounds__(256) void td_symv_kernel(const double *__restrict__
     s = eig_wsum(s);
     if (lane == 0) red[threadIdx.x >> 6] = s;
     __syncthreads();
-    if (threadIdx.x == 0) ab[idx] = (red[0] + red[1]) + (red[2] + red[3]);
+    if (threadIdx.x == 0) {
+      const double dot = (red[0] + red[1]) + (red[2] + red[3]);
+      ab[idx] = dot;
+      // u_q . u_j is entry (q, k) of the panel's Y Y^T, which the compact-WY factor of the back-transformation needs
+      if ((idx & 1) && Spanel) Spanel[q * EIG_NB + k] = dot;
+    }
   } else {
     const long r = (long)(b - nsymv - 2 * k) * 256 + threadIdx.x;
     if (r < n) {
@@ -606,8 +612,9 @@ __global__ void dc_gather_rows_kernel(const double *__restrict__ src, long n, in
 // ---------------------------------------------------------------- 3. back-transformation
 // forward compact-WY factor (LAPACK dlarft, columnwise): T(i,i) = tau_i,
 // T(0:i,i) = -tau_i T(0:i,0:i) S(0:i,i) with S = Y^T Y.  Single workgroup, T upper triangular (kp x kp).
-__global__ __launch_bounds__(256) void bt_tfactor_kernel(const double *__restrict__ S, const double *__restrict__ tau,
-                                                         int kp, double *__restrict__ T) {
+__global__ __launch_bounds__(256) void bt_tfactor_kernel(const double *__restrict__ S, int lds,
+                                                         const double *__restrict__ tau, int kp,
+                                                         double *__restrict__ T) {
   const int t = threadIdx.x;
   for (int idx = t; idx < kp * kp; idx += 256) T[idx] = 0.0;
   __syncthreads();
@@ -615,7 +622,7 @@ __global__ __launch_bounds__(256) void bt_tfactor_kernel(const double *__restric
     const double ti = tau[i];
     if (t < i) {
       double acc = 0.0;
-      for (int c = t; c < i; ++c) acc += T[t * kp + c] * S[c * kp + i];
+      for (int c = t; c < i; ++c) acc += T[t * kp + c] * S[c * lds + i];
       T[t * kp + i] = -ti * acc;
     }
     if (t == 0) T[i * kp + i] = ti;
@@ -659,6 +666,7 @@ struct EigWs {
   double *d = nullptr, *e = nullptr, *tau = nullptr;
   double *Delta = nullptr, *Wk = nullptr, *QB = nullptr;
   double *P = nullptr, *P2 = nullptr, *S = nullptr, *T = nullptr;
+  double *Sall = nullptr; // per panel: strict upper triangle of Y Y^T, collected by the tridiagonalisation (ld EIG_NB)
   double *zbuf = nullptr, *dl = nullptr, *w = nullptr, *lam = nullptr, *zhat = nullptr, *dphys = nullptr;
   int *ibuf = nullptr, *info = nullptr;
   GivensRot *rot = nullptr;
@@ -716,7 +724,8 @@ static inline int eig_tridiagonalize(double *A, long n, EigWs &ws, hipStream_t s
                            ws.colP, ws.p);
       }
       hipLaunchKernelGGL(td_symv_kernel, dim3(nsymv + 2 * (int)k + nrow), dim3(256), 0, s, A, n, j, j0, ws.VT, ws.WT,
-                         ws.xcol, ws.ssbuf, nparts, ws.p, ws.ab, nsymv, (int)k, ws.d, ws.e, ws.tau);
+                         ws.xcol, ws.ssbuf, nparts, ws.p, ws.ab, nsymv, (int)k, ws.d, ws.e, ws.tau,
+                         ws.Sall ? ws.Sall + (j0 / EIG_NB) * EIG_NB * EIG_NB : nullptr);
       const int nparts2 = (int)((m + TD_CHUNK - 1) / TD_CHUNK);
       if (m > 0)
         hipLaunchKernelGGL(td_w1_kernel, dim3(nparts2), dim3(TD_CHUNK), 0, s, n, j, j0, ws.VT, ws.WT, ws.p, ws.ab,
@@ -929,9 +938,15 @@ static inline int eig_backtransform(double *ZT, long n, EigWs &ws, hipStream_t s
     const long Kc = n - c0;
     if (Kc <= 0) continue;
     const double *Y = ws.VT + j0 * n + c0; // kp x Kc, ld n
-    // S = Y Y^T
-    EIG_HIP(launch_dgemm('N', 'T', kp, kp, Kc, 1.0, Y, n, Y, n, 0.0, ws.S, kp, false, false, s));
-    hipLaunchKernelGGL(bt_tfactor_kernel, dim3(1), dim3(256), 0, s, ws.S, ws.tau + j0, (int)kp, ws.T);
+    // S = Y Y^T: its strict upper triangle (all dlarft reads) was stored by the tridiagonalisation's panel dots; a
+    // 128 x 128 x Kc product here would run on ONE workgroup (~2 ms per panel at n = 20000)
+    if (ws.Sall) {
+      hipLaunchKernelGGL(bt_tfactor_kernel, dim3(1), dim3(256), 0, s, ws.Sall + pnl * EIG_NB * EIG_NB, EIG_NB,
+                         ws.tau + j0, (int)kp, ws.T);
+    } else {
+      EIG_HIP(launch_dgemm('N', 'T', kp, kp, Kc, 1.0, Y, n, Y, n, 0.0, ws.S, kp, false, false, s));
+      hipLaunchKernelGGL(bt_tfactor_kernel, dim3(1), dim3(256), 0, s, ws.S, (int)kp, ws.tau + j0, (int)kp, ws.T);
+    }
     EIG_HIP(hipGetLastError());
     // P = ZT[:, c0:] * Y^T  (n x kp)
     EIG_HIP(launch_dgemm('N', 'T', n, kp, Kc, 1.0, ZT + c0, n, Y, n, 0.0, ws.P, kp, false, false, s));
@@ -956,6 +971,12 @@ static inline int eigh_device(double *G, long n, double *U, double *eval, hipStr
             ws.get(ws.T, (size_t)EIG_NB * EIG_NB) && ws.get(ws.zbuf, n) && ws.get(ws.dl, n) && ws.get(ws.w, n) &&
             ws.get(ws.lam, n) && ws.get(ws.zhat, n) && ws.get(ws.dphys, n) && ws.get(ws.ibuf, 2 * (size_t)n + 64) &&
             ws.get(ws.info, 1) && ws.get(ws.rot, n);
+  {
+    // panel Gram matrices from the tridiagonalisation; GEMMA_HIP_EIGH_PANEL_S=0 recomputes them as GEMMs
+    const char *e = getenv("GEMMA_HIP_EIGH_PANEL_S");
+    if (ok && !(e && e[0] == '0'))
+      ok = ws.get(ws.Sall, (size_t)((n + EIG_NB - 1) / EIG_NB) * EIG_NB * EIG_NB);
+  }
   {
     // symmetric (lower-triangle) SYMV partials; GEMMA_HIP_EIGH_SYMV=0 keeps the row-per-wave form
     const char *e = getenv("GEMMA_HIP_EIGH_SYMV");

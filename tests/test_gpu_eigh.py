@@ -131,6 +131,24 @@ def test_eigh_end_to_end(gpu_api, n, kind):
     assert np.all((w >= 1e-10) | (w == 0.0))
 
 
+@pytest.mark.parametrize("n", [130, 517, 1000])
+def test_backtransform_gram_sources_agree(gpu_api, n, monkeypatch):
+    """The compact-WY factor of each 128-reflector panel needs Y Y^T: by default the strict upper triangle comes from the
+    panel dots the tridiagonalisation computes anyway; GEMMA_HIP_EIGH_PANEL_S=0 recomputes it as a GEMM.  Both must
+    give an orthogonal eigenbasis with the same residual bar (ragged last panel included)."""
+    A = _sym(n, 31 * n, "kinship")
+    out = []
+    for flag in ("1", "0"):
+        monkeypatch.setenv("GEMMA_HIP_EIGH_PANEL_S", flag)
+        U, w = np.zeros((n, n)), np.zeros(n)
+        gpu_api.EigenDecomp_Zeroed(A.copy(), U, w)
+        w_raw = np.where(w == 0.0, np.einsum("ij,ij->j", U, A @ U), w)
+        assert np.linalg.norm(U.T @ U - np.eye(n)) < 50 * n * EPS
+        assert np.linalg.norm(A @ U - U * w_raw[None, :]) / np.linalg.norm(A, 2) < 50 * n * EPS
+        out.append(w)
+    assert np.allclose(out[0], out[1], rtol=0, atol=1e-12)
+
+
 def test_identity_and_diagonal(gpu_api):
     n = 200
     A = np.diag(np.linspace(-1, 3, n))
