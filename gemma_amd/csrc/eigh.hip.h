@@ -111,41 +111,105 @@ __device__ __forceinline__ TdScalars td_reflector(const double *__restrict__ xco
   return r;
 }
 
-__global__ __launch_bounds__(TD_CHUNK) void td_col_kernel(const double *__restrict__ A, long n, long j, long j0,
-                                                          const double *__restrict__ VT,
-                                                          const double *__restrict__ WT,
-                                                          double *__restrict__ xcol, double *__restrict__ ssbuf) {
+// td_col and td_w1 are skinny panel products (m rows x 2k panel columns): 64 rows per block, the panel index q dealt
+// over the block's four wavefronts (q = wave, wave + 4, ...) and combined through LDS in a fixed order -- four times the
+// blocks and a quarter of the dependent-load chain of a thread-per-row loop.
+constexpr int TD_ROWS = 64;
+__global__ __launch_bounds__(256) void td_col_kernel(const double *__restrict__ A, long n, long j, long j0,
+                                                     const double *__restrict__ VT, const double *__restrict__ WT,
+                                                     double *__restrict__ xcol, double *__restrict__ ssbuf) {
   __shared__ double sv[EIG_NB], sw[EIG_NB];
-  __shared__ double red[4];
-  const int t = threadIdx.x;
+  __shared__ double part[4][TD_ROWS];
+  const int t = threadIdx.x, rl = t & 63, qg = t >> 6;
   const int k = (int)(j - j0);
-  for (int q = t; q < k; q += TD_CHUNK) {
+  for (int q = t; q < k; q += 256) {
     sv[q] = VT[(j0 + q) * n + j];
     sw[q] = WT[(long)q * n + j];
   }
   __syncthreads();
-  const long r = j + (long)blockIdx.x * TD_CHUNK + t;
-  double ss = 0.0;
-  if (r < n) {
-    double x = A[j * n + r];
-    for (int q = 0; q < k; ++q) x -= VT[(j0 + q) * n + r] * sw[q] + WT[(long)q * n + r] * sv[q];
-    xcol[r] = x;
-    if (r >= j + 2) ss = x * x;
-  }
-  ss = eig_wsum(ss);
-  if ((t & 63) == 0) red[t >> 6] = ss;
+  const long r = j + (long)blockIdx.x * TD_ROWS + rl;
+  double acc = 0.0;
+  if (r < n)
+    for (int q = qg; q < k; q += 4) acc += VT[(j0 + q) * n + r] * sw[q] + WT[(long)q * n + r] * sv[q];
+  part[qg][rl] = acc;
   __syncthreads();
-  if (t == 0) ssbuf[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+  if (qg == 0) {
+    double ss = 0.0;
+    if (r < n) {
+      const double x = A[j * n + r] - ((part[0][rl] + part[1][rl]) + (part[2][rl] + part[3][rl]));
+      xcol[r] = x;
+      if (r >= j + 2) ss = x * x;
+    }
+    ss = eig_wsum(ss);
+    if (rl == 0) ssbuf[blockIdx.x] = ss;
+  }
 }
 
-// grid: [0, nsymv) SYMV rows (4 per block) | [nsymv, nsymv+2k) panel dots | then ceil(n/256) writers of VT row j
-__global__ __launch_bounds__(256) void td_symv_kernel(const double *__restrict__ A, long n, long j, long j0,
-                                                      double *__restrict__ VT, const double *__restrict__ WT,
-                                                      const double *__restrict__ xcol,
+// The per-column work that only touches the panel: idx in [0, 2k) is one dot of the new reflector u_j with W_q (even)
+// or u_q (odd), q = idx >> 1; idx >= 2k are the writers of VT row j (256 entries each; the first also stores d, e, tau).
+struct TdPanel {
+  long n, j, j0;
+  double *VT;
+  const double *WT;
+  const double *xcol;
+  double *ab;
+  int k;
+  double *d, *e, *tau;
+  double *Spanel; // strict upper triangle of the panel's Y Y^T (ld EIG_NB) for the back-transformation, or nullptr
+};
+
+__device__ __forceinline__ void td_panel_block(const TdPanel &g, int idx, const TdScalars &sc, double *red) {
+  const long n = g.n, j = g.j, j1 = g.j + 1;
+  const double scale = sc.scale;
+  const int t = threadIdx.x;
+  if (idx < 2 * g.k) {
+    const int q = idx >> 1;
+    const double *__restrict__ vecp = (idx & 1) ? (g.VT + (g.j0 + q) * n) : (g.WT + (long)q * n);
+    const double *__restrict__ xcol = g.xcol;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    long c = j1 + t;
+    for (; c + 768 < n; c += 1024) { // four independent loads per operand in flight
+      const double v0 = vecp[c], v1 = vecp[c + 256], v2 = vecp[c + 512], v3 = vecp[c + 768];
+      const double x0 = xcol[c], x1 = xcol[c + 256], x2 = xcol[c + 512], x3 = xcol[c + 768];
+      s0 += v0 * ((c == j1) ? 1.0 : x0 * scale);
+      s1 += v1 * (x1 * scale);
+      s2 += v2 * (x2 * scale);
+      s3 += v3 * (x3 * scale);
+    }
+    for (; c < n; c += 256) s0 += vecp[c] * ((c == j1) ? 1.0 : xcol[c] * scale);
+    const double s = eig_wsum((s0 + s1) + (s2 + s3));
+    if ((t & 63) == 0) red[t >> 6] = s;
+    __syncthreads();
+    if (t == 0) {
+      const double dot = (red[0] + red[1]) + (red[2] + red[3]);
+      g.ab[idx] = dot;
+      if ((idx & 1) && g.Spanel) g.Spanel[q * EIG_NB + g.k] = dot; // u_q . u_j
+    }
+  } else {
+    const int w = idx - 2 * g.k;
+    if (w == 0 && t == 0) {
+      g.d[j] = g.xcol[j];
+      if (sc.has_e) g.e[j] = sc.beta;
+      g.tau[j] = sc.tau;
+    }
+    const long r = (long)w * 256 + t;
+    if (r < n) {
+      double v = 0.0;
+      if (r == j1)
+        v = 1.0;
+      else if (r > j1)
+        v = g.xcol[r] * scale;
+      g.VT[j * n + r] = v;
+    }
+  }
+}
+
+// grid: [0, nsymv) SYMV rows (4 per block) | then the 2k + ceil(n/256) panel blocks (td_panel_block)
+__global__ __launch_bounds__(256) void td_symv_kernel(const double *__restrict__ A, TdPanel pg,
                                                       const double *__restrict__ ssbuf, int nparts,
-                                                      double *__restrict__ p, double *__restrict__ ab, int nsymv,
-                                                      int k, double *d, double *e, double *tau,
-                                                      double *__restrict__ Spanel) {
+                                                      double *__restrict__ p, int nsymv) {
+  const long n = pg.n, j = pg.j;
+  const double *__restrict__ xcol = pg.xcol;
   __shared__ double sh;
   __shared__ double red[4];
   const double xnorm2 = td_sum_parts(ssbuf, nparts, &sh);
@@ -153,11 +217,6 @@ __global__ __launch_bounds__(256) void td_symv_kernel(const double *__restrict__
   const double scale = sc.scale;
   const int lane = threadIdx.x & 63;
   const long j1 = j + 1;
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
-    d[j] = xcol[j];
-    if (sc.has_e) e[j] = sc.beta;
-    tau[j] = sc.tau;
-  }
   const int b = (int)blockIdx.x;
   if (b < nsymv) {
     const long r = j1 + (long)b * 4 + (threadIdx.x >> 6);
@@ -196,34 +255,8 @@ __global__ __launch_bounds__(256) void td_symv_kernel(const double *__restrict__
     }
     const double s = eig_wsum(s0 + s1);
     if (lane == 0) p[r] = s;
-  } else if (b < nsymv + 2 * k) {
-    const int idx = b - nsymv;
-    const int q = idx >> 1;
-    const double *__restrict__ vecp = (idx & 1) ? (VT + (j0 + q) * n) : (WT + (long)q * n);
-    double s = 0.0;
-    for (long c = j1 + threadIdx.x; c < n; c += 256) {
-      const double u = (c == j1) ? 1.0 : xcol[c] * scale;
-      s += vecp[c] * u;
-    }
-    s = eig_wsum(s);
-    if (lane == 0) red[threadIdx.x >> 6] = s;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      const double dot = (red[0] + red[1]) + (red[2] + red[3]);
-      ab[idx] = dot;
-      // u_q . u_j is entry (q, k) of the panel's Y Y^T, which the compact-WY factor of the back-transformation needs
-      if ((idx & 1) && Spanel) Spanel[q * EIG_NB + k] = dot;
-    }
   } else {
-    const long r = (long)(b - nsymv - 2 * k) * 256 + threadIdx.x;
-    if (r < n) {
-      double v = 0.0;
-      if (r == j1)
-        v = 1.0;
-      else if (r > j1)
-        v = xcol[r] * scale;
-      VT[j * n + r] = v;
-    }
+    td_panel_block(pg, b - nsymv, sc, red);
   }
 }
 
@@ -235,15 +268,26 @@ __global__ __launch_bounds__(256) void td_symv_kernel(const double *__restrict__
 //   col part  colacc[..] += A[r][c] u[r]          (c <  r)   -> colP[I][c]     after an 8-way LDS sum per sub-tile
 // td_symv_reduce_kernel then forms p[r] = sum_seg rowP[seg][r] + sum_{I' >= strip(r)} colP[I'][r] in a fixed order (no
 // atomics: the result does not depend on scheduling).  Needs n even (16-byte row alignment).
-constexpr int TS_STRIP = 64, TS_SEG = 1024, TS_WIDE = 256;
+constexpr int TS_STRIP = 64, TS_SEG_MIN = 512, TS_WIDE = 256; // segment width: runtime, a multiple of TS_WIDE
 __global__ __launch_bounds__(256) void td_symv_sym_kernel(const double *__restrict__ A, long n, long j,
                                                           const double *__restrict__ xcol,
                                                           const double *__restrict__ ssbuf, int nparts,
-                                                          double *__restrict__ rowP, double *__restrict__ colP) {
+                                                          double *__restrict__ rowP, double *__restrict__ colP,
+                                                          TdPanel pg, int ny_panel, int n_panel, int TS_SEG) {
   __shared__ double sh;
   __shared__ double cbuf[2][8][TS_WIDE];
   const long j1 = j + 1;
-  const long I = (long)blockIdx.y + j1 / TS_STRIP;      // strip index (absolute)
+  if ((int)blockIdx.y < ny_panel) {
+    // the panel dots and the VT row writers ride in the first grid rows: latency-bound reads of 2k panel rows that
+    // overlap the HBM-bound strips instead of costing a launch of their own (~55 us per column at n = 20000)
+    const int idx = (int)blockIdx.y * (int)gridDim.x + (int)blockIdx.x;
+    if (idx >= n_panel) return;
+    const double xn2 = td_sum_parts(ssbuf, nparts, &sh);
+    const TdScalars scp = td_reflector(xcol, n, j, xn2);
+    td_panel_block(pg, idx, scp, &cbuf[0][0][0]);
+    return;
+  }
+  const long I = (long)blockIdx.y - ny_panel + j1 / TS_STRIP; // strip index (absolute)
   const long seg = (long)blockIdx.x + j1 / TS_SEG;      // column segment (absolute)
   const long r0 = I * TS_STRIP;
   if (r0 >= n) return;
@@ -327,7 +371,8 @@ __global__ __launch_bounds__(256) void td_symv_sym_kernel(const double *__restri
 // p[r] = sum_seg rowP[seg][r] + sum_{I' >= strip(r)} colP[I'][r], r in [j+1, n): 64 rows per block, four threads per
 // row take every fourth partial (independent loads), fixed-order combine
 __global__ __launch_bounds__(256) void td_symv_reduce_kernel(long n, long j, const double *__restrict__ rowP,
-                                                             const double *__restrict__ colP, double *__restrict__ p) {
+                                                             const double *__restrict__ colP, double *__restrict__ p,
+                                                             int TS_SEG) {
   __shared__ double part[4][64];
   const long j1 = j + 1;
   const int rl = threadIdx.x & 63, pt = threadIdx.x >> 6;
@@ -348,34 +393,35 @@ __global__ __launch_bounds__(256) void td_symv_reduce_kernel(long n, long j, con
   if (pt == 0 && r < n) p[r] = (part[0][rl] + part[1][rl]) + (part[2][rl] + part[3][rl]);
 }
 
-__global__ __launch_bounds__(TD_CHUNK) void td_w1_kernel(long n, long j, long j0, const double *__restrict__ VT,
-                                                         const double *__restrict__ WT,
-                                                         const double *__restrict__ p,
-                                                         const double *__restrict__ ab, const double *tau,
-                                                         double *__restrict__ wtmp, double *__restrict__ dotbuf) {
+__global__ __launch_bounds__(256) void td_w1_kernel(long n, long j, long j0, const double *__restrict__ VT,
+                                                    const double *__restrict__ WT, const double *__restrict__ p,
+                                                    const double *__restrict__ ab, const double *tau,
+                                                    double *__restrict__ wtmp, double *__restrict__ dotbuf) {
   __shared__ double sa[EIG_NB], sb[EIG_NB];
-  __shared__ double red[4];
-  const int t = threadIdx.x;
+  __shared__ double part[4][TD_ROWS];
+  const int t = threadIdx.x, rl = t & 63, qg = t >> 6;
   const int k = (int)(j - j0);
-  for (int q = t; q < k; q += TD_CHUNK) {
+  for (int q = t; q < k; q += 256) {
     sa[q] = ab[2 * q];
     sb[q] = ab[2 * q + 1];
   }
   __syncthreads();
-  const double tj = tau[j];
-  const long r = j + 1 + (long)blockIdx.x * TD_CHUNK + t;
-  double dot = 0.0;
-  if (r < n) {
-    double w = p[r];
-    for (int q = 0; q < k; ++q) w -= VT[(j0 + q) * n + r] * sa[q] + WT[(long)q * n + r] * sb[q];
-    w *= tj;
-    wtmp[r] = w;
-    dot = w * VT[j * n + r];
-  }
-  dot = eig_wsum(dot);
-  if ((t & 63) == 0) red[t >> 6] = dot;
+  const long r = j + 1 + (long)blockIdx.x * TD_ROWS + rl;
+  double acc = 0.0;
+  if (r < n)
+    for (int q = qg; q < k; q += 4) acc += VT[(j0 + q) * n + r] * sa[q] + WT[(long)q * n + r] * sb[q];
+  part[qg][rl] = acc;
   __syncthreads();
-  if (t == 0) dotbuf[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+  if (qg == 0) {
+    double dot = 0.0;
+    if (r < n) {
+      const double w = tau[j] * (p[r] - ((part[0][rl] + part[1][rl]) + (part[2][rl] + part[3][rl])));
+      wtmp[r] = w;
+      dot = w * VT[j * n + r];
+    }
+    dot = eig_wsum(dot);
+    if (rl == 0) dotbuf[blockIdx.x] = dot;
+  }
 }
 
 __global__ __launch_bounds__(TD_CHUNK) void td_w2_kernel(long n, long j, long j0, const double *__restrict__ VT,
@@ -611,10 +657,18 @@ __global__ void dc_gather_rows_kernel(const double *__restrict__ src, long n, in
 
 // ---------------------------------------------------------------- 3. back-transformation
 // forward compact-WY factor (LAPACK dlarft, columnwise): T(i,i) = tau_i,
-// T(0:i,i) = -tau_i T(0:i,0:i) S(0:i,i) with S = Y^T Y.  Single workgroup, T upper triangular (kp x kp).
-__global__ __launch_bounds__(256) void bt_tfactor_kernel(const double *__restrict__ S, int lds,
-                                                         const double *__restrict__ tau, int kp,
-                                                         double *__restrict__ T) {
+// T(0:i,i) = -tau_i T(0:i,0:i) S(0:i,i) with S = Y^T Y.  One workgroup per panel (blockIdx.x): the panels' factors are
+// independent, so all of them are formed by ONE launch after the tridiagonalisation (the recurrence is a serial chain
+// of kp steps, ~1.2 ms on its own).  S has leading dimension lds, T is kp x kp upper triangular with leading dimension kp.
+__global__ __launch_bounds__(256) void bt_tfactor_kernel(const double *__restrict__ Sbase, long s_stride, int lds,
+                                                         const double *__restrict__ tau_base, long n,
+                                                         double *__restrict__ Tbase, long t_stride) {
+  const long pnl = blockIdx.x;
+  const double *__restrict__ S = Sbase + pnl * s_stride;
+  const double *__restrict__ tau = tau_base + pnl * EIG_NB;
+  double *__restrict__ T = Tbase + pnl * t_stride;
+  const long rem = n - pnl * EIG_NB;
+  const int kp = (int)(rem < EIG_NB ? rem : EIG_NB);
   const int t = threadIdx.x;
   for (int idx = t; idx < kp * kp; idx += 256) T[idx] = 0.0;
   __syncthreads();
@@ -662,10 +716,12 @@ struct EigWs {
   long n = 0;
   double *VT = nullptr, *WT = nullptr, *xcol = nullptr, *p = nullptr, *ab = nullptr;
   double *ssbuf = nullptr, *dotbuf = nullptr, *wtmp = nullptr;
+  int segw = 1024;                         // column-segment width of the symmetric SYMV (512 or 1024)
   double *rowP = nullptr, *colP = nullptr; // symmetric SYMV partials (nullptr: row-per-wave SYMV)
   double *d = nullptr, *e = nullptr, *tau = nullptr;
   double *Delta = nullptr, *Wk = nullptr, *QB = nullptr;
   double *P = nullptr, *P2 = nullptr, *S = nullptr, *T = nullptr;
+  double *Tall = nullptr; // per panel: compact-WY factor (kp x kp, ld kp), formed in one launch
   double *Sall = nullptr; // per panel: strict upper triangle of Y Y^T, collected by the tridiagonalisation (ld EIG_NB)
   double *zbuf = nullptr, *dl = nullptr, *w = nullptr, *lam = nullptr, *zhat = nullptr, *dphys = nullptr;
   int *ibuf = nullptr, *info = nullptr;
@@ -702,33 +758,40 @@ static inline int eig_tridiagonalize(double *A, long n, EigWs &ws, hipStream_t s
   // symmetric SYMV for trailing sizes >= sym_min: below that the row-per-wave form has less overhead
   // (GEMMA_HIP_EIGH_SYMV_MIN overrides the switch-over; read per call so that tests can force the path)
   const char *esm = getenv("GEMMA_HIP_EIGH_SYMV_MIN");
-  const long sym_min = esm ? atol(esm) : 12288;
+  const long sym_min = esm ? atol(esm) : 8192;
+  const char *esg = getenv("GEMMA_HIP_EIGH_SEG");
+  ws.segw = (esg && atoi(esg) == 512) ? 512 : 1024;
   for (long j0 = 0; j0 < n; j0 += EIG_NB) {
     const long kp = std::min<long>(EIG_NB, n - j0);
     for (long k = 0; k < kp; ++k) {
       const long j = j0 + k;
       const long m = n - j - 1;
-      const int nparts = (int)((n - j + TD_CHUNK - 1) / TD_CHUNK);
-      hipLaunchKernelGGL(td_col_kernel, dim3(nparts), dim3(TD_CHUNK), 0, s, A, n, j, j0, ws.VT, ws.WT, ws.xcol,
+      const int nparts = (int)((n - j + TD_ROWS - 1) / TD_ROWS);
+      hipLaunchKernelGGL(td_col_kernel, dim3(nparts), dim3(256), 0, s, A, n, j, j0, ws.VT, ws.WT, ws.xcol,
                          ws.ssbuf);
       const bool sym = ws.rowP != nullptr && m >= sym_min;
       const int nsymv = sym ? 0 : (int)((m + 3) / 4);
       const int nrow = (int)((n + 255) / 256);
+      TdPanel pg{n, j, j0, ws.VT, ws.WT, ws.xcol, ws.ab, (int)k, ws.d, ws.e, ws.tau,
+                 ws.Sall ? ws.Sall + (j0 / EIG_NB) * EIG_NB * EIG_NB : nullptr};
+      const int n_panel = 2 * (int)k + nrow;
       if (sym) {
         const long j1 = j + 1;
+        const int TS_SEG = ws.segw;
         const unsigned gx = (unsigned)((n - 1) / TS_SEG - j1 / TS_SEG + 1);
         const unsigned gy = (unsigned)((n - 1) / TS_STRIP - j1 / TS_STRIP + 1);
-        hipLaunchKernelGGL(td_symv_sym_kernel, dim3(gx, gy), dim3(256), 0, s, A, n, j, ws.xcol, ws.ssbuf, nparts,
-                           ws.rowP, ws.colP);
+        const unsigned nyp = ((unsigned)n_panel + gx - 1) / gx;
+        hipLaunchKernelGGL(td_symv_sym_kernel, dim3(gx, gy + nyp), dim3(256), 0, s, A, n, j, ws.xcol, ws.ssbuf, nparts,
+                           ws.rowP, ws.colP, pg, (int)nyp, n_panel, TS_SEG);
         hipLaunchKernelGGL(td_symv_reduce_kernel, dim3((unsigned)((m + 63) / 64)), dim3(256), 0, s, n, j, ws.rowP,
-                           ws.colP, ws.p);
+                           ws.colP, ws.p, TS_SEG);
+      } else {
+        hipLaunchKernelGGL(td_symv_kernel, dim3(nsymv + n_panel), dim3(256), 0, s, A, pg, ws.ssbuf, nparts, ws.p,
+                           nsymv);
       }
-      hipLaunchKernelGGL(td_symv_kernel, dim3(nsymv + 2 * (int)k + nrow), dim3(256), 0, s, A, n, j, j0, ws.VT, ws.WT,
-                         ws.xcol, ws.ssbuf, nparts, ws.p, ws.ab, nsymv, (int)k, ws.d, ws.e, ws.tau,
-                         ws.Sall ? ws.Sall + (j0 / EIG_NB) * EIG_NB * EIG_NB : nullptr);
-      const int nparts2 = (int)((m + TD_CHUNK - 1) / TD_CHUNK);
+      const int nparts2 = (int)((m + TD_ROWS - 1) / TD_ROWS);
       if (m > 0)
-        hipLaunchKernelGGL(td_w1_kernel, dim3(nparts2), dim3(TD_CHUNK), 0, s, n, j, j0, ws.VT, ws.WT, ws.p, ws.ab,
+        hipLaunchKernelGGL(td_w1_kernel, dim3(nparts2), dim3(256), 0, s, n, j, j0, ws.VT, ws.WT, ws.p, ws.ab,
                            ws.tau, ws.wtmp, ws.dotbuf);
       hipLaunchKernelGGL(td_w2_kernel, dim3((unsigned)((n + TD_CHUNK - 1) / TD_CHUNK)), dim3(TD_CHUNK), 0, s, n, j,
                          j0, ws.VT, ws.WT, ws.wtmp, ws.dotbuf, nparts2, ws.tau);
@@ -928,30 +991,36 @@ static inline int eig_stedc(long n, std::vector<double> &hd, std::vector<double>
   return 0;
 }
 
-// ZT (rows = eigenvectors of T) <- ZT * H_{n-3} ... H_0, panel by panel from the last one
+// ZT (rows = eigenvectors of T) <- ZT * H_{n-3} ... H_0, panel by panel from the last one.
+// Y = VT[j0 : j0+kp, j0:] -- reflector j0+q is zero in columns <= j0+q, so starting at column j0 (not j0+1) only adds
+// a zero column and keeps every operand 16-byte aligned with K a multiple of the GEMM's K tile when n is.
 static inline int eig_backtransform(double *ZT, long n, EigWs &ws, hipStream_t s, std::string &msg) {
   const long npan = (n + EIG_NB - 1) / EIG_NB;
+  const long nb2 = (long)EIG_NB * EIG_NB;
+  if (ws.Sall) {
+    // Y Y^T's strict upper triangle (all dlarft reads) was stored by the tridiagonalisation's panel dots
+    hipLaunchKernelGGL(bt_tfactor_kernel, dim3((unsigned)npan), dim3(256), 0, s, ws.Sall, nb2, EIG_NB, ws.tau, n,
+                       ws.Tall, nb2);
+    EIG_HIP(hipGetLastError());
+  }
   for (long pnl = npan - 1; pnl >= 0; --pnl) {
     const long j0 = pnl * EIG_NB;
     const long kp = std::min<long>(EIG_NB, n - j0);
-    const long c0 = j0 + 1; // reflector j0+q is zero in columns <= j0+q
+    const long c0 = j0;
     const long Kc = n - c0;
-    if (Kc <= 0) continue;
     const double *Y = ws.VT + j0 * n + c0; // kp x Kc, ld n
-    // S = Y Y^T: its strict upper triangle (all dlarft reads) was stored by the tridiagonalisation's panel dots; a
-    // 128 x 128 x Kc product here would run on ONE workgroup (~2 ms per panel at n = 20000)
+    const double *T = ws.T;
     if (ws.Sall) {
-      hipLaunchKernelGGL(bt_tfactor_kernel, dim3(1), dim3(256), 0, s, ws.Sall + pnl * EIG_NB * EIG_NB, EIG_NB,
-                         ws.tau + j0, (int)kp, ws.T);
+      T = ws.Tall + pnl * nb2;
     } else {
+      // S = Y Y^T as a product: a 128 x 128 x Kc GEMM runs on ONE workgroup (~2 ms per panel at n = 20000)
       EIG_HIP(launch_dgemm('N', 'T', kp, kp, Kc, 1.0, Y, n, Y, n, 0.0, ws.S, kp, false, false, s));
-      hipLaunchKernelGGL(bt_tfactor_kernel, dim3(1), dim3(256), 0, s, ws.S, (int)kp, ws.tau + j0, (int)kp, ws.T);
+      hipLaunchKernelGGL(bt_tfactor_kernel, dim3(1), dim3(256), 0, s, ws.S, 0L, (int)kp, ws.tau + j0, kp, ws.T, 0L);
     }
-    EIG_HIP(hipGetLastError());
     // P = ZT[:, c0:] * Y^T  (n x kp)
     EIG_HIP(launch_dgemm('N', 'T', n, kp, Kc, 1.0, ZT + c0, n, Y, n, 0.0, ws.P, kp, false, false, s));
     // P2 = P * T^T
-    EIG_HIP(launch_dgemm('N', 'T', n, kp, kp, 1.0, ws.P, kp, ws.T, kp, 0.0, ws.P2, kp, false, false, s));
+    EIG_HIP(launch_dgemm('N', 'T', n, kp, kp, 1.0, ws.P, kp, T, kp, 0.0, ws.P2, kp, false, false, s));
     // ZT[:, c0:] -= P2 * Y
     EIG_HIP(launch_dgemm('N', 'N', n, Kc, kp, -1.0, ws.P2, kp, Y, n, 1.0, ZT + c0, n, false, false, s));
   }
@@ -964,7 +1033,7 @@ static inline int eigh_device(double *G, long n, double *U, double *eval, hipStr
   ws.n = n;
   const size_t nn = (size_t)n * n;
   bool ok = ws.get(ws.VT, nn) && ws.get(ws.WT, (size_t)EIG_NB * n) && ws.get(ws.xcol, n + 2) && ws.get(ws.p, n) &&
-            ws.get(ws.ab, 2 * EIG_NB) && ws.get(ws.ssbuf, n / TD_CHUNK + 2) && ws.get(ws.dotbuf, n / TD_CHUNK + 2) &&
+            ws.get(ws.ab, 2 * EIG_NB) && ws.get(ws.ssbuf, n / TD_ROWS + 2) && ws.get(ws.dotbuf, n / TD_ROWS + 2) &&
             ws.get(ws.wtmp, n) && ws.get(ws.d, n) && ws.get(ws.e, n) && ws.get(ws.tau, n) &&
             ws.get(ws.Delta, nn) && ws.get(ws.Wk, nn) && ws.get(ws.P, (size_t)n * EIG_NB) &&
             ws.get(ws.P2, (size_t)n * EIG_NB) && ws.get(ws.S, (size_t)EIG_NB * EIG_NB) &&
@@ -975,13 +1044,14 @@ static inline int eigh_device(double *G, long n, double *U, double *eval, hipStr
     // panel Gram matrices from the tridiagonalisation; GEMMA_HIP_EIGH_PANEL_S=0 recomputes them as GEMMs
     const char *e = getenv("GEMMA_HIP_EIGH_PANEL_S");
     if (ok && !(e && e[0] == '0'))
-      ok = ws.get(ws.Sall, (size_t)((n + EIG_NB - 1) / EIG_NB) * EIG_NB * EIG_NB);
+      ok = ws.get(ws.Sall, (size_t)((n + EIG_NB - 1) / EIG_NB) * EIG_NB * EIG_NB) &&
+           ws.get(ws.Tall, (size_t)((n + EIG_NB - 1) / EIG_NB) * EIG_NB * EIG_NB);
   }
   {
     // symmetric (lower-triangle) SYMV partials; GEMMA_HIP_EIGH_SYMV=0 keeps the row-per-wave form
     const char *e = getenv("GEMMA_HIP_EIGH_SYMV");
     if (ok && (n & 1) == 0 && !(e && e[0] == '0')) {
-      const size_t nseg = (size_t)(n + TS_SEG - 1) / TS_SEG, nstrip = (size_t)(n + TS_STRIP - 1) / TS_STRIP;
+      const size_t nseg = (size_t)(n + TS_SEG_MIN - 1) / TS_SEG_MIN, nstrip = (size_t)(n + TS_STRIP - 1) / TS_STRIP;
       ok = ws.get(ws.rowP, nseg * (size_t)n) && ws.get(ws.colP, nstrip * (size_t)n);
     }
   }

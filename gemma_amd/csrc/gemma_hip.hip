@@ -508,12 +508,12 @@ extern "C" int gemma_hip_dbg_tridiag(const double *G, size_t n, double *d, doubl
   const size_t nn = n * n;
   if (dG.reserve(nn * 8)) return fail(GEMMA_HIP_ENOMEM, "dbg_tridiag");
   bool ok = ws.get(ws.VT, nn) && ws.get(ws.WT, (size_t)EIG_NB * n) && ws.get(ws.xcol, n + 2) && ws.get(ws.p, n) &&
-            ws.get(ws.ab, 2 * EIG_NB) && ws.get(ws.ssbuf, n / TD_CHUNK + 2) && ws.get(ws.dotbuf, n / TD_CHUNK + 2) &&
+            ws.get(ws.ab, 2 * EIG_NB) && ws.get(ws.ssbuf, n / TD_ROWS + 2) && ws.get(ws.dotbuf, n / TD_ROWS + 2) &&
             ws.get(ws.wtmp, n) && ws.get(ws.d, n) && ws.get(ws.e, n) && ws.get(ws.tau, n);
   {
     const char *e = getenv("GEMMA_HIP_EIGH_SYMV");
     if (ok && (n & 1) == 0 && !(e && e[0] == '0')) {
-      const size_t nseg = (n + TS_SEG - 1) / TS_SEG, nstrip = (n + TS_STRIP - 1) / TS_STRIP;
+      const size_t nseg = (n + TS_SEG_MIN - 1) / TS_SEG_MIN, nstrip = (n + TS_STRIP - 1) / TS_STRIP;
       ok = ws.get(ws.rowP, nseg * n) && ws.get(ws.colP, nstrip * n);
     }
   }

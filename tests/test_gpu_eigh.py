@@ -69,13 +69,15 @@ def test_tridiagonalisation_stage(gpu_api, n):
     assert np.max(np.abs(np.linalg.eigvalsh(T) - np.linalg.eigvalsh(A))) / nrm < 50 * n * EPS
 
 
-@pytest.mark.parametrize("n", [64, 130, 200, 1030, 2200])
-def test_symmetric_symv_path(gpu_api, n, monkeypatch):
+@pytest.mark.parametrize("n,seg", [(64, 1024), (130, 512), (200, 1024), (1030, 512), (1030, 1024), (2200, 512),
+                                   (2200, 1024)])
+def test_symmetric_symv_path(gpu_api, n, seg, monkeypatch):
     """The lower-triangle SYMV (td_symv_sym_kernel: 64-row strips x 1024-column segments, fixed-order partial sums) forced
-    on from the first column (it normally takes over for trailing sizes >= 2048): strips and segments that are ragged,
+    on from the first column (it normally takes over for trailing sizes >= 8192): strips and segments that are ragged,
     straddle the diagonal or start inside a 64-column sub-tile; same bar as the row-per-wave form (even n only)."""
     from gemma_amd import _lib as L
     monkeypatch.setenv("GEMMA_HIP_EIGH_SYMV_MIN", "1")
+    monkeypatch.setenv("GEMMA_HIP_EIGH_SEG", str(seg))
     A = _sym(n, 900 + n)
     d, e, tau, VT = np.zeros(n), np.zeros(max(n - 1, 1)), np.zeros(n), np.zeros((n, n))
     L.check(L.lib().gemma_hip_dbg_tridiag(_p(A), n, _p(d), _p(e), _p(tau), _p(VT)), "dbg_tridiag")
