@@ -18,6 +18,7 @@ SYMBOLS = [
     "gemma_hip_lm_finish", "gemma_hip_profile_enable",
     "gemma_hip_profile_read", "gemma_hip_dbg_tridiag", "gemma_hip_dbg_stedc", "gemma_hip_dbg_utx", "gemma_hip_lmm_gene_batch", "gemma_hip_lmm_gene_batch_d", "gemma_hip_lmm_set_env",
     "gemma_hip_lmm_gxe_batch", "gemma_hip_lmm_gxe_batch_d",
+    "gemma_hip_mvlmm_null", "gemma_hip_mvlmm_set", "gemma_hip_mvlmm_batch", "gemma_hip_mvlmm_batch_d",
 ]
 
 OK, EINVAL, ENODEV, ENOMEM, ERUNTIME, ESTATE, ENOCONV = range(7)
@@ -39,6 +40,18 @@ class LmmCfg(C.Structure):
 class QcCfg(C.Structure):
     _fields_ = [("maf_level", C.c_double), ("miss_level", C.c_double), ("hwe_level", C.c_double),
                 ("r2_level", C.c_double)]
+
+
+class MvNull(C.Structure):
+    """gemma_mvlmm_null: V_g, V_e (d x d, leading dimension d), B (d x n_cvt), logl for the REMLE and the MLE null fit"""
+    _fields_ = [("Vg_remle", C.c_double * 25), ("Ve_remle", C.c_double * 25), ("B_remle", C.c_double * 20),
+                ("logl_remle_H0", C.c_double), ("Vg_mle", C.c_double * 25), ("Ve_mle", C.c_double * 25),
+                ("B_mle", C.c_double * 20), ("logl_mle_H0", C.c_double)]
+
+
+class MvOpt(C.Structure):
+    _fields_ = [("em_iter", C.c_size_t), ("nr_iter", C.c_size_t), ("em_prec", C.c_double), ("nr_prec", C.c_double),
+                ("p_nr", C.c_double)]
 
 
 class GemmaHipError(RuntimeError):
@@ -100,6 +113,10 @@ def lib():
     L.gemma_hip_lmm_gxe_batch.argtypes = [ci, vp, sz, sz, vp]
     L.gemma_hip_lmm_gxe_batch_d.argtypes = [ci, vp, sz, sz, vp, vp]
     L.gemma_hip_lmm_gene_batch_d.argtypes = [dp, sz, sz, vp, vp]
+    L.gemma_hip_mvlmm_null.argtypes = [sz, sz, sz, dp, dp, dp, cd, cd, sz, C.POINTER(MvOpt), C.POINTER(MvNull)]
+    L.gemma_hip_mvlmm_set.argtypes = [sz, dp, C.POINTER(MvNull), C.POINTER(MvOpt)]
+    L.gemma_hip_mvlmm_batch.argtypes = [ci, vp, sz, sz, dp]
+    L.gemma_hip_mvlmm_batch_d.argtypes = [ci, vp, sz, sz, dp, vp]
     L.gemma_hip_lmm_finish.argtypes = [C.POINTER(cd), C.POINTER(cd)]
     L.gemma_hip_lm_setup.argtypes = [ci, sz, sz, dp, dp]
     L.gemma_hip_lm_batch.argtypes = [ci, vp, sz, sz, vp]

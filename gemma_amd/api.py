@@ -479,3 +479,93 @@ class LM:
         finally:
             L.check(L.lib().gemma_hip_lm_finish(), "LM.finish")
         return self.sumStat
+
+
+class MVLMM:
+    """Mirror of class MVLMM (src/mvlmm.h:32-104): the fields CopyFromParam fills (src/mvlmm.cpp:51-90) and
+    AnalyzeBimbam / AnalyzePlink (:2972-3899) with crt = 0.  sumStat is a dict of arrays with MPHSUMSTAT's fields
+    (src/param.h:68-77): beta (l x d), Vbeta / Vg / Ve (l x d(d+1)/2, upper triangles row by row), p_wald, p_lrt, p_score."""
+
+    def __init__(self, a_mode=1, l_min=1e-5, l_max=1e5, n_region=10, em_iter=10000, nr_iter=100, em_prec=1e-4,
+                 nr_prec=1e-4, p_nr=1e-3):
+        self.a_mode = a_mode
+        self.l_min, self.l_max, self.n_region = l_min, l_max, n_region
+        self.em_iter, self.nr_iter, self.em_prec, self.nr_prec, self.p_nr = em_iter, nr_iter, em_prec, nr_prec, p_nr
+        self.sumStat = {}
+        self.null = None
+
+    def _opt(self):
+        return L.MvOpt(self.em_iter, self.nr_iter, self.em_prec, self.nr_prec, self.p_nr)
+
+    def fit_null(self, eval_, UtW, UtY):
+        """The null block (src/mvlmm.cpp:3056-3208) -> dict with Vg/Ve/B/logl for 'remle' and 'mle'; also fills the
+        members WriteFiles' callers read (Vg_remle_null, ..., logl_mle_H0)."""
+        UtY = np.ascontiguousarray(UtY, dtype=np.float64)
+        n, d = UtY.shape
+        UtW = np.ascontiguousarray(UtW, dtype=np.float64).reshape(n, -1)
+        c = UtW.shape[1]
+        ev = np.ascontiguousarray(eval_, dtype=np.float64)
+        nf, opt = L.MvNull(), self._opt()
+        L.check(L.lib().gemma_hip_mvlmm_null(n, c, d, _ptr(ev), _ptr(UtW), _ptr(UtY), self.l_min, self.l_max,
+                                             self.n_region, C.byref(opt), C.byref(nf)), "MVLMM.fit_null")
+        self._null_struct = nf
+        g = lambda a, r, k: np.array(a[:r * k]).reshape(r, k)
+        self.null = {"Vg_remle": g(nf.Vg_remle, d, d), "Ve_remle": g(nf.Ve_remle, d, d), "B_remle": g(nf.B_remle, d, c),
+                     "logl_remle": nf.logl_remle_H0, "Vg_mle": g(nf.Vg_mle, d, d), "Ve_mle": g(nf.Ve_mle, d, d),
+                     "B_mle": g(nf.B_mle, d, c), "logl_mle": nf.logl_mle_H0}
+        self.logl_remle_H0, self.logl_mle_H0 = nf.logl_remle_H0, nf.logl_mle_H0
+        return self.null
+
+    def Analyze(self, U, eval_, UtW, UtY, geno, geno_kind, indicator_idv=None, batch=LMM_BATCH_SIZE):
+        UtY = np.ascontiguousarray(UtY, dtype=np.float64)
+        n, d = UtY.shape
+        self.fit_null(eval_, UtW, UtY)
+        lmm = LMM(a_mode=self.a_mode, l_min=self.l_min, l_max=self.l_max, n_region=self.n_region)
+        lmm.setup(U, eval_, UtW, np.ascontiguousarray(UtY[:, 0]), plink=(geno_kind == L.GENO_PLINK_2BIT))
+        v = d * (d + 1) // 2
+        stride = d + 3 * v + 3
+        outs = []
+        try:
+            if indicator_idv is not None:
+                lmm.set_indicator(indicator_idv)
+            opt = self._opt()
+            L.check(L.lib().gemma_hip_mvlmm_set(d, _ptr(UtY), C.byref(self._null_struct), C.byref(opt)), "MVLMM.set")
+            geno = np.ascontiguousarray(geno)
+            for s0 in range(0, geno.shape[0], batch):
+                blk = geno[s0:s0 + batch]
+                out = np.zeros((blk.shape[0], stride))
+                L.check(L.lib().gemma_hip_mvlmm_batch(geno_kind, _ptr(blk), blk.shape[0], blk.shape[1], _ptr(out)),
+                        "MVLMM.Analyze")
+                outs.append(out)
+        finally:
+            lmm.finish()
+        o = np.concatenate(outs) if outs else np.zeros((0, stride))
+        self.sumStat = {"beta": o[:, :d], "Vbeta": o[:, d:d + v], "Vg": o[:, d + v:d + 2 * v],
+                        "Ve": o[:, d + 2 * v:d + 3 * v], "p_wald": o[:, d + 3 * v], "p_lrt": o[:, d + 3 * v + 1],
+                        "p_score": o[:, d + 3 * v + 2]}
+        return self.sumStat
+
+    def AnalyzeBimbam(self, U, eval_, UtW, UtY, X_snpmajor, batch=LMM_BATCH_SIZE):
+        """src/mvlmm.cpp:2972-3416: X_snpmajor holds one row per analysed SNP over the analysed individuals, NaN = NA."""
+        return self.Analyze(U, eval_, UtW, UtY, np.ascontiguousarray(X_snpmajor, dtype=np.float64), L.GENO_F64_SNP_MAJOR,
+                            batch=batch)
+
+    def AnalyzePlink(self, U, eval_, UtW, UtY, bed_rows, indicator_idv, batch=LMM_BATCH_SIZE):
+        """src/mvlmm.cpp:3418-3899"""
+        return self.Analyze(U, eval_, UtW, UtY, np.ascontiguousarray(bed_rows, dtype=np.uint8), L.GENO_PLINK_2BIT,
+                            indicator_idv=indicator_idv, batch=batch)
+
+    def WriteFiles(self, path, snp_info):
+        """MVLMM::WriteFiles (src/mvlmm.cpp:117-210)"""
+        d = self.sumStat["beta"].shape[1]
+        head = ["chr", "rs", "ps", "n_miss", "allele1", "allele0", "af"] + ["beta_%d" % (i + 1) for i in range(d)]
+        head += ["Vbeta_%d_%d" % (i + 1, j + 1) for i in range(d) for j in range(i, d)]
+        pcols = {1: ["p_wald"], 2: ["p_lrt"], 3: ["p_score"], 4: ["p_wald", "p_lrt", "p_score"]}[self.a_mode]
+        with open(path, "w") as f:
+            f.write("\t".join(head + pcols) + "\n")
+            for t, si in enumerate(snp_info):
+                row = [str(si["chr"]), str(si["rs"]), str(si["ps"]), str(si["n_miss"]), str(si["allele1"]),
+                       str(si["allele0"]), "%.3f" % si["af"]]
+                row += ["%.6e" % x for x in self.sumStat["beta"][t]] + ["%.6e" % x for x in self.sumStat["Vbeta"][t]]
+                row += ["%.6e" % self.sumStat[k][t] for k in pcols]
+                f.write("\t".join(row) + "\n")

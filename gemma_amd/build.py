@@ -6,8 +6,8 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libgemma_hip.so")
-SOURCES = ["gemma_hip.hip"]
-HEADERS = ["dgemm_mfma.hip.h", "lmm_grid.hip.h", "i8gemm.hip.h", "lmm_assoc.hip.h", "ingest.hip.h", "eigh.hip.h", "qc.hip.h", "lm_assoc.hip.h"]
+SOURCES = ["gemma_hip.hip", "mvlmm_kernels.hip"]  # one object each, compiled concurrently
+HEADERS = ["dgemm_mfma.hip.h", "lmm_grid.hip.h", "i8gemm.hip.h", "lmm_assoc.hip.h", "ingest.hip.h", "eigh.hip.h", "qc.hip.h", "lm_assoc.hip.h", "mvlmm.hip.h"]
 
 
 def hipcc():
@@ -30,8 +30,25 @@ def build(force=False, verbose=False):
     """hipcc --offload-arch=gfx950 -> gemma_amd/libgemma_hip.so (cross-compiles without a GPU)."""
     if not force and not stale():
         return LIB
-    cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
+    cc = hipcc()
+    objdir = os.path.join(HERE, "_obj")
+    os.makedirs(objdir, exist_ok=True)
+    procs, objs = [], []
+    for src in SOURCES:
+        obj = os.path.join(objdir, src.replace(".hip", ".o"))
+        objs.append(obj)
+        hdrs = HEADERS if src == "gemma_hip.hip" else ["mvlmm.hip.h"]
+        deps = [os.path.join(CSRC, f) for f in [src] + hdrs] + [os.path.join(HERE, "..", "include", "gemma_hip.h")]
+        if not force and os.path.exists(obj) and all(os.path.getmtime(d) <= os.path.getmtime(obj) for d in deps):
+            continue
+        cmd = [cc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", os.path.join(CSRC, src), "-o", obj]
+        if verbose:
+            print(" ".join(cmd))
+        procs.append((cmd, subprocess.Popen(cmd, cwd=CSRC)))
+    for cmd, pr in procs:
+        if pr.wait() != 0:
+            raise subprocess.CalledProcessError(pr.returncode, cmd)
+    cmd = [cc, "--offload-arch=gfx950", "-fPIC", "-shared", "-o", LIB] + objs
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd, cwd=CSRC)

@@ -1,0 +1,1148 @@
+// Multivariate LMM, per-SNP stage (GEMMA src/mvlmm.cpp:3287-3374): MphEM (:599-724), MphCalcP (:727-831)
+// and MphNR (:2608-2760) for one SNP per WAVEFRONT.
+//
+// Everything is done in the basis that diagonalises all H_k = delta_k V_g + V_e at once (EigenProc :213-282):
+// H_k^-1 = UltVehi^T diag(1 / (delta_k D_l + 1)) UltVehi.  There the dc x dc matrix Q of CalcQi (:285-329) is a
+// direct sum of d blocks of size c x c (its entries couple (covariate i, component l) with (covariate j, component l)
+// only), so "LU-invert Q" becomes d small SPD inversions, the REML part of CalcSigma (:517-548) and the x P x of
+// MphCalcP are diagonal, and the whole EM iteration is two passes (REML; three for ML) over the n individuals with
+// < 50 running sums, which the 64 lanes of a wavefront stride over and butterfly-reduce.  Small matrices live in
+// registers (D, C are template parameters, every loop over them unrolls); all lanes carry the same copy.
+//
+// The lane policy makes the same source run on one CPU "lane" in tests/host_mvlmm_harness.cpp (test infrastructure:
+// the shipped library has no CPU path).
+#pragma once
+#include <math.h>
+
+#ifndef MV_HD
+#define MV_HD __device__ __forceinline__
+#endif
+
+namespace gemma_hip {
+
+constexpr int MV_DMAX = 5;  // phenotypes
+constexpr int MV_CMAX = 4;  // covariates + the SNP
+
+struct MvArgs {
+  const double *UtX;  // l x ld, SNP-major
+  long ld, l;
+  int n;
+  const double *eval;  // n
+  const double *Wt;    // (c - 1) x n : U^T W transposed
+  const double *Yt;    // d x n       : U^T Y transposed
+  double Vg_null[MV_DMAX * MV_DMAX], Ve_null[MV_DMAX * MV_DMAX], B_null[MV_DMAX * MV_CMAX]; // B_null: d x (c - 1)
+  double logl_H0;      // MLE null log-likelihood (the LRT reference, :3317)
+  int a_mode;
+  int em_iter;         // per-SNP cap (the caller passes em_iter / 10, :3310)
+  double em_prec;      // em_prec * 10
+  int nr_iter;         // nr_iter / 10
+  double nr_prec;      // nr_prec * 10
+  double p_nr;
+  double *out;         // l x stride: beta[d], Vbeta[v], Vg[v], Ve[v], p_wald, p_lrt, p_score
+  int stride;
+};
+
+#ifdef __HIPCC__
+struct MvWaveLanes {
+  static constexpr int N = 64;
+  static MV_HD int lane() { return (int)(threadIdx.x & 63); }
+  static MV_HD double sum(double v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+  }
+};
+#endif
+
+// ---------------------------------------------------------------- small dense algebra (registers)
+// cyclic Jacobi, A = V diag(w) V^T, eigenvalues ascending (LAPACK's order), each vector signed so that its entry of
+// largest magnitude is positive.  The ML EM subtracts the PREVIOUS iteration's U_l^T V_e^-1/2 B X from this
+// iteration's rotated phenotypes (UltVehiBX is not refreshed before UpdateU, src/mvlmm.cpp:679-686), so the component
+// order and signs must not jump between two nearly equal matrices.
+template <int M> MV_HD void mv_jacobi(const double (&A)[M * M], double (&w)[M], double (&V)[M * M]) {
+  double a[M * M];
+#pragma unroll
+  for (int i = 0; i < M * M; ++i) a[i] = A[i];
+#pragma unroll
+  for (int i = 0; i < M; ++i)
+#pragma unroll
+    for (int j = 0; j < M; ++j) V[i * M + j] = (i == j) ? 1.0 : 0.0;
+  if (M > 1) {
+    for (int sweep = 0; sweep < 60; ++sweep) {
+      double off = 0.0, diag = 0.0;
+#pragma unroll
+      for (int i = 0; i < M; ++i) {
+        diag += a[i * M + i] * a[i * M + i];
+#pragma unroll
+        for (int j = i + 1; j < M; ++j) off += a[i * M + j] * a[i * M + j];
+      }
+      if (off <= 1e-34 * diag || off == 0.0) break;
+#pragma unroll
+      for (int p = 0; p < M; ++p)
+#pragma unroll
+        for (int q = p + 1; q < M; ++q) {
+          const double apq = a[p * M + q];
+          if (apq != 0.0) {
+            const double theta = (a[q * M + q] - a[p * M + p]) / (2.0 * apq);
+            const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+            const double cs = 1.0 / sqrt(t * t + 1.0), sn = t * cs;
+#pragma unroll
+            for (int k = 0; k < M; ++k) {
+              const double akp = a[k * M + p], akq = a[k * M + q];
+              a[k * M + p] = cs * akp - sn * akq;
+              a[k * M + q] = sn * akp + cs * akq;
+            }
+#pragma unroll
+            for (int k = 0; k < M; ++k) {
+              const double apk = a[p * M + k], aqk = a[q * M + k];
+              a[p * M + k] = cs * apk - sn * aqk;
+              a[q * M + k] = sn * apk + cs * aqk;
+            }
+#pragma unroll
+            for (int k = 0; k < M; ++k) {
+              const double vkp = V[k * M + p], vkq = V[k * M + q];
+              V[k * M + p] = cs * vkp - sn * vkq;
+              V[k * M + q] = sn * vkp + cs * vkq;
+            }
+          }
+        }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < M; ++i) w[i] = a[i * M + i];
+#pragma unroll
+  for (int i = 0; i < M; ++i) // selection sort, ascending; columns follow
+#pragma unroll
+    for (int j = i + 1; j < M; ++j)
+      if (w[j] < w[i]) {
+        double t = w[i];
+        w[i] = w[j];
+        w[j] = t;
+#pragma unroll
+        for (int k = 0; k < M; ++k) {
+          t = V[k * M + i];
+          V[k * M + i] = V[k * M + j];
+          V[k * M + j] = t;
+        }
+      }
+#pragma unroll
+  for (int i = 0; i < M; ++i) {
+    double big = 0.0, sgn = 1.0;
+#pragma unroll
+    for (int k = 0; k < M; ++k)
+      if (fabs(V[k * M + i]) > big) {
+        big = fabs(V[k * M + i]);
+        sgn = V[k * M + i] < 0 ? -1.0 : 1.0;
+      }
+#pragma unroll
+    for (int k = 0; k < M; ++k) V[k * M + i] *= sgn;
+  }
+}
+
+// inverse and log-determinant of a symmetric positive definite M x M matrix (Cholesky); a non-positive pivot
+// propagates NaN like the reference's LU of a singular Q propagates inf/NaN
+template <int M> MV_HD double mv_spd_inverse(const double (&A)[M * M], double (&Ai)[M * M]) {
+  double L[M * M], Li[M * M];
+  double lndet = 0.0;
+#pragma unroll
+  for (int j = 0; j < M; ++j) {
+    double s = A[j * M + j];
+#pragma unroll
+    for (int k = 0; k < j; ++k) s -= L[j * M + k] * L[j * M + k];
+    const double ljj = sqrt(s);
+    L[j * M + j] = ljj;
+    lndet += 2.0 * log(ljj);
+#pragma unroll
+    for (int i = j + 1; i < M; ++i) {
+      double t = A[i * M + j];
+#pragma unroll
+      for (int k = 0; k < j; ++k) t -= L[i * M + k] * L[j * M + k];
+      L[i * M + j] = t / ljj;
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < M; ++j) { // Li = L^-1 (lower)
+    Li[j * M + j] = 1.0 / L[j * M + j];
+#pragma unroll
+    for (int i = j + 1; i < M; ++i) {
+      double t = 0.0;
+#pragma unroll
+      for (int k = j; k < i; ++k) t -= L[i * M + k] * Li[k * M + j];
+      Li[i * M + j] = t / L[i * M + i];
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < M; ++i)
+#pragma unroll
+    for (int j = 0; j <= i; ++j) {
+      double t = 0.0;
+#pragma unroll
+      for (int k = i; k < M; ++k) t += Li[k * M + i] * Li[k * M + j];
+      Ai[i * M + j] = t;
+      Ai[j * M + i] = t;
+    }
+  return lndet;
+}
+
+// gsl_cdf_chisq_Q(x, nu), integer nu: finite sums for integer / half-integer shape (all terms positive)
+MV_HD double mv_chisq_Q(double x, int nu) {
+  if (!(x > 0.0)) return (x == x) ? 1.0 : x;
+  const double y = 0.5 * x;
+  if ((nu & 1) == 0) {
+    double term = 1.0, sum = 1.0;
+    for (int k = 1; k < nu / 2; ++k) {
+      term *= y / k;
+      sum += term;
+    }
+    return exp(-y) * sum;
+  }
+  double sum = 0.0, term = sqrt(y) / 0.886226925452758013649;
+  for (int k = 1; k <= (nu - 1) / 2; ++k) {
+    sum += term;
+    term *= y / (k + 0.5);
+  }
+  return erfc(sqrt(y)) + exp(-y) * sum;
+}
+
+// ---------------------------------------------------------------- per-SNP state
+template <int D> struct MvBasis { // EigenProc, src/mvlmm.cpp:213-282
+  double Dl[D], UltVeh[D * D], UltVehi[D * D], logdet_Ve;
+  MV_HD void build(const double (&Vg)[D * D], const double (&Ve)[D * D]) {
+    double w[D], Ul[D * D], Veh[D * D], Vehi[D * D], T1[D * D], Lam[D * D];
+    mv_jacobi<D>(Ve, w, Ul);
+    logdet_Ve = 0.0;
+#pragma unroll
+    for (int i = 0; i < D * D; ++i) Veh[i] = Vehi[i] = 0.0;
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+      if (w[i] > 0) {
+        logdet_Ve += log(w[i]);
+        const double s = sqrt(w[i]), si = 1.0 / s;
+#pragma unroll
+        for (int a = 0; a < D; ++a)
+#pragma unroll
+          for (int b = 0; b < D; ++b) {
+            Veh[a * D + b] += s * Ul[a * D + i] * Ul[b * D + i];
+            Vehi[a * D + b] += si * Ul[a * D + i] * Ul[b * D + i];
+          }
+      }
+    }
+#pragma unroll
+    for (int a = 0; a < D; ++a)
+#pragma unroll
+      for (int b = 0; b < D; ++b) {
+        double s = 0.0;
+#pragma unroll
+        for (int t = 0; t < D; ++t) s += Vg[a * D + t] * Vehi[t * D + b];
+        T1[a * D + b] = s;
+      }
+#pragma unroll
+    for (int a = 0; a < D; ++a)
+#pragma unroll
+      for (int b = 0; b < D; ++b) {
+        double s = 0.0;
+#pragma unroll
+        for (int t = 0; t < D; ++t) s += Vehi[a * D + t] * T1[t * D + b];
+        Lam[a * D + b] = s;
+      }
+#pragma unroll
+    for (int a = 0; a < D; ++a)
+#pragma unroll
+      for (int b = a + 1; b < D; ++b) Lam[a * D + b] = Lam[b * D + a] = 0.5 * (Lam[a * D + b] + Lam[b * D + a]);
+    mv_jacobi<D>(Lam, Dl, Ul);
+#pragma unroll
+    for (int i = 0; i < D; ++i)
+      if (Dl[i] < 0) Dl[i] = 0;
+#pragma unroll
+    for (int a = 0; a < D; ++a)
+#pragma unroll
+      for (int b = 0; b < D; ++b) {
+        double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+        for (int t = 0; t < D; ++t) {
+          s1 += Ul[t * D + a] * Veh[t * D + b];
+          s2 += Ul[t * D + a] * Vehi[t * D + b];
+        }
+        UltVeh[a * D + b] = s1;
+        UltVehi[a * D + b] = s2;
+      }
+  }
+};
+
+// the sums of one pass over the individuals at a fixed basis: per component l the c x c block Q_l (upper triangle),
+// xHiy (c per component) and the scalar part of MphCalcLogL (:571-581)
+template <int D, int C> struct MvMoments {
+  static constexpr int T = C * (C + 1) / 2;
+  double Q[D * T], xHiy[D * C], ll;
+};
+
+template <int D, int C, class Lanes>
+MV_HD void mv_pass_moments(const MvArgs &g, const double *__restrict__ x, const MvBasis<D> &bs, MvMoments<D, C> &m) {
+  constexpr int T = C * (C + 1) / 2;
+#pragma unroll
+  for (int i = 0; i < D * T; ++i) m.Q[i] = 0.0;
+#pragma unroll
+  for (int i = 0; i < D * C; ++i) m.xHiy[i] = 0.0;
+  m.ll = 0.0;
+  for (int k = Lanes::lane(); k < g.n; k += Lanes::N) {
+    const double delta = g.eval[k];
+    double xv[C], yv[D];
+#pragma unroll
+    for (int j = 0; j < C - 1; ++j) xv[j] = g.Wt[(long)j * g.n + k];
+    xv[C - 1] = x[k];
+#pragma unroll
+    for (int i = 0; i < D; ++i) yv[i] = g.Yt[(long)i * g.n + k];
+#pragma unroll
+    for (int l = 0; l < D; ++l) {
+      const double dd = delta * bs.Dl[l] + 1.0, w = 1.0 / dd;
+      double yt = 0.0;
+#pragma unroll
+      for (int i = 0; i < D; ++i) yt += bs.UltVehi[l * D + i] * yv[i];
+      m.ll += yt * yt * w + log(dd);
+      int t = 0;
+#pragma unroll
+      for (int a = 0; a < C; ++a) {
+        const double xa = xv[a] * w;
+        m.xHiy[l * C + a] += xa * yt;
+#pragma unroll
+        for (int b = a; b < C; ++b, ++t) m.Q[l * T + t] += xa * xv[b];
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < D * T; ++i) m.Q[i] = Lanes::sum(m.Q[i]);
+#pragma unroll
+  for (int i = 0; i < D * C; ++i) m.xHiy[i] = Lanes::sum(m.xHiy[i]);
+  m.ll = Lanes::sum(m.ll);
+}
+
+template <int C> MV_HD void mv_unpack_sym(const double *tri, double (&A)[C * C]) {
+  int t = 0;
+#pragma unroll
+  for (int a = 0; a < C; ++a)
+#pragma unroll
+    for (int b = a; b < C; ++b, ++t) A[a * C + b] = A[b * C + a] = tri[t];
+}
+
+// log|X X^T| and (X X^T)^-1 over the c covariate rows (:631-649)
+template <int C, class Lanes>
+MV_HD double mv_xxt(const MvArgs &g, const double *__restrict__ x, double (&XXti)[C * C]) {
+  constexpr int T = C * (C + 1) / 2;
+  double tri[T];
+#pragma unroll
+  for (int i = 0; i < T; ++i) tri[i] = 0.0;
+  for (int k = Lanes::lane(); k < g.n; k += Lanes::N) {
+    double xv[C];
+#pragma unroll
+    for (int j = 0; j < C - 1; ++j) xv[j] = g.Wt[(long)j * g.n + k];
+    xv[C - 1] = x[k];
+    int t = 0;
+#pragma unroll
+    for (int a = 0; a < C; ++a)
+#pragma unroll
+      for (int b = a; b < C; ++b, ++t) tri[t] += xv[a] * xv[b];
+  }
+#pragma unroll
+  for (int i = 0; i < T; ++i) tri[i] = Lanes::sum(tri[i]);
+  double XXt[C * C];
+  mv_unpack_sym<C>(tri, XXt);
+  return mv_spd_inverse<C>(XXt, XXti);
+}
+
+// MphEM, src/mvlmm.cpp:599-724.  Vg, Ve (d x d) and B (d x c) are updated in place; returns the last logl.
+template <int D, int C, class Lanes>
+MV_HD double mv_em(const MvArgs &g, const double *__restrict__ x, bool reml, int max_iter, double max_prec,
+                   double lndet_xxt, const double (&XXti)[C * C], double (&Vg)[D * D], double (&Ve)[D * D],
+                   double (&B)[D * C]) {
+  constexpr int T = C * (C + 1) / 2;
+  constexpr double LOG2PI = 1.8378770664093454836;
+  const int n = g.n;
+  const double logl_const = reml ? -0.5 * (double)(n - C) * (double)D * LOG2PI + 0.5 * (double)D * lndet_xxt
+                                 : -0.5 * (double)n * (double)D * LOG2PI;
+  double UltVehiB[D * C]; // component-major: [l][j]
+#pragma unroll
+  for (int i = 0; i < D * C; ++i) UltVehiB[i] = 0.0;
+  double logl_old = 0.0, logl_new = 0.0;
+  MvBasis<D> bs;
+  MvMoments<D, C> m;
+  double Qi[D][C * C];
+  for (int t = 0; t < max_iter; ++t) {
+    bs.build(Vg, Ve);
+    mv_pass_moments<D, C, Lanes>(g, x, bs, m);
+    double logdet_Q = 0.0, quad = 0.0, bl[D * C];
+#pragma unroll
+    for (int l = 0; l < D; ++l) {
+      double Ql[C * C];
+      mv_unpack_sym<C>(m.Q + l * T, Ql);
+      logdet_Q += mv_spd_inverse<C>(Ql, Qi[l]);
+#pragma unroll
+      for (int a = 0; a < C; ++a) {
+        double s = 0.0;
+#pragma unroll
+        for (int b = 0; b < C; ++b) s += Qi[l][a * C + b] * m.xHiy[l * C + b];
+        bl[l * C + a] = s;
+        quad += s * m.xHiy[l * C + a];
+      }
+    }
+    logl_new = logl_const - 0.5 * (m.ll - quad) - 0.5 * (double)n * bs.logdet_Ve;
+    if (reml) logl_new += -0.5 * (logdet_Q - (double)C * bs.logdet_Ve);
+    if (t != 0 && fabs(logl_new - logl_old) < max_prec) break;
+    logl_old = logl_new;
+    // UltVehiB used by UpdateU (:674-686)
+    if (reml) {
+#pragma unroll
+      for (int i = 0; i < D * C; ++i) UltVehiB[i] = bl[i];
+    } else if (t == 0) {
+#pragma unroll
+      for (int l = 0; l < D; ++l)
+#pragma unroll
+        for (int j = 0; j < C; ++j) {
+          double s = 0.0;
+#pragma unroll
+          for (int i = 0; i < D; ++i) s += bs.UltVehi[l * D + i] * B[i * C + j];
+          UltVehiB[l * C + j] = s;
+        }
+    }
+    double Bnew[D * C]; // UltVehiB after UpdateL_B (ML) -- equal to UltVehiB for REML
+#pragma unroll
+    for (int i = 0; i < D * C; ++i) Bnew[i] = UltVehiB[i];
+    if (!reml) { // UpdateL_B :402-418: (UltVehiY - UltVehiU) X^T (X X^T)^-1
+      double YUX[D * C];
+#pragma unroll
+      for (int i = 0; i < D * C; ++i) YUX[i] = 0.0;
+      for (int k = Lanes::lane(); k < n; k += Lanes::N) {
+        const double delta = g.eval[k];
+        double xv[C], yv[D];
+#pragma unroll
+        for (int j = 0; j < C - 1; ++j) xv[j] = g.Wt[(long)j * n + k];
+        xv[C - 1] = x[k];
+#pragma unroll
+        for (int i = 0; i < D; ++i) yv[i] = g.Yt[(long)i * n + k];
+#pragma unroll
+        for (int l = 0; l < D; ++l) {
+          double yt = 0.0, bx = 0.0;
+#pragma unroll
+          for (int i = 0; i < D; ++i) yt += bs.UltVehi[l * D + i] * yv[i];
+#pragma unroll
+          for (int j = 0; j < C; ++j) bx += UltVehiB[l * C + j] * xv[j];
+          const double oe = delta * bs.Dl[l] / (delta * bs.Dl[l] + 1.0);
+          const double r = yt - (yt - bx) * oe;
+#pragma unroll
+          for (int j = 0; j < C; ++j) YUX[l * C + j] += r * xv[j];
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < D * C; ++i) YUX[i] = Lanes::sum(YUX[i]);
+#pragma unroll
+      for (int l = 0; l < D; ++l)
+#pragma unroll
+        for (int j = 0; j < C; ++j) {
+          double s = 0.0;
+#pragma unroll
+          for (int a = 0; a < C; ++a) s += YUX[l * C + a] * XXti[a * C + j];
+          Bnew[l * C + j] = s;
+        }
+    }
+    // U_hat, E_hat, Sigma (UpdateU / UpdateE / CalcSigma / UpdateV :686-708)
+    constexpr int TD = D * (D + 1) / 2;
+    double VgS[TD], VeS[TD], Suu[D], See[D];
+#pragma unroll
+    for (int i = 0; i < TD; ++i) VgS[i] = VeS[i] = 0.0;
+#pragma unroll
+    for (int i = 0; i < D; ++i) Suu[i] = See[i] = 0.0;
+    for (int k = Lanes::lane(); k < n; k += Lanes::N) {
+      const double delta = g.eval[k];
+      double xv[C], yv[D], Uv[D], Ev[D];
+#pragma unroll
+      for (int j = 0; j < C - 1; ++j) xv[j] = g.Wt[(long)j * n + k];
+      xv[C - 1] = x[k];
+#pragma unroll
+      for (int i = 0; i < D; ++i) yv[i] = g.Yt[(long)i * n + k];
+#pragma unroll
+      for (int l = 0; l < D; ++l) {
+        const double w = 1.0 / (delta * bs.Dl[l] + 1.0), ou = bs.Dl[l] * w, oe = delta * ou;
+        double yt = 0.0, bx0 = 0.0, bx1 = 0.0;
+#pragma unroll
+        for (int i = 0; i < D; ++i) yt += bs.UltVehi[l * D + i] * yv[i];
+#pragma unroll
+        for (int j = 0; j < C; ++j) {
+          bx0 += UltVehiB[l * C + j] * xv[j];
+          bx1 += Bnew[l * C + j] * xv[j];
+        }
+        Uv[l] = (yt - bx0) * oe;
+        Ev[l] = yt - bx1 - Uv[l];
+        double su = ou, se = oe;
+        if (reml) { // x^T Q_l^-1 x
+          double q = 0.0;
+#pragma unroll
+          for (int a = 0; a < C; ++a)
+#pragma unroll
+            for (int b = 0; b < C; ++b) q += xv[a] * Qi[l][a * C + b] * xv[b];
+          su += delta * ou * ou * q;
+          se += w * w * q;
+        }
+        Suu[l] += su;
+        See[l] += se;
+      }
+      double Uh[D], Eh[D];
+#pragma unroll
+      for (int a = 0; a < D; ++a) {
+        double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+        for (int l = 0; l < D; ++l) {
+          s1 += bs.UltVeh[l * D + a] * Uv[l];
+          s2 += bs.UltVeh[l * D + a] * Ev[l];
+        }
+        Uh[a] = s1;
+        Eh[a] = s2;
+      }
+      const double di = (delta != 0.0) ? 1.0 / delta : 0.0;
+      int t2 = 0;
+#pragma unroll
+      for (int a = 0; a < D; ++a)
+#pragma unroll
+        for (int b = a; b < D; ++b, ++t2) {
+          VgS[t2] += Uh[a] * Uh[b] * di;
+          VeS[t2] += Eh[a] * Eh[b];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < TD; ++i) {
+      VgS[i] = Lanes::sum(VgS[i]);
+      VeS[i] = Lanes::sum(VeS[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+      Suu[i] = Lanes::sum(Suu[i]);
+      See[i] = Lanes::sum(See[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < D * C; ++i) UltVehiB[i] = Bnew[i];
+    // B = UltVeh^T UltVehiB; V = (sums + UltVeh^T diag(S) UltVeh) / n
+#pragma unroll
+    for (int a = 0; a < D; ++a)
+#pragma unroll
+      for (int j = 0; j < C; ++j) {
+        double s = 0.0;
+#pragma unroll
+        for (int l = 0; l < D; ++l) s += bs.UltVeh[l * D + a] * UltVehiB[l * C + j];
+        B[a * C + j] = s;
+      }
+    int t2 = 0;
+#pragma unroll
+    for (int a = 0; a < D; ++a)
+#pragma unroll
+      for (int b = a; b < D; ++b, ++t2) {
+        double su = 0.0, se = 0.0;
+#pragma unroll
+        for (int l = 0; l < D; ++l) {
+          su += bs.UltVeh[l * D + a] * Suu[l] * bs.UltVeh[l * D + b];
+          se += bs.UltVeh[l * D + a] * See[l] * bs.UltVeh[l * D + b];
+        }
+        Vg[a * D + b] = Vg[b * D + a] = (VgS[t2] + su) / (double)n;
+        Ve[a * D + b] = Ve[b * D + a] = (VeS[t2] + se) / (double)n;
+      }
+  }
+  return logl_new;
+}
+
+// MphCalcP, src/mvlmm.cpp:727-831: the covariates are the first C - 1 rows, the SNP the last; beta (d), Vbeta (d x d)
+template <int D, int C, class Lanes>
+MV_HD double mv_calcp(const MvArgs &g, const double *__restrict__ x, const double (&Vg)[D * D], const double (&Ve)[D * D],
+                      double (&beta)[D], double (&Vbeta)[D * D]) {
+  constexpr int T = C * (C + 1) / 2, CW = C - 1;
+  MvBasis<D> bs;
+  MvMoments<D, C> m;
+  bs.build(Vg, Ve);
+  mv_pass_moments<D, C, Lanes>(g, x, bs, m);
+  double sol[D], vinv[D], stat = 0.0;
+#pragma unroll
+  for (int l = 0; l < D; ++l) {
+    double Ql[C * C];
+    mv_unpack_sym<C>(m.Q + l * T, Ql);
+    double xPx = Ql[(C - 1) * C + (C - 1)], xPy = m.xHiy[l * C + (C - 1)];
+    if (CW > 0) {
+      double QW[(CW > 0 ? CW : 1) * (CW > 0 ? CW : 1)], QWi[(CW > 0 ? CW : 1) * (CW > 0 ? CW : 1)];
+#pragma unroll
+      for (int a = 0; a < CW; ++a)
+#pragma unroll
+        for (int b = 0; b < CW; ++b) QW[a * CW + b] = Ql[a * C + b];
+      mv_spd_inverse<(CW > 0 ? CW : 1)>(QW, QWi);
+#pragma unroll
+      for (int a = 0; a < CW; ++a) {
+        double s = 0.0;
+#pragma unroll
+        for (int b = 0; b < CW; ++b) s += QWi[a * CW + b] * Ql[b * C + (C - 1)]; // Qi WHix
+        xPx -= Ql[a * C + (C - 1)] * s;
+        xPy -= s * m.xHiy[l * C + a];
+      }
+    }
+    sol[l] = xPy / xPx;
+    vinv[l] = 1.0 / xPx;
+    stat += sol[l] * xPy;
+  }
+#pragma unroll
+  for (int a = 0; a < D; ++a) {
+    double s = 0.0;
+#pragma unroll
+    for (int l = 0; l < D; ++l) s += bs.UltVeh[l * D + a] * sol[l];
+    beta[a] = s;
+#pragma unroll
+    for (int b = 0; b < D; ++b) {
+      double v = 0.0;
+#pragma unroll
+      for (int l = 0; l < D; ++l) v += bs.UltVeh[l * D + a] * vinv[l] * bs.UltVeh[l * D + b];
+      Vbeta[a * D + b] = v;
+    }
+  }
+  return mv_chisq_Q(stat, D);
+}
+
+// ---------------------------------------------------------------- MphNR (src/mvlmm.cpp:2608-2760)
+// index of the pair (a <= b) in a packed upper triangle of order N (GetIndex :1093-1109)
+MV_HD constexpr int mv_tri(int a, int b, int N) { return a <= b ? (2 * N - a + 1) * a / 2 + b - a : (2 * N - b + 1) * b / 2 + a - b; }
+
+// Per-wavefront scratch of the Newton-Raphson stage (LDS on the GPU): the moment tables below are independent of the
+// derivative direction, so one sweep of 3 d passes serves the whole gradient and Hessian.  With w_l = 1/(delta D_l + 1),
+// u = w o (UltVehi y - Btilde x)  (= the rotated (P y)_k), weights delta^a (a = 0: V_e, 1: V_g) and delta^s (s = a1 + a2):
+//   W1[a][l]          sum w_l                      UU[a][p<=q]           sum u_p u_q
+//   R[a][j][l][q]     sum x_j w_l u_q              S[a][l1<=l2][j1<=j2]  sum x_j1 x_j2 w_l1 w_l2
+//   WW[s][l1<=l2]     sum w_l1 w_l2                Y3[s][q][p<=r]        sum u_p w_q u_r
+//   S3[s][l][q][j1<=j2] sum x_j1 x_j2 w_l^2 w_q
+template <int D, int C> struct MvNrScratch {
+  static constexpr int T = C * (C + 1) / 2, TD = D * (D + 1) / 2, VS = TD, H2 = 2 * VS;
+  static constexpr int W1 = 0, UU = W1 + 2 * D, R = UU + 2 * TD, S = R + 2 * C * D * D, WW = S + 2 * TD * T;
+  static constexpr int Y3 = WW + 3 * TD, S3 = Y3 + 3 * D * TD, DT = S3 + 3 * D * D * T; // DT: rotated directions
+  static constexpr int QI = DT + VS * D * D, GRAD = QI + D * C * C, HESS = GRAD + H2, HINV = HESS + H2 * H2;
+  static constexpr int LU = HINV + H2 * H2, DOUBLES = LU + H2 * H2;
+};
+
+MV_HD void mv_lane_fence() {
+#ifdef __HIPCC__
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+#endif
+}
+
+template <int D, int C, class Lanes> struct MvNr {
+  using SC = MvNrScratch<D, C>;
+  static constexpr int T = SC::T, TD = SC::TD, VS = SC::VS, H2 = SC::H2;
+  const MvArgs &g;
+  double *lds;            // SC::DOUBLES doubles owned by this wavefront
+  const double *x = nullptr;
+
+  // logl at (Vg, Ve) and, if want_dev, gradient + CalcDev's Hessian in lds[GRAD], lds[HESS]
+  MV_HD double eval(bool reml, double logl_const, const double (&Vg)[D * D], const double (&Ve)[D * D], bool want_dev) {
+    const int n = g.n;
+    MvBasis<D> bs;
+    MvMoments<D, C> m;
+    bs.build(Vg, Ve);
+    mv_pass_moments<D, C, Lanes>(g, x, bs, m);
+    double logdet_Q = 0.0, quad = 0.0, Bt[D * C], Qi[D][C * C];
+#pragma unroll
+    for (int l = 0; l < D; ++l) {
+      double Ql[C * C];
+      mv_unpack_sym<C>(m.Q + l * T, Ql);
+      logdet_Q += mv_spd_inverse<C>(Ql, Qi[l]);
+#pragma unroll
+      for (int a = 0; a < C; ++a) {
+        double s = 0.0;
+#pragma unroll
+        for (int b = 0; b < C; ++b) s += Qi[l][a * C + b] * m.xHiy[l * C + b];
+        Bt[l * C + a] = s;
+        quad += s * m.xHiy[l * C + a];
+      }
+    }
+    double logl = logl_const - 0.5 * (m.ll - quad) - 0.5 * (double)n * bs.logdet_Ve;
+    if (reml) logl += -0.5 * (logdet_Q - (double)C * bs.logdet_Ve);
+    if (!want_dev) return logl;
+
+    // ---- moment passes: one per (power of delta, first component index)
+    for (int s = 0; s < 3; ++s)
+#pragma unroll
+      for (int l1 = 0; l1 < D; ++l1) {
+        double aW1 = 0.0, aUU[TD], aR[C * D], aS[D * T], aWW[D], aY3[TD], aS3[D * T];
+#pragma unroll
+        for (int i = 0; i < TD; ++i) aUU[i] = aY3[i] = 0.0;
+#pragma unroll
+        for (int i = 0; i < C * D; ++i) aR[i] = 0.0;
+#pragma unroll
+        for (int i = 0; i < D * T; ++i) aS[i] = aS3[i] = 0.0;
+#pragma unroll
+        for (int i = 0; i < D; ++i) aWW[i] = 0.0;
+        for (int k = Lanes::lane(); k < n; k += Lanes::N) {
+          const double delta = g.eval[k];
+          const double ws = (s == 0) ? 1.0 : (s == 1 ? delta : delta * delta);
+          double xv[C], yv[D], w[D], u[D];
+#pragma unroll
+          for (int j = 0; j < C - 1; ++j) xv[j] = g.Wt[(long)j * n + k];
+          xv[C - 1] = x[k];
+#pragma unroll
+          for (int i = 0; i < D; ++i) yv[i] = g.Yt[(long)i * n + k];
+#pragma unroll
+          for (int l = 0; l < D; ++l) {
+            w[l] = 1.0 / (delta * bs.Dl[l] + 1.0);
+            double yt = 0.0, bx = 0.0;
+#pragma unroll
+            for (int i = 0; i < D; ++i) yt += bs.UltVehi[l * D + i] * yv[i];
+#pragma unroll
+            for (int j = 0; j < C; ++j) bx += Bt[l * C + j] * xv[j];
+            u[l] = w[l] * (yt - bx);
+          }
+          const double wl = ws * w[l1];
+          aW1 += wl;
+          if (l1 == 0) {
+            int t = 0;
+#pragma unroll
+            for (int p = 0; p < D; ++p)
+#pragma unroll
+              for (int q = p; q < D; ++q, ++t) aUU[t] += ws * u[p] * u[q];
+          }
+#pragma unroll
+          for (int j = 0; j < C; ++j)
+#pragma unroll
+            for (int q = 0; q < D; ++q) aR[j * D + q] += wl * xv[j] * u[q];
+          {
+            int t = 0;
+#pragma unroll
+            for (int p = 0; p < D; ++p)
+#pragma unroll
+              for (int r = p; r < D; ++r, ++t) aY3[t] += wl * u[p] * u[r];
+          }
+#pragma unroll
+          for (int l2 = 0; l2 < D; ++l2) {
+            const double ww = wl * w[l2];
+            aWW[l2] += ww;          // only l2 >= l1 is stored
+            int t = 0;
+#pragma unroll
+            for (int j1 = 0; j1 < C; ++j1)
+#pragma unroll
+              for (int j2 = j1; j2 < C; ++j2, ++t) {
+                const double xx = xv[j1] * xv[j2];
+                aS[l2 * T + t] += ww * xx;              // x x w_l1 w_l2
+                aS3[l2 * T + t] += ww * w[l1] * xx;     // x x w_l1^2 w_q   (q = l2)
+              }
+          }
+        }
+        // reduce and store (every lane holds the totals; lane 0 writes)
+        const bool wr = Lanes::lane() == 0;
+        if (s < 2) {
+          const double v = Lanes::sum(aW1);
+          if (wr) lds[SC::W1 + s * D + l1] = v;
+          if (l1 == 0)
+#pragma unroll
+            for (int i = 0; i < TD; ++i) {
+              const double v2 = Lanes::sum(aUU[i]);
+              if (wr) lds[SC::UU + s * TD + i] = v2;
+            }
+#pragma unroll
+          for (int j = 0; j < C; ++j)
+#pragma unroll
+            for (int q = 0; q < D; ++q) {
+              const double v2 = Lanes::sum(aR[j * D + q]);
+              if (wr) lds[SC::R + ((s * C + j) * D + l1) * D + q] = v2;
+            }
+#pragma unroll
+          for (int l2 = l1; l2 < D; ++l2)
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+              const double v2 = Lanes::sum(aS[l2 * T + t]);
+              if (wr) lds[SC::S + (s * TD + mv_tri(l1, l2, D)) * T + t] = v2;
+            }
+        }
+#pragma unroll
+        for (int l2 = l1; l2 < D; ++l2) {
+          const double v2 = Lanes::sum(aWW[l2]);
+          if (wr) lds[SC::WW + s * TD + mv_tri(l1, l2, D)] = v2;
+        }
+#pragma unroll
+        for (int i = 0; i < TD; ++i) {
+          const double v2 = Lanes::sum(aY3[i]);
+          if (wr) lds[SC::Y3 + (s * D + l1) * TD + i] = v2;
+        }
+#pragma unroll
+        for (int q = 0; q < D; ++q)
+#pragma unroll
+          for (int t = 0; t < T; ++t) {
+            const double v2 = Lanes::sum(aS3[q * T + t]);
+            if (wr) lds[SC::S3 + ((s * D + l1) * D + q) * T + t] = v2;
+          }
+      }
+    // rotated directions and the Q blocks
+    if (Lanes::lane() == 0) {
+#pragma unroll
+      for (int i = 0; i < D; ++i)
+#pragma unroll
+        for (int j = i; j < D; ++j) {
+          const int v = mv_tri(i, j, D);
+#pragma unroll
+          for (int p = 0; p < D; ++p)
+#pragma unroll
+            for (int q = 0; q < D; ++q) {
+              const double a = bs.UltVehi[p * D + i] * bs.UltVehi[q * D + j];
+              lds[SC::DT + (v * D + p) * D + q] = (i == j) ? a : a + bs.UltVehi[p * D + j] * bs.UltVehi[q * D + i];
+            }
+        }
+#pragma unroll
+      for (int l = 0; l < D; ++l)
+#pragma unroll
+        for (int t = 0; t < C * C; ++t) lds[SC::QI + l * C * C + t] = Qi[l][t];
+    }
+    mv_lane_fence();
+    contract(reml);
+    mv_lane_fence();
+    return logl;
+  }
+
+  // symmetric c x c block stored as a packed triangle
+  MV_HD double symget(const double *tri, int a, int b) const { return tri[mv_tri(a, b, C)]; }
+
+  // gradient and Hessian from the tables (every lane computes the same values; plain loops over LDS)
+  MV_HD void contract(bool reml) {
+    const double *DT = lds + SC::DT, *QI = lds + SC::QI;
+    double *grad = lds + SC::GRAD, *hess = lds + SC::HESS;
+    for (int v = 0; v < VS; ++v) {
+      const double *Dv = DT + v * D * D;
+      for (int a = 0; a < 2; ++a) {
+        double yPDPy = 0.0, trHiD = 0.0, trQM = 0.0;
+        for (int p = 0; p < D; ++p)
+          for (int q = 0; q < D; ++q) yPDPy += Dv[p * D + q] * lds[SC::UU + a * TD + mv_tri(p, q, D)];
+        for (int l = 0; l < D; ++l) {
+          trHiD += Dv[l * D + l] * lds[SC::W1 + a * D + l];
+          if (reml) {
+            const double *Sl = lds + SC::S + (a * TD + mv_tri(l, l, D)) * T;
+            double t = 0.0;
+            for (int j1 = 0; j1 < C; ++j1)
+              for (int j2 = 0; j2 < C; ++j2) t += QI[l * C * C + j1 * C + j2] * symget(Sl, j1, j2);
+            trQM += Dv[l * D + l] * t;
+          }
+        }
+        grad[(a ? 0 : VS) + v] = -0.5 * (trHiD - trQM) + 0.5 * yPDPy;
+      }
+    }
+    for (int i = 0; i < H2 * H2; ++i) hess[i] = 0.0;
+    for (int v1 = 0; v1 < VS; ++v1)
+      for (int v2 = v1; v2 < VS; ++v2) {
+        const double *D1 = DT + v1 * D * D, *D2 = DT + v2 * D * D;
+        double dev2[3];
+        for (int sI = 0; sI < 3; ++sI) { // ee, ge (D1 = V_g direction, D2 = V_e direction), gg
+          const int a1 = sI >= 1, a2 = sI == 2;
+          double yy = 0.0, trHH = 0.0, t2 = 0.0, t4 = 0.0, rQr = 0.0;
+          for (int q = 0; q < D; ++q) {
+            const double *Y3q = lds + SC::Y3 + (sI * D + q) * TD;
+            for (int p = 0; p < D; ++p)
+              for (int r = 0; r < D; ++r) yy += D1[q * D + p] * D2[q * D + r] * Y3q[mv_tri(p, r, D)];
+          }
+          for (int l = 0; l < D; ++l) {
+            double r1[C], r2[C];
+            for (int j = 0; j < C; ++j) {
+              double s1 = 0.0, s2 = 0.0;
+              for (int q = 0; q < D; ++q) {
+                s1 += D1[l * D + q] * lds[SC::R + ((a1 * C + j) * D + l) * D + q];
+                s2 += D2[l * D + q] * lds[SC::R + ((a2 * C + j) * D + l) * D + q];
+              }
+              r1[j] = s1;
+              r2[j] = s2;
+            }
+            for (int j1 = 0; j1 < C; ++j1)
+              for (int j2 = 0; j2 < C; ++j2) rQr += r1[j1] * QI[l * C * C + j1 * C + j2] * r2[j2];
+          }
+          for (int l1 = 0; l1 < D; ++l1)
+            for (int l2 = 0; l2 < D; ++l2) {
+              const double dd = D1[l1 * D + l2] * D2[l2 * D + l1];
+              trHH += dd * lds[SC::WW + sI * TD + mv_tri(l1, l2, D)];
+              if (reml) {
+                const double *S3 = lds + SC::S3 + ((sI * D + l1) * D + l2) * T; // q = l2
+                double t = 0.0;
+                for (int j1 = 0; j1 < C; ++j1)
+                  for (int j2 = 0; j2 < C; ++j2) t += QI[l1 * C * C + j1 * C + j2] * symget(S3, j1, j2);
+                t2 += dd * t;
+                const double *A = lds + SC::S + (a1 * TD + mv_tri(l1, l2, D)) * T;
+                const double *Bm = lds + SC::S + (a2 * TD + mv_tri(l1, l2, D)) * T;
+                double tr = 0.0; // tr(Qi_l1 A Qi_l2 B)
+                for (int i1 = 0; i1 < C; ++i1)
+                  for (int i2 = 0; i2 < C; ++i2) {
+                    double qa = 0.0, qb = 0.0; // (Qi_l1 A)[i1][i2], (Qi_l2 B)[i2][i1]
+                    for (int t3 = 0; t3 < C; ++t3) {
+                      qa += QI[l1 * C * C + i1 * C + t3] * symget(A, t3, i2);
+                      qb += QI[l2 * C * C + i2 * C + t3] * symget(Bm, t3, i1);
+                    }
+                    tr += qa * qb;
+                  }
+                t4 += dd * tr;
+              }
+            }
+          double tr = trHH;
+          if (reml) tr += -2.0 * t2 + t4;
+          dev2[sI] = 0.5 * tr - (yy - rQr);
+        }
+        hess[v1 * H2 + v2] = hess[v2 * H2 + v1] = dev2[2];
+        hess[(v1 + VS) * H2 + v2 + VS] = hess[(v2 + VS) * H2 + v1 + VS] = dev2[0];
+        hess[v1 * H2 + v2 + VS] = hess[(v2 + VS) * H2 + v1] = dev2[1]; // mirrored as :2494-2504 does
+        hess[v2 * H2 + v1 + VS] = hess[(v1 + VS) * H2 + v2] = dev2[1];
+      }
+  }
+
+  // Hinv = HESS^-1 by LU with partial pivoting (LUDecomp / LUInvert :2510-2518), in scratch
+  MV_HD void invert_hessian() {
+    double *lu = lds + SC::LU, *Hi = lds + SC::HINV;
+    const double *H = lds + SC::HESS;
+    for (int i = 0; i < H2 * H2; ++i) lu[i] = H[i];
+    int perm[H2];
+    for (int i = 0; i < H2; ++i) perm[i] = i;
+    for (int j = 0; j < H2; ++j) {
+      int ip = j;
+      double amax = fabs(lu[j * H2 + j]);
+      for (int i = j + 1; i < H2; ++i)
+        if (fabs(lu[i * H2 + j]) > amax) {
+          amax = fabs(lu[i * H2 + j]);
+          ip = i;
+        }
+      if (ip != j) {
+        for (int k = 0; k < H2; ++k) {
+          const double t = lu[j * H2 + k];
+          lu[j * H2 + k] = lu[ip * H2 + k];
+          lu[ip * H2 + k] = t;
+        }
+        const int t = perm[j];
+        perm[j] = perm[ip];
+        perm[ip] = t;
+      }
+      const double ajj = lu[j * H2 + j];
+      if (ajj != 0.0)
+        for (int i = j + 1; i < H2; ++i) {
+          const double f = lu[i * H2 + j] / ajj;
+          lu[i * H2 + j] = f;
+          for (int k = j + 1; k < H2; ++k) lu[i * H2 + k] -= f * lu[j * H2 + k];
+        }
+    }
+    for (int col = 0; col < H2; ++col) {
+      double xs[H2];
+      for (int i = 0; i < H2; ++i) xs[i] = (perm[i] == col) ? 1.0 : 0.0;
+      for (int i = 0; i < H2; ++i)
+        for (int k = 0; k < i; ++k) xs[i] -= lu[i * H2 + k] * xs[k];
+      for (int ii = H2 - 1; ii >= 0; --ii) {
+        for (int k = ii + 1; k < H2; ++k) xs[ii] -= lu[ii * H2 + k] * xs[k];
+        xs[ii] /= lu[ii * H2 + ii];
+      }
+      for (int i = 0; i < H2; ++i) Hi[i * H2 + col] = xs[i];
+    }
+  }
+
+  MV_HD static bool is_pd(const double (&V)[D * D]) {
+    double w[D], Z[D * D];
+    mv_jacobi<D>(V, w, Z);
+    bool ok = true;
+#pragma unroll
+    for (int i = 0; i < D; ++i) ok = ok && (w[i] > 0);
+    return ok;
+  }
+
+  // MphNR with the per-SNP limits (nr_iter / 10, nr_prec * 10); returns logl_H1
+  MV_HD double operator()(bool reml, double lndet_xxt, double (&Vg)[D * D], double (&Ve)[D * D]) {
+    constexpr double LOG2PI = 1.8378770664093454836;
+    const int n = g.n;
+    const double logl_const = reml ? -0.5 * (double)(n - C) * (double)D * LOG2PI + 0.5 * (double)D * lndet_xxt
+                                   : -0.5 * (double)n * (double)D * LOG2PI;
+    double Vg_save[D * D], Ve_save[D * D];
+    double logl_old = 0.0, logl_new = 0.0;
+    const double *Hi = lds + SC::HINV, *grad = lds + SC::GRAD;
+    for (int t = 0; t < g.nr_iter; ++t) {
+#pragma unroll
+      for (int i = 0; i < D * D; ++i) {
+        Vg_save[i] = Vg[i];
+        Ve_save[i] = Ve[i];
+      }
+      double step_scale = 1.0;
+      int step_iter = 0;
+      bool flag_pd;
+      do {
+#pragma unroll
+        for (int i = 0; i < D * D; ++i) {
+          Vg[i] = Vg_save[i];
+          Ve[i] = Ve_save[i];
+        }
+        if (t != 0) { // UpdateVgVe :2557-2606
+#pragma unroll
+          for (int i = 0; i < D; ++i)
+#pragma unroll
+            for (int j = i; j < D; ++j) {
+              const int v = mv_tri(i, j, D);
+              double sg = 0.0, se = 0.0;
+              for (int q = 0; q < H2; ++q) {
+                sg += Hi[v * H2 + q] * grad[q];
+                se += Hi[(v + VS) * H2 + q] * grad[q];
+              }
+              Vg[i * D + j] = Vg[j * D + i] = Vg_save[i * D + j] - step_scale * sg;
+              Ve[i * D + j] = Ve[j * D + i] = Ve_save[i * D + j] - step_scale * se;
+            }
+        }
+        flag_pd = is_pd(Ve) && is_pd(Vg);
+        if (flag_pd) logl_new = eval(reml, logl_const, Vg, Ve, false);
+        step_scale /= 2.0;
+        step_iter++;
+      } while ((!flag_pd || logl_new < logl_old || logl_new - logl_old > 10) && step_iter < 10 && t != 0);
+      if (t != 0) {
+        if (logl_new < logl_old || !flag_pd) {
+#pragma unroll
+          for (int i = 0; i < D * D; ++i) {
+            Vg[i] = Vg_save[i];
+            Ve[i] = Ve_save[i];
+          }
+          break;
+        }
+        if (logl_new - logl_old < g.nr_prec) break;
+      }
+      logl_old = logl_new;
+      eval(reml, logl_const, Vg, Ve, true);
+      invert_hessian();
+      mv_lane_fence();
+    }
+    return logl_new;
+  }
+};
+
+// One SNP: the body of the loop at src/mvlmm.cpp:3287-3374 (crt = 0).  nr: callable (reml) -> logl_H1 that refines
+// Vg, Ve by Newton-Raphson, or a no-op returning NaN when the stage is not compiled in.
+template <int D, int C, class Lanes, class NR>
+MV_HD void mv_one_snp(const MvArgs &g, long s, NR &&nr) {
+  constexpr int CW = C - 1;
+  const double *__restrict__ x = g.UtX + s * g.ld;
+  double Vg[D * D], Ve[D * D], Vg0[D * D], Ve0[D * D], B[D * C], beta[D], Vbeta[D * D], XXti[C * C];
+#pragma unroll
+  for (int i = 0; i < D * D; ++i) {
+    Vg[i] = Vg0[i] = g.Vg_null[i];
+    Ve[i] = Ve0[i] = g.Ve_null[i];
+    Vbeta[i] = 0.0;
+  }
+#pragma unroll
+  for (int i = 0; i < D; ++i) {
+    beta[i] = 0.0;
+#pragma unroll
+    for (int j = 0; j < CW; ++j) B[i * C + j] = g.B_null[i * CW + j];
+    B[i * C + CW] = 0.0;
+  }
+  const double lndet_xxt = mv_xxt<C, Lanes>(g, x, XXti);
+  double p_wald = 0.0, p_lrt = 0.0, p_score = 0.0;
+  if (g.a_mode == 3 || g.a_mode == 4) p_score = mv_calcp<D, C, Lanes>(g, x, Vg0, Ve0, beta, Vbeta);
+  if (g.a_mode == 2 || g.a_mode == 4) {
+    double logl_H1 = mv_em<D, C, Lanes>(g, x, false, g.em_iter, g.em_prec, lndet_xxt, XXti, Vg, Ve, B);
+    mv_calcp<D, C, Lanes>(g, x, Vg, Ve, beta, Vbeta);
+    p_lrt = mv_chisq_Q(2.0 * (logl_H1 - g.logl_H0), D);
+    if (p_lrt < g.p_nr) {
+      logl_H1 = nr(false, lndet_xxt, Vg, Ve);
+      mv_calcp<D, C, Lanes>(g, x, Vg, Ve, beta, Vbeta);
+      p_lrt = mv_chisq_Q(2.0 * (logl_H1 - g.logl_H0), D);
+    }
+  }
+  if (g.a_mode == 1 || g.a_mode == 4) {
+    mv_em<D, C, Lanes>(g, x, true, g.em_iter, g.em_prec, lndet_xxt, XXti, Vg, Ve, B);
+    p_wald = mv_calcp<D, C, Lanes>(g, x, Vg, Ve, beta, Vbeta);
+    if (p_wald < g.p_nr) {
+      nr(true, lndet_xxt, Vg, Ve);
+      p_wald = mv_calcp<D, C, Lanes>(g, x, Vg, Ve, beta, Vbeta);
+    }
+  }
+  if (Lanes::lane() == 0) {
+    constexpr int V = D * (D + 1) / 2;
+    double *o = g.out + s * g.stride;
+#pragma unroll
+    for (int i = 0; i < D; ++i) o[i] = beta[i];
+    int q = 0;
+#pragma unroll
+    for (int i = 0; i < D; ++i)
+#pragma unroll
+      for (int j = i; j < D; ++j, ++q) {
+        o[D + q] = Vbeta[i * D + j];
+        o[D + V + q] = Vg[i * D + j];
+        o[D + 2 * V + q] = Ve[i * D + j];
+      }
+    o[D + 3 * V] = p_wald;
+    o[D + 3 * V + 1] = p_lrt;
+    o[D + 3 * V + 2] = p_score;
+  }
+}
+
+} // namespace gemma_hip
+
+// ---------------------------------------------------------------- null model (src/mvlmm.cpp:3056-3208)
+namespace gemma_hip {
+
+// B = GLS estimate of the fixed effects at (Vg, Ve): what MphCalcBeta (:835-935) leaves in B
+template <int D, int C, class Lanes>
+MV_HD void mv_gls_B(const MvArgs &g, const double *__restrict__ x, const double (&Vg)[D * D], const double (&Ve)[D * D],
+                    double (&B)[D * C]) {
+  constexpr int T = C * (C + 1) / 2;
+  MvBasis<D> bs;
+  MvMoments<D, C> m;
+  bs.build(Vg, Ve);
+  mv_pass_moments<D, C, Lanes>(g, x, bs, m);
+  double bl[D * C];
+#pragma unroll
+  for (int l = 0; l < D; ++l) {
+    double Ql[C * C], Qi[C * C];
+    mv_unpack_sym<C>(m.Q + l * T, Ql);
+    mv_spd_inverse<C>(Ql, Qi);
+#pragma unroll
+    for (int a = 0; a < C; ++a) {
+      double s = 0.0;
+#pragma unroll
+      for (int b = 0; b < C; ++b) s += Qi[a * C + b] * m.xHiy[l * C + b];
+      bl[l * C + a] = s;
+    }
+  }
+#pragma unroll
+  for (int a = 0; a < D; ++a)
+#pragma unroll
+    for (int j = 0; j < C; ++j) {
+      double s = 0.0;
+#pragma unroll
+      for (int l = 0; l < D; ++l) s += bs.UltVeh[l * D + a] * bl[l * C + j];
+      B[a * C + j] = s;
+    }
+}
+
+struct MvNullArgs {
+  MvArgs g;            // eval, Wt (all c covariate rows: the last one plays the "x" row), Yt, n; nr_iter / nr_prec
+  int em_iter;
+  double em_prec;
+  double Vg0[MV_DMAX * MV_DMAX], Ve0[MV_DMAX * MV_DMAX]; // MphInitial's starting point
+  double *out;         // 2 x (d*d + d*d + d*c + 1): REMLE then MLE block: Vg, Ve, B (d x c), logl
+};
+
+// EM + NR for REML, then for ML starting from the REML fit; one "lane group" does the whole fit
+template <int D, int C, class Lanes> MV_HD void mv_null_fit(const MvNullArgs &a, double *scratch) {
+  const MvArgs &g = a.g;
+  const double *x = g.Wt + (long)(C - 1) * g.n;
+  double Vg[D * D], Ve[D * D], B[D * C], XXti[C * C];
+#pragma unroll
+  for (int i = 0; i < D * D; ++i) {
+    Vg[i] = a.Vg0[i];
+    Ve[i] = a.Ve0[i];
+  }
+#pragma unroll
+  for (int i = 0; i < D * C; ++i) B[i] = 0.0;
+  const double lndet_xxt = mv_xxt<C, Lanes>(g, x, XXti);
+  MvNr<D, C, Lanes> nr{g, scratch};
+  nr.x = x;
+  constexpr int BLK = 2 * D * D + D * C + 1;
+  for (int pass = 0; pass < 2; ++pass) {
+    const bool reml = pass == 0;
+    mv_em<D, C, Lanes>(g, x, reml, a.em_iter, a.em_prec, lndet_xxt, XXti, Vg, Ve, B);
+    const double logl = nr(reml, lndet_xxt, Vg, Ve);
+    mv_gls_B<D, C, Lanes>(g, x, Vg, Ve, B);
+    if (Lanes::lane() == 0) {
+      double *o = a.out + pass * BLK;
+#pragma unroll
+      for (int i = 0; i < D * D; ++i) {
+        o[i] = Vg[i];
+        o[D * D + i] = Ve[i];
+      }
+#pragma unroll
+      for (int i = 0; i < D * C; ++i) o[2 * D * D + i] = B[i];
+      o[2 * D * D + D * C] = logl;
+    }
+  }
+}
+
+} // namespace gemma_hip

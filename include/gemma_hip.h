@@ -199,6 +199,35 @@ int gemma_hip_lmm_assoc_d(const double *UtX_d, size_t l, size_t ld_utx, gemma_su
  * minutes, the unit of LMM::time_UtX / time_opt (src/lmm.cpp:1523,1556) */
 int gemma_hip_lmm_finish(double *time_UtX_min, double *time_opt_min);
 
+/* ---- multivariate LMM (-lmm 1..4 -n a b c ...) ------------------------------------ */
+/* MVLMM::AnalyzeBimbam / AnalyzePlink, src/mvlmm.cpp:2972-3416 / :3418-3899.  d phenotypes (1..5), n_cvt covariates
+ * (1..3); crt = 0 (the Edgeworth correction CalcCRT / PCRT, :2054-2358 / :2952-2970, is not built).
+ * gemma_mvlmm_null holds what the null-model block (:3056-3208) leaves behind: V_g, V_e (d x d row-major, leading
+ * dimension d), B (d x n_cvt) and the log-likelihood, for the REMLE and the MLE fit. */
+typedef struct {
+  double Vg_remle[25], Ve_remle[25], B_remle[20], logl_remle_H0;
+  double Vg_mle[25], Ve_mle[25], B_mle[20], logl_mle_H0;
+} gemma_mvlmm_null;
+/* PARAM defaults (src/param.cpp:94-107): em_iter 10000, em_prec 1e-4, nr_iter 100, nr_prec 1e-4, p_nr 1e-3 */
+typedef struct {
+  size_t em_iter, nr_iter;
+  double em_prec, nr_prec, p_nr;
+} gemma_mvlmm_opt;
+/* The null block: MphInitial (:2763-2948; one univariate REML fit per trait, and for d > 4 one two-trait fit per pair),
+ * MphEM + MphNR + MphCalcBeta for 'R', then for 'L' starting from the REMLE fit.  Host pointers: eval (n), UtW (n x
+ * n_cvt row-major), UtY (n x d row-major) -- the arguments of AnalyzeBimbam.  Stand-alone (no lmm_setup needed). */
+int gemma_hip_mvlmm_null(size_t n, size_t n_cvt, size_t d, const double *eval, const double *UtW, const double *UtY,
+                         double l_min, double l_max, size_t n_region, const gemma_mvlmm_opt *opt, gemma_mvlmm_null *out);
+/* After gemma_hip_lmm_setup (which holds U, eval, UtW, cfg.a_mode, cfg.n, cfg.n_cvt; its Uty slot is not read by this
+ * path): the rotated phenotypes UtY (n x d row-major, host) and the null fit the per-SNP loop starts from (:3206-3208:
+ * the MLE block; logl_mle_H0 is the LRT reference). */
+int gemma_hip_mvlmm_set(size_t d, const double *UtY, const gemma_mvlmm_null *null_fit, const gemma_mvlmm_opt *opt);
+/* One block of SNPs (:3218-3375), same genotype encodings / indicator mapping / imputation as lmm_batch.  Per SNP the
+ * record MPHSUMSTAT (src/param.h:68-77) as doubles: beta[d], Vbeta[v], Vg[v], Ve[v], p_wald, p_lrt, p_score with
+ * v = d (d + 1) / 2 (upper triangles, row by row) -- out holds l x (d + 3 v + 3) doubles. */
+int gemma_hip_mvlmm_batch(int geno_kind, const void *geno, size_t l, size_t ld, double *out);
+int gemma_hip_mvlmm_batch_d(int geno_kind, const void *geno_d, size_t l, size_t ld, double *out_d, void *stream);
+
 /* ---- linear model without a random effect (-lm 1..4) ----------------------- */
 /* LM::AnalyzeBimbam / AnalyzePlink, src/lm.cpp:382-640 (CalcvPv :224-263, LmCalcP :266-287): per SNP ordinary
  * regression of y on (W, x); a_mode 51 Wald, 52 LRT, 53 score, 54 all (src/gemma.h:39-43).  W (n x n_cvt) and y are

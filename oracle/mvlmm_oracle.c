@@ -1,0 +1,905 @@
+/* CPU ORACLE for the multivariate LMM (GEMMA src/mvlmm.cpp) -- TEST INFRASTRUCTURE ONLY.
+ *
+ * A plain-C restatement of the reference's per-SNP multivariate path: EigenProc, CalcQi, the EM of MphEM, the Wald
+ * statistic of MphCalcP, the Newton-Raphson of MphNR (gradient / observed Hessian of CalcDev) and MphInitial.  Only
+ * tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may call it; the product (gemma_amd/csrc) never does.
+ *
+ * PINNING: the reference's own tests hold no numeric golden for this path (test/dev_test_suite.sh:196-208 checks the
+ * line count of the 5-trait run; its value checksum "777.32" is commented out), and the reference cannot be built in
+ * this image (GSL / OpenBLAS absent).  tests/test_oracle_mvlmm.py therefore checks this file against (a) that commented
+ * checksum on the reference's own data, (b) the univariate oracle (d = 1 must reproduce -lmm), (c) finite differences
+ * of the log-likelihood for the gradient and Hessian.  Until a reference binary confirms it: "parity weakly pinned".
+ *
+ * Where the reference expands  P = H^-1 - H^-1 X Q^-1 X^T H^-1  into eight products of precomputed tables
+ * (src/mvlmm.cpp:1863-2049), this file evaluates the same quantities from u_k = (P y)_k directly; the algebra is
+ * identical (see the derivation next to dev_eval), the rounding is not -- no statement here depends on it.
+ *
+ * Layout: Y is d x n (trait-major rows), X is c x n (covariate rows; the SNP is the last row), eval has n entries.
+ * Small matrices are row-major with their natural leading dimension.
+ */
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define MV_MAXD 8
+#define MV_MAXC 8
+#define MV_MAXDC (MV_MAXD * MV_MAXC)
+#define MV_MAXV (MV_MAXD * (MV_MAXD + 1) / 2)
+
+/* from gemma_oracle.c (same shared object) */
+void orc_CalcLambda_null(char func_name, size_t n, size_t c, const double *eval, const double *UtW, const double *Uty,
+                         double l_min, double l_max, size_t n_region, double *lambda, double *logl_H0);
+void orc_CalcLmmVgVeBeta(size_t n, size_t c, const double *eval, const double *UtW, const double *Uty, double lambda,
+                         double *vg, double *ve, double *beta, double *se_beta);
+
+/* ------------------------------------------------------------------ small dense helpers */
+/* cyclic Jacobi for a symmetric m x m matrix: A = V diag(w) V^T, w ascending, V[:, i] the i-th vector, signed so
+ * that its entry of largest magnitude is positive.  (the reference calls LAPACK through EigenDecomp(.., 0),
+ * src/lapack.cpp:173-266.  Every use is invariant to the signs and the order EXCEPT the ML EM, which subtracts the
+ * previous iteration's UltVehiBX from this iteration's UltVehiY (:679-686): there only jumps between two consecutive,
+ * nearly equal matrices matter, and a fixed convention avoids them; LAPACK's own signs are not reproducible.) */
+static void mv_jacobi(const double *A, size_t m, double *w, double *V) {
+  double a[MV_MAXD * MV_MAXD];
+  memcpy(a, A, m * m * sizeof(double));
+  for (size_t i = 0; i < m; ++i)
+    for (size_t j = 0; j < m; ++j) V[i * m + j] = (i == j) ? 1.0 : 0.0;
+  for (int sweep = 0; sweep < 60; ++sweep) {
+    double off = 0.0, diag = 0.0;
+    for (size_t i = 0; i < m; ++i) {
+      diag += a[i * m + i] * a[i * m + i];
+      for (size_t j = i + 1; j < m; ++j) off += a[i * m + j] * a[i * m + j];
+    }
+    if (off <= 1e-34 * diag || off == 0.0) break;
+    for (size_t p = 0; p < m; ++p)
+      for (size_t q = p + 1; q < m; ++q) {
+        const double apq = a[p * m + q];
+        if (apq == 0.0) continue;
+        const double theta = (a[q * m + q] - a[p * m + p]) / (2.0 * apq);
+        const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+        const double cs = 1.0 / sqrt(t * t + 1.0), sn = t * cs;
+        for (size_t k = 0; k < m; ++k) { /* columns p, q */
+          const double akp = a[k * m + p], akq = a[k * m + q];
+          a[k * m + p] = cs * akp - sn * akq;
+          a[k * m + q] = sn * akp + cs * akq;
+        }
+        for (size_t k = 0; k < m; ++k) { /* rows p, q */
+          const double apk = a[p * m + k], aqk = a[q * m + k];
+          a[p * m + k] = cs * apk - sn * aqk;
+          a[q * m + k] = sn * apk + cs * aqk;
+        }
+        for (size_t k = 0; k < m; ++k) {
+          const double vkp = V[k * m + p], vkq = V[k * m + q];
+          V[k * m + p] = cs * vkp - sn * vkq;
+          V[k * m + q] = sn * vkp + cs * vkq;
+        }
+      }
+  }
+  for (size_t i = 0; i < m; ++i) w[i] = a[i * m + i];
+  for (size_t i = 0; i + 1 < m; ++i) { /* ascending, columns follow */
+    size_t mi = i;
+    for (size_t j = i + 1; j < m; ++j)
+      if (w[j] < w[mi]) mi = j;
+    if (mi != i) {
+      double t = w[i];
+      w[i] = w[mi];
+      w[mi] = t;
+      for (size_t k = 0; k < m; ++k) {
+        t = V[k * m + i];
+        V[k * m + i] = V[k * m + mi];
+        V[k * m + mi] = t;
+      }
+    }
+  }
+  for (size_t i = 0; i < m; ++i) {
+    double big = 0.0, sgn = 1.0;
+    for (size_t k = 0; k < m; ++k)
+      if (fabs(V[k * m + i]) > big) {
+        big = fabs(V[k * m + i]);
+        sgn = V[k * m + i] < 0 ? -1.0 : 1.0;
+      }
+    for (size_t k = 0; k < m; ++k) V[k * m + i] *= sgn;
+  }
+}
+
+/* LU with partial pivoting (GSL linalg/lu.c through src/lapack.cpp:307-352): inverse and log|det| */
+static double mv_lu_invert(const double *A, size_t m, double *Ai) {
+  double lu[MV_MAXDC * MV_MAXDC];
+  size_t perm[MV_MAXDC];
+  memcpy(lu, A, m * m * sizeof(double));
+  for (size_t i = 0; i < m; ++i) perm[i] = i;
+  for (size_t j = 0; j < m; ++j) {
+    size_t ip = j;
+    double amax = fabs(lu[j * m + j]);
+    for (size_t i = j + 1; i < m; ++i)
+      if (fabs(lu[i * m + j]) > amax) {
+        amax = fabs(lu[i * m + j]);
+        ip = i;
+      }
+    if (ip != j) {
+      for (size_t k = 0; k < m; ++k) {
+        const double t = lu[j * m + k];
+        lu[j * m + k] = lu[ip * m + k];
+        lu[ip * m + k] = t;
+      }
+      const size_t t = perm[j];
+      perm[j] = perm[ip];
+      perm[ip] = t;
+    }
+    const double ajj = lu[j * m + j];
+    if (ajj != 0.0)
+      for (size_t i = j + 1; i < m; ++i) {
+        const double f = lu[i * m + j] / ajj;
+        lu[i * m + j] = f;
+        for (size_t k = j + 1; k < m; ++k) lu[i * m + k] -= f * lu[j * m + k];
+      }
+  }
+  double lndet = 0.0;
+  for (size_t i = 0; i < m; ++i) lndet += log(fabs(lu[i * m + i]));
+  if (Ai)
+    for (size_t col = 0; col < m; ++col) {
+      double x[MV_MAXDC];
+      for (size_t i = 0; i < m; ++i) x[i] = (perm[i] == col) ? 1.0 : 0.0;
+      for (size_t i = 0; i < m; ++i)
+        for (size_t k = 0; k < i; ++k) x[i] -= lu[i * m + k] * x[k];
+      for (size_t ii = m; ii-- > 0;) {
+        for (size_t k = ii + 1; k < m; ++k) x[ii] -= lu[ii * m + k] * x[k];
+        x[ii] /= lu[ii * m + ii];
+      }
+      for (size_t i = 0; i < m; ++i) Ai[i * m + col] = x[i];
+    }
+  return lndet;
+}
+
+/* C (m x p) = op(A) * B ; ta != 0: A is k x m and used transposed, else m x k; B is k x p */
+static void mv_mm(int ta, size_t m, size_t p, size_t k, const double *A, const double *B, double *C) {
+  for (size_t i = 0; i < m; ++i)
+    for (size_t j = 0; j < p; ++j) {
+      double s = 0.0;
+      for (size_t t = 0; t < k; ++t) s += (ta ? A[t * m + i] : A[i * k + t]) * B[t * p + j];
+      C[i * p + j] = s;
+    }
+}
+
+/* gsl_cdf_chisq_Q(x, nu) = Q(nu/2, x/2) for integer nu >= 1 (GSL cdf/chisq.c -> cdf/gamma.c): the finite sums for
+ * integer and half-integer shape (all terms positive) */
+double orc_cdf_chisq_Q(double x, double nu) {
+  if (!(x > 0.0)) return (x == x) ? 1.0 : x;
+  const int inu = (int)nu;
+  const double y = 0.5 * x;
+  if (inu % 2 == 0) {
+    double term = 1.0, sum = 1.0;
+    for (int k = 1; k < inu / 2; ++k) {
+      term *= y / k;
+      sum += term;
+    }
+    return exp(-y) * sum;
+  }
+  double sum = 0.0, term = sqrt(y) / 0.886226925452758013649; /* y^(1/2) / Gamma(3/2) */
+  for (int k = 1; k <= (inu - 1) / 2; ++k) {
+    sum += term;
+    term *= y / (k + 0.5);
+  }
+  return erfc(sqrt(y)) + exp(-y) * sum;
+}
+
+/* ------------------------------------------------------------------ EigenProc, CalcQi */
+/* src/mvlmm.cpp:213-282 */
+static double mv_eigen_proc(size_t d, const double *Vg, const double *Ve, double *Dl, double *UltVeh, double *UltVehi) {
+  double w[MV_MAXD], Ul[MV_MAXD * MV_MAXD], Veh[MV_MAXD * MV_MAXD], Vehi[MV_MAXD * MV_MAXD];
+  double T1[MV_MAXD * MV_MAXD], Lam[MV_MAXD * MV_MAXD];
+  double logdet_Ve = 0.0;
+  mv_jacobi(Ve, d, w, Ul);
+  memset(Veh, 0, sizeof(Veh));
+  memset(Vehi, 0, sizeof(Vehi));
+  for (size_t i = 0; i < d; ++i) {
+    if (w[i] <= 0) continue;
+    logdet_Ve += log(w[i]);
+    const double s = sqrt(w[i]), si = 1.0 / s;
+    for (size_t a = 0; a < d; ++a)
+      for (size_t b = 0; b < d; ++b) {
+        Veh[a * d + b] += s * Ul[a * d + i] * Ul[b * d + i];
+        Vehi[a * d + b] += si * Ul[a * d + i] * Ul[b * d + i];
+      }
+  }
+  mv_mm(0, d, d, d, Vg, Vehi, T1);
+  mv_mm(0, d, d, d, Vehi, T1, Lam);
+  for (size_t a = 0; a < d; ++a) /* exact symmetry for the Jacobi sweep */
+    for (size_t b = a + 1; b < d; ++b) Lam[a * d + b] = Lam[b * d + a] = 0.5 * (Lam[a * d + b] + Lam[b * d + a]);
+  mv_jacobi(Lam, d, Dl, Ul);
+  for (size_t i = 0; i < d; ++i)
+    if (Dl[i] < 0) Dl[i] = 0;
+  mv_mm(1, d, d, d, Ul, Veh, UltVeh);
+  mv_mm(1, d, d, d, Ul, Vehi, UltVehi);
+  return logdet_Ve;
+}
+
+/* src/mvlmm.cpp:285-329: Q[(i d + l), (j d + l)] = sum_k x_ik x_jk / (D_l delta_k + 1); returns log|Q|, Qi = Q^-1 */
+static double mv_calc_qi(size_t n, size_t d, size_t c, const double *eval, const double *Dl, const double *X,
+                         double *Qi) {
+  const size_t dc = d * c;
+  double Q[MV_MAXDC * MV_MAXDC];
+  memset(Q, 0, dc * dc * sizeof(double));
+  for (size_t i = 0; i < c; ++i)
+    for (size_t j = i; j < c; ++j)
+      for (size_t l = 0; l < d; ++l) {
+        double s = 0.0;
+        for (size_t k = 0; k < n; ++k) s += X[i * n + k] * X[j * n + k] / (Dl[l] * eval[k] + 1.0);
+        Q[(i * d + l) * dc + j * d + l] = s;
+        Q[(j * d + l) * dc + i * d + l] = s;
+      }
+  return mv_lu_invert(Q, dc, Qi);
+}
+
+/* log|X X^T| (src/mvlmm.cpp:631-649) */
+static double mv_lndet_xxt(size_t n, size_t c, const double *X, double *XXti) {
+  double XXt[MV_MAXC * MV_MAXC];
+  for (size_t i = 0; i < c; ++i)
+    for (size_t j = i; j < c; ++j) {
+      double s = 0.0;
+      for (size_t k = 0; k < n; ++k) s += X[i * n + k] * X[j * n + k];
+      XXt[i * c + j] = XXt[j * c + i] = s;
+    }
+  return mv_lu_invert(XXt, c, XXti);
+}
+
+/* ------------------------------------------------------------------ MphEM  (src/mvlmm.cpp:599-724) */
+double orc_mph_em(char func, size_t max_iter, double max_prec, size_t n, size_t d, size_t c, const double *eval,
+                  const double *X, const double *Y, double *Vg, double *Ve, double *B) {
+  const size_t dc = d * c;
+  const int reml = (func == 'R' || func == 'r');
+  double XXti[MV_MAXC * MV_MAXC];
+  const double lndet_xxt = mv_lndet_xxt(n, c, X, XXti);
+  const double logl_const = reml ? -0.5 * (double)(n - c) * (double)d * log(2.0 * M_PI) + 0.5 * (double)d * lndet_xxt
+                                 : -0.5 * (double)n * (double)d * log(2.0 * M_PI);
+  double *UltVehiY = (double *)malloc(6 * d * n * sizeof(double));
+  double *UltVehiBX = UltVehiY + d * n, *UltVehiU = UltVehiBX + d * n, *UltVehiE = UltVehiU + d * n;
+  double *U_hat = UltVehiE + d * n, *E_hat = U_hat + d * n;
+  double Dl[MV_MAXD], UltVeh[MV_MAXD * MV_MAXD], UltVehi[MV_MAXD * MV_MAXD], UltVehiB[MV_MAXD * MV_MAXC];
+  double Qi[MV_MAXDC * MV_MAXDC], xHiy[MV_MAXDC], Suu[MV_MAXD * MV_MAXD], See[MV_MAXD * MV_MAXD];
+  double logl_old = 0.0, logl_new = 0.0;
+  for (size_t t = 0; t < max_iter; ++t) {
+    const double logdet_Ve = mv_eigen_proc(d, Vg, Ve, Dl, UltVeh, UltVehi);
+    const double logdet_Q = mv_calc_qi(n, d, c, eval, Dl, X, Qi);
+    mv_mm(0, d, n, d, UltVehi, Y, UltVehiY);
+    /* CalcXHiY :334-359 */
+    for (size_t i = 0; i < d; ++i)
+      for (size_t j = 0; j < c; ++j) {
+        double s = 0.0;
+        for (size_t k = 0; k < n; ++k) s += X[j * n + k] * UltVehiY[i * n + k] / (eval[k] * Dl[i] + 1.0);
+        xHiy[j * d + i] = s;
+      }
+    /* MphCalcLogL :565-594 */
+    double ll = 0.0;
+    for (size_t k = 0; k < n; ++k)
+      for (size_t i = 0; i < d; ++i) {
+        const double y = UltVehiY[i * n + k], dd = eval[k] * Dl[i] + 1.0;
+        ll += y * y / dd + log(dd);
+      }
+    double q = 0.0;
+    for (size_t a = 0; a < dc; ++a) {
+      double s = 0.0;
+      for (size_t b = 0; b < dc; ++b) s += Qi[a * dc + b] * xHiy[b];
+      q += xHiy[a] * s;
+    }
+    ll -= q;
+    logl_new = logl_const + (-0.5 * ll) - 0.5 * (double)n * logdet_Ve;
+    if (reml) logl_new += -0.5 * (logdet_Q - (double)c * logdet_Ve);
+    if (t != 0 && fabs(logl_new - logl_old) < max_prec) break;
+    logl_old = logl_new;
+    /* UltVehiB, UltVehiBX */
+    if (reml) { /* UpdateRL_B :420-441 */
+      for (size_t j = 0; j < c; ++j)
+        for (size_t i = 0; i < d; ++i) {
+          double s = 0.0;
+          for (size_t b = 0; b < dc; ++b) s += Qi[(j * d + i) * dc + b] * xHiy[b];
+          UltVehiB[i * c + j] = s;
+        }
+      mv_mm(0, d, n, c, UltVehiB, X, UltVehiBX);
+    } else if (t == 0) {
+      mv_mm(0, d, c, d, UltVehi, B, UltVehiB);
+      mv_mm(0, d, n, c, UltVehiB, X, UltVehiBX);
+    }
+    /* UpdateU :384-391 with CalcOmega :363-382 */
+    for (size_t i = 0; i < d; ++i)
+      for (size_t k = 0; k < n; ++k) {
+        const double ou = Dl[i] / (eval[k] * Dl[i] + 1.0), oe = eval[k] * ou;
+        UltVehiU[i * n + k] = (UltVehiY[i * n + k] - UltVehiBX[i * n + k]) * oe;
+      }
+    if (!reml) { /* UpdateL_B :402-418 */
+      double YUX[MV_MAXD * MV_MAXC];
+      for (size_t i = 0; i < d; ++i)
+        for (size_t j = 0; j < c; ++j) {
+          double s = 0.0;
+          for (size_t k = 0; k < n; ++k) s += (UltVehiY[i * n + k] - UltVehiU[i * n + k]) * X[j * n + k];
+          YUX[i * c + j] = s;
+        }
+      mv_mm(0, d, c, c, YUX, XXti, UltVehiB);
+      mv_mm(0, d, n, c, UltVehiB, X, UltVehiBX);
+    }
+    for (size_t i = 0; i < d * n; ++i) UltVehiE[i] = UltVehiY[i] - UltVehiBX[i] - UltVehiU[i]; /* UpdateE */
+    mv_mm(1, d, n, d, UltVeh, UltVehiU, U_hat);
+    mv_mm(1, d, n, d, UltVeh, UltVehiE, E_hat);
+    mv_mm(1, d, c, d, UltVeh, UltVehiB, B);
+    /* CalcSigma :485-560 */
+    memset(Suu, 0, sizeof(Suu));
+    memset(See, 0, sizeof(See));
+    for (size_t k = 0; k < n; ++k)
+      for (size_t i = 0; i < d; ++i) {
+        const double ou = Dl[i] / (eval[k] * Dl[i] + 1.0);
+        Suu[i * d + i] += ou;
+        See[i * d + i] += eval[k] * ou;
+      }
+    if (reml) {
+      /* M_u[(j d + i), i] = x_j D_l_i / (delta D_l_i + 1), M_e likewise without D_l: only one entry per row, so
+       * (M^T Qi M)[i1][i2] = sum_{j1 j2} m_{j1 i1} Qi[(j1 d + i1), (j2 d + i2)] m_{j2 i2} */
+      for (size_t k = 0; k < n; ++k) {
+        double me[MV_MAXDC], mu[MV_MAXDC];
+        for (size_t i = 0; i < d; ++i)
+          for (size_t j = 0; j < c; ++j) {
+            const double v = X[j * n + k] / (eval[k] * Dl[i] + 1.0);
+            me[j * d + i] = v;
+            mu[j * d + i] = v * Dl[i];
+          }
+        for (size_t i1 = 0; i1 < d; ++i1)
+          for (size_t i2 = 0; i2 < d; ++i2) {
+            double su = 0.0, se = 0.0;
+            for (size_t j1 = 0; j1 < c; ++j1)
+              for (size_t j2 = 0; j2 < c; ++j2) {
+                const double qv = Qi[(j1 * d + i1) * dc + j2 * d + i2];
+                su += mu[j1 * d + i1] * qv * mu[j2 * d + i2];
+                se += me[j1 * d + i1] * qv * me[j2 * d + i2];
+              }
+            Suu[i1 * d + i2] += eval[k] * su;
+            See[i1 * d + i2] += se;
+          }
+      }
+    }
+    {
+      double M[MV_MAXD * MV_MAXD];
+      mv_mm(0, d, d, d, Suu, UltVeh, M);
+      mv_mm(1, d, d, d, UltVeh, M, Suu);
+      mv_mm(0, d, d, d, See, UltVeh, M);
+      mv_mm(1, d, d, d, UltVeh, M, See);
+    }
+    /* UpdateV :443-483 */
+    for (size_t a = 0; a < d; ++a)
+      for (size_t b = a; b < d; ++b) {
+        double sg = 0.0, se = 0.0;
+        for (size_t k = 0; k < n; ++k) {
+          if (eval[k] != 0) sg += U_hat[a * n + k] * U_hat[b * n + k] / eval[k];
+          se += E_hat[a * n + k] * E_hat[b * n + k];
+        }
+        Vg[a * d + b] = Vg[b * d + a] = sg;
+        Ve[a * d + b] = Ve[b * d + a] = se;
+      }
+    for (size_t a = 0; a < d * d; ++a) {
+      Vg[a] = (Vg[a] + Suu[a]) / (double)n;
+      Ve[a] = (Ve[a] + See[a]) / (double)n;
+    }
+  }
+  free(UltVehiY);
+  return logl_new;
+}
+
+/* ------------------------------------------------------------------ MphCalcP  (src/mvlmm.cpp:727-831) */
+/* W: cw x n covariate rows WITHOUT the SNP, x: the SNP row.  beta[d], Vbeta[d x d]; returns the Wald p value. */
+double orc_mph_calcp(size_t n, size_t d, size_t cw, const double *eval, const double *x, const double *W,
+                     const double *Y, const double *Vg, const double *Ve, double *beta, double *Vbeta) {
+  const size_t dc = d * cw;
+  double Dl[MV_MAXD], UltVeh[MV_MAXD * MV_MAXD], UltVehi[MV_MAXD * MV_MAXD], Qi[MV_MAXDC * MV_MAXDC];
+  double WHix[MV_MAXDC * MV_MAXD], QiWHix[MV_MAXDC * MV_MAXD], xPx[MV_MAXD * MV_MAXD], xPy[MV_MAXD], WHiy[MV_MAXDC];
+  double *UltVehiY = (double *)malloc(d * n * sizeof(double));
+  mv_eigen_proc(d, Vg, Ve, Dl, UltVeh, UltVehi);
+  mv_calc_qi(n, d, cw, eval, Dl, W, Qi);
+  mv_mm(0, d, n, d, UltVehi, Y, UltVehiY);
+  memset(xPx, 0, sizeof(xPx));
+  memset(WHix, 0, sizeof(WHix));
+  for (size_t i = 0; i < d; ++i) {
+    double d1 = 0.0, d2 = 0.0;
+    for (size_t k = 0; k < n; ++k) {
+      const double w = eval[k] * Dl[i] + 1.0;
+      d1 += x[k] * UltVehiY[i * n + k] / w;
+      d2 += x[k] * x[k] / w;
+    }
+    xPy[i] = d1;
+    xPx[i * d + i] = d2;
+    for (size_t j = 0; j < cw; ++j) {
+      d1 = 0.0;
+      d2 = 0.0;
+      for (size_t k = 0; k < n; ++k) {
+        const double w = eval[k] * Dl[i] + 1.0;
+        d1 += x[k] * W[j * n + k] / w;
+        d2 += UltVehiY[i * n + k] * W[j * n + k] / w;
+      }
+      WHix[(j * d + i) * d + i] = d1;
+      WHiy[j * d + i] = d2;
+    }
+  }
+  mv_mm(0, dc, d, dc, Qi, WHix, QiWHix);
+  for (size_t a = 0; a < d; ++a) {
+    for (size_t b = 0; b < d; ++b) {
+      double s = 0.0;
+      for (size_t t = 0; t < dc; ++t) s += WHix[t * d + a] * QiWHix[t * d + b];
+      xPx[a * d + b] -= s;
+    }
+    double s = 0.0;
+    for (size_t t = 0; t < dc; ++t) s += QiWHix[t * d + a] * WHiy[t];
+    xPy[a] -= s;
+  }
+  double xPxi[MV_MAXD * MV_MAXD], sol[MV_MAXD], T[MV_MAXD * MV_MAXD];
+  mv_lu_invert(xPx, d, xPxi);
+  for (size_t a = 0; a < d; ++a) {
+    double s = 0.0;
+    for (size_t b = 0; b < d; ++b) s += xPxi[a * d + b] * xPy[b];
+    sol[a] = s;
+  }
+  for (size_t a = 0; a < d; ++a) {
+    double s = 0.0;
+    for (size_t b = 0; b < d; ++b) s += UltVeh[b * d + a] * sol[b];
+    beta[a] = s;
+  }
+  mv_mm(0, d, d, d, xPxi, UltVeh, T);
+  mv_mm(1, d, d, d, UltVeh, T, Vbeta);
+  double stat = 0.0;
+  for (size_t a = 0; a < d; ++a) stat += sol[a] * xPy[a];
+  free(UltVehiY);
+  return orc_cdf_chisq_Q(stat, (double)d);
+}
+
+/* ------------------------------------------------------------------ MphNR  (src/mvlmm.cpp:2608-2760) */
+/* GetIndex :1093-1109 */
+static size_t mv_vindex(size_t i, size_t j, size_t d) {
+  const size_t s = i < j ? i : j, l = i < j ? j : i;
+  return (2 * d - s + 1) * s / 2 + l - s;
+}
+
+typedef struct {
+  double logl;                       /* log (restricted) likelihood at (Vg, Ve) */
+  double grad[2 * MV_MAXV];          /* d logl / d (Vg_v), then d logl / d (Ve_v) */
+  double hess[4 * MV_MAXV * MV_MAXV]; /* the matrix CalcDev builds (before inversion), 2v x 2v */
+} mv_dev;
+
+/* One evaluation at (Vg, Ve): CalcHiQi :942-1012, the logl of :2697-2713 and, if want_dev, CalcDev :2360-2554.
+ *
+ * With G_k = H_k^-1 (d x d), b = Qi X^T H^-1 y (B = its d x c reshape) and u_k = (P y)_k = G_k (y_k - B x_k), and
+ * writing the derivative direction D_v (e_i e_j^T + e_j e_i^T, or e_i e_i^T) weighted by delta_k^a (a = 1 for V_g,
+ * 0 for V_e):
+ *   y P D P y        = sum_k w u^T D u
+ *   tr(H^-1 D)       = sum_k w tr(G D)                      tr(P D) = that - tr(Qi M_v),   M_v = sum_k w x x^T (x) G D G
+ *   y P D1 P D2 P y  = sum_k w1 w2 u^T D1 G D2 u - r_v1^T Qi r_v2,                         r_v = sum_k w x (x) G D u
+ *   tr(P D1 P D2)    = sum_k w1 w2 tr(G D1 G D2) - 2 tr(Qi M12) + tr(Qi M_v1 Qi M_v2),     M12 = sum_k w1 w2 x x^T (x) G D1 G D2 G
+ * which are the eight-term expansions of :1863-2049 and :1526-1621 collected (P = H^-1 - H^-1 X Qi X^T H^-1).
+ * The "ge" entries take D1 as the V_g direction and D2 as the V_e direction for v1 <= v2 ONLY and mirror that value
+ * into the (v2, v1) slots as well (:2494-2504) -- reproduced here as is. */
+static int mv_eval(int reml, size_t n, size_t d, size_t c, const double *eval, const double *X, const double *Y,
+                   const double *Vg, const double *Ve, double logl_const, int want_dev, mv_dev *out) {
+  const size_t dc = d * c, vs = d * (d + 1) / 2;
+  double Dl[MV_MAXD], UltVeh[MV_MAXD * MV_MAXD], UltVehi[MV_MAXD * MV_MAXD], Qe[MV_MAXDC * MV_MAXDC];
+  double Qi[MV_MAXDC * MV_MAXDC];
+  const double logdet_Ve = mv_eigen_proc(d, Vg, Ve, Dl, UltVeh, UltVehi);
+  double logdet_H = (double)n * logdet_Ve;
+  double *G = (double *)malloc((d * d + d) * n * sizeof(double)); /* G_k, then Hiy_k / u_k */
+  double *U = G + d * d * n;
+  for (size_t k = 0; k < n; ++k) {
+    double S[MV_MAXD * MV_MAXD];
+    for (size_t i = 0; i < d; ++i) {
+      const double dd = eval[k] * Dl[i] + 1.0;
+      for (size_t j = 0; j < d; ++j) S[i * d + j] = UltVehi[i * d + j] / dd;
+      logdet_H += log(dd);
+    }
+    mv_mm(1, d, d, d, UltVehi, S, G + k * d * d);
+  }
+  double logdet_Q = mv_calc_qi(n, d, c, eval, Dl, X, Qe) - (double)c * logdet_Ve;
+  for (size_t i = 0; i < c; ++i) /* Qi blocks: UltVeh^T (.) UltVeh */
+    for (size_t j = 0; j < c; ++j) {
+      double blk[MV_MAXD * MV_MAXD], T[MV_MAXD * MV_MAXD], R[MV_MAXD * MV_MAXD];
+      for (size_t a = 0; a < d; ++a)
+        for (size_t b = 0; b < d; ++b) blk[a * d + b] = Qe[(i * d + a) * dc + j * d + b];
+      mv_mm(0, d, d, d, blk, UltVeh, T);
+      mv_mm(1, d, d, d, UltVeh, T, R);
+      for (size_t a = 0; a < d; ++a)
+        for (size_t b = 0; b < d; ++b) Qi[(i * d + a) * dc + j * d + b] = R[a * d + b];
+    }
+  /* Hiy, xHiy, b = Qi xHiy, yPy */
+  double xHiy[MV_MAXDC], b[MV_MAXDC], yHiy = 0.0;
+  memset(xHiy, 0, sizeof(xHiy));
+  for (size_t k = 0; k < n; ++k) {
+    const double *Gk = G + k * d * d;
+    for (size_t i = 0; i < d; ++i) {
+      double s = 0.0;
+      for (size_t j = 0; j < d; ++j) s += Gk[i * d + j] * Y[j * n + k];
+      U[k * d + i] = s;
+      yHiy += s * Y[i * n + k];
+      for (size_t j = 0; j < c; ++j) xHiy[j * d + i] += X[j * n + k] * s;
+    }
+  }
+  double yPy = yHiy;
+  for (size_t a = 0; a < dc; ++a) {
+    double s = 0.0;
+    for (size_t t = 0; t < dc; ++t) s += Qi[a * dc + t] * xHiy[t];
+    b[a] = s;
+    yPy -= s * xHiy[a];
+  }
+  out->logl = reml ? logl_const - 0.5 * logdet_H - 0.5 * logdet_Q - 0.5 * yPy : logl_const - 0.5 * logdet_H - 0.5 * yPy;
+  if (!want_dev) {
+    free(G);
+    return 0;
+  }
+  /* u_k = Hiy_k - G_k B x_k */
+  for (size_t k = 0; k < n; ++k) {
+    const double *Gk = G + k * d * d;
+    double bx[MV_MAXD];
+    for (size_t i = 0; i < d; ++i) {
+      double s = 0.0;
+      for (size_t j = 0; j < c; ++j) s += b[j * d + i] * X[j * n + k];
+      bx[i] = s;
+    }
+    for (size_t i = 0; i < d; ++i) {
+      double s = 0.0;
+      for (size_t j = 0; j < d; ++j) s += Gk[i * d + j] * bx[j];
+      U[k * d + i] -= s;
+    }
+  }
+  /* direction matrices */
+  double Dm[MV_MAXV][MV_MAXD * MV_MAXD];
+  for (size_t i = 0; i < d; ++i)
+    for (size_t j = i; j < d; ++j) {
+      double *D = Dm[mv_vindex(i, j, d)];
+      memset(D, 0, d * d * sizeof(double));
+      D[i * d + j] = 1.0;
+      D[j * d + i] = 1.0;
+    }
+  /* accumulators: index a = 0 (V_e weight 1), 1 (V_g weight delta); pair weight index s = 0 (ee), 1 (ge), 2 (gg) */
+  const size_t m2 = dc * dc;
+  double *acc = (double *)calloc(2 * vs * (2 + dc + m2) + 3 * vs * vs * (2 + m2), sizeof(double));
+  double *yPDPy = acc, *trHiD = yPDPy + 2 * vs, *rv = trHiD + 2 * vs, *Mv = rv + 2 * vs * dc;
+  double *yy = Mv + 2 * vs * m2, *trHH = yy + 3 * vs * vs, *M12 = trHH + 3 * vs * vs;
+  for (size_t k = 0; k < n; ++k) {
+    const double *Gk = G + k * d * d, *u = U + k * d;
+    const double dl = eval[k];
+    double t[MV_MAXV][MV_MAXD], Gt[MV_MAXV][MV_MAXD], GDG[MV_MAXV][MV_MAXD * MV_MAXD], GD[MV_MAXD * MV_MAXD];
+    for (size_t v = 0; v < vs; ++v) {
+      for (size_t i = 0; i < d; ++i) {
+        double s = 0.0;
+        for (size_t j = 0; j < d; ++j) s += Dm[v][i * d + j] * u[j];
+        t[v][i] = s;
+      }
+      for (size_t i = 0; i < d; ++i) {
+        double s = 0.0;
+        for (size_t j = 0; j < d; ++j) s += Gk[i * d + j] * t[v][j];
+        Gt[v][i] = s;
+      }
+      mv_mm(0, d, d, d, Gk, Dm[v], GD);
+      mv_mm(0, d, d, d, GD, Gk, GDG[v]);
+      double udu = 0.0, tr = 0.0;
+      for (size_t i = 0; i < d; ++i) {
+        udu += u[i] * t[v][i];
+        tr += GD[i * d + i];
+      }
+      for (int a = 0; a < 2; ++a) {
+        const double w = a ? dl : 1.0;
+        yPDPy[a * vs + v] += w * udu;
+        trHiD[a * vs + v] += w * tr;
+        for (size_t j = 0; j < c; ++j)
+          for (size_t i = 0; i < d; ++i) rv[(a * vs + v) * dc + j * d + i] += w * X[j * n + k] * Gt[v][i];
+        for (size_t j1 = 0; j1 < c; ++j1)
+          for (size_t j2 = 0; j2 < c; ++j2) {
+            const double xx = w * X[j1 * n + k] * X[j2 * n + k];
+            for (size_t i1 = 0; i1 < d; ++i1)
+              for (size_t i2 = 0; i2 < d; ++i2)
+                Mv[(a * vs + v) * m2 + (j1 * d + i1) * dc + j2 * d + i2] += xx * GDG[v][i1 * d + i2];
+          }
+      }
+    }
+    for (size_t v1 = 0; v1 < vs; ++v1)
+      for (size_t v2 = v1; v2 < vs; ++v2) {
+        double s = 0.0, tr = 0.0, GDGD[MV_MAXD * MV_MAXD], GDGDG[MV_MAXD * MV_MAXD];
+        for (size_t i = 0; i < d; ++i) s += t[v1][i] * Gt[v2][i];
+        mv_mm(0, d, d, d, GDG[v1], Dm[v2], GDGD);
+        for (size_t i = 0; i < d; ++i) tr += GDGD[i * d + i];
+        mv_mm(0, d, d, d, GDGD, Gk, GDGDG);
+        for (int sI = 0; sI < 3; ++sI) {
+          const double w = sI == 0 ? 1.0 : (sI == 1 ? dl : dl * dl);
+          const size_t p = (sI * vs + v1) * vs + v2;
+          yy[p] += w * s;
+          trHH[p] += w * tr;
+          for (size_t j1 = 0; j1 < c; ++j1)
+            for (size_t j2 = 0; j2 < c; ++j2) {
+              const double xx = w * X[j1 * n + k] * X[j2 * n + k];
+              for (size_t i1 = 0; i1 < d; ++i1)
+                for (size_t i2 = 0; i2 < d; ++i2)
+                  M12[p * m2 + (j1 * d + i1) * dc + j2 * d + i2] += xx * GDGDG[i1 * d + i2];
+            }
+        }
+      }
+  }
+  /* Qi M_v, Qi r_v */
+  double *QM = (double *)malloc(2 * vs * (m2 + dc) * sizeof(double)), *Qr = QM + 2 * vs * m2;
+  for (size_t av = 0; av < 2 * vs; ++av) {
+    mv_mm(0, dc, dc, dc, Qi, Mv + av * m2, QM + av * m2);
+    for (size_t a = 0; a < dc; ++a) {
+      double s = 0.0;
+      for (size_t t2 = 0; t2 < dc; ++t2) s += Qi[a * dc + t2] * rv[av * dc + t2];
+      Qr[av * dc + a] = s;
+    }
+  }
+  const size_t H2 = 2 * vs;
+  memset(out->hess, 0, sizeof(out->hess));
+  for (size_t v1 = 0; v1 < vs; ++v1) {
+    for (int a = 0; a < 2; ++a) {
+      double trPD = trHiD[a * vs + v1];
+      if (reml)
+        for (size_t i = 0; i < dc; ++i) trPD -= QM[(a * vs + v1) * m2 + i * dc + i];
+      out->grad[(a ? 0 : vs) + v1] = -0.5 * trPD + 0.5 * yPDPy[a * vs + v1];
+    }
+    for (size_t v2 = v1; v2 < vs; ++v2) {
+      double dev2[3]; /* ee, ge, gg */
+      for (int sI = 0; sI < 3; ++sI) {
+        const int a1 = sI >= 1, a2 = sI == 2; /* ge: D1 = g (v1), D2 = e (v2) */
+        const size_t p = (sI * vs + v1) * vs + v2;
+        double yPDPDPy = yy[p];
+        for (size_t i = 0; i < dc; ++i) yPDPDPy -= rv[(a1 * vs + v1) * dc + i] * Qr[(a2 * vs + v2) * dc + i];
+        double tr = trHH[p];
+        if (reml) {
+          double t2 = 0.0, t4 = 0.0;
+          for (size_t i = 0; i < dc; ++i)
+            for (size_t j = 0; j < dc; ++j) {
+              t2 += Qi[i * dc + j] * M12[p * m2 + j * dc + i];
+              t4 += QM[(a1 * vs + v1) * m2 + i * dc + j] * QM[(a2 * vs + v2) * m2 + j * dc + i];
+            }
+          tr += -2.0 * t2 + t4;
+        }
+        dev2[sI] = 0.5 * tr - yPDPDPy;
+      }
+      out->hess[v1 * H2 + v2] = out->hess[v2 * H2 + v1] = dev2[2];
+      out->hess[(v1 + vs) * H2 + v2 + vs] = out->hess[(v2 + vs) * H2 + v1 + vs] = dev2[0];
+      out->hess[v1 * H2 + v2 + vs] = out->hess[(v2 + vs) * H2 + v1] = dev2[1];
+      out->hess[v2 * H2 + v1 + vs] = out->hess[(v1 + vs) * H2 + v2] = dev2[1];
+    }
+  }
+  free(QM);
+  free(acc);
+  free(G);
+  return 0;
+}
+
+static int mv_is_pd(size_t d, const double *V) {
+  double w[MV_MAXD], Z[MV_MAXD * MV_MAXD];
+  mv_jacobi(V, d, w, Z);
+  for (size_t i = 0; i < d; ++i)
+    if (w[i] <= 0) return 0;
+  return 1;
+}
+
+/* Hessian_inv receives MINUS the inverse of the last Hessian (the variance matrix, :2742-2744); 2v x 2v */
+double orc_mph_nr(char func, size_t max_iter, double max_prec, size_t n, size_t d, size_t c, const double *eval,
+                  const double *X, const double *Y, double *Vg, double *Ve, double *Hessian_inv) {
+  const int reml = (func == 'R' || func == 'r');
+  const size_t vs = d * (d + 1) / 2, H2 = 2 * vs;
+  const double lndet_xxt = mv_lndet_xxt(n, c, X, NULL);
+  const double logl_const = reml ? -0.5 * (double)(n - c) * (double)d * log(2.0 * M_PI) + 0.5 * (double)d * lndet_xxt
+                                 : -0.5 * (double)n * (double)d * log(2.0 * M_PI);
+  mv_dev *ev = (mv_dev *)malloc(sizeof(mv_dev));
+  double Vg_save[MV_MAXD * MV_MAXD], Ve_save[MV_MAXD * MV_MAXD], Hi[4 * MV_MAXV * MV_MAXV], grad[2 * MV_MAXV];
+  double logl_old = 0.0, logl_new = 0.0;
+  memset(Hi, 0, sizeof(Hi));
+  memset(grad, 0, sizeof(grad));
+  for (size_t t = 0; t < max_iter; ++t) {
+    memcpy(Vg_save, Vg, d * d * sizeof(double));
+    memcpy(Ve_save, Ve, d * d * sizeof(double));
+    double step_scale = 1.0;
+    size_t step_iter = 0;
+    int flag_pd;
+    do {
+      memcpy(Vg, Vg_save, d * d * sizeof(double));
+      memcpy(Ve, Ve_save, d * d * sizeof(double));
+      if (t != 0) { /* UpdateVgVe :2557-2606 */
+        for (size_t i = 0; i < d; ++i)
+          for (size_t j = i; j < d; ++j) {
+            const size_t v = mv_vindex(i, j, d);
+            double sg = 0.0, se = 0.0;
+            for (size_t q = 0; q < H2; ++q) {
+              sg += Hi[v * H2 + q] * grad[q];
+              se += Hi[(v + vs) * H2 + q] * grad[q];
+            }
+            Vg[i * d + j] = Vg[j * d + i] = Vg_save[i * d + j] - step_scale * sg;
+            Ve[i * d + j] = Ve[j * d + i] = Ve_save[i * d + j] - step_scale * se;
+          }
+      }
+      flag_pd = mv_is_pd(d, Ve) && mv_is_pd(d, Vg);
+      if (flag_pd) {
+        mv_eval(reml, n, d, c, eval, X, Y, Vg, Ve, logl_const, 0, ev);
+        logl_new = ev->logl;
+      }
+      step_scale /= 2.0;
+      step_iter++;
+    } while ((flag_pd == 0 || logl_new < logl_old || logl_new - logl_old > 10) && step_iter < 10 && t != 0);
+    if (t != 0) {
+      if (logl_new < logl_old || flag_pd == 0) {
+        memcpy(Vg, Vg_save, d * d * sizeof(double));
+        memcpy(Ve, Ve_save, d * d * sizeof(double));
+        break;
+      }
+      if (logl_new - logl_old < max_prec) break;
+    }
+    logl_old = logl_new;
+    mv_eval(reml, n, d, c, eval, X, Y, Vg, Ve, logl_const, 1, ev);
+    memcpy(grad, ev->grad, H2 * sizeof(double));
+    mv_lu_invert(ev->hess, H2, Hi);
+  }
+  if (Hessian_inv)
+    for (size_t i = 0; i < H2 * H2; ++i) Hessian_inv[i] = -Hi[i];
+  free(ev);
+  return logl_new;
+}
+
+/* test hook: logl, gradient and the CalcDev Hessian at a point (finite-difference checks) */
+double orc_mph_dev(char func, size_t n, size_t d, size_t c, const double *eval, const double *X, const double *Y,
+                   const double *Vg, const double *Ve, double *grad, double *hess) {
+  const int reml = (func == 'R' || func == 'r');
+  const size_t H2 = d * (d + 1);
+  const double lndet_xxt = mv_lndet_xxt(n, c, X, NULL);
+  const double logl_const = reml ? -0.5 * (double)(n - c) * (double)d * log(2.0 * M_PI) + 0.5 * (double)d * lndet_xxt
+                                 : -0.5 * (double)n * (double)d * log(2.0 * M_PI);
+  mv_dev *ev = (mv_dev *)malloc(sizeof(mv_dev));
+  mv_eval(reml, n, d, c, eval, X, Y, Vg, Ve, logl_const, grad != NULL, ev);
+  const double ll = ev->logl;
+  if (grad) {
+    memcpy(grad, ev->grad, H2 * sizeof(double));
+    memcpy(hess, ev->hess, H2 * H2 * sizeof(double));
+  }
+  free(ev);
+  return ll;
+}
+
+/* B = GLS estimate of the fixed effects at (Vg, Ve): the tail of MphInitial (:2886-2935) and the B that MphCalcBeta
+ * (:835-935) stores (its standard errors are not needed on this path) */
+static void mv_gls_B(size_t n, size_t d, size_t c, const double *eval, const double *X, const double *Y,
+                     const double *Vg, const double *Ve, double *B) {
+  double Dl[MV_MAXD], UltVeh[MV_MAXD * MV_MAXD], UltVehi[MV_MAXD * MV_MAXD], Qi[MV_MAXDC * MV_MAXDC];
+  double xHiy[MV_MAXDC], beta[MV_MAXDC];
+  const size_t dc = d * c;
+  double *UltVehiY = (double *)malloc(d * n * sizeof(double));
+  mv_eigen_proc(d, Vg, Ve, Dl, UltVeh, UltVehi);
+  mv_calc_qi(n, d, c, eval, Dl, X, Qi);
+  mv_mm(0, d, n, d, UltVehi, Y, UltVehiY);
+  for (size_t i = 0; i < d; ++i)
+    for (size_t j = 0; j < c; ++j) {
+      double s = 0.0;
+      for (size_t k = 0; k < n; ++k) s += UltVehiY[i * n + k] * X[j * n + k] / (eval[k] * Dl[i] + 1.0);
+      xHiy[j * d + i] = s;
+    }
+  for (size_t a = 0; a < dc; ++a) {
+    double s = 0.0;
+    for (size_t t = 0; t < dc; ++t) s += Qi[a * dc + t] * xHiy[t];
+    beta[a] = s;
+  }
+  for (size_t j = 0; j < c; ++j)
+    for (size_t a = 0; a < d; ++a) {
+      double s = 0.0;
+      for (size_t t = 0; t < d; ++t) s += UltVeh[t * d + a] * beta[j * d + t];
+      B[a * c + j] = s;
+    }
+  free(UltVehiY);
+}
+
+/* ------------------------------------------------------------------ MphInitial  (src/mvlmm.cpp:2763-2948) */
+void orc_mph_initial(size_t em_iter, double em_prec, size_t nr_iter, double nr_prec, size_t n, size_t d, size_t c,
+                     const double *eval, const double *X, const double *Y, double l_min, double l_max, size_t n_region,
+                     double *Vg, double *Ve, double *B) {
+  memset(Vg, 0, d * d * sizeof(double));
+  memset(Ve, 0, d * d * sizeof(double));
+  memset(B, 0, d * c * sizeof(double));
+  double *Xt = (double *)malloc(n * c * sizeof(double));
+  for (size_t k = 0; k < n; ++k)
+    for (size_t j = 0; j < c; ++j) Xt[k * c + j] = X[j * n + k];
+  for (size_t i = 0; i < d; ++i) {
+    double lambda, logl, vg, ve, bt[MV_MAXC], sb[MV_MAXC];
+    orc_CalcLambda_null('R', n, c, eval, Xt, Y + i * n, l_min, l_max, n_region, &lambda, &logl);
+    orc_CalcLmmVgVeBeta(n, c, eval, Xt, Y + i * n, lambda, &vg, &ve, bt, sb);
+    Vg[i * d + i] = vg;
+    Ve[i * d + i] = ve;
+  }
+  free(Xt);
+  if (d > 4) { /* pairwise two-trait fits for the off-diagonals */
+    double *Ys = (double *)malloc(2 * n * sizeof(double));
+    for (size_t i = 0; i < d; ++i) {
+      memcpy(Ys, Y + i * n, n * sizeof(double));
+      for (size_t j = i + 1; j < d; ++j) {
+        memcpy(Ys + n, Y + j * n, n * sizeof(double));
+        double Vgs[4] = {Vg[i * d + i], 0, 0, Vg[j * d + j]}, Ves[4] = {Ve[i * d + i], 0, 0, Ve[j * d + j]};
+        double Bs[2 * MV_MAXC];
+        orc_mph_em('R', em_iter, em_prec, n, 2, c, eval, X, Ys, Vgs, Ves, Bs);
+        orc_mph_nr('R', nr_iter, nr_prec, n, 2, c, eval, X, Ys, Vgs, Ves, NULL);
+        Vg[i * d + j] = Vg[j * d + i] = Vgs[1];
+        Ve[i * d + j] = Ve[j * d + i] = Ves[1];
+      }
+    }
+    free(Ys);
+  }
+  mv_gls_B(n, d, c, eval, X, Y, Vg, Ve, B);
+}
+
+/* ------------------------------------------------------------------ the drivers */
+typedef struct {
+  size_t em_iter, nr_iter, n_region;
+  double em_prec, nr_prec, l_min, l_max, p_nr;
+} orc_mv_cfg;
+
+/* The null-model block of MVLMM::AnalyzeBimbam, src/mvlmm.cpp:3056-3208.  W: cw x n.  Outputs the REMLE and MLE fits
+ * (Vg, Ve, B as d x cw), both log-likelihoods; the per-SNP loop starts from the MLE fit (:3206-3208). */
+void orc_mvlmm_null(const orc_mv_cfg *cfg, size_t n, size_t d, size_t cw, const double *eval, const double *W,
+                    const double *Y, double *Vg_remle, double *Ve_remle, double *B_remle, double *logl_remle,
+                    double *Vg_mle, double *Ve_mle, double *B_mle, double *logl_mle) {
+  double Vg[MV_MAXD * MV_MAXD], Ve[MV_MAXD * MV_MAXD], B[MV_MAXD * MV_MAXC];
+  orc_mph_initial(cfg->em_iter, cfg->em_prec, cfg->nr_iter, cfg->nr_prec, n, d, cw, eval, W, Y, cfg->l_min, cfg->l_max,
+                  cfg->n_region, Vg, Ve, B);
+  orc_mph_em('R', cfg->em_iter, cfg->em_prec, n, d, cw, eval, W, Y, Vg, Ve, B);
+  *logl_remle = orc_mph_nr('R', cfg->nr_iter, cfg->nr_prec, n, d, cw, eval, W, Y, Vg, Ve, NULL);
+  mv_gls_B(n, d, cw, eval, W, Y, Vg, Ve, B); /* MphCalcBeta :3070 */
+  memcpy(Vg_remle, Vg, d * d * sizeof(double));
+  memcpy(Ve_remle, Ve, d * d * sizeof(double));
+  memcpy(B_remle, B, d * cw * sizeof(double));
+  orc_mph_em('L', cfg->em_iter, cfg->em_prec, n, d, cw, eval, W, Y, Vg, Ve, B);
+  *logl_mle = orc_mph_nr('L', cfg->nr_iter, cfg->nr_prec, n, d, cw, eval, W, Y, Vg, Ve, NULL);
+  mv_gls_B(n, d, cw, eval, W, Y, Vg, Ve, B); /* MphCalcBeta :3137 */
+  memcpy(Vg_mle, Vg, d * d * sizeof(double));
+  memcpy(Ve_mle, Ve, d * d * sizeof(double));
+  memcpy(B_mle, B, d * cw * sizeof(double));
+}
+
+/* The per-SNP block, src/mvlmm.cpp:3287-3374.  UtX: l x n (SNP-major).  out per SNP: beta[d], Vbeta[v], Vg[v], Ve[v],
+ * p_wald, p_lrt, p_score  (stride 3 v + d + 3).  B_null is d x cw. */
+void orc_mvlmm_batch(int a_mode, const orc_mv_cfg *cfg, size_t n, size_t d, size_t cw, const double *eval,
+                     const double *W, const double *Y, const double *UtX, size_t l, const double *Vg_null,
+                     const double *Ve_null, const double *B_null, double logl_H0, double *out) {
+  const size_t c = cw + 1, vs = d * (d + 1) / 2, stride = 3 * vs + d + 3;
+  double *X = (double *)malloc(c * n * sizeof(double));
+  memcpy(X, W, cw * n * sizeof(double));
+  for (size_t s = 0; s < l; ++s) {
+    const double *x = UtX + s * n;
+    memcpy(X + cw * n, x, n * sizeof(double));
+    double Vg[MV_MAXD * MV_MAXD], Ve[MV_MAXD * MV_MAXD], B[MV_MAXD * MV_MAXC], beta[MV_MAXD], Vbeta[MV_MAXD * MV_MAXD];
+    double p_wald = 0, p_lrt = 0, p_score = 0, logl_H1;
+    memset(beta, 0, sizeof(beta));
+    memset(Vbeta, 0, sizeof(Vbeta));
+    memcpy(Vg, Vg_null, d * d * sizeof(double));
+    memcpy(Ve, Ve_null, d * d * sizeof(double));
+    for (size_t i = 0; i < d; ++i) {
+      for (size_t j = 0; j < cw; ++j) B[i * c + j] = B_null[i * cw + j];
+      B[i * c + cw] = 0.0;
+    }
+    if (a_mode == 3 || a_mode == 4) p_score = orc_mph_calcp(n, d, cw, eval, x, W, Y, Vg_null, Ve_null, beta, Vbeta);
+    if (a_mode == 2 || a_mode == 4) {
+      logl_H1 = orc_mph_em('L', cfg->em_iter / 10, cfg->em_prec * 10, n, d, c, eval, X, Y, Vg, Ve, B);
+      orc_mph_calcp(n, d, cw, eval, x, W, Y, Vg, Ve, beta, Vbeta);
+      p_lrt = orc_cdf_chisq_Q(2.0 * (logl_H1 - logl_H0), (double)d);
+      if (p_lrt < cfg->p_nr) {
+        logl_H1 = orc_mph_nr('L', cfg->nr_iter / 10, cfg->nr_prec * 10, n, d, c, eval, X, Y, Vg, Ve, NULL);
+        orc_mph_calcp(n, d, cw, eval, x, W, Y, Vg, Ve, beta, Vbeta);
+        p_lrt = orc_cdf_chisq_Q(2.0 * (logl_H1 - logl_H0), (double)d);
+      }
+    }
+    if (a_mode == 1 || a_mode == 4) {
+      orc_mph_em('R', cfg->em_iter / 10, cfg->em_prec * 10, n, d, c, eval, X, Y, Vg, Ve, B);
+      p_wald = orc_mph_calcp(n, d, cw, eval, x, W, Y, Vg, Ve, beta, Vbeta);
+      if (p_wald < cfg->p_nr) {
+        orc_mph_nr('R', cfg->nr_iter / 10, cfg->nr_prec * 10, n, d, c, eval, X, Y, Vg, Ve, NULL);
+        p_wald = orc_mph_calcp(n, d, cw, eval, x, W, Y, Vg, Ve, beta, Vbeta);
+      }
+    }
+    double *o = out + s * stride;
+    for (size_t i = 0; i < d; ++i) o[i] = beta[i];
+    size_t q = 0;
+    for (size_t i = 0; i < d; ++i)
+      for (size_t j = i; j < d; ++j, ++q) {
+        o[d + q] = Vbeta[i * d + j];
+        o[d + vs + q] = Vg[i * d + j];
+        o[d + 2 * vs + q] = Ve[i * d + j];
+      }
+    o[d + 3 * vs] = p_wald;
+    o[d + 3 * vs + 1] = p_lrt;
+    o[d + 3 * vs + 2] = p_score;
+  }
+  free(X);
+}

@@ -34,10 +34,20 @@ SUMSTAT_DTYPE = np.dtype([(k, "f8") for k in
                            "logl_H1")])
 
 
+class MvCfg(C.Structure):
+    """orc_mv_cfg: the MVLMM members CopyFromParam fills (src/mvlmm.cpp:51-90) with PARAM's defaults"""
+    _fields_ = [("em_iter", C.c_size_t), ("nr_iter", C.c_size_t), ("n_region", C.c_size_t), ("em_prec", C.c_double),
+                ("nr_prec", C.c_double), ("l_min", C.c_double), ("l_max", C.c_double), ("p_nr", C.c_double)]
+
+
+def mv_cfg(em_iter=10000, nr_iter=100, em_prec=1e-4, nr_prec=1e-4, l_min=1e-5, l_max=1e5, n_region=10, p_nr=1e-3):
+    return MvCfg(em_iter, nr_iter, n_region, em_prec, nr_prec, l_min, l_max, p_nr)
+
+
 def build():
     so = os.path.join(_HERE, "libgemma_oracle.so")
-    src = os.path.join(_HERE, "gemma_oracle.c")
-    if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+    srcs = [os.path.join(_HERE, f) for f in ("gemma_oracle.c", "mvlmm_oracle.c")]
+    if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(f) for f in srcs):
         subprocess.check_call(["make", "-s", "-C", _HERE, "libgemma_oracle.so"])
     return so
 
@@ -78,6 +88,21 @@ def lib():
         L.orc_zero_small_eval.argtypes = [dp, C.c_size_t]
         L.orc_dgemm.argtypes = [C.c_char, C.c_char, C.c_size_t, C.c_size_t, C.c_size_t, C.c_double, dp,
                                 C.c_size_t, dp, C.c_size_t, C.c_double, dp, C.c_size_t]
+        sz, cd = C.c_size_t, C.c_double
+        L.orc_cdf_chisq_Q.restype = cd
+        L.orc_cdf_chisq_Q.argtypes = [cd, cd]
+        L.orc_mph_em.restype = cd
+        L.orc_mph_em.argtypes = [C.c_char, sz, cd, sz, sz, sz, dp, dp, dp, dp, dp, dp]
+        L.orc_mph_nr.restype = cd
+        L.orc_mph_nr.argtypes = [C.c_char, sz, cd, sz, sz, sz, dp, dp, dp, dp, dp, dp]
+        L.orc_mph_calcp.restype = cd
+        L.orc_mph_calcp.argtypes = [sz, sz, sz, dp, dp, dp, dp, dp, dp, dp, dp]
+        L.orc_mph_dev.restype = cd
+        L.orc_mph_dev.argtypes = [C.c_char, sz, sz, sz, dp, dp, dp, dp, dp, dp, dp]
+        L.orc_mvlmm_null.restype = None
+        L.orc_mvlmm_null.argtypes = [C.POINTER(MvCfg), sz, sz, sz, dp, dp, dp] + [dp] * 8
+        L.orc_mvlmm_batch.restype = None
+        L.orc_mvlmm_batch.argtypes = [C.c_int, C.POINTER(MvCfg), sz, sz, sz, dp, dp, dp, dp, sz, dp, dp, dp, cd, dp]
         _LIB = L
     return _LIB
 
@@ -488,3 +513,66 @@ def run_lmm(a_mode, G_all, indicator_idv, indicator_snp, y_all, W, K_full, maf_n
     null = dict(l_mle_null=l_mle_null, logl_mle_H0=logl_mle_H0, l_remle_null=l_remle_null,
                 logl_remle_H0=logl_remle_H0, pve=pve, pve_se=pve_se, trace_G=trace_G)
     return stats, null, dict(U=U, eval=ev, UtW=UtW, Uty=Uty, X=X)
+
+
+# --------------------------------------------------------------------------- multivariate LMM (mvlmm_oracle.c)
+def chisq_Q(x, nu):
+    return lib().orc_cdf_chisq_Q(float(x), float(nu))
+
+
+def mph_em(func, max_iter, max_prec, ev, X, Y, Vg, Ve, B):
+    """MphEM on X (c x n), Y (d x n); Vg, Ve, B (d x c) are updated in place; returns logl."""
+    d, n = Y.shape
+    return lib().orc_mph_em(func.encode(), max_iter, max_prec, n, d, X.shape[0], _dp(ev), _dp(X), _dp(Y), _dp(Vg), _dp(Ve),
+                            _dp(B))
+
+
+def mph_nr(func, max_iter, max_prec, ev, X, Y, Vg, Ve):
+    d, n = Y.shape
+    Hi = np.zeros((d * (d + 1), d * (d + 1)))
+    ll = lib().orc_mph_nr(func.encode(), max_iter, max_prec, n, d, X.shape[0], _dp(ev), _dp(X), _dp(Y), _dp(Vg), _dp(Ve),
+                          _dp(Hi))
+    return ll, Hi
+
+
+def mph_calcp(ev, x, W, Y, Vg, Ve):
+    d, n = Y.shape
+    beta, Vbeta = np.zeros(d), np.zeros((d, d))
+    p = lib().orc_mph_calcp(n, d, W.shape[0], _dp(ev), _dp(x), _dp(W), _dp(Y), _dp(Vg), _dp(Ve), _dp(beta), _dp(Vbeta))
+    return p, beta, Vbeta
+
+
+def mph_dev(func, ev, X, Y, Vg, Ve, want_dev=True):
+    d, n = Y.shape
+    g, H = np.zeros(d * (d + 1)), np.zeros((d * (d + 1), d * (d + 1)))
+    null = C.POINTER(C.c_double)()
+    ll = lib().orc_mph_dev(func.encode(), n, d, X.shape[0], _dp(ev), _dp(X), _dp(Y), _dp(Vg), _dp(Ve),
+                           _dp(g) if want_dev else null, _dp(H) if want_dev else null)
+    return ll, g, H
+
+
+def mvlmm_null(cfg, ev, W, Y):
+    """The null block of MVLMM::AnalyzeBimbam: dict with the REMLE and MLE fits (W: cw x n, Y: d x n)."""
+    d, n = Y.shape
+    cw = W.shape[0]
+    o = {k: np.zeros((d, d)) for k in ("Vg_remle", "Ve_remle", "Vg_mle", "Ve_mle")}
+    o["B_remle"], o["B_mle"] = np.zeros((d, cw)), np.zeros((d, cw))
+    lr, lm = C.c_double(), C.c_double()
+    lib().orc_mvlmm_null(C.byref(cfg), n, d, cw, _dp(ev), _dp(W), _dp(Y), _dp(o["Vg_remle"]), _dp(o["Ve_remle"]),
+                         _dp(o["B_remle"]), C.cast(C.byref(lr), C.POINTER(C.c_double)), _dp(o["Vg_mle"]),
+                         _dp(o["Ve_mle"]), _dp(o["B_mle"]), C.cast(C.byref(lm), C.POINTER(C.c_double)))
+    o["logl_remle"], o["logl_mle"] = lr.value, lm.value
+    return o
+
+
+def mvlmm_batch(a_mode, cfg, ev, W, Y, UtX_snpmajor, null):
+    """Per-SNP block; returns dict of arrays: beta (l x d), Vbeta/Vg/Ve (l x v), p_wald, p_lrt, p_score."""
+    d, n = Y.shape
+    l = UtX_snpmajor.shape[0]
+    v = d * (d + 1) // 2
+    out = np.zeros((l, 3 * v + d + 3))
+    X = _c64(UtX_snpmajor)
+    lib().orc_mvlmm_batch(a_mode, C.byref(cfg), n, d, W.shape[0], _dp(ev), _dp(W), _dp(Y), _dp(X), l, _dp(null["Vg_mle"]),
+                          _dp(null["Ve_mle"]), _dp(null["B_mle"]), null["logl_mle"], _dp(out))
+    return {"beta": out[:, :d], "Vbeta": out[:, d:d + v], "Vg": out[:, d + v:d + 2 * v], "Ve": out[:, d + 2 * v:d + 3 * v],
+            "p_wald": out[:, d + 3 * v], "p_lrt": out[:, d + 3 * v + 1], "p_score": out[:, d + 3 * v + 2]}
