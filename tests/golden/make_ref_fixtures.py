@@ -1,0 +1,261 @@
+"""Generates tests/golden/ref_*.npz: outputs of the REFERENCE ITSELF (oracle/_ref/gemma = /root/reference/src/*.cpp
+compiled unchanged against oracle/gslshim, see oracle/Makefile `ref`) on the datasets that ship in the reference tree,
+together with the inputs a test needs to redo the run without /root/reference (the GPU box never sees it).
+
+Run in the build container:  python tests/golden/make_ref_fixtures.py
+
+Before anything is stored the binary has to reproduce the reference's own golden values (test/dev_tests.rb:26-55,
+test/dev_test_suite.sh:40-118): BXD kinship checksum -116 / 198 lines, BXD -lm 4 word count 95134 and checksum
+3089042886, BXD -lmm 2 p_lrt 1.234747e-01 / max 9.997119e-01 / 73180 words, BXD -lmm 9 max l_mle 0.7531109 / 80498
+words, issue188 kinship checksum 194.  That is what validates the GSL shim under it.
+
+Fixtures:
+  ref_bxd.npz       BIMBAM + covariates (c = 3): cXX, -lmm 1/2/3/4/9 -maf 0.1, -lm 1..4
+  ref_issue188.npz  PLINK with missing calls and 132 unphenotyped individuals: -gk 1/2, -lmm 1..4, -lmm 4 with
+                    covariates, -lmm 1 on sXX, -lm 4, -gxe
+  ref_mv.npz        multivariate LMM: issue243 (first 800 SNPs, 2 traits) and issue188 genotypes with 3 simulated
+                    traits, -lmm 1..4 (-n 1 2 [3])
+"""
+import os
+import re
+import shutil
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+GEMMA = os.path.join(ROOT, "oracle", "_ref", "gemma")
+REF = "/root/reference"
+OUT = os.path.join(ROOT, "tests", "golden")
+STAT_COLS = ("beta", "se", "logl_H1", "l_remle", "l_mle", "p_wald", "p_lrt", "p_score")
+
+
+def gemma(tmp, *args):
+    r = subprocess.run([GEMMA] + [str(a) for a in args], cwd=tmp, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    if r.returncode != 0:
+        raise RuntimeError("reference failed: %s\n%s" % (" ".join(map(str, args)), r.stdout.decode()[-2000:]))
+
+
+def read_assoc(path):
+    with open(path) as f:
+        hdr = f.readline().split()
+        rows = [l.split() for l in f if l.strip()]
+    out = {"rs": np.array([r[hdr.index("rs")] for r in rows])}
+    for j, h in enumerate(hdr):
+        if h in ("chr", "rs", "allele1", "allele0"):
+            continue
+        out[h] = np.array([float(r[j]) for r in rows])
+    return out, len(hdr) * (len(rows) + 1)
+
+
+def read_log(path):
+    """`## key = value` scalars and the small matrices mvLMM prints under `## ...:` headings."""
+    sc, mats, cur = {}, {}, None
+    for line in open(path):
+        s = line.rstrip("\n")
+        if s.startswith("## ") and "=" in s and not s.rstrip().endswith(":"):
+            k, v = s[3:].split("=", 1)
+            try:
+                sc[k.strip()] = float(v.split()[0])
+            except (ValueError, IndexError):
+                pass
+            cur = None
+        elif s.startswith("## ") and s.rstrip().endswith(":"):
+            cur = s[3:].rstrip().rstrip(":").strip()
+            mats[cur] = []
+        elif cur is not None and s and not s.startswith("#"):
+            mats[cur].extend(float(x) for x in s.split())
+    return sc, {k: np.array(v) for k, v in mats.items() if v}
+
+
+def checksum(path):
+    """perl one-liner of test/dev_test_suite.sh:52: sum of sprintf('%.2f', substr(field, 0, 6))."""
+    tot = 0.0
+    num = re.compile(r"^[+-]?(\d+\.?\d*|\.\d+)([eE][+-]?\d+)?")  # perl's numeric prefix of a string
+    for line in open(path):
+        for x in line.split():
+            m = num.match(x[:6])
+            if m:
+                tot += float("%.2f" % float(m.group(0)))
+    return tot
+
+
+def read_matrix(path):
+    return np.array([[float(x) for x in l.split()] for l in open(path) if l.strip()])
+
+
+def stats_of(a, prefix, dst):
+    for c in STAT_COLS:
+        if c in a:
+            dst["%s_%s" % (prefix, c)] = a[c]
+
+
+def bxd(tmp):
+    E = REF + "/example/"
+    base = ["-g", E + "BXD_geno.txt.gz", "-p", E + "BXD_pheno.txt", "-c", E + "BXD_covariates2.txt", "-a", E + "BXD_snps.txt"]
+    gemma(tmp, *base, "-gk", "-o", "BXD")
+    cxx = os.path.join(tmp, "output", "BXD.cXX.txt")
+    assert len(open(cxx).readlines()) == 198 and "%.0f" % checksum(cxx) == "-116"
+    d = {"cXX": read_matrix(cxx)}
+    for m in (1, 2, 3, 4, 9):
+        gemma(tmp, *base, "-k", cxx, "-lmm", m, "-no-check", "-maf", "0.1", "-o", "L%d" % m)
+        a, words = read_assoc(os.path.join(tmp, "output", "L%d.assoc.txt" % m))
+        if m == 2:
+            assert words == 73180 and "%.6e" % a["p_lrt"][0] == "1.234747e-01" and "%.6e" % a["p_lrt"].max() == "9.997119e-01"
+        if m == 9:
+            assert words == 80498 and "%.7g" % a["l_mle"].max() == "0.7531109" and "%.6e" % a["p_lrt"].max() == "9.997119e-01"
+        stats_of(a, "lmm%d" % m, d)
+        d["rs"] = a["rs"]
+        d["af"] = a["af"]
+        if m == 1:
+            sc, _ = read_log(os.path.join(tmp, "output", "L1.log.txt"))
+            d["null"] = np.array([sc["pve estimate in the null model"], sc["se(pve) in the null model"],
+                                  sc["vg estimate in the null model"], sc["ve estimate in the null model"],
+                                  sc["REMLE log-likelihood in the null model"], sc["MLE log-likelihood in the null model"]])
+    for m in (1, 2, 3, 4):
+        gemma(tmp, *base, "-lm", m, "-maf", "0.1", "-o", "LM%d" % m)
+        f = os.path.join(tmp, "output", "LM%d.assoc.txt" % m)
+        a, words = read_assoc(f)
+        if m == 4:
+            assert words == 95134 and "%.0f" % checksum(f) == "3089042886"  # dev_test_suite.sh:67-68
+        stats_of(a, "lm%d" % m, d)
+    np.savez_compressed(os.path.join(OUT, "ref_bxd.npz"), **d)
+    print("ref_bxd.npz:", len(d["rs"]), "SNPs")
+
+
+def copy_plink(src_prefix, dst_prefix, fam_lines=None, n_snps=None):
+    fam = [l for l in open(src_prefix + ".fam") if l.strip()]
+    bim = [l for l in open(src_prefix + ".bim") if l.strip()]
+    raw = np.fromfile(src_prefix + ".bed", dtype=np.uint8)
+    nb = (len(fam) + 3) // 4
+    if n_snps is not None:
+        bim = bim[:n_snps]
+        raw = raw[: 3 + n_snps * nb]
+    open(dst_prefix + ".bed", "wb").write(raw.tobytes())
+    open(dst_prefix + ".bim", "w").writelines(bim)
+    open(dst_prefix + ".fam", "w").writelines(fam if fam_lines is None else fam_lines)
+    return raw, fam, bim
+
+
+def rs_index(bim, rs):
+    pos = {l.split()[1]: i for i, l in enumerate(bim)}
+    return np.array([pos[r] for r in rs], dtype=np.int64)
+
+
+def issue188(tmp):
+    src = REF + "/test/data/issue188/2000"
+    raw, fam, bim = copy_plink(src, os.path.join(tmp, "p188"))
+    n_total = len(fam)
+    rng = np.random.default_rng(188)
+    cov = np.column_stack([np.ones(n_total), rng.standard_normal(n_total), rng.integers(0, 2, n_total).astype(float)])
+    env = rng.standard_normal(n_total)
+    np.savetxt(os.path.join(tmp, "cov.txt"), cov, fmt="%.10g")
+    np.savetxt(os.path.join(tmp, "env.txt"), env, fmt="%.10g")
+    d = {"bed": raw, "n_total": np.array(n_total), "pheno_col6": np.array([l.split()[5] for l in fam]),
+         "cov": np.loadtxt(os.path.join(tmp, "cov.txt")), "env": np.loadtxt(os.path.join(tmp, "env.txt"))}
+    gemma(tmp, "-bfile", "p188", "-gk", 1, "-o", "k1")
+    gemma(tmp, "-bfile", "p188", "-gk", 2, "-o", "k2")
+    cxx, sxx = os.path.join(tmp, "output", "k1.cXX.txt"), os.path.join(tmp, "output", "k2.sXX.txt")
+    assert "%.0f" % checksum(cxx) == "194"  # dev_test_suite.sh:110
+    for tag, f in (("cXX", cxx), ("sXX", sxx)):
+        K = read_matrix(f)
+        d[tag + "_rows"] = K[:24]  # first rows + diagonal + a checksum are enough to pin the kinship; K itself is 8 MB
+        d[tag + "_diag"] = np.diag(K).copy()
+        d[tag + "_sum"] = np.array(K.sum())
+    runs = [("lmm%d" % m, ["-k", cxx, "-lmm", m]) for m in (1, 2, 3, 4)]
+    runs += [("lmm4cov", ["-k", cxx, "-lmm", 4, "-c", "cov.txt"]), ("lmm1sxx", ["-k", sxx, "-lmm", 1]),
+             ("lm4", ["-lm", 4]), ("lm1cov", ["-lm", 1, "-c", "cov.txt"]), ("gxe1", ["-k", cxx, "-lmm", 1, "-gxe", "env.txt"]),
+             ("gxe4", ["-k", cxx, "-lmm", 4, "-gxe", "env.txt"])]
+    for tag, args in runs:
+        gemma(tmp, "-bfile", "p188", *args, "-o", tag)
+        a, _ = read_assoc(os.path.join(tmp, "output", tag + ".assoc.txt"))
+        stats_of(a, tag, d)
+        d[tag + "_snp"] = rs_index(bim, a["rs"])
+        for extra in ("n_miss", "af"):
+            if extra in a:
+                d[tag + "_" + extra] = a[extra]
+        if tag in ("lmm1", "lmm4cov"):
+            sc, _ = read_log(os.path.join(tmp, "output", tag + ".log.txt"))
+            d[tag + "_null"] = np.array([sc["pve estimate in the null model"], sc["se(pve) in the null model"],
+                                         sc["vg estimate in the null model"], sc["ve estimate in the null model"],
+                                         sc["REMLE log-likelihood in the null model"], sc["MLE log-likelihood in the null model"]])
+            d[tag + "_counts"] = np.array([sc["number of analyzed individuals"], sc["number of analyzed SNPs/var"]])
+    np.savez_compressed(os.path.join(OUT, "ref_issue188.npz"), **d)
+    print("ref_issue188.npz:", {k: v.shape for k, v in d.items() if k.endswith("_snp")})
+    return raw, fam, bim
+
+
+MV_COLS_EXTRA = ("p_wald", "p_lrt", "p_score")
+
+
+def mv_run(tmp, prefix, tag, kfile, traits, d, bim):
+    for m in (1, 2, 3, 4):
+        gemma(tmp, "-bfile", prefix, "-k", kfile, "-lmm", m, "-n", *traits, "-o", "%s_m%d" % (tag, m))
+        a, _ = read_assoc(os.path.join(tmp, "output", "%s_m%d.assoc.txt" % (tag, m)))
+        for c, v in a.items():
+            if c.startswith("beta_") or c.startswith("Vbeta_") or c in MV_COLS_EXTRA:
+                d["%s_m%d_%s" % (tag, m, c)] = v
+        d["%s_snp" % tag] = rs_index(bim, a["rs"])
+        if m == 4:
+            sc, mats = read_log(os.path.join(tmp, "output", "%s_m4.log.txt" % tag))
+            d[tag + "_logl_null"] = np.array([sc["REMLE log-likelihood in the null model"], sc["MLE log-likelihood in the null model"]])
+            for k, v in mats.items():
+                key = k.replace(" ", "_").replace("(", "").replace(")", "").replace(",", "")
+                d["%s_log_%s" % (tag, key[:60])] = v
+
+
+def mv(tmp, raw188, fam188, bim188):
+    d = {}
+    # (a) issue243: 1000 individuals, 2 traits, first 800 SNPs
+    src = REF + "/test/data/issue243/multivariate_2traits"
+    raw, fam, bim = copy_plink(src, os.path.join(tmp, "mv2"), n_snps=800)
+    d["a_bed"] = raw
+    d["a_pheno"] = np.array([[float(x) for x in l.split()[5:7]] for l in fam])
+    gemma(tmp, "-bfile", "mv2", "-gk", 1, "-o", "mv2")
+    mv_run(tmp, "mv2", "a", os.path.join(tmp, "output", "mv2.cXX.txt"), (1, 2), d, bim)
+    # (b) issue188 genotypes, 3 simulated traits with a shared polygenic component (interior V_g, V_e), a few NA
+    n_total = len(fam188)
+    nb = (n_total + 3) // 4
+    codes = np.unpackbits(raw188[3:].reshape(-1, nb)[:400], axis=1, bitorder="little").reshape(400, -1, 2)[:, :n_total]
+    g = (codes[:, :, 0] + codes[:, :, 1]).astype(float)  # rough allele count (missing 01 -> 1): only used to simulate
+    g = (g - g.mean(1, keepdims=True)) / (g.std(1, keepdims=True) + 1e-9)
+    rng = np.random.default_rng(243)
+    A = np.array([[1.0, 0.5, 0.2], [0.0, 0.8, 0.3], [0.0, 0.0, 0.7]])
+    Y = (g.T @ rng.standard_normal((400, 3)) / np.sqrt(400)) @ A + rng.standard_normal((n_total, 3)) @ np.array(
+        [[0.9, 0.2, 0.0], [0.0, 0.8, 0.1], [0.0, 0.0, 1.0]])
+    Y += 0.35 * g[7][:, None] * np.array([1.0, -0.5, 0.8])  # one SNP with an effect large enough for Newton-Raphson
+    txt = [["%.8g" % v for v in row] for row in Y]
+    for i in rng.choice(n_total, 25, replace=False):
+        txt[i][rng.integers(0, 3)] = "NA"
+    fam_lines = [" ".join(l.split()[:5] + t) + "\n" for l, t in zip(fam188, txt)]
+    copy_plink(REF + "/test/data/issue188/2000", os.path.join(tmp, "mv3"), fam_lines=fam_lines)
+    d["b_pheno_txt"] = np.array(txt)
+    gemma(tmp, "-bfile", "mv3", "-gk", 1, "-o", "mv3")
+    mv_run(tmp, "mv3", "b", os.path.join(tmp, "output", "mv3.cXX.txt"), (1, 2, 3), d, bim188)
+    np.savez_compressed(os.path.join(OUT, "ref_mv.npz"), **d)
+    print("ref_mv.npz:", len(d["a_snp"]), "+", len(d["b_snp"]), "SNPs")
+
+
+def main():
+    if not os.path.exists(GEMMA):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "ref"])
+    tmp = tempfile.mkdtemp(prefix="gemma_ref_")
+    try:
+        which = sys.argv[1:] or ["bxd", "issue188", "mv"]
+        if "bxd" in which:
+            bxd(tmp)
+        raw, fam, bim = None, None, None
+        if "issue188" in which:
+            raw, fam, bim = issue188(tmp)
+        if "mv" in which:
+            if raw is None:
+                raw, fam, bim = copy_plink(REF + "/test/data/issue188/2000", os.path.join(tmp, "p188"))
+            mv(tmp, raw, fam, bim)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+if __name__ == "__main__":
+    main()
