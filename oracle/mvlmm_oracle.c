@@ -101,6 +101,32 @@ static void mv_jacobi(const double *A, size_t m, double *w, double *V) {
   }
 }
 
+/* Optional LAPACK basis.  The reference's ML EM depends on the signs/order LAPACK's dsyevr happens to return for the
+ * d x d problem of EigenProc (see mv_jacobi above), so its `-lmm 2/4` output for d >= 3 is reproducible only with the same
+ * routine.  A test can hand over the address of dsyevr_ (scipy's OpenBLAS: the one oracle/_ref/gemma is linked against);
+ * EigenProc then calls it exactly as src/lapack.cpp:173-236 does (JOBZ=V, RANGE=A, UPLO=L on the row-major array, ABSTOL
+ * 1e-7, eigenvector k = column k after the transpose).  Default (no hook): the Jacobi convention above. */
+typedef void (*mv_dsyevr_fn)(char *, char *, char *, int *, double *, int *, double *, double *, int *, int *, double *, int *,
+                             double *, double *, int *, int *, double *, int *, int *, int *, int *);
+static mv_dsyevr_fn mv_dsyevr = 0;
+void orc_mv_set_lapack_dsyevr(void *fn) { mv_dsyevr = (mv_dsyevr_fn)fn; }
+
+static void mv_eig(const double *A, size_t m, double *w, double *V) {
+  if (!mv_dsyevr) {
+    mv_jacobi(A, m, w, V);
+    return;
+  }
+  double a[MV_MAXD * MV_MAXD], z[MV_MAXD * MV_MAXD], work[26 * MV_MAXD + 64], vl = 0.0, vu = 0.0, abstol = 1.0e-7;
+  int n = (int)m, lda = (int)m, ldz = (int)m, il = 0, iu = 0, mm = 0, info = 0, isuppz[2 * MV_MAXD];
+  int lwork = (int)(sizeof(work) / sizeof(work[0])), iwork[10 * MV_MAXD + 16], liwork = 10 * MV_MAXD + 16;
+  char jobz = 'V', range = 'A', uplo = 'L';
+  memcpy(a, A, m * m * sizeof(double));
+  mv_dsyevr(&jobz, &range, &uplo, &n, a, &lda, &vl, &vu, &il, &iu, &abstol, &mm, w, z, &ldz, isuppz, work, &lwork, iwork,
+            &liwork, &info);
+  for (size_t i = 0; i < m; ++i)
+    for (size_t k = 0; k < m; ++k) V[i * m + k] = z[k * m + i];
+}
+
 /* LU with partial pivoting (GSL linalg/lu.c through src/lapack.cpp:307-352): inverse and log|det| */
 static double mv_lu_invert(const double *A, size_t m, double *Ai) {
   double lu[MV_MAXDC * MV_MAXDC];
@@ -188,7 +214,7 @@ static double mv_eigen_proc(size_t d, const double *Vg, const double *Ve, double
   double w[MV_MAXD], Ul[MV_MAXD * MV_MAXD], Veh[MV_MAXD * MV_MAXD], Vehi[MV_MAXD * MV_MAXD];
   double T1[MV_MAXD * MV_MAXD], Lam[MV_MAXD * MV_MAXD];
   double logdet_Ve = 0.0;
-  mv_jacobi(Ve, d, w, Ul);
+  mv_eig(Ve, d, w, Ul);
   memset(Veh, 0, sizeof(Veh));
   memset(Vehi, 0, sizeof(Vehi));
   for (size_t i = 0; i < d; ++i) {
@@ -203,9 +229,10 @@ static double mv_eigen_proc(size_t d, const double *Vg, const double *Ve, double
   }
   mv_mm(0, d, d, d, Vg, Vehi, T1);
   mv_mm(0, d, d, d, Vehi, T1, Lam);
-  for (size_t a = 0; a < d; ++a) /* exact symmetry for the Jacobi sweep */
-    for (size_t b = a + 1; b < d; ++b) Lam[a * d + b] = Lam[b * d + a] = 0.5 * (Lam[a * d + b] + Lam[b * d + a]);
-  mv_jacobi(Lam, d, Dl, Ul);
+  if (!mv_dsyevr)
+    for (size_t a = 0; a < d; ++a) /* exact symmetry for the Jacobi sweep (LAPACK reads one triangle only) */
+      for (size_t b = a + 1; b < d; ++b) Lam[a * d + b] = Lam[b * d + a] = 0.5 * (Lam[a * d + b] + Lam[b * d + a]);
+  mv_eig(Lam, d, Dl, Ul);
   for (size_t i = 0; i < d; ++i)
     if (Dl[i] < 0) Dl[i] = 0;
   mv_mm(1, d, d, d, Ul, Veh, UltVeh);

@@ -520,6 +520,25 @@ def chisq_Q(x, nu):
     return lib().orc_cdf_chisq_Q(float(x), float(nu))
 
 
+def mv_use_lapack_basis(on=True):
+    """EigenProc of the multivariate oracle through LAPACK's dsyevr_ (the OpenBLAS inside scipy, the routine oracle/_ref/gemma
+    is linked against) instead of the Jacobi convention: the reference's ML EM depends on the eigenvector signs dsyevr
+    returns (mvlmm_oracle.c, mv_eig), so only this mode reproduces its `-lmm 2/4` output on every SNP for d >= 3."""
+    L = lib()
+    L.orc_mv_set_lapack_dsyevr.argtypes = [C.c_void_p]
+    L.orc_mv_set_lapack_dsyevr.restype = None
+    if not on:
+        L.orc_mv_set_lapack_dsyevr(None)
+        return
+    import glob
+    import scipy
+    libs = glob.glob(os.path.join(os.path.dirname(os.path.dirname(scipy.__file__)), "scipy.libs", "libscipy_openblas*.so"))
+    if not libs:
+        raise RuntimeError("scipy's OpenBLAS not found")
+    ob = C.CDLL(libs[0])
+    L.orc_mv_set_lapack_dsyevr(C.cast(ob.scipy_dsyevr_, C.c_void_p))
+
+
 def mph_em(func, max_iter, max_prec, ev, X, Y, Vg, Ve, B):
     """MphEM on X (c x n), Y (d x n); Vg, Ve, B (d x c) are updated in place; returns logl."""
     d, n = Y.shape
