@@ -464,6 +464,7 @@ class LM:
         y = np.ascontiguousarray(y, dtype=np.float64)
         W = np.ascontiguousarray(W, dtype=np.float64).reshape(len(y), -1)
         L.check(L.lib().gemma_hip_lm_setup(self.a_mode, W.shape[0], W.shape[1], _ptr(W), _ptr(y)), "LM.setup")
+        geno = np.ascontiguousarray(geno)  # SNP-major rows (a Fortran-ordered array would hand over a stride of 1)
         try:
             if indicator_idv is not None:
                 ind = np.ascontiguousarray(indicator_idv, dtype=np.int32)
