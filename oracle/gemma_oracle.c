@@ -11,9 +11,14 @@
  * finders, gsl_root_test_interval/delta and gsl_cdf_fdist_Q / gsl_cdf_chisq_Q
  * are restated here from GSL's published algorithms (roots/brent.c,
  * roots/newton.c, roots/convergence.c, cdf/fdist.c, cdf/beta_inc.c,
- * cdf/gamma.c).  The restatement is pinned by the reference's own golden
- * values for BXD (test/dev_tests.rb:26-55, test/dev_test_suite.sh:51-52):
- * see tests/test_oracle_golden.py.
+ * cdf/gamma.c).  PINNING, two layers: (1) the reference's own golden values
+ * for BXD (test/dev_tests.rb:26-55, test/dev_test_suite.sh:51-52), see
+ * tests/test_oracle_golden.py; (2) outputs of the reference itself -- its
+ * sources compiled unchanged into oracle/_ref/gemma (oracle/Makefile `ref`,
+ * GSL API from oracle/gslshim) and run on BXD, issue188 and issue243 -- which
+ * this file reproduces to every printed digit for -gk 1/2, -lmm 1/2/3/4/9,
+ * covariates, -lm 1..4 and GXE (tests/test_reference_pin.py, fixtures
+ * tests/golden/ref_*.npz).
  *
  * Plain C99, links libm only.  Dense linear algebra that the reference hands
  * to OpenBLAS (cblas_dgemm, dsyevr_) is done by the Python side of the oracle

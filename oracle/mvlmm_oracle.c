@@ -4,11 +4,17 @@
  * statistic of MphCalcP, the Newton-Raphson of MphNR (gradient / observed Hessian of CalcDev) and MphInitial.  Only
  * tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may call it; the product (gemma_amd/csrc) never does.
  *
- * PINNING: the reference's own tests hold no numeric golden for this path (test/dev_test_suite.sh:196-208 checks the
- * line count of the 5-trait run; its value checksum "777.32" is commented out), and the reference cannot be built in
- * this image (GSL / OpenBLAS absent).  tests/test_oracle_mvlmm.py therefore checks this file against (a) that commented
- * checksum on the reference's own data, (b) the univariate oracle (d = 1 must reproduce -lmm), (c) finite differences
- * of the log-likelihood for the gradient and Hessian.  Until a reference binary confirms it: "parity weakly pinned".
+ * PINNING: the reference's own tests hold no numeric golden for this path (test/dev_test_suite.sh:196-208 checks a line
+ * count; its value checksum is commented out).  It is pinned on the reference ITSELF instead: oracle/_ref (the reference's
+ * sources compiled unchanged against oracle/gslshim, oracle/Makefile `ref`) run on issue243 (2 traits) and on issue188's
+ * genotypes with 3 simulated traits; this file reproduces every printed digit of beta, Vbeta, p_wald / p_lrt / p_score
+ * and the null-model matrices in all four modes for d = 2 and in the REML / score modes for d = 3, and the reference's
+ * free functions MphEM / MphNR / MphCalcP called directly (oracle/ref_bridge.cpp) to 1e-9 (tests/test_reference_pin.py).
+ * The one exception is the reference's own instability: its ML EM for d >= 3 depends on the eigenvector signs LAPACK
+ * happens to return (mv_jacobi below), which flip under 1e-15 perturbations, so on ~10 % of SNPs its -lmm 2/4 trajectory
+ * is not reproducible by anything but the same binary on the same machine; there the test bounds the likelihood instead.
+ * tests/test_oracle_mvlmm.py keeps the independent legs: the univariate oracle at d = 1 and finite differences of the
+ * log-likelihood for the gradient and Hessian.
  *
  * Where the reference expands  P = H^-1 - H^-1 X Q^-1 X^T H^-1  into eight products of precomputed tables
  * (src/mvlmm.cpp:1863-2049), this file evaluates the same quantities from u_k = (P y)_k directly; the algebra is

@@ -6,6 +6,8 @@ module; nothing under gemma_amd/ does.  It drives the C restatement
 through numpy/scipy's bundled OpenBLAS (cblas_dgemm == numpy matmul,
 dsyevr_ == scipy.linalg.lapack.dsyevr), plus restatements of the reference's file
 readers / QC filters so that the reference's own golden values (BXD) can be reproduced.
+The whole restatement is pinned against the reference itself (oracle/_ref/gemma, built by
+`make -C oracle ref` from /root/reference/src unchanged): tests/test_reference_pin.py.
 
 File:line citations are relative to /root/reference.
 """

@@ -112,7 +112,7 @@ def test_plink_decode_and_missing(oracle):
 
 def test_lm_against_ols(oracle):
     """-lm restatement (src/lm.cpp:224-287,382-640) against an independent OLS fit: Wald p == two-sided t-test.
-    (The reference's own -lm golden, test/dev_tests.rb:13-24, needs the missing mouse_hs1940 genotype blob.)"""
+    (The reference's own -lm outputs on BXD and issue188 are checked in tests/test_reference_pin.py.)"""
     from scipy import stats
     rng = np.random.default_rng(1)
     n, c = 200, 3
