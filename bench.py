@@ -14,8 +14,9 @@ with no collective in the timed region (weak scaling: B SNPs per rank per step).
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
   roofline     -- the dominant kernel (UtX GEMM): algorithmic flops / hipEvent-measured duration
-  cpu_baseline -- the oracle (kind "port": OpenBLAS dgemm through numpy + the serial C per-SNP
-                  loop of oracle/) timed on this box's host cores on a bounded SNP sample.
+  cpu_baseline -- the reference's own LMM::Analyze (kind "reference": oracle/_ref/libgemma_ref.so, the reference's
+                  sources compiled unchanged) timed on this box's host cores on a bounded SNP sample; the oracle
+                  (kind "port") beside it, and alone when that library is absent.
 """
 import argparse
 import json
@@ -307,8 +308,12 @@ def main():
 
 
 def cpu_baseline(args, np, torch, block, U, ev, UtW, Uty, gpu_res, n, B):
-    """Oracle ("port" of the reference's CPU path) on a bounded sample of the same block: OpenBLAS dgemm
-    (numpy) on all host cores for U^T X, then the serial per-SNP loop (src/lmm.cpp:1526-1562)."""
+    """The CPU path on a bounded sample of the last timed block, on this box's host cores.
+    kind "reference": the reference's own LMM::Analyze (src/lmm.cpp:1474-1658: Xlarge batching, mean imputation,
+    fast_dgemm(U^T X) on OpenBLAS, the serial per-SNP loop), called in-process from oracle/_ref/libgemma_ref.so -- the
+    reference's sources compiled unchanged (oracle/Makefile `ref`) -- when that library travelled with the repo;
+    kind "port": the oracle (numpy/OpenBLAS dgemm + the serial C restatement of the same loop) otherwise.  The oracle leg
+    always runs: it is also the parity check of the timed GPU block."""
     from oracle import oracle as O
     S = min(args.cpu_sample, B)
     raw = block[:S].cpu().numpy()
@@ -322,19 +327,36 @@ def cpu_baseline(args, np, torch, block, U, ev, UtW, Uty, gpu_res, n, B):
     t1 = time.perf_counter()
     ref = O.lmm_batch_UtX(args.a_mode, evh, UtWh, Utyh, UtX, plink_nan_rule=1)
     t2 = time.perf_counter()
-    # parity of the timed GPU block against the checker, on the sample
-    worst = 0.0
-    for k, col in (("beta", 0), ("se", 1), ("p_wald", 4), ("logl_H1", 7)):
-        r = ref[k]
-        g = gpu_res[:S, col]
-        ok = np.isfinite(r)
-        worst = max(worst, float(np.max(np.abs(g[ok] - r[ok]) / np.abs(r[ok]))))
-    # the reference amortises the GEMM over 20000-SNP batches: scale the GEMM leg by its flop rate
+
+    def worst_err(r):
+        w = 0.0
+        for k, col in (("beta", 0), ("se", 1), ("p_wald", 4), ("logl_H1", 7)):
+            g = gpu_res[:S, col]
+            ok = np.isfinite(r[k])
+            w = max(w, float(np.max(np.abs(g[ok] - r[k][ok]) / np.abs(r[k][ok]))))
+        return w
+
+    # the reference amortises the GEMM over 20000-SNP batches: report the GEMM leg's flop rate beside it
     gemm_rate = 2.0 * n * n * S / (t1 - t0)
-    return {"value": round(S / (t2 - t0), 2), "unit": "SNPs/s", "cores": cores, "kind": "port",
+    port = {"value": round(S / (t2 - t0), 2), "unit": "SNPs/s", "cores": cores, "kind": "port",
             "sample": "%d SNPs of the last timed block: numpy/OpenBLAS dgemm on %d threads (%.1f GFLOP/s) %.2f s + "
                       "serial per-SNP loop on 1 thread %.2f s" % (S, cores, gemm_rate / 1e9, t1 - t0, t2 - t1),
-            "gpu_vs_oracle_max_rel_err": worst}
+            "gpu_vs_oracle_max_rel_err": worst_err(ref)}
+    if args.a_mode != 1 or O.ref_lib() is None:  # the other modes need the null-model scalars handed over too
+        return port
+    try:
+        t3 = time.perf_counter()
+        rr = O.ref_lmm_analyze(args.a_mode, Uh, evh, UtWh, Utyh, X)
+        t4 = time.perf_counter()
+    except Exception as e:  # the checker must never take the bench down
+        port["reference_error"] = repr(e)[:200]
+        return port
+    threads = O.ref_blas_threads()
+    return {"value": round(S / (t4 - t3), 2), "unit": "SNPs/s", "cores": threads, "kind": "reference",
+            "sample": "%d SNPs of the last timed block through the reference's own LMM::Analyze (oracle/_ref/libgemma_ref.so = "
+                      "/root/reference/src compiled unchanged, GSL API from oracle/gslshim): %.2f s wall, OpenBLAS dgemm on %d "
+                      "threads + its serial per-SNP loop, incl. its 2 x n x 20000 batch buffers" % (S, t4 - t3, threads),
+            "gpu_vs_reference_max_rel_err": worst_err(rr), "port": port}
 
 
 if __name__ == "__main__":

@@ -517,6 +517,58 @@ def run_lmm(a_mode, G_all, indicator_idv, indicator_snp, y_all, W, K_full, maf_n
     return stats, null, dict(U=U, eval=ev, UtW=UtW, Uty=Uty, X=X)
 
 
+# --------------------------------------------------------------------------- the reference itself (oracle/_ref)
+_REF = None
+
+
+def ref_lib():
+    """oracle/_ref/libgemma_ref.so -- the reference's own objects (built by `make -C oracle ref` from /root/reference/src,
+    unchanged) plus the C entry points of oracle/ref_bridge.cpp -- or None when it was never built."""
+    global _REF
+    if _REF is None:
+        path = os.path.join(_HERE, "_ref", "libgemma_ref.so")
+        if not os.path.exists(path):
+            return None
+        try:
+            _REF = C.CDLL(path)
+        except OSError:
+            return None
+        P = C.POINTER(C.c_double)
+        _REF.ref_lmm_analyze.restype = C.c_long
+        _REF.ref_lmm_analyze.argtypes = [C.c_int, C.c_size_t, C.c_size_t, C.c_size_t] + [P] * 7 + [C.c_double, C.c_double, C.c_size_t,
+                                                                                               C.c_double, C.c_double, P]
+    return _REF
+
+
+def ref_blas_threads():
+    import glob
+    import scipy
+    libs = glob.glob(os.path.join(os.path.dirname(os.path.dirname(scipy.__file__)), "scipy.libs", "libscipy_openblas*.so"))
+    return int(C.CDLL(libs[0]).scipy_openblas_get_num_threads()) if libs else 0
+
+
+def ref_lmm_analyze(a_mode, U, ev, UtW, Uty, X_snpmajor_nan, l_mle_null=0.0, logl_mle_H0=0.0, l_min=1e-5, l_max=1e5, n_region=10):
+    """LMM::Analyze of the reference (src/lmm.cpp:1474-1658), called in-process on SNP-major rows over the analysed
+    individuals (NaN = NA).  Returns SUMSTAT records like lmm_analyze."""
+    R = ref_lib()
+    if R is None:
+        raise RuntimeError("oracle/_ref/libgemma_ref.so not built")
+    U, ev, Uty = _c64(U), _c64(ev), _c64(Uty)
+    n = U.shape[0]
+    UtW = _c64(np.asarray(UtW).reshape(n, -1))
+    X = _c64(X_snpmajor_nan)
+    W, y = _c64(U @ UtW), _c64(U @ Uty)  # only echoed by the reference's debug writer
+    out = np.zeros((X.shape[0], 8))
+    got = R.ref_lmm_analyze(a_mode, n, UtW.shape[1], X.shape[0], _dp(U), _dp(ev), _dp(UtW), _dp(Uty), _dp(W), _dp(y), _dp(X),
+                            l_min, l_max, n_region, l_mle_null, logl_mle_H0, _dp(out))
+    assert got == X.shape[0], (got, X.shape[0])
+    st = np.zeros(X.shape[0], dtype=[(k, "<f8") for k in ("beta", "se", "lambda_remle", "lambda_mle", "p_wald", "p_lrt", "p_score",
+                                                        "logl_H1")])
+    for j, k in enumerate(st.dtype.names):
+        st[k] = out[:, j]
+    return st
+
+
 # --------------------------------------------------------------------------- multivariate LMM (mvlmm_oracle.c)
 def chisq_Q(x, nu):
     return lib().orc_cdf_chisq_Q(float(x), float(nu))

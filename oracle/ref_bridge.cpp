@@ -2,9 +2,18 @@
 // call them with plain arrays through ctypes and compare function by function with the restatement in mvlmm_oracle.c.
 // Linked with the reference's objects (oracle/Makefile `ref` -> oracle/_ref/libgemma_ref.so); nothing is copied: the
 // declarations below repeat the signatures the reference defines at the cited lines.
+#include <cmath>
 #include <cstring>
+#include <functional>
+#include <iostream>
+#include <set>
+#include <sstream>
+#include <string>
+#include <tuple>
+#include <vector>
 #include "gsl/gsl_matrix.h"
 #include "gsl/gsl_vector.h"
+#include "lmm.h"  // the reference's own header (-I/root/reference/src): class LMM, SUMSTAT, SnpNameValues
 
 // src/mvlmm.cpp:599-604
 double MphEM(const char func_name, const size_t max_iter, const double max_prec, const gsl_vector *eval, const gsl_matrix *X,
@@ -67,5 +76,44 @@ double ref_EigenProc(size_t d, const double *Vg, const double *Ve, double *Dl, d
   gsl_matrix_view Vgm = mview(Vg, d, d), Vem = mview(Ve, d, d), A = mview(UltVeh, d, d), Bi = mview(UltVehi, d, d);
   gsl_vector_view D = vview(Dl, d);
   return EigenProc(&Vgm.matrix, &Vem.matrix, &D.vector, &A.matrix, &Bi.matrix);
+}
+
+// The reference's univariate driver itself: LMM::Analyze (src/lmm.cpp:1474-1658) -- its batching into Xlarge, mean imputation,
+// fast_dgemm("T","N",U,Xlarge) and the per-SNP loop of batch_compute (CalcUab, CalcRLScore, CalcLambda, CalcRLWald, LRT) -- fed
+// from memory through the fetch_snp callback AnalyzeBimbam builds from a file (:1675-1700).  X is SNP-major, l x n, NaN = NA;
+// every individual is analysed.  out: l records of SUMSTAT (8 doubles, src/param.h:54-66).  Used by tests and by bench.py's
+// cpu_baseline leg ("kind": "reference"); returns the number of SNPs the reference produced.
+long ref_lmm_analyze(int a_mode, size_t n, size_t c, size_t l, const double *U, const double *eval, const double *UtW,
+                     const double *Uty, const double *W, const double *y, const double *X, double l_min, double l_max,
+                     size_t n_region, double l_mle_null, double logl_mle_H0, double *out) {
+  LMM lmm;
+  lmm.a_mode = a_mode;
+  lmm.d_pace = 100000000;
+  lmm.l_min = l_min; lmm.l_max = l_max; lmm.n_region = n_region;
+  lmm.l_mle_null = l_mle_null; lmm.logl_mle_H0 = logl_mle_H0;
+  lmm.ni_total = lmm.ni_test = n;
+  lmm.ns_total = lmm.ns_test = l;
+  lmm.n_cvt = c;
+  lmm.time_UtX = lmm.time_opt = 0.0;
+  lmm.indicator_idv.assign(n, 1);
+  lmm.indicator_snp.assign(l, 1);
+  gsl_matrix_view Um = mview(U, n, n), UtWm = mview(UtW, n, c), Wm = mview(W, n, c);
+  gsl_vector_view ev = vview(eval, n), Utyv = vview(Uty, n), yv = vview(y, n);
+  std::function<SnpNameValues(size_t)> fetch = [&](size_t t) {
+    std::vector<double> gs(X + t * n, X + (t + 1) * n);
+    return std::make_tuple(std::string("s") + std::to_string(t), gs);
+  };
+  std::ostringstream sink;  // the progress bar goes to cout
+  std::streambuf *old = std::cout.rdbuf(sink.rdbuf());
+  lmm.Analyze(fetch, &Um.matrix, &ev.vector, &UtWm.matrix, &Utyv.vector, &Wm.matrix, &yv.vector, std::set<std::string>());
+  std::cout.rdbuf(old);
+  const size_t m = lmm.sumStat.size() < l ? lmm.sumStat.size() : l;
+  for (size_t i = 0; i < m; i++) {
+    const SUMSTAT &s = lmm.sumStat[i];
+    double *o = out + 8 * i;
+    o[0] = s.beta; o[1] = s.se; o[2] = s.lambda_remle; o[3] = s.lambda_mle;
+    o[4] = s.p_wald; o[5] = s.p_lrt; o[6] = s.p_score; o[7] = s.logl_H1;
+  }
+  return (long)lmm.sumStat.size();
 }
 }

@@ -311,3 +311,24 @@ def test_reference_eigenproc_basis_is_unstable(mvcases):
                             flips += 1
                 prev = Ai
     assert flips > 0
+
+
+@pytest.mark.parametrize("mode", [1, 4])
+def test_reference_lmm_analyze_in_process(oracle, bxd, ref_bxd, mode):
+    """LMM::Analyze of the reference called in-process (oracle/ref_bridge.cpp: ref_lmm_analyze, what bench.py times as
+    cpu_baseline kind "reference"): at full precision the restatement follows it to 1e-7 on beta / se / p and 1e-12 on
+    logl; its printed output is the fixture."""
+    if oracle.ref_lib() is None:
+        pytest.skip("oracle/_ref/libgemma_ref.so not built")
+    X = np.ascontiguousarray(bxd["X"], dtype=np.float64)
+    got = oracle.ref_lmm_analyze(mode, bxd["U"], bxd["eval"], bxd["UtW"], bxd["Uty"], X, l_mle_null=bxd["null"][0],
+                                 logl_mle_H0=bxd["null"][1])
+    mine = bxd["stat_mode%d" % mode]
+    for k in ("beta", "se", "p_wald", "logl_H1") + (("p_lrt", "p_score") if mode == 4 else ()):
+        e = R.rel_err(mine[k], got[k])
+        assert np.nanmax(e) <= 2e-7, (k, float(np.nanmax(e)))
+    assert np.nanmax(R.rel_err(mine["logl_H1"], got["logl_H1"])) <= 1e-10
+    e = R.rel_err(mine["lambda_remle"], got["lambda_remle"])
+    assert np.mean(e <= 1e-6) >= 0.99 and np.nanmax(e) <= 1e-3
+    # a failed REML search (Newton cycling for 100 iterations, NaN) is itself rounding-sensitive: at most the known few
+    assert int(np.isnan(mine["p_wald"]).sum()) <= 3 and int(np.isnan(got["p_wald"]).sum()) <= 3
