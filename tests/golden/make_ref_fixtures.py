@@ -13,6 +13,8 @@ Fixtures:
   ref_bxd.npz       BIMBAM + covariates (c = 3): cXX, -lmm 1/2/3/4/9 -maf 0.1, -lm 1..4
   ref_issue188.npz  PLINK with missing calls and 132 unphenotyped individuals: -gk 1/2, -lmm 1..4, -lmm 4 with
                     covariates, -lmm 1 on sXX, -lm 4, -gxe
+  ref_loco.npz      -loco (BIMBAM only in the reference: PlinkKin ignores it, src/param.cpp:1307): issue188 re-written as a
+                    mean-genotype file with four synthetic chromosomes; -gk 1 -loco c and -lmm 1/4 -loco c for c = 2, 4
   ref_mv.npz        multivariate LMM: issue243 (first 800 SNPs, 2 traits) and issue188 genotypes with 3 simulated
                     traits, -lmm 1..4 (-n 1 2 [3])
 """
@@ -187,6 +189,42 @@ def issue188(tmp):
     return raw, fam, bim
 
 
+def loco(tmp, raw188, fam188, bim188):
+    sys.path.insert(0, ROOT)
+    from oracle import oracle as O  # decoding the .bed into the text format only (no statistic involved)
+    n_total = len(fam188)
+    nb = (n_total + 3) // 4
+    G = O.bed_decode(np.ascontiguousarray(raw188[3:].reshape(-1, nb)), n_total)
+    p = G.shape[0]
+    chrs = 1 + (np.arange(p) * 4) // p
+    rs = [l.split()[1] for l in bim188]
+    with open(os.path.join(tmp, "g.txt"), "w") as f:
+        for t in range(p):
+            f.write("%s, A, T, %s\n" % (rs[t], ", ".join("NA" if np.isnan(v) else "%g" % v for v in G[t])))
+    with open(os.path.join(tmp, "ph.txt"), "w") as f:
+        for l in fam188:
+            v = l.split()[5]
+            f.write(("NA" if v in ("-9", "NA") else v) + "\n")
+    with open(os.path.join(tmp, "anno.txt"), "w") as f:
+        for t in range(p):
+            f.write("%s\t%d\t%d\n" % (rs[t], 1000 + t, chrs[t]))
+    d = {"chr": chrs.astype(np.int32)}
+    base = ["-g", "g.txt", "-p", "ph.txt", "-a", "anno.txt"]
+    for c in (2, 4):
+        gemma(tmp, *base, "-gk", 1, "-loco", c, "-o", "k%d" % c)
+        K = read_matrix(os.path.join(tmp, "output", "k%d.cXX.txt" % c))
+        d["c%d_cXX_rows" % c] = K[:16]
+        d["c%d_cXX_diag" % c] = np.diag(K).copy()
+        for m in (1, 4):
+            tag = "c%d_lmm%d" % (c, m)
+            gemma(tmp, *base, "-k", os.path.join(tmp, "output", "k%d.cXX.txt" % c), "-lmm", m, "-loco", c, "-o", tag)
+            a, _ = read_assoc(os.path.join(tmp, "output", tag + ".assoc.txt"))
+            stats_of(a, tag, d)
+            d[tag + "_snp"] = rs_index(bim188, a["rs"])
+    np.savez_compressed(os.path.join(OUT, "ref_loco.npz"), **d)
+    print("ref_loco.npz:", {k: v.shape for k, v in d.items() if k.endswith("_snp")})
+
+
 MV_COLS_EXTRA = ("p_wald", "p_lrt", "p_score")
 
 
@@ -243,16 +281,18 @@ def main():
         subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "ref"])
     tmp = tempfile.mkdtemp(prefix="gemma_ref_")
     try:
-        which = sys.argv[1:] or ["bxd", "issue188", "mv"]
+        which = sys.argv[1:] or ["bxd", "issue188", "mv", "loco"]
         if "bxd" in which:
             bxd(tmp)
         raw, fam, bim = None, None, None
         if "issue188" in which:
             raw, fam, bim = issue188(tmp)
+        if raw is None and ("mv" in which or "loco" in which):
+            raw, fam, bim = copy_plink(REF + "/test/data/issue188/2000", os.path.join(tmp, "p188"))
         if "mv" in which:
-            if raw is None:
-                raw, fam, bim = copy_plink(REF + "/test/data/issue188/2000", os.path.join(tmp, "p188"))
             mv(tmp, raw, fam, bim)
+        if "loco" in which:
+            loco(tmp, raw, fam, bim)
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
 

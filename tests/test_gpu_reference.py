@@ -187,3 +187,39 @@ def test_mvlmm_ml_em_three_traits(gpu_api, mvprep, mode):
     worse = got["p_lrt"] > ref["p_lrt"] * (1.0 + 5e-3)
     assert not worse[~exact].any(), np.flatnonzero(worse & ~exact)[:10]
     assert np.all(np.isfinite(got["p_lrt"])) and np.all(np.isfinite(got["beta"]))
+
+
+# ----------------------------------------------------------------------------- -loco
+def test_loco_vs_reference_output(gpu_api, i188):
+    """-gk 1 -loco c for every chromosome in one pass on the device (all-SNP SYRK minus the chromosome's own,
+    gemma_hip_kin_loco_d) against the reference's per-chromosome cXX.txt, then -lmm 1/4 -loco c on that kinship."""
+    fx = R.load("ref_loco.npz")
+    raw, n_total, y_all, indp = i188["raw"], i188["n_total"], i188["y_all"], i188["indp"]
+    codes = np.unpackbits(raw, axis=1, bitorder="little").reshape(raw.shape[0], -1, 2)[:, :n_total]
+    two = codes[:, :, 0] * 1 + codes[:, :, 1] * 2  # PLINK code per individual: 0 -> 2, 1 -> NA, 2 -> 1, 3 -> 0 (src/lmm.cpp:1797-1812)
+    G = np.choose(two, [2.0, np.nan, 1.0, 0.0])     # the mean-genotype file the fixture generator wrote
+    chrs = fx["chr"]
+    ind, W = _indicator(indp, None)
+    isnp, _, _ = gpu_api.SnpQC(G, L.GENO_F64_SNP_MAJOR, ind, W)
+    keep = isnp == 1
+    Kl = gpu_api.CalcKinLOCO(np.ascontiguousarray(G[keep]), L.GENO_F64_SNP_MAJOR, n_total, chrs[keep], 1)
+    sel = ind == 1
+    y = y_all[sel]
+    for c in (2, 4):
+        K10 = gpu_api.WriteMatrix10(Kl[c])
+        for got, ref in ((K10[:16], fx["c%d_cXX_rows" % c]), (np.diag(K10), fx["c%d_cXX_diag" % c])):
+            assert np.mean(got == ref) > 0.995
+            np.testing.assert_allclose(got, ref, rtol=5e-10, atol=1e-12)
+        Gc = gpu_api.CenterMatrix(np.ascontiguousarray(K10[np.ix_(sel, sel)]))
+        n = int(sel.sum())
+        U, ev = np.zeros((n, n)), np.zeros(n)
+        tr = gpu_api.EigenDecomp_Zeroed(Gc, U, ev)
+        UtW, Uty = gpu_api.CalcUtX(U, W), gpu_api.CalcUtX(U, y)
+        null = gpu_api.CalcLambdaNull(ev, UtW, Uty, trace_G=tr)
+        gsel = keep & (chrs == c)
+        for mode in (1, 4):
+            tag = "c%d_lmm%d" % (c, mode)
+            assert np.array_equal(np.flatnonzero(gsel), fx[tag + "_snp"])
+            lmm = gpu_api.LMM(a_mode=mode, l_mle_null=null["l_mle_null"], logl_mle_H0=null["logl_mle_H0"])
+            st = lmm.AnalyzeBimbam(U, ev, UtW, Uty, np.ascontiguousarray(G[gsel][:, sel]))
+            R.assert_stats(st, fx, tag, lam_tol=1e-3, lam_frac=0.98)

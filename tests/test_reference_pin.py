@@ -332,3 +332,22 @@ def test_reference_lmm_analyze_in_process(oracle, bxd, ref_bxd, mode):
     assert np.mean(e <= 1e-6) >= 0.99 and np.nanmax(e) <= 1e-3
     # a failed REML search (Newton cycling for 100 iterations, NaN) is itself rounding-sensitive: at most the known few
     assert int(np.isnan(mine["p_wald"]).sum()) <= 3 and int(np.isnan(got["p_wald"]).sum()) <= 3
+
+
+# ----------------------------------------------------------------------------- -loco (BIMBAM; PlinkKin ignores it in the reference)
+@pytest.mark.parametrize("c", [2, 4])
+def test_loco_kinship_and_lmm(oracle, i188, c):
+    """-gk 1 -loco c (kinship from the SNPs NOT on chromosome c, src/param.cpp:52-66,497-500, gemma_io.cpp:1479) and
+    -lmm 1/4 -loco c (tests only the SNPs on c): cXX digit for digit, every statistic to the printed digits."""
+    fx = R.load("ref_loco.npz")
+    G, chrs = i188["G_all"], fx["chr"]
+    ind, W = oracle.process_cvt_phen(i188["indp"])
+    isnp, _, _ = oracle.qc_snps(G, ind, W)
+    ksel, gsel = (isnp == 1) & (chrs != c), (isnp == 1) & (chrs == c)
+    K10 = oracle.round10(oracle.calc_kin(G[ksel], 1))
+    assert np.array_equal(K10[:16], fx["c%d_cXX_rows" % c]) and np.array_equal(np.diag(K10), fx["c%d_cXX_diag" % c])
+    for mode in (1, 4):
+        tag = "c%d_lmm%d" % (c, mode)
+        assert np.array_equal(np.flatnonzero(gsel), fx[tag + "_snp"])
+        st, _, _ = oracle.run_lmm(mode, G, ind, gsel.astype(np.int32), i188["y_all"], W, K10)
+        R.assert_stats(st, fx, tag)
