@@ -228,16 +228,16 @@ def loco(tmp, raw188, fam188, bim188):
 MV_COLS_EXTRA = ("p_wald", "p_lrt", "p_score")
 
 
-def mv_run(tmp, prefix, tag, kfile, traits, d, bim):
-    for m in (1, 2, 3, 4):
-        gemma(tmp, "-bfile", prefix, "-k", kfile, "-lmm", m, "-n", *traits, "-o", "%s_m%d" % (tag, m))
+def mv_run(tmp, prefix, tag, kfile, traits, d, bim, modes=(1, 2, 3, 4), extra=()):
+    for m in modes:
+        gemma(tmp, "-bfile", prefix, "-k", kfile, "-lmm", m, "-n", *traits, *extra, "-o", "%s_m%d" % (tag, m))
         a, _ = read_assoc(os.path.join(tmp, "output", "%s_m%d.assoc.txt" % (tag, m)))
         for c, v in a.items():
             if c.startswith("beta_") or c.startswith("Vbeta_") or c in MV_COLS_EXTRA:
                 d["%s_m%d_%s" % (tag, m, c)] = v
         d["%s_snp" % tag] = rs_index(bim, a["rs"])
-        if m == 4:
-            sc, mats = read_log(os.path.join(tmp, "output", "%s_m4.log.txt" % tag))
+        if m == modes[-1]:
+            sc, mats = read_log(os.path.join(tmp, "output", "%s_m%d.log.txt" % (tag, m)))
             d[tag + "_logl_null"] = np.array([sc["REMLE log-likelihood in the null model"], sc["MLE log-likelihood in the null model"]])
             for k, v in mats.items():
                 key = k.replace(" ", "_").replace("(", "").replace(")", "").replace(",", "")
@@ -272,8 +272,27 @@ def mv(tmp, raw188, fam188, bim188):
     d["b_pheno_txt"] = np.array(txt)
     gemma(tmp, "-bfile", "mv3", "-gk", 1, "-o", "mv3")
     mv_run(tmp, "mv3", "b", os.path.join(tmp, "output", "mv3.cXX.txt"), (1, 2, 3), d, bim188)
+    # (c) five traits (the pairwise two-trait initialisation of MphInitial, src/mvlmm.cpp:2805-2884) and a covariate besides the
+    #     intercept, on every 8th SNP (-snps); REML and score modes (the ML EM of d >= 3 is not reproducible, see the tests)
+    A5 = np.triu(rng.uniform(0.2, 0.9, (5, 5)))
+    E5 = np.triu(rng.uniform(0.1, 0.5, (5, 5))) + 0.8 * np.eye(5)
+    Y5 = (g.T @ rng.standard_normal((400, 5)) / np.sqrt(400)) @ A5 + rng.standard_normal((n_total, 5)) @ E5
+    cov = np.column_stack([np.ones(n_total), rng.standard_normal(n_total)])
+    Y5 += 0.4 * cov[:, 1:2] * rng.standard_normal((1, 5))
+    txt5 = [["%.8g" % v for v in row] for row in Y5]
+    fam_lines = [" ".join(l.split()[:5] + t) + "\n" for l, t in zip(fam188, txt5)]
+    copy_plink(REF + "/test/data/issue188/2000", os.path.join(tmp, "mv5"), fam_lines=fam_lines)
+    np.savetxt(os.path.join(tmp, "cov5.txt"), cov, fmt="%.10g")
+    with open(os.path.join(tmp, "snps5.txt"), "w") as f:
+        f.writelines(l.split()[1] + "\n" for l in bim188[::8])
+    d["c_pheno"] = np.array([[float(x) for x in row] for row in txt5])
+    d["c_cov"] = np.loadtxt(os.path.join(tmp, "cov5.txt"))
+    d["c_snps_listed"] = np.arange(0, len(bim188), 8)
+    gemma(tmp, "-bfile", "mv5", "-gk", 1, "-o", "mv5")
+    mv_run(tmp, "mv5", "c", os.path.join(tmp, "output", "mv5.cXX.txt"), (1, 2, 3, 4, 5), d, bim188, modes=(1, 3),
+           extra=("-c", "cov5.txt", "-snps", "snps5.txt"))
     np.savez_compressed(os.path.join(OUT, "ref_mv.npz"), **d)
-    print("ref_mv.npz:", len(d["a_snp"]), "+", len(d["b_snp"]), "SNPs")
+    print("ref_mv.npz:", len(d["a_snp"]), "+", len(d["b_snp"]), "+", len(d["c_snp"]), "SNPs")
 
 
 def main():

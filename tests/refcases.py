@@ -65,6 +65,12 @@ def mv_case_inputs(fx, f188, tag):
         bed = fx["a_bed"]
         ind = np.ones(n_total, dtype=np.int32)
         ind1 = ind
+    elif tag == "c":
+        Y = fx["c_pheno"]
+        n_total = Y.shape[0]
+        bed = f188["bed"]
+        ind = np.ones(n_total, dtype=np.int32)
+        ind1 = ind
     else:
         txt = fx["b_pheno_txt"]
         n_total = txt.shape[0]

@@ -334,6 +334,79 @@ def test_reference_lmm_analyze_in_process(oracle, bxd, ref_bxd, mode):
     assert int(np.isnan(mine["p_wald"]).sum()) <= 3 and int(np.isnan(got["p_wald"]).sum()) <= 3
 
 
+# ----------------------------------------------------------------------------- five traits + a covariate
+@pytest.fixture(scope="module")
+def mv5(oracle):
+    fx, f188 = R.load("ref_mv.npz"), R.load("ref_issue188.npz")
+    raw, n_total, Yall, ind_all, _ = R.mv_case_inputs(fx, f188, "c")
+    G = oracle.bed_decode(raw, n_total)
+    ones = np.ones(n_total, dtype=np.int32)
+    _, W = oracle.process_cvt_phen(ones, fx["c_cov"], ones)
+    _, W1 = oracle.process_cvt_phen(ones)
+    K10 = oracle.round10(oracle.calc_kin(G[oracle.qc_snps_bed(G, W1) == 1], 1))
+    listed = np.zeros(G.shape[0], dtype=bool)
+    listed[fx["c_snps_listed"]] = True
+    sel = (oracle.qc_snps_bed(G, W) == 1) & listed  # -snps: only the listed SNPs are analysed
+    U, ev, _ = oracle.eigen_decomp_zeroed(oracle.center_matrix(K10))
+    UtW, UtY = np.ascontiguousarray((U.T @ W).T), np.ascontiguousarray((U.T @ Yall).T)
+    cfg = oracle.mv_cfg()
+    return dict(fx=fx, sel=sel, ev=ev, UtW=UtW, UtY=UtY, UtX=np.ascontiguousarray(oracle.impute_mean(G[sel]) @ U), cfg=cfg,
+                null=oracle.mvlmm_null(cfg, ev, UtW, UtY), d=5)
+
+
+def test_mvlmm_five_traits_null_and_per_snp(oracle, mv5):
+    """d = 5 takes MphInitial's pairwise two-trait initialisation (src/mvlmm.cpp:2805-2884); two covariates.  The REML null
+    fit (which runs first, from that initialisation) agrees with the reference's log at its 6 digits.  The ML null fit goes
+    through the basis-unstable ML EM, so the reference's V_g,null carries ~2e-3 of implementation-defined noise although its
+    likelihood agrees to the printed digits -- and every per-SNP fit starts from V_g,null (:3291-3293), so the per-SNP
+    output can only be followed to that level: median well under 1e-2, all within 6e-2.  The per-SNP arithmetic itself at
+    d = 5 is pinned function by function below."""
+    fx, null = mv5["fx"], mv5["null"]
+    assert np.array_equal(np.flatnonzero(mv5["sel"]), fx["c_snp"])
+    assert null["logl_remle"] == pytest.approx(fx["c_logl_null"][0], rel=2e-6)
+    assert null["logl_mle"] == pytest.approx(fx["c_logl_null"][1], rel=2e-6)
+    lo = np.tril_indices(5)
+    np.testing.assert_allclose(null["Vg_remle"][lo], fx["c_log_REMLE_estimate_for_Vg_in_the_null_model"], rtol=2e-5)
+    np.testing.assert_allclose(null["Ve_remle"][lo], fx["c_log_REMLE_estimate_for_Ve_in_the_null_model"], rtol=2e-5)
+    np.testing.assert_allclose(null["Vg_mle"].ravel(), fx["c_log_MLE_estimate_for_Vg_in_the_null_model"], atol=5e-3)
+    np.testing.assert_allclose(null["B_mle"].ravel(), fx["c_log_estimate_for_B_d_by_c_in_the_null_model_columns_correspond_t"],
+                               rtol=2e-3, atol=2e-4)
+    for mode in (1, 3):
+        got = oracle.mvlmm_batch(mode, mv5["cfg"], mv5["ev"], mv5["UtW"], mv5["UtY"], mv5["UtX"], null)
+        err = R.mv_row_err(got, R.mv_ref_table(fx, "c", mode, 5))
+        assert np.median(err) < 1e-2 and err.max() < 6e-2, (mode, float(np.median(err)), float(err.max()))
+
+
+def test_reference_functions_five_traits(oracle, mv5):
+    """MphEM('R') to convergence, MphNR('R') and MphCalcP of the reference at d = 5 with two covariates + the SNP, from
+    identical starting values: 1e-8."""
+    so = _refso()
+    c = mv5
+    n, d = c["ev"].size, 5
+    for s in (0, 17, 101, 249):
+        Xs = np.ascontiguousarray(np.vstack([c["UtW"], c["UtX"][s:s + 1]]))
+        B0 = np.ascontiguousarray(np.hstack([c["null"]["B_mle"], np.zeros((d, 1))]))
+        a = [c["null"]["Vg_mle"].copy(), c["null"]["Ve_mle"].copy(), B0.copy()]
+        b = [x.copy() for x in a]
+        lo = oracle.mph_em("R", 1000, 1e-3, c["ev"], Xs, c["UtY"], a[0], a[1], a[2])
+        lr = so.ref_MphEM(b"R", 1000, 1e-3, n, d, Xs.shape[0], _dp(c["ev"]), _dp(Xs), _dp(c["UtY"]), _dp(b[0]), _dp(b[1]), _dp(b[2]))
+        assert lo == pytest.approx(lr, rel=1e-11)
+        for x, y in zip(a, b):
+            assert np.abs(x - y).max() <= 1e-8 * max(1.0, np.abs(y).max())
+        l2, Hi = oracle.mph_nr("R", 10, 1e-3, c["ev"], Xs, c["UtY"], a[0], a[1])
+        Hr = np.zeros((d * (d + 1), d * (d + 1)))
+        r2 = so.ref_MphNR(b"R", 10, 1e-3, n, d, Xs.shape[0], _dp(c["ev"]), _dp(Xs), _dp(c["UtY"]), _dp(b[0]), _dp(b[1]), _dp(Hr))
+        assert l2 == pytest.approx(r2, rel=1e-10)
+        assert np.abs(a[0] - b[0]).max() < 1e-7 and np.abs(a[1] - b[1]).max() < 1e-7
+        x = np.ascontiguousarray(c["UtX"][s])
+        beta_r, Vb_r = np.zeros(d), np.zeros((d, d))
+        p_o, beta_o, Vb_o = oracle.mph_calcp(c["ev"], x, c["UtW"], c["UtY"], a[0], a[1])
+        p_r = so.ref_MphCalcP(n, d, c["UtW"].shape[0], _dp(c["ev"]), _dp(x), _dp(c["UtW"]), _dp(c["UtY"]), _dp(b[0]), _dp(b[1]),
+                              _dp(beta_r), _dp(Vb_r))
+        assert p_o == pytest.approx(p_r, rel=1e-7)
+        assert np.abs(beta_o - beta_r).max() < 1e-8 and np.abs(Vb_o - Vb_r).max() < 1e-8
+
+
 # ----------------------------------------------------------------------------- -loco (BIMBAM; PlinkKin ignores it in the reference)
 @pytest.mark.parametrize("c", [2, 4])
 def test_loco_kinship_and_lmm(oracle, i188, c):
