@@ -223,3 +223,28 @@ def test_loco_vs_reference_output(gpu_api, i188):
             lmm = gpu_api.LMM(a_mode=mode, l_mle_null=null["l_mle_null"], logl_mle_H0=null["logl_mle_H0"])
             st = lmm.AnalyzeBimbam(U, ev, UtW, Uty, np.ascontiguousarray(G[gsel][:, sel]))
             R.assert_stats(st, fx, tag, lam_tol=1e-3, lam_frac=0.98)
+
+
+def test_mvlmm_five_traits_vs_reference_output(gpu_api):
+    """d = 5 (pairwise initialisation of the null fit), intercept + one covariate, every 8th SNP (-snps).  REML null fit to
+    the log's 6 digits; the per-SNP output only as far as the reference's own ML null fit is defined (its basis-unstable ML EM
+    leaves ~2e-3 of noise in V_g,null, the start of every per-SNP fit -- tests/test_reference_pin.py)."""
+    fx, f188 = R.load("ref_mv.npz"), R.load("ref_issue188.npz")
+    raw, n_total, Yall, ind, _ = R.mv_case_inputs(fx, f188, "c")
+    W = np.ascontiguousarray(fx["c_cov"])
+    _, U, ev, _, isnp = _device_chain(gpu_api, raw, n_total, None, ind, ind, W, 1)
+    listed = np.zeros(raw.shape[0], dtype=bool)
+    listed[fx["c_snps_listed"]] = True
+    sel = (isnp == 1) & listed
+    assert np.array_equal(np.flatnonzero(sel), fx["c_snp"])
+    UtW, UtY = gpu_api.CalcUtX(U, W), gpu_api.CalcUtX(U, np.ascontiguousarray(Yall))
+    for mode in (1, 3):
+        mv = gpu_api.MVLMM(a_mode=mode)
+        got = mv.AnalyzePlink(U, ev, UtW, UtY, np.ascontiguousarray(raw[sel]), ind)
+        lo = np.tril_indices(5)
+        assert mv.null["logl_remle"] == pytest.approx(fx["c_logl_null"][0], rel=2e-6)
+        assert mv.null["logl_mle"] == pytest.approx(fx["c_logl_null"][1], rel=2e-6)
+        np.testing.assert_allclose(mv.null["Vg_remle"][lo], fx["c_log_REMLE_estimate_for_Vg_in_the_null_model"], rtol=5e-5)
+        np.testing.assert_allclose(mv.null["Ve_remle"][lo], fx["c_log_REMLE_estimate_for_Ve_in_the_null_model"], rtol=5e-5)
+        err = R.mv_row_err(got, R.mv_ref_table(fx, "c", mode, 5))
+        assert np.median(err) < 1e-2 and err.max() < 6e-2, (mode, float(np.median(err)), float(err.max()))
