@@ -15,6 +15,7 @@ Fixtures:
                     covariates, -lmm 1 on sXX, -lm 4, -gxe
   ref_loco.npz      -loco (BIMBAM only in the reference: PlinkKin ignores it, src/param.cpp:1307): issue188 re-written as a
                     mean-genotype file with four synthetic chromosomes; -gk 1 -loco c and -lmm 1/4 -loco c for c = 2, 4
+  ref_gene.npz      -gene (LMM::AnalyzeGene): 40 simulated expression rows over issue188's individuals, -lmm 1 and 4
   ref_mv.npz        multivariate LMM: issue243 (first 800 SNPs, 2 traits) and issue188 genotypes with 3 simulated
                     traits, -lmm 1..4 (-n 1 2 [3])
 """
@@ -225,6 +226,41 @@ def loco(tmp, raw188, fam188, bim188):
     print("ref_loco.npz:", {k: v.shape for k, v in d.items() if k.endswith("_snp")})
 
 
+def gene(tmp, raw188, fam188, bim188):
+    """LMM::AnalyzeGene (src/lmm.cpp:1365-1471): every row of the expression file is a phenotype, the -p phenotype is the
+    tested variable."""
+    n_total = len(fam188)
+    nb = (n_total + 3) // 4
+    codes = np.unpackbits(raw188[3:].reshape(-1, nb)[:300], axis=1, bitorder="little").reshape(300, -1, 2)[:, :n_total]
+    g = (codes[:, :, 0] + codes[:, :, 1]).astype(float)
+    g = (g - g.mean(1, keepdims=True)) / (g.std(1, keepdims=True) + 1e-9)
+    rng = np.random.default_rng(1365)
+    h2 = rng.uniform(0.0, 0.8, 40)
+    E = np.sqrt(h2)[:, None] * (rng.standard_normal((40, 300)) @ g / np.sqrt(300)) + np.sqrt(1 - h2)[:, None] * rng.standard_normal((40, n_total))
+    ph = np.array([(np.nan if l.split()[5] in ("-9", "NA") else float(l.split()[5])) for l in fam188])
+    E[:8] += 0.02 * np.nan_to_num(ph)[None, :] * rng.standard_normal((8, 1))  # a few rows that depend on the tested variable
+    with open(os.path.join(tmp, "gene.txt"), "w") as f:
+        f.write("id\t" + "\t".join("i%d" % i for i in range(n_total)) + "\n")
+        for r in range(40):
+            f.write("g%d\t" % r + "\t".join("%.10g" % v for v in E[r]) + "\n")
+    with open(os.path.join(tmp, "gph.txt"), "w") as f:
+        f.writelines(("NA" if np.isnan(v) else "%.10g" % v) + "\n" for v in ph)
+    E = np.array([[float("%.10g" % v) for v in row] for row in E])
+    d = {"expr": E}
+    copy_plink(REF + "/test/data/issue188/2000", os.path.join(tmp, "pg"))
+    gemma(tmp, "-bfile", "pg", "-gk", 1, "-o", "kg")
+    for m in (1, 4):
+        gemma(tmp, "-gene", "gene.txt", "-p", "gph.txt", "-k", os.path.join(tmp, "output", "kg.cXX.txt"), "-lmm", m, "-o", "ge%d" % m)
+        with open(os.path.join(tmp, "output", "ge%d.assoc.txt" % m)) as f:
+            hdr = f.readline().split()
+            rows = [l.split() for l in f if l.strip()]
+        assert len(rows) == 40
+        for j, h in enumerate(hdr[1:], 1):
+            d["lmm%d_%s" % (m, h)] = np.array([float(r[j]) for r in rows])
+    np.savez_compressed(os.path.join(OUT, "ref_gene.npz"), **d)
+    print("ref_gene.npz: 40 rows; interior lambda on", int((d["lmm1_l_remle"] > 2e-5).sum()))
+
+
 MV_COLS_EXTRA = ("p_wald", "p_lrt", "p_score")
 
 
@@ -300,18 +336,20 @@ def main():
         subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "ref"])
     tmp = tempfile.mkdtemp(prefix="gemma_ref_")
     try:
-        which = sys.argv[1:] or ["bxd", "issue188", "mv", "loco"]
+        which = sys.argv[1:] or ["bxd", "issue188", "mv", "loco", "gene"]
         if "bxd" in which:
             bxd(tmp)
         raw, fam, bim = None, None, None
         if "issue188" in which:
             raw, fam, bim = issue188(tmp)
-        if raw is None and ("mv" in which or "loco" in which):
+        if raw is None and ("mv" in which or "loco" in which or "gene" in which):
             raw, fam, bim = copy_plink(REF + "/test/data/issue188/2000", os.path.join(tmp, "p188"))
         if "mv" in which:
             mv(tmp, raw, fam, bim)
         if "loco" in which:
             loco(tmp, raw, fam, bim)
+        if "gene" in which:
+            gene(tmp, raw, fam, bim)
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
 

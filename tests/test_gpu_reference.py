@@ -248,3 +248,13 @@ def test_mvlmm_five_traits_vs_reference_output(gpu_api):
         np.testing.assert_allclose(mv.null["Ve_remle"][lo], fx["c_log_REMLE_estimate_for_Ve_in_the_null_model"], rtol=5e-5)
         err = R.mv_row_err(got, R.mv_ref_table(fx, "c", mode, 5))
         assert np.median(err) < 1e-2 and err.max() < 6e-2, (mode, float(np.median(err)), float(err.max()))
+
+
+@pytest.mark.parametrize("mode", [1, 4])
+def test_issue188_analyze_gene(gpu_api, i188, mode):
+    """-gene: 40 expression rows as phenotypes, the -p phenotype as the tested variable, per-row null fit on the device."""
+    fx = R.load("ref_gene.npz")
+    p = _prep188(gpu_api, i188, None, 1)
+    sel = p["ind"] == 1
+    st = gpu_api.LMM(a_mode=mode).AnalyzeGene(p["U"], p["ev"], p["UtW"], p["Uty"], np.ascontiguousarray(fx["expr"][:, sel]))
+    R.assert_stats(st, fx, "lmm%d" % mode, lam_tol=1e-3, lam_frac=0.95)

@@ -424,3 +424,15 @@ def test_loco_kinship_and_lmm(oracle, i188, c):
         assert np.array_equal(np.flatnonzero(gsel), fx[tag + "_snp"])
         st, _, _ = oracle.run_lmm(mode, G, ind, gsel.astype(np.int32), i188["y_all"], W, K10)
         R.assert_stats(st, fx, tag)
+
+
+# ----------------------------------------------------------------------------- -gene (LMM::AnalyzeGene)
+@pytest.mark.parametrize("mode", [1, 4])
+def test_issue188_analyze_gene(oracle, i188, mode):
+    """40 expression rows as phenotypes, the -p phenotype as the tested variable (src/lmm.cpp:1365-1471), per-row null fit."""
+    fx = R.load("ref_gene.npz")
+    ind, W, isnp, K10 = _prep188(oracle, i188, None, 1)
+    sel = ind == 1
+    U, ev, _ = oracle.eigen_decomp_zeroed(oracle.center_matrix(K10[np.ix_(sel, sel)]))
+    got = oracle.gene_analyze(mode, U, ev, U.T @ W, U.T @ i188["y_all"][sel], np.ascontiguousarray(fx["expr"][:, sel]))
+    R.assert_stats(got, fx, "lmm%d" % mode)
