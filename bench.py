@@ -140,6 +140,17 @@ def main():
         kin_ms, kin_n = api.profile_read(L.STAGE_KIN_GEMM, reset=True)
         setup_info["kinship_s"] = round(time.time() - t0, 3)
         setup_info["kinship_gemm_tflops"] = round(2.0 * n * n * args.kin_snps / (kin_ms * 1e-3) / 1e12, 2) if kin_ms else None
+        if kin_ms:
+            # K = Xc Xc^T as a SYRK: only the 128 x 128 tiles with tile_n >= tile_m are launched (dgemm_mfma.hip.h), so the
+            # flops EXECUTED are tiles * 2 * 128^2 * p; SURVEY 8(d)'s GEMM-form figure 2 n^2 p (what the reference's
+            # cblas_dgemm does) is the line above and is what "142" means -- it is not a rate of the matrix pipe
+            tn = (n + 127) // 128
+            executed = tn * (tn + 1) / 2 * 2.0 * 128 * 128 * args.kin_snps
+            setup_info["roofline_kinship"] = {
+                "kernel": "dgemm_mfma_glds_kernel, SYRK grid (K = Xc Xc^T)", "bound": "mfma", "unit": "TFLOP/s",
+                "achieved": round(executed / (kin_ms * 1e-3) / 1e12, 2), "peak": 78.6,
+                "frac": round(executed / (kin_ms * 1e-3) / 1e12 / 78.6, 4), "launch_ms_total": round(kin_ms, 3),
+                "launches": kin_n, "flops": "executed (upper-triangle tiles); GEMM-form 2 n^2 p in kinship_gemm_tflops"}
         y += torch.randn(n, dtype=torch.float64, device=dev, generator=gen) * y.std().clamp_min(1e-3)
         api.CenterMatrix(K)
         t0 = time.time()
