@@ -12,10 +12,12 @@
 #ifndef GEMMA_HOST_HPP
 #define GEMMA_HOST_HPP
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <fstream>
+#include <functional>
 #include <iomanip>
 #include <iostream>
 #include <limits>
@@ -306,6 +308,23 @@ public:
     for (size_t s0 = 0; s0 < n_snps; s0 += LMM_BATCH_SIZE) {
       const size_t l = std::min(LMM_BATCH_SIZE, n_snps - s0);
       batch_compute(GEMMA_GENO_F64_SNP_MAJOR, X + s0 * ld, l, ld, out);
+    }
+    finish();
+  }
+
+  // LMM::Analyze with a pull-style block source (what fetch_snp, src/lmm.cpp:1675-1700, is to the reference): feed()
+  // refills X (ld doubles per row, rows = analysed SNPs over the ni_test analysed individuals, NaN = missing) with at
+  // most max_rows rows and returns how many it wrote, 0 at the end.  include/gemma_io_host.hpp feeds it from a
+  // BIMBAM text file parsed on a pool of host threads.
+  typedef std::function<size_t(double *X, size_t max_rows)> RowFeeder;
+  void AnalyzeFeed(const Matrix *U, const Vector *eval, const Matrix *UtW, const Vector *Uty, RowFeeder &feed, double *X,
+                   size_t max_rows, size_t ld) {
+    setup(U, eval, UtW, Uty, 0);
+    std::vector<gemma_sumstat> out(std::min(max_rows, LMM_BATCH_SIZE));
+    for (;;) {
+      const size_t l = feed(X, out.size());
+      if (l == 0) break;
+      batch_compute(GEMMA_GENO_F64_SNP_MAJOR, X, l, ld, out);
     }
     finish();
   }

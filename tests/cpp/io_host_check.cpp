@@ -1,0 +1,248 @@
+// CPU harness for include/gemma_io_host.hpp (tests/test_io_host.py builds and drives it): every sub-command runs one
+// reader / writer of the host layer and prints what it produced in a form the Python side can compare exactly
+// (doubles as %.17g or raw bytes).  No device call is made here.
+//
+//   parse                          tokens on stdin, one per line -> the 8 bytes of parse_double() as hex
+//   pheno|fam <file> <col>...      indicator and value per row and column
+//   cvt <file>                     n_cvt, then indicator and values per row
+//   bim <file> | anno <file>
+//   cvtphen <pheno|fam:file> <cvt|-> <col>...   ProcessCvtPhen + CopyCvtPhen: indicator_idv, n_cvt, W, Y
+//   geno <file> <ni_total> <threads> <block> <out.bin> [keep-file] [cols-file]
+//                                  BimbamReader blocks appended to out.bin (raw doubles), "rs minor major" per row
+//   eigen <U-in> <D-in> <n> <outdir> <name>     ReadFile_eigenU/D -> WriteEigen
+//   assoc <assoc-in> <a_mode> <outdir> <name>   parse a reference .assoc.txt, LMM::WriteFiles it again
+//   kin <cXX-in> <n> <out>                      ReadFile_kin (all individuals) -> WriteMatrix
+//   genobench <file> <ni_total> <threads>       wall time of BimbamReader over the whole file (threads = 0: the
+//                                               reference's own way, one thread of strtok + atof, for comparison)
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <fstream>
+#include <iostream>
+#include <string>
+#include <vector>
+
+#include "gemma_io_host.hpp"
+
+using namespace gemma_amd;
+
+static std::vector<int> read_ints(const char *path) {
+  std::vector<int> v;
+  std::ifstream f(path);
+  int x;
+  while (f >> x) v.push_back(x);
+  return v;
+}
+
+int main(int argc, char **argv) {
+  if (argc < 2) return 2;
+  const std::string cmd = argv[1];
+  if (cmd == "parse") {
+    std::string tok;
+    while (std::getline(std::cin, tok)) {
+      const double d = parse_double(tok.data(), tok.data() + tok.size());
+      unsigned long long u;
+      memcpy(&u, &d, 8);
+      printf("%016llx\n", u);
+    }
+    return 0;
+  }
+  if (cmd == "pheno" || cmd == "fam") {
+    std::vector<std::vector<int>> ind;
+    std::vector<std::vector<double>> ph;
+    std::vector<size_t> cols;
+    for (int i = 3; i < argc; ++i) cols.push_back(strtoul(argv[i], nullptr, 10));
+    std::map<std::string, int> ids;
+    const bool ok = cmd == "pheno" ? ReadFile_pheno(argv[2], ind, ph, cols) : ReadFile_fam(argv[2], ind, ph, ids, cols);
+    if (!ok) return 1;
+    for (size_t i = 0; i < ph.size(); ++i) {
+      for (size_t j = 0; j < ph[i].size(); ++j) printf("%d %.17g ", ind[i][j], ph[i][j]);
+      printf("\n");
+    }
+    if (cmd == "fam") printf("ids %zu\n", ids.size());
+    return 0;
+  }
+  if (cmd == "cvt") {
+    std::vector<int> ind;
+    std::vector<std::vector<double>> cvt;
+    size_t n_cvt = 0;
+    if (!ReadFile_cvt(argv[2], ind, cvt, n_cvt)) return 1;
+    printf("%zu\n", n_cvt);
+    for (size_t i = 0; i < cvt.size(); ++i) {
+      printf("%d", ind[i]);
+      for (double v : cvt[i]) printf(" %.17g", v);
+      printf("\n");
+    }
+    return 0;
+  }
+  if (cmd == "bim") {
+    std::vector<SNPINFO> info;
+    if (!ReadFile_bim(argv[2], info)) return 1;
+    for (const SNPINFO &s : info)
+      printf("%s %s %.17g %ld %s %s\n", s.chr.c_str(), s.rs_number.c_str(), s.cM, s.base_position, s.a_minor.c_str(),
+             s.a_major.c_str());
+    return 0;
+  }
+  if (cmd == "anno") {
+    std::map<std::string, std::string> chr;
+    std::map<std::string, long int> bp;
+    std::map<std::string, double> cm;
+    if (!ReadFile_anno(argv[2], chr, bp, cm)) return 1;
+    for (const auto &kv : bp) printf("%s %ld %s %.17g\n", kv.first.c_str(), kv.second, chr[kv.first].c_str(), cm[kv.first]);
+    return 0;
+  }
+  if (cmd == "cvtphen") {
+    CvtPhen cp;
+    std::vector<size_t> cols;
+    for (int i = 4; i < argc; ++i) cols.push_back(strtoul(argv[i], nullptr, 10));
+    const std::string src = argv[2];
+    std::map<std::string, int> ids;
+    const bool ok = src.compare(0, 4, "fam:") == 0 ? ReadFile_fam(src.substr(4), cp.indicator_pheno, cp.pheno, ids, cols)
+                                                   : ReadFile_pheno(src, cp.indicator_pheno, cp.pheno, cols);
+    if (!ok) return 1;
+    if (std::string(argv[3]) != "-" && !ReadFile_cvt(argv[3], cp.indicator_cvt, cp.cvt, cp.n_cvt)) return 1;
+    cp.ProcessCvtPhen();
+    if (cp.error) return 1;
+    std::vector<double> W, Y;
+    cp.CopyCvtPhen(W, Y);
+    printf("%zu %zu\n", cp.ni_test, cp.n_cvt);
+    for (int v : cp.indicator_idv) printf("%d ", v);
+    printf("\n");
+    for (double v : W) printf("%.17g ", v);
+    printf("\n");
+    for (double v : Y) printf("%.17g ", v);
+    printf("\n");
+    return 0;
+  }
+  if (cmd == "geno") {
+    const size_t ni_total = strtoul(argv[3], nullptr, 10), block = strtoul(argv[5], nullptr, 10);
+    BimbamReader rd(argv[2], ni_total, (unsigned)atoi(argv[4]));
+    if (!rd.ok()) return 1;
+    std::vector<int> keep, cols;
+    if (argc > 7 && std::string(argv[7]) != "-") keep = read_ints(argv[7]);
+    if (argc > 8) cols = read_ints(argv[8]);
+    size_t ld = ni_total;
+    if (!cols.empty()) {
+      ld = 0;
+      for (int c : cols) ld += c != 0;
+    }
+    std::vector<double> X(block * ld);
+    std::vector<BimbamReader::Row> rows;
+    FILE *out = fopen(argv[6], "wb");
+    for (;;) {
+      const size_t l = rd.read_block(block, X.data(), ld, &rows, keep.empty() ? nullptr : &keep,
+                                     cols.empty() ? nullptr : cols.data());
+      if (l == (size_t)-1) return 1;
+      if (l == 0) break;
+      fwrite(X.data(), 8, l * ld, out);
+      for (size_t i = 0; i < l; ++i) printf("%s %s %s\n", rows[i].rs.c_str(), rows[i].minor.c_str(), rows[i].major.c_str());
+    }
+    fclose(out);
+    return 0;
+  }
+  if (cmd == "genobench") {
+    const size_t ni_total = strtoul(argv[3], nullptr, 10);
+    const unsigned threads = (unsigned)atoi(argv[4]);
+    const size_t block = 2048;
+    std::vector<double> X(block * ni_total);
+    const auto t0 = std::chrono::steady_clock::now();
+    size_t rows = 0;
+    double sum = 0;
+    if (threads == 0) { // src/lmm.cpp:1675-1700 / src/gemma_io.cpp:1487-1509: getline, strtok, strcmp "NA", atof
+      TextFile in(argv[2]);
+      std::string line;
+      while (in.getline(line)) {
+        char *save = nullptr;
+        char *tok = strtok_r(&line[0], " ,\t", &save);
+        tok = strtok_r(nullptr, " ,\t", &save);
+        tok = strtok_r(nullptr, " ,\t", &save);
+        double *x = X.data() + (rows % block) * ni_total;
+        for (size_t i = 0; i < ni_total; ++i) {
+          tok = strtok_r(nullptr, " ,\t", &save);
+          if (!tok) return 1;
+          x[i] = strcmp(tok, "NA") == 0 ? std::numeric_limits<double>::quiet_NaN() : atof(tok);
+        }
+        sum += x[ni_total / 2] == x[ni_total / 2] ? x[ni_total / 2] : 0;
+        ++rows;
+      }
+    } else {
+      BimbamReader rd(argv[2], ni_total, threads);
+      if (!rd.ok()) return 1;
+      for (;;) {
+        const size_t l = rd.read_block(block, X.data(), ni_total);
+        if (l == (size_t)-1) return 1;
+        if (l == 0) break;
+        for (size_t r = 0; r < l; ++r) {
+          const double v = X[r * ni_total + ni_total / 2];
+          sum += v == v ? v : 0;
+        }
+        rows += l;
+      }
+    }
+    const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    printf("rows %zu values %zu seconds %.3f values_per_s %.3e checksum %.6f\n", rows, rows * ni_total, sec,
+           (double)(rows * ni_total) / sec, sum);
+    return 0;
+  }
+  if (cmd == "eigen") {
+    const size_t n = strtoul(argv[4], nullptr, 10);
+    std::vector<double> Ub(n * n), Db(n);
+    Matrix U = matrix_view(Ub.data(), n, n);
+    Vector D = vector_view(Db.data(), n);
+    bool error = false;
+    ReadFile_eigenU(argv[2], error, &U);
+    ReadFile_eigenD(argv[3], error, &D);
+    if (error) return 1;
+    return WriteEigen(&U, &D, argv[5], argv[6]) ? 0 : 1;
+  }
+  if (cmd == "kin") {
+    const size_t n = strtoul(argv[3], nullptr, 10);
+    std::vector<double> Gb(n * n);
+    Matrix G = matrix_view(Gb.data(), n, n);
+    std::vector<int> ind(n, 1);
+    bool error = false;
+    ReadFile_kin(argv[2], ind, error, &G);
+    if (error) return 1;
+    return WriteMatrix(&G, argv[4]) ? 0 : 1;
+  }
+  if (cmd == "assoc") {
+    LMM lmm;
+    lmm.a_mode = atoi(argv[3]);
+    lmm.path_out = argv[4];
+    lmm.file_out = argv[5];
+    std::ifstream f(argv[2]);
+    std::string line;
+    std::getline(f, line); // header
+    while (std::getline(f, line)) {
+      std::vector<std::string> t;
+      size_t p = 0;
+      while (p <= line.size()) {
+        const size_t q = line.find('\t', p);
+        t.push_back(line.substr(p, q == std::string::npos ? std::string::npos : q - p));
+        if (q == std::string::npos) break;
+        p = q + 1;
+      }
+      SNPINFO s;
+      s.chr = t[0]; s.rs_number = t[1]; s.base_position = atol(t[2].c_str()); s.n_miss = strtoul(t[3].c_str(), nullptr, 10);
+      s.a_minor = t[4]; s.a_major = t[5]; s.maf = atof(t[6].c_str());
+      s.cM = 0; s.missingness = 0; s.n_idv = 0; s.n_nb = 0; s.file_position = 0;
+      lmm.snpInfo.push_back(s);
+      lmm.indicator_snp.push_back(1);
+      std::vector<double> v;
+      for (size_t k = 7; k < t.size(); ++k) v.push_back(atof(t[k].c_str()));
+      SUMSTAT st = {0, 0, 0, 0, 0, 0, 0, 0};
+      switch (lmm.a_mode) {
+      case 1: st.beta = v[0]; st.se = v[1]; st.logl_H1 = v[2]; st.lambda_remle = v[3]; st.p_wald = v[4]; break;
+      case 2: st.logl_H1 = v[0]; st.lambda_mle = v[1]; st.p_lrt = v[2]; break;
+      case 3: st.beta = v[0]; st.se = v[1]; st.p_score = v[2]; break;
+      case 4: st.beta = v[0]; st.se = v[1]; st.logl_H1 = v[2]; st.lambda_remle = v[3]; st.lambda_mle = v[4];
+              st.p_wald = v[5]; st.p_lrt = v[6]; st.p_score = v[7]; break;
+      case 9: st.beta = v[0]; st.se = v[1]; st.lambda_mle = v[2]; st.p_lrt = v[3]; break;
+      }
+      lmm.sumStat.push_back(st);
+    }
+    lmm.WriteFiles();
+    return 0;
+  }
+  return 2;
+}

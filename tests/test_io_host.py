@@ -1,0 +1,256 @@
+"""Host layer either side of the hot path (include/gemma_io_host.hpp), on the CPU:
+the readers that select individuals and SNPs, the multi-threaded BIMBAM text parser and the writers of the
+artefacts GEMMA leaves between runs -- against the reference binary's own files (tests/golden/text/, written by
+tests/golden/make_text_fixtures.py from oracle/_ref/gemma) byte for byte, and against libc's atof for every token.
+The harness (tests/cpp/io_host_check.cpp) makes no device call."""
+import ctypes
+import gzip
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TXT = os.path.join(ROOT, "tests", "golden", "text")
+
+
+@pytest.fixture(scope="module")
+def exe(tmp_path_factory):
+    from gemma_amd import build
+    build.build()  # the header's inline wrappers reference the C ABI; the library loads without a GPU
+    out = str(tmp_path_factory.mktemp("iohost") / "io_host_check")
+    subprocess.check_call(["g++", "-std=c++11", "-O2", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "cpp", "io_host_check.cpp"),
+                           "-L" + os.path.join(ROOT, "gemma_amd"), "-lgemma_hip",
+                           "-Wl,-rpath," + os.path.join(ROOT, "gemma_amd"), "-lz", "-pthread", "-o", out])
+    return out
+
+
+def run(exe, *args, stdin=None, ok=True):
+    r = subprocess.run([exe] + [str(a) for a in args], input=stdin, capture_output=True, text=True)
+    if ok:
+        assert r.returncode == 0, r.stdout + r.stderr
+    return r
+
+
+def test_parse_double_is_atof(exe):
+    libc = ctypes.CDLL(None)
+    libc.atof.restype = ctypes.c_double
+    libc.atof.argtypes = [ctypes.c_char_p]
+    rng = np.random.default_rng(11)
+    toks = ["0", "1", "2", "0.5", "-0", "+1.5", "1.", ".5", ".", "-", "1e", "1e+", "1e5", "1E-3", "2.5e22", "2.5e23", "1e-22",
+            "1e-23", "9007199254740992", "9007199254740993", "9007199254740993e3", "0.1", "0.30000000000000004",
+            "123456789012345678901234567890", "0.000000000000000000000000000001", "1e400", "1e-400", "0x10", "inf", "-inf",
+            "nan", "NAN", "abc", "1.5abc", "1,5", "4.9e-324", "2.2250738585072014e-308", "1.7976931348623157e308",
+            "0.1e1", "00012.500", "12345678901234567890e-5", "1e0010", "-1.25E+2", "8.98846567431158e307",
+            "0.500000000000000166533453693773481063544750213623046875", "17.000000000000000000001"]
+    for _ in range(4000):
+        kind = rng.integers(0, 5)
+        if kind == 0:
+            toks.append("%.3f" % rng.uniform(0, 2))
+        elif kind == 1:
+            toks.append(repr(float(rng.standard_normal() * 10.0 ** rng.integers(-30, 30))))
+        elif kind == 2:
+            toks.append("%.*e" % (int(rng.integers(0, 20)), rng.standard_normal() * 10.0 ** rng.integers(-5, 5)))
+        elif kind == 3:
+            toks.append("%d.%0*d" % (rng.integers(0, 10 ** 6), int(rng.integers(1, 18)), rng.integers(0, 10 ** 9)))
+        else:
+            toks.append("%de%d" % (rng.integers(-10 ** 17, 10 ** 17), rng.integers(-30, 30)))
+    out = run(exe, "parse", stdin="\n".join(toks) + "\n").stdout.split()
+    assert len(out) == len(toks)
+    for t, h in zip(toks, out):
+        want = np.float64(libc.atof(t.encode())).view(np.uint64)
+        assert int(h, 16) == int(want), (t, h, hex(int(want)))
+
+
+def _tok(line):
+    return line.replace(",", " ").split()
+
+
+def test_bxd_individual_selection_matches_reference_log(exe, oracle):
+    """ReadFile_pheno + ReadFile_cvt + ProcessCvtPhen on the BXD example: the counts the reference's log reports,
+    W / y equal to the oracle's restatement of the same functions."""
+    log = json.load(open(os.path.join(TXT, "L1.log.json")))
+    ph, cv = os.path.join(TXT, "BXD_pheno.txt"), os.path.join(TXT, "BXD_covariates2.txt")
+    out = run(exe, "cvtphen", ph, cv, 1).stdout.split("\n")
+    ni_test, n_cvt = map(int, out[0].split())
+    ind = np.array(out[1].split(), dtype=int)
+    assert ni_test == int(log["number of analyzed individuals"]) and n_cvt == int(log["number of covariates"])
+    assert ind.size == int(log["number of total individuals"]) and ind.sum() == ni_test
+    y_all, ind_ph = oracle.read_pheno(ph, 1)
+    cvt, ind_cvt = oracle.read_cvt(cv)
+    ind_ref, W_ref = oracle.process_cvt_phen(ind_ph, cvt, ind_cvt)
+    assert (ind == ind_ref).all()
+    W = np.array(out[2].split(), dtype=float).reshape(ni_test, n_cvt)
+    y = np.array(out[3].split(), dtype=float)
+    assert (W == W_ref).all() and (y == y_all[ind_ref == 1]).all()
+
+
+@pytest.mark.parametrize("case", ["no_intercept", "all_constant", "with_intercept", "na_rows", "none"])
+def test_cvt_intercept_rules(exe, oracle, tmp_path, case):
+    """PARAM::CheckCvt (src/param.cpp:1937-1990): a column of 1s is appended when no column is constant, covariates
+    made only of constant columns are dropped, rows with NA leave the analysis."""
+    rng = np.random.default_rng(5)
+    n = 40
+    y = rng.standard_normal(n)
+    miss = rng.random(n) < 0.2
+    ph = tmp_path / "p.txt"
+    ph.write_text("".join("NA\n" if m else "%r\n" % float(v) for v, m in zip(y, miss)))
+    cv = tmp_path / "c.txt"
+    C = rng.standard_normal((n, 2))
+    if case == "all_constant":
+        C[:] = [1.0, 3.0]
+    if case == "with_intercept":
+        C[:, 0] = 1.0
+    rows = [" ".join(repr(float(v)) for v in r) for r in C]
+    if case == "na_rows":
+        rows[3] = "NA 0.5"
+        rows[7] = "0.25\tNA"
+    cv.write_text("\n".join(rows) + "\n")
+    out = run(exe, "cvtphen", ph, "-" if case == "none" else cv, 1).stdout.split("\n")
+    ni_test, n_cvt = map(int, out[0].split())
+    ind = np.array(out[1].split(), dtype=int)
+    y_all, ind_ph = oracle.read_pheno(str(ph), 1)
+    if case == "none":
+        ind_ref, W_ref = oracle.process_cvt_phen(ind_ph)
+    else:
+        cvt, ind_cvt = oracle.read_cvt(str(cv))
+        ind_ref, W_ref = oracle.process_cvt_phen(ind_ph, cvt, ind_cvt)
+    assert (ind == ind_ref).all() and ni_test == ind_ref.sum()
+    W = np.array(out[2].split(), dtype=float).reshape(ni_test, n_cvt)
+    expect = {"no_intercept": 3, "all_constant": 1, "with_intercept": 2, "na_rows": 3, "none": 1}[case]
+    assert n_cvt == expect and W.shape == W_ref.shape and (W == W_ref).all()
+    if case == "na_rows":
+        assert ind[3] == 0 and ind[7] == 0
+
+
+def test_fam_reader_missing_codes_and_columns(exe, tmp_path):
+    """ReadFile_fam (src/gemma_io.cpp:559-635): phenotype n is column 5 + n; NA and -9 both mean missing."""
+    lines = ["f1 i1 0 0 1 1.5 2.5 NA", "f2 i2 0 0 2 -9 0.25 7", "f3\ti3\t0\t0\t1\tNA\t-9.0\t8", "f4 i4 0 0 1 3 4 5"]
+    fam = tmp_path / "x.fam"
+    fam.write_text("\n".join(lines) + "\n")
+    out = run(exe, "fam", fam, 1, 3).stdout.strip().split("\n")
+    assert out[-1] == "ids 4"
+    got = [l.split() for l in out[:-1]]
+    assert got == [["1", "1.5", "0", "-9"], ["0", "-9", "1", "7"], ["0", "-9", "1", "8"], ["1", "3", "1", "5"]]
+    out = run(exe, "fam", fam, 2).stdout.strip().split("\n")
+    assert [l.split() for l in out[:-1]] == [["1", "2.5"], ["1", "0.25"], ["0", "-9"], ["1", "4"]]
+    short = tmp_path / "s.fam"
+    short.write_text("f1 i1 0 0 1\n")
+    assert run(exe, "fam", short, 1, ok=False).returncode == 1
+
+
+def test_bim_and_anno_readers(exe, tmp_path):
+    bim = tmp_path / "x.bim"
+    bim.write_text("1\trs1\t0\t1000\tA\tG\n2 rs2 0.5 2000 C T\nX\trs3\t1e-2\t3000\tG\tA\r\n")
+    got = run(exe, "bim", bim).stdout.strip().split("\n")
+    assert got == ["1 rs1 0 1000 A G", "2 rs2 0.5 2000 C T", "X rs3 0.01 3000 G A"]
+    got = run(exe, "anno", os.path.join(TXT, "BXD_snps_head.txt")).stdout.strip().split("\n")
+    ref = sorted(l.split() for l in open(os.path.join(TXT, "BXD_snps_head.txt")))
+    assert [g.split()[:3] for g in got] == [[r[0], r[1], r[2]] for r in ref] and all(g.split()[3] == "-9" for g in got)
+    an = tmp_path / "a.txt"
+    an.write_text("rsA, 100, 3, 0.5\nrsB, NA, NA\nrsC\t7\n")
+    got = run(exe, "anno", an).stdout.strip().split("\n")
+    assert got == ["rsA 100 3 0.5", "rsB -9 -9 -9", "rsC 7 -9 -9"]
+
+
+def _expected_rows(lines, ni_total):
+    X = np.full((len(lines), ni_total), np.nan)
+    names = []
+    for r, line in enumerate(lines):
+        t = _tok(line)
+        names.append(" ".join(t[:3]))
+        for i in range(ni_total):
+            if t[3 + i] != "NA":
+                X[r, i] = float(t[3 + i])
+    return X, names
+
+
+@pytest.mark.parametrize("threads,block", [(1, 1000), (8, 1000), (8, 37), (3, 16)])
+def test_bimbam_reader_bxd_head(exe, tmp_path, threads, block):
+    """The threaded BIMBAM parser on the first lines of the reference's own BXD genotype file: every value the double
+    atof gives, NA -> NaN, rs / alleles kept, whatever the thread count and block size."""
+    src = os.path.join(TXT, "BXD_geno_head.txt")
+    lines = [l for l in open(src).read().split("\n") if l]
+    ni_total = len(_tok(lines[0])) - 3
+    want, names = _expected_rows(lines, ni_total)
+    out = tmp_path / "x.bin"
+    r = run(exe, "geno", src, ni_total, threads, block, out)
+    got = np.fromfile(out).reshape(-1, ni_total)
+    assert got.shape == want.shape and (np.isnan(got) == np.isnan(want)).all()
+    assert (got[~np.isnan(got)] == want[~np.isnan(want)]).all()
+    assert r.stdout.strip().split("\n") == names
+
+
+def test_bimbam_reader_formats_gzip_selection(exe, tmp_path):
+    """Tabs / commas / blanks as separators, CR-LF line ends, exponent and long-mantissa dosages, a gzip-compressed
+    file, SNP rows dropped through `keep` and individuals through `cols` (what BimbamKin / AnalyzeBimbam ask for)."""
+    rng = np.random.default_rng(3)
+    ni_total, ns = 53, 700
+    lines = []
+    for s in range(ns):
+        vals = []
+        for i in range(ni_total):
+            u = rng.random()
+            if u < 0.05:
+                vals.append("NA")
+            elif u < 0.5:
+                vals.append(str(int(rng.integers(0, 3))))
+            elif u < 0.8:
+                vals.append("%.3f" % rng.uniform(0, 2))
+            elif u < 0.9:
+                vals.append(repr(float(rng.uniform(0, 2))))
+            else:
+                vals.append("%.12e" % rng.uniform(0, 2))
+        sep = [", ", "\t", " ", ","][s % 4]
+        lines.append(sep.join(["rs%d" % s, "A", "G"] + vals))
+    path = tmp_path / "g.txt.gz"
+    with gzip.open(path, "wt", newline="") as f:
+        f.write("\r\n".join(lines) + "\r\n")
+    want, names = _expected_rows(lines, ni_total)
+    out = tmp_path / "all.bin"
+    r = run(exe, "geno", path, ni_total, 8, 64, out)
+    got = np.fromfile(out).reshape(-1, ni_total)
+    assert got.shape == want.shape and np.array_equal(got, want, equal_nan=True)
+    assert r.stdout.strip().split("\n") == names
+    keep = (rng.random(ns) < 0.6).astype(int)
+    cols = (rng.random(ni_total) < 0.7).astype(int)
+    (tmp_path / "keep.txt").write_text(" ".join(map(str, keep)))
+    (tmp_path / "cols.txt").write_text(" ".join(map(str, cols)))
+    out2 = tmp_path / "sel.bin"
+    r = run(exe, "geno", path, ni_total, 5, 50, out2, tmp_path / "keep.txt", tmp_path / "cols.txt")
+    got = np.fromfile(out2).reshape(-1, int(cols.sum()))
+    assert np.array_equal(got, want[keep == 1][:, cols == 1], equal_nan=True)
+    assert r.stdout.strip().split("\n") == [n for n, k in zip(names, keep) if k]
+    bad = tmp_path / "bad.txt"
+    bad.write_text("\n".join(lines[:5]) + "\nrsX A G 1 2\n")
+    assert run(exe, "geno", bad, ni_total, 4, 64, tmp_path / "bad.bin", ok=False).returncode == 1
+
+
+def test_eigen_artefacts_byte_identical_to_reference(exe, tmp_path):
+    """`-eigen` writes <o>.eigenU.txt / <o>.eigenD.txt (src/gemma.cpp:1779-1800): reading the reference's files with
+    ReadFile_eigenU / ReadFile_eigenD and writing them back through WriteEigen gives the same bytes."""
+    n = len(open(os.path.join(TXT, "E.eigenD.txt")).read().split())
+    run(exe, "eigen", os.path.join(TXT, "E.eigenU.txt"), os.path.join(TXT, "E.eigenD.txt"), n, tmp_path, "R")
+    for suf in ("eigenU", "eigenD"):
+        assert open(tmp_path / ("R.%s.txt" % suf), "rb").read() == open(os.path.join(TXT, "E.%s.txt" % suf), "rb").read()
+    assert run(exe, "eigen", os.path.join(TXT, "E.eigenU.txt"), os.path.join(TXT, "E.eigenD.txt"), n - 1, tmp_path, "X",
+               ok=False).returncode == 1
+
+
+def test_kinship_text_byte_identical_to_reference(exe, tmp_path):
+    """ReadFile_kin -> PARAM::WriteMatrix (precision(10), tabs, src/param.cpp:1886-1911) on the reference's cXX corner"""
+    src = os.path.join(TXT, "BXD.cXX.corner.txt")
+    run(exe, "kin", src, 24, tmp_path / "k.txt")
+    assert open(tmp_path / "k.txt", "rb").read() == open(src, "rb").read()
+
+
+@pytest.mark.parametrize("mode", [1, 2, 3, 4, 9])
+def test_assoc_writer_byte_identical_to_reference(exe, tmp_path, mode):
+    """LMM::WriteFiles (src/lmm.cpp:101-225): header, column order and number formats of every -lmm mode, on the
+    first lines the reference wrote for BXD."""
+    src = os.path.join(TXT, "L%d.assoc.head.txt" % mode)
+    run(exe, "assoc", src, mode, tmp_path, "W")
+    assert open(tmp_path / "W.assoc.txt", "rb").read() == open(src, "rb").read()
