@@ -1,0 +1,309 @@
+// TEST DOUBLE of the C ABI (include/gemma_hip.h) over the CPU oracle -- builds into a library with the product's
+// soname so that the C++ host layer (gemma_host.hpp, gemma_io_host.hpp, tests/cpp/gemma_file_driver.cpp) can be run
+// end to end in a container without a GPU ("a CPU implementation of the same ABI (the oracle) is the test
+// double").  It lives under tests/, is built only by tests/test_file_driver_cpu.py into a temporary directory, and is
+// never installed next to the product: gemma_amd/ has no CPU path and keeps failing with GEMMA_HIP_ENODEV without a
+// device.  Only the entry points the file driver reaches are implemented; everything else is absent on purpose
+// (an unexpected call is a link error, not a silent fallback).
+//
+// Arithmetic: oracle/gemma_oracle.c (orc_*: restatement of the reference, pinned on the reference binary's outputs)
+// for imputation, centring, kinship preparation, the null model and the per-SNP statistics; plain loops for the
+// GEMMs; a cyclic Jacobi sweep for the symmetric eigenproblem (the statistics do not depend on the eigenbasis,
+// SURVEY App. A.6); the first-pass SNP filters restated here from src/gemma_io.cpp:753-853 / :942-1049 (no HWE).
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <limits>
+#include <string>
+#include <vector>
+
+#include "gemma_hip.h"
+
+extern "C" {
+typedef struct {
+  double beta, se, lambda_remle, lambda_mle, p_wald, p_lrt, p_score, logl_H1;
+} orc_sumstat;
+void orc_lmm_batch(int a_mode, size_t n, size_t c, const double *eval, const double *UtW, const double *Uty,
+                   const double *UtX, size_t l, double l_min, double l_max, size_t n_region, double l_mle_null,
+                   double logl_mle_H0, int plink_nan_rule, double *carry, orc_sumstat *out, long *diag);
+void orc_impute_mean(double *X, size_t l, size_t n);
+void orc_kin_prepare(double *X, size_t l, size_t n, int k_mode);
+size_t orc_bed_decode(const unsigned char *bytes, size_t ni_total, const int *indicator, double *x);
+void orc_CenterMatrix(double *G, size_t n);
+double orc_zero_small_eval(double *eval, size_t n);
+void orc_CalcLambda_null(char func_name, size_t n, size_t c, const double *eval, const double *UtW, const double *Uty,
+                         double l_min, double l_max, size_t n_region, double *lambda, double *logl_H0);
+void orc_CalcPve(size_t n, size_t c, const double *eval, const double *UtW, const double *Uty, double lambda,
+                 double trace_G, double *pve, double *pve_se);
+void orc_CalcLmmVgVeBeta(size_t n, size_t c, const double *eval, const double *UtW, const double *Uty, double lambda,
+                         double *vg, double *ve, double *beta, double *se_beta);
+}
+
+namespace {
+std::string g_err;
+int fail(int code, const char *msg) {
+  g_err = msg;
+  return code;
+}
+const double NaN = std::numeric_limits<double>::quiet_NaN();
+
+struct Kin {
+  size_t n = 0, ns = 0;
+  int k_mode = 1;
+  std::vector<double> K;
+} g_kin;
+
+struct Lmm {
+  bool on = false;
+  gemma_lmm_cfg cfg;
+  std::vector<double> U, eval, UtW, Uty, carry;
+  std::vector<int> ind;
+} g_lmm;
+
+// rows of l SNPs over `n_out` individuals (NaN = missing) from either encoding
+void decode(int kind, const void *geno, size_t l, size_t ld, const int *ind, size_t ni_total, size_t n_out,
+            std::vector<double> &X) {
+  X.assign(l * n_out, 0.0);
+  for (size_t s = 0; s < l; ++s) {
+    double *x = &X[s * n_out];
+    if (kind == GEMMA_GENO_PLINK_2BIT) {
+      orc_bed_decode(static_cast<const unsigned char *>(geno) + s * ld, ni_total, ind, x);
+    } else {
+      const double *g = static_cast<const double *>(geno) + s * ld;
+      size_t o = 0;
+      for (size_t i = 0; i < ni_total; ++i)
+        if (!ind || ind[i]) x[o++] = g[i];
+    }
+  }
+}
+} // namespace
+
+extern "C" {
+
+int gemma_hip_init(int, int) { return GEMMA_HIP_OK; }
+void gemma_hip_shutdown(void) {}
+int gemma_hip_abi_version(void) { return GEMMA_HIP_ABI_VERSION; }
+const char *gemma_hip_strerror(int code) { return code == 0 ? "ok" : "error (test double)"; }
+const char *gemma_hip_last_error(void) { return g_err.c_str(); }
+
+int gemma_hip_dgemm(char ta, char tb, size_t M, size_t N, size_t K, double alpha, const double *A, size_t lda,
+                    const double *B, size_t ldb, double beta, double *C, size_t ldc) {
+  const bool tA = ta == 'T' || ta == 't', tB = tb == 'T' || tb == 't';
+  std::vector<double> acc(N);
+  for (size_t i = 0; i < M; ++i) {
+    std::fill(acc.begin(), acc.end(), 0.0);
+    for (size_t k = 0; k < K; ++k) {
+      const double a = tA ? A[k * lda + i] : A[i * lda + k];
+      for (size_t j = 0; j < N; ++j) acc[j] += a * (tB ? B[j * ldb + k] : B[k * ldb + j]);
+    }
+    for (size_t j = 0; j < N; ++j) C[i * ldc + j] = alpha * acc[j] + (beta == 0.0 ? 0.0 : beta * C[i * ldc + j]);
+  }
+  return GEMMA_HIP_OK;
+}
+
+int gemma_hip_kin_begin(size_t n_total, int k_mode) {
+  g_kin.n = n_total;
+  g_kin.ns = 0;
+  g_kin.k_mode = k_mode;
+  g_kin.K.assign(n_total * n_total, 0.0);
+  return GEMMA_HIP_OK;
+}
+int gemma_hip_kin_add(int kind, const void *geno, size_t l, size_t ld) {
+  if (kind != GEMMA_GENO_F64_SNP_MAJOR && kind != GEMMA_GENO_PLINK_2BIT) return fail(GEMMA_HIP_EINVAL, "kin_add kind");
+  const size_t n = g_kin.n;
+  std::vector<double> X;
+  decode(kind, geno, l, ld, nullptr, n, n, X);
+  orc_kin_prepare(X.data(), l, n, g_kin.k_mode);
+  for (size_t s = 0; s < l; ++s) {
+    const double *x = &X[s * n];
+    for (size_t i = 0; i < n; ++i) {
+      const double xi = x[i];
+      double *k = &g_kin.K[i * n];
+      for (size_t j = 0; j < n; ++j) k[j] += xi * x[j];
+    }
+  }
+  g_kin.ns += l;
+  return GEMMA_HIP_OK;
+}
+int gemma_hip_kin_end(double *K, size_t *ns_used) {
+  for (size_t i = 0; i < g_kin.n * g_kin.n; ++i) K[i] = g_kin.K[i] / (double)g_kin.ns;
+  if (ns_used) *ns_used = g_kin.ns;
+  return GEMMA_HIP_OK;
+}
+
+// ReadFile_geno src/gemma_io.cpp:753-853 / ReadFile_bed :942-1049, statistics over the analysed individuals
+int gemma_hip_snp_qc(int kind, const void *geno, size_t l, size_t ld, const int *indicator_idv, size_t ni_total,
+                     const double *W, size_t n, size_t c, const gemma_qc_cfg *cfg, int *indicator_snp, double *maf_out,
+                     size_t *n_miss_out) {
+  if (cfg->hwe_level != 0) return fail(GEMMA_HIP_EINVAL, "test double: no HWE filter");
+  std::vector<double> X;
+  decode(kind, geno, l, ld, indicator_idv, ni_total, n, X);
+  // (W^T W)^-1 by Gauss-Jordan
+  std::vector<double> A(c * 2 * c, 0.0);
+  for (size_t a = 0; a < c; ++a) {
+    for (size_t b = 0; b < c; ++b)
+      for (size_t i = 0; i < n; ++i) A[a * 2 * c + b] += W[i * c + a] * W[i * c + b];
+    A[a * 2 * c + c + a] = 1.0;
+  }
+  for (size_t p = 0; p < c; ++p) {
+    size_t piv = p;
+    for (size_t r = p + 1; r < c; ++r)
+      if (std::fabs(A[r * 2 * c + p]) > std::fabs(A[piv * 2 * c + p])) piv = r;
+    for (size_t j = 0; j < 2 * c; ++j) std::swap(A[p * 2 * c + j], A[piv * 2 * c + j]);
+    const double d = A[p * 2 * c + p];
+    for (size_t j = 0; j < 2 * c; ++j) A[p * 2 * c + j] /= d;
+    for (size_t r = 0; r < c; ++r) {
+      if (r == p) continue;
+      const double f = A[r * 2 * c + p];
+      for (size_t j = 0; j < 2 * c; ++j) A[r * 2 * c + j] -= f * A[p * 2 * c + j];
+    }
+  }
+  for (size_t s = 0; s < l; ++s) {
+    double *x = &X[s * n];
+    double sum = 0.0, first = NaN;
+    size_t n_miss = 0, n0 = 0, n1 = 0, n2 = 0;
+    bool differ = false;
+    for (size_t i = 0; i < n; ++i) {
+      const double g = x[i];
+      if (g != g) { ++n_miss; continue; }
+      if (g >= 0 && g <= 0.5) ++n0;
+      if (g > 0.5 && g < 1.5) ++n1;
+      if (g >= 1.5 && g <= 2.0) ++n2;
+      if (first != first) first = g; else if (g != first) differ = true;
+      sum += g;
+    }
+    const double maf = sum / (2.0 * (double)(n - n_miss));
+    if (maf_out) maf_out[s] = maf;
+    if (n_miss_out) n_miss_out[s] = n_miss;
+    int keep = 1;
+    if ((double)n_miss / (double)n > cfg->miss_level) keep = 0;
+    else if ((maf < cfg->maf_level || maf > 1.0 - cfg->maf_level) && cfg->maf_level != -1) keep = 0;
+    else if (kind == GEMMA_GENO_PLINK_2BIT ? ((n0 + n1) == 0 || (n1 + n2) == 0 || (n2 + n0) == 0) : !differ) keep = 0;
+    else if (c != 1) {
+      std::vector<double> Wtx(c, 0.0);
+      double v_x = 0.0, v_w = 0.0;
+      for (size_t i = 0; i < n; ++i) {
+        const double g = x[i] != x[i] ? maf * 2.0 : x[i];
+        v_x += g * g;
+        for (size_t a = 0; a < c; ++a) Wtx[a] += W[i * c + a] * g;
+      }
+      for (size_t a = 0; a < c; ++a) {
+        double t = 0.0;
+        for (size_t b = 0; b < c; ++b) t += A[a * 2 * c + c + b] * Wtx[b];
+        v_w += Wtx[a] * t;
+      }
+      if (v_w / v_x > cfg->r2_level) keep = 0;
+    }
+    indicator_snp[s] = keep;
+  }
+  return GEMMA_HIP_OK;
+}
+
+int gemma_hip_center(double *G, size_t n) {
+  orc_CenterMatrix(G, n);
+  return GEMMA_HIP_OK;
+}
+
+// cyclic Jacobi; eigenvalues ascending, eigenvector k = column k of row-major U; EigenDecomp_Zeroed's clean-up
+int gemma_hip_eigh(double *G, size_t n, double *U, double *eval, double *trace_G) {
+  std::vector<double> V(n * n, 0.0);
+  for (size_t i = 0; i < n; ++i) V[i * n + i] = 1.0;
+  for (int sweep = 0; sweep < 60; ++sweep) {
+    double off = 0.0;
+    for (size_t p = 0; p < n; ++p)
+      for (size_t q = p + 1; q < n; ++q) off += G[p * n + q] * G[p * n + q];
+    if (off < 1e-30) break;
+    for (size_t p = 0; p < n; ++p)
+      for (size_t q = p + 1; q < n; ++q) {
+        const double apq = G[p * n + q];
+        if (apq == 0.0) continue;
+        const double theta = (G[q * n + q] - G[p * n + p]) / (2.0 * apq);
+        const double t = (theta >= 0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
+        const double cs = 1.0 / std::sqrt(t * t + 1.0), sn = t * cs;
+        for (size_t k = 0; k < n; ++k) {
+          const double gkp = G[k * n + p], gkq = G[k * n + q];
+          G[k * n + p] = cs * gkp - sn * gkq;
+          G[k * n + q] = sn * gkp + cs * gkq;
+        }
+        for (size_t k = 0; k < n; ++k) {
+          const double gpk = G[p * n + k], gqk = G[q * n + k];
+          G[p * n + k] = cs * gpk - sn * gqk;
+          G[q * n + k] = sn * gpk + cs * gqk;
+        }
+        for (size_t k = 0; k < n; ++k) {
+          const double vkp = V[k * n + p], vkq = V[k * n + q];
+          V[k * n + p] = cs * vkp - sn * vkq;
+          V[k * n + q] = sn * vkp + cs * vkq;
+        }
+      }
+  }
+  std::vector<size_t> order(n);
+  for (size_t i = 0; i < n; ++i) order[i] = i;
+  std::sort(order.begin(), order.end(), [&](size_t a, size_t b) { return G[a * n + a] < G[b * n + b]; });
+  for (size_t k = 0; k < n; ++k) {
+    eval[k] = G[order[k] * n + order[k]];
+    for (size_t i = 0; i < n; ++i) U[i * n + k] = V[i * n + order[k]];
+  }
+  *trace_G = orc_zero_small_eval(eval, n);
+  return GEMMA_HIP_OK;
+}
+
+int gemma_hip_lmm_null(size_t n, size_t c, const double *eval, const double *UtW, const double *Uty, double l_min,
+                       double l_max, size_t n_region, double trace_G, double *o) {
+  orc_CalcLambda_null('L', n, c, eval, UtW, Uty, l_min, l_max, n_region, &o[0], &o[1]);
+  orc_CalcLambda_null('R', n, c, eval, UtW, Uty, l_min, l_max, n_region, &o[2], &o[3]);
+  orc_CalcPve(n, c, eval, UtW, Uty, o[2], trace_G, &o[4], &o[5]);
+  std::vector<double> beta(c), se(c);
+  orc_CalcLmmVgVeBeta(n, c, eval, UtW, Uty, o[2], &o[6], &o[7], beta.data(), se.data());
+  return GEMMA_HIP_OK;
+}
+
+int gemma_hip_lmm_setup(const gemma_lmm_cfg *cfg, const double *U, const double *eval, const double *UtW,
+                        const double *Uty) {
+  const size_t n = cfg->n, c = cfg->n_cvt;
+  g_lmm.on = true;
+  g_lmm.cfg = *cfg;
+  g_lmm.U.assign(U, U + n * n);
+  g_lmm.eval.assign(eval, eval + n);
+  g_lmm.UtW.assign(UtW, UtW + n * c);
+  g_lmm.Uty.assign(Uty, Uty + n);
+  g_lmm.carry.assign(2, 0.0);
+  g_lmm.ind.clear();
+  return GEMMA_HIP_OK;
+}
+int gemma_hip_lmm_set_indicator(const int *ind, size_t ni_total) {
+  if (!g_lmm.on) return fail(GEMMA_HIP_ESTATE, "lmm_set_indicator before lmm_setup");
+  g_lmm.ind.assign(ind, ind + (ind ? ni_total : 0));
+  return GEMMA_HIP_OK;
+}
+int gemma_hip_lmm_batch(int kind, const void *geno, size_t l, size_t ld, gemma_sumstat *out) {
+  if (!g_lmm.on) return fail(GEMMA_HIP_ESTATE, "lmm_batch before lmm_setup");
+  const size_t n = g_lmm.cfg.n, c = g_lmm.cfg.n_cvt;
+  std::vector<double> X;
+  if (kind == GEMMA_GENO_PLINK_2BIT)
+    decode(kind, geno, l, ld, g_lmm.ind.empty() ? nullptr : g_lmm.ind.data(), g_lmm.ind.empty() ? n : g_lmm.ind.size(), n, X);
+  else if (kind == GEMMA_GENO_F64_SNP_MAJOR)
+    decode(kind, geno, l, ld, nullptr, n, n, X);
+  else
+    return fail(GEMMA_HIP_EINVAL, "lmm_batch kind");
+  orc_impute_mean(X.data(), l, n);
+  std::vector<double> UtX(l * n);
+  gemma_hip_dgemm('N', 'N', l, n, n, 1.0, X.data(), n, g_lmm.U.data(), n, 0.0, UtX.data(), n); // row s = (U^T x_s)^T
+  static_assert(sizeof(orc_sumstat) == sizeof(gemma_sumstat), "SUMSTAT layout");
+  orc_lmm_batch(g_lmm.cfg.a_mode, n, c, g_lmm.eval.data(), g_lmm.UtW.data(), g_lmm.Uty.data(), UtX.data(), l,
+                g_lmm.cfg.l_min, g_lmm.cfg.l_max, g_lmm.cfg.n_region, g_lmm.cfg.l_mle_null, g_lmm.cfg.logl_mle_H0,
+                g_lmm.cfg.plink_nan_rule, g_lmm.carry.data(), reinterpret_cast<orc_sumstat *>(out), nullptr);
+  return GEMMA_HIP_OK;
+}
+int gemma_hip_lmm_finish(double *t_utx, double *t_opt) {
+  g_lmm.on = false;
+  if (t_utx) *t_utx = 0.0;
+  if (t_opt) *t_opt = 0.0;
+  return GEMMA_HIP_OK;
+}
+
+// referenced by inline members of class LMM the driver does not call (the linker still wants them with -O0)
+int gemma_hip_lmm_gene_batch(const double *, size_t, size_t, gemma_sumstat *) { return fail(GEMMA_HIP_EINVAL, "not in the double"); }
+int gemma_hip_lmm_set_env(const double *) { return fail(GEMMA_HIP_EINVAL, "not in the double"); }
+int gemma_hip_lmm_gxe_batch(int, const void *, size_t, size_t, gemma_sumstat *) { return fail(GEMMA_HIP_EINVAL, "not in the double"); }
+}

@@ -1,0 +1,183 @@
+// File-driven run of the path, the way `gemma` is invoked (test harness for include/gemma_io_host.hpp +
+// include/gemma_host.hpp; NOT a replacement of GEMMA's CLI -- INTEGRATION.md binds the C ABI inside GEMMA itself):
+//
+//   gemma_file_driver (-g geno[.gz] -p pheno [-a anno] | -bfile prefix) [-c cvt] [-n col]
+//                     (-gk [1|2] | -k kin (-eigen | -lmm [1|2|3|4|9]) | -d eigenD -u eigenU -lmm m)
+//                     [-maf x] [-miss x] [-hwe x] [-r2 x] [-o name] [-outdir dir]
+//
+// following PARAM::ReadFiles (src/param.cpp:115-300) and BatchRun (src/gemma.cpp:1900-1926 `-gk`, :1779-1800 `-eigen`,
+// :2557-2830 `-lmm`): first pass over the genotypes (device QC) -> kinship over all individuals -> <o>.cXX.txt / .sXX.txt;
+// or kinship file -> rows of the analysed individuals -> centre -> eigendecomposition (-> <o>.eigenU/D.txt) -> U^T W,
+// U^T y -> null model -> per-SNP association -> <o>.assoc.txt.  One line of key=value pairs on stdout is the log.
+#include <cstdlib>
+#include <iostream>
+#include <string>
+#include <vector>
+
+#include "gemma_io_host.hpp"
+
+using namespace gemma_amd;
+
+int main(int argc, char **argv) {
+  std::string file_geno, file_pheno, file_anno, file_bfile, file_cvt, file_kin, file_kd, file_ku, file_out = "result",
+                                                                                                  path_out = "./output";
+  size_t p_column = 1;
+  int k_mode = 0, a_mode = 0;
+  bool do_eigen = false;
+  QcLevels qc;
+  for (int i = 1; i < argc; ++i) {
+    const std::string a = argv[i];
+    const bool has = i + 1 < argc && argv[i + 1][0] != '-';
+    if (a == "-g" && has) file_geno = argv[++i];
+    else if (a == "-p" && has) file_pheno = argv[++i];
+    else if (a == "-a" && has) file_anno = argv[++i];
+    else if (a == "-bfile" && has) file_bfile = argv[++i];
+    else if (a == "-c" && has) file_cvt = argv[++i];
+    else if (a == "-k" && has) file_kin = argv[++i];
+    else if (a == "-d" && has) file_kd = argv[++i];
+    else if (a == "-u" && has) file_ku = argv[++i];
+    else if (a == "-n" && has) p_column = strtoul(argv[++i], nullptr, 10);
+    else if (a == "-o" && has) file_out = argv[++i];
+    else if (a == "-outdir" && has) path_out = argv[++i];
+    else if (a == "-gk") k_mode = has ? atoi(argv[++i]) : 1;
+    else if (a == "-lmm") a_mode = has ? atoi(argv[++i]) : 1;
+    else if (a == "-eigen") do_eigen = true;
+    else if (a == "-maf" && has) qc.maf_level = atof(argv[++i]);
+    else if (a == "-miss" && has) qc.miss_level = atof(argv[++i]);
+    else if (a == "-hwe" && has) qc.hwe_level = atof(argv[++i]);
+    else if (a == "-r2" && has) qc.r2_level = atof(argv[++i]);
+    else {
+      std::cerr << "unknown or incomplete option " << a << std::endl;
+      return 2;
+    }
+  }
+  try {
+    enforce_hip(gemma_hip_init(0, 0), "init");
+    // ---- PARAM::ReadFiles ---------------------------------------------------------------------------------------
+    CvtPhen cp;
+    std::vector<SNPINFO> snpInfo;
+    std::vector<int> indicator_snp;
+    std::map<std::string, int> mapID2num;
+    std::map<std::string, std::string> mapRS2chr;
+    std::map<std::string, long int> mapRS2bp;
+    std::map<std::string, double> mapRS2cM;
+    const std::set<std::string> setSnps;
+    const std::vector<size_t> cols(1, p_column);
+    if (!file_cvt.empty() && !ReadFile_cvt(file_cvt, cp.indicator_cvt, cp.cvt, cp.n_cvt)) return 3;
+    if (cp.indicator_cvt.empty()) cp.n_cvt = 1;
+    size_t ns_test = 0;
+    std::vector<double> Wb, Yb;
+    if (!file_bfile.empty()) {
+      if (!ReadFile_bim(file_bfile + ".bim", snpInfo)) return 3;
+      if (!(file_pheno.empty() ? ReadFile_fam(file_bfile + ".fam", cp.indicator_pheno, cp.pheno, mapID2num, cols)
+                               : ReadFile_pheno(file_pheno, cp.indicator_pheno, cp.pheno, cols)))
+        return 3;
+    } else if (!file_geno.empty()) {
+      if (!file_anno.empty() && !ReadFile_anno(file_anno, mapRS2chr, mapRS2bp, mapRS2cM)) return 3;
+      if (!ReadFile_pheno(file_pheno, cp.indicator_pheno, cp.pheno, cols)) return 3;
+    } else {
+      std::cerr << "need -g/-p or -bfile" << std::endl;
+      return 2;
+    }
+    cp.ProcessCvtPhen();
+    if (cp.error) return 3;
+    cp.CopyCvtPhen(Wb, Yb);
+    const size_t ni_total = cp.indicator_idv.size(), ni_test = cp.ni_test, n_cvt = cp.n_cvt;
+    Matrix W = matrix_view(Wb.data(), ni_test, n_cvt);
+    if (!file_bfile.empty()) {
+      if (!ReadFile_bed(file_bfile + ".bed", setSnps, &W, cp.indicator_idv, indicator_snp, snpInfo, qc.maf_level,
+                        qc.miss_level, qc.hwe_level, qc.r2_level, ns_test))
+        return 3;
+    } else {
+      if (!ReadFile_geno(file_geno, setSnps, &W, cp.indicator_idv, indicator_snp, qc.maf_level, qc.miss_level,
+                         qc.hwe_level, qc.r2_level, mapRS2chr, mapRS2bp, mapRS2cM, snpInfo, ns_test))
+        return 3;
+    }
+    std::cout << "ni_total=" << ni_total << " ni_test=" << ni_test << " n_cvt=" << n_cvt
+              << " ns_total=" << indicator_snp.size() << " ns_test=" << ns_test;
+
+    // ---- -gk (src/gemma.cpp:1900-1926) ----------------------------------------------------------------------------
+    if (k_mode) {
+      std::vector<double> Kb(ni_total * ni_total, 0.0);
+      Matrix K = matrix_view(Kb.data(), ni_total, ni_total);
+      const bool ok = file_bfile.empty() ? BimbamKinThreaded(file_geno, indicator_snp, k_mode, &K)
+                                         : PlinkKin(file_bfile + ".bed", indicator_snp, k_mode, 0, &K);
+      if (!ok) return 4;
+      if (!WriteMatrix(&K, path_out + "/" + file_out + (k_mode == 1 ? ".cXX.txt" : ".sXX.txt"))) return 4;
+      std::cout << std::endl;
+      gemma_hip_shutdown();
+      return 0;
+    }
+
+    // ---- eigen pairs: from -k (centre + decompose) or from -d / -u ------------------------------------------------
+    std::vector<double> Ub(ni_test * ni_test), evalb(ni_test);
+    Matrix U = matrix_view(Ub.data(), ni_test, ni_test);
+    Vector eval = vector_view(evalb.data(), ni_test);
+    double trace_G = 0.0;
+    bool error = false;
+    if (!file_kin.empty()) {
+      std::vector<double> Gb(ni_test * ni_test);
+      Matrix G = matrix_view(Gb.data(), ni_test, ni_test);
+      ReadFile_kin(file_kin, cp.indicator_idv, error, &G);
+      if (error) return 5;
+      CenterMatrix(&G);
+      trace_G = EigenDecomp_Zeroed(&G, &U, &eval, 0);
+    } else if (!file_kd.empty() && !file_ku.empty()) {
+      ReadFile_eigenU(file_ku, error, &U);
+      ReadFile_eigenD(file_kd, error, &eval);
+      if (error) return 5;
+      for (size_t i = 0; i < ni_test; ++i) { // src/gemma.cpp:2640-2647
+        if (evalb[i] < 1e-10) evalb[i] = 0;
+        trace_G += evalb[i];
+      }
+      trace_G /= (double)ni_test;
+    } else {
+      std::cerr << "need -gk, -k or -d/-u" << std::endl;
+      return 2;
+    }
+    std::cout << " trace_G=" << std::setprecision(12) << trace_G;
+    if (do_eigen) { // src/gemma.cpp:1779-1800
+      if (!WriteEigen(&U, &eval, path_out, file_out)) return 5;
+      std::cout << std::endl;
+      gemma_hip_shutdown();
+      return 0;
+    }
+    if (!a_mode) {
+      std::cerr << "nothing to do" << std::endl;
+      return 2;
+    }
+
+    // ---- -lmm (src/gemma.cpp:2699-2830) ---------------------------------------------------------------------------
+    std::vector<double> UtWb(ni_test * n_cvt), Utyb(ni_test);
+    Matrix Y = matrix_view(Yb.data(), ni_test, 1), UtW = matrix_view(UtWb.data(), ni_test, n_cvt),
+           UtY = matrix_view(Utyb.data(), ni_test, 1);
+    CalcUtX(&U, &W, &UtW);
+    CalcUtX(&U, &Y, &UtY);
+    Vector Uty = vector_view(Utyb.data(), ni_test);
+    const NullModel nm = CalcLambdaNull(&eval, &UtW, &Uty, 1e-5, 1e5, 10, trace_G);
+    std::cout << " l_mle_null=" << nm.l_mle_null << " logl_mle_H0=" << nm.logl_mle_H0 << " l_remle_null=" << nm.l_remle_null
+              << " logl_remle_H0=" << nm.logl_remle_H0 << " pve=" << nm.pve_null << " se_pve=" << nm.pve_se_null
+              << " vg=" << nm.vg_remle_null << " ve=" << nm.ve_remle_null;
+    LMM cLmm;
+    cLmm.a_mode = a_mode;
+    cLmm.file_bfile = file_bfile;
+    cLmm.file_geno = file_geno;
+    cLmm.path_out = path_out;
+    cLmm.file_out = file_out;
+    cLmm.ni_total = ni_total;
+    cLmm.indicator_idv = cp.indicator_idv;
+    cLmm.indicator_snp = indicator_snp;
+    cLmm.snpInfo = snpInfo;
+    cLmm.l_mle_null = nm.l_mle_null;
+    cLmm.logl_mle_H0 = nm.logl_mle_H0;
+    if (!file_bfile.empty()) cLmm.AnalyzePlink(&U, &eval, &UtW, &Uty);
+    else AnalyzeBimbam(cLmm, &U, &eval, &UtW, &Uty);
+    cLmm.WriteFiles();
+    std::cout << " snps=" << cLmm.sumStat.size() << std::endl;
+    gemma_hip_shutdown();
+  } catch (const std::exception &e) {
+    std::cerr << "error: " << e.what() << std::endl;
+    return 1;
+  }
+  return 0;
+}

@@ -1,0 +1,144 @@
+"""File-driven runs of tests/cpp/gemma_file_driver.cpp (gemma's own command lines: -g/-p/-c/-a or -bfile, -gk, -k ... -lmm,
+-eigen, -d/-u) checked against what the reference binary wrote for the same files (tests/golden/text/, made by
+tests/golden/make_text_fixtures.py from oracle/_ref/gemma).  Shared by tests/test_file_driver_cpu.py (the C++ host layer
+over the oracle-backed ABI test double, CPU) and tests/test_gpu_workflow_files.py (the same driver over the HIP library)."""
+import gzip
+import json
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TXT = os.path.join(ROOT, "tests", "golden", "text")
+STAT_TOL = 2e-6  # 7 printed digits (5e-7) + the 1e-6 parity bar
+LAM_COLS = ("l_remle", "l_mle")
+
+
+def build_driver(tmp, libdir, extra_rpath=()):
+    exe = os.path.join(str(tmp), "gemma_file_driver")
+    rp = ["-Wl,-rpath," + d for d in (libdir,) + tuple(extra_rpath)]
+    subprocess.check_call(["g++", "-std=c++11", "-O2", "-Wall", "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "cpp", "gemma_file_driver.cpp"), "-L" + libdir, "-lgemma_hip"] + rp +
+                          ["-lz", "-pthread", "-o", exe])
+    return exe
+
+
+def drive(exe, *args):
+    r = subprocess.run([exe] + [str(a) for a in args], capture_output=True, text=True)
+    assert r.returncode == 0, "driver failed: %s\n%s\n%s" % (" ".join(map(str, args)), r.stdout, r.stderr)
+    return dict(kv.split("=", 1) for kv in r.stdout.split() if "=" in kv)
+
+
+def read_assoc(path):
+    op = gzip.open if str(path).endswith(".gz") else open
+    with op(path, "rt") as f:
+        lines = f.read().strip().split("\n")
+    hdr = lines[0].split("\t")
+    rows = [l.split("\t") for l in lines[1:]]
+    return hdr, rows
+
+
+def compare_assoc(got_path, ref_path, n_ref_rows=None):
+    """Same header, same SNPs in the same order, identical annotation columns, statistics to the printed digits;
+    lambda: >= 98 % to the printed digits, all within 1e-3 (the reference reports the penultimate Newton iterate)."""
+    gh, gr = read_assoc(got_path)
+    rh, rr = read_assoc(ref_path)
+    assert gh == rh
+    if n_ref_rows is None:
+        assert len(gr) == len(rr)
+    else:
+        assert len(gr) == n_ref_rows
+        gr = gr[:len(rr)]
+    for g, r in zip(gr, rr):
+        assert g[:7] == r[:7], (g[:7], r[:7])
+    for j in range(7, len(gh)):
+        got = np.array([float(g[j]) for g in gr])
+        ref = np.array([float(r[j]) for r in rr])
+        both_nan = np.isnan(got) & np.isnan(ref)
+        rel = np.where(both_nan, 0.0, np.abs(got - ref) / np.maximum(np.abs(ref), 1e-300))
+        if gh[j] in LAM_COLS:
+            assert (rel <= 1e-3).all() and (rel <= STAT_TOL).mean() >= 0.98, (gh[j], np.nanmax(rel))
+        else:
+            flips = np.isnan(got) != np.isnan(ref)  # a failed lambda search is a Newton loop that cycled: <= 0.1 % may flip
+            assert flips.mean() <= 1e-3 and (rel[~flips] <= STAT_TOL).all(), (gh[j], np.nanmax(rel[~flips]))
+
+
+def check_log(kv, log_json):
+    log = json.load(open(os.path.join(TXT, log_json)))
+    assert int(kv["ni_total"]) == int(log["number of total individuals"])
+    assert int(kv["ni_test"]) == int(log["number of analyzed individuals"])
+    assert int(kv["n_cvt"]) == int(log["number of covariates"])
+    assert int(kv["ns_total"]) == int(log["number of total SNPs/var"])
+    assert int(kv["ns_test"]) == int(log["number of analyzed SNPs/var"])
+    if "pve" in kv:  # the log prints 6 significant digits
+        for key, name in (("pve", "pve estimate in the null model"), ("se_pve", "se(pve) in the null model"),
+                          ("vg", "vg estimate in the null model"), ("ve", "ve estimate in the null model"),
+                          ("logl_remle_H0", "REMLE log-likelihood in the null model"),
+                          ("logl_mle_H0", "MLE log-likelihood in the null model")):
+            assert abs(float(kv[key]) - float(log[name])) <= 2e-5 * abs(float(log[name])) + 1e-12, (key, kv[key], log[name])
+
+
+def bxd_bimbam_workflow(exe, out):
+    """BIMBAM text input with covariates and annotation: -gk, -lmm 1/4/9 through the 10-digit cXX hand-off, -eigen,
+    then -lmm from the -d/-u artefacts."""
+    out = str(out)
+    base = ["-g", os.path.join(TXT, "BXD_geno.txt.gz"), "-p", os.path.join(TXT, "BXD_pheno.txt"),
+            "-c", os.path.join(TXT, "BXD_covariates2.txt"), "-a", os.path.join(TXT, "BXD_snps.txt.gz"), "-outdir", out]
+    kv = drive(exe, *base, "-gk", "-o", "BXD")
+    assert (int(kv["ni_total"]), int(kv["ni_test"]), int(kv["ns_total"]), int(kv["ns_test"])) == (198, 67, 7320, 7317)
+    cxx = os.path.join(out, "BXD.cXX.txt")
+    K = np.loadtxt(cxx)
+    ref = np.load(os.path.join(ROOT, "tests", "golden", "ref_bxd.npz"))["cXX"]
+    assert K.shape == ref.shape and np.abs(K - ref).max() <= 2e-10  # one unit of the 10th printed digit
+    corner = np.loadtxt(os.path.join(TXT, "BXD.cXX.corner.txt"))
+    assert np.abs(K[:24, :24] - corner).max() <= 2e-10
+    for m in (1, 4, 9):
+        kv = drive(exe, *base, "-k", cxx, "-lmm", m, "-maf", "0.1", "-o", "L%d" % m)
+        check_log(kv, "L1.log.json")
+        compare_assoc(os.path.join(out, "L%d.assoc.txt" % m), os.path.join(TXT, "L%d.assoc.head.txt" % m), n_ref_rows=7317)
+        full = np.load(os.path.join(ROOT, "tests", "golden", "ref_bxd.npz"))
+        hdr, rows = read_assoc(os.path.join(out, "L%d.assoc.txt" % m))
+        assert [r[1] for r in rows] == list(full["rs"])
+        for j, name in enumerate(hdr[7:], start=7):
+            got = np.array([float(r[j]) for r in rows])
+            want = full["lmm%d_%s" % (m, name)]
+            rel = np.abs(got - want) / np.maximum(np.abs(want), 1e-300)
+            rel[np.isnan(got) & np.isnan(want)] = 0.0
+            flips = np.isnan(got) != np.isnan(want)
+            assert flips.mean() <= 1e-3
+            if name in LAM_COLS:
+                assert (rel[~flips] <= 1e-3).all() and (rel[~flips] <= STAT_TOL).mean() >= 0.98, (m, name)
+            else:
+                assert (rel[~flips] <= STAT_TOL).all(), (m, name, np.nanmax(rel[~flips]))
+    drive(exe, *base, "-k", cxx, "-eigen", "-o", "E")
+    D = np.loadtxt(os.path.join(out, "E.eigenD.txt"))
+    Dref = np.loadtxt(os.path.join(TXT, "E.eigenD.txt"))
+    assert D.shape == Dref.shape and np.allclose(D, Dref, rtol=1e-8, atol=1e-9)
+    U = np.loadtxt(os.path.join(out, "E.eigenU.txt"))
+    assert np.abs(U.T @ U - np.eye(len(D))).max() < 1e-8
+    kv = drive(exe, *base, "-d", os.path.join(out, "E.eigenD.txt"), "-u", os.path.join(out, "E.eigenU.txt"), "-lmm", 1,
+               "-maf", "0.1", "-o", "L1du")
+    compare_assoc(os.path.join(out, "L1du.assoc.txt"), os.path.join(TXT, "L1.assoc.head.txt"), n_ref_rows=7317)
+
+
+def plink_workflow(exe, out):
+    """PLINK input with missing calls and unphenotyped individuals (.fam phenotypes, -9 = missing): -gk, -lmm 4 with and
+    without a covariate file (no intercept column, one NA row), tightened -miss / -maf filters."""
+    out = str(out)
+    base = ["-bfile", os.path.join(TXT, "P"), "-outdir", out]
+    kv = drive(exe, *base, "-gk", "-o", "P")
+    check_log(kv, "P4.log.json")
+    cxx = os.path.join(out, "P.cXX.txt")
+    head = np.loadtxt(os.path.join(TXT, "P.cXX.head.txt"))
+    K = np.loadtxt(cxx)
+    assert K.shape == (240, 240) and np.abs(K[:8] - head).max() <= 2e-10 and np.abs(K - K.T).max() == 0
+    kv = drive(exe, *base, "-k", cxx, "-lmm", 4, "-o", "P4")
+    check_log(kv, "P4.log.json")
+    compare_assoc(os.path.join(out, "P4.assoc.txt"), os.path.join(TXT, "P4.assoc.txt.gz"))
+    kv = drive(exe, *base, "-k", cxx, "-lmm", 4, "-c", os.path.join(TXT, "P.cov.txt"), "-o", "P4c")
+    check_log(kv, "P4c.log.json")
+    compare_assoc(os.path.join(out, "P4c.assoc.txt"), os.path.join(TXT, "P4c.assoc.txt.gz"))
+    kv = drive(exe, *base, "-k", cxx, "-lmm", 1, "-miss", "0.02", "-maf", "0.05", "-o", "P1q")
+    check_log(kv, "P1q.log.json")
+    compare_assoc(os.path.join(out, "P1q.assoc.txt"), os.path.join(TXT, "P1q.assoc.txt.gz"))

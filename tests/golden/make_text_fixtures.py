@@ -15,6 +15,8 @@ import shutil
 import subprocess
 import tempfile
 
+import numpy as np
+
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 GEMMA = os.path.join(ROOT, "oracle", "_ref", "gemma")
 E = "/root/reference/example/"
@@ -34,6 +36,50 @@ def head(src, dst, n):
             if i >= n:
                 break
             g.write(line)
+
+
+def plink_subset(tmp, ni=240, ns=800):
+    """The first `ni` individuals x `ns` SNPs of the reference's test/data/issue188/2000 PLINK set (missing calls,
+    unphenotyped individuals), re-packed, and what the reference writes for it: cXX (first rows), -lmm 4 with and
+    without covariates."""
+    src = "/root/reference/test/data/issue188/2000"
+    fam = [l for l in open(src + ".fam") if l.strip()]
+    bim = [l for l in open(src + ".bim") if l.strip()][:ns]
+    raw = np.fromfile(src + ".bed", dtype=np.uint8)
+    nb = (len(fam) + 3) // 4
+    rows = raw[3:3 + ns * nb].reshape(ns, nb)
+    codes = np.stack([(rows >> (2 * k)) & 3 for k in range(4)], axis=2).reshape(ns, nb * 4)[:, :ni]
+    pad = np.full((ns, (ni + 3) // 4 * 4), 0, dtype=np.uint8)
+    pad[:, :ni] = codes
+    packed = (pad[:, 0::4] | (pad[:, 1::4] << 2) | (pad[:, 2::4] << 4) | (pad[:, 3::4] << 6)).astype(np.uint8)
+    pre = os.path.join(tmp, "P")
+    open(pre + ".bed", "wb").write(bytes([0x6C, 0x1B, 0x01]) + packed.tobytes())
+    open(pre + ".bim", "w").writelines(bim)
+    open(pre + ".fam", "w").writelines(fam[:ni])
+    rng = np.random.default_rng(240)
+    cov = np.column_stack([rng.standard_normal(ni), rng.integers(0, 2, ni).astype(float)])  # no intercept column
+    lines = [" ".join("%.10g" % v for v in r) for r in cov]
+    lines[5] = "NA 1"
+    open(os.path.join(tmp, "P.cov.txt"), "w").write("\n".join(lines) + "\n")
+    gemma(tmp, "-bfile", "P", "-gk", 1, "-o", "P")
+    cxx = os.path.join(tmp, "output", "P.cXX.txt")
+    gemma(tmp, "-bfile", "P", "-k", cxx, "-lmm", 4, "-o", "P4")
+    gemma(tmp, "-bfile", "P", "-k", cxx, "-lmm", 4, "-c", "P.cov.txt", "-o", "P4c")
+    gemma(tmp, "-bfile", "P", "-k", cxx, "-lmm", 1, "-miss", 0.02, "-maf", 0.05, "-o", "P1q")
+    for ext in (".bed", ".bim", ".fam", ".cov.txt"):
+        shutil.copy(pre + ext, os.path.join(OUT, "P" + ext))
+    head(cxx, os.path.join(OUT, "P.cXX.head.txt"), 8)
+    for tag in ("P4", "P4c", "P1q"):
+        with open(os.path.join(tmp, "output", tag + ".assoc.txt"), "rb") as f, \
+                gzip.GzipFile(os.path.join(OUT, tag + ".assoc.txt.gz"), "wb", mtime=0) as g:
+            g.write(f.read())
+        meta = {}
+        for line in open(os.path.join(tmp, "output", tag + ".log.txt")):
+            if "=" in line and line.startswith("##"):
+                k, v = line[2:].split("=", 1)
+                if k.strip().startswith(("number of", "pve", "se(pve)", "vg", "ve", "REMLE", "MLE")):
+                    meta[k.strip()] = v.strip()
+        json.dump(meta, open(os.path.join(OUT, tag + ".log.json"), "w"), indent=1, sort_keys=True)
 
 
 def main():
@@ -73,6 +119,11 @@ def main():
             if k.strip().startswith(("number of", "pve", "se(pve)", "vg", "ve", "REMLE", "MLE")):
                 meta[k.strip()] = v.strip()
     json.dump(meta, open(os.path.join(OUT, "L1.log.json"), "w"), indent=1, sort_keys=True)
+    plink_subset(tmp)
+    for f in ("BXD_geno.txt.gz",):
+        shutil.copy(E + f, os.path.join(OUT, f))
+    with open(E + "BXD_snps.txt", "rb") as f, gzip.GzipFile(os.path.join(OUT, "BXD_snps.txt.gz"), "wb", mtime=0) as g:
+        g.write(f.read())
     shutil.rmtree(tmp)
     print("wrote", sorted(os.listdir(OUT)))
 

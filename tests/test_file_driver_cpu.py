@@ -1,0 +1,44 @@
+"""The C++ host layer end to end on the CPU: tests/cpp/gemma_file_driver.cpp (readers, first pass, feeders, hand-off
+files, writers of include/gemma_io_host.hpp + include/gemma_host.hpp) linked against tests/cpp/abi_double.cpp -- the
+C ABI implemented over the oracle, a TEST DOUBLE built into a temporary directory -- and checked against
+the files the reference binary wrote for the same inputs (tests/golden/text/).  What this pins is the host side: which
+individuals and SNPs are selected, what is fed in which order and layout, and every byte of the output formats.  The
+device side of the same workflows is tests/test_gpu_workflow_files.py."""
+import os
+import subprocess
+
+import pytest
+
+import filecases as fc
+
+ROOT = fc.ROOT
+
+
+@pytest.fixture(scope="module")
+def driver(tmp_path_factory, oracle):
+    oracle.lib()  # builds oracle/libgemma_oracle.so
+    tmp = tmp_path_factory.mktemp("double")
+    subprocess.check_call(["g++", "-std=c++11", "-O2", "-Wall", "-shared", "-fPIC", "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "cpp", "abi_double.cpp"), "-L" + os.path.join(ROOT, "oracle"),
+                           "-lgemma_oracle", "-Wl,-rpath," + os.path.join(ROOT, "oracle"),
+                           "-o", str(tmp / "libgemma_hip.so")])
+    return fc.build_driver(tmp, str(tmp))
+
+
+def test_bxd_bimbam_files_to_reference_outputs(driver, tmp_path):
+    fc.bxd_bimbam_workflow(driver, tmp_path)
+
+
+def test_plink_files_to_reference_outputs(driver, tmp_path):
+    fc.plink_workflow(driver, tmp_path)
+
+
+def test_driver_reports_reader_errors(driver, tmp_path):
+    """Where the reference's readers return false the driver stops (exit code 3) instead of analysing garbage."""
+    bad = tmp_path / "short.txt"
+    bad.write_text("rs1, A, G, 0, 1\n")
+    r = subprocess.run([driver, "-g", str(bad), "-p", os.path.join(fc.TXT, "BXD_pheno.txt"), "-gk", "-outdir", str(tmp_path)],
+                       capture_output=True, text=True)
+    assert r.returncode == 3 and "not enough genotypes" in r.stdout
+    r = subprocess.run([driver, "-bfile", str(tmp_path / "nothing"), "-gk", "-outdir", str(tmp_path)], capture_output=True, text=True)
+    assert r.returncode == 3 and "error opening .bim file" in r.stdout

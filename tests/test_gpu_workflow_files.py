@@ -1,0 +1,26 @@
+"""File in, file out on the MI355X: gemma's own command lines (-g/-p/-c/-a or -bfile; -gk; -k ... -lmm; -eigen; -d/-u)
+through tests/cpp/gemma_file_driver.cpp over the HIP library -- first-pass QC, kinship, the 10-digit hand-off, centring,
+eigendecomposition, null model and the per-SNP loop all on the device, text parsed by the host thread pool -- against the
+files the reference binary wrote for the same inputs (tests/golden/text/).  CPU twin: tests/test_file_driver_cpu.py."""
+import os
+
+import pytest
+
+import filecases as fc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def driver(tmp_path_factory):
+    from gemma_amd import build
+    build.build()
+    return fc.build_driver(tmp_path_factory.mktemp("drv"), os.path.join(fc.ROOT, "gemma_amd"))
+
+
+def test_bxd_bimbam_files_to_reference_outputs(driver, tmp_path):
+    fc.bxd_bimbam_workflow(driver, tmp_path)
+
+
+def test_plink_files_to_reference_outputs(driver, tmp_path):
+    fc.plink_workflow(driver, tmp_path)
