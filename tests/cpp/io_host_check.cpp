@@ -12,6 +12,7 @@
 //   eigen <U-in> <D-in> <n> <outdir> <name>     ReadFile_eigenU/D -> WriteEigen
 //   assoc <assoc-in> <a_mode> <outdir> <name>   parse a reference .assoc.txt, LMM::WriteFiles it again
 //   kin <cXX-in> <n> <out>                      ReadFile_kin (all individuals) -> WriteMatrix
+//   genogen <file> <ni_total> <n_snps>          synthetic BIMBAM file ("0.123"-style dosages, hard calls, 1 % NA)
 //   genobench <file> <ni_total> <threads>       wall time of BimbamReader over the whole file (threads = 0: the
 //                                               reference's own way, one thread of strtok + atof, for comparison)
 #include <chrono>
@@ -136,6 +137,30 @@ int main(int argc, char **argv) {
       if (l == 0) break;
       fwrite(X.data(), 8, l * ld, out);
       for (size_t i = 0; i < l; ++i) printf("%s %s %s\n", rows[i].rs.c_str(), rows[i].minor.c_str(), rows[i].major.c_str());
+    }
+    fclose(out);
+    return 0;
+  }
+  if (cmd == "genogen") {
+    const size_t ni_total = strtoul(argv[3], nullptr, 10), ns = strtoul(argv[4], nullptr, 10);
+    FILE *out = fopen(argv[2], "wb");
+    std::vector<char> line;
+    unsigned long long st = 88172645463325252ull;
+    for (size_t s = 0; s < ns; ++s) {
+      line.clear();
+      char tmp[32];
+      int k = snprintf(tmp, sizeof tmp, "rs%zu, A, G", s);
+      line.insert(line.end(), tmp, tmp + k);
+      for (size_t i = 0; i < ni_total; ++i) {
+        st ^= st << 13; st ^= st >> 7; st ^= st << 17; // xorshift64
+        const unsigned r = (unsigned)(st >> 33) % 3000u;
+        if (r < 30) k = snprintf(tmp, sizeof tmp, ", NA");
+        else if (r < 1000) k = snprintf(tmp, sizeof tmp, ", %u", r % 3);
+        else k = snprintf(tmp, sizeof tmp, ", %u.%03u", (r - 1000) / 1000, (r - 1000) % 1000);
+        line.insert(line.end(), tmp, tmp + k);
+      }
+      line.push_back('\n');
+      fwrite(line.data(), 1, line.size(), out);
     }
     fclose(out);
     return 0;
