@@ -14,16 +14,20 @@
 
 #include <algorithm>
 #include <cmath>
+#include <condition_variable>
 #include <cstdio>
 #include <cstring>
+#include <exception>
 #include <fstream>
 #include <functional>
 #include <iomanip>
 #include <iostream>
 #include <limits>
+#include <mutex>
 #include <sstream>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "gemma_hip.h"
@@ -104,6 +108,123 @@ inline double EigenDecomp_Zeroed(Matrix *G, Matrix *U, Vector *eval, const size_
 // CalcUtX(U, X, UtX), src/mathfunc.cpp:504-506
 inline void CalcUtX(const Matrix *U, const Matrix *X, Matrix *UtX) { fast_dgemm("T", "N", 1.0, U, X, 0.0, UtX); }
 
+// ---------------------------------------------------------------------------------------------------------------
+// two-slot producer / consumer: a host thread fills block k+1 (file read, text parsing) while the calling thread has
+// block k on the device.  The C ABI is entered from the calling thread only (gemma_hip.h: one calling host thread).
+// ---------------------------------------------------------------------------------------------------------------
+class BlockPrefetch {
+public:
+  // fill(slot memory, slot index 0/1) -> rows written; 0 = end of input; (size_t)-1 = malformed input
+  typedef std::function<size_t(void *, int)> Fill;
+  BlockPrefetch(size_t slot_bytes, Fill fill) : fill_(fill), held_(-1), turn_(0), done_(false), stop_(false) {
+    for (int k = 0; k < 2; ++k) {
+      buf_[k].resize(slot_bytes);
+      full_[k] = false;
+      rows_[k] = 0;
+    }
+    th_ = std::thread([this] { produce(); });
+  }
+  ~BlockPrefetch() {
+    {
+      std::lock_guard<std::mutex> g(m_);
+      stop_ = true;
+      full_[0] = full_[1] = false;
+    }
+    cv_.notify_all();
+    th_.join();
+  }
+  BlockPrefetch(const BlockPrefetch &) = delete;
+  BlockPrefetch &operator=(const BlockPrefetch &) = delete;
+  // hands back the previous block, waits for the next one; 0 at the end, (size_t)-1 on malformed input.
+  // *index (optional) = which of the two slots holds the block (for per-slot side data of the producer)
+  size_t next(void *&slot, int *index = nullptr) {
+    std::unique_lock<std::mutex> g(m_);
+    if (held_ >= 0) {
+      full_[held_] = false;
+      held_ = -1;
+      cv_.notify_all();
+    }
+    if (done_) return 0;
+    const int k = turn_;
+    cv_.wait(g, [&] { return full_[k]; });
+    if (err_) std::rethrow_exception(err_);
+    const size_t n = rows_[k];
+    if (n == 0 || n == (size_t)-1) {
+      done_ = true;
+      return n;
+    }
+    held_ = k;
+    turn_ ^= 1;
+    slot = buf_[k].data();
+    if (index) *index = k;
+    return n;
+  }
+
+private:
+  void produce() {
+    for (int k = 0;; k ^= 1) {
+      {
+        std::unique_lock<std::mutex> g(m_);
+        cv_.wait(g, [&] { return !full_[k] || stop_; });
+        if (stop_) return;
+      }
+      size_t n = 0;
+      std::exception_ptr err;
+      try {
+        n = fill_(buf_[k].data(), k);
+      } catch (...) {
+        err = std::current_exception();
+      }
+      {
+        std::lock_guard<std::mutex> g(m_);
+        rows_[k] = n;
+        full_[k] = true;
+        if (err) err_ = err;
+      }
+      cv_.notify_all();
+      if (err || n == 0 || n == (size_t)-1) return;
+    }
+  }
+  Fill fill_;
+  std::vector<unsigned char> buf_[2];
+  bool full_[2];
+  size_t rows_[2];
+  int held_, turn_;
+  bool done_, stop_;
+  std::exception_ptr err_;
+  std::mutex m_;
+  std::condition_variable cv_;
+  std::thread th_;
+};
+
+// rows per block of the text / .bed feeders; GEMMA_HIP_IO_BLOCK overrides (the tests use it to force many blocks)
+inline size_t io_block_rows(size_t dflt) {
+  const char *env = getenv("GEMMA_HIP_IO_BLOCK");
+  return env && atol(env) > 0 ? (size_t)atol(env) : dflt;
+}
+
+// up to max_rows rows of the SNPs t >= t_next with indicator_snp[t] != 0 from a .bed stream into dst (n_bit bytes per
+// row); consecutive kept SNPs are fetched with one read, the stream is only repositioned across dropped ones
+inline size_t read_bed_rows(std::ifstream &infile, const std::vector<int> &indicator_snp, size_t &t_next, size_t n_bit,
+                            unsigned char *dst, size_t max_rows) {
+  size_t l = 0;
+  const size_t ns = indicator_snp.size();
+  while (l < max_rows && t_next < ns) {
+    if (indicator_snp[t_next] == 0) {
+      ++t_next;
+      continue;
+    }
+    size_t run = 1;
+    while (l + run < max_rows && t_next + run < ns && indicator_snp[t_next + run] != 0) ++run;
+    infile.seekg((std::streamoff)(t_next * n_bit + 3)); // 3 magic bytes, skipped unchecked like the reference
+    infile.read(reinterpret_cast<char *>(dst + l * n_bit), (std::streamsize)(run * n_bit));
+    if ((size_t)infile.gcount() != run * n_bit) return (size_t)-1;
+    l += run;
+    t_next += run;
+  }
+  return l;
+}
+
 // PlinkKin, src/gemma_io.cpp:1599-1738: the device decodes, imputes, centres/scales and accumulates
 inline bool PlinkKin(const std::string &file_bed, std::vector<int> &indicator_snp, const int k_mode,
                      const int /*display_pace*/, Matrix *matrix_kin) {
@@ -116,18 +237,21 @@ inline bool PlinkKin(const std::string &file_bed, std::vector<int> &indicator_sn
   const size_t n_bit = (ni_total + 3) / 4;
   if (matrix_kin->tda != matrix_kin->size2) return false;
   enforce_hip(gemma_hip_kin_begin(ni_total, k_mode), "PlinkKin");
-  std::vector<unsigned char> block(K_BATCH_SIZE * n_bit);
-  size_t l = 0;
-  for (size_t t = 0; t < indicator_snp.size(); ++t) {
-    if (indicator_snp[t] == 0) continue;
-    infile.seekg((std::streamoff)(t * n_bit + 3)); // 3 magic bytes, skipped unchecked like the reference
-    infile.read(reinterpret_cast<char *>(&block[l * n_bit]), (std::streamsize)n_bit);
-    if (++l == K_BATCH_SIZE) {
-      enforce_hip(gemma_hip_kin_add(GEMMA_GENO_PLINK_2BIT, block.data(), l, n_bit), "PlinkKin");
-      l = 0;
+  const size_t B = io_block_rows(K_BATCH_SIZE);
+  size_t t_next = 0;
+  BlockPrefetch pf(B * n_bit, [&](void *slot, int) {
+    return read_bed_rows(infile, indicator_snp, t_next, n_bit, static_cast<unsigned char *>(slot), B);
+  });
+  for (;;) {
+    void *slot = nullptr;
+    const size_t l = pf.next(slot);
+    if (l == (size_t)-1) {
+      std::cout << "error reading bed file:" << file_bed << " (truncated)" << std::endl;
+      return false;
     }
+    if (l == 0) break;
+    enforce_hip(gemma_hip_kin_add(GEMMA_GENO_PLINK_2BIT, slot, l, n_bit), "PlinkKin");
   }
-  if (l) enforce_hip(gemma_hip_kin_add(GEMMA_GENO_PLINK_2BIT, block.data(), l, n_bit), "PlinkKin");
   size_t ns = 0;
   enforce_hip(gemma_hip_kin_end(matrix_kin->data, &ns), "PlinkKin");
   return true;
@@ -283,19 +407,20 @@ public:
     setup(U, eval, UtW, Uty, 1);
     enforce_hip(gemma_hip_lmm_set_indicator(indicator_idv.data(), indicator_idv.size()), "AnalyzePlink");
     const size_t n_bit = (ni_total + 3) / 4;
-    std::vector<unsigned char> block(LMM_BATCH_SIZE * n_bit);
-    std::vector<gemma_sumstat> out(LMM_BATCH_SIZE);
-    size_t l = 0;
-    for (size_t t = 0; t < indicator_snp.size(); ++t) {
-      if (indicator_snp[t] == 0) continue;
-      infile.seekg((std::streamoff)(t * n_bit + 3));
-      infile.read(reinterpret_cast<char *>(&block[l * n_bit]), (std::streamsize)n_bit);
-      if (++l == LMM_BATCH_SIZE) {
-        batch_compute(GEMMA_GENO_PLINK_2BIT, block.data(), l, n_bit, out);
-        l = 0;
-      }
+    const size_t B = io_block_rows(LMM_BATCH_SIZE);
+    std::vector<gemma_sumstat> out(B);
+    size_t t_next = 0;
+    // the .bed rows of block k+1 are read by a host thread while block k is on the device
+    BlockPrefetch pf(B * n_bit, [&](void *slot, int) {
+      return read_bed_rows(infile, indicator_snp, t_next, n_bit, static_cast<unsigned char *>(slot), B);
+    });
+    for (;;) {
+      void *slot = nullptr;
+      const size_t l = pf.next(slot);
+      if (l == (size_t)-1) throw std::runtime_error("error reading genotype (.bed) file (truncated)");
+      if (l == 0) break;
+      batch_compute(GEMMA_GENO_PLINK_2BIT, slot, l, n_bit, out);
     }
-    batch_compute(GEMMA_GENO_PLINK_2BIT, block.data(), l, n_bit, out);
     finish();
   }
 
@@ -312,18 +437,20 @@ public:
     finish();
   }
 
-  // LMM::Analyze with a pull-style block source (what fetch_snp, src/lmm.cpp:1675-1700, is to the reference): feed()
-  // refills X (ld doubles per row, rows = analysed SNPs over the ni_test analysed individuals, NaN = missing) with at
-  // most max_rows rows and returns how many it wrote, 0 at the end.  include/gemma_io_host.hpp feeds it from a
-  // BIMBAM text file parsed on a pool of host threads.
-  typedef std::function<size_t(double *X, size_t max_rows)> RowFeeder;
-  void AnalyzeFeed(const Matrix *U, const Vector *eval, const Matrix *UtW, const Vector *Uty, RowFeeder &feed, double *X,
+  // LMM::Analyze with a pull-style block source (what fetch_snp, src/lmm.cpp:1675-1700, is to the reference): feed(X)
+  // points X at the next block (ld doubles per row, rows = analysed SNPs over the ni_test analysed individuals,
+  // NaN = missing, at most max_rows rows, valid until the next call) and returns its row count, 0 at the end.
+  // include/gemma_io_host.hpp feeds it from a BIMBAM text file parsed on a pool of host threads, one block ahead.
+  typedef std::function<size_t(const double *&X)> RowFeeder;
+  void AnalyzeFeed(const Matrix *U, const Vector *eval, const Matrix *UtW, const Vector *Uty, RowFeeder &feed,
                    size_t max_rows, size_t ld) {
     setup(U, eval, UtW, Uty, 0);
-    std::vector<gemma_sumstat> out(std::min(max_rows, LMM_BATCH_SIZE));
+    std::vector<gemma_sumstat> out(max_rows);
     for (;;) {
-      const size_t l = feed(X, out.size());
+      const double *X = nullptr;
+      const size_t l = feed(X);
       if (l == 0) break;
+      if (l > max_rows) throw HipError(GEMMA_HIP_EINVAL, "AnalyzeFeed: block larger than max_rows");
       batch_compute(GEMMA_GENO_F64_SNP_MAJOR, X, l, ld, out);
     }
     finish();

@@ -604,6 +604,11 @@ private:
   std::vector<std::pair<size_t, size_t>> spans_;
 };
 
+// rows per block of the text feeders: at most `cap` rows and about 256 MiB of doubles (two such slots are in flight)
+inline size_t bimbam_block_rows(size_t row_len, size_t cap) {
+  return io_block_rows(std::max<size_t>(64, std::min<size_t>(cap, (size_t(256) << 20) / (8 * std::max<size_t>(row_len, 1)))));
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // first pass: which SNPs are analysed
 // ---------------------------------------------------------------------------------------------------------------
@@ -629,21 +634,24 @@ inline bool ReadFile_bed(const std::string &file_bed, const std::set<std::string
   for (int v : indicator_idv) ni_test += v;
   ns_test = 0;
   const gemma_qc_cfg cfg = {maf_level, miss_level, hwe_level, r2_level};
-  const size_t B = std::min<size_t>(std::max<size_t>(ns_total, 1), K_BATCH_SIZE);
-  std::vector<unsigned char> block(B * n_bit);
+  const size_t B = io_block_rows(std::min<size_t>(std::max<size_t>(ns_total, 1), K_BATCH_SIZE));
   std::vector<int> ind(B);
   std::vector<double> maf(B);
   std::vector<size_t> n_miss(B);
-  infile.seekg(3); // the three magic bytes, unchecked like the reference
-  for (size_t t0 = 0; t0 < ns_total; t0 += B) {
-    const size_t l = std::min(B, ns_total - t0);
-    infile.read(reinterpret_cast<char *>(block.data()), (std::streamsize)(l * n_bit));
-    if ((size_t)infile.gcount() != l * n_bit) {
+  const std::vector<int> all(ns_total, 1); // the first pass looks at every SNP of the file
+  size_t t_next = 0;
+  BlockPrefetch pf(B * n_bit, [&](void *slot, int) {
+    return read_bed_rows(infile, all, t_next, n_bit, static_cast<unsigned char *>(slot), B);
+  });
+  for (size_t t0 = 0; t0 < ns_total;) {
+    void *slot = nullptr;
+    const size_t l = pf.next(slot);
+    if (l == 0 || l == (size_t)-1) {
       std::cout << "error reading bed file:" << file_bed << " (truncated)" << std::endl;
       return false;
     }
-    enforce_hip(gemma_hip_snp_qc(GEMMA_GENO_PLINK_2BIT, block.data(), l, n_bit, indicator_idv.data(), ni_total,
-                                 W->data, W->size1, W->size2, &cfg, ind.data(), maf.data(), n_miss.data()),
+    enforce_hip(gemma_hip_snp_qc(GEMMA_GENO_PLINK_2BIT, slot, l, n_bit, indicator_idv.data(), ni_total, W->data, W->size1,
+                                 W->size2, &cfg, ind.data(), maf.data(), n_miss.data()),
                 "ReadFile_bed");
     for (size_t i = 0; i < l; ++i) {
       SNPINFO &s = snpInfo[t0 + i];
@@ -663,6 +671,7 @@ inline bool ReadFile_bed(const std::string &file_bed, const std::set<std::string
       indicator_snp.push_back(ind[i]);
       ns_test += ind[i] != 0;
     }
+    t0 += l;
   }
   return true;
 }
@@ -686,19 +695,25 @@ inline bool ReadFile_geno(const std::string &file_geno, const std::set<std::stri
   for (int v : indicator_idv) ni_test += v;
   ns_test = 0;
   const gemma_qc_cfg cfg = {maf_level, miss_level, hwe_level, r2_level};
-  const size_t B = std::max<size_t>(64, std::min<size_t>(8192, (size_t(256) << 20) / (8 * std::max<size_t>(ni_total, 1))));
-  std::vector<double> X(B * ni_total);
-  std::vector<BimbamReader::Row> rows;
+  const size_t B = bimbam_block_rows(ni_total, 8192);
+  std::vector<BimbamReader::Row> names[2];
   std::vector<int> ind(B);
   std::vector<double> maf(B);
   std::vector<size_t> n_miss(B);
   size_t file_pos = 0;
+  // block k+1 is read and parsed while the device filters block k
+  BlockPrefetch pf(B * ni_total * sizeof(double), [&](void *slot, int k) {
+    return rd.read_block(B, static_cast<double *>(slot), ni_total, &names[k]);
+  });
   for (;;) {
-    const size_t l = rd.read_block(B, X.data(), ni_total, &rows);
+    void *slot = nullptr;
+    int k = 0;
+    const size_t l = pf.next(slot, &k);
     if (l == (size_t)-1) return false;
     if (l == 0) break;
-    enforce_hip(gemma_hip_snp_qc(GEMMA_GENO_F64_SNP_MAJOR, X.data(), l, ni_total, indicator_idv.data(), ni_total,
-                                 W->data, W->size1, W->size2, &cfg, ind.data(), maf.data(), n_miss.data()),
+    const std::vector<BimbamReader::Row> &rows = names[k];
+    enforce_hip(gemma_hip_snp_qc(GEMMA_GENO_F64_SNP_MAJOR, slot, l, ni_total, indicator_idv.data(), ni_total, W->data,
+                                 W->size1, W->size2, &cfg, ind.data(), maf.data(), n_miss.data()),
                 "ReadFile_geno");
     for (size_t i = 0; i < l; ++i, ++file_pos) {
       const BimbamReader::Row &r = rows[i];
@@ -746,14 +761,17 @@ inline bool BimbamKinThreaded(const std::string &file_geno, const std::vector<in
   }
   if (matrix_kin->tda != matrix_kin->size2) return false;
   enforce_hip(gemma_hip_kin_begin(ni_total, k_mode), "BimbamKin");
-  const size_t B = std::max<size_t>(64, std::min<size_t>(8192, (size_t(256) << 20) / (8 * std::max<size_t>(ni_total, 1))));
-  std::vector<double> X(B * ni_total);
+  const size_t B = bimbam_block_rows(ni_total, 8192);
+  BlockPrefetch pf(B * ni_total * sizeof(double), [&](void *slot, int) -> size_t {
+    if (rd.lines_read() >= indicator_snp.size()) return 0;
+    return rd.read_block(B, static_cast<double *>(slot), ni_total, nullptr, &indicator_snp);
+  });
   for (;;) {
-    if (rd.lines_read() >= indicator_snp.size()) break;
-    const size_t l = rd.read_block(B, X.data(), ni_total, nullptr, &indicator_snp);
+    void *slot = nullptr;
+    const size_t l = pf.next(slot);
     if (l == (size_t)-1) return false;
     if (l == 0) break;
-    enforce_hip(gemma_hip_kin_add(GEMMA_GENO_F64_SNP_MAJOR, X.data(), l, ni_total), "BimbamKin");
+    enforce_hip(gemma_hip_kin_add(GEMMA_GENO_F64_SNP_MAJOR, slot, l, ni_total), "BimbamKin");
   }
   size_t ns = 0;
   enforce_hip(gemma_hip_kin_end(matrix_kin->data, &ns), "BimbamKin");
@@ -761,21 +779,24 @@ inline bool BimbamKinThreaded(const std::string &file_geno, const std::vector<in
 }
 
 // LMM::AnalyzeBimbam, src/lmm.cpp:1660-1706: rows of the analysed SNPs over the analysed individuals, NaN = missing,
-// in blocks of LMM_BATCH_SIZE rows at most (smaller when a block would exceed 1 GiB of host memory)
+// in blocks of LMM_BATCH_SIZE rows at most (about 256 MiB of doubles per block), parsed one block ahead of the device
 inline void AnalyzeBimbam(LMM &lmm, const Matrix *U, const Vector *eval, const Matrix *UtW, const Vector *Uty) {
   const size_t ni_total = lmm.indicator_idv.size(), n = U->size1;
   BimbamReader rd(lmm.file_geno, ni_total);
   if (!rd.ok()) throw std::runtime_error("error reading genotype file");
-  const size_t B = std::max<size_t>(64, std::min<size_t>(LMM_BATCH_SIZE, (size_t(1) << 30) / (8 * std::max<size_t>(n, 1))));
-  std::vector<double> X(B * n);
-  LMM::RowFeeder feed = [&](double *dst, size_t max_rows) -> size_t {
+  const size_t B = bimbam_block_rows(n, LMM_BATCH_SIZE);
+  BlockPrefetch pf(B * n * sizeof(double), [&](void *slot, int) -> size_t {
     if (rd.lines_read() >= lmm.indicator_snp.size()) return 0;
-    const size_t l = rd.read_block(std::min(max_rows, B), dst, n, nullptr, &lmm.indicator_snp,
-                                   lmm.indicator_idv.data());
+    return rd.read_block(B, static_cast<double *>(slot), n, nullptr, &lmm.indicator_snp, lmm.indicator_idv.data());
+  });
+  LMM::RowFeeder feed = [&](const double *&X) -> size_t {
+    void *slot = nullptr;
+    const size_t l = pf.next(slot);
     if (l == (size_t)-1) throw std::runtime_error("Problem reading geno file (not enough genotypes in line)");
+    X = static_cast<const double *>(slot);
     return l;
   };
-  lmm.AnalyzeFeed(U, eval, UtW, Uty, feed, X.data(), B, n);
+  lmm.AnalyzeFeed(U, eval, UtW, Uty, feed, B, n);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

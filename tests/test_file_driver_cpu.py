@@ -25,11 +25,19 @@ def driver(tmp_path_factory, oracle):
     return fc.build_driver(tmp, str(tmp))
 
 
-def test_bxd_bimbam_files_to_reference_outputs(driver, tmp_path):
+@pytest.mark.parametrize("block", [None, "97"])
+def test_bxd_bimbam_files_to_reference_outputs(driver, tmp_path, monkeypatch, block):
+    """block = 97: every feeder (first pass, kinship, association) runs many blocks through the two-slot prefetcher"""
+    if block:
+        monkeypatch.setenv("GEMMA_HIP_IO_BLOCK", block)
+        monkeypatch.setenv("GEMMA_HIP_IO_THREADS", "3")
     fc.bxd_bimbam_workflow(driver, tmp_path)
 
 
-def test_plink_files_to_reference_outputs(driver, tmp_path):
+@pytest.mark.parametrize("block", [None, "61"])
+def test_plink_files_to_reference_outputs(driver, tmp_path, monkeypatch, block):
+    if block:
+        monkeypatch.setenv("GEMMA_HIP_IO_BLOCK", block)
     fc.plink_workflow(driver, tmp_path)
 
 
