@@ -4,11 +4,14 @@
 //   gemma_file_driver (-g geno[.gz] -p pheno [-a anno] | -bfile prefix) [-c cvt] [-n col]
 //                     (-gk [1|2] | -k kin (-eigen | -lmm [1|2|3|4|9]) | -d eigenD -u eigenU -lmm m)
 //                     [-maf x] [-miss x] [-hwe x] [-r2 x] [-o name] [-outdir dir]
+//   gemma_file_driver -bfile prefix -inproc [1|2] -lmm m ...   kinship, eigendecomposition and association in ONE
+//                     process: K never becomes text; wall seconds of every stage on the log line
 //
 // following PARAM::ReadFiles (src/param.cpp:115-300) and BatchRun (src/gemma.cpp:1900-1926 `-gk`, :1779-1800 `-eigen`,
 // :2557-2830 `-lmm`): first pass over the genotypes (device QC) -> kinship over all individuals -> <o>.cXX.txt / .sXX.txt;
 // or kinship file -> rows of the analysed individuals -> centre -> eigendecomposition (-> <o>.eigenU/D.txt) -> U^T W,
 // U^T y -> null model -> per-SNP association -> <o>.assoc.txt.  One line of key=value pairs on stdout is the log.
+#include <chrono>
 #include <cstdlib>
 #include <iostream>
 #include <string>
@@ -22,8 +25,10 @@ int main(int argc, char **argv) {
   std::string file_geno, file_pheno, file_anno, file_bfile, file_cvt, file_kin, file_kd, file_ku, file_out = "result",
                                                                                                   path_out = "./output";
   size_t p_column = 1;
-  int k_mode = 0, a_mode = 0;
+  int k_mode = 0, a_mode = 0, inproc = 0;
   bool do_eigen = false;
+  const auto t_start = std::chrono::steady_clock::now();
+  auto lap = [&]() { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count(); };
   QcLevels qc;
   for (int i = 1; i < argc; ++i) {
     const std::string a = argv[i];
@@ -40,6 +45,7 @@ int main(int argc, char **argv) {
     else if (a == "-o" && has) file_out = argv[++i];
     else if (a == "-outdir" && has) path_out = argv[++i];
     else if (a == "-gk") k_mode = has ? atoi(argv[++i]) : 1;
+    else if (a == "-inproc") inproc = has ? atoi(argv[++i]) : 1;
     else if (a == "-lmm") a_mode = has ? atoi(argv[++i]) : 1;
     else if (a == "-eigen") do_eigen = true;
     else if (a == "-maf" && has) qc.maf_level = atof(argv[++i]);
@@ -95,6 +101,7 @@ int main(int argc, char **argv) {
     }
     std::cout << "ni_total=" << ni_total << " ni_test=" << ni_test << " n_cvt=" << n_cvt
               << " ns_total=" << indicator_snp.size() << " ns_test=" << ns_test;
+    if (inproc) std::cout << " t_first_pass=" << lap();
 
     // ---- -gk (src/gemma.cpp:1900-1926) ----------------------------------------------------------------------------
     if (k_mode) {
@@ -115,7 +122,25 @@ int main(int argc, char **argv) {
     Vector eval = vector_view(evalb.data(), ni_test);
     double trace_G = 0.0;
     bool error = false;
-    if (!file_kin.empty()) {
+    if (inproc) { // -gk and -lmm in one process: K stays binary (changes K at the 1e-10 level)
+      std::vector<double> Kb(ni_total * ni_total, 0.0), Gb(ni_test * ni_test);
+      Matrix K = matrix_view(Kb.data(), ni_total, ni_total), G = matrix_view(Gb.data(), ni_test, ni_test);
+      const bool ok = file_bfile.empty() ? BimbamKinThreaded(file_geno, indicator_snp, inproc, &K)
+                                         : PlinkKin(file_bfile + ".bed", indicator_snp, inproc, 0, &K);
+      if (!ok) return 4;
+      std::cout << " t_kinship=" << lap();
+      size_t r = 0;
+      for (size_t i = 0; i < ni_total; ++i) { // the sub-selection ReadFile_kin does (src/gemma_io.cpp:1205-1243)
+        if (!cp.indicator_idv[i]) continue;
+        size_t c = 0;
+        for (size_t j = 0; j < ni_total; ++j)
+          if (cp.indicator_idv[j]) Gb[r * ni_test + c++] = Kb[i * ni_total + j];
+        ++r;
+      }
+      CenterMatrix(&G);
+      trace_G = EigenDecomp_Zeroed(&G, &U, &eval, 0);
+      std::cout << " t_eigen=" << lap();
+    } else if (!file_kin.empty()) {
       std::vector<double> Gb(ni_test * ni_test);
       Matrix G = matrix_view(Gb.data(), ni_test, ni_test);
       ReadFile_kin(file_kin, cp.indicator_idv, error, &G);
@@ -132,7 +157,7 @@ int main(int argc, char **argv) {
       }
       trace_G /= (double)ni_test;
     } else {
-      std::cerr << "need -gk, -k or -d/-u" << std::endl;
+      std::cerr << "need -gk, -inproc, -k or -d/-u" << std::endl;
       return 2;
     }
     std::cout << " trace_G=" << std::setprecision(12) << trace_G;
@@ -170,9 +195,15 @@ int main(int argc, char **argv) {
     cLmm.snpInfo = snpInfo;
     cLmm.l_mle_null = nm.l_mle_null;
     cLmm.logl_mle_H0 = nm.logl_mle_H0;
+    const double t_a0 = lap();
     if (!file_bfile.empty()) cLmm.AnalyzePlink(&U, &eval, &UtW, &Uty);
     else AnalyzeBimbam(cLmm, &U, &eval, &UtW, &Uty);
+    const double t_a1 = lap();
     cLmm.WriteFiles();
+    if (inproc)
+      std::cout << " t_null=" << t_a0 << " t_assoc=" << t_a1 << " t_written=" << lap() << " assoc_seconds=" << t_a1 - t_a0
+                << " assoc_snps_per_s=" << (double)cLmm.sumStat.size() / (t_a1 - t_a0)
+                << " gpu_min_UtX=" << cLmm.time_UtX << " gpu_min_opt=" << cLmm.time_opt;
     std::cout << " snps=" << cLmm.sumStat.size() << std::endl;
     gemma_hip_shutdown();
   } catch (const std::exception &e) {

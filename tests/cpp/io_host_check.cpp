@@ -12,6 +12,8 @@
 //   eigen <U-in> <D-in> <n> <outdir> <name>     ReadFile_eigenU/D -> WriteEigen
 //   assoc <assoc-in> <a_mode> <outdir> <name>   parse a reference .assoc.txt, LMM::WriteFiles it again
 //   kin <cXX-in> <n> <out>                      ReadFile_kin (all individuals) -> WriteMatrix
+//   plinkgen <prefix> <ni> <ns> [threads]      synthetic PLINK set: two sub-populations, maf ~ U(0.1, 0.45) +- 0.075, 1 % missing calls,
+//                                               y = 0.3 * (first 20 SNPs) + 0.8 * population + N(0,1), 2 % of the phenotypes -9
 //   genogen <file> <ni_total> <n_snps>          synthetic BIMBAM file ("0.123"-style dosages, hard calls, 1 % NA)
 //   genobench <file> <ni_total> <threads>       wall time of BimbamReader over the whole file (threads = 0: the
 //                                               reference's own way, one thread of strtok + atof, for comparison)
@@ -21,6 +23,7 @@
 #include <fstream>
 #include <iostream>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "gemma_io_host.hpp"
@@ -139,6 +142,63 @@ int main(int argc, char **argv) {
       for (size_t i = 0; i < l; ++i) printf("%s %s %s\n", rows[i].rs.c_str(), rows[i].minor.c_str(), rows[i].major.c_str());
     }
     fclose(out);
+    return 0;
+  }
+  if (cmd == "plinkgen") {
+    const std::string prefix = argv[2];
+    const size_t ni = strtoul(argv[3], nullptr, 10), ns = strtoul(argv[4], nullptr, 10), nb = (ni + 3) / 4;
+    const unsigned nt = argc > 5 ? (unsigned)atoi(argv[5]) : 8u;
+    std::vector<unsigned char> bed(ns * nb, 0);
+    auto rnd = [](unsigned long long &st) { st ^= st << 13; st ^= st >> 7; st ^= st << 17; return st; };
+    auto gen = [&](size_t s0, size_t s1) {
+      for (size_t s = s0; s < s1; ++s) {
+        unsigned long long st = 0x9E3779B97F4A7C15ull * (s + 1) + 12345;
+        for (int k = 0; k < 4; ++k) rnd(st);
+        // two sub-populations (first / second half of the individuals) whose allele frequencies differ by up to 0.15
+        const double maf = 0.1 + 0.35 * (double)(rnd(st) >> 11) / 9007199254740992.0;
+        const double dlt = 0.15 * ((double)(rnd(st) >> 11) / 9007199254740992.0 - 0.5);
+        const unsigned long long thr2[2] = {(unsigned long long)((maf + dlt) * 4294967296.0),
+                                            (unsigned long long)((maf - dlt) * 4294967296.0)};
+        unsigned char *row = &bed[s * nb];
+        for (size_t i = 0; i < ni; ++i) {
+          const unsigned long long thr = thr2[i >= ni / 2];
+          const unsigned long long r = rnd(st);
+          unsigned code;
+          if ((r >> 54) < 10) code = 1; // ~1 % missing (bits 01)
+          else {
+            const unsigned g = ((r & 0xffffffffull) < thr) + (((r >> 20) & 0xffffffffull) < thr); // minor-allele count
+            code = g == 2 ? 0u : g == 1 ? 2u : 3u; // 00 -> 2, 10 -> 1, 11 -> 0 (src/lmm.cpp:1797-1812)
+          }
+          row[i >> 2] |= (unsigned char)(code << (2 * (i & 3)));
+        }
+      }
+    };
+    std::vector<std::thread> pool;
+    for (unsigned w = 0; w < nt; ++w) pool.emplace_back(gen, ns * w / nt, ns * (w + 1) / nt);
+    for (std::thread &t : pool) t.join();
+    FILE *f = fopen((prefix + ".bed").c_str(), "wb");
+    const unsigned char magic[3] = {0x6C, 0x1B, 0x01};
+    fwrite(magic, 1, 3, f);
+    fwrite(bed.data(), 1, bed.size(), f);
+    fclose(f);
+    f = fopen((prefix + ".bim").c_str(), "w");
+    for (size_t s = 0; s < ns; ++s) fprintf(f, "%zu\trs%zu\t0\t%zu\tA\tG\n", 1 + s * 20 / ns, s, s + 1);
+    fclose(f);
+    unsigned long long st = 424242;
+    f = fopen((prefix + ".fam").c_str(), "w");
+    for (size_t i = 0; i < ni; ++i) {
+      double y = 0;
+      for (int k = 0; k < 12; ++k) y += (double)(rnd(st) >> 11) / 9007199254740992.0; // Irwin-Hall ~ N(6, 1)
+      y -= 6.0;
+      if (i >= ni / 2) y += 0.8; // population effect: the kinship's structure carries phenotypic variance
+      for (size_t s = 0; s < 20 && s < ns; ++s) {
+        const unsigned code = (bed[s * nb + (i >> 2)] >> (2 * (i & 3))) & 3u;
+        y += 0.3 * (code == 0 ? 2.0 : code == 2 ? 1.0 : 0.0);
+      }
+      if (rnd(st) % 50 == 0) fprintf(f, "f%zu i%zu 0 0 1 -9\n", i, i);
+      else fprintf(f, "f%zu i%zu 0 0 1 %.6f\n", i, i, y);
+    }
+    fclose(f);
     return 0;
   }
   if (cmd == "genogen") {
