@@ -24,6 +24,7 @@
 #include <iostream>
 #include <limits>
 #include <mutex>
+#include <set>
 #include <sstream>
 #include <stdexcept>
 #include <string>
@@ -398,6 +399,16 @@ public:
   std::vector<int> indicator_idv, indicator_snp;
   std::vector<SNPINFO> snpInfo;
   std::vector<SUMSTAT> sumStat;
+  std::set<std::string> setGWASnps; // -loco / -gwasnps: the SNPs tested (src/lmm.cpp:87,1585-1587); empty = all
+
+  // the SNPs Analyze visits: indicator_snp, and with -loco only the members of setGWASnps (src/lmm.cpp:1578-1587)
+  std::vector<int> analysed_snps() const {
+    std::vector<int> keep(indicator_snp);
+    if (!setGWASnps.empty())
+      for (size_t t = 0; t < keep.size() && t < snpInfo.size(); ++t)
+        if (keep[t] && setGWASnps.count(snpInfo[t].rs_number) == 0) keep[t] = 0;
+    return keep;
+  }
 
   // AnalyzePlink, src/lmm.cpp:1710-1903: raw .bed rows go to the device (decode, drop, impute there)
   void AnalyzePlink(const Matrix *U, const Vector *eval, const Matrix *UtW, const Vector *Uty) {
@@ -410,9 +421,10 @@ public:
     const size_t B = io_block_rows(LMM_BATCH_SIZE);
     std::vector<gemma_sumstat> out(B);
     size_t t_next = 0;
+    const std::vector<int> keep = analysed_snps();
     // the .bed rows of block k+1 are read by a host thread while block k is on the device
     BlockPrefetch pf(B * n_bit, [&](void *slot, int) {
-      return read_bed_rows(infile, indicator_snp, t_next, n_bit, static_cast<unsigned char *>(slot), B);
+      return read_bed_rows(infile, keep, t_next, n_bit, static_cast<unsigned char *>(slot), B);
     });
     for (;;) {
       void *slot = nullptr;
@@ -514,6 +526,7 @@ public:
     size_t t = 0;
     for (size_t i = 0; i < snpInfo.size(); ++i) {
       if (indicator_snp[i] == 0) continue;
+      if (!setGWASnps.empty() && setGWASnps.count(snpInfo[i].rs_number) == 0) continue; // src/lmm.cpp:208-210
       const SNPINFO &s = snpInfo[i];
       const SUMSTAT &st = sumStat[t];
       outfile << s.chr << "\t" << s.rs_number << "\t" << s.base_position << "\t" << s.n_miss << "\t" << s.a_minor

@@ -750,9 +750,23 @@ inline bool ReadFile_geno(const std::string &file_geno, const std::set<std::stri
 // ---------------------------------------------------------------------------------------------------------------
 // feeders over the threaded reader
 // ---------------------------------------------------------------------------------------------------------------
-// BimbamKin, src/gemma_io.cpp:1418-1597 (kinship over ALL ni_total individuals, analysed SNPs only)
-inline bool BimbamKinThreaded(const std::string &file_geno, const std::vector<int> &indicator_snp, const int k_mode,
-                              Matrix *matrix_kin) {
+// LOCO_set_Snps, src/param.cpp:52-66: with `-loco C` the kinship uses the annotated SNPs NOT on chromosome C and the
+// association tests the ones on it (SNPs without annotation are in neither set)
+inline void LOCO_set_Snps(std::set<std::string> &ksnps, std::set<std::string> &gwasnps,
+                          const std::map<std::string, std::string> &mapchr, const std::string &loco) {
+  for (std::map<std::string, std::string>::const_iterator kv = mapchr.begin(); kv != mapchr.end(); ++kv)
+    (kv->second != loco ? ksnps : gwasnps).insert(kv->first);
+}
+
+// BimbamKin, src/gemma_io.cpp:1418-1597 (kinship over ALL ni_total individuals, analysed SNPs only; with a non-empty
+// ksnps only its members, :1478-1480 -- snpInfo supplies the rs of every file line from the first pass)
+inline bool BimbamKinThreaded(const std::string &file_geno, const std::vector<int> &indicator_snp_in, const int k_mode,
+                              Matrix *matrix_kin, const std::set<std::string> &ksnps = std::set<std::string>(),
+                              const std::vector<SNPINFO> *snpInfo = nullptr) {
+  std::vector<int> indicator_snp(indicator_snp_in);
+  if (!ksnps.empty() && snpInfo)
+    for (size_t t = 0; t < indicator_snp.size() && t < snpInfo->size(); ++t)
+      if (indicator_snp[t] && ksnps.count((*snpInfo)[t].rs_number) == 0) indicator_snp[t] = 0;
   const size_t ni_total = matrix_kin->size1;
   BimbamReader rd(file_geno, ni_total);
   if (!rd.ok()) {
@@ -785,9 +799,10 @@ inline void AnalyzeBimbam(LMM &lmm, const Matrix *U, const Vector *eval, const M
   BimbamReader rd(lmm.file_geno, ni_total);
   if (!rd.ok()) throw std::runtime_error("error reading genotype file");
   const size_t B = bimbam_block_rows(n, LMM_BATCH_SIZE);
+  const std::vector<int> keep = lmm.analysed_snps();
   BlockPrefetch pf(B * n * sizeof(double), [&](void *slot, int) -> size_t {
-    if (rd.lines_read() >= lmm.indicator_snp.size()) return 0;
-    return rd.read_block(B, static_cast<double *>(slot), n, nullptr, &lmm.indicator_snp, lmm.indicator_idv.data());
+    if (rd.lines_read() >= keep.size()) return 0;
+    return rd.read_block(B, static_cast<double *>(slot), n, nullptr, &keep, lmm.indicator_idv.data());
   });
   LMM::RowFeeder feed = [&](const double *&X) -> size_t {
     void *slot = nullptr;

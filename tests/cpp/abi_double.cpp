@@ -8,10 +8,14 @@
 //
 // Arithmetic: oracle/gemma_oracle.c (orc_*: restatement of the reference, pinned on the reference binary's outputs)
 // for imputation, centring, kinship preparation, the null model and the per-SNP statistics; plain loops for the
-// GEMMs; a cyclic Jacobi sweep for the symmetric eigenproblem (the statistics do not depend on the eigenbasis,
+// GEMMs; for the symmetric eigenproblem LAPACK's dsyev from the OpenBLAS inside scipy when the test names it in
+// GEMMA_DOUBLE_LAPACK (dlopen), otherwise a cyclic Jacobi sweep (the statistics do not depend on the eigenbasis,
 // SURVEY App. A.6); the first-pass SNP filters restated here from src/gemma_io.cpp:753-853 / :942-1049 (no HWE).
+#include <dlfcn.h>
+
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <string>
@@ -204,8 +208,31 @@ int gemma_hip_center(double *G, size_t n) {
   return GEMMA_HIP_OK;
 }
 
-// cyclic Jacobi; eigenvalues ascending, eigenvector k = column k of row-major U; EigenDecomp_Zeroed's clean-up
+// eigenvalues ascending, eigenvector k = column k of row-major U; EigenDecomp_Zeroed's clean-up
 int gemma_hip_eigh(double *G, size_t n, double *U, double *eval, double *trace_G) {
+  typedef void (*dsyev_t)(char *, char *, int *, double *, int *, double *, double *, int *, int *);
+  static dsyev_t dsyev = nullptr;
+  static bool looked = false;
+  if (!looked) {
+    looked = true;
+    const char *path = getenv("GEMMA_DOUBLE_LAPACK");
+    void *h = path ? dlopen(path, RTLD_NOW | RTLD_GLOBAL) : nullptr;
+    if (h) dsyev = reinterpret_cast<dsyev_t>(dlsym(h, "scipy_dsyev_"));
+  }
+  if (dsyev) {
+    char jobz = 'V', uplo = 'L';
+    int N = (int)n, lwork = -1, info = 0;
+    double wq = 0;
+    dsyev(&jobz, &uplo, &N, G, &N, eval, &wq, &lwork, &info);
+    lwork = (int)wq;
+    std::vector<double> work((size_t)lwork);
+    dsyev(&jobz, &uplo, &N, G, &N, eval, work.data(), &lwork, &info);
+    if (info != 0) return fail(GEMMA_HIP_ENOCONV, "dsyev");
+    for (size_t k = 0; k < n; ++k) // column-major eigenvector k = G[k * n + i]
+      for (size_t i = 0; i < n; ++i) U[i * n + k] = G[k * n + i];
+    *trace_G = orc_zero_small_eval(eval, n);
+    return GEMMA_HIP_OK;
+  }
   std::vector<double> V(n * n, 0.0);
   for (size_t i = 0; i < n; ++i) V[i * n + i] = 1.0;
   for (int sweep = 0; sweep < 60; ++sweep) {

@@ -3,7 +3,7 @@
 //
 //   gemma_file_driver (-g geno[.gz] -p pheno [-a anno] | -bfile prefix) [-c cvt] [-n col]
 //                     (-gk [1|2] | -k kin (-eigen | -lmm [1|2|3|4|9]) | -d eigenD -u eigenU -lmm m)
-//                     [-maf x] [-miss x] [-hwe x] [-r2 x] [-o name] [-outdir dir]
+//                     [-maf x] [-miss x] [-hwe x] [-r2 x] [-loco chr] [-o name] [-outdir dir]
 //   gemma_file_driver -bfile prefix -inproc [1|2] -lmm m ...   kinship, eigendecomposition and association in ONE
 //                     process: K never becomes text; wall seconds of every stage on the log line
 //
@@ -22,6 +22,7 @@
 using namespace gemma_amd;
 
 int main(int argc, char **argv) {
+  std::string loco;
   std::string file_geno, file_pheno, file_anno, file_bfile, file_cvt, file_kin, file_kd, file_ku, file_out = "result",
                                                                                                   path_out = "./output";
   size_t p_column = 1;
@@ -48,6 +49,7 @@ int main(int argc, char **argv) {
     else if (a == "-inproc") inproc = has ? atoi(argv[++i]) : 1;
     else if (a == "-lmm") a_mode = has ? atoi(argv[++i]) : 1;
     else if (a == "-eigen") do_eigen = true;
+    else if (a == "-loco" && has) loco = argv[++i];
     else if (a == "-maf" && has) qc.maf_level = atof(argv[++i]);
     else if (a == "-miss" && has) qc.miss_level = atof(argv[++i]);
     else if (a == "-hwe" && has) qc.hwe_level = atof(argv[++i]);
@@ -101,13 +103,18 @@ int main(int argc, char **argv) {
     }
     std::cout << "ni_total=" << ni_total << " ni_test=" << ni_test << " n_cvt=" << n_cvt
               << " ns_total=" << indicator_snp.size() << " ns_test=" << ns_test;
+    std::set<std::string> setKSnps, setGWASnps; // src/param.cpp:497-500
+    if (!loco.empty()) {
+      LOCO_set_Snps(setKSnps, setGWASnps, mapRS2chr, loco);
+      std::cout << " ksnps=" << setKSnps.size() << " gwasnps=" << setGWASnps.size();
+    }
     if (inproc) std::cout << " t_first_pass=" << lap();
 
     // ---- -gk (src/gemma.cpp:1900-1926) ----------------------------------------------------------------------------
     if (k_mode) {
       std::vector<double> Kb(ni_total * ni_total, 0.0);
       Matrix K = matrix_view(Kb.data(), ni_total, ni_total);
-      const bool ok = file_bfile.empty() ? BimbamKinThreaded(file_geno, indicator_snp, k_mode, &K)
+      const bool ok = file_bfile.empty() ? BimbamKinThreaded(file_geno, indicator_snp, k_mode, &K, setKSnps, &snpInfo)
                                          : PlinkKin(file_bfile + ".bed", indicator_snp, k_mode, 0, &K);
       if (!ok) return 4;
       if (!WriteMatrix(&K, path_out + "/" + file_out + (k_mode == 1 ? ".cXX.txt" : ".sXX.txt"))) return 4;
@@ -125,7 +132,7 @@ int main(int argc, char **argv) {
     if (inproc) { // -gk and -lmm in one process: K stays binary (changes K at the 1e-10 level)
       std::vector<double> Kb(ni_total * ni_total, 0.0), Gb(ni_test * ni_test);
       Matrix K = matrix_view(Kb.data(), ni_total, ni_total), G = matrix_view(Gb.data(), ni_test, ni_test);
-      const bool ok = file_bfile.empty() ? BimbamKinThreaded(file_geno, indicator_snp, inproc, &K)
+      const bool ok = file_bfile.empty() ? BimbamKinThreaded(file_geno, indicator_snp, inproc, &K, setKSnps, &snpInfo)
                                          : PlinkKin(file_bfile + ".bed", indicator_snp, inproc, 0, &K);
       if (!ok) return 4;
       std::cout << " t_kinship=" << lap();
@@ -193,6 +200,7 @@ int main(int argc, char **argv) {
     cLmm.indicator_idv = cp.indicator_idv;
     cLmm.indicator_snp = indicator_snp;
     cLmm.snpInfo = snpInfo;
+    cLmm.setGWASnps = setGWASnps;
     cLmm.l_mle_null = nm.l_mle_null;
     cLmm.logl_mle_H0 = nm.logl_mle_H0;
     const double t_a0 = lap();

@@ -142,3 +142,53 @@ def plink_workflow(exe, out):
     kv = drive(exe, *base, "-k", cxx, "-lmm", 1, "-miss", "0.02", "-maf", "0.05", "-o", "P1q")
     check_log(kv, "P1q.log.json")
     compare_assoc(os.path.join(out, "P1q.assoc.txt"), os.path.join(TXT, "P1q.assoc.txt.gz"))
+
+
+def loco_workflow(exe, out, chrs=(2,), modes=(1,)):
+    """`-loco C` on BIMBAM text (src/param.cpp:52-66,497-500): the issue188 genotypes written as a mean-genotype file with
+    four chromosomes in the annotation -- the input tests/golden/make_ref_fixtures.py::loco gave the reference binary --
+    kinship from the SNPs off chromosome C, association on the SNPs on it, against the reference's cXX rows and .assoc.txt
+    values (tests/golden/ref_loco.npz)."""
+    out = str(out)
+    fx = np.load(os.path.join(ROOT, "tests", "golden", "ref_issue188.npz"))
+    ref = np.load(os.path.join(ROOT, "tests", "golden", "ref_loco.npz"))
+    n_total = int(fx["n_total"])
+    nb = (n_total + 3) // 4
+    raw = fx["bed"][3:].reshape(-1, nb)
+    codes = np.stack([(raw >> (2 * k)) & 3 for k in range(4)], axis=2).reshape(raw.shape[0], nb * 4)[:, :n_total]
+    text = np.array(["2", "NA", "1", "0"])[codes]  # 00 -> 2, 01 -> missing, 10 -> 1, 11 -> 0 (src/lmm.cpp:1797-1812)
+    p = text.shape[0]
+    with open(os.path.join(out, "g.txt"), "w") as f:
+        for t in range(p):
+            f.write("rs%d, A, T, %s\n" % (t, ", ".join(text[t])))
+    with open(os.path.join(out, "ph.txt"), "w") as f:
+        for v in fx["pheno_col6"]:
+            f.write(("NA" if v in ("-9", "NA") else str(v)) + "\n")
+    with open(os.path.join(out, "anno.txt"), "w") as f:
+        for t in range(p):
+            f.write("rs%d\t%d\t%d\n" % (t, 1000 + t, ref["chr"][t]))
+    base = ["-g", os.path.join(out, "g.txt"), "-p", os.path.join(out, "ph.txt"), "-a", os.path.join(out, "anno.txt"),
+            "-outdir", out]
+    for c in chrs:
+        kv = drive(exe, *base, "-gk", 1, "-loco", c, "-o", "k%d" % c)
+        assert int(kv["gwasnps"]) == int((ref["chr"] == c).sum()) and int(kv["ksnps"]) == int((ref["chr"] != c).sum())
+        cxx = os.path.join(out, "k%d.cXX.txt" % c)
+        K = np.loadtxt(cxx)
+        assert np.abs(K[:16] - ref["c%d_cXX_rows" % c]).max() <= 2e-10 and np.abs(np.diag(K) - ref["c%d_cXX_diag" % c]).max() <= 2e-10
+        for m in modes:
+            tag = "c%d_lmm%d" % (c, m)
+            drive(exe, *base, "-k", cxx, "-lmm", m, "-loco", c, "-o", tag)
+            hdr, rows = read_assoc(os.path.join(out, tag + ".assoc.txt"))
+            idx = ref[tag + "_snp"]
+            assert [r[1] for r in rows] == ["rs%d" % t for t in idx] and all(r[0] == str(c) for r in rows)
+            for j, name in enumerate(hdr[7:], start=7):
+                if tag + "_" + name not in ref.files:
+                    continue
+                got = np.array([float(r[j]) for r in rows])
+                want = ref[tag + "_" + name]
+                both = np.isnan(got) & np.isnan(want)
+                rel = np.where(both, 0.0, np.abs(got - want) / np.maximum(np.abs(want), 1e-300))
+                if name in LAM_COLS:
+                    assert (rel <= 1e-3).all() and (rel <= STAT_TOL).mean() >= 0.98, (tag, name)
+                else:
+                    assert (rel <= STAT_TOL).all(), (tag, name, np.nanmax(rel))

@@ -20,7 +20,7 @@ def driver(tmp_path_factory, oracle):
     tmp = tmp_path_factory.mktemp("double")
     subprocess.check_call(["g++", "-std=c++11", "-O2", "-Wall", "-shared", "-fPIC", "-I" + os.path.join(ROOT, "include"),
                            os.path.join(ROOT, "tests", "cpp", "abi_double.cpp"), "-L" + os.path.join(ROOT, "oracle"),
-                           "-lgemma_oracle", "-Wl,-rpath," + os.path.join(ROOT, "oracle"),
+                           "-lgemma_oracle", "-Wl,-rpath," + os.path.join(ROOT, "oracle"), "-ldl",
                            "-o", str(tmp / "libgemma_hip.so")])
     return fc.build_driver(tmp, str(tmp))
 
@@ -39,6 +39,17 @@ def test_plink_files_to_reference_outputs(driver, tmp_path, monkeypatch, block):
     if block:
         monkeypatch.setenv("GEMMA_HIP_IO_BLOCK", block)
     fc.plink_workflow(driver, tmp_path)
+
+
+def test_loco_bimbam_files_to_reference_outputs(driver, tmp_path, monkeypatch):
+    """n = 1008 here: the double takes LAPACK's dsyev from the OpenBLAS inside scipy for the eigenproblem"""
+    import glob
+    import scipy
+    libs = glob.glob(os.path.join(os.path.dirname(os.path.dirname(scipy.__file__)), "scipy.libs", "libscipy_openblas*.so"))
+    if libs:
+        monkeypatch.setenv("GEMMA_DOUBLE_LAPACK", libs[0])
+    monkeypatch.setenv("GEMMA_HIP_IO_BLOCK", "700")
+    fc.loco_workflow(driver, tmp_path, chrs=(2,), modes=(1,))
 
 
 def test_driver_reports_reader_errors(driver, tmp_path):

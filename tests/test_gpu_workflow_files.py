@@ -24,3 +24,7 @@ def test_bxd_bimbam_files_to_reference_outputs(driver, tmp_path):
 
 def test_plink_files_to_reference_outputs(driver, tmp_path):
     fc.plink_workflow(driver, tmp_path)
+
+
+def test_loco_bimbam_files_to_reference_outputs(driver, tmp_path):
+    fc.loco_workflow(driver, tmp_path, chrs=(2, 4), modes=(1, 4))
