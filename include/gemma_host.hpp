@@ -571,5 +571,126 @@ private:
   void finish() { enforce_hip(gemma_hip_lmm_finish(&time_UtX, &time_opt), "LMM::Analyze"); }
 };
 
+// class MVLMM, src/mvlmm.h:32-104 -- multivariate LMM (`-lmm m -n a b c ...`): the members CopyFromParam fills
+// (src/mvlmm.cpp:51-90), AnalyzePlink / AnalyzeBimbam rows (:3418-3899 / :2972-3416, crt = 0) and WriteFiles (:117-210).
+// sumStat holds MPHSUMSTAT (src/param.h:68-77) flat: per SNP beta[d], Vbeta[v], Vg[v], Ve[v], p_wald, p_lrt, p_score
+// with v = d (d + 1) / 2 -- the record gemma_hip_mvlmm_batch writes.
+class MVLMM {
+public:
+  int a_mode = 1;
+  std::string file_bfile, file_geno, file_out, path_out = "./output/";
+  double l_min = 1e-5, l_max = 1e5;
+  size_t n_region = 10;
+  size_t em_iter = 10000, nr_iter = 100; // src/param.cpp:94-107
+  double em_prec = 1e-4, nr_prec = 1e-4, p_nr = 1e-3;
+  size_t ni_total = 0, ni_test = 0, n_cvt = 1, n_ph = 0;
+  double logl_remle_H0 = 0.0, logl_mle_H0 = 0.0, time_UtX = 0.0, time_opt = 0.0;
+  gemma_mvlmm_null null_fit;
+  std::vector<int> indicator_idv, indicator_snp;
+  std::vector<SNPINFO> snpInfo;
+  std::vector<double> sumStat;
+  size_t stride() const { return n_ph + 3 * (n_ph * (n_ph + 1) / 2) + 3; }
+
+  // UtY: ni_test x n_ph row-major (the gsl_matrix the reference passes)
+  void AnalyzePlink(const Matrix *U, const Vector *eval, const Matrix *UtW, const Matrix *UtY) {
+    const std::string file_bed = file_bfile + ".bed";
+    std::ifstream infile(file_bed.c_str(), std::ios::binary);
+    if (!infile) throw std::runtime_error("error reading genotype (.bed) file");
+    setup(U, eval, UtW, UtY, 1);
+    enforce_hip(gemma_hip_lmm_set_indicator(indicator_idv.data(), indicator_idv.size()), "MVLMM::AnalyzePlink");
+    const size_t n_bit = (ni_total + 3) / 4, B = io_block_rows(LMM_BATCH_SIZE);
+    std::vector<double> out(B * stride());
+    size_t t_next = 0;
+    BlockPrefetch pf(B * n_bit, [&](void *slot, int) {
+      return read_bed_rows(infile, indicator_snp, t_next, n_bit, static_cast<unsigned char *>(slot), B);
+    });
+    for (;;) {
+      void *slot = nullptr;
+      const size_t l = pf.next(slot);
+      if (l == (size_t)-1) throw std::runtime_error("error reading genotype (.bed) file (truncated)");
+      if (l == 0) break;
+      enforce_hip(gemma_hip_mvlmm_batch(GEMMA_GENO_PLINK_2BIT, slot, l, n_bit, out.data()), "MVLMM::AnalyzePlink");
+      sumStat.insert(sumStat.end(), out.begin(), out.begin() + l * stride());
+    }
+    enforce_hip(gemma_hip_lmm_finish(&time_UtX, &time_opt), "MVLMM::AnalyzePlink");
+  }
+
+  // the BIMBAM twin with the rows already parsed: X rows = analysed SNPs over the analysed individuals, NaN = missing
+  void AnalyzeRows(const Matrix *U, const Vector *eval, const Matrix *UtW, const Matrix *UtY, const double *X, size_t n_snps,
+                   size_t ld) {
+    setup(U, eval, UtW, UtY, 0);
+    std::vector<double> out(std::min(n_snps, LMM_BATCH_SIZE) * stride());
+    for (size_t s0 = 0; s0 < n_snps; s0 += LMM_BATCH_SIZE) {
+      const size_t l = std::min(LMM_BATCH_SIZE, n_snps - s0);
+      enforce_hip(gemma_hip_mvlmm_batch(GEMMA_GENO_F64_SNP_MAJOR, X + s0 * ld, l, ld, out.data()), "MVLMM::AnalyzeBimbam");
+      sumStat.insert(sumStat.end(), out.begin(), out.begin() + l * stride());
+    }
+    enforce_hip(gemma_hip_lmm_finish(&time_UtX, &time_opt), "MVLMM::AnalyzeBimbam");
+  }
+
+  // MVLMM::WriteFiles, src/mvlmm.cpp:117-210
+  void WriteFiles() {
+    const std::string file_str = path_out + "/" + file_out + ".assoc.txt";
+    std::ofstream outfile(file_str.c_str(), std::ofstream::out);
+    if (!outfile) {
+      std::cout << "error writing file: " << file_str << std::endl;
+      return;
+    }
+    outfile << "chr\trs\tps\tn_miss\tallele1\tallele0\taf\t";
+    for (size_t i = 0; i < n_ph; i++) outfile << "beta_" << i + 1 << "\t";
+    for (size_t i = 0; i < n_ph; i++)
+      for (size_t j = i; j < n_ph; j++) outfile << "Vbeta_" << i + 1 << "_" << j + 1 << "\t";
+    switch (a_mode) {
+    case 1: outfile << "p_wald" << std::endl; break;
+    case 2: outfile << "p_lrt" << std::endl; break;
+    case 3: outfile << "p_score" << std::endl; break;
+    case 4: outfile << "p_wald\tp_lrt\tp_score" << std::endl; break;
+    }
+    const size_t d = n_ph, v = d * (d + 1) / 2, st = stride();
+    size_t t = 0;
+    for (size_t i = 0; i < snpInfo.size(); ++i) {
+      if (indicator_snp[i] == 0) continue;
+      const SNPINFO &s = snpInfo[i];
+      const double *r = &sumStat[t * st];
+      outfile << s.chr << "\t" << s.rs_number << "\t" << s.base_position << "\t" << s.n_miss << "\t" << s.a_minor << "\t"
+              << s.a_major << "\t" << std::fixed << std::setprecision(3) << s.maf << "\t";
+      outfile << std::scientific << std::setprecision(6);
+      for (size_t k = 0; k < d + v; ++k) outfile << r[k] << "\t"; // beta then Vbeta (upper triangle, row by row)
+      const double p_wald = r[d + 3 * v], p_lrt = r[d + 3 * v + 1], p_score = r[d + 3 * v + 2];
+      switch (a_mode) {
+      case 1: outfile << p_wald << std::endl; break;
+      case 2: outfile << p_lrt << std::endl; break;
+      case 3: outfile << p_score << std::endl; break;
+      case 4: outfile << p_wald << "\t" << p_lrt << "\t" << p_score << std::endl; break;
+      }
+      t++;
+    }
+  }
+
+private:
+  // the null block (src/mvlmm.cpp:3056-3208) and the per-SNP loop's state
+  void setup(const Matrix *U, const Vector *eval, const Matrix *UtW, const Matrix *UtY, int plink) {
+    if (U->tda != U->size2 || UtW->tda != UtW->size2 || UtY->tda != UtY->size2 || eval->stride != 1)
+      throw HipError(GEMMA_HIP_EINVAL, "MVLMM: contiguous U/UtW/UtY/eval required");
+    ni_test = U->size1;
+    n_cvt = UtW->size2;
+    n_ph = UtY->size2;
+    const gemma_mvlmm_opt opt = {em_iter, nr_iter, em_prec, nr_prec, p_nr};
+    enforce_hip(gemma_hip_mvlmm_null(ni_test, n_cvt, n_ph, eval->data, UtW->data, UtY->data, l_min, l_max, n_region, &opt,
+                                     &null_fit),
+                "MVLMM (null model)");
+    logl_remle_H0 = null_fit.logl_remle_H0;
+    logl_mle_H0 = null_fit.logl_mle_H0;
+    gemma_lmm_cfg cfg;
+    cfg.a_mode = a_mode; cfg.n = ni_test; cfg.n_cvt = n_cvt; cfg.l_min = l_min; cfg.l_max = l_max;
+    cfg.n_region = n_region; cfg.l_mle_null = 0; cfg.logl_mle_H0 = 0; cfg.plink_nan_rule = plink;
+    std::vector<double> y0(ni_test); // the univariate Uty slot is not read by the multivariate path
+    for (size_t i = 0; i < ni_test; ++i) y0[i] = UtY->data[i * UtY->tda];
+    enforce_hip(gemma_hip_lmm_setup(&cfg, U->data, eval->data, UtW->data, y0.data()), "MVLMM::Analyze");
+    enforce_hip(gemma_hip_mvlmm_set(n_ph, UtY->data, &null_fit, &opt), "MVLMM::Analyze");
+    sumStat.clear();
+  }
+};
+
 } // namespace gemma_amd
 #endif

@@ -39,6 +39,16 @@ void orc_CalcLambda_null(char func_name, size_t n, size_t c, const double *eval,
                          double l_min, double l_max, size_t n_region, double *lambda, double *logl_H0);
 void orc_CalcPve(size_t n, size_t c, const double *eval, const double *UtW, const double *Uty, double lambda,
                  double trace_G, double *pve, double *pve_se);
+typedef struct {
+  size_t em_iter, nr_iter, n_region;
+  double em_prec, nr_prec, l_min, l_max, p_nr;
+} orc_mv_cfg;
+void orc_mvlmm_null(const orc_mv_cfg *cfg, size_t n, size_t d, size_t cw, const double *eval, const double *W,
+                    const double *Y, double *Vg_remle, double *Ve_remle, double *B_remle, double *logl_remle,
+                    double *Vg_mle, double *Ve_mle, double *B_mle, double *logl_mle);
+void orc_mvlmm_batch(int a_mode, const orc_mv_cfg *cfg, size_t n, size_t d, size_t cw, const double *eval, const double *W,
+                     const double *Y, const double *UtX, size_t l, const double *Vg_null, const double *Ve_null,
+                     const double *B_null, double logl_H0, double *out);
 void orc_CalcLmmVgVeBeta(size_t n, size_t c, const double *eval, const double *UtW, const double *Uty, double lambda,
                          double *vg, double *ve, double *beta, double *se_beta);
 }
@@ -62,7 +72,19 @@ struct Lmm {
   gemma_lmm_cfg cfg;
   std::vector<double> U, eval, UtW, Uty, carry;
   std::vector<int> ind;
+  // multivariate: phenotypes and covariates transposed (d x n, c x n: the oracle's layout), null fit, options
+  size_t d = 0;
+  std::vector<double> Yt, Wt;
+  gemma_mvlmm_null mv_null;
+  orc_mv_cfg mv_cfg;
 } g_lmm;
+
+std::vector<double> transposed(const double *A, size_t rows, size_t cols) {
+  std::vector<double> T(rows * cols);
+  for (size_t i = 0; i < rows; ++i)
+    for (size_t j = 0; j < cols; ++j) T[j * rows + i] = A[i * cols + j];
+  return T;
+}
 
 // rows of l SNPs over `n_out` individuals (NaN = missing) from either encoding
 void decode(int kind, const void *geno, size_t l, size_t ld, const int *ind, size_t ni_total, size_t n_out,
@@ -296,6 +318,7 @@ int gemma_hip_lmm_setup(const gemma_lmm_cfg *cfg, const double *U, const double 
   g_lmm.Uty.assign(Uty, Uty + n);
   g_lmm.carry.assign(2, 0.0);
   g_lmm.ind.clear();
+  g_lmm.d = 0;
   return GEMMA_HIP_OK;
 }
 int gemma_hip_lmm_set_indicator(const int *ind, size_t ni_total) {
@@ -326,6 +349,44 @@ int gemma_hip_lmm_finish(double *t_utx, double *t_opt) {
   g_lmm.on = false;
   if (t_utx) *t_utx = 0.0;
   if (t_opt) *t_opt = 0.0;
+  return GEMMA_HIP_OK;
+}
+
+// ---- multivariate LMM over oracle/mvlmm_oracle.c ----------------------------------------------------------------
+int gemma_hip_mvlmm_null(size_t n, size_t c, size_t d, const double *eval, const double *UtW, const double *UtY, double l_min,
+                         double l_max, size_t n_region, const gemma_mvlmm_opt *opt, gemma_mvlmm_null *out) {
+  const orc_mv_cfg cfg = {opt->em_iter, opt->nr_iter, n_region, opt->em_prec, opt->nr_prec, l_min, l_max, opt->p_nr};
+  const std::vector<double> Wt = transposed(UtW, n, c), Yt = transposed(UtY, n, d);
+  memset(out, 0, sizeof(*out));
+  orc_mvlmm_null(&cfg, n, d, c, eval, Wt.data(), Yt.data(), out->Vg_remle, out->Ve_remle, out->B_remle, &out->logl_remle_H0,
+                 out->Vg_mle, out->Ve_mle, out->B_mle, &out->logl_mle_H0);
+  return GEMMA_HIP_OK;
+}
+int gemma_hip_mvlmm_set(size_t d, const double *UtY, const gemma_mvlmm_null *null_fit, const gemma_mvlmm_opt *opt) {
+  if (!g_lmm.on) return fail(GEMMA_HIP_ESTATE, "mvlmm_set before lmm_setup");
+  const size_t n = g_lmm.cfg.n, c = g_lmm.cfg.n_cvt;
+  g_lmm.d = d;
+  g_lmm.Yt = transposed(UtY, n, d);
+  g_lmm.Wt = transposed(g_lmm.UtW.data(), n, c);
+  g_lmm.mv_null = *null_fit;
+  const orc_mv_cfg cfg = {opt->em_iter, opt->nr_iter, g_lmm.cfg.n_region, opt->em_prec, opt->nr_prec, g_lmm.cfg.l_min,
+                          g_lmm.cfg.l_max, opt->p_nr};
+  g_lmm.mv_cfg = cfg;
+  return GEMMA_HIP_OK;
+}
+int gemma_hip_mvlmm_batch(int kind, const void *geno, size_t l, size_t ld, double *out) {
+  if (!g_lmm.on || g_lmm.d == 0) return fail(GEMMA_HIP_ESTATE, "mvlmm_batch before mvlmm_set");
+  const size_t n = g_lmm.cfg.n, c = g_lmm.cfg.n_cvt;
+  std::vector<double> X;
+  if (kind == GEMMA_GENO_PLINK_2BIT)
+    decode(kind, geno, l, ld, g_lmm.ind.empty() ? nullptr : g_lmm.ind.data(), g_lmm.ind.empty() ? n : g_lmm.ind.size(), n, X);
+  else
+    decode(kind, geno, l, ld, nullptr, n, n, X);
+  orc_impute_mean(X.data(), l, n);
+  std::vector<double> UtX(l * n);
+  gemma_hip_dgemm('N', 'N', l, n, n, 1.0, X.data(), n, g_lmm.U.data(), n, 0.0, UtX.data(), n);
+  orc_mvlmm_batch(g_lmm.cfg.a_mode, &g_lmm.mv_cfg, n, g_lmm.d, c, g_lmm.eval.data(), g_lmm.Wt.data(), g_lmm.Yt.data(),
+                  UtX.data(), l, g_lmm.mv_null.Vg_mle, g_lmm.mv_null.Ve_mle, g_lmm.mv_null.B_mle, g_lmm.mv_null.logl_mle_H0, out);
   return GEMMA_HIP_OK;
 }
 

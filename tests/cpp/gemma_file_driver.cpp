@@ -1,7 +1,7 @@
 // File-driven run of the path, the way `gemma` is invoked (test harness for include/gemma_io_host.hpp +
 // include/gemma_host.hpp; NOT a replacement of GEMMA's CLI -- INTEGRATION.md binds the C ABI inside GEMMA itself):
 //
-//   gemma_file_driver (-g geno[.gz] -p pheno [-a anno] | -bfile prefix) [-c cvt] [-n col]
+//   gemma_file_driver (-g geno[.gz] -p pheno [-a anno] | -bfile prefix) [-c cvt] [-n col [col ...]]
 //                     (-gk [1|2] | -k kin (-eigen | -lmm [1|2|3|4|9]) | -d eigenD -u eigenU -lmm m)
 //                     [-maf x] [-miss x] [-hwe x] [-r2 x] [-loco chr] [-o name] [-outdir dir]
 //   gemma_file_driver -bfile prefix -inproc [1|2] -lmm m ...   kinship, eigendecomposition and association in ONE
@@ -11,6 +11,7 @@
 // :2557-2830 `-lmm`): first pass over the genotypes (device QC) -> kinship over all individuals -> <o>.cXX.txt / .sXX.txt;
 // or kinship file -> rows of the analysed individuals -> centre -> eigendecomposition (-> <o>.eigenU/D.txt) -> U^T W,
 // U^T y -> null model -> per-SNP association -> <o>.assoc.txt.  One line of key=value pairs on stdout is the log.
+// Several phenotype columns (-n 1 2 3, PLINK input) take the multivariate LMM (src/gemma.cpp:2796-2830 -> class MVLMM).
 #include <chrono>
 #include <cstdlib>
 #include <iostream>
@@ -25,7 +26,7 @@ int main(int argc, char **argv) {
   std::string loco;
   std::string file_geno, file_pheno, file_anno, file_bfile, file_cvt, file_kin, file_kd, file_ku, file_out = "result",
                                                                                                   path_out = "./output";
-  size_t p_column = 1;
+  std::vector<size_t> p_column;
   int k_mode = 0, a_mode = 0, inproc = 0;
   bool do_eigen = false;
   const auto t_start = std::chrono::steady_clock::now();
@@ -42,7 +43,9 @@ int main(int argc, char **argv) {
     else if (a == "-k" && has) file_kin = argv[++i];
     else if (a == "-d" && has) file_kd = argv[++i];
     else if (a == "-u" && has) file_ku = argv[++i];
-    else if (a == "-n" && has) p_column = strtoul(argv[++i], nullptr, 10);
+    else if (a == "-n" && has) {
+      while (i + 1 < argc && argv[i + 1][0] != '-') p_column.push_back(strtoul(argv[++i], nullptr, 10));
+    }
     else if (a == "-o" && has) file_out = argv[++i];
     else if (a == "-outdir" && has) path_out = argv[++i];
     else if (a == "-gk") k_mode = has ? atoi(argv[++i]) : 1;
@@ -70,7 +73,9 @@ int main(int argc, char **argv) {
     std::map<std::string, long int> mapRS2bp;
     std::map<std::string, double> mapRS2cM;
     const std::set<std::string> setSnps;
-    const std::vector<size_t> cols(1, p_column);
+    if (p_column.empty()) p_column.push_back(1);
+    const std::vector<size_t> &cols = p_column;
+    const size_t n_ph = cols.size();
     if (!file_cvt.empty() && !ReadFile_cvt(file_cvt, cp.indicator_cvt, cp.cvt, cp.n_cvt)) return 3;
     if (cp.indicator_cvt.empty()) cp.n_cvt = 1;
     size_t ns_test = 0;
@@ -180,11 +185,37 @@ int main(int argc, char **argv) {
     }
 
     // ---- -lmm (src/gemma.cpp:2699-2830) ---------------------------------------------------------------------------
-    std::vector<double> UtWb(ni_test * n_cvt), Utyb(ni_test);
-    Matrix Y = matrix_view(Yb.data(), ni_test, 1), UtW = matrix_view(UtWb.data(), ni_test, n_cvt),
-           UtY = matrix_view(Utyb.data(), ni_test, 1);
+    std::vector<double> UtWb(ni_test * n_cvt), Utyb(ni_test * n_ph);
+    Matrix Y = matrix_view(Yb.data(), ni_test, n_ph), UtW = matrix_view(UtWb.data(), ni_test, n_cvt),
+           UtY = matrix_view(Utyb.data(), ni_test, n_ph);
     CalcUtX(&U, &W, &UtW);
     CalcUtX(&U, &Y, &UtY);
+    if (n_ph > 1) { // src/gemma.cpp:2796-2830: MVLMM
+      if (file_bfile.empty()) {
+        std::cerr << "the multivariate path of this driver takes -bfile input" << std::endl;
+        return 2;
+      }
+      MVLMM cMv;
+      cMv.a_mode = a_mode;
+      cMv.file_bfile = file_bfile;
+      cMv.path_out = path_out;
+      cMv.file_out = file_out;
+      cMv.ni_total = ni_total;
+      cMv.indicator_idv = cp.indicator_idv;
+      cMv.indicator_snp = indicator_snp;
+      cMv.snpInfo = snpInfo;
+      const double t_a0 = lap();
+      cMv.AnalyzePlink(&U, &eval, &UtW, &UtY);
+      const double t_a1 = lap();
+      cMv.WriteFiles();
+      std::cout << " logl_remle_H0=" << cMv.logl_remle_H0 << " logl_mle_H0=" << cMv.logl_mle_H0;
+      if (inproc)
+        std::cout << " t_assoc=" << t_a1 << " t_written=" << lap() << " assoc_seconds=" << t_a1 - t_a0
+                  << " assoc_snps_per_s=" << (double)(cMv.sumStat.size() / cMv.stride()) / (t_a1 - t_a0);
+      std::cout << " snps=" << cMv.sumStat.size() / cMv.stride() << std::endl;
+      gemma_hip_shutdown();
+      return 0;
+    }
     Vector Uty = vector_view(Utyb.data(), ni_test);
     const NullModel nm = CalcLambdaNull(&eval, &UtW, &Uty, 1e-5, 1e5, 10, trace_G);
     std::cout << " l_mle_null=" << nm.l_mle_null << " logl_mle_H0=" << nm.logl_mle_H0 << " l_remle_null=" << nm.l_remle_null

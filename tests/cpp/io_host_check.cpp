@@ -12,7 +12,7 @@
 //   eigen <U-in> <D-in> <n> <outdir> <name>     ReadFile_eigenU/D -> WriteEigen
 //   assoc <assoc-in> <a_mode> <outdir> <name>   parse a reference .assoc.txt, LMM::WriteFiles it again
 //   kin <cXX-in> <n> <out>                      ReadFile_kin (all individuals) -> WriteMatrix
-//   plinkgen <prefix> <ni> <ns> [threads]      synthetic PLINK set: two sub-populations, maf ~ U(0.1, 0.45) +- 0.075, 1 % missing calls,
+//   plinkgen <prefix> <ni> <ns> [threads [n_ph]]  synthetic PLINK set (n_ph correlated traits in .fam columns 6..): two sub-populations, maf ~ U(0.1, 0.45) +- 0.075, 1 % missing calls,
 //                                               y = 0.3 * (first 20 SNPs) + 0.8 * population + N(0,1), 2 % of the phenotypes -9
 //   genogen <file> <ni_total> <n_snps>          synthetic BIMBAM file ("0.123"-style dosages, hard calls, 1 % NA)
 //   genobench <file> <ni_total> <threads>       wall time of BimbamReader over the whole file (threads = 0: the
@@ -184,19 +184,30 @@ int main(int argc, char **argv) {
     f = fopen((prefix + ".bim").c_str(), "w");
     for (size_t s = 0; s < ns; ++s) fprintf(f, "%zu\trs%zu\t0\t%zu\tA\tG\n", 1 + s * 20 / ns, s, s + 1);
     fclose(f);
+    const size_t n_ph = argc > 6 ? strtoul(argv[6], nullptr, 10) : 1;
     unsigned long long st = 424242;
+    auto gauss = [&]() { // Irwin-Hall ~ N(0, 1)
+      double y = 0;
+      for (int k = 0; k < 12; ++k) y += (double)(rnd(st) >> 11) / 9007199254740992.0;
+      return y - 6.0;
+    };
     f = fopen((prefix + ".fam").c_str(), "w");
     for (size_t i = 0; i < ni; ++i) {
-      double y = 0;
-      for (int k = 0; k < 12; ++k) y += (double)(rnd(st) >> 11) / 9007199254740992.0; // Irwin-Hall ~ N(6, 1)
-      y -= 6.0;
-      if (i >= ni / 2) y += 0.8; // population effect: the kinship's structure carries phenotypic variance
+      double g = 0;
       for (size_t s = 0; s < 20 && s < ns; ++s) {
         const unsigned code = (bed[s * nb + (i >> 2)] >> (2 * (i & 3))) & 3u;
-        y += 0.3 * (code == 0 ? 2.0 : code == 2 ? 1.0 : 0.0);
+        g += 0.3 * (code == 0 ? 2.0 : code == 2 ? 1.0 : 0.0);
       }
-      if (rnd(st) % 50 == 0) fprintf(f, "f%zu i%zu 0 0 1 -9\n", i, i);
-      else fprintf(f, "f%zu i%zu 0 0 1 %.6f\n", i, i, y);
+      if (i >= ni / 2) g += 0.8; // population effect: the kinship's structure carries phenotypic variance
+      const double shared = n_ph > 1 ? 0.6 * gauss() : 0.0;
+      fprintf(f, "f%zu i%zu 0 0 1", i, i);
+      const bool miss = rnd(st) % 50 == 0;
+      for (size_t k = 0; k < n_ph; ++k) {
+        const double y = g * (1.0 - 0.3 * (double)k) + shared + (n_ph > 1 ? 0.8 : 1.0) * gauss();
+        if (miss && k == 0) fprintf(f, " -9");
+        else fprintf(f, " %.6f", y);
+      }
+      fprintf(f, "\n");
     }
     fclose(f);
     return 0;

@@ -52,6 +52,17 @@ def test_loco_bimbam_files_to_reference_outputs(driver, tmp_path, monkeypatch):
     fc.loco_workflow(driver, tmp_path, chrs=(2,), modes=(1,))
 
 
+def test_mvlmm_plink_files_to_reference_outputs(driver, tmp_path, monkeypatch):
+    """class MVLMM of the C++ host layer (null block, per-SNP blocks, WriteFiles) over the double's oracle-backed mvLMM"""
+    import glob
+    import scipy
+    libs = glob.glob(os.path.join(os.path.dirname(os.path.dirname(scipy.__file__)), "scipy.libs", "libscipy_openblas*.so"))
+    if libs:
+        monkeypatch.setenv("GEMMA_DOUBLE_LAPACK", libs[0])
+    monkeypatch.setenv("GEMMA_HIP_IO_BLOCK", "300")
+    fc.mvlmm_workflow(driver, tmp_path, modes=(1, 4))
+
+
 def test_driver_reports_reader_errors(driver, tmp_path):
     """Where the reference's readers return false the driver stops (exit code 3) instead of analysing garbage."""
     bad = tmp_path / "short.txt"

@@ -28,3 +28,7 @@ def test_plink_files_to_reference_outputs(driver, tmp_path):
 
 def test_loco_bimbam_files_to_reference_outputs(driver, tmp_path):
     fc.loco_workflow(driver, tmp_path, chrs=(2, 4), modes=(1, 4))
+
+
+def test_mvlmm_plink_files_to_reference_outputs(driver, tmp_path):
+    fc.mvlmm_workflow(driver, tmp_path, modes=(1, 2, 3, 4))
