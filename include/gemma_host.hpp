@@ -571,6 +571,106 @@ private:
   void finish() { enforce_hip(gemma_hip_lmm_finish(&time_UtX, &time_opt), "LMM::Analyze"); }
 };
 
+// class LM, src/lm.h -- `-lm 1..4` (a_mode 51..54): per-SNP ordinary regression of y on (W, x), no kinship.
+// AnalyzePlink / AnalyzeBimbam (src/lm.cpp:382-640) and WriteFiles (:83-223, the SNP branch; note its "n_mis" / "n_obs"
+// header, which the LMM writer does not have).
+class LM {
+public:
+  int a_mode = 51;
+  std::string file_bfile, file_geno, file_out, path_out = "./output/";
+  size_t ni_total = 0, ni_test = 0;
+  std::vector<int> indicator_idv, indicator_snp;
+  std::vector<SNPINFO> snpInfo;
+  std::vector<SUMSTAT> sumStat;
+
+  // W: ni_test x n_cvt, y: ni_test (the analysed individuals)
+  void AnalyzePlink(const Matrix *W, const Vector *y) {
+    const std::string file_bed = file_bfile + ".bed";
+    std::ifstream infile(file_bed.c_str(), std::ios::binary);
+    if (!infile) throw std::runtime_error("error reading bed file");
+    setup(W, y);
+    enforce_hip(gemma_hip_lmm_set_indicator(indicator_idv.data(), indicator_idv.size()), "LM::AnalyzePlink");
+    const size_t n_bit = (ni_total + 3) / 4, B = io_block_rows(LMM_BATCH_SIZE);
+    std::vector<gemma_sumstat> out(B);
+    size_t t_next = 0;
+    BlockPrefetch pf(B * n_bit, [&](void *slot, int) {
+      return read_bed_rows(infile, indicator_snp, t_next, n_bit, static_cast<unsigned char *>(slot), B);
+    });
+    for (;;) {
+      void *slot = nullptr;
+      const size_t l = pf.next(slot);
+      if (l == (size_t)-1) throw std::runtime_error("error reading bed file (truncated)");
+      if (l == 0) break;
+      batch(GEMMA_GENO_PLINK_2BIT, slot, l, n_bit, out);
+    }
+    enforce_hip(gemma_hip_lm_finish(), "LM::AnalyzePlink");
+  }
+
+  // pull-style block source as in LMM::AnalyzeFeed (rows = analysed SNPs over the analysed individuals, NaN = missing)
+  void AnalyzeFeed(const Matrix *W, const Vector *y, LMM::RowFeeder &feed, size_t max_rows, size_t ld) {
+    setup(W, y);
+    std::vector<gemma_sumstat> out(max_rows);
+    for (;;) {
+      const double *X = nullptr;
+      const size_t l = feed(X);
+      if (l == 0) break;
+      if (l > max_rows) throw HipError(GEMMA_HIP_EINVAL, "LM::AnalyzeFeed: block larger than max_rows");
+      batch(GEMMA_GENO_F64_SNP_MAJOR, X, l, ld, out);
+    }
+    enforce_hip(gemma_hip_lm_finish(), "LM::AnalyzeBimbam");
+  }
+
+  // LM::WriteFiles, src/lm.cpp:83-223 (SNP branch)
+  void WriteFiles() {
+    const std::string file_str = path_out + "/" + file_out + ".assoc.txt";
+    std::ofstream outfile(file_str.c_str(), std::ofstream::out);
+    if (!outfile) {
+      std::cout << "error writing file: " << file_str << std::endl;
+      return;
+    }
+    outfile << "chr\trs\tps\tn_mis\tn_obs\tallele1\tallele0\taf\t";
+    switch (a_mode) {
+    case 51: outfile << "beta\tse\tp_wald" << std::endl; break;
+    case 52: outfile << "p_lrt" << std::endl; break;
+    case 53: outfile << "beta\tse\tp_score" << std::endl; break;
+    case 54: outfile << "beta\tse\tp_wald\tp_lrt\tp_score" << std::endl; break;
+    }
+    size_t t = 0;
+    for (size_t i = 0; i < snpInfo.size(); ++i) {
+      if (indicator_snp[i] == 0) continue;
+      const SNPINFO &s = snpInfo[i];
+      const SUMSTAT &st = sumStat[t];
+      outfile << s.chr << "\t" << s.rs_number << "\t" << s.base_position << "\t" << s.n_miss << "\t" << ni_test - s.n_miss
+              << "\t" << s.a_minor << "\t" << s.a_major << "\t" << std::fixed << std::setprecision(3) << s.maf << "\t";
+      outfile << std::scientific << std::setprecision(6);
+      switch (a_mode) {
+      case 51: outfile << st.beta << "\t" << st.se << "\t" << st.p_wald << std::endl; break;
+      case 52: outfile << st.p_lrt << std::endl; break;
+      case 53: outfile << st.beta << "\t" << st.se << "\t" << st.p_score << std::endl; break;
+      case 54: outfile << st.beta << "\t" << st.se << "\t" << st.p_wald << "\t" << st.p_lrt << "\t" << st.p_score << std::endl; break;
+      }
+      t++;
+    }
+  }
+
+private:
+  void setup(const Matrix *W, const Vector *y) {
+    if (W->tda != W->size2 || y->stride != 1 || y->size != W->size1)
+      throw HipError(GEMMA_HIP_EINVAL, "LM: contiguous W (n x c) and y (n) required");
+    ni_test = W->size1;
+    enforce_hip(gemma_hip_lm_setup(a_mode, W->size1, W->size2, W->data, y->data), "LM::Analyze");
+    sumStat.clear();
+  }
+  void batch(int kind, const void *geno, size_t l, size_t ld, std::vector<gemma_sumstat> &out) {
+    enforce_hip(gemma_hip_lm_batch(kind, geno, l, ld, out.data()), "LM::Analyze");
+    for (size_t i = 0; i < l; ++i) {
+      SUMSTAT s = {out[i].beta, out[i].se, out[i].lambda_remle, out[i].lambda_mle,
+                   out[i].p_wald, out[i].p_lrt, out[i].p_score, out[i].logl_H1};
+      sumStat.push_back(s);
+    }
+  }
+};
+
 // class MVLMM, src/mvlmm.h:32-104 -- multivariate LMM (`-lmm m -n a b c ...`): the members CopyFromParam fills
 // (src/mvlmm.cpp:51-90), AnalyzePlink / AnalyzeBimbam rows (:3418-3899 / :2972-3416, crt = 0) and WriteFiles (:117-210).
 // sumStat holds MPHSUMSTAT (src/param.h:68-77) flat: per SNP beta[d], Vbeta[v], Vg[v], Ve[v], p_wald, p_lrt, p_score

@@ -814,6 +814,26 @@ inline void AnalyzeBimbam(LMM &lmm, const Matrix *U, const Vector *eval, const M
   lmm.AnalyzeFeed(U, eval, UtW, Uty, feed, B, n);
 }
 
+// LM::AnalyzeBimbam, src/lm.cpp:382-503, over the same threaded reader (lm.file_geno, lm.indicator_idv / _snp)
+inline void AnalyzeBimbam(LM &lm, const Matrix *W, const Vector *y) {
+  const size_t ni_total = lm.indicator_idv.size(), n = W->size1;
+  BimbamReader rd(lm.file_geno, ni_total);
+  if (!rd.ok()) throw std::runtime_error("error reading genotype file");
+  const size_t B = bimbam_block_rows(n, LMM_BATCH_SIZE);
+  BlockPrefetch pf(B * n * sizeof(double), [&](void *slot, int) -> size_t {
+    if (rd.lines_read() >= lm.indicator_snp.size()) return 0;
+    return rd.read_block(B, static_cast<double *>(slot), n, nullptr, &lm.indicator_snp, lm.indicator_idv.data());
+  });
+  LMM::RowFeeder feed = [&](const double *&X) -> size_t {
+    void *slot = nullptr;
+    const size_t l = pf.next(slot);
+    if (l == (size_t)-1) throw std::runtime_error("Problem reading geno file (not enough genotypes in line)");
+    X = static_cast<const double *>(slot);
+    return l;
+  };
+  lm.AnalyzeFeed(W, y, feed, B, n);
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // -eigen artefacts and their readers
 // ---------------------------------------------------------------------------------------------------------------

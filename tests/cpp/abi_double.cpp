@@ -30,6 +30,8 @@ typedef struct {
 void orc_lmm_batch(int a_mode, size_t n, size_t c, const double *eval, const double *UtW, const double *Uty,
                    const double *UtX, size_t l, double l_min, double l_max, size_t n_region, double l_mle_null,
                    double logl_mle_H0, int plink_nan_rule, double *carry, orc_sumstat *out, long *diag);
+void orc_lm_batch(int a_mode, size_t n, size_t c, const double *W, const double *WtWi, const double *y, const double *X,
+                  size_t l, orc_sumstat *out);
 void orc_impute_mean(double *X, size_t l, size_t n);
 void orc_kin_prepare(double *X, size_t l, size_t n, int k_mode);
 size_t orc_bed_decode(const unsigned char *bytes, size_t ni_total, const int *indicator, double *x);
@@ -78,6 +80,13 @@ struct Lmm {
   gemma_mvlmm_null mv_null;
   orc_mv_cfg mv_cfg;
 } g_lmm;
+
+struct Lm {
+  bool on = false;
+  int a_mode = 51;
+  size_t n = 0, c = 0;
+  std::vector<double> W, WtWi, y;
+} g_lm;
 
 std::vector<double> transposed(const double *A, size_t rows, size_t cols) {
   std::vector<double> T(rows * cols);
@@ -322,7 +331,7 @@ int gemma_hip_lmm_setup(const gemma_lmm_cfg *cfg, const double *U, const double 
   return GEMMA_HIP_OK;
 }
 int gemma_hip_lmm_set_indicator(const int *ind, size_t ni_total) {
-  if (!g_lmm.on) return fail(GEMMA_HIP_ESTATE, "lmm_set_indicator before lmm_setup");
+  if (!g_lmm.on && !g_lm.on) return fail(GEMMA_HIP_ESTATE, "lmm_set_indicator before lmm_setup / lm_setup");
   g_lmm.ind.assign(ind, ind + (ind ? ni_total : 0));
   return GEMMA_HIP_OK;
 }
@@ -387,6 +396,57 @@ int gemma_hip_mvlmm_batch(int kind, const void *geno, size_t l, size_t ld, doubl
   gemma_hip_dgemm('N', 'N', l, n, n, 1.0, X.data(), n, g_lmm.U.data(), n, 0.0, UtX.data(), n);
   orc_mvlmm_batch(g_lmm.cfg.a_mode, &g_lmm.mv_cfg, n, g_lmm.d, c, g_lmm.eval.data(), g_lmm.Wt.data(), g_lmm.Yt.data(),
                   UtX.data(), l, g_lmm.mv_null.Vg_mle, g_lmm.mv_null.Ve_mle, g_lmm.mv_null.B_mle, g_lmm.mv_null.logl_mle_H0, out);
+  return GEMMA_HIP_OK;
+}
+
+// ---- -lm over orc_lm_batch ----------------------------------------------------------------------------------------
+int gemma_hip_lm_setup(int a_mode, size_t n, size_t c, const double *W, const double *y) {
+  g_lm.on = true;
+  g_lm.a_mode = a_mode;
+  g_lm.n = n;
+  g_lm.c = c;
+  g_lm.W.assign(W, W + n * c);
+  g_lm.y.assign(y, y + n);
+  std::vector<double> A(c * 2 * c, 0.0); // (W^T W)^-1 by Gauss-Jordan
+  for (size_t a = 0; a < c; ++a) {
+    for (size_t b = 0; b < c; ++b)
+      for (size_t i = 0; i < n; ++i) A[a * 2 * c + b] += W[i * c + a] * W[i * c + b];
+    A[a * 2 * c + c + a] = 1.0;
+  }
+  for (size_t p = 0; p < c; ++p) {
+    size_t piv = p;
+    for (size_t r = p + 1; r < c; ++r)
+      if (std::fabs(A[r * 2 * c + p]) > std::fabs(A[piv * 2 * c + p])) piv = r;
+    for (size_t j = 0; j < 2 * c; ++j) std::swap(A[p * 2 * c + j], A[piv * 2 * c + j]);
+    const double d = A[p * 2 * c + p];
+    for (size_t j = 0; j < 2 * c; ++j) A[p * 2 * c + j] /= d;
+    for (size_t r = 0; r < c; ++r) {
+      if (r == p) continue;
+      const double f = A[r * 2 * c + p];
+      for (size_t j = 0; j < 2 * c; ++j) A[r * 2 * c + j] -= f * A[p * 2 * c + j];
+    }
+  }
+  g_lm.WtWi.assign(c * c, 0.0);
+  for (size_t a = 0; a < c; ++a)
+    for (size_t b = 0; b < c; ++b) g_lm.WtWi[a * c + b] = A[a * 2 * c + c + b];
+  g_lmm.ind.clear();
+  return GEMMA_HIP_OK;
+}
+int gemma_hip_lm_batch(int kind, const void *geno, size_t l, size_t ld, gemma_sumstat *out) {
+  if (!g_lm.on) return fail(GEMMA_HIP_ESTATE, "lm_batch before lm_setup");
+  const size_t n = g_lm.n;
+  std::vector<double> X;
+  if (kind == GEMMA_GENO_PLINK_2BIT)
+    decode(kind, geno, l, ld, g_lmm.ind.empty() ? nullptr : g_lmm.ind.data(), g_lmm.ind.empty() ? n : g_lmm.ind.size(), n, X);
+  else
+    decode(kind, geno, l, ld, nullptr, n, n, X);
+  orc_impute_mean(X.data(), l, n);
+  orc_lm_batch(g_lm.a_mode, n, g_lm.c, g_lm.W.data(), g_lm.WtWi.data(), g_lm.y.data(), X.data(), l,
+               reinterpret_cast<orc_sumstat *>(out));
+  return GEMMA_HIP_OK;
+}
+int gemma_hip_lm_finish(void) {
+  g_lm.on = false;
   return GEMMA_HIP_OK;
 }
 

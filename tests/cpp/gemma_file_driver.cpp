@@ -2,7 +2,7 @@
 // include/gemma_host.hpp; NOT a replacement of GEMMA's CLI -- INTEGRATION.md binds the C ABI inside GEMMA itself):
 //
 //   gemma_file_driver (-g geno[.gz] -p pheno [-a anno] | -bfile prefix) [-c cvt] [-n col [col ...]]
-//                     (-gk [1|2] | -k kin (-eigen | -lmm [1|2|3|4|9]) | -d eigenD -u eigenU -lmm m)
+//                     (-gk [1|2] | -k kin (-eigen | -lmm [1|2|3|4|9]) | -d eigenD -u eigenU -lmm m | -lm [1|2|3|4])
 //                     [-maf x] [-miss x] [-hwe x] [-r2 x] [-loco chr] [-o name] [-outdir dir]
 //   gemma_file_driver -bfile prefix -inproc [1|2] -lmm m ...   kinship, eigendecomposition and association in ONE
 //                     process: K never becomes text; wall seconds of every stage on the log line
@@ -27,7 +27,7 @@ int main(int argc, char **argv) {
   std::string file_geno, file_pheno, file_anno, file_bfile, file_cvt, file_kin, file_kd, file_ku, file_out = "result",
                                                                                                   path_out = "./output";
   std::vector<size_t> p_column;
-  int k_mode = 0, a_mode = 0, inproc = 0;
+  int k_mode = 0, a_mode = 0, inproc = 0, lm_mode = 0;
   bool do_eigen = false;
   const auto t_start = std::chrono::steady_clock::now();
   auto lap = [&]() { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count(); };
@@ -51,6 +51,7 @@ int main(int argc, char **argv) {
     else if (a == "-gk") k_mode = has ? atoi(argv[++i]) : 1;
     else if (a == "-inproc") inproc = has ? atoi(argv[++i]) : 1;
     else if (a == "-lmm") a_mode = has ? atoi(argv[++i]) : 1;
+    else if (a == "-lm") lm_mode = has ? atoi(argv[++i]) : 1;
     else if (a == "-eigen") do_eigen = true;
     else if (a == "-loco" && has) loco = argv[++i];
     else if (a == "-maf" && has) qc.maf_level = atof(argv[++i]);
@@ -114,6 +115,27 @@ int main(int argc, char **argv) {
       std::cout << " ksnps=" << setKSnps.size() << " gwasnps=" << setGWASnps.size();
     }
     if (inproc) std::cout << " t_first_pass=" << lap();
+
+    // ---- -lm (src/gemma.cpp:2475-2555): no kinship ------------------------------------------------------------------
+    if (lm_mode) {
+      Vector yv = vector_view(Yb.data(), ni_test);
+      LM cLm;
+      cLm.a_mode = 50 + lm_mode;
+      cLm.file_bfile = file_bfile;
+      cLm.file_geno = file_geno;
+      cLm.path_out = path_out;
+      cLm.file_out = file_out;
+      cLm.ni_total = ni_total;
+      cLm.indicator_idv = cp.indicator_idv;
+      cLm.indicator_snp = indicator_snp;
+      cLm.snpInfo = snpInfo;
+      if (!file_bfile.empty()) cLm.AnalyzePlink(&W, &yv);
+      else AnalyzeBimbam(cLm, &W, &yv);
+      cLm.WriteFiles();
+      std::cout << " snps=" << cLm.sumStat.size() << std::endl;
+      gemma_hip_shutdown();
+      return 0;
+    }
 
     // ---- -gk (src/gemma.cpp:1900-1926) ----------------------------------------------------------------------------
     if (k_mode) {

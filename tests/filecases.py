@@ -39,7 +39,7 @@ def read_assoc(path):
     return hdr, rows
 
 
-def compare_assoc(got_path, ref_path, n_ref_rows=None):
+def compare_assoc(got_path, ref_path, n_ref_rows=None, n_anno=7):
     """Same header, same SNPs in the same order, identical annotation columns, statistics to the printed digits;
     lambda: >= 98 % to the printed digits, all within 1e-3 (the reference reports the penultimate Newton iterate)."""
     gh, gr = read_assoc(got_path)
@@ -51,8 +51,8 @@ def compare_assoc(got_path, ref_path, n_ref_rows=None):
         assert len(gr) == n_ref_rows
         gr = gr[:len(rr)]
     for g, r in zip(gr, rr):
-        assert g[:7] == r[:7], (g[:7], r[:7])
-    for j in range(7, len(gh)):
+        assert g[:n_anno] == r[:n_anno], (g[:n_anno], r[:n_anno])
+    for j in range(n_anno, len(gh)):
         got = np.array([float(g[j]) for g in gr])
         ref = np.array([float(r[j]) for r in rr])
         both_nan = np.isnan(got) & np.isnan(ref)
@@ -234,3 +234,42 @@ def mvlmm_workflow(exe, out, modes=(1, 4)):
                 got[c] = col[c]
         err = R.mv_row_err(got, R.mv_ref_table(fx, "a", m, 2))
         assert np.mean(err <= STAT_TOL) >= 0.97 and err.max() <= 5e-3, (m, float(np.mean(err <= STAT_TOL)), float(err.max()))
+
+
+def perl_checksum(path):
+    """the one-liner of test/dev_test_suite.sh:52,68: sum over all fields of sprintf('%.2f', substr(field, 0, 6))"""
+    import re
+    num = re.compile(r"^[+-]?(\d+\.?\d*|\.\d+)([eE][+-]?\d+)?")
+    tot = 0.0
+    for line in open(path):
+        for x in line.split():
+            m = num.match(x[:6])
+            if m:
+                tot += float("%.2f" % float(m.group(0)))
+    return tot
+
+
+def lm_workflow(exe, out):
+    """`-lm m` (class LM: no kinship) from BIMBAM text and from PLINK files.  BXD `-lm 4`: the reference's OWN golden for this
+    run -- 95134 words, field checksum 3089042886 (test/dev_test_suite.sh:60-68) -- on the file this driver writes, and every
+    column against the reference binary's output; PLINK subset with covariates against its `-lm 4` file."""
+    out = str(out)
+    base = ["-g", os.path.join(TXT, "BXD_geno.txt.gz"), "-p", os.path.join(TXT, "BXD_pheno.txt"),
+            "-c", os.path.join(TXT, "BXD_covariates2.txt"), "-a", os.path.join(TXT, "BXD_snps.txt.gz"), "-outdir", out]
+    full = np.load(os.path.join(ROOT, "tests", "golden", "ref_bxd.npz"))
+    for m in (1, 2, 3, 4):
+        drive(exe, *base, "-lm", m, "-maf", "0.1", "-o", "LM%d" % m)
+        path = os.path.join(out, "LM%d.assoc.txt" % m)
+        hdr, rows = read_assoc(path)
+        assert hdr[:8] == ["chr", "rs", "ps", "n_mis", "n_obs", "allele1", "allele0", "af"]
+        assert [r[1] for r in rows] == list(full["rs"])
+        for j, name in enumerate(hdr[8:], start=8):
+            got = np.array([float(r[j]) for r in rows])
+            want = full["lm%d_%s" % (m, name)]
+            assert (np.abs(got - want) <= STAT_TOL * np.abs(want)).all(), (m, name)
+        if m == 4:
+            assert len(open(path).read().split()) == 95134
+            assert "%.0f" % perl_checksum(path) == "3089042886"
+    kv = drive(exe, "-bfile", os.path.join(TXT, "P"), "-outdir", out, "-lm", 4, "-c", os.path.join(TXT, "P.cov.txt"), "-o", "Plm4c")
+    check_log(kv, "Plm4c.log.json")
+    compare_assoc(os.path.join(out, "Plm4c.assoc.txt"), os.path.join(TXT, "Plm4c.assoc.txt.gz"), n_anno=8)

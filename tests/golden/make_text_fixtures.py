@@ -41,7 +41,7 @@ def head(src, dst, n):
 def plink_subset(tmp, ni=240, ns=800):
     """The first `ni` individuals x `ns` SNPs of the reference's test/data/issue188/2000 PLINK set (missing calls,
     unphenotyped individuals), re-packed, and what the reference writes for it: cXX (first rows), -lmm 4 with and
-    without covariates."""
+    without covariates, -lmm 1 with tightened filters, -lm 4 with covariates."""
     src = "/root/reference/test/data/issue188/2000"
     fam = [l for l in open(src + ".fam") if l.strip()]
     bim = [l for l in open(src + ".bim") if l.strip()][:ns]
@@ -66,10 +66,11 @@ def plink_subset(tmp, ni=240, ns=800):
     gemma(tmp, "-bfile", "P", "-k", cxx, "-lmm", 4, "-o", "P4")
     gemma(tmp, "-bfile", "P", "-k", cxx, "-lmm", 4, "-c", "P.cov.txt", "-o", "P4c")
     gemma(tmp, "-bfile", "P", "-k", cxx, "-lmm", 1, "-miss", 0.02, "-maf", 0.05, "-o", "P1q")
+    gemma(tmp, "-bfile", "P", "-lm", 4, "-c", "P.cov.txt", "-o", "Plm4c")
     for ext in (".bed", ".bim", ".fam", ".cov.txt"):
         shutil.copy(pre + ext, os.path.join(OUT, "P" + ext))
     head(cxx, os.path.join(OUT, "P.cXX.head.txt"), 8)
-    for tag in ("P4", "P4c", "P1q"):
+    for tag in ("P4", "P4c", "P1q", "Plm4c"):
         with open(os.path.join(tmp, "output", tag + ".assoc.txt"), "rb") as f, \
                 gzip.GzipFile(os.path.join(OUT, tag + ".assoc.txt.gz"), "wb", mtime=0) as g:
             g.write(f.read())

@@ -63,6 +63,11 @@ def test_mvlmm_plink_files_to_reference_outputs(driver, tmp_path, monkeypatch):
     fc.mvlmm_workflow(driver, tmp_path, modes=(1, 4))
 
 
+def test_lm_files_to_reference_outputs_and_golden_checksum(driver, tmp_path, monkeypatch):
+    monkeypatch.setenv("GEMMA_HIP_IO_BLOCK", "1000")
+    fc.lm_workflow(driver, tmp_path)
+
+
 def test_driver_reports_reader_errors(driver, tmp_path):
     """Where the reference's readers return false the driver stops (exit code 3) instead of analysing garbage."""
     bad = tmp_path / "short.txt"

@@ -32,3 +32,7 @@ def test_loco_bimbam_files_to_reference_outputs(driver, tmp_path):
 
 def test_mvlmm_plink_files_to_reference_outputs(driver, tmp_path):
     fc.mvlmm_workflow(driver, tmp_path, modes=(1, 2, 3, 4))
+
+
+def test_lm_files_to_reference_outputs_and_golden_checksum(driver, tmp_path):
+    fc.lm_workflow(driver, tmp_path)
