@@ -385,6 +385,45 @@ inline NullModel CalcLambdaNull(const Vector *eval, const Matrix *UtW, const Vec
   return NullModel{o[0], o[1], o[2], o[3], o[4], o[5], o[6], o[7]};
 }
 
+// Row formatter of the .assoc.txt writers: the reference streams every field through ofstream with std::endl (a flush
+// per SNP); here the same bytes -- `scientific << setprecision(6)` is printf's "%.6e", `fixed << setprecision(3)` is
+// "%.3f" (libstdc++ formats through vsnprintf, so nan / inf spell the same) -- are formatted into per-thread buffers by
+// write_rows() and written in row order.
+class AssocLine {
+public:
+  AssocLine &str(const std::string &s) { buf_ += s; return *this; }
+  AssocLine &tab() { buf_ += '\t'; return *this; }
+  AssocLine &sci(double v) { return fmt("%.6e", v); }
+  AssocLine &fix3(double v) { return fmt("%.3f", v); }
+  AssocLine &num(long v) { char t[32]; buf_.append(t, (size_t)snprintf(t, sizeof t, "%ld", v)); return *this; }
+  AssocLine &unum(size_t v) { char t[32]; buf_.append(t, (size_t)snprintf(t, sizeof t, "%zu", v)); return *this; }
+  void endl() { buf_ += '\n'; }
+  const std::string &text() const { return buf_; }
+  void reserve(size_t n) { buf_.reserve(n); }
+
+private:
+  AssocLine &fmt(const char *f, double v) { char t[64]; buf_.append(t, (size_t)snprintf(t, sizeof t, f, v)); return *this; }
+  std::string buf_;
+};
+
+// rows 0..n-1 through row(ln, r), formatted by up to 16 host threads (GEMMA_HIP_IO_THREADS overrides), written in order
+template <class RowFn> inline void write_rows(std::ofstream &out, size_t n, RowFn row) {
+  unsigned nt = std::thread::hardware_concurrency();
+  if (const char *env = getenv("GEMMA_HIP_IO_THREADS"))
+    if (atoi(env) > 0) nt = (unsigned)atoi(env);
+  nt = (unsigned)std::max<size_t>(1, std::min<size_t>(std::min(nt ? nt : 4u, 16u), n / 2048 + 1));
+  std::vector<AssocLine> part(nt);
+  auto work = [&](unsigned w) {
+    part[w].reserve((n / nt + 1) * 96);
+    for (size_t r = n * w / nt; r < n * (w + 1) / nt; ++r) row(part[w], r);
+  };
+  std::vector<std::thread> pool;
+  for (unsigned w = 1; w < nt; ++w) pool.emplace_back(work, w);
+  work(0);
+  for (std::thread &th : pool) th.join();
+  for (unsigned w = 0; w < nt; ++w) out.write(part[w].text().data(), (std::streamsize)part[w].text().size());
+}
+
 // class LMM, src/lmm.h:49-125 -- the members CopyFromParam fills (src/lmm.cpp:56-90) and the drivers
 class LMM {
 public:
@@ -523,27 +562,29 @@ public:
     case 4: outfile << "beta\tse\tlogl_H1\tl_remle\tl_mle\tp_wald\tp_lrt\tp_score" << std::endl; break;
     case 9: outfile << "beta\tse\tl_mle\tp_lrt" << std::endl; break;
     }
-    size_t t = 0;
+    std::vector<size_t> rows; // snpInfo index of the t-th record of sumStat
     for (size_t i = 0; i < snpInfo.size(); ++i) {
       if (indicator_snp[i] == 0) continue;
       if (!setGWASnps.empty() && setGWASnps.count(snpInfo[i].rs_number) == 0) continue; // src/lmm.cpp:208-210
-      const SNPINFO &s = snpInfo[i];
-      const SUMSTAT &st = sumStat[t];
-      outfile << s.chr << "\t" << s.rs_number << "\t" << s.base_position << "\t" << s.n_miss << "\t" << s.a_minor
-              << "\t" << s.a_major << "\t" << std::fixed << std::setprecision(3) << s.maf << "\t";
-      outfile << std::scientific << std::setprecision(6);
-      switch (a_mode) {
-      case 1: outfile << st.beta << "\t" << st.se << "\t" << st.logl_H1 << "\t" << st.lambda_remle << "\t" << st.p_wald << std::endl; break;
-      case 2: outfile << st.logl_H1 << "\t" << st.lambda_mle << "\t" << st.p_lrt << std::endl; break;
-      case 3: outfile << st.beta << "\t" << st.se << "\t" << st.p_score << std::endl; break;
-      case 4:
-        outfile << st.beta << "\t" << st.se << "\t" << st.logl_H1 << "\t" << st.lambda_remle << "\t" << st.lambda_mle
-                << "\t" << st.p_wald << "\t" << st.p_lrt << "\t" << st.p_score << std::endl;
-        break;
-      case 9: outfile << st.beta << "\t" << st.se << "\t" << st.lambda_mle << "\t" << st.p_lrt << std::endl; break;
-      }
-      t++;
+      rows.push_back(i);
     }
+    write_rows(outfile, std::min(rows.size(), sumStat.size()), [&](AssocLine &ln, size_t t) {
+      const SNPINFO &s = snpInfo[rows[t]];
+      const SUMSTAT &st = sumStat[t];
+      ln.str(s.chr).tab().str(s.rs_number).tab().num(s.base_position).tab().unum(s.n_miss).tab().str(s.a_minor).tab()
+          .str(s.a_major).tab().fix3(s.maf).tab();
+      switch (a_mode) {
+      case 1: ln.sci(st.beta).tab().sci(st.se).tab().sci(st.logl_H1).tab().sci(st.lambda_remle).tab().sci(st.p_wald); break;
+      case 2: ln.sci(st.logl_H1).tab().sci(st.lambda_mle).tab().sci(st.p_lrt); break;
+      case 3: ln.sci(st.beta).tab().sci(st.se).tab().sci(st.p_score); break;
+      case 4:
+        ln.sci(st.beta).tab().sci(st.se).tab().sci(st.logl_H1).tab().sci(st.lambda_remle).tab().sci(st.lambda_mle).tab()
+            .sci(st.p_wald).tab().sci(st.p_lrt).tab().sci(st.p_score);
+        break;
+      case 9: ln.sci(st.beta).tab().sci(st.se).tab().sci(st.lambda_mle).tab().sci(st.p_lrt); break;
+      }
+      ln.endl();
+    });
   }
 
 private:
@@ -635,22 +676,22 @@ public:
     case 53: outfile << "beta\tse\tp_score" << std::endl; break;
     case 54: outfile << "beta\tse\tp_wald\tp_lrt\tp_score" << std::endl; break;
     }
-    size_t t = 0;
-    for (size_t i = 0; i < snpInfo.size(); ++i) {
-      if (indicator_snp[i] == 0) continue;
-      const SNPINFO &s = snpInfo[i];
+    std::vector<size_t> rows;
+    for (size_t i = 0; i < snpInfo.size(); ++i)
+      if (indicator_snp[i] != 0) rows.push_back(i);
+    write_rows(outfile, std::min(rows.size(), sumStat.size()), [&](AssocLine &ln, size_t t) {
+      const SNPINFO &s = snpInfo[rows[t]];
       const SUMSTAT &st = sumStat[t];
-      outfile << s.chr << "\t" << s.rs_number << "\t" << s.base_position << "\t" << s.n_miss << "\t" << ni_test - s.n_miss
-              << "\t" << s.a_minor << "\t" << s.a_major << "\t" << std::fixed << std::setprecision(3) << s.maf << "\t";
-      outfile << std::scientific << std::setprecision(6);
+      ln.str(s.chr).tab().str(s.rs_number).tab().num(s.base_position).tab().unum(s.n_miss).tab().unum(ni_test - s.n_miss).tab()
+          .str(s.a_minor).tab().str(s.a_major).tab().fix3(s.maf).tab();
       switch (a_mode) {
-      case 51: outfile << st.beta << "\t" << st.se << "\t" << st.p_wald << std::endl; break;
-      case 52: outfile << st.p_lrt << std::endl; break;
-      case 53: outfile << st.beta << "\t" << st.se << "\t" << st.p_score << std::endl; break;
-      case 54: outfile << st.beta << "\t" << st.se << "\t" << st.p_wald << "\t" << st.p_lrt << "\t" << st.p_score << std::endl; break;
+      case 51: ln.sci(st.beta).tab().sci(st.se).tab().sci(st.p_wald); break;
+      case 52: ln.sci(st.p_lrt); break;
+      case 53: ln.sci(st.beta).tab().sci(st.se).tab().sci(st.p_score); break;
+      case 54: ln.sci(st.beta).tab().sci(st.se).tab().sci(st.p_wald).tab().sci(st.p_lrt).tab().sci(st.p_score); break;
       }
-      t++;
-    }
+      ln.endl();
+    });
   }
 
 private:
@@ -747,24 +788,24 @@ public:
     case 4: outfile << "p_wald\tp_lrt\tp_score" << std::endl; break;
     }
     const size_t d = n_ph, v = d * (d + 1) / 2, st = stride();
-    size_t t = 0;
-    for (size_t i = 0; i < snpInfo.size(); ++i) {
-      if (indicator_snp[i] == 0) continue;
-      const SNPINFO &s = snpInfo[i];
+    std::vector<size_t> rows;
+    for (size_t i = 0; i < snpInfo.size(); ++i)
+      if (indicator_snp[i] != 0) rows.push_back(i);
+    write_rows(outfile, std::min(rows.size(), sumStat.size() / st), [&](AssocLine &ln, size_t t) {
+      const SNPINFO &s = snpInfo[rows[t]];
       const double *r = &sumStat[t * st];
-      outfile << s.chr << "\t" << s.rs_number << "\t" << s.base_position << "\t" << s.n_miss << "\t" << s.a_minor << "\t"
-              << s.a_major << "\t" << std::fixed << std::setprecision(3) << s.maf << "\t";
-      outfile << std::scientific << std::setprecision(6);
-      for (size_t k = 0; k < d + v; ++k) outfile << r[k] << "\t"; // beta then Vbeta (upper triangle, row by row)
+      ln.str(s.chr).tab().str(s.rs_number).tab().num(s.base_position).tab().unum(s.n_miss).tab().str(s.a_minor).tab()
+          .str(s.a_major).tab().fix3(s.maf).tab();
+      for (size_t k = 0; k < d + v; ++k) ln.sci(r[k]).tab(); // beta then Vbeta (upper triangle, row by row)
       const double p_wald = r[d + 3 * v], p_lrt = r[d + 3 * v + 1], p_score = r[d + 3 * v + 2];
       switch (a_mode) {
-      case 1: outfile << p_wald << std::endl; break;
-      case 2: outfile << p_lrt << std::endl; break;
-      case 3: outfile << p_score << std::endl; break;
-      case 4: outfile << p_wald << "\t" << p_lrt << "\t" << p_score << std::endl; break;
+      case 1: ln.sci(p_wald); break;
+      case 2: ln.sci(p_lrt); break;
+      case 3: ln.sci(p_score); break;
+      case 4: ln.sci(p_wald).tab().sci(p_lrt).tab().sci(p_score); break;
       }
-      t++;
-    }
+      ln.endl();
+    });
   }
 
 private:

@@ -11,6 +11,7 @@
 //                                  BimbamReader blocks appended to out.bin (raw doubles), "rs minor major" per row
 //   eigen <U-in> <D-in> <n> <outdir> <name>     ReadFile_eigenU/D -> WriteEigen
 //   assoc <assoc-in> <a_mode> <outdir> <name>   parse a reference .assoc.txt, LMM::WriteFiles it again
+//   assocbench <a_mode> <n_snps> <outdir>       wall time of LMM::WriteFiles on n_snps synthetic records
 //   kin <cXX-in> <n> <out>                      ReadFile_kin (all individuals) -> WriteMatrix
 //   plinkgen <prefix> <ni> <ns> [threads [n_ph]]  synthetic PLINK set (n_ph correlated traits in .fam columns 6..): two sub-populations, maf ~ U(0.1, 0.45) +- 0.075, 1 % missing calls,
 //                                               y = 0.3 * (first 20 SNPs) + 0.8 * population + N(0,1), 2 % of the phenotypes -9
@@ -300,6 +301,28 @@ int main(int argc, char **argv) {
     ReadFile_kin(argv[2], ind, error, &G);
     if (error) return 1;
     return WriteMatrix(&G, argv[4]) ? 0 : 1;
+  }
+  if (cmd == "assocbench") {
+    LMM lmm;
+    lmm.a_mode = atoi(argv[2]);
+    const size_t ns = strtoul(argv[3], nullptr, 10);
+    lmm.path_out = argv[4];
+    lmm.file_out = "bench";
+    for (size_t t = 0; t < ns; ++t) {
+      SNPINFO s;
+      s.chr = "1"; s.rs_number = "rs" + std::to_string(t); s.cM = 0; s.base_position = (long)t + 1; s.a_minor = "A";
+      s.a_major = "G"; s.n_miss = t % 300; s.missingness = 0; s.maf = 0.05 + 0.45 * (double)(t % 1000) / 1000.0; s.n_idv = 0;
+      s.n_nb = 0; s.file_position = t;
+      lmm.snpInfo.push_back(s);
+      lmm.indicator_snp.push_back(1);
+      const double x = 1e-3 * (double)(t % 7919) + 1e-7;
+      SUMSTAT st = {0.3 - x, 0.02 + x * 1e-2, 1.5 + x, 1.4 + x, x * 1e-20, x * 1e-3, x * 1e-2, -32000.0 - x};
+      lmm.sumStat.push_back(st);
+    }
+    const auto t0 = std::chrono::steady_clock::now();
+    lmm.WriteFiles();
+    printf("WriteFiles %zu records: %.3f s\n", ns, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+    return 0;
   }
   if (cmd == "assoc") {
     LMM lmm;
