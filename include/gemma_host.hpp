@@ -295,6 +295,47 @@ inline bool BimbamKin(const std::string file_geno, std::vector<int> &indicator_s
   return true;
 }
 
+// Row formatter of the text writers (.assoc.txt, cXX / eigen matrices): the reference streams every field through ofstream with std::endl (a flush
+// per SNP); here the same bytes -- `scientific << setprecision(6)` is printf's "%.6e", `fixed << setprecision(3)` is
+// "%.3f" (libstdc++ formats through vsnprintf, so nan / inf spell the same) -- are formatted into per-thread buffers by
+// write_rows() and written in row order.
+class AssocLine {
+public:
+  AssocLine &str(const std::string &s) { buf_ += s; return *this; }
+  AssocLine &tab() { buf_ += '\t'; return *this; }
+  AssocLine &sci(double v) { return fmt("%.6e", v); }
+  AssocLine &fix3(double v) { return fmt("%.3f", v); }
+  AssocLine &g10(double v) { return fmt("%.10g", v); } // ostream default float format at precision(10)
+  AssocLine &num(long v) { char t[32]; buf_.append(t, (size_t)snprintf(t, sizeof t, "%ld", v)); return *this; }
+  AssocLine &unum(size_t v) { char t[32]; buf_.append(t, (size_t)snprintf(t, sizeof t, "%zu", v)); return *this; }
+  void endl() { buf_ += '\n'; }
+  const std::string &text() const { return buf_; }
+  void reserve(size_t n) { buf_.reserve(n); }
+
+private:
+  AssocLine &fmt(const char *f, double v) { char t[64]; buf_.append(t, (size_t)snprintf(t, sizeof t, f, v)); return *this; }
+  std::string buf_;
+};
+
+// rows 0..n-1 through row(ln, r), formatted by up to 16 host threads (GEMMA_HIP_IO_THREADS overrides), written in order
+template <class RowFn> inline void write_rows(std::ofstream &out, size_t n, RowFn row, size_t approx_row_bytes = 96) {
+  unsigned nt = std::thread::hardware_concurrency();
+  if (const char *env = getenv("GEMMA_HIP_IO_THREADS"))
+    if (atoi(env) > 0) nt = (unsigned)atoi(env);
+  nt = (unsigned)std::max<size_t>(1, std::min<size_t>(std::min<size_t>(nt ? nt : 4u, 16u),
+                                                       std::min<size_t>(n, n * approx_row_bytes / (size_t(1) << 18) + 1)));
+  std::vector<AssocLine> part(nt);
+  auto work = [&](unsigned w) {
+    part[w].reserve((n / nt + 1) * approx_row_bytes);
+    for (size_t r = n * w / nt; r < n * (w + 1) / nt; ++r) row(part[w], r);
+  };
+  std::vector<std::thread> pool;
+  for (unsigned w = 1; w < nt; ++w) pool.emplace_back(work, w);
+  work(0);
+  for (std::thread &th : pool) th.join();
+  for (unsigned w = 0; w < nt; ++w) out.write(part[w].text().data(), (std::streamsize)part[w].text().size());
+}
+
 // PARAM::WriteMatrix / WriteVector, src/param.cpp:1886-1935: tab-separated text, precision(10)
 inline bool WriteMatrix(const Matrix *M, const std::string &file_str) {
   std::ofstream outfile(file_str.c_str(), std::ofstream::out);
@@ -302,10 +343,17 @@ inline bool WriteMatrix(const Matrix *M, const std::string &file_str) {
     std::cout << "error writing file: " << file_str << std::endl;
     return false;
   }
-  outfile.precision(10);
-  for (size_t i = 0; i < M->size1; ++i) {
-    for (size_t j = 0; j < M->size2; ++j) outfile << (j ? "\t" : "") << M->data[i * M->tda + j];
-    outfile << std::endl;
+  // bands of rows, each formatted by the thread pool (about 64 MiB of text per band)
+  const size_t band = std::max<size_t>(1, (size_t(64) << 20) / (14 * std::max<size_t>(M->size2, 1)));
+  for (size_t i0 = 0; i0 < M->size1; i0 += band) {
+    write_rows(outfile, std::min(band, M->size1 - i0), [&](AssocLine &ln, size_t r) {
+      const double *row = M->data + (i0 + r) * M->tda;
+      for (size_t j = 0; j < M->size2; ++j) {
+        if (j) ln.tab();
+        ln.g10(row[j]);
+      }
+      ln.endl();
+    }, 14 * M->size2);
   }
   return true;
 }
@@ -383,45 +431,6 @@ inline NullModel CalcLambdaNull(const Vector *eval, const Matrix *UtW, const Vec
                                  trace_G, o),
               "CalcLambda (null)");
   return NullModel{o[0], o[1], o[2], o[3], o[4], o[5], o[6], o[7]};
-}
-
-// Row formatter of the .assoc.txt writers: the reference streams every field through ofstream with std::endl (a flush
-// per SNP); here the same bytes -- `scientific << setprecision(6)` is printf's "%.6e", `fixed << setprecision(3)` is
-// "%.3f" (libstdc++ formats through vsnprintf, so nan / inf spell the same) -- are formatted into per-thread buffers by
-// write_rows() and written in row order.
-class AssocLine {
-public:
-  AssocLine &str(const std::string &s) { buf_ += s; return *this; }
-  AssocLine &tab() { buf_ += '\t'; return *this; }
-  AssocLine &sci(double v) { return fmt("%.6e", v); }
-  AssocLine &fix3(double v) { return fmt("%.3f", v); }
-  AssocLine &num(long v) { char t[32]; buf_.append(t, (size_t)snprintf(t, sizeof t, "%ld", v)); return *this; }
-  AssocLine &unum(size_t v) { char t[32]; buf_.append(t, (size_t)snprintf(t, sizeof t, "%zu", v)); return *this; }
-  void endl() { buf_ += '\n'; }
-  const std::string &text() const { return buf_; }
-  void reserve(size_t n) { buf_.reserve(n); }
-
-private:
-  AssocLine &fmt(const char *f, double v) { char t[64]; buf_.append(t, (size_t)snprintf(t, sizeof t, f, v)); return *this; }
-  std::string buf_;
-};
-
-// rows 0..n-1 through row(ln, r), formatted by up to 16 host threads (GEMMA_HIP_IO_THREADS overrides), written in order
-template <class RowFn> inline void write_rows(std::ofstream &out, size_t n, RowFn row) {
-  unsigned nt = std::thread::hardware_concurrency();
-  if (const char *env = getenv("GEMMA_HIP_IO_THREADS"))
-    if (atoi(env) > 0) nt = (unsigned)atoi(env);
-  nt = (unsigned)std::max<size_t>(1, std::min<size_t>(std::min(nt ? nt : 4u, 16u), n / 2048 + 1));
-  std::vector<AssocLine> part(nt);
-  auto work = [&](unsigned w) {
-    part[w].reserve((n / nt + 1) * 96);
-    for (size_t r = n * w / nt; r < n * (w + 1) / nt; ++r) row(part[w], r);
-  };
-  std::vector<std::thread> pool;
-  for (unsigned w = 1; w < nt; ++w) pool.emplace_back(work, w);
-  work(0);
-  for (std::thread &th : pool) th.join();
-  for (unsigned w = 0; w < nt; ++w) out.write(part[w].text().data(), (std::streamsize)part[w].text().size());
 }
 
 // class LMM, src/lmm.h:49-125 -- the members CopyFromParam fills (src/lmm.cpp:56-90) and the drivers

@@ -465,9 +465,12 @@ public:
   struct Row {
     std::string rs, minor, major;
   };
-  BimbamReader(const std::string &path, size_t ni_total, unsigned n_threads = 0)
+  // skip_fields: leading tokens that are not values (3 for BIMBAM: rs, allele, allele; 0 for a plain matrix such as the
+  // kinship file); strict_columns: a line with more than skip_fields + ni_total tokens is malformed
+  BimbamReader(const std::string &path, size_t ni_total, unsigned n_threads = 0, int skip_fields = 3,
+               bool strict_columns = false)
       : f_(gzopen(path.c_str(), "rb")), ni_total_(ni_total), n_threads_(n_threads ? n_threads : default_threads()),
-        line_no_(0), beg_(0), end_(0), eof_(false), buf_(nullptr), cap_(0) {
+        skip_(skip_fields), strict_(strict_columns), line_no_(0), beg_(0), end_(0), eof_(false), buf_(nullptr), cap_(0) {
     if (f_) gzbuffer(f_, 1 << 20);
   }
   ~BimbamReader() {
@@ -543,7 +546,7 @@ public:
     }
     for (int b : bad)
       if (b) {
-        std::cout << "Problem reading geno file (not enough genotypes in line)" << std::endl;
+        if (skip_) std::cout << "Problem reading geno file (not enough genotypes in line)" << std::endl;
         return (size_t)-1;
       }
     return l;
@@ -582,7 +585,7 @@ private:
   }
   bool parse_line(const char *p, const char *end, double *x, Row *row, const int *cols) const {
     const char *b, *e;
-    for (int k = 0; k < 3; ++k) {
+    for (int k = 0; k < skip_; ++k) {
       if (!detail::next_token(p, end, b, e)) return false;
       if (row) (k == 0 ? row->rs : k == 1 ? row->minor : row->major).assign(b, e);
     }
@@ -590,13 +593,16 @@ private:
     for (size_t i = 0; i < ni_total_; ++i) {
       if (!detail::next_token(p, end, b, e)) return false;
       if (cols && cols[i] == 0) continue;
-      x[o++] = detail::tok_is_na(b, e) ? std::numeric_limits<double>::quiet_NaN() : parse_double(b, e);
+      // plain matrices go through atof alone ("NA" -> 0.0 as in the reference's kinship reader)
+      x[o++] = (skip_ && detail::tok_is_na(b, e)) ? std::numeric_limits<double>::quiet_NaN() : parse_double(b, e);
     }
-    return true;
+    return !(strict_ && detail::next_token(p, end, b, e));
   }
   gzFile f_;
   size_t ni_total_;
   unsigned n_threads_;
+  int skip_;
+  bool strict_;
   size_t line_no_, beg_, end_;
   bool eof_;
   char *buf_;
@@ -832,6 +838,43 @@ inline void AnalyzeBimbam(LM &lm, const Matrix *W, const Vector *y) {
     return l;
   };
   lm.AnalyzeFeed(W, y, feed, B, n);
+}
+
+// ReadFile_kin (k_mode == 1), src/gemma_io.cpp:1186-1243, on the thread pool: the same dense ni_total x ni_total text,
+// rows and columns of non-analysed individuals dropped while parsing, straight into G (the serial twin is
+// gemma_host.hpp's ReadFile_kin; at n = 20 000 the file holds 4e8 numbers)
+inline void ReadFile_kin_threaded(const std::string &file_kin, std::vector<int> &indicator_idv, bool &error, Matrix *G) {
+  const size_t ni_total = indicator_idv.size();
+  BimbamReader rd(file_kin, ni_total, 0, 0, true);
+  if (!rd.ok()) {
+    std::cout << "error! fail to open kinship file: " << file_kin << std::endl;
+    error = true;
+    return;
+  }
+  size_t i_test = 0;
+  while (i_test < G->size1) {
+    const size_t l = rd.read_block(G->size1 - i_test, G->data + i_test * G->tda, G->tda, nullptr, &indicator_idv,
+                                   indicator_idv.data());
+    if (l == (size_t)-1) {
+      std::cout << "number of columns in the kinship file does not match the number of individuals" << std::endl;
+      error = true;
+      return;
+    }
+    if (l == 0) break;
+    i_test += l;
+  }
+  // whatever is left must be rows of non-analysed individuals, and the file must end with row ni_total
+  std::vector<double> rest(G->size2 ? G->size2 : 1);
+  while (rd.lines_read() < ni_total) {
+    const size_t before = rd.lines_read();
+    const size_t l = rd.read_block(1, rest.data(), rest.size(), nullptr, &indicator_idv, indicator_idv.data());
+    if (l == (size_t)-1 || (l == 0 && rd.lines_read() == before)) break;
+  }
+  std::vector<double> extra(ni_total ? ni_total : 1);
+  if (i_test != G->size1 || rd.lines_read() != ni_total || rd.read_block(1, extra.data(), extra.size()) != 0) {
+    std::cout << "number of rows in the kinship file does not match the number of individuals." << std::endl;
+    error = true;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------------

@@ -177,7 +177,7 @@ int main(int argc, char **argv) {
     } else if (!file_kin.empty()) {
       std::vector<double> Gb(ni_test * ni_test);
       Matrix G = matrix_view(Gb.data(), ni_test, ni_test);
-      ReadFile_kin(file_kin, cp.indicator_idv, error, &G);
+      ReadFile_kin_threaded(file_kin, cp.indicator_idv, error, &G);
       if (error) return 5;
       CenterMatrix(&G);
       trace_G = EigenDecomp_Zeroed(&G, &U, &eval, 0);

@@ -12,6 +12,7 @@
 //   eigen <U-in> <D-in> <n> <outdir> <name>     ReadFile_eigenU/D -> WriteEigen
 //   assoc <assoc-in> <a_mode> <outdir> <name>   parse a reference .assoc.txt, LMM::WriteFiles it again
 //   assocbench <a_mode> <n_snps> <outdir>       wall time of LMM::WriteFiles on n_snps synthetic records
+//   kinbench <n> <file>                         wall time of WriteMatrix + ReadFile_kin on an n x n matrix
 //   kin <cXX-in> <n> <out>                      ReadFile_kin (all individuals) -> WriteMatrix
 //   plinkgen <prefix> <ni> <ns> [threads [n_ph]]  synthetic PLINK set (n_ph correlated traits in .fam columns 6..): two sub-populations, maf ~ U(0.1, 0.45) +- 0.075, 1 % missing calls,
 //                                               y = 0.3 * (first 20 SNPs) + 0.8 * population + N(0,1), 2 % of the phenotypes -9
@@ -292,13 +293,50 @@ int main(int argc, char **argv) {
     if (error) return 1;
     return WriteEigen(&U, &D, argv[5], argv[6]) ? 0 : 1;
   }
+  if (cmd == "kinbench") {
+    const size_t n = strtoul(argv[2], nullptr, 10);
+    std::vector<double> Gb(n * n), Hb(n * n);
+    unsigned long long st = 99;
+    for (double &v : Gb) { st ^= st << 13; st ^= st >> 7; st ^= st << 17; v = ((double)(st >> 11) / 9007199254740992.0 - 0.5) * 0.3; }
+    Matrix G = matrix_view(Gb.data(), n, n), H = matrix_view(Hb.data(), n, n);
+    auto t0 = std::chrono::steady_clock::now();
+    if (!WriteMatrix(&G, argv[3])) return 1;
+    const double tw = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    std::vector<int> ind(n, 1);
+    bool error = false;
+    t0 = std::chrono::steady_clock::now();
+    ReadFile_kin(argv[3], ind, error, &H);
+    const double tr1 = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    std::vector<double> H1(Hb);
+    t0 = std::chrono::steady_clock::now();
+    ReadFile_kin_threaded(argv[3], ind, error, &H);
+    const double tr = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (error || memcmp(H1.data(), Hb.data(), n * n * 8) != 0) return 1;
+    printf("ReadFile_kin serial %.3f s; ", tr1);
+    double worst = 0;
+    for (size_t i = 0; i < n * n; ++i) worst = std::max(worst, std::fabs(Hb[i] - Gb[i]));
+    printf("n %zu WriteMatrix %.3f s ReadFile_kin %.3f s max |read - written| %.3e\n", n, tw, tr, worst);
+    return 0;
+  }
   if (cmd == "kin") {
     const size_t n = strtoul(argv[3], nullptr, 10);
     std::vector<double> Gb(n * n);
     Matrix G = matrix_view(Gb.data(), n, n);
     std::vector<int> ind(n, 1);
     bool error = false;
-    ReadFile_kin(argv[2], ind, error, &G);
+    if (argc > 5) { // kin <in> <n_total> <out> <indicator-file>: threaded reader with individuals dropped
+      ind = read_ints(argv[5]);
+      size_t nt = 0;
+      for (int v : ind) nt += v != 0;
+      std::vector<double> Sb(nt * nt), S2(nt * nt);
+      Matrix S = matrix_view(Sb.data(), nt, nt), T = matrix_view(S2.data(), nt, nt);
+      ReadFile_kin_threaded(argv[2], ind, error, &S);
+      if (error) return 1;
+      ReadFile_kin(argv[2], ind, error, &T);
+      if (error || memcmp(Sb.data(), S2.data(), nt * nt * 8) != 0) return 3;
+      return WriteMatrix(&S, argv[4]) ? 0 : 1;
+    }
+    ReadFile_kin_threaded(argv[2], ind, error, &G);
     if (error) return 1;
     return WriteMatrix(&G, argv[4]) ? 0 : 1;
   }

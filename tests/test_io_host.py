@@ -247,6 +247,33 @@ def test_kinship_text_byte_identical_to_reference(exe, tmp_path):
     assert open(tmp_path / "k.txt", "rb").read() == open(src, "rb").read()
 
 
+def test_threaded_kinship_reader_drops_individuals_and_rejects_bad_files(exe, tmp_path):
+    """ReadFile_kin_threaded == ReadFile_kin bit for bit (the harness compares them) with rows / columns of non-analysed
+    individuals dropped; a row with a surplus column, a missing row and a surplus row are errors as in the reference."""
+    rng = np.random.default_rng(9)
+    n = 57
+    K = rng.standard_normal((n, n))
+    src = tmp_path / "k.txt"
+    src.write_text("\n".join("\t".join("%.10g" % v for v in r) for r in K) + "\n")
+    ind = (rng.random(n) < 0.7).astype(int)
+    (tmp_path / "ind.txt").write_text(" ".join(map(str, ind)))
+    run(exe, "kin", src, n, tmp_path / "sub.txt", tmp_path / "ind.txt")
+    got = np.loadtxt(tmp_path / "sub.txt")
+    want = np.loadtxt(src)[ind == 1][:, ind == 1]
+    assert np.array_equal(got, want)
+    lines = src.read_text().strip().split("\n")
+    bad = tmp_path / "bad1.txt"
+    r = int(np.flatnonzero(ind == 1)[5])  # rows of dropped individuals are skipped unparsed, as in the reference
+    bad.write_text("\n".join(lines[:r] + [lines[r] + "\t0.5"] + lines[r + 1:]) + "\n")
+    assert run(exe, "kin", bad, n, tmp_path / "o.txt", tmp_path / "ind.txt", ok=False).returncode == 1
+    bad.write_text("\n".join(lines[:-1]) + "\n")
+    assert run(exe, "kin", bad, n, tmp_path / "o.txt", tmp_path / "ind.txt", ok=False).returncode == 1
+    bad.write_text("\n".join(lines + [lines[0]]) + "\n")
+    assert run(exe, "kin", bad, n, tmp_path / "o.txt", tmp_path / "ind.txt", ok=False).returncode == 1
+    bad.write_text("\n".join(lines[:r] + ["\t".join(lines[r].split("\t")[:-1])] + lines[r + 1:]) + "\n")
+    assert run(exe, "kin", bad, n, tmp_path / "o.txt", tmp_path / "ind.txt", ok=False).returncode == 1
+
+
 @pytest.mark.parametrize("mode", [1, 2, 3, 4, 9])
 def test_assoc_writer_byte_identical_to_reference(exe, tmp_path, mode):
     """LMM::WriteFiles (src/lmm.cpp:101-225): header, column order and number formats of every -lmm mode, on the
