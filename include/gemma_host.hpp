@@ -484,6 +484,39 @@ public:
     finish();
   }
 
+  // AnalyzePlinkGXE, src/lmm.cpp:2427-2608 (`-gxe`): covariates [W, env, x_s], tested variable x_s . env; env over the
+  // ni_test analysed individuals.  (The reference's BIMBAM twin opens file_gene instead of file_geno, :2289, and cannot run.)
+  void AnalyzePlinkGXE(const Matrix *U, const Vector *eval, const Matrix *UtW, const Vector *Uty, const Vector *env) {
+    const std::string file_bed = file_bfile + ".bed";
+    std::ifstream infile(file_bed.c_str(), std::ios::binary);
+    if (!infile) throw std::runtime_error("error reading bed file");
+    setup(U, eval, UtW, Uty, 1);
+    enforce_hip(gemma_hip_lmm_set_indicator(indicator_idv.data(), indicator_idv.size()), "AnalyzePlinkGXE");
+    std::vector<double> e(env->size);
+    for (size_t i = 0; i < env->size; ++i) e[i] = env->data[i * env->stride];
+    enforce_hip(gemma_hip_lmm_set_env(e.data()), "AnalyzePlinkGXE");
+    const size_t n_bit = (ni_total + 3) / 4, B = io_block_rows(LMM_BATCH_SIZE);
+    std::vector<gemma_sumstat> out(B);
+    size_t t_next = 0;
+    const std::vector<int> keep = analysed_snps();
+    BlockPrefetch pf(B * n_bit, [&](void *slot, int) {
+      return read_bed_rows(infile, keep, t_next, n_bit, static_cast<unsigned char *>(slot), B);
+    });
+    for (;;) {
+      void *slot = nullptr;
+      const size_t l = pf.next(slot);
+      if (l == (size_t)-1) throw std::runtime_error("error reading bed file (truncated)");
+      if (l == 0) break;
+      enforce_hip(gemma_hip_lmm_gxe_batch(GEMMA_GENO_PLINK_2BIT, slot, l, n_bit, out.data()), "AnalyzePlinkGXE");
+      for (size_t i = 0; i < l; ++i) {
+        SUMSTAT SNPs = {out[i].beta, out[i].se, out[i].lambda_remle, out[i].lambda_mle,
+                        out[i].p_wald, out[i].p_lrt, out[i].p_score, out[i].logl_H1};
+        sumStat.push_back(SNPs);
+      }
+    }
+    finish();
+  }
+
   // LMM::Analyze with a caller-supplied SNP-major block source (the fetch_snp closure of src/lmm.cpp:1675-1700
   // factored out): X rows = analysed SNPs over the ni_test analysed individuals, NaN = missing
   void AnalyzeRows(const Matrix *U, const Vector *eval, const Matrix *UtW, const Vector *Uty, const double *X,

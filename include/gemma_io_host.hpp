@@ -157,6 +157,36 @@ inline bool tok_is_na(const char *b, const char *e) { return e - b == 2 && b[0] 
 // ---------------------------------------------------------------------------------------------------------------
 // phenotypes, covariates, annotation
 // ---------------------------------------------------------------------------------------------------------------
+// ReadFile_column, src/gemma_io.cpp:344-383: one column of a text file (the -gxe / -widv inputs); "NA" -> indicator 0
+inline bool ReadFile_column(const std::string &file_pheno, std::vector<int> &indicator_idv, std::vector<double> &pheno,
+                            const int &p_column) {
+  indicator_idv.clear();
+  pheno.clear();
+  TextFile infile(file_pheno);
+  if (!infile.ok()) {
+    std::cout << "error! fail to open phenotype file: " << file_pheno << std::endl;
+    return false;
+  }
+  std::string line;
+  while (infile.getline(line)) {
+    const char *p = line.data(), *end = p + line.size(), *b = nullptr, *e = nullptr;
+    bool have = false;
+    for (int i = 0; i < p_column; ++i) have = detail::next_token(p, end, b, e);
+    if (!have) {
+      std::cout << "Problem reading PHENO column" << std::endl;
+      return false;
+    }
+    if (detail::tok_is_na(b, e)) {
+      indicator_idv.push_back(0);
+      pheno.push_back(-9);
+    } else {
+      indicator_idv.push_back(1);
+      pheno.push_back(parse_double(b, e));
+    }
+  }
+  return true;
+}
+
 // ReadFile_pheno, src/gemma_io.cpp:386-444: BIMBAM phenotype file, p_column = 1-based columns; "NA" -> indicator 0, -9
 inline bool ReadFile_pheno(const std::string &file_pheno, std::vector<std::vector<int>> &indicator_pheno,
                            std::vector<std::vector<double>> &pheno, const std::vector<size_t> &p_column) {
@@ -375,6 +405,8 @@ struct CvtPhen {
   std::vector<std::vector<double>> pheno;
   std::vector<int> indicator_cvt;
   std::vector<std::vector<double>> cvt;
+  std::vector<int> indicator_gxe; // -gxe: environment variable per individual (src/param.cpp:228-233)
+  std::vector<double> gxe;
   std::vector<int> indicator_idv;
   size_t n_cvt = 0, ni_test = 0;
   bool error = false;
@@ -411,7 +443,7 @@ struct CvtPhen {
     }
   }
 
-  // PARAM::ProcessCvtPhen, src/param.cpp:1993-2098 (no -gxe / -widv / subsampling here)
+  // PARAM::ProcessCvtPhen, src/param.cpp:1993-2098 (no -widv / subsampling here)
   void ProcessCvtPhen() {
     indicator_idv.clear();
     for (size_t i = 0; i < indicator_pheno.size(); i++) {
@@ -422,6 +454,8 @@ struct CvtPhen {
     }
     if (!indicator_cvt.empty())
       for (size_t i = 0; i < indicator_idv.size(); ++i) indicator_idv[i] *= indicator_cvt[i];
+    if (!indicator_gxe.empty()) // individuals with a missing environment value leave the analysis (:2016-2020)
+      for (size_t i = 0; i < indicator_idv.size(); ++i) indicator_idv[i] *= indicator_gxe[i];
     ni_test = 0;
     for (size_t i = 0; i < indicator_idv.size(); ++i) ni_test += indicator_idv[i] != 0;
     if (ni_test == 0) {
@@ -435,6 +469,13 @@ struct CvtPhen {
       indicator_cvt.assign(indicator_idv.size(), 1);
       n_cvt = 1;
     }
+  }
+
+  // PARAM::CopyGxe, src/param.cpp:2116-2128
+  void CopyGxe(std::vector<double> &env) const {
+    env.clear();
+    for (size_t i = 0; i < indicator_idv.size(); ++i)
+      if (indicator_idv[i] != 0 && indicator_gxe[i] != 0) env.push_back(gxe[i]);
   }
 
   // PARAM::CopyCvtPhen (flag 0), src/param.cpp:2146-2198: W (ni_test x n_cvt), Y (ni_test x n_ph) of the analysed

@@ -30,6 +30,9 @@ typedef struct {
 void orc_lmm_batch(int a_mode, size_t n, size_t c, const double *eval, const double *UtW, const double *Uty,
                    const double *UtX, size_t l, double l_min, double l_max, size_t n_region, double l_mle_null,
                    double logl_mle_H0, int plink_nan_rule, double *carry, orc_sumstat *out, long *diag);
+void orc_gxe_batch(int a_mode, size_t n, size_t c, const double *eval, const double *UtWe, const double *Uty,
+                   const double *UtX, const double *UtZ, const int *flip, size_t l, double l_min, double l_max,
+                   size_t n_region, double l_mle_null, orc_sumstat *out);
 void orc_lm_batch(int a_mode, size_t n, size_t c, const double *W, const double *WtWi, const double *y, const double *X,
                   size_t l, orc_sumstat *out);
 void orc_impute_mean(double *X, size_t l, size_t n);
@@ -74,6 +77,7 @@ struct Lmm {
   gemma_lmm_cfg cfg;
   std::vector<double> U, eval, UtW, Uty, carry;
   std::vector<int> ind;
+  std::vector<double> env, UtWe; // -gxe: environment variable, [U^T W | U^T env] (n x (c + 1))
   // multivariate: phenotypes and covariates transposed (d x n, c x n: the oracle's layout), null fit, options
   size_t d = 0;
   std::vector<double> Yt, Wt;
@@ -327,6 +331,7 @@ int gemma_hip_lmm_setup(const gemma_lmm_cfg *cfg, const double *U, const double 
   g_lmm.Uty.assign(Uty, Uty + n);
   g_lmm.carry.assign(2, 0.0);
   g_lmm.ind.clear();
+  g_lmm.env.clear();
   g_lmm.d = 0;
   return GEMMA_HIP_OK;
 }
@@ -452,6 +457,50 @@ int gemma_hip_lm_finish(void) {
 
 // referenced by inline members of class LMM the driver does not call (the linker still wants them with -O0)
 int gemma_hip_lmm_gene_batch(const double *, size_t, size_t, gemma_sumstat *) { return fail(GEMMA_HIP_EINVAL, "not in the double"); }
-int gemma_hip_lmm_set_env(const double *) { return fail(GEMMA_HIP_EINVAL, "not in the double"); }
-int gemma_hip_lmm_gxe_batch(int, const void *, size_t, size_t, gemma_sumstat *) { return fail(GEMMA_HIP_EINVAL, "not in the double"); }
+
+// ---- -gxe over orc_gxe_batch (feeder part as in LMM::AnalyzePlinkGXE, src/lmm.cpp:2490-2538) -------------------------
+int gemma_hip_lmm_set_env(const double *env) {
+  if (!g_lmm.on) return fail(GEMMA_HIP_ESTATE, "lmm_set_env before lmm_setup");
+  const size_t n = g_lmm.cfg.n, c = g_lmm.cfg.n_cvt;
+  g_lmm.env.assign(env, env + n);
+  std::vector<double> Ute(n, 0.0);
+  for (size_t i = 0; i < n; ++i)
+    for (size_t k = 0; k < n; ++k) Ute[k] += g_lmm.U[i * n + k] * env[i];
+  g_lmm.UtWe.assign(n * (c + 1), 0.0);
+  for (size_t i = 0; i < n; ++i) {
+    for (size_t a = 0; a < c; ++a) g_lmm.UtWe[i * (c + 1) + a] = g_lmm.UtW[i * c + a];
+    g_lmm.UtWe[i * (c + 1) + c] = Ute[i];
+  }
+  return GEMMA_HIP_OK;
+}
+int gemma_hip_lmm_gxe_batch(int kind, const void *geno, size_t l, size_t ld, gemma_sumstat *out) {
+  if (!g_lmm.on || g_lmm.env.empty()) return fail(GEMMA_HIP_ESTATE, "lmm_gxe_batch before lmm_set_env");
+  const size_t n = g_lmm.cfg.n, c = g_lmm.cfg.n_cvt;
+  std::vector<double> X;
+  if (kind == GEMMA_GENO_PLINK_2BIT)
+    decode(kind, geno, l, ld, g_lmm.ind.empty() ? nullptr : g_lmm.ind.data(), g_lmm.ind.empty() ? n : g_lmm.ind.size(), n, X);
+  else
+    decode(kind, geno, l, ld, nullptr, n, n, X);
+  std::vector<int> flip(l, 0);
+  for (size_t s = 0; s < l; ++s) { // x_mean over the non-missing calls decides the 2 - x recoding (:2519-2536)
+    double tot = 0.0;
+    size_t cnt = 0;
+    for (size_t i = 0; i < n; ++i)
+      if (X[s * n + i] == X[s * n + i]) { tot += X[s * n + i]; ++cnt; }
+    flip[s] = cnt && tot / (double)cnt > 1.0;
+  }
+  orc_impute_mean(X.data(), l, n);
+  std::vector<double> Z(l * n), UtX(l * n), UtZ(l * n);
+  for (size_t s = 0; s < l; ++s)
+    for (size_t i = 0; i < n; ++i) {
+      if (flip[s]) X[s * n + i] = 2.0 - X[s * n + i];
+      Z[s * n + i] = X[s * n + i] * g_lmm.env[i];
+    }
+  gemma_hip_dgemm('N', 'N', l, n, n, 1.0, X.data(), n, g_lmm.U.data(), n, 0.0, UtX.data(), n);
+  gemma_hip_dgemm('N', 'N', l, n, n, 1.0, Z.data(), n, g_lmm.U.data(), n, 0.0, UtZ.data(), n);
+  orc_gxe_batch(g_lmm.cfg.a_mode, n, c, g_lmm.eval.data(), g_lmm.UtWe.data(), g_lmm.Uty.data(), UtX.data(), UtZ.data(),
+                flip.data(), l, g_lmm.cfg.l_min, g_lmm.cfg.l_max, g_lmm.cfg.n_region, g_lmm.cfg.l_mle_null,
+                reinterpret_cast<orc_sumstat *>(out));
+  return GEMMA_HIP_OK;
+}
 }

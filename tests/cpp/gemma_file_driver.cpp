@@ -3,7 +3,7 @@
 //
 //   gemma_file_driver (-g geno[.gz] -p pheno [-a anno] | -bfile prefix) [-c cvt] [-n col [col ...]]
 //                     (-gk [1|2] | -k kin (-eigen | -lmm [1|2|3|4|9]) | -d eigenD -u eigenU -lmm m | -lm [1|2|3|4])
-//                     [-maf x] [-miss x] [-hwe x] [-r2 x] [-loco chr] [-o name] [-outdir dir]
+//                     [-maf x] [-miss x] [-hwe x] [-r2 x] [-loco chr] [-gxe env] [-o name] [-outdir dir]
 //   gemma_file_driver -bfile prefix -inproc [1|2] -lmm m ...   kinship, eigendecomposition and association in ONE
 //                     process: K never becomes text; wall seconds of every stage on the log line
 //
@@ -23,7 +23,7 @@
 using namespace gemma_amd;
 
 int main(int argc, char **argv) {
-  std::string loco;
+  std::string loco, file_gxe;
   std::string file_geno, file_pheno, file_anno, file_bfile, file_cvt, file_kin, file_kd, file_ku, file_out = "result",
                                                                                                   path_out = "./output";
   std::vector<size_t> p_column;
@@ -54,6 +54,7 @@ int main(int argc, char **argv) {
     else if (a == "-lm") lm_mode = has ? atoi(argv[++i]) : 1;
     else if (a == "-eigen") do_eigen = true;
     else if (a == "-loco" && has) loco = argv[++i];
+    else if (a == "-gxe" && has) file_gxe = argv[++i];
     else if (a == "-maf" && has) qc.maf_level = atof(argv[++i]);
     else if (a == "-miss" && has) qc.miss_level = atof(argv[++i]);
     else if (a == "-hwe" && has) qc.hwe_level = atof(argv[++i]);
@@ -79,6 +80,7 @@ int main(int argc, char **argv) {
     const size_t n_ph = cols.size();
     if (!file_cvt.empty() && !ReadFile_cvt(file_cvt, cp.indicator_cvt, cp.cvt, cp.n_cvt)) return 3;
     if (cp.indicator_cvt.empty()) cp.n_cvt = 1;
+    if (!file_gxe.empty() && !ReadFile_column(file_gxe, cp.indicator_gxe, cp.gxe, 1)) return 3; // src/param.cpp:232-236
     size_t ns_test = 0;
     std::vector<double> Wb, Yb;
     if (!file_bfile.empty()) {
@@ -257,7 +259,16 @@ int main(int argc, char **argv) {
     cLmm.l_mle_null = nm.l_mle_null;
     cLmm.logl_mle_H0 = nm.logl_mle_H0;
     const double t_a0 = lap();
-    if (!file_bfile.empty()) cLmm.AnalyzePlink(&U, &eval, &UtW, &Uty);
+    if (!file_gxe.empty()) { // src/gemma.cpp:2809-2827
+      if (file_bfile.empty()) {
+        std::cerr << "-gxe takes -bfile input (the reference's BIMBAM GXE reader cannot open its file, src/lmm.cpp:2289)" << std::endl;
+        return 2;
+      }
+      std::vector<double> envb;
+      cp.CopyGxe(envb);
+      Vector env = vector_view(envb.data(), envb.size());
+      cLmm.AnalyzePlinkGXE(&U, &eval, &UtW, &Uty, &env);
+    } else if (!file_bfile.empty()) cLmm.AnalyzePlink(&U, &eval, &UtW, &Uty);
     else AnalyzeBimbam(cLmm, &U, &eval, &UtW, &Uty);
     const double t_a1 = lap();
     cLmm.WriteFiles();

@@ -273,3 +273,43 @@ def lm_workflow(exe, out):
     kv = drive(exe, "-bfile", os.path.join(TXT, "P"), "-outdir", out, "-lm", 4, "-c", os.path.join(TXT, "P.cov.txt"), "-o", "Plm4c")
     check_log(kv, "Plm4c.log.json")
     compare_assoc(os.path.join(out, "Plm4c.assoc.txt"), os.path.join(TXT, "Plm4c.assoc.txt.gz"), n_anno=8)
+
+
+def gxe_workflow(exe, out, modes=(1,)):
+    """`-gxe env.txt` on PLINK files (LMM::AnalyzePlinkGXE): the issue188 set rebuilt from tests/golden/ref_issue188.npz
+    (1008 individuals, 132 without phenotype, missing calls), -gk, then -k ... -lmm m -gxe, against the reference's output."""
+    out = str(out)
+    fx = np.load(os.path.join(ROOT, "tests", "golden", "ref_issue188.npz"))
+    n_total = int(fx["n_total"])
+    nb = (n_total + 3) // 4
+    ns = (fx["bed"].size - 3) // nb
+    pre = os.path.join(out, "p188")
+    open(pre + ".bed", "wb").write(fx["bed"].tobytes())
+    with open(pre + ".bim", "w") as f:
+        for t in range(ns):
+            f.write("1\trs%d\t0\t%d\tA\tG\n" % (t, t + 1))
+    with open(pre + ".fam", "w") as f:
+        for i, v in enumerate(fx["pheno_col6"]):
+            f.write("f%d i%d 0 0 1 %s\n" % (i, i, v))
+    np.savetxt(os.path.join(out, "env.txt"), fx["env"], fmt="%.10g")
+    base = ["-bfile", pre, "-outdir", out]
+    drive(exe, *base, "-gk", "-o", "k1")
+    cxx = os.path.join(out, "k1.cXX.txt")
+    K = np.loadtxt(cxx)
+    assert np.abs(K[:24] - fx["cXX_rows"]).max() <= 2e-10 and np.abs(np.diag(K) - fx["cXX_diag"]).max() <= 2e-10
+    for m in modes:
+        tag = "gxe%d" % m
+        drive(exe, *base, "-k", cxx, "-lmm", m, "-gxe", os.path.join(out, "env.txt"), "-o", tag)
+        hdr, rows = read_assoc(os.path.join(out, tag + ".assoc.txt"))
+        assert [r[1] for r in rows] == ["rs%d" % t for t in fx[tag + "_snp"]]
+        assert np.array_equal(np.array([float(r[3]) for r in rows]), fx[tag + "_n_miss"])
+        assert np.array_equal(np.array([float(r[6]) for r in rows]), fx[tag + "_af"])
+        for j, name in enumerate(hdr[7:], start=7):
+            got = np.array([float(r[j]) for r in rows])
+            want = fx[tag + "_" + name]
+            both = np.isnan(got) & np.isnan(want)
+            rel = np.where(both, 0.0, np.abs(got - want) / np.maximum(np.abs(want), 1e-300))
+            if name in LAM_COLS:
+                assert (rel <= 1e-3).all() and (rel <= STAT_TOL).mean() >= 0.98, (tag, name)
+            else:
+                assert (rel <= STAT_TOL).all(), (tag, name, np.nanmax(rel))

@@ -68,6 +68,16 @@ def test_lm_files_to_reference_outputs_and_golden_checksum(driver, tmp_path, mon
     fc.lm_workflow(driver, tmp_path)
 
 
+def test_gxe_plink_files_to_reference_outputs(driver, tmp_path, monkeypatch):
+    import glob
+    import scipy
+    libs = glob.glob(os.path.join(os.path.dirname(os.path.dirname(scipy.__file__)), "scipy.libs", "libscipy_openblas*.so"))
+    if libs:
+        monkeypatch.setenv("GEMMA_DOUBLE_LAPACK", libs[0])
+    monkeypatch.setenv("GEMMA_HIP_IO_BLOCK", "800")
+    fc.gxe_workflow(driver, tmp_path, modes=(1,))
+
+
 def test_driver_reports_reader_errors(driver, tmp_path):
     """Where the reference's readers return false the driver stops (exit code 3) instead of analysing garbage."""
     bad = tmp_path / "short.txt"

@@ -36,3 +36,7 @@ def test_mvlmm_plink_files_to_reference_outputs(driver, tmp_path):
 
 def test_lm_files_to_reference_outputs_and_golden_checksum(driver, tmp_path):
     fc.lm_workflow(driver, tmp_path)
+
+
+def test_gxe_plink_files_to_reference_outputs(driver, tmp_path):
+    fc.gxe_workflow(driver, tmp_path, modes=(1, 4))
