@@ -438,7 +438,7 @@ class LMM {
 public:
   int a_mode = 1;
   size_t d_pace = 100000;
-  std::string file_bfile, file_geno, file_out, path_out = "./output/";
+  std::string file_bfile, file_geno, file_gene, file_out, path_out = "./output/";
   double l_min = 1e-5, l_max = 1e5;
   size_t n_region = 10;
   double l_mle_null = 0.0, logl_mle_H0 = 0.0;
@@ -549,6 +549,26 @@ public:
     finish();
   }
 
+  // AnalyzeGene with a pull-style block source (rows = genes over the ni_test analysed individuals)
+  void AnalyzeGeneFeed(const Matrix *U, const Vector *eval, const Matrix *UtW, const Vector *Utx, RowFeeder &feed,
+                       size_t max_rows, size_t ld) {
+    setup(U, eval, UtW, Utx, 0);
+    std::vector<gemma_sumstat> out(max_rows);
+    for (;;) {
+      const double *Y = nullptr;
+      const size_t l = feed(Y);
+      if (l == 0) break;
+      if (l > max_rows) throw HipError(GEMMA_HIP_EINVAL, "AnalyzeGeneFeed: block larger than max_rows");
+      enforce_hip(gemma_hip_lmm_gene_batch(Y, l, ld, out.data()), "AnalyzeGene");
+      for (size_t i = 0; i < l; ++i) {
+        SUMSTAT SNPs = {out[i].beta, out[i].se, out[i].lambda_remle, out[i].lambda_mle,
+                        out[i].p_wald, out[i].p_lrt, out[i].p_score, out[i].logl_H1};
+        sumStat.push_back(SNPs);
+      }
+    }
+    finish();
+  }
+
   // AnalyzeGene, src/lmm.cpp:1365-1471 (the file reader factored out): Y rows = one phenotype (gene) each over the
   // ni_test analysed individuals, Utx = the rotated fixed tested variable; every row gets its own null fit
   void AnalyzeGeneRows(const Matrix *U, const Vector *eval, const Matrix *UtW, const Vector *Utx, const double *Y,
@@ -596,7 +616,8 @@ public:
       std::cout << "error writing file: " << file_str << std::endl;
       return;
     }
-    outfile << "chr\trs\tps\tn_miss\tallele1\tallele0\taf\t";
+    const bool gene = !file_gene.empty(); // src/lmm.cpp:172-179: one id column instead of the seven SNP columns
+    outfile << (gene ? "geneID\t" : "chr\trs\tps\tn_miss\tallele1\tallele0\taf\t");
     switch (a_mode) {
     case 1: outfile << "beta\tse\tlogl_H1\tl_remle\tp_wald" << std::endl; break;
     case 2: outfile << "logl_H1\tl_mle\tp_lrt" << std::endl; break;
@@ -606,6 +627,10 @@ public:
     }
     std::vector<size_t> rows; // snpInfo index of the t-th record of sumStat
     for (size_t i = 0; i < snpInfo.size(); ++i) {
+      if (gene) {
+        rows.push_back(i);
+        continue;
+      }
       if (indicator_snp[i] == 0) continue;
       if (!setGWASnps.empty() && setGWASnps.count(snpInfo[i].rs_number) == 0) continue; // src/lmm.cpp:208-210
       rows.push_back(i);
@@ -613,8 +638,11 @@ public:
     write_rows(outfile, std::min(rows.size(), sumStat.size()), [&](AssocLine &ln, size_t t) {
       const SNPINFO &s = snpInfo[rows[t]];
       const SUMSTAT &st = sumStat[t];
-      ln.str(s.chr).tab().str(s.rs_number).tab().num(s.base_position).tab().unum(s.n_miss).tab().str(s.a_minor).tab()
-          .str(s.a_major).tab().fix3(s.maf).tab();
+      if (gene)
+        ln.str(s.rs_number).tab();
+      else
+        ln.str(s.chr).tab().str(s.rs_number).tab().num(s.base_position).tab().unum(s.n_miss).tab().str(s.a_minor).tab()
+            .str(s.a_major).tab().fix3(s.maf).tab();
       switch (a_mode) {
       case 1: ln.sci(st.beta).tab().sci(st.se).tab().sci(st.logl_H1).tab().sci(st.lambda_remle).tab().sci(st.p_wald); break;
       case 2: ln.sci(st.logl_H1).tab().sci(st.lambda_mle).tab().sci(st.p_lrt); break;

@@ -522,6 +522,28 @@ public:
   BimbamReader &operator=(const BimbamReader &) = delete;
   bool ok() const { return f_ != nullptr; }
   size_t lines_read() const { return line_no_; }
+  // consumes one line without counting it (the header of a gene-expression file); false at end of file
+  bool skip_line() {
+    if (!f_) return false;
+    for (;;) {
+      size_t b, e, next;
+      if (next_line(beg_, b, e, next)) {
+        beg_ = next;
+        return true;
+      }
+      if (eof_) {
+        const bool had = beg_ < end_;
+        beg_ = end_;
+        return had;
+      }
+      if (beg_ > 0) {
+        memmove(buf_, buf_ + beg_, end_ - beg_);
+        end_ -= beg_;
+        beg_ = 0;
+      }
+      fill();
+    }
+  }
   static unsigned default_threads() {
     const char *env = getenv("GEMMA_HIP_IO_THREADS");
     if (env && atoi(env) > 0) return (unsigned)atoi(env);
@@ -587,7 +609,7 @@ public:
     }
     for (int b : bad)
       if (b) {
-        if (skip_) std::cout << "Problem reading geno file (not enough genotypes in line)" << std::endl;
+        if (skip_ == 3) std::cout << "Problem reading geno file (not enough genotypes in line)" << std::endl;
         return (size_t)-1;
       }
     return l;
@@ -634,8 +656,8 @@ private:
     for (size_t i = 0; i < ni_total_; ++i) {
       if (!detail::next_token(p, end, b, e)) return false;
       if (cols && cols[i] == 0) continue;
-      // plain matrices go through atof alone ("NA" -> 0.0 as in the reference's kinship reader)
-      x[o++] = (skip_ && detail::tok_is_na(b, e)) ? std::numeric_limits<double>::quiet_NaN() : parse_double(b, e);
+      // only the genotype reader knows "NA"; the kinship and gene-expression readers call atof on every token
+      x[o++] = (skip_ == 3 && detail::tok_is_na(b, e)) ? std::numeric_limits<double>::quiet_NaN() : parse_double(b, e);
     }
     return !(strict_ && detail::next_token(p, end, b, e));
   }
@@ -859,6 +881,62 @@ inline void AnalyzeBimbam(LMM &lmm, const Matrix *U, const Vector *eval, const M
     return l;
   };
   lmm.AnalyzeFeed(U, eval, UtW, Uty, feed, B, n);
+}
+
+// ReadFile_gene, src/gemma_io.cpp:2307-2364 (`-gene`): a header line, then one row per gene: id and ni_total expression
+// values.  Only the ids (into snpInfo.rs_number) and the row count matter to the LMM path.
+inline bool ReadFile_gene(const std::string &file_gene, std::vector<SNPINFO> &snpInfo, size_t &ng_total) {
+  ng_total = 0;
+  TextFile infile(file_gene);
+  if (!infile.ok()) {
+    std::cout << "error! fail to open gene expression file: " << file_gene << std::endl;
+    return false;
+  }
+  std::string line;
+  infile.getline(line); // header
+  size_t n_idv = 0;
+  while (infile.getline(line)) {
+    const char *p = line.data(), *end = p + line.size(), *b, *e;
+    if (!detail::next_token(p, end, b, e)) {
+      std::cout << "Parsing input file '" << file_gene << "' failed in function ReadFile_gene" << std::endl;
+      return false;
+    }
+    SNPINFO s;
+    s.chr = "-9"; s.rs_number.assign(b, e); s.cM = -9; s.base_position = -9; s.a_minor = "-9"; s.a_major = "-9";
+    s.n_miss = 0; s.missingness = -9; s.maf = -9; s.n_idv = 0; s.n_nb = 0; s.file_position = 0;
+    size_t t = 0;
+    while (detail::next_token(p, end, b, e)) ++t;
+    if (ng_total == 0) n_idv = t;
+    if (t != n_idv) {
+      std::cout << "error! number of columns doesn't match in row: " << ng_total << std::endl;
+      return false;
+    }
+    snpInfo.push_back(s);
+    ng_total++;
+  }
+  return true;
+}
+
+// LMM::AnalyzeGene, src/lmm.cpp:1365-1471, from the file: rows = genes over the analysed individuals (atof on every
+// token), the tested variable is the -p phenotype whose rotation arrives in Utx; ng_total rows after the header
+inline void AnalyzeGene(LMM &lmm, const Matrix *U, const Vector *eval, const Matrix *UtW, const Vector *Utx, size_t ng_total) {
+  const size_t ni_total = lmm.indicator_idv.size(), n = U->size1;
+  BimbamReader rd(lmm.file_gene, ni_total, 0, 1);
+  if (!rd.ok() || !rd.skip_line()) throw std::runtime_error("error reading gene expression file");
+  const size_t B = bimbam_block_rows(n, LMM_BATCH_SIZE);
+  BlockPrefetch pf(B * n * sizeof(double), [&](void *slot, int) -> size_t {
+    if (rd.lines_read() >= ng_total) return 0;
+    return rd.read_block(std::min(B, ng_total - rd.lines_read()), static_cast<double *>(slot), n, nullptr, nullptr,
+                         lmm.indicator_idv.data());
+  });
+  LMM::RowFeeder feed = [&](const double *&Y) -> size_t {
+    void *slot = nullptr;
+    const size_t l = pf.next(slot);
+    if (l == (size_t)-1) throw std::runtime_error("Parsing the gene expression file failed (not enough columns)");
+    Y = static_cast<const double *>(slot);
+    return l;
+  };
+  lmm.AnalyzeGeneFeed(U, eval, UtW, Utx, feed, B, n);
 }
 
 // LM::AnalyzeBimbam, src/lm.cpp:382-503, over the same threaded reader (lm.file_geno, lm.indicator_idv / _snp)

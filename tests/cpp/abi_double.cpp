@@ -30,6 +30,8 @@ typedef struct {
 void orc_lmm_batch(int a_mode, size_t n, size_t c, const double *eval, const double *UtW, const double *Uty,
                    const double *UtX, size_t l, double l_min, double l_max, size_t n_region, double l_mle_null,
                    double logl_mle_H0, int plink_nan_rule, double *carry, orc_sumstat *out, long *diag);
+void orc_gene_batch(int a_mode, size_t n, size_t c, const double *eval, const double *UtW, const double *Utx,
+                    const double *UtY, size_t l, double l_min, double l_max, size_t n_region, orc_sumstat *out);
 void orc_gxe_batch(int a_mode, size_t n, size_t c, const double *eval, const double *UtWe, const double *Uty,
                    const double *UtX, const double *UtZ, const int *flip, size_t l, double l_min, double l_max,
                    size_t n_region, double l_mle_null, orc_sumstat *out);
@@ -456,7 +458,16 @@ int gemma_hip_lm_finish(void) {
 }
 
 // referenced by inline members of class LMM the driver does not call (the linker still wants them with -O0)
-int gemma_hip_lmm_gene_batch(const double *, size_t, size_t, gemma_sumstat *) { return fail(GEMMA_HIP_EINVAL, "not in the double"); }
+// LMM::AnalyzeGene: rows of Y are phenotypes, the Uty slot of lmm_setup holds the rotated tested variable
+int gemma_hip_lmm_gene_batch(const double *Y, size_t l, size_t ld, gemma_sumstat *out) {
+  if (!g_lmm.on) return fail(GEMMA_HIP_ESTATE, "lmm_gene_batch before lmm_setup");
+  const size_t n = g_lmm.cfg.n, c = g_lmm.cfg.n_cvt;
+  std::vector<double> UtY(l * n);
+  gemma_hip_dgemm('N', 'N', l, n, n, 1.0, Y, ld, g_lmm.U.data(), n, 0.0, UtY.data(), n); // row g = (U^T y_g)^T
+  orc_gene_batch(g_lmm.cfg.a_mode, n, c, g_lmm.eval.data(), g_lmm.UtW.data(), g_lmm.Uty.data(), UtY.data(), l,
+                 g_lmm.cfg.l_min, g_lmm.cfg.l_max, g_lmm.cfg.n_region, reinterpret_cast<orc_sumstat *>(out));
+  return GEMMA_HIP_OK;
+}
 
 // ---- -gxe over orc_gxe_batch (feeder part as in LMM::AnalyzePlinkGXE, src/lmm.cpp:2490-2538) -------------------------
 int gemma_hip_lmm_set_env(const double *env) {

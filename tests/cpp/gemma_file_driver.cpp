@@ -4,6 +4,7 @@
 //   gemma_file_driver (-g geno[.gz] -p pheno [-a anno] | -bfile prefix) [-c cvt] [-n col [col ...]]
 //                     (-gk [1|2] | -k kin (-eigen | -lmm [1|2|3|4|9]) | -d eigenD -u eigenU -lmm m | -lm [1|2|3|4])
 //                     [-maf x] [-miss x] [-hwe x] [-r2 x] [-loco chr] [-gxe env] [-o name] [-outdir dir]
+//   gemma_file_driver -gene expr.txt -p pheno -k kin -lmm m        every row of expr.txt is a phenotype (LMM::AnalyzeGene)
 //   gemma_file_driver -bfile prefix -inproc [1|2] -lmm m ...   kinship, eigendecomposition and association in ONE
 //                     process: K never becomes text; wall seconds of every stage on the log line
 //
@@ -23,7 +24,7 @@
 using namespace gemma_amd;
 
 int main(int argc, char **argv) {
-  std::string loco, file_gxe;
+  std::string loco, file_gxe, file_gene;
   std::string file_geno, file_pheno, file_anno, file_bfile, file_cvt, file_kin, file_kd, file_ku, file_out = "result",
                                                                                                   path_out = "./output";
   std::vector<size_t> p_column;
@@ -55,6 +56,7 @@ int main(int argc, char **argv) {
     else if (a == "-eigen") do_eigen = true;
     else if (a == "-loco" && has) loco = argv[++i];
     else if (a == "-gxe" && has) file_gxe = argv[++i];
+    else if (a == "-gene" && has) file_gene = argv[++i];
     else if (a == "-maf" && has) qc.maf_level = atof(argv[++i]);
     else if (a == "-miss" && has) qc.miss_level = atof(argv[++i]);
     else if (a == "-hwe" && has) qc.hwe_level = atof(argv[++i]);
@@ -91,8 +93,10 @@ int main(int argc, char **argv) {
     } else if (!file_geno.empty()) {
       if (!file_anno.empty() && !ReadFile_anno(file_anno, mapRS2chr, mapRS2bp, mapRS2cM)) return 3;
       if (!ReadFile_pheno(file_pheno, cp.indicator_pheno, cp.pheno, cols)) return 3;
+    } else if (!file_gene.empty()) { // src/param.cpp:441-470: phenotypes, then the gene ids
+      if (!ReadFile_pheno(file_pheno, cp.indicator_pheno, cp.pheno, cols)) return 3;
     } else {
-      std::cerr << "need -g/-p or -bfile" << std::endl;
+      std::cerr << "need -g/-p, -gene/-p or -bfile" << std::endl;
       return 2;
     }
     cp.ProcessCvtPhen();
@@ -100,7 +104,10 @@ int main(int argc, char **argv) {
     cp.CopyCvtPhen(Wb, Yb);
     const size_t ni_total = cp.indicator_idv.size(), ni_test = cp.ni_test, n_cvt = cp.n_cvt;
     Matrix W = matrix_view(Wb.data(), ni_test, n_cvt);
-    if (!file_bfile.empty()) {
+    size_t ng_total = 0;
+    if (!file_gene.empty()) {
+      if (!ReadFile_gene(file_gene, snpInfo, ng_total)) return 3;
+    } else if (!file_bfile.empty()) {
       if (!ReadFile_bed(file_bfile + ".bed", setSnps, &W, cp.indicator_idv, indicator_snp, snpInfo, qc.maf_level,
                         qc.miss_level, qc.hwe_level, qc.r2_level, ns_test))
         return 3;
@@ -249,6 +256,7 @@ int main(int argc, char **argv) {
     cLmm.a_mode = a_mode;
     cLmm.file_bfile = file_bfile;
     cLmm.file_geno = file_geno;
+    cLmm.file_gene = file_gene;
     cLmm.path_out = path_out;
     cLmm.file_out = file_out;
     cLmm.ni_total = ni_total;
@@ -259,7 +267,9 @@ int main(int argc, char **argv) {
     cLmm.l_mle_null = nm.l_mle_null;
     cLmm.logl_mle_H0 = nm.logl_mle_H0;
     const double t_a0 = lap();
-    if (!file_gxe.empty()) { // src/gemma.cpp:2809-2827
+    if (!file_gene.empty()) { // src/gemma.cpp:2675-2690: y is the predictor, the genes are the phenotypes
+      AnalyzeGene(cLmm, &U, &eval, &UtW, &Uty, ng_total);
+    } else if (!file_gxe.empty()) { // src/gemma.cpp:2809-2827
       if (file_bfile.empty()) {
         std::cerr << "-gxe takes -bfile input (the reference's BIMBAM GXE reader cannot open its file, src/lmm.cpp:2289)" << std::endl;
         return 2;

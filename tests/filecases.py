@@ -313,3 +313,44 @@ def gxe_workflow(exe, out, modes=(1,)):
                 assert (rel <= 1e-3).all() and (rel <= STAT_TOL).mean() >= 0.98, (tag, name)
             else:
                 assert (rel <= STAT_TOL).all(), (tag, name, np.nanmax(rel))
+
+
+def gene_workflow(exe, out, modes=(1,)):
+    """`-gene expr.txt -p pheno -k K -lmm m` (LMM::AnalyzeGene from the file): 40 expression rows over the issue188
+    individuals (tests/golden/ref_gene.npz), kinship from the PLINK set, against the reference's geneID table."""
+    out = str(out)
+    fx = np.load(os.path.join(ROOT, "tests", "golden", "ref_issue188.npz"))
+    ge = np.load(os.path.join(ROOT, "tests", "golden", "ref_gene.npz"))
+    n_total = int(fx["n_total"])
+    nb = (n_total + 3) // 4
+    ns = (fx["bed"].size - 3) // nb
+    pre = os.path.join(out, "pg")
+    open(pre + ".bed", "wb").write(fx["bed"].tobytes())
+    with open(pre + ".bim", "w") as f:
+        for t in range(ns):
+            f.write("1\trs%d\t0\t%d\tA\tG\n" % (t, t + 1))
+    with open(pre + ".fam", "w") as f:
+        for i, v in enumerate(fx["pheno_col6"]):
+            f.write("f%d i%d 0 0 1 %s\n" % (i, i, v))
+    with open(os.path.join(out, "gene.txt"), "w") as f:
+        f.write("id\t" + "\t".join("i%d" % i for i in range(n_total)) + "\n")
+        for r in range(ge["expr"].shape[0]):
+            f.write("g%d\t" % r + "\t".join("%.10g" % v for v in ge["expr"][r]) + "\n")
+    with open(os.path.join(out, "gph.txt"), "w") as f:
+        for v in fx["pheno_col6"]:
+            f.write(("NA" if v in ("-9", "NA") else str(v)) + "\n")
+    drive(exe, "-bfile", pre, "-outdir", out, "-gk", "-o", "kg")
+    cxx = os.path.join(out, "kg.cXX.txt")
+    for m in modes:
+        drive(exe, "-gene", os.path.join(out, "gene.txt"), "-p", os.path.join(out, "gph.txt"), "-k", cxx, "-lmm", m,
+              "-outdir", out, "-o", "ge%d" % m)
+        hdr, rows = read_assoc(os.path.join(out, "ge%d.assoc.txt" % m))
+        assert hdr[0] == "geneID" and [r[0] for r in rows] == ["g%d" % r for r in range(ge["expr"].shape[0])]
+        for j, name in enumerate(hdr[1:], start=1):
+            got = np.array([float(r[j]) for r in rows])
+            want = ge["lmm%d_%s" % (m, name)]
+            rel = np.abs(got - want) / np.maximum(np.abs(want), 1e-300)
+            if name in LAM_COLS:
+                assert (rel <= 1e-3).all() and (rel <= STAT_TOL).mean() >= 0.9, (m, name)
+            else:
+                assert (rel <= STAT_TOL).all(), (m, name, float(rel.max()))

@@ -78,6 +78,16 @@ def test_gxe_plink_files_to_reference_outputs(driver, tmp_path, monkeypatch):
     fc.gxe_workflow(driver, tmp_path, modes=(1,))
 
 
+def test_gene_expression_file_to_reference_outputs(driver, tmp_path, monkeypatch):
+    import glob
+    import scipy
+    libs = glob.glob(os.path.join(os.path.dirname(os.path.dirname(scipy.__file__)), "scipy.libs", "libscipy_openblas*.so"))
+    if libs:
+        monkeypatch.setenv("GEMMA_DOUBLE_LAPACK", libs[0])
+    monkeypatch.setenv("GEMMA_HIP_IO_BLOCK", "16")  # 40 genes in three blocks
+    fc.gene_workflow(driver, tmp_path, modes=(1, 4))
+
+
 def test_driver_reports_reader_errors(driver, tmp_path):
     """Where the reference's readers return false the driver stops (exit code 3) instead of analysing garbage."""
     bad = tmp_path / "short.txt"

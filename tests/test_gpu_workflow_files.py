@@ -40,3 +40,7 @@ def test_lm_files_to_reference_outputs_and_golden_checksum(driver, tmp_path):
 
 def test_gxe_plink_files_to_reference_outputs(driver, tmp_path):
     fc.gxe_workflow(driver, tmp_path, modes=(1, 4))
+
+
+def test_gene_expression_file_to_reference_outputs(driver, tmp_path):
+    fc.gene_workflow(driver, tmp_path, modes=(1, 4))
