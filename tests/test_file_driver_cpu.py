@@ -97,3 +97,41 @@ def test_driver_reports_reader_errors(driver, tmp_path):
     assert r.returncode == 3 and "not enough genotypes" in r.stdout
     r = subprocess.run([driver, "-bfile", str(tmp_path / "nothing"), "-gk", "-outdir", str(tmp_path)], capture_output=True, text=True)
     assert r.returncode == 3 and "error opening .bim file" in r.stdout
+
+
+def test_driver_edge_cases(driver, tmp_path):
+    """Empty and ragged inputs end where the reference's readers end: no analysed individual, a truncated .bed, a kinship
+    file of the wrong size; an input without a single SNP line is an empty (not a crashing) first pass."""
+    import numpy as np
+    out = str(tmp_path)
+    geno = os.path.join(fc.TXT, "BXD_geno_head.txt")
+    ni = len(open(os.path.join(fc.TXT, "BXD_pheno.txt")).read().split())
+    allna = tmp_path / "na.txt"
+    allna.write_text("NA\n" * ni)
+    r = subprocess.run([driver, "-g", geno, "-p", str(allna), "-gk", "-outdir", out], capture_output=True, text=True)
+    assert r.returncode == 3 and "number of analyzed individuals equals 0" in r.stdout
+    # truncated .bed: the first pass reports it instead of analysing a short block
+    pre = str(tmp_path / "T")
+    for ext in (".bim", ".fam"):
+        open(pre + ext, "w").write(open(os.path.join(fc.TXT, "P" + ext)).read())
+    raw = open(os.path.join(fc.TXT, "P.bed"), "rb").read()
+    open(pre + ".bed", "wb").write(raw[: len(raw) // 2])
+    r = subprocess.run([driver, "-bfile", pre, "-gk", "-outdir", out], capture_output=True, text=True)
+    assert r.returncode == 3 and "truncated" in r.stdout
+    # kinship file with one row too few / one column too many for the .fam
+    K = np.eye(240)
+    np.savetxt(tmp_path / "short.cXX.txt", K[:239], fmt="%.10g", delimiter="\t")
+    r = subprocess.run([driver, "-bfile", os.path.join(fc.TXT, "P"), "-k", str(tmp_path / "short.cXX.txt"), "-lmm", "1",
+                        "-outdir", out], capture_output=True, text=True)
+    assert r.returncode == 5 and "rows in the kinship file" in r.stdout
+    np.savetxt(tmp_path / "wide.cXX.txt", np.eye(240, 241), fmt="%.10g", delimiter="\t")
+    r = subprocess.run([driver, "-bfile", os.path.join(fc.TXT, "P"), "-k", str(tmp_path / "wide.cXX.txt"), "-lmm", "1",
+                        "-outdir", out], capture_output=True, text=True)
+    assert r.returncode == 5 and "columns in the kinship file" in r.stdout
+    # no SNP at all: an empty genotype file passes the first pass with zero SNPs
+    empty = tmp_path / "empty.txt"
+    empty.write_text("")
+    r = subprocess.run([driver, "-g", str(empty), "-p", os.path.join(fc.TXT, "BXD_pheno.txt"), "-lm", "1", "-outdir", out,
+                        "-o", "none"], capture_output=True, text=True)
+    assert r.returncode == 0 and "ns_total=0 ns_test=0" in r.stdout and "snps=0" in r.stdout
+    assert len(open(tmp_path / "none.assoc.txt").read().strip().split("\n")) == 1  # the header alone
