@@ -157,6 +157,26 @@ inline bool tok_is_na(const char *b, const char *e) { return e - b == 2 && b[0] 
 // ---------------------------------------------------------------------------------------------------------------
 // phenotypes, covariates, annotation
 // ---------------------------------------------------------------------------------------------------------------
+// ReadFile_snps, src/gemma_io.cpp:153-178 (`-snps`): one SNP id per line (first token)
+inline bool ReadFile_snps(const std::string &file_snps, std::set<std::string> &setSnps) {
+  setSnps.clear();
+  TextFile infile(file_snps);
+  if (!infile.ok()) {
+    std::cout << "error! fail to open snps file: " << file_snps << std::endl;
+    return false;
+  }
+  std::string line;
+  while (infile.getline(line)) {
+    const char *p = line.data(), *end = p + line.size(), *b, *e;
+    if (!detail::next_token(p, end, b, e)) {
+      std::cout << "Problem reading SNP file" << std::endl;
+      return false;
+    }
+    setSnps.insert(std::string(b, e));
+  }
+  return true;
+}
+
 // ReadFile_column, src/gemma_io.cpp:344-383: one column of a text file (the -gxe / -widv inputs); "NA" -> indicator 0
 inline bool ReadFile_column(const std::string &file_pheno, std::vector<int> &indicator_idv, std::vector<double> &pheno,
                             const int &p_column) {
@@ -993,6 +1013,50 @@ inline void ReadFile_kin_threaded(const std::string &file_kin, std::vector<int> 
   if (i_test != G->size1 || rd.lines_read() != ni_total || rd.read_block(1, extra.data(), extra.size()) != 0) {
     std::cout << "number of rows in the kinship file does not match the number of individuals." << std::endl;
     error = true;
+  }
+}
+
+// ReadFile_kin with k_mode == 2 (`-km 2`), src/gemma_io.cpp:1244-1288: "id1 id2 value" triples over the .fam ids
+// (mapID2num from ReadFile_fam); pairs with an unknown or non-analysed id are skipped, the matrix is filled symmetrically,
+// a pair given twice with different values is an error
+inline void ReadFile_kin_km2(const std::string &file_kin, const std::vector<int> &indicator_idv,
+                             const std::map<std::string, int> &mapID2num, bool &error, Matrix *G) {
+  TextFile infile(file_kin);
+  if (!infile.ok()) {
+    std::cout << "error! fail to open kinship file: " << file_kin << std::endl;
+    error = true;
+    return;
+  }
+  for (size_t i = 0; i < G->size1; ++i)
+    for (size_t j = 0; j < G->size2; ++j) G->data[i * G->tda + j] = 0.0;
+  std::vector<long> id2id(indicator_idv.size(), -1);
+  long c = 0;
+  for (size_t i = 0; i < indicator_idv.size(); ++i)
+    if (indicator_idv[i] == 1) id2id[i] = c++;
+  std::string line;
+  while (infile.getline(line)) {
+    const char *p = line.data(), *end = p + line.size(), *b[3], *e[3];
+    for (int k = 0; k < 3; ++k)
+      if (!detail::next_token(p, end, b[k], e[k])) {
+        std::cout << "Parsing input file '" << file_kin << "' failed in function ReadFile_kin" << std::endl;
+        error = true;
+        return;
+      }
+    const std::map<std::string, int>::const_iterator i1 = mapID2num.find(std::string(b[0], e[0])),
+                                                     i2 = mapID2num.find(std::string(b[1], e[1]));
+    if (i1 == mapID2num.end() || i2 == mapID2num.end()) continue;
+    const long r = id2id[(size_t)i1->second], q = id2id[(size_t)i2->second];
+    if (r < 0 || q < 0) continue;
+    const double d = parse_double(b[2], e[2]);
+    const double have = G->data[(size_t)r * G->tda + (size_t)q];
+    if (have != 0 && have != d) {
+      std::cout << "error! redundant and unequal terms in the kinship file, for id1 = " << std::string(b[0], e[0])
+                << " and id2 = " << std::string(b[1], e[1]) << std::endl;
+      error = true;
+      return;
+    }
+    G->data[(size_t)r * G->tda + (size_t)q] = d;
+    G->data[(size_t)q * G->tda + (size_t)r] = d;
   }
 }
 

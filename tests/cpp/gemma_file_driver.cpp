@@ -3,7 +3,7 @@
 //
 //   gemma_file_driver (-g geno[.gz] -p pheno [-a anno] | -bfile prefix) [-c cvt] [-n col [col ...]]
 //                     (-gk [1|2] | -k kin (-eigen | -lmm [1|2|3|4|9]) | -d eigenD -u eigenU -lmm m | -lm [1|2|3|4])
-//                     [-maf x] [-miss x] [-hwe x] [-r2 x] [-loco chr] [-gxe env] [-o name] [-outdir dir]
+//                     [-maf x] [-miss x] [-hwe x] [-r2 x] [-loco chr] [-gxe env] [-snps list] [-notsnp] [-km 2] [-o name] [-outdir dir]
 //   gemma_file_driver -gene expr.txt -p pheno -k kin -lmm m        every row of expr.txt is a phenotype (LMM::AnalyzeGene)
 //   gemma_file_driver -bfile prefix -inproc [1|2] -lmm m ...   kinship, eigendecomposition and association in ONE
 //                     process: K never becomes text; wall seconds of every stage on the log line
@@ -24,7 +24,8 @@
 using namespace gemma_amd;
 
 int main(int argc, char **argv) {
-  std::string loco, file_gxe, file_gene;
+  std::string loco, file_gxe, file_gene, file_snps;
+  int km = 1;
   std::string file_geno, file_pheno, file_anno, file_bfile, file_cvt, file_kin, file_kd, file_ku, file_out = "result",
                                                                                                   path_out = "./output";
   std::vector<size_t> p_column;
@@ -57,6 +58,9 @@ int main(int argc, char **argv) {
     else if (a == "-loco" && has) loco = argv[++i];
     else if (a == "-gxe" && has) file_gxe = argv[++i];
     else if (a == "-gene" && has) file_gene = argv[++i];
+    else if (a == "-snps" && has) file_snps = argv[++i];
+    else if (a == "-km" && has) km = atoi(argv[++i]);
+    else if (a == "-notsnp") qc.maf_level = -1; // src/gemma.cpp:1116-1117
     else if (a == "-maf" && has) qc.maf_level = atof(argv[++i]);
     else if (a == "-miss" && has) qc.miss_level = atof(argv[++i]);
     else if (a == "-hwe" && has) qc.hwe_level = atof(argv[++i]);
@@ -76,7 +80,8 @@ int main(int argc, char **argv) {
     std::map<std::string, std::string> mapRS2chr;
     std::map<std::string, long int> mapRS2bp;
     std::map<std::string, double> mapRS2cM;
-    const std::set<std::string> setSnps;
+    std::set<std::string> setSnps;
+    if (!file_snps.empty() && !ReadFile_snps(file_snps, setSnps)) return 3; // src/param.cpp:147-153
     if (p_column.empty()) p_column.push_back(1);
     const std::vector<size_t> &cols = p_column;
     const size_t n_ph = cols.size();
@@ -186,7 +191,8 @@ int main(int argc, char **argv) {
     } else if (!file_kin.empty()) {
       std::vector<double> Gb(ni_test * ni_test);
       Matrix G = matrix_view(Gb.data(), ni_test, ni_test);
-      ReadFile_kin_threaded(file_kin, cp.indicator_idv, error, &G);
+      if (km == 2) ReadFile_kin_km2(file_kin, cp.indicator_idv, mapID2num, error, &G);
+      else ReadFile_kin_threaded(file_kin, cp.indicator_idv, error, &G);
       if (error) return 5;
       CenterMatrix(&G);
       trace_G = EigenDecomp_Zeroed(&G, &U, &eval, 0);

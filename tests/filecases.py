@@ -354,3 +354,32 @@ def gene_workflow(exe, out, modes=(1,)):
                 assert (rel <= 1e-3).all() and (rel <= STAT_TOL).mean() >= 0.9, (m, name)
             else:
                 assert (rel <= STAT_TOL).all(), (m, name, float(rel.max()))
+
+
+def selection_options_workflow(exe, out):
+    """The switches that change WHICH SNPs / kinship entries are used: `-snps list` (BIMBAM: unlisted SNPs stay in the file
+    order with indicator 0), `-notsnp` (no maf filter) and `-km 2` (kinship as id-pair triples over the .fam ids), each
+    against the reference binary's output for the same command."""
+    out = str(out)
+    base = ["-g", os.path.join(TXT, "BXD_geno.txt.gz"), "-p", os.path.join(TXT, "BXD_pheno.txt"),
+            "-c", os.path.join(TXT, "BXD_covariates2.txt"), "-a", os.path.join(TXT, "BXD_snps.txt.gz"), "-outdir", out]
+    drive(exe, *base, "-gk", "-o", "BXD")
+    kv = drive(exe, *base, "-k", os.path.join(out, "BXD.cXX.txt"), "-lmm", 1, "-maf", "0.1", "-snps",
+               os.path.join(TXT, "BXD_snps7.txt"), "-o", "Ls")
+    assert int(kv["ns_total"]) == 7320 and int(kv["ns_test"]) == 1045
+    compare_assoc(os.path.join(out, "Ls.assoc.txt"), os.path.join(TXT, "Ls.assoc.txt.gz"))
+    pb = ["-bfile", os.path.join(TXT, "P"), "-outdir", out]
+    drive(exe, *pb, "-gk", "-o", "P")
+    cxx = os.path.join(out, "P.cXX.txt")
+    kv = drive(exe, *pb, "-k", cxx, "-lmm", 1, "-notsnp", "-o", "P1n")
+    check_log(kv, "P1n.log.json")
+    compare_assoc(os.path.join(out, "P1n.assoc.txt"), os.path.join(TXT, "P1n.assoc.txt.gz"))
+    ids = [l.split()[1] for l in open(os.path.join(TXT, "P.fam"))]
+    toks = [l.rstrip("\n").split("\t") for l in open(cxx)]
+    with open(os.path.join(out, "P.km2.txt"), "w") as f:
+        for i in range(len(ids)):
+            for j in range(i, len(ids)):
+                f.write("%s\t%s\t%s\n" % (ids[i], ids[j], toks[i][j]))
+    kv = drive(exe, *pb, "-k", os.path.join(out, "P.km2.txt"), "-km", 2, "-lmm", 1, "-o", "P1km2")
+    check_log(kv, "P1km2.log.json")
+    compare_assoc(os.path.join(out, "P1km2.assoc.txt"), os.path.join(TXT, "P1km2.assoc.txt.gz"))

@@ -67,10 +67,19 @@ def plink_subset(tmp, ni=240, ns=800):
     gemma(tmp, "-bfile", "P", "-k", cxx, "-lmm", 4, "-c", "P.cov.txt", "-o", "P4c")
     gemma(tmp, "-bfile", "P", "-k", cxx, "-lmm", 1, "-miss", 0.02, "-maf", 0.05, "-o", "P1q")
     gemma(tmp, "-bfile", "P", "-lm", 4, "-c", "P.cov.txt", "-o", "Plm4c")
+    gemma(tmp, "-bfile", "P", "-k", cxx, "-lmm", 1, "-notsnp", "-o", "P1n")
+    # -km 2: the same kinship as "id id value" triples (upper triangle) over the .fam ids
+    ids = [l.split()[1] for l in fam[:ni]]
+    toks = [l.rstrip("\n").split("\t") for l in open(cxx)]
+    with open(os.path.join(tmp, "P.km2.txt"), "w") as f:
+        for i in range(ni):
+            for j in range(i, ni):
+                f.write("%s\t%s\t%s\n" % (ids[i], ids[j], toks[i][j]))
+    gemma(tmp, "-bfile", "P", "-k", "P.km2.txt", "-km", 2, "-lmm", 1, "-o", "P1km2")
     for ext in (".bed", ".bim", ".fam", ".cov.txt"):
         shutil.copy(pre + ext, os.path.join(OUT, "P" + ext))
     head(cxx, os.path.join(OUT, "P.cXX.head.txt"), 8)
-    for tag in ("P4", "P4c", "P1q", "Plm4c"):
+    for tag in ("P4", "P4c", "P1q", "Plm4c", "P1n", "P1km2"):
         with open(os.path.join(tmp, "output", tag + ".assoc.txt"), "rb") as f, \
                 gzip.GzipFile(os.path.join(OUT, tag + ".assoc.txt.gz"), "wb", mtime=0) as g:
             g.write(f.read())
@@ -114,6 +123,13 @@ def main():
     for m in (1, 2, 3, 4, 9):
         gemma(tmp, *base, "-k", cxx, "-lmm", m, "-no-check", "-maf", "0.1", "-o", "L%d" % m)
         head(os.path.join(tmp, "output", "L%d.assoc.txt" % m), os.path.join(OUT, "L%d.assoc.head.txt" % m), HEAD)
+    # -snps: a listed subset is analysed (-ksnps / -gwasnps are in the help text but are not parsed, src/gemma.cpp:468)
+    rs_all = [l.split()[0] for l in open(E + "BXD_snps.txt")]
+    with open(os.path.join(OUT, "BXD_snps7.txt"), "w") as f:
+        f.writelines(r + "\n" for r in rs_all[::7])
+    gemma(tmp, *base, "-k", cxx, "-lmm", 1, "-no-check", "-maf", "0.1", "-snps", os.path.join(OUT, "BXD_snps7.txt"), "-o", "Ls")
+    with open(os.path.join(tmp, "output", "Ls.assoc.txt"), "rb") as f, gzip.GzipFile(os.path.join(OUT, "Ls.assoc.txt.gz"), "wb", mtime=0) as g:
+        g.write(f.read())
     for line in open(os.path.join(tmp, "output", "L1.log.txt")):
         if "=" in line and line.startswith("##"):
             k, v = line[2:].split("=", 1)

@@ -44,3 +44,7 @@ def test_gxe_plink_files_to_reference_outputs(driver, tmp_path):
 
 def test_gene_expression_file_to_reference_outputs(driver, tmp_path):
     fc.gene_workflow(driver, tmp_path, modes=(1, 4))
+
+
+def test_snps_notsnp_km2_to_reference_outputs(driver, tmp_path):
+    fc.selection_options_workflow(driver, tmp_path)
