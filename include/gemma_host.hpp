@@ -826,7 +826,24 @@ public:
     enforce_hip(gemma_hip_lmm_finish(&time_UtX, &time_opt), "MVLMM::AnalyzePlink");
   }
 
-  // the BIMBAM twin with the rows already parsed: X rows = analysed SNPs over the analysed individuals, NaN = missing
+  // pull-style block source as in LMM::AnalyzeFeed (rows = analysed SNPs over the analysed individuals, NaN = missing):
+  // MVLMM::AnalyzeBimbam, src/mvlmm.cpp:2972-3416, with the file reader factored out
+  void AnalyzeFeed(const Matrix *U, const Vector *eval, const Matrix *UtW, const Matrix *UtY, LMM::RowFeeder &feed,
+                   size_t max_rows, size_t ld) {
+    setup(U, eval, UtW, UtY, 0);
+    std::vector<double> out(max_rows * stride());
+    for (;;) {
+      const double *X = nullptr;
+      const size_t l = feed(X);
+      if (l == 0) break;
+      if (l > max_rows) throw HipError(GEMMA_HIP_EINVAL, "MVLMM::AnalyzeFeed: block larger than max_rows");
+      enforce_hip(gemma_hip_mvlmm_batch(GEMMA_GENO_F64_SNP_MAJOR, X, l, ld, out.data()), "MVLMM::AnalyzeBimbam");
+      sumStat.insert(sumStat.end(), out.begin(), out.begin() + l * stride());
+    }
+    enforce_hip(gemma_hip_lmm_finish(&time_UtX, &time_opt), "MVLMM::AnalyzeBimbam");
+  }
+
+  // the same with the rows already in memory
   void AnalyzeRows(const Matrix *U, const Vector *eval, const Matrix *UtW, const Matrix *UtY, const double *X, size_t n_snps,
                    size_t ld) {
     setup(U, eval, UtW, UtY, 0);

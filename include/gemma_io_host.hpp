@@ -903,6 +903,26 @@ inline void AnalyzeBimbam(LMM &lmm, const Matrix *U, const Vector *eval, const M
   lmm.AnalyzeFeed(U, eval, UtW, Uty, feed, B, n);
 }
 
+// MVLMM::AnalyzeBimbam, src/mvlmm.cpp:2972-3416, over the same threaded reader (mv.file_geno, mv.indicator_idv / _snp)
+inline void AnalyzeBimbam(MVLMM &mv, const Matrix *U, const Vector *eval, const Matrix *UtW, const Matrix *UtY) {
+  const size_t ni_total = mv.indicator_idv.size(), n = U->size1;
+  BimbamReader rd(mv.file_geno, ni_total);
+  if (!rd.ok()) throw std::runtime_error("error reading genotype file");
+  const size_t B = bimbam_block_rows(n, LMM_BATCH_SIZE);
+  BlockPrefetch pf(B * n * sizeof(double), [&](void *slot, int) -> size_t {
+    if (rd.lines_read() >= mv.indicator_snp.size()) return 0;
+    return rd.read_block(B, static_cast<double *>(slot), n, nullptr, &mv.indicator_snp, mv.indicator_idv.data());
+  });
+  LMM::RowFeeder feed = [&](const double *&X) -> size_t {
+    void *slot = nullptr;
+    const size_t l = pf.next(slot);
+    if (l == (size_t)-1) throw std::runtime_error("Problem reading geno file (not enough genotypes in line)");
+    X = static_cast<const double *>(slot);
+    return l;
+  };
+  mv.AnalyzeFeed(U, eval, UtW, UtY, feed, B, n);
+}
+
 // ReadFile_gene, src/gemma_io.cpp:2307-2364 (`-gene`): a header line, then one row per gene: id and ni_total expression
 // values.  Only the ids (into snpInfo.rs_number) and the row count matter to the LMM path.
 inline bool ReadFile_gene(const std::string &file_gene, std::vector<SNPINFO> &snpInfo, size_t &ng_total) {

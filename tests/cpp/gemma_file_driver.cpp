@@ -12,7 +12,7 @@
 // :2557-2830 `-lmm`): first pass over the genotypes (device QC) -> kinship over all individuals -> <o>.cXX.txt / .sXX.txt;
 // or kinship file -> rows of the analysed individuals -> centre -> eigendecomposition (-> <o>.eigenU/D.txt) -> U^T W,
 // U^T y -> null model -> per-SNP association -> <o>.assoc.txt.  One line of key=value pairs on stdout is the log.
-// Several phenotype columns (-n 1 2 3, PLINK input) take the multivariate LMM (src/gemma.cpp:2796-2830 -> class MVLMM).
+// Several phenotype columns (-n 1 2 3) take the multivariate LMM (src/gemma.cpp:2796-2830 -> class MVLMM).
 #include <chrono>
 #include <cstdlib>
 #include <iostream>
@@ -228,11 +228,8 @@ int main(int argc, char **argv) {
     CalcUtX(&U, &W, &UtW);
     CalcUtX(&U, &Y, &UtY);
     if (n_ph > 1) { // src/gemma.cpp:2796-2830: MVLMM
-      if (file_bfile.empty()) {
-        std::cerr << "the multivariate path of this driver takes -bfile input" << std::endl;
-        return 2;
-      }
       MVLMM cMv;
+      cMv.file_geno = file_geno;
       cMv.a_mode = a_mode;
       cMv.file_bfile = file_bfile;
       cMv.path_out = path_out;
@@ -242,7 +239,8 @@ int main(int argc, char **argv) {
       cMv.indicator_snp = indicator_snp;
       cMv.snpInfo = snpInfo;
       const double t_a0 = lap();
-      cMv.AnalyzePlink(&U, &eval, &UtW, &UtY);
+      if (!file_bfile.empty()) cMv.AnalyzePlink(&U, &eval, &UtW, &UtY);
+      else AnalyzeBimbam(cMv, &U, &eval, &UtW, &UtY);
       const double t_a1 = lap();
       cMv.WriteFiles();
       std::cout << " logl_remle_H0=" << cMv.logl_remle_H0 << " logl_mle_H0=" << cMv.logl_mle_H0;

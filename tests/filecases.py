@@ -194,7 +194,7 @@ def loco_workflow(exe, out, chrs=(2,), modes=(1,)):
                     assert (rel <= STAT_TOL).all(), (tag, name, np.nanmax(rel))
 
 
-def mvlmm_workflow(exe, out, modes=(1, 4)):
+def mvlmm_workflow(exe, out, modes=(1, 4), bimbam=False):
     """`-lmm m -n 1 2` (multivariate LMM, class MVLMM) from PLINK files: the reference's test/data/issue243 set (1000
     individuals, 2 traits, first 800 SNPs) rebuilt from tests/golden/ref_mv.npz, -gk then -k ... -lmm, against the
     reference's .assoc.txt columns.  An EM that stops one iteration earlier or later moves the estimates by ~1e-4:
@@ -215,6 +215,17 @@ def mvlmm_workflow(exe, out, modes=(1, 4)):
         for i in range(n_total):
             f.write("f%d i%d 0 0 1 %r %r\n" % (i, i, float(Y[i, 0]), float(Y[i, 1])))
     base = ["-bfile", pre, "-outdir", out]
+    if bimbam:  # the same data as a mean-genotype text file: the reference prints the same table for it (checked when
+        # this case was written: oracle/_ref/gemma -g ... -n 1 2 gives the PLINK run's numbers digit for digit)
+        codes = np.stack([(fx["a_bed"][3:].reshape(-1, nb) >> (2 * k)) & 3 for k in range(4)], axis=2).reshape(ns, nb * 4)[:, :n_total]
+        text = np.array(["2", "NA", "1", "0"])[codes]
+        with open(os.path.join(out, "g.txt"), "w") as f:
+            for t in range(ns):
+                f.write("rs%d, A, G, %s\n" % (t, ", ".join(text[t])))
+        with open(os.path.join(out, "ph.txt"), "w") as f:
+            for i in range(n_total):
+                f.write("%r %r\n" % (float(Y[i, 0]), float(Y[i, 1])))
+        base = ["-g", os.path.join(out, "g.txt"), "-p", os.path.join(out, "ph.txt"), "-outdir", out]
     drive(exe, *base, "-gk", "-o", "mv2")
     cxx = os.path.join(out, "mv2.cXX.txt")
     for m in modes:

@@ -63,6 +63,17 @@ def test_mvlmm_plink_files_to_reference_outputs(driver, tmp_path, monkeypatch):
     fc.mvlmm_workflow(driver, tmp_path, modes=(1, 4))
 
 
+def test_mvlmm_bimbam_text_to_reference_outputs(driver, tmp_path, monkeypatch):
+    """MVLMM::AnalyzeBimbam from the text file (threaded reader, one block ahead)"""
+    import glob
+    import scipy
+    libs = glob.glob(os.path.join(os.path.dirname(os.path.dirname(scipy.__file__)), "scipy.libs", "libscipy_openblas*.so"))
+    if libs:
+        monkeypatch.setenv("GEMMA_DOUBLE_LAPACK", libs[0])
+    monkeypatch.setenv("GEMMA_HIP_IO_BLOCK", "300")
+    fc.mvlmm_workflow(driver, tmp_path, modes=(1,), bimbam=True)
+
+
 def test_lm_files_to_reference_outputs_and_golden_checksum(driver, tmp_path, monkeypatch):
     monkeypatch.setenv("GEMMA_HIP_IO_BLOCK", "1000")
     fc.lm_workflow(driver, tmp_path)

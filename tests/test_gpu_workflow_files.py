@@ -48,3 +48,7 @@ def test_gene_expression_file_to_reference_outputs(driver, tmp_path):
 
 def test_snps_notsnp_km2_to_reference_outputs(driver, tmp_path):
     fc.selection_options_workflow(driver, tmp_path)
+
+
+def test_mvlmm_bimbam_text_to_reference_outputs(driver, tmp_path):
+    fc.mvlmm_workflow(driver, tmp_path, modes=(1, 3), bimbam=True)
