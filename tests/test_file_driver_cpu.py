@@ -150,3 +150,31 @@ def test_driver_edge_cases(driver, tmp_path):
                         "-o", "none"], capture_output=True, text=True)
     assert r.returncode == 0 and "ns_total=0 ns_test=0" in r.stdout and "snps=0" in r.stdout
     assert len(open(tmp_path / "none.assoc.txt").read().strip().split("\n")) == 1  # the header alone
+
+
+def test_feeders_are_race_free_under_thread_sanitizer(driver, tmp_path, monkeypatch):
+    """The host layer runs three kinds of helper threads (the prefetch producer, the text parsers, the row formatters)
+    beside the thread that owns the C ABI: the driver rebuilt with -fsanitize=thread goes through first pass, kinship and
+    association in many small blocks and must finish without a ThreadSanitizer report, with the same output bytes."""
+    exe = str(tmp_path / "driver_tsan")
+    libdir = os.path.dirname(driver)
+    r = subprocess.run(["g++", "-std=c++11", "-O1", "-g", "-fsanitize=thread", "-I" + os.path.join(ROOT, "include"),
+                        os.path.join(ROOT, "tests", "cpp", "gemma_file_driver.cpp"), "-L" + libdir, "-lgemma_hip",
+                        "-Wl,-rpath," + libdir, "-lz", "-pthread", "-o", exe], capture_output=True, text=True)
+    if r.returncode != 0:
+        pytest.skip("no ThreadSanitizer runtime here: " + r.stderr[-200:])
+    monkeypatch.setenv("GEMMA_HIP_IO_BLOCK", "97")
+    monkeypatch.setenv("GEMMA_HIP_IO_THREADS", "4")
+    T = fc.TXT
+    base = ["-g", os.path.join(T, "BXD_geno.txt.gz"), "-p", os.path.join(T, "BXD_pheno.txt"),
+            "-c", os.path.join(T, "BXD_covariates2.txt"), "-a", os.path.join(T, "BXD_snps.txt.gz"), "-outdir", str(tmp_path)]
+    runs = [base + ["-gk", "-o", "B"],
+            base + ["-k", str(tmp_path / "B.cXX.txt"), "-lmm", "1", "-maf", "0.1", "-o", "L"],
+            ["-bfile", os.path.join(T, "P"), "-outdir", str(tmp_path), "-gk", "-o", "P"],
+            ["-bfile", os.path.join(T, "P"), "-outdir", str(tmp_path), "-k", str(tmp_path / "P.cXX.txt"), "-lmm", "4", "-o", "P4"]]
+    for args in runs:
+        r = subprocess.run([exe] + args, capture_output=True, text=True)
+        assert r.returncode == 0, r.stdout + r.stderr
+        assert "ThreadSanitizer" not in r.stderr, r.stderr[-3000:]
+    assert open(tmp_path / "L.assoc.txt").read().split("\n")[:120] == open(os.path.join(T, "L1.assoc.head.txt")).read().split("\n")[:120]
+    fc.compare_assoc(str(tmp_path / "P4.assoc.txt"), os.path.join(T, "P4.assoc.txt.gz"))
