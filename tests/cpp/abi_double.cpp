@@ -10,7 +10,8 @@
 // for imputation, centring, kinship preparation, the null model and the per-SNP statistics; plain loops for the
 // GEMMs; for the symmetric eigenproblem LAPACK's dsyev from the OpenBLAS inside scipy when the test names it in
 // GEMMA_DOUBLE_LAPACK (dlopen), otherwise a cyclic Jacobi sweep (the statistics do not depend on the eigenbasis,
-// SURVEY App. A.6); the first-pass SNP filters restated here from src/gemma_io.cpp:753-853 / :942-1049 (no HWE).
+// SURVEY App. A.6); the first-pass SNP filters restated here from src/gemma_io.cpp:753-853 / :942-1049, the exact HWE
+// test from src/mathfunc.cpp:546-640 (Wigginton et al. 2005).
 #include <dlfcn.h>
 
 #include <algorithm>
@@ -101,6 +102,41 @@ std::vector<double> transposed(const double *A, size_t rows, size_t cols) {
   return T;
 }
 
+// exact test of Hardy-Weinberg equilibrium: probability of every heterozygote count given the allele counts, built
+// outwards from the most likely count; p = total probability of the counts no likelier than the observed one
+double calc_hwe(size_t n_hom1, size_t n_hom2, size_t n_ab) {
+  if (n_hom1 + n_hom2 + n_ab == 0) return 1.0;
+  const long n_aa = (long)std::min(n_hom1, n_hom2), n_bb = (long)std::max(n_hom1, n_hom2), nab = (long)n_ab;
+  const long rare = 2 * n_aa + nab, genotypes = nab + n_bb + n_aa;
+  std::vector<double> het((size_t)rare + 1, 0.0);
+  long mid = rare * (2 * genotypes - rare) / (2 * genotypes);
+  if ((rare & 1) ^ (mid & 1)) mid++;
+  het[(size_t)mid] = 1.0;
+  double sum = 1.0;
+  long homr = (rare - mid) / 2, homc = genotypes - mid - homr;
+  for (long h = mid; h > 1; h -= 2) {
+    het[(size_t)h - 2] = het[(size_t)h] * (double)h * ((double)h - 1.0) / (4.0 * ((double)homr + 1.0) * ((double)homc + 1.0));
+    sum += het[(size_t)h - 2];
+    homr++;
+    homc++;
+  }
+  homr = (rare - mid) / 2;
+  homc = genotypes - mid - homr;
+  for (long h = mid; h <= rare - 2; h += 2) {
+    het[(size_t)h + 2] = het[(size_t)h] * 4.0 * (double)homr * (double)homc / (((double)h + 2.0) * ((double)h + 1.0));
+    sum += het[(size_t)h + 2];
+    homr--;
+    homc--;
+  }
+  double p = 0.0;
+  for (long i = 0; i <= rare; ++i) {
+    const double v = het[(size_t)i] / sum;
+    if (v > het[(size_t)nab] / sum) continue;
+    p += v;
+  }
+  return p > 1.0 ? 1.0 : p;
+}
+
 // rows of l SNPs over `n_out` individuals (NaN = missing) from either encoding
 void decode(int kind, const void *geno, size_t l, size_t ld, const int *ind, size_t ni_total, size_t n_out,
             std::vector<double> &X) {
@@ -176,7 +212,6 @@ int gemma_hip_kin_end(double *K, size_t *ns_used) {
 int gemma_hip_snp_qc(int kind, const void *geno, size_t l, size_t ld, const int *indicator_idv, size_t ni_total,
                      const double *W, size_t n, size_t c, const gemma_qc_cfg *cfg, int *indicator_snp, double *maf_out,
                      size_t *n_miss_out) {
-  if (cfg->hwe_level != 0) return fail(GEMMA_HIP_EINVAL, "test double: no HWE filter");
   std::vector<double> X;
   decode(kind, geno, l, ld, indicator_idv, ni_total, n, X);
   // (W^T W)^-1 by Gauss-Jordan
@@ -220,6 +255,7 @@ int gemma_hip_snp_qc(int kind, const void *geno, size_t l, size_t ld, const int 
     if ((double)n_miss / (double)n > cfg->miss_level) keep = 0;
     else if ((maf < cfg->maf_level || maf > 1.0 - cfg->maf_level) && cfg->maf_level != -1) keep = 0;
     else if (kind == GEMMA_GENO_PLINK_2BIT ? ((n0 + n1) == 0 || (n1 + n2) == 0 || (n2 + n0) == 0) : !differ) keep = 0;
+    else if (cfg->hwe_level != 0 && cfg->maf_level != -1 && calc_hwe(n0, n2, n1) < cfg->hwe_level) keep = 0;
     else if (c != 1) {
       std::vector<double> Wtx(c, 0.0);
       double v_x = 0.0, v_w = 0.0;

@@ -394,3 +394,23 @@ def selection_options_workflow(exe, out):
     kv = drive(exe, *pb, "-k", os.path.join(out, "P.km2.txt"), "-km", 2, "-lmm", 1, "-o", "P1km2")
     check_log(kv, "P1km2.log.json")
     compare_assoc(os.path.join(out, "P1km2.assoc.txt"), os.path.join(TXT, "P1km2.assoc.txt.gz"))
+
+
+def hwe_reference_sets():
+    """(rs kept without, rs kept with `-hwe 0.05`) as the reference binary printed them for tests/golden/text/H.*"""
+    _, all_rows = read_assoc(os.path.join(TXT, "Hall.assoc.txt.gz"))
+    _, hwe_rows = read_assoc(os.path.join(TXT, "Hhwe.assoc.txt.gz"))
+    return [r[1] for r in all_rows], [r[1] for r in hwe_rows]
+
+
+def hwe_workflow(exe, out):
+    """`-hwe 0.05` on a PLINK set with heterozygotes: the exact test of CalcHWE (src/mathfunc.cpp:546-640) runs in the device's
+    first pass; same surviving SNPs and statistics as the reference."""
+    out = str(out)
+    pb = ["-bfile", os.path.join(TXT, "H"), "-outdir", out]
+    drive(exe, *pb, "-gk", "-o", "H")
+    cxx = os.path.join(out, "H.cXX.txt")
+    kv = drive(exe, *pb, "-k", cxx, "-lmm", 1, "-hwe", "0.05", "-o", "Hhwe")
+    all_rs, hwe_rs = hwe_reference_sets()
+    assert int(kv["ns_test"]) == len(hwe_rs) < len(all_rs)
+    compare_assoc(os.path.join(out, "Hhwe.assoc.txt"), os.path.join(TXT, "Hhwe.assoc.txt.gz"))

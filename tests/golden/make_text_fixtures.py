@@ -92,6 +92,27 @@ def plink_subset(tmp, ni=240, ns=800):
         json.dump(meta, open(os.path.join(OUT, tag + ".log.json"), "w"), indent=1, sort_keys=True)
 
 
+def hwe_set(tmp):
+    """A small synthetic PLINK set WITH heterozygotes (the issue188 lines are inbred: no hets, every SNP fails any HWE
+    test) from tests/cpp/io_host_check.cpp's generator, and the reference's `-hwe 0.05` run on it: which SNPs survive
+    CalcHWE (src/mathfunc.cpp:546-640) and their statistics."""
+    exe = os.path.join(tmp, "io_check")
+    subprocess.check_call(["g++", "-std=c++11", "-O2", "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "cpp", "io_host_check.cpp"), "-L" + os.path.join(ROOT, "gemma_amd"),
+                           "-lgemma_hip", "-Wl,-rpath," + os.path.join(ROOT, "gemma_amd"), "-lz", "-pthread", "-o", exe])
+    subprocess.check_call([exe, "plinkgen", os.path.join(tmp, "H"), "300", "600", "2"])
+    gemma(tmp, "-bfile", "H", "-gk", 1, "-o", "H")
+    cxx = os.path.join(tmp, "output", "H.cXX.txt")
+    gemma(tmp, "-bfile", "H", "-k", cxx, "-lmm", 1, "-hwe", 0.05, "-o", "Hhwe")
+    gemma(tmp, "-bfile", "H", "-k", cxx, "-lmm", 1, "-o", "Hall")
+    for ext in (".bed", ".bim", ".fam"):
+        shutil.copy(os.path.join(tmp, "H" + ext), os.path.join(OUT, "H" + ext))
+    for tag in ("Hhwe", "Hall"):
+        with open(os.path.join(tmp, "output", tag + ".assoc.txt"), "rb") as f, \
+                gzip.GzipFile(os.path.join(OUT, tag + ".assoc.txt.gz"), "wb", mtime=0) as g:
+            g.write(f.read())
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     tmp = tempfile.mkdtemp()
@@ -137,6 +158,7 @@ def main():
                 meta[k.strip()] = v.strip()
     json.dump(meta, open(os.path.join(OUT, "L1.log.json"), "w"), indent=1, sort_keys=True)
     plink_subset(tmp)
+    hwe_set(tmp)
     for f in ("BXD_geno.txt.gz",):
         shutil.copy(E + f, os.path.join(OUT, f))
     with open(E + "BXD_snps.txt", "rb") as f, gzip.GzipFile(os.path.join(OUT, "BXD_snps.txt.gz"), "wb", mtime=0) as g:

@@ -52,3 +52,7 @@ def test_snps_notsnp_km2_to_reference_outputs(driver, tmp_path):
 
 def test_mvlmm_bimbam_text_to_reference_outputs(driver, tmp_path):
     fc.mvlmm_workflow(driver, tmp_path, modes=(1, 3), bimbam=True)
+
+
+def test_hwe_filter_to_reference_outputs(driver, tmp_path):
+    fc.hwe_workflow(driver, tmp_path)

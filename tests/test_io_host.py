@@ -281,3 +281,24 @@ def test_assoc_writer_byte_identical_to_reference(exe, tmp_path, mode):
     src = os.path.join(TXT, "L%d.assoc.head.txt" % mode)
     run(exe, "assoc", src, mode, tmp_path, "W")
     assert open(tmp_path / "W.assoc.txt", "rb").read() == open(src, "rb").read()
+
+
+def test_oracle_hwe_filter_keeps_the_reference_snp_set(oracle):
+    """Pins the oracle's restatement of CalcHWE (src/mathfunc.cpp:546-640) and of the filter order of ReadFile_bed on the
+    reference itself: `gemma -hwe 0.05` on tests/golden/text/H.* (a synthetic PLINK set with heterozygotes) keeps 567 of 600
+    SNPs -- the same ones the oracle's first pass keeps; the GPU first pass is checked against the oracle in
+    tests/test_gpu_parity.py and against this file in tests/test_gpu_workflow_files.py."""
+    import filecases as fc
+    all_rs, hwe_rs = fc.hwe_reference_sets()
+    raw = np.fromfile(os.path.join(TXT, "H.bed"), dtype=np.uint8)[3:].reshape(600, -1)
+    fam = [l.split() for l in open(os.path.join(TXT, "H.fam"))]
+    ind = np.array([0 if f[5] in ("-9", "NA") else 1 for f in fam], dtype=np.int32)
+    G = oracle.bed_decode(raw, len(fam))[:, ind == 1]
+    W = np.ones((int(ind.sum()), 1))
+    rs = np.array([l.split()[1] for l in open(os.path.join(TXT, "H.bim"))])
+    keep_all = oracle.qc_snps_bed(G, W)
+    keep_hwe = oracle.qc_snps_bed(G, W, hwe_level=0.05)
+    keep_all = keep_all[0] if isinstance(keep_all, tuple) else keep_all
+    keep_hwe = keep_hwe[0] if isinstance(keep_hwe, tuple) else keep_hwe
+    assert list(rs[np.asarray(keep_all) == 1]) == all_rs
+    assert list(rs[np.asarray(keep_hwe) == 1]) == hwe_rs and len(hwe_rs) == 567
