@@ -79,7 +79,7 @@ def check_log(kv, log_json):
             assert abs(float(kv[key]) - float(log[name])) <= 2e-5 * abs(float(log[name])) + 1e-12, (key, kv[key], log[name])
 
 
-def bxd_bimbam_workflow(exe, out):
+def bxd_bimbam_workflow(exe, out, modes=(1, 4, 9)):
     """BIMBAM text input with covariates and annotation: -gk, -lmm 1/4/9 through the 10-digit cXX hand-off, -eigen,
     then -lmm from the -d/-u artefacts."""
     out = str(out)
@@ -93,7 +93,7 @@ def bxd_bimbam_workflow(exe, out):
     assert K.shape == ref.shape and np.abs(K - ref).max() <= 2e-10  # one unit of the 10th printed digit
     corner = np.loadtxt(os.path.join(TXT, "BXD.cXX.corner.txt"))
     assert np.abs(K[:24, :24] - corner).max() <= 2e-10
-    for m in (1, 4, 9):
+    for m in modes:
         kv = drive(exe, *base, "-k", cxx, "-lmm", m, "-maf", "0.1", "-o", "L%d" % m)
         check_log(kv, "L1.log.json")
         compare_assoc(os.path.join(out, "L%d.assoc.txt" % m), os.path.join(TXT, "L%d.assoc.head.txt" % m), n_ref_rows=7317)
