@@ -78,7 +78,7 @@ def test_cpp_host_mirror_compiles():
     with tempfile.TemporaryDirectory() as td:
         subprocess.check_call(["g++", "-std=c++11", "-O1", "-Wall", "-I" + os.path.join(ROOT, "include"),
                                os.path.join(ROOT, "tests", "cpp", "host_mirror_driver.cpp"),
-                               "-L" + os.path.dirname(so), "-lgemma_hip", "-Wl,-rpath," + os.path.dirname(so),
+                               "-L" + os.path.dirname(so), "-lgemma_hip", "-pthread", "-Wl,-rpath," + os.path.dirname(so),
                                "-o", os.path.join(td, "drv")])
         r = subprocess.run([os.path.join(td, "drv")], capture_output=True)
         assert r.returncode == 2  # usage error, before any GPU call

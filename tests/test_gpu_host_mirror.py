@@ -18,7 +18,7 @@ def _build(tmp):
     build.build()
     subprocess.check_call(["g++", "-std=c++11", "-O2", "-I" + os.path.join(ROOT, "include"),
                            os.path.join(ROOT, "tests", "cpp", "host_mirror_driver.cpp"),
-                           "-L" + os.path.join(ROOT, "gemma_amd"), "-lgemma_hip",
+                           "-L" + os.path.join(ROOT, "gemma_amd"), "-lgemma_hip", "-pthread",
                            "-Wl,-rpath," + os.path.join(ROOT, "gemma_amd"), "-o", exe])
     return exe
 

@@ -58,6 +58,9 @@ def test_parse_double_is_atof(exe):
             toks.append("%d.%0*d" % (rng.integers(0, 10 ** 6), int(rng.integers(1, 18)), rng.integers(0, 10 ** 9)))
         else:
             toks.append("%de%d" % (rng.integers(-10 ** 17, 10 ** 17), rng.integers(-30, 30)))
+    alphabet = list("0123456789.eE+-xXpPnNaAiIfF")
+    for _ in range(3000):  # fuzz: whatever strtod makes of it, parse_double must make the same
+        toks.append("".join(rng.choice(alphabet, size=int(rng.integers(1, 13)))))
     out = run(exe, "parse", stdin="\n".join(toks) + "\n").stdout.split()
     assert len(out) == len(toks)
     for t, h in zip(toks, out):
