@@ -414,3 +414,42 @@ def hwe_workflow(exe, out):
     all_rs, hwe_rs = hwe_reference_sets()
     assert int(kv["ns_test"]) == len(hwe_rs) < len(all_rs)
     compare_assoc(os.path.join(out, "Hhwe.assoc.txt"), os.path.join(TXT, "Hhwe.assoc.txt.gz"))
+
+
+def mvlmm3_workflow(exe, out, modes=(1, 3)):
+    """Three traits with missing phenotypes (fixture `b` of ref_mv.npz: issue188 genotypes, simulated correlated traits, 25 NA
+    entries): the `-gk` run selects individuals by trait 1 alone, the `-lmm m -n 1 2 3` run by all three -- as the reference
+    does; REML and score modes (the reference's ML EM for d >= 3 is basis-unstable)."""
+    import refcases as R
+    out = str(out)
+    fx = np.load(os.path.join(ROOT, "tests", "golden", "ref_mv.npz"))
+    f188 = np.load(os.path.join(ROOT, "tests", "golden", "ref_issue188.npz"))
+    txt = fx["b_pheno_txt"]
+    n_total = txt.shape[0]
+    nb = (n_total + 3) // 4
+    ns = (f188["bed"].size - 3) // nb
+    pre = os.path.join(out, "mv3")
+    open(pre + ".bed", "wb").write(f188["bed"].tobytes())
+    with open(pre + ".bim", "w") as f:
+        for t in range(ns):
+            f.write("1\trs%d\t0\t%d\tA\tG\n" % (t, t + 1))
+    with open(pre + ".fam", "w") as f:
+        for i in range(n_total):
+            f.write("f%d i%d 0 0 1 %s\n" % (i, i, " ".join(txt[i])))
+    base = ["-bfile", pre, "-outdir", out]
+    drive(exe, *base, "-gk", "-o", "mv3")
+    cxx = os.path.join(out, "mv3.cXX.txt")
+    for m in modes:
+        kv = drive(exe, *base, "-k", cxx, "-lmm", m, "-n", 1, 2, 3, "-o", "mv3_m%d" % m)
+        assert int(kv["ni_test"]) == int((np.array([["NA" in r for r in txt]]) == 0).sum())
+        assert abs(float(kv["logl_remle_H0"]) - fx["b_logl_null"][0]) <= 2e-6 * abs(fx["b_logl_null"][0])
+        hdr, rows = read_assoc(os.path.join(out, "mv3_m%d.assoc.txt" % m))
+        assert [r[1] for r in rows] == ["rs%d" % t for t in fx["b_snp"]]
+        col = {name: np.array([float(r[j]) for r in rows]) for j, name in enumerate(hdr) if j >= 7}
+        got = {"beta": np.column_stack([col["beta_%d" % (i + 1)] for i in range(3)]),
+               "Vbeta": np.column_stack([col["Vbeta_%d_%d" % (i + 1, j + 1)] for i in range(3) for j in range(i, 3)])}
+        for c in ("p_wald", "p_lrt", "p_score"):
+            if c in col:
+                got[c] = col[c]
+        err = R.mv_row_err(got, R.mv_ref_table(fx, "b", m, 3))
+        assert np.mean(err <= STAT_TOL) >= 0.97 and err.max() <= 5e-3, (m, float(np.mean(err <= STAT_TOL)), float(err.max()))

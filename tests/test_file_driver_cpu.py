@@ -63,6 +63,15 @@ def test_mvlmm_plink_files_to_reference_outputs(driver, tmp_path, monkeypatch):
     fc.mvlmm_workflow(driver, tmp_path, modes=(1, 4))
 
 
+def test_mvlmm_three_traits_missing_phenotypes(driver, tmp_path, monkeypatch):
+    import glob
+    import scipy
+    libs = glob.glob(os.path.join(os.path.dirname(os.path.dirname(scipy.__file__)), "scipy.libs", "libscipy_openblas*.so"))
+    if libs:
+        monkeypatch.setenv("GEMMA_DOUBLE_LAPACK", libs[0])
+    fc.mvlmm3_workflow(driver, tmp_path, modes=(1,))
+
+
 def test_mvlmm_bimbam_text_to_reference_outputs(driver, tmp_path, monkeypatch):
     """MVLMM::AnalyzeBimbam from the text file (threaded reader, one block ahead)"""
     import glob

@@ -56,3 +56,7 @@ def test_mvlmm_bimbam_text_to_reference_outputs(driver, tmp_path):
 
 def test_hwe_filter_to_reference_outputs(driver, tmp_path):
     fc.hwe_workflow(driver, tmp_path)
+
+
+def test_mvlmm_three_traits_missing_phenotypes(driver, tmp_path):
+    fc.mvlmm3_workflow(driver, tmp_path, modes=(1, 3))
