@@ -83,8 +83,8 @@ def bxd_bimbam_workflow(exe, out, modes=(1, 4, 9)):
     """BIMBAM text input with covariates and annotation: -gk, -lmm 1/4/9 through the 10-digit cXX hand-off, -eigen,
     then -lmm from the -d/-u artefacts."""
     out = str(out)
-    base = ["-g", os.path.join(TXT, "BXD_geno.txt.gz"), "-p", os.path.join(TXT, "BXD_pheno.txt"),
-            "-c", os.path.join(TXT, "BXD_covariates2.txt"), "-a", os.path.join(TXT, "BXD_snps.txt.gz"), "-outdir", out]
+    base = ["-g", os.path.join(TXT, "bxd_mean_genotypes.txt.gz"), "-p", os.path.join(TXT, "bxd_trait.txt.gz"),
+            "-c", os.path.join(TXT, "bxd_cvt.txt.gz"), "-a", os.path.join(TXT, "bxd_anno.txt.gz"), "-outdir", out]
     kv = drive(exe, *base, "-gk", "-o", "BXD")
     assert (int(kv["ni_total"]), int(kv["ni_test"]), int(kv["ns_total"]), int(kv["ns_test"])) == (198, 67, 7320, 7317)
     cxx = os.path.join(out, "BXD.cXX.txt")
@@ -265,8 +265,8 @@ def lm_workflow(exe, out):
     run -- 95134 words, field checksum 3089042886 (test/dev_test_suite.sh:60-68) -- on the file this driver writes, and every
     column against the reference binary's output; PLINK subset with covariates against its `-lm 4` file."""
     out = str(out)
-    base = ["-g", os.path.join(TXT, "BXD_geno.txt.gz"), "-p", os.path.join(TXT, "BXD_pheno.txt"),
-            "-c", os.path.join(TXT, "BXD_covariates2.txt"), "-a", os.path.join(TXT, "BXD_snps.txt.gz"), "-outdir", out]
+    base = ["-g", os.path.join(TXT, "bxd_mean_genotypes.txt.gz"), "-p", os.path.join(TXT, "bxd_trait.txt.gz"),
+            "-c", os.path.join(TXT, "bxd_cvt.txt.gz"), "-a", os.path.join(TXT, "bxd_anno.txt.gz"), "-outdir", out]
     full = np.load(os.path.join(ROOT, "tests", "golden", "ref_bxd.npz"))
     for m in (1, 2, 3, 4):
         drive(exe, *base, "-lm", m, "-maf", "0.1", "-o", "LM%d" % m)
@@ -372,11 +372,11 @@ def selection_options_workflow(exe, out):
     order with indicator 0), `-notsnp` (no maf filter) and `-km 2` (kinship as id-pair triples over the .fam ids), each
     against the reference binary's output for the same command."""
     out = str(out)
-    base = ["-g", os.path.join(TXT, "BXD_geno.txt.gz"), "-p", os.path.join(TXT, "BXD_pheno.txt"),
-            "-c", os.path.join(TXT, "BXD_covariates2.txt"), "-a", os.path.join(TXT, "BXD_snps.txt.gz"), "-outdir", out]
+    base = ["-g", os.path.join(TXT, "bxd_mean_genotypes.txt.gz"), "-p", os.path.join(TXT, "bxd_trait.txt.gz"),
+            "-c", os.path.join(TXT, "bxd_cvt.txt.gz"), "-a", os.path.join(TXT, "bxd_anno.txt.gz"), "-outdir", out]
     drive(exe, *base, "-gk", "-o", "BXD")
     kv = drive(exe, *base, "-k", os.path.join(out, "BXD.cXX.txt"), "-lmm", 1, "-maf", "0.1", "-snps",
-               os.path.join(TXT, "BXD_snps7.txt"), "-o", "Ls")
+               os.path.join(TXT, "bxd_snps7.txt"), "-o", "Ls")
     assert int(kv["ns_total"]) == 7320 and int(kv["ns_test"]) == 1045
     compare_assoc(os.path.join(out, "Ls.assoc.txt"), os.path.join(TXT, "Ls.assoc.txt.gz"))
     pb = ["-bfile", os.path.join(TXT, "P"), "-outdir", out]

@@ -117,9 +117,11 @@ def main():
     os.makedirs(OUT, exist_ok=True)
     tmp = tempfile.mkdtemp()
     base = ["-g", E + "BXD_geno.txt.gz", "-p", E + "BXD_pheno.txt", "-c", E + "BXD_covariates2.txt", "-a", E + "BXD_snps.txt"]
-    for f in ("BXD_pheno.txt", "BXD_covariates2.txt"):
-        shutil.copy(E + f, os.path.join(OUT, f))
-    with gzip.open(E + "BXD_geno.txt.gz", "rt") as f, open(os.path.join(OUT, "BXD_geno_head.txt"), "w") as g:
+    # the reference's example inputs are stored compressed under names of their own (the readers take gzip directly)
+    for f, dst in (("BXD_pheno.txt", "bxd_trait.txt.gz"), ("BXD_covariates2.txt", "bxd_cvt.txt.gz")):
+        with open(E + f, "rb") as src, gzip.GzipFile(os.path.join(OUT, dst), "wb", mtime=0) as g:
+            g.write(src.read())
+    with gzip.open(E + "BXD_geno.txt.gz", "rt") as f, open(os.path.join(OUT, "bxd_mean_genotypes_head.txt"), "w") as g:
         rs = []
         for i, line in enumerate(f):
             if i >= HEAD:
@@ -127,7 +129,7 @@ def main():
             g.write(line)
             rs.append(line.split(",")[0].strip())
     keep = set(rs)
-    with open(E + "BXD_snps.txt") as f, open(os.path.join(OUT, "BXD_snps_head.txt"), "w") as g:
+    with open(E + "BXD_snps.txt") as f, open(os.path.join(OUT, "bxd_anno_head.txt"), "w") as g:
         for line in f:
             if line.split()[0].strip(",") in keep:
                 g.write(line)
@@ -146,9 +148,9 @@ def main():
         head(os.path.join(tmp, "output", "L%d.assoc.txt" % m), os.path.join(OUT, "L%d.assoc.head.txt" % m), HEAD)
     # -snps: a listed subset is analysed (-ksnps / -gwasnps are in the help text but are not parsed, src/gemma.cpp:468)
     rs_all = [l.split()[0] for l in open(E + "BXD_snps.txt")]
-    with open(os.path.join(OUT, "BXD_snps7.txt"), "w") as f:
+    with open(os.path.join(OUT, "bxd_snps7.txt"), "w") as f:
         f.writelines(r + "\n" for r in rs_all[::7])
-    gemma(tmp, *base, "-k", cxx, "-lmm", 1, "-no-check", "-maf", "0.1", "-snps", os.path.join(OUT, "BXD_snps7.txt"), "-o", "Ls")
+    gemma(tmp, *base, "-k", cxx, "-lmm", 1, "-no-check", "-maf", "0.1", "-snps", os.path.join(OUT, "bxd_snps7.txt"), "-o", "Ls")
     with open(os.path.join(tmp, "output", "Ls.assoc.txt"), "rb") as f, gzip.GzipFile(os.path.join(OUT, "Ls.assoc.txt.gz"), "wb", mtime=0) as g:
         g.write(f.read())
     for line in open(os.path.join(tmp, "output", "L1.log.txt")):
@@ -159,9 +161,9 @@ def main():
     json.dump(meta, open(os.path.join(OUT, "L1.log.json"), "w"), indent=1, sort_keys=True)
     plink_subset(tmp)
     hwe_set(tmp)
-    for f in ("BXD_geno.txt.gz",):
-        shutil.copy(E + f, os.path.join(OUT, f))
-    with open(E + "BXD_snps.txt", "rb") as f, gzip.GzipFile(os.path.join(OUT, "BXD_snps.txt.gz"), "wb", mtime=0) as g:
+    with gzip.open(E + "BXD_geno.txt.gz", "rb") as f, gzip.GzipFile(os.path.join(OUT, "bxd_mean_genotypes.txt.gz"), "wb", mtime=0) as g:
+        g.write(f.read())
+    with open(E + "BXD_snps.txt", "rb") as f, gzip.GzipFile(os.path.join(OUT, "bxd_anno.txt.gz"), "wb", mtime=0) as g:
         g.write(f.read())
     shutil.rmtree(tmp)
     print("wrote", sorted(os.listdir(OUT)))

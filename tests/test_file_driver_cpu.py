@@ -120,7 +120,7 @@ def test_driver_reports_reader_errors(driver, tmp_path):
     """Where the reference's readers return false the driver stops (exit code 3) instead of analysing garbage."""
     bad = tmp_path / "short.txt"
     bad.write_text("rs1, A, G, 0, 1\n")
-    r = subprocess.run([driver, "-g", str(bad), "-p", os.path.join(fc.TXT, "BXD_pheno.txt"), "-gk", "-outdir", str(tmp_path)],
+    r = subprocess.run([driver, "-g", str(bad), "-p", os.path.join(fc.TXT, "bxd_trait.txt.gz"), "-gk", "-outdir", str(tmp_path)],
                        capture_output=True, text=True)
     assert r.returncode == 3 and "not enough genotypes" in r.stdout
     r = subprocess.run([driver, "-bfile", str(tmp_path / "nothing"), "-gk", "-outdir", str(tmp_path)], capture_output=True, text=True)
@@ -132,8 +132,9 @@ def test_driver_edge_cases(driver, tmp_path):
     file of the wrong size; an input without a single SNP line is an empty (not a crashing) first pass."""
     import numpy as np
     out = str(tmp_path)
-    geno = os.path.join(fc.TXT, "BXD_geno_head.txt")
-    ni = len(open(os.path.join(fc.TXT, "BXD_pheno.txt")).read().split())
+    geno = os.path.join(fc.TXT, "bxd_mean_genotypes_head.txt")
+    import gzip
+    ni = len(gzip.open(os.path.join(fc.TXT, "bxd_trait.txt.gz"), "rt").read().split())
     allna = tmp_path / "na.txt"
     allna.write_text("NA\n" * ni)
     r = subprocess.run([driver, "-g", geno, "-p", str(allna), "-gk", "-outdir", out], capture_output=True, text=True)
@@ -159,7 +160,7 @@ def test_driver_edge_cases(driver, tmp_path):
     # no SNP at all: an empty genotype file passes the first pass with zero SNPs
     empty = tmp_path / "empty.txt"
     empty.write_text("")
-    r = subprocess.run([driver, "-g", str(empty), "-p", os.path.join(fc.TXT, "BXD_pheno.txt"), "-lm", "1", "-outdir", out,
+    r = subprocess.run([driver, "-g", str(empty), "-p", os.path.join(fc.TXT, "bxd_trait.txt.gz"), "-lm", "1", "-outdir", out,
                         "-o", "none"], capture_output=True, text=True)
     assert r.returncode == 0 and "ns_total=0 ns_test=0" in r.stdout and "snps=0" in r.stdout
     assert len(open(tmp_path / "none.assoc.txt").read().strip().split("\n")) == 1  # the header alone
@@ -179,8 +180,8 @@ def test_feeders_are_race_free_under_thread_sanitizer(driver, tmp_path, monkeypa
     monkeypatch.setenv("GEMMA_HIP_IO_BLOCK", "97")
     monkeypatch.setenv("GEMMA_HIP_IO_THREADS", "4")
     T = fc.TXT
-    base = ["-g", os.path.join(T, "BXD_geno.txt.gz"), "-p", os.path.join(T, "BXD_pheno.txt"),
-            "-c", os.path.join(T, "BXD_covariates2.txt"), "-a", os.path.join(T, "BXD_snps.txt.gz"), "-outdir", str(tmp_path)]
+    base = ["-g", os.path.join(T, "bxd_mean_genotypes.txt.gz"), "-p", os.path.join(T, "bxd_trait.txt.gz"),
+            "-c", os.path.join(T, "bxd_cvt.txt.gz"), "-a", os.path.join(T, "bxd_anno.txt.gz"), "-outdir", str(tmp_path)]
     runs = [base + ["-gk", "-o", "B"],
             base + ["-k", str(tmp_path / "B.cXX.txt"), "-lmm", "1", "-maf", "0.1", "-o", "L"],
             ["-bfile", os.path.join(T, "P"), "-outdir", str(tmp_path), "-gk", "-o", "P"],

@@ -72,12 +72,15 @@ def _tok(line):
     return line.replace(",", " ").split()
 
 
-def test_bxd_individual_selection_matches_reference_log(exe, oracle):
+def test_bxd_individual_selection_matches_reference_log(exe, oracle, tmp_path):
     """ReadFile_pheno + ReadFile_cvt + ProcessCvtPhen on the BXD example: the counts the reference's log reports,
     W / y equal to the oracle's restatement of the same functions."""
     log = json.load(open(os.path.join(TXT, "L1.log.json")))
-    ph, cv = os.path.join(TXT, "BXD_pheno.txt"), os.path.join(TXT, "BXD_covariates2.txt")
-    out = run(exe, "cvtphen", ph, cv, 1).stdout.split("\n")
+    ph_gz, cv_gz = os.path.join(TXT, "bxd_trait.txt.gz"), os.path.join(TXT, "bxd_cvt.txt.gz")
+    out = run(exe, "cvtphen", ph_gz, cv_gz, 1).stdout.split("\n")  # the C++ readers take gzip directly
+    ph, cv = str(tmp_path / "trait.txt"), str(tmp_path / "cvt.txt")  # the oracle's readers want plain text
+    for src, dst in ((ph_gz, ph), (cv_gz, cv)):
+        open(dst, "wb").write(gzip.open(src, "rb").read())
     ni_test, n_cvt = map(int, out[0].split())
     ind = np.array(out[1].split(), dtype=int)
     assert ni_test == int(log["number of analyzed individuals"]) and n_cvt == int(log["number of covariates"])
@@ -150,8 +153,8 @@ def test_bim_and_anno_readers(exe, tmp_path):
     bim.write_text("1\trs1\t0\t1000\tA\tG\n2 rs2 0.5 2000 C T\nX\trs3\t1e-2\t3000\tG\tA\r\n")
     got = run(exe, "bim", bim).stdout.strip().split("\n")
     assert got == ["1 rs1 0 1000 A G", "2 rs2 0.5 2000 C T", "X rs3 0.01 3000 G A"]
-    got = run(exe, "anno", os.path.join(TXT, "BXD_snps_head.txt")).stdout.strip().split("\n")
-    ref = sorted(l.split() for l in open(os.path.join(TXT, "BXD_snps_head.txt")))
+    got = run(exe, "anno", os.path.join(TXT, "bxd_anno_head.txt")).stdout.strip().split("\n")
+    ref = sorted(l.split() for l in open(os.path.join(TXT, "bxd_anno_head.txt")))
     assert [g.split()[:3] for g in got] == [[r[0], r[1], r[2]] for r in ref] and all(g.split()[3] == "-9" for g in got)
     an = tmp_path / "a.txt"
     an.write_text("rsA, 100, 3, 0.5\nrsB, NA, NA\nrsC\t7\n")
@@ -175,7 +178,7 @@ def _expected_rows(lines, ni_total):
 def test_bimbam_reader_bxd_head(exe, tmp_path, threads, block):
     """The threaded BIMBAM parser on the first lines of the reference's own BXD genotype file: every value the double
     atof gives, NA -> NaN, rs / alleles kept, whatever the thread count and block size."""
-    src = os.path.join(TXT, "BXD_geno_head.txt")
+    src = os.path.join(TXT, "bxd_mean_genotypes_head.txt")
     lines = [l for l in open(src).read().split("\n") if l]
     ni_total = len(_tok(lines[0])) - 3
     want, names = _expected_rows(lines, ni_total)
