@@ -433,6 +433,15 @@ inline NullModel CalcLambdaNull(const Vector *eval, const Matrix *UtW, const Vec
   return NullModel{o[0], o[1], o[2], o[3], o[4], o[5], o[6], o[7]};
 }
 
+// SNP sharding over ranks (one process per GPU): rank r of w analyses the analysed SNPs
+// [r * ceil(p / w), (r + 1) * ceil(p / w)) -- contiguous, so that every rank reads one contiguous range of the genotype
+// file and the per-rank .assoc.txt parts concatenate in rank order (gemma_amd/dist.py: shard_range is the same rule)
+inline void shard_range(size_t p, int rank, int world, size_t &begin, size_t &end) {
+  const size_t per = world > 0 ? (p + (size_t)world - 1) / (size_t)world : p;
+  begin = std::min(p, per * (size_t)rank);
+  end = std::min(p, begin + per);
+}
+
 // class LMM, src/lmm.h:49-125 -- the members CopyFromParam fills (src/lmm.cpp:56-90) and the drivers
 class LMM {
 public:
@@ -449,12 +458,25 @@ public:
   std::vector<SUMSTAT> sumStat;
   std::set<std::string> setGWASnps; // -loco / -gwasnps: the SNPs tested (src/lmm.cpp:87,1585-1587); empty = all
 
-  // the SNPs Analyze visits: indicator_snp, and with -loco only the members of setGWASnps (src/lmm.cpp:1578-1587)
+  int shard_rank = 0, shard_world = 1; // multi-GPU: this process analyses (and writes) its contiguous share of the SNPs
+
+  // the SNPs Analyze visits: indicator_snp, with -loco only the members of setGWASnps (src/lmm.cpp:1578-1587), and of
+  // those the share of this rank
   std::vector<int> analysed_snps() const {
     std::vector<int> keep(indicator_snp);
     if (!setGWASnps.empty())
       for (size_t t = 0; t < keep.size() && t < snpInfo.size(); ++t)
         if (keep[t] && setGWASnps.count(snpInfo[t].rs_number) == 0) keep[t] = 0;
+    if (shard_world > 1) {
+      size_t p = 0, b, e, k = 0;
+      for (int v : keep) p += v != 0;
+      shard_range(p, shard_rank, shard_world, b, e);
+      for (size_t t = 0; t < keep.size(); ++t)
+        if (keep[t]) {
+          if (k < b || k >= e) keep[t] = 0;
+          ++k;
+        }
+    }
     return keep;
   }
 
@@ -617,8 +639,8 @@ public:
       return;
     }
     const bool gene = !file_gene.empty(); // src/lmm.cpp:172-179: one id column instead of the seven SNP columns
-    outfile << (gene ? "geneID\t" : "chr\trs\tps\tn_miss\tallele1\tallele0\taf\t");
-    switch (a_mode) {
+    if (shard_rank == 0) outfile << (gene ? "geneID\t" : "chr\trs\tps\tn_miss\tallele1\tallele0\taf\t");
+    switch (shard_rank == 0 ? a_mode : -1) { // the parts of ranks > 0 are appended to rank 0's file: no header
     case 1: outfile << "beta\tse\tlogl_H1\tl_remle\tp_wald" << std::endl; break;
     case 2: outfile << "logl_H1\tl_mle\tp_lrt" << std::endl; break;
     case 3: outfile << "beta\tse\tp_score" << std::endl; break;
@@ -626,15 +648,9 @@ public:
     case 9: outfile << "beta\tse\tl_mle\tp_lrt" << std::endl; break;
     }
     std::vector<size_t> rows; // snpInfo index of the t-th record of sumStat
-    for (size_t i = 0; i < snpInfo.size(); ++i) {
-      if (gene) {
-        rows.push_back(i);
-        continue;
-      }
-      if (indicator_snp[i] == 0) continue;
-      if (!setGWASnps.empty() && setGWASnps.count(snpInfo[i].rs_number) == 0) continue; // src/lmm.cpp:208-210
-      rows.push_back(i);
-    }
+    const std::vector<int> keep = analysed_snps(); // indicator_snp, setGWASnps (src/lmm.cpp:208-210), this rank's share
+    for (size_t i = 0; i < snpInfo.size(); ++i)
+      if (gene || (i < keep.size() && keep[i])) rows.push_back(i);
     write_rows(outfile, std::min(rows.size(), sumStat.size()), [&](AssocLine &ln, size_t t) {
       const SNPINFO &s = snpInfo[rows[t]];
       const SUMSTAT &st = sumStat[t];

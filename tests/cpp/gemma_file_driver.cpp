@@ -4,6 +4,10 @@
 //   gemma_file_driver (-g geno[.gz] -p pheno [-a anno] | -bfile prefix) [-c cvt] [-n col [col ...]]
 //                     (-gk [1|2] | -k kin (-eigen | -lmm [1|2|3|4|9]) | -d eigenD -u eigenU -lmm m | -lm [1|2|3|4])
 //                     [-maf x] [-miss x] [-hwe x] [-r2 x] [-loco chr] [-gxe env] [-snps list] [-notsnp] [-km 2] [-o name] [-outdir dir]
+//   gemma_file_driver ... -lmm m -gpus N [-samegpu]    one process per GPU: every rank repeats the run-once stages
+//                     (first pass, kinship file, eigendecomposition: "replicas only" for those) and analyses its contiguous
+//                     share of the SNPs; the parent concatenates the per-rank parts in rank order into <o>.assoc.txt.
+//                     (-samegpu puts every rank on device 0: a test hook for 1-GPU boxes)
 //   gemma_file_driver -gene expr.txt -p pheno -k kin -lmm m        every row of expr.txt is a phenotype (LMM::AnalyzeGene)
 //   gemma_file_driver -bfile prefix -inproc [1|2] -lmm m ...   kinship, eigendecomposition and association in ONE
 //                     process: K never becomes text; wall seconds of every stage on the log line
@@ -16,6 +20,9 @@
 #include <chrono>
 #include <cstdlib>
 #include <iostream>
+
+#include <sys/wait.h>
+#include <unistd.h>
 #include <string>
 #include <vector>
 
@@ -25,7 +32,8 @@ using namespace gemma_amd;
 
 int main(int argc, char **argv) {
   std::string loco, file_gxe, file_gene, file_snps;
-  int km = 1;
+  int km = 1, gpus = 1, rank = 0, device = 0;
+  bool samegpu = false;
   std::string file_geno, file_pheno, file_anno, file_bfile, file_cvt, file_kin, file_kd, file_ku, file_out = "result",
                                                                                                   path_out = "./output";
   std::vector<size_t> p_column;
@@ -60,6 +68,8 @@ int main(int argc, char **argv) {
     else if (a == "-gene" && has) file_gene = argv[++i];
     else if (a == "-snps" && has) file_snps = argv[++i];
     else if (a == "-km" && has) km = atoi(argv[++i]);
+    else if (a == "-gpus" && has) gpus = atoi(argv[++i]);
+    else if (a == "-samegpu") samegpu = true;
     else if (a == "-notsnp") qc.maf_level = -1; // src/gemma.cpp:1116-1117
     else if (a == "-maf" && has) qc.maf_level = atof(argv[++i]);
     else if (a == "-miss" && has) qc.miss_level = atof(argv[++i]);
@@ -70,8 +80,44 @@ int main(int argc, char **argv) {
       return 2;
     }
   }
+  if (gpus > 1 && a_mode && !k_mode && !do_eigen) {
+    // one process per GPU, forked before anything touches the device; rank r writes <o>.rank<r>.assoc.txt
+    std::vector<pid_t> kids;
+    for (int r = 0; r < gpus; ++r) {
+      const pid_t pid = fork();
+      if (pid < 0) return 6;
+      if (pid == 0) {
+        rank = r;
+        device = samegpu ? 0 : r;
+        file_out += ".rank" + std::to_string(r);
+        break;
+      }
+      kids.push_back(pid);
+    }
+    if ((int)kids.size() == gpus) { // the parent: wait, then concatenate in rank order
+      int bad = 0;
+      for (pid_t k : kids) {
+        int st = 0;
+        waitpid(k, &st, 0);
+        if (!WIFEXITED(st) || WEXITSTATUS(st) != 0) bad = 1;
+      }
+      if (bad) return 7;
+      std::ofstream all((path_out + "/" + file_out + ".assoc.txt").c_str(), std::ios::binary);
+      for (int r = 0; r < gpus; ++r) {
+        const std::string part = path_out + "/" + file_out + ".rank" + std::to_string(r) + ".assoc.txt";
+        std::ifstream in(part.c_str(), std::ios::binary);
+        all << in.rdbuf();
+        in.close();
+        remove(part.c_str());
+      }
+      std::cout << "ranks=" << gpus << std::endl;
+      return 0;
+    }
+  } else {
+    gpus = 1;
+  }
   try {
-    enforce_hip(gemma_hip_init(0, 0), "init");
+    enforce_hip(gemma_hip_init(device, 0), "init");
     // ---- PARAM::ReadFiles ---------------------------------------------------------------------------------------
     CvtPhen cp;
     std::vector<SNPINFO> snpInfo;
@@ -268,6 +314,8 @@ int main(int argc, char **argv) {
     cLmm.indicator_snp = indicator_snp;
     cLmm.snpInfo = snpInfo;
     cLmm.setGWASnps = setGWASnps;
+    cLmm.shard_rank = rank;
+    cLmm.shard_world = gpus;
     cLmm.l_mle_null = nm.l_mle_null;
     cLmm.logl_mle_H0 = nm.logl_mle_H0;
     const double t_a0 = lap();

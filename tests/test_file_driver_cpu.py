@@ -192,3 +192,38 @@ def test_feeders_are_race_free_under_thread_sanitizer(driver, tmp_path, monkeypa
         assert "ThreadSanitizer" not in r.stderr, r.stderr[-3000:]
     assert open(tmp_path / "L.assoc.txt").read().split("\n")[:120] == open(os.path.join(T, "L1.assoc.head.txt")).read().split("\n")[:120]
     fc.compare_assoc(str(tmp_path / "P4.assoc.txt"), os.path.join(T, "P4.assoc.txt.gz"))
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_snp_sharded_ranks_write_the_single_process_file(driver, tmp_path, world):
+    """SURVEY 8e at the C++ host level: `-gpus N` forks one process per GPU; every rank analyses the contiguous share
+    [r ceil(p/N), (r+1) ceil(p/N)) of the analysed SNPs (shard_range, the rule of gemma_amd/dist.py) and writes its part, the
+    parent concatenates the parts in rank order -- byte for byte the file of the single-process run, for PLINK and for
+    BIMBAM text input.  (Here every rank runs on the CPU test double; on a GPU node rank r takes device r.)"""
+    out = str(tmp_path)
+    T = fc.TXT
+    pb = ["-bfile", os.path.join(T, "P"), "-outdir", out]
+    fc.drive(driver, *pb, "-gk", "-o", "P")
+    cxx = os.path.join(out, "P.cXX.txt")
+    fc.drive(driver, *pb, "-k", cxx, "-lmm", 4, "-c", os.path.join(T, "P.cov.txt"), "-o", "one")
+    kv = fc.drive(driver, *pb, "-k", cxx, "-lmm", 4, "-c", os.path.join(T, "P.cov.txt"), "-gpus", world, "-o", "many")
+    assert int(kv["ranks"]) == world
+    assert open(os.path.join(out, "many.assoc.txt"), "rb").read() == open(os.path.join(out, "one.assoc.txt"), "rb").read()
+    assert not [f for f in os.listdir(out) if ".rank" in f]
+    fc.compare_assoc(os.path.join(out, "many.assoc.txt"), os.path.join(T, "P4c.assoc.txt.gz"))
+    bb = ["-g", os.path.join(T, "bxd_mean_genotypes.txt.gz"), "-p", os.path.join(T, "bxd_trait.txt.gz"),
+          "-c", os.path.join(T, "bxd_cvt.txt.gz"), "-a", os.path.join(T, "bxd_anno.txt.gz"), "-outdir", out]
+    fc.drive(driver, *bb, "-gk", "-o", "B")
+    fc.drive(driver, *bb, "-k", os.path.join(out, "B.cXX.txt"), "-lmm", 1, "-maf", "0.1", "-o", "b1")
+    fc.drive(driver, *bb, "-k", os.path.join(out, "B.cXX.txt"), "-lmm", 1, "-maf", "0.1", "-gpus", world, "-o", "bN")
+    assert open(os.path.join(out, "bN.assoc.txt"), "rb").read() == open(os.path.join(out, "b1.assoc.txt"), "rb").read()
+
+
+def test_shard_range_rule_matches_the_python_side():
+    from gemma_amd.dist import shard_range
+    for p in (0, 1, 7, 574, 1000001):
+        for w in (1, 2, 3, 8):
+            per = (p + w - 1) // w
+            for r in range(w):
+                b = min(p, per * r)
+                assert shard_range(p, r, w) == (b, min(p, b + per))
