@@ -442,6 +442,19 @@ inline void shard_range(size_t p, int rank, int world, size_t &begin, size_t &en
   end = std::min(p, begin + per);
 }
 
+// restricts a 0/1 keep vector to the share of `rank` (the k-th kept entry stays iff k lies in shard_range)
+inline void shard_keep(std::vector<int> &keep, int rank, int world) {
+  if (world <= 1) return;
+  size_t p = 0, b, e, k = 0;
+  for (int v : keep) p += v != 0;
+  shard_range(p, rank, world, b, e);
+  for (size_t t = 0; t < keep.size(); ++t)
+    if (keep[t]) {
+      if (k < b || k >= e) keep[t] = 0;
+      ++k;
+    }
+}
+
 // class LMM, src/lmm.h:49-125 -- the members CopyFromParam fills (src/lmm.cpp:56-90) and the drivers
 class LMM {
 public:
@@ -467,16 +480,7 @@ public:
     if (!setGWASnps.empty())
       for (size_t t = 0; t < keep.size() && t < snpInfo.size(); ++t)
         if (keep[t] && setGWASnps.count(snpInfo[t].rs_number) == 0) keep[t] = 0;
-    if (shard_world > 1) {
-      size_t p = 0, b, e, k = 0;
-      for (int v : keep) p += v != 0;
-      shard_range(p, shard_rank, shard_world, b, e);
-      for (size_t t = 0; t < keep.size(); ++t)
-        if (keep[t]) {
-          if (k < b || k >= e) keep[t] = 0;
-          ++k;
-        }
-    }
+    shard_keep(keep, shard_rank, shard_world);
     return keep;
   }
 
@@ -709,6 +713,12 @@ public:
   std::vector<int> indicator_idv, indicator_snp;
   std::vector<SNPINFO> snpInfo;
   std::vector<SUMSTAT> sumStat;
+  int shard_rank = 0, shard_world = 1; // as in class LMM
+  std::vector<int> analysed_snps() const {
+    std::vector<int> keep(indicator_snp);
+    shard_keep(keep, shard_rank, shard_world);
+    return keep;
+  }
 
   // W: ni_test x n_cvt, y: ni_test (the analysed individuals)
   void AnalyzePlink(const Matrix *W, const Vector *y) {
@@ -720,8 +730,9 @@ public:
     const size_t n_bit = (ni_total + 3) / 4, B = io_block_rows(LMM_BATCH_SIZE);
     std::vector<gemma_sumstat> out(B);
     size_t t_next = 0;
+    const std::vector<int> keep = analysed_snps();
     BlockPrefetch pf(B * n_bit, [&](void *slot, int) {
-      return read_bed_rows(infile, indicator_snp, t_next, n_bit, static_cast<unsigned char *>(slot), B);
+      return read_bed_rows(infile, keep, t_next, n_bit, static_cast<unsigned char *>(slot), B);
     });
     for (;;) {
       void *slot = nullptr;
@@ -755,16 +766,17 @@ public:
       std::cout << "error writing file: " << file_str << std::endl;
       return;
     }
-    outfile << "chr\trs\tps\tn_mis\tn_obs\tallele1\tallele0\taf\t";
-    switch (a_mode) {
+    if (shard_rank == 0) outfile << "chr\trs\tps\tn_mis\tn_obs\tallele1\tallele0\taf\t";
+    switch (shard_rank == 0 ? a_mode : -1) {
     case 51: outfile << "beta\tse\tp_wald" << std::endl; break;
     case 52: outfile << "p_lrt" << std::endl; break;
     case 53: outfile << "beta\tse\tp_score" << std::endl; break;
     case 54: outfile << "beta\tse\tp_wald\tp_lrt\tp_score" << std::endl; break;
     }
     std::vector<size_t> rows;
-    for (size_t i = 0; i < snpInfo.size(); ++i)
-      if (indicator_snp[i] != 0) rows.push_back(i);
+    const std::vector<int> keep = analysed_snps();
+    for (size_t i = 0; i < snpInfo.size() && i < keep.size(); ++i)
+      if (keep[i] != 0) rows.push_back(i);
     write_rows(outfile, std::min(rows.size(), sumStat.size()), [&](AssocLine &ln, size_t t) {
       const SNPINFO &s = snpInfo[rows[t]];
       const SUMSTAT &st = sumStat[t];
@@ -816,6 +828,12 @@ public:
   std::vector<int> indicator_idv, indicator_snp;
   std::vector<SNPINFO> snpInfo;
   std::vector<double> sumStat;
+  int shard_rank = 0, shard_world = 1; // as in class LMM
+  std::vector<int> analysed_snps() const {
+    std::vector<int> keep(indicator_snp);
+    shard_keep(keep, shard_rank, shard_world);
+    return keep;
+  }
   size_t stride() const { return n_ph + 3 * (n_ph * (n_ph + 1) / 2) + 3; }
 
   // UtY: ni_test x n_ph row-major (the gsl_matrix the reference passes)
@@ -828,8 +846,9 @@ public:
     const size_t n_bit = (ni_total + 3) / 4, B = io_block_rows(LMM_BATCH_SIZE);
     std::vector<double> out(B * stride());
     size_t t_next = 0;
+    const std::vector<int> keep = analysed_snps();
     BlockPrefetch pf(B * n_bit, [&](void *slot, int) {
-      return read_bed_rows(infile, indicator_snp, t_next, n_bit, static_cast<unsigned char *>(slot), B);
+      return read_bed_rows(infile, keep, t_next, n_bit, static_cast<unsigned char *>(slot), B);
     });
     for (;;) {
       void *slot = nullptr;
@@ -880,11 +899,13 @@ public:
       std::cout << "error writing file: " << file_str << std::endl;
       return;
     }
-    outfile << "chr\trs\tps\tn_miss\tallele1\tallele0\taf\t";
-    for (size_t i = 0; i < n_ph; i++) outfile << "beta_" << i + 1 << "\t";
-    for (size_t i = 0; i < n_ph; i++)
-      for (size_t j = i; j < n_ph; j++) outfile << "Vbeta_" << i + 1 << "_" << j + 1 << "\t";
-    switch (a_mode) {
+    if (shard_rank == 0) {
+      outfile << "chr\trs\tps\tn_miss\tallele1\tallele0\taf\t";
+      for (size_t i = 0; i < n_ph; i++) outfile << "beta_" << i + 1 << "\t";
+      for (size_t i = 0; i < n_ph; i++)
+        for (size_t j = i; j < n_ph; j++) outfile << "Vbeta_" << i + 1 << "_" << j + 1 << "\t";
+    }
+    switch (shard_rank == 0 ? a_mode : -1) {
     case 1: outfile << "p_wald" << std::endl; break;
     case 2: outfile << "p_lrt" << std::endl; break;
     case 3: outfile << "p_score" << std::endl; break;
@@ -892,8 +913,9 @@ public:
     }
     const size_t d = n_ph, v = d * (d + 1) / 2, st = stride();
     std::vector<size_t> rows;
-    for (size_t i = 0; i < snpInfo.size(); ++i)
-      if (indicator_snp[i] != 0) rows.push_back(i);
+    const std::vector<int> keep = analysed_snps();
+    for (size_t i = 0; i < snpInfo.size() && i < keep.size(); ++i)
+      if (keep[i] != 0) rows.push_back(i);
     write_rows(outfile, std::min(rows.size(), sumStat.size() / st), [&](AssocLine &ln, size_t t) {
       const SNPINFO &s = snpInfo[rows[t]];
       const double *r = &sumStat[t * st];

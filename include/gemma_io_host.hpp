@@ -909,9 +909,10 @@ inline void AnalyzeBimbam(MVLMM &mv, const Matrix *U, const Vector *eval, const 
   BimbamReader rd(mv.file_geno, ni_total);
   if (!rd.ok()) throw std::runtime_error("error reading genotype file");
   const size_t B = bimbam_block_rows(n, LMM_BATCH_SIZE);
+  const std::vector<int> keep = mv.analysed_snps();
   BlockPrefetch pf(B * n * sizeof(double), [&](void *slot, int) -> size_t {
-    if (rd.lines_read() >= mv.indicator_snp.size()) return 0;
-    return rd.read_block(B, static_cast<double *>(slot), n, nullptr, &mv.indicator_snp, mv.indicator_idv.data());
+    if (rd.lines_read() >= keep.size()) return 0;
+    return rd.read_block(B, static_cast<double *>(slot), n, nullptr, &keep, mv.indicator_idv.data());
   });
   LMM::RowFeeder feed = [&](const double *&X) -> size_t {
     void *slot = nullptr;
@@ -985,9 +986,10 @@ inline void AnalyzeBimbam(LM &lm, const Matrix *W, const Vector *y) {
   BimbamReader rd(lm.file_geno, ni_total);
   if (!rd.ok()) throw std::runtime_error("error reading genotype file");
   const size_t B = bimbam_block_rows(n, LMM_BATCH_SIZE);
+  const std::vector<int> keep = lm.analysed_snps();
   BlockPrefetch pf(B * n * sizeof(double), [&](void *slot, int) -> size_t {
-    if (rd.lines_read() >= lm.indicator_snp.size()) return 0;
-    return rd.read_block(B, static_cast<double *>(slot), n, nullptr, &lm.indicator_snp, lm.indicator_idv.data());
+    if (rd.lines_read() >= keep.size()) return 0;
+    return rd.read_block(B, static_cast<double *>(slot), n, nullptr, &keep, lm.indicator_idv.data());
   });
   LMM::RowFeeder feed = [&](const double *&X) -> size_t {
     void *slot = nullptr;

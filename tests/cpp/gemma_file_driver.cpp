@@ -80,7 +80,7 @@ int main(int argc, char **argv) {
       return 2;
     }
   }
-  if (gpus > 1 && a_mode && !k_mode && !do_eigen) {
+  if (gpus > 1 && (a_mode || lm_mode) && !k_mode && !do_eigen && file_gene.empty()) {
     // one process per GPU, forked before anything touches the device; rank r writes <o>.rank<r>.assoc.txt
     std::vector<pid_t> kids;
     for (int r = 0; r < gpus; ++r) {
@@ -189,6 +189,8 @@ int main(int argc, char **argv) {
       cLm.indicator_idv = cp.indicator_idv;
       cLm.indicator_snp = indicator_snp;
       cLm.snpInfo = snpInfo;
+      cLm.shard_rank = rank;
+      cLm.shard_world = gpus;
       if (!file_bfile.empty()) cLm.AnalyzePlink(&W, &yv);
       else AnalyzeBimbam(cLm, &W, &yv);
       cLm.WriteFiles();
@@ -284,6 +286,8 @@ int main(int argc, char **argv) {
       cMv.indicator_idv = cp.indicator_idv;
       cMv.indicator_snp = indicator_snp;
       cMv.snpInfo = snpInfo;
+      cMv.shard_rank = rank;
+      cMv.shard_world = gpus;
       const double t_a0 = lap();
       if (!file_bfile.empty()) cMv.AnalyzePlink(&U, &eval, &UtW, &UtY);
       else AnalyzeBimbam(cMv, &U, &eval, &UtW, &UtY);

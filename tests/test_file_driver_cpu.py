@@ -219,6 +219,36 @@ def test_snp_sharded_ranks_write_the_single_process_file(driver, tmp_path, world
     assert open(os.path.join(out, "bN.assoc.txt"), "rb").read() == open(os.path.join(out, "b1.assoc.txt"), "rb").read()
 
 
+def test_snp_sharded_ranks_lm_and_multivariate(driver, tmp_path, monkeypatch):
+    """the same for `-lm` (class LM) and the multivariate LMM (class MVLMM): 2 ranks, parts concatenated = one process"""
+    import glob
+    import scipy
+    libs = glob.glob(os.path.join(os.path.dirname(os.path.dirname(scipy.__file__)), "scipy.libs", "libscipy_openblas*.so"))
+    if libs:
+        monkeypatch.setenv("GEMMA_DOUBLE_LAPACK", libs[0])
+    out = str(tmp_path)
+    T = fc.TXT
+    pb = ["-bfile", os.path.join(T, "P"), "-outdir", out]
+    fc.drive(driver, *pb, "-lm", 4, "-o", "lm1")
+    fc.drive(driver, *pb, "-lm", 4, "-gpus", 2, "-o", "lm2")
+    assert open(os.path.join(out, "lm2.assoc.txt"), "rb").read() == open(os.path.join(out, "lm1.assoc.txt"), "rb").read()
+    hb = ["-bfile", os.path.join(T, "H"), "-outdir", out]  # two correlated traits from the single-trait set: trait, trait^2
+    fam = [l.split() for l in open(os.path.join(T, "H.fam"))]
+    with open(os.path.join(out, "H2.fam"), "w") as f:
+        for r in fam:
+            y = float(r[5])
+            f.write(" ".join(r[:5]) + (" -9 -9\n" if y == -9 else " %r %r\n" % (y, 0.3 * y * y - y)))
+    for ext in (".bed", ".bim"):
+        open(os.path.join(out, "H2" + ext), "wb").write(open(os.path.join(T, "H" + ext), "rb").read())
+    h2 = ["-bfile", os.path.join(out, "H2"), "-outdir", out]
+    fc.drive(driver, *h2, "-gk", "-o", "H2")
+    cxx = os.path.join(out, "H2.cXX.txt")
+    fc.drive(driver, *h2, "-k", cxx, "-lmm", 1, "-n", 1, 2, "-o", "mv1")
+    fc.drive(driver, *h2, "-k", cxx, "-lmm", 1, "-n", 1, 2, "-gpus", 2, "-o", "mv2")
+    assert open(os.path.join(out, "mv2.assoc.txt"), "rb").read() == open(os.path.join(out, "mv1.assoc.txt"), "rb").read()
+    assert len(open(os.path.join(out, "mv1.assoc.txt")).read().strip().split("\n")) == 601
+
+
 def test_shard_range_rule_matches_the_python_side():
     from gemma_amd.dist import shard_range
     for p in (0, 1, 7, 574, 1000001):
