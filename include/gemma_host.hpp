@@ -6,6 +6,13 @@
 // `Matrix` / `Vector` are layout-compatible views of gsl_matrix / gsl_vector data: row-major with
 // leading dimension tda, vector stride in elements.
 //
+// Contents: fast_dgemm / CenterMatrix / EigenDecomp_Zeroed / CalcUtX; PlinkKin / BimbamKin; WriteMatrix / WriteVector /
+// ReadFile_kin (the 10-digit hand-off); CalcLambdaNull; class LMM (AnalyzePlink, AnalyzePlinkGXE, AnalyzeFeed / AnalyzeRows,
+// AnalyzeGene*, WriteFiles), class LM (-lm), class MVLMM (-lmm -n a b c).  Host-side machinery they share: BlockPrefetch
+// (genotype blocks produced one ahead of the device by a helper thread), AssocLine / write_rows (text rows formatted by a
+// thread pool, byte-identical to the reference's ofstream output), shard_range / shard_keep (SNP sharding over ranks).
+// Link with -pthread.  The file readers and feeders that sit on top of this are in gemma_io_host.hpp.
+//
 // Errors: GEMMA prints a message and raises SIGINT through fail_msg / enforce_msg (src/debug.h:113-164) or
 // sets cPar.error and returns false.  Here void functions throw gemma_amd::HipError (code + text) and the
 // bool readers return false after printing the message, exactly where the reference returns false.
