@@ -1159,5 +1159,70 @@ inline void ReadFile_eigenD(const std::string &file_kd, bool &error, Vector *eva
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// <o>.log.txt -- the lines of GEMMA::WriteLog (src/gemma.cpp:3159-3590) that belong to this path, in its format
+// ("## key = value", ostream default precision): the summary counts, the null-model estimates of the univariate LMM and
+// the five timers (minutes), plus one line naming the device.  The null model's beta / se(beta) lines are not written
+// (gemma_hip_lmm_null returns the variance components only).
+// ---------------------------------------------------------------------------------------------------------------
+struct RunLog {
+  std::string command_line;
+  int a_mode = 0; // 1-4, 9: -lmm; 21 / 22: -gk; 51-54: -lm (src/gemma.h:39-43)
+  size_t ni_total = 0, ni_test = 0, n_cvt = 1, n_ph = 1, ns_total = 0, ns_test = 0;
+  bool have_null = false;
+  NullModel null;
+  double time_total = 0, time_G = 0, time_eigen = 0, time_UtX = 0, time_opt = 0; // minutes
+
+  bool Write(const std::string &path_out, const std::string &file_out) const {
+    const std::string file_str = path_out + "/" + file_out + ".log.txt";
+    std::ofstream outfile(file_str.c_str(), std::ofstream::out);
+    if (!outfile) {
+      std::cout << "error writing log file: " << file_str << std::endl;
+      return false;
+    }
+    char name[256] = "no device";
+    int n_cu = 0;
+    size_t hbm = 0;
+    gemma_hip_device_info(name, sizeof name, &n_cu, &hbm);
+    outfile << "##" << std::endl;
+    outfile << "## GEMMA path on HIP, C ABI version = " << gemma_hip_abi_version() << std::endl;
+    outfile << "## device = " << name << ", " << n_cu << " CUs, " << (double)hbm / 1e9 << " GB" << std::endl;
+    outfile << "##" << std::endl;
+    outfile << "## Command Line Input = " << command_line << std::endl;
+    outfile << "##" << std::endl;
+    outfile << "## Summary Statistics:" << std::endl;
+    outfile << "## number of total individuals = " << ni_total << std::endl;
+    outfile << "## number of analyzed individuals = " << ni_test << std::endl;
+    outfile << "## number of covariates = " << n_cvt << std::endl;
+    outfile << "## number of phenotypes = " << n_ph << std::endl;
+    outfile << "## number of total SNPs/var = " << ns_total << std::endl;
+    outfile << "## number of analyzed SNPs/var = " << ns_test << std::endl;
+    if (have_null) {
+      outfile << "## REMLE log-likelihood in the null model = " << null.logl_remle_H0 << std::endl;
+      outfile << "## MLE log-likelihood in the null model = " << null.logl_mle_H0 << std::endl;
+      if (n_ph == 1) {
+        outfile << "## pve estimate in the null model = " << null.pve_null << std::endl;
+        outfile << "## se(pve) in the null model = " << null.pve_se_null << std::endl;
+        outfile << "## vg estimate in the null model = " << null.vg_remle_null << std::endl;
+        outfile << "## ve estimate in the null model = " << null.ve_remle_null << std::endl;
+      }
+    }
+    outfile << "##" << std::endl;
+    outfile << "## Computation Time:" << std::endl;
+    outfile << "## total computation time = " << time_total << " min " << std::endl;
+    outfile << "## computation time break down: " << std::endl;
+    if (a_mode == 21 || a_mode == 22)
+      outfile << "##      time on calculating relatedness matrix = " << time_G << " min " << std::endl;
+    if ((a_mode >= 1 && a_mode <= 4) || a_mode == 9) {
+      outfile << "##      time on eigen-decomposition = " << time_eigen << " min " << std::endl;
+      outfile << "##      time on calculating UtX = " << time_UtX << " min " << std::endl;
+    }
+    if ((a_mode >= 1 && a_mode <= 4) || a_mode == 9 || (a_mode >= 51 && a_mode <= 54))
+      outfile << "##      time on optimization = " << time_opt << " min " << std::endl;
+    outfile << "##" << std::endl;
+    return true;
+  }
+};
+
 } // namespace gemma_amd
 #endif

@@ -16,6 +16,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <limits>
@@ -162,6 +163,12 @@ void gemma_hip_shutdown(void) {}
 int gemma_hip_abi_version(void) { return GEMMA_HIP_ABI_VERSION; }
 const char *gemma_hip_strerror(int code) { return code == 0 ? "ok" : "error (test double)"; }
 const char *gemma_hip_last_error(void) { return g_err.c_str(); }
+int gemma_hip_device_info(char *name, size_t len, int *n_cu, size_t *hbm_bytes) {
+  if (name && len) snprintf(name, len, "CPU test double over the oracle");
+  if (n_cu) *n_cu = 0;
+  if (hbm_bytes) *hbm_bytes = 0;
+  return GEMMA_HIP_OK;
+}
 
 int gemma_hip_dgemm(char ta, char tb, size_t M, size_t N, size_t K, double alpha, const double *A, size_t lda,
                     const double *B, size_t ldb, double beta, double *C, size_t ldc) {

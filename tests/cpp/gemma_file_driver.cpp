@@ -42,6 +42,8 @@ int main(int argc, char **argv) {
   const auto t_start = std::chrono::steady_clock::now();
   auto lap = [&]() { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count(); };
   QcLevels qc;
+  RunLog log;
+  for (int i = 0; i < argc; ++i) log.command_line += std::string(i ? " " : "") + argv[i];
   for (int i = 1; i < argc; ++i) {
     const std::string a = argv[i];
     const bool has = i + 1 < argc && argv[i + 1][0] != '-';
@@ -175,6 +177,8 @@ int main(int argc, char **argv) {
       std::cout << " ksnps=" << setKSnps.size() << " gwasnps=" << setGWASnps.size();
     }
     if (inproc) std::cout << " t_first_pass=" << lap();
+    log.ni_total = ni_total; log.ni_test = ni_test; log.n_cvt = n_cvt; log.n_ph = n_ph;
+    log.ns_total = indicator_snp.size(); log.ns_test = ns_test;
 
     // ---- -lm (src/gemma.cpp:2475-2555): no kinship ------------------------------------------------------------------
     if (lm_mode) {
@@ -194,6 +198,9 @@ int main(int argc, char **argv) {
       if (!file_bfile.empty()) cLm.AnalyzePlink(&W, &yv);
       else AnalyzeBimbam(cLm, &W, &yv);
       cLm.WriteFiles();
+      log.a_mode = 50 + lm_mode;
+      log.time_total = lap() / 60.0;
+      if (rank == 0) log.Write(path_out, gpus > 1 ? file_out.substr(0, file_out.rfind(".rank")) : file_out);
       std::cout << " snps=" << cLm.sumStat.size() << std::endl;
       gemma_hip_shutdown();
       return 0;
@@ -206,7 +213,11 @@ int main(int argc, char **argv) {
       const bool ok = file_bfile.empty() ? BimbamKinThreaded(file_geno, indicator_snp, k_mode, &K, setKSnps, &snpInfo)
                                          : PlinkKin(file_bfile + ".bed", indicator_snp, k_mode, 0, &K);
       if (!ok) return 4;
+      log.time_G = lap() / 60.0;
       if (!WriteMatrix(&K, path_out + "/" + file_out + (k_mode == 1 ? ".cXX.txt" : ".sXX.txt"))) return 4;
+      log.a_mode = 20 + k_mode;
+      log.time_total = lap() / 60.0;
+      log.Write(path_out, file_out);
       std::cout << std::endl;
       gemma_hip_shutdown();
       return 0;
@@ -243,7 +254,9 @@ int main(int argc, char **argv) {
       else ReadFile_kin_threaded(file_kin, cp.indicator_idv, error, &G);
       if (error) return 5;
       CenterMatrix(&G);
+      const double t_e0 = lap();
       trace_G = EigenDecomp_Zeroed(&G, &U, &eval, 0);
+      log.time_eigen = (lap() - t_e0) / 60.0;
     } else if (!file_kd.empty() && !file_ku.empty()) {
       ReadFile_eigenU(file_ku, error, &U);
       ReadFile_eigenD(file_kd, error, &eval);
@@ -338,6 +351,13 @@ int main(int argc, char **argv) {
     else AnalyzeBimbam(cLmm, &U, &eval, &UtW, &Uty);
     const double t_a1 = lap();
     cLmm.WriteFiles();
+    log.a_mode = a_mode;
+    log.have_null = true;
+    log.null = nm;
+    log.time_UtX = cLmm.time_UtX;
+    log.time_opt = cLmm.time_opt;
+    log.time_total = lap() / 60.0;
+    if (rank == 0) log.Write(path_out, gpus > 1 ? file_out.substr(0, file_out.rfind(".rank")) : file_out);
     if (inproc)
       std::cout << " t_null=" << t_a0 << " t_assoc=" << t_a1 << " t_written=" << lap() << " assoc_seconds=" << t_a1 - t_a0
                 << " assoc_snps_per_s=" << (double)cLmm.sumStat.size() / (t_a1 - t_a0)

@@ -79,6 +79,26 @@ def check_log(kv, log_json):
             assert abs(float(kv[key]) - float(log[name])) <= 2e-5 * abs(float(log[name])) + 1e-12, (key, kv[key], log[name])
 
 
+def check_log_file(path, log_json):
+    """<o>.log.txt written by the driver (RunLog, the lines of GEMMA::WriteLog this path owns) against the same lines of the
+    reference's log: counts equal, null-model estimates equal at the 6 digits both print; the timer lines the reference's
+    tests grep for are present."""
+    ref = json.load(open(os.path.join(TXT, log_json)))
+    got = {}
+    for line in open(path):
+        if line.startswith("## ") and "=" in line:
+            k, v = line[3:].split("=", 1)
+            got[k.strip()] = v.strip()
+    for k, v in ref.items():
+        assert k in got, k
+        if k.startswith("number of"):
+            assert got[k] == v, (k, got[k], v)
+        else:
+            assert got[k] == v or abs(float(got[k]) - float(v)) <= 2e-5 * abs(float(v)), (k, got[k], v)
+    assert "total computation time" in got and got["total computation time"].endswith("min")
+    assert "device" in got and "Command Line Input" in got
+
+
 def bxd_bimbam_workflow(exe, out, modes=(1, 4, 9)):
     """BIMBAM text input with covariates and annotation: -gk, -lmm 1/4/9 through the 10-digit cXX hand-off, -eigen,
     then -lmm from the -d/-u artefacts."""
@@ -96,6 +116,7 @@ def bxd_bimbam_workflow(exe, out, modes=(1, 4, 9)):
     for m in modes:
         kv = drive(exe, *base, "-k", cxx, "-lmm", m, "-maf", "0.1", "-o", "L%d" % m)
         check_log(kv, "L1.log.json")
+        check_log_file(os.path.join(out, "L%d.log.txt" % m), "L1.log.json")
         compare_assoc(os.path.join(out, "L%d.assoc.txt" % m), os.path.join(TXT, "L%d.assoc.head.txt" % m), n_ref_rows=7317)
         full = np.load(os.path.join(ROOT, "tests", "golden", "ref_bxd.npz"))
         hdr, rows = read_assoc(os.path.join(out, "L%d.assoc.txt" % m))
@@ -138,6 +159,7 @@ def plink_workflow(exe, out):
     compare_assoc(os.path.join(out, "P4.assoc.txt"), os.path.join(TXT, "P4.assoc.txt.gz"))
     kv = drive(exe, *base, "-k", cxx, "-lmm", 4, "-c", os.path.join(TXT, "P.cov.txt"), "-o", "P4c")
     check_log(kv, "P4c.log.json")
+    check_log_file(os.path.join(out, "P4c.log.txt"), "P4c.log.json")
     compare_assoc(os.path.join(out, "P4c.assoc.txt"), os.path.join(TXT, "P4c.assoc.txt.gz"))
     kv = drive(exe, *base, "-k", cxx, "-lmm", 1, "-miss", "0.02", "-maf", "0.05", "-o", "P1q")
     check_log(kv, "P1q.log.json")
