@@ -24,6 +24,7 @@
 #include <sys/wait.h>
 #include <unistd.h>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "gemma_io_host.hpp"
@@ -192,7 +193,7 @@ int main(int argc, char **argv) {
       cLm.ni_total = ni_total;
       cLm.indicator_idv = cp.indicator_idv;
       cLm.indicator_snp = indicator_snp;
-      cLm.snpInfo = snpInfo;
+      cLm.snpInfo = std::move(snpInfo);
       cLm.shard_rank = rank;
       cLm.shard_world = gpus;
       if (!file_bfile.empty()) cLm.AnalyzePlink(&W, &yv);
@@ -298,7 +299,7 @@ int main(int argc, char **argv) {
       cMv.ni_total = ni_total;
       cMv.indicator_idv = cp.indicator_idv;
       cMv.indicator_snp = indicator_snp;
-      cMv.snpInfo = snpInfo;
+      cMv.snpInfo = std::move(snpInfo);
       cMv.shard_rank = rank;
       cMv.shard_world = gpus;
       const double t_a0 = lap();
@@ -329,7 +330,7 @@ int main(int argc, char **argv) {
     cLmm.ni_total = ni_total;
     cLmm.indicator_idv = cp.indicator_idv;
     cLmm.indicator_snp = indicator_snp;
-    cLmm.snpInfo = snpInfo;
+    cLmm.snpInfo = std::move(snpInfo); // not read again below
     cLmm.setGWASnps = setGWASnps;
     cLmm.shard_rank = rank;
     cLmm.shard_world = gpus;
