@@ -596,7 +596,7 @@ public:
             break;
           }
         } else {
-          if (!spans_.empty() && end_ >= TEXT_CAP) break;
+          if (!spans_.empty() && end_ >= text_cap()) break;
           fill();
           continue;
         }
@@ -637,15 +637,21 @@ public:
 
 private:
   static constexpr size_t TEXT_CAP = size_t(1) << 30, CHUNK = size_t(16) << 20;
+  // bytes of text one block may hold before read_block returns what it has (GEMMA_HIP_IO_TEXT_CAP: test hook)
+  static size_t text_cap() {
+    const char *env = getenv("GEMMA_HIP_IO_TEXT_CAP");
+    return env && atol(env) > 0 ? (size_t)atol(env) : TEXT_CAP;
+  }
   // appends up to CHUNK further bytes of text
   void fill() {
-    if (cap_ < end_ + CHUNK) { // plain realloc: no zero fill of text that is about to be overwritten
-      cap_ = std::max(cap_ + cap_ / 2, end_ + CHUNK);
+    const size_t chunk = std::min(CHUNK, text_cap()); // (a small test cap also makes the reads small)
+    if (cap_ < end_ + chunk) { // plain realloc: no zero fill of text that is about to be overwritten
+      cap_ = std::max(cap_ + cap_ / 2, end_ + chunk);
       char *nb = static_cast<char *>(realloc(buf_, cap_));
       if (!nb) throw std::bad_alloc();
       buf_ = nb;
     }
-    const int r = gzread(f_, buf_ + end_, (unsigned)CHUNK);
+    const int r = gzread(f_, buf_ + end_, (unsigned)chunk);
     if (r <= 0) eof_ = true; else end_ += (size_t)r;
   }
   // next complete line [b, e) at or after `from`; "\n", "\r\n" and "\r" end a line (src/gemma_io.cpp:118-151)

@@ -221,6 +221,11 @@ def test_bimbam_reader_formats_gzip_selection(exe, tmp_path):
     got = np.fromfile(out).reshape(-1, ni_total)
     assert got.shape == want.shape and np.array_equal(got, want, equal_nan=True)
     assert r.stdout.strip().split("\n") == names
+    # a text cap of a few lines: read_block hands back partial blocks, the caller loops -- same rows
+    capped = tmp_path / "capped.bin"
+    r2 = subprocess.run([exe, "geno", str(path), str(ni_total), "8", "64", str(capped)], capture_output=True, text=True,
+                        env=dict(os.environ, GEMMA_HIP_IO_TEXT_CAP="2048"))
+    assert r2.returncode == 0 and open(capped, "rb").read() == open(out, "rb").read() and r2.stdout == r.stdout
     keep = (rng.random(ns) < 0.6).astype(int)
     cols = (rng.random(ni_total) < 0.7).astype(int)
     (tmp_path / "keep.txt").write_text(" ".join(map(str, keep)))
@@ -267,6 +272,11 @@ def test_threaded_kinship_reader_drops_individuals_and_rejects_bad_files(exe, tm
     got = np.loadtxt(tmp_path / "sub.txt")
     want = np.loadtxt(src)[ind == 1][:, ind == 1]
     assert np.array_equal(got, want)
+    # a text cap far below the file size: the reader returns partial blocks and the kinship reader loops over them
+    r = subprocess.run([exe, "kin", str(src), str(n), str(tmp_path / "sub2.txt"), str(tmp_path / "ind.txt")],
+                       capture_output=True, text=True, env=dict(os.environ, GEMMA_HIP_IO_TEXT_CAP="3000"))
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert open(tmp_path / "sub2.txt", "rb").read() == open(tmp_path / "sub.txt", "rb").read()
     lines = src.read_text().strip().split("\n")
     bad = tmp_path / "bad1.txt"
     r = int(np.flatnonzero(ind == 1)[5])  # rows of dropped individuals are skipped unparsed, as in the reference
