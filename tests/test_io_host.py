@@ -318,3 +318,41 @@ def test_oracle_hwe_filter_keeps_the_reference_snp_set(oracle):
     keep_hwe = keep_hwe[0] if isinstance(keep_hwe, tuple) else keep_hwe
     assert list(rs[np.asarray(keep_all) == 1]) == all_rs
     assert list(rs[np.asarray(keep_hwe) == 1]) == hwe_rs and len(hwe_rs) == 567
+
+
+def test_text_reader_crlf_across_buffer_boundary(exe, tmp_path):
+    """TextFile refills a 1 MiB buffer: a "\r\n" whose two bytes fall either side of the refill must still end ONE line
+    (safeGetline's behaviour, src/gemma_io.cpp:118-151), also for "\r" alone at the boundary and for a last line without end."""
+    for first_len, ending in ((1048575, "\r\n"), (1048576, "\r\n"), (1048575, "\r"), (1048574, "\n")):
+        f = tmp_path / ("p%d_%d.txt" % (first_len, len(ending)))
+        with open(f, "w", newline="") as g:
+            g.write("7" + "0" * (first_len - 3) + ".5" + ending + "1.5" + ending + "NA" + ending + "2.25")
+        out = run(exe, "pheno", f, 1).stdout.strip().split("\n")
+        assert len(out) == 4, (first_len, ending, len(out))
+        assert [o.split()[0] for o in out] == ["1", "1", "0", "1"]
+        assert float(out[1].split()[1]) == 1.5 and float(out[3].split()[1]) == 2.25 and float(out[0].split()[1]) == float("inf")
+
+
+def test_block_reader_cr_at_the_end_of_a_read(exe, tmp_path):
+    """BimbamReader reads the text in chunks: when a chunk ends on the "\r" of a "\r\n" the line is only closed once the
+    next chunk shows whether a "\n" follows.  Lines of exactly chunk - 1 bytes put every "\r" there."""
+    ni = 100
+    rng = np.random.default_rng(12)
+    lines, want = [], []
+    for k in range(9):
+        vals = ["%.3f" % v for v in rng.uniform(0, 2, ni)]
+        body = ", A, G, " + ", ".join(vals)
+        name = "rs" + "x" * (2047 - 2 - len(body))
+        assert len(name + body) == 2047
+        lines.append(name + body)
+        want.append([float(v) for v in vals])
+    f = tmp_path / "cr.txt"
+    with open(f, "w", newline="") as g:
+        g.write("\r\n".join(lines) + "\r\n")
+    out = tmp_path / "cr.bin"
+    r = subprocess.run([exe, "geno", str(f), str(ni), "3", "4", str(out)], capture_output=True, text=True,
+                       env=dict(os.environ, GEMMA_HIP_IO_TEXT_CAP="2048"))
+    assert r.returncode == 0, r.stdout + r.stderr
+    got = np.fromfile(out).reshape(-1, ni)
+    assert got.shape == (9, ni) and np.array_equal(got, np.array(want))
+    assert [l.split()[0] for l in r.stdout.strip().split("\n")] == [l.split(",")[0] for l in lines]
