@@ -12,6 +12,8 @@
 //   eigen <U-in> <D-in> <n> <outdir> <name>     ReadFile_eigenU/D -> WriteEigen
 //   assoc <assoc-in> <a_mode> <outdir> <name>   parse a reference .assoc.txt, LMM::WriteFiles it again
 //   assocbench <a_mode> <n_snps> <outdir>       wall time of LMM::WriteFiles on n_snps synthetic records
+//   prefetch                                    BlockPrefetch scenarios: order of blocks, an exception in the producer,
+//                                               a consumer that stops early (no deadlock), an immediately empty source
 //   kinbench <n> <file>                         wall time of WriteMatrix + ReadFile_kin on an n x n matrix
 //   kin <cXX-in> <n> <out>                      ReadFile_kin (all individuals) -> WriteMatrix
 //   plinkgen <prefix> <ni> <ns> [threads [n_ph]]  synthetic PLINK set (n_ph correlated traits in .fam columns 6..): two sub-populations, maf ~ U(0.1, 0.45) +- 0.075, 1 % missing calls,
@@ -292,6 +294,60 @@ int main(int argc, char **argv) {
     ReadFile_eigenD(argv[3], error, &D);
     if (error) return 1;
     return WriteEigen(&U, &D, argv[5], argv[6]) ? 0 : 1;
+  }
+  if (cmd == "prefetch") {
+    // (a) 37 blocks arrive in order, each slot intact while it is held
+    {
+      int produced = 0;
+      BlockPrefetch pf(1024, [&](void *slot, int) -> size_t {
+        if (produced == 37) return 0;
+        memset(slot, produced & 0xff, 1024);
+        return (size_t)(++produced);
+      });
+      for (int k = 1; k <= 37; ++k) {
+        void *slot = nullptr;
+        const size_t n = pf.next(slot);
+        if (n != (size_t)k) return 10;
+        std::this_thread::sleep_for(std::chrono::microseconds(200 * (k % 3))); // the producer runs ahead meanwhile
+        const unsigned char *b = static_cast<unsigned char *>(slot);
+        for (int i = 0; i < 1024; ++i)
+          if (b[i] != (unsigned char)((k - 1) & 0xff)) return 11;
+      }
+      void *slot = nullptr;
+      if (pf.next(slot) != 0 || pf.next(slot) != 0) return 12; // the end is sticky
+    }
+    // (b) an exception in the producer surfaces in next()
+    {
+      int produced = 0;
+      BlockPrefetch pf(64, [&](void *, int) -> size_t {
+        if (++produced == 3) throw std::runtime_error("producer failed");
+        return 1;
+      });
+      void *slot = nullptr;
+      bool threw = false;
+      try {
+        for (int k = 0; k < 5; ++k) pf.next(slot);
+      } catch (const std::runtime_error &e) {
+        threw = std::string(e.what()) == "producer failed";
+      }
+      if (!threw) return 13;
+    }
+    // (c) the consumer walks away after one block while the producer has more: the destructor must not hang
+    {
+      BlockPrefetch pf(64, [&](void *, int) -> size_t { return 1; });
+      void *slot = nullptr;
+      if (pf.next(slot) != 1) return 14;
+    }
+    // (d) empty source, malformed source
+    {
+      BlockPrefetch pf(64, [&](void *, int) -> size_t { return 0; });
+      void *slot = nullptr;
+      if (pf.next(slot) != 0) return 15;
+      BlockPrefetch bad(64, [&](void *, int) -> size_t { return (size_t)-1; });
+      if (bad.next(slot) != (size_t)-1 || bad.next(slot) != 0) return 16;
+    }
+    printf("prefetch ok\n");
+    return 0;
   }
   if (cmd == "kinbench") {
     const size_t n = strtoul(argv[2], nullptr, 10);

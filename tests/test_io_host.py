@@ -356,3 +356,10 @@ def test_block_reader_cr_at_the_end_of_a_read(exe, tmp_path):
     got = np.fromfile(out).reshape(-1, ni)
     assert got.shape == (9, ni) and np.array_equal(got, np.array(want))
     assert [l.split()[0] for l in r.stdout.strip().split("\n")] == [l.split(",")[0] for l in lines]
+
+
+def test_block_prefetch_scenarios(exe):
+    """BlockPrefetch (gemma_host.hpp): blocks in order and intact while held, a producer exception rethrown by next(), a
+    consumer that stops early (destructor joins a producer that still has work), empty and malformed sources."""
+    r = subprocess.run([exe, "prefetch"], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0 and "prefetch ok" in r.stdout, (r.returncode, r.stdout, r.stderr)
