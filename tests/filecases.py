@@ -475,3 +475,13 @@ def mvlmm3_workflow(exe, out, modes=(1, 3)):
                 got[c] = col[c]
         err = R.mv_row_err(got, R.mv_ref_table(fx, "b", m, 3))
         assert np.mean(err <= STAT_TOL) >= 0.97 and err.max() <= 5e-3, (m, float(np.mean(err <= STAT_TOL)), float(err.max()))
+
+
+def standardised_kinship_workflow(exe, out):
+    """`-gk 2` from BIMBAM text (rows scaled by 1/sqrt(var), src/gemma_io.cpp:1535-1538) against the reference's sXX.txt"""
+    out = str(out)
+    base = ["-g", os.path.join(TXT, "bxd_mean_genotypes.txt.gz"), "-p", os.path.join(TXT, "bxd_trait.txt.gz"),
+            "-c", os.path.join(TXT, "bxd_cvt.txt.gz"), "-a", os.path.join(TXT, "bxd_anno.txt.gz"), "-outdir", out]
+    drive(exe, *base, "-gk", 2, "-o", "BXD2")
+    S = np.loadtxt(os.path.join(out, "BXD2.sXX.txt"))
+    assert S.shape == (198, 198) and np.abs(S[:24, :24] - np.loadtxt(os.path.join(TXT, "BXD.sXX.corner.txt"))).max() <= 2e-10

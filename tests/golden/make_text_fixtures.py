@@ -139,6 +139,11 @@ def main():
         for i, line in enumerate(f):
             if i < 24:
                 g.write("\t".join(line.rstrip("\n").split("\t")[:24]) + "\n")
+    gemma(tmp, *base, "-gk", 2, "-o", "BXD2")  # standardised kinship from the text input
+    with open(os.path.join(tmp, "output", "BXD2.sXX.txt")) as f, open(os.path.join(OUT, "BXD.sXX.corner.txt"), "w") as g:
+        for i, line in enumerate(f):
+            if i < 24:
+                g.write("\t".join(line.rstrip("\n").split("\t")[:24]) + "\n")
     gemma(tmp, *base, "-k", cxx, "-eigen", "-o", "E")
     shutil.copy(os.path.join(tmp, "output", "E.eigenD.txt"), os.path.join(OUT, "E.eigenD.txt"))
     shutil.copy(os.path.join(tmp, "output", "E.eigenU.txt"), os.path.join(OUT, "E.eigenU.txt"))

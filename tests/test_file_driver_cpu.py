@@ -116,6 +116,10 @@ def test_hwe_filter_to_reference_outputs(driver, tmp_path):
     fc.hwe_workflow(driver, tmp_path)
 
 
+def test_standardised_kinship_from_text(driver, tmp_path):
+    fc.standardised_kinship_workflow(driver, tmp_path)
+
+
 def test_driver_reports_reader_errors(driver, tmp_path):
     """Where the reference's readers return false the driver stops (exit code 3) instead of analysing garbage."""
     bad = tmp_path / "short.txt"

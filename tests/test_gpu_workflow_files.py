@@ -60,3 +60,7 @@ def test_hwe_filter_to_reference_outputs(driver, tmp_path):
 
 def test_mvlmm_three_traits_missing_phenotypes(driver, tmp_path):
     fc.mvlmm3_workflow(driver, tmp_path, modes=(1, 3))
+
+
+def test_standardised_kinship_from_text(driver, tmp_path):
+    fc.standardised_kinship_workflow(driver, tmp_path)
