@@ -82,3 +82,24 @@ def test_cpp_host_mirror_compiles():
                                "-o", os.path.join(td, "drv")])
         r = subprocess.run([os.path.join(td, "drv")], capture_output=True)
         assert r.returncode == 2  # usage error, before any GPU call
+
+
+def test_file_driver_on_the_product_library_fails_loudly_without_gpu():
+    """tests/cpp/gemma_file_driver.cpp linked against the PRODUCT library (not the test double): without a GPU the run
+    stops at gemma_hip_init with the no-device message -- nothing is computed on the CPU; sharded ranks report it to the parent."""
+    import subprocess
+    import tempfile
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: covered by tests/test_gpu_workflow_files.py")
+    so = _built()
+    with tempfile.TemporaryDirectory() as td:
+        exe = os.path.join(td, "drv")
+        subprocess.check_call(["g++", "-std=c++11", "-O1", "-I" + os.path.join(ROOT, "include"),
+                               os.path.join(ROOT, "tests", "cpp", "gemma_file_driver.cpp"), "-L" + os.path.dirname(so),
+                               "-lgemma_hip", "-Wl,-rpath," + os.path.dirname(so), "-lz", "-pthread", "-o", exe])
+        P = os.path.join(ROOT, "tests", "golden", "text", "P")
+        r = subprocess.run([exe, "-bfile", P, "-gk", "-outdir", td], capture_output=True, text=True)
+        assert r.returncode == 1 and "no CPU fallback" in r.stderr and not os.path.exists(os.path.join(td, "result.cXX.txt"))
+        r = subprocess.run([exe, "-bfile", P, "-k", "none", "-lmm", "1", "-gpus", "2", "-outdir", td], capture_output=True, text=True)
+        assert r.returncode == 7 and r.stderr.count("no CPU fallback") == 2
