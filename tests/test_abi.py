@@ -57,6 +57,9 @@ def test_product_does_not_import_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 txt = open(os.path.join(dp, f), errors="ignore").read()
                 assert "oracle" not in txt.replace("(oracle", "").lower() or "oracle" not in txt, (dp, f)
+    for f in os.listdir(os.path.join(ROOT, "include")):  # the public headers: C ABI and the C++ host layer
+        txt = open(os.path.join(ROOT, "include", f), errors="ignore").read().lower()
+        assert "oracle" not in txt and "orc_" not in txt, f
 
 
 def test_shard_range_covers_everything():
