@@ -1,12 +1,18 @@
 """Text artefacts of the reference binary (oracle/_ref/gemma = /root/reference/src/*.cpp compiled unchanged, see
-oracle/Makefile) for the host-layer tests of include/gemma_io_host.hpp -- run in the build container only:
+oracle/Makefile) for the host-layer tests of include/gemma_io_host.hpp / gemma_host.hpp -- run in the build container only:
 
     python tests/golden/make_text_fixtures.py
 
-Writes tests/golden/text/: the BXD inputs the readers are tested on (phenotypes, covariates, annotation and the first
-genotype lines -- small public example files of the GEMMA tree, kept verbatim because the tests compare parsers
-byte for byte), and what the reference wrote for them: `-gk` cXX (24 x 24 corner), `-eigen` eigenD / eigenU, the first
-lines of every `-lmm 1/2/3/4/9` .assoc.txt, and the individual / SNP selection the log reports.
+Writes tests/golden/text/ (deterministic: a second run reproduces the same bytes):
+* inputs: the reference's BXD example (mean genotypes, trait, covariates, annotation), stored gzip-compressed under names of
+  their own (bxd_*.gz; the readers take gzip directly) plus the first 120 genotype lines as plain text; P.* = the first
+  240 individuals x 800 SNPs of test/data/issue188 re-packed (missing calls, -9 phenotypes) with a covariate file that has
+  no intercept column and one NA row; H.* = a 300 x 600 synthetic PLINK set WITH heterozygotes (tests/cpp/io_host_check.cpp
+  plinkgen) for the HWE filter;
+* what the reference wrote for them: BXD -gk 1 / -gk 2 (24 x 24 corners of cXX / sXX), -eigen (eigenD / eigenU), the first
+  120 lines of every -lmm 1/2/3/4/9 .assoc.txt, -lmm 1 -snps (Ls); P: cXX head, -lmm 4 with and without covariates, -lmm 1
+  with tightened -miss / -maf (P1q), -notsnp (P1n), -km 2 (P1km2), -lm 4 with covariates (Plm4c); H: -lmm 1 with and
+  without -hwe 0.05; and the counts / null-model lines of each run's log (*.log.json).
 """
 import gzip
 import json
