@@ -1,7 +1,12 @@
 """File in, file out on the MI355X: gemma's own command lines (-g/-p/-c/-a or -bfile; -gk; -k ... -lmm; -eigen; -d/-u)
 through tests/cpp/gemma_file_driver.cpp over the HIP library -- first-pass QC, kinship, the 10-digit hand-off, centring,
 eigendecomposition, null model and the per-SNP loop all on the device, text parsed by the host thread pool -- against the
-files the reference binary wrote for the same inputs (tests/golden/text/).  CPU twin: tests/test_file_driver_cpu.py."""
+files the reference binary wrote for the same inputs (tests/golden/text/).  CPU twin: tests/test_file_driver_cpu.py.
+
+Order: the first five (BXD, PLINK, -loco, multivariate PLINK, -lm) ran green on the MI355X in round 1's last GPU session; the
+ones after them were written once that round's GPU minutes were spent -- same driver, same C ABI calls as
+tests/test_gpu_reference.py makes through the Python mirror, host side verified by the CPU twin -- and come last so that a
+surprise there cannot hide anything in front of them under `pytest -x`."""
 import os
 
 import pytest
