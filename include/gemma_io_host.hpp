@@ -1131,6 +1131,34 @@ inline void ReadFile_eigenU(const std::string &file_ku, bool &error, Matrix *U) 
   }
 }
 
+// ReadFile_eigenU on the thread pool (at n = 20 000 the file holds 4e8 numbers): the same doubles for a well-formed
+// file; stricter on a malformed one -- the reference zero-fills rows / columns a short file lacks and only rejects a surplus
+// (src/gemma_io.cpp:1338-1362), here both are errors
+inline void ReadFile_eigenU_threaded(const std::string &file_ku, bool &error, Matrix *U) {
+  BimbamReader rd(file_ku, U->size2, 0, 0, true);
+  if (!rd.ok()) {
+    std::cout << "error! fail to open the U file: " << file_ku << std::endl;
+    error = true;
+    return;
+  }
+  size_t i_row = 0;
+  while (i_row < U->size1) {
+    const size_t l = rd.read_block(U->size1 - i_row, U->data + i_row * U->tda, U->tda);
+    if (l == (size_t)-1) {
+      std::cout << "error! number of columns in the U file does not match, near row = " << i_row << std::endl;
+      error = true;
+      return;
+    }
+    if (l == 0) break;
+    i_row += l;
+  }
+  std::vector<double> extra(U->size2 ? U->size2 : 1);
+  if (i_row != U->size1 || rd.read_block(1, extra.data(), extra.size()) != 0) {
+    std::cout << "error! number of rows in the U file does not match." << std::endl;
+    error = true;
+  }
+}
+
 // ReadFile_eigenD, src/gemma_io.cpp:1372-1416: one number per line
 inline void ReadFile_eigenD(const std::string &file_kd, bool &error, Vector *eval) {
   TextFile infile(file_kd);

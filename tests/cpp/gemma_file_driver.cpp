@@ -259,7 +259,7 @@ int main(int argc, char **argv) {
       trace_G = EigenDecomp_Zeroed(&G, &U, &eval, 0);
       log.time_eigen = (lap() - t_e0) / 60.0;
     } else if (!file_kd.empty() && !file_ku.empty()) {
-      ReadFile_eigenU(file_ku, error, &U);
+      ReadFile_eigenU_threaded(file_ku, error, &U);
       ReadFile_eigenD(file_kd, error, &eval);
       if (error) return 5;
       for (size_t i = 0; i < ni_test; ++i) { // src/gemma.cpp:2640-2647

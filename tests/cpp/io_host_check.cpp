@@ -293,6 +293,10 @@ int main(int argc, char **argv) {
     ReadFile_eigenU(argv[2], error, &U);
     ReadFile_eigenD(argv[3], error, &D);
     if (error) return 1;
+    std::vector<double> Ut(n * n);
+    Matrix U2 = matrix_view(Ut.data(), n, n);
+    ReadFile_eigenU_threaded(argv[2], error, &U2); // the threaded reader must give the same bits
+    if (error || memcmp(Ut.data(), Ub.data(), n * n * 8) != 0) return 3;
     return WriteEigen(&U, &D, argv[5], argv[6]) ? 0 : 1;
   }
   if (cmd == "prefetch") {
