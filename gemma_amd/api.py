@@ -156,9 +156,8 @@ def kin_begin(n_total, k_mode=1):
 
 def kin_add(geno, geno_kind, l=None, ld=None):
     if _is_torch(geno):
-        l = geno.shape[0] if l is None else l
-        if geno_kind == L.GENO_F64_IDV_MAJOR and l is None:
-            l = geno.shape[1]
+        if l is None:  # individual-major: SNP j is column j (the reference's Xlarge)
+            l = geno.shape[1] if geno_kind == L.GENO_F64_IDV_MAJOR else geno.shape[0]
         ld = _tld(geno) if ld is None else ld
         rc = L.lib().gemma_hip_kin_add_d(geno_kind, C.c_void_p(geno.data_ptr()), l, ld, _stream())
     else:
@@ -252,8 +251,10 @@ def CalcLambdaNull(eval_, UtW, Uty, l_min=1e-5, l_max=1e5, n_region=10, trace_G=
     UtW = np.ascontiguousarray(UtW, dtype=np.float64).reshape(len(eval_), -1)
     out = np.zeros(8)
     n, c = UtW.shape
-    L.check(L.lib().gemma_hip_lmm_null(n, c, _ptr(_np64(np.ascontiguousarray(eval_), "eval")), _ptr(UtW),
-                                       _ptr(np.ascontiguousarray(Uty, dtype=np.float64)), l_min, l_max,
+    # converted copies stay bound to names until the call returns (_ptr keeps only the address)
+    ev_c = _np64(np.ascontiguousarray(eval_, dtype=np.float64), "eval")
+    Uty_c = np.ascontiguousarray(Uty, dtype=np.float64)
+    L.check(L.lib().gemma_hip_lmm_null(n, c, _ptr(ev_c), _ptr(UtW), _ptr(Uty_c), l_min, l_max,
                                        n_region, trace_G, _ptr(out)), "CalcLambdaNull")
     keys = ("l_mle_null", "logl_mle_H0", "l_remle_null", "logl_remle_H0", "pve", "pve_se", "vg_remle",
             "ve_remle")
@@ -299,9 +300,11 @@ class LMM:
             UtW = np.ascontiguousarray(UtW, dtype=np.float64).reshape(n, -1)
             c = UtW.shape[1]
             cfg = self._cfg(n, c, plink)
-            rc = L.lib().gemma_hip_lmm_setup(C.byref(cfg), _ptr(_np64(np.ascontiguousarray(U), "U")),
-                                             _ptr(np.ascontiguousarray(eval_, dtype=np.float64)), _ptr(UtW),
-                                             _ptr(np.ascontiguousarray(Uty, dtype=np.float64)))
+            # converted copies stay bound to names until the call returns (_ptr keeps only the address)
+            U_c = _np64(np.ascontiguousarray(U), "U")
+            ev_c = np.ascontiguousarray(eval_, dtype=np.float64)
+            Uty_c = np.ascontiguousarray(Uty, dtype=np.float64)
+            rc = L.lib().gemma_hip_lmm_setup(C.byref(cfg), _ptr(U_c), _ptr(ev_c), _ptr(UtW), _ptr(Uty_c))
         L.check(rc, "LMM.setup")
         self.ni_test, self.n_cvt = n, c
         self._active = True

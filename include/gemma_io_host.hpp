@@ -542,6 +542,7 @@ public:
   BimbamReader &operator=(const BimbamReader &) = delete;
   bool ok() const { return f_ != nullptr; }
   size_t lines_read() const { return line_no_; }
+  size_t text_buffer_bytes() const { return cap_; } // capacity of the text buffer (tests: stays O(chunk) over dropped lines)
   // consumes one line without counting it (the header of a gene-expression file); false at end of file
   bool skip_line() {
     if (!f_) return false;
@@ -597,6 +598,13 @@ public:
           }
         } else {
           if (!spans_.empty() && end_ >= text_cap()) break;
+          // nothing kept yet: the text before `scan` belongs to dropped lines only (a shard's skipped prefix, -loco /
+          // -snps with the kept SNPs late in the file) -- discard it so that the buffer tracks one chunk, not the prefix
+          if (spans_.empty() && scan > 0) {
+            memmove(buf_, buf_ + scan, end_ - scan);
+            end_ -= scan;
+            scan = 0;
+          }
           fill();
           continue;
         }

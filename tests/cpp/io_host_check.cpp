@@ -146,6 +146,7 @@ int main(int argc, char **argv) {
       for (size_t i = 0; i < l; ++i) printf("%s %s %s\n", rows[i].rs.c_str(), rows[i].minor.c_str(), rows[i].major.c_str());
     }
     fclose(out);
+    fprintf(stderr, "text_buffer_bytes %zu\n", rd.text_buffer_bytes());
     return 0;
   }
   if (cmd == "plinkgen") {

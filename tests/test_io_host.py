@@ -240,6 +240,29 @@ def test_bimbam_reader_formats_gzip_selection(exe, tmp_path):
     assert run(exe, "geno", bad, ni_total, 4, 64, tmp_path / "bad.bin", ok=False).returncode == 1
 
 
+def test_bimbam_reader_buffer_stays_bounded_over_a_dropped_prefix(exe, tmp_path):
+    """A shard of rank r > 0 (or -loco / -snps with the kept SNPs late in the file) drops a long run of leading lines:
+    the reader must discard their text as it goes instead of buffering the whole prefix (the text buffer then tracks
+    one read chunk; the cap below makes a chunk 4 KiB so that a 1.5 MB file shows it)."""
+    ni_total, ns = 40, 9000
+    rng = np.random.default_rng(8)
+    lines = ["rs%d A G " % s + " ".join(str(int(v)) for v in rng.integers(0, 3, ni_total)) for s in range(ns)]
+    path = tmp_path / "long.txt"
+    path.write_text("\n".join(lines) + "\n")
+    keep = np.zeros(ns, dtype=int)
+    keep[-10:] = 1
+    (tmp_path / "keep.txt").write_text(" ".join(map(str, keep)))
+    out = tmp_path / "tail.bin"
+    r = subprocess.run([exe, "geno", str(path), str(ni_total), "4", "64", str(out), str(tmp_path / "keep.txt")],
+                       capture_output=True, text=True, env=dict(os.environ, GEMMA_HIP_IO_TEXT_CAP="4096"))
+    assert r.returncode == 0, r.stderr
+    want, names = _expected_rows(lines[-10:], ni_total)
+    assert np.array_equal(np.fromfile(out).reshape(-1, ni_total), want)
+    assert r.stdout.strip().split("\n") == names
+    cap = int(r.stderr.split("text_buffer_bytes")[1].split()[0])
+    assert cap < 64 * 1024 < os.path.getsize(path) // 10, cap
+
+
 def test_eigen_artefacts_byte_identical_to_reference(exe, tmp_path):
     """`-eigen` writes <o>.eigenU.txt / <o>.eigenD.txt (src/gemma.cpp:1779-1800): reading the reference's files with
     ReadFile_eigenU / ReadFile_eigenD and writing them back through WriteEigen gives the same bytes."""
