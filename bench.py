@@ -40,12 +40,16 @@ def parse():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--individuals", dest="n", type=int, default=20000, help="analysed individuals (n)")
     ap.add_argument("--batch", type=int, default=20000, help="SNPs per step and per rank")
-    ap.add_argument("--kin-snps", type=int, default=20000, help="SNPs used for the kinship matrix (setup)")
+    ap.add_argument("--kin-snps", type=int, default=100000, help="SNPs used for the kinship matrix (setup; SURVEY 8d: >= 100 000)")
     ap.add_argument("--eigen", default="auto", choices=["auto", "gemma", "torch"])
     ap.add_argument("--cpu-sample", type=int, default=2048, help="SNPs in the CPU baseline sample (0 = skip)")
     ap.add_argument("--a-mode", type=int, default=1)
     ap.add_argument("--fp64-steps", type=int, default=2, help="extra untimed-region steps through the fp64 GEMM path (0 = skip)")
     ap.add_argument("--seed", type=int, default=20000)
+    ap.add_argument("--e2e-snps", type=int, default=0,
+                    help="opt-in end-to-end leg after the timed region: a synthetic PLINK set of this many SNPs on disk -> "
+                         "tests/cpp/gemma_file_driver -inproc (first pass, kinship, eigen, -lmm, .assoc.txt), wall seconds "
+                         "per stage reported under \"e2e\" (0 = skip)")
     return ap.parse_args()
 
 
@@ -303,6 +307,10 @@ def main():
             try:
                 pj = json.load(open(pmc))
                 if pj.get("n") == n and pj.get("batch") == B:
+                    # NOT measured in this run: PMC counters need their own rocprofv3 passes (MI355X_MICROARCH.md), so the
+                    # per-launch HBM bytes are read from the committed counter summary of the same kernels and shapes
+                    line["roofline"]["traffic_source"] = line["roofline_assoc"]["traffic_source"] = \
+                        "static profile: profiles/pmc_traffic.json (rocprofv3 --pmc passes, %s)" % pj.get("collected", "round 1")
                     line["roofline_assoc"]["traffic"] = pj.get("assoc_hbm_bytes_per_launch")
                     line["roofline"]["traffic"] = pj.get("i8gemm_hbm_bytes_per_launch" if i8_path
                                                          else "utx_gemm_hbm_bytes_per_launch")
@@ -311,14 +319,59 @@ def main():
             except Exception:
                 pass
         if world == 1 and args.cpu_sample > 0:
-            line["cpu_baseline"] = cpu_baseline(args, np, torch, blocks[args.warmup + args.steps - 1], U, ev, UtW, Uty, res, n, B)
+            line["cpu_baseline"] = cpu_baseline(args, np, torch, blocks[args.warmup + args.steps - 1], U, ev, UtW, Uty, res, n, B,
+                                                null=(float(null[0]), float(null[1])))
+        lmm.finish()
+        if world == 1 and args.e2e_snps > 0:
+            del blocks, out, U
+            torch.cuda.empty_cache()
+            line["e2e"] = e2e_files(args, n)
         print(json.dumps(line), flush=True)
-    lmm.finish()
+    else:
+        lmm.finish()
     if world > 1:
         dist.destroy_process_group()
 
 
-def cpu_baseline(args, np, torch, block, U, ev, UtW, Uty, gpu_res, n, B):
+def e2e_files(args, n):
+    """End to end from files (SURVEY 8d "end-to-end"): PLINK .bed/.bim/.fam on disk -> first pass -> kinship ->
+    eigendecomposition -> -lmm -> .assoc.txt through the C++ host layer (include/gemma_host.hpp over the host-pointer
+    entry points of the C ABI; tests/cpp/gemma_file_driver.cpp -inproc), in a child process; the synthetic set is written by
+    tests/cpp/io_host_check plinkgen.  Never part of `value`."""
+    import shutil
+    import subprocess
+    import tempfile
+    tmp = tempfile.mkdtemp(prefix="gemma_e2e_")
+    try:
+        inc, libdir = os.path.join(ROOT, "include"), os.path.join(ROOT, "gemma_amd")
+        gen, drv = os.path.join(tmp, "io_host_check"), os.path.join(tmp, "gemma_file_driver")
+        subprocess.check_call(["g++", "-std=c++11", "-O2", "-I" + inc, os.path.join(ROOT, "tests", "cpp", "io_host_check.cpp"),
+                               "-lz", "-pthread", "-o", gen])
+        subprocess.check_call(["g++", "-std=c++11", "-O2", "-I" + inc, os.path.join(ROOT, "tests", "cpp", "gemma_file_driver.cpp"),
+                               "-L" + libdir, "-lgemma_hip", "-Wl,-rpath," + libdir, "-lz", "-pthread", "-o", drv])
+        prefix = os.path.join(tmp, "S")
+        subprocess.check_call([gen, "plinkgen", prefix, str(n), str(args.e2e_snps), str(min(64, os.cpu_count() or 8))],
+                              stdout=subprocess.DEVNULL)
+        t0 = time.perf_counter()
+        r = subprocess.run([drv, "-bfile", prefix, "-inproc", "1", "-lmm", str(args.a_mode), "-outdir", tmp, "-o", "e2e"],
+                           capture_output=True, text=True)
+        wall = time.perf_counter() - t0
+        if r.returncode != 0:
+            return {"error": (r.stderr or r.stdout)[-300:]}
+        kv = dict(t.split("=", 1) for t in r.stdout.split() if "=" in t)
+        f = lambda k: float(kv[k]) if k in kv else None
+        return {"workload": "PLINK files n=%d p=%d -> .assoc.txt, -lmm %d, one process, files in the page cache" % (n, args.e2e_snps, args.a_mode),
+                "wall_s": round(wall, 2), "snps": int(kv.get("snps", 0)), "ni_test": int(kv.get("ni_test", 0)),
+                "ns_test": int(kv.get("ns_test", 0)),
+                "stage_end_s": {k: f(k) for k in ("t_first_pass", "t_kinship", "t_eigen", "t_null", "t_assoc", "t_written")},
+                "assoc_snps_per_s": f("assoc_snps_per_s"), "whole_run_snps_per_s": round(int(kv.get("snps", 0)) / wall, 1)}
+    except Exception as e:  # opt-in diagnostics must not take the bench line down
+        return {"error": repr(e)[:300]}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+def cpu_baseline(args, np, torch, block, U, ev, UtW, Uty, gpu_res, n, B, null=(0.0, 0.0)):
     """The CPU path on a bounded sample of the last timed block, on this box's host cores.
     kind "reference": the reference's own LMM::Analyze (src/lmm.cpp:1474-1658: Xlarge batching, mean imputation,
     fast_dgemm(U^T X) on OpenBLAS, the serial per-SNP loop), called in-process from oracle/_ref/libgemma_ref.so -- the
@@ -336,31 +389,49 @@ def cpu_baseline(args, np, torch, block, U, ev, UtW, Uty, gpu_res, n, B):
     Xi = O.impute_mean(X)
     UtX = np.ascontiguousarray(Xi @ Uh)
     t1 = time.perf_counter()
-    ref = O.lmm_batch_UtX(args.a_mode, evh, UtWh, Utyh, UtX, plink_nan_rule=1)
+    ref = O.lmm_batch_UtX(args.a_mode, evh, UtWh, Utyh, UtX, l_mle_null=null[0], logl_mle_H0=null[1], plink_nan_rule=1)
     t2 = time.perf_counter()
 
+    cols = {"beta": 0, "se": 1, "lambda_remle": 2, "lambda_mle": 3, "p_wald": 4, "p_lrt": 5, "p_score": 6, "logl_H1": 7}
+    used = {1: ["beta", "se", "logl_H1", "p_wald"], 2: ["logl_H1", "p_lrt"], 3: ["beta", "se", "p_score"],
+            4: ["beta", "se", "logl_H1", "p_wald", "p_lrt", "p_score"], 9: ["beta", "se", "logl_H1", "p_lrt", "p_score"]}[args.a_mode]
+    lams = {1: ["lambda_remle"], 2: ["lambda_mle"], 3: [], 4: ["lambda_remle", "lambda_mle"], 9: ["lambda_mle"]}[args.a_mode]
+
+    def rel_err(r, k):
+        g = gpu_res[:len(r[k]), cols[k]]
+        ok = np.isfinite(r[k]) & np.isfinite(g)
+        return np.abs(g[ok] - r[k][ok]) / np.maximum(np.abs(r[k][ok]), 1e-300)
+
     def worst_err(r):
-        w = 0.0
-        for k, col in (("beta", 0), ("se", 1), ("p_wald", 4), ("logl_H1", 7)):
-            g = gpu_res[:len(r[k]), col]
-            ok = np.isfinite(r[k])
-            w = max(w, float(np.max(np.abs(g[ok] - r[k][ok]) / np.abs(r[k][ok]))))
-        return w
+        """beta / se / logl / p-values: the worst relative error over the sample (bar: 1e-6)."""
+        return max(float(rel_err(r, k).max()) for k in used)
+
+    def lambda_err(r):
+        """lambda-hat: the reference reports the Newton iterate before the one that met its stopping rule
+        (src/lmm.cpp:2071-2073,2096), so a flipped trip count moves it by the size of the penultimate step: reported as
+        the fraction of the sample within 1e-6 and the worst case (bar: >= 98 % within 1e-6, all within 1e-3)."""
+        out = {}
+        for k in lams:
+            e = rel_err(r, k)
+            out[k] = {"frac_within_1e-6": round(float(np.mean(e <= 1e-6)), 5), "max_rel_err": float(e.max()), "n": int(e.size)}
+        g_nan = ~np.isfinite(gpu_res[:len(r["logl_H1"]), 7])
+        out["failed_search_flips"] = int((g_nan != ~np.isfinite(r["logl_H1"])).sum()) if args.a_mode != 3 else 0
+        return out
 
     # the reference amortises the GEMM over 20000-SNP batches: report the GEMM leg's flop rate beside it
     gemm_rate = 2.0 * n * n * S / (t1 - t0)
     port = {"value": round(S / (t2 - t0), 2), "unit": "SNPs/s", "cores": cores, "kind": "port",
             "sample": "%d SNPs of the last timed block: numpy/OpenBLAS dgemm on %d threads (%.1f GFLOP/s) %.2f s + "
                       "serial per-SNP loop on 1 thread %.2f s" % (S, cores, gemm_rate / 1e9, t1 - t0, t2 - t1),
-            "gpu_vs_oracle_max_rel_err": worst_err(ref)}
-    if args.a_mode != 1 or O.ref_lib() is None:  # the other modes need the null-model scalars handed over too
+            "host_threads": cores, "gpu_vs_oracle_max_rel_err": worst_err(ref), "gpu_vs_oracle_lambda": lambda_err(ref)}
+    if O.ref_lib() is None:
         return port
     # the reference's loop costs ~60 ms per SNP at n = 20 000 (13x the oracle's: heap allocations and strided Uab columns
     # in every likelihood evaluation), so its sample is cut to keep this leg at ~20 s
     S_port, S = S, min(S, max(64, int(320 * (20000.0 / n) ** 2)))
     try:
         t3 = time.perf_counter()
-        rr = O.ref_lmm_analyze(args.a_mode, Uh, evh, UtWh, Utyh, X[:S])
+        rr = O.ref_lmm_analyze(args.a_mode, Uh, evh, UtWh, Utyh, X[:S], l_mle_null=null[0], logl_mle_H0=null[1])
         t4 = time.perf_counter()
     except Exception as e:  # the checker must never take the bench down
         port["reference_error"] = repr(e)[:200]
@@ -370,7 +441,9 @@ def cpu_baseline(args, np, torch, block, U, ev, UtW, Uty, gpu_res, n, B):
             "sample": "%d SNPs of the last timed block through the reference's own LMM::Analyze (oracle/_ref/libgemma_ref.so = "
                       "/root/reference/src compiled unchanged, GSL API from oracle/gslshim): %.2f s wall, OpenBLAS dgemm on %d "
                       "threads + its serial per-SNP loop, incl. its 2 x n x 20000 batch buffers" % (S, t4 - t3, threads),
-            "gpu_vs_reference_max_rel_err": worst_err(rr), "port": port, "port_sample_snps": S_port}
+            "host_threads": cores, "threads_note": "the reference's OpenBLAS build caps its pool at %d threads; the box has %d" % (threads, cores),
+            "gpu_vs_reference_max_rel_err": worst_err(rr), "gpu_vs_reference_lambda": lambda_err(rr),
+            "port": port, "port_sample_snps": S_port}
 
 
 if __name__ == "__main__":

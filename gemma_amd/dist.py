@@ -3,7 +3,8 @@ over xGMI on the GPU box, "gloo" in the CPU tests).
 
 SNPs are independent ("the computations are independent per SNP", GEMMA src/lmm.cpp:1514); the only
 shared state is read-only: (U, eval, UtW, Uty) and the null-model scalars.  So the whole multi-GPU
-protocol is: rank 0 computes the eigendecomposition, ONE broadcast round ships the four tensors,
+protocol is: rank 0 computes the eigendecomposition, ONE broadcast round (U on its own, everything
+else coalesced into one flat buffer) ships them,
 every rank analyses a contiguous range of the analysed-SNP sequence, and the 64 B/SNP SUMSTAT
 records are gathered in rank order (= SNP order, what LMM::WriteFiles needs, src/lmm.cpp:204-219).
 No collective runs in steady state.
@@ -18,16 +19,63 @@ def shard_range(p, rank, world):
     return lo, hi
 
 
-def broadcast_state(tensors, src=0, group=None):
-    """The single broadcast of (U, eval, UtW, Uty[, scalars]) -- in place on every rank.
-    Coalesced into one flat buffer when the tensors share dtype/device and are small; U (n^2) is
-    sent on its own so no 3.2 GB staging copy is made."""
+def _staged(t, group):
+    """gloo (CPU tests, and the same-device 2-rank GPU test) moves host memory: device tensors are staged through a
+    host copy there; with nccl (= RCCL, the real multi-GPU runs) tensors are used in place."""
+    import torch.distributed as dist
+    return t.is_cuda and dist.get_backend(group) != "nccl"
+
+
+def broadcast_state(tensors, src=0, group=None, small_limit=1 << 22):
+    """The single broadcast round of (U, eval, UtW, Uty[, scalars]) -- in place on every rank.  Tensors of up to
+    `small_limit` elements (eval, UtW, Uty, the null-model scalars: 8 n (c + 2) bytes) travel coalesced in ONE flat
+    buffer; larger ones (U, n^2) are sent on their own so that no second 8 n^2-byte staging copy is made.  At n = 20 000
+    that is two collectives in total: 3.2 GB + 0.5 MB."""
+    import torch
     import torch.distributed as dist
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         return tensors
+    small = [t for t in tensors if t.numel() <= small_limit]
     for t in tensors:
-        dist.broadcast(t, src=src, group=group)
+        if t.numel() > small_limit:
+            if _staged(t, group):
+                h = t.cpu()
+                dist.broadcast(h, src=src, group=group)
+                t.copy_(h)
+            else:
+                dist.broadcast(t, src=src, group=group)
+    # one flat buffer per (dtype, device) class -- in practice one: everything here is float64 on this rank's GPU
+    classes = {}
+    for t in small:
+        classes.setdefault((t.dtype, t.device), []).append(t)
+    for (dtype, device), ts in classes.items():
+        flat = torch.cat([t.reshape(-1) for t in ts])
+        if _staged(flat, group):
+            h = flat.cpu()
+            dist.broadcast(h, src=src, group=group)
+            flat = h.to(device)
+        else:
+            dist.broadcast(flat, src=src, group=group)
+        off = 0
+        for t in ts:
+            t.copy_(flat[off:off + t.numel()].reshape(t.shape))
+            off += t.numel()
     return tensors
+
+
+def seed_plink_carry(analyse_one, lo):
+    """AnalyzePlink prints the PREVIOUS SNP's beta / se for a SNP whose lambda search failed (function-scope variables,
+    src/lmm.cpp:1725,1870-1884), so a shard that starts at SNP `lo` > 0 must start with the carry the unsharded run has
+    there.  A successful SNP overwrites the carry with its own values and a failed one leaves it alone, so it is enough
+    to analyse -- before the shard, results discarded -- the SNPs lo-1, lo-2, ... until one succeeds (almost always the
+    first).  analyse_one(j) runs SNP j alone through LMM.batch and returns its logl_H1."""
+    j = lo - 1
+    while j >= 0:
+        logl = analyse_one(j)
+        if logl == logl:  # not NaN: the search succeeded, the carry now holds this SNP's beta / se
+            break
+        j -= 1
+    return lo - 1 - j if j >= 0 else lo
 
 
 def gather_sumstat(local, p_total, group=None):
@@ -41,8 +89,11 @@ def gather_sumstat(local, p_total, group=None):
     per = (p_total + world - 1) // world
     buf = torch.zeros((per, local.shape[1]), dtype=local.dtype, device=local.device)
     buf[: local.shape[0]] = local
+    if _staged(buf, group):
+        buf = buf.cpu()
     parts = [torch.empty_like(buf) for _ in range(world)]
     dist.all_gather(parts, buf, group=group)
+    parts = [p.to(local.device) for p in parts]
     out = []
     for r, part in enumerate(parts):
         lo, hi = shard_range(p_total, r, world)

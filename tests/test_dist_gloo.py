@@ -107,3 +107,41 @@ def test_two_rank_kinship_allreduce(tmp_path, oracle, bxd):
     K0, K1 = np.load(tmp_path / "K_rank0.npy"), np.load(tmp_path / "K_rank1.npy")
     assert np.array_equal(K0, K1)
     np.testing.assert_allclose(K0, ref, rtol=1e-12, atol=1e-14)
+
+
+def test_seed_plink_carry_reproduces_the_unsharded_chain():
+    """AnalyzePlink's beta / se carry over failed lambda searches (src/lmm.cpp:1725,1870-1884) at a shard boundary:
+    gemma_amd.dist.seed_plink_carry walks back from the shard's first SNP until a search succeeds; a model of the
+    library's carry state (a success overwrites it, a failure copies it) must then give the shard the rows of the
+    unsharded run for every failure pattern, including 'everything before the shard failed'."""
+    from gemma_amd import dist as gdist
+    rng = np.random.default_rng(5)
+    for trial in range(200):
+        p = int(rng.integers(2, 40))
+        failed = rng.random(p) < (0.6 if trial % 3 == 0 else 0.15)
+        beta = rng.standard_normal(p)
+
+        def run(lo, hi, carry):
+            rows = []
+            for s in range(lo, hi):
+                if not failed[s]:
+                    carry = beta[s]
+                rows.append(carry)
+            return rows, carry
+
+        full, _ = run(0, p, 0.0)
+        for world in (2, 3, 5):
+            got = []
+            for r in range(world):
+                lo, hi = gdist.shard_range(p, r, world)
+                state = {"carry": 0.0}
+
+                def analyse_one(j):
+                    _, state["carry"] = run(j, j + 1, state["carry"])
+                    return float("nan") if failed[j] else 1.0
+
+                steps = gdist.seed_plink_carry(analyse_one, lo)
+                assert steps <= lo
+                rows, _ = run(lo, hi, state["carry"])
+                got += rows
+            assert got == full

@@ -1,0 +1,182 @@
+"""Parity AT THE SIZES of BASELINE.json's configs: the whole device chain -- synthetic PLINK
+2-bit genotypes generated on the GPU (bench.synth_block), kinship, centring, eigendecomposition, U^T W / U^T y, null
+model, then one block of the association loop through the device-pointer entry points -- against the oracle on a few
+hundred sampled SNPs of that block (the oracle is handed the device's U / eval, so what is compared is the per-SNP
+path at that n: U^T x through the int8-digit product, lambda search, tests).
+
+  config 2  n = 5 000, -lmm 4 (Wald + LRT + score), c = 1 and c = 3     src/lmm.cpp:1526-1562
+  config 4  n = 33 000 > 32 640: the UNFUSED 7-plane int8-digit product (256 C_hi + C_lo would overflow int32);
+            also forced at small n with GEMMA_HIP_I8_FUSE=0
+  config 5  n = 10 000, three phenotypes, -lmm 4 multivariate            src/mvlmm.cpp:3218-3375
+"""
+import numpy as np
+import pytest
+
+from test_gpu_parity import _cmp_stats, _plink_case, _record
+
+pytestmark = pytest.mark.gpu
+
+
+def _device_chain(gpu_api, n, kin_snps, seed, c=1, n_traits=1):
+    """-> dict of torch device tensors U, ev, UtW (n x c), UtY (n x n_traits), plus W, Y and the generator."""
+    import torch
+    import bench
+    from gemma_amd import _lib as L
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(seed)
+    gen = torch.Generator(device=dev).manual_seed(seed)
+    K = torch.empty((n, n), dtype=torch.float64, device=dev)
+    gpu_api.kin_begin(n, 1)
+    done = 0
+    Y = torch.zeros((n, n_traits), dtype=torch.float64, device=dev)
+    while done < kin_snps:
+        l = min(20000, kin_snps - done)
+        blk = bench.synth_block(torch, n, l, gen, dev)
+        gpu_api.kin_add(blk, L.GENO_PLINK_2BIT)
+        if done == 0:  # 30 causal SNPs per trait
+            codes = (blk[:30 * n_traits].unsqueeze(2) >> torch.tensor([0, 2, 4, 6], device=dev, dtype=torch.uint8)) & 3
+            codes = codes.reshape(30 * n_traits, -1)[:, :n]
+            gv = torch.where(codes == 0, 2.0, torch.where(codes == 2, 1.0, 0.0)).to(torch.float64)
+            for t in range(n_traits):
+                b = torch.randn(30, dtype=torch.float64, device=dev, generator=gen) * 0.2
+                Y[:, t] += gv[30 * t:30 * (t + 1)].T @ b
+        done += l
+        del blk
+    gpu_api.kin_end(K)
+    gpu_api.CenterMatrix(K)
+    U = torch.empty((n, n), dtype=torch.float64, device=dev)
+    ev = torch.empty(n, dtype=torch.float64, device=dev)
+    gpu_api.EigenDecomp_Zeroed(K, U, ev)
+    del K
+    # polygenic term g ~ N(0, K) = U sqrt(ev) z, shared noise between traits, then independent noise
+    z = torch.randn((n, n_traits), dtype=torch.float64, device=dev, generator=gen)
+    g = U @ (ev.clamp_min(0).sqrt().unsqueeze(1) * z)
+    Y += 0.8 * g * (Y.std(dim=0).clamp_min(0.3) / g.std(dim=0).clamp_min(1e-6))
+    e = torch.randn((n, n_traits), dtype=torch.float64, device=dev, generator=gen)
+    if n_traits > 1:
+        e = e + 0.5 * e[:, :1]
+    Y += e * Y.std(dim=0).clamp_min(0.3)
+    W = torch.ones((n, c), dtype=torch.float64, device=dev)
+    if c > 1:
+        W[:, :c - 1] = torch.randn((n, c - 1), dtype=torch.float64, device=dev, generator=gen)
+    UtW = torch.empty((n, c), dtype=torch.float64, device=dev)
+    gpu_api.fast_dgemm("T", "N", 1.0, U, W, 0.0, UtW)
+    UtY = torch.empty((n, n_traits), dtype=torch.float64, device=dev)
+    gpu_api.fast_dgemm("T", "N", 1.0, U, Y.contiguous(), 0.0, UtY)
+    torch.cuda.synchronize()
+    return dict(U=U, ev=ev, UtW=UtW, UtY=UtY, gen=gen, dev=dev)
+
+
+def _sumstat(gpu_api, out):
+    got = np.zeros(out.shape[0], dtype=gpu_api.SUMSTAT_DTYPE)
+    got.view(np.float64).reshape(-1, 8)[:] = out.cpu().numpy()
+    return got
+
+
+@pytest.mark.parametrize("c", [1, 3])
+def test_config2_n5000_lmm4(gpu_api, oracle, c):
+    """BASELINE config 2 shape: n = 5 000, -gk + -lmm 4, PLINK 2-bit block of 20 000 SNPs, c = 1 and c = 3."""
+    import torch
+    import bench
+    from gemma_amd import _lib as L
+    n, B, S = 5000, 20000, 384
+    ch = _device_chain(gpu_api, n, 20000, seed=5000 + c, c=c)
+    U, ev, UtW, Uty = ch["U"], ch["ev"], ch["UtW"], ch["UtY"][:, 0].contiguous()
+    Uh, evh, UtWh, Utyh = U.cpu().numpy(), ev.cpu().numpy(), UtW.cpu().numpy(), Uty.cpu().numpy()
+    nm = gpu_api.CalcLambdaNull(evh, UtWh, Utyh, trace_G=float(evh.mean()))
+    l_ref, logl_ref = oracle.calc_lambda_null("L", evh, UtWh, Utyh)
+    assert nm["l_mle_null"] == pytest.approx(l_ref, rel=1e-3) and nm["logl_mle_H0"] == pytest.approx(logl_ref, rel=1e-9)
+    blk = bench.synth_block(torch, n, B, ch["gen"], ch["dev"])
+    lmm = gpu_api.LMM(a_mode=4, l_mle_null=nm["l_mle_null"], logl_mle_H0=nm["logl_mle_H0"])
+    lmm.setup(U, ev, UtW, Uty, plink=True)
+    out = lmm.batch(blk, L.GENO_PLINK_2BIT)
+    torch.cuda.synchronize()
+    lmm.finish()
+    got = _sumstat(gpu_api, out)
+    sample = np.sort(np.random.default_rng(c).choice(B, S, replace=False))
+    X = oracle.bed_decode(blk[torch.from_numpy(sample).to(ch["dev"])].cpu().numpy(), n)
+    ref = oracle.lmm_analyze(4, Uh, evh, UtWh, Utyh, X, l_mle_null=nm["l_mle_null"], logl_mle_H0=nm["logl_mle_H0"],
+                             plink_nan_rule=1)
+    assert np.isfinite(got["p_wald"]).mean() > 0.99
+    _cmp_stats(got[sample], ref, 4, "config2 n=5000 c=%d" % c)
+
+
+def test_config4_shape_unfused_int8_planes_n33000(gpu_api, oracle):
+    """n = 33 000 (> 32 640): the int8-digit product writes 7 separate int32 planes per operand instead of 4 fused ones
+    (csrc/gemma_hip.hip i8_begin); -gk + -lmm 1 at that size against the oracle on 96 sampled SNPs."""
+    import torch
+    import bench
+    from gemma_amd import _lib as L
+    n, B, S = 33000, 4096, 96
+    ch = _device_chain(gpu_api, n, 36000, seed=50000)
+    U, ev, UtW, Uty = ch["U"], ch["ev"], ch["UtW"], ch["UtY"][:, 0].contiguous()
+    blk = bench.synth_block(torch, n, B, ch["gen"], ch["dev"])
+    lmm = gpu_api.LMM(a_mode=1)
+    lmm.setup(U, ev, UtW, Uty, plink=True)
+    out = lmm.batch(blk, L.GENO_PLINK_2BIT)
+    torch.cuda.synchronize()
+    lmm.finish()
+    got = _sumstat(gpu_api, out)
+    sample = np.sort(np.random.default_rng(4).choice(B, S, replace=False))
+    X = oracle.bed_decode(blk[torch.from_numpy(sample).to(ch["dev"])].cpu().numpy(), n)
+    ref = oracle.lmm_analyze(1, U.cpu().numpy(), ev.cpu().numpy(), UtW.cpu().numpy(), Uty.cpu().numpy(), X,
+                             plink_nan_rule=1)
+    assert np.isfinite(got["p_wald"]).mean() > 0.99
+    _cmp_stats(got[sample], ref, 1, "config4-shape n=33000 (unfused int8 planes)")
+
+
+@pytest.mark.parametrize("ni_total,p", [(611, 257), (1301, 300)])
+def test_unfused_int8_planes_forced_small(gpu_api, oracle, monkeypatch, ni_total, p):
+    """GEMMA_HIP_I8_FUSE=0 forces the n > 32 640 code path at a size the oracle covers completely: the U^T x rows must be
+    bit-identical to the fused form (both are exact integer sums assembled by the same Horner pass) and the statistics
+    must meet the usual bar."""
+    from gemma_amd import _lib as L
+    rng = np.random.default_rng(ni_total)
+    ind, raw = _plink_case(oracle, rng, ni_total, p)
+    n = int(ind.sum())
+    Xn = oracle.bed_decode(raw, ni_total, ind)
+    Kg = oracle.bed_decode(raw, ni_total)[:, ind == 1]
+    U, ev, _ = oracle.eigen_decomp_zeroed(oracle.center_matrix(oracle.calc_kin(Kg, 1)))
+    y = rng.standard_normal(n)
+    UtW, Uty = U.T @ np.ones((n, 1)), U.T @ y
+    ref = oracle.lmm_analyze(1, U, ev, UtW, Uty, Xn, plink_nan_rule=1)
+    utx = {}
+    for fuse in ("1", "0"):
+        monkeypatch.setenv("GEMMA_HIP_I8_FUSE", fuse)
+        lmm = gpu_api.LMM(a_mode=1)
+        lmm.setup(U, ev, UtW, Uty, plink=True)
+        lmm.set_indicator(ind)
+        utx[fuse] = lmm.dbg_utx(raw, L.GENO_PLINK_2BIT, 1)
+        got = lmm.batch(raw, L.GENO_PLINK_2BIT)
+        lmm.finish()
+        _cmp_stats(got, ref, 1, "plink fuse=%s ni_total=%d" % (fuse, ni_total))
+    assert np.array_equal(utx["0"], utx["1"])
+    exact = oracle.impute_mean(Xn) @ U
+    assert np.max(np.abs(utx["0"] - exact)) < 1e-12 * np.max(np.abs(exact)) * n
+
+
+def test_config5_mvlmm_n10000_three_traits(gpu_api, oracle):
+    """BASELINE config 5 shape: n = 10 000, three phenotypes, -lmm 4 multivariate (EM + Wald + LRT + score, Newton-Raphson
+    for p < 1e-3), one PLINK 2-bit block through gemma_hip_mvlmm_batch; oracle on 160 sampled SNPs."""
+    import torch
+    import bench
+    from gemma_amd import _lib as L
+    from test_gpu_mvlmm import _compare
+    n, B, S, d = 10000, 4096, 160, 3
+    ch = _device_chain(gpu_api, n, 20000, seed=10000, n_traits=d)
+    Uh, evh = ch["U"].cpu().numpy(), ch["ev"].cpu().numpy()
+    UtWh, UtYh = ch["UtW"].cpu().numpy(), ch["UtY"].cpu().numpy()
+    blk = bench.synth_block(torch, n, B, ch["gen"], ch["dev"]).cpu().numpy()
+    mv = gpu_api.MVLMM(a_mode=4)
+    got = mv.AnalyzePlink(Uh, evh, UtWh, UtYh, blk, np.ones(n, dtype=np.int32))
+    cfg = oracle.mv_cfg()
+    W_t, Y_t = np.ascontiguousarray(UtWh.T), np.ascontiguousarray(UtYh.T)
+    null = oracle.mvlmm_null(cfg, evh, W_t, Y_t)
+    for k in ("Vg_mle", "Ve_mle", "Vg_remle", "Ve_remle"):
+        assert np.abs(mv.null[k] - null[k]).max() < 1e-5 * np.abs(null[k]).max(), k
+    sample = np.sort(np.random.default_rng(5).choice(B, S, replace=False))
+    X = oracle.impute_mean(oracle.bed_decode(blk[sample], n))
+    ref = oracle.mvlmm_batch(4, cfg, evh, W_t, Y_t, np.ascontiguousarray(X @ Uh), null)
+    sub = {k: np.asarray(v)[sample] for k, v in got.items()}
+    _compare(sub, ref, "config5 n=10000 d=3")
+    _record("parity[config5 n=10000 d=3 mvLMM -lmm 4] %d sampled SNPs within the mvLMM bar (>= 97 %% at 1e-6, all at 5e-3)" % S)

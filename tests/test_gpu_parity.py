@@ -55,14 +55,30 @@ def _cmp_stats(got, ref, mode, tag=""):
             rel = np.abs(g - r) / np.abs(r)
         rel = np.where(np.isnan(rel) | (g == r), 0.0, rel)
         w = int(np.argmax(rel))
-        report.append("%s: max rel %.3e at %d (%r vs %r), #>1e-6: %d" % (k, rel[w], w, g[w], r[w], int((rel > 1e-6).sum())))
+        report.append("%s: max rel %.3e at %d (%r vs %r), #>1e-6: %d of %d (frac <=1e-6: %.5f)" % (
+            k, rel[w], w, g[w], r[w], int((rel > 1e-6).sum()), len(rel), float(np.mean(rel <= 1e-6)) if len(rel) else 1.0))
         if k.startswith("lambda"):
             if rel.max() > 1e-3 or np.mean(rel <= 1e-6) < 0.98:
                 bad.append(report[-1])
         elif rel.max() > RTOL:
             bad.append(report[-1])
-    print("parity[%s mode %d] " % (tag, mode) + "; ".join(report))
+    line = "parity[%s mode %d] n_snps=%d nan_flips=%d; " % (tag, mode, len(nan_g), n_mis) + "; ".join(report)
+    print(line)
+    _record(line)
     assert not bad, "mode %d %s: %s" % (mode, tag, " | ".join(bad))
+
+
+def _record(line):
+    """Observed parity numbers (max relative error, fraction of lambda-hat within 1e-6, NaN flips) of every comparison,
+    appended to gpurun_out/parity_report.txt on the GPU box; the round's copy is committed under profiles/."""
+    import os
+    try:
+        d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+        os.makedirs(d, exist_ok=True)
+        with open(os.path.join(d, "parity_report.txt"), "a") as f:
+            f.write(line + "\n")
+    except OSError:
+        pass
 
 
 # --------------------------------------------------------------------------- GEMM

@@ -1,0 +1,106 @@
+"""Two ranks of the HIP library (not the oracle) on ONE device: the N > 1 protocol of gemma_amd.dist with the real
+per-shard compute -- rank 0 holds (U, eval, UtW, Uty), one broadcast round, every rank runs libgemma_hip.so on its
+contiguous SNP range (device-pointer entry points), SUMSTAT gathered in rank order -- must equal the single-rank run
+BIT FOR BIT, including AnalyzePlink's carry of the previous SNP's beta / se over a failed lambda search at a shard
+boundary (src/lmm.cpp:1725,1870-1884).  gloo carries the collectives here because RCCL refuses two ranks on one
+device; on the multi-GPU node the same code runs over nccl = RCCL (bench.py --gpus N)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, case_path, outdir, batch):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import torch
+    import torch.distributed as dist
+    from gemma_amd import api
+    from gemma_amd import _lib as L
+    from gemma_amd import dist as gdist
+
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    api.init(0, verbose=0)
+    d = np.load(case_path)
+    n = d["U"].shape[0]
+    if rank == 0:
+        U, ev = torch.from_numpy(d["U"]).to(dev), torch.from_numpy(d["ev"]).to(dev)
+        UtW, Uty = torch.from_numpy(d["UtW"]).to(dev), torch.from_numpy(d["Uty"]).to(dev)
+    else:
+        U, ev = torch.zeros((n, n), dtype=torch.float64, device=dev), torch.zeros(n, dtype=torch.float64, device=dev)
+        UtW = torch.zeros((n, 1), dtype=torch.float64, device=dev)
+        Uty = torch.zeros(n, dtype=torch.float64, device=dev)
+    gdist.broadcast_state([U, ev, UtW, Uty], small_limit=4 * n)  # U on its own, the three vectors coalesced
+    assert torch.equal(U.cpu(), torch.from_numpy(d["U"]))
+    raw = torch.from_numpy(d["raw"]).to(dev)
+    p_total = raw.shape[0]
+    lo, hi = gdist.shard_range(p_total, rank, world)
+    lmm = api.LMM(a_mode=1)
+    lmm.setup(U, ev, UtW, Uty, plink=True)
+    lmm.set_indicator(d["ind"])
+    gdist.seed_plink_carry(lambda j: float(lmm.batch(raw[j:j + 1], L.GENO_PLINK_2BIT)[0, 7]), lo)
+    outs = [lmm.batch(raw[s0:min(hi, s0 + batch)], L.GENO_PLINK_2BIT) for s0 in range(lo, hi, batch)]
+    local = torch.cat(outs) if outs else torch.zeros((0, 8), dtype=torch.float64, device=dev)
+    torch.cuda.synchronize()
+    lmm.finish()
+    full = gdist.gather_sumstat(local, p_total)
+    if rank == 0:
+        np.save(os.path.join(outdir, "gathered.npy"), full.cpu().numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("batch", [97, 4096])
+def test_two_hip_ranks_on_one_device_equal_single_rank(gpu_api, oracle, tmp_path, batch):
+    import torch.multiprocessing as mp
+    from gemma_amd import _lib as L
+    from test_gpu_parity import _plink_case
+    rng = np.random.default_rng(2024)
+    ni_total, p_total = 700, 601
+    ind, raw = _plink_case(oracle, rng, ni_total, p_total)
+    n = int(ind.sum())
+    # SNPs whose lambda search fails (every call missing: the imputed mean is 0/0, the likelihoods are NaN,
+    # src/lmm.cpp:1819-1827): the first SNP of the file, the first two of rank 1's shard, the one just before it and
+    # one in the middle of a shard
+    lo1 = (p_total + 1) // 2
+    dead = [0, lo1 - 1, lo1, lo1 + 1, 450]
+    for s in dead:
+        raw[s, :] = 0x55  # code 01 = missing for every individual
+    Kg = np.delete(oracle.bed_decode(raw, ni_total)[:, ind == 1], dead, axis=0)
+    U, ev, _ = oracle.eigen_decomp_zeroed(oracle.center_matrix(oracle.calc_kin(Kg, 1)))
+    y = rng.standard_normal(n)
+    UtW, Uty = U.T @ np.ones((n, 1)), U.T @ y
+    case = tmp_path / "case.npz"
+    np.savez(case, U=U, ev=ev, UtW=UtW, Uty=Uty, raw=raw, ind=ind)
+    # single rank, same batching
+    lmm = gpu_api.LMM(a_mode=1)
+    lmm.setup(U, ev, UtW, Uty, plink=True)
+    lmm.set_indicator(ind)
+    single = np.concatenate([lmm.batch(raw[s0:s0 + batch], L.GENO_PLINK_2BIT) for s0 in range(0, p_total, batch)])
+    lmm.finish()
+    single = single.view(np.float64).reshape(-1, 8)
+    failed = np.isnan(single[:, 7])
+    assert failed[dead].all() and failed.sum() < 12
+    assert single[0, 0] == 0.0 and single[lo1, 0] == single[lo1 - 2, 0] != 0.0  # the carry is what is being tested
+    mp.spawn(_worker, args=(2, _free_port(), str(case), str(tmp_path), batch), nprocs=2, join=True)
+    got = np.load(tmp_path / "gathered.npy")
+    assert got.shape == single.shape
+    assert np.array_equal(got, single, equal_nan=True)
