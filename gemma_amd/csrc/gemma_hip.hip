@@ -80,6 +80,9 @@ struct Ctx {
   bool have_map = false;
   DevBuf X, UtX, stage_in, stage_out, carry;
   DevBuf grid_R, grid_F, grid_T; // fixed-lambda table (lmm_grid.hip.h)
+  DevBuf cheb_R, cheb_F, cheb_T, cheb_slots, cheb_list, cheb_count, cheb_D, cheb_Ck, cheb_Gk, cheb_dends, cheb_res; // bracket-interval series
+  double cheb_mid[ASSOC_MAX_REGION], cheb_inv_half[ASSOC_MAX_REGION];
+  GridGeom cheb_geom;
   DevBuf gxe_env, gxe_UtWt, gxe_Z, gxe_UtZ, gxe_flip; // GXE variants
   bool gxe_ready = false;
   double gxe_lnbeta = 0.0;
@@ -704,6 +707,77 @@ static bool grid_blocks(size_t c, int nq, int *nbx, int *nba) {
   *nba = ((int)(c + 1) * nq + 15) / 16;
   return c >= 1 && c <= 4 && nq == 23;
 }
+// Chebyshev-in-log(lambda) series of the bracket intervals (lmm_search.hip.h), SNP-independent part: per interval
+// [lam_grid[j], lam_grid[j + 1]] with lam_grid[j] >= CHEB_MIN_LAMBDA the weight matrix of the table product and the
+// series of the covariate / phenotype pairs and of g = sum (1 - H).  Needs the fixed-lambda table (the scan reads it) and
+// intervals no longer than the decade the accuracy figures were established on; GEMMA_HIP_ASSOC_CHEB=0 switches it off
+// (every Brent / Newton evaluation then streams the row, as in round 1).
+static int make_cheb(hipStream_t s) {
+  AssocArgs &a = g_ctx.assoc_proto;
+  a.have_cheb = 0;
+  a.cheb_T = nullptr; a.cheb_F = nullptr; a.cheb_slots = nullptr; a.cheb_res = nullptr;
+  const char *e = getenv("GEMMA_HIP_ASSOC_CHEB");
+  if (e && e[0] == '0') return GEMMA_HIP_OK;
+  const size_t n = g_ctx.cfg.n, c = g_ctx.cfg.n_cvt;
+  const int nreg = (int)g_ctx.cfg.n_region;
+  const double width = log(g_ctx.cfg.l_max / g_ctx.cfg.l_min) / (double)nreg;
+  if (c < 1 || c > 4 || width > 2.31 || nreg > 62) return GEMMA_HIP_OK;
+  int j0 = 0;
+  while (j0 < nreg && a.lam_grid[j0] < CHEB_MIN_LAMBDA * (1.0 - 1e-9)) ++j0;
+  const int nint = nreg - j0;
+  if (nint <= 0) return GEMMA_HIP_OK;
+  GridGeom gg;
+  gg.nq = CHEB_N;
+  gg.nbx = (CHEB_N + 15) / 16;
+  gg.nba = ((int)(c + 1) * CHEB_N + 15) / 16;
+  gg.nc = (int)((n + 15) / 16);
+  if (!(gg.nbx == 2 && (gg.nba == 3 || gg.nba == 5 || gg.nba == 6 || gg.nba == 8))) return GEMMA_HIP_OK;
+  const size_t nb = (size_t)(gg.nbx + gg.nba);
+  const size_t r_elems = (size_t)gg.nc * nb * 256;
+  const size_t npairs = (c + 1) * (c + 2) / 2;
+  const size_t fld = (npairs + 1) * CHEB_N;
+  if (g_ctx.cheb_R.reserve((size_t)nint * r_elems * 8) || g_ctx.cheb_F.reserve((size_t)nint * fld * 8) ||
+      g_ctx.cheb_D.reserve(CHEB_N * CHEB_N * 8) || g_ctx.cheb_Ck.reserve(n * CHEB_N * 8) ||
+      g_ctx.cheb_Gk.reserve(n * CHEB_N * 8))
+    return fail(GEMMA_HIP_ENOMEM, "lmm_setup: Chebyshev tables (%zu bytes)", (size_t)nint * r_elems * 8);
+  // fit matrix: coefficients = D * node values (cheb_fit of lmm_search.hip.h)
+  std::vector<double> D((size_t)CHEB_N * CHEB_N);
+  for (int k = 0; k < CHEB_N; ++k)
+    for (int m = 0; m < CHEB_N; ++m)
+      D[(size_t)k * CHEB_N + m] = cos(M_PI * k * (m + 0.5) / CHEB_N) * (k == 0 ? 1.0 : 2.0) / CHEB_N;
+  HIPCHK(hipMemcpyAsync(g_ctx.cheb_D.p, D.data(), D.size() * 8, hipMemcpyHostToDevice, s));
+  HIPCHK(hipStreamSynchronize(s)); // D is a local
+  AssocArgs k = a;
+  k.eval = g_ctx.eval;
+  k.Uty = g_ctx.Uty;
+  k.UtWt = g_ctx.UtWt.as<double>();
+  for (int q = 0; q < nint; ++q) {
+    const ChebInterval iv = cheb_interval(a.lam_grid[j0 + q], a.lam_grid[j0 + q + 1], CHEB_MARGIN);
+    g_ctx.cheb_mid[q] = iv.mid;
+    g_ctx.cheb_inv_half[q] = 1.0 / iv.half;
+    ChebNodes nd;
+    for (int m = 0; m < CHEB_N; ++m) nd.lam[m] = exp(cheb_node(iv, m));
+    hipLaunchKernelGGL(cheb_coeff_kernel, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, s, g_ctx.eval, (int)n, nd,
+                       g_ctx.cheb_D.as<double>(), g_ctx.cheb_Ck.as<double>(), g_ctx.cheb_Gk.as<double>());
+    HIPCHK(hipGetLastError());
+    hipLaunchKernelGGL(cheb_weights_kernel, dim3((unsigned)((r_elems + 255) / 256)), dim3(256), 0, s, k, gg, (int)c,
+                       g_ctx.cheb_Ck.as<double>(), g_ctx.cheb_R.as<double>() + (size_t)q * r_elems);
+    HIPCHK(hipGetLastError());
+    hipLaunchKernelGGL(cheb_fixed_kernel, dim3((unsigned)(npairs + 1)), dim3(256), 0, s, k, (int)c,
+                       g_ctx.cheb_Ck.as<double>(), g_ctx.cheb_Gk.as<double>(), g_ctx.cheb_F.as<double>() + (size_t)q * fld);
+    HIPCHK(hipGetLastError());
+  }
+  g_ctx.cheb_geom = gg;
+  a.cheb_F = g_ctx.cheb_F.as<double>();
+  a.cheb_ld = (int)(nb * 16);
+  a.cheb_fld = (int)fld;
+  a.cheb_xa0 = gg.nbx * 16;
+  a.cheb_j0 = j0;
+  a.cheb_nint = nint;
+  a.have_cheb = 1;
+  return GEMMA_HIP_OK;
+}
+
 static int make_grid(hipStream_t s) {
   AssocArgs &a = g_ctx.assoc_proto;
   a.have_grid = 0;
@@ -735,7 +809,7 @@ static int make_grid(hipStream_t s) {
   a.grid_nq = gg.nq;
   a.grid_xa0 = gg.nbx * 16;
   a.have_grid = 1;
-  return GEMMA_HIP_OK;
+  return make_cheb(s);
 }
 
 // the per-batch part: T = [X.X | X] * R for the l SNP rows of UtX
@@ -748,13 +822,76 @@ static int launch_grid_table(const double *UtX, size_t l, size_t ld, hipStream_t
   double *T = g_ctx.grid_T.as<double>();
   const int n = (int)g_ctx.cfg.n;
   switch (gg.nba) {
-  case 3: hipLaunchKernelGGL((grid_table_kernel<2, 3>), dim3(grid), dim3(256), 0, s, UtX, (long)ld, (long)l, n, gg.nc, R, T); break;
-  case 5: hipLaunchKernelGGL((grid_table_kernel<2, 5>), dim3(grid), dim3(256), 0, s, UtX, (long)ld, (long)l, n, gg.nc, R, T); break;
-  case 6: hipLaunchKernelGGL((grid_table_kernel<2, 6>), dim3(grid), dim3(256), 0, s, UtX, (long)ld, (long)l, n, gg.nc, R, T); break;
-  case 8: hipLaunchKernelGGL((grid_table_kernel<2, 8>), dim3(grid), dim3(256), 0, s, UtX, (long)ld, (long)l, n, gg.nc, R, T); break;
+  case 3: hipLaunchKernelGGL((grid_table_kernel<2, 3, false>), dim3(grid), dim3(256), 0, s, UtX, (long)ld, (long)l, n, gg.nc, R, T, TableGather()); break;
+  case 5: hipLaunchKernelGGL((grid_table_kernel<2, 5, false>), dim3(grid), dim3(256), 0, s, UtX, (long)ld, (long)l, n, gg.nc, R, T, TableGather()); break;
+  case 6: hipLaunchKernelGGL((grid_table_kernel<2, 6, false>), dim3(grid), dim3(256), 0, s, UtX, (long)ld, (long)l, n, gg.nc, R, T, TableGather()); break;
+  case 8: hipLaunchKernelGGL((grid_table_kernel<2, 8, false>), dim3(grid), dim3(256), 0, s, UtX, (long)ld, (long)l, n, gg.nc, R, T, TableGather()); break;
   default: return fail(GEMMA_HIP_ERUNTIME, "lmm_assoc: no fixed-lambda table kernel for %d column blocks", gg.nba);
   }
   HIPCHK(hipGetLastError());
+  return GEMMA_HIP_OK;
+}
+
+// the per-batch part of the bracket-interval series: which (SNP, interval) pairs exist (scan over the fixed-lambda table),
+// then the table product for exactly those rows.  `a` must already carry grid_T; fills a.cheb_T / a.cheb_slots.
+static int launch_cheb_tables(AssocArgs &a, const double *UtX, size_t l, size_t ld, hipStream_t s) {
+  const GridGeom &gg = g_ctx.cheb_geom;
+  const size_t nb = (size_t)(gg.nbx + gg.nba), nint = (size_t)a.cheb_nint;
+  if (g_ctx.cheb_T.reserve(nint * l * nb * 16 * 8) || g_ctx.cheb_slots.reserve(l * nint * sizeof(int)) ||
+      g_ctx.cheb_list.reserve(nint * l * sizeof(int)) || g_ctx.cheb_count.reserve(ASSOC_MAX_REGION * sizeof(int)) ||
+      g_ctx.cheb_dends.reserve(2 * nint * l * sizeof(double2)) || g_ctx.cheb_res.reserve(2 * nint * l * sizeof(ChebResult)))
+    return fail(GEMMA_HIP_ENOMEM, "lmm_assoc: Chebyshev tables of the batch (%zu bytes)", nint * l * nb * 16 * 8);
+  HIPCHK(hipMemsetAsync(g_ctx.cheb_count.p, 0, ASSOC_MAX_REGION * sizeof(int), s));
+  a.cheb_T = g_ctx.cheb_T.as<double>();
+  a.cheb_cap = (long)l;
+  ChebScanArgs sc;
+  sc.count = g_ctx.cheb_count.as<int>();
+  sc.list = g_ctx.cheb_list.as<int>();
+  sc.slots = g_ctx.cheb_slots.as<int>();
+  sc.dends = g_ctx.cheb_dends.as<double2>();
+  sc.cap = (long)l;
+  const unsigned sgrid = (unsigned)((l + 3) / 4);
+  const size_t c = g_ctx.cfg.n_cvt;
+  switch (c) {
+  case 1: hipLaunchKernelGGL(cheb_scan_kernel<1>, dim3(sgrid), dim3(256), 0, s, a, sc); break;
+  case 2: hipLaunchKernelGGL(cheb_scan_kernel<2>, dim3(sgrid), dim3(256), 0, s, a, sc); break;
+  case 3: hipLaunchKernelGGL(cheb_scan_kernel<3>, dim3(sgrid), dim3(256), 0, s, a, sc); break;
+  default: hipLaunchKernelGGL(cheb_scan_kernel<4>, dim3(sgrid), dim3(256), 0, s, a, sc); break;
+  }
+  HIPCHK(hipGetLastError());
+  TableGather tg;
+  tg.list = sc.list;
+  tg.count = sc.count;
+  tg.cap = (long)l;
+  tg.rp_stride = (long)gg.nc * (long)nb * 256;
+  const dim3 grid((unsigned)((l + 15) / 16), (unsigned)nint);
+  const double *R = g_ctx.cheb_R.as<double>();
+  double *T = g_ctx.cheb_T.as<double>();
+  const int n = (int)g_ctx.cfg.n;
+  switch (gg.nba) {
+  case 3: hipLaunchKernelGGL((grid_table_kernel<2, 3, true>), grid, dim3(256), 0, s, UtX, (long)ld, (long)l, n, gg.nc, R, T, tg); break;
+  case 5: hipLaunchKernelGGL((grid_table_kernel<2, 5, true>), grid, dim3(256), 0, s, UtX, (long)ld, (long)l, n, gg.nc, R, T, tg); break;
+  case 6: hipLaunchKernelGGL((grid_table_kernel<2, 6, true>), grid, dim3(256), 0, s, UtX, (long)ld, (long)l, n, gg.nc, R, T, tg); break;
+  case 8: hipLaunchKernelGGL((grid_table_kernel<2, 8, true>), grid, dim3(256), 0, s, UtX, (long)ld, (long)l, n, gg.nc, R, T, tg); break;
+  default: return fail(GEMMA_HIP_ERUNTIME, "lmm_assoc: no table kernel for %d column blocks", gg.nba);
+  }
+  HIPCHK(hipGetLastError());
+  ChebSearchArgs sa;
+  sa.count = sc.count;
+  sa.dends = sc.dends;
+  sa.res = g_ctx.cheb_res.as<ChebResult>();
+  memcpy(sa.mid, g_ctx.cheb_mid, sizeof sa.mid);
+  memcpy(sa.inv_half, g_ctx.cheb_inv_half, sizeof sa.inv_half);
+  const dim3 qgrid((unsigned)((l + 63) / 64), (unsigned)nint, 2);
+  switch (c) {
+  case 1: hipLaunchKernelGGL(cheb_search_kernel<1>, qgrid, dim3(64), 0, s, a, sa); break;
+  case 2: hipLaunchKernelGGL(cheb_search_kernel<2>, qgrid, dim3(64), 0, s, a, sa); break;
+  case 3: hipLaunchKernelGGL(cheb_search_kernel<3>, qgrid, dim3(64), 0, s, a, sa); break;
+  default: hipLaunchKernelGGL(cheb_search_kernel<4>, qgrid, dim3(64), 0, s, a, sa); break;
+  }
+  HIPCHK(hipGetLastError());
+  a.cheb_slots = sc.slots;
+  a.cheb_res = sa.res;
   return GEMMA_HIP_OK;
 }
 
@@ -862,6 +999,13 @@ static int launch_assoc(const double *UtX, size_t l, size_t ld, gemma_sumstat *o
       int rc = launch_grid_table(UtX, l, ld, s);
       if (rc) return rc;
       a.grid_T = g_ctx.grid_T.as<double>();
+      a.cheb_T = nullptr;
+      a.cheb_slots = nullptr;
+      a.cheb_res = nullptr;
+      if (a.have_cheb) {
+        rc = launch_cheb_tables(a, UtX, l, ld, s);
+        if (rc) return rc;
+      }
     }
     switch (sel) {
     case 1: {
@@ -1711,6 +1855,9 @@ extern "C" int gemma_hip_lmm_finish(double *time_UtX_min, double *time_opt_min) 
   g_ctx.UtWt.release(); g_ctx.idx_map.release(); g_ctx.X.release(); g_ctx.UtX.release();
   g_ctx.stage_in.release(); g_ctx.stage_out.release();
   g_ctx.grid_R.release(); g_ctx.grid_F.release(); g_ctx.grid_T.release();
+  g_ctx.cheb_R.release(); g_ctx.cheb_F.release(); g_ctx.cheb_T.release(); g_ctx.cheb_slots.release();
+  g_ctx.cheb_list.release(); g_ctx.cheb_count.release(); g_ctx.cheb_D.release(); g_ctx.cheb_Ck.release();
+  g_ctx.cheb_Gk.release(); g_ctx.cheb_dends.release(); g_ctx.cheb_res.release();
   g_ctx.i8_Bt.release(); g_ctx.i8_ej.release(); g_ctx.i8_cmax.release(); g_ctx.i8_A.release(); g_ctx.i8_C.release();
   g_ctx.i8_mean.release();
   g_ctx.i8_ready = false;

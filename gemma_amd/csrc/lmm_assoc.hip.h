@@ -18,6 +18,8 @@
 #include <math.h>
 #include <float.h>
 
+#include "lmm_search.hip.h"
+
 namespace gemma_hip {
 
 struct SumStat {
@@ -25,6 +27,14 @@ struct SumStat {
 };
 
 constexpr int ASSOC_MAX_REGION = 64;
+
+// outcome of one bracket's Brent + Newton polish (polish_bracket of lmm_search.hip.h) computed ahead of the per-SNP kernel
+struct ChebResult {
+  double l;
+  int status; // PB_OK / PB_STOP / PB_FAILED; PB_OUTSIDE or CHEB_NONE: not available, polish with streaming evaluations
+  int pad;
+};
+constexpr int CHEB_NONE = 7;
 
 struct AssocArgs {
   const double *UtX;   // l x ld, SNP-major
@@ -52,6 +62,19 @@ struct AssocArgs {
   int grid_ld, grid_nq, grid_xa0;
   int have_grid;
   double lam_grid[ASSOC_MAX_REGION + 1]; // l_min*exp(i*log(l_max/l_min)/n_region), host libm
+  // Brackets already polished from Chebyshev-in-log(lambda) series (lmm_search.hip.h; cheb_scan_kernel / cheb_search_kernel
+  // of lmm_grid.hip.h) for the grid intervals cheb_j0 .. cheb_j0 + cheb_nint - 1: cheb_slots[snp * cheb_nint + k] = the
+  // SNP's slot in interval k or -1, cheb_res[(func * cheb_nint + k) * cheb_cap + slot] = what polish_bracket returned
+  // (func 0: REML, 1: ML).  Everything else of this block describes the tables to those two kernels.
+  const double *cheb_T;   // [k][col][slot]: series of the x-dependent sums, column-major over the interval's slots
+  const double *cheb_F;   // [k][cheb_fld]: SNP-independent series
+  const int *cheb_slots;
+  const ChebResult *cheb_res;
+  long cheb_cap;
+  int cheb_ld, cheb_fld, cheb_xa0;
+  int cheb_j0, cheb_nint;
+  int have_cheb;
+  double cheb_mid[ASSOC_MAX_REGION], cheb_inv_half[ASSOC_MAX_REGION];
 };
 
 // ------------------------------------------------------------------ wave helpers
@@ -80,15 +103,6 @@ __device__ __forceinline__ double recip(double v) {
   r = fma(e, r, r);
   if (!(fabs(r) <= DBL_MAX)) r = 1.0 / v;
   return r;
-}
-
-// GetabIndex, GEMMA src/param.cpp:1400-1415 (1-based, symmetric)
-template <int C>
-__host__ __device__ constexpr int ab_index(int a, int b) {
-  const int cols = C + 2;
-  const int a1 = (b <= a) ? b : a;
-  const int b1 = (b <= a) ? a : b;
-  return (2 * cols - a1 + 2) * (a1 - 1) / 2 + b1 - a1;
 }
 
 // safe_sqrt, GEMMA src/mathfunc.cpp:122-131 (the reference's `fabs(d < 0.001)` is `d < 0.001`)
@@ -338,6 +352,8 @@ struct Agg {
 template <int C, int UNR = 2, bool WL = false>
 struct FixedC {
   static constexpr bool HAS_GRID = !WL;
+  static constexpr bool HAS_CHEB = !WL;
+  static constexpr int CC = C;
   const double *wlast = nullptr;
   __device__ __forceinline__ int c() const { return C; }
   template <int ORDER>
@@ -429,6 +445,8 @@ __device__ __forceinline__ int ab_index_rt(int a, int b, int c) {
 
 struct GenericC {
   static constexpr bool HAS_GRID = false;
+  static constexpr bool HAS_CHEB = false;
+  static constexpr int CC = 1; // unused
   int cc;
   double *L; // this wave's LDS scratch, GEN_LDS_PER_WAVE doubles
   const double *wlast = nullptr; // non-null: the last covariate is this per-SNP vector (GXE)
@@ -585,6 +603,7 @@ struct SnpCtx {
   M m;
   double logdet_iw; // sum_i log(Iab(i, ww_{i+1})), i < c+1  (H == 1; SNP constant)
   const double *trow; // this SNP's row of the fixed-lambda table, nullptr: stream every evaluation
+  const int *cslots;  // this SNP's slots in the per-interval Chebyshev tables (-1: none), nullptr: no tables
 };
 
 // LogRL_dev1 / LogRL_dev12 (src/lmm.cpp:866-943, :1035-1125) and LogL_dev1 / LogL_dev12
@@ -698,114 +717,21 @@ __device__ __forceinline__ void wald_score(const SnpCtx<M> &s, double l, double 
   wald_score_from<M, SCORE>(s, A, beta, se, pval);
 }
 
-// ------------------------------------------------------------------ root finders
-// GSL roots/brent.c (brent_init / brent_iterate), restated; state lives in registers.
-struct Brent {
-  double a, b, c, d, e, fa, fb, fc;
-  double root, x_lower, x_upper;
+// ------------------------------------------------------------------ root finders: lmm_search.hip.h
+// the evaluator for polish_bracket of this kernel: every evaluation a streaming pass over the SNP's row
+template <class M, bool REML>
+struct StreamEvaluator {
+  const SnpCtx<M> *cx;
+  __device__ __forceinline__ bool dev1(double l, double &d1) {
+    double d2;
+    deriv<M, REML, 2>(*cx, l, d1, d2);
+    return true;
+  }
+  __device__ __forceinline__ bool dev12(double l, double &d1, double &d2) {
+    deriv<M, REML, 3>(*cx, l, d1, d2);
+    return true;
+  }
 };
-enum { RS_SUCCESS = 0, RS_CONTINUE = -2, RS_EINVAL = 4, RS_EBADFUNC = 9, RS_EZERODIV = 12 };
-
-template <class M, bool REML>
-__device__ __forceinline__ double dev1_of(const SnpCtx<M> &s, double l) {
-  double d1, d2;
-  deriv<M, REML, 2>(s, l, d1, d2);
-  return d1;
-}
-
-__device__ __forceinline__ bool finite_d(double v) { return fabs(v) <= DBL_MAX; }
-
-__device__ __forceinline__ int brent_set(Brent &s, double x_lower, double x_upper, double f_lower, double f_upper) {
-  // f_lower/f_upper: the reference re-evaluates dev1 at both ends (gsl_root_fsolver_set ->
-  // brent_init); the function is pure, so the grid-scan values are the same numbers.
-  if (x_lower > x_upper) return RS_EINVAL;
-  s.root = 0.5 * (x_lower + x_upper);
-  s.x_lower = x_lower;
-  s.x_upper = x_upper;
-  if (!finite_d(f_lower)) return RS_EBADFUNC;
-  if (!finite_d(f_upper)) return RS_EBADFUNC;
-  s.a = x_lower; s.fa = f_lower;
-  s.b = x_upper; s.fb = f_upper;
-  s.c = x_upper; s.fc = f_upper;
-  s.d = x_upper - x_lower;
-  s.e = x_upper - x_lower;
-  if ((f_lower < 0.0 && f_upper < 0.0) || (f_lower > 0.0 && f_upper > 0.0)) return RS_EINVAL;
-  return RS_SUCCESS;
-}
-
-template <class M, bool REML>
-__device__ __forceinline__ int brent_iterate(Brent &s, const SnpCtx<M> &cx) {
-  double tol, m;
-  bool ac_equal = false;
-  double a = s.a, b = s.b, c = s.c, fa = s.fa, fb = s.fb, fc = s.fc, d = s.d, e = s.e;
-  if ((fb < 0 && fc < 0) || (fb > 0 && fc > 0)) {
-    ac_equal = true;
-    c = a; fc = fa; d = b - a; e = b - a;
-  }
-  if (fabs(fc) < fabs(fb)) {
-    ac_equal = true;
-    a = b; b = c; c = a;
-    fa = fb; fb = fc; fc = fa;
-  }
-  tol = 0.5 * DBL_EPSILON * fabs(b);
-  m = 0.5 * (c - b);
-  if (fb == 0) {
-    s.root = b; s.x_lower = b; s.x_upper = b;
-    return RS_SUCCESS;
-  }
-  if (fabs(m) <= tol) {
-    s.root = b;
-    if (b < c) { s.x_lower = b; s.x_upper = c; } else { s.x_lower = c; s.x_upper = b; }
-    return RS_SUCCESS;
-  }
-  if (fabs(e) < tol || fabs(fa) <= fabs(fb)) {
-    d = m; e = m;
-  } else {
-    double p, q, r;
-    const double sv = fb / fa;
-    if (ac_equal) {
-      p = 2 * m * sv;
-      q = 1 - sv;
-    } else {
-      q = fa / fc;
-      r = fb / fc;
-      p = sv * (2 * m * q * (q - r) - (b - a) * (r - 1));
-      q = (q - 1) * (r - 1) * (sv - 1);
-    }
-    if (p > 0) q = -q; else p = -p;
-    const double lim1 = 3 * m * q - fabs(tol * q), lim2 = fabs(e * q);
-    if (2 * p < (lim1 < lim2 ? lim1 : lim2)) {
-      e = d; d = p / q;
-    } else {
-      d = m; e = m;
-    }
-  }
-  a = b; fa = fb;
-  if (fabs(d) > tol) b += d; else b += (m > 0 ? +tol : -tol);
-  fb = dev1_of<M, REML>(cx, b);
-  if (!finite_d(fb)) return RS_EBADFUNC;
-  s.a = a; s.b = b; s.c = c; s.d = d; s.e = e; s.fa = fa; s.fb = fb; s.fc = fc;
-  s.root = b;
-  if ((fb < 0 && fc < 0) || (fb > 0 && fc > 0)) c = a;
-  if (b < c) { s.x_lower = b; s.x_upper = c; } else { s.x_lower = c; s.x_upper = b; }
-  return RS_SUCCESS;
-}
-
-// gsl_root_test_interval(lo, hi, 0, 1e-1) and gsl_root_test_delta(x1, x0, 0, 1e-5) (GSL
-// roots/convergence.c) as used at src/lmm.cpp:2050,2073
-__device__ __forceinline__ int test_interval_dev(double lo, double hi, double epsrel) {
-  if (lo > hi) return RS_EINVAL;
-  double min_abs;
-  if ((lo > 0.0 && hi > 0.0) || (lo < 0.0 && hi < 0.0))
-    min_abs = fmin(fabs(lo), fabs(hi));
-  else
-    min_abs = 0;
-  return (fabs(hi - lo) < epsrel * min_abs) ? RS_SUCCESS : RS_CONTINUE;
-}
-__device__ __forceinline__ int test_delta_dev(double x1, double x0, double epsrel) {
-  return (fabs(x1 - x0) < epsrel * fabs(x1) || x1 == x0) ? RS_SUCCESS : RS_CONTINUE;
-}
-
 // CalcLambda, src/lmm.cpp:1945-2140.  Brackets are processed as soon as the grid scan finds
 // them (the evaluations are pure, so interleaving scan and polish gives the reference's
 // sequence of results); `return NaN` and `break` semantics of :2057-2060,:2087-2094 are kept.
@@ -824,59 +750,40 @@ __device__ __forceinline__ void calc_lambda(const SnpCtx<M> &cx, double &lambda,
     const bool bracket = (d_lo * d_hi <= 0);
     if (bracket) any = true;
     if (bracket && !stop && !failed) {
-      Brent bs;
-      bs.a = bs.b = bs.c = bs.d = bs.e = bs.fa = bs.fb = bs.fc = 0.0;
-      bs.root = bs.x_lower = bs.x_upper = 0.0;
-      (void)brent_set(bs, lambda_l0, lambda_h0, d_lo, d_hi);
-      int status;
-      int iter = 0;
-      double lambda_l, lambda_h;
-      do {
-        iter++;
-        status = brent_iterate<M, REML>(bs, cx);
-        if (status != RS_SUCCESS && status != RS_CONTINUE) break;
-        l = bs.root;
-        lambda_l = bs.x_lower;
-        lambda_h = bs.x_upper;
-        status = test_interval_dev(lambda_l, lambda_h, 1e-1);
-        if (status != RS_SUCCESS && status != RS_CONTINUE) break;
-      } while (status == RS_CONTINUE && iter < 100);
-      if (status == RS_CONTINUE) {
-        stop = true; // :2057-2060 leaves the bracket loop
-      } else {
-        // Newton, GSL roots/newton.c: set() evaluates (f, df) at the start
-        int iter2 = 0;
-        double root = l, nf, ndf;
-        deriv<M, REML, 3>(cx, root, nf, ndf);
-        do {
-          iter2++;
-          if (ndf == 0.0) {
-            status = RS_EZERODIV;
-          } else {
-            const double root_new = root - (nf / ndf);
-            root = root_new;
-            deriv<M, REML, 3>(cx, root_new, nf, ndf);
-            status = (!finite_d(nf) || !finite_d(ndf)) ? RS_EBADFUNC : RS_SUCCESS;
+      int pb = PB_OUTSIDE;
+      if constexpr (M::HAS_CHEB) {
+        const int k = i - g.cheb_j0;
+        if (cx.cslots && k >= 0 && k < g.cheb_nint) {
+          const int slot = __builtin_amdgcn_readfirstlane(cx.cslots[k]);
+          if (slot >= 0) {
+            // this bracket was polished from the SNP's series of the interval (cheb_search_kernel); anything but a
+            // clean verdict there (an iterate left the interval, a non-finite value) is redone below, streaming
+            const ChebResult r = g.cheb_res[((long)(REML ? 0 : 1) * g.cheb_nint + k) * g.cheb_cap + slot];
+            const int st = __builtin_amdgcn_readfirstlane(r.status);
+            if (st == PB_OK || st == PB_STOP || st == PB_FAILED) {
+              pb = st;
+              if (st == PB_OK) l = uniform(r.l);
+            }
           }
-          if (status != RS_SUCCESS && status != RS_CONTINUE) break;
-          l_temp = l;
-          l = root;
-          status = test_delta_dev(l, l_temp, 1e-5);
-        } while (status == RS_CONTINUE && iter2 < 100 && l > l_min && l < l_max);
-        if (status != RS_SUCCESS) {
-          failed = true; // :2087-2094: lambda = logf = NaN, return
-        } else {
-          l = l_temp; // :2096 -- the previous Newton iterate is reported
-          if (l < l_min) l = l_min;
-          if (l > l_max) l = l_max;
-          const double logf_l = logf<M, REML>(cx, l, cand);
-          if (first) {
-            lf = logf_l; lam = l; best = cand;
-          } else if (lf < logf_l) {
-            lf = logf_l; lam = l; best = cand;
-          }
-          first = false;
         }
+      }
+      if (pb == PB_OUTSIDE) {
+        StreamEvaluator<M, REML> ev;
+        ev.cx = &cx;
+        pb = polish_bracket(ev, lambda_l0, lambda_h0, d_lo, d_hi, l_min, l_max, l, l_temp);
+      }
+      if (pb == PB_STOP) {
+        stop = true; // :2057-2060 leaves the bracket loop
+      } else if (pb == PB_FAILED) {
+        failed = true; // :2087-2094: lambda = logf = NaN, return
+      } else {
+        const double logf_l = logf<M, REML>(cx, l, cand);
+        if (first) {
+          lf = logf_l; lam = l; best = cand;
+        } else if (lf < logf_l) {
+          lf = logf_l; lam = l; best = cand;
+        }
+        first = false;
       }
     }
     d_lo = d_hi;
@@ -926,6 +833,7 @@ __device__ __forceinline__ void assoc_one_snp(const AssocArgs &g, const M &model
   cx.m = model;
   cx.logdet_iw = 0.0;
   cx.trow = (g.have_grid && g.grid_T) ? g.grid_T + snp * g.grid_ld : nullptr;
+  cx.cslots = (cx.trow && g.have_cheb && g.cheb_slots) ? g.cheb_slots + snp * g.cheb_nint : nullptr;
   const int a_mode = g.a_mode;
 
   double lambda_mle = 0.0, lambda_remle = 0.0, beta = 0.0, se = 0.0, p_wald = 0.0;
@@ -1024,6 +932,7 @@ __device__ __forceinline__ void gene_one_row(const AssocArgs &g, const M &model,
     cn.m = null_model;
     cn.logdet_iw = 0.0;
     cn.trow = nullptr;
+    cn.cslots = nullptr;
     Agg tmp;
     calc_lambda<MN, false>(cn, l_H0, logl_H0, tmp);
   }
@@ -1035,6 +944,7 @@ __device__ __forceinline__ void gene_one_row(const AssocArgs &g, const M &model,
   cx.m = model;
   cx.logdet_iw = 0.0;
   cx.trow = nullptr;
+  cx.cslots = nullptr;
   if (a_mode == 3 || a_mode == 4 || a_mode == 9) wald_score<M, true>(cx, l_H0, beta, se, p_score);
   if (a_mode == 1 || a_mode == 4) {
     cx.logdet_iw = logdet_iw_of(cx);
@@ -1106,6 +1016,7 @@ __device__ __forceinline__ void gxe_one_snp(const AssocArgs &g, M model, const M
     cn.m = null_model;
     cn.logdet_iw = 0.0;
     cn.trow = nullptr;
+    cn.cslots = nullptr;
     Agg tmp;
     calc_lambda<MN, false>(cn, lambda_mle, logl_H0, tmp);
   }
@@ -1118,6 +1029,7 @@ __device__ __forceinline__ void gxe_one_snp(const AssocArgs &g, M model, const M
   cx.m = model;
   cx.logdet_iw = 0.0;
   cx.trow = nullptr;
+  cx.cslots = nullptr;
   if (a_mode == 3 || a_mode == 4 || a_mode == 9) wald_score<M, true>(cx, g.l_mle_null, beta, se, p_score);
   if (a_mode == 1 || a_mode == 4) {
     cx.logdet_iw = logdet_iw_of(cx);
@@ -1203,6 +1115,7 @@ __device__ __forceinline__ void null_model(const AssocArgs &g, const M &model, i
   cx.lane = lane;
   cx.m = model;
   cx.trow = nullptr;
+  cx.cslots = nullptr;
   cx.logdet_iw = logdet_iw_of(cx);
   NullOut o;
   Agg tmp;

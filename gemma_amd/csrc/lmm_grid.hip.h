@@ -102,10 +102,20 @@ __global__ __launch_bounds__(256) void grid_fixed_kernel(AssocArgs g, int c, dou
 // One block = 16 SNP rows; its 4 waves split K; v_mfma_f64_16x16x4_f64 with the A operand read straight from
 // the UtX rows (lane (i, kq) takes x[s0 + i][16 chunk + 4 kq .. + 3]: a full 128-byte line per row per chunk;
 // the k order inside a chunk is permuted identically on both operands).
-template <int NBX, int NBA>
+// GATHER (the Chebyshev tables of the bracket intervals): blockIdx.y = interval k; the rows are the SNPs listed in
+// list[k * cap ..] (count[k] of them, written by cheb_scan_kernel), the weights Rp + k * rp_stride, and the series of
+// `slot` is column `slot` of the interval's plane: T[(k * NB * 16 + col) * cap + slot].  A SNP's sums depend on its own row only (fixed k order), so its series
+// is the same bits whichever slot and whichever neighbours it gets.
+struct TableGather {
+  const int *list;
+  const int *count;
+  long cap;
+  long rp_stride;
+};
+template <int NBX, int NBA, bool GATHER>
 __global__ __launch_bounds__(256) void grid_table_kernel(const double *__restrict__ UtX, long ld, long l, int n,
                                                         int nc, const double *__restrict__ Rp,
-                                                        double *__restrict__ T) {
+                                                        double *__restrict__ T, TableGather tg) {
   constexpr int NB = NBX + NBA;
   __shared__ double red[3][NB][256];
   const int t = threadIdx.x, lane = t & 63;
@@ -113,7 +123,17 @@ __global__ __launch_bounds__(256) void grid_table_kernel(const double *__restric
   const int i = lane & 15, kq = lane >> 4;
   const long s0 = (long)blockIdx.x * 16;
   long row = s0 + i;
-  if (row >= l) row = l - 1;
+  if (GATHER) {
+    const int kint = blockIdx.y;
+    l = tg.count[kint];
+    if (s0 >= l) return;
+    if (row >= l) row = l - 1;
+    row = tg.list[(long)kint * tg.cap + row];
+    Rp += (long)kint * tg.rp_stride;
+    T += (long)kint * tg.cap * (NB * 16); // this interval's [col][slot] plane
+  } else {
+    if (row >= l) row = l - 1;
+  }
   const double *xr = UtX + row * ld + 4 * kq;
   const int c0 = (int)((long)nc * wave / 4), c1 = (int)((long)nc * (wave + 1) / 4);
   f64x4 acc[NB];
@@ -162,8 +182,221 @@ __global__ __launch_bounds__(256) void grid_table_kernel(const double *__restric
       for (int r = 0; r < 4; ++r) {
         const double v = ((acc[b][r] + red[0][b][r * 64 + lane]) + red[1][b][r * 64 + lane]) + red[2][b][r * 64 + lane];
         const long srow = s0 + kq + 4 * r;
-        if (srow < l) T[srow * (NB * 16) + b * 16 + i] = v;
+        if (srow < l) {
+          if (GATHER)
+            T[(long)(b * 16 + i) * tg.cap + srow] = v; // column-major over the slots: cheb_search_kernel reads coalesced
+          else
+            T[srow * (NB * 16) + b * 16 + i] = v;
+        }
       }
+  }
+}
+
+// ------------------------------------------------------------------ Chebyshev tables of the bracket intervals
+// (lmm_search.hip.h).  Per lmm_setup and interval: c_k(delta_i), the series coefficients of t -> H_i(t) and of
+// t -> 1 - H_i(t) (cheb_coeff_kernel), from them the weight matrix of the table product in MFMA operand order
+// (cheb_weights_kernel; columns: [k] for x^2, [a * CHEB_N + k] for x u_a) and the SNP-independent series
+// (cheb_fixed_kernel).  Per batch: cheb_scan_kernel finds every SNP's bracket intervals from the fixed-lambda table and
+// hands out slots, grid_table_kernel<.., GATHER> computes the series of exactly those (SNP, interval) pairs.
+constexpr double CHEB_MARGIN = 0.15; // of the interval's length, either side
+constexpr double CHEB_MIN_LAMBDA = 1e-3; // intervals below keep streaming: dS/dt is O(lambda) of S there, and a series
+                                         // good to 1e-15 of S carries 1e-13/lambda of relative error in it
+
+struct ChebNodes {
+  double lam[CHEB_N]; // exp(node m)
+};
+
+__global__ void cheb_coeff_kernel(const double *__restrict__ eval, int n, ChebNodes nd, const double *__restrict__ Dfit,
+                                  double *__restrict__ Ck, double *__restrict__ Gk) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double d = eval[i];
+  double hm[CHEB_N], gm[CHEB_N];
+#pragma unroll
+  for (int m = 0; m < CHEB_N; ++m) {
+    const double ld = nd.lam[m] * d;
+    hm[m] = 1.0 / (ld + 1.0);
+    gm[m] = ld / (ld + 1.0);
+  }
+  for (int k = 0; k < CHEB_N; ++k) {
+    double sh = 0.0, sg = 0.0;
+#pragma unroll
+    for (int m = 0; m < CHEB_N; ++m) {
+      const double w = Dfit[k * CHEB_N + m];
+      sh += hm[m] * w;
+      sg += gm[m] * w;
+    }
+    Ck[(long)i * CHEB_N + k] = sh;
+    Gk[(long)i * CHEB_N + k] = sg;
+  }
+}
+
+// weight matrix of one interval in the B-operand order of grid_table_kernel (see grid_weights_kernel)
+__global__ void cheb_weights_kernel(AssocArgs g, GridGeom gg, int c, const double *__restrict__ Ck,
+                                    double *__restrict__ Rp) {
+  const long total = (long)gg.nc * (gg.nbx + gg.nba) * 256;
+  const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= total) return;
+  const int j = (int)(e & 3), col = (int)((e >> 2) & 15), kq = (int)((e >> 6) & 3);
+  const long r = e >> 8;
+  const int nb = gg.nbx + gg.nba;
+  const int cb = (int)(r % nb);
+  const long chunk = r / nb;
+  const long k = chunk * 16 + 4 * kq + j;
+  double v = 0.0;
+  if (k < g.n) {
+    if (cb < gg.nbx) {
+      const int q = cb * 16 + col;
+      if (q < CHEB_N) v = Ck[k * CHEB_N + q];
+    } else {
+      const int idx = (cb - gg.nbx) * 16 + col;
+      const int a = idx / CHEB_N, q = idx - a * CHEB_N;
+      if (a <= c) {
+        const double u = (a < c) ? g.UtWt[(long)a * g.n + k] : g.Uty[k];
+        v = u * Ck[k * CHEB_N + q];
+      }
+    }
+  }
+  Rp[e] = v;
+}
+
+// SNP-independent series of one interval, one block per function: block b < npairs: the pair (a <= bb) among
+// (w_1..w_c, y) in row-major upper-triangle order, a_k = sum_i u_a u_bb c_k(delta_i); block npairs: g, a_k = sum_i Gk[i][k]
+__global__ __launch_bounds__(256) void cheb_fixed_kernel(AssocArgs g, int c, const double *__restrict__ Ck,
+                                                        const double *__restrict__ Gk, double *__restrict__ F) {
+  const int nv = c + 1, npairs = nv * (nv + 1) / 2;
+  const int b = blockIdx.x;
+  int pa = 0, pb = 0;
+  if (b < npairs) {
+    int p = 0;
+    for (int a = 0; a < nv; ++a)
+      for (int bb = a; bb < nv; ++bb, ++p)
+        if (p == b) { pa = a; pb = bb; }
+  }
+  double s[CHEB_N];
+#pragma unroll
+  for (int k = 0; k < CHEB_N; ++k) s[k] = 0.0;
+  for (long i = threadIdx.x; i < g.n; i += 256) {
+    double w = 1.0;
+    const double *src = Gk;
+    if (b < npairs) {
+      const double ua = (pa < c) ? g.UtWt[(long)pa * g.n + i] : g.Uty[i];
+      const double ub = (pb < c) ? g.UtWt[(long)pb * g.n + i] : g.Uty[i];
+      w = ua * ub;
+      src = Ck;
+    }
+#pragma unroll
+    for (int k = 0; k < CHEB_N; ++k) s[k] += w * src[i * CHEB_N + k];
+  }
+  __shared__ double red[4][CHEB_N];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < CHEB_N; ++k) {
+    const double v = wave_sum(s[k]);
+    if (lane == 0) red[wave][k] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < CHEB_N)
+    F[(long)b * CHEB_N + threadIdx.x] =
+        ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
+}
+
+// Which grid intervals bracket a sign change of dev1 for this SNP (REML and / or ML search, as a_mode asks): the
+// same dev1_grid values calc_lambda computes from the fixed-lambda table.  Every (SNP, tabulated interval) pair with a
+// bracket gets a slot of that interval's table (slots[snp * nint + k], -1 = none) and the bracket's end values
+// dends[(func * nint + k) * cap + slot] = {dev1(lambda_lo), dev1(lambda_hi)} (NaN = func has no bracket there).
+struct ChebScanArgs {
+  int *count;     // nint, zeroed before the launch
+  int *list;      // nint x cap
+  int *slots;     // l x nint
+  double2 *dends; // 2 x nint x cap
+  long cap;
+};
+template <int C, bool REML>
+__device__ __forceinline__ void cheb_scan_func(const AssocArgs &g, const SnpCtx<FixedC<C>> &cx, const ChebScanArgs &sc,
+                                               long snp, int lane) {
+  const int func = REML ? 0 : 1;
+  double d_lo = dev1_grid<FixedC<C>, REML>(cx, 0);
+  for (int i = 0; i < g.n_region; ++i) {
+    const double d_hi = dev1_grid<FixedC<C>, REML>(cx, i + 1);
+    const int k = i - g.cheb_j0;
+    if (d_lo * d_hi <= 0 && k >= 0 && k < g.cheb_nint && lane == 0) {
+      int slot = sc.slots[snp * g.cheb_nint + k]; // this thread's own earlier write, if any
+      if (slot < 0) {
+        slot = atomicAdd(&sc.count[k], 1);
+        sc.list[(long)k * sc.cap + slot] = (int)snp;
+        sc.slots[snp * g.cheb_nint + k] = slot;
+        sc.dends[((long)(1 - func) * g.cheb_nint + k) * sc.cap + slot] = make_double2(NAN, NAN);
+      }
+      sc.dends[((long)func * g.cheb_nint + k) * sc.cap + slot] = make_double2(d_lo, d_hi);
+    }
+    d_lo = d_hi;
+  }
+}
+template <int C>
+__global__ __launch_bounds__(256) void cheb_scan_kernel(AssocArgs g, ChebScanArgs sc) {
+  const int lane = threadIdx.x & 63;
+  const long snp = (long)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  if (snp >= g.l) return;
+  SnpCtx<FixedC<C>> cx;
+  cx.g = &g;
+  cx.x = g.UtX + snp * g.ld;
+  cx.y = g.Uty;
+  cx.lane = lane;
+  cx.m = FixedC<C>();
+  cx.logdet_iw = 0.0;
+  cx.trow = g.grid_T + snp * g.grid_ld;
+  cx.cslots = nullptr;
+  if (lane == 0)
+    for (int k = 0; k < g.cheb_nint; ++k) sc.slots[snp * g.cheb_nint + k] = -1;
+  if (g.a_mode == 1 || g.a_mode == 4) cheb_scan_func<C, true>(g, cx, sc, snp, lane);
+  if (g.a_mode == 2 || g.a_mode == 4 || g.a_mode == 9) cheb_scan_func<C, false>(g, cx, sc, snp, lane);
+}
+
+// One THREAD per (slot, interval, func): Brent + Newton of that bracket on the SNP's series (polish_bracket over
+// ChebEvaluator, lmm_search.hip.h -- the code tests/cpp/cheb_search_check.cpp runs on the CPU).  The series are read
+// column-major over the slots (coalesced across the wave), the SNP-independent series are the same addresses for every
+// thread.  grid = (ceil(cap / 64), nint, 2).
+struct ChebSearchArgs {
+  const int *count;
+  const double2 *dends;
+  ChebResult *res;
+  double mid[ASSOC_MAX_REGION], inv_half[ASSOC_MAX_REGION];
+};
+template <int C, bool REML>
+__device__ __forceinline__ void cheb_search_one(const AssocArgs &g, const ChebSearchArgs &sa, int k, long slot) {
+  const int func = REML ? 0 : 1;
+  const long e = ((long)func * g.cheb_nint + k) * g.cheb_cap + slot;
+  const double2 d = sa.dends[e];
+  ChebResult r;
+  r.l = 0.0;
+  r.status = CHEB_NONE;
+  r.pad = 0;
+  if (!(d.x != d.x)) { // this function has a bracket in the interval
+    ChebEvaluator<C, REML> ev;
+    ev.cs.snp = g.cheb_T + (long)k * g.cheb_cap * g.cheb_ld + slot;
+    ev.cs.sstride = g.cheb_cap;
+    ev.cs.fix = g.cheb_F + (long)k * g.cheb_fld;
+    ev.cs.xa0 = g.cheb_xa0;
+    ev.cs.mid = sa.mid[k];
+    ev.cs.inv_half = sa.inv_half[k];
+    ev.cs.n = (double)g.n;
+    double l = 0.0, l_temp = 0.0;
+    const int j = g.cheb_j0 + k;
+    r.status = polish_bracket(ev, g.lam_grid[j], g.lam_grid[j + 1], d.x, d.y, g.l_min, g.l_max, l, l_temp);
+    r.l = l;
+  }
+  sa.res[e] = r;
+}
+template <int C>
+__global__ __launch_bounds__(64) void cheb_search_kernel(AssocArgs g, ChebSearchArgs sa) {
+  const int k = blockIdx.y;
+  const long slot = (long)blockIdx.x * 64 + threadIdx.x;
+  if (slot >= sa.count[k]) return;
+  if (blockIdx.z == 0) {
+    if (g.a_mode == 1 || g.a_mode == 4) cheb_search_one<C, true>(g, sa, k, slot);
+  } else {
+    if (g.a_mode == 2 || g.a_mode == 4 || g.a_mode == 9) cheb_search_one<C, false>(g, sa, k, slot);
   }
 }
 

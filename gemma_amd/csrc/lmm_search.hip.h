@@ -216,7 +216,7 @@ GH_HD void cheb_fit(const double *fm, double *out) {
 
 // p(s) = sum_k a_k T_k(s) with its first two derivatives in s (Clenshaw and its derivatives); stride between terms
 template <int ORDER>
-GH_HD void cheb_eval(const double *__restrict__ a, int stride, double s, double &p0, double &p1, double &p2) {
+GH_HD void cheb_eval(const double *__restrict__ a, long stride, double s, double &p0, double &p1, double &p2) {
   double b1 = 0.0, b2 = 0.0, d1 = 0.0, d2 = 0.0, e1 = 0.0, e2 = 0.0;
   const double s2 = 2.0 * s;
 #pragma unroll
@@ -244,13 +244,16 @@ GH_HD constexpr int ab_index(int a, int b) {
 }
 
 // What one SNP's table-driven evaluations read.  Layouts (written by lmm_grid.hip.h / the host harness):
-//   snp : this SNP's row of the interval's table product: [k] = series of sum x^2 H (k < CHEB_N),
-//         [xa0 + a * CHEB_N + k] = series of sum x u_a H  (a < C: U^T W column a, a = C: U^T y)
+//   snp : this SNP's series from the interval's table product, element (col) at snp[col * sstride]:
+//         col k = series of sum x^2 H (k < CHEB_N), col xa0 + a * CHEB_N + k = series of sum x u_a H
+//         (a < C: U^T W column a, a = C: U^T y).  On the device the table is stored column-major over the
+//         interval's slots (sstride = slots per interval) so that one thread per SNP reads coalesced.
 //   fix : the interval's SNP-independent series, [pair * CHEB_N + k] for the pairs (a <= b) among (w_1..w_C, y) in
 //         row-major upper-triangle order, then [npairs * CHEB_N + k] = series of g(t) = sum_i (1 - H_i)
 template <int C>
 struct ChebSnp {
   const double *snp;
+  long sstride;
   const double *fix;
   int xa0;
   double mid, inv_half; // t -> s = (t - mid) * inv_half
@@ -276,16 +279,14 @@ GH_HD bool cheb_deriv(const ChebSnp<C> &cs, double l, double &dev1, double &dev2
       // variables 1..C: covariates (fixed index a - 1), C + 1: x, C + 2: y (fixed index C)
       const bool ax = (a == C + 1), bx = (b == C + 1);
       const int fa = (a == C + 2) ? C : a - 1, fb = (b == C + 2) ? C : b - 1;
-      const double *src;
-      if (ax && bx) {
-        src = cs.snp;
-      } else if (ax || bx) {
-        src = cs.snp + cs.xa0 + (ax ? fb : fa) * CHEB_N;
-      } else {
-        src = cs.fix + (fa * (C + 1) - fa * (fa - 1) / 2 + (fb - fa)) * CHEB_N;
-      }
       double v0, v1, v2;
-      cheb_eval<ORDER>(src, 1, s, v0, v1, v2);
+      if (ax && bx) {
+        cheb_eval<ORDER>(cs.snp, cs.sstride, s, v0, v1, v2);
+      } else if (ax || bx) {
+        cheb_eval<ORDER>(cs.snp + (long)(cs.xa0 + (ax ? fb : fa) * CHEB_N) * cs.sstride, cs.sstride, s, v0, v1, v2);
+      } else {
+        cheb_eval<ORDER>(cs.fix + (fa * (C + 1) - fa * (fa - 1) / 2 + (fb - fa)) * CHEB_N, 1, s, v0, v1, v2);
+      }
       p0[q] = v0;
       p1[q] = v1 * k1;
       p2[q] = v2 * k2;
@@ -303,9 +304,7 @@ GH_HD bool cheb_deriv(const ChebSnp<C> &cs, double l, double &dev1, double &dev2
     sr += r;
     if (ORDER >= 2) sq += r + r * r - W2 / W0;
     if (W0 != 0) {
-      double n0[NI], n1[NI], n2[NI];
-#pragma unroll
-      for (int q = 0; q < NI; ++q) { n0[q] = p0[q]; n1[q] = p1[q]; n2[q] = p2[q]; }
+      // in place: entries (a, b > p) read only entries with index p of this level, which this level does not write
 #pragma unroll
       for (int a = p + 1; a <= NV; ++a) {
 #pragma unroll
@@ -315,16 +314,14 @@ GH_HD bool cheb_deriv(const ChebSnp<C> &cs, double l, double &dev1, double &dev2
           const double m0 = A0 * B0, m1 = A1 * B0 + A0 * B1;
           const double u0 = m0 / W0;
           const double u1 = (m1 - u0 * W1) / W0;
-          n0[iab] = p0[iab] - u0;
-          n1[iab] = p1[iab] - u1;
           if (ORDER >= 2) {
             const double m2 = p2[iaw] * B0 + 2.0 * A1 * B1 + A0 * p2[ibw];
-            n2[iab] = p2[iab] - (m2 - 2.0 * u1 * W1 - u0 * W2) / W0;
+            p2[iab] -= (m2 - 2.0 * u1 * W1 - u0 * W2) / W0;
           }
+          p0[iab] -= u0;
+          p1[iab] -= u1;
         }
       }
-#pragma unroll
-      for (int q = 0; q < NI; ++q) { p0[q] = n0[q]; p1[q] = n1[q]; p2[q] = n2[q]; }
     }
   }
   constexpr int iyy = ab_index<C>(C + 2, C + 2);
@@ -350,15 +347,19 @@ GH_HD bool cheb_deriv(const ChebSnp<C> &cs, double l, double &dev1, double &dev2
   return true;
 }
 
-// the evaluator polish_bracket takes, over one SNP's series on one interval
+// The evaluator polish_bracket takes, over one SNP's series on one interval.  A non-finite value counts as "cannot
+// evaluate": the reference's handling of those (GSL_EBADFUNC, which can leave CalcLambda's `l` at the previous bracket's
+// value, src/lmm.cpp:2040-2047) is reproduced by the streaming evaluator, which then repeats the bracket.
 template <int C, bool REML>
 struct ChebEvaluator {
   ChebSnp<C> cs;
   GH_HD bool dev1(double l, double &d1) {
     double d2;
-    return cheb_deriv<C, REML, 1>(cs, l, d1, d2);
+    return cheb_deriv<C, REML, 1>(cs, l, d1, d2) && finite_d(d1);
   }
-  GH_HD bool dev12(double l, double &d1, double &d2) { return cheb_deriv<C, REML, 2>(cs, l, d1, d2); }
+  GH_HD bool dev12(double l, double &d1, double &d2) {
+    return cheb_deriv<C, REML, 2>(cs, l, d1, d2) && finite_d(d1) && finite_d(d2);
+  }
 };
 
 } // namespace gemma_hip

@@ -24,6 +24,7 @@ static void run(const double *in, size_t L, double n, double *out) {
     const double *c = in + s * stride;
     ChebEvaluator<C, REML> ev;
     ev.cs.snp = c + 9;
+    ev.cs.sstride = 1;
     ev.cs.fix = c + 9 + nsnp;
     ev.cs.xa0 = CHEB_N;
     ev.cs.mid = c[6];
