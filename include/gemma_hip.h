@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define GEMMA_HIP_ABI_VERSION 1
+#define GEMMA_HIP_ABI_VERSION 2
 
 enum {
   GEMMA_HIP_OK = 0,
@@ -238,6 +238,50 @@ int gemma_hip_lm_setup(int a_mode, size_t n, size_t n_cvt, const double *W, cons
 int gemma_hip_lm_batch(int geno_kind, const void *geno, size_t l, size_t ld, gemma_sumstat *out);
 int gemma_hip_lm_batch_d(int geno_kind, const void *geno_d, size_t l, size_t ld, gemma_sumstat *out_d, void *stream);
 int gemma_hip_lm_finish(void);
+
+/* ---- the device-resident chain behind the host-pointer API ------------------------------ */
+/* In a file-driven run K, the analysed block G and U cross PCIe five times (K out of kin_end, G into eigh, U out, U in
+ * for CalcUtX, U in for lmm_setup: 8 n^2 bytes each).  These entry points keep them where they are produced.  One kept K
+ * and one kept (U, eval) per process; lmm_finish does not release them, gemma_hip_kept_release does.
+ *   kin_begin / kin_add ... -> kin_end_keep            K (ni_total^2) stays on the device; with a communicator of more than one
+ *                                                       rank and allreduce != 0 the ranks' partial sums over THEIR SNPs are
+ *                                                       all-reduced first (SNP-sharded kinship) and ns_used is the total
+ *   kept_K_get                                          copy of the kept K for <o>.cXX.txt (PARAM::WriteMatrix)
+ *   eigh_kept_K(indicator_idv)                          rows / columns of the analysed individuals (what ReadFile_kin keeps,
+ *                                                       src/gemma_io.cpp:1205-1243), CenterMatrix, EigenDecomp_Zeroed -- all on the
+ *                                                       device; U and eval stay there, eval and trace_G also come back
+ *   eigh_keep(G)                                        the same from a host G (the -k file route): G is centred by the caller
+ *   kept_bcast(root)                                    ONE ncclBroadcast of (U, eval) to every rank of the communicator
+ *   calc_utx_kept / lmm_setup_kept                      CalcUtX and lmm_setup on the kept U
+ *   kept_U_get                                          copy of U / eval for the -eigen artefacts */
+int gemma_hip_kin_end_keep(size_t *ns_used, int allreduce);
+int gemma_hip_kept_K_get(double *K /* ni_total^2 */);
+int gemma_hip_eigh_kept_K(const int *indicator_idv /* NULL: all */, size_t ni_total, double *eval /* n_test, may be NULL */,
+                          double *trace_G);
+int gemma_hip_eigh_keep(const double *G /* n^2, already centred; not modified */, size_t n, double *eval /* may be NULL */,
+                        double *trace_G);
+int gemma_hip_kept_n(size_t *n /* order of the kept U, 0 = none */);
+int gemma_hip_kept_bcast(int root);
+int gemma_hip_kept_U_get(double *U /* n^2, may be NULL */, double *eval /* n, may be NULL */);
+int gemma_hip_calc_utx_kept(const double *X, size_t n, size_t m, double *UtX);
+int gemma_hip_lmm_setup_kept(const gemma_lmm_cfg *cfg, const double *UtW, const double *Uty);
+int gemma_hip_kept_release(void);
+
+/* ---- multi-GPU: RCCL over xGMI, one process per GPU ------------------------------------------ */
+/* SNPs are independent (src/lmm.cpp:1513-1514); the shared state is read-only.  Two collectives exist on the path: ONE
+ * broadcast of (U, eval) from the rank that ran the eigensolver, and -- for a SNP-sharded kinship -- ONE all-reduce of the
+ * n^2 partial sums.  Both are issued directly on RCCL (ncclBroadcast / ncclAllReduce, librccl bound with dlopen when a
+ * communicator of more than one rank is created).  Bootstrap: rank 0 calls comm_unique_id (ncclGetUniqueId), the host
+ * program ships the 128 bytes to the other ranks, every rank calls comm_init with its device current (ncclCommInitRank).
+ * GEMMA_HIP_COMM=shm in the environment selects a host shared-memory transport instead: a TEST hook for boxes with one
+ * GPU (RCCL refuses two ranks on one device); it is never chosen implicitly. */
+#define GEMMA_HIP_COMM_ID_BYTES 128
+int gemma_hip_comm_unique_id(void *id /* GEMMA_HIP_COMM_ID_BYTES */);
+int gemma_hip_comm_init(const void *id /* may be NULL when world == 1 */, int rank, int world);
+int gemma_hip_comm_info(int *rank, int *world, int *transport /* 0 none, 1 RCCL, 2 shm test transport */);
+int gemma_hip_comm_bcast_d(void *buf_d, size_t bytes, int root, void *stream);
+int gemma_hip_comm_allreduce_sum_d(double *buf_d, size_t count, void *stream);
+int gemma_hip_comm_finalize(void);
 
 /* ---- measurement -------------------------------------------------------- */
 enum { GEMMA_STAGE_INGEST = 0, GEMMA_STAGE_UTX_GEMM = 1, GEMMA_STAGE_ASSOC = 2,
