@@ -262,10 +262,14 @@ def main():
         gemm_avg_s = gemm_ms * 1e-3 / max(1, gemm_n)
         assoc_avg_s = assoc_ms * 1e-3 / max(1, assoc_n)
         if i8_path:
-            # 7 digits x {genotype, missing mask}: 14 int8 products of 2 n^2 ops per SNP (2 n^2 per SNP)
-            ops_per_launch = 14.0 * 2.0 * B * n * n
+            # D digits of U x {genotype, missing mask}: 2 D int8 products of 2 n^2 ops per SNP (2 n^2 per SNP);
+            # D = 7, or 6 from n = 16384 up (csrc/i8gemm.hip.h)
+            import ctypes
+            dg = ctypes.c_int(7)
+            L.lib().gemma_hip_dbg_i8_digits(n, ctypes.byref(dg))
+            ops_per_launch = 2.0 * dg.value * 2.0 * B * n * n
             achieved = ops_per_launch / gemm_avg_s / 1e12
-            roof = {"kernel": "i8gemm_packed_kernel (14 exact int8-digit products = UtX)", "bound": "mfma",
+            roof = {"kernel": "i8gemm_packed_kernel (%d int8-digit products = UtX; %d base-256 digits of U)" % (2 * dg.value, dg.value), "bound": "mfma",
                     "achieved": round(achieved, 1), "peak": INT8_MFMA_PEAK_TOPS, "unit": "TOP/s",
                     "frac": round(achieved / INT8_MFMA_PEAK_TOPS, 4), "traffic": None, "launches": gemm_n,
                     "avg_launch_ms": round(gemm_avg_s * 1e3, 3),

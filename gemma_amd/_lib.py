@@ -19,7 +19,12 @@ SYMBOLS = [
     "gemma_hip_profile_read", "gemma_hip_dbg_tridiag", "gemma_hip_dbg_stedc", "gemma_hip_dbg_utx", "gemma_hip_lmm_gene_batch", "gemma_hip_lmm_gene_batch_d", "gemma_hip_lmm_set_env",
     "gemma_hip_lmm_gxe_batch", "gemma_hip_lmm_gxe_batch_d",
     "gemma_hip_mvlmm_null", "gemma_hip_mvlmm_set", "gemma_hip_mvlmm_batch", "gemma_hip_mvlmm_batch_d",
+    "gemma_hip_kin_end_keep", "gemma_hip_kept_K_get", "gemma_hip_eigh_kept_K", "gemma_hip_eigh_keep", "gemma_hip_kept_n",
+    "gemma_hip_kept_bcast", "gemma_hip_kept_U_get", "gemma_hip_calc_utx_kept", "gemma_hip_lmm_setup_kept", "gemma_hip_kept_release",
+    "gemma_hip_comm_unique_id", "gemma_hip_comm_init", "gemma_hip_comm_info", "gemma_hip_comm_bcast_d",
+    "gemma_hip_comm_allreduce_sum_d", "gemma_hip_comm_finalize", "gemma_hip_dbg_i8_digits",
 ]
+COMM_ID_BYTES = 128
 
 OK, EINVAL, ENODEV, ENOMEM, ERUNTIME, ESTATE, ENOCONV = range(7)
 GENO_F64_SNP_MAJOR, GENO_PLINK_2BIT, GENO_F64_IDV_MAJOR = 0, 1, 2
@@ -126,6 +131,21 @@ def lib():
     L.gemma_hip_dbg_tridiag.argtypes = [dp, sz, dp, dp, dp, dp]
     L.gemma_hip_dbg_stedc.argtypes = [dp, dp, sz, dp, dp]
     L.gemma_hip_dbg_utx.argtypes = [C.c_int, vp, sz, sz, C.c_int, dp]
+    L.gemma_hip_kin_end_keep.argtypes = [C.POINTER(sz), ci]
+    L.gemma_hip_kept_K_get.argtypes = [dp]
+    L.gemma_hip_eigh_kept_K.argtypes = [vp, sz, dp, C.POINTER(cd)]
+    L.gemma_hip_eigh_keep.argtypes = [dp, sz, dp, C.POINTER(cd)]
+    L.gemma_hip_kept_n.argtypes = [C.POINTER(sz)]
+    L.gemma_hip_kept_bcast.argtypes = [ci, C.POINTER(cd)]
+    L.gemma_hip_kept_U_get.argtypes = [dp, dp]
+    L.gemma_hip_calc_utx_kept.argtypes = [dp, sz, sz, dp]
+    L.gemma_hip_lmm_setup_kept.argtypes = [C.POINTER(LmmCfg), dp, dp]
+    L.gemma_hip_dbg_i8_digits.argtypes = [sz, C.POINTER(ci)]
+    L.gemma_hip_comm_unique_id.argtypes = [vp]
+    L.gemma_hip_comm_init.argtypes = [vp, ci, ci]
+    L.gemma_hip_comm_info.argtypes = [C.POINTER(ci), C.POINTER(ci), C.POINTER(ci)]
+    L.gemma_hip_comm_bcast_d.argtypes = [vp, sz, ci, vp]
+    L.gemma_hip_comm_allreduce_sum_d.argtypes = [dp, sz, vp]
     for s in SYMBOLS:
         getattr(L, s)  # AttributeError if the library does not export what the header declares
     _lib = L

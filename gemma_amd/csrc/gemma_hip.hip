@@ -21,6 +21,7 @@
 #include "i8gemm.hip.h"
 #include "qc.hip.h"
 #include "mvlmm.hip.h"
+#include "comm.hip.h"
 
 using namespace gemma_hip;
 
@@ -80,9 +81,10 @@ struct Ctx {
   bool have_map = false;
   DevBuf X, UtX, stage_in, stage_out, carry;
   DevBuf grid_R, grid_F, grid_T; // fixed-lambda table (lmm_grid.hip.h)
-  DevBuf cheb_R, cheb_F, cheb_T, cheb_slots, cheb_list, cheb_count, cheb_D, cheb_Ck, cheb_Gk, cheb_dends, cheb_res; // bracket-interval series
+  DevBuf cheb_R, cheb_F, cheb_T, cheb_slots, cheb_list, cheb_count, cheb_D, cheb_Ck, cheb_Gk, cheb_Lk, cheb_iv, cheb_dends, cheb_res; // bracket-interval series
   double cheb_mid[ASSOC_MAX_REGION], cheb_inv_half[ASSOC_MAX_REGION];
   GridGeom cheb_geom;
+  DevBuf table_P; // K-slice partial sums of the table products (table_v2_kernel)
   DevBuf gxe_env, gxe_UtWt, gxe_Z, gxe_UtZ, gxe_flip; // GXE variants
   bool gxe_ready = false;
   double gxe_lnbeta = 0.0;
@@ -93,6 +95,7 @@ struct Ctx {
   DevBuf i8_Bt, i8_ej, i8_cmax, i8_A, i8_C, i8_mean; // exact int8-digit U^T x (i8gemm.hip.h)
   bool i8_ready = false;
   size_t i8_ldk = 0, i8_npad = 0;
+  int i8_digits = I8_DIGITS;
   GridGeom grid_geom;
   int carry_flip = 0;
   AssocArgs assoc_proto;
@@ -104,6 +107,12 @@ struct Ctx {
 
   // misc scratch
   DevBuf scratch;
+
+  // device-resident chain (kin_end_keep -> eigh_kept_K -> lmm_setup_kept) and the communicator
+  DevBuf kept_K, kept_UE; // K: ni_total^2; UE: U (n^2) followed by eval (n) -- one buffer, one broadcast
+  size_t kept_K_n = 0, kept_n = 0;
+  double kept_trace = 0.0;
+  Comm comm;
 } g_ctx;
 
 int fail(int code, const char *fmt, ...) {
@@ -227,6 +236,9 @@ extern "C" void gemma_hip_shutdown(void) {
   g_ctx.UtWt.release(); g_ctx.idx_map.release(); g_ctx.X.release(); g_ctx.UtX.release();
   g_ctx.stage_in.release(); g_ctx.stage_out.release(); g_ctx.carry.release(); g_ctx.scratch.release();
   g_ctx.kin_active = g_ctx.lmm_active = false;
+  g_ctx.kept_K.release(); g_ctx.kept_UE.release();
+  g_ctx.kept_K_n = g_ctx.kept_n = 0;
+  g_ctx.comm.finalize();
   gemm_aux_destroy();
   g_ctx.inited = false;
 }
@@ -735,10 +747,11 @@ static int make_cheb(hipStream_t s) {
   const size_t nb = (size_t)(gg.nbx + gg.nba);
   const size_t r_elems = (size_t)gg.nc * nb * 256;
   const size_t npairs = (c + 1) * (c + 2) / 2;
-  const size_t fld = (npairs + 1) * CHEB_N;
+  const size_t fld = (npairs + 2) * CHEB_N;
   if (g_ctx.cheb_R.reserve((size_t)nint * r_elems * 8) || g_ctx.cheb_F.reserve((size_t)nint * fld * 8) ||
       g_ctx.cheb_D.reserve(CHEB_N * CHEB_N * 8) || g_ctx.cheb_Ck.reserve(n * CHEB_N * 8) ||
-      g_ctx.cheb_Gk.reserve(n * CHEB_N * 8))
+      g_ctx.cheb_Gk.reserve(n * CHEB_N * 8) || g_ctx.cheb_Lk.reserve(n * CHEB_N * 8) ||
+      g_ctx.cheb_iv.reserve(2 * ASSOC_MAX_REGION * 8))
     return fail(GEMMA_HIP_ENOMEM, "lmm_setup: Chebyshev tables (%zu bytes)", (size_t)nint * r_elems * 8);
   // fit matrix: coefficients = D * node values (cheb_fit of lmm_search.hip.h)
   std::vector<double> D((size_t)CHEB_N * CHEB_N);
@@ -758,16 +771,26 @@ static int make_cheb(hipStream_t s) {
     ChebNodes nd;
     for (int m = 0; m < CHEB_N; ++m) nd.lam[m] = exp(cheb_node(iv, m));
     hipLaunchKernelGGL(cheb_coeff_kernel, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, s, g_ctx.eval, (int)n, nd,
-                       g_ctx.cheb_D.as<double>(), g_ctx.cheb_Ck.as<double>(), g_ctx.cheb_Gk.as<double>());
+                       g_ctx.cheb_D.as<double>(), g_ctx.cheb_Ck.as<double>(), g_ctx.cheb_Gk.as<double>(),
+                       g_ctx.cheb_Lk.as<double>());
     HIPCHK(hipGetLastError());
     hipLaunchKernelGGL(cheb_weights_kernel, dim3((unsigned)((r_elems + 255) / 256)), dim3(256), 0, s, k, gg, (int)c,
                        g_ctx.cheb_Ck.as<double>(), g_ctx.cheb_R.as<double>() + (size_t)q * r_elems);
     HIPCHK(hipGetLastError());
-    hipLaunchKernelGGL(cheb_fixed_kernel, dim3((unsigned)(npairs + 1)), dim3(256), 0, s, k, (int)c,
-                       g_ctx.cheb_Ck.as<double>(), g_ctx.cheb_Gk.as<double>(), g_ctx.cheb_F.as<double>() + (size_t)q * fld);
+    hipLaunchKernelGGL(cheb_fixed_kernel, dim3((unsigned)(npairs + 2)), dim3(256), 0, s, k, (int)c,
+                       g_ctx.cheb_Ck.as<double>(), g_ctx.cheb_Gk.as<double>(), g_ctx.cheb_Lk.as<double>(),
+                       g_ctx.cheb_F.as<double>() + (size_t)q * fld);
     HIPCHK(hipGetLastError());
   }
+  {
+    std::vector<double> ivs(2 * (size_t)nint);
+    for (int q = 0; q < nint; ++q) { ivs[2 * q] = g_ctx.cheb_mid[q]; ivs[2 * q + 1] = g_ctx.cheb_inv_half[q]; }
+    HIPCHK(hipMemcpyAsync(g_ctx.cheb_iv.p, ivs.data(), ivs.size() * 8, hipMemcpyHostToDevice, s));
+    HIPCHK(hipStreamSynchronize(s));
+  }
   g_ctx.cheb_geom = gg;
+  a.cheb_iv = g_ctx.cheb_iv.as<double>();
+  a.cheb_logdet_off = (int)((npairs + 1) * CHEB_N);
   a.cheb_F = g_ctx.cheb_F.as<double>();
   a.cheb_ld = (int)(nb * 16);
   a.cheb_fld = (int)fld;
@@ -812,6 +835,54 @@ static int make_grid(hipStream_t s) {
   return make_cheb(s);
 }
 
+// table_v2_kernel + table_reduce_kernel (lmm_grid.hip.h): T = [X.X | X] * R with RG * 16 rows per wave and the K range cut
+// into slices; tg == nullptr: the dense fixed-lambda table of all l rows, else the per-interval gather tables
+static bool table_v2_enabled() {
+  const char *e = getenv("GEMMA_HIP_TABLE_V2");
+  return !(e && e[0] == '0');
+}
+template <int NBX, int NBA, int RG>
+static int launch_table_v2_t(const GridGeom &gg, const double *UtX, size_t l, size_t ld, const double *R, double *T,
+                             const TableGather *tg, int nint, hipStream_t s) {
+  constexpr int NB16 = (NBX + NBA) * 16;
+  const size_t rows_per_block = (size_t)RG * 16 * 4;
+  const size_t bx = (l + rows_per_block - 1) / rows_per_block;
+  size_t row_waves = (l + RG * 16 - 1) / (RG * 16);
+  int ksplit = (int)((4096 + row_waves - 1) / row_waves);
+  ksplit = std::max(1, std::min(ksplit, std::min(32, gg.nc)));
+  const size_t planes = tg ? (size_t)nint : 1;
+  if (g_ctx.table_P.reserve(planes * (size_t)ksplit * l * NB16 * 8))
+    return fail(GEMMA_HIP_ENOMEM, "lmm_assoc: table partial sums (%zu bytes)", planes * (size_t)ksplit * l * NB16 * 8);
+  TableV2 a;
+  a.UtX = UtX; a.ld = (long)ld; a.l = (long)l; a.n = (int)g_ctx.cfg.n; a.nc = gg.nc; a.ksplit = ksplit; a.Rp = R;
+  a.P = g_ctx.table_P.as<double>(); a.cap = (long)l;
+  if (tg) a.tg = *tg; else a.tg = TableGather();
+  const long total = (long)l * NB16;
+  if (tg) {
+    hipLaunchKernelGGL((table_v2_kernel<NBX, NBA, RG, true>), dim3((unsigned)bx, (unsigned)ksplit, (unsigned)nint), dim3(256), 0, s, a);
+    HIPCHK(hipGetLastError());
+    hipLaunchKernelGGL(table_reduce_kernel<true>, dim3((unsigned)((total + 255) / 256), (unsigned)nint), dim3(256), 0, s,
+                       a.P, ksplit, a.cap, NB16, (long)l, tg->count, T);
+  } else {
+    hipLaunchKernelGGL((table_v2_kernel<NBX, NBA, RG, false>), dim3((unsigned)bx, (unsigned)ksplit), dim3(256), 0, s, a);
+    HIPCHK(hipGetLastError());
+    hipLaunchKernelGGL(table_reduce_kernel<false>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a.P, ksplit,
+                       a.cap, NB16, (long)l, (const int *)nullptr, T);
+  }
+  HIPCHK(hipGetLastError());
+  return GEMMA_HIP_OK;
+}
+static int launch_table_v2(const GridGeom &gg, const double *UtX, size_t l, size_t ld, const double *R, double *T,
+                           const TableGather *tg, int nint, hipStream_t s) {
+  switch (gg.nba) {
+  case 3: return launch_table_v2_t<2, 3, 4>(gg, UtX, l, ld, R, T, tg, nint, s);
+  case 5: return launch_table_v2_t<2, 5, 2>(gg, UtX, l, ld, R, T, tg, nint, s);
+  case 6: return launch_table_v2_t<2, 6, 2>(gg, UtX, l, ld, R, T, tg, nint, s);
+  case 8: return launch_table_v2_t<2, 8, 2>(gg, UtX, l, ld, R, T, tg, nint, s);
+  default: return fail(GEMMA_HIP_ERUNTIME, "lmm_assoc: no table kernel for %d column blocks", gg.nba);
+  }
+}
+
 // the per-batch part: T = [X.X | X] * R for the l SNP rows of UtX
 static int launch_grid_table(const double *UtX, size_t l, size_t ld, hipStream_t s) {
   const GridGeom &gg = g_ctx.grid_geom;
@@ -821,6 +892,7 @@ static int launch_grid_table(const double *UtX, size_t l, size_t ld, hipStream_t
   const double *R = g_ctx.grid_R.as<double>();
   double *T = g_ctx.grid_T.as<double>();
   const int n = (int)g_ctx.cfg.n;
+  if (table_v2_enabled()) return launch_table_v2(gg, UtX, l, ld, R, T, nullptr, 0, s);
   switch (gg.nba) {
   case 3: hipLaunchKernelGGL((grid_table_kernel<2, 3, false>), dim3(grid), dim3(256), 0, s, UtX, (long)ld, (long)l, n, gg.nc, R, T, TableGather()); break;
   case 5: hipLaunchKernelGGL((grid_table_kernel<2, 5, false>), dim3(grid), dim3(256), 0, s, UtX, (long)ld, (long)l, n, gg.nc, R, T, TableGather()); break;
@@ -868,6 +940,10 @@ static int launch_cheb_tables(AssocArgs &a, const double *UtX, size_t l, size_t 
   const double *R = g_ctx.cheb_R.as<double>();
   double *T = g_ctx.cheb_T.as<double>();
   const int n = (int)g_ctx.cfg.n;
+  if (table_v2_enabled()) {
+    int rc = launch_table_v2(gg, UtX, l, ld, R, T, &tg, (int)nint, s);
+    if (rc) return rc;
+  } else
   switch (gg.nba) {
   case 3: hipLaunchKernelGGL((grid_table_kernel<2, 3, true>), grid, dim3(256), 0, s, UtX, (long)ld, (long)l, n, gg.nc, R, T, tg); break;
   case 5: hipLaunchKernelGGL((grid_table_kernel<2, 5, true>), grid, dim3(256), 0, s, UtX, (long)ld, (long)l, n, gg.nc, R, T, tg); break;
@@ -1060,11 +1136,20 @@ static int utx_i8_mode() {
 
 static size_t round_up(size_t v, size_t m) { return (v + m - 1) / m * m; }
 
+// digits of U in the exact int8 product (i8gemm.hip.h): 7, or 6 from n = 16384 up where the 2^-47 rounding of U stays at
+// the level of an fp64 GEMM's own rounding; GEMMA_HIP_I8_DIGITS=6|7 forces either
+static int i8_digits_for(size_t n) {
+  const char *e = getenv("GEMMA_HIP_I8_DIGITS");
+  if (e && (atoi(e) == 6 || atoi(e) == 7)) return atoi(e);
+  return n >= 16384 ? 6 : 7;
+}
+
 // one-time: per-column exponents of U and its 7 balanced base-256 digit matrices, transposed (K contiguous)
 static int i8_prepare_u(hipStream_t s) {
   if (g_ctx.i8_ready) return GEMMA_HIP_OK;
   const size_t n = g_ctx.cfg.n;
   const size_t ldk = round_up(n, I8_BK), npad = round_up(n, I8_BN);
+  g_ctx.i8_digits = i8_digits_for(n);
   if (g_ctx.i8_Bt.reserve((size_t)I8_DIGITS * npad * ldk) || g_ctx.i8_ej.reserve(n * sizeof(int)) ||
       g_ctx.i8_cmax.reserve(n * 8))
     return fail(GEMMA_HIP_ENOMEM, "lmm_batch: int8 digits of U (%zu bytes)", (size_t)I8_DIGITS * npad * ldk);
@@ -1078,7 +1163,7 @@ static int i8_prepare_u(hipStream_t s) {
   HIPCHK(hipGetLastError());
   hipLaunchKernelGGL(u_digits_kernel, dim3((unsigned)((n + 31) / 32), (unsigned)((n + 31) / 32)), dim3(256), 0, s,
                      g_ctx.U, (long)n, (long)n, g_ctx.i8_ej.as<int>(), g_ctx.i8_Bt.as<int8_t>(), (long)ldk,
-                     (long)(npad * ldk));
+                     (long)(npad * ldk), g_ctx.i8_digits);
   HIPCHK(hipGetLastError());
   g_ctx.i8_ldk = ldk;
   g_ctx.i8_npad = npad;
@@ -1089,7 +1174,7 @@ static int i8_prepare_u(hipStream_t s) {
 // ---- exact int8-digit U^T x (i8gemm.hip.h): buffers, the product on an already packed left factor, ingest variants
 struct I8Dims {
   size_t n, ldk, npad, lpad, mrows;
-  int fuse;
+  int fuse, digits, nplanes;
 };
 static int i8_begin(size_t l, I8Dims *d, hipStream_t s) {
   int rc = i8_prepare_u(s);
@@ -1099,7 +1184,9 @@ static int i8_begin(size_t l, I8Dims *d, hipStream_t s) {
   // two digits per int32 output plane while 256 * C_hi + C_lo cannot overflow: n * 2 * 128 * 257 < 2^31
   const char *ef = getenv("GEMMA_HIP_I8_FUSE");
   d->fuse = (!(ef && ef[0] == '0') && (double)d->n * 2.0 * 128.0 * 257.0 < 2147483648.0) ? 1 : 0;
-  const size_t c_elems = (size_t)(d->fuse ? 4 : I8_DIGITS) * d->mrows * d->npad;
+  d->digits = g_ctx.i8_digits;
+  d->nplanes = d->fuse ? (d->digits + 1) / 2 : d->digits;
+  const size_t c_elems = (size_t)d->nplanes * d->mrows * d->npad;
   if (g_ctx.i8_A.reserve(d->lpad * d->ldk) || g_ctx.i8_C.reserve(c_elems * 4) || g_ctx.i8_mean.reserve(l * 8))
     return fail(GEMMA_HIP_ENOMEM, "lmm_batch: int8 product buffers (%zu bytes)", d->lpad * d->ldk + c_elems * 4);
   if (d->lpad != l) HIPCHK(hipMemsetAsync(g_ctx.i8_A.p, 0, d->lpad * d->ldk, s)); // padding rows
@@ -1128,7 +1215,8 @@ static int i8_product(size_t l, const I8Dims &d, double *UtX, size_t ldx, hipStr
     const char *e = getenv("GEMMA_HIP_I8_GM");
     g.gm = e ? atoi(e) : 0;
     g.fuse = d.fuse;
-    const dim3 grid((unsigned)(g.tiles_m * g.tiles_n), d.fuse ? 4 : I8_DIGITS);
+    g.digits = d.digits;
+    const dim3 grid((unsigned)(g.tiles_m * g.tiles_n), (unsigned)d.nplanes);
     hipLaunchKernelGGL(i8gemm_packed_kernel, grid, dim3(512), 3 * I8P_STAGE, s, g);
     HIPCHK(hipGetLastError());
   }
@@ -1137,7 +1225,8 @@ static int i8_product(size_t l, const I8Dims &d, double *UtX, size_t ldx, hipStr
     hipLaunchKernelGGL(i8_combine_kernel, dim3((unsigned)((d.n + 255) / 256), (unsigned)std::min<size_t>(l, 65535)),
                        dim3(256), 0, s,
                        g_ctx.i8_C.as<int>(), (long)d.npad, (long)(d.mrows * d.npad), (long)d.lpad,
-                       g_ctx.i8_mean.as<double>(), g_ctx.i8_ej.as<int>(), (long)l, (long)d.n, UtX, (long)ldx, 1.0, d.fuse);
+                       g_ctx.i8_mean.as<double>(), g_ctx.i8_ej.as<int>(), (long)l, (long)d.n, UtX, (long)ldx, 1.0, d.fuse,
+                       d.digits);
     HIPCHK(hipGetLastError());
   }
   return GEMMA_HIP_OK;
@@ -1855,9 +1944,10 @@ extern "C" int gemma_hip_lmm_finish(double *time_UtX_min, double *time_opt_min) 
   g_ctx.UtWt.release(); g_ctx.idx_map.release(); g_ctx.X.release(); g_ctx.UtX.release();
   g_ctx.stage_in.release(); g_ctx.stage_out.release();
   g_ctx.grid_R.release(); g_ctx.grid_F.release(); g_ctx.grid_T.release();
+  g_ctx.table_P.release();
   g_ctx.cheb_R.release(); g_ctx.cheb_F.release(); g_ctx.cheb_T.release(); g_ctx.cheb_slots.release();
   g_ctx.cheb_list.release(); g_ctx.cheb_count.release(); g_ctx.cheb_D.release(); g_ctx.cheb_Ck.release();
-  g_ctx.cheb_Gk.release(); g_ctx.cheb_dends.release(); g_ctx.cheb_res.release();
+  g_ctx.cheb_Gk.release(); g_ctx.cheb_Lk.release(); g_ctx.cheb_iv.release(); g_ctx.cheb_dends.release(); g_ctx.cheb_res.release();
   g_ctx.i8_Bt.release(); g_ctx.i8_ej.release(); g_ctx.i8_cmax.release(); g_ctx.i8_A.release(); g_ctx.i8_C.release();
   g_ctx.i8_mean.release();
   g_ctx.i8_ready = false;
@@ -1868,5 +1958,266 @@ extern "C" int gemma_hip_lmm_finish(double *time_UtX_min, double *time_opt_min) 
   g_ctx.gxe_ready = false;
   g_ctx.U = g_ctx.eval = g_ctx.Uty = nullptr;
   g_ctx.lmm_active = false;
+  return GEMMA_HIP_OK;
+}
+
+
+// ------------------------------------------------------------------------------ device-resident chain
+namespace {
+__global__ void subselect_kernel(const double *__restrict__ K, long ni_total, const int *__restrict__ map, long n,
+                                 double *__restrict__ G) {
+  const long c = (long)blockIdx.x * blockDim.x + threadIdx.x, r = blockIdx.y;
+  if (c < n) G[r * n + c] = K[(long)map[r] * ni_total + map[c]];
+}
+double *kept_U() { return g_ctx.kept_UE.as<double>(); }
+double *kept_eval() { return g_ctx.kept_UE.as<double>() + g_ctx.kept_n * g_ctx.kept_n; }
+} // namespace
+
+extern "C" int gemma_hip_kin_end_keep(size_t *ns_used, int allreduce) {
+  NEED_INIT();
+  if (!g_ctx.kin_active) return fail(GEMMA_HIP_ESTATE, "kin_end before kin_begin");
+  const size_t n = g_ctx.kin_n;
+  size_t ns = g_ctx.kin_ns;
+  if (allreduce && g_ctx.comm.active && g_ctx.comm.world > 1) {
+    // SNP-sharded kinship: every rank holds sum_s x_s x_s^T over ITS SNPs (unscaled, upper-triangle tiles); one all-reduce
+    // of the n^2 sums and one of the SNP counts, then the common 1/ns scale and the mirror
+    std::string err;
+    if (g_ctx.comm.allreduce_sum(g_ctx.kin_K.as<double>(), n * n, nullptr, err)) return fail(GEMMA_HIP_ERUNTIME, "%s", err.c_str());
+    if (g_ctx.scratch.reserve(16)) return fail(GEMMA_HIP_ENOMEM, "kin_end_keep: scratch");
+    double cnt = (double)ns;
+    HIPCHK(hipMemcpy(g_ctx.scratch.p, &cnt, 8, hipMemcpyHostToDevice));
+    if (g_ctx.comm.allreduce_sum(g_ctx.scratch.as<double>(), 1, nullptr, err)) return fail(GEMMA_HIP_ERUNTIME, "%s", err.c_str());
+    HIPCHK(hipMemcpy(&cnt, g_ctx.scratch.p, 8, hipMemcpyDeviceToHost));
+    ns = (size_t)(cnt + 0.5);
+  }
+  if (ns_used) *ns_used = ns;
+  const double scale = ns ? 1.0 / (double)ns : 1.0;
+  const unsigned nb = (unsigned)((n + 31) / 32);
+  hipLaunchKernelGGL(symm_fill_scale_kernel, dim3(nb, nb), dim3(32, 8), 0, 0, g_ctx.kin_K.as<double>(), (long)n, (long)n,
+                     scale);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipDeviceSynchronize());
+  g_ctx.kept_K.release();
+  g_ctx.kept_K = g_ctx.kin_K; // ownership moves: K stays where the SYRK left it
+  g_ctx.kin_K = DevBuf();
+  g_ctx.kept_K_n = n;
+  g_ctx.kin_active = false;
+  g_ctx.kin_X.release();
+  g_ctx.kin_stage.release();
+  return GEMMA_HIP_OK;
+}
+
+extern "C" int gemma_hip_kept_K_get(double *K) {
+  NEED_INIT();
+  if (!g_ctx.kept_K_n) return fail(GEMMA_HIP_ESTATE, "kept_K_get: no kept K");
+  if (!K) return fail(GEMMA_HIP_EINVAL, "kept_K_get: null pointer");
+  HIPCHK(hipMemcpy(K, g_ctx.kept_K.p, g_ctx.kept_K_n * g_ctx.kept_K_n * 8, hipMemcpyDeviceToHost));
+  return GEMMA_HIP_OK;
+}
+
+static int kept_alloc_ue(size_t n) {
+  if (g_ctx.kept_UE.reserve((n * n + n) * 8)) return fail(GEMMA_HIP_ENOMEM, "kept U: %zu bytes", (n * n + n) * 8);
+  g_ctx.kept_n = n;
+  return GEMMA_HIP_OK;
+}
+
+static int kept_eigh_of(double *G_d, size_t n, double *eval, double *trace_G) {
+  int rc = kept_alloc_ue(n);
+  if (rc) return rc;
+  double tr = 0.0;
+  rc = gemma_hip_eigh_d(G_d, n, kept_U(), kept_eval(), &tr, nullptr);
+  if (rc) {
+    g_ctx.kept_n = 0;
+    return rc;
+  }
+  g_ctx.kept_trace = tr;
+  if (trace_G) *trace_G = tr;
+  if (eval) HIPCHK(hipMemcpy(eval, kept_eval(), n * 8, hipMemcpyDeviceToHost));
+  return GEMMA_HIP_OK;
+}
+
+extern "C" int gemma_hip_eigh_kept_K(const int *indicator_idv, size_t ni_total, double *eval, double *trace_G) {
+  NEED_INIT();
+  if (!g_ctx.kept_K_n) return fail(GEMMA_HIP_ESTATE, "eigh_kept_K: no kept K (kin_end_keep first)");
+  if (ni_total != g_ctx.kept_K_n) return fail(GEMMA_HIP_EINVAL, "eigh_kept_K: ni_total=%zu, kept K is %zu", ni_total, g_ctx.kept_K_n);
+  std::vector<int> map;
+  for (size_t i = 0; i < ni_total; ++i)
+    if (!indicator_idv || indicator_idv[i] != 0) map.push_back((int)i);
+  const size_t n = map.size();
+  if (n == 0) return fail(GEMMA_HIP_EINVAL, "eigh_kept_K: no analysed individual");
+  DevBuf G, dmap;
+  if (G.reserve(n * n * 8) || dmap.reserve(n * sizeof(int))) {
+    G.release(); dmap.release();
+    return fail(GEMMA_HIP_ENOMEM, "eigh_kept_K: %zu bytes", n * n * 8);
+  }
+  int rc = GEMMA_HIP_OK;
+  hipError_t e = hipMemcpy(dmap.p, map.data(), n * sizeof(int), hipMemcpyHostToDevice);
+  if (e == hipSuccess) {
+    // the rows / columns ReadFile_kin keeps (src/gemma_io.cpp:1205-1243), then CenterMatrix, then EigenDecomp_Zeroed
+    hipLaunchKernelGGL(subselect_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)n), dim3(256), 0, 0,
+                       g_ctx.kept_K.as<double>(), (long)ni_total, dmap.as<int>(), (long)n, G.as<double>());
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) rc = gemma_hip_center_d(G.as<double>(), n, nullptr);
+  if (e == hipSuccess && rc == GEMMA_HIP_OK) rc = kept_eigh_of(G.as<double>(), n, eval, trace_G);
+  G.release(); dmap.release();
+  if (e != hipSuccess) return fail(GEMMA_HIP_ERUNTIME, "eigh_kept_K: %s", hipGetErrorString(e));
+  return rc;
+}
+
+extern "C" int gemma_hip_eigh_keep(const double *G, size_t n, double *eval, double *trace_G) {
+  NEED_INIT();
+  if (!G || n == 0) return fail(GEMMA_HIP_EINVAL, "eigh_keep: null/empty argument");
+  DevBuf dG;
+  if (dG.reserve(n * n * 8)) return fail(GEMMA_HIP_ENOMEM, "eigh_keep: %zu bytes", n * n * 8);
+  hipError_t e = hipMemcpy(dG.p, G, n * n * 8, hipMemcpyHostToDevice);
+  int rc = GEMMA_HIP_OK;
+  if (e == hipSuccess) rc = kept_eigh_of(dG.as<double>(), n, eval, trace_G);
+  dG.release();
+  if (e != hipSuccess) return fail(GEMMA_HIP_ERUNTIME, "eigh_keep: %s", hipGetErrorString(e));
+  return rc;
+}
+
+extern "C" int gemma_hip_kept_n(size_t *n) {
+  if (n) *n = g_ctx.kept_n;
+  return GEMMA_HIP_OK;
+}
+
+// ONE ncclBroadcast of (U, eval) -- they share a buffer -- after a 16-byte header {n, trace_G} that tells the other
+// ranks what to allocate
+extern "C" int gemma_hip_kept_bcast(int root, double *trace_G) {
+  NEED_INIT();
+  Comm &cm = g_ctx.comm;
+  if (!cm.active || cm.world == 1) {
+    if (trace_G && g_ctx.kept_n) *trace_G = g_ctx.kept_trace;
+    return GEMMA_HIP_OK;
+  }
+  if (root < 0 || root >= cm.world) return fail(GEMMA_HIP_EINVAL, "kept_bcast: root %d of %d", root, cm.world);
+  if (cm.rank == root && !g_ctx.kept_n) return fail(GEMMA_HIP_ESTATE, "kept_bcast: the root holds no kept U");
+  if (g_ctx.scratch.reserve(16)) return fail(GEMMA_HIP_ENOMEM, "kept_bcast: scratch");
+  double hdr[2] = {(double)g_ctx.kept_n, g_ctx.kept_trace};
+  std::string err;
+  if (cm.rank == root) HIPCHK(hipMemcpy(g_ctx.scratch.p, hdr, 16, hipMemcpyHostToDevice));
+  if (cm.bcast(g_ctx.scratch.p, 16, root, nullptr, err)) return fail(GEMMA_HIP_ERUNTIME, "%s", err.c_str());
+  HIPCHK(hipMemcpy(hdr, g_ctx.scratch.p, 16, hipMemcpyDeviceToHost)); // synchronises with the broadcast on the null stream
+  const size_t n = (size_t)(hdr[0] + 0.5);
+  if (cm.rank != root) {
+    int rc = kept_alloc_ue(n);
+    if (rc) return rc;
+    g_ctx.kept_trace = hdr[1];
+  }
+  if (cm.bcast(g_ctx.kept_UE.p, (n * n + n) * 8, root, nullptr, err)) return fail(GEMMA_HIP_ERUNTIME, "%s", err.c_str());
+  HIPCHK(hipDeviceSynchronize());
+  if (trace_G) *trace_G = g_ctx.kept_trace;
+  return GEMMA_HIP_OK;
+}
+
+extern "C" int gemma_hip_kept_U_get(double *U, double *eval) {
+  NEED_INIT();
+  if (!g_ctx.kept_n) return fail(GEMMA_HIP_ESTATE, "kept_U_get: no kept U");
+  const size_t n = g_ctx.kept_n;
+  if (U) HIPCHK(hipMemcpy(U, kept_U(), n * n * 8, hipMemcpyDeviceToHost));
+  if (eval) HIPCHK(hipMemcpy(eval, kept_eval(), n * 8, hipMemcpyDeviceToHost));
+  return GEMMA_HIP_OK;
+}
+
+// CalcUtX (src/mathfunc.cpp:504-506) on the kept U: UtX (n x m) = U^T X, X and UtX on the host
+extern "C" int gemma_hip_calc_utx_kept(const double *X, size_t n, size_t m, double *UtX) {
+  NEED_INIT();
+  if (!g_ctx.kept_n) return fail(GEMMA_HIP_ESTATE, "calc_utx_kept: no kept U");
+  if (n != g_ctx.kept_n || !X || !UtX || m == 0) return fail(GEMMA_HIP_EINVAL, "calc_utx_kept: n=%zu, kept U is %zu", n, g_ctx.kept_n);
+  DevBuf dX, dO;
+  if (dX.reserve(n * m * 8) || dO.reserve(n * m * 8)) {
+    dX.release(); dO.release();
+    return fail(GEMMA_HIP_ENOMEM, "calc_utx_kept: %zu bytes", 2 * n * m * 8);
+  }
+  hipError_t e = hipMemcpy(dX.p, X, n * m * 8, hipMemcpyHostToDevice);
+  int rc = GEMMA_HIP_OK;
+  if (e == hipSuccess)
+    rc = gemma_hip_dgemm_d('T', 'N', n, m, n, 1.0, kept_U(), n, dX.as<double>(), m, 0.0, dO.as<double>(), m, nullptr);
+  if (e == hipSuccess && rc == GEMMA_HIP_OK) e = hipMemcpy(UtX, dO.p, n * m * 8, hipMemcpyDeviceToHost);
+  dX.release(); dO.release();
+  if (e != hipSuccess) return fail(GEMMA_HIP_ERUNTIME, "calc_utx_kept: %s", hipGetErrorString(e));
+  return rc;
+}
+
+extern "C" int gemma_hip_lmm_setup_kept(const gemma_lmm_cfg *cfg, const double *UtW, const double *Uty) {
+  NEED_INIT();
+  if (!g_ctx.kept_n) return fail(GEMMA_HIP_ESTATE, "lmm_setup_kept: no kept U");
+  if (!cfg || !UtW || !Uty) return fail(GEMMA_HIP_EINVAL, "lmm_setup_kept: null pointer");
+  if (cfg->n != g_ctx.kept_n) return fail(GEMMA_HIP_EINVAL, "lmm_setup_kept: cfg.n=%zu, kept U is %zu", cfg->n, g_ctx.kept_n);
+  int rc = lmm_common_setup(cfg);
+  if (rc) return rc;
+  const size_t n = cfg->n, c = cfg->n_cvt;
+  if (g_ctx.own_Uty.reserve(n * 8) || g_ctx.own_UtW.reserve(n * c * 8)) return fail(GEMMA_HIP_ENOMEM, "lmm_setup_kept");
+  HIPCHK(hipMemcpy(g_ctx.own_Uty.p, Uty, n * 8, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(g_ctx.own_UtW.p, UtW, n * c * 8, hipMemcpyHostToDevice));
+  g_ctx.U = kept_U();
+  g_ctx.eval = kept_eval();
+  g_ctx.Uty = g_ctx.own_Uty.as<double>();
+  rc = make_utwt(g_ctx.own_UtW.as<double>(), 0);
+  if (rc) return rc;
+  HIPCHK(hipDeviceSynchronize());
+  g_ctx.lmm_active = true;
+  return GEMMA_HIP_OK;
+}
+
+extern "C" int gemma_hip_kept_release(void) {
+  if (g_ctx.lmm_active && g_ctx.U == kept_U() && g_ctx.kept_n)
+    return fail(GEMMA_HIP_ESTATE, "kept_release: the LMM state borrows the kept U (lmm_finish first)");
+  g_ctx.kept_K.release();
+  g_ctx.kept_UE.release();
+  g_ctx.kept_K_n = g_ctx.kept_n = 0;
+  return GEMMA_HIP_OK;
+}
+
+// ------------------------------------------------------------------------------ multi-GPU: RCCL (csrc/comm.hip.h)
+extern "C" int gemma_hip_comm_unique_id(void *id) {
+  if (!id) return fail(GEMMA_HIP_EINVAL, "comm_unique_id: null pointer");
+  std::string err;
+  if (g_ctx.comm.unique_id(id, err)) return fail(GEMMA_HIP_ERUNTIME, "%s", err.c_str());
+  return GEMMA_HIP_OK;
+}
+
+extern "C" int gemma_hip_comm_init(const void *id, int rank, int world) {
+  NEED_INIT();
+  if (world < 1 || rank < 0 || rank >= world) return fail(GEMMA_HIP_EINVAL, "comm_init: rank %d of %d", rank, world);
+  std::string err;
+  if (g_ctx.comm.init(id, rank, world, err)) return fail(GEMMA_HIP_ERUNTIME, "%s", err.c_str());
+  return GEMMA_HIP_OK;
+}
+
+extern "C" int gemma_hip_comm_info(int *rank, int *world, int *transport) {
+  const Comm &cm = g_ctx.comm;
+  if (rank) *rank = cm.active ? cm.rank : 0;
+  if (world) *world = cm.active ? cm.world : 1;
+  if (transport) *transport = (!cm.active || cm.world == 1) ? 0 : (cm.shm ? 2 : 1);
+  return GEMMA_HIP_OK;
+}
+
+extern "C" int gemma_hip_comm_bcast_d(void *buf_d, size_t bytes, int root, void *stream) {
+  NEED_INIT();
+  if (!buf_d && bytes) return fail(GEMMA_HIP_EINVAL, "comm_bcast: null pointer");
+  std::string err;
+  if (g_ctx.comm.bcast(buf_d, bytes, root, S(stream), err)) return fail(GEMMA_HIP_ERUNTIME, "%s", err.c_str());
+  return GEMMA_HIP_OK;
+}
+
+extern "C" int gemma_hip_comm_allreduce_sum_d(double *buf_d, size_t count, void *stream) {
+  NEED_INIT();
+  if (!buf_d && count) return fail(GEMMA_HIP_EINVAL, "comm_allreduce: null pointer");
+  std::string err;
+  if (g_ctx.comm.allreduce_sum(buf_d, count, S(stream), err)) return fail(GEMMA_HIP_ERUNTIME, "%s", err.c_str());
+  return GEMMA_HIP_OK;
+}
+
+extern "C" int gemma_hip_comm_finalize(void) {
+  g_ctx.comm.finalize();
+  return GEMMA_HIP_OK;
+}
+
+
+extern "C" int gemma_hip_dbg_i8_digits(size_t n, int *digits) {
+  if (digits) *digits = i8_digits_for(n);
   return GEMMA_HIP_OK;
 }

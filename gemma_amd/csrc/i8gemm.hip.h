@@ -29,8 +29,14 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int I8_BM = 256, I8_BN = 256, I8_BK = 128;
-constexpr int I8_DIGITS = 7;
-constexpr int I8_SCALE_BITS = 54;
+constexpr int I8_DIGITS = 7;      // most digits a build handles (buffers are sized for it)
+constexpr int I8_SCALE_BITS = 54;  // with 7 digits; D digits scale to 8 D - 2 bits (|V| <= 2^(8D-2) < 128 * 256^(D-1))
+// Digits actually used (host: i8_digits_for): 7 reproduce U to its last bit in the column's top binade (error elsewhere
+// <= 2^-55 of the column maximum).  From n = 16384 up 6 digits are used: U is then rounded at 2^-47 of the column maximum,
+// which perturbs a dot product by ~2^-47 cmax |x|_2 / sqrt(12) -- in the units of the accuracy test (sum_k |x_k||u_k|)
+// about 1.3e-14 / sqrt(n), i.e. <= 1e-16 typical and ~5e-16 at the worst of 4e8 outputs at n = 20000: the level of the
+// fp64 MFMA GEMM's own rounding (5e-16), an order below the test's bar -- for 6/7 of the matrix-pipe cycles.
+__host__ __device__ inline int i8_scale_bits(int digits) { return 8 * digits - 2; }
 
 // ---------------------------------------------------------------------------------------------------------------
 // ONE packed left factor per SNP row, byte = g | (m << 4).  A wave reads an A fragment from LDS once and
@@ -54,7 +60,9 @@ struct I8PackArgs {
   int tiles_m, tiles_n;
   int nk;
   int gm;
-  int fuse;          // 1: 4 output planes {0}, {2,1}, {4,3}, {6,5} (needs n * 2 * 128 * 257 < 2^31), 0: 7 planes
+  int fuse;          // 1: two digits per output plane (needs n * 2 * 128 * 257 < 2^31): 7 digits -> planes {0}, {2,1},
+                     // {4,3}, {6,5}; 6 digits -> {1,0}, {3,2}, {5,4};  0: one plane per digit
+  int digits;        // 6 or 7
 };
 constexpr int I8P_BM = 128;
 constexpr int I8P_STAGE = 49152;
@@ -78,8 +86,10 @@ __global__ __launch_bounds__(512, 2) void i8gemm_packed_kernel(I8PackArgs g) {
   // output plane q: fused pairs of digits when g.fuse (256 * C_{d+1} + C_d still fits int32): planes
   // {0}, {2,1}, {4,3}, {6,5}; otherwise one digit per plane
   const int plane = blockIdx.y;
-  const int d_first = g.fuse ? (plane == 0 ? 0 : 2 * plane) : plane; // most significant digit of the plane
-  const int nd = (g.fuse && plane > 0) ? 2 : 1;
+  const int odd = g.digits & 1;
+  // most significant digit of the plane and the number of digits it carries
+  const int d_first = g.fuse ? (odd ? (plane == 0 ? 0 : 2 * plane) : 2 * plane + 1) : plane;
+  const int nd = (g.fuse && !(odd && plane == 0)) ? 2 : 1;
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int wm = wave >> 2, wn = wave & 3; // rows wm*64, cols wn*64
@@ -282,22 +292,21 @@ __global__ void u_exponent_kernel(const unsigned long long *__restrict__ colmax_
 // 32 x 32 tile of U (rows k, cols j) -> digit tiles [j][k]
 __global__ __launch_bounds__(256) void u_digits_kernel(const double *__restrict__ U, long n, long ld,
                                                        const int *__restrict__ ej, int8_t *__restrict__ Bt, long ldk,
-                                                       long strideB) {
+                                                       long strideB, int digits) {
   __shared__ long long tile[32][33];
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5; // 32 x 8
   const long k0 = (long)blockIdx.y * 32, j0 = (long)blockIdx.x * 32;
   for (int r = ty; r < 32; r += 8) {
     const long k = k0 + r, j = j0 + tx;
     long long v = 0;
-    if (k < n && j < n) v = llrint(ldexp(U[k * ld + j], I8_SCALE_BITS - ej[j]));
+    if (k < n && j < n) v = llrint(ldexp(U[k * ld + j], i8_scale_bits(digits) - ej[j]));
     tile[r][tx] = v;
   }
   __syncthreads();
   for (int r = ty; r < 32; r += 8) {
     const long j = j0 + r, k = k0 + tx; // write row j, column k (k contiguous across tx)
     long long v = tile[tx][r];
-#pragma unroll
-    for (int d = 0; d < I8_DIGITS; ++d) {
+    for (int d = 0; d < digits; ++d) {
       const int dig = (int)(int8_t)(unsigned char)(v & 0xff); // low byte as a signed digit
       v = (v - dig) >> 8;                                      // exact: v - dig is a multiple of 256
       Bt[(long)d * strideB + j * ldk + k] = (int8_t)dig;
@@ -403,31 +412,25 @@ __global__ __launch_bounds__(256) void pack_f64_kernel(PackF64Args g) {
   }
 }
 
-// UtX[s][j] = 2^(e_j - 54) * sum_d 256^d (CG_d[s][j] + mean_s * CM_d[s][j]);  planes: 7 single digits (fuse = 0) or
-// {0}, {2,1}, {4,3}, {6,5} with 256 * C_{d+1} + C_d per plane (fuse = 1)
+// UtX[s][j] = 2^(e_j - scale_bits) * sum_d 256^d (CG_d[s][j] + mean_s * CM_d[s][j]);  planes: one per digit (fuse = 0) or
+// two digits per plane with 256 * C_{d+1} + C_d (fuse = 1; with an odd digit count plane 0 holds digit 0 alone)
 __global__ __launch_bounds__(256) void i8_combine_kernel(const int *__restrict__ C, long ldc, long strideC, long m_row0,
                                                          const double *__restrict__ mean, const int *__restrict__ ej,
                                                          long l, long n, double *__restrict__ UtX, long ldx,
-                                                         double m_scale, int fuse) {
+                                                         double m_scale, int fuse, int digits) {
   const long j = (long)blockIdx.x * 256 + threadIdx.x;
   if (j >= n) return;
+  const int nplanes = fuse ? (digits + 1) / 2 : digits;
+  const int odd = digits & 1;
   for (long s = blockIdx.y; s < l; s += gridDim.y) { // gridDim.y is capped at 65535 rows per sweep
-  double tg = 0.0, tmk = 0.0;
-  if (fuse) {
-#pragma unroll
-    for (int q = 3; q >= 0; --q) {
-      const double w = (q == 0) ? 256.0 : 65536.0; // plane q sits 2 digits above plane q-1, plane 1 one above plane 0
+    double tg = 0.0, tmk = 0.0;
+    for (int q = nplanes - 1; q >= 0; --q) {
+      // fused: plane q sits two digits above plane q - 1, except that an odd count leaves plane 0 one digit wide
+      const double w = fuse ? ((q == 0 && odd) ? 256.0 : 65536.0) : 256.0;
       tg = tg * w + (double)C[(long)q * strideC + s * ldc + j];
       tmk = tmk * w + (double)C[(long)q * strideC + (m_row0 + s) * ldc + j];
     }
-  } else {
-#pragma unroll
-    for (int d = I8_DIGITS - 1; d >= 0; --d) {
-      tg = tg * 256.0 + (double)C[(long)d * strideC + s * ldc + j];
-      tmk = tmk * 256.0 + (double)C[(long)d * strideC + (m_row0 + s) * ldc + j];
-    }
-  }
-  UtX[s * ldx + j] = ldexp(fma(mean[s] * m_scale, tmk, tg), ej[j] - I8_SCALE_BITS); // m_scale: exact power of two
+    UtX[s * ldx + j] = ldexp(fma(mean[s] * m_scale, tmk, tg), ej[j] - i8_scale_bits(digits)); // m_scale: exact power of two
   }
 }
 

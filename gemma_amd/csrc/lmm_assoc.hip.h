@@ -74,6 +74,8 @@ struct AssocArgs {
   int cheb_ld, cheb_fld, cheb_xa0;
   int cheb_j0, cheb_nint;
   int have_cheb;
+  int cheb_logdet_off;     // offset of the series of sum_i log(lambda delta_i + 1) inside an interval's cheb_F block
+  const double *cheb_iv;   // [k][2] = {mid, 1 / half} of interval k in t = log(lambda)
   double cheb_mid[ASSOC_MAX_REGION], cheb_inv_half[ASSOC_MAX_REGION];
 };
 
@@ -660,7 +662,7 @@ __device__ __forceinline__ double dev1_grid(const SnpCtx<M> &s, int gi) {
 
 // LogRL_f (src/lmm.cpp:799-864) / LogL_f (:484-542)
 template <class M, bool REML>
-__device__ __forceinline__ double logf(const SnpCtx<M> &s, double l, Agg &A) {
+__device__ __forceinline__ double logf(const SnpCtx<M> &s, double l, Agg &A, int kint = -1) {
   // log|H| at the two interval ends does not depend on the SNP: taken from the setup kernel, which sums
   // in this kernel's own order (bit-identical to evaluating it here)
   if (s.g->have_logdet_ends && (l == s.g->l_min || l == s.g->l_max)) {
@@ -674,7 +676,27 @@ __device__ __forceinline__ double logf(const SnpCtx<M> &s, double l, Agg &A) {
     if (!done) s.m.template eval<1, false>(*s.g, s.x, s.y, l, s.lane, A);
     A.logdet = (l == s.g->l_min) ? s.g->logdet_lmin : s.g->logdet_lmax;
   } else {
-    s.m.template eval<1, true>(*s.g, s.x, s.y, l, s.lane, A);
+    // log|H| = sum_i log(lambda delta_i + 1) is SNP-independent and smooth in log(lambda): inside a tabulated interval
+    // it comes from its Chebyshev series (lmm_grid.hip.h; ~1e-14 of its size), which takes the one log per element out
+    // of the streaming pass
+    bool have_ld = false;
+    double ldet = 0.0;
+    if constexpr (M::HAS_CHEB) {
+      if (s.cslots && kint >= 0 && kint < s.g->cheb_nint) {
+        const double sv = (log(l) - s.g->cheb_iv[2 * kint]) * s.g->cheb_iv[2 * kint + 1];
+        if (fabs(sv) <= 1.0) {
+          double d1, d2;
+          cheb_eval<0>(s.g->cheb_F + (long)kint * s.g->cheb_fld + s.g->cheb_logdet_off, 1, sv, ldet, d1, d2);
+          have_ld = true;
+        }
+      }
+    }
+    if (have_ld) {
+      s.m.template eval<1, false>(*s.g, s.x, s.y, l, s.lane, A);
+      A.logdet = uniform(ldet);
+    } else {
+      s.m.template eval<1, true>(*s.g, s.x, s.y, l, s.lane, A);
+    }
   }
   const double n = (double)s.g->n;
   double P_yy = A.yy1;
@@ -777,7 +799,7 @@ __device__ __forceinline__ void calc_lambda(const SnpCtx<M> &cx, double &lambda,
       } else if (pb == PB_FAILED) {
         failed = true; // :2087-2094: lambda = logf = NaN, return
       } else {
-        const double logf_l = logf<M, REML>(cx, l, cand);
+        const double logf_l = logf<M, REML>(cx, l, cand, i - g.cheb_j0);
         if (first) {
           lf = logf_l; lam = l; best = cand;
         } else if (lf < logf_l) {

@@ -192,6 +192,118 @@ __global__ __launch_bounds__(256) void grid_table_kernel(const double *__restric
   }
 }
 
+// ---- the same table product, tiled for reuse (default): one WAVE owns RG * 16 SNP rows and one slice of K, so that a
+// 16-k chunk of the weight matrix (NB * 2 KiB) feeds RG * NB * 4 MFMAs instead of NB * 4; a block's four waves take four
+// different row sets over the SAME K slice (their weight reads coincide in the L1), blockIdx.y picks the K slice.  The K
+// slices leave partial sums P[ks][row][col]; table_reduce_kernel adds them in slice order (fixed order, no atomics: a
+// SNP's sums do not depend on its neighbours or on the launch shape -- the slicing depends only on n and the batch cap).
+struct TableV2 {
+  const double *UtX;
+  long ld;
+  long l;        // rows (dense) -- GATHER: unused, count[kint] rules
+  int n, nc;     // individuals, 16-k chunks
+  int ksplit;    // K slices
+  const double *Rp;
+  double *P;     // partial sums: [(kint * ksplit + ks) * cap + row] * NB16 + col
+  long cap;      // rows allocated per interval / batch
+  TableGather tg;
+};
+template <int NBX, int NBA, int RG, bool GATHER>
+__global__ __launch_bounds__(256) void table_v2_kernel(TableV2 a) {
+  constexpr int NB = NBX + NBA;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int i = lane & 15, kq = lane >> 4;
+  const int ks = blockIdx.y;
+  const int kint = GATHER ? blockIdx.z : 0;
+  long l = a.l;
+  const double *Rp = a.Rp;
+  if (GATHER) {
+    l = a.tg.count[kint];
+    Rp += (long)kint * a.tg.rp_stride;
+  }
+  const long s0 = ((long)blockIdx.x * 4 + wave) * (RG * 16);
+  if (s0 >= l) return;
+  const double *xr[RG];
+#pragma unroll
+  for (int g = 0; g < RG; ++g) {
+    long row = s0 + g * 16 + i;
+    if (row >= l) row = l - 1;
+    if (GATHER) row = a.tg.list[(long)kint * a.tg.cap + row];
+    xr[g] = a.UtX + row * a.ld + 4 * kq;
+  }
+  const int c0 = (int)((long)a.nc * ks / a.ksplit), c1 = (int)((long)a.nc * (ks + 1) / a.ksplit);
+  f64x4 acc[RG][NB];
+#pragma unroll
+  for (int g = 0; g < RG; ++g)
+#pragma unroll
+    for (int b = 0; b < NB; ++b) acc[g][b] = f64x4{0.0, 0.0, 0.0, 0.0};
+  const double *rp = Rp + ((long)c0 * NB * 64 + lane) * 4;
+  const int n = a.n;
+  for (int ch = c0; ch < c1; ++ch) {
+    const long k = (long)ch * 16 + 4 * kq;
+    double rb[NB][4];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      const f64x2 lo = *reinterpret_cast<const f64x2 *>(rp + (long)b * 256);
+      const f64x2 hi = *reinterpret_cast<const f64x2 *>(rp + (long)b * 256 + 2);
+      rb[b][0] = lo.x; rb[b][1] = lo.y; rb[b][2] = hi.x; rb[b][3] = hi.y;
+    }
+    rp += (long)NB * 256;
+    double xv[RG][4];
+#pragma unroll
+    for (int g = 0; g < RG; ++g) {
+      if (k + 3 < n) {
+        const f64x2 lo = *reinterpret_cast<const f64x2 *>(xr[g] + (long)ch * 16);
+        const f64x2 hi = *reinterpret_cast<const f64x2 *>(xr[g] + (long)ch * 16 + 2);
+        xv[g][0] = lo.x; xv[g][1] = lo.y; xv[g][2] = hi.x; xv[g][3] = hi.y;
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) xv[g][j] = (k + j < n) ? xr[g][(long)ch * 16 + j] : 0.0;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+#pragma unroll
+      for (int g = 0; g < RG; ++g) {
+        const double xs = xv[g][j] * xv[g][j];
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+          acc[g][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(b < NBX ? xs : xv[g][j], rb[b][j], acc[g][b], 0, 0, 0);
+      }
+    }
+  }
+  // accumulator r of lane: row kq + 4r of the row group, column i of the block
+  double *P = a.P + ((long)(kint * a.ksplit + ks) * a.cap) * (NB * 16);
+#pragma unroll
+  for (int g = 0; g < RG; ++g)
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const long srow = s0 + g * 16 + kq + 4 * r;
+        if (srow < l) P[srow * (NB * 16) + b * 16 + i] = acc[g][b][r];
+      }
+}
+// T = sum over the K slices, in slice order.  Dense: T[row][col]; GATHER: T[(kint * NB16 + col) * cap + slot]
+template <bool GATHER>
+__global__ __launch_bounds__(256) void table_reduce_kernel(const double *__restrict__ P, int ksplit, long cap, int nb16,
+                                                          long l, const int *__restrict__ count, double *__restrict__ T) {
+  const int kint = GATHER ? blockIdx.y : 0;
+  if (GATHER) l = count[kint];
+  const long e = (long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= l * nb16) return;
+  const long row = e / nb16;
+  const int col = (int)(e - row * nb16);
+  const double *p = P + ((long)kint * ksplit * cap + row) * nb16 + col;
+  double v = 0.0;
+  for (int ks = 0; ks < ksplit; ++ks) v += p[(long)ks * cap * nb16];
+  if (GATHER)
+    T[((long)kint * nb16 + col) * cap + row] = v;
+  else
+    T[row * nb16 + col] = v;
+}
+
 // ------------------------------------------------------------------ Chebyshev tables of the bracket intervals
 // (lmm_search.hip.h).  Per lmm_setup and interval: c_k(delta_i), the series coefficients of t -> H_i(t) and of
 // t -> 1 - H_i(t) (cheb_coeff_kernel), from them the weight matrix of the table product in MFMA operand order
@@ -206,28 +318,32 @@ struct ChebNodes {
   double lam[CHEB_N]; // exp(node m)
 };
 
+// Ck: series of H_i, Gk: of 1 - H_i, Lk: of log(lambda delta_i + 1)  (each n x CHEB_N)
 __global__ void cheb_coeff_kernel(const double *__restrict__ eval, int n, ChebNodes nd, const double *__restrict__ Dfit,
-                                  double *__restrict__ Ck, double *__restrict__ Gk) {
+                                  double *__restrict__ Ck, double *__restrict__ Gk, double *__restrict__ Lk) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const double d = eval[i];
-  double hm[CHEB_N], gm[CHEB_N];
+  double hm[CHEB_N], gm[CHEB_N], lm[CHEB_N];
 #pragma unroll
   for (int m = 0; m < CHEB_N; ++m) {
     const double ld = nd.lam[m] * d;
     hm[m] = 1.0 / (ld + 1.0);
     gm[m] = ld / (ld + 1.0);
+    lm[m] = log(fabs(ld + 1.0)); // as the row passes: log|lambda delta + 1|
   }
   for (int k = 0; k < CHEB_N; ++k) {
-    double sh = 0.0, sg = 0.0;
+    double sh = 0.0, sg = 0.0, sl = 0.0;
 #pragma unroll
     for (int m = 0; m < CHEB_N; ++m) {
       const double w = Dfit[k * CHEB_N + m];
       sh += hm[m] * w;
       sg += gm[m] * w;
+      sl += lm[m] * w;
     }
     Ck[(long)i * CHEB_N + k] = sh;
     Gk[(long)i * CHEB_N + k] = sg;
+    Lk[(long)i * CHEB_N + k] = sl;
   }
 }
 
@@ -261,9 +377,11 @@ __global__ void cheb_weights_kernel(AssocArgs g, GridGeom gg, int c, const doubl
 }
 
 // SNP-independent series of one interval, one block per function: block b < npairs: the pair (a <= bb) among
-// (w_1..w_c, y) in row-major upper-triangle order, a_k = sum_i u_a u_bb c_k(delta_i); block npairs: g, a_k = sum_i Gk[i][k]
+// (w_1..w_c, y) in row-major upper-triangle order, a_k = sum_i u_a u_bb c_k(delta_i); block npairs: g, a_k = sum_i Gk[i][k];
+// block npairs + 1: log|H| = sum_i log(lambda delta_i + 1), a_k = sum_i Lk[i][k]
 __global__ __launch_bounds__(256) void cheb_fixed_kernel(AssocArgs g, int c, const double *__restrict__ Ck,
-                                                        const double *__restrict__ Gk, double *__restrict__ F) {
+                                                        const double *__restrict__ Gk, const double *__restrict__ Lk,
+                                                        double *__restrict__ F) {
   const int nv = c + 1, npairs = nv * (nv + 1) / 2;
   const int b = blockIdx.x;
   int pa = 0, pb = 0;
@@ -278,7 +396,7 @@ __global__ __launch_bounds__(256) void cheb_fixed_kernel(AssocArgs g, int c, con
   for (int k = 0; k < CHEB_N; ++k) s[k] = 0.0;
   for (long i = threadIdx.x; i < g.n; i += 256) {
     double w = 1.0;
-    const double *src = Gk;
+    const double *src = (b == npairs) ? Gk : Lk;
     if (b < npairs) {
       const double ua = (pa < c) ? g.UtWt[(long)pa * g.n + i] : g.Uty[i];
       const double ub = (pb < c) ? g.UtWt[(long)pb * g.n + i] : g.Uty[i];

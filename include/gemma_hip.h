@@ -261,7 +261,7 @@ int gemma_hip_eigh_kept_K(const int *indicator_idv /* NULL: all */, size_t ni_to
 int gemma_hip_eigh_keep(const double *G /* n^2, already centred; not modified */, size_t n, double *eval /* may be NULL */,
                         double *trace_G);
 int gemma_hip_kept_n(size_t *n /* order of the kept U, 0 = none */);
-int gemma_hip_kept_bcast(int root);
+int gemma_hip_kept_bcast(int root, double *trace_G /* out on every rank: mean(eval) of the root's decomposition; may be NULL */);
 int gemma_hip_kept_U_get(double *U /* n^2, may be NULL */, double *eval /* n, may be NULL */);
 int gemma_hip_calc_utx_kept(const double *X, size_t n, size_t m, double *UtX);
 int gemma_hip_lmm_setup_kept(const gemma_lmm_cfg *cfg, const double *UtW, const double *Uty);
@@ -302,6 +302,8 @@ int gemma_hip_dbg_stedc(const double *d, const double *e, size_t n, double *w, d
  * (U^T x_s)^T of the mean-imputed SNP s (the column fast_dgemm("T","N",U,Xlarge) produces, GEMMA src/lmm.cpp:1521).
  * path 0: fp64 MFMA GEMM; path 1: exact int8-digit product (PLINK 2-bit input only, see csrc/i8gemm.hip.h) */
 int gemma_hip_dbg_utx(int geno_kind, const void *geno, size_t l, size_t ld, int path, double *UtX);
+/* base-256 digits of U the exact int8 product uses at this n (7; 6 from n = 16384 up; GEMMA_HIP_I8_DIGITS overrides) */
+int gemma_hip_dbg_i8_digits(size_t n, int *digits);
 
 #ifdef __cplusplus
 }

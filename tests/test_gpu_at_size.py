@@ -115,11 +115,21 @@ def test_config4_shape_unfused_int8_planes_n33000(gpu_api, oracle):
     lmm.setup(U, ev, UtW, Uty, plink=True)
     out = lmm.batch(blk, L.GENO_PLINK_2BIT)
     torch.cuda.synchronize()
+    sample = np.sort(np.random.default_rng(4).choice(B, S, replace=False))
+    raw = blk[torch.from_numpy(sample).to(ch["dev"])].cpu().numpy()
+    utx6 = lmm.dbg_utx(raw[:6], L.GENO_PLINK_2BIT, 1)  # the int8-digit product alone, 6 rows
     lmm.finish()
     got = _sumstat(gpu_api, out)
-    sample = np.sort(np.random.default_rng(4).choice(B, S, replace=False))
-    X = oracle.bed_decode(blk[torch.from_numpy(sample).to(ch["dev"])].cpu().numpy(), n)
-    ref = oracle.lmm_analyze(1, U.cpu().numpy(), ev.cpu().numpy(), UtW.cpu().numpy(), Uty.cpu().numpy(), X,
+    X = oracle.bed_decode(raw, n)
+    Uh = U.cpu().numpy()
+    # at this n the product uses 6 base-256 digits of U (csrc/i8gemm.hip.h): still inside the accuracy bar of
+    # test_utx_int8_digit_product_matches_fp64, in units of sum_k |x_k||u_k|
+    Xi6 = oracle.impute_mean(X[:6])
+    exact = (Xi6.astype(np.longdouble) @ Uh.astype(np.longdouble)).astype(np.float64)
+    err8 = float(np.max(np.abs(utx6 - exact) / (np.abs(Xi6) @ np.abs(Uh))))
+    _record("U^T x int8-digit product at n=%d: max err %.2e in units of sum|x||u| (bar 1.84e-15)" % (n, err8))
+    assert err8 < 8 * 2.3e-16, err8
+    ref = oracle.lmm_analyze(1, Uh, ev.cpu().numpy(), UtW.cpu().numpy(), Uty.cpu().numpy(), X,
                              plink_nan_rule=1)
     assert np.isfinite(got["p_wald"]).mean() > 0.99
     _cmp_stats(got[sample], ref, 1, "config4-shape n=33000 (unfused int8 planes)")
