@@ -233,9 +233,61 @@ inline size_t read_bed_rows(std::ifstream &infile, const std::vector<int> &indic
   return l;
 }
 
+// SNP sharding over ranks (SURVEY 8e, one process per GPU): rank r of w analyses the analysed SNPs
+// [r * ceil(p / w), (r + 1) * ceil(p / w)) -- contiguous, so that every rank reads one contiguous range of the genotype
+// file and the per-rank .assoc.txt parts concatenate in rank order (gemma_amd/dist.py: shard_range is the same rule)
+inline void shard_range(size_t p, int rank, int world, size_t &begin, size_t &end) {
+  const size_t per = world > 0 ? (p + (size_t)world - 1) / (size_t)world : p;
+  begin = std::min(p, per * (size_t)rank);
+  end = std::min(p, begin + per);
+}
+
+// restricts a 0/1 keep vector to the share of `rank` (the k-th kept entry stays iff k lies in shard_range)
+inline void shard_keep(std::vector<int> &keep, int rank, int world) {
+  if (world <= 1) return;
+  size_t p = 0, b, e, k = 0;
+  for (int v : keep) p += v != 0;
+  shard_range(p, rank, world, b, e);
+  for (size_t t = 0; t < keep.size(); ++t)
+    if (keep[t]) {
+      if (k < b || k >= e) keep[t] = 0;
+      ++k;
+    }
+}
+
+// The device-resident chain (gemma_hip.h: kin_end_keep -> eigh_kept_K -> calc_utx_kept -> lmm_setup_kept): how a kinship
+// routine ends.  keep: K stays on the device (matrix_kin->data may be null, size1 must be ni_total); with world > 1 this
+// rank accumulates only ITS share of the analysed SNPs and the partial sums are all-reduced (ncclAllReduce) in kin_end_keep.
+struct KinKeep {
+  bool keep = false;
+  int rank = 0, world = 1;
+};
+inline void kin_finish(Matrix *matrix_kin, const KinKeep &kk, const char *who) {
+  size_t ns = 0;
+  if (kk.keep)
+    enforce_hip(gemma_hip_kin_end_keep(&ns, kk.world > 1 ? 1 : 0), who);
+  else
+    enforce_hip(gemma_hip_kin_end(matrix_kin->data, &ns), who);
+}
+// EigenDecomp_Zeroed on the kept K: rows / columns of the analysed individuals, CenterMatrix, eigendecomposition, all on
+// the device; eval comes back (U stays: CalcUtXKept / LMM::kept_U), returns trace_G
+inline double EigenDecompKept(const std::vector<int> &indicator_idv, Vector *eval) {
+  double tr = 0.0;
+  enforce_hip(gemma_hip_eigh_kept_K(indicator_idv.data(), indicator_idv.size(), eval->data, &tr), "EigenDecomp_Zeroed (kept K)");
+  return tr;
+}
+// CalcUtX on the kept U
+inline void CalcUtXKept(const Matrix *X, Matrix *UtX) {
+  if (X->tda != X->size2 || UtX->tda != UtX->size2 || UtX->size1 != X->size1 || UtX->size2 != X->size2)
+    throw HipError(GEMMA_HIP_EINVAL, "CalcUtX (kept U): contiguous n x m matrices");
+  enforce_hip(gemma_hip_calc_utx_kept(X->data, X->size1, X->size2, UtX->data), "CalcUtX (kept U)");
+}
+
 // PlinkKin, src/gemma_io.cpp:1599-1738: the device decodes, imputes, centres/scales and accumulates
-inline bool PlinkKin(const std::string &file_bed, std::vector<int> &indicator_snp, const int k_mode,
-                     const int /*display_pace*/, Matrix *matrix_kin) {
+inline bool PlinkKin(const std::string &file_bed, std::vector<int> &indicator_snp_in, const int k_mode,
+                     const int /*display_pace*/, Matrix *matrix_kin, const KinKeep &kk = KinKeep()) {
+  std::vector<int> indicator_snp(indicator_snp_in);
+  if (kk.keep) shard_keep(indicator_snp, kk.rank, kk.world);
   std::ifstream infile(file_bed.c_str(), std::ios::binary);
   if (!infile) {
     std::cout << "error reading bed file:" << file_bed << std::endl;
@@ -260,8 +312,7 @@ inline bool PlinkKin(const std::string &file_bed, std::vector<int> &indicator_sn
     if (l == 0) break;
     enforce_hip(gemma_hip_kin_add(GEMMA_GENO_PLINK_2BIT, slot, l, n_bit), "PlinkKin");
   }
-  size_t ns = 0;
-  enforce_hip(gemma_hip_kin_end(matrix_kin->data, &ns), "PlinkKin");
+  kin_finish(matrix_kin, kk, "PlinkKin");
   return true;
 }
 
@@ -440,28 +491,6 @@ inline NullModel CalcLambdaNull(const Vector *eval, const Matrix *UtW, const Vec
   return NullModel{o[0], o[1], o[2], o[3], o[4], o[5], o[6], o[7]};
 }
 
-// SNP sharding over ranks (SURVEY 8e, one process per GPU): rank r of w analyses the analysed SNPs
-// [r * ceil(p / w), (r + 1) * ceil(p / w)) -- contiguous, so that every rank reads one contiguous range of the genotype
-// file and the per-rank .assoc.txt parts concatenate in rank order (gemma_amd/dist.py: shard_range is the same rule)
-inline void shard_range(size_t p, int rank, int world, size_t &begin, size_t &end) {
-  const size_t per = world > 0 ? (p + (size_t)world - 1) / (size_t)world : p;
-  begin = std::min(p, per * (size_t)rank);
-  end = std::min(p, begin + per);
-}
-
-// restricts a 0/1 keep vector to the share of `rank` (the k-th kept entry stays iff k lies in shard_range)
-inline void shard_keep(std::vector<int> &keep, int rank, int world) {
-  if (world <= 1) return;
-  size_t p = 0, b, e, k = 0;
-  for (int v : keep) p += v != 0;
-  shard_range(p, rank, world, b, e);
-  for (size_t t = 0; t < keep.size(); ++t)
-    if (keep[t]) {
-      if (k < b || k >= e) keep[t] = 0;
-      ++k;
-    }
-}
-
 // class LMM, src/lmm.h:49-125 -- the members CopyFromParam fills (src/lmm.cpp:56-90) and the drivers
 class LMM {
 public:
@@ -479,16 +508,39 @@ public:
   std::set<std::string> setGWASnps; // -loco / -gwasnps: the SNPs tested (src/lmm.cpp:87,1585-1587); empty = all
 
   int shard_rank = 0, shard_world = 1; // multi-GPU: this process analyses (and writes) its contiguous share of the SNPs
+  bool kept_U = false;                 // U / eval are the library's kept ones (EigenDecompKept / kept_bcast): U->data is not read
 
   // the SNPs Analyze visits: indicator_snp, with -loco only the members of setGWASnps (src/lmm.cpp:1578-1587), and of
   // those the share of this rank
-  std::vector<int> analysed_snps() const {
+  std::vector<int> analysed_snps(bool this_rank_only = true) const {
     std::vector<int> keep(indicator_snp);
     if (!setGWASnps.empty())
       for (size_t t = 0; t < keep.size() && t < snpInfo.size(); ++t)
         if (keep[t] && setGWASnps.count(snpInfo[t].rs_number) == 0) keep[t] = 0;
-    shard_keep(keep, shard_rank, shard_world);
+    if (this_rank_only) shard_keep(keep, shard_rank, shard_world);
     return keep;
+  }
+
+  // AnalyzePlink prints the PREVIOUS SNP's beta / se for a SNP whose lambda search failed (function-scope variables,
+  // src/lmm.cpp:1725,1870-1884), so a shard must start with the carry the unsharded run has at its first SNP.  A
+  // successful SNP overwrites the library's carry with its own values and a failed one leaves it alone: analysing the
+  // analysed SNPs BEFORE the shard, backwards, one at a time and with the results discarded, until one succeeds (almost
+  // always the first) leaves exactly that state.  (gemma_amd/dist.py: seed_plink_carry is the same rule.)
+  void seed_plink_carry(std::ifstream &infile, const std::vector<int> &keep_mine, size_t n_bit) {
+    const std::vector<int> all = analysed_snps(false);
+    size_t first = 0;
+    while (first < keep_mine.size() && !keep_mine[first]) ++first;
+    std::vector<unsigned char> row(n_bit);
+    gemma_sumstat o;
+    for (size_t t = first; t-- > 0;) {
+      if (!all[t]) continue;
+      infile.seekg((std::streamoff)(3 + t * n_bit));
+      infile.read(reinterpret_cast<char *>(row.data()), (std::streamsize)n_bit);
+      if ((size_t)infile.gcount() != n_bit) throw std::runtime_error("error reading genotype (.bed) file (truncated)");
+      enforce_hip(gemma_hip_lmm_batch(GEMMA_GENO_PLINK_2BIT, row.data(), 1, n_bit, &o), "AnalyzePlink (carry)");
+      if (o.logl_H1 == o.logl_H1) break; // not NaN: this SNP's beta / se are the carry now
+    }
+    infile.clear();
   }
 
   // AnalyzePlink, src/lmm.cpp:1710-1903: raw .bed rows go to the device (decode, drop, impute there)
@@ -503,6 +555,7 @@ public:
     std::vector<gemma_sumstat> out(B);
     size_t t_next = 0;
     const std::vector<int> keep = analysed_snps();
+    if (shard_world > 1 && shard_rank > 0 && a_mode == 1) seed_plink_carry(infile, keep, n_bit);
     // the .bed rows of block k+1 are read by a host thread while block k is on the device
     BlockPrefetch pf(B * n_bit, [&](void *slot, int) {
       return read_bed_rows(infile, keep, t_next, n_bit, static_cast<unsigned char *>(slot), B);
@@ -686,14 +739,17 @@ public:
 
 private:
   void setup(const Matrix *U, const Vector *eval, const Matrix *UtW, const Vector *Uty, int plink) {
-    if (U->tda != U->size2 || UtW->tda != UtW->size2 || eval->stride != 1 || Uty->stride != 1)
+    if ((!kept_U && U->tda != U->size2) || UtW->tda != UtW->size2 || eval->stride != 1 || Uty->stride != 1)
       throw HipError(GEMMA_HIP_EINVAL, "LMM: contiguous U/UtW/eval/Uty required");
     ni_test = U->size1;
     n_cvt = UtW->size2;
     gemma_lmm_cfg cfg;
     cfg.a_mode = a_mode; cfg.n = ni_test; cfg.n_cvt = n_cvt; cfg.l_min = l_min; cfg.l_max = l_max;
     cfg.n_region = n_region; cfg.l_mle_null = l_mle_null; cfg.logl_mle_H0 = logl_mle_H0; cfg.plink_nan_rule = plink;
-    enforce_hip(gemma_hip_lmm_setup(&cfg, U->data, eval->data, UtW->data, Uty->data), "LMM::Analyze");
+    if (kept_U)
+      enforce_hip(gemma_hip_lmm_setup_kept(&cfg, UtW->data, Uty->data), "LMM::Analyze");
+    else
+      enforce_hip(gemma_hip_lmm_setup(&cfg, U->data, eval->data, UtW->data, Uty->data), "LMM::Analyze");
     sumStat.clear();
   }
   // batch_compute, src/lmm.cpp:1513-1564
@@ -836,6 +892,7 @@ public:
   std::vector<SNPINFO> snpInfo;
   std::vector<double> sumStat;
   int shard_rank = 0, shard_world = 1; // as in class LMM
+  bool kept_U = false;                 // as in class LMM
   std::vector<int> analysed_snps() const {
     std::vector<int> keep(indicator_snp);
     shard_keep(keep, shard_rank, shard_world);
@@ -943,7 +1000,7 @@ public:
 private:
   // the null block (src/mvlmm.cpp:3056-3208) and the per-SNP loop's state
   void setup(const Matrix *U, const Vector *eval, const Matrix *UtW, const Matrix *UtY, int plink) {
-    if (U->tda != U->size2 || UtW->tda != UtW->size2 || UtY->tda != UtY->size2 || eval->stride != 1)
+    if ((!kept_U && U->tda != U->size2) || UtW->tda != UtW->size2 || UtY->tda != UtY->size2 || eval->stride != 1)
       throw HipError(GEMMA_HIP_EINVAL, "MVLMM: contiguous U/UtW/UtY/eval required");
     ni_test = U->size1;
     n_cvt = UtW->size2;
@@ -959,7 +1016,10 @@ private:
     cfg.n_region = n_region; cfg.l_mle_null = 0; cfg.logl_mle_H0 = 0; cfg.plink_nan_rule = plink;
     std::vector<double> y0(ni_test); // the univariate Uty slot is not read by the multivariate path
     for (size_t i = 0; i < ni_test; ++i) y0[i] = UtY->data[i * UtY->tda];
-    enforce_hip(gemma_hip_lmm_setup(&cfg, U->data, eval->data, UtW->data, y0.data()), "MVLMM::Analyze");
+    if (kept_U)
+      enforce_hip(gemma_hip_lmm_setup_kept(&cfg, UtW->data, y0.data()), "MVLMM::Analyze");
+    else
+      enforce_hip(gemma_hip_lmm_setup(&cfg, U->data, eval->data, UtW->data, y0.data()), "MVLMM::Analyze");
     enforce_hip(gemma_hip_mvlmm_set(n_ph, UtY->data, &null_fit, &opt), "MVLMM::Analyze");
     sumStat.clear();
   }

@@ -865,11 +865,12 @@ inline void LOCO_set_Snps(std::set<std::string> &ksnps, std::set<std::string> &g
 // ksnps only its members, :1478-1480 -- snpInfo supplies the rs of every file line from the first pass)
 inline bool BimbamKinThreaded(const std::string &file_geno, const std::vector<int> &indicator_snp_in, const int k_mode,
                               Matrix *matrix_kin, const std::set<std::string> &ksnps = std::set<std::string>(),
-                              const std::vector<SNPINFO> *snpInfo = nullptr) {
+                              const std::vector<SNPINFO> *snpInfo = nullptr, const KinKeep &kk = KinKeep()) {
   std::vector<int> indicator_snp(indicator_snp_in);
   if (!ksnps.empty() && snpInfo)
     for (size_t t = 0; t < indicator_snp.size() && t < snpInfo->size(); ++t)
       if (indicator_snp[t] && ksnps.count((*snpInfo)[t].rs_number) == 0) indicator_snp[t] = 0;
+  if (kk.keep) shard_keep(indicator_snp, kk.rank, kk.world);
   const size_t ni_total = matrix_kin->size1;
   BimbamReader rd(file_geno, ni_total);
   if (!rd.ok()) {
@@ -890,8 +891,7 @@ inline bool BimbamKinThreaded(const std::string &file_geno, const std::vector<in
     if (l == 0) break;
     enforce_hip(gemma_hip_kin_add(GEMMA_GENO_F64_SNP_MAJOR, slot, l, ni_total), "BimbamKin");
   }
-  size_t ns = 0;
-  enforce_hip(gemma_hip_kin_end(matrix_kin->data, &ns), "BimbamKin");
+  kin_finish(matrix_kin, kk, "BimbamKin");
   return true;
 }
 

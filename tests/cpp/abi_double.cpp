@@ -24,6 +24,7 @@
 #include <vector>
 
 #include "gemma_hip.h"
+#include "../../gemma_amd/csrc/comm_shm.hpp" // the host shared-memory transport (pure POSIX) the library uses for its tests too
 
 extern "C" {
 typedef struct {
@@ -555,6 +556,134 @@ int gemma_hip_lmm_gxe_batch(int kind, const void *geno, size_t l, size_t ld, gem
   orc_gxe_batch(g_lmm.cfg.a_mode, n, c, g_lmm.eval.data(), g_lmm.UtWe.data(), g_lmm.Uty.data(), UtX.data(), UtZ.data(),
                 flip.data(), l, g_lmm.cfg.l_min, g_lmm.cfg.l_max, g_lmm.cfg.n_region, g_lmm.cfg.l_mle_null,
                 reinterpret_cast<orc_sumstat *>(out));
+  return GEMMA_HIP_OK;
+}
+
+// ---- the device-resident chain and the communicator, on host memory (same semantics as the product's) ----
+namespace {
+struct Kept {
+  std::vector<double> K, U, eval;
+  size_t K_n = 0, n = 0;
+  double trace = 0.0;
+} g_kept;
+struct DoubleComm {
+  int rank = 0, world = 1;
+  bool active = false;
+  gemma_hip::ShmTransport tr;
+} g_comm;
+} // namespace
+
+int gemma_hip_kin_end_keep(size_t *ns_used, int allreduce) {
+  const size_t n = g_kin.n;
+  double ns = (double)g_kin.ns;
+  if (allreduce && g_comm.active && g_comm.world > 1) {
+    g_comm.tr.allreduce_host(g_kin.K.data(), n * n);
+    g_comm.tr.allreduce_host(&ns, 1);
+  }
+  g_kept.K.resize(n * n);
+  for (size_t i = 0; i < n * n; ++i) g_kept.K[i] = g_kin.K[i] / ns;
+  g_kept.K_n = n;
+  if (ns_used) *ns_used = (size_t)(ns + 0.5);
+  return GEMMA_HIP_OK;
+}
+int gemma_hip_kept_K_get(double *K) {
+  if (!g_kept.K_n) return fail(GEMMA_HIP_ESTATE, "kept_K_get: no kept K");
+  std::copy(g_kept.K.begin(), g_kept.K.end(), K);
+  return GEMMA_HIP_OK;
+}
+static int kept_eigh_of(std::vector<double> &G, size_t n, double *eval, double *trace_G) {
+  g_kept.U.assign(n * n, 0.0);
+  g_kept.eval.assign(n, 0.0);
+  double tr = 0.0;
+  const int rc = gemma_hip_eigh(G.data(), n, g_kept.U.data(), g_kept.eval.data(), &tr);
+  if (rc) return rc;
+  g_kept.n = n;
+  g_kept.trace = tr;
+  if (trace_G) *trace_G = tr;
+  if (eval) std::copy(g_kept.eval.begin(), g_kept.eval.end(), eval);
+  return GEMMA_HIP_OK;
+}
+int gemma_hip_eigh_kept_K(const int *indicator_idv, size_t ni_total, double *eval, double *trace_G) {
+  if (!g_kept.K_n || ni_total != g_kept.K_n) return fail(GEMMA_HIP_ESTATE, "eigh_kept_K: no matching kept K");
+  std::vector<size_t> map;
+  for (size_t i = 0; i < ni_total; ++i)
+    if (!indicator_idv || indicator_idv[i]) map.push_back(i);
+  const size_t n = map.size();
+  std::vector<double> G(n * n);
+  for (size_t r = 0; r < n; ++r)
+    for (size_t c = 0; c < n; ++c) G[r * n + c] = g_kept.K[map[r] * ni_total + map[c]];
+  orc_CenterMatrix(G.data(), n);
+  return kept_eigh_of(G, n, eval, trace_G);
+}
+int gemma_hip_eigh_keep(const double *G, size_t n, double *eval, double *trace_G) {
+  std::vector<double> Gc(G, G + n * n);
+  return kept_eigh_of(Gc, n, eval, trace_G);
+}
+int gemma_hip_kept_n(size_t *n) {
+  if (n) *n = g_kept.n;
+  return GEMMA_HIP_OK;
+}
+int gemma_hip_kept_bcast(int root, double *trace_G) {
+  if (g_comm.active && g_comm.world > 1) {
+    double hdr[2] = {(double)g_kept.n, g_kept.trace};
+    g_comm.tr.bcast_host(hdr, 16, root);
+    const size_t n = (size_t)(hdr[0] + 0.5);
+    if (g_comm.rank != root) {
+      g_kept.U.assign(n * n, 0.0);
+      g_kept.eval.assign(n, 0.0);
+      g_kept.n = n;
+      g_kept.trace = hdr[1];
+    }
+    g_comm.tr.bcast_host(g_kept.U.data(), n * n * 8, root);
+    g_comm.tr.bcast_host(g_kept.eval.data(), n * 8, root);
+  }
+  if (trace_G) *trace_G = g_kept.trace;
+  return GEMMA_HIP_OK;
+}
+int gemma_hip_kept_U_get(double *U, double *eval) {
+  if (!g_kept.n) return fail(GEMMA_HIP_ESTATE, "kept_U_get: no kept U");
+  if (U) std::copy(g_kept.U.begin(), g_kept.U.end(), U);
+  if (eval) std::copy(g_kept.eval.begin(), g_kept.eval.end(), eval);
+  return GEMMA_HIP_OK;
+}
+int gemma_hip_calc_utx_kept(const double *X, size_t n, size_t m, double *UtX) {
+  if (!g_kept.n || n != g_kept.n) return fail(GEMMA_HIP_ESTATE, "calc_utx_kept: no matching kept U");
+  return gemma_hip_dgemm('T', 'N', n, m, n, 1.0, g_kept.U.data(), n, X, m, 0.0, UtX, m);
+}
+int gemma_hip_lmm_setup_kept(const gemma_lmm_cfg *cfg, const double *UtW, const double *Uty) {
+  if (!g_kept.n || cfg->n != g_kept.n) return fail(GEMMA_HIP_ESTATE, "lmm_setup_kept: no matching kept U");
+  return gemma_hip_lmm_setup(cfg, g_kept.U.data(), g_kept.eval.data(), UtW, Uty);
+}
+int gemma_hip_kept_release(void) {
+  g_kept = Kept();
+  return GEMMA_HIP_OK;
+}
+
+int gemma_hip_comm_unique_id(void *id) {
+  gemma_hip::ShmTransport::make_id(id);
+  return GEMMA_HIP_OK;
+}
+int gemma_hip_comm_init(const void *id, int rank, int world) {
+  g_comm.rank = rank;
+  g_comm.world = world;
+  g_comm.active = true;
+  if (world > 1) {
+    std::string err;
+    if (!g_comm.tr.open(id, rank, world, err)) return fail(GEMMA_HIP_ERUNTIME, err.c_str());
+  }
+  return GEMMA_HIP_OK;
+}
+int gemma_hip_comm_info(int *rank, int *world, int *transport) {
+  if (rank) *rank = g_comm.rank;
+  if (world) *world = g_comm.world;
+  if (transport) *transport = g_comm.world > 1 ? 2 : 0;
+  return GEMMA_HIP_OK;
+}
+int gemma_hip_comm_finalize(void) {
+  if (g_comm.tr.is_open()) g_comm.tr.close_segment();
+  g_comm.active = false;
+  g_comm.rank = 0;
+  g_comm.world = 1;
   return GEMMA_HIP_OK;
 }
 }

@@ -4,10 +4,14 @@
 //   gemma_file_driver (-g geno[.gz] -p pheno [-a anno] | -bfile prefix) [-c cvt] [-n col [col ...]]
 //                     (-gk [1|2] | -k kin (-eigen | -lmm [1|2|3|4|9]) | -d eigenD -u eigenU -lmm m | -lm [1|2|3|4])
 //                     [-maf x] [-miss x] [-hwe x] [-r2 x] [-loco chr] [-gxe env] [-snps list] [-notsnp] [-km 2] [-o name] [-outdir dir]
-//   gemma_file_driver ... -lmm m -gpus N [-samegpu]    one process per GPU: every rank repeats the run-once stages
-//                     (first pass, kinship file, eigendecomposition: "replicas only" for those) and analyses its contiguous
-//                     share of the SNPs; the parent concatenates the per-rank parts in rank order into <o>.assoc.txt.
-//                     (-samegpu puts every rank on device 0: a test hook for 1-GPU boxes)
+//   gemma_file_driver ... -lmm m -gpus N [-samegpu]    one process per GPU over RCCL.  Every rank reads the
+//                     small files and makes the first pass; with -inproc the kinship is SNP-SHARDED (each rank accumulates its
+//                     share of the SNPs, ONE ncclAllReduce of the n^2 sums); the eigendecomposition runs on rank 0 ONLY and
+//                     (U, eval) reach the other ranks in ONE ncclBroadcast (with -k likewise: rank 0 alone reads the kinship
+//                     file); every rank analyses its contiguous share of the SNPs; the parent concatenates the per-rank parts
+//                     in rank order into <o>.assoc.txt.  The communicator id travels over a pipe opened before the fork.
+//                     (-samegpu puts every rank on device 0 and selects the library's shared-memory test transport,
+//                     GEMMA_HIP_COMM=shm -- RCCL refuses two ranks on one device: a test hook for 1-GPU boxes)
 //   gemma_file_driver -gene expr.txt -p pheno -k kin -lmm m        every row of expr.txt is a phenotype (LMM::AnalyzeGene)
 //   gemma_file_driver -bfile prefix -inproc [1|2] -lmm m ...   kinship, eigendecomposition and association in ONE
 //                     process: K never becomes text; wall seconds of every stage on the log line
@@ -83,8 +87,18 @@ int main(int argc, char **argv) {
       return 2;
     }
   }
+  std::vector<int> id_pipe_r, id_pipe_w; // rank 0 -> rank r: the 128-byte communicator id
   if (gpus > 1 && (a_mode || lm_mode) && !k_mode && !do_eigen && file_gene.empty()) {
     // one process per GPU, forked before anything touches the device; rank r writes <o>.rank<r>.assoc.txt
+    if (samegpu) setenv("GEMMA_HIP_COMM", "shm", 1);
+    id_pipe_r.assign(gpus, -1);
+    id_pipe_w.assign(gpus, -1);
+    for (int r = 1; r < gpus; ++r) {
+      int fd[2];
+      if (pipe(fd) != 0) return 6;
+      id_pipe_r[r] = fd[0];
+      id_pipe_w[r] = fd[1];
+    }
     std::vector<pid_t> kids;
     for (int r = 0; r < gpus; ++r) {
       const pid_t pid = fork();
@@ -121,6 +135,17 @@ int main(int argc, char **argv) {
   }
   try {
     enforce_hip(gemma_hip_init(device, 0), "init");
+    if (gpus > 1) { // the communicator: rank 0 makes the id, the pipes carry it
+      unsigned char id[GEMMA_HIP_COMM_ID_BYTES];
+      if (rank == 0) {
+        enforce_hip(gemma_hip_comm_unique_id(id), "comm_unique_id");
+        for (int r = 1; r < gpus; ++r)
+          if (write(id_pipe_w[r], id, sizeof id) != (ssize_t)sizeof id) return 6;
+      } else if (read(id_pipe_r[rank], id, sizeof id) != (ssize_t)sizeof id) {
+        return 6;
+      }
+      enforce_hip(gemma_hip_comm_init(id, rank, gpus), "comm_init");
+    }
     // ---- PARAM::ReadFiles ---------------------------------------------------------------------------------------
     CvtPhen cp;
     std::vector<SNPINFO> snpInfo;
@@ -225,30 +250,38 @@ int main(int argc, char **argv) {
     }
 
     // ---- eigen pairs: from -k (centre + decompose) or from -d / -u ------------------------------------------------
-    std::vector<double> Ub(ni_test * ni_test), evalb(ni_test);
-    Matrix U = matrix_view(Ub.data(), ni_test, ni_test);
-    Vector eval = vector_view(evalb.data(), ni_test);
+    // With -inproc, and with -k on several GPUs, U and eval stay on the device (the library's kept chain): U is then an
+    // empty view and cLmm.kept_U says so; only -eigen copies them out.
+    std::vector<double> Ub, evalb(ni_test);
+    bool kept = false;
     double trace_G = 0.0;
     bool error = false;
-    if (inproc) { // -gk and -lmm in one process: K stays binary (changes K at the 1e-10 level)
-      std::vector<double> Kb(ni_total * ni_total, 0.0), Gb(ni_test * ni_test);
-      Matrix K = matrix_view(Kb.data(), ni_total, ni_total), G = matrix_view(Gb.data(), ni_test, ni_test);
-      const bool ok = file_bfile.empty() ? BimbamKinThreaded(file_geno, indicator_snp, inproc, &K, setKSnps, &snpInfo)
-                                         : PlinkKin(file_bfile + ".bed", indicator_snp, inproc, 0, &K);
+    Vector eval = vector_view(evalb.data(), ni_test);
+    if (inproc) { // -gk and -lmm in one process: K stays binary AND on the device (changes K at the 1e-10 level)
+      Matrix K = matrix_view(nullptr, ni_total, ni_total);
+      KinKeep kk;
+      kk.keep = true; kk.rank = rank; kk.world = gpus;
+      const bool ok = file_bfile.empty() ? BimbamKinThreaded(file_geno, indicator_snp, inproc, &K, setKSnps, &snpInfo, kk)
+                                         : PlinkKin(file_bfile + ".bed", indicator_snp, inproc, 0, &K, kk);
       if (!ok) return 4;
       std::cout << " t_kinship=" << lap();
-      size_t r = 0;
-      for (size_t i = 0; i < ni_total; ++i) { // the sub-selection ReadFile_kin does (src/gemma_io.cpp:1205-1243)
-        if (!cp.indicator_idv[i]) continue;
-        size_t c = 0;
-        for (size_t j = 0; j < ni_total; ++j)
-          if (cp.indicator_idv[j]) Gb[r * ni_test + c++] = Kb[i * ni_total + j];
-        ++r;
-      }
-      CenterMatrix(&G);
-      trace_G = EigenDecomp_Zeroed(&G, &U, &eval, 0);
+      if (rank == 0) trace_G = EigenDecompKept(cp.indicator_idv, &eval); // sub-selection, centring, eigendecomposition
+      kept = true;
       std::cout << " t_eigen=" << lap();
+    } else if (!file_kin.empty() && gpus > 1) {
+      if (rank == 0) { // rank 0 alone reads the kinship file and decomposes
+        std::vector<double> Gb(ni_test * ni_test);
+        Matrix G = matrix_view(Gb.data(), ni_test, ni_test);
+        if (km == 2) ReadFile_kin_km2(file_kin, cp.indicator_idv, mapID2num, error, &G);
+        else ReadFile_kin_threaded(file_kin, cp.indicator_idv, error, &G);
+        if (error) return 5;
+        CenterMatrix(&G);
+        enforce_hip(gemma_hip_eigh_keep(G.data, ni_test, evalb.data(), &trace_G), "EigenDecomp_Zeroed (kept)");
+      }
+      kept = true;
     } else if (!file_kin.empty()) {
+      Ub.resize(ni_test * ni_test);
+      Matrix U1 = matrix_view(Ub.data(), ni_test, ni_test);
       std::vector<double> Gb(ni_test * ni_test);
       Matrix G = matrix_view(Gb.data(), ni_test, ni_test);
       if (km == 2) ReadFile_kin_km2(file_kin, cp.indicator_idv, mapID2num, error, &G);
@@ -256,10 +289,12 @@ int main(int argc, char **argv) {
       if (error) return 5;
       CenterMatrix(&G);
       const double t_e0 = lap();
-      trace_G = EigenDecomp_Zeroed(&G, &U, &eval, 0);
+      trace_G = EigenDecomp_Zeroed(&G, &U1, &eval, 0);
       log.time_eigen = (lap() - t_e0) / 60.0;
     } else if (!file_kd.empty() && !file_ku.empty()) {
-      ReadFile_eigenU_threaded(file_ku, error, &U);
+      Ub.resize(ni_test * ni_test);
+      Matrix U1 = matrix_view(Ub.data(), ni_test, ni_test);
+      ReadFile_eigenU_threaded(file_ku, error, &U1);
       ReadFile_eigenD(file_kd, error, &eval);
       if (error) return 5;
       for (size_t i = 0; i < ni_test; ++i) { // src/gemma.cpp:2640-2647
@@ -271,6 +306,15 @@ int main(int argc, char **argv) {
       std::cerr << "need -gk, -inproc, -k or -d/-u" << std::endl;
       return 2;
     }
+    if (kept && gpus > 1) { // the ONE broadcast of (U, eval); the other ranks then fetch eval (n doubles) for the null model
+      enforce_hip(gemma_hip_kept_bcast(0, &trace_G), "kept_bcast");
+      if (rank != 0) enforce_hip(gemma_hip_kept_U_get(nullptr, evalb.data()), "kept_U_get");
+    }
+    if (kept && do_eigen) { // -eigen wants the artefacts on disk
+      Ub.resize(ni_test * ni_test);
+      enforce_hip(gemma_hip_kept_U_get(Ub.data(), nullptr), "kept_U_get");
+    }
+    Matrix U = matrix_view(Ub.empty() ? nullptr : Ub.data(), ni_test, ni_test);
     std::cout << " trace_G=" << std::setprecision(12) << trace_G;
     if (do_eigen) { // src/gemma.cpp:1779-1800
       if (!WriteEigen(&U, &eval, path_out, file_out)) return 5;
@@ -287,8 +331,13 @@ int main(int argc, char **argv) {
     std::vector<double> UtWb(ni_test * n_cvt), Utyb(ni_test * n_ph);
     Matrix Y = matrix_view(Yb.data(), ni_test, n_ph), UtW = matrix_view(UtWb.data(), ni_test, n_cvt),
            UtY = matrix_view(Utyb.data(), ni_test, n_ph);
-    CalcUtX(&U, &W, &UtW);
-    CalcUtX(&U, &Y, &UtY);
+    if (kept) {
+      CalcUtXKept(&W, &UtW);
+      CalcUtXKept(&Y, &UtY);
+    } else {
+      CalcUtX(&U, &W, &UtW);
+      CalcUtX(&U, &Y, &UtY);
+    }
     if (n_ph > 1) { // src/gemma.cpp:2796-2830: MVLMM
       MVLMM cMv;
       cMv.file_geno = file_geno;
@@ -302,6 +351,7 @@ int main(int argc, char **argv) {
       cMv.snpInfo = std::move(snpInfo);
       cMv.shard_rank = rank;
       cMv.shard_world = gpus;
+      cMv.kept_U = kept;
       const double t_a0 = lap();
       if (!file_bfile.empty()) cMv.AnalyzePlink(&U, &eval, &UtW, &UtY);
       else AnalyzeBimbam(cMv, &U, &eval, &UtW, &UtY);
@@ -334,6 +384,7 @@ int main(int argc, char **argv) {
     cLmm.setGWASnps = setGWASnps;
     cLmm.shard_rank = rank;
     cLmm.shard_world = gpus;
+    cLmm.kept_U = kept;
     cLmm.l_mle_null = nm.l_mle_null;
     cLmm.logl_mle_H0 = nm.logl_mle_H0;
     const double t_a0 = lap();

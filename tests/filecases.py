@@ -485,3 +485,31 @@ def standardised_kinship_workflow(exe, out):
     drive(exe, *base, "-gk", 2, "-o", "BXD2")
     S = np.loadtxt(os.path.join(out, "BXD2.sXX.txt"))
     assert S.shape == (198, 198) and np.abs(S[:24, :24] - np.loadtxt(os.path.join(TXT, "BXD.sXX.corner.txt"))).max() <= 2e-10
+
+
+def sharded_inproc_workflow(exe, out, world=2, samegpu=False):
+    """SURVEY 8e through the C++ host layer with the collectives in: `-inproc 1 -lmm m -gpus N` = every rank accumulates
+    the kinship of ITS share of the SNPs, one all-reduce (gemma_hip_kin_end_keep), rank 0 alone runs the eigensolver on the
+    kept K, one broadcast of (U, eval) (gemma_hip_kept_bcast), every rank analyses its SNP share; `-k K -lmm m -gpus N` =
+    rank 0 alone reads the kinship file and decomposes, one broadcast.  Against the single-process `-inproc` run (the
+    kinship sums are added in another order: statistics to the printed digits, not byte for byte); the kinship-file route
+    also against the reference's own file."""
+    out = str(out)
+    same = ["-samegpu"] if samegpu else []
+    base = ["-bfile", os.path.join(TXT, "P"), "-outdir", out]
+    kv1 = drive(exe, *base, "-inproc", 1, "-lmm", 4, "-o", "in1")
+    kvN = drive(exe, *base, "-inproc", 1, "-lmm", 4, "-gpus", world, *same, "-o", "inN")
+    assert int(kvN["ranks"]) == world and int(kv1["snps"]) > 0
+    compare_assoc(os.path.join(out, "inN.assoc.txt"), os.path.join(out, "in1.assoc.txt"))
+    # mode 1 on PLINK input: the shard of rank > 0 seeds AnalyzePlink's beta / se carry (LMM::seed_plink_carry)
+    drive(exe, *base, "-inproc", 1, "-lmm", 1, "-o", "w1")
+    drive(exe, *base, "-inproc", 1, "-lmm", 1, "-gpus", world, *same, "-o", "wN")
+    compare_assoc(os.path.join(out, "wN.assoc.txt"), os.path.join(out, "w1.assoc.txt"))
+    # the kinship-file route: rank 0 reads and decomposes, (U, eval) are broadcast -- same file as one process, byte for byte
+    drive(exe, *base, "-gk", "-o", "P")
+    cxx = os.path.join(out, "P.cXX.txt")
+    drive(exe, *base, "-k", cxx, "-lmm", 4, "-o", "k1")
+    drive(exe, *base, "-k", cxx, "-lmm", 4, "-gpus", world, *same, "-o", "kN")
+    assert open(os.path.join(out, "kN.assoc.txt"), "rb").read() == open(os.path.join(out, "k1.assoc.txt"), "rb").read()
+    compare_assoc(os.path.join(out, "kN.assoc.txt"), os.path.join(TXT, "P4.assoc.txt.gz"))  # and the reference's own file
+    assert not [f for f in os.listdir(out) if ".rank" in f]

@@ -255,6 +255,14 @@ def test_snp_sharded_ranks_lm_and_multivariate(driver, tmp_path, monkeypatch):
     assert len(open(os.path.join(out, "mv1.assoc.txt")).read().strip().split("\n")) == 601
 
 
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_kinship_allreduce_and_eigen_broadcast(driver, tmp_path, world):
+    """`-inproc 1 -gpus N` and `-k K -gpus N` through the communicator entry points of the C ABI (the double runs them over
+    the host shared-memory transport the library itself uses for its 1-GPU tests): SNP-sharded kinship + all-reduce, rank-0
+    eigendecomposition + ONE broadcast of (U, eval), SNP-sharded association."""
+    fc.sharded_inproc_workflow(driver, tmp_path, world=world)
+
+
 def test_shard_range_rule_matches_the_python_side():
     from gemma_amd.dist import shard_range
     for p in (0, 1, 7, 574, 1000001):

@@ -69,3 +69,35 @@ def test_mvlmm_three_traits_missing_phenotypes(driver, tmp_path):
 
 def test_standardised_kinship_from_text(driver, tmp_path):
     fc.standardised_kinship_workflow(driver, tmp_path)
+
+
+def test_two_ranks_on_one_device_kinship_allreduce_eigen_broadcast(driver, tmp_path):
+    """The N > 1 protocol of the C++ host with the REAL kernels: two ranks on device 0 (-samegpu: the library's
+    shared-memory test transport stands in for RCCL, which refuses two ranks on one device), SNP-sharded kinship with the
+    all-reduce, rank-0 eigensolver, one broadcast of the kept (U, eval), SNP-sharded association with the carry seeded."""
+    fc.sharded_inproc_workflow(driver, tmp_path, world=2, samegpu=True)
+
+
+def test_rccl_entry_points_single_rank(driver):
+    """ncclGetUniqueId / ncclCommInitRank / ncclBroadcast / ncclAllReduce through the library on the one device there is:
+    a communicator of one rank over the real librccl (dlopen), broadcast and all-reduce are then the identity."""
+    import ctypes as C
+    import torch
+    from gemma_amd import api, _lib as L
+    api.init(0)
+    lib = L.lib()
+    ident = C.create_string_buffer(L.COMM_ID_BYTES)
+    import os as _os
+    _os.environ.pop("GEMMA_HIP_COMM", None)
+    L.check(lib.gemma_hip_comm_unique_id(ident), "comm_unique_id")
+    assert any(b != 0 for b in ident.raw)
+    L.check(lib.gemma_hip_comm_init(ident, 0, 1), "comm_init")
+    x = torch.arange(1000, dtype=torch.float64, device="cuda")
+    L.check(lib.gemma_hip_comm_bcast_d(C.c_void_p(x.data_ptr()), x.numel() * 8, 0, None), "bcast")
+    L.check(lib.gemma_hip_comm_allreduce_sum_d(C.c_void_p(x.data_ptr()), x.numel(), None), "allreduce")
+    torch.cuda.synchronize()
+    assert torch.equal(x.cpu(), torch.arange(1000, dtype=torch.float64))
+    r, w, t = C.c_int(), C.c_int(), C.c_int()
+    lib.gemma_hip_comm_info(C.byref(r), C.byref(w), C.byref(t))
+    assert (r.value, w.value) == (0, 1)
+    L.check(lib.gemma_hip_comm_finalize(), "comm_finalize")
