@@ -192,9 +192,19 @@ def main():
         setup_info["null"] = {k: nm[k] for k in ("l_remle_null", "pve")}
         api.profile_read(L.STAGE_UTX_GEMM, reset=True)
     t0 = time.time()
-    gdist.broadcast_state([U, ev, UtW, Uty, null])  # the single RCCL broadcast
+    # the single broadcast round: ncclBroadcast issued by the library's own RCCL communicator (csrc/comm.hip.h) when every
+    # rank could create it, otherwise the same two collectives through torch.distributed (nccl = RCCL as well)
+    bpath = "none (1 rank)"
+    if world > 1:
+        if os.environ.get("BENCH_DIST_BACKEND", "nccl") == "nccl" and gdist.native_comm_init():
+            gdist.broadcast_state_native([U, ev, UtW, Uty, null])
+            bpath = "native: ncclBroadcast from libgemma_hip.so's communicator"
+        else:
+            gdist.broadcast_state([U, ev, UtW, Uty, null])
+            bpath = "torch.distributed broadcast (%s)" % os.environ.get("BENCH_DIST_BACKEND", "nccl")
     torch.cuda.synchronize()
     setup_info["broadcast_s"] = round(time.time() - t0, 3)
+    setup_info["broadcast"] = bpath
 
     blocks = [synth_block(torch, n, B, gen, dev) for _ in range(args.steps + args.warmup)]
     out = torch.empty((B, 8), dtype=torch.float64, device=dev)

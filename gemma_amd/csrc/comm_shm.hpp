@@ -2,7 +2,7 @@
 // processes of one node: a POSIX segment named by the communicator id, one payload slot per rank, a process-shared
 // barrier.  TEST transport only (GEMMA_HIP_COMM=shm): RCCL refuses two ranks on one device, so this is what lets
 // `-gpus 2 -samegpu` and the 2-rank tests run the real protocol on a 1-GPU box; tests/cpp/abi_double.cpp (the
-// oracle-backed test double of the C ABI) uses it too, on host arrays.  Pure POSIX: no HIP here.
+// CPU test double of the C ABI) uses it too, on host arrays.  Pure POSIX: no HIP here.
 #pragma once
 #include <fcntl.h>
 #include <pthread.h>

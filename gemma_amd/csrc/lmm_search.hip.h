@@ -1,5 +1,5 @@
 // The lambda search of one SNP as plain C++ that compiles for the device (hipcc) AND for the host (g++: the CPU
-// test harness tests/cpp/cheb_search_check.cpp runs this very code against the oracle).
+// test harness tests/cpp/cheb_search_check.cpp runs this very code against the reference restatement under tests).
 //
 //  (1) GSL's root finders as CalcLambda uses them (GEMMA src/lmm.cpp:2024-2102): roots/brent.c, roots/newton.c and
 //      roots/convergence.c restated over an evaluator object E { bool dev1(l, &d1); bool dev12(l, &d1, &d2); } whose

@@ -63,6 +63,68 @@ def broadcast_state(tensors, src=0, group=None, small_limit=1 << 22):
     return tensors
 
 
+_native_ready = False
+
+
+def native_comm_init(group=None):
+    """Bootstrap the LIBRARY's own RCCL communicator (csrc/comm.hip.h: ncclGetUniqueId on rank 0, the 128-byte id shipped
+    through torch.distributed's store, ncclCommInitRank on every rank's device).  Every rank learns whether ALL ranks
+    succeeded (one MIN all-reduce), so that they take the same branch afterwards.  Returns True when the native
+    communicator is usable."""
+    global _native_ready
+    import ctypes as C
+    import torch
+    import torch.distributed as dist
+    from . import _lib as L
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return False
+    if _native_ready:
+        return True
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    ok = 1
+    try:
+        ident = C.create_string_buffer(L.COMM_ID_BYTES)
+        box = [None]
+        if rank == 0:
+            L.check(L.lib().gemma_hip_comm_unique_id(ident), "comm_unique_id")
+            box[0] = ident.raw
+        dist.broadcast_object_list(box, src=0, group=group)
+        ident = C.create_string_buffer(box[0], L.COMM_ID_BYTES)
+        L.check(L.lib().gemma_hip_comm_init(ident, rank, world), "comm_init")
+    except Exception:  # the other ranks must still reach the agreement below
+        ok = 0
+    dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+    flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+    _native_ready = bool(int(flag[0]) == 1)
+    if not _native_ready:
+        L.lib().gemma_hip_comm_finalize()
+    return _native_ready
+
+
+def broadcast_state_native(tensors, src=0, small_limit=1 << 22):
+    """broadcast_state over the library's communicator: ncclBroadcast issued by libgemma_hip.so itself on torch's current
+    stream (device tensors, in place): U on its own, everything else coalesced into one flat buffer."""
+    import ctypes as C
+    import torch
+    from . import _lib as L
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    small = [t for t in tensors if t.numel() <= small_limit]
+    for t in tensors:
+        if t.numel() > small_limit:
+            assert t.is_contiguous()
+            L.check(L.lib().gemma_hip_comm_bcast_d(C.c_void_p(t.data_ptr()), t.numel() * t.element_size(), src, stream), "comm_bcast")
+    if small:
+        flat = torch.cat([t.reshape(-1).to(torch.float64) for t in small])
+        L.check(L.lib().gemma_hip_comm_bcast_d(C.c_void_p(flat.data_ptr()), flat.numel() * 8, src, stream), "comm_bcast")
+        off = 0
+        for t in small:
+            t.copy_(flat[off:off + t.numel()].reshape(t.shape))
+            off += t.numel()
+    torch.cuda.current_stream().synchronize()
+    return tensors
+
+
 def seed_plink_carry(analyse_one, lo):
     """AnalyzePlink prints the PREVIOUS SNP's beta / se for a SNP whose lambda search failed (function-scope variables,
     src/lmm.cpp:1725,1870-1884), so a shard that starts at SNP `lo` > 0 must start with the carry the unsharded run has

@@ -18,7 +18,7 @@ def _built():
 def test_header_symbols_exported():
     so = _built()
     hdr = open(os.path.join(ROOT, "include", "gemma_hip.h")).read()
-    declared = sorted(set(re.findall(r"\b(gemma_hip_[a-z0-9_]+)\s*\(", hdr)))
+    declared = sorted(set(re.findall(r"\b(gemma_hip_[A-Za-z0-9_]+)\s*\(", hdr)))
     assert len(declared) >= 25
     lib = C.CDLL(so)
     for name in declared:
