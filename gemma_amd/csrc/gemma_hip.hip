@@ -847,17 +847,10 @@ static int launch_table_v2_t(const GridGeom &gg, const double *UtX, size_t l, si
   constexpr int NB16 = (NBX + NBA) * 16;
   const size_t rows_per_block = (size_t)RG * 16 * 4;
   const size_t bx = (l + rows_per_block - 1) / rows_per_block;
-  // K slices: one wave per SIMD (1024 slots on the 256 CUs); pick the count in [8, 32] whose row-waves x slices fill whole
-  // rounds of the chip best (313 row-waves at 20 000 rows: 13 slices = 3.97 rounds)
-  const size_t row_waves = (l + RG * 16 - 1) / (RG * 16);
-  const size_t slots = (size_t)g_ctx.prop.multiProcessorCount * 4;
-  int ksplit = 1;
-  double best = -1.0;
-  for (int k = std::min(8, gg.nc); k <= std::min(32, gg.nc); ++k) {
-    const size_t waves = row_waves * (size_t)k, rounds = (waves + slots - 1) / slots;
-    const double eff = (double)waves / (double)(rounds * slots) - 0.002 * k; // slight preference for fewer partial planes
-    if (eff > best) { best = eff; ksplit = k; }
-  }
+  // K slices: a function of n ALONE (a SNP's sums must not depend on the batch it arrives in: sharded == unsharded, and
+  // tests/test_gpu_parity.py::test_lmm_reference_xlarge_layout_and_batching compares bits across batch sizes); 16 slices of
+  // >= 32 chunks give ~5000 waves for a 20 000-row batch at n = 20 000
+  const int ksplit = std::max(1, std::min(16, gg.nc / 32));
   const size_t planes = tg ? (size_t)nint : 1;
   if (g_ctx.table_P.reserve(planes * (size_t)ksplit * l * NB16 * 8))
     return fail(GEMMA_HIP_ENOMEM, "lmm_assoc: table partial sums (%zu bytes)", planes * (size_t)ksplit * l * NB16 * 8);

@@ -196,7 +196,7 @@ __global__ __launch_bounds__(256) void grid_table_kernel(const double *__restric
 // 16-k chunk of the weight matrix (NB * 2 KiB) feeds RG * NB * 4 MFMAs instead of NB * 4; a block's four waves take four
 // different row sets over the SAME K slice (their weight reads coincide in the L1), blockIdx.y picks the K slice.  The K
 // slices leave partial sums P[ks][row][col]; table_reduce_kernel adds them in slice order (fixed order, no atomics: a
-// SNP's sums do not depend on its neighbours or on the launch shape -- the slicing depends only on n and the batch cap).
+// SNP's sums do not depend on its neighbours, its slot or the batch size -- the number of slices depends on n alone).
 struct TableV2 {
   const double *UtX;
   long ld;
@@ -209,7 +209,7 @@ struct TableV2 {
   TableGather tg;
 };
 template <int NBX, int NBA, int RG, bool GATHER>
-__global__ __launch_bounds__(256, 1) void table_v2_kernel(TableV2 a) {
+__global__ __launch_bounds__(256) void table_v2_kernel(TableV2 a) {
   constexpr int NB = NBX + NBA;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -238,56 +238,44 @@ __global__ __launch_bounds__(256, 1) void table_v2_kernel(TableV2 a) {
   for (int g = 0; g < RG; ++g)
 #pragma unroll
     for (int b = 0; b < NB; ++b) acc[g][b] = f64x4{0.0, 0.0, 0.0, 0.0};
-  const double *rp0 = Rp + (long)lane * 4;
+  const double *rp = Rp + ((long)c0 * NB * 64 + lane) * 4;
   const int n = a.n;
-  // Two operand register sets: the loads of chunk ch + 1 are issued BEFORE the RG * NB * 4 MFMAs of chunk ch, so one
-  // wave per SIMD keeps the matrix pipe busy (two waves without the prefetch fall into lock-step and both wait on their
-  // loads together: 57 % of the MFMA rate measured)
-  double rbA[NB][4], xvA[RG][4], rbB[NB][4], xvB[RG][4];
-#define TV2_LOAD(RB, XV, CH)                                                                                      \
-  do {                                                                                                            \
-    const double *rp_ = rp0 + (long)(CH) * NB * 256;                                                              \
-    _Pragma("unroll") for (int b = 0; b < NB; ++b) {                                                              \
-      const f64x2 lo = *reinterpret_cast<const f64x2 *>(rp_ + (long)b * 256);                                     \
-      const f64x2 hi = *reinterpret_cast<const f64x2 *>(rp_ + (long)b * 256 + 2);                                 \
-      RB[b][0] = lo.x; RB[b][1] = lo.y; RB[b][2] = hi.x; RB[b][3] = hi.y;                                         \
-    }                                                                                                             \
-    const long k_ = (long)(CH) * 16 + 4 * kq;                                                                     \
-    _Pragma("unroll") for (int g = 0; g < RG; ++g) {                                                              \
-      if (k_ + 3 < n) {                                                                                           \
-        const f64x2 lo = *reinterpret_cast<const f64x2 *>(xr[g] + (long)(CH) * 16);                               \
-        const f64x2 hi = *reinterpret_cast<const f64x2 *>(xr[g] + (long)(CH) * 16 + 2);                           \
-        XV[g][0] = lo.x; XV[g][1] = lo.y; XV[g][2] = hi.x; XV[g][3] = hi.y;                                       \
-      } else {                                                                                                    \
-        _Pragma("unroll") for (int j = 0; j < 4; ++j) XV[g][j] = (k_ + j < n) ? xr[g][(long)(CH) * 16 + j] : 0.0; \
-      }                                                                                                           \
-    }                                                                                                             \
-  } while (0)
-#define TV2_MFMA(RB, XV)                                                                                          \
-  do {                                                                                                            \
-    _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                               \
-      _Pragma("unroll") for (int g = 0; g < RG; ++g) {                                                            \
-        const double xs = XV[g][j] * XV[g][j];                                                                    \
-        _Pragma("unroll") for (int b = 0; b < NB; ++b)                                                            \
-          acc[g][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(b < NBX ? xs : XV[g][j], RB[b][j], acc[g][b], 0, 0, 0); \
-      }                                                                                                           \
-    }                                                                                                             \
-  } while (0)
-  if (c0 < c1) TV2_LOAD(rbA, xvA, c0);
-  for (int ch = c0; ch < c1; ch += 2) {
-    if (ch + 1 < c1) TV2_LOAD(rbB, xvB, ch + 1);
-    __builtin_amdgcn_sched_barrier(0);
-    TV2_MFMA(rbA, xvA);
-    __builtin_amdgcn_sched_barrier(0);
-    if (ch + 1 < c1) {
-      if (ch + 2 < c1) TV2_LOAD(rbA, xvA, ch + 2);
-      __builtin_amdgcn_sched_barrier(0);
-      TV2_MFMA(rbB, xvB);
-      __builtin_amdgcn_sched_barrier(0);
+  // (An explicit two-set operand prefetch at one wave per SIMD was measured and dropped: 2.25 ms against 1.43 ms for this
+  // plain loop at two waves per SIMD, n = B = 20 000 -- the limit is the 128-byte-per-row access pattern of the row reads,
+  // not load latency; profiles/r02_assoc_stage_notes.txt.)
+  for (int ch = c0; ch < c1; ++ch) {
+    const long k = (long)ch * 16 + 4 * kq;
+    double rb[NB][4];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      const f64x2 lo = *reinterpret_cast<const f64x2 *>(rp + (long)b * 256);
+      const f64x2 hi = *reinterpret_cast<const f64x2 *>(rp + (long)b * 256 + 2);
+      rb[b][0] = lo.x; rb[b][1] = lo.y; rb[b][2] = hi.x; rb[b][3] = hi.y;
+    }
+    rp += (long)NB * 256;
+    double xv[RG][4];
+#pragma unroll
+    for (int g = 0; g < RG; ++g) {
+      if (k + 3 < n) {
+        const f64x2 lo = *reinterpret_cast<const f64x2 *>(xr[g] + (long)ch * 16);
+        const f64x2 hi = *reinterpret_cast<const f64x2 *>(xr[g] + (long)ch * 16 + 2);
+        xv[g][0] = lo.x; xv[g][1] = lo.y; xv[g][2] = hi.x; xv[g][3] = hi.y;
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) xv[g][j] = (k + j < n) ? xr[g][(long)ch * 16 + j] : 0.0;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+#pragma unroll
+      for (int g = 0; g < RG; ++g) {
+        const double xs = xv[g][j] * xv[g][j];
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+          acc[g][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(b < NBX ? xs : xv[g][j], rb[b][j], acc[g][b], 0, 0, 0);
+      }
     }
   }
-#undef TV2_LOAD
-#undef TV2_MFMA
   // accumulator r of lane: row kq + 4r of the row group, column i of the block
   double *P = a.P + ((long)(kint * a.ksplit + ks) * a.cap) * (NB * 16);
 #pragma unroll
