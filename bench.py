@@ -46,6 +46,10 @@ def parse():
     ap.add_argument("--a-mode", type=int, default=1)
     ap.add_argument("--fp64-steps", type=int, default=2, help="extra untimed-region steps through the fp64 GEMM path (0 = skip)")
     ap.add_argument("--seed", type=int, default=20000)
+    ap.add_argument("--state-file", default="",
+                    help="measurement aid: keep the setup's result (U, eval, UtW, Uty, null scalars) in this file -- written "
+                         "when absent, loaded when present -- so that a profiler run (rocprofv3 --pmc crashes inside the "
+                         "eigensolver's ~80 000 launches) can start at the timed region")
     ap.add_argument("--e2e-snps", type=int, default=0,
                     help="opt-in end-to-end leg after the timed region: a synthetic PLINK set of this many SNPs on disk -> "
                          "tests/cpp/gemma_file_driver -inproc (first pass, kinship, eigen, -lmm, .assoc.txt), wall seconds "
@@ -120,7 +124,15 @@ def main():
     Uty = torch.empty(n, dtype=torch.float64, device=dev)
     setup_info = {}
     null = torch.zeros(2, dtype=torch.float64, device=dev)
-    if rank == 0:
+    loaded = False
+    if rank == 0 and args.state_file and os.path.exists(args.state_file):
+        st = torch.load(args.state_file, map_location=dev)
+        if st["U"].shape == U.shape:
+            U.copy_(st["U"]); ev.copy_(st["ev"]); UtW.copy_(st["UtW"]); Uty.copy_(st["Uty"]); null.copy_(st["null"])
+            setup_info["state"] = "loaded from " + args.state_file
+            loaded = True
+        del st
+    if rank == 0 and not loaded:
         t0 = time.time()
         K = torch.empty((n, n), dtype=torch.float64, device=dev)
         api.profile_enable(True)
@@ -191,6 +203,8 @@ def main():
         null[0], null[1] = nm["l_mle_null"], nm["logl_mle_H0"]
         setup_info["null"] = {k: nm[k] for k in ("l_remle_null", "pve")}
         api.profile_read(L.STAGE_UTX_GEMM, reset=True)
+        if args.state_file:
+            torch.save({"U": U, "ev": ev, "UtW": UtW, "Uty": Uty, "null": null}, args.state_file)
     t0 = time.time()
     # the single broadcast round: ncclBroadcast issued by the library's own RCCL communicator (csrc/comm.hip.h) when every
     # rank could create it, otherwise the same two collectives through torch.distributed (nccl = RCCL as well)

@@ -108,6 +108,18 @@ struct Ctx {
   // misc scratch
   DevBuf scratch;
 
+  // pipelined host-block path (lmm_batch_submit / _collect): two pinned staging slots, a copy and a compute stream
+  struct PipeSlot {
+    void *pin_in = nullptr, *pin_out = nullptr;
+    size_t pin_in_cap = 0, pin_out_cap = 0;
+    DevBuf dev_in, dev_out;
+    hipEvent_t h2d = nullptr, done = nullptr;
+    size_t l = 0;
+    bool busy = false;
+  } pipe[2];
+  hipStream_t pipe_copy = nullptr, pipe_comp = nullptr;
+  int pipe_head = 0, pipe_count = 0; // oldest busy slot, number in flight
+
   // device-resident chain (kin_end_keep -> eigh_kept_K -> lmm_setup_kept) and the communicator
   DevBuf kept_K, kept_UE; // K: ni_total^2; UE: U (n^2) followed by eval (n) -- one buffer, one broadcast
   size_t kept_K_n = 0, kept_n = 0;
@@ -181,6 +193,8 @@ int prof_collect(int stage) {
 inline hipStream_t S(void *s) { return reinterpret_cast<hipStream_t>(s); }
 
 } // namespace
+
+static void pipe_release(); // pipelined host-block path, defined with lmm_batch_submit
 
 // ------------------------------------------------------------------------------ lifetime
 extern "C" int gemma_hip_abi_version(void) { return GEMMA_HIP_ABI_VERSION; }
@@ -1935,6 +1949,7 @@ extern "C" int gemma_hip_lmm_finish(double *time_UtX_min, double *time_opt_min) 
   NEED_INIT();
   if (!g_ctx.lmm_active) return fail(GEMMA_HIP_ESTATE, "lmm_finish before lmm_setup");
   HIPCHK(hipDeviceSynchronize());
+  pipe_release(); // blocks still in flight are dropped with the state
   prof_collect(GEMMA_STAGE_UTX_GEMM);
   prof_collect(GEMMA_STAGE_UTX_POST);
   prof_collect(GEMMA_STAGE_ASSOC);
@@ -2160,6 +2175,93 @@ extern "C" int gemma_hip_lmm_setup_kept(const gemma_lmm_cfg *cfg, const double *
   if (rc) return rc;
   HIPCHK(hipDeviceSynchronize());
   g_ctx.lmm_active = true;
+  return GEMMA_HIP_OK;
+}
+
+// ---- pipelined host blocks --------------------------------------------------------------------------------------
+static void pipe_release() {
+  for (auto &p : g_ctx.pipe) {
+    if (p.pin_in) (void)hipHostFree(p.pin_in);
+    if (p.pin_out) (void)hipHostFree(p.pin_out);
+    p.pin_in = p.pin_out = nullptr;
+    p.pin_in_cap = p.pin_out_cap = 0;
+    p.dev_in.release(); p.dev_out.release();
+    if (p.h2d) (void)hipEventDestroy(p.h2d);
+    if (p.done) (void)hipEventDestroy(p.done);
+    p.h2d = p.done = nullptr;
+    p.busy = false;
+  }
+  if (g_ctx.pipe_copy) (void)hipStreamDestroy(g_ctx.pipe_copy);
+  if (g_ctx.pipe_comp) (void)hipStreamDestroy(g_ctx.pipe_comp);
+  g_ctx.pipe_copy = g_ctx.pipe_comp = nullptr;
+  g_ctx.pipe_head = g_ctx.pipe_count = 0;
+}
+
+extern "C" int gemma_hip_lmm_batch_submit(int kind, const void *geno, size_t l, size_t ld) {
+  NEED_INIT();
+  if (!g_ctx.lmm_active) return fail(GEMMA_HIP_ESTATE, "lmm_batch_submit before lmm_setup");
+  if (g_ctx.pipe_count >= 2) return fail(GEMMA_HIP_ESTATE, "lmm_batch_submit: two blocks already in flight (collect first)");
+  if (l == 0) return fail(GEMMA_HIP_EINVAL, "lmm_batch_submit: empty block");
+  int dummy = 0;
+  int rc = check_batch_args("lmm_batch_submit", kind, geno, l, ld, &dummy);
+  if (rc) return rc;
+  if (!g_ctx.pipe_copy) {
+    HIPCHK(hipStreamCreateWithFlags(&g_ctx.pipe_copy, hipStreamNonBlocking));
+    HIPCHK(hipStreamCreateWithFlags(&g_ctx.pipe_comp, hipStreamNonBlocking));
+  }
+  const int slot = (g_ctx.pipe_head + g_ctx.pipe_count) & 1;
+  Ctx::PipeSlot &p = g_ctx.pipe[slot];
+  const size_t esz = (kind == GEMMA_GENO_PLINK_2BIT) ? 1 : 8;
+  const size_t rows = (kind == GEMMA_GENO_F64_IDV_MAJOR) ? g_ctx.cfg.n : l;
+  const size_t n = g_ctx.cfg.n;
+  const size_t per_row = (kind == GEMMA_GENO_PLINK_2BIT && g_ctx.have_map) ? g_ctx.ni_total : n;
+  const size_t need = min_ld_for(kind, per_row, l);
+  const size_t bytes = ((rows - 1) * ld + need) * esz; // the last row may be shorter than ld in the caller's buffer
+  if (p.pin_in_cap < rows * ld * esz) {
+    if (p.pin_in) (void)hipHostFree(p.pin_in);
+    p.pin_in = nullptr;
+    p.pin_in_cap = 0;
+    HIPCHK(hipHostMalloc(&p.pin_in, rows * ld * esz, hipHostMallocDefault));
+    p.pin_in_cap = rows * ld * esz;
+  }
+  if (p.pin_out_cap < l * sizeof(gemma_sumstat)) {
+    if (p.pin_out) (void)hipHostFree(p.pin_out);
+    p.pin_out = nullptr;
+    p.pin_out_cap = 0;
+    HIPCHK(hipHostMalloc(&p.pin_out, l * sizeof(gemma_sumstat), hipHostMallocDefault));
+    p.pin_out_cap = l * sizeof(gemma_sumstat);
+  }
+  if (p.dev_in.reserve(rows * ld * esz) || p.dev_out.reserve(l * sizeof(gemma_sumstat)))
+    return fail(GEMMA_HIP_ENOMEM, "lmm_batch_submit: staging %zu bytes", rows * ld * esz);
+  if (!p.h2d) {
+    HIPCHK(hipEventCreateWithFlags(&p.h2d, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&p.done, hipEventDisableTiming));
+  }
+  memcpy(p.pin_in, geno, bytes);
+  HIPCHK(hipMemcpyAsync(p.dev_in.p, p.pin_in, bytes, hipMemcpyHostToDevice, g_ctx.pipe_copy));
+  HIPCHK(hipEventRecord(p.h2d, g_ctx.pipe_copy));
+  HIPCHK(hipStreamWaitEvent(g_ctx.pipe_comp, p.h2d, 0));
+  rc = gemma_hip_lmm_batch_d(kind, p.dev_in.p, l, ld, p.dev_out.as<gemma_sumstat>(), g_ctx.pipe_comp);
+  if (rc) return rc;
+  HIPCHK(hipMemcpyAsync(p.pin_out, p.dev_out.p, l * sizeof(gemma_sumstat), hipMemcpyDeviceToHost, g_ctx.pipe_comp));
+  HIPCHK(hipEventRecord(p.done, g_ctx.pipe_comp));
+  p.l = l;
+  p.busy = true;
+  g_ctx.pipe_count += 1;
+  return GEMMA_HIP_OK;
+}
+
+extern "C" int gemma_hip_lmm_batch_collect(gemma_sumstat *out, size_t *l) {
+  NEED_INIT();
+  if (g_ctx.pipe_count == 0) return fail(GEMMA_HIP_ESTATE, "lmm_batch_collect: nothing in flight");
+  if (!out) return fail(GEMMA_HIP_EINVAL, "lmm_batch_collect: null pointer");
+  Ctx::PipeSlot &p = g_ctx.pipe[g_ctx.pipe_head];
+  HIPCHK(hipEventSynchronize(p.done));
+  memcpy(out, p.pin_out, p.l * sizeof(gemma_sumstat));
+  if (l) *l = p.l;
+  p.busy = false;
+  g_ctx.pipe_head ^= 1;
+  g_ctx.pipe_count -= 1;
   return GEMMA_HIP_OK;
 }
 

@@ -176,6 +176,13 @@ int gemma_hip_lmm_set_indicator(const int *indicator_idv, size_t ni_total);
 int gemma_hip_lmm_batch(int geno_kind, const void *geno, size_t l, size_t ld, gemma_sumstat *out);
 int gemma_hip_lmm_batch_d(int geno_kind, const void *geno_d, size_t l, size_t ld,
                           gemma_sumstat *out_d, void *stream);
+/* The same for a STREAM of host blocks, pipelined (pinned, double-buffered H2D; the feeder this replaces is the
+ * per-SNP read loop of src/lmm.cpp:1776-1827): submit copies the block into one of two pinned staging slots and queues its
+ * H2D copy (copy stream), the batch (compute stream, after the copy) and the D2H of its SUMSTAT records; collect waits for
+ * the OLDEST submitted block and hands its records over.  At most two blocks in flight: submit(k + 1) before collect(k) moves
+ * block k + 1 across PCIe while block k computes.  The caller's buffer is free again when submit returns. */
+int gemma_hip_lmm_batch_submit(int geno_kind, const void *geno, size_t l, size_t ld);
+int gemma_hip_lmm_batch_collect(gemma_sumstat *out /* room for the block's l records */, size_t *l /* may be NULL */);
 /* LMM::AnalyzeGene (src/lmm.cpp:1365-1471; `-gene`): every row of Y (l x ld, row-major, ld >= cfg.n) is a PHENOTYPE
  * (a gene's expression over the analysed individuals); the tested variable is the one fixed vector whose rotation
  * U^T x was handed to gemma_hip_lmm_setup in the Uty slot.  Per row: U^T y_g (:1415), the row's own null ML fit

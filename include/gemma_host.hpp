@@ -556,16 +556,34 @@ public:
     size_t t_next = 0;
     const std::vector<int> keep = analysed_snps();
     if (shard_world > 1 && shard_rank > 0 && a_mode == 1) seed_plink_carry(infile, keep, n_bit);
-    // the .bed rows of block k+1 are read by a host thread while block k is on the device
+    // Three stages in flight: a host thread reads the .bed rows of block k + 2 (BlockPrefetch), block k + 1 crosses PCIe
+    // from a pinned staging slot, block k computes (gemma_hip_lmm_batch_submit / _collect: two blocks in the library)
     BlockPrefetch pf(B * n_bit, [&](void *slot, int) {
       return read_bed_rows(infile, keep, t_next, n_bit, static_cast<unsigned char *>(slot), B);
     });
-    for (;;) {
-      void *slot = nullptr;
-      const size_t l = pf.next(slot);
-      if (l == (size_t)-1) throw std::runtime_error("error reading genotype (.bed) file (truncated)");
-      if (l == 0) break;
-      batch_compute(GEMMA_GENO_PLINK_2BIT, slot, l, n_bit, out);
+    size_t in_flight = 0;
+    bool more = true;
+    while (more || in_flight) {
+      if (more && in_flight < 2) {
+        void *slot = nullptr;
+        const size_t l = pf.next(slot);
+        if (l == (size_t)-1) throw std::runtime_error("error reading genotype (.bed) file (truncated)");
+        if (l == 0) {
+          more = false;
+        } else {
+          enforce_hip(gemma_hip_lmm_batch_submit(GEMMA_GENO_PLINK_2BIT, slot, l, n_bit), "batch_compute");
+          ++in_flight;
+        }
+        continue;
+      }
+      size_t l = 0;
+      enforce_hip(gemma_hip_lmm_batch_collect(out.data(), &l), "batch_compute");
+      --in_flight;
+      for (size_t i = 0; i < l; ++i) {
+        SUMSTAT st = {out[i].beta, out[i].se, out[i].lambda_remle, out[i].lambda_mle,
+                      out[i].p_wald, out[i].p_lrt, out[i].p_score, out[i].logl_H1};
+        sumStat.push_back(st);
+      }
     }
     finish();
   }

@@ -405,7 +405,27 @@ int gemma_hip_lmm_batch(int kind, const void *geno, size_t l, size_t ld, gemma_s
                 g_lmm.cfg.plink_nan_rule, g_lmm.carry.data(), reinterpret_cast<orc_sumstat *>(out), nullptr);
   return GEMMA_HIP_OK;
 }
+// pipelined form: the double computes at submit and hands the records over at collect (same ordering rules)
+namespace {
+std::vector<std::vector<gemma_sumstat>> g_pipe;
+}
+int gemma_hip_lmm_batch_submit(int kind, const void *geno, size_t l, size_t ld) {
+  if (g_pipe.size() >= 2) return fail(GEMMA_HIP_ESTATE, "lmm_batch_submit: two blocks already in flight");
+  std::vector<gemma_sumstat> out(l);
+  const int rc = gemma_hip_lmm_batch(kind, geno, l, ld, out.data());
+  if (rc) return rc;
+  g_pipe.push_back(out);
+  return GEMMA_HIP_OK;
+}
+int gemma_hip_lmm_batch_collect(gemma_sumstat *out, size_t *l) {
+  if (g_pipe.empty()) return fail(GEMMA_HIP_ESTATE, "lmm_batch_collect: nothing in flight");
+  std::copy(g_pipe.front().begin(), g_pipe.front().end(), out);
+  if (l) *l = g_pipe.front().size();
+  g_pipe.erase(g_pipe.begin());
+  return GEMMA_HIP_OK;
+}
 int gemma_hip_lmm_finish(double *t_utx, double *t_opt) {
+  g_pipe.clear();
   g_lmm.on = false;
   if (t_utx) *t_utx = 0.0;
   if (t_opt) *t_opt = 0.0;

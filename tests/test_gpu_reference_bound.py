@@ -19,8 +19,9 @@ EXE = os.path.join(fc.ROOT, "oracle", "_ref_hip", "gemma")
 
 
 def _run(cwd, *args):
-    r = subprocess.run([EXE] + [str(a) for a in args], cwd=str(cwd), capture_output=True, text=True)
-    assert r.returncode == 0, "bound reference failed: %s\n%s\n%s" % (" ".join(map(str, args)), r.stdout[-2000:], r.stderr[-2000:])
+    r = subprocess.run([EXE] + [str(a) for a in args], cwd=str(cwd), capture_output=True)  # its progress bar is not UTF-8
+    assert r.returncode == 0, "bound reference failed: %s\n%s\n%s" % (
+        " ".join(map(str, args)), r.stdout[-2000:].decode(errors="replace"), r.stderr[-2000:].decode(errors="replace"))
     return r
 
 
