@@ -27,9 +27,15 @@ def _run(cwd, *args):
 
 @pytest.mark.skipif(not os.path.exists(EXE), reason="oracle/_ref_hip/gemma was not built (needs /root/reference at build time)")
 def test_bound_reference_bxd_gk_and_lmm4(tmp_path):
+    import gzip
     T = fc.TXT
-    base = ["-g", os.path.join(T, "bxd_mean_genotypes.txt.gz"), "-p", os.path.join(T, "bxd_trait.txt.gz"),
-            "-c", os.path.join(T, "bxd_cvt.txt.gz"), "-a", os.path.join(T, "bxd_anno.txt.gz")]
+    plain = {}
+    for name in ("bxd_trait", "bxd_cvt", "bxd_anno"):  # the reference reads these three as plain text (only -g through zlib)
+        plain[name] = str(tmp_path / (name + ".txt"))
+        with gzip.open(os.path.join(T, name + ".txt.gz"), "rb") as f, open(plain[name], "wb") as g:
+            g.write(f.read())
+    base = ["-g", os.path.join(T, "bxd_mean_genotypes.txt.gz"), "-p", plain["bxd_trait"], "-c", plain["bxd_cvt"],
+            "-a", plain["bxd_anno"]]
     full = np.load(os.path.join(fc.ROOT, "tests", "golden", "ref_bxd.npz"))
     _run(tmp_path, *base, "-gk", "-o", "BXD")                       # kinship: Xlarge Xlarge^T on the device
     cxx = tmp_path / "output" / "BXD.cXX.txt"
