@@ -356,6 +356,42 @@ def test_fixed_lambda_table_vs_streaming(gpu_api, oracle, n, c, monkeypatch):
         np.testing.assert_allclose(a[ok], b[ok], rtol=1e-7, err_msg=k)
 
 
+@pytest.mark.parametrize("n,c,mode", [(1500, 1, 4), (1203, 2, 9), (1100, 3, 2), (1001, 4, 4)])
+def test_bracket_polish_from_series_vs_streaming(gpu_api, oracle, n, c, mode, monkeypatch):
+    """The Brent / Newton polish from the SNP's Chebyshev-in-log(lambda) series (lmm_search.hip.h; default) against the same
+    kernels streaming every evaluation (GEMMA_HIP_ASSOC_CHEB=0), both against the oracle: c = 1..4, REML and ML searches,
+    ragged n (masked last K chunk of the table products), a block that is not a multiple of the 64-row wave tile; beta / se /
+    p / logl must agree between the two to 1e-7 (they share the final streaming pass), lambda-hat within the usual bar."""
+    X, U, ev, UtW, Uty, tr = _synthetic(oracle, n, 333, c, seed=4000 + n)
+    l_mle, logl0 = oracle.calc_lambda_null("L", ev, UtW, Uty)
+    ref = oracle.lmm_analyze(mode, U, ev, UtW, Uty, X, l_mle_null=l_mle, logl_mle_H0=logl0)
+    res = {}
+    for cheb in ("1", "0"):
+        monkeypatch.setenv("GEMMA_HIP_ASSOC_CHEB", cheb)
+        lmm = gpu_api.LMM(a_mode=mode, l_mle_null=l_mle, logl_mle_H0=logl0)
+        res[cheb] = lmm.AnalyzeBimbam(U, ev, UtW, Uty, X)
+        _cmp_stats(res[cheb], ref, mode, "n=%d c=%d series=%s" % (n, c, cheb))
+    for k in ("beta", "se", "p_wald", "p_lrt", "p_score", "logl_H1"):
+        a, b = res["1"][k], res["0"][k]
+        ok = ~(np.isnan(a) | np.isnan(b))
+        np.testing.assert_allclose(a[ok], b[ok], rtol=1e-7, atol=0, err_msg=k)
+
+
+def test_series_path_single_snp_blocks_and_sharding(gpu_api, oracle):
+    """A SNP's result must not depend on the block it arrives in (table slices, slots and lists are per batch): blocks of
+    1, 7 and 64 SNPs against one block, bit for bit."""
+    from gemma_amd import _lib as L
+    X, U, ev, UtW, Uty, tr = _synthetic(oracle, 700, 130, 1, seed=81)
+    lmm = gpu_api.LMM(a_mode=1)
+    lmm.setup(U, ev, UtW, Uty)
+    whole = lmm.batch(X, L.GENO_F64_SNP_MAJOR)
+    for step in (1, 7, 64):
+        parts = np.concatenate([lmm.batch(X[s:s + step], L.GENO_F64_SNP_MAJOR) for s in range(0, len(X), step)])
+        for k in whole.dtype.names:
+            assert np.array_equal(parts[k], whole[k], equal_nan=True), (step, k)
+    lmm.finish()
+
+
 @pytest.mark.parametrize("n_region", [7, 16])
 def test_lmm_other_region_counts_stream(gpu_api, oracle, n_region):
     """-region != 10: no table kernel is built for that weight count, every evaluation streams (FixedC path)."""
