@@ -66,7 +66,7 @@ def broadcast_state(tensors, src=0, group=None, small_limit=1 << 22):
 _native_ready = False
 
 
-def native_comm_init(group=None):
+def native_comm_init(group=None, timeout=180.0):
     """Bootstrap the LIBRARY's own RCCL communicator (csrc/comm.hip.h: ncclGetUniqueId on rank 0, the 128-byte id shipped
     through torch.distributed's store, ncclCommInitRank on every rank's device).  Every rank learns whether ALL ranks
     succeeded (one MIN all-reduce), so that they take the same branch afterwards.  Returns True when the native
@@ -90,15 +90,32 @@ def native_comm_init(group=None):
             box[0] = ident.raw
         dist.broadcast_object_list(box, src=0, group=group)
         ident = C.create_string_buffer(box[0], L.COMM_ID_BYTES)
-        L.check(L.lib().gemma_hip_comm_init(ident, rank, world), "comm_init")
+        # ncclCommInitRank is itself a collective: run it on a helper thread with a deadline, so that a bootstrap that
+        # never completes costs a delay and the agreed fallback below, not the run
+        import threading
+        res = {}
+        dev_index = torch.cuda.current_device()
+
+        def _init():
+            try:
+                torch.cuda.set_device(dev_index)
+                res["rc"] = L.lib().gemma_hip_comm_init(ident, rank, world)
+            except Exception as e:  # noqa: BLE001
+                res["rc"] = repr(e)
+
+        th = threading.Thread(target=_init, daemon=True)
+        th.start()
+        th.join(timeout)
+        if th.is_alive() or res.get("rc") != 0:
+            ok = 0
     except Exception:  # the other ranks must still reach the agreement below
         ok = 0
     dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
     flag = torch.tensor([ok], dtype=torch.int32, device=dev)
     dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
     _native_ready = bool(int(flag[0]) == 1)
-    if not _native_ready:
-        L.lib().gemma_hip_comm_finalize()
+    if not _native_ready and ok == 1:
+        L.lib().gemma_hip_comm_finalize()  # this rank could, another could not: drop the communicator, all take the fallback
     return _native_ready
 
 
