@@ -3,8 +3,8 @@
 
 A step = one pass of the hot path over one block of B SNPs (B = LMM_BATCH_SIZE = 20000, the
 reference's own batch, src/lmm.h:33) with the block's PLINK 2-bit genotypes already resident in
-HBM: ingest (2-bit decode + mean imputation) -> UtX = X U (fp64 MFMA GEMM) -> per-SNP lambda
-search + Wald test -> 64 B/SNP SUMSTAT left in HBM.  Nothing is skipped or cached between steps
+HBM: ingest (2-bit decode + mean imputation) -> UtX = X U (exact int8-digit MFMA products for hard
+calls; fp64 MFMA GEMM for dosages) -> per-SNP lambda search + Wald test -> 64 B/SNP SUMSTAT left in HBM.  Nothing is skipped or cached between steps
 (every step gets its own genotype block).
 
 Untimed setup on rank 0: synthetic genotypes -> kinship K (this library's SYRK path) -> centring
@@ -319,7 +319,8 @@ def main():
                        "device": name, "cus": n_cu, "utx_path": "int8-digit" if i8_path else "fp64-gemm",
                        "setup": setup_info, "nan_p_wald": n_nan},
             "roofline": roof,
-            "roofline_assoc": {"kernel": "lmm_assoc_kernel (lambda search + Wald)", "bound": "hbm",
+            "roofline_assoc": {"kernel": "per-SNP stage: fixed-lambda table + bracket scan + interval series tables (fp64 MFMA) + series-driven "
+                                         "Brent/Newton + one streaming pass per SNP (lmm_grid.hip.h, lmm_search.hip.h, lmm_assoc.hip.h)", "bound": "hbm",
                                "achieved": round(8.0 * n * B / assoc_avg_s / 1e9, 2) if assoc_avg_s else None,
                                "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": round(8.0 * n * B / assoc_avg_s / 1e9 / HBM_PEAK_GBS, 5) if assoc_avg_s else None,
