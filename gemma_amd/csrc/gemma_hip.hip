@@ -873,13 +873,17 @@ static int launch_table_v2_t(const GridGeom &gg, const double *UtX, size_t l, si
   a.P = g_ctx.table_P.as<double>(); a.cap = (long)l;
   if (tg) a.tg = *tg; else a.tg = TableGather();
   const long total = (long)l * NB16;
+  const char *epf = getenv("GEMMA_HIP_TABLE_PF");
+  const bool pf = epf && epf[0] == '1';
   if (tg) {
-    hipLaunchKernelGGL((table_v2_kernel<NBX, NBA, RG, true>), dim3((unsigned)bx, (unsigned)ksplit, (unsigned)nint), dim3(256), 0, s, a);
+    if (pf) hipLaunchKernelGGL((table_v2_kernel<NBX, NBA, RG, true, true>), dim3((unsigned)bx, (unsigned)ksplit, (unsigned)nint), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((table_v2_kernel<NBX, NBA, RG, true, false>), dim3((unsigned)bx, (unsigned)ksplit, (unsigned)nint), dim3(256), 0, s, a);
     HIPCHK(hipGetLastError());
     hipLaunchKernelGGL(table_reduce_kernel<true>, dim3((unsigned)((total + 255) / 256), (unsigned)nint), dim3(256), 0, s,
                        a.P, ksplit, a.cap, NB16, (long)l, tg->count, T);
   } else {
-    hipLaunchKernelGGL((table_v2_kernel<NBX, NBA, RG, false>), dim3((unsigned)bx, (unsigned)ksplit), dim3(256), 0, s, a);
+    if (pf) hipLaunchKernelGGL((table_v2_kernel<NBX, NBA, RG, false, true>), dim3((unsigned)bx, (unsigned)ksplit), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((table_v2_kernel<NBX, NBA, RG, false, false>), dim3((unsigned)bx, (unsigned)ksplit), dim3(256), 0, s, a);
     HIPCHK(hipGetLastError());
     hipLaunchKernelGGL(table_reduce_kernel<false>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a.P, ksplit,
                        a.cap, NB16, (long)l, (const int *)nullptr, T);

@@ -208,8 +208,8 @@ struct TableV2 {
   long cap;      // rows allocated per interval / batch
   TableGather tg;
 };
-template <int NBX, int NBA, int RG, bool GATHER>
-__global__ __launch_bounds__(256) void table_v2_kernel(TableV2 a) {
+template <int NBX, int NBA, int RG, bool GATHER, bool PF>
+__global__ __launch_bounds__(256, PF ? 1 : 2) void table_v2_kernel(TableV2 a) {
   constexpr int NB = NBX + NBA;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -238,44 +238,80 @@ __global__ __launch_bounds__(256) void table_v2_kernel(TableV2 a) {
   for (int g = 0; g < RG; ++g)
 #pragma unroll
     for (int b = 0; b < NB; ++b) acc[g][b] = f64x4{0.0, 0.0, 0.0, 0.0};
-  const double *rp = Rp + ((long)c0 * NB * 64 + lane) * 4;
+  const double *rp0 = Rp + (long)lane * 4;
   const int n = a.n;
-  // (An explicit two-set operand prefetch at one wave per SIMD was measured and dropped: 2.25 ms against 1.43 ms for this
-  // plain loop at two waves per SIMD, n = B = 20 000 -- the limit is the 128-byte-per-row access pattern of the row reads,
-  // not load latency; profiles/r02_assoc_stage_notes.txt.)
-  for (int ch = c0; ch < c1; ++ch) {
-    const long k = (long)ch * 16 + 4 * kq;
-    double rb[NB][4];
-#pragma unroll
-    for (int b = 0; b < NB; ++b) {
-      const f64x2 lo = *reinterpret_cast<const f64x2 *>(rp + (long)b * 256);
-      const f64x2 hi = *reinterpret_cast<const f64x2 *>(rp + (long)b * 256 + 2);
-      rb[b][0] = lo.x; rb[b][1] = lo.y; rb[b][2] = hi.x; rb[b][3] = hi.y;
+  // The main loop runs over the chunks that lie entirely inside n and is branch-free: one block of vector loads, then
+  // RG * NB * 4 MFMAs (a per-lane "is this k inside n" test inside the loop made the compiler serialise the row loads of
+  // the row groups with a full s_waitcnt between them -- two memory latencies per chunk).  The one partial chunk of a
+  // ragged n is done after it with masked loads.  PF: operands of chunk ch + 1 are requested before the MFMAs of chunk ch.
+  const int nfull = n / 16;
+  const int cfull = c1 < nfull ? c1 : nfull;
+#define TV2_LOAD(RB, XV, CH)                                                                                      \
+  do {                                                                                                            \
+    const double *rp_ = rp0 + (long)(CH) * NB * 256;                                                              \
+    _Pragma("unroll") for (int b = 0; b < NB; ++b) {                                                              \
+      const f64x2 lo = *reinterpret_cast<const f64x2 *>(rp_ + (long)b * 256);                                     \
+      const f64x2 hi = *reinterpret_cast<const f64x2 *>(rp_ + (long)b * 256 + 2);                                 \
+      RB[b][0] = lo.x; RB[b][1] = lo.y; RB[b][2] = hi.x; RB[b][3] = hi.y;                                         \
+    }                                                                                                             \
+    _Pragma("unroll") for (int g = 0; g < RG; ++g) {                                                              \
+      const f64x2 lo = *reinterpret_cast<const f64x2 *>(xr[g] + (long)(CH) * 16);                                 \
+      const f64x2 hi = *reinterpret_cast<const f64x2 *>(xr[g] + (long)(CH) * 16 + 2);                             \
+      XV[g][0] = lo.x; XV[g][1] = lo.y; XV[g][2] = hi.x; XV[g][3] = hi.y;                                         \
+    }                                                                                                             \
+  } while (0)
+#define TV2_MFMA(RB, XV)                                                                                          \
+  do {                                                                                                            \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                               \
+      _Pragma("unroll") for (int g = 0; g < RG; ++g) {                                                            \
+        const double xs = XV[g][j] * XV[g][j];                                                                    \
+        _Pragma("unroll") for (int b = 0; b < NB; ++b)                                                            \
+          acc[g][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(b < NBX ? xs : XV[g][j], RB[b][j], acc[g][b], 0, 0, 0); \
+      }                                                                                                           \
+    }                                                                                                             \
+  } while (0)
+  double rbA[NB][4], xvA[RG][4];
+  if (PF) {
+    double rbB[NB][4], xvB[RG][4];
+    if (c0 < cfull) TV2_LOAD(rbA, xvA, c0);
+    int ch = c0;
+    for (; ch + 1 < cfull; ch += 2) {
+      TV2_LOAD(rbB, xvB, ch + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      TV2_MFMA(rbA, xvA);
+      __builtin_amdgcn_sched_barrier(0);
+      // unconditional (the last round re-requests chunk ch + 1): a conditional load makes the compiler wait for every
+      // outstanding load at the merge point, which would undo the overlap for set B
+      TV2_LOAD(rbA, xvA, (ch + 2 < cfull ? ch + 2 : ch + 1));
+      __builtin_amdgcn_sched_barrier(0);
+      TV2_MFMA(rbB, xvB);
+      __builtin_amdgcn_sched_barrier(0);
     }
-    rp += (long)NB * 256;
-    double xv[RG][4];
-#pragma unroll
-    for (int g = 0; g < RG; ++g) {
-      if (k + 3 < n) {
-        const f64x2 lo = *reinterpret_cast<const f64x2 *>(xr[g] + (long)ch * 16);
-        const f64x2 hi = *reinterpret_cast<const f64x2 *>(xr[g] + (long)ch * 16 + 2);
-        xv[g][0] = lo.x; xv[g][1] = lo.y; xv[g][2] = hi.x; xv[g][3] = hi.y;
-      } else {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) xv[g][j] = (k + j < n) ? xr[g][(long)ch * 16 + j] : 0.0;
-      }
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-#pragma unroll
-      for (int g = 0; g < RG; ++g) {
-        const double xs = xv[g][j] * xv[g][j];
-#pragma unroll
-        for (int b = 0; b < NB; ++b)
-          acc[g][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(b < NBX ? xs : xv[g][j], rb[b][j], acc[g][b], 0, 0, 0);
-      }
+    if (ch < cfull) TV2_MFMA(rbA, xvA); // odd count: the last chunk's operands are already in set A
+  } else {
+    for (int ch = c0; ch < cfull; ++ch) {
+      TV2_LOAD(rbA, xvA, ch);
+      TV2_MFMA(rbA, xvA);
     }
   }
+  if (c1 > nfull && c0 <= nfull) { // the partial chunk nfull of a ragged n belongs to this slice
+    const int ch = nfull;
+    const long k = (long)ch * 16 + 4 * kq;
+    const double *rp_ = rp0 + (long)ch * NB * 256;
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      const f64x2 lo = *reinterpret_cast<const f64x2 *>(rp_ + (long)b * 256);
+      const f64x2 hi = *reinterpret_cast<const f64x2 *>(rp_ + (long)b * 256 + 2);
+      rbA[b][0] = lo.x; rbA[b][1] = lo.y; rbA[b][2] = hi.x; rbA[b][3] = hi.y;
+    }
+#pragma unroll
+    for (int g = 0; g < RG; ++g)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) xvA[g][j] = (k + j < n) ? xr[g][(long)ch * 16 + j] : 0.0;
+    TV2_MFMA(rbA, xvA);
+  }
+#undef TV2_LOAD
+#undef TV2_MFMA
   // accumulator r of lane: row kq + 4r of the row group, column i of the block
   double *P = a.P + ((long)(kint * a.ksplit + ks) * a.cap) * (NB * 16);
 #pragma unroll
