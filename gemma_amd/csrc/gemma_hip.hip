@@ -22,6 +22,7 @@
 #include "qc.hip.h"
 #include "mvlmm.hip.h"
 #include "comm.hip.h"
+#include "kin_i8.hip.h"
 
 using namespace gemma_hip;
 
@@ -71,6 +72,9 @@ struct Ctx {
   int kin_mode = 1;
   size_t kin_ns = 0;
   DevBuf kin_K, kin_X, kin_stage;
+  // exact-integer path of the centred kinship of hard calls (kin_i8.hip.h)
+  bool kin_i8 = false, kin_i8_used = false;
+  DevBuf kin_GtG, kin_S, kin_a, kin_At, kin_Gt;
 
   // lmm state
   bool lmm_active = false;
@@ -195,6 +199,7 @@ inline hipStream_t S(void *s) { return reinterpret_cast<hipStream_t>(s); }
 } // namespace
 
 static void pipe_release(); // pipelined host-block path, defined with lmm_batch_submit
+static void kin_i8_release(); // integer kinship path, defined with kin_begin
 
 // ------------------------------------------------------------------------------ lifetime
 extern "C" int gemma_hip_abi_version(void) { return GEMMA_HIP_ABI_VERSION; }
@@ -246,6 +251,7 @@ extern "C" void gemma_hip_shutdown(void) {
   (void)hipDeviceSynchronize();
   for (int s = 0; s < GEMMA_STAGE_COUNT; ++s) prof_collect(s);
   g_ctx.kin_K.release(); g_ctx.kin_X.release(); g_ctx.kin_stage.release();
+  kin_i8_release();
   g_ctx.own_U.release(); g_ctx.own_eval.release(); g_ctx.own_Uty.release(); g_ctx.own_UtW.release();
   g_ctx.UtWt.release(); g_ctx.idx_map.release(); g_ctx.X.release(); g_ctx.UtX.release();
   g_ctx.stage_in.release(); g_ctx.stage_out.release(); g_ctx.carry.release(); g_ctx.scratch.release();
@@ -355,6 +361,95 @@ extern "C" int gemma_hip_kin_begin(size_t n_total, int k_mode) {
   g_ctx.kin_n = n_total;
   g_ctx.kin_mode = k_mode;
   g_ctx.kin_ns = 0;
+  // -gk 1 on PLINK 2-bit blocks: G^T G as an exact int8 product + a sparse pass over the missing calls (kin_i8.hip.h);
+  // GEMMA_HIP_KIN_I8=0 keeps every block on the fp64 SYRK
+  const char *e = getenv("GEMMA_HIP_KIN_I8");
+  g_ctx.kin_i8 = (k_mode == 1) && !(e && e[0] == '0');
+  g_ctx.kin_i8_used = false;
+  return GEMMA_HIP_OK;
+}
+
+static void kin_i8_release() {
+  g_ctx.kin_GtG.release(); g_ctx.kin_S.release(); g_ctx.kin_a.release(); g_ctx.kin_At.release(); g_ctx.kin_Gt.release();
+  g_ctx.kin_i8_used = false;
+}
+
+// one PLINK block through the integer path: packed rows, transposed operands, G^T G (int32, exact), accumulators
+static int kin_add_i8(const void *geno, size_t l, size_t ld, hipStream_t s) {
+  const size_t n = g_ctx.kin_n;
+  const size_t ldk = (n + I8_BK - 1) / I8_BK * I8_BK;          // bytes per SNP-major row (K of the LMM product; here the i axis)
+  const size_t ldl = (l + I8_BK - 1) / I8_BK * I8_BK;          // bytes per individual-major row (K of THIS product: SNPs)
+  const size_t rows_a = (n + I8P_BM - 1) / I8P_BM * I8P_BM;    // A operand rows (128-row tiles)
+  const size_t rows_b = (n + I8_BN - 1) / I8_BN * I8_BN;       // B operand rows (256-column tiles)
+  const size_t rows_t = std::max(rows_a, rows_b);
+  if (!g_ctx.kin_i8_used) {
+    if (g_ctx.kin_GtG.reserve(n * n * 8) || g_ctx.kin_S.reserve(n * n * 8) || g_ctx.kin_a.reserve((n + 1) * 8))
+      return fail(GEMMA_HIP_ENOMEM, "kin_add: integer-path accumulators (%zu bytes)", 2 * n * n * 8);
+    HIPCHK(hipMemsetAsync(g_ctx.kin_GtG.p, 0, n * n * 8, s));
+    HIPCHK(hipMemsetAsync(g_ctx.kin_S.p, 0, n * n * 8, s));
+    HIPCHK(hipMemsetAsync(g_ctx.kin_a.p, 0, (n + 1) * 8, s));
+    g_ctx.kin_i8_used = true;
+  }
+  if (g_ctx.i8_A.reserve(l * ldk) || g_ctx.i8_mean.reserve(l * 8) || g_ctx.kin_At.reserve(rows_t * ldl) ||
+      g_ctx.kin_Gt.reserve(rows_t * ldl) || g_ctx.i8_C.reserve(2 * rows_a * rows_b * 4))
+    return fail(GEMMA_HIP_ENOMEM, "kin_add: integer-path buffers");
+  {
+    ProfScope ps(GEMMA_STAGE_INGEST, s);
+    IngestI8Args a;
+    a.src = reinterpret_cast<const unsigned char *>(geno); a.ld = (long)ld; a.l = (long)l; a.idx_map = nullptr;
+    a.n = (int)n; a.A = g_ctx.i8_A.as<int8_t>(); a.ldk = (long)ldk; a.mean = g_ctx.i8_mean.as<double>();
+    hipLaunchKernelGGL(ingest_i8_kernel, dim3((unsigned)((l + 3) / 4)), dim3(256), 0, s, a);
+    HIPCHK(hipGetLastError());
+    hipLaunchKernelGGL(kin_i8_transpose_kernel, dim3((unsigned)((ldl + 63) / 64), (unsigned)((rows_t + 63) / 64)), dim3(256), 0,
+                       s, g_ctx.i8_A.as<int8_t>(), (long)l, (long)ldk, (long)n, g_ctx.kin_At.as<int8_t>(),
+                       g_ctx.kin_Gt.as<int8_t>(), (long)ldl, (long)rows_t);
+    HIPCHK(hipGetLastError());
+  }
+  {
+    ProfScope ps(GEMMA_STAGE_KIN_GEMM, s);
+    static bool attr_set = false;
+    if (!attr_set) {
+      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(i8gemm_packed_kernel),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 3 * I8P_STAGE));
+      attr_set = true;
+    }
+    I8PackArgs g;
+    g.A = g_ctx.kin_At.as<int8_t>();  // rows = individuals, K = SNPs; the kernel masks g = a & 3 (and m, unused here)
+    g.Bt = g_ctx.kin_Gt.as<int8_t>(); // the same block as plain genotypes: C = G^T G
+    g.C = g_ctx.i8_C.as<int>();
+    g.ldk = (long)ldl; g.ldc = (long)rows_b;
+    g.strideB = 0; g.strideC = 0;
+    g.m_row0 = (long)rows_a;
+    g.tiles_m = (int)(rows_a / I8P_BM); g.tiles_n = (int)(rows_b / I8_BN);
+    g.nk = (int)(ldl / I8_BK);
+    g.gm = 0; g.fuse = 0; g.digits = 1;
+    hipLaunchKernelGGL(i8gemm_packed_kernel, dim3((unsigned)(g.tiles_m * g.tiles_n), 1), dim3(512), 3 * I8P_STAGE, s, g);
+    HIPCHK(hipGetLastError());
+    hipLaunchKernelGGL(kin_i8_accum_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)std::min<size_t>(n, 32768)), dim3(256), 0, s,
+                       g_ctx.i8_C.as<int>(), (long)rows_b, (long)n, g_ctx.kin_GtG.as<double>());
+    HIPCHK(hipGetLastError());
+    KinCorrArgs c;
+    c.A = g_ctx.i8_A.as<int8_t>(); c.At = g_ctx.kin_At.as<int8_t>(); c.mean = g_ctx.i8_mean.as<double>();
+    c.l = (long)l; c.ldk = (long)ldk; c.ldl = (long)ldl; c.n = (long)n;
+    c.S = g_ctx.kin_S.as<double>(); c.a = g_ctx.kin_a.as<double>(); c.smu2 = g_ctx.kin_a.as<double>() + n;
+    hipLaunchKernelGGL(kin_i8_corr_kernel, dim3((unsigned)n, (unsigned)((n + KI8_SEG - 1) / KI8_SEG)), dim3(256), 0, s, c);
+    HIPCHK(hipGetLastError());
+  }
+  g_ctx.kin_ns += l;
+  return GEMMA_HIP_OK;
+}
+
+// fold the integer-path accumulators into the (unscaled, upper-triangle) sums of kin_K; call before the scale / mirror
+static int kin_fold_i8(hipStream_t s) {
+  if (!g_ctx.kin_i8_used) return GEMMA_HIP_OK;
+  const size_t n = g_ctx.kin_n;
+  const unsigned nb = (unsigned)((n + 31) / 32);
+  hipLaunchKernelGGL(kin_i8_fold_kernel, dim3(nb, nb), dim3(32, 8), 0, s, g_ctx.kin_K.as<double>(), (long)n,
+                     g_ctx.kin_GtG.as<double>(), g_ctx.kin_S.as<double>(), g_ctx.kin_a.as<double>(),
+                     g_ctx.kin_a.as<double>() + n);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(s));
+  kin_i8_release();
   return GEMMA_HIP_OK;
 }
 
@@ -376,6 +471,7 @@ extern "C" int gemma_hip_kin_add_d(int kind, const void *geno, size_t l, size_t 
   if (need == (size_t)-1) return fail(GEMMA_HIP_EINVAL, "kin_add: unknown geno_kind %d", kind);
   if (!geno || ld < need) return fail(GEMMA_HIP_EINVAL, "kin_add: ld=%zu < %zu", ld, need);
   hipStream_t s = S(stream);
+  if (g_ctx.kin_i8 && kind == GEMMA_GENO_PLINK_2BIT) return kin_add_i8(geno, l, ld, s);
   const size_t ldx = (n + 1) & ~(size_t)1;
   if (g_ctx.kin_X.reserve(l * ldx * 8))
     return fail(GEMMA_HIP_ENOMEM, "kin_add: cannot allocate %zu bytes", l * ldx * 8);
@@ -431,6 +527,10 @@ extern "C" int gemma_hip_kin_end_d(double *K_d, size_t *ns_used, void *stream) {
   if (!g_ctx.kin_active) return fail(GEMMA_HIP_ESTATE, "kin_end before kin_begin");
   const size_t n = g_ctx.kin_n;
   hipStream_t s = S(stream);
+  {
+    int rc = kin_fold_i8(s);
+    if (rc) return rc;
+  }
   if (ns_used) *ns_used = g_ctx.kin_ns;
   const double scale = g_ctx.kin_ns ? 1.0 / (double)g_ctx.kin_ns : 1.0;
   const unsigned nb = (unsigned)((n + 31) / 32);
@@ -450,6 +550,10 @@ extern "C" int gemma_hip_kin_end(double *K, size_t *ns_used) {
   NEED_INIT();
   if (!g_ctx.kin_active) return fail(GEMMA_HIP_ESTATE, "kin_end before kin_begin");
   const size_t n = g_ctx.kin_n;
+  {
+    int rc = kin_fold_i8(nullptr);
+    if (rc) return rc;
+  }
   if (ns_used) *ns_used = g_ctx.kin_ns;
   const double scale = g_ctx.kin_ns ? 1.0 / (double)g_ctx.kin_ns : 1.0;
   const unsigned nb = (unsigned)((n + 31) / 32);
@@ -1998,6 +2102,10 @@ extern "C" int gemma_hip_kin_end_keep(size_t *ns_used, int allreduce) {
   if (!g_ctx.kin_active) return fail(GEMMA_HIP_ESTATE, "kin_end before kin_begin");
   const size_t n = g_ctx.kin_n;
   size_t ns = g_ctx.kin_ns;
+  {
+    int rc = kin_fold_i8(nullptr); // the all-reduce below works on the folded, unscaled upper-triangle sums
+    if (rc) return rc;
+  }
   if (allreduce && g_ctx.comm.active && g_ctx.comm.world > 1) {
     // SNP-sharded kinship: every rank holds sum_s x_s x_s^T over ITS SNPs (unscaled, upper-triangle tiles); one all-reduce
     // of the n^2 sums and one of the SNP counts, then the common 1/ns scale and the mirror
