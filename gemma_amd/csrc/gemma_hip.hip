@@ -391,7 +391,7 @@ static int kin_add_i8(const void *geno, size_t l, size_t ld, hipStream_t s) {
     g_ctx.kin_i8_used = true;
   }
   if (g_ctx.i8_A.reserve(l * ldk) || g_ctx.i8_mean.reserve(l * 8) || g_ctx.kin_At.reserve(rows_t * ldl) ||
-      g_ctx.kin_Gt.reserve(rows_t * ldl) || g_ctx.i8_C.reserve(2 * rows_a * rows_b * 4))
+      g_ctx.kin_Gt.reserve(rows_t * ldl) || g_ctx.i8_C.reserve(rows_a * rows_b * 4))
     return fail(GEMMA_HIP_ENOMEM, "kin_add: integer-path buffers");
   {
     ProfScope ps(GEMMA_STAGE_INGEST, s);
@@ -409,12 +409,12 @@ static int kin_add_i8(const void *geno, size_t l, size_t ld, hipStream_t s) {
     ProfScope ps(GEMMA_STAGE_KIN_GEMM, s);
     static bool attr_set = false;
     if (!attr_set) {
-      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(i8gemm_packed_kernel),
+      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(i8gemm_packed_kernel_t<false>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 3 * I8P_STAGE));
       attr_set = true;
     }
     I8PackArgs g;
-    g.A = g_ctx.kin_At.as<int8_t>();  // rows = individuals, K = SNPs; the kernel masks g = a & 3 (and m, unused here)
+    g.A = g_ctx.kin_At.as<int8_t>();  // rows = individuals, K = SNPs; the kernel masks g = a & 3 (WITH_M = false: no mask product)
     g.Bt = g_ctx.kin_Gt.as<int8_t>(); // the same block as plain genotypes: C = G^T G
     g.C = g_ctx.i8_C.as<int>();
     g.ldk = (long)ldl; g.ldc = (long)rows_b;
@@ -423,7 +423,7 @@ static int kin_add_i8(const void *geno, size_t l, size_t ld, hipStream_t s) {
     g.tiles_m = (int)(rows_a / I8P_BM); g.tiles_n = (int)(rows_b / I8_BN);
     g.nk = (int)(ldl / I8_BK);
     g.gm = 0; g.fuse = 0; g.digits = 1;
-    hipLaunchKernelGGL(i8gemm_packed_kernel, dim3((unsigned)(g.tiles_m * g.tiles_n), 1), dim3(512), 3 * I8P_STAGE, s, g);
+    hipLaunchKernelGGL(i8gemm_packed_kernel_t<false>, dim3((unsigned)(g.tiles_m * g.tiles_n), 1), dim3(512), 3 * I8P_STAGE, s, g);
     HIPCHK(hipGetLastError());
     hipLaunchKernelGGL(kin_i8_accum_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)std::min<size_t>(n, 32768)), dim3(256), 0, s,
                        g_ctx.i8_C.as<int>(), (long)rows_b, (long)n, g_ctx.kin_GtG.as<double>());
@@ -1322,7 +1322,7 @@ static int i8_product(size_t l, const I8Dims &d, double *UtX, size_t ldx, hipStr
     ProfScope ps(GEMMA_STAGE_UTX_GEMM, s);
     static bool attr_set = false;
     if (!attr_set) {
-      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(i8gemm_packed_kernel),
+      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(i8gemm_packed_kernel_t<true>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 3 * I8P_STAGE));
       attr_set = true;
     }
@@ -1340,7 +1340,7 @@ static int i8_product(size_t l, const I8Dims &d, double *UtX, size_t ldx, hipStr
     g.fuse = d.fuse;
     g.digits = d.digits;
     const dim3 grid((unsigned)(g.tiles_m * g.tiles_n), (unsigned)d.nplanes);
-    hipLaunchKernelGGL(i8gemm_packed_kernel, grid, dim3(512), 3 * I8P_STAGE, s, g);
+    hipLaunchKernelGGL(i8gemm_packed_kernel_t<true>, grid, dim3(512), 3 * I8P_STAGE, s, g);
     HIPCHK(hipGetLastError());
   }
   {

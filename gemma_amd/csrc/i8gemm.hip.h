@@ -11,7 +11,7 @@
 // fp64 product.  The fp64 result is assembled once per element (Horner over the digits, <= 2 roundings), which is
 // closer to the exact dot product than an fp64 GEMM's 20000-term rounding chain.
 //
-// Kernel (i8gemm_packed_kernel below): 128 SNP rows x 256 columns x 128 K-bytes per tile, 512 threads = 8 wavefronts,
+// Kernel (i8gemm_packed_kernel_t<true> below): 128 SNP rows x 256 columns x 128 K-bytes per tile, 512 threads = 8 wavefronts,
 // operands global -> LDS by global_load_lds_dwordx4 into three 48 KiB stages; both LDS images are [row][128 bytes of K]
 // with the 16-byte chunk index XOR-ed by (row >> 1) & 7 on the source address and on the ds_read_b128 fragment reads
 // (conflict-free).  One block per CU.  History and ablations: profiles/r01_i8gemm_variants.txt.
@@ -67,7 +67,10 @@ struct I8PackArgs {
 constexpr int I8P_BM = 128;
 constexpr int I8P_STAGE = 49152;
 
-__global__ __launch_bounds__(512, 2) void i8gemm_packed_kernel(I8PackArgs g) {
+// WITH_M = false: the genotype product alone (kin_i8.hip.h: G^T G needs no mask product) -- the same schedule with the mask
+// MFMAs, their operand masks and their epilogue left out
+template <bool WITH_M>
+__global__ __launch_bounds__(512, 2) void i8gemm_packed_kernel_t(I8PackArgs g) {
   extern __shared__ __attribute__((aligned(1024))) int8_t i8lds[];
   int tm, tn;
   {
@@ -147,7 +150,7 @@ __global__ __launch_bounds__(512, 2) void i8gemm_packed_kernel(I8PackArgs g) {
 #define I8P_MASK(i, RA, RG, RM)                                                                                   \
   do {                                                                                                            \
     RG[i] = RA[i] & mask_g;                                                                                       \
-    RM[i] = (RA[i] >> 4) & mask_m;                                                                                \
+    if (WITH_M) RM[i] = (RA[i] >> 4) & mask_m;                                                                    \
   } while (0)
 // MFMA q of a K-step: block (i, j) = (q >> 2, (q >> 1) & 1), q & 1: 0 = G, 1 = M
 #define I8P_MF(q, RG, RM, RB)                                                                                     \
@@ -155,7 +158,7 @@ __global__ __launch_bounds__(512, 2) void i8gemm_packed_kernel(I8PackArgs g) {
     if (((q)&1) == 0)                                                                                             \
       accg[(q) >> 2][((q) >> 1) & 1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(RG[(q) >> 2], RB[((q) >> 1) & 1],    \
                                                                              accg[(q) >> 2][((q) >> 1) & 1], 0, 0, 0); \
-    else                                                                                                          \
+    else if (WITH_M)                                                                                              \
       accm[(q) >> 2][((q) >> 1) & 1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(RM[(q) >> 2], RB[((q) >> 1) & 1],    \
                                                                              accm[(q) >> 2][((q) >> 1) & 1], 0, 0, 0); \
   } while (0)
@@ -207,7 +210,7 @@ __global__ __launch_bounds__(512, 2) void i8gemm_packed_kernel(I8PackArgs g) {
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) { accg[i][j][r] <<= 8; accm[i][j][r] <<= 8; }
+          for (int r = 0; r < 16; ++r) { accg[i][j][r] <<= 8; if (WITH_M) accm[i][j][r] <<= 8; }
     }
     I8P_INIT_SRC(d_first - dd);
     // prologue: tiles 0 and 1 in flight, tile 0 landed (every LDS read of the previous digit completed before its
@@ -258,7 +261,7 @@ __global__ __launch_bounds__(512, 2) void i8gemm_packed_kernel(I8PackArgs g) {
       for (int r = 0; r < 16; ++r) {
         const long row = (long)tm * I8P_BM + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
         Cg[row * g.ldc + col] = accg[i][j][r];
-        Cg[(g.m_row0 + row) * g.ldc + col] = accm[i][j][r];
+        if (WITH_M) Cg[(g.m_row0 + row) * g.ldc + col] = accm[i][j][r];
       }
     }
 }

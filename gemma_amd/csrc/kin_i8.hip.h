@@ -77,7 +77,7 @@ __global__ __launch_bounds__(256) void kin_i8_corr_kernel(KinCorrArgs g) {
   double acc[16];
 #pragma unroll
   for (int q = 0; q < 16; ++q) acc[q] = 0.0;
-  double a_part = 0.0, mu2_part = 0.0;
+  double a_part = 0.0, mu2_part = 0.0, cj = 0.0;
   for (long r0 = 0; r0 < g.l; r0 += KI8_LIST) {
     const long r1 = r0 + KI8_LIST < g.l ? r0 + KI8_LIST : g.l;
     // the SNPs of [r0, r1) at which j is missing, in SNP order
@@ -104,36 +104,54 @@ __global__ __launch_bounds__(256) void kin_i8_corr_kernel(KinCorrArgs g) {
       base += wcount[0] + wcount[1] + wcount[2] + wcount[3];
       __syncthreads();
     }
-    // S[j][i] += mu_s d'_si over the listed SNPs, i = i0 + 1024 q + 4 t .. + 3
-    for (int e = 0; e < base; ++e) {
-      const int s = list[e];
-      const double mu = g.mean[s];
-      const int8_t *row = g.A + (long)s * g.ldk;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const long i = i0 + 1024 * q + 4 * t;
-        if (i < g.ldk) { // ldk is a multiple of 128 >= n: a whole 4-byte group is inside the (zero-padded) row
-          const unsigned int w = *reinterpret_cast<const unsigned int *>(row + i);
-#pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            const unsigned int b = (w >> (8 * k)) & 0xffu;
-            const double gv = (double)(b & 3u);
-            const double dp = (b & 16u) ? -0.5 * mu : gv - mu; // g = 0 at a missing call: g - mu (1 - 1/2) = -mu / 2
-            acc[4 * q + k] += mu * dp;
-          }
-        }
+    // S[j][i] += mu_s d'_si over the listed SNPs, i = i0 + 16 t .. + 15 (one 16-byte load per thread and SNP: the
+    // block reads 4 KiB of the SNP's packed row).  mu d' = mu g + (mu^2 / 2) m - mu^2: two bit-field extracts, two
+    // conversions and two FMAs per call (the stage is VALU-bound -- a chain of 64-bit selects costs twice that); the
+    // constant -sum mu_s^2 over the list is the same for every i and comes off at the end.
+    const long ib = i0 + 16 * t;
+    if (ib < g.ldk) { // ldk is a multiple of 128 >= n: a whole 16-byte group lies inside the zero-padded row
+      const int8_t *colbase = g.A + ib;
+#define KI8_APPLY(W4, MU)                                                                                          \
+  do {                                                                                                            \
+    const double h_ = 0.5 * (MU) * (MU);                                                                          \
+    cj += (MU) * (MU);                                                                                            \
+    const unsigned int ww_[4] = {(W4).x, (W4).y, (W4).z, (W4).w};                                                 \
+    _Pragma("unroll") for (int q = 0; q < 4; ++q) _Pragma("unroll") for (int k = 0; k < 4; ++k) {                 \
+      const double gq_ = (double)__builtin_amdgcn_ubfe(ww_[q], 8 * k, 2);                                         \
+      const double mq_ = (double)__builtin_amdgcn_ubfe(ww_[q], 8 * k + 4, 1);                                     \
+      acc[4 * q + k] = fma((MU), gq_, acc[4 * q + k]);                                                            \
+      acc[4 * q + k] = fma(h_, mq_, acc[4 * q + k]);                                                              \
+    }                                                                                                             \
+  } while (0)
+      int e = 0;
+      for (; e + 4 <= base; e += 4) { // four independent 16-byte loads in flight per thread
+        const int s0 = list[e], s1 = list[e + 1], s2 = list[e + 2], s3 = list[e + 3];
+        const uint4 w0 = *reinterpret_cast<const uint4 *>(colbase + (long)s0 * g.ldk);
+        const uint4 w1 = *reinterpret_cast<const uint4 *>(colbase + (long)s1 * g.ldk);
+        const uint4 w2 = *reinterpret_cast<const uint4 *>(colbase + (long)s2 * g.ldk);
+        const uint4 w3 = *reinterpret_cast<const uint4 *>(colbase + (long)s3 * g.ldk);
+        const double m0 = g.mean[s0], m1 = g.mean[s1], m2 = g.mean[s2], m3 = g.mean[s3];
+        KI8_APPLY(w0, m0);
+        KI8_APPLY(w1, m1);
+        KI8_APPLY(w2, m2);
+        KI8_APPLY(w3, m3);
       }
+      for (; e < base; ++e) {
+        const int s0 = list[e];
+        const uint4 w0 = *reinterpret_cast<const uint4 *>(colbase + (long)s0 * g.ldk);
+        const double m0 = g.mean[s0];
+        KI8_APPLY(w0, m0);
+      }
+#undef KI8_APPLY
     }
     __syncthreads();
   }
   double *Sj = g.S + j * g.n;
 #pragma unroll
-  for (int q = 0; q < 4; ++q)
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const long i = i0 + 1024 * q + 4 * t + k;
-      if (i < g.n) Sj[i] += acc[4 * q + k];
-    }
+  for (int q = 0; q < 16; ++q) {
+    const long i = i0 + 16 * t + q;
+    if (i < g.n) Sj[i] += acc[q] - cj;
+  }
   if (blockIdx.y == 0) {
     double v = wsum(a_part);
     if (lane == 0) red[wave] = v;
