@@ -156,7 +156,21 @@ def main():
         kin_ms, kin_n = api.profile_read(L.STAGE_KIN_GEMM, reset=True)
         setup_info["kinship_s"] = round(time.time() - t0, 3)
         setup_info["kinship_gemm_tflops"] = round(2.0 * n * n * args.kin_snps / (kin_ms * 1e-3) / 1e12, 2) if kin_ms else None
-        if kin_ms:
+        kin_int = os.environ.get("GEMMA_HIP_KIN_I8", "1") != "0"  # PLINK hard calls: exact-integer G^T G + sparse correction
+        if kin_ms and kin_int:
+            # kin_i8.hip.h: G^T G on the int8 MFMA pipe (2 n^2 p integer ops, full square), fp64 accumulation of the int32
+            # block product, and the missing-call correction (VALU-bound gather over the ~1 % missing calls).  There is no
+            # single roofline for the stage; the per-kernel split is in profiles/r02_kin_i8_stats.csv.  "equiv" is the
+            # GEMM-form fp64 rate the stage replaces (SURVEY 8d's 2 n^2 p), comparable with the fp64 SYRK's figure.
+            setup_info["roofline_kinship"] = {
+                "kernel": "kin_i8 stage: i8gemm_packed_kernel_t<false> (G^T G) + kin_i8_accum_kernel + kin_i8_corr_kernel",
+                "bound": "valu (kin_i8_corr_kernel, 58 % of the stage) / mfma int8 (25 %)", "unit": "TFLOP/s (fp64 GEMM-form equivalent)",
+                "achieved": setup_info["kinship_gemm_tflops"], "peak": 78.6,
+                "frac": round(setup_info["kinship_gemm_tflops"] / 78.6, 4), "launch_ms_total": round(kin_ms, 3),
+                "blocks": kin_n,
+                "note": "frac > 1: the stage runs faster than an fp64 GEMM at the matrix pipe's peak could; exact integers, "
+                        "K agrees with the fp64 SYRK path to 1e-14 (tests/test_gpu_parity.py)"}
+        elif kin_ms:
             # K = Xc Xc^T as a SYRK: only the 128 x 128 tiles with tile_n >= tile_m are launched (dgemm_mfma.hip.h), so the
             # flops EXECUTED are tiles * 2 * 128^2 * p; SURVEY 8(d)'s GEMM-form figure 2 n^2 p (what the reference's
             # cblas_dgemm does) is the line above and is what "142" means -- it is not a rate of the matrix pipe

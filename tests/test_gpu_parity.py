@@ -195,6 +195,48 @@ def test_kinship_plink_and_idv_major(gpu_api, oracle):
     assert np.linalg.norm(K2 - ref) / np.linalg.norm(ref) < 1e-13
 
 
+def test_kinship_integer_path(gpu_api, oracle, monkeypatch):
+    """-gk 1 on PLINK blocks takes the exact-integer route (kin_i8.hip.h: int8 G^T G + the missing-call correction).
+    Against the restatement and against the fp64 SYRK (GEMMA_HIP_KIN_I8=0) on the same blocks: n spans two ranges of
+    the correction kernel (4096 individuals each) and is not a multiple of 4 / 16 / 128, ragged last block, one individual
+    missing at every SNP, one SNP missing for most individuals, and a run that mixes PLINK blocks with an fp64 block."""
+    from gemma_amd import _lib as L
+    rng = np.random.default_rng(77)
+    n, p = 4503, 700
+    codes = rng.choice([0, 1, 2, 3], size=(p, n), p=[0.3, 0.04, 0.36, 0.3]).astype(np.uint8)
+    codes[:, 17] = 1              # never called
+    codes[9, rng.random(n) < 0.9] = 1
+    nb = (n + 3) // 4
+    pad = np.zeros((p, nb * 4), dtype=np.uint8)
+    pad[:, :n] = codes
+    raw = (pad[:, 0::4] | (pad[:, 1::4] << 2) | (pad[:, 2::4] << 4) | (pad[:, 3::4] << 6)).astype(np.uint8)
+    G = oracle.bed_decode(raw, n)
+    ref = oracle.calc_kin(G, 1)
+    monkeypatch.setenv("GEMMA_HIP_KIN_I8", "1")
+    K1 = gpu_api.CalcKin(raw, L.GENO_PLINK_2BIT, n, 1, batch=300)
+    monkeypatch.setenv("GEMMA_HIP_KIN_I8", "0")
+    K0 = gpu_api.CalcKin(raw, L.GENO_PLINK_2BIT, n, 1, batch=300)
+    scale = np.abs(ref).max()
+    assert np.abs(K1 - ref).max() / scale < 2e-14 and np.abs(K0 - ref).max() / scale < 2e-14
+    assert np.array_equal(K1, K1.T) and np.abs(K1[17]).max() < 1e-13 * scale  # a never-called individual: centred row of zeros
+    _record("kinship -gk 1 PLINK n=%d p=%d: integer path %.2e, fp64 SYRK %.2e (max abs err / max |K|)"
+            % (n, p, np.abs(K1 - ref).max() / scale, np.abs(K0 - ref).max() / scale))
+    # mixed run: 400 SNPs as PLINK blocks (integer accumulators) + 300 as an fp64 individual-major block (SYRK), one kin_end
+    monkeypatch.setenv("GEMMA_HIP_KIN_I8", "1")
+    Xc = oracle.kin_prepare(G[400:], 1)
+    gpu_api.kin_begin(n, 1)
+    gpu_api.kin_add(raw[:250], L.GENO_PLINK_2BIT)
+    gpu_api.kin_add(np.ascontiguousarray(Xc.T), L.GENO_F64_IDV_MAJOR)
+    gpu_api.kin_add(raw[250:400], L.GENO_PLINK_2BIT)
+    Km = np.zeros((n, n))
+    assert gpu_api.kin_end(Km) == p
+    assert np.abs(Km - ref).max() / scale < 2e-14
+    # -gk 2 never takes the integer route (rows are scaled by 1 / sd)
+    K2 = gpu_api.CalcKin(raw[:200], L.GENO_PLINK_2BIT, n, 2, batch=128)
+    ref2 = oracle.calc_kin(G[:200], 2)
+    assert np.abs(K2 - ref2).max() / np.abs(ref2).max() < 2e-14
+
+
 def test_snp_qc_bimbam_and_plink(gpu_api, oracle):
     """First-pass SNP filters against the oracle's restatement of ReadFile_geno / ReadFile_bed:
     missingness, maf, polymorphism, HWE, r2 with covariates -- identical indicator_snp, maf, n_miss."""
