@@ -16,7 +16,7 @@ SYMBOLS = [
     "gemma_hip_lmm_null", "gemma_hip_lmm_set_indicator", "gemma_hip_lmm_batch", "gemma_hip_lmm_batch_d",
     "gemma_hip_lmm_assoc_d", "gemma_hip_lmm_finish", "gemma_hip_lm_setup", "gemma_hip_lm_batch", "gemma_hip_lm_batch_d",
     "gemma_hip_lm_finish", "gemma_hip_profile_enable",
-    "gemma_hip_profile_read", "gemma_hip_dbg_tridiag", "gemma_hip_dbg_stedc", "gemma_hip_dbg_utx", "gemma_hip_lmm_gene_batch", "gemma_hip_lmm_gene_batch_d", "gemma_hip_lmm_set_env",
+    "gemma_hip_profile_read", "gemma_hip_dbg_tridiag", "gemma_hip_dbg_stedc", "gemma_hip_dbg_eigh2", "gemma_hip_dbg_utx", "gemma_hip_lmm_gene_batch", "gemma_hip_lmm_gene_batch_d", "gemma_hip_lmm_set_env",
     "gemma_hip_lmm_gxe_batch", "gemma_hip_lmm_gxe_batch_d",
     "gemma_hip_mvlmm_null", "gemma_hip_mvlmm_set", "gemma_hip_mvlmm_batch", "gemma_hip_mvlmm_batch_d",
     "gemma_hip_kin_end_keep", "gemma_hip_kept_K_get", "gemma_hip_eigh_kept_K", "gemma_hip_eigh_keep", "gemma_hip_kept_n",
@@ -130,6 +130,7 @@ def lib():
     L.gemma_hip_profile_read.argtypes = [ci, C.POINTER(cd), C.POINTER(C.c_long), ci]
     L.gemma_hip_dbg_tridiag.argtypes = [dp, sz, dp, dp, dp, dp]
     L.gemma_hip_dbg_stedc.argtypes = [dp, dp, sz, dp, dp]
+    L.gemma_hip_dbg_eigh2.argtypes = [dp, sz, dp, dp, dp]
     L.gemma_hip_dbg_utx.argtypes = [C.c_int, vp, sz, sz, C.c_int, dp]
     L.gemma_hip_kin_end_keep.argtypes = [C.POINTER(sz), ci]
     L.gemma_hip_kept_K_get.argtypes = [dp]

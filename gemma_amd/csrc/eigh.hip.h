@@ -1027,6 +1027,23 @@ static inline int eig_backtransform(double *ZT, long n, EigWs &ws, hipStream_t s
   return 0;
 }
 
+} // namespace gemma_hip
+#include "eigh2.hip.h"
+namespace gemma_hip {
+
+// GEMMA_HIP_EIGH_STAGES: 1 = one-stage tridiagonalisation (HBM-bound SYMV per column), 2 = two-stage (dense -> band ->
+// tridiagonal, eigh2.hip.h) whenever the matrix has at least one stage-1 panel; unset: two-stage from n = 12000 (measured:
+// n = 8192 0.50 s one-stage / 0.70 s two-stage, n = 20000 4.46 / 3.09 s -- the n sequential panel launches and the 2 n
+// dependent chase steps are latency, the SYMV they replace is bandwidth).  Odd n stays on the one-stage path (the panel
+// GEMMs want even leading dimensions).
+static inline bool eig_two_stage(long n) {
+  const char *e = getenv("GEMMA_HIP_EIGH_STAGES");
+  if (e && e[0] == '1') return false;
+  if (n < 3 * E2_B || (n & 1)) return false;
+  if (e && e[0] == '2') return true;
+  return n >= 12000;
+}
+
 // G (n x n symmetric, device, destroyed) -> U (row-major, eigenvector k in column k), eval ascending.
 static inline int eigh_device(double *G, long n, double *U, double *eval, hipStream_t s, std::string &msg) {
   EigWs ws;
@@ -1055,6 +1072,12 @@ static inline int eigh_device(double *G, long n, double *U, double *eval, hipStr
       ok = ws.get(ws.rowP, nseg * (size_t)n) && ws.get(ws.colP, nstrip * (size_t)n);
     }
   }
+  const bool two = eig_two_stage(n);
+  Eig2Ws w2;
+  if (ok && two) {
+    if (!ws.Tall) ok = ws.get(ws.Tall, (size_t)((n + EIG_NB - 1) / EIG_NB) * EIG_NB * EIG_NB);
+    ok = ok && eig2_alloc(n, ws, w2);
+  }
   if (!ok) {
     ws.release();
     msg = "cannot allocate the eigensolver workspace (about 3 n^2 doubles)";
@@ -1069,7 +1092,7 @@ static inline int eigh_device(double *G, long n, double *U, double *eval, hipStr
     (void)hipStreamSynchronize(s);
     return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
   };
-  double t0 = timing ? now() : 0.0, t1 = 0.0, t2 = 0.0, t3 = 0.0;
+  double t0 = timing ? now() : 0.0, t1 = 0.0, t2 = 0.0, t3 = 0.0, t1a = 0.0, t2a = 0.0;
   do {
     if (n == 1) {
       hipError_t e1 = hipMemcpyAsync(eval, G, 8, hipMemcpyDeviceToDevice, s);
@@ -1079,7 +1102,13 @@ static inline int eigh_device(double *G, long n, double *U, double *eval, hipStr
       if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) { msg = "copy failed"; rc = 4; }
       break;
     }
-    rc = eig_tridiagonalize(G, n, ws, s, msg);
+    if (two) {
+      rc = eig2_sy2sb(G, n, ws, w2, s, msg);
+      if (timing) t1a = now();
+      if (!rc) rc = eig2_sb2st(n, ws, w2, s, msg);
+    } else {
+      rc = eig_tridiagonalize(G, n, ws, s, msg);
+    }
     if (rc) break;
     if (hipMemcpyAsync(hd.data(), ws.d, n * 8, hipMemcpyDeviceToHost, s) != hipSuccess ||
         hipMemcpyAsync(he.data(), ws.e, (n - 1) * 8, hipMemcpyDeviceToHost, s) != hipSuccess ||
@@ -1111,7 +1140,13 @@ static inline int eigh_device(double *G, long n, double *U, double *eval, hipStr
     rc = eig_stedc(n, hd, he, G, U, ws, s, &Z, dphys, msg);
     if (rc) break;
     if (timing) t2 = now();
-    rc = eig_backtransform(Z, n, ws, s, msg);
+    if (two) {
+      rc = eig2_apply_q2(Z, n, w2, s, msg);
+      if (timing) t2a = now();
+      if (!rc) rc = eig2_apply_q1(Z, n, ws, s, msg);
+    } else {
+      rc = eig_backtransform(Z, n, ws, s, msg);
+    }
     if (rc) break;
     if (timing) t3 = now();
     std::vector<int> perm(n);
@@ -1137,9 +1172,15 @@ static inline int eigh_device(double *G, long n, double *U, double *eval, hipStr
     }
   } while (0);
   (void)hipStreamSynchronize(s);
-  if (timing && rc == 0 && n > 1)
-    fprintf(stderr, "gemma_hip_eigh n=%ld: tridiagonalisation %.3f s, divide&conquer %.3f s, back-transform %.3f s, "
-                    "sort+transpose %.3f s\n", n, t1 - t0, t2 - t1, t3 - t2, now() - t3);
+  if (timing && rc == 0 && n > 1) {
+    if (two)
+      fprintf(stderr, "gemma_hip_eigh n=%ld (two-stage): dense->band %.3f s, band->tridiagonal %.3f s, divide&conquer %.3f s, "
+                      "back-transform Q2 %.3f s, Q1 %.3f s, sort+transpose %.3f s\n", n, t1a - t0, t1 - t1a, t2 - t1,
+              t2a - t2, t3 - t2a, now() - t3);
+    else
+      fprintf(stderr, "gemma_hip_eigh n=%ld: tridiagonalisation %.3f s, divide&conquer %.3f s, back-transform %.3f s, "
+                      "sort+transpose %.3f s\n", n, t1 - t0, t2 - t1, t3 - t2, now() - t3);
+  }
   ws.release();
   return rc;
 }

@@ -1,0 +1,867 @@
+// Two-stage reduction for the symmetric eigensolver (included by eigh.hip.h): dense -> band -> tridiagonal.
+//
+// The one-stage tridiagonalisation of eigh.hip.h streams the trailing matrix from HBM once per column (the SYMV half of
+// its flops: (8/3) n^3 bytes, 2.4 s of 4.4 s at n = 20 000, 45+ s at n = 50 000).  Here the dense matrix is touched by
+// GEMMs only:
+//
+//  stage 1 (sy2sb)  panels of E2_B = 128 columns: Householder QR of the block below the band (the panel is read as the
+//                   contiguous ROWS j0 .. j0+127 of the symmetric matrix; one launch per column, every workgroup owns
+//                   256 columns of the panel, the column norms and the v.y products of the next reflector ride on the
+//                   update of the previous one), compact-WY factor T, and the two-sided update
+//                   A22 -= V W^T + W V^T with W = Y - V (T^T (V^T Y)) / 2, Y = A22 V T  -- all on the fp64 MFMA GEMM.
+//  stage 2 (sb2st)  bulge chasing on the band (n x 256 doubles: L2 / MALL resident).  Task (j, k) of sweep j works on
+//                   rows j+1+128k ..: it applies the previous task's reflector from the right to the 128 x 128 block
+//                   left of its diagonal block, annihilates that block's first column, and updates its diagonal block
+//                   from both sides.  Tasks with 2 j + k = t are independent; one launch per time step t
+//                   (scripts/two_stage_model.py checks the schedule and the group order below in numpy).
+//  back-transform   Z^T <- Z^T Q2^T Q1^T.  Q2 (the n^2 / 256 reflectors of stage 2): 32 consecutive sweeps at the same
+//                   k form one block reflector I - V T V^T whose V is a 160 x 32 parallelogram; groups are applied with k
+//                   ascending outside and the sweep blocks descending inside, so the 160-column window of Z^T slides by
+//                   32 columns per group.  One wavefront owns 16 rows of Z^T and keeps its window in REGISTERS in the
+//                   accumulator layout of the transposed products (X^T tiles), which is also the MFMA operand layout:
+//                   W^T = V^T X^T, W2^T = T W^T, X^T -= V W2^T chain without touching LDS; only V and T (52 KB per group,
+//                   packed once by q2_pack_kernel) go through LDS.  Q1 (stage 1) reuses the three-GEMM panel update of
+//                   eigh.hip.h.
+//
+// LAPACK equivalents: dsytrd_sy2sb / dsytrd_sb2st / dormtr-like back-transformations; semantics of the whole solver as
+// before (GEMMA src/lapack.cpp:149-291).
+#pragma once
+
+namespace gemma_hip {
+
+constexpr int E2_B = EIG_NB;             // half-bandwidth after stage 1 (= the back-transform block of eigh.hip.h)
+constexpr int E2_LDB = 2 * E2_B;         // doubles per column of the band storage: Bd[j * E2_LDB + (i - j)] = B(i, j), i >= j
+constexpr int E2_NB = 32;                // sweeps per block reflector of the stage-2 back-transformation
+constexpr int E2_WIN = E2_B + E2_NB;     // window of Z^T columns one group touches (b + nb - 1, rounded up to 16)
+constexpr int E2_VLD = 34;               // leading dimension of the packed group (bank-conflict padding)
+constexpr int E2_PACK = (E2_WIN + E2_NB) * E2_VLD; // doubles per packed group: V (160 x 34) then T (32 x 34)
+constexpr int SB_COLS = 256;             // panel columns per workgroup of sb_panel_kernel
+constexpr int GR_CH = 512, GR_KS = 16;   // Gram kernel: columns per workgroup, columns per LDS step
+
+__device__ __forceinline__ double e2_bsum256(double v, double *red /* 8 doubles */) {
+  v = eig_wsum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// LAPACK dlarfg from alpha = x[0] and |x[1:]|^2
+__device__ __forceinline__ void e2_larfg(double alpha, double xnorm2, double &tau, double &beta, double &scale) {
+  if (xnorm2 == 0.0) {
+    tau = 0.0;
+    beta = alpha;
+    scale = 0.0;
+    return;
+  }
+  double b = sqrt(alpha * alpha + xnorm2);
+  if (alpha > 0.0) b = -b;
+  tau = (b - alpha) / b;
+  scale = 1.0 / (alpha - b);
+  beta = b;
+}
+
+// ---------------------------------------------------------------- stage 1: panel QR
+// Launch c of panel j0 (c = 0 .. kk): applies reflector c-1 to the rows c .. 127 of the panel (columns >= its head) and
+// stores it (row j0+c-1 of VT, head element 1), then forms the partial sums that define reflector c: for every row q >= c
+// sum over the columns right of head_c of x_c[col] y_q[col] (q = c: |x_c[1:]|^2).  The head column's entries are kept in
+// `heads` by the workgroup that owns it, so that nothing is read in place while another workgroup rewrites it.
+struct SbPanelArgs {
+  double *A;
+  long n, j0;
+  int c, kk, nwg;
+  double *VT, *part, *heads, *tau, *betas;
+};
+__global__ __launch_bounds__(256) void sb_panel_kernel(SbPanelArgs g) {
+  __shared__ double sf[E2_B], sred[E2_B], sc[4];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const long n = g.n, j0 = g.j0, r0 = j0 + E2_B;
+  const int c = g.c, prev = c - 1;
+  const long head_prev = r0 + prev, head_c = r0 + c;
+  double scale = 0.0, beta = 0.0;
+  if (c > 0) {
+    if (t < E2_B && t >= prev) {
+      const double *pp = g.part + (size_t)(prev & 1) * g.nwg * E2_B + t;
+      double s = 0.0;
+#pragma unroll 16
+      for (int w = 0; w < g.nwg; ++w) s += pp[(size_t)w * E2_B];
+      sred[t] = s;
+    }
+    __syncthreads();
+    if (t == 0) {
+      double tau, b, sc_;
+      e2_larfg(g.heads[(prev & 1) * E2_B + prev], sred[prev], tau, b, sc_);
+      sc[0] = sc_;
+      sc[1] = b;
+      sc[2] = tau;
+      if (blockIdx.x == 0) {
+        g.tau[j0 + prev] = tau;
+        g.betas[j0 + prev] = b;
+      }
+    }
+    __syncthreads();
+    scale = sc[0];
+    beta = sc[1];
+    if (t < E2_B && t > prev) sf[t] = sc[2] * (g.heads[(prev & 1) * E2_B + t] + scale * sred[t]);
+    __syncthreads();
+  }
+  (void)beta;
+  const long base = r0 + (long)blockIdx.x * SB_COLS + lane;
+  double v[4], xc[4];
+  bool valid[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const long col = base + 64 * i;
+    valid[i] = col < n;
+    v[i] = 0.0;
+    xc[i] = 0.0;
+    if (c > 0 && valid[i] && col >= head_prev) {
+      v[i] = (col == head_prev) ? 1.0 : scale * g.A[(j0 + prev) * n + col];
+      if (wave == 0) g.VT[(j0 + prev) * n + col] = v[i];
+    }
+  }
+  const bool more = c < g.kk;
+  if (more) { // row c after the pending update: x of the next reflector (every wavefront needs it for its own columns)
+    const double *row = g.A + (j0 + c) * n;
+    const double f = (c > 0) ? sf[c] : 0.0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const double y = (valid[i] ? row[base + 64 * i] : 0.0) - f * v[i];
+      xc[i] = (base + 64 * i > head_c) ? y : 0.0;
+    }
+  }
+  // this wavefront's rows q = q0, q0 + 4, ...: four rows per step, all loads of a step in flight together
+  for (int q0 = c + ((wave - c) & 3); q0 < E2_B; q0 += 16) {
+    double y[4][4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int q = q0 + 4 * u;
+      const double *row = g.A + (j0 + q) * n;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) y[u][i] = (q < E2_B && valid[i]) ? row[base + 64 * i] : 0.0;
+    }
+    double pr[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int q = q0 + 4 * u;
+      pr[u] = 0.0;
+      if (q < E2_B) {
+        double *row = g.A + (j0 + q) * n;
+        const double f = (c > 0) ? sf[q] : 0.0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          y[u][i] -= f * v[i];
+          if (c > 0 && valid[i] && base + 64 * i >= head_prev) row[base + 64 * i] = y[u][i];
+          pr[u] += xc[i] * y[u][i];
+          if (more && valid[i] && base + 64 * i == head_c) g.heads[(c & 1) * E2_B + q] = y[u][i];
+        }
+      }
+    }
+    if (more) {
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) pr[u] += __shfl_xor(pr[u], off, 64);
+      if (lane == 0)
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (q0 + 4 * u < E2_B) sred[q0 + 4 * u] = pr[u];
+    }
+  }
+  if (more) {
+    __syncthreads();
+    if (t < E2_B && t >= c) g.part[(size_t)(c & 1) * g.nwg * E2_B + (size_t)blockIdx.x * E2_B + t] = sred[t];
+  }
+}
+
+// P[blockIdx.x] (128 x 128) = X[:, chunk] Y[:, chunk]^T over the chunk's GR_CH columns; X, Y: 128 rows, K columns
+__global__ __launch_bounds__(256) void sb_gram_kernel(const double *__restrict__ X, long ldx,
+                                                      const double *__restrict__ Y, long ldy, long K,
+                                                      double *__restrict__ P) {
+  __shared__ double Xs[GR_KS][E2_B + 4], Ys[GR_KS][E2_B + 4];
+  const int t = threadIdx.x, ty = t >> 4, tx = t & 15;
+  const int lrow = t >> 1, lk = (t & 1) * 8;
+  double acc[8][8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[i][j] = 0.0;
+  const long k0 = (long)blockIdx.x * GR_CH;
+  for (int kc = 0; kc < GR_CH; kc += GR_KS) {
+    const long kb = k0 + kc + lk;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const bool ok = kb + e < K;
+      Xs[lk + e][lrow] = ok ? X[lrow * ldx + kb + e] : 0.0;
+      Ys[lk + e][lrow] = ok ? Y[lrow * ldy + kb + e] : 0.0;
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int kk = 0; kk < GR_KS; ++kk) {
+      double a[8], b[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) a[i] = Xs[kk][ty * 8 + i];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) b[j] = Ys[kk][tx * 8 + j];
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] += a[i] * b[j];
+    }
+    __syncthreads();
+  }
+  double *out = P + (size_t)blockIdx.x * E2_B * E2_B;
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) out[(ty * 8 + i) * E2_B + tx * 8 + j] = acc[i][j];
+}
+__global__ void sb_gram_reduce_kernel(const double *__restrict__ P, int nwg, double *__restrict__ S) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  double s = 0.0;
+  for (int w = 0; w < nwg; ++w) s += P[(size_t)w * E2_B * E2_B + idx];
+  S[idx] = s;
+}
+
+// forward compact-WY factor of 128 reflectors from S = V V^T (strict upper triangle read) and tau, in LDS (the global-
+// memory recurrence of bt_tfactor_kernel takes 1.2 ms per panel; this one ~40 us).  T row-major upper triangular, ld 128.
+__global__ __launch_bounds__(256) void sb_tfactor_kernel(const double *__restrict__ S, const double *__restrict__ tau,
+                                                         double *__restrict__ T) {
+  extern __shared__ double e2sm[];
+  double *Tt = e2sm, *scol = e2sm + E2_B * E2_B; // Tt[c][r] = T[r][c]
+  const int t = threadIdx.x;
+  for (int idx = t; idx < E2_B * E2_B; idx += 256) Tt[idx] = 0.0;
+  __syncthreads();
+  for (int i = 0; i < E2_B; ++i) {
+    const double ti = tau[i];
+    if (t < i) scol[t] = S[t * E2_B + i];
+    __syncthreads();
+    if (t < i) {
+      double acc = 0.0;
+      for (int c = t; c < i; ++c) acc += Tt[c * E2_B + t] * scol[c];
+      Tt[i * E2_B + t] = -ti * acc;
+    }
+    if (t == i) Tt[i * E2_B + i] = ti;
+    __syncthreads();
+  }
+  for (int idx = t; idx < E2_B * E2_B; idx += 256) {
+    const int r = idx >> 7, c = idx & (E2_B - 1);
+    T[idx] = Tt[c * E2_B + r];
+  }
+}
+
+// band storage from the reduced matrix: Bd[j][t] = A[j][j + t], t <= 128 (row j of the upper triangle is contiguous);
+// the entry at distance 128 of a row that carries a reflector is that reflector's beta
+__global__ __launch_bounds__(256) void sb_extract_band_kernel(const double *__restrict__ A, long n,
+                                                              const double *__restrict__ betas, double *__restrict__ Bd) {
+  const long j = blockIdx.x;
+  const int t = threadIdx.x;
+  double v = 0.0;
+  if (t <= E2_B && j + t < n) {
+    v = A[j * n + j + t];
+    if (t == E2_B) {
+      const double b = betas[j];
+      if (b == b) v = b; // not NaN: row j was eliminated by a stage-1 reflector
+    }
+  }
+  Bd[j * E2_LDB + t] = v;
+}
+__global__ void sb_band_de_kernel(const double *__restrict__ Bd, long n, double *__restrict__ d, double *__restrict__ e) {
+  const long j = (long)blockIdx.x * 256 + threadIdx.x;
+  if (j < n) {
+    d[j] = Bd[j * E2_LDB];
+    if (j + 1 < n) e[j] = Bd[j * E2_LDB + 1];
+  }
+}
+
+// ---------------------------------------------------------------- stage 2: one time step of the bulge chase
+struct BcArgs {
+  double *Bd;
+  long n, t, jlo;
+  double *V2, *tau2; // V2[(k n + j) 128 + i], tau2[k n + j]
+};
+constexpr int BC_LD = E2_B + 1; // padded column stride of the 128 x 128 block in LDS: row sums and column sums both conflict-free
+constexpr int BC_LDS_DOUBLES = E2_B * BC_LD + 8 * E2_B + 16;
+// task (j, k): the caller guarantees that it exists (j <= n - 3, j + 1 + 128 k < n) and that (j, k-1) and (j-1, k+1) are done
+#define BC_STAMP(i)                                                  \
+  do {                                                               \
+    if (dbg && threadIdx.x == 0) dbg[i] = (long long)wall_clock64(); \
+  } while (0)
+// value of lane `l` (compile-time constant after unrolling) as a wave-uniform scalar: VALU readlane, no LDS traffic
+__device__ __forceinline__ double bc_bcast(double x, int l) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(x), l);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(x), l);
+  return __hiloint2double(hi, lo);
+}
+// task (j, k): the caller guarantees that it exists (j <= n - 3, j + 1 + 128 k < n) and that (j, k-1) and (j-1, k+1) are done.
+// Thread (a, h) owns row a of the 128 x 128 blocks and the 64 columns cb = 64 h ..; its 64 entries of E and of the diagonal
+// block's lower triangle stay in REGISTERS from the global load to the global store.  Row sums (E v_p, D v) run on those
+// registers with the vector's entries broadcast by readlane; only the column sums (v^T E, the transposed half of D v) need
+// the block in LDS: one store pass and one read pass per block (the stage is bound by the LDS pipe, not by HBM or flops:
+// the first version, which kept E in LDS for every step, spent 18 of its 29 us per task there).
+__device__ __forceinline__ void bc_task(double *__restrict__ B, long n, long j, long k, double *__restrict__ V2g,
+                                        double *__restrict__ tau2g, double *e2sm, long long *dbg = nullptr) {
+  BC_STAMP(0);
+  double *E = e2sm; // E[c][a] (column stride 129): the block whose column sums are being formed
+  double *vp = e2sm + E2_B * BC_LD, *v = vp + E2_B, *zc = v + E2_B, *wv = zc + E2_B;
+  double *ybuf = wv + E2_B, *zbuf = ybuf + 2 * E2_B, *red = zbuf + 2 * E2_B;
+  const int t = threadIdx.x, a = t & (E2_B - 1), h = t >> 7, lane = t & 63;
+  const long r = j + 1 + k * E2_B;
+  const int L = (int)((n - r < E2_B) ? (n - r) : E2_B);
+  const int cb = h * 64;
+  double er[64], dr[64];
+  double xa, ya = 0.0, taup = 0.0, vph = 0.0;
+  if (k > 0) {
+    const double *src = B + (r - E2_B + cb) * E2_LDB + E2_B + a - cb;
+#pragma unroll
+    for (int c = 0; c < 64; ++c) er[c] = (a < L) ? src[c * (E2_LDB - 1)] : 0.0;
+    vph = V2g[((size_t)(k - 1) * n + j) * E2_B + cb + lane]; // v_p of this wavefront's columns, one per lane
+    taup = tau2g[(k - 1) * n + j];
+  }
+  {
+    const double *srd = B + (r + cb) * E2_LDB + a - cb;
+#pragma unroll
+    for (int c = 0; c < 64; ++c) dr[c] = (a >= cb + c && a < L) ? srd[c * (E2_LDB - 1)] : 0.0;
+  }
+  if (k > 0) {
+#pragma unroll
+    for (int c = 0; c < 64; ++c) E[(cb + c) * BC_LD + a] = er[c];
+    double ys = 0.0;
+#pragma unroll
+    for (int c = 0; c < 64; ++c) ys += er[c] * bc_bcast(vph, c);
+    ybuf[h * E2_B + a] = ys;
+    if ((t & 64) == 0) vp[cb + lane] = vph; // waves 0 and 2 publish v_p (needed by column index below)
+    __syncthreads();
+    BC_STAMP(1);
+    ya = taup * (ybuf[a] + ybuf[E2_B + a]);
+    xa = E[a] - ya * vp[0]; // first column of E (I - tau_p v_p v_p^T)
+  } else {
+    xa = (a < L) ? B[j * E2_LDB + 1 + a] : 0.0;
+  }
+  BC_STAMP(2);
+  if (t == 0) red[8] = xa;
+  const double xnorm2 = e2_bsum256((h == 0 && a >= 1 && a < L) ? xa * xa : 0.0, red);
+  double tau, beta, scale;
+  e2_larfg(red[8], xnorm2, tau, beta, scale);
+  const double va = (a == 0) ? 1.0 : ((a < L) ? scale * xa : 0.0);
+  if (h == 0) {
+    v[a] = va;
+    V2g[((size_t)k * n + j) * E2_B + a] = va;
+  }
+  if (t == 0) tau2g[k * n + j] = tau;
+  // s = v . y (the right-hand reflector's share of z = v^T E (I - tau_p v_p v_p^T))
+  const double sdot = e2_bsum256((h == 0) ? va * ya : 0.0, red); // includes the barrier that publishes v
+  BC_STAMP(3);
+  if (k > 0) {
+    // z0_c = sum_q v_q E[c][q]: thread = column a, rows 64 h ..
+    const double vrow = v[cb + lane];
+    double zs = 0.0;
+#pragma unroll
+    for (int q = 0; q < 64; ++q) zs += E[a * BC_LD + cb + q] * bc_bcast(vrow, q);
+    zbuf[h * E2_B + a] = zs;
+    __syncthreads();
+    if (h == 0) zc[a] = (zbuf[a] + zbuf[E2_B + a]) - sdot * vp[a];
+    __syncthreads();
+    const double zch = zc[cb + lane];
+    const double tva = tau * va;
+    double *dst = B + (r - E2_B + cb) * E2_LDB + E2_B + a - cb;
+#pragma unroll
+    for (int c = 0; c < 64; ++c) {
+      double e = er[c] - ya * bc_bcast(vph, c) - tva * bc_bcast(zch, c);
+      if (cb + c == 0) e = (a == 0) ? beta : 0.0;
+      if (a < L) dst[c * (E2_LDB - 1)] = e;
+    }
+  } else if (h == 0 && a < L) {
+    B[j * E2_LDB + 1 + a] = (a == 0) ? beta : 0.0;
+  }
+  BC_STAMP(4);
+  if (tau == 0.0) return; // H = I (uniform over the block)
+  // diagonal block (lower triangle dr, diagonal included): p = tau D v = tau (L v + strict(L)^T v),
+  // w = p - (tau/2)(v.p) v, D -= v w^T + w v^T
+  __syncthreads(); // the column sums above are done with E
+  const double vh = v[cb + lane];
+  double p1 = 0.0;
+#pragma unroll
+  for (int c = 0; c < 64; ++c) {
+    E[(cb + c) * BC_LD + a] = (a > cb + c) ? dr[c] : 0.0; // strictly lower part for the transposed product
+    p1 += dr[c] * bc_bcast(vh, c);
+  }
+  ybuf[h * E2_B + a] = p1;
+  __syncthreads();
+  BC_STAMP(5);
+  {
+    double p2 = 0.0;
+#pragma unroll
+    for (int q = 0; q < 64; ++q) p2 += E[a * BC_LD + cb + q] * bc_bcast(vh, q); // column a, rows cb + q; vh = v of those rows
+    zbuf[h * E2_B + a] = p2;
+  }
+  __syncthreads();
+  const double pa = tau * ((ybuf[a] + ybuf[E2_B + a]) + (zbuf[a] + zbuf[E2_B + a]));
+  const double gamma = e2_bsum256((h == 0) ? va * pa : 0.0, red);
+  const double wa = pa - 0.5 * tau * gamma * va;
+  if (h == 0) wv[a] = wa;
+  __syncthreads();
+  BC_STAMP(6);
+  {
+    const double wh = wv[cb + lane];
+    double *dst = B + (r + cb) * E2_LDB + a - cb;
+#pragma unroll
+    for (int c = 0; c < 64; ++c)
+      if (a >= cb + c && a < L) dst[c * (E2_LDB - 1)] = dr[c] - va * bc_bcast(wh, c) - wa * bc_bcast(vh, c);
+  }
+  BC_STAMP(7);
+}
+
+__global__ __launch_bounds__(256) void bc_step_kernel(BcArgs g) {
+  extern __shared__ double e2sm[];
+  const long n = g.n, j = g.jlo + blockIdx.x, k = g.t - 2 * j;
+  if (k < 0 || j > n - 3 || j + 1 + k * E2_B >= n) return;
+  bc_task(g.Bd, n, j, k, g.V2, g.tau2, e2sm);
+}
+
+// The same chase as ONE launch: workgroup w owns the chase positions k = 2 w and 2 w + 1 and walks the sweeps j = 0, 1, ...;
+// (j, k) waits for (j, k-1) and (j-1, k+1) through per-position progress counters (agent-scope release / acquire).  A
+// sweep can start only two steps behind its predecessor, so one workgroup alternating between two adjacent positions is
+// never the bottleneck, and ceil(positions / 2) <= number of CUs keeps every workgroup resident (the host checks it; the
+// per-step launches above remain as the fallback).  Every wait is bounded: a time-out raises *err and all workgroups leave.
+struct BcPersistArgs {
+  double *Bd;
+  long n;
+  double *V2, *tau2;
+  int *prog, *err;
+  long long *dbg; // GEMMA_HIP_EIGH_BC_DBG=1: wall-clock stamps (100 MHz) of workgroup 1's first tasks, 16 per task
+};
+__device__ __forceinline__ bool bc_wait(int *p, int target, int *err) {
+  for (long it = 0; it < (1L << 22); ++it) {
+    if (__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) return true;
+    if ((it & 63) == 63 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return false;
+    __builtin_amdgcn_s_sleep(1);
+  }
+  __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return false;
+}
+__global__ __launch_bounds__(256) void bc_persist_kernel(BcPersistArgs g) {
+  extern __shared__ double e2sm[];
+  __shared__ int s_ok;
+  const long n = g.n;
+  const long k0 = 2 * (long)blockIdx.x;
+  for (long j = 0; j <= n - 3; ++j) {
+    if (j + 1 + k0 * E2_B >= n) break;
+    for (int sidx = 0; sidx < 2; ++sidx) {
+      const long k = k0 + sidx;
+      if (j + 1 + k * E2_B >= n) break;
+      if (threadIdx.x == 0) {
+        bool ok = true;
+        if (sidx == 0 && k > 0) ok = bc_wait(g.prog + (k - 1), (int)(j + 1), g.err);
+        if (ok && sidx == 1 && j >= 1 && j + (k + 1) * E2_B < n) ok = bc_wait(g.prog + (k + 1), (int)j, g.err);
+        s_ok = ok ? 1 : 0;
+      }
+      __syncthreads();
+      if (!s_ok) return;
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      long long *dbg = (g.dbg && blockIdx.x == 1 && sidx == 0 && j < 512) ? g.dbg + 16 * j : nullptr;
+      bc_task(g.Bd, n, j, k, g.V2, g.tau2, e2sm, dbg);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      __syncthreads();
+      if (threadIdx.x == 0) __hip_atomic_store(g.prog + k, (int)(j + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (dbg && threadIdx.x == 0) dbg[8] = (long long)wall_clock64();
+    }
+  }
+}
+
+// ---------------------------------------------------------------- stage-2 back-transformation
+// group (Jb, k): sweeps J0 = 32 Jb .. J0 + 31 at chase step k; first window column c0 = J0 + 1 + 128 k.
+// pack: V as 160 x 34 (V[wc][jj] = v_{J0+jj,k}[wc - jj]) then T (32 x 34, forward compact WY, row-major upper).
+struct Q2PackArgs {
+  const double *V2, *tau2;
+  long n;
+  const long *goff; // first group index of sweep block Jb
+  double *pack;
+};
+__global__ __launch_bounds__(256) void q2_pack_kernel(Q2PackArgs g) {
+  __shared__ double Vd[E2_WIN][E2_NB + 1];
+  __shared__ double Ss[E2_NB][E2_NB + 1], Tt[E2_NB][E2_NB + 1], stau[E2_NB];
+  const int t = threadIdx.x;
+  const long n = g.n, Jb = blockIdx.x, k = blockIdx.y, J0 = Jb * E2_NB;
+  if (J0 > n - 3 || J0 + 1 + k * E2_B >= n) return;
+  for (int idx = t; idx < E2_WIN * (E2_NB + 1); idx += 256) (&Vd[0][0])[idx] = 0.0;
+  __syncthreads();
+  for (int idx = t; idx < E2_NB * E2_B; idx += 256) {
+    const int jj = idx >> 7, i = idx & (E2_B - 1);
+    const long j = J0 + jj;
+    const bool ex = (j <= n - 3) && (j + 1 + k * E2_B < n);
+    if (ex) Vd[jj + i][jj] = g.V2[((size_t)k * n + j) * E2_B + i];
+    if (i == 0) stau[jj] = ex ? g.tau2[k * n + j] : 0.0;
+  }
+  __syncthreads();
+  for (int idx = t; idx < E2_NB * E2_NB; idx += 256) {
+    const int p = idx >> 5, q = idx & (E2_NB - 1);
+    double s = 0.0;
+    if (p < q)
+      for (int wc = q; wc < p + E2_B && wc < E2_WIN; ++wc) s += Vd[wc][p] * Vd[wc][q];
+    Ss[p][q] = s;
+    Tt[p][q] = 0.0;
+  }
+  __syncthreads();
+  for (int i = 0; i < E2_NB; ++i) {
+    if (t < i) {
+      double acc = 0.0;
+      for (int c = t; c < i; ++c) acc += Tt[t][c] * Ss[c][i];
+      Tt[t][i] = -stau[i] * acc;
+    }
+    if (t == i) Tt[i][i] = stau[i];
+    __syncthreads();
+  }
+  double *dst = g.pack + (size_t)(g.goff[Jb] + k) * E2_PACK;
+  for (int idx = t; idx < E2_WIN * E2_VLD; idx += 256) {
+    const int wc = idx / E2_VLD, jj = idx % E2_VLD;
+    dst[idx] = (jj < E2_NB) ? Vd[wc][jj] : 0.0;
+  }
+  for (int idx = t; idx < E2_NB * E2_VLD; idx += 256) {
+    const int p = idx / E2_VLD, q = idx % E2_VLD;
+    dst[E2_WIN * E2_VLD + idx] = (q < E2_NB) ? Tt[p][q] : 0.0;
+  }
+}
+
+typedef double e2_v4 __attribute__((ext_vector_type(4)));
+typedef double e2_v2 __attribute__((ext_vector_type(2)));
+
+struct Q2ApplyArgs {
+  double *ZT;
+  long n;
+  const double *pack;
+  const long *goff;
+  int nJ, kmaxall;
+};
+// 4 wavefronts x 16 rows of Z^T per workgroup.  Lane l = (li = l & 15, lk = l >> 4) holds
+// x[4 ct + r] = Z^T[row0 + li][c0 + 16 ct + lk + 4 r]: tile ct of X^T in the MFMA accumulator layout, and at the same
+// time the operand fragment of k-step 4 ct + r.
+__global__ __launch_bounds__(256, 2) void q2_apply_kernel(Q2ApplyArgs g) {
+  __shared__ double Ls[E2_PACK];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, li = lane & 15, lk = lane >> 4;
+  const long n = g.n;
+  const long row = (long)blockIdx.x * 64 + wave * 16 + li;
+  const bool rok = row < n;
+  double *zrow = g.ZT + (rok ? row : 0) * n;
+  constexpr int NT = E2_WIN / 16; // 10 window tiles
+  constexpr int PK_N = (E2_PACK / 2 + 255) / 256; // 16-byte pieces of a pack per thread
+  double x[4 * NT];
+  e2_v2 pk[PK_N];
+  {
+    const long lim0 = n - 2; // first group: k = 0, the last sweep block
+    const long Jb0 = (lim0 / E2_NB < g.nJ - 1) ? lim0 / E2_NB : g.nJ - 1;
+    const e2_v2 *src = reinterpret_cast<const e2_v2 *>(g.pack + (size_t)(g.goff[Jb0]) * E2_PACK);
+#pragma unroll
+    for (int q = 0; q < PK_N; ++q)
+      if (t + 256 * q < E2_PACK / 2) pk[q] = src[t + 256 * q];
+  }
+  for (int k = 0; k < g.kmaxall; ++k) {
+    const long lim = n - 2 - (long)k * E2_B; // sweep blocks with J0 <= lim have a task at step k
+    if (lim < 0) break;
+    long Jbmax = lim / E2_NB;
+    if (Jbmax > g.nJ - 1) Jbmax = g.nJ - 1;
+    for (long Jb = Jbmax; Jb >= 0; --Jb) {
+      const long c0 = Jb * E2_NB + 1 + (long)k * E2_B;
+      if (Jb == Jbmax) {
+#pragma unroll
+        for (int ct = 0; ct < NT; ++ct)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const long col = c0 + 16 * ct + lk + 4 * r;
+            x[4 * ct + r] = (rok && col < n) ? zrow[col] : 0.0;
+          }
+      } else {
+        // the window moved down by 32 columns: tiles 8, 9 leave (their columns are c0 + 160 .. c0 + 191 of the new c0)
+#pragma unroll
+        for (int ct = NT - 2; ct < NT; ++ct)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const long col = c0 + E2_NB + 16 * ct + lk + 4 * r;
+            if (rok && col < n) zrow[col] = x[4 * ct + r];
+          }
+#pragma unroll
+        for (int q = 4 * NT - 1; q >= 8; --q) x[q] = x[q - 8];
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const long col = c0 + 16 * ct + lk + 4 * r;
+            x[4 * ct + r] = (rok && col < n) ? zrow[col] : 0.0;
+          }
+      }
+      __syncthreads(); // everyone is done with the previous group's V and T
+#pragma unroll
+      for (int q = 0; q < PK_N; ++q)
+        if (t + 256 * q < E2_PACK / 2) reinterpret_cast<e2_v2 *>(Ls)[t + 256 * q] = pk[q];
+      __syncthreads();
+      {
+        // the next group's pack (the next sweep block of this k, or the first one of k + 1) goes into registers now and is
+        // in flight behind the MFMAs of this group
+        long nJb = Jb - 1, nk = k;
+        if (nJb < 0) {
+          nk = k + 1;
+          const long nlim = n - 2 - nk * E2_B;
+          nJb = (nk < g.kmaxall && nlim >= 0) ? (nlim / E2_NB < g.nJ - 1 ? nlim / E2_NB : g.nJ - 1) : -1;
+        }
+        if (nJb >= 0) {
+          const e2_v2 *src = reinterpret_cast<const e2_v2 *>(g.pack + (size_t)(g.goff[nJb] + nk) * E2_PACK);
+#pragma unroll
+          for (int q = 0; q < PK_N; ++q)
+            if (t + 256 * q < E2_PACK / 2) pk[q] = src[t + 256 * q];
+        }
+      }
+      const double *Vd = Ls, *Tm = Ls + E2_WIN * E2_VLD;
+      // W^T (32 x 16) = V^T X^T
+      e2_v4 wt0 = {0.0, 0.0, 0.0, 0.0}, wt1 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int ks = 0; ks < E2_WIN / 4; ++ks) {
+        // V[wc][jj] = 0 outside 0 <= wc - jj < 128: sweeps 0..15 end at window column 142, sweeps 16..31 start at 16
+        if (4 * ks < E2_B + 16) {
+          const double a0 = Vd[(4 * ks + lk) * E2_VLD + li];
+          wt0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, x[ks], wt0, 0, 0, 0);
+        }
+        if (4 * ks + 3 >= 16) {
+          const double a1 = Vd[(4 * ks + lk) * E2_VLD + 16 + li];
+          wt1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, x[ks], wt1, 0, 0, 0);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      // W2^T = T W^T
+      e2_v4 w20 = {0.0, 0.0, 0.0, 0.0}, w21 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int ks = 0; ks < E2_NB / 4; ++ks) {
+        const double b = (ks < 4) ? wt0[ks & 3] : wt1[ks & 3];
+        const double a0 = Tm[li * E2_VLD + 4 * ks + lk], a1 = Tm[(16 + li) * E2_VLD + 4 * ks + lk];
+        w20 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b, w20, 0, 0, 0);
+        w21 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b, w21, 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      // X^T tile ct -= V[16 ct .., :] W2^T
+#pragma unroll
+      for (int ct = 0; ct < NT; ++ct) {
+        e2_v4 acc = {x[4 * ct], x[4 * ct + 1], x[4 * ct + 2], x[4 * ct + 3]};
+#pragma unroll
+        for (int ks = 0; ks < E2_NB / 4; ++ks) {
+          if ((ct == 0 && ks >= 4) || (ct == NT - 1 && ks < 4)) continue; // zero corners of the parallelogram
+          const double a = -Vd[(16 * ct + li) * E2_VLD + 4 * ks + lk];
+          const double b = (ks < 4) ? w20[ks & 3] : w21[ks & 3];
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+        }
+        x[4 * ct] = acc[0];
+        x[4 * ct + 1] = acc[1];
+        x[4 * ct + 2] = acc[2];
+        x[4 * ct + 3] = acc[3];
+        __builtin_amdgcn_sched_barrier(0); // keep the operand reads of later tiles from being hoisted (register pressure)
+      }
+      if (Jb == 0) {
+#pragma unroll
+        for (int ct = 0; ct < NT; ++ct)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const long col = c0 + 16 * ct + lk + 4 * r;
+            if (rok && col < n) zrow[col] = x[4 * ct + r];
+          }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------- host orchestration
+struct Eig2Ws {
+  double *Bd = nullptr, *part = nullptr, *heads = nullptr, *betas = nullptr, *gramP = nullptr, *YT = nullptr;
+  double *V2 = nullptr, *tau2 = nullptr, *pack = nullptr;
+  long *goff = nullptr;
+  int *prog = nullptr; // progress counters of the persistent bulge chase (+ the error flag)
+  long ngroups = 0, kmaxall = 0, nJ = 0;
+};
+
+static inline int eig2_gram(const double *X, const double *Y, long ld, long K, double *P, double *S, hipStream_t s,
+                            std::string &msg) {
+  const int nwg = (int)((K + GR_CH - 1) / GR_CH);
+  hipLaunchKernelGGL(sb_gram_kernel, dim3(nwg), dim3(256), 0, s, X, ld, Y, ld, K, P);
+  hipLaunchKernelGGL(sb_gram_reduce_kernel, dim3(E2_B * E2_B / 256), dim3(256), 0, s, P, nwg, S);
+  EIG_HIP(hipGetLastError());
+  return 0;
+}
+
+// A (n x n, both triangles) -> band in w2.Bd; reflectors in ws.VT (row j0 + c: reflector c of the panel at j0, head at
+// column j0 + 128 + c), their compact-WY factors in ws.Tall.  A is destroyed.
+static inline int eig2_sy2sb(double *A, long n, EigWs &ws, Eig2Ws &w2, hipStream_t s, std::string &msg) {
+  const long nb2 = (long)E2_B * E2_B;
+  EIG_HIP(hipMemsetAsync(ws.VT, 0, (size_t)n * n * 8, s));
+  EIG_HIP(hipMemsetAsync(ws.tau, 0, (size_t)n * 8, s));
+  EIG_HIP(hipMemsetAsync(w2.betas, 0xFF, (size_t)n * 8, s));
+  EIG_HIP(hipMemsetAsync(ws.Tall, 0, (size_t)((n + E2_B - 1) / E2_B) * nb2 * 8, s));
+  static bool attr = false;
+  if (!attr) {
+    EIG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(sb_tfactor_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (E2_B * E2_B + E2_B) * 8));
+    attr = true;
+  }
+  for (long j0 = 0;; j0 += E2_B) {
+    const long r0 = j0 + E2_B, m = n - r0;
+    if (m < 2) break;
+    const int kk = (int)std::min<long>(E2_B, m - 1);
+    const int nwg = (int)((m + SB_COLS - 1) / SB_COLS);
+    SbPanelArgs pa{A, n, j0, 0, kk, nwg, ws.VT, w2.part, w2.heads, ws.tau, w2.betas};
+    for (int c = 0; c <= kk; ++c) {
+      pa.c = c;
+      hipLaunchKernelGGL(sb_panel_kernel, dim3(nwg), dim3(256), 0, s, pa);
+    }
+    EIG_HIP(hipGetLastError());
+    const long p = j0 / E2_B;
+    const double *Vr = ws.VT + j0 * n + r0;
+    double *A22 = A + r0 * n + r0;
+    double *T = ws.Tall + p * nb2;
+    int rc = eig2_gram(Vr, Vr, n, m, w2.gramP, ws.S, s, msg);
+    if (rc) return rc;
+    hipLaunchKernelGGL(sb_tfactor_kernel, dim3(1), dim3(256), (E2_B * E2_B + E2_B) * 8, s, ws.S, ws.tau + j0, T);
+    EIG_HIP(hipGetLastError());
+    // Z1 = V^T A22 (128 x m), Y^T = T^T Z1
+    EIG_HIP(launch_dgemm('N', 'N', E2_B, m, m, 1.0, Vr, n, A22, n, 0.0, ws.WT, n, false, false, s));
+    EIG_HIP(launch_dgemm('T', 'N', E2_B, m, E2_B, 1.0, T, E2_B, ws.WT, n, 0.0, w2.YT, n, false, false, s));
+    // W^T = Y^T - (Mid^T T / 2) V^T,  Mid = V^T Y
+    rc = eig2_gram(Vr, w2.YT, n, m, w2.gramP, ws.S, s, msg);
+    if (rc) return rc;
+    EIG_HIP(launch_dgemm('T', 'N', E2_B, E2_B, E2_B, 0.5, ws.S, E2_B, T, E2_B, 0.0, ws.T, E2_B, false, false, s));
+    EIG_HIP(launch_dgemm('N', 'N', E2_B, m, E2_B, -1.0, ws.T, E2_B, Vr, n, 1.0, w2.YT, n, false, false, s));
+    // A22 -= V W^T + W V^T
+    EIG_HIP(launch_dgemm('T', 'N', m, m, E2_B, -1.0, Vr, n, w2.YT, n, 1.0, A22, n, false, false, s));
+    EIG_HIP(launch_dgemm('T', 'N', m, m, E2_B, -1.0, w2.YT, n, Vr, n, 1.0, A22, n, false, false, s));
+  }
+  hipLaunchKernelGGL(sb_extract_band_kernel, dim3((unsigned)n), dim3(256), 0, s, A, n, w2.betas, w2.Bd);
+  EIG_HIP(hipGetLastError());
+  return 0;
+}
+
+// band -> tridiagonal (ws.d, ws.e); reflectors in w2.V2 / w2.tau2
+static inline int eig2_sb2st(long n, EigWs &ws, Eig2Ws &w2, hipStream_t s, std::string &msg) {
+  static bool attr = false;
+  if (!attr) {
+    EIG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(bc_step_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, BC_LDS_DOUBLES * 8));
+    attr = true;
+  }
+  EIG_HIP(hipMemsetAsync(w2.tau2, 0, (size_t)w2.kmaxall * n * 8, s));
+  const long b = E2_B, tmax = 2 * (n - 3);
+  {
+    // one persistent launch when every workgroup can be resident (one per CU: 140 KB of LDS each); GEMMA_HIP_EIGH_BC=steps
+    // forces the per-step launches
+    static int ncu = 0;
+    if (!ncu) {
+      int dev = 0;
+      hipDeviceProp_t prop;
+      if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ncu = prop.multiProcessorCount;
+      if (ncu <= 0) ncu = 1;
+      EIG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(bc_persist_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, BC_LDS_DOUBLES * 8));
+    }
+    const char *eb = getenv("GEMMA_HIP_EIGH_BC");
+    const long nwg = (w2.kmaxall + 1) / 2;
+    if (!(eb && eb[0] == 's') && nwg <= ncu) {
+      EIG_HIP(hipMemsetAsync(w2.prog, 0, (size_t)(w2.kmaxall + 2) * sizeof(int), s));
+      BcPersistArgs pa{w2.Bd, n, w2.V2, w2.tau2, w2.prog, w2.prog + w2.kmaxall + 1, nullptr};
+      const char *ed = getenv("GEMMA_HIP_EIGH_BC_DBG");
+      long long *dbg_d = nullptr;
+      if (ed && ed[0] == '1' && hipMalloc(reinterpret_cast<void **>(&dbg_d), 512 * 16 * 8) == hipSuccess) {
+        (void)hipMemsetAsync(dbg_d, 0, 512 * 16 * 8, s);
+        pa.dbg = dbg_d;
+      }
+      hipLaunchKernelGGL(bc_persist_kernel, dim3((unsigned)nwg), dim3(256), BC_LDS_DOUBLES * 8, s, pa);
+      EIG_HIP(hipGetLastError());
+      if (dbg_d) {
+        std::vector<long long> hs(512 * 16);
+        (void)hipStreamSynchronize(s);
+        (void)hipMemcpy(hs.data(), dbg_d, hs.size() * 8, hipMemcpyDeviceToHost);
+        (void)hipFree(dbg_d);
+        double acc[9] = {0};
+        int cnt = 0;
+        for (int jj = 128; jj < 512; ++jj) {
+          const long long *q = hs.data() + 16 * jj;
+          if (!q[0] || !q[8]) continue;
+          for (int i = 1; i <= 8; ++i) acc[i] += (double)(q[i] - q[i - 1]) * 0.01;
+          acc[0] += (jj + 1 < 512 && hs[16 * (jj + 1)]) ? (double)(hs[16 * (jj + 1)] - q[0]) * 0.01 : 0.0;
+          ++cnt;
+        }
+        if (cnt)
+          fprintf(stderr, "bulge chase, position 2 (us per task): load+LDS %.2f | y,update %.2f | larfg %.2f | z,store %.2f | "
+                          "D to LDS %.2f | p,gamma %.2f | D update,store %.2f | fence+flag %.2f | sweep period %.2f\n",
+                  acc[1] / cnt, acc[2] / cnt, acc[3] / cnt, acc[4] / cnt, acc[5] / cnt, acc[6] / cnt, acc[7] / cnt, acc[8] / cnt,
+                  acc[0] / cnt);
+      }
+      int err = 0;
+      EIG_HIP(hipMemcpyAsync(&err, w2.prog + w2.kmaxall + 1, sizeof(int), hipMemcpyDeviceToHost, s));
+      EIG_HIP(hipStreamSynchronize(s));
+      if (err) {
+        msg = "band -> tridiagonal: a workgroup of the persistent bulge chase timed out waiting for its neighbour";
+        return 5;
+      }
+      hipLaunchKernelGGL(sb_band_de_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, w2.Bd, n, ws.d, ws.e);
+      EIG_HIP(hipGetLastError());
+      return 0;
+    }
+  }
+  BcArgs a{w2.Bd, n, 0, 0, w2.V2, w2.tau2};
+  for (long t = 0; t <= tmax; ++t) {
+    const long num = t * b - n + 1;
+    const long jlo = num >= 0 ? num / (2 * b - 1) + 1 : 0;
+    const long jhi = std::min<long>(n - 3, t / 2);
+    if (jlo > jhi) continue;
+    a.t = t;
+    a.jlo = jlo;
+    hipLaunchKernelGGL(bc_step_kernel, dim3((unsigned)(jhi - jlo + 1)), dim3(256), BC_LDS_DOUBLES * 8, s, a);
+    if ((t & 1023) == 0) EIG_HIP(hipGetLastError());
+  }
+  hipLaunchKernelGGL(sb_band_de_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, w2.Bd, n, ws.d, ws.e);
+  EIG_HIP(hipGetLastError());
+  return 0;
+}
+
+// Z^T <- Z^T Q2^T (the reflectors of the bulge chase)
+static inline int eig2_apply_q2(double *ZT, long n, Eig2Ws &w2, hipStream_t s, std::string &msg) {
+  Q2PackArgs pa{w2.V2, w2.tau2, n, w2.goff, w2.pack};
+  hipLaunchKernelGGL(q2_pack_kernel, dim3((unsigned)w2.nJ, (unsigned)w2.kmaxall), dim3(256), 0, s, pa);
+  EIG_HIP(hipGetLastError());
+  Q2ApplyArgs aa{ZT, n, w2.pack, w2.goff, (int)w2.nJ, (int)w2.kmaxall};
+  hipLaunchKernelGGL(q2_apply_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, s, aa);
+  EIG_HIP(hipGetLastError());
+  return 0;
+}
+
+// Z^T <- Z^T Q1^T (stage-1 panels, compact WY: three GEMMs per panel as in eig_backtransform)
+static inline int eig2_apply_q1(double *ZT, long n, EigWs &ws, hipStream_t s, std::string &msg) {
+  const long nb2 = (long)E2_B * E2_B;
+  long last = -1;
+  for (long j0 = 0; n - (j0 + E2_B) >= 2; j0 += E2_B) last = j0;
+  for (long j0 = last; j0 >= 0; j0 -= E2_B) {
+    const long c0 = j0 + E2_B, Kc = n - c0;
+    const double *Y = ws.VT + j0 * n + c0;
+    const double *T = ws.Tall + (j0 / E2_B) * nb2;
+    EIG_HIP(launch_dgemm('N', 'T', n, E2_B, Kc, 1.0, ZT + c0, n, Y, n, 0.0, ws.P, E2_B, false, false, s));
+    EIG_HIP(launch_dgemm('N', 'T', n, E2_B, E2_B, 1.0, ws.P, E2_B, T, E2_B, 0.0, ws.P2, E2_B, false, false, s));
+    EIG_HIP(launch_dgemm('N', 'N', n, Kc, E2_B, -1.0, ws.P2, E2_B, Y, n, 1.0, ZT + c0, n, false, false, s));
+  }
+  return 0;
+}
+
+static inline bool eig2_alloc(long n, EigWs &ws, Eig2Ws &w2) {
+  const long nsweep = n - 2;
+  w2.kmaxall = (n - 1 + E2_B - 1) / E2_B;
+  w2.nJ = (nsweep + E2_NB - 1) / E2_NB;
+  std::vector<long> goff((size_t)w2.nJ + 1, 0);
+  for (long Jb = 0; Jb < w2.nJ; ++Jb) {
+    const long J0 = Jb * E2_NB;
+    goff[Jb + 1] = goff[Jb] + (n - 1 - J0 + E2_B - 1) / E2_B; // tasks of the block's first sweep
+  }
+  w2.ngroups = goff[w2.nJ];
+  const size_t nwg_panel = (size_t)(n + SB_COLS - 1) / SB_COLS, nwg_gram = (size_t)(n + GR_CH - 1) / GR_CH;
+  bool ok = ws.get(w2.Bd, (size_t)n * E2_LDB) && ws.get(w2.part, 2 * nwg_panel * E2_B) && ws.get(w2.heads, 2 * E2_B) &&
+            ws.get(w2.betas, n) && ws.get(w2.gramP, nwg_gram * E2_B * E2_B) && ws.get(w2.YT, (size_t)E2_B * n) &&
+            ws.get(w2.V2, (size_t)w2.kmaxall * n * E2_B) && ws.get(w2.tau2, (size_t)w2.kmaxall * n) &&
+            ws.get(w2.pack, (size_t)w2.ngroups * E2_PACK) && ws.get(w2.goff, (size_t)w2.nJ + 1) &&
+            ws.get(w2.prog, (size_t)w2.kmaxall + 4);
+  if (!ok) return false;
+  return hipMemcpy(w2.goff, goff.data(), goff.size() * sizeof(long), hipMemcpyHostToDevice) == hipSuccess;
+}
+
+} // namespace gemma_hip

@@ -672,6 +672,39 @@ extern "C" int gemma_hip_dbg_tridiag(const double *G, size_t n, double *d, doubl
   return GEMMA_HIP_OK;
 }
 
+// two-stage reduction only (eigh2.hip.h): G (host, n x n, n even, n >= 384) -> band after stage 1 (n x 129: row j holds
+// B(j .. j+128, j)) and the tridiagonal d[n], e[n-1] after the bulge chase
+extern "C" int gemma_hip_dbg_eigh2(const double *G, size_t n, double *band, double *d, double *e) {
+  NEED_INIT();
+  if (n < 3 * (size_t)E2_B || (n & 1)) return fail(GEMMA_HIP_EINVAL, "dbg_eigh2: n must be even and >= %d", 3 * E2_B);
+  EigWs ws;
+  Eig2Ws w2;
+  DevBuf dG;
+  const size_t nn = n * n;
+  if (dG.reserve(nn * 8)) return fail(GEMMA_HIP_ENOMEM, "dbg_eigh2");
+  bool ok = ws.get(ws.VT, nn) && ws.get(ws.WT, (size_t)EIG_NB * n) && ws.get(ws.d, n) && ws.get(ws.e, n) &&
+            ws.get(ws.tau, n) && ws.get(ws.S, (size_t)EIG_NB * EIG_NB) && ws.get(ws.T, (size_t)EIG_NB * EIG_NB) &&
+            ws.get(ws.Tall, ((n + EIG_NB - 1) / EIG_NB) * EIG_NB * EIG_NB) && eig2_alloc((long)n, ws, w2);
+  std::string msg;
+  int rc = ok ? 0 : GEMMA_HIP_ENOMEM;
+  if (!rc && hipMemcpy(dG.p, G, nn * 8, hipMemcpyHostToDevice) != hipSuccess) rc = GEMMA_HIP_ERUNTIME;
+  if (!rc) rc = eig2_sy2sb(dG.as<double>(), (long)n, ws, w2, 0, msg);
+  if (!rc && hipDeviceSynchronize() != hipSuccess) rc = GEMMA_HIP_ERUNTIME;
+  if (!rc && band &&
+      hipMemcpy2D(band, (E2_B + 1) * 8, w2.Bd, E2_LDB * 8, (E2_B + 1) * 8, n, hipMemcpyDeviceToHost) != hipSuccess)
+    rc = GEMMA_HIP_ERUNTIME;
+  if (!rc) rc = eig2_sb2st((long)n, ws, w2, 0, msg);
+  if (!rc && hipDeviceSynchronize() != hipSuccess) rc = GEMMA_HIP_ERUNTIME;
+  if (!rc) {
+    (void)hipMemcpy(d, ws.d, n * 8, hipMemcpyDeviceToHost);
+    (void)hipMemcpy(e, ws.e, (n - 1) * 8, hipMemcpyDeviceToHost);
+  }
+  ws.release();
+  dG.release();
+  if (rc) return fail(rc, "dbg_eigh2: %s (%s)", msg.c_str(), hipGetErrorString(hipGetLastError()));
+  return GEMMA_HIP_OK;
+}
+
 // divide-and-conquer on a symmetric tridiagonal (host d[n], e[n-1]) -> w[n] ascending, ZT (n x n, row k =
 // eigenvector k)
 extern "C" int gemma_hip_dbg_stedc(const double *d, const double *e, size_t n, double *w, double *ZT) {

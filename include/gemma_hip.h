@@ -305,6 +305,9 @@ int gemma_hip_profile_read(int stage, double *total_ms, long *launches, int rese
 int gemma_hip_dbg_tridiag(const double *G, size_t n, double *d, double *e, double *tau, double *VT);
 /* divide and conquer on a symmetric tridiagonal: w[n] ascending, ZT (n x n, row k = eigenvector k) */
 int gemma_hip_dbg_stedc(const double *d, const double *e, size_t n, double *w, double *ZT);
+/* two-stage reduction of the eigensolver alone (n even, >= 384): band (n x 129, row j = B(j..j+128, j)) after the dense ->
+ * band stage, d[n], e[n-1] after the bulge chase */
+int gemma_hip_dbg_eigh2(const double *G, size_t n, double *band, double *d, double *e);
 /* the U^T x stage of gemma_hip_lmm_batch alone (after lmm_setup; host pointers): UtX is l x n row-major, row s =
  * (U^T x_s)^T of the mean-imputed SNP s (the column fast_dgemm("T","N",U,Xlarge) produces, GEMMA src/lmm.cpp:1521).
  * path 0: fp64 MFMA GEMM; path 1: exact int8-digit product (PLINK 2-bit input only, see csrc/i8gemm.hip.h) */

@@ -123,14 +123,18 @@ def band_to_tridiag(B, b, schedule="pipelined"):
     return d, e, V2, A
 
 
-def apply_q2_grouped(Z, V2, n, b, nb):
+def apply_q2_grouped(Z, V2, n, b, nb, order="k_outer"):
     """Z <- Q2 Z with Q2 = prod_{j ascending} prod_{k ascending} H_{j,k}: sweep blocks J from the last to the first, inside
     a block k ASCENDING, each group (J, k) as one compact-WY block reflector of the nb sweeps (rows shift by one per sweep)."""
     nsweep = n - 2
     kmax = lambda j: -(-(n - 1 - j) // b)
-    for J0 in reversed(range(0, nsweep, nb)):
+    if order == "J_outer":
+        seq = [(J0, k) for J0 in reversed(range(0, nsweep, nb)) for k in range(kmax(J0))]
+    else:  # what q2_apply_kernel does: k ascending outside, sweep blocks descending inside (the window slides by nb columns)
+        seq = [(J0, k) for k in range(kmax(0)) for J0 in reversed(range(0, nsweep, nb)) if k < kmax(J0)]
+    for (J0, k) in seq:
         js = list(range(J0, min(J0 + nb, nsweep)))
-        for k in range(kmax(J0)):
+        if True:
             r0 = J0 + 1 + k * b
             width = min(b + len(js) - 1, n - r0)
             if width <= 0:
@@ -181,6 +185,8 @@ def main():
     T = np.diag(d) + np.diag(e, 1) + np.diag(e, -1)
     w, Z = np.linalg.eigh(T)
     U = apply_q1(apply_q2_grouped(Z.copy(), V2, n, b, nb), refl)
+    U2 = apply_q1(apply_q2_grouped(Z.copy(), V2, n, b, nb, "J_outer"), refl)
+    print("Q2 group order k-outer vs J-outer: %.2e" % np.abs(U - U2).max())
     scale = np.abs(A).max() * n
     print("eigenvalues vs LAPACK %.2e" % (np.abs(w - np.linalg.eigvalsh(A)).max() / np.abs(w).max()))
     print("||A U - U w|| / (n |A|) %.2e   ||U^T U - I|| %.2e" % (np.abs(A @ U - U * w).max() / scale,
