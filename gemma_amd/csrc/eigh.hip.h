@@ -1143,7 +1143,7 @@ static inline int eigh_device(double *G, long n, double *U, double *eval, hipStr
     if (two) {
       rc = eig2_apply_q2(Z, n, w2, s, msg);
       if (timing) t2a = now();
-      if (!rc) rc = eig2_apply_q1(Z, n, ws, s, msg);
+      if (!rc) rc = eig2_apply_q1(Z, n, ws, w2, s, msg);
     } else {
       rc = eig_backtransform(Z, n, ws, s, msg);
     }

@@ -250,6 +250,23 @@ __global__ __launch_bounds__(256) void sb_tfactor_kernel(const double *__restric
   }
 }
 
+// lower triangle <- transpose of the strict upper triangle (32 x 32 tiles; the upper triangle is only read)
+__global__ void e2_mirror_upper_kernel(double *__restrict__ A, long m, long ld) {
+  __shared__ double tile[32][33];
+  const int bx = blockIdx.x, by = blockIdx.y;
+  if (bx < by) return;
+  const int tx = threadIdx.x, ty = threadIdx.y; // 32 x 8
+  for (int r = ty; r < 32; r += 8) {
+    const long i = (long)by * 32 + r, j = (long)bx * 32 + tx;
+    tile[r][tx] = (i < m && j < m) ? A[i * ld + j] : 0.0;
+  }
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8) {
+    const long j = (long)bx * 32 + r, i = (long)by * 32 + tx;
+    if (i < m && j < m && j > i) A[j * ld + i] = tile[tx][r];
+  }
+}
+
 // band storage from the reduced matrix: Bd[j][t] = A[j][j + t], t <= 128 (row j of the upper triangle is contiguous);
 // the entry at distance 128 of a row that carries a reflector is that reflector's beta
 __global__ __launch_bounds__(256) void sb_extract_band_kernel(const double *__restrict__ A, long n,
@@ -675,6 +692,31 @@ struct Eig2Ws {
   long ngroups = 0, kmaxall = 0, nJ = 0;
 };
 
+// C0 + C1 = alpha op(A) op(B) with the K range cut in two: skinny products (M or N = 128, K = thousands) have only
+// n / 128 output tiles -- fewer than the chip has CUs -- so the two halves run side by side on the caller's stream and on the
+// GEMM side stream; the consumer adds the halves in its own product (beta = 1), no reduction kernel.  Without a side
+// stream C0 gets everything and C1 is cleared.
+static inline int eig2_dgemm_split2(char ta, char tb, long M, long N, long K, double alpha, const double *A, long lda,
+                                    const double *B, long ldb, double *C0, double *C1, long ldc, hipStream_t s,
+                                    std::string &msg) {
+  const long Kh = (K / 2) / GEMM_BK * GEMM_BK;
+  if (!g_gemm_aux.stream || Kh < 4 * GEMM_BK) {
+    EIG_HIP(launch_dgemm(ta, tb, M, N, K, alpha, A, lda, B, ldb, 0.0, C0, ldc, false, false, s));
+    EIG_HIP(hipMemset2DAsync(C1, ldc * 8, 0, N * 8, M, s));
+    return 0;
+  }
+  const bool tA = (ta == 'T'), tB = (tb == 'T');
+  const double *A1 = tA ? A + Kh * lda : A + Kh, *B1 = tB ? B + Kh : B + Kh * ldb;
+  hipStream_t es = g_gemm_aux.stream;
+  EIG_HIP(hipEventRecord(g_gemm_aux.ready, s));
+  EIG_HIP(hipStreamWaitEvent(es, g_gemm_aux.ready, 0));
+  EIG_HIP(launch_dgemm(ta, tb, M, N, K - Kh, alpha, A1, lda, B1, ldb, 0.0, C1, ldc, false, false, es));
+  EIG_HIP(hipEventRecord(g_gemm_aux.done, es));
+  EIG_HIP(launch_dgemm(ta, tb, M, N, Kh, alpha, A, lda, B, ldb, 0.0, C0, ldc, false, false, s));
+  EIG_HIP(hipStreamWaitEvent(s, g_gemm_aux.done, 0));
+  return 0;
+}
+
 static inline int eig2_gram(const double *X, const double *Y, long ld, long K, double *P, double *S, hipStream_t s,
                             std::string &msg) {
   const int nwg = (int)((K + GR_CH - 1) / GR_CH);
@@ -718,16 +760,27 @@ static inline int eig2_sy2sb(double *A, long n, EigWs &ws, Eig2Ws &w2, hipStream
     hipLaunchKernelGGL(sb_tfactor_kernel, dim3(1), dim3(256), (E2_B * E2_B + E2_B) * 8, s, ws.S, ws.tau + j0, T);
     EIG_HIP(hipGetLastError());
     // Z1 = V^T A22 (128 x m), Y^T = T^T Z1
-    EIG_HIP(launch_dgemm('N', 'N', E2_B, m, m, 1.0, Vr, n, A22, n, 0.0, ws.WT, n, false, false, s));
-    EIG_HIP(launch_dgemm('T', 'N', E2_B, m, E2_B, 1.0, T, E2_B, ws.WT, n, 0.0, w2.YT, n, false, false, s));
+    double *SA = w2.YT, *SB = w2.YT + (size_t)2 * E2_B * n; // stacked operands [V; W] and [W; V], 256 x m each (ld n)
+    double *Wr = SA + (size_t)E2_B * n;
+    rc = eig2_dgemm_split2('N', 'N', E2_B, m, m, 1.0, Vr, n, A22, n, ws.WT, SB, n, s, msg);
+    if (rc) return rc;
+    EIG_HIP(launch_dgemm('T', 'N', E2_B, m, E2_B, 1.0, T, E2_B, ws.WT, n, 0.0, Wr, n, false, false, s));
+    EIG_HIP(launch_dgemm('T', 'N', E2_B, m, E2_B, 1.0, T, E2_B, SB, n, 1.0, Wr, n, false, false, s));
     // W^T = Y^T - (Mid^T T / 2) V^T,  Mid = V^T Y
-    rc = eig2_gram(Vr, w2.YT, n, m, w2.gramP, ws.S, s, msg);
+    rc = eig2_gram(Vr, Wr, n, m, w2.gramP, ws.S, s, msg);
     if (rc) return rc;
     EIG_HIP(launch_dgemm('T', 'N', E2_B, E2_B, E2_B, 0.5, ws.S, E2_B, T, E2_B, 0.0, ws.T, E2_B, false, false, s));
-    EIG_HIP(launch_dgemm('N', 'N', E2_B, m, E2_B, -1.0, ws.T, E2_B, Vr, n, 1.0, w2.YT, n, false, false, s));
-    // A22 -= V W^T + W V^T
-    EIG_HIP(launch_dgemm('T', 'N', m, m, E2_B, -1.0, Vr, n, w2.YT, n, 1.0, A22, n, false, false, s));
-    EIG_HIP(launch_dgemm('T', 'N', m, m, E2_B, -1.0, w2.YT, n, Vr, n, 1.0, A22, n, false, false, s));
+    EIG_HIP(launch_dgemm('N', 'N', E2_B, m, E2_B, -1.0, ws.T, E2_B, Vr, n, 1.0, Wr, n, false, false, s));
+    // A22 -= V W^T + W V^T as ONE rank-256 product on the upper-triangle tiles ([V; W]^T [W; V]), then the mirror: the
+    // trailing matrix is read and written once instead of twice, and half of the tiles are never formed
+    EIG_HIP(hipMemcpy2DAsync(SA, n * 8, Vr, n * 8, m * 8, E2_B, hipMemcpyDeviceToDevice, s));
+    EIG_HIP(hipMemcpy2DAsync(SB, n * 8, Wr, n * 8, m * 8, E2_B, hipMemcpyDeviceToDevice, s));
+    EIG_HIP(hipMemcpy2DAsync(SB + (size_t)E2_B * n, n * 8, Vr, n * 8, m * 8, E2_B, hipMemcpyDeviceToDevice, s));
+    EIG_HIP(launch_dgemm('T', 'N', m, m, 2 * E2_B, -1.0, SA, n, SB, n, 1.0, A22, n, true, false, s));
+    {
+      const unsigned nb32 = (unsigned)((m + 31) / 32);
+      hipLaunchKernelGGL(e2_mirror_upper_kernel, dim3(nb32, nb32), dim3(32, 8), 0, s, A22, m, n);
+    }
   }
   hipLaunchKernelGGL(sb_extract_band_kernel, dim3((unsigned)n), dim3(256), 0, s, A, n, w2.betas, w2.Bd);
   EIG_HIP(hipGetLastError());
@@ -829,16 +882,19 @@ static inline int eig2_apply_q2(double *ZT, long n, Eig2Ws &w2, hipStream_t s, s
 }
 
 // Z^T <- Z^T Q1^T (stage-1 panels, compact WY: three GEMMs per panel as in eig_backtransform)
-static inline int eig2_apply_q1(double *ZT, long n, EigWs &ws, hipStream_t s, std::string &msg) {
+static inline int eig2_apply_q1(double *ZT, long n, EigWs &ws, Eig2Ws &w2, hipStream_t s, std::string &msg) {
   const long nb2 = (long)E2_B * E2_B;
+  double *Pb = w2.YT; // second half of the split product (n x 128; the stage-1 operand buffer is free by now)
   long last = -1;
   for (long j0 = 0; n - (j0 + E2_B) >= 2; j0 += E2_B) last = j0;
   for (long j0 = last; j0 >= 0; j0 -= E2_B) {
     const long c0 = j0 + E2_B, Kc = n - c0;
     const double *Y = ws.VT + j0 * n + c0;
     const double *T = ws.Tall + (j0 / E2_B) * nb2;
-    EIG_HIP(launch_dgemm('N', 'T', n, E2_B, Kc, 1.0, ZT + c0, n, Y, n, 0.0, ws.P, E2_B, false, false, s));
+    int rc = eig2_dgemm_split2('N', 'T', n, E2_B, Kc, 1.0, ZT + c0, n, Y, n, ws.P, Pb, E2_B, s, msg);
+    if (rc) return rc;
     EIG_HIP(launch_dgemm('N', 'T', n, E2_B, E2_B, 1.0, ws.P, E2_B, T, E2_B, 0.0, ws.P2, E2_B, false, false, s));
+    EIG_HIP(launch_dgemm('N', 'T', n, E2_B, E2_B, 1.0, Pb, E2_B, T, E2_B, 1.0, ws.P2, E2_B, false, false, s));
     EIG_HIP(launch_dgemm('N', 'N', n, Kc, E2_B, -1.0, ws.P2, E2_B, Y, n, 1.0, ZT + c0, n, false, false, s));
   }
   return 0;
@@ -856,7 +912,7 @@ static inline bool eig2_alloc(long n, EigWs &ws, Eig2Ws &w2) {
   w2.ngroups = goff[w2.nJ];
   const size_t nwg_panel = (size_t)(n + SB_COLS - 1) / SB_COLS, nwg_gram = (size_t)(n + GR_CH - 1) / GR_CH;
   bool ok = ws.get(w2.Bd, (size_t)n * E2_LDB) && ws.get(w2.part, 2 * nwg_panel * E2_B) && ws.get(w2.heads, 2 * E2_B) &&
-            ws.get(w2.betas, n) && ws.get(w2.gramP, nwg_gram * E2_B * E2_B) && ws.get(w2.YT, (size_t)E2_B * n) &&
+            ws.get(w2.betas, n) && ws.get(w2.gramP, nwg_gram * E2_B * E2_B) && ws.get(w2.YT, (size_t)4 * E2_B * n) &&
             ws.get(w2.V2, (size_t)w2.kmaxall * n * E2_B) && ws.get(w2.tau2, (size_t)w2.kmaxall * n) &&
             ws.get(w2.pack, (size_t)w2.ngroups * E2_PACK) && ws.get(w2.goff, (size_t)w2.nJ + 1) &&
             ws.get(w2.prog, (size_t)w2.kmaxall + 4);

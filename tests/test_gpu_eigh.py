@@ -207,3 +207,94 @@ def test_eigh_4096_device(gpu_api):
     print("eigh n=4096: %.2f s, resid %.2f orth %.2f (n*eps), max eval err %.2e" % (dt, float(res), float(orth), float((w - wr).abs().max())))
     assert float(res) < 30 and float(orth) < 30
     assert float((w - wr).abs().max() / nrm) < 1e-12
+
+
+# --------------------------------------------------------------------------- two-stage reduction (eigh2.hip.h)
+@pytest.mark.parametrize("n,kind", [(384, "random"), (386, "kinship"), (768, "kinship"), (1026, "lowrank"),
+                                    (1538, "clustered")])
+def test_two_stage_reduction_stages(gpu_api, n, kind):
+    """dense -> band (panel QR + two-sided GEMM update) and band -> tridiagonal (bulge chase) are orthogonal
+    similarity transformations: both keep the spectrum of the input.  n = 384 / 386: one full panel and the smallest
+    ragged one; 1026 / 1538: last chase blocks shorter than 128 rows."""
+    from gemma_amd import _lib as L
+    from scipy.linalg import eigvalsh_tridiagonal
+    A = _sym(n, 31 * n + 5, kind)
+    band, d, e = np.zeros((n, 129)), np.zeros(n), np.zeros(n - 1)
+    L.check(L.lib().gemma_hip_dbg_eigh2(_p(np.ascontiguousarray(A)), n, _p(band), _p(d), _p(e)), "dbg_eigh2")
+    B = np.zeros((n, n))
+    for t in range(129):
+        idx = np.arange(n - t)
+        B[idx + t, idx] = band[: n - t, t]
+        B[idx, idx + t] = band[: n - t, t]
+    wr = np.linalg.eigvalsh(A)
+    scale = max(np.abs(wr).max(), 1e-300) * n * EPS
+    eb = np.abs(np.linalg.eigvalsh(B) - wr).max() / scale
+    et = np.abs(eigvalsh_tridiagonal(d, e) - wr).max() / scale
+    print("two-stage[%s] n=%d: band eigenvalues %.2f, tridiagonal %.2f (n*eps)" % (kind, n, eb, et))
+    assert eb < 5.0 and et < 5.0
+
+
+@pytest.mark.parametrize("n,kind,chase", [(384, "random", "persist"), (640, "kinship", "persist"), (1000, "kinship", "steps"),
+                                          (1538, "clustered", "persist"), (2050, "lowrank", "persist")])
+def test_eigh_two_stage_end_to_end(gpu_api, n, kind, chase, monkeypatch):
+    """The whole solver on the two-stage path (forced: by default it starts at n = 12000), with the bounds of
+    test_eigh_end_to_end; `steps` runs the bulge chase as one launch per time step instead of the persistent kernel."""
+    monkeypatch.setenv("GEMMA_HIP_EIGH_STAGES", "2")
+    monkeypatch.setenv("GEMMA_HIP_EIGH_BC", chase)
+    A = _sym(n, 7 * n + 3, kind)
+    U, w = np.zeros((n, n)), np.zeros(n)
+    tr = gpu_api.EigenDecomp_Zeroed(A.copy(), U, w)
+    wz = np.linalg.eigvalsh(A)
+    wz[wz < 1e-10] = 0.0
+    assert tr == pytest.approx(wz.mean(), rel=1e-9, abs=1e-12)
+    w_raw = np.where(w == 0.0, np.einsum("ij,ij->j", U, A @ U), w)
+    assert np.linalg.norm(U.T @ U - np.eye(n)) < 50 * n * EPS
+    assert np.linalg.norm(A @ U - U * w_raw[None, :]) / max(np.linalg.norm(A, 2), 1e-300) < 50 * n * EPS
+    assert np.all((w >= 1e-10) | (w == 0.0))
+    monkeypatch.setenv("GEMMA_HIP_EIGH_STAGES", "1")
+    U1, w1 = np.zeros((n, n)), np.zeros(n)
+    gpu_api.EigenDecomp_Zeroed(A.copy(), U1, w1)
+    assert np.abs(w - w1).max() <= 30 * n * EPS * max(np.abs(w1).max(), 1e-300)
+
+
+def test_eigh_two_stage_4096_device(gpu_api, monkeypatch):
+    import torch
+    monkeypatch.setenv("GEMMA_HIP_EIGH_STAGES", "2")
+    n = 4096
+    g = torch.Generator(device="cuda").manual_seed(5)
+    X = torch.randn((n, n // 2), dtype=torch.float64, device="cuda", generator=g)  # rank n / 2: half the spectrum is zero
+    A = X @ X.T / n
+    A = (A + A.T) / 2
+    U = torch.empty_like(A)
+    w = torch.empty(n, dtype=torch.float64, device="cuda")
+    gpu_api.EigenDecomp_Zeroed(A.clone(), U, w)
+    torch.cuda.synchronize()
+    nrm = torch.linalg.matrix_norm(A, 2)
+    res = torch.linalg.matrix_norm(A @ U - U * w[None, :]) / (nrm * n * EPS)
+    orth = torch.linalg.matrix_norm(U.T @ U - torch.eye(n, dtype=torch.float64, device="cuda")) / (n * EPS)
+    wr = torch.linalg.eigvalsh(A).clamp_min(0)
+    print("two-stage eigh n=4096: resid %.2f orth %.2f (n*eps)" % (float(res), float(orth)))
+    assert float(res) < 30 and float(orth) < 30
+    assert float((w - torch.where(wr < 1e-10, torch.zeros_like(wr), wr)).abs().max() / nrm) < 1e-12
+
+
+def test_two_stage_degenerate_inputs(gpu_api, monkeypatch):
+    """Inputs whose reflectors vanish (tau = 0 everywhere): a diagonal matrix and a block-diagonal one on the two-stage
+    path; and a NaN must be reported, not looped on (the bulge-chase kernel's waits are bounded)."""
+    from gemma_amd import _lib as L
+    monkeypatch.setenv("GEMMA_HIP_EIGH_STAGES", "2")
+    n = 512
+    rng = np.random.default_rng(4)
+    dvals = rng.uniform(0.5, 2.0, n)
+    U, w = np.zeros((n, n)), np.zeros(n)
+    gpu_api.EigenDecomp_Zeroed(np.diag(dvals), U, w)
+    assert np.allclose(w, np.sort(dvals), rtol=1e-14) and np.allclose(np.abs(U).sum(0), 1.0, atol=1e-12)
+    A = np.zeros((n, n))
+    for b0 in range(0, n, 64):
+        Bk = rng.standard_normal((64, 64))
+        A[b0:b0 + 64, b0:b0 + 64] = Bk @ Bk.T / 64
+    gpu_api.EigenDecomp_Zeroed(A.copy(), U, w)
+    _check(A, U, w, "two-stage-blockdiag")
+    A[3, 5] = A[5, 3] = np.nan
+    with pytest.raises(L.GemmaHipError):
+        gpu_api.EigenDecomp_Zeroed(A.copy(), U, w)
