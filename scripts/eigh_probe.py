@@ -11,6 +11,7 @@ A = X @ X.T / (n // 2)
 del X
 A = (A + A.T) / 2
 A0 = A.clone() if n <= 8192 else None
+torch.cuda.empty_cache()
 U = torch.empty_like(A)
 w = torch.empty(n, dtype=torch.float64, device="cuda")
 torch.cuda.synchronize()
