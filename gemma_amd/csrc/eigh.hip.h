@@ -1032,16 +1032,16 @@ static inline int eig_backtransform(double *ZT, long n, EigWs &ws, hipStream_t s
 namespace gemma_hip {
 
 // GEMMA_HIP_EIGH_STAGES: 1 = one-stage tridiagonalisation (HBM-bound SYMV per column), 2 = two-stage (dense -> band ->
-// tridiagonal, eigh2.hip.h) whenever the matrix has at least one stage-1 panel; unset: two-stage from n = 12000 (measured:
+// tridiagonal, eigh2.hip.h) whenever the matrix has at least one stage-1 panel; unset: two-stage from n = 14000 (measured:
 // n = 8192 0.50 s one-stage / 0.70 s two-stage, n = 20000 4.46 / 3.09 s -- the n sequential panel launches and the 2 n
-// dependent chase steps are latency, the SYMV they replace is bandwidth).  Odd n stays on the one-stage path (the panel
+// dependent chase steps are latency, the SYMV they replace is bandwidth: a n + b n^3 fits through the two sizes cross at 14000).  Odd n stays on the one-stage path (the panel
 // GEMMs want even leading dimensions).
 static inline bool eig_two_stage(long n) {
   const char *e = getenv("GEMMA_HIP_EIGH_STAGES");
   if (e && e[0] == '1') return false;
   if (n < 3 * E2_B || (n & 1)) return false;
   if (e && e[0] == '2') return true;
-  return n >= 12000;
+  return n >= 14000;
 }
 
 // G (n x n symmetric, device, destroyed) -> U (row-major, eigenvector k in column k), eval ascending.

@@ -73,13 +73,37 @@ struct SbPanelArgs {
   double *VT, *part, *heads, *tau, *betas;
 };
 __global__ __launch_bounds__(256) void sb_panel_kernel(SbPanelArgs g) {
-  __shared__ double sf[E2_B], sred[E2_B], sc[4];
+  __shared__ double sf[E2_B], sred[E2_B];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const long n = g.n, j0 = g.j0, r0 = j0 + E2_B;
   const int c = g.c, prev = c - 1;
   const long head_prev = r0 + prev, head_c = r0 + c;
-  double scale = 0.0, beta = 0.0;
+  const bool more = c < g.kk;
+  const long base = r0 + (long)blockIdx.x * SB_COLS + lane;
+  // every global load this launch depends on is issued here, in one round trip: the previous launch's partial sums and
+  // head entries, row c-1 (the pending reflector), row c (the next one)
+  bool valid[4];
+  double xprev[4], yc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const long col = base + 64 * i;
+    valid[i] = col < n;
+    xprev[i] = (c > 0 && valid[i] && col > head_prev) ? g.A[(j0 + prev) * n + col] : 0.0;
+    yc[i] = (more && valid[i]) ? g.A[(j0 + c) * n + col] : 0.0;
+  }
+  const int qfirst = c + ((wave - c) & 3);
+  double ynext[4][4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int q = qfirst + 4 * u;
+    const double *row = g.A + (j0 + (q < E2_B ? q : 0)) * n;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) ynext[u][i] = (q < E2_B && valid[i]) ? row[base + 64 * i] : 0.0;
+  }
+  double scale = 0.0;
   if (c > 0) {
+    const double alpha = g.heads[(prev & 1) * E2_B + prev];
+    const double myhead = (t < E2_B && t > prev) ? g.heads[(prev & 1) * E2_B + t] : 0.0;
     if (t < E2_B && t >= prev) {
       const double *pp = g.part + (size_t)(prev & 1) * g.nwg * E2_B + t;
       double s = 0.0;
@@ -88,57 +112,47 @@ __global__ __launch_bounds__(256) void sb_panel_kernel(SbPanelArgs g) {
       sred[t] = s;
     }
     __syncthreads();
-    if (t == 0) {
-      double tau, b, sc_;
-      e2_larfg(g.heads[(prev & 1) * E2_B + prev], sred[prev], tau, b, sc_);
-      sc[0] = sc_;
-      sc[1] = b;
-      sc[2] = tau;
-      if (blockIdx.x == 0) {
-        g.tau[j0 + prev] = tau;
-        g.betas[j0 + prev] = b;
-      }
+    double tau, beta;
+    e2_larfg(alpha, sred[prev], tau, beta, scale); // every thread: no second barrier for three scalars
+    if (t == 0 && blockIdx.x == 0) {
+      g.tau[j0 + prev] = tau;
+      g.betas[j0 + prev] = beta;
     }
-    __syncthreads();
-    scale = sc[0];
-    beta = sc[1];
-    if (t < E2_B && t > prev) sf[t] = sc[2] * (g.heads[(prev & 1) * E2_B + t] + scale * sred[t]);
+    if (t < E2_B && t > prev) sf[t] = tau * (myhead + scale * sred[t]);
     __syncthreads();
   }
-  (void)beta;
-  const long base = r0 + (long)blockIdx.x * SB_COLS + lane;
   double v[4], xc[4];
-  bool valid[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const long col = base + 64 * i;
-    valid[i] = col < n;
     v[i] = 0.0;
     xc[i] = 0.0;
     if (c > 0 && valid[i] && col >= head_prev) {
-      v[i] = (col == head_prev) ? 1.0 : scale * g.A[(j0 + prev) * n + col];
+      v[i] = (col == head_prev) ? 1.0 : scale * xprev[i];
       if (wave == 0) g.VT[(j0 + prev) * n + col] = v[i];
     }
   }
-  const bool more = c < g.kk;
   if (more) { // row c after the pending update: x of the next reflector (every wavefront needs it for its own columns)
-    const double *row = g.A + (j0 + c) * n;
     const double f = (c > 0) ? sf[c] : 0.0;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const double y = (valid[i] ? row[base + 64 * i] : 0.0) - f * v[i];
-      xc[i] = (base + 64 * i > head_c) ? y : 0.0;
-    }
+    for (int i = 0; i < 4; ++i) xc[i] = (base + 64 * i > head_c) ? yc[i] - f * v[i] : 0.0;
   }
-  // this wavefront's rows q = q0, q0 + 4, ...: four rows per step, all loads of a step in flight together
-  for (int q0 = c + ((wave - c) & 3); q0 < E2_B; q0 += 16) {
+  // this wavefront's rows q = q0, q0 + 4, ...: four rows per step, all loads of a step in flight together and the next
+  // step's loads issued before this step's arithmetic (the first step's were issued before the barriers above)
+  for (int q0 = qfirst; q0 < E2_B; q0 += 16) {
     double y[4][4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int q = q0 + 4 * u;
-      const double *row = g.A + (j0 + q) * n;
+    for (int u = 0; u < 4; ++u)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) y[u][i] = (q < E2_B && valid[i]) ? row[base + 64 * i] : 0.0;
+      for (int i = 0; i < 4; ++i) y[u][i] = ynext[u][i];
+    if (q0 + 16 < E2_B) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int q = q0 + 16 + 4 * u;
+        const double *row = g.A + (j0 + q) * n;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ynext[u][i] = (q < E2_B && valid[i]) ? row[base + 64 * i] : 0.0;
+      }
     }
     double pr[4];
 #pragma unroll

@@ -237,7 +237,7 @@ def test_two_stage_reduction_stages(gpu_api, n, kind):
 @pytest.mark.parametrize("n,kind,chase", [(384, "random", "persist"), (640, "kinship", "persist"), (1000, "kinship", "steps"),
                                           (1538, "clustered", "persist"), (2050, "lowrank", "persist")])
 def test_eigh_two_stage_end_to_end(gpu_api, n, kind, chase, monkeypatch):
-    """The whole solver on the two-stage path (forced: by default it starts at n = 12000), with the bounds of
+    """The whole solver on the two-stage path (forced: by default it starts at n = 14000), with the bounds of
     test_eigh_end_to_end; `steps` runs the bulge chase as one launch per time step instead of the persistent kernel."""
     monkeypatch.setenv("GEMMA_HIP_EIGH_STAGES", "2")
     monkeypatch.setenv("GEMMA_HIP_EIGH_BC", chase)
