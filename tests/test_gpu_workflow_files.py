@@ -101,3 +101,45 @@ def test_rccl_entry_points_single_rank(driver):
     lib.gemma_hip_comm_info(C.byref(r), C.byref(w), C.byref(t))
     assert (r.value, w.value) == (0, 1)
     L.check(lib.gemma_hip_comm_finalize(), "comm_finalize")
+
+
+# BASELINE config 1.  The genotype file of the reference's example (mouse_hs1940.geno.txt.gz, 14 MB) is a blob that neither
+# this repository nor the reference checkout here carries; where it is present (GEMMA_EXAMPLE_DIR, or an example/ directory
+# next to the repository / under the reference tree) the published rows of example/demo.txt:27-32 and the null-model pve
+# of :40-41 are the check.  Absent -> skipped, never faked.
+_DEMO_ROWS = [  # rs, beta, se, l_remle, p_wald (example/demo.txt:28-32)
+    ("rs3683945", -7.788665e-02, 6.193502e-02, 4.317993e+00, 2.087616e-01),
+    ("rs3707673", -6.654282e-02, 6.210234e-02, 4.316144e+00, 2.841271e-01),
+    ("rs6269442", -5.344241e-02, 5.377464e-02, 4.323611e+00, 3.204804e-01),
+    ("rs6336442", -6.770154e-02, 6.209267e-02, 4.315713e+00, 2.757541e-01),
+    ("rs13475700", -5.659089e-02, 7.175374e-02, 4.340145e+00, 4.304306e-01),
+]
+
+
+def _mouse_dir():
+    cands = [os.environ.get("GEMMA_EXAMPLE_DIR"), os.path.join(fc.ROOT, "example"), os.path.join(fc.ROOT, "tests", "golden", "example"),
+             "/root/reference/example", "/data/gemma/example"]
+    for d in cands:
+        if d and all(os.path.exists(os.path.join(d, f)) for f in
+                     ("mouse_hs1940.geno.txt.gz", "mouse_hs1940.pheno.txt", "mouse_hs1940.anno.txt")):
+            return d
+    return None
+
+
+def test_mouse_hs1940_demo_rows(driver, tmp_path):
+    d = _mouse_dir()
+    if d is None:
+        pytest.skip("mouse_hs1940.geno.txt.gz is not available on this machine (blob outside the repository)")
+    g, p, a = (os.path.join(d, "mouse_hs1940." + s) for s in ("geno.txt.gz", "pheno.txt", "anno.txt"))
+    fc.drive(driver, "-g", g, "-p", p, "-n", 1, "-a", a, "-gk", 1, "-outdir", tmp_path, "-o", "mouse")
+    kv = fc.drive(driver, "-g", g, "-p", p, "-n", 1, "-a", a, "-k", tmp_path / "mouse.cXX.txt", "-lmm", 1, "-outdir", tmp_path,
+                  "-o", "mouse_lmm")
+    hdr, rows = fc.read_assoc(tmp_path / "mouse_lmm.assoc.txt")
+    col = {h: i for i, h in enumerate(hdr)}
+    by_rs = {r[col["rs"]]: r for r in rows[:50]}
+    for rs, beta, se, lam, pw in _DEMO_ROWS:
+        r = by_rs[rs]
+        for name, ref, tol in (("beta", beta, 2e-6), ("se", se, 2e-6), ("l_remle", lam, 1e-3), ("p_wald", pw, 2e-6)):
+            assert float(r[col[name]]) == pytest.approx(ref, rel=tol), (rs, name)
+    if "pve" in kv:
+        assert float(kv["pve"]) == pytest.approx(0.608801, rel=2e-6)
