@@ -189,7 +189,9 @@ def main():
             try:
                 Kc = K.clone()
                 api.EigenDecomp_Zeroed(Kc, U, ev)
-                eig = "gemma_hip_eigh"
+                st = os.environ.get("GEMMA_HIP_EIGH_STAGES", "")
+                two = (st == "2" and n >= 384 or st != "1" and n >= 14000) and n % 2 == 0  # eigh.hip.h: eig_two_stage
+                eig = "gemma_hip_eigh (%s)" % ("two-stage: dense -> band -> tridiagonal" if two else "one-stage tridiagonalisation")
                 del Kc
             except L.GemmaHipError:
                 if eig == "gemma":
