@@ -699,7 +699,7 @@ __global__ __launch_bounds__(256, 2) void q2_apply_kernel(Q2ApplyArgs g) {
 
 // ---------------------------------------------------------------- host orchestration
 struct Eig2Ws {
-  double *Bd = nullptr, *part = nullptr, *heads = nullptr, *betas = nullptr, *gramP = nullptr, *YT = nullptr;
+  double *Bd = nullptr, *Bd0 = nullptr, *part = nullptr, *heads = nullptr, *betas = nullptr, *gramP = nullptr, *YT = nullptr;
   double *V2 = nullptr, *tau2 = nullptr, *pack = nullptr;
   long *goff = nullptr;
   int *prog = nullptr; // progress counters of the persistent bulge chase (+ the error flag)
@@ -827,6 +827,7 @@ static inline int eig2_sb2st(long n, EigWs &ws, Eig2Ws &w2, hipStream_t s, std::
     const long nwg = (w2.kmaxall + 1) / 2;
     if (!(eb && eb[0] == 's') && nwg <= ncu) {
       EIG_HIP(hipMemsetAsync(w2.prog, 0, (size_t)(w2.kmaxall + 2) * sizeof(int), s));
+      EIG_HIP(hipMemcpyAsync(w2.Bd0, w2.Bd, (size_t)n * E2_LDB * 8, hipMemcpyDeviceToDevice, s));
       BcPersistArgs pa{w2.Bd, n, w2.V2, w2.tau2, w2.prog, w2.prog + w2.kmaxall + 1, nullptr};
       const char *ed = getenv("GEMMA_HIP_EIGH_BC_DBG");
       long long *dbg_d = nullptr;
@@ -859,13 +860,16 @@ static inline int eig2_sb2st(long n, EigWs &ws, Eig2Ws &w2, hipStream_t s, std::
       int err = 0;
       EIG_HIP(hipMemcpyAsync(&err, w2.prog + w2.kmaxall + 1, sizeof(int), hipMemcpyDeviceToHost, s));
       EIG_HIP(hipStreamSynchronize(s));
-      if (err) {
-        msg = "band -> tridiagonal: a workgroup of the persistent bulge chase timed out waiting for its neighbour";
-        return 5;
+      if (!err) {
+        hipLaunchKernelGGL(sb_band_de_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, w2.Bd, n, ws.d, ws.e);
+        EIG_HIP(hipGetLastError());
+        return 0;
       }
-      hipLaunchKernelGGL(sb_band_de_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, w2.Bd, n, ws.d, ws.e);
-      EIG_HIP(hipGetLastError());
-      return 0;
+      // a workgroup waited too long for its neighbour (possible only when something else kept part of the chip busy, so that
+      // not every workgroup was resident): the band is restored from the copy taken above and the chase repeated as one
+      // launch per time step, which needs no co-residency
+      EIG_HIP(hipMemcpyAsync(w2.Bd, w2.Bd0, (size_t)n * E2_LDB * 8, hipMemcpyDeviceToDevice, s));
+      EIG_HIP(hipMemsetAsync(w2.tau2, 0, (size_t)w2.kmaxall * n * 8, s));
     }
   }
   BcArgs a{w2.Bd, n, 0, 0, w2.V2, w2.tau2};
@@ -925,7 +929,7 @@ static inline bool eig2_alloc(long n, EigWs &ws, Eig2Ws &w2) {
   }
   w2.ngroups = goff[w2.nJ];
   const size_t nwg_panel = (size_t)(n + SB_COLS - 1) / SB_COLS, nwg_gram = (size_t)(n + GR_CH - 1) / GR_CH;
-  bool ok = ws.get(w2.Bd, (size_t)n * E2_LDB) && ws.get(w2.part, 2 * nwg_panel * E2_B) && ws.get(w2.heads, 2 * E2_B) &&
+  bool ok = ws.get(w2.Bd, (size_t)n * E2_LDB) && ws.get(w2.Bd0, (size_t)n * E2_LDB) && ws.get(w2.part, 2 * nwg_panel * E2_B) && ws.get(w2.heads, 2 * E2_B) &&
             ws.get(w2.betas, n) && ws.get(w2.gramP, nwg_gram * E2_B * E2_B) && ws.get(w2.YT, (size_t)4 * E2_B * n) &&
             ws.get(w2.V2, (size_t)w2.kmaxall * n * E2_B) && ws.get(w2.tau2, (size_t)w2.kmaxall * n) &&
             ws.get(w2.pack, (size_t)w2.ngroups * E2_PACK) && ws.get(w2.goff, (size_t)w2.nJ + 1) &&
