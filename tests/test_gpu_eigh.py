@@ -298,3 +298,21 @@ def test_two_stage_degenerate_inputs(gpu_api, monkeypatch):
     A[3, 5] = A[5, 3] = np.nan
     with pytest.raises(L.GemmaHipError):
         gpu_api.EigenDecomp_Zeroed(A.copy(), U, w)
+
+
+@pytest.mark.parametrize("n,stages", [(193, "1"), (333, "1"), (1001, "2"), (2049, "2")])
+def test_eigh_odd_n_is_padded(gpu_api, n, stages, monkeypatch):
+    """Odd n runs as an (n+1) x (n+1) problem with one exactly decoupled extra eigenpair (aligned GEMM paths, symmetric
+    SYMV, two-stage reduction all need even n); the result must be the one of the unpadded, unaligned path."""
+    monkeypatch.setenv("GEMMA_HIP_EIGH_STAGES", stages)
+    A = _sym(n, 11 * n, "kinship")
+    U, w = np.zeros((n, n)), np.zeros(n)
+    gpu_api.EigenDecomp_Zeroed(A.copy(), U, w)
+    w_raw = np.where(w == 0.0, np.einsum("ij,ij->j", U, A @ U), w)
+    assert np.linalg.norm(U.T @ U - np.eye(n)) < 50 * n * EPS
+    assert np.linalg.norm(A @ U - U * w_raw[None, :]) / np.linalg.norm(A, 2) < 50 * n * EPS
+    monkeypatch.setenv("GEMMA_HIP_EIGH_PAD", "0")
+    monkeypatch.setenv("GEMMA_HIP_EIGH_STAGES", "1")
+    U0, w0 = np.zeros((n, n)), np.zeros(n)
+    gpu_api.EigenDecomp_Zeroed(A.copy(), U0, w0)
+    assert np.abs(w - w0).max() <= 30 * n * EPS * np.abs(w0).max()
