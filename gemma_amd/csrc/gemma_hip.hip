@@ -74,6 +74,8 @@ struct Ctx {
   DevBuf kin_K, kin_X, kin_stage;
   // exact-integer path of the centred kinship of hard calls (kin_i8.hip.h)
   bool kin_i8 = false, kin_i8_used = false;
+  DevBuf U_even;            // odd n: U copied to an even leading dimension for the fp64 GEMM's aligned path
+  const double *U_even_of = nullptr; // the U that copy was made from
   DevBuf kin_GtG, kin_S, kin_a, kin_At, kin_Gt;
 
   // lmm state
@@ -1156,6 +1158,7 @@ extern "C" int gemma_hip_lmm_setup_d(const gemma_lmm_cfg *cfg, const double *U_d
   int rc = lmm_common_setup(cfg);
   if (rc) return rc;
   g_ctx.U = U_d;
+  g_ctx.U_even_of = nullptr;
   g_ctx.eval = eval_d;
   g_ctx.Uty = Uty_d;
   rc = make_utwt(UtW_d, S(stream));
@@ -1179,6 +1182,7 @@ extern "C" int gemma_hip_lmm_setup(const gemma_lmm_cfg *cfg, const double *U, co
   HIPCHK(hipMemcpy(g_ctx.own_Uty.p, Uty, n * 8, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(g_ctx.own_UtW.p, UtW, n * c * 8, hipMemcpyHostToDevice));
   g_ctx.U = g_ctx.own_U.as<double>();
+  g_ctx.U_even_of = nullptr;
   g_ctx.eval = g_ctx.own_eval.as<double>();
   g_ctx.Uty = g_ctx.own_Uty.as<double>();
   rc = make_utwt(g_ctx.own_UtW.as<double>(), 0);
@@ -1435,6 +1439,24 @@ static int utx_f64_try_i8(const double *src, size_t l, size_t ld, bool nan_missi
   return i8_product(l, d, UtX, ldx, s);
 }
 
+// U as the right-hand operand of the fp64 GEMM.  With an odd n the caller's U (leading dimension n) would send every tile down
+// the bounds-checked kernel (the LDS-DMA path wants even leading dimensions): a copy with leading dimension n + 1 is made
+// once per lmm_setup and used instead.
+static int gemm_U(const double **U, long *ld, hipStream_t s) {
+  const size_t n = g_ctx.cfg.n;
+  *U = g_ctx.U;
+  *ld = (long)n;
+  if ((n & 1) == 0) return GEMMA_HIP_OK;
+  if (g_ctx.U_even_of != g_ctx.U) {
+    if (g_ctx.U_even.reserve(n * (n + 1) * 8)) return fail(GEMMA_HIP_ENOMEM, "lmm_batch: even-ld copy of U");
+    HIPCHK(hipMemcpy2DAsync(g_ctx.U_even.p, (n + 1) * 8, g_ctx.U, n * 8, n * 8, n, hipMemcpyDeviceToDevice, s));
+    g_ctx.U_even_of = g_ctx.U;
+  }
+  *U = g_ctx.U_even.as<double>();
+  *ld = (long)n + 1;
+  return GEMMA_HIP_OK;
+}
+
 // UtX (l x ldx, SNP-major) = mean-imputed X (l x n) * U (n x n): row s is (U^T x_s)^T, i.e. the column the
 // reference's fast_dgemm("T","N",U,Xlarge) (src/lmm.cpp:1521) produces for SNP s.  path < 0: by GEMMA_HIP_UTX_I8.
 static int compute_utx(int kind, const void *geno, size_t l, size_t ld, int path, double **UtX_out, size_t *ldx_out,
@@ -1484,7 +1506,11 @@ static int compute_utx(int kind, const void *geno, size_t l, size_t ld, int path
   }
   {
     ProfScope ps(GEMMA_STAGE_UTX_GEMM, s);
-    HIPCHK(launch_dgemm('N', 'N', (long)l, (long)n, (long)n, 1.0, X, (long)ldx, g_ctx.U, (long)n, 0.0, UtX,
+    const double *Ug;
+    long ldu;
+    int rcu = gemm_U(&Ug, &ldu, s);
+    if (rcu) return rcu;
+    HIPCHK(launch_dgemm('N', 'N', (long)l, (long)n, (long)n, 1.0, X, (long)ldx, Ug, ldu, 0.0, UtX,
                         (long)ldx, false, false, s));
   }
   return GEMMA_HIP_OK;
@@ -1528,7 +1554,11 @@ extern "C" int gemma_hip_lmm_gene_batch_d(const double *Y_d, size_t l, size_t ld
   double *UtY = g_ctx.UtX.as<double>();
   {
     ProfScope ps(GEMMA_STAGE_UTX_GEMM, s); // U^T y_g for every row (:1415)
-    HIPCHK(launch_dgemm('N', 'N', (long)l, (long)n, (long)n, 1.0, Y_d, (long)ld, g_ctx.U, (long)n, 0.0, UtY, (long)ldx,
+    const double *Ug;
+    long ldu;
+    int rcu = gemm_U(&Ug, &ldu, s);
+    if (rcu) return rcu;
+    HIPCHK(launch_dgemm('N', 'N', (long)l, (long)n, (long)n, 1.0, Y_d, (long)ld, Ug, ldu, 0.0, UtY, (long)ldx,
                         false, false, s));
   }
   AssocArgs a = g_ctx.assoc_proto;
@@ -1820,9 +1850,13 @@ extern "C" int gemma_hip_lmm_gxe_batch_d(int kind, const void *geno, size_t l, s
   }
   {
     ProfScope ps(GEMMA_STAGE_UTX_GEMM, s); // U^T x_s (:2364) and U^T (x_s . env) (:2366); z is real-valued: fp64 GEMMs
-    HIPCHK(launch_dgemm('N', 'N', (long)l, (long)n, (long)n, 1.0, X, (long)ldx, g_ctx.U, (long)n, 0.0, UtX, (long)ldx,
+    const double *Ug;
+    long ldu;
+    int rcu = gemm_U(&Ug, &ldu, s);
+    if (rcu) return rcu;
+    HIPCHK(launch_dgemm('N', 'N', (long)l, (long)n, (long)n, 1.0, X, (long)ldx, Ug, ldu, 0.0, UtX, (long)ldx,
                         false, false, s));
-    HIPCHK(launch_dgemm('N', 'N', (long)l, (long)n, (long)n, 1.0, Z, (long)ldx, g_ctx.U, (long)n, 0.0, UtZ, (long)ldx,
+    HIPCHK(launch_dgemm('N', 'N', (long)l, (long)n, (long)n, 1.0, Z, (long)ldx, Ug, ldu, 0.0, UtZ, (long)ldx,
                         false, false, s));
   }
   AssocArgs a = g_ctx.assoc_proto;
@@ -2114,6 +2148,8 @@ extern "C" int gemma_hip_lmm_finish(double *time_UtX_min, double *time_opt_min) 
   g_ctx.gxe_flip.release();
   g_ctx.gxe_ready = false;
   g_ctx.U = g_ctx.eval = g_ctx.Uty = nullptr;
+  g_ctx.U_even_of = nullptr;
+  g_ctx.U_even.release();
   g_ctx.lmm_active = false;
   return GEMMA_HIP_OK;
 }
@@ -2314,6 +2350,7 @@ extern "C" int gemma_hip_lmm_setup_kept(const gemma_lmm_cfg *cfg, const double *
   HIPCHK(hipMemcpy(g_ctx.own_Uty.p, Uty, n * 8, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(g_ctx.own_UtW.p, UtW, n * c * 8, hipMemcpyHostToDevice));
   g_ctx.U = kept_U();
+  g_ctx.U_even_of = nullptr;
   g_ctx.eval = kept_eval();
   g_ctx.Uty = g_ctx.own_Uty.as<double>();
   rc = make_utwt(g_ctx.own_UtW.as<double>(), 0);
