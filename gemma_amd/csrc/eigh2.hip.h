@@ -702,6 +702,7 @@ struct Eig2Ws {
   double *Bd = nullptr, *Bd0 = nullptr, *part = nullptr, *heads = nullptr, *betas = nullptr, *gramP = nullptr, *YT = nullptr;
   double *V2 = nullptr, *tau2 = nullptr, *pack = nullptr;
   long *goff = nullptr;
+  double *P256 = nullptr, *Tpair = nullptr; // Q1 applied two panels at a time: three n x 256 buffers, one 256 x 256 factor
   int *prog = nullptr; // progress counters of the persistent bulge chase (+ the error flag)
   long ngroups = 0, kmaxall = 0, nJ = 0;
 };
@@ -902,18 +903,44 @@ static inline int eig2_apply_q2(double *ZT, long n, Eig2Ws &w2, hipStream_t s, s
 // Z^T <- Z^T Q1^T (stage-1 panels, compact WY: three GEMMs per panel as in eig_backtransform)
 static inline int eig2_apply_q1(double *ZT, long n, EigWs &ws, Eig2Ws &w2, hipStream_t s, std::string &msg) {
   const long nb2 = (long)E2_B * E2_B;
-  double *Pb = w2.YT; // second half of the split product (n x 128; the stage-1 operand buffer is free by now)
-  long last = -1;
-  for (long j0 = 0; n - (j0 + E2_B) >= 2; j0 += E2_B) last = j0;
-  for (long j0 = last; j0 >= 0; j0 -= E2_B) {
-    const long c0 = j0 + E2_B, Kc = n - c0;
+  long npan = 0;
+  for (long j0 = 0; n - (j0 + E2_B) >= 2; j0 += E2_B) ++npan;
+  // Two consecutive panels are applied as ONE block reflector of 256 vectors,
+  //   (I - V1 T1 V1^T)(I - V2 T2 V2^T) = I - [V1 V2] [[T1, -T1 (V1^T V2) T2], [0, T2]] [V1 V2]^T:
+  // the rank-k update of Z^T has K = 256 (its reads and writes of Z^T halve) and the skinny product Z^T Y^T has two tile
+  // columns.  GEMMA_HIP_EIGH_Q1_PAIR=0: panel by panel.
+  const char *ep = getenv("GEMMA_HIP_EIGH_Q1_PAIR");
+  const bool pair = !(ep && ep[0] == '0') && w2.P256 != nullptr;
+  long pnl = npan - 1;
+  while (pnl >= 0) {
+    const bool two = pair && pnl >= 1 && ((npan - 1 - pnl) % 2 == 0); // pairs (pnl-1, pnl) counted from the last panel
+    const long pa = two ? pnl - 1 : pnl;
+    const long j0 = pa * E2_B, c0 = j0 + E2_B, Kc = n - c0;
+    const long kp = two ? 2 * E2_B : E2_B;
     const double *Y = ws.VT + j0 * n + c0;
-    const double *T = ws.Tall + (j0 / E2_B) * nb2;
-    int rc = eig2_dgemm_split2('N', 'T', n, E2_B, Kc, 1.0, ZT + c0, n, Y, n, ws.P, Pb, E2_B, s, msg);
+    const double *T = ws.Tall + pa * nb2;
+    if (two) {
+      const long cB = c0 + E2_B; // first column where the second panel's reflectors are non-zero
+      const double *T1 = ws.Tall + pa * nb2, *T2 = ws.Tall + (pa + 1) * nb2;
+      double *TP = w2.Tpair;
+      int rc = eig2_gram(ws.VT + j0 * n + cB, ws.VT + (j0 + E2_B) * n + cB, n, n - cB, w2.gramP, ws.S, s, msg); // V1^T V2
+      if (rc) return rc;
+      EIG_HIP(launch_dgemm('N', 'N', E2_B, E2_B, E2_B, 1.0, T1, E2_B, ws.S, E2_B, 0.0, ws.T, E2_B, false, false, s));
+      EIG_HIP(hipMemsetAsync(TP, 0, (size_t)4 * nb2 * 8, s));
+      EIG_HIP(launch_dgemm('N', 'N', E2_B, E2_B, E2_B, -1.0, ws.T, E2_B, T2, E2_B, 0.0, TP + E2_B, 2 * E2_B, false, false, s));
+      EIG_HIP(hipMemcpy2DAsync(TP, 2 * E2_B * 8, T1, E2_B * 8, E2_B * 8, E2_B, hipMemcpyDeviceToDevice, s));
+      EIG_HIP(hipMemcpy2DAsync(TP + (size_t)E2_B * 2 * E2_B + E2_B, 2 * E2_B * 8, T2, E2_B * 8, E2_B * 8, E2_B,
+                               hipMemcpyDeviceToDevice, s));
+      T = TP;
+    }
+    double *P = two ? w2.P256 : ws.P, *P2 = two ? w2.P256 + (size_t)n * kp : ws.P2;
+    double *Pb = two ? w2.P256 + (size_t)2 * n * kp : w2.YT;
+    int rc = eig2_dgemm_split2('N', 'T', n, kp, Kc, 1.0, ZT + c0, n, Y, n, P, Pb, kp, s, msg);
     if (rc) return rc;
-    EIG_HIP(launch_dgemm('N', 'T', n, E2_B, E2_B, 1.0, ws.P, E2_B, T, E2_B, 0.0, ws.P2, E2_B, false, false, s));
-    EIG_HIP(launch_dgemm('N', 'T', n, E2_B, E2_B, 1.0, Pb, E2_B, T, E2_B, 1.0, ws.P2, E2_B, false, false, s));
-    EIG_HIP(launch_dgemm('N', 'N', n, Kc, E2_B, -1.0, ws.P2, E2_B, Y, n, 1.0, ZT + c0, n, false, false, s));
+    EIG_HIP(launch_dgemm('N', 'T', n, kp, kp, 1.0, P, kp, T, kp, 0.0, P2, kp, false, false, s));
+    EIG_HIP(launch_dgemm('N', 'T', n, kp, kp, 1.0, Pb, kp, T, kp, 1.0, P2, kp, false, false, s));
+    EIG_HIP(launch_dgemm('N', 'N', n, Kc, kp, -1.0, P2, kp, Y, n, 1.0, ZT + c0, n, false, false, s));
+    pnl = pa - 1;
   }
   return 0;
 }
@@ -933,7 +960,8 @@ static inline bool eig2_alloc(long n, EigWs &ws, Eig2Ws &w2) {
             ws.get(w2.betas, n) && ws.get(w2.gramP, nwg_gram * E2_B * E2_B) && ws.get(w2.YT, (size_t)4 * E2_B * n) &&
             ws.get(w2.V2, (size_t)w2.kmaxall * n * E2_B) && ws.get(w2.tau2, (size_t)w2.kmaxall * n) &&
             ws.get(w2.pack, (size_t)w2.ngroups * E2_PACK) && ws.get(w2.goff, (size_t)w2.nJ + 1) &&
-            ws.get(w2.prog, (size_t)w2.kmaxall + 4);
+            ws.get(w2.prog, (size_t)w2.kmaxall + 4) && ws.get(w2.P256, (size_t)3 * n * 2 * E2_B) &&
+            ws.get(w2.Tpair, (size_t)4 * E2_B * E2_B);
   if (!ok) return false;
   return hipMemcpy(w2.goff, goff.data(), goff.size() * sizeof(long), hipMemcpyHostToDevice) == hipSuccess;
 }
