@@ -12,8 +12,11 @@
 //  stage 2 (sb2st)  bulge chasing on the band (n x 256 doubles: L2 / MALL resident).  Task (j, k) of sweep j works on
 //                   rows j+1+128k ..: it applies the previous task's reflector from the right to the 128 x 128 block
 //                   left of its diagonal block, annihilates that block's first column, and updates its diagonal block
-//                   from both sides.  Tasks with 2 j + k = t are independent; one launch per time step t
-//                   (scripts/two_stage_model.py checks the schedule and the group order below in numpy).
+//                   from both sides.  Tasks with 2 j + k = t are independent (scripts/two_stage_model.py checks the
+//                   schedule and the group order below in numpy).  ONE persistent launch: workgroup w owns the chase
+//                   positions 2w, 2w+1, walks the sweeps and waits for its neighbours on progress counters (bounded
+//                   waits; fallback: one launch per time step).  Inside a task both blocks stay in registers from the
+//                   global load to the store; only the two column sums go through LDS.
 //  back-transform   Z^T <- Z^T Q2^T Q1^T.  Q2 (the n^2 / 256 reflectors of stage 2): 32 consecutive sweeps at the same
 //                   k form one block reflector I - V T V^T whose V is a 160 x 32 parallelogram; groups are applied with k
 //                   ascending outside and the sweep blocks descending inside, so the 160-column window of Z^T slides by
@@ -21,7 +24,7 @@
 //                   accumulator layout of the transposed products (X^T tiles), which is also the MFMA operand layout:
 //                   W^T = V^T X^T, W2^T = T W^T, X^T -= V W2^T chain without touching LDS; only V and T (52 KB per group,
 //                   packed once by q2_pack_kernel) go through LDS.  Q1 (stage 1) reuses the three-GEMM panel update of
-//                   eigh.hip.h.
+//                   eigh.hip.h, two panels (256 reflectors) per block reflector.
 //
 // LAPACK equivalents: dsytrd_sy2sb / dsytrd_sb2st / dormtr-like back-transformations; semantics of the whole solver as
 // before (GEMMA src/lapack.cpp:149-291).
