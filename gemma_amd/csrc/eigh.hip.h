@@ -1039,7 +1039,7 @@ namespace gemma_hip {
 static inline bool eig_two_stage(long n) {
   const char *e = getenv("GEMMA_HIP_EIGH_STAGES");
   if (e && e[0] == '1') return false;
-  if (n < 3 * E2_B || (n & 1)) return false;
+  if (n < 3 * E2_B || (n & 1) || (n - 2 + E2_NB - 1) / E2_NB > Q2_MAXJ) return false; // q2_apply_kernel's LDS table: n <= 65 536
   if (e && e[0] == '2') return true;
   return n >= 14000;
 }

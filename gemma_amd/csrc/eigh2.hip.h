@@ -570,13 +570,18 @@ struct Q2ApplyArgs {
 // 4 wavefronts x 16 rows of Z^T per workgroup.  Lane l = (li = l & 15, lk = l >> 4) holds
 // x[4 ct + r] = Z^T[row0 + li][c0 + 16 ct + lk + 4 r]: tile ct of X^T in the MFMA accumulator layout, and at the same
 // time the operand fragment of k-step 4 ct + r.
+constexpr int Q2_MAXJ = 2048; // sweep blocks the kernel can index (n <= 65 536)
 __global__ __launch_bounds__(256, 2) void q2_apply_kernel(Q2ApplyArgs g) {
   __shared__ double Ls[E2_PACK];
+  __shared__ int sgoff[Q2_MAXJ]; // first group of every sweep block: looked up through LDS so that the lookup never waits on
+                                 // the vector-memory counter behind the window loads in flight
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, li = lane & 15, lk = lane >> 4;
   const long n = g.n;
   const long row = (long)blockIdx.x * 64 + wave * 16 + li;
   const bool rok = row < n;
   double *zrow = g.ZT + (rok ? row : 0) * n;
+  for (int i = t; i < g.nJ; i += 256) sgoff[i] = (int)g.goff[i];
+  __syncthreads();
   constexpr int NT = E2_WIN / 16; // 10 window tiles
   constexpr int PK_N = (E2_PACK / 2 + 255) / 256; // 16-byte pieces of a pack per thread
   double x[4 * NT];
@@ -584,7 +589,7 @@ __global__ __launch_bounds__(256, 2) void q2_apply_kernel(Q2ApplyArgs g) {
   {
     const long lim0 = n - 2; // first group: k = 0, the last sweep block
     const long Jb0 = (lim0 / E2_NB < g.nJ - 1) ? lim0 / E2_NB : g.nJ - 1;
-    const e2_v2 *src = reinterpret_cast<const e2_v2 *>(g.pack + (size_t)(g.goff[Jb0]) * E2_PACK);
+    const e2_v2 *src = reinterpret_cast<const e2_v2 *>(g.pack + (size_t)(sgoff[Jb0]) * E2_PACK);
 #pragma unroll
     for (int q = 0; q < PK_N; ++q)
       if (t + 256 * q < E2_PACK / 2) pk[q] = src[t + 256 * q];
@@ -596,14 +601,19 @@ __global__ __launch_bounds__(256, 2) void q2_apply_kernel(Q2ApplyArgs g) {
     if (Jbmax > g.nJ - 1) Jbmax = g.nJ - 1;
     for (long Jb = Jbmax; Jb >= 0; --Jb) {
       const long c0 = Jb * E2_NB + 1 + (long)k * E2_B;
+      // loads are unconditional (column clamped into the row; rows past n read row 0): a select on the loaded value would make
+      // the compiler wait for it on the spot.  What such a lane holds is never stored, and the rows of V that multiply window
+      // columns past n are zero.
+      const bool inside = c0 + E2_WIN <= n; // the whole window lies inside the row: one base address, immediate offsets
+      const double *zw = zrow + c0 + lk;
       if (Jb == Jbmax) {
+        if (inside) {
 #pragma unroll
-        for (int ct = 0; ct < NT; ++ct)
+          for (int q = 0; q < 4 * NT; ++q) x[q] = zw[4 * q];
+        } else {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const long col = c0 + 16 * ct + lk + 4 * r;
-            x[4 * ct + r] = (rok && col < n) ? zrow[col] : 0.0;
-          }
+          for (int q = 0; q < 4 * NT; ++q) x[q] = zrow[c0 + lk + 4 * q < n ? c0 + lk + 4 * q : n - 1];
+        }
       } else {
         // the window moved down by 32 columns: tiles 8, 9 leave (their columns are c0 + 160 .. c0 + 191 of the new c0)
 #pragma unroll
@@ -616,39 +626,21 @@ __global__ __launch_bounds__(256, 2) void q2_apply_kernel(Q2ApplyArgs g) {
 #pragma unroll
         for (int q = 4 * NT - 1; q >= 8; --q) x[q] = x[q - 8];
 #pragma unroll
-        for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const long col = c0 + 16 * ct + lk + 4 * r;
-            x[4 * ct + r] = (rok && col < n) ? zrow[col] : 0.0;
-          }
+        for (int q = 0; q < 8; ++q) x[q] = zw[4 * q]; // columns c0 .. c0 + 31 < n always (the group has a task)
       }
       __syncthreads(); // everyone is done with the previous group's V and T
 #pragma unroll
       for (int q = 0; q < PK_N; ++q)
         if (t + 256 * q < E2_PACK / 2) reinterpret_cast<e2_v2 *>(Ls)[t + 256 * q] = pk[q];
       __syncthreads();
-      {
-        // the next group's pack (the next sweep block of this k, or the first one of k + 1) goes into registers now and is
-        // in flight behind the MFMAs of this group
-        long nJb = Jb - 1, nk = k;
-        if (nJb < 0) {
-          nk = k + 1;
-          const long nlim = n - 2 - nk * E2_B;
-          nJb = (nk < g.kmaxall && nlim >= 0) ? (nlim / E2_NB < g.nJ - 1 ? nlim / E2_NB : g.nJ - 1) : -1;
-        }
-        if (nJb >= 0) {
-          const e2_v2 *src = reinterpret_cast<const e2_v2 *>(g.pack + (size_t)(g.goff[nJb] + nk) * E2_PACK);
-#pragma unroll
-          for (int q = 0; q < PK_N; ++q)
-            if (t + 256 * q < E2_PACK / 2) pk[q] = src[t + 256 * q];
-        }
-      }
       const double *Vd = Ls, *Tm = Ls + E2_WIN * E2_VLD;
       // W^T (32 x 16) = V^T X^T
       e2_v4 wt0 = {0.0, 0.0, 0.0, 0.0}, wt1 = {0.0, 0.0, 0.0, 0.0};
+      // k-steps 8 .. 39 first: the window tiles 0 and 1 (k-steps 0 .. 7) were requested from global memory at the top of this
+      // group and get the MFMAs of the thirty-two older k-steps to arrive
 #pragma unroll
-      for (int ks = 0; ks < E2_WIN / 4; ++ks) {
+      for (int kq = 0; kq < E2_WIN / 4; ++kq) {
+        const int ks = (kq + 8) % (E2_WIN / 4);
         // V[wc][jj] = 0 outside 0 <= wc - jj < 128: sweeps 0..15 end at window column 142, sweeps 16..31 start at 16
         if (4 * ks < E2_B + 16) {
           const double a0 = Vd[(4 * ks + lk) * E2_VLD + li];
@@ -668,6 +660,22 @@ __global__ __launch_bounds__(256, 2) void q2_apply_kernel(Q2ApplyArgs g) {
         const double a0 = Tm[li * E2_VLD + 4 * ks + lk], a1 = Tm[(16 + li) * E2_VLD + 4 * ks + lk];
         w20 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b, w20, 0, 0, 0);
         w21 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b, w21, 0, 0, 0);
+      }
+      {
+        // the next group's pack (the next sweep block of this k, or the first one of k + 1) goes into registers now (after the first
+        // two products: their accumulators' registers are free) and is in flight behind the 72 MFMAs of the third
+        long nJb = Jb - 1, nk = k;
+        if (nJb < 0) {
+          nk = k + 1;
+          const long nlim = n - 2 - nk * E2_B;
+          nJb = (nk < g.kmaxall && nlim >= 0) ? (nlim / E2_NB < g.nJ - 1 ? nlim / E2_NB : g.nJ - 1) : -1;
+        }
+        if (nJb >= 0) {
+          const e2_v2 *src = reinterpret_cast<const e2_v2 *>(g.pack + (size_t)(sgoff[nJb] + nk) * E2_PACK);
+#pragma unroll
+          for (int q = 0; q < PK_N; ++q)
+            if (t + 256 * q < E2_PACK / 2) pk[q] = src[t + 256 * q];
+        }
       }
       __builtin_amdgcn_sched_barrier(0);
       // X^T tile ct -= V[16 ct .., :] W2^T
