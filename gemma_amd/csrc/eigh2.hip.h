@@ -288,10 +288,10 @@ __global__ void e2_mirror_upper_kernel(double *__restrict__ A, long m, long ld) 
 // the entry at distance 128 of a row that carries a reflector is that reflector's beta
 __global__ __launch_bounds__(256) void sb_extract_band_kernel(const double *__restrict__ A, long n,
                                                               const double *__restrict__ betas, double *__restrict__ Bd) {
-  const long j = blockIdx.x;
+  const long j = blockIdx.x; // n .. n + 127: slack columns, all zero
   const int t = threadIdx.x;
   double v = 0.0;
-  if (t <= E2_B && j + t < n) {
+  if (j < n && t <= E2_B && j + t < n) {
     v = A[j * n + j + t];
     if (t == E2_B) {
       const double b = betas[j];
@@ -319,7 +319,7 @@ constexpr int BC_LDS_DOUBLES = E2_B * BC_LD + 8 * E2_B + 16;
 // task (j, k): the caller guarantees that it exists (j <= n - 3, j + 1 + 128 k < n) and that (j, k-1) and (j-1, k+1) are done
 #define BC_STAMP(i)                                                  \
   do {                                                               \
-    if (dbg && threadIdx.x == 0) dbg[i] = (long long)wall_clock64(); \
+    if (DBG && threadIdx.x == 0) dbg[i] = (long long)wall_clock64(); \
   } while (0)
 // value of lane `l` (compile-time constant after unrolling) as a wave-uniform scalar: VALU readlane, no LDS traffic
 __device__ __forceinline__ double bc_bcast(double x, int l) {
@@ -333,6 +333,7 @@ __device__ __forceinline__ double bc_bcast(double x, int l) {
 // registers with the vector's entries broadcast by readlane; only the column sums (v^T E, the transposed half of D v) need
 // the block in LDS: one store pass and one read pass per block (the stage is bound by the LDS pipe, not by HBM or flops:
 // the first version, which kept E in LDS for every step, spent 18 of its 29 us per task there).
+template <bool DBG>
 __device__ __forceinline__ void bc_task(double *__restrict__ B, long n, long j, long k, double *__restrict__ V2g,
                                         double *__restrict__ tau2g, double *e2sm, long long *dbg = nullptr) {
   BC_STAMP(0);
@@ -346,20 +347,33 @@ __device__ __forceinline__ void bc_task(double *__restrict__ B, long n, long j, 
   double er[64], dr[64];
   double xa, ya = 0.0, taup = 0.0, vph = 0.0;
   if (k > 0) {
-    const double *src = B + (r - E2_B + cb) * E2_LDB + E2_B + a - cb;
-#pragma unroll
-    for (int c = 0; c < 64; ++c) er[c] = (a < L) ? src[c * (E2_LDB - 1)] : 0.0;
+    // v_p and tau_p first: the counter retires in order, so whoever waits for E has them too and nothing later in the E phase
+    // has to wait behind the diagonal block's loads
     vph = V2g[((size_t)(k - 1) * n + j) * E2_B + cb + lane]; // v_p of this wavefront's columns, one per lane
     taup = tau2g[(k - 1) * n + j];
+    const double *src = B + (r - E2_B + cb) * E2_LDB + E2_B + a - cb;
+#pragma unroll
+    for (int c = 0; c < 64; ++c) er[c] = src[c * (E2_LDB - 1)]; // rows past n: slots of the band storage that stay zero
+  } else {
+    // first task of a sweep: the "block" is column j alone (there is no previous reflector: v_p = 0, tau_p = 0); the code below
+    // is the same, which keeps every global load of the task in front of the first barrier
+#pragma unroll
+    for (int c = 0; c < 64; ++c) er[c] = 0.0;
+    if (h == 0) er[0] = B[j * E2_LDB + 1 + a]; // rows past n: zero slots
   }
+#pragma unroll
+  for (int c = 0; c < 64; ++c) E[(cb + c) * BC_LD + a] = er[c];
   {
+    // the diagonal block's 64 loads go out once E has arrived (a wavefront tracks at most 63 vector-memory operations, more
+    // would only stall the issue) and stay in flight behind the whole E phase
+    // unconditional as well (a select on the loaded value would be placed right behind the load and wait for it): columns
+    // past n lie in the zeroed slack of the band storage, rows past n in slots that stay zero; above the diagonal (a < column)
+    // the address falls into the previous column and the value is masked where it is used
     const double *srd = B + (r + cb) * E2_LDB + a - cb;
 #pragma unroll
-    for (int c = 0; c < 64; ++c) dr[c] = (a >= cb + c && a < L) ? srd[c * (E2_LDB - 1)] : 0.0;
+    for (int c = 0; c < 64; ++c) dr[c] = srd[c * (E2_LDB - 1)];
   }
-  if (k > 0) {
-#pragma unroll
-    for (int c = 0; c < 64; ++c) E[(cb + c) * BC_LD + a] = er[c];
+  {
     double ys = 0.0;
 #pragma unroll
     for (int c = 0; c < 64; ++c) ys += er[c] * bc_bcast(vph, c);
@@ -369,8 +383,6 @@ __device__ __forceinline__ void bc_task(double *__restrict__ B, long n, long j, 
     BC_STAMP(1);
     ya = taup * (ybuf[a] + ybuf[E2_B + a]);
     xa = E[a] - ya * vp[0]; // first column of E (I - tau_p v_p v_p^T)
-  } else {
-    xa = (a < L) ? B[j * E2_LDB + 1 + a] : 0.0;
   }
   BC_STAMP(2);
   if (t == 0) red[8] = xa;
@@ -418,7 +430,7 @@ __device__ __forceinline__ void bc_task(double *__restrict__ B, long n, long j, 
 #pragma unroll
   for (int c = 0; c < 64; ++c) {
     E[(cb + c) * BC_LD + a] = (a > cb + c) ? dr[c] : 0.0; // strictly lower part for the transposed product
-    p1 += dr[c] * bc_bcast(vh, c);
+    p1 += ((a >= cb + c) ? dr[c] : 0.0) * bc_bcast(vh, c);
   }
   ybuf[h * E2_B + a] = p1;
   __syncthreads();
@@ -450,7 +462,7 @@ __global__ __launch_bounds__(256) void bc_step_kernel(BcArgs g) {
   extern __shared__ double e2sm[];
   const long n = g.n, j = g.jlo + blockIdx.x, k = g.t - 2 * j;
   if (k < 0 || j > n - 3 || j + 1 + k * E2_B >= n) return;
-  bc_task(g.Bd, n, j, k, g.V2, g.tau2, e2sm);
+  bc_task<false>(g.Bd, n, j, k, g.V2, g.tau2, e2sm);
 }
 
 // The same chase as ONE launch: workgroup w owns the chase positions k = 2 w and 2 w + 1 and walks the sweeps j = 0, 1, ...;
@@ -474,6 +486,8 @@ __device__ __forceinline__ bool bc_wait(int *p, int target, int *err) {
   __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   return false;
 }
+template <bool DBG> // DBG: wall-clock stamps of workgroup 1's tasks (compiled out otherwise: a conditional store in the task
+                    // makes the compiler wait for every load in flight at the join)
 __global__ __launch_bounds__(256) void bc_persist_kernel(BcPersistArgs g) {
   extern __shared__ double e2sm[];
   __shared__ int s_ok;
@@ -493,12 +507,13 @@ __global__ __launch_bounds__(256) void bc_persist_kernel(BcPersistArgs g) {
       __syncthreads();
       if (!s_ok) return;
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      long long *dbg = (g.dbg && blockIdx.x == 1 && sidx == 0 && j < 512) ? g.dbg + 16 * j : nullptr;
-      bc_task(g.Bd, n, j, k, g.V2, g.tau2, e2sm, dbg);
+      long long *dbg = (DBG && g.dbg && blockIdx.x == 1 && sidx == 0 && j < 512) ? g.dbg + 16 * j : nullptr;
+      if (DBG && dbg) bc_task<true>(g.Bd, n, j, k, g.V2, g.tau2, e2sm, dbg);
+      else bc_task<false>(g.Bd, n, j, k, g.V2, g.tau2, e2sm);
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
       __syncthreads();
       if (threadIdx.x == 0) __hip_atomic_store(g.prog + k, (int)(j + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (dbg && threadIdx.x == 0) dbg[8] = (long long)wall_clock64();
+      if (DBG && dbg && threadIdx.x == 0) dbg[8] = (long long)wall_clock64();
     }
   }
 }
@@ -808,7 +823,8 @@ static inline int eig2_sy2sb(double *A, long n, EigWs &ws, Eig2Ws &w2, hipStream
       hipLaunchKernelGGL(e2_mirror_upper_kernel, dim3(nb32, nb32), dim3(32, 8), 0, s, A22, m, n);
     }
   }
-  hipLaunchKernelGGL(sb_extract_band_kernel, dim3((unsigned)n), dim3(256), 0, s, A, n, w2.betas, w2.Bd);
+  // 128 columns of zeroed slack behind the band: the chase reads whole 128 x 128 blocks without bounds checks
+  hipLaunchKernelGGL(sb_extract_band_kernel, dim3((unsigned)(n + E2_B)), dim3(256), 0, s, A, n, w2.betas, w2.Bd);
   EIG_HIP(hipGetLastError());
   return 0;
 }
@@ -832,14 +848,16 @@ static inline int eig2_sb2st(long n, EigWs &ws, Eig2Ws &w2, hipStream_t s, std::
       hipDeviceProp_t prop;
       if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ncu = prop.multiProcessorCount;
       if (ncu <= 0) ncu = 1;
-      EIG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(bc_persist_kernel),
+      EIG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(bc_persist_kernel<false>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, BC_LDS_DOUBLES * 8));
+      EIG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(bc_persist_kernel<true>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, BC_LDS_DOUBLES * 8));
     }
     const char *eb = getenv("GEMMA_HIP_EIGH_BC");
     const long nwg = (w2.kmaxall + 1) / 2;
     if (!(eb && eb[0] == 's') && nwg <= ncu) {
       EIG_HIP(hipMemsetAsync(w2.prog, 0, (size_t)(w2.kmaxall + 2) * sizeof(int), s));
-      EIG_HIP(hipMemcpyAsync(w2.Bd0, w2.Bd, (size_t)n * E2_LDB * 8, hipMemcpyDeviceToDevice, s));
+      EIG_HIP(hipMemcpyAsync(w2.Bd0, w2.Bd, (size_t)(n + E2_B) * E2_LDB * 8, hipMemcpyDeviceToDevice, s));
       BcPersistArgs pa{w2.Bd, n, w2.V2, w2.tau2, w2.prog, w2.prog + w2.kmaxall + 1, nullptr};
       const char *ed = getenv("GEMMA_HIP_EIGH_BC_DBG");
       long long *dbg_d = nullptr;
@@ -847,7 +865,8 @@ static inline int eig2_sb2st(long n, EigWs &ws, Eig2Ws &w2, hipStream_t s, std::
         (void)hipMemsetAsync(dbg_d, 0, 512 * 16 * 8, s);
         pa.dbg = dbg_d;
       }
-      hipLaunchKernelGGL(bc_persist_kernel, dim3((unsigned)nwg), dim3(256), BC_LDS_DOUBLES * 8, s, pa);
+      if (dbg_d) hipLaunchKernelGGL(bc_persist_kernel<true>, dim3((unsigned)nwg), dim3(256), BC_LDS_DOUBLES * 8, s, pa);
+      else hipLaunchKernelGGL(bc_persist_kernel<false>, dim3((unsigned)nwg), dim3(256), BC_LDS_DOUBLES * 8, s, pa);
       EIG_HIP(hipGetLastError());
       if (dbg_d) {
         std::vector<long long> hs(512 * 16);
@@ -880,7 +899,7 @@ static inline int eig2_sb2st(long n, EigWs &ws, Eig2Ws &w2, hipStream_t s, std::
       // a workgroup waited too long for its neighbour (possible only when something else kept part of the chip busy, so that
       // not every workgroup was resident): the band is restored from the copy taken above and the chase repeated as one
       // launch per time step, which needs no co-residency
-      EIG_HIP(hipMemcpyAsync(w2.Bd, w2.Bd0, (size_t)n * E2_LDB * 8, hipMemcpyDeviceToDevice, s));
+      EIG_HIP(hipMemcpyAsync(w2.Bd, w2.Bd0, (size_t)(n + E2_B) * E2_LDB * 8, hipMemcpyDeviceToDevice, s));
       EIG_HIP(hipMemsetAsync(w2.tau2, 0, (size_t)w2.kmaxall * n * 8, s));
     }
   }
@@ -967,7 +986,7 @@ static inline bool eig2_alloc(long n, EigWs &ws, Eig2Ws &w2) {
   }
   w2.ngroups = goff[w2.nJ];
   const size_t nwg_panel = (size_t)(n + SB_COLS - 1) / SB_COLS, nwg_gram = (size_t)(n + GR_CH - 1) / GR_CH;
-  bool ok = ws.get(w2.Bd, (size_t)n * E2_LDB) && ws.get(w2.Bd0, (size_t)n * E2_LDB) && ws.get(w2.part, 2 * nwg_panel * E2_B) && ws.get(w2.heads, 2 * E2_B) &&
+  bool ok = ws.get(w2.Bd, (size_t)(n + E2_B) * E2_LDB) && ws.get(w2.Bd0, (size_t)(n + E2_B) * E2_LDB) && ws.get(w2.part, 2 * nwg_panel * E2_B) && ws.get(w2.heads, 2 * E2_B) &&
             ws.get(w2.betas, n) && ws.get(w2.gramP, nwg_gram * E2_B * E2_B) && ws.get(w2.YT, (size_t)4 * E2_B * n) &&
             ws.get(w2.V2, (size_t)w2.kmaxall * n * E2_B) && ws.get(w2.tau2, (size_t)w2.kmaxall * n) &&
             ws.get(w2.pack, (size_t)w2.ngroups * E2_PACK) && ws.get(w2.goff, (size_t)w2.nJ + 1) &&
