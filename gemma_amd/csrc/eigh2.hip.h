@@ -39,7 +39,7 @@ constexpr int E2_WIN = E2_B + E2_NB;     // window of Z^T columns one group touc
 constexpr int E2_VLD = 34;               // leading dimension of the packed group (bank-conflict padding)
 constexpr int E2_PACK = (E2_WIN + E2_NB) * E2_VLD; // doubles per packed group: V (160 x 34) then T (32 x 34)
 constexpr int SB_COLS = 256;             // panel columns per workgroup of sb_panel_kernel
-constexpr int GR_CH = 512, GR_KS = 16;   // Gram kernel: columns per workgroup, columns per LDS step
+constexpr int GR_CH = 256, GR_KS = 16;   // Gram kernel: columns per workgroup (n / 256 workgroups per call), columns per LDS step
 
 __device__ __forceinline__ double e2_bsum256(double v, double *red /* 8 doubles */) {
   v = eig_wsum(v);
@@ -85,23 +85,28 @@ __global__ __launch_bounds__(256) void sb_panel_kernel(SbPanelArgs g) {
   const long base = r0 + (long)blockIdx.x * SB_COLS + lane;
   // every global load this launch depends on is issued here, in one round trip: the previous launch's partial sums and
   // head entries, row c-1 (the pending reflector), row c (the next one)
+  // loads are unconditional (column clamped into the row, row clamped into the panel): a predicated load becomes its own
+  // branch region and a select on its value a wait right behind it; what a clamped lane reads is masked where it is used
   bool valid[4];
+  long ccol[4];
   double xprev[4], yc[4];
+  const int prow = c > 0 ? prev : 0, crow = more ? c : (E2_B - 1);
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const long col = base + 64 * i;
     valid[i] = col < n;
-    xprev[i] = (c > 0 && valid[i] && col > head_prev) ? g.A[(j0 + prev) * n + col] : 0.0;
-    yc[i] = (more && valid[i]) ? g.A[(j0 + c) * n + col] : 0.0;
+    ccol[i] = valid[i] ? col : n - 1;
+    xprev[i] = g.A[(j0 + prow) * n + ccol[i]];
+    yc[i] = g.A[(j0 + crow) * n + ccol[i]];
   }
   const int qfirst = c + ((wave - c) & 3);
   double ynext[4][4];
 #pragma unroll
   for (int u = 0; u < 4; ++u) {
     const int q = qfirst + 4 * u;
-    const double *row = g.A + (j0 + (q < E2_B ? q : 0)) * n;
+    const double *row = g.A + (j0 + (q < E2_B ? q : E2_B - 1)) * n;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) ynext[u][i] = (q < E2_B && valid[i]) ? row[base + 64 * i] : 0.0;
+    for (int i = 0; i < 4; ++i) ynext[u][i] = row[ccol[i]];
   }
   double scale = 0.0;
   if (c > 0) {
@@ -138,7 +143,7 @@ __global__ __launch_bounds__(256) void sb_panel_kernel(SbPanelArgs g) {
   if (more) { // row c after the pending update: x of the next reflector (every wavefront needs it for its own columns)
     const double f = (c > 0) ? sf[c] : 0.0;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) xc[i] = (base + 64 * i > head_c) ? yc[i] - f * v[i] : 0.0;
+    for (int i = 0; i < 4; ++i) xc[i] = (valid[i] && base + 64 * i > head_c) ? yc[i] - f * v[i] : 0.0;
   }
   // this wavefront's rows q = q0, q0 + 4, ...: four rows per step, all loads of a step in flight together and the next
   // step's loads issued before this step's arithmetic (the first step's were issued before the barriers above)
@@ -152,9 +157,9 @@ __global__ __launch_bounds__(256) void sb_panel_kernel(SbPanelArgs g) {
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const int q = q0 + 16 + 4 * u;
-        const double *row = g.A + (j0 + q) * n;
+        const double *row = g.A + (j0 + (q < E2_B ? q : E2_B - 1)) * n;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) ynext[u][i] = (q < E2_B && valid[i]) ? row[base + 64 * i] : 0.0;
+        for (int i = 0; i < 4; ++i) ynext[u][i] = row[ccol[i]];
       }
     }
     double pr[4];
