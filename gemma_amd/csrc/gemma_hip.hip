@@ -19,6 +19,7 @@
 #include "lmm_assoc.hip.h"
 #include "lmm_grid.hip.h"
 #include "i8gemm.hip.h"
+#include "i8gemm_sparse.hip.h"
 #include "qc.hip.h"
 #include "mvlmm.hip.h"
 #include "comm.hip.h"
@@ -74,6 +75,7 @@ struct Ctx {
   DevBuf kin_K, kin_X, kin_stage;
   // exact-integer path of the centred kinship of hard calls (kin_i8.hip.h)
   bool kin_i8 = false, kin_i8_used = false;
+  DevBuf i8_meta, i8_rowsur; // sparse mask operand: the words of the packed block, dropped calls per row
   DevBuf U_even;            // odd n: U copied to an even leading dimension for the fp64 GEMM's aligned path
   const double *U_even_of = nullptr; // the U that copy was made from
   DevBuf kin_GtG, kin_S, kin_a, kin_At, kin_Gt;
@@ -1355,6 +1357,21 @@ static int i8_begin(size_t l, I8Dims *d, hipStream_t s) {
 
 // UtX (l x ldx) from the packed left factor in g_ctx.i8_A and the per-SNP means in g_ctx.i8_mean
 static int i8_product(size_t l, const I8Dims &d, double *UtX, size_t ldx, hipStream_t s) {
+  // GEMMA_HIP_I8_SPARSE=0: the mask product on dense MFMAs (i8gemm_packed_kernel_t); default: on the 2:4 sparse MFMA
+  // (i8gemm_sparse.hip.h) -- one word per (row, 32 individuals) describes the operand, rows that lose calls to the 2-of-4
+  // limit are completed in fp64 after the digits are combined
+  const char *esp = getenv("GEMMA_HIP_I8_SPARSE");
+  const bool sparse = !(esp && esp[0] == '0');
+  if (sparse) {
+    ProfScope ps(GEMMA_STAGE_INGEST, s);
+    const size_t nk = d.ldk / I8_BK, total = d.lpad * nk * 2;
+    if (g_ctx.i8_meta.reserve(total * sizeof(uint4)) || g_ctx.i8_rowsur.reserve(d.lpad * sizeof(int)))
+      return fail(GEMMA_HIP_ENOMEM, "lmm_batch: mask words of the sparse product");
+    HIPCHK(hipMemsetAsync(g_ctx.i8_rowsur.p, 0, d.lpad * sizeof(int), s));
+    hipLaunchKernelGGL(sparse_meta_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, g_ctx.i8_A.as<int8_t>(),
+                       (long)d.lpad, (long)d.ldk, g_ctx.i8_meta.as<uint4>(), g_ctx.i8_rowsur.as<int>());
+    HIPCHK(hipGetLastError());
+  }
   {
     ProfScope ps(GEMMA_STAGE_UTX_GEMM, s);
     static bool attr_set = false;
@@ -1377,7 +1394,21 @@ static int i8_product(size_t l, const I8Dims &d, double *UtX, size_t ldx, hipStr
     g.fuse = d.fuse;
     g.digits = d.digits;
     const dim3 grid((unsigned)(g.tiles_m * g.tiles_n), (unsigned)d.nplanes);
-    hipLaunchKernelGGL(i8gemm_packed_kernel_t<true>, grid, dim3(512), 3 * I8P_STAGE, s, g);
+    if (sparse) {
+      static bool attr2 = false;
+      if (!attr2) {
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(i8gemm_sparse_kernel),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, 3 * SP_STAGE));
+        attr2 = true;
+      }
+      SparseMeta sm;
+      sm.m4 = g_ctx.i8_meta.as<uint4>();
+      sm.row_surplus = g_ctx.i8_rowsur.as<int>();
+      sm.ntiles = (long)g.nk;
+      hipLaunchKernelGGL(i8gemm_sparse_kernel, grid, dim3(512), 3 * SP_STAGE, s, g, sm);
+    } else {
+      hipLaunchKernelGGL(i8gemm_packed_kernel_t<true>, grid, dim3(512), 3 * I8P_STAGE, s, g);
+    }
     HIPCHK(hipGetLastError());
   }
   {
@@ -1388,6 +1419,12 @@ static int i8_product(size_t l, const I8Dims &d, double *UtX, size_t ldx, hipStr
                        g_ctx.i8_mean.as<double>(), g_ctx.i8_ej.as<int>(), (long)l, (long)d.n, UtX, (long)ldx, 1.0, d.fuse,
                        d.digits);
     HIPCHK(hipGetLastError());
+    if (sparse) {
+      hipLaunchKernelGGL(i8_surplus_fix_kernel, dim3((unsigned)l), dim3(256), 0, s, g_ctx.i8_A.as<int8_t>(), (long)d.ldk,
+                         g_ctx.i8_rowsur.as<int>(), g_ctx.i8_mean.as<double>(), g_ctx.U, (long)d.n, (long)d.n, (long)l, UtX,
+                         (long)ldx);
+      HIPCHK(hipGetLastError());
+    }
   }
   return GEMMA_HIP_OK;
 }

@@ -559,6 +559,42 @@ def test_utx_int8_digit_product_matches_fp64(gpu_api, oracle, ni_total, p):
     assert err8 < 8 * 2.3e-16  # assembled from exact integer sums: a few roundings, not a 600-term chain
 
 
+def test_utx_int8_sparse_mask_operand_and_surplus_rows(gpu_api, oracle, monkeypatch):
+    """The missing-mask product runs on the 2:4 structured-sparse MFMA (csrc/i8gemm_sparse.hip.h): a group of four
+    individuals with three or four missing calls keeps two in the matrix product, the rest is added in fp64 per flagged row.
+    35 % missingness makes such groups common (one in five); one SNP is missing for 90 % of the individuals, one nowhere.  Against the exact
+    product and against the dense mask product (GEMMA_HIP_I8_SPARSE=0): identical to the last bits of the combine."""
+    from gemma_amd import _lib as L
+    rng = np.random.default_rng(99)
+    ni_total, p = 777, 300
+    ind, raw = _plink_case(oracle, rng, ni_total, p, drop=0.1, miss=0.35)
+    raw[7, : raw.shape[1] * 9 // 10] = 0x55  # nine tenths of the individuals missing at this SNP (code 1)
+    raw[8] = 0xFF                             # code 3 everywhere: no missing call
+    n = int(ind.sum())
+    Xn = oracle.bed_decode(raw, ni_total, ind)
+    Q, _ = np.linalg.qr(rng.standard_normal((n, n)))
+    ev = np.sort(rng.uniform(0.0, 3.0, n))
+    y = rng.standard_normal(n)
+    out = {}
+    for sp in ("1", "0"):
+        monkeypatch.setenv("GEMMA_HIP_I8_SPARSE", sp)
+        lmm = gpu_api.LMM(a_mode=1)
+        lmm.setup(Q, ev, Q.T @ np.ones((n, 1)), Q.T @ y, plink=True)
+        lmm.set_indicator(ind)
+        try:
+            out[sp] = lmm.dbg_utx(raw, L.GENO_PLINK_2BIT, 1)
+        finally:
+            lmm.finish()
+    Xi = np.where(np.isnan(Xn), np.nan_to_num(np.nanmean(Xn, axis=1))[:, None], Xn)
+    exact = (Xi.astype(np.longdouble) @ Q.astype(np.longdouble)).astype(np.float64)
+    scale = np.maximum(np.abs(Xi) @ np.abs(Q), 1e-300)
+    e_sparse = np.max(np.abs(out["1"] - exact) / scale)
+    e_dense = np.max(np.abs(out["0"] - exact) / scale)
+    _record("U^T x int8, 35 %% missing: sparse mask operand err %.2e, dense %.2e (units of sum|x||u|); sparse vs dense max diff %.2e"
+            % (e_sparse, e_dense, np.max(np.abs(out["1"] - out["0"]) / scale)))
+    assert e_dense < 8 * 2.3e-16 and e_sparse < 8 * 2.3e-16
+
+
 def test_utx_int8_more_rows_than_a_grid_dimension(gpu_api, oracle):
     """70 000 SNPs in one block: more rows than a HIP grid's y extent (65 535) -- the digit-combine pass sweeps."""
     from gemma_amd import _lib as L
