@@ -309,10 +309,23 @@ def main():
             dg = ctypes.c_int(7)
             L.lib().gemma_hip_dbg_i8_digits(n, ctypes.byref(dg))
             ops_per_launch = 2.0 * dg.value * 2.0 * B * n * n
-            achieved = ops_per_launch / gemm_avg_s / 1e12
-            roof = {"kernel": "i8gemm_packed_kernel (%d int8-digit products = UtX; %d base-256 digits of U)" % (2 * dg.value, dg.value), "bound": "mfma",
+            logical = ops_per_launch / gemm_avg_s / 1e12
+            sparse = os.environ.get("GEMMA_HIP_I8_SPARSE", "1") != "0"
+            # With the mask product on the 2:4 sparse MFMA (csrc/i8gemm_sparse.hip.h) a pair of K-steps issues 8 dense + 4 sparse
+            # matrix instructions instead of 16 dense ones, and a sparse instruction holds the pipe as long as a dense one
+            # (profiles/r02_smfmac_i8_rate.txt): the pipe does 12/16 of the dense work.  `achieved` / `frac` price what the pipe
+            # executes against the DENSE int8 peak; `logical_top_s` is the rate of the 2 D products as written.
+            achieved = logical * (0.75 if sparse else 1.0)
+            kname = ("i8gemm_sparse_kernel (%d int8-digit products = UtX: %d dense genotype products + %d mask products on the 2:4 sparse MFMA; "
+                     "%d base-256 digits of U)" % (2 * dg.value, dg.value, dg.value, dg.value)) if sparse else \
+                    "i8gemm_packed_kernel (%d int8-digit products = UtX; %d base-256 digits of U)" % (2 * dg.value, dg.value)
+            roof = {"kernel": kname, "bound": "mfma",
                     "achieved": round(achieved, 1), "peak": INT8_MFMA_PEAK_TOPS, "unit": "TOP/s",
-                    "frac": round(achieved / INT8_MFMA_PEAK_TOPS, 4), "traffic": None, "launches": gemm_n,
+                    "frac": round(achieved / INT8_MFMA_PEAK_TOPS, 4), "logical_top_s": round(logical, 1),
+                    "logical_frac_of_dense_peak": round(logical / INT8_MFMA_PEAK_TOPS, 4),
+                    "note": "achieved = dense-equivalent work of the matrix pipe (a 2:4 sparse instruction counted as the dense one it "
+                            "takes the time of); logical_top_s = the 2 D products as written" if sparse else "dense int8 MFMA",
+                    "traffic": None, "launches": gemm_n,
                     "avg_launch_ms": round(gemm_avg_s * 1e3, 3),
                     # the same launch priced as the fp64 product it replaces (2 n^2 flop per SNP)
                     "equiv_fp64_tflops": round(2.0 * B * n * n / gemm_avg_s / 1e12, 1)}
