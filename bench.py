@@ -373,6 +373,8 @@ def main():
                     line["roofline_assoc"]["traffic"] = pj.get("assoc_hbm_bytes_per_launch")
                     line["roofline"]["traffic"] = pj.get("i8gemm_hbm_bytes_per_launch" if i8_path
                                                          else "utx_gemm_hbm_bytes_per_launch")
+                    if i8_path and pj.get("i8gemm_note") and os.environ.get("GEMMA_HIP_I8_SPARSE", "1") != "0":
+                        line["roofline"]["traffic_note"] = pj["i8gemm_note"]
                     if fp64_path:
                         fp64_path["roofline"]["traffic"] = pj.get("utx_gemm_hbm_bytes_per_launch")
             except Exception:
