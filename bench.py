@@ -83,8 +83,27 @@ def synth_block(torch, n, l, gen, dev, miss=0.01, fst=0.05):
     return packed.contiguous()
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` with no torch.distributed environment: launch the N ranks ourselves, exactly the way the
+    driver does (one process per GPU under torch.distributed.run, rendezvous on 127.0.0.1), and pass rank 0's JSON line
+    through.  With WORLD_SIZE already set (the driver's own torchrun launch) this is never taken."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -92,6 +111,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world and rank == 0:
+        print("bench.py: --gpus %d but WORLD_SIZE=%d: the launcher's world size is used" % (args.gpus, world), file=sys.stderr)
     # test hooks (1-GPU box): BENCH_FORCE_DEVICE pins every rank to one device, BENCH_DIST_BACKEND=gloo then
     # carries the collectives; the driver's multi-GPU runs use neither (one rank per GPU over RCCL)
     if os.environ.get("BENCH_FORCE_DEVICE"):
@@ -227,9 +248,13 @@ def main():
     # rank could create it, otherwise the same two collectives through torch.distributed (nccl = RCCL as well)
     bpath = "none (1 rank)"
     if world > 1:
-        if os.environ.get("BENCH_DIST_BACKEND", "nccl") == "nccl" and gdist.native_comm_init():
+        # the library's own communicator: RCCL, or -- only when asked for by name, for N ranks on ONE device in the tests --
+        # its shared-memory test transport behind the same entry points (csrc/comm_shm.hpp)
+        want_native = os.environ.get("BENCH_DIST_BACKEND", "nccl") == "nccl" or os.environ.get("GEMMA_HIP_COMM", "") == "shm"
+        if want_native and gdist.native_comm_init():
             gdist.broadcast_state_native([U, ev, UtW, Uty, null])
-            bpath = "native: ncclBroadcast from libgemma_hip.so's communicator"
+            bpath = "native: ncclBroadcast from libgemma_hip.so's communicator" if os.environ.get("GEMMA_HIP_COMM", "") != "shm" \
+                else "native: libgemma_hip.so's communicator over its shm test transport (GEMMA_HIP_COMM=shm)"
         else:
             gdist.broadcast_state([U, ev, UtW, Uty, null])
             bpath = "torch.distributed broadcast (%s)" % os.environ.get("BENCH_DIST_BACKEND", "nccl")
@@ -310,14 +335,17 @@ def main():
             L.lib().gemma_hip_dbg_i8_digits(n, ctypes.byref(dg))
             ops_per_launch = 2.0 * dg.value * 2.0 * B * n * n
             logical = ops_per_launch / gemm_avg_s / 1e12
-            sparse = os.environ.get("GEMMA_HIP_I8_SPARSE", "1") != "0"
+            smode = os.environ.get("GEMMA_HIP_I8_SPARSE", "2")[:1]
+            smode = smode if smode in ("0", "1", "2") else "2"
+            sparse = smode != "0"
+            kfn = {"0": "i8gemm_packed_kernel", "1": "i8gemm_sparse_kernel", "2": "i8gemm_sparse2_kernel"}[smode]
             # With the mask product on the 2:4 sparse MFMA (csrc/i8gemm_sparse.hip.h) a pair of K-steps issues 8 dense + 4 sparse
             # matrix instructions instead of 16 dense ones, and a sparse instruction holds the pipe as long as a dense one
             # (profiles/r02_smfmac_i8_rate.txt): the pipe does 12/16 of the dense work.  `achieved` / `frac` price what the pipe
             # executes against the DENSE int8 peak; `logical_top_s` is the rate of the 2 D products as written.
             achieved = logical * (0.75 if sparse else 1.0)
-            kname = ("i8gemm_sparse_kernel (%d int8-digit products = UtX: %d dense genotype products + %d mask products on the 2:4 sparse MFMA; "
-                     "%d base-256 digits of U)" % (2 * dg.value, dg.value, dg.value, dg.value)) if sparse else \
+            kname = ("%s (%d int8-digit products = UtX: %d dense genotype products + %d mask products on the 2:4 sparse MFMA; "
+                     "%d base-256 digits of U)" % (kfn, 2 * dg.value, dg.value, dg.value, dg.value)) if sparse else \
                     "i8gemm_packed_kernel (%d int8-digit products = UtX; %d base-256 digits of U)" % (2 * dg.value, dg.value)
             roof = {"kernel": kname, "bound": "mfma",
                     "achieved": round(achieved, 1), "peak": INT8_MFMA_PEAK_TOPS, "unit": "TOP/s",
@@ -359,6 +387,20 @@ def main():
                                   "utx_post": round(post_ms / max(1, args.steps), 3),
                                   "assoc": round(assoc_ms / max(1, args.steps), 3)},
         }
+        # Amdahl statement for the BASELINE config of this n (SNP-sharded run over N GPUs: setup once, then p / N SNPs per
+        # rank with no collective): every term measured in THIS run; the N > 1 rows are projections from the per-GPU rate,
+        # the driver's SCALE run is the measurement
+        p_cfg = {20000: 1000000, 50000: 500000, 5000: 100000, 10000: 500000}.get(n, B * args.steps)
+        per_gpu = value / world
+        setup_once = sum(float(setup_info.get(k) or 0.0) for k in ("kinship_s", "eigen_s", "broadcast_s"))
+        line["amdahl"] = {
+            "p_total": p_cfg, "setup_once_s": round(setup_once, 3),
+            "setup_terms_s": {k: setup_info.get(k) for k in ("kinship_s", "eigen_s", "broadcast_s")},
+            "kinship_note": "kinship_s covers %d SNPs here; over all p SNPs it shards with the SNPs (one ncclAllReduce of n^2 sums)" % args.kin_snps,
+            "assoc_s_per_rank": {str(N): round(p_cfg / N / per_gpu, 3) for N in (1, 2, 4, 8)},
+            "projected_total_s": {str(N): round(setup_once + p_cfg / N / per_gpu, 3) for N in (1, 2, 4, 8)},
+            "serial_fraction_at_8": round(setup_once / (setup_once + p_cfg / 8 / per_gpu), 4) if setup_once else None,
+            "note": "eigendecomposition runs on one GPU (replicas only for that stage); ranks idle during it"}
         if fp64_path:
             line["fp64_gemm_path"] = fp64_path
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
@@ -373,7 +415,7 @@ def main():
                     line["roofline_assoc"]["traffic"] = pj.get("assoc_hbm_bytes_per_launch")
                     line["roofline"]["traffic"] = pj.get("i8gemm_hbm_bytes_per_launch" if i8_path
                                                          else "utx_gemm_hbm_bytes_per_launch")
-                    if i8_path and pj.get("i8gemm_note") and os.environ.get("GEMMA_HIP_I8_SPARSE", "1") != "0":
+                    if i8_path and pj.get("i8gemm_note"):
                         line["roofline"]["traffic_note"] = pj["i8gemm_note"]
                     if fp64_path:
                         fp64_path["roofline"]["traffic"] = pj.get("utx_gemm_hbm_bytes_per_launch")

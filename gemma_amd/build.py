@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libgemma_hip.so")
 SOURCES = ["gemma_hip.hip", "mvlmm_kernels.hip"]  # one object each, compiled concurrently
-HEADERS = ["dgemm_mfma.hip.h", "lmm_grid.hip.h", "i8gemm.hip.h", "i8gemm_sparse.hip.h", "lmm_assoc.hip.h", "lmm_search.hip.h", "comm.hip.h", "comm_shm.hpp", "kin_i8.hip.h", "ingest.hip.h", "eigh.hip.h", "eigh2.hip.h", "qc.hip.h", "lm_assoc.hip.h", "mvlmm.hip.h"]
+HEADERS = ["dgemm_mfma.hip.h", "lmm_grid.hip.h", "i8gemm.hip.h", "i8gemm_sparse.hip.h", "i8gemm_sparse2.hip.h", "lmm_assoc.hip.h", "lmm_search.hip.h", "comm.hip.h", "comm_shm.hpp", "kin_i8.hip.h", "ingest.hip.h", "eigh.hip.h", "eigh2.hip.h", "qc.hip.h", "lm_assoc.hip.h", "mvlmm.hip.h"]
 
 
 def hipcc():

@@ -20,6 +20,7 @@
 #include "lmm_grid.hip.h"
 #include "i8gemm.hip.h"
 #include "i8gemm_sparse.hip.h"
+#include "i8gemm_sparse2.hip.h"
 #include "qc.hip.h"
 #include "mvlmm.hip.h"
 #include "comm.hip.h"
@@ -1338,11 +1339,19 @@ struct I8Dims {
   size_t n, ldk, npad, lpad, mrows;
   int fuse, digits, nplanes;
 };
+// GEMMA_HIP_I8_SPARSE: 0 = the mask product on dense MFMAs (i8gemm_packed_kernel_t), 1 = on the 2:4 sparse MFMA with byte-wise
+// genotypes and separate mask words (i8gemm_sparse.hip.h), 2 (default) = sparse MFMA, left factor as 16-byte records of 2-bit
+// genotypes + mask words, 256 x 128 tiles (i8gemm_sparse2.hip.h)
+static int i8_sparse_mode() {
+  const char *e = getenv("GEMMA_HIP_I8_SPARSE");
+  if (e && e[0] >= '0' && e[0] <= '2') return e[0] - '0';
+  return 2;
+}
 static int i8_begin(size_t l, I8Dims *d, hipStream_t s) {
   int rc = i8_prepare_u(s);
   if (rc) return rc;
   d->n = g_ctx.cfg.n; d->ldk = g_ctx.i8_ldk; d->npad = g_ctx.i8_npad;
-  d->lpad = round_up(l, I8P_BM); d->mrows = 2 * d->lpad;
+  d->lpad = round_up(l, i8_sparse_mode() == 2 ? (size_t)S2_BM : (size_t)I8P_BM); d->mrows = 2 * d->lpad;
   // two digits per int32 output plane while 256 * C_hi + C_lo cannot overflow: n * 2 * 128 * 257 < 2^31
   const char *ef = getenv("GEMMA_HIP_I8_FUSE");
   d->fuse = (!(ef && ef[0] == '0') && (double)d->n * 2.0 * 128.0 * 257.0 < 2147483648.0) ? 1 : 0;
@@ -1360,16 +1369,20 @@ static int i8_product(size_t l, const I8Dims &d, double *UtX, size_t ldx, hipStr
   // GEMMA_HIP_I8_SPARSE=0: the mask product on dense MFMAs (i8gemm_packed_kernel_t); default: on the 2:4 sparse MFMA
   // (i8gemm_sparse.hip.h) -- one word per (row, 32 individuals) describes the operand, rows that lose calls to the 2-of-4
   // limit are completed in fp64 after the digits are combined
-  const char *esp = getenv("GEMMA_HIP_I8_SPARSE");
-  const bool sparse = !(esp && esp[0] == '0');
+  const int mode = i8_sparse_mode();
+  const bool sparse = mode != 0;
   if (sparse) {
     ProfScope ps(GEMMA_STAGE_INGEST, s);
-    const size_t nk = d.ldk / I8_BK, total = d.lpad * nk * 2;
+    const size_t nk = d.ldk / I8_BK, total = d.lpad * nk * (mode == 2 ? 4 : 2);
     if (g_ctx.i8_meta.reserve(total * sizeof(uint4)) || g_ctx.i8_rowsur.reserve(d.lpad * sizeof(int)))
       return fail(GEMMA_HIP_ENOMEM, "lmm_batch: mask words of the sparse product");
     HIPCHK(hipMemsetAsync(g_ctx.i8_rowsur.p, 0, d.lpad * sizeof(int), s));
-    hipLaunchKernelGGL(sparse_meta_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, g_ctx.i8_A.as<int8_t>(),
-                       (long)d.lpad, (long)d.ldk, g_ctx.i8_meta.as<uint4>(), g_ctx.i8_rowsur.as<int>());
+    if (mode == 2)
+      hipLaunchKernelGGL(sparse2_meta_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, g_ctx.i8_A.as<int8_t>(),
+                         (long)d.lpad, (long)d.ldk, g_ctx.i8_meta.as<uint4>(), g_ctx.i8_rowsur.as<int>());
+    else
+      hipLaunchKernelGGL(sparse_meta_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, g_ctx.i8_A.as<int8_t>(),
+                         (long)d.lpad, (long)d.ldk, g_ctx.i8_meta.as<uint4>(), g_ctx.i8_rowsur.as<int>());
     HIPCHK(hipGetLastError());
   }
   {
@@ -1394,7 +1407,22 @@ static int i8_product(size_t l, const I8Dims &d, double *UtX, size_t ldx, hipStr
     g.fuse = d.fuse;
     g.digits = d.digits;
     const dim3 grid((unsigned)(g.tiles_m * g.tiles_n), (unsigned)d.nplanes);
-    if (sparse) {
+    if (mode == 2) {
+      static bool attr3 = false;
+      if (!attr3) {
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(i8gemm_sparse2_kernel),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, S2_NST * S2_STAGE));
+        attr3 = true;
+      }
+      Sparse2Args g2;
+      g2.AM = g_ctx.i8_meta.as<uint4>();
+      g2.Bt = g.Bt; g2.C = g.C; g2.ldk = g.ldk; g2.ldc = g.ldc; g2.strideB = g.strideB; g2.strideC = g.strideC;
+      g2.m_row0 = g.m_row0;
+      g2.tiles_m = (int)(d.lpad / S2_BM); g2.tiles_n = (int)(d.npad / S2_BN);
+      g2.nk = g.nk; g2.gm = g.gm; g2.fuse = g.fuse; g2.digits = g.digits;
+      hipLaunchKernelGGL(i8gemm_sparse2_kernel, dim3((unsigned)(g2.tiles_m * g2.tiles_n), (unsigned)d.nplanes), dim3(512),
+                         S2_NST * S2_STAGE, s, g2);
+    } else if (sparse) {
       static bool attr2 = false;
       if (!attr2) {
         HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(i8gemm_sparse_kernel),

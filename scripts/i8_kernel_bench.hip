@@ -2,7 +2,8 @@
 // digit planes on the device, the kernel timed with HIP events, sampled output entries checked against integer sums on the host.
 // Seconds per run instead of the minute a Python session costs -- the development loop for kernel variants.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -Igemma_amd/csrc scripts/i8_kernel_bench.hip -o /tmp/i8_kernel_bench
-//   /tmp/i8_kernel_bench [n] [B] [variant]     variant 0 = production kernel, 1 = sparse mask operand (i8gemm_sparse.hip.h)
+//   /tmp/i8_kernel_bench [n] [B] [variant] [gm]    variant 0 = dense mask product, 1 = sparse mask operand (i8gemm_sparse.hip.h),
+//                                                  2 = records + 256 x 128 tiles (i8gemm_sparse2.hip.h)
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -13,6 +14,12 @@
 #define HAVE_SPARSE 1
 #else
 #define HAVE_SPARSE 0
+#endif
+#if __has_include("i8gemm_sparse2.hip.h")
+#include "i8gemm_sparse2.hip.h"
+#define HAVE_SPARSE2 1
+#else
+#define HAVE_SPARSE2 0
 #endif
 
 using namespace gemma_hip;
@@ -59,7 +66,9 @@ int main(int argc, char **argv) {
   const int variant = argc > 3 ? atoi(argv[3]) : 0;
   const int digits = 6, fuse = 1, nplanes = 3;
   const long ldk = (n + I8_BK - 1) / I8_BK * I8_BK, npad = (n + I8_BN - 1) / I8_BN * I8_BN;
-  const long lpad = (B + I8P_BM - 1) / I8P_BM * I8P_BM, mrows = 2 * lpad;
+  const long rowtile = variant == 2 ? 256 : I8P_BM;
+  const long lpad = (B + rowtile - 1) / rowtile * rowtile, mrows = 2 * lpad;
+  const int gm = argc > 4 ? atoi(argv[4]) : 0;
   int8_t *A, *Bt;
   int *C;
   CK(hipMalloc(&A, lpad * ldk));
@@ -76,13 +85,46 @@ int main(int argc, char **argv) {
   g.m_row0 = lpad;
   g.tiles_m = (int)(lpad / I8P_BM); g.tiles_n = (int)(npad / I8_BN);
   g.nk = (int)(ldk / I8_BK);
-  g.gm = 0; g.fuse = fuse; g.digits = digits;
+  g.gm = argc > 4 ? atoi(argv[4]) : 0; g.fuse = fuse; g.digits = digits;
   const dim3 grid((unsigned)(g.tiles_m * g.tiles_n), (unsigned)nplanes);
 #if HAVE_SPARSE
   SparseMeta sm;
   if (variant == 1 && sparse_meta_build(A, lpad, ldk, &sm)) return 1;
 #endif
+#if HAVE_SPARSE2
+  Sparse2Args g2;
+  uint4 *AM = nullptr;
+  int *rsur = nullptr;
+  dim3 grid2;
+  if (variant == 2) {
+    const long total = lpad * (ldk / I8_BK) * 4;
+    CK(hipMalloc(&AM, (size_t)total * sizeof(uint4)));
+    CK(hipMalloc(&rsur, lpad * sizeof(int)));
+    CK(hipMemset(rsur, 0, lpad * sizeof(int)));
+    hipEvent_t m0, m1;
+    CK(hipEventCreate(&m0)); CK(hipEventCreate(&m1));
+    CK(hipEventRecord(m0));
+    hipLaunchKernelGGL(sparse2_meta_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, 0, A, lpad, ldk, AM, rsur);
+    CK(hipEventRecord(m1));
+    CK(hipEventSynchronize(m1));
+    float mms = 0;
+    CK(hipEventElapsedTime(&mms, m0, m1));
+    printf("sparse2_meta_kernel: %.3f ms\n", mms);
+    g2.AM = AM; g2.Bt = Bt; g2.C = C; g2.ldk = ldk; g2.ldc = npad; g2.strideB = npad * ldk; g2.strideC = mrows * npad;
+    g2.m_row0 = lpad; g2.tiles_m = (int)(lpad / S2_BM); g2.tiles_n = (int)(npad / S2_BN); g2.nk = (int)(ldk / I8_BK);
+    g2.gm = gm; g2.fuse = fuse; g2.digits = digits;
+    grid2 = dim3((unsigned)(g2.tiles_m * g2.tiles_n), (unsigned)nplanes);
+    CK(hipFuncSetAttribute(reinterpret_cast<const void *>(i8gemm_sparse2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                           S2_NST * S2_STAGE));
+  }
+#endif
   auto launch = [&]() {
+#if HAVE_SPARSE2
+    if (variant == 2) {
+      hipLaunchKernelGGL(i8gemm_sparse2_kernel, grid2, dim3(512), S2_NST * S2_STAGE, 0, g2);
+      return;
+    }
+#endif
 #if HAVE_SPARSE
     if (variant == 1) {
       hipLaunchKernelGGL(i8gemm_sparse_kernel, grid, dim3(512), 3 * SP_STAGE, 0, g, sm);
@@ -98,6 +140,7 @@ int main(int argc, char **argv) {
                          3 * SP_STAGE));
 #endif
   launch();
+  CK(hipGetLastError());
   CK(hipDeviceSynchronize());
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0));
@@ -123,7 +166,7 @@ int main(int argc, char **argv) {
       int cnt = 0;
       for (int q = 0; q < 4; ++q) {
         const int m = (hrow[k0 + q] >> 4) & 1;
-        mrow[k0 + q] = (int8_t)((variant == 1) ? (m && cnt < 2) : m);
+        mrow[k0 + q] = (int8_t)((variant >= 1) ? (m && cnt < 2) : m);
         cnt += m;
       }
       has_surplus = has_surplus || cnt > 2;

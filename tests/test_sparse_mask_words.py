@@ -56,3 +56,71 @@ def test_mask_words_reproduce_the_mask(miss):
         assert np.array_equal(d, m)                  # kept + dropped = the mask
         assert int(d @ u) == int(m @ u)
         assert all(expand(bits)[k] in (0, 1) for k in range(16))
+
+
+# ---- round 3: the 16-byte records of gemma_amd/csrc/i8gemm_sparse2.hip.h (sparse2_meta_kernel) ------------------------------
+def record(packed_tile_row, p, h):
+    """packed_tile_row: the 128 packed bytes g | m << 4 of one SNP row and one K-tile -> the record of chunk 2 p + h:
+    (genotype word of step 2p, of step 2p+1, index word, kept bits), as sparse2_meta_kernel writes it."""
+    words = []
+    for e in range(2):
+        src = packed_tile_row[32 * (2 * p + e) + 16 * h: 32 * (2 * p + e) + 16 * h + 16]
+        w = 0
+        for i in range(4):
+            for j in range(4):
+                w |= (int(src[4 * i + j]) & 3) << (8 * j + 2 * i)
+        words.append(w)
+    m = [(int(b) >> 4) & 1 for b in packed_tile_row[32 * (2 * p + h): 32 * (2 * p + h) + 32]]
+    idx, bits16, dropped = encode(m)
+    bits = 0
+    for e in range(16):  # kept element e -> bit 8 (e % 4) + e / 4
+        bits |= ((bits16 >> e) & 1) << (8 * (e & 3) + (e >> 2))
+    return words[0], words[1], idx, bits, dropped
+
+
+def unpack_g(w):
+    """s2_unpack_g: operand dword i = (w >> 2 i) & 0x03030303; operand byte 4 i + j = individual 4 i + j of the lane's 16."""
+    out = []
+    for i in range(4):
+        d = (w >> (2 * i)) & 0x03030303
+        out += [(d >> (8 * j)) & 0xFF for j in range(4)]
+    return out
+
+
+def expand2(bits):
+    """s2_expand: operand dword i = (bits >> i) & 0x01010101; byte 4 i + j = kept element 4 i + j."""
+    out = []
+    for i in range(4):
+        d = (bits >> i) & 0x01010101
+        out += [(d >> (8 * j)) & 0xFF for j in range(4)]
+    return out
+
+
+@pytest.mark.parametrize("miss", [0.01, 0.3])
+def test_records_reproduce_genotypes_and_mask(miss):
+    rng = np.random.default_rng(77 + int(100 * miss))
+    for _ in range(60):
+        g = rng.integers(0, 3, size=128)
+        m = (rng.random(128) < miss).astype(np.int64)
+        g[m == 1] = 0
+        row = (g | (m << 4)).astype(np.uint8)
+        u = rng.integers(-128, 128, size=128)
+        for p in range(2):
+            for h in range(2):
+                w0, w1, idx, bits, dropped = record(row, p, h)
+                assert max(w0, w1, idx, bits) < 2 ** 32
+                # lane half h of the dense instruction of K-step 2 p + e holds individuals 32 (2 p + e) + 16 h + 0..15
+                for e, w in ((0, w0), (1, w1)):
+                    k0 = 32 * (2 * p + e) + 16 * h
+                    assert unpack_g(w) == list(g[k0:k0 + 16])
+                # lane half h of the sparse instruction of the pair covers the 32 individuals of K-step 2 p + h
+                k0 = 32 * (2 * p + h)
+                vals = expand2(bits)
+                dense = np.zeros(32, dtype=np.int64)
+                for gq in range(8):
+                    nib = (idx >> (4 * gq)) & 0xF
+                    for e in range(2):
+                        dense[4 * gq + ((nib >> (2 * e)) & 3)] += vals[2 * gq + e]
+                dense[dropped] += 1
+                assert np.array_equal(dense, m[k0:k0 + 32])
+                assert int(dense @ u[k0:k0 + 32]) == int(m[k0:k0 + 32] @ u[k0:k0 + 32])
