@@ -45,6 +45,9 @@ def parse():
     ap.add_argument("--cpu-sample", type=int, default=2048, help="SNPs in the CPU baseline sample (0 = skip)")
     ap.add_argument("--a-mode", type=int, default=1)
     ap.add_argument("--fp64-steps", type=int, default=2, help="extra untimed-region steps through the fp64 GEMM path (0 = skip)")
+    ap.add_argument("--dosage-steps", type=int, default=2,
+                    help="extra untimed-region steps on BIMBAM-style fixed-point dosages (k/100, fp64 input): the int8-digit "
+                         "dosage path, checked against the fp64 GEMM path on the same block (0 = skip)")
     ap.add_argument("--seed", type=int, default=20000)
     ap.add_argument("--state-file", default="",
                     help="measurement aid: keep the setup's result (U, eval, UtW, Uty, null scalars) in this file -- written "
@@ -55,6 +58,14 @@ def parse():
                          "tests/cpp/gemma_file_driver -inproc (first pass, kinship, eigen, -lmm, .assoc.txt), wall seconds "
                          "per stage reported under \"e2e\" (0 = skip)")
     return ap.parse_args()
+
+
+def ctypes_digits(L, n):
+    """base-256 digits of U the int8 product uses at this n (csrc/i8gemm.hip.h: 7, or 6 from n = 16384 up)"""
+    import ctypes
+    dg = ctypes.c_int(7)
+    L.lib().gemma_hip_dbg_i8_digits(n, ctypes.byref(dg))
+    return dg.value
 
 
 def synth_block(torch, n, l, gen, dev, miss=0.01, fst=0.05):
@@ -322,6 +333,51 @@ def main():
                                   "achieved": round(tf, 2), "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                                   "frac": round(tf / FP64_MFMA_PEAK_TFLOPS, 4), "avg_launch_ms": round(g64_s * 1e3, 3)}}
 
+    # fixed-point dosages (BIMBAM mean genotypes, doc/manual.tex:398-404) as fp64 input: int8-digit dosage planes, then the
+    # fp64 MFMA GEMM on the same block as the check; outside the timed region, single GPU only
+    dosage_path = None
+    if world == 1 and i8_path and args.dosage_steps > 0:
+        Xd = [torch.randint(0, 201, (B, n), device=dev, generator=gen, dtype=torch.int32).to(torch.float64).div_(100.0)
+              for _ in range(2)]
+        outd = torch.empty((B, 8), dtype=torch.float64, device=dev)
+        lmm.batch(Xd[0], L.GENO_F64_SNP_MAJOR, out=outd)
+        torch.cuda.synchronize()
+        took = api.last_utx_path()
+        for st in (L.STAGE_UTX_GEMM, L.STAGE_UTX_POST, L.STAGE_INGEST):
+            api.profile_read(st, reset=True)
+        t1 = time.perf_counter()
+        for i in range(args.dosage_steps):
+            lmm.batch(Xd[i % 2], L.GENO_F64_SNP_MAJOR, out=outd)
+        torch.cuda.synchronize()
+        eld = time.perf_counter() - t1
+        gd_ms, gd_n = api.profile_read(L.STAGE_UTX_GEMM)
+        pd_ms, _ = api.profile_read(L.STAGE_UTX_POST)
+        id_ms, _ = api.profile_read(L.STAGE_INGEST)
+        res_i8 = outd.cpu().numpy().copy()
+        os.environ["GEMMA_HIP_UTX_DOSAGE_I8"] = "0"
+        lmm.batch(Xd[(args.dosage_steps - 1) % 2], L.GENO_F64_SNP_MAJOR, out=outd)
+        torch.cuda.synchronize()
+        os.environ.pop("GEMMA_HIP_UTX_DOSAGE_I8")
+        res_64 = outd.cpu().numpy()
+        okm = np.isfinite(res_i8) & np.isfinite(res_64) & (res_64 != 0)
+        cols_used = {1: [0, 1, 4, 7], 2: [5, 7], 3: [0, 1, 6], 4: [0, 1, 4, 5, 6, 7], 9: [0, 1, 5, 6, 7]}[args.a_mode]
+        worst = max(float(np.max(np.abs(res_i8[:, c][okm[:, c]] - res_64[:, c][okm[:, c]]) / np.abs(res_64[:, c][okm[:, c]])))
+                    for c in cols_used)
+        dgd = ctypes_digits(L, n)
+        gd_s = gd_ms * 1e-3 / max(1, args.dosage_steps)
+        dosage_path = {"value": round(B * args.dosage_steps / eld, 1), "unit": "SNPs/s", "steps": args.dosage_steps,
+                       "ms_per_step": round(eld / args.dosage_steps * 1e3, 3),
+                       "input": "fp64 SNP-major rows, every value k/100 in [0, 2], no missing entry (BIMBAM mean genotypes)",
+                       "utx_path": api.UTX_PATHS.get(took, str(took)),
+                       "stage_ms_per_step": {"ingest_and_pack": round(id_ms / args.dosage_steps, 3), "utx_gemm": round(gd_ms / args.dosage_steps, 3),
+                                             "utx_post": round(pd_ms / args.dosage_steps, 3)},
+                       "roofline": {"kernel": "i8gemm_packed_kernel_t<false, true> (one signed byte plane x %d digits of U, dense int8 MFMA)" % dgd,
+                                    "bound": "mfma", "achieved": round(dgd * 2.0 * B * n * n / gd_s / 1e12, 1), "peak": INT8_MFMA_PEAK_TOPS,
+                                    "unit": "TOP/s", "frac": round(dgd * 2.0 * B * n * n / gd_s / 1e12 / INT8_MFMA_PEAK_TOPS, 4),
+                                    "launches_per_step": 1, "ms_per_step": round(gd_s * 1e3, 3)},
+                       "vs_fp64_gemm_path_max_rel_diff": worst}
+        del Xd, outd
+
     if rank == 0:
         total_snps = B * args.steps * world
         value = total_snps / elapsed
@@ -403,6 +459,8 @@ def main():
             "note": "eigendecomposition runs on one GPU (replicas only for that stage); ranks idle during it"}
         if fp64_path:
             line["fp64_gemm_path"] = fp64_path
+        if dosage_path:
+            line["dosage_path"] = dosage_path
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc):
             try:

@@ -22,7 +22,7 @@ SYMBOLS = [
     "gemma_hip_kin_end_keep", "gemma_hip_kept_K_get", "gemma_hip_eigh_kept_K", "gemma_hip_eigh_keep", "gemma_hip_kept_n",
     "gemma_hip_kept_bcast", "gemma_hip_kept_U_get", "gemma_hip_calc_utx_kept", "gemma_hip_lmm_setup_kept", "gemma_hip_kept_release",
     "gemma_hip_comm_unique_id", "gemma_hip_comm_init", "gemma_hip_comm_info", "gemma_hip_comm_bcast_d",
-    "gemma_hip_comm_allreduce_sum_d", "gemma_hip_comm_finalize", "gemma_hip_dbg_i8_digits", "gemma_hip_lmm_batch_submit", "gemma_hip_lmm_batch_collect",
+    "gemma_hip_comm_allreduce_sum_d", "gemma_hip_comm_finalize", "gemma_hip_dbg_i8_digits", "gemma_hip_dbg_last_utx_path", "gemma_hip_lmm_batch_submit", "gemma_hip_lmm_batch_collect",
 ]
 COMM_ID_BYTES = 128
 
@@ -142,6 +142,7 @@ def lib():
     L.gemma_hip_calc_utx_kept.argtypes = [dp, sz, sz, dp]
     L.gemma_hip_lmm_setup_kept.argtypes = [C.POINTER(LmmCfg), dp, dp]
     L.gemma_hip_dbg_i8_digits.argtypes = [sz, C.POINTER(ci)]
+    L.gemma_hip_dbg_last_utx_path.argtypes = [C.POINTER(ci)]
     L.gemma_hip_lmm_batch_submit.argtypes = [ci, vp, sz, sz]
     L.gemma_hip_lmm_batch_collect.argtypes = [vp, C.POINTER(sz)]
     L.gemma_hip_comm_unique_id.argtypes = [vp]

@@ -82,6 +82,16 @@ def profile_read(stage, reset=False):
     return ms.value, n.value
 
 
+UTX_PATHS = {0: "fp64 MFMA GEMM", 1: "int8 digits, hard calls", 2: "int8 digits, dosages k/100", 3: "int8 digits, dosages k/1000"}
+
+
+def last_utx_path():
+    """What the last U^T x (LMM.batch, LMM.dbg_utx) ran on: a key of UTX_PATHS."""
+    p = C.c_int()
+    L.check(L.lib().gemma_hip_dbg_last_utx_path(C.byref(p)), "dbg_last_utx_path")
+    return p.value
+
+
 # ----------------------------------------------------------------------------- B2
 def fast_dgemm(TransA, TransB, alpha, A, B, beta, Cm):
     """C = alpha*op(A)*op(B) + beta*C (row-major).  Shape mismatch -> GemmaHipError(EINVAL), the
@@ -347,7 +357,8 @@ class LMM:
 
     def dbg_utx(self, geno, geno_kind, path):
         """The U^T x stage alone (after setup): (l x n) array, row s = (U^T x_s)^T.  path 0: fp64 MFMA GEMM,
-        path 1: exact int8-digit product (PLINK 2-bit input only)."""
+        path 1: exact int8-digit product where the input allows it (PLINK 2-bit, fp64 hard calls, fixed-point dosages);
+        last_utx_path() says what ran."""
         geno = np.ascontiguousarray(geno)
         l, ld = geno.shape[0], geno.shape[1]
         if geno_kind == L.GENO_F64_IDV_MAJOR:

@@ -102,6 +102,9 @@ struct Ctx {
   size_t mv_d = 0;
   MvArgs mv_proto;
   DevBuf i8_Bt, i8_ej, i8_cmax, i8_A, i8_C, i8_mean; // exact int8-digit U^T x (i8gemm.hip.h)
+  DevBuf i8_colsum;            // column sums of U from its digit planes (fixed-point dosage path)
+  bool i8_colsum_ready = false;
+  int last_utx_path = 0;       // what the last U^T x took: 0 fp64 GEMM, 1 int8 hard calls, 2 int8 dosages k/100, 3 int8 dosages k/1000
   bool i8_ready = false;
   size_t i8_ldk = 0, i8_npad = 0;
   int i8_digits = I8_DIGITS;
@@ -862,6 +865,7 @@ static int lmm_common_setup(const gemma_lmm_cfg *cfg) {
   g_ctx.have_map = false;
   g_ctx.ni_total = 0;
   g_ctx.i8_ready = false; // digits belong to the previous U
+  g_ctx.i8_colsum_ready = false;
   g_ctx.gxe_ready = false;
   g_ctx.mv_ready = false;
   return GEMMA_HIP_OK;
@@ -1475,6 +1479,75 @@ static int utx_plink_i8(const void *geno, size_t l, size_t ld, double *UtX, size
   return i8_product(l, d, UtX, ldx, s);
 }
 
+// Fixed-point dosage rows (i8gemm.hip.h: pack_dosage_kernel): byte planes a0 [, a1] [, mask] x the digits of U on the dense int8
+// kernel, one int32 plane per (byte plane, digit); GEMMA_HIP_UTX_DOSAGE_I8=0 keeps such batches on the fp64 GEMM.
+static bool dosage_i8_enabled() {
+  const char *e = getenv("GEMMA_HIP_UTX_DOSAGE_I8");
+  return !(e && e[0] == '0');
+}
+static int utx_dosage_i8(const double *src, size_t l, size_t ld, bool nan_missing, bool two, bool have_m, const I8Dims &d,
+                         double *UtX, size_t ldx, hipStream_t s) {
+  const int np = (two ? 2 : 1) + (have_m ? 1 : 0);
+  const size_t plane_a = d.lpad * d.ldk, plane_c = d.lpad * d.npad;
+  if (g_ctx.i8_A.reserve((size_t)np * plane_a) || g_ctx.i8_C.reserve((size_t)np * d.digits * plane_c * 4) ||
+      g_ctx.i8_colsum.reserve(d.n * 8))
+    return fail(GEMMA_HIP_ENOMEM, "lmm_batch: dosage planes (%zu bytes)", (size_t)np * (plane_a + d.digits * plane_c * 4));
+  int8_t *A0 = g_ctx.i8_A.as<int8_t>();
+  {
+    ProfScope ps(GEMMA_STAGE_INGEST, s);
+    if (d.lpad != l) HIPCHK(hipMemsetAsync(A0, 0, (size_t)np * plane_a, s)); // padding rows of every plane
+    PackDosageArgs a;
+    a.src = src; a.ld = (long)ld; a.l = (long)l; a.n = (int)d.n; a.nan_missing = nan_missing ? 1 : 0; a.two = two ? 1 : 0;
+    a.A0 = A0; a.A1 = two ? A0 + plane_a : nullptr; a.Am = have_m ? A0 + (size_t)(np - 1) * plane_a : nullptr;
+    a.ldk = (long)d.ldk; a.mean = g_ctx.i8_mean.as<double>();
+    hipLaunchKernelGGL(pack_dosage_kernel, dim3((unsigned)((l + 3) / 4)), dim3(256), 0, s, a);
+    HIPCHK(hipGetLastError());
+    if (!g_ctx.i8_colsum_ready) {
+      hipLaunchKernelGGL(u_digit_colsum_kernel, dim3((unsigned)((d.n + 3) / 4)), dim3(256), 0, s, g_ctx.i8_Bt.as<int8_t>(),
+                         (long)d.ldk, (long)(d.npad * d.ldk), g_ctx.i8_ej.as<int>(), (long)d.n, d.digits,
+                         g_ctx.i8_colsum.as<double>());
+      HIPCHK(hipGetLastError());
+      g_ctx.i8_colsum_ready = true;
+    }
+  }
+  {
+    ProfScope ps(GEMMA_STAGE_UTX_GEMM, s);
+    static bool attr_set = false;
+    if (!attr_set) {
+      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(i8gemm_packed_kernel_t<false, true>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 3 * I8P_STAGE));
+      attr_set = true;
+    }
+    for (int a = 0; a < np; ++a) {
+      I8PackArgs g;
+      g.A = A0 + (size_t)a * plane_a;
+      g.Bt = g_ctx.i8_Bt.as<int8_t>();
+      g.C = g_ctx.i8_C.as<int>() + (size_t)a * d.digits * plane_c;
+      g.ldk = (long)d.ldk; g.ldc = (long)d.npad;
+      g.strideB = (long)(d.npad * d.ldk); g.strideC = (long)plane_c;
+      g.m_row0 = 0;
+      g.tiles_m = (int)(d.lpad / I8P_BM); g.tiles_n = (int)(d.npad / I8_BN);
+      g.nk = (int)(d.ldk / I8_BK);
+      const char *e = getenv("GEMMA_HIP_I8_GM");
+      g.gm = e ? atoi(e) : 0;
+      g.fuse = 0;
+      g.digits = d.digits;
+      hipLaunchKernelGGL((i8gemm_packed_kernel_t<false, true>), dim3((unsigned)(g.tiles_m * g.tiles_n), (unsigned)d.digits),
+                         dim3(512), 3 * I8P_STAGE, s, g);
+      HIPCHK(hipGetLastError());
+    }
+  }
+  {
+    ProfScope ps(GEMMA_STAGE_UTX_POST, s);
+    hipLaunchKernelGGL(i8_combine_dosage_kernel, dim3((unsigned)((d.n + 255) / 256), (unsigned)std::min<size_t>(l, 65535)),
+                       dim3(256), 0, s, g_ctx.i8_C.as<int>(), (long)d.npad, (long)plane_c, g_ctx.i8_mean.as<double>(),
+                       g_ctx.i8_ej.as<int>(), g_ctx.i8_colsum.as<double>(), (long)l, (long)d.n, UtX, (long)ldx, d.digits,
+                       two ? 1 : 0, have_m ? 1 : 0, two ? 1000.0 : 100.0);
+    HIPCHK(hipGetLastError());
+  }
+  return GEMMA_HIP_OK;
+}
+
 // fp64 SNP-major rows (src: l x ld): if every row is a hard-call row (i8gemm.hip.h, pack_f64_kernel) the batch goes
 // through the int8-digit product and *done = true; otherwise nothing is computed and the caller takes the fp64 GEMM.
 // One stream synchronisation per batch (the verdict is read back).
@@ -1485,8 +1558,8 @@ static int utx_f64_try_i8(const double *src, size_t l, size_t ld, bool nan_missi
   int rc = i8_begin(l, &d, s);
   if (rc) return rc;
   if (g_ctx.scratch.reserve(16)) return fail(GEMMA_HIP_ENOMEM, "lmm_batch: scratch");
-  int one = 1;
-  HIPCHK(hipMemcpyAsync(g_ctx.scratch.p, &one, sizeof one, hipMemcpyHostToDevice, s));
+  const int init[4] = {1, 1, 1, 0}; // hard calls, dosages k/1000, dosages k/100, any missing entry
+  HIPCHK(hipMemcpyAsync(g_ctx.scratch.p, init, sizeof init, hipMemcpyHostToDevice, s));
   {
     ProfScope ps(GEMMA_STAGE_INGEST, s);
     PackF64Args a;
@@ -1496,12 +1569,20 @@ static int utx_f64_try_i8(const double *src, size_t l, size_t ld, bool nan_missi
     hipLaunchKernelGGL(pack_f64_kernel, dim3((unsigned)((l + 3) / 4)), dim3(256), 0, s, a);
     HIPCHK(hipGetLastError());
   }
-  int verdict = 0;
-  HIPCHK(hipMemcpyAsync(&verdict, g_ctx.scratch.p, sizeof verdict, hipMemcpyDeviceToHost, s));
+  int verdict[4] = {0, 0, 0, 0};
+  HIPCHK(hipMemcpyAsync(verdict, g_ctx.scratch.p, sizeof verdict, hipMemcpyDeviceToHost, s));
   HIPCHK(hipStreamSynchronize(s));
-  if (!verdict) return GEMMA_HIP_OK;
-  *done = true;
-  return i8_product(l, d, UtX, ldx, s);
+  if (verdict[0]) {
+    *done = true;
+    g_ctx.last_utx_path = 1;
+    return i8_product(l, d, UtX, ldx, s);
+  }
+  if (verdict[1] && dosage_i8_enabled()) { // fixed-point dosages: k/100 on one byte plane, k/1000 on two
+    *done = true;
+    g_ctx.last_utx_path = verdict[2] ? 2 : 3;
+    return utx_dosage_i8(src, l, ld, nan_missing, !verdict[2], verdict[3] != 0, d, UtX, ldx, s);
+  }
+  return GEMMA_HIP_OK;
 }
 
 // U as the right-hand operand of the fp64 GEMM.  With an odd n the caller's U (leading dimension n) would send every tile down
@@ -1529,13 +1610,13 @@ static int compute_utx(int kind, const void *geno, size_t l, size_t ld, int path
   const size_t n = g_ctx.cfg.n;
   const size_t ldx = (n + 1) & ~(size_t)1;
   const bool want_i8 = (path < 0 ? utx_i8_mode() == 1 : path == 1);
-  if (path == 1 && kind != GEMMA_GENO_PLINK_2BIT) return fail(GEMMA_HIP_EINVAL, "dbg_utx: path 1 needs PLINK 2-bit input");
   const bool plink_i8 = want_i8 && kind == GEMMA_GENO_PLINK_2BIT;
   if (g_ctx.UtX.reserve(l * ldx * 8) || (!plink_i8 && g_ctx.X.reserve(l * ldx * 8)))
     return fail(GEMMA_HIP_ENOMEM, "lmm_batch: cannot allocate 2 x %zu bytes", l * ldx * 8);
   double *UtX = g_ctx.UtX.as<double>();
   *UtX_out = UtX;
   *ldx_out = ldx;
+  g_ctx.last_utx_path = plink_i8 ? 1 : 0;
   if (plink_i8) return utx_plink_i8(geno, l, ld, UtX, ldx, s);
   double *X = g_ctx.X.as<double>();
   bool done = false;
@@ -2205,8 +2286,9 @@ extern "C" int gemma_hip_lmm_finish(double *time_UtX_min, double *time_opt_min) 
   g_ctx.cheb_list.release(); g_ctx.cheb_count.release(); g_ctx.cheb_D.release(); g_ctx.cheb_Ck.release();
   g_ctx.cheb_Gk.release(); g_ctx.cheb_Lk.release(); g_ctx.cheb_iv.release(); g_ctx.cheb_dends.release(); g_ctx.cheb_res.release();
   g_ctx.i8_Bt.release(); g_ctx.i8_ej.release(); g_ctx.i8_cmax.release(); g_ctx.i8_A.release(); g_ctx.i8_C.release();
-  g_ctx.i8_mean.release();
+  g_ctx.i8_mean.release(); g_ctx.i8_meta.release(); g_ctx.i8_rowsur.release(); g_ctx.i8_colsum.release();
   g_ctx.i8_ready = false;
+  g_ctx.i8_colsum_ready = false;
   g_ctx.gxe_env.release(); g_ctx.gxe_UtWt.release(); g_ctx.gxe_Z.release(); g_ctx.gxe_UtZ.release();
   g_ctx.mv_Yt.release(); g_ctx.mv_out.release();
   g_ctx.mv_ready = false;
@@ -2566,6 +2648,11 @@ extern "C" int gemma_hip_comm_finalize(void) {
   return GEMMA_HIP_OK;
 }
 
+
+extern "C" int gemma_hip_dbg_last_utx_path(int *path) {
+  if (path) *path = g_ctx.last_utx_path;
+  return GEMMA_HIP_OK;
+}
 
 extern "C" int gemma_hip_dbg_i8_digits(size_t n, int *digits) {
   if (digits) *digits = i8_digits_for(n);

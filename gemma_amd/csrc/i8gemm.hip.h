@@ -69,7 +69,8 @@ constexpr int I8P_STAGE = 49152;
 
 // WITH_M = false: the genotype product alone (kin_i8.hip.h: G^T G needs no mask product) -- the same schedule with the mask
 // MFMAs, their operand masks and their epilogue left out
-template <bool WITH_M>
+// RAW = true (dosage planes, below): the A bytes are signed int8 values used as they are (no genotype mask)
+template <bool WITH_M, bool RAW = false>
 __global__ __launch_bounds__(512, 2) void i8gemm_packed_kernel_t(I8PackArgs g) {
   extern __shared__ __attribute__((aligned(1024))) int8_t i8lds[];
   int tm, tn;
@@ -149,7 +150,7 @@ __global__ __launch_bounds__(512, 2) void i8gemm_packed_kernel_t(I8PackArgs g) {
   } while (0)
 #define I8P_MASK(i, RA, RG, RM)                                                                                   \
   do {                                                                                                            \
-    RG[i] = RA[i] & mask_g;                                                                                       \
+    RG[i] = RAW ? RA[i] : (RA[i] & mask_g);                                                                       \
     if (WITH_M) RM[i] = (RA[i] >> 4) & mask_m;                                                                    \
   } while (0)
 // MFMA q of a K-step: block (i, j) = (q >> 2, (q >> 1) & 1), q & 1: 0 = G, 1 = M
@@ -361,18 +362,37 @@ struct PackF64Args {
   int8_t *A;
   long ldk;
   double *mean;
-  int *all_hard;
+  int *all_hard; // [0] every row is a hard-call row; [1] every row is a fixed-point dosage row with 3 decimals (values k / 1000
+                 // in [0, 2], plus the missing marker: NaN, or with nan_missing = 0 one repeated other value); [2] ... with 2
+                 // decimals (k / 100); [3] set when any row has a missing entry
 };
+// v is k / 1000 for an integer 0 <= k <= 2000 (to the rounding of the decimal-to-double conversion); *q = k
+__device__ __forceinline__ bool dosage_on_grid(double v, int *q) {
+  const double t = v * 1000.0, r = rint(t);
+  *q = (int)r;
+  return fabs(t - r) <= 1e-6 && r >= 0.0 && r <= 2000.0;
+}
 __global__ __launch_bounds__(256) void pack_f64_kernel(PackF64Args g) {
   const int lane = threadIdx.x & 63;
   const long s = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (s >= g.l) return;
   const double *xs = g.src + s * g.ld;
   int8_t *gr = g.A + s * g.ldk;
-  double tot = 0.0, cnt = 0.0, vfirst = 0.0;
-  int n_nan = 0, have = 0, bad = 0;
+  double tot = 0.0, cnt = 0.0, vfirst = 0.0, dfirst = 0.0;
+  int n_nan = 0, have = 0, bad = 0, dhave = 0, dbad = 0, not100 = 0;
   for (int i = lane; i < g.n; i += 64) {
     const double v = xs[i];
+    if (!isnan(v)) { // dosage verdict: on the 1/1000 grid, or the row's one repeated off-grid value (an imputed mean)
+      int q;
+      if (dosage_on_grid(v, &q)) {
+        not100 |= (q % 10) != 0;
+      } else if (!dhave) {
+        dfirst = v;
+        dhave = 1;
+      } else if (v != dfirst) {
+        dbad = 1;
+      }
+    }
     int8_t b;
     if (v == 0.0 || v == 1.0 || v == 2.0) {
       b = (int8_t)(int)v;
@@ -409,9 +429,122 @@ __global__ __launch_bounds__(256) void pack_f64_kernel(PackF64Args g) {
   } else {
     if (any_nan) row_bad = true;
   }
+  // dosage verdict of the row
+  const unsigned long long dv = __ballot(dhave != 0);
+  if (dv) {
+    const double d0 = __shfl(dfirst, __ffsll((long long)dv) - 1, 64);
+    if (dhave && dfirst != d0) dbad = 1;
+  }
+  bool drow_bad = __ballot(dbad != 0) != 0;
+  if (g.nan_missing ? dv != 0 : any_nan) drow_bad = true; // NaN input: no finite off-grid value; imputed input: no NaN
+  const bool drow_not100 = __ballot(not100 != 0) != 0;
+  const bool drow_missing = g.nan_missing ? any_nan : dv != 0;
   if (lane == 0) {
     g.mean[s] = g.nan_missing ? tot / cnt : v0;
     if (row_bad) atomicAnd(g.all_hard, 0);
+    if (drow_bad) atomicAnd(g.all_hard + 1, 0);
+    if (drow_bad || drow_not100) atomicAnd(g.all_hard + 2, 0);
+    if (drow_missing) atomicOr(g.all_hard + 3, 1);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Fixed-point dosages (BIMBAM mean genotypes: "0.98, 0.04, 1.00", doc/manual.tex:398-404) on the int8 pipe.  With scale S = 100
+// or 1000 a dosage is x = 1 + q' / S, q' = round(S x) - S in [-S, S]: ONE signed byte for S = 100, two balanced base-256 bytes
+// for S = 1000 (q' = 256 a1 + a0).  With m the 0/1 mask of missing entries (q' = 0 there) and mean_s the SNP's mean,
+//     (U^T x_s)[j] = ( sum_k q'_sk U[k][j] ) / S  +  sum_k U[k][j]  +  (mean_s - 1) sum_k m_sk U[k][j]:
+// integer left factors again, one dense int8 product per byte plane and digit of U, the column sums of U once per setup
+// (from the same digits).  The products run on i8gemm_packed_kernel_t<false, true>, one int32 plane per digit (|sum| <=
+// 128 * 128 * n does not leave room to fuse two).
+struct PackDosageArgs {
+  const double *src; // l x ld
+  long ld, l;
+  int n;
+  int nan_missing, two; // two: S = 1000 (planes a0, a1), else S = 100 (plane a0)
+  int8_t *A0, *A1, *Am; // l x ldk each; Am may be null when the batch has no missing entry
+  long ldk;
+  double *mean;         // nan_missing: mean of the present entries; else the row's off-grid value (or 1.0 when it has none)
+};
+__global__ __launch_bounds__(256) void pack_dosage_kernel(PackDosageArgs g) {
+  const int lane = threadIdx.x & 63;
+  const long s = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (s >= g.l) return;
+  const double *xs = g.src + s * g.ld;
+  int8_t *r0 = g.A0 + s * g.ldk, *r1 = g.two ? g.A1 + s * g.ldk : nullptr, *rm = g.Am ? g.Am + s * g.ldk : nullptr;
+  double tot = 0.0, cnt = 0.0, other = 1.0;
+  int have = 0;
+  for (int i = lane; i < g.n; i += 64) {
+    const double v = xs[i];
+    int q = 0;
+    const bool present = !isnan(v) && dosage_on_grid(v, &q);
+    int qc = 0, m = 0;
+    if (present) {
+      qc = g.two ? q - 1000 : q / 10 - 100;
+      tot += v;
+      cnt += 1.0;
+    } else {
+      m = 1;
+      if (!isnan(v)) { other = v; have = 1; }
+    }
+    const int a1 = (qc + 128) >> 8; // floor: balanced digits, a0 in [-128, 127]
+    r0[i] = (int8_t)(qc - 256 * a1);
+    if (r1) r1[i] = (int8_t)a1;
+    if (rm) rm[i] = (int8_t)m;
+  }
+  for (long i = g.n + lane; i < g.ldk; i += 64) { // K padding
+    r0[i] = 0;
+    if (r1) r1[i] = 0;
+    if (rm) rm[i] = 0;
+  }
+  tot = wsum(tot);
+  cnt = wsum(cnt);
+  const unsigned long long hv = __ballot(have != 0);
+  if (hv) other = __shfl(other, __ffsll((long long)hv) - 1, 64);
+  if (lane == 0) g.mean[s] = g.nan_missing ? tot / cnt : other;
+}
+
+// colsum[j] = 2^(e_j - scale_bits) * sum_d 256^d sum_k D_d[j][k]: the column sums of U as the digit planes hold it; one
+// wavefront per column
+__global__ __launch_bounds__(256) void u_digit_colsum_kernel(const int8_t *__restrict__ Bt, long ldk, long strideB,
+                                                             const int *__restrict__ ej, long n, int digits,
+                                                             double *__restrict__ colsum) {
+  const int lane = threadIdx.x & 63;
+  const long j = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (j >= n) return;
+  double t = 0.0;
+  for (int d = digits - 1; d >= 0; --d) {
+    const int8_t *row = Bt + (long)d * strideB + j * ldk;
+    int acc = 0;
+    for (long k = lane; k < ldk; k += 64) acc += row[k];
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    t = t * 256.0 + (double)acc;
+  }
+  if (lane == 0) colsum[j] = ldexp(t, ej[j] - i8_scale_bits(digits));
+}
+
+// UtX[s][j] = 2^(e_j - scale_bits) * ( T0 / S + (mean_s - 1) TM ) + colsum[j],  T0 = sum_d 256^d (C0_d + 256 C1_d),
+// TM = sum_d 256^d CM_d; planes: digit d of byte plane a at C + (a * digits + d) * strideC (a = 0: a0, 1: a1 if two, last: mask
+// if have_m)
+__global__ __launch_bounds__(256) void i8_combine_dosage_kernel(const int *__restrict__ C, long ldc, long strideC,
+                                                                const double *__restrict__ mean, const int *__restrict__ ej,
+                                                                const double *__restrict__ colsum, long l, long n,
+                                                                double *__restrict__ UtX, long ldx, int digits, int two,
+                                                                int have_m, double inv_scale_is_S) {
+  const long j = (long)blockIdx.x * 256 + threadIdx.x;
+  if (j >= n) return;
+  const int e = ej[j] - i8_scale_bits(digits);
+  const double cs = colsum[j];
+  const int *Cm = C + (long)((two ? 2 : 1) * digits) * strideC;
+  for (long s = blockIdx.y; s < l; s += gridDim.y) {
+    double t0 = 0.0, t1 = 0.0, tm = 0.0;
+    for (int d = digits - 1; d >= 0; --d) {
+      t0 = t0 * 256.0 + (double)C[(long)d * strideC + s * ldc + j];
+      if (two) t1 = t1 * 256.0 + (double)C[(long)(digits + d) * strideC + s * ldc + j];
+      if (have_m) tm = tm * 256.0 + (double)Cm[(long)d * strideC + s * ldc + j];
+    }
+    double v = (t0 + 256.0 * t1) / inv_scale_is_S;
+    if (have_m) v = fma(mean[s] - 1.0, tm, v);
+    UtX[s * ldx + j] = ldexp(v, e) + cs;
   }
 }
 

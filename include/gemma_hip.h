@@ -310,8 +310,13 @@ int gemma_hip_dbg_stedc(const double *d, const double *e, size_t n, double *w, d
 int gemma_hip_dbg_eigh2(const double *G, size_t n, double *band, double *d, double *e);
 /* the U^T x stage of gemma_hip_lmm_batch alone (after lmm_setup; host pointers): UtX is l x n row-major, row s =
  * (U^T x_s)^T of the mean-imputed SNP s (the column fast_dgemm("T","N",U,Xlarge) produces, GEMMA src/lmm.cpp:1521).
- * path 0: fp64 MFMA GEMM; path 1: exact int8-digit product (PLINK 2-bit input only, see csrc/i8gemm.hip.h) */
+ * path 0: fp64 MFMA GEMM; path 1: exact int8-digit product where the input allows it (PLINK 2-bit; fp64 rows of hard calls;
+ * fp64 rows of fixed-point dosages k/100 or k/1000 -- csrc/i8gemm.hip.h), else the fp64 GEMM */
 int gemma_hip_dbg_utx(int geno_kind, const void *geno, size_t l, size_t ld, int path, double *UtX);
+/* what the last U^T x (lmm_batch*, dbg_utx) ran on: 0 fp64 MFMA GEMM (src/lmm.cpp:1521 as one fp64 product), 1 int8-digit
+ * product of hard calls, 2 / 3 int8-digit product of fixed-point dosages k/100 / k/1000 (BIMBAM mean genotypes,
+ * doc/manual.tex:398-404) */
+int gemma_hip_dbg_last_utx_path(int *path);
 /* base-256 digits of U the exact int8 product uses at this n (7; 6 from n = 16384 up; GEMMA_HIP_I8_DIGITS overrides) */
 int gemma_hip_dbg_i8_digits(size_t n, int *digits);
 

@@ -5,6 +5,8 @@ Tolerances (BASELINE.json north_star / SURVEY.md section 8c, App. A.5):
   lambda                  : <= 1e-6 relative on >= 98 % of SNPs, <= 1e-3 on all (see _cmp_stats)
   K, centred K, GEMM      : <= 1e-12 relative (Frobenius / max-abs scaled)
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -856,3 +858,78 @@ def test_lmm_medium_size_device_path(gpu_api, oracle):
     ref = oracle.lmm_analyze(1, U, ev, UtW, Uty, X[sample])
     _cmp_stats(got[sample], ref, 1, "n=2000")
     assert np.isfinite(got["p_wald"]).all()
+
+
+# ---- round 3: fixed-point dosages (BIMBAM mean genotypes, doc/manual.tex:398-404) on the int8-digit pipe -------------------
+def _dosage_case(rng, n, p, decimals, miss):
+    S = 10 ** decimals
+    X = rng.integers(0, 2 * S + 1, size=(p, n)).astype(np.float64) / S  # what atof() makes of "0.98"
+    X[:3] = rng.integers(0, 3, size=(3, n))                               # hard-call rows inside a dosage batch
+    if miss > 0:
+        X[rng.random(X.shape) < miss] = np.nan
+        X[5, : n * 9 // 10] = np.nan                                      # a SNP missing for 90 % of the individuals
+        X[6] = np.where(np.isnan(X[6]), 1.0, X[6])                        # and one missing nowhere
+    return X
+
+
+@pytest.mark.parametrize("decimals,miss,want", [(2, 0.02, 2), (2, 0.0, 2), (3, 0.02, 3), (3, 0.0, 3)])
+def test_utx_int8_dosage_product_is_exact(gpu_api, oracle, decimals, miss, want):
+    """csrc/i8gemm.hip.h (pack_dosage_kernel): dosages k/100 (one signed byte plane) and k/1000 (two balanced base-256 planes)
+    times the digits of U, the missing-entry mask as one more plane, the column sums of U from the digits; against a long-double
+    product of the mean-imputed rows, in units of sum |x||u| -- the bar of the hard-call product -- and against the fp64 GEMM."""
+    from gemma_amd import _lib as L
+    rng = np.random.default_rng(31 + 7 * decimals + int(100 * miss))
+    n, p = 645, 300
+    X = _dosage_case(rng, n, p, decimals, miss)
+    Q, _ = np.linalg.qr(rng.standard_normal((n, n)))
+    Q[:, 0] = 1.0 / np.sqrt(n)  # a column with a large sum, as the kinship's constant eigenvector
+    ev = np.sort(rng.uniform(0.0, 3.0, n))
+    lmm = gpu_api.LMM(a_mode=1)
+    lmm.setup(Q, ev, Q.T @ np.ones((n, 1)), Q.T @ rng.standard_normal(n))
+    try:
+        b = lmm.dbg_utx(X, L.GENO_F64_SNP_MAJOR, 1)
+        assert gpu_api.last_utx_path() == want, gpu_api.UTX_PATHS[gpu_api.last_utx_path()]
+        a = lmm.dbg_utx(X, L.GENO_F64_SNP_MAJOR, 0)
+        assert gpu_api.last_utx_path() == 0
+        # the reference's own layout: individuals x SNPs, already mean-imputed (src/lmm.cpp:1590-1618)
+        Xi = oracle.impute_mean(X)
+        c = lmm.dbg_utx(np.ascontiguousarray(Xi.T), L.GENO_F64_IDV_MAJOR, 1)
+        assert gpu_api.last_utx_path() in (want, 3)  # an imputed mean may itself need the finer grid: still the int8 pipe
+        # one value off both grids: the batch belongs to the fp64 GEMM
+        Xo = X.copy()
+        Xo[11, 17] = 0.123456
+        lmm.dbg_utx(Xo, L.GENO_F64_SNP_MAJOR, 1)
+        assert gpu_api.last_utx_path() == 0
+    finally:
+        lmm.finish()
+    exact = (Xi.astype(np.longdouble) @ Q.astype(np.longdouble)).astype(np.float64)
+    scale = np.maximum(np.abs(Xi) @ np.abs(Q), 1e-300)
+    e8, e8t, e64 = (np.max(np.abs(v - exact) / scale) for v in (b, c, a))
+    print("dosage U^T x (%d decimals, miss %.2f): int8-digit %.2e, from the imputed layout %.2e, fp64 GEMM %.2e (units of sum|x||u|)"
+          % (decimals, miss, e8, e8t, e64))
+    assert e64 < 64 * 2.3e-16
+    assert e8 < 8 * 2.3e-16 and e8t < 8 * 2.3e-16
+
+
+def test_lmm_bimbam_dosages_match_the_oracle(gpu_api, oracle):
+    """-lmm 4 on a BIMBAM mean-genotype block (two decimals, NA entries) through the int8-digit dosage path and through the fp64
+    GEMM (GEMMA_HIP_UTX_DOSAGE_I8=0) against the oracle's LMM::Analyze restatement."""
+    rng = np.random.default_rng(2031)
+    n, p = 520, 260
+    X = _dosage_case(rng, n, p, 2, 0.03)
+    Kx = oracle.impute_mean(_dosage_case(rng, n, 900, 2, 0.0))
+    U, ev, _ = oracle.eigen_decomp_zeroed(oracle.center_matrix(oracle.calc_kin(Kx, 1)))
+    W = np.column_stack([np.ones(n), rng.standard_normal(n)])
+    y = rng.standard_normal(n) + 0.5 * np.nan_to_num(X[10] - 1.0) - 0.4 * np.nan_to_num(X[40] - 1.0)
+    UtW, Uty = U.T @ W, U.T @ y
+    ref = oracle.lmm_analyze(4, U, ev, UtW, Uty, X)
+    outs = {}
+    for mode in ("1", "0"):
+        os.environ["GEMMA_HIP_UTX_DOSAGE_I8"] = mode
+        try:
+            outs[mode] = gpu_api.LMM(a_mode=4).AnalyzeBimbam(U, ev, UtW, Uty, X)
+            assert gpu_api.last_utx_path() == (2 if mode == "1" else 0)
+        finally:
+            os.environ.pop("GEMMA_HIP_UTX_DOSAGE_I8", None)
+    for mode, got in outs.items():
+        _cmp_stats(got, ref, 4, "bimbam dosage k/100 DOSAGE_I8=%s" % mode)
