@@ -42,12 +42,34 @@ def parse():
     ap.add_argument("--batch", type=int, default=20000, help="SNPs per step and per rank")
     ap.add_argument("--kin-snps", type=int, default=100000, help="SNPs used for the kinship matrix (setup; SURVEY 8d: >= 100 000)")
     ap.add_argument("--eigen", default="auto", choices=["auto", "gemma", "torch"])
-    ap.add_argument("--cpu-sample", type=int, default=2048, help="SNPs in the CPU baseline sample (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=2560, help="SNPs in the CPU baseline sample (0 = skip)")
     ap.add_argument("--a-mode", type=int, default=1)
     ap.add_argument("--fp64-steps", type=int, default=2, help="extra untimed-region steps through the fp64 GEMM path (0 = skip)")
     ap.add_argument("--dosage-steps", type=int, default=2,
                     help="extra untimed-region steps on BIMBAM-style fixed-point dosages (k/100, fp64 input): the int8-digit "
                          "dosage path, checked against the fp64 GEMM path on the same block (0 = skip)")
+    ap.add_argument("--miss", type=float, default=0.01, help="missing-call rate of the synthetic PLINK blocks (timed region)")
+    ap.add_argument("--miss-leg", type=float, default=0.05,
+                    help="extra untimed-region steps at this missing-call rate (GEMMA's default -miss ceiling is 0.05): every row then "
+                         "has groups of four with 3-4 missing calls, which the sparse mask operand hands to the fp64 fix-up (0 = skip)")
+    ap.add_argument("--lowh2-leg", type=float, default=3e-4,
+                    help="extra untimed-region steps on a second phenotype whose variance ratio lambda is this value (next to no "
+                         "heritability: lambda-hat in the decades below 1e-3, the common case in human GWAS) -- the per-SNP stage must "
+                         "not fall off the table path there (0 = skip)")
+    ap.add_argument("--ref-procs", type=int, default=8,
+                    help="independent processes of the reference's LMM::Analyze in the cpu_baseline leg (each on its own slice of the "
+                         "last timed block; 1 = one in-process call as in rounds 1-2)")
+    ap.add_argument("--cpu-setup", type=int, default=1,
+                    help="1: also time the reference's setup stages on the host cores -- EigenDecomp_Zeroed (dsyevr) at this n and "
+                         "PlinkKin on one batch -- in a child process beside the GPU legs, reported as cpu_baseline.setup (0 = skip)")
+    ap.add_argument("--cpu-setup-n", type=int, default=8192,
+                    help="order of the leading principal block of the centred kinship the host eigendecomposition runs on (0 = this "
+                         "run's n: 334 s at n = 20000 on the GPU box, profiles/r03_cpu_setup_baseline.json, which is why the default "
+                         "run measures a block and cites the full-n measurement)")
+    ap.add_argument("--cpu-setup-budget", type=float, default=600.0,
+                    help="seconds after which the host eigendecomposition is abandoned and reported as unfinished")
+    ap.add_argument("--child", default="", help=argparse.SUPPRESS)
+    ap.add_argument("--child-spec", default="", help=argparse.SUPPRESS)
     ap.add_argument("--seed", type=int, default=20000)
     ap.add_argument("--state-file", default="",
                     help="measurement aid: keep the setup's result (U, eval, UtW, Uty, null scalars) in this file -- written "
@@ -94,6 +116,48 @@ def synth_block(torch, n, l, gen, dev, miss=0.01, fst=0.05):
     return packed.contiguous()
 
 
+def run_child(args):
+    """Helper processes of the CPU legs (no torch, no GPU): `ref_lmm` = the reference's LMM::Analyze on one slice of SNP rows;
+    `ref_setup` = the reference's PlinkKin on one .bed batch and its EigenDecomp_Zeroed on the centred kinship."""
+    import numpy as np
+    from oracle import oracle as O
+    spec = json.load(open(args.child_spec))
+    if args.child == "ref_lmm":
+        U = np.load(spec["U"], mmap_mode="r")
+        ev, UtW, Uty, X = (np.load(spec[k]) for k in ("ev", "UtW", "Uty", "X"))
+        t0 = time.perf_counter()
+        r = O.ref_lmm_analyze(spec["a_mode"], U, ev, UtW, Uty, X, l_mle_null=spec["l_mle_null"], logl_mle_H0=spec["logl_mle_H0"])
+        dt = time.perf_counter() - t0
+        np.save(spec["out"], np.stack([r[k] for k in r.dtype.names], axis=1))
+        json.dump({"seconds": dt, "snps": int(X.shape[0]), "threads": O.ref_blas_threads()}, open(spec["out"] + ".json", "w"))
+    elif args.child == "ref_setup":
+        res = {"threads": O.ref_blas_threads()}
+        n = spec["n"]
+        if spec.get("bed"):
+            t0 = time.perf_counter()
+            K = O.ref_plink_kin(spec["bed"], n, spec["bed_snps"], 1)
+            res["plink_kin"] = {"seconds": round(time.perf_counter() - t0, 2), "snps": spec["bed_snps"],
+                                "checksum": float(np.abs(K).sum())}
+            json.dump(res, open(spec["out"], "w"))
+            del K
+        G = np.load(spec["G"])
+        t0 = time.perf_counter()
+        U, ev, tr = O.ref_eigen_decomp_zeroed(G)
+        res["eigen"] = {"seconds": round(time.perf_counter() - t0, 2), "n": n, "n_block": int(G.shape[0]), "eval_sum": float(ev.sum()),
+                        "eval_max": float(ev.max())}
+        json.dump(res, open(spec["out"], "w"))
+    else:
+        raise SystemExit("unknown --child " + args.child)
+
+
+def shm_dir():
+    import tempfile
+    for d in ("/dev/shm", "/tmp"):
+        if os.path.isdir(d) and os.access(d, os.W_OK):
+            return tempfile.mkdtemp(prefix="gemma_bench_", dir=d)
+    return tempfile.mkdtemp(prefix="gemma_bench_")
+
+
 def self_launch(args):
     """`python bench.py --gpus N` with no torch.distributed environment: launch the N ranks ourselves, exactly the way the
     driver does (one process per GPU under torch.distributed.run, rendezvous on 127.0.0.1), and pass rank 0's JSON line
@@ -113,6 +177,8 @@ def self_launch(args):
 
 def main():
     args = parse()
+    if args.child:
+        return run_child(args)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args))
     import numpy as np
@@ -149,12 +215,14 @@ def main():
     gen = torch.Generator(device=dev).manual_seed(args.seed + 1000 * rank)
 
     # ------------------------------------------------------------------ setup (untimed)
+    t_bench0 = time.time()
     t_setup = time.time()
     U = torch.empty((n, n), dtype=torch.float64, device=dev)
     ev = torch.empty(n, dtype=torch.float64, device=dev)
     UtW = torch.empty((n, 1), dtype=torch.float64, device=dev)
     Uty = torch.empty(n, dtype=torch.float64, device=dev)
     setup_info = {}
+    cpu_setup = None
     null = torch.zeros(2, dtype=torch.float64, device=dev)
     loaded = False
     if rank == 0 and args.state_file and os.path.exists(args.state_file):
@@ -215,6 +283,10 @@ def main():
                 "launches": kin_n, "flops": "executed (upper-triangle tiles); GEMM-form 2 n^2 p in kinship_gemm_tflops"}
         y += torch.randn(n, dtype=torch.float64, device=dev, generator=gen) * y.std().clamp_min(1e-3)
         api.CenterMatrix(K)
+        # the reference's setup stages on the host cores, in a child process beside everything the GPU does from here on
+        # (dsyevr at this n "measured once and reported separately", the reference's -gk beside the GPU kinship)
+        if world == 1 and args.cpu_setup and args.cpu_sample > 0:
+            cpu_setup = start_cpu_setup(args, np, torch, K, n, B, dev)
         t0 = time.time()
         eig = args.eigen
         if eig in ("auto", "gemma"):
@@ -273,7 +345,7 @@ def main():
     setup_info["broadcast_s"] = round(time.time() - t0, 3)
     setup_info["broadcast"] = bpath
 
-    blocks = [synth_block(torch, n, B, gen, dev) for _ in range(args.steps + args.warmup)]
+    blocks = [synth_block(torch, n, B, gen, dev, miss=args.miss) for _ in range(args.steps + args.warmup)]
     out = torch.empty((B, 8), dtype=torch.float64, device=dev)
     lmm = api.LMM(a_mode=args.a_mode, l_mle_null=float(null[0]), logl_mle_H0=float(null[1]))
     lmm.setup(U, ev, UtW, Uty, plink=True)
@@ -332,6 +404,29 @@ def main():
                      "roofline": {"kernel": "dgemm_mfma_glds_kernel (UtX = X*U, fp64)", "bound": "mfma",
                                   "achieved": round(tf, 2), "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                                   "frac": round(tf / FP64_MFMA_PEAK_TFLOPS, 4), "avg_launch_ms": round(g64_s * 1e3, 3)}}
+
+    # the same step at GEMMA's default missingness ceiling (-miss 0.05): ~2.4 over-full groups of four per row, every row goes
+    # through i8_surplus_fix_kernel; outside the timed region, single GPU only
+    miss_leg = None
+    if world == 1 and i8_path and args.miss_leg > 0:
+        mb = [synth_block(torch, n, B, gen, dev, miss=args.miss_leg) for _ in range(2)]
+        lmm.batch(mb[0], L.GENO_PLINK_2BIT, out=out)
+        torch.cuda.synchronize()
+        for st in range(L.STAGE_UTX_POST + 1):
+            api.profile_read(st, reset=True)
+        t1 = time.perf_counter()
+        for i in range(2):
+            lmm.batch(mb[i], L.GENO_PLINK_2BIT, out=out)
+        torch.cuda.synchronize()
+        elm = time.perf_counter() - t1
+        miss_leg = {"miss": args.miss_leg, "steps": 2, "ms_per_step": round(elm / 2 * 1e3, 3), "value": round(B * 2 / elm, 1), "unit": "SNPs/s",
+                    "ratio_to_timed_step": round(elm / 2 / (elapsed / args.steps), 4),
+                    "stage_ms_per_step": {"ingest": round(api.profile_read(L.STAGE_INGEST)[0] / 2, 3),
+                                          "utx_gemm": round(api.profile_read(L.STAGE_UTX_GEMM)[0] / 2, 3),
+                                          "utx_post (digit combine + fp64 fix-up of the dropped calls)": round(api.profile_read(L.STAGE_UTX_POST)[0] / 2, 3),
+                                          "assoc": round(api.profile_read(L.STAGE_ASSOC)[0] / 2, 3)},
+                    "nan_p_wald": int(np.isnan(out.cpu().numpy()[:, 4]).sum())}
+        del mb
 
     # fixed-point dosages (BIMBAM mean genotypes, doc/manual.tex:398-404) as fp64 input: int8-digit dosage planes, then the
     # fp64 MFMA GEMM on the same block as the check; outside the timed region, single GPU only
@@ -427,8 +522,8 @@ def main():
             "dtype": "f64 (U^T x as exact int8-digit MFMA products, int32 accumulate)" if i8_path else "f64",
             "data": "synthetic",
             "config": {"workload": "%ssynthetic n=%d, -lmm %d, %d SNPs per step per GPU (PLINK 2-bit, "
-                                   "1%% missing, Balding-Nichols Fst 0.05), c=1" % (
-                                       "configs[2] (headline): " if (n == 20000 and args.a_mode == 1) else "", n, args.a_mode, B),
+                                   "%g%% missing, Balding-Nichols Fst 0.05), c=1" % (
+                                       "configs[2] (headline): " if (n == 20000 and args.a_mode == 1) else "", n, args.a_mode, B, 100.0 * args.miss),
                        "n": n, "snps_per_step": B, "kinship_snps": args.kin_snps, "parallelism": "snp-shard x%d" % world,
                        "device": name, "cus": n_cu, "utx_path": "int8-digit" if i8_path else "fp64-gemm",
                        "setup": setup_info, "nan_p_wald": n_nan},
@@ -461,6 +556,8 @@ def main():
             line["fp64_gemm_path"] = fp64_path
         if dosage_path:
             line["dosage_path"] = dosage_path
+        if miss_leg:
+            line["miss_leg"] = miss_leg
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc):
             try:
@@ -479,10 +576,52 @@ def main():
                         fp64_path["roofline"]["traffic"] = pj.get("utx_gemm_hbm_bytes_per_launch")
             except Exception:
                 pass
+        if cpu_setup is not None:
+            setup_cpu = finish_cpu_setup(args, cpu_setup, t_bench0, setup_info)
         if world == 1 and args.cpu_sample > 0:
             line["cpu_baseline"] = cpu_baseline(args, np, torch, blocks[args.warmup + args.steps - 1], U, ev, UtW, Uty, res, n, B,
                                                 null=(float(null[0]), float(null[1])))
+        if cpu_setup is not None and "cpu_baseline" in line:
+            line["cpu_baseline"]["setup"] = setup_cpu
         lmm.finish()
+        if world == 1 and i8_path and args.lowh2_leg > 0 and args.a_mode in (1, 4):
+            # The same trait on a kinship measured in other units: eigenvalues times S moves every lambda-hat to lambda-hat / S
+            # (only lambda * delta enters the likelihood), so with S = lambda_null / lambda0 the brackets of the whole block sit
+            # in the decades below 1e-3 -- where a trait with next to no heritability puts them on a kinship with large eigenvalues.
+            l0 = float(setup_info.get("null", {}).get("l_remle_null", 1.0)) if not loaded else 1.0
+            S = max(1.0, l0 / args.lowh2_leg)
+            # (One random covariate instead of the intercept: U^T 1 lies in the null space of the centred kinship, and with the
+            # eigenvalues times 1e4 the REFERENCE's own REML Newton iteration fails on that structure -- NaN in the oracle too.)
+            ev2 = (ev * S).contiguous()
+            Uty2 = Uty
+            UtW2 = torch.randn((n, 1), dtype=torch.float64, device=dev, generator=gen)
+            nm2 = api.CalcLambdaNull(ev2.cpu().numpy(), UtW2.cpu().numpy(), Uty2.cpu().numpy(), trace_G=float(ev2.mean()))
+            lmm2 = api.LMM(a_mode=args.a_mode, l_mle_null=nm2["l_mle_null"], logl_mle_H0=nm2["logl_mle_H0"])
+            lmm2.setup(U, ev2, UtW2, Uty2, plink=True)
+            out2 = torch.empty((B, 8), dtype=torch.float64, device=dev)
+            legs = {}
+            for low in ("1", "0"):  # tables below 1e-3 in Q form (default) / streaming below 1e-3 (round 2)
+                os.environ["GEMMA_HIP_CHEB_LOWLAMBDA"] = low
+                if low == "0":
+                    lmm2.finish()
+                    lmm2.setup(U, ev2, UtW2, Uty2, plink=True)
+                lmm2.batch(blocks[0], L.GENO_PLINK_2BIT, out=out2)
+                torch.cuda.synchronize()
+                api.profile_read(L.STAGE_ASSOC, reset=True)
+                t1 = time.perf_counter()
+                for i in range(2):
+                    lmm2.batch(blocks[i % len(blocks)], L.GENO_PLINK_2BIT, out=out2)
+                torch.cuda.synchronize()
+                el2 = time.perf_counter() - t1
+                legs[low] = {"ms_per_step": round(el2 / 2 * 1e3, 3), "assoc_ms_per_step": round(api.profile_read(L.STAGE_ASSOC)[0] / 2, 3),
+                             "lambda_remle_median": float(np.nanmedian(out2.cpu().numpy()[:, 2])) if np.isfinite(out2.cpu().numpy()[:, 2]).any() else None,
+                             "nan_p_wald": int(np.isnan(out2.cpu().numpy()[:, 4]).sum())}
+            os.environ.pop("GEMMA_HIP_CHEB_LOWLAMBDA", None)
+            lmm2.finish()
+            line["lowh2_leg"] = {"lambda0": args.lowh2_leg, "eigenvalue_scale": S, "l_remle_null": nm2["l_remle_null"], "steps": 2,
+                                 "tables_in_Q_form_below_1e-3": legs["1"], "streaming_below_1e-3 (round 2)": legs["0"],
+                                 "assoc_ratio_to_timed_region": round(legs["1"]["assoc_ms_per_step"] / max(1e-9, assoc_ms / max(1, args.steps)), 3)}
+            del out2
         if world == 1 and args.e2e_snps > 0:
             del blocks, out, U
             torch.cuda.empty_cache()
@@ -492,6 +631,90 @@ def main():
         lmm.finish()
     if world > 1:
         dist.destroy_process_group()
+
+
+def start_cpu_setup(args, np, torch, Kc, n, B, dev):
+    """Lay out the inputs of `bench.py --child ref_setup` while the kinship is at hand: one synthetic .bed batch of B SNPs for the
+    reference's PlinkKin (src/gemma_io.cpp:1599-1738) and the centred kinship of this run (its leading --cpu-setup-n block) for
+    its EigenDecomp_Zeroed (src/lapack.cpp:260-291, dsyevr).  The child itself runs AFTER every GPU leg (finish_cpu_setup): 64
+    spinning BLAS threads beside the timed region cost it 4 % in an early version of this leg."""
+    import subprocess
+    from oracle import oracle as O
+    if O.ref_lib() is None:
+        return None
+    try:
+        d = shm_dir()
+        ne = n if args.cpu_setup_n <= 0 else min(n, args.cpu_setup_n)
+        np.save(os.path.join(d, "G.npy"), Kc[:ne, :ne].contiguous().cpu().numpy())
+        g2 = torch.Generator(device=dev).manual_seed(args.seed + 777)
+        st = torch.random.get_rng_state()
+        dst = torch.cuda.get_rng_state(dev)
+        blk = synth_block(torch, n, B, g2, dev)
+        torch.random.set_rng_state(st)  # synth_block draws its Beta variates from the global generators: leave them as they were
+        torch.cuda.set_rng_state(dst, dev)
+        bed = os.path.join(d, "batch.bed")
+        with open(bed, "wb") as f:
+            f.write(bytes([0x6C, 0x1B, 0x01]))
+            f.write(blk.cpu().numpy().tobytes())
+        del blk
+        spec = {"n": n, "G": os.path.join(d, "G.npy"), "bed": bed, "bed_snps": B, "out": os.path.join(d, "setup.json")}
+        json.dump(spec, open(os.path.join(d, "spec.json"), "w"))
+        env = dict(os.environ)
+        env.pop("RANK", None); env.pop("WORLD_SIZE", None)
+        return {"dir": d, "out": spec["out"], "spec": os.path.join(d, "spec.json"), "env": env, "n_eig": ne}
+    except Exception as e:  # a reported baseline must never take the bench down
+        return {"error": repr(e)[:300]}
+
+
+def finish_cpu_setup(args, cs, t_bench0, setup_info):
+    """Wait for the child (bounded), read what it measured, and put the GPU's figures of the same stages beside it."""
+    import shutil
+    import subprocess
+    if "error" in cs:
+        return cs
+    cs["t0"] = time.time()
+    pr = subprocess.Popen([sys.executable, os.path.abspath(__file__), "--child", "ref_setup", "--child-spec", cs["spec"]],
+                          env=cs["env"], stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
+    try:
+        pr.wait(timeout=args.cpu_setup_budget)
+        finished = True
+    except Exception:
+        pr.kill()
+        finished = False
+    res = {}
+    try:
+        res = json.load(open(cs["out"]))
+    except Exception:
+        pass
+    out = {"kind": "reference", "where": "child process beside the GPU legs, host cores of this box",
+           "threads": res.get("threads"), "never_in_value": True}
+    if "plink_kin" in res:
+        pk = res["plink_kin"]
+        out["plink_kin"] = {"seconds_per_batch": pk["seconds"], "snps": pk["snps"],
+                            "what": "the reference's PlinkKin (src/gemma_io.cpp:1599-1738) on one .bed batch: per-SNP decode / impute / "
+                                    "centre + cblas_dgemm(Xlarge Xlarge^T)",
+                            "gpu_seconds_per_batch": round(setup_info.get("kinship_s", 0.0) / max(1, (args.kin_snps + pk["snps"] - 1) // pk["snps"]), 4)}
+    if "eigen" in res:
+        ne = cs["n_eig"]
+        out["eigen"] = {"seconds": res["eigen"]["seconds"], "n": ne,
+                        "what": "the reference's EigenDecomp_Zeroed (src/lapack.cpp:260-291 -> dsyevr_) on the leading %d x %d block of this "
+                                "run's centred kinship" % (ne, ne),
+                        "gpu_seconds_at_bench_n": setup_info.get("eigen_s"), "bench_n": res["eigen"]["n"], "eval_sum": res["eigen"]["eval_sum"]}
+        full = os.path.join(ROOT, "profiles", "r03_cpu_setup_baseline.json")
+        if ne != res["eigen"]["n"] and os.path.exists(full):
+            try:
+                fj = json.load(open(full))
+                if fj.get("eigen", {}).get("n") == res["eigen"]["n"]:
+                    out["eigen"]["measured_once_at_bench_n"] = dict(fj["eigen"], source="profiles/r03_cpu_setup_baseline.json")
+            except Exception:
+                pass
+    elif not finished:
+        out["eigen"] = {"unfinished_after_s": round(time.time() - cs["t0"], 1), "n": None,
+                        "what": "the reference's EigenDecomp_Zeroed (dsyevr_) did not finish inside --cpu-setup-budget"}
+    else:
+        out["error"] = (pr.stderr.read().decode(errors="replace")[-300:] if pr.stderr else "no result")
+    shutil.rmtree(cs["dir"], ignore_errors=True)
+    return out
 
 
 def e2e_files(args, n):
@@ -587,22 +810,70 @@ def cpu_baseline(args, np, torch, block, U, ev, UtW, Uty, gpu_res, n, B, null=(0
             "host_threads": cores, "gpu_vs_oracle_max_rel_err": worst_err(ref), "gpu_vs_oracle_lambda": lambda_err(ref)}
     if O.ref_lib() is None:
         return port
-    # the reference's loop costs ~60 ms per SNP at n = 20 000 (13x the oracle's: heap allocations and strided Uab columns
-    # in every likelihood evaluation), so its sample is cut to keep this leg at ~20 s
-    S_port, S = S, min(S, max(64, int(320 * (20000.0 / n) ** 2)))
-    try:
-        t3 = time.perf_counter()
-        rr = O.ref_lmm_analyze(args.a_mode, Uh, evh, UtWh, Utyh, X[:S], l_mle_null=null[0], logl_mle_H0=null[1])
-        t4 = time.perf_counter()
-    except Exception as e:  # the checker must never take the bench down
-        port["reference_error"] = repr(e)[:200]
-        return port
+    # the reference's loop costs ~45-60 ms per SNP at n = 20 000 (13x the oracle's: heap allocations and strided Uab columns in
+    # every likelihood evaluation), so ONE call is cut to ~15-20 s; --ref-procs independent processes, each the reference's own
+    # LMM::Analyze on its own slice, run side by side (the host has the cores) so that the parity sample is >= 2000 SNPs
+    S_port = S
+    S1 = min(S, max(64, int(320 * (20000.0 / n) ** 2)))
+    P = max(1, min(args.ref_procs, S // S1))
     threads = O.ref_blas_threads()
-    return {"value": round(S / (t4 - t3), 2), "unit": "SNPs/s", "cores": threads, "kind": "reference",
+    try:
+        if P == 1:
+            t3 = time.perf_counter()
+            rr = O.ref_lmm_analyze(args.a_mode, Uh, evh, UtWh, Utyh, X[:S1], l_mle_null=null[0], logl_mle_H0=null[1])
+            wall = time.perf_counter() - t3
+            per_proc = [wall]
+        else:
+            import shutil
+            import subprocess
+            d = shm_dir()
+            try:
+                for k, v in (("U", Uh), ("ev", evh), ("UtW", UtWh), ("Uty", Utyh)):
+                    np.save(os.path.join(d, k + ".npy"), v)
+                procs = []
+                env = dict(os.environ)
+                # few BLAS threads per process: the loop is serial, its per-SNP vector calls wake the whole pool each time, and 8 x 32
+                # spinning threads on a 256-thread host made one process 20 x slower than alone (277 s for 320 SNPs)
+                env["OPENBLAS_NUM_THREADS"] = str(max(1, min(threads, 8, cores // (2 * P))))
+                t3 = time.perf_counter()
+                for i in range(P):
+                    np.save(os.path.join(d, "X%d.npy" % i), X[i * S1:(i + 1) * S1])
+                    spec = {"U": os.path.join(d, "U.npy"), "ev": os.path.join(d, "ev.npy"), "UtW": os.path.join(d, "UtW.npy"),
+                            "Uty": os.path.join(d, "Uty.npy"), "X": os.path.join(d, "X%d.npy" % i), "a_mode": args.a_mode,
+                            "l_mle_null": null[0], "logl_mle_H0": null[1], "out": os.path.join(d, "out%d.npy" % i)}
+                    json.dump(spec, open(os.path.join(d, "spec%d.json" % i), "w"))
+                    procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), "--child", "ref_lmm", "--child-spec",
+                                                   os.path.join(d, "spec%d.json" % i)], env=env, stdout=subprocess.DEVNULL,
+                                                  stderr=subprocess.PIPE))
+                try:
+                    for pr in procs:
+                        if pr.wait(timeout=max(5.0, 150.0 - (time.perf_counter() - t3))) != 0:
+                            raise RuntimeError("reference child failed: " + pr.stderr.read().decode(errors="replace")[-200:])
+                finally:
+                    for pr in procs:
+                        if pr.poll() is None:
+                            pr.kill()
+                wall = time.perf_counter() - t3
+                outs = [np.load(os.path.join(d, "out%d.npy" % i)) for i in range(P)]
+                per_proc = [json.load(open(os.path.join(d, "out%d.npy.json" % i)))["seconds"] for i in range(P)]
+                threads = int(env["OPENBLAS_NUM_THREADS"])
+            finally:
+                shutil.rmtree(d, ignore_errors=True)
+            rr = np.zeros(P * S1, dtype=[(k, "<f8") for k in ("beta", "se", "lambda_remle", "lambda_mle", "p_wald", "p_lrt", "p_score", "logl_H1")])
+            allo = np.concatenate(outs, axis=0)
+            for j, k in enumerate(rr.dtype.names):
+                rr[k] = allo[:, j]
+    except Exception as e:  # the checker must never take the bench down
+        port["reference_error"] = repr(e)[:300]
+        return port
+    one = float(np.median(per_proc))
+    return {"value": round(S1 / one, 2), "unit": "SNPs/s", "cores": threads, "kind": "reference",
             "sample": "%d SNPs of the last timed block through the reference's own LMM::Analyze (oracle/_ref/libgemma_ref.so = "
-                      "/root/reference/src compiled unchanged, GSL API from oracle/gslshim): %.2f s wall, OpenBLAS dgemm on %d "
-                      "threads + its serial per-SNP loop, incl. its 2 x n x 20000 batch buffers" % (S, t4 - t3, threads),
-            "host_threads": cores, "threads_note": "the reference's OpenBLAS build caps its pool at %d threads; the box has %d" % (threads, cores),
+                      "/root/reference/src compiled unchanged, GSL API from oracle/gslshim): %d independent processes x %d SNPs side by "
+                      "side, %.2f s wall, %.2f s median per process; value = the rate of ONE process (its OpenBLAS dgemm on %d threads + "
+                      "its serial per-SNP loop, incl. its 2 x n x 20000 batch buffers)" % (P * S1, P, S1, wall, one, threads),
+            "processes": P, "aggregate_snps_per_s": round(P * S1 / wall, 2), "host_threads": cores,
+            "threads_note": "the reference's OpenBLAS build caps its pool at %d threads; the box has %d" % (O.ref_blas_threads(), cores),
             "gpu_vs_reference_max_rel_err": worst_err(rr), "gpu_vs_reference_lambda": lambda_err(rr),
             "port": port, "port_sample_snps": S_port}
 

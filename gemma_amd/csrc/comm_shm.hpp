@@ -8,6 +8,7 @@
 #include <pthread.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
+#include <time.h>
 #include <unistd.h>
 
 #include <cstdio>
@@ -23,8 +24,21 @@ constexpr size_t COMM_ID_BYTES = 128;               // == NCCL_UNIQUE_ID_BYTES =
 class ShmTransport {
 public:
   static void make_id(void *id) {
+    // a name no earlier run can have left behind: pid + 64 bits from the kernel's generator (a stale segment of a crashed run
+    // with a recycled pid would carry ready = 1 and an initialised barrier)
     memset(id, 0, COMM_ID_BYTES);
-    snprintf(static_cast<char *>(id), COMM_ID_BYTES, "/gemma_hip_comm_%d_%ld", (int)getpid(), (long)random());
+    unsigned long long r = 0;
+    int fd = ::open("/dev/urandom", O_RDONLY);
+    if (fd >= 0) {
+      if (read(fd, &r, sizeof r) != (ssize_t)sizeof r) r = 0;
+      ::close(fd);
+    }
+    if (!r) {
+      struct timespec ts;
+      clock_gettime(CLOCK_MONOTONIC, &ts);
+      r = (unsigned long long)ts.tv_nsec * 2654435761ull ^ (unsigned long long)ts.tv_sec;
+    }
+    snprintf(static_cast<char *>(id), COMM_ID_BYTES, "/gemma_hip_comm_%d_%016llx", (int)getpid(), r);
   }
   bool open(const void *id, int rank, int world, std::string &err) {
     rank_ = rank;
@@ -33,7 +47,8 @@ public:
     bytes_ = sizeof(Header) + (size_t)world * COMM_SHM_CHUNK;
     int fd = -1;
     if (rank == 0) {
-      fd = shm_open(name_.c_str(), O_CREAT | O_RDWR, 0600);
+      shm_unlink(name_.c_str()); // never adopt a segment of that name: create it afresh, exclusively
+      fd = shm_open(name_.c_str(), O_CREAT | O_EXCL | O_RDWR, 0600);
       if (fd < 0 || ftruncate(fd, (off_t)bytes_) != 0) {
         err = "comm(shm): cannot create " + name_;
         return false;
@@ -62,6 +77,8 @@ public:
     hdr_ = static_cast<Header *>(m);
     slots_ = static_cast<char *>(m) + sizeof(Header);
     if (rank == 0) {
+      hdr_->ready = 0; // (a fresh segment is zero-filled; stated for the reader)
+      __sync_synchronize();
       pthread_barrierattr_t at;
       pthread_barrierattr_init(&at);
       pthread_barrierattr_setpshared(&at, PTHREAD_PROCESS_SHARED);

@@ -102,6 +102,8 @@ struct Ctx {
   size_t mv_d = 0;
   MvArgs mv_proto;
   DevBuf i8_Bt, i8_ej, i8_cmax, i8_A, i8_C, i8_mean; // exact int8-digit U^T x (i8gemm.hip.h)
+  unsigned long long cheb_qmask = 0; // bit k: tabulated interval k is in Q form (ends at or below lambda = 1e-3)
+  DevBuf i8_surlist;           // per row: count + up to SUR_MAX individuals the sparse mask operand dropped
   DevBuf i8_colsum;            // column sums of U from its digit planes (fixed-point dosage path)
   bool i8_colsum_ready = false;
   int last_utx_path = 0;       // what the last U^T x took: 0 fp64 GEMM, 1 int8 hard calls, 2 int8 dosages k/100, 3 int8 dosages k/1000
@@ -263,6 +265,12 @@ extern "C" void gemma_hip_shutdown(void) {
   g_ctx.own_U.release(); g_ctx.own_eval.release(); g_ctx.own_Uty.release(); g_ctx.own_UtW.release();
   g_ctx.UtWt.release(); g_ctx.idx_map.release(); g_ctx.X.release(); g_ctx.UtX.release();
   g_ctx.stage_in.release(); g_ctx.stage_out.release(); g_ctx.carry.release(); g_ctx.scratch.release();
+  g_ctx.i8_Bt.release(); g_ctx.i8_ej.release(); g_ctx.i8_cmax.release(); g_ctx.i8_A.release(); g_ctx.i8_C.release();
+  g_ctx.i8_mean.release(); g_ctx.i8_meta.release(); g_ctx.i8_rowsur.release(); g_ctx.i8_colsum.release(); g_ctx.i8_surlist.release();
+  g_ctx.i8_ready = g_ctx.i8_colsum_ready = false;
+  g_ctx.table_P.release(); g_ctx.U_even.release();
+  g_ctx.U_even_of = nullptr;
+  pipe_release(); // pinned slots, copy stream and events of the pipelined host-block path
   g_ctx.kin_active = g_ctx.lmm_active = false;
   g_ctx.kept_K.release(); g_ctx.kept_UE.release();
   g_ctx.kept_K_n = g_ctx.kept_n = 0;
@@ -894,9 +902,15 @@ static int make_cheb(hipStream_t s) {
   const int nreg = (int)g_ctx.cfg.n_region;
   const double width = log(g_ctx.cfg.l_max / g_ctx.cfg.l_min) / (double)nreg;
   if (c < 1 || c > 4 || width > 2.31 || nreg > 62) return GEMMA_HIP_OK;
+  // Intervals that end at or below lambda = 1e-3 are tabulated in Q form (series of sum a b delta H, the constant sum a b from
+  // the fixed-lambda table) -- low-heritability traits stay on the table path; GEMMA_HIP_CHEB_LOWLAMBDA=0 leaves them to the
+  // streaming evaluations as in round 2.
   int j0 = 0;
-  while (j0 < nreg && a.lam_grid[j0] < CHEB_MIN_LAMBDA * (1.0 - 1e-9)) ++j0;
+  const char *elow = getenv("GEMMA_HIP_CHEB_LOWLAMBDA");
+  if (elow && elow[0] == '0')
+    while (j0 < nreg && a.lam_grid[j0] < CHEB_MIN_LAMBDA * (1.0 - 1e-9)) ++j0;
   const int nint = nreg - j0;
+  g_ctx.cheb_qmask = 0;
   if (nint <= 0) return GEMMA_HIP_OK;
   GridGeom gg;
   gg.nq = CHEB_N;
@@ -907,10 +921,10 @@ static int make_cheb(hipStream_t s) {
   const size_t nb = (size_t)(gg.nbx + gg.nba);
   const size_t r_elems = (size_t)gg.nc * nb * 256;
   const size_t npairs = (c + 1) * (c + 2) / 2;
-  const size_t fld = (npairs + 2) * CHEB_N;
+  const size_t fld = (npairs + 3) * CHEB_N; // pairs, g, log|H|, sum (1 - H)^2
   if (g_ctx.cheb_R.reserve((size_t)nint * r_elems * 8) || g_ctx.cheb_F.reserve((size_t)nint * fld * 8) ||
       g_ctx.cheb_D.reserve(CHEB_N * CHEB_N * 8) || g_ctx.cheb_Ck.reserve(n * CHEB_N * 8) ||
-      g_ctx.cheb_Gk.reserve(n * CHEB_N * 8) || g_ctx.cheb_Lk.reserve(n * CHEB_N * 8) ||
+      g_ctx.cheb_Gk.reserve(2 * n * CHEB_N * 8) || g_ctx.cheb_Lk.reserve(n * CHEB_N * 8) ||
       g_ctx.cheb_iv.reserve(2 * ASSOC_MAX_REGION * 8))
     return fail(GEMMA_HIP_ENOMEM, "lmm_setup: Chebyshev tables (%zu bytes)", (size_t)nint * r_elems * 8);
   // fit matrix: coefficients = D * node values (cheb_fit of lmm_search.hip.h)
@@ -930,15 +944,18 @@ static int make_cheb(hipStream_t s) {
     g_ctx.cheb_inv_half[q] = 1.0 / iv.half;
     ChebNodes nd;
     for (int m = 0; m < CHEB_N; ++m) nd.lam[m] = exp(cheb_node(iv, m));
+    const int qform = a.lam_grid[j0 + q + 1] <= CHEB_MIN_LAMBDA * (1.0 + 1e-9) ? 1 : 0;
+    if (qform) g_ctx.cheb_qmask |= 1ull << q;
+    double *G2k = g_ctx.cheb_Gk.as<double>() + n * CHEB_N;
     hipLaunchKernelGGL(cheb_coeff_kernel, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, s, g_ctx.eval, (int)n, nd,
-                       g_ctx.cheb_D.as<double>(), g_ctx.cheb_Ck.as<double>(), g_ctx.cheb_Gk.as<double>(),
-                       g_ctx.cheb_Lk.as<double>());
+                       g_ctx.cheb_D.as<double>(), qform, g_ctx.cheb_Ck.as<double>(), g_ctx.cheb_Gk.as<double>(),
+                       g_ctx.cheb_Lk.as<double>(), G2k);
     HIPCHK(hipGetLastError());
     hipLaunchKernelGGL(cheb_weights_kernel, dim3((unsigned)((r_elems + 255) / 256)), dim3(256), 0, s, k, gg, (int)c,
                        g_ctx.cheb_Ck.as<double>(), g_ctx.cheb_R.as<double>() + (size_t)q * r_elems);
     HIPCHK(hipGetLastError());
-    hipLaunchKernelGGL(cheb_fixed_kernel, dim3((unsigned)(npairs + 2)), dim3(256), 0, s, k, (int)c,
-                       g_ctx.cheb_Ck.as<double>(), g_ctx.cheb_Gk.as<double>(), g_ctx.cheb_Lk.as<double>(),
+    hipLaunchKernelGGL(cheb_fixed_kernel, dim3((unsigned)(npairs + 3)), dim3(256), 0, s, k, (int)c,
+                       g_ctx.cheb_Ck.as<double>(), g_ctx.cheb_Gk.as<double>(), g_ctx.cheb_Lk.as<double>(), G2k,
                        g_ctx.cheb_F.as<double>() + (size_t)q * fld);
     HIPCHK(hipGetLastError());
   }
@@ -1119,6 +1136,8 @@ static int launch_cheb_tables(AssocArgs &a, const double *UtX, size_t l, size_t 
   HIPCHK(hipGetLastError());
   ChebSearchArgs sa;
   sa.count = sc.count;
+  sa.list = sc.list;
+  sa.qmask = g_ctx.cheb_qmask;
   sa.dends = sc.dends;
   sa.res = g_ctx.cheb_res.as<ChebResult>();
   memcpy(sa.mid, g_ctx.cheb_mid, sizeof sa.mid);
@@ -1239,15 +1258,19 @@ static int launch_assoc(const double *UtX, size_t l, size_t ld, gemma_sumstat *o
     a.grid_T = nullptr;
     if (a.have_grid && sel <= 4 && (ld & 1) == 0 && (reinterpret_cast<uintptr_t>(UtX) & 15) == 0 &&
         a.a_mode != 3) { // mode 3 (score only) never searches lambda
+      // The tables are an accelerator, not a requirement: when their buffers do not fit (the K-slice partial sums are
+      // planes x slices x l x 80 doubles -- 1.6 GB at l = n = 20000, c = 1) the batch falls back to the streaming evaluations
+      // (the round-1 path, same statistics) instead of failing.
       int rc = launch_grid_table(UtX, l, ld, s);
-      if (rc) return rc;
-      a.grid_T = g_ctx.grid_T.as<double>();
+      if (rc && rc != GEMMA_HIP_ENOMEM) return rc;
+      a.grid_T = rc ? nullptr : g_ctx.grid_T.as<double>();
       a.cheb_T = nullptr;
       a.cheb_slots = nullptr;
       a.cheb_res = nullptr;
-      if (a.have_cheb) {
+      if (!rc && a.have_cheb) {
         rc = launch_cheb_tables(a, UtX, l, ld, s);
-        if (rc) return rc;
+        if (rc && rc != GEMMA_HIP_ENOMEM) return rc;
+        if (rc) { a.cheb_T = nullptr; a.cheb_slots = nullptr; a.cheb_res = nullptr; }
       }
     }
     switch (sel) {
@@ -1445,16 +1468,28 @@ static int i8_product(size_t l, const I8Dims &d, double *UtX, size_t ldx, hipStr
   }
   {
     ProfScope ps(GEMMA_STAGE_UTX_POST, s);
+    // the calls the sparse mask operand dropped (groups of four with 3-4 missing calls): rows with up to SUR_MAX of them are
+    // completed inside the digit combine from a short per-row list, the rare rows with more by the fp64 fix-up pass
+    int *sur_cnt = nullptr, *sur_list = nullptr;
+    if (sparse) {
+      if (g_ctx.i8_surlist.reserve(l * (SUR_MAX + 1) * sizeof(int)))
+        return fail(GEMMA_HIP_ENOMEM, "lmm_batch: dropped-call lists");
+      sur_cnt = g_ctx.i8_surlist.as<int>();
+      sur_list = sur_cnt + l;
+      hipLaunchKernelGGL(i8_surplus_list_kernel, dim3((unsigned)((l + 3) / 4)), dim3(256), 0, s, g_ctx.i8_A.as<int8_t>(),
+                         (long)d.ldk, g_ctx.i8_rowsur.as<int>(), (long)l, sur_cnt, sur_list);
+      HIPCHK(hipGetLastError());
+    }
     hipLaunchKernelGGL(i8_combine_kernel, dim3((unsigned)((d.n + 255) / 256), (unsigned)std::min<size_t>(l, 65535)),
                        dim3(256), 0, s,
                        g_ctx.i8_C.as<int>(), (long)d.npad, (long)(d.mrows * d.npad), (long)d.lpad,
                        g_ctx.i8_mean.as<double>(), g_ctx.i8_ej.as<int>(), (long)l, (long)d.n, UtX, (long)ldx, 1.0, d.fuse,
-                       d.digits);
+                       d.digits, sur_cnt, sur_list, g_ctx.U, (long)d.n);
     HIPCHK(hipGetLastError());
     if (sparse) {
       hipLaunchKernelGGL(i8_surplus_fix_kernel, dim3((unsigned)l), dim3(256), 0, s, g_ctx.i8_A.as<int8_t>(), (long)d.ldk,
                          g_ctx.i8_rowsur.as<int>(), g_ctx.i8_mean.as<double>(), g_ctx.U, (long)d.n, (long)d.n, (long)l, UtX,
-                         (long)ldx);
+                         (long)ldx, SUR_MAX);
       HIPCHK(hipGetLastError());
     }
   }
@@ -2286,7 +2321,7 @@ extern "C" int gemma_hip_lmm_finish(double *time_UtX_min, double *time_opt_min) 
   g_ctx.cheb_list.release(); g_ctx.cheb_count.release(); g_ctx.cheb_D.release(); g_ctx.cheb_Ck.release();
   g_ctx.cheb_Gk.release(); g_ctx.cheb_Lk.release(); g_ctx.cheb_iv.release(); g_ctx.cheb_dends.release(); g_ctx.cheb_res.release();
   g_ctx.i8_Bt.release(); g_ctx.i8_ej.release(); g_ctx.i8_cmax.release(); g_ctx.i8_A.release(); g_ctx.i8_C.release();
-  g_ctx.i8_mean.release(); g_ctx.i8_meta.release(); g_ctx.i8_rowsur.release(); g_ctx.i8_colsum.release();
+  g_ctx.i8_mean.release(); g_ctx.i8_meta.release(); g_ctx.i8_rowsur.release(); g_ctx.i8_colsum.release(); g_ctx.i8_surlist.release();
   g_ctx.i8_ready = false;
   g_ctx.i8_colsum_ready = false;
   g_ctx.gxe_env.release(); g_ctx.gxe_UtWt.release(); g_ctx.gxe_Z.release(); g_ctx.gxe_UtZ.release();

@@ -550,10 +550,15 @@ __global__ __launch_bounds__(256) void i8_combine_dosage_kernel(const int *__res
 
 // UtX[s][j] = 2^(e_j - scale_bits) * sum_d 256^d (CG_d[s][j] + mean_s * CM_d[s][j]);  planes: one per digit (fuse = 0) or
 // two digits per plane with 256 * C_{d+1} + C_d (fuse = 1; with an odd digit count plane 0 holds digit 0 alone)
+// sur_cnt / sur_list (may be null): the calls the 2:4 sparse mask operand dropped, per row (i8gemm_sparse.hip.h:
+// i8_surplus_list_kernel); rows with 1 .. 16 of them get mean_s * sum_e U[i_e][j] added here, in list order
 __global__ __launch_bounds__(256) void i8_combine_kernel(const int *__restrict__ C, long ldc, long strideC, long m_row0,
                                                          const double *__restrict__ mean, const int *__restrict__ ej,
                                                          long l, long n, double *__restrict__ UtX, long ldx,
-                                                         double m_scale, int fuse, int digits) {
+                                                         double m_scale, int fuse, int digits,
+                                                         const int *__restrict__ sur_cnt = nullptr,
+                                                         const int *__restrict__ sur_list = nullptr,
+                                                         const double *__restrict__ U = nullptr, long ldu = 0) {
   const long j = (long)blockIdx.x * 256 + threadIdx.x;
   if (j >= n) return;
   const int nplanes = fuse ? (digits + 1) / 2 : digits;
@@ -566,7 +571,16 @@ __global__ __launch_bounds__(256) void i8_combine_kernel(const int *__restrict__
       tg = tg * w + (double)C[(long)q * strideC + s * ldc + j];
       tmk = tmk * w + (double)C[(long)q * strideC + (m_row0 + s) * ldc + j];
     }
-    UtX[s * ldx + j] = ldexp(fma(mean[s] * m_scale, tmk, tg), ej[j] - i8_scale_bits(digits)); // m_scale: exact power of two
+    double v = ldexp(fma(mean[s] * m_scale, tmk, tg), ej[j] - i8_scale_bits(digits)); // m_scale: exact power of two
+    if (sur_cnt) {
+      const int cnt = sur_cnt[s]; // uniform over the block: no divergence
+      if (cnt > 0) {
+        double acc = 0.0;
+        for (int e = 0; e < cnt; ++e) acc += U[(long)sur_list[s * 16 + e] * ldu + j];
+        v += mean[s] * acc;
+      }
+    }
+    UtX[s * ldx + j] = v;
   }
 }
 

@@ -245,9 +245,9 @@ __global__ __launch_bounds__(512, 2) void i8gemm_sparse2_kernel(Sparse2Args g) {
     S2_G(3, 1, 1); GEMMA_SB();                                                                                    \
   } while (0)
 
-#ifdef S2_PRIO_EXPERIMENT
+  // the second-dispatched half of the workgroup loses every issue arbitration on age; one static priority step evens it out
+  // (MI355X_MICROARCH.md, two waves per SIMD, item 4): 57.2 -> 56.2-56.9 ms (profiles/r03_i8_sparse_ablation.txt)
   if (wave >= 4) __builtin_amdgcn_s_setprio(1);
-#endif
   const int nk = g.nk;
   for (int dd = 0; dd < nd; ++dd) {
     if (dd > 0) { // second digit of a fused pair: acc = 256 * C_hi, then accumulate C_lo on top

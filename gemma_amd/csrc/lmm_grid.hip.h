@@ -350,16 +350,18 @@ __global__ __launch_bounds__(256) void table_reduce_kernel(const double *__restr
 // (cheb_fixed_kernel).  Per batch: cheb_scan_kernel finds every SNP's bracket intervals from the fixed-lambda table and
 // hands out slots, grid_table_kernel<.., GATHER> computes the series of exactly those (SNP, interval) pairs.
 constexpr double CHEB_MARGIN = 0.15; // of the interval's length, either side
-constexpr double CHEB_MIN_LAMBDA = 1e-3; // intervals below keep streaming: dS/dt is O(lambda) of S there, and a series
-                                         // good to 1e-15 of S carries 1e-13/lambda of relative error in it
+constexpr double CHEB_MIN_LAMBDA = 1e-3; // intervals below are tabulated in Q form (lmm_search.hip.h): dS/dt is O(lambda) of S
+                                         // there, and a series good to 1e-15 of S would carry 1e-13/lambda of relative error in it
 
 struct ChebNodes {
   double lam[CHEB_N]; // exp(node m)
 };
 
-// Ck: series of H_i, Gk: of 1 - H_i, Lk: of log(lambda delta_i + 1)  (each n x CHEB_N)
+// Ck: series of H_i -- or, for an interval in Q form (lmm_search.hip.h: below lambda = 1e-3), of delta_i H_i --, Gk: of 1 - H_i,
+// Lk: of log(lambda delta_i + 1), G2k: of (1 - H_i)^2  (each n x CHEB_N)
 __global__ void cheb_coeff_kernel(const double *__restrict__ eval, int n, ChebNodes nd, const double *__restrict__ Dfit,
-                                  double *__restrict__ Ck, double *__restrict__ Gk, double *__restrict__ Lk) {
+                                  int qform, double *__restrict__ Ck, double *__restrict__ Gk, double *__restrict__ Lk,
+                                  double *__restrict__ G2k) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const double d = eval[i];
@@ -367,22 +369,24 @@ __global__ void cheb_coeff_kernel(const double *__restrict__ eval, int n, ChebNo
 #pragma unroll
   for (int m = 0; m < CHEB_N; ++m) {
     const double ld = nd.lam[m] * d;
-    hm[m] = 1.0 / (ld + 1.0);
+    hm[m] = (qform ? d : 1.0) / (ld + 1.0);
     gm[m] = ld / (ld + 1.0);
     lm[m] = log(fabs(ld + 1.0)); // as the row passes: log|lambda delta + 1|
   }
   for (int k = 0; k < CHEB_N; ++k) {
-    double sh = 0.0, sg = 0.0, sl = 0.0;
+    double sh = 0.0, sg = 0.0, sl = 0.0, s2 = 0.0;
 #pragma unroll
     for (int m = 0; m < CHEB_N; ++m) {
       const double w = Dfit[k * CHEB_N + m];
       sh += hm[m] * w;
       sg += gm[m] * w;
       sl += lm[m] * w;
+      s2 += gm[m] * gm[m] * w;
     }
     Ck[(long)i * CHEB_N + k] = sh;
     Gk[(long)i * CHEB_N + k] = sg;
     Lk[(long)i * CHEB_N + k] = sl;
+    G2k[(long)i * CHEB_N + k] = s2;
   }
 }
 
@@ -417,10 +421,10 @@ __global__ void cheb_weights_kernel(AssocArgs g, GridGeom gg, int c, const doubl
 
 // SNP-independent series of one interval, one block per function: block b < npairs: the pair (a <= bb) among
 // (w_1..w_c, y) in row-major upper-triangle order, a_k = sum_i u_a u_bb c_k(delta_i); block npairs: g, a_k = sum_i Gk[i][k];
-// block npairs + 1: log|H| = sum_i log(lambda delta_i + 1), a_k = sum_i Lk[i][k]
+// block npairs + 1: log|H| = sum_i log(lambda delta_i + 1), a_k = sum_i Lk[i][k]; block npairs + 2: sum_i (1 - H_i)^2
 __global__ __launch_bounds__(256) void cheb_fixed_kernel(AssocArgs g, int c, const double *__restrict__ Ck,
                                                         const double *__restrict__ Gk, const double *__restrict__ Lk,
-                                                        double *__restrict__ F) {
+                                                        const double *__restrict__ G2k, double *__restrict__ F) {
   const int nv = c + 1, npairs = nv * (nv + 1) / 2;
   const int b = blockIdx.x;
   int pa = 0, pb = 0;
@@ -435,7 +439,7 @@ __global__ __launch_bounds__(256) void cheb_fixed_kernel(AssocArgs g, int c, con
   for (int k = 0; k < CHEB_N; ++k) s[k] = 0.0;
   for (long i = threadIdx.x; i < g.n; i += 256) {
     double w = 1.0;
-    const double *src = (b == npairs) ? Gk : Lk;
+    const double *src = (b == npairs) ? Gk : (b == npairs + 1) ? Lk : G2k;
     if (b < npairs) {
       const double ua = (pa < c) ? g.UtWt[(long)pa * g.n + i] : g.Uty[i];
       const double ub = (pb < c) ? g.UtWt[(long)pb * g.n + i] : g.Uty[i];
@@ -516,6 +520,8 @@ __global__ __launch_bounds__(256) void cheb_scan_kernel(AssocArgs g, ChebScanArg
 // thread.  grid = (ceil(cap / 64), nint, 2).
 struct ChebSearchArgs {
   const int *count;
+  const int *list;            // [k * cap + slot] = SNP index (the constants of a Q-form interval come from its fixed-lambda row)
+  unsigned long long qmask;   // bit k: interval k is in Q form
   const double2 *dends;
   ChebResult *res;
   double mid[ASSOC_MAX_REGION], inv_half[ASSOC_MAX_REGION];
@@ -538,6 +544,16 @@ __device__ __forceinline__ void cheb_search_one(const AssocArgs &g, const ChebSe
     ev.cs.mid = sa.mid[k];
     ev.cs.inv_half = sa.inv_half[k];
     ev.cs.n = (double)g.n;
+    ev.cs.qform = (int)((sa.qmask >> k) & 1ull);
+    ev.cs.s0f = g.grid_F; // weight q = 0 is 1: F[0][pair] = sum_i u_a u_b
+#pragma unroll
+    for (int a = 0; a < C + 2; ++a) ev.cs.s0x[a] = 0.0;
+    if (ev.cs.qform) {
+      const double *trow = g.grid_T + (long)sa.list[(long)k * g.cheb_cap + slot] * g.grid_ld;
+      ev.cs.s0x[0] = trow[0];
+#pragma unroll
+      for (int a = 0; a <= C; ++a) ev.cs.s0x[1 + a] = trow[g.grid_xa0 + a * g.grid_nq];
+    }
     double l = 0.0, l_temp = 0.0;
     const int j = g.cheb_j0 + k;
     r.status = polish_bracket(ev, g.lam_grid[j], g.lam_grid[j + 1], d.x, d.y, g.l_min, g.l_max, l, l_temp);

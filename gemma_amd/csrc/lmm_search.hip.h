@@ -249,7 +249,8 @@ GH_HD constexpr int ab_index(int a, int b) {
 //         (a < C: U^T W column a, a = C: U^T y).  On the device the table is stored column-major over the
 //         interval's slots (sstride = slots per interval) so that one thread per SNP reads coalesced.
 //   fix : the interval's SNP-independent series, [pair * CHEB_N + k] for the pairs (a <= b) among (w_1..w_C, y) in
-//         row-major upper-triangle order, then [npairs * CHEB_N + k] = series of g(t) = sum_i (1 - H_i)
+//         row-major upper-triangle order, then [npairs * CHEB_N + k] = series of g(t) = sum_i (1 - H_i), [(npairs + 1) ..]
+//         = series of log|H| (used by the final pass only), [(npairs + 2) ..] = series of sum_i (1 - H_i)^2
 template <int C>
 struct ChebSnp {
   const double *snp;
@@ -258,6 +259,13 @@ struct ChebSnp {
   int xa0;
   double mid, inv_half; // t -> s = (t - mid) * inv_half
   double n;             // individuals
+  // "Q form", the intervals below lambda = 1e-3: there S_ab(t) = S0_ab - lambda Q_ab(t), S0_ab = sum_i a_i b_i and
+  // Q_ab = sum_i a_i b_i delta_i H_i; dS/dt = -lambda (Q + Q') is O(lambda) S, and a series of S itself good to 1e-15 of S
+  // would carry 1e-13 / lambda of relative error in it.  So for those intervals `snp` and the pair part of `fix` hold the
+  // series of Q (same table product, weights c_k of delta_i H_i instead of H_i) and the constants come beside them:
+  int qform;
+  double s0x[C + 2];    // sum_i x_i^2, sum_i x_i u_a(i) (a < C: U^T W column a, a = C: U^T y)
+  const double *s0f;    // the SNP-independent pairs, in the order of `fix`
 };
 
 // dev1 (ORDER 1) or dev1 and dev2 (ORDER 2) of logRL (REML) / logL at lambda = l from the series; false when l lies
@@ -287,14 +295,26 @@ GH_HD bool cheb_deriv(const ChebSnp<C> &cs, double l, double &dev1, double &dev2
       } else {
         cheb_eval<ORDER>(cs.fix + (fa * (C + 1) - fa * (fa - 1) / 2 + (fb - fa)) * CHEB_N, 1, s, v0, v1, v2);
       }
-      p0[q] = v0;
-      p1[q] = v1 * k1;
-      p2[q] = v2 * k2;
+      if (cs.qform) {
+        const double S0 = (ax && bx) ? cs.s0x[0]
+                          : (ax || bx) ? cs.s0x[1 + (ax ? fb : fa)]
+                                       : cs.s0f[fa * (C + 1) - fa * (fa - 1) / 2 + (fb - fa)];
+        const double Q1 = v1 * k1, Q2 = v2 * k2;
+        p0[q] = S0 - l * v0;
+        p1[q] = -l * (v0 + Q1);
+        p2[q] = -l * (v0 + 2.0 * Q1 + Q2);
+      } else {
+        p0[q] = v0;
+        p1[q] = v1 * k1;
+        p2[q] = v2 * k2;
+      }
     }
   }
-  double g0, g1, g2;
-  cheb_eval<(ORDER >= 2 ? 1 : 0)>(cs.fix + NPAIR * CHEB_N, 1, s, g0, g1, g2);
-  g1 *= k1;
+  // g = sum_i (1 - H_i) and, for the second derivative, gg = g - dg/dt = sum_i (1 - H_i)^2 from a series of its own (the
+  // difference of the two O(lambda) terms cancels to O(lambda^2))
+  double g0, g1, g2, gg = 0.0;
+  cheb_eval<0>(cs.fix + NPAIR * CHEB_N, 1, s, g0, g1, g2);
+  if (ORDER >= 2) cheb_eval<0>(cs.fix + (NPAIR + 2) * CHEB_N, 1, s, gg, g1, g2);
   double sr = 0.0, sq = 0.0;
 #pragma unroll
   for (int p = 1; p <= C + 1; ++p) {
@@ -333,14 +353,14 @@ GH_HD bool cheb_deriv(const ChebSnp<C> &cs, double l, double &dev1, double &dev2
     const double trace_PK = (g0 + sr) / l;
     dev1 = -0.5 * trace_PK + 0.5 * df * yPKPy / Pyy;
     if (ORDER >= 2) {
-      const double trace_PKPK = ((g0 - g1) + sq) / (l * l);
+      const double trace_PKPK = (gg + sq) / (l * l);
       dev2 = 0.5 * trace_PKPK - 0.5 * df * (2.0 * yPKPKPy * Pyy - yPKPy * yPKPy) / (Pyy * Pyy);
     }
   } else {
     const double trace_HiK = g0 / l;
     dev1 = -0.5 * trace_HiK + 0.5 * cs.n * yPKPy / Pyy;
     if (ORDER >= 2) {
-      const double trace_HiKHiK = (g0 - g1) / (l * l);
+      const double trace_HiKHiK = gg / (l * l);
       dev2 = 0.5 * trace_HiKHiK - 0.5 * cs.n * (2.0 * yPKPKPy * Pyy - yPKPy * yPKPy) / (Pyy * Pyy);
     }
   }

@@ -64,6 +64,7 @@ def broadcast_state(tensors, src=0, group=None, small_limit=1 << 22):
 
 
 _native_ready = False
+_native_poisoned = False  # a bootstrap thread timed out inside the library: the comm API is off limits for this process
 
 
 def native_comm_init(group=None, timeout=180.0):
@@ -71,7 +72,7 @@ def native_comm_init(group=None, timeout=180.0):
     through torch.distributed's store, ncclCommInitRank on every rank's device).  Every rank learns whether ALL ranks
     succeeded (one MIN all-reduce), so that they take the same branch afterwards.  Returns True when the native
     communicator is usable."""
-    global _native_ready
+    global _native_ready, _native_poisoned
     import ctypes as C
     import torch
     import torch.distributed as dist
@@ -80,6 +81,8 @@ def native_comm_init(group=None, timeout=180.0):
         return False
     if _native_ready:
         return True
+    if _native_poisoned:
+        return False
     rank, world = dist.get_rank(group), dist.get_world_size(group)
     ok = 1
     try:
@@ -106,7 +109,12 @@ def native_comm_init(group=None, timeout=180.0):
         th = threading.Thread(target=_init, daemon=True)
         th.start()
         th.join(timeout)
-        if th.is_alive() or res.get("rc") != 0:
+        if th.is_alive():
+            # the helper is still inside gemma_hip_comm_init and may complete (or mutate the library's communicator) at any
+            # later time: never touch the comm API again from this process -- no finalize, no second attempt
+            _native_poisoned = True
+            ok = 0
+        elif res.get("rc") != 0:
             ok = 0
     except Exception:  # the other ranks must still reach the agreement below
         ok = 0
@@ -114,7 +122,7 @@ def native_comm_init(group=None, timeout=180.0):
     flag = torch.tensor([ok], dtype=torch.int32, device=dev)
     dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
     _native_ready = bool(int(flag[0]) == 1)
-    if not _native_ready and ok == 1:
+    if not _native_ready and ok == 1 and not _native_poisoned:
         L.lib().gemma_hip_comm_finalize()  # this rank could, another could not: drop the communicator, all take the fallback
     return _native_ready
 

@@ -540,6 +540,35 @@ def ref_lib():
     return _REF
 
 
+def ref_eigen_decomp_zeroed(G):
+    """The reference's own EigenDecomp_Zeroed (src/lapack.cpp:260-291, dsyevr_ of the OpenBLAS the reference binary is linked
+    against) -> (U, eval, trace_G); G is copied."""
+    R = ref_lib()
+    if R is None:
+        raise RuntimeError("oracle/_ref/libgemma_ref.so not built")
+    G = _c64(G).copy()
+    n = G.shape[0]
+    U, ev = np.empty((n, n)), np.empty(n)
+    R.ref_eigen_decomp_zeroed.restype = C.c_double
+    R.ref_eigen_decomp_zeroed.argtypes = [C.c_size_t, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    tr = R.ref_eigen_decomp_zeroed(n, _dp(G), _dp(U), _dp(ev))
+    return U, ev, tr
+
+
+def ref_plink_kin(bed_path, ni, ns, k_mode=1):
+    """The reference's own PlinkKin (src/gemma_io.cpp:1599-1738) on a .bed file (3 magic bytes + ns rows of ceil(ni/4) bytes)."""
+    R = ref_lib()
+    if R is None:
+        raise RuntimeError("oracle/_ref/libgemma_ref.so not built")
+    K = np.zeros((ni, ni))
+    R.ref_plink_kin.restype = C.c_int
+    R.ref_plink_kin.argtypes = [C.c_char_p, C.c_size_t, C.c_size_t, C.c_int, C.POINTER(C.c_double)]
+    rc = R.ref_plink_kin(os.fsencode(bed_path), ni, ns, k_mode, _dp(K))
+    if rc:
+        raise RuntimeError("PlinkKin failed on " + bed_path)
+    return K
+
+
 def ref_blas_threads():
     import glob
     import scipy

@@ -15,6 +15,12 @@
 #include "gsl/gsl_vector.h"
 #include "lmm.h"  // the reference's own header (-I/root/reference/src): class LMM, SUMSTAT, SnpNameValues
 
+// src/lapack.h:34 (definition src/lapack.cpp:260-291): all eigenpairs through dsyevr_, eval < 1e-10 -> 0
+double EigenDecomp_Zeroed(gsl_matrix *G, gsl_matrix *U, gsl_vector *eval, const size_t flag_largematrix);
+// src/gemma_io.h:94 (definition src/gemma_io.cpp:1599-1738): the -gk loop over a .bed file
+bool PlinkKin(const std::string &file_bed, std::vector<int> &indicator_snp, const int k_mode, const int display_pace,
+              gsl_matrix *matrix_kin);
+
 // src/mvlmm.cpp:599-604
 double MphEM(const char func_name, const size_t max_iter, const double max_prec, const gsl_vector *eval, const gsl_matrix *X,
              const gsl_matrix *Y, gsl_matrix *U_hat, gsl_matrix *E_hat, gsl_matrix *OmegaU, gsl_matrix *OmegaE,
@@ -115,5 +121,23 @@ long ref_lmm_analyze(int a_mode, size_t n, size_t c, size_t l, const double *U, 
     o[4] = s.p_wald; o[5] = s.p_lrt; o[6] = s.p_score; o[7] = s.logl_H1;
   }
   return (long)lmm.sumStat.size();
+}
+
+// The reference's setup stages, for bench.py's cpu_baseline.setup leg (timed on the GPU box's host cores, never part of `value`).
+// EigenDecomp_Zeroed (src/lapack.cpp:260-291 -> lapack_eigen_symmv :149-236 -> dsyevr_): G is overwritten as the reference does.
+double ref_eigen_decomp_zeroed(size_t n, double *G, double *U, double *eval) {
+  gsl_matrix_view Gm = gsl_matrix_view_array(G, n, n), Um = gsl_matrix_view_array(U, n, n);
+  gsl_vector_view ev = gsl_vector_view_array(eval, n);
+  return EigenDecomp_Zeroed(&Gm.matrix, &Um.matrix, &ev.vector, 0);
+}
+// PlinkKin (src/gemma_io.cpp:1599-1738) on a .bed file of ns SNPs x ni individuals, every SNP used; K: ni x ni, overwritten
+int ref_plink_kin(const char *file_bed, size_t ni, size_t ns, int k_mode, double *K) {
+  gsl_matrix_view Km = gsl_matrix_view_array(K, ni, ni);
+  std::vector<int> ind(ns, 1);
+  std::ostringstream sink;
+  std::streambuf *old = std::cout.rdbuf(sink.rdbuf());
+  const bool ok = PlinkKin(std::string(file_bed), ind, k_mode, 100000000, &Km.matrix);
+  std::cout.rdbuf(old);
+  return ok ? 0 : 1;
 }
 }

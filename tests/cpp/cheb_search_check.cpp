@@ -5,8 +5,9 @@
 //
 //   cheb_search_check in.bin out.bin
 //   in : doubles  [C, reml, n, L]  then L cases of
-//          [lam_lo, lam_hi, d_lo, d_hi, l_min, l_max, mid, inv_half, probe_lambda,
-//           snp row ((C + 2) * CHEB_N), fix row (((C + 1)(C + 2)/2 + 1) * CHEB_N)]
+//          [lam_lo, lam_hi, d_lo, d_hi, l_min, l_max, mid, inv_half, probe_lambda, qform,
+//           s0x (C + 2: sum x^2, sum x u_a), s0f ((C + 1)(C + 2)/2: sum u_a u_b),
+//           snp row ((C + 2) * CHEB_N), fix row (((C + 1)(C + 2)/2 + 3) * CHEB_N: pairs, g, log|H| (unused here), sum (1-H)^2)]
 //   out: per case [status, l, probe_ok, probe_dev1, probe_dev2]
 #include <cstdio>
 #include <cstdlib>
@@ -18,14 +19,19 @@ using namespace gemma_hip;
 
 template <int C, bool REML>
 static void run(const double *in, size_t L, double n, double *out) {
-  const size_t nsnp = (size_t)(C + 2) * CHEB_N, nfix = (size_t)((C + 1) * (C + 2) / 2 + 1) * CHEB_N;
-  const size_t stride = 9 + nsnp + nfix;
+  const size_t npair = (size_t)(C + 1) * (C + 2) / 2;
+  const size_t nsnp = (size_t)(C + 2) * CHEB_N, nfix = (npair + 3) * CHEB_N;
+  const size_t head = 10 + (C + 2) + npair;
+  const size_t stride = head + nsnp + nfix;
   for (size_t s = 0; s < L; ++s) {
     const double *c = in + s * stride;
     ChebEvaluator<C, REML> ev;
-    ev.cs.snp = c + 9;
+    ev.cs.snp = c + head;
     ev.cs.sstride = 1;
-    ev.cs.fix = c + 9 + nsnp;
+    ev.cs.fix = c + head + nsnp;
+    ev.cs.qform = c[9] != 0.0;
+    for (int a = 0; a < C + 2; ++a) ev.cs.s0x[a] = c[10 + a];
+    ev.cs.s0f = c + 10 + (C + 2);
     ev.cs.xa0 = CHEB_N;
     ev.cs.mid = c[6];
     ev.cs.inv_half = c[7];
@@ -49,7 +55,8 @@ int main(int argc, char **argv) {
   const bool reml = hdr[1] != 0.0;
   const double n = hdr[2];
   const size_t L = (size_t)hdr[3];
-  const size_t stride = 9 + (size_t)(C + 2) * CHEB_N + (size_t)((C + 1) * (C + 2) / 2 + 1) * CHEB_N;
+  const size_t npair = (size_t)(C + 1) * (C + 2) / 2;
+  const size_t stride = 10 + (C + 2) + npair + (size_t)(C + 2) * CHEB_N + (npair + 3) * CHEB_N;
   std::vector<double> in(L * stride), out(L * 5);
   if (fread(in.data(), 8, in.size(), f) != in.size()) return 3;
   fclose(f);

@@ -25,6 +25,7 @@
 #include <cstdlib>
 #include <iostream>
 
+#include <signal.h>
 #include <sys/wait.h>
 #include <unistd.h>
 #include <string>
@@ -107,16 +108,36 @@ int main(int argc, char **argv) {
         rank = r;
         device = samegpu ? 0 : r;
         file_out += ".rank" + std::to_string(r);
+        // keep only the pipe ends this rank uses (rank 0: every write end; rank r: its read end), so that a rank whose peer
+        // died sees EOF instead of blocking on a descriptor a sibling still holds open
+        for (int q = 1; q < gpus; ++q) {
+          if (r != 0) close(id_pipe_w[q]);
+          if (q != r) close(id_pipe_r[q]);
+        }
         break;
       }
       kids.push_back(pid);
     }
     if ((int)kids.size() == gpus) { // the parent: wait, then concatenate in rank order
+      for (int q = 1; q < gpus; ++q) { close(id_pipe_r[q]); close(id_pipe_w[q]); }
+      // The ranks meet in collectives that have no time-out (ncclBroadcast, the shm transport's barrier): when one of them
+      // leaves early -- an unreadable kinship file on rank 0, a failed eigendecomposition -- the others would wait for ever.
+      // So: reap in completion order, and on the first failure end the siblings.
       int bad = 0;
-      for (pid_t k : kids) {
+      for (size_t left = kids.size(); left > 0; --left) {
         int st = 0;
-        waitpid(k, &st, 0);
-        if (!WIFEXITED(st) || WEXITSTATUS(st) != 0) bad = 1;
+        const pid_t done = waitpid(-1, &st, 0);
+        if (done < 0) { bad = 1; break; }
+        if (!WIFEXITED(st) || WEXITSTATUS(st) != 0) {
+          bad = 1;
+          for (pid_t k : kids)
+            if (k != done) kill(k, SIGKILL);
+          for (pid_t k : kids) {
+            int s2 = 0;
+            if (k != done) waitpid(k, &s2, 0);
+          }
+          break;
+        }
       }
       if (bad) return 7;
       std::ofstream all((path_out + "/" + file_out + ".assoc.txt").c_str(), std::ios::binary);

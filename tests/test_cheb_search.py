@@ -89,22 +89,33 @@ def _interval(lam_lo, lam_hi):
     return mid, half, nodes
 
 
+QFORM_BELOW = 1e-3  # lmm_grid.hip.h: CHEB_MIN_LAMBDA -- intervals ending at or below it are tabulated in Q form
+
+
 def _series(lam_lo, lam_hi, d, W, y, X):
-    """-> mid, half, fix row, per-SNP rows (l x (c + 2) CHEB_N) for the interval."""
+    """-> mid, half, head (qform, s0x, s0f), fix row, per-SNP rows (l x (c + 2) CHEB_N) for the interval.  Q form (interval at or
+    below lambda = 1e-3): the series are those of sum a b delta H, the constants sum a b travel beside them."""
     mid, half, nodes = _interval(lam_lo, lam_hi)
+    qform = lam_hi <= QFORM_BELOW * (1 + 1e-9)
     Hn = 1.0 / (np.exp(nodes)[:, None] * d[None, :] + 1.0)      # N x n
-    Ck = _fit_matrix() @ Hn                                       # N x n: c_k(delta_i)
+    Ck = _fit_matrix() @ (Hn * d[None, :] if qform else Hn)       # N x n: c_k(delta_i)
     c = W.shape[1]
     F = np.column_stack([W, y])                                   # fixed variables
-    fix = []
+    fix, s0f = [], []
     for a in range(c + 1):
         for b in range(a, c + 1):
             fix.append(Ck @ (F[:, a] * F[:, b]))
+            s0f.append(float(F[:, a] @ F[:, b]))
     fix.append(_fit_matrix() @ (1.0 - Hn).sum(axis=1))            # g(t) = sum (1 - H)
+    fix.append(np.zeros(CHEB_N))                                  # log|H|: the final pass's, not the search's
+    fix.append(_fit_matrix() @ ((1.0 - Hn) ** 2).sum(axis=1))     # sum (1 - H)^2
     rows = [(X * X) @ Ck.T]
+    s0x = [(X * X).sum(axis=1)]
     for a in range(c + 1):
         rows.append((X * F[:, a][None, :]) @ Ck.T)
-    return mid, half, np.concatenate(fix), np.hstack(rows)
+        s0x.append(X @ F[:, a])
+    head = [np.concatenate([[1.0 if qform else 0.0], np.array([v[s] for v in s0x]), s0f]) for s in range(X.shape[0])]
+    return mid, half, head, np.concatenate(fix), np.hstack(rows)
 
 
 def _run(harness, tmp_path, c, reml, n, cases):
@@ -115,7 +126,7 @@ def _run(harness, tmp_path, c, reml, n, cases):
     return np.fromfile(fout).reshape(len(cases), 5)
 
 
-def _case(oracle, n, p, c, seed):
+def _case(oracle, n, p, c, seed, gs=0.9, causal=(0.3, -0.2, 0.25)):
     rng = np.random.default_rng(seed)
     maf = rng.uniform(0.05, 0.5, size=p + 2 * n)
     G = rng.binomial(2, maf[:, None], size=(p + 2 * n, n)).astype(np.float64)
@@ -123,7 +134,7 @@ def _case(oracle, n, p, c, seed):
     U, ev, _ = oracle.eigen_decomp_zeroed(oracle.center_matrix(K))
     W = np.ones((n, 1)) if c == 1 else np.hstack([rng.standard_normal((n, c - 1)), np.ones((n, 1))])
     g = U @ (np.sqrt(np.maximum(ev, 0)) * rng.standard_normal(n))
-    y = G[:3].T @ np.array([0.3, -0.2, 0.25]) + 0.9 * g / g.std() + rng.standard_normal(n)
+    y = G[:3].T @ np.array(causal) + gs * g / g.std() + rng.standard_normal(n)
     return G[:p] @ U, ev, U.T @ W, U.T @ y
 
 
@@ -135,29 +146,49 @@ def test_series_derivatives_match_exact_sums(harness, tmp_path, oracle, c, reml)
     rng = np.random.default_rng(c)
     cases, probes = [], []
     for j in range(10):
-        mid, half, fix, rows = _series(lam[j], lam[j + 1], d, UtW, Uty, UtX)
+        mid, half, head, fix, rows = _series(lam[j], lam[j + 1], d, UtW, Uty, UtX)
         for s in range(p):
             pl = float(np.exp(rng.uniform(np.log(lam[j]) - 0.1, np.log(lam[j + 1]) + 0.1)))
-            cases.append([np.array([lam[j], lam[j + 1], 1.0, -1.0, 1e-5, 1e5, mid, 1.0 / half, pl]), rows[s], fix])
+            cases.append([np.array([lam[j], lam[j + 1], 1.0, -1.0, 1e-5, 1e5, mid, 1.0 / half, pl]), head[s], rows[s], fix])
             probes.append((s, j, pl))
     out = _run(harness, tmp_path, c, reml, n, cases)
     worst1 = worst2 = 0.0
     for (s, j, pl), o in zip(probes, out):
         assert o[2] == 1.0
         V = np.column_stack([UtW, UtX[s], Uty])
-        e1, e2, scale = _derivs_exact(pl, d, V, c, reml)
-        # the reference's own formula loses ~1e-16 / lambda at small lambda; compare at the precision both can have
-        tol_scale = scale * max(1.0, 1e-3 / pl)
-        worst1 = max(worst1, abs(o[3] - e1) / tol_scale)
-        worst2 = max(worst2, abs(o[4] - e2) / (abs(e2) + scale / pl) / max(1.0, 1e-3 / pl))
+        # the reference's own formulas lose ~1e-16 / lambda in double precision (P_yy - PP_yy at small lambda): the exact
+        # values are taken in long double, and the series must meet them WITHOUT a small-lambda allowance -- the intervals
+        # below 1e-3 are in Q form exactly for that
+        e1, e2, scale = (float(v) for v in _derivs_exact(np.longdouble(pl), d.astype(np.longdouble), V.astype(np.longdouble), c, reml))
+        worst1 = max(worst1, abs(o[3] - e1) / scale)
+        worst2 = max(worst2, abs(o[4] - e2) / (abs(e2) + scale / pl))
+    print("series derivatives c=%d reml=%s: dev1 %.2e of its scale, dev2 %.2e" % (c, reml, worst1, worst2))
     assert worst1 < 2e-10, worst1
     assert worst2 < 2e-7, worst2
 
 
-@pytest.mark.parametrize("c", [1, 3])
-def test_table_search_reproduces_the_oracles_lambda(harness, tmp_path, oracle, c):
+def _case_low_lambda(n, p, c, lam0, seed):
+    """Rotated inputs drawn directly: a kinship spectrum with a few very large eigenvalues (population structure: delta up to
+    3e4) and a phenotype with variance lam0 * delta_i + 1 in the eigenbasis, so that lambda-hat sits near lam0 << 1e-3 -- the
+    decades whose intervals are tabulated in Q form."""
+    rng = np.random.default_rng(seed)
+    d = np.concatenate([10.0 ** rng.uniform(1.0, 4.5, size=60), rng.uniform(0.0, 2.0, size=n - 61), [0.0]])
+    d = np.sort(d)
+    UtW = rng.standard_normal((n, c))
+    Uty = np.sqrt(lam0 * d + 1.0) * rng.standard_normal(n)
+    UtX = rng.standard_normal((p, n)) * np.sqrt(0.3 * d + 1.0)[None, :]  # SNPs correlated with the structure, as real ones are
+    return UtX, d, UtW, Uty
+
+
+@pytest.mark.parametrize("c,gs", [(1, 0.9), (3, 0.9), (1, -3e-4), (2, -6e-5)])
+def test_table_search_reproduces_the_oracles_lambda(harness, tmp_path, oracle, c, gs):
+    """gs > 0: a heritable trait on a simulated kinship, lambda-hat around 1; gs < 0: -gs is the true lambda of a trait with next
+    to no heritability on a spectrum with large eigenvalues, lambda-hat in the decades below 1e-3 (Q-form intervals)."""
     n, p = 500, 420
-    UtX, d, UtW, Uty = _case(oracle, n, p, c, seed=77 + c)
+    if gs > 0:
+        UtX, d, UtW, Uty = _case(oracle, n, p, c, seed=77 + c, gs=gs)
+    else:
+        UtX, d, UtW, Uty = _case_low_lambda(n, p, c, -gs, seed=177 + c)
     l_mle, logl0 = oracle.calc_lambda_null("L", d, UtW, Uty)
     ref = oracle.lmm_batch_UtX(4, d, UtW, Uty, np.ascontiguousarray(UtX), l_mle_null=l_mle, logl_mle_H0=logl0)
     lam = _grid()
@@ -172,14 +203,15 @@ def test_table_search_reproduces_the_oracles_lambda(harness, tmp_path, oracle, c
             if len(br) != 1 or not (lam[0] < lh < lam[-1]):
                 continue  # boundary optimum: no bracket produced lambda-hat (the choice between candidates is not under test)
             j = br[0]
-            mid, half, fix, rows = series[j]
-            cases.append([np.array([lam[j], lam[j + 1], dv[j], dv[j + 1], 1e-5, 1e5, mid, 1.0 / half, lam[j]]), rows[s], fix])
+            mid, half, head, fix, rows = series[j]
+            cases.append([np.array([lam[j], lam[j + 1], dv[j], dv[j + 1], 1e-5, 1e5, mid, 1.0 / half, lam[j]]), head[s], rows[s], fix])
             who.append(s)
-        assert len(cases) > 0.6 * p
+        low = sum(1 for k in cases if k[0][1] <= QFORM_BELOW * (1 + 1e-9))
+        assert len(cases) > 0.6 * p and (gs > 0 or low > 0.5 * p), (len(cases), low)
         out = _run(harness, tmp_path, c, reml, n, cases)
         ok = out[:, 0] == 0  # PB_OK; PB_OUTSIDE (3) = Newton left the widened interval: the kernel repeats those streaming
         assert np.mean(ok) > 0.97 and set(out[~ok, 0]) <= {3.0}, (np.mean(ok), set(out[:, 0]))
         rel = np.abs(out[ok, 1] - ref[key][np.array(who)[ok]]) / ref[key][np.array(who)[ok]]
-        print("table search %s c=%d: %d SNPs, outside %d, max rel %.3e, frac <= 1e-6 %.4f" % (
-            key, c, ok.sum(), (~ok).sum(), rel.max(), np.mean(rel <= 1e-6)))
+        print("table search %s c=%d gs=%g: %d SNPs (%d in Q-form intervals), outside %d, max rel %.3e, frac <= 1e-6 %.4f" % (
+            key, c, gs, ok.sum(), low, (~ok).sum(), rel.max(), np.mean(rel <= 1e-6)))
         assert rel.max() < 1e-3 and np.mean(rel <= 1e-6) >= 0.98

@@ -271,3 +271,20 @@ def test_shard_range_rule_matches_the_python_side():
             for r in range(w):
                 b = min(p, per * r)
                 assert shard_range(p, r, w) == (b, min(p, b + per))
+
+
+def test_failed_rank_does_not_hang_the_run(driver, tmp_path):
+    """with `-k K -gpus N` only rank 0 reads the kinship; when that fails (here: a truncated file) the other ranks
+    sit in the broadcast, which has no time-out.  The parent must end them and report the failure instead of waiting for ever."""
+    import subprocess
+    out = str(tmp_path)
+    base = ["-bfile", os.path.join(fc.TXT, "P"), "-outdir", out]
+    fc.drive(driver, *base, "-gk", "-o", "P")
+    good = open(os.path.join(out, "P.cXX.txt")).read().split("\n")
+    bad = os.path.join(out, "bad.cXX.txt")
+    with open(bad, "w") as f:
+        f.write("\n".join(good[: len(good) // 2]) + "\nnot_a_number\t1\n")
+    r = subprocess.run([driver] + [str(a) for a in base + ["-k", bad, "-lmm", 1, "-gpus", 2, "-o", "hang"]],
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0
+    assert not os.path.exists(os.path.join(out, "hang.assoc.txt"))

@@ -131,8 +131,13 @@ def test_config4_shape_unfused_int8_planes_n33000(gpu_api, oracle):
     scale = np.abs(Xi6) @ np.abs(Uh)
     err8 = float(np.max(np.abs(utx8 - exact) / scale))
     err64 = float(np.max(np.abs(utx64 - exact) / scale))
-    _record("U^T x at n=%d, 6 rows: int8-digit product (6 digits) max err %.2e, fp64 MFMA GEMM max err %.2e "
-            "(units of sum|x||u|; bar 64 x 2.3e-16 = 1.47e-14)" % (n, err8, err64))
+    # where the two maxima sit and what the typical error is (the two maxima were the same number)
+    e8m, e64m = np.abs(utx8 - exact) / scale, np.abs(utx64 - exact) / scale
+    w8, w64 = np.unravel_index(np.argmax(e8m), e8m.shape), np.unravel_index(np.argmax(e64m), e64m.shape)
+    _record("U^T x at n=%d, 6 rows: int8-digit product (6 digits) max err %.2e at %s (rms %.2e), fp64 MFMA GEMM max err %.2e at %s "
+            "(rms %.2e) (units of sum|x||u|; bar 64 x 2.3e-16 = 1.47e-14); at the int8 maximum: exact %.17g int8 %.17g fp64 %.17g, "
+            "eigenvalue there %.3e" % (n, err8, w8, float(np.sqrt(np.mean(e8m ** 2))), err64, w64, float(np.sqrt(np.mean(e64m ** 2))),
+                                       exact[w8], utx8[w8], utx64[w8], float(ev[w8[1]])))
     assert err8 < 64 * 2.3e-16 and err64 < 64 * 2.3e-16, (err8, err64)
     ref = oracle.lmm_analyze(1, Uh, ev.cpu().numpy(), UtW.cpu().numpy(), Uty.cpu().numpy(), X,
                              plink_nan_rule=1)
@@ -195,3 +200,46 @@ def test_config5_mvlmm_n10000_three_traits(gpu_api, oracle):
     sub = {k: np.asarray(v)[sample] for k, v in got.items()}
     _compare(sub, ref, "config5 n=10000 d=3")
     _record("parity[config5 n=10000 d=3 mvLMM -lmm 4] %d sampled SNPs within the mvLMM bar (>= 97 %% at 1e-6, all at 5e-3)" % S)
+
+
+def test_six_digit_rounding_of_U_is_what_the_model_says(gpu_api, oracle, monkeypatch):
+    """From n = 16384 up U enters the int8 product rounded to 6 base-256 digits (46 bits below each column's binade) instead
+    of 7 (54 bits): the same rows through both (GEMMA_HIP_I8_DIGITS) at n = 16640.  The difference must be there (non-zero),
+    inside the rigorous bound sum_k |x_k| (2^(e_j-47) + 2^(e_j-55)) + assembly roundings, and of the size the error model of
+    DESIGN 3.1b gives (rms = 2^(e_j-47) |x|_2 / sqrt(3) for uniformly distributed roundings) -- a test that fails if the
+    6-digit path loses more than it should, or silently runs 7 digits."""
+    import torch
+    import bench
+    from gemma_amd import _lib as L
+    n, S = 16640, 48
+    ch = _device_chain(gpu_api, n, 20000, seed=16640)
+    U, ev, UtW, Uty = ch["U"], ch["ev"], ch["UtW"], ch["UtY"][:, 0].contiguous()
+    blk = bench.synth_block(torch, n, 256, ch["gen"], ch["dev"])
+    raw = blk[:S].cpu().numpy()
+    utx = {}
+    for dg in ("7", "6"):
+        monkeypatch.setenv("GEMMA_HIP_I8_DIGITS", dg)
+        lmm = gpu_api.LMM(a_mode=1)
+        lmm.setup(U, ev, UtW, Uty, plink=True)
+        try:
+            utx[dg] = lmm.dbg_utx(raw, L.GENO_PLINK_2BIT, 1)
+        finally:
+            lmm.finish()
+    monkeypatch.delenv("GEMMA_HIP_I8_DIGITS")
+    Uh = U.cpu().numpy()
+    Xi = oracle.impute_mean(oracle.bed_decode(raw, n))
+    cmax = np.abs(Uh).max(axis=0)
+    ej = np.frexp(cmax)[1].astype(np.float64)  # cmax < 2^ej
+    diff = np.abs(utx["6"] - utx["7"])
+    bound = np.abs(Xi).sum(axis=1)[:, None] * (np.exp2(ej - 47) + np.exp2(ej - 55))[None, :]
+    slack = 4 * 2.3e-16 * (np.abs(Xi) @ np.abs(Uh))
+    model_rms = np.sqrt((Xi ** 2).sum(axis=1))[:, None] * np.exp2(ej - 47)[None, :] / np.sqrt(3.0)
+    ratio = float(np.sqrt(np.mean(diff ** 2)) / np.sqrt(np.mean(model_rms ** 2)))
+    scale = np.abs(Xi) @ np.abs(Uh)
+    _record("6 vs 7 digits of U at n=%d, %d rows: max |diff| / bound %.3f, rms diff / model rms %.3f, max diff %.2e rms %.2e "
+            "(units of sum|x||u|), exactly equal entries %.4f" % (n, S, float(np.max(diff / (bound + slack))), ratio,
+                                                                 float(np.max(diff / scale)), float(np.sqrt(np.mean((diff / scale) ** 2))),
+                                                                 float(np.mean(diff == 0))))
+    assert diff.max() > 0 and np.mean(diff == 0) < 0.5  # two different roundings of U
+    assert np.all(diff <= bound + slack)
+    assert 0.3 < ratio < 1.5

@@ -641,8 +641,9 @@ def test_lmm_plink_through_int8_digit_product(gpu_api, oracle, monkeypatch, i8):
 
 
 def test_hard_call_detection_picks_the_product(gpu_api, oracle, monkeypatch):
-    """fp64 input: rows holding only 0/1/2 + one missing (NaN) or imputed value take the exact int8-digit product,
-    dosages take the fp64 GEMM; both agree with the oracle and with each other (GEMMA_HIP_UTX_I8=0)."""
+    """fp64 input: rows holding only 0/1/2 + one missing (NaN) or imputed value take the exact int8-digit product, fixed-point
+    dosages the int8-digit dosage planes, anything else the fp64 GEMM; all agree with the oracle and with each other
+    (GEMMA_HIP_UTX_I8=0)."""
     from gemma_amd import _lib as L
     X, U, ev, UtW, Uty, _ = _synthetic(oracle, 330, 150, 2, seed=4242, miss=0.03)
     ref = oracle.lmm_analyze(1, U, ev, UtW, Uty, X)
@@ -666,9 +667,13 @@ def test_hard_call_detection_picks_the_product(gpu_api, oracle, monkeypatch):
     assert nb == 1
     _cmp_stats(b, ref, 1, "xlarge-hardcall")
     Xd = X.copy()
-    Xd[3, 5] = 0.37                                            # one dosage value: the whole batch takes the fp64 GEMM
+    Xd[3, 5] = 0.37                                            # a fixed-point dosage k/100: the int8-digit dosage planes (round 3)
     c, nc = run(Xd, L.GENO_F64_SNP_MAJOR)
-    assert nc == 0
+    assert nc == 1 and gpu_api.last_utx_path() == 2
+    _cmp_stats(c, oracle.lmm_analyze(1, U, ev, UtW, Uty, Xd), 1, "bimbam-dosage-k/100")
+    Xd[3, 5] = 0.123456                                        # one value off both grids: the whole batch takes the fp64 GEMM
+    c, nc = run(Xd, L.GENO_F64_SNP_MAJOR)
+    assert nc == 0 and gpu_api.last_utx_path() == 0
     _cmp_stats(c, oracle.lmm_analyze(1, U, ev, UtW, Uty, Xd), 1, "bimbam-dosage")
     monkeypatch.setenv("GEMMA_HIP_UTX_I8", "0")
     d, nd = run(X, L.GENO_F64_SNP_MAJOR)
@@ -933,3 +938,44 @@ def test_lmm_bimbam_dosages_match_the_oracle(gpu_api, oracle):
             os.environ.pop("GEMMA_HIP_UTX_DOSAGE_I8", None)
     for mode, got in outs.items():
         _cmp_stats(got, ref, 4, "bimbam dosage k/100 DOSAGE_I8=%s" % mode)
+
+
+@pytest.mark.parametrize("c,lam0", [(1, 3e-4), (2, 6e-5)])
+def test_low_heritability_trait_stays_on_the_tables(gpu_api, oracle, monkeypatch, c, lam0):
+    """lambda-hat in the decades below 1e-3 (a trait with next to no heritability on a kinship with large eigenvalues): round 2
+    handed those brackets to the streaming evaluations; now their intervals are tabulated in Q form (lmm_search.hip.h).  The
+    rotated problem is fed directly (U = I, eval = the spectrum): tables on (default), GEMMA_HIP_CHEB_LOWLAMBDA=0 (streaming
+    below 1e-3) and the oracle must agree, and most lambda-hats must really lie below 1e-3."""
+    rng = np.random.default_rng(900 + c)
+    n, p = 512, 300
+    d = np.sort(np.concatenate([10.0 ** rng.uniform(1.0, 4.5, size=60), rng.uniform(0.0, 2.0, size=n - 61), [0.0]]))
+    W = rng.standard_normal((n, c))
+    y = np.sqrt(lam0 * d + 1.0) * rng.standard_normal(n)
+    X = rng.standard_normal((p, n)) * np.sqrt(0.3 * d + 1.0)[None, :]
+    I = np.eye(n)
+    l_mle, logl0 = oracle.calc_lambda_null("L", d, W, y)
+    ref = oracle.lmm_batch_UtX(4, d, W, y, np.ascontiguousarray(X), l_mle_null=l_mle, logl_mle_H0=logl0)
+    assert np.mean(ref["lambda_remle"] < 1e-3) > 0.9 and np.mean(ref["lambda_remle"] > 1e-5) > 0.6
+    for low in ("1", "0"):
+        monkeypatch.setenv("GEMMA_HIP_CHEB_LOWLAMBDA", low)
+        got = gpu_api.LMM(a_mode=4, l_mle_null=l_mle, logl_mle_H0=logl0).AnalyzeBimbam(I, d, W, y, X)
+        _cmp_stats(got, ref, 4, "low-lambda trait c=%d lam0=%g tables_below_1e-3=%s" % (c, lam0, low))
+
+
+@pytest.mark.parametrize("S", [1.0e2, 1.0e4])
+def test_kinship_in_other_units(gpu_api, oracle, S):
+    """Only lambda * delta enters the likelihood: the same trait on S * K has lambda-hat / S and the same beta, se, p.  A
+    whole spectrum times 1e4 (every non-zero eigenvalue large, lambda-hat of every SNP in the decades below 1e-3) must go
+    through the null model and the per-SNP stage like the oracle does."""
+    X, U, ev, UtW, _, _ = _synthetic(oracle, 400, 200, 1, seed=515)
+    Uty = np.sqrt(ev + 1.0) * np.random.default_rng(516).standard_normal(400)  # a trait with lambda = 1 on K
+    evS = ev * S
+    l_r, logl_r = oracle.calc_lambda_null("R", evS, UtW, Uty)
+    l_m, logl_m = oracle.calc_lambda_null("L", evS, UtW, Uty)
+    nm = gpu_api.CalcLambdaNull(evS, UtW, Uty, trace_G=float(evS.mean()))
+    print("S=%g: oracle l_remle %.6e l_mle %.6e; gpu %r" % (S, l_r, l_m, nm))
+    assert nm["l_remle_null"] == pytest.approx(l_r, rel=1e-3) and nm["l_mle_null"] == pytest.approx(l_m, rel=1e-3)
+    assert nm["logl_mle_H0"] == pytest.approx(logl_m, rel=1e-9)
+    ref = oracle.lmm_analyze(4, U, evS, UtW, Uty, X, l_mle_null=l_m, logl_mle_H0=logl_m)
+    got = gpu_api.LMM(a_mode=4, l_mle_null=l_m, logl_mle_H0=logl_m).AnalyzeBimbam(U, evS, UtW, Uty, X)
+    _cmp_stats(got, ref, 4, "kinship x %g" % S)

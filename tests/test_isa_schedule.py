@@ -1,0 +1,64 @@
+"""Build-quality guard for the dominant kernel (CPU; needs only the built library and llvm-objdump): the steady-state K loop of
+i8gemm_sparse2_kernel must be what gemma_amd/csrc/i8gemm_sparse2.hip.h writes down -- 16 dense + 8 sparse matrix instructions,
+4 LDS-DMA pieces, 12 ds_read_b128, ONE counted vmcnt wait and no compiler-inserted `s_waitcnt vmcnt(0)` (round 2's kernel lost
+its two-tiles-ahead prefetch to exactly that), no two consecutive matrix instructions on one accumulator, no scratch."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB = os.path.join(ROOT, "gemma_amd", "libgemma_hip.so")
+OBJDUMP = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+
+
+def _kernel_text(tmp_path, symbol):
+    work = tmp_path / "o"
+    work.mkdir()
+    shutil.copy(LIB, work / "lib.so")
+    subprocess.run([OBJDUMP, "--offloading", "lib.so"], cwd=work, check=True, capture_output=True)
+    for f in sorted(os.listdir(work)):
+        if "gfx950" not in f:
+            continue
+        dis = subprocess.run([OBJDUMP, "-d", f], cwd=work, check=True, capture_output=True, text=True).stdout
+        m = re.search(r"^[0-9a-f]+ <(_ZN9gemma_hip\d+%s[^>]*)>:\n(.*?)(?=^\S|\Z)" % symbol, dis, re.S | re.M)
+        if m:
+            return m.group(2).split("\n")
+    return None
+
+
+@pytest.mark.skipif(not (os.path.exists(LIB) and os.path.exists(OBJDUMP)), reason="needs the built library and llvm-objdump")
+def test_sparse2_kernel_steady_state_loop_is_as_written(tmp_path):
+    lines = _kernel_text(tmp_path, "i8gemm_sparse2_kernel")
+    assert lines, "i8gemm_sparse2_kernel not found in the gfx950 code object"
+    ops = [ln.split("//")[0].strip() for ln in lines if ln.strip()]
+    # the steady-state loop: the backward branch whose body holds the most matrix instructions
+    addr = []
+    for ln in lines:
+        m = re.search(r"//\s*([0-9A-F]{8,16}):", ln)
+        addr.append(int(m.group(1), 16) if m else None)
+    best = None
+    for i, op in enumerate(ops):
+        m = re.match(r"s_cbranch_scc1\s+(\d+)", op)
+        if not m or int(m.group(1)) < 32768:  # backward: the 16-bit offset is negative
+            continue
+        target = addr[i] + 4 + 4 * (int(m.group(1)) - 65536)
+        j = next(k for k in range(i) if addr[k] == target)
+        body = ops[j:i + 1]
+        nm = sum(("v_mfma" in o) or ("v_smfmac" in o) for o in body)
+        if best is None or nm > best[0]:
+            best = (nm, body)
+    assert best is not None
+    body = best[1]
+    cnt = lambda pat: sum(bool(re.match(pat, o)) for o in body)
+    assert cnt(r"v_mfma_i32_32x32x32_i8") == 16 and cnt(r"v_smfmac_i32_32x32x64_i8") == 8
+    assert cnt(r"global_load_lds_dwordx4") == 4 and cnt(r"ds_read_b128") == 12
+    assert cnt(r"s_barrier") == 1
+    assert cnt(r"s_waitcnt vmcnt\(8\)") == 1 and cnt(r"s_waitcnt vmcnt\(0\)") == 0, [o for o in body if "vmcnt" in o]
+    assert not any(o.startswith(("scratch_", "buffer_store", "buffer_load_dword ")) for o in body)
+    mats = [re.match(r"v_s?mfmac?\w*\s+(v\[\d+:\d+\])", o).group(1) for o in body if re.match(r"v_s?mfma", o)]
+    assert len(mats) == 24 and all(a != b for a, b in zip(mats, mats[1:] + mats[:1])), mats
+    # every accumulator block is visited the same number of times: 4 genotype + 4 mask accumulators
+    assert sorted(mats.count(a) for a in set(mats)) == [2] * 4 + [4] * 4

@@ -436,3 +436,27 @@ def test_issue188_analyze_gene(oracle, i188, mode):
     U, ev, _ = oracle.eigen_decomp_zeroed(oracle.center_matrix(K10[np.ix_(sel, sel)]))
     got = oracle.gene_analyze(mode, U, ev, U.T @ W, U.T @ i188["y_all"][sel], np.ascontiguousarray(fx["expr"][:, sel]))
     R.assert_stats(got, fx, "lmm%d" % mode)
+
+
+def test_reference_setup_stages_through_the_bridge(oracle, tmp_path):
+    """oracle/ref_bridge.cpp: ref_plink_kin = the reference's own PlinkKin on a .bed file, ref_eigen_decomp_zeroed = its own
+    EigenDecomp_Zeroed -- what bench.py's cpu_baseline.setup times -- against the restatement."""
+    if oracle.ref_lib() is None:
+        pytest.skip("oracle/_ref/libgemma_ref.so not built (no reference tree here)")
+    rng = np.random.default_rng(11)
+    n, p = 211, 333
+    codes = rng.choice([0, 1, 2, 3], size=(p, n), p=[0.3, 0.03, 0.37, 0.3]).astype(np.uint8)
+    nb = (n + 3) // 4
+    pad = np.zeros((p, nb * 4), np.uint8)
+    pad[:, :n] = codes
+    raw = (pad[:, 0::4] | (pad[:, 1::4] << 2) | (pad[:, 2::4] << 4) | (pad[:, 3::4] << 6)).astype(np.uint8)
+    bed = tmp_path / "t.bed"
+    bed.write_bytes(bytes([0x6C, 0x1B, 0x01]) + raw.tobytes())
+    K = oracle.ref_plink_kin(str(bed), n, p, 1)
+    K2 = oracle.calc_kin(oracle.bed_decode(raw, n), 1)
+    assert np.max(np.abs(K - K2)) <= 1e-13 * np.max(np.abs(K2))
+    G = oracle.center_matrix(K2)
+    U, ev, tr = oracle.ref_eigen_decomp_zeroed(G)
+    U2, ev2, tr2 = oracle.eigen_decomp_zeroed(G)
+    assert np.allclose(ev, ev2, rtol=0, atol=1e-12) and tr == pytest.approx(tr2, rel=1e-12)
+    assert np.max(np.abs(U @ np.diag(ev) @ U.T - G)) < 1e-11
