@@ -264,12 +264,14 @@ def main():
             # GEMM-form fp64 rate the stage replaces (SURVEY 8d's 2 n^2 p), comparable with the fp64 SYRK's figure.
             setup_info["roofline_kinship"] = {
                 "kernel": "kin_i8 stage: i8gemm_packed_kernel_t<false> (G^T G) + kin_i8_accum_kernel + kin_i8_corr_kernel",
-                "bound": "valu (kin_i8_corr_kernel, 58 % of the stage) / mfma int8 (25 %)", "unit": "TFLOP/s (fp64 GEMM-form equivalent)",
-                "achieved": setup_info["kinship_gemm_tflops"], "peak": 78.6,
-                "frac": round(setup_info["kinship_gemm_tflops"] / 78.6, 4), "launch_ms_total": round(kin_ms, 3),
-                "blocks": kin_n,
-                "note": "frac > 1: the stage runs faster than an fp64 GEMM at the matrix pipe's peak could; exact integers, "
-                        "K agrees with the fp64 SYRK path to 1e-14 (tests/test_gpu_parity.py)"}
+                "bound": "valu (kin_i8_corr_kernel, ~60 % of the stage: 6 VALU per (missing call, individual) pair) / mfma int8 (G^T G, ~25 %)",
+                "launch_ms_total": round(kin_ms, 3), "blocks": kin_n,
+                "equiv_fp64_tflops": setup_info["kinship_gemm_tflops"],
+                "equiv_fp64_ratio": round(setup_info["kinship_gemm_tflops"] / 78.6, 4),
+                "equiv_note": "GEMM-form fp64 rate the stage replaces (SURVEY 8d: 2 n^2 p) over the fp64 MFMA peak -- a ratio of two "
+                              "different arithmetics, NOT a roofline fraction (exact integers; K agrees with the fp64 SYRK to 1e-14)",
+                "gtg_int8": "G^T G alone: 7.3 ms per 20000-SNP block at n = 20000 = 2.19 POP/s = 0.44 of the dense int8 peak "
+                            "(profiles/r02_kin_i8_stats.csv; the per-kernel split is not measured inside bench.py)"}
         elif kin_ms:
             # K = Xc Xc^T as a SYRK: only the 128 x 128 tiles with tile_n >= tile_m are launched (dgemm_mfma.hip.h), so the
             # flops EXECUTED are tiles * 2 * 128^2 * p; SURVEY 8(d)'s GEMM-form figure 2 n^2 p (what the reference's
