@@ -595,7 +595,8 @@ def main():
             # (One random covariate instead of the intercept: U^T 1 lies in the null space of the centred kinship, and with the
             # eigenvalues times 1e4 the REFERENCE's own REML Newton iteration fails on that structure -- NaN in the oracle too.)
             ev2 = (ev * S).contiguous()
-            Uty2 = Uty
+            Uty2 = Uty.clone()
+            Uty2[torch.argmin(ev)] = 0.0  # the phenotype's mean (its component along the kinship's null vector): no intercept here to absorb it
             UtW2 = torch.randn((n, 1), dtype=torch.float64, device=dev, generator=gen)
             nm2 = api.CalcLambdaNull(ev2.cpu().numpy(), UtW2.cpu().numpy(), Uty2.cpu().numpy(), trace_G=float(ev2.mean()))
             lmm2 = api.LMM(a_mode=args.a_mode, l_mle_null=nm2["l_mle_null"], logl_mle_H0=nm2["logl_mle_H0"])

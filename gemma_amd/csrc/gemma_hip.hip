@@ -974,6 +974,12 @@ static int make_cheb(hipStream_t s) {
   a.cheb_xa0 = gg.nbx * 16;
   a.cheb_j0 = j0;
   a.cheb_nint = nint;
+  a.cheb_qmask = g_ctx.cheb_qmask;
+  {
+    // GEMMA_HIP_ASSOC_FINAL_SERIES=0: the final likelihood at lambda-hat streams the SNP's row as in round 2
+    const char *ef = getenv("GEMMA_HIP_ASSOC_FINAL_SERIES");
+    a.cheb_final = (ef && ef[0] == '0') ? 0 : 1;
+  }
   a.have_cheb = 1;
   return GEMMA_HIP_OK;
 }

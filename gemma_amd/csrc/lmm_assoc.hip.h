@@ -74,6 +74,9 @@ struct AssocArgs {
   int cheb_ld, cheb_fld, cheb_xa0;
   int cheb_j0, cheb_nint;
   int have_cheb;
+  unsigned long long cheb_qmask; // bit k: interval k is tabulated in Q form (series of sum a b delta H; lmm_search.hip.h)
+  int cheb_final;          // 1: the final likelihood at lambda-hat (and with it CalcRLWald's sums) is assembled from the bracket's
+                           //    series too -- the SNP's row is not read at all when its search ran on the tables
   int cheb_logdet_off;     // offset of the series of sum_i log(lambda delta_i + 1) inside an interval's cheb_F block
   const double *cheb_iv;   // [k][2] = {mid, 1 / half} of interval k in t = log(lambda)
   double cheb_mid[ASSOC_MAX_REGION], cheb_inv_half[ASSOC_MAX_REGION];
@@ -430,6 +433,49 @@ struct FixedC {
     R.logdet = 0.0;
     finish<ORDER>(R, A);
   }
+  // The order-1 evaluation at a lambda inside tabulated interval kint (sv = its position in [-1, 1]) from the SNP's series
+  // of that interval (slot) and the SNP-independent series -- what LogRL_f / LogL_f and CalcRLWald need at lambda-hat, without
+  // a pass over the SNP's row.  Q-form intervals: S = S0 - lambda Q with S0 from the fixed-lambda table's weight-1 column.
+  __device__ __forceinline__ void eval_cheb(const AssocArgs &g, const double *__restrict__ trow, int kint, int slot, double l,
+                                            double sv, Agg &A) const {
+    Row0<C> R;
+    const double *__restrict__ snp = g.cheb_T + (long)kint * g.cheb_cap * g.cheb_ld + slot;
+    const double *__restrict__ fix = g.cheb_F + (long)kint * g.cheb_fld;
+    const bool qf = (g.cheb_qmask >> kint) & 1ull;
+    constexpr int NPAIR = (C + 1) * (C + 2) / 2;
+#pragma unroll
+    for (int a = 1; a <= C + 2; ++a) {
+#pragma unroll
+      for (int b = a; b <= C + 2; ++b) {
+        const int q = ab_index<C>(a, b);
+        const bool ax = (a == C + 1), bx = (b == C + 1);
+        const int fa = (a == C + 2) ? C : a - 1, fb = (b == C + 2) ? C : b - 1;
+        double v, d1, d2, s0;
+        if (ax && bx) {
+          cheb_eval<0>(snp, g.cheb_cap, sv, v, d1, d2);
+          s0 = trow[0];
+        } else if (ax || bx) {
+          const int f = ax ? fb : fa;
+          cheb_eval<0>(snp + (long)(g.cheb_xa0 + f * CHEB_N) * g.cheb_cap, g.cheb_cap, sv, v, d1, d2);
+          s0 = trow[g.grid_xa0 + f * g.grid_nq];
+        } else {
+          const int pidx = fa * (C + 1) - fa * (fa - 1) / 2 + (fb - fa);
+          cheb_eval<0>(fix + pidx * CHEB_N, 1, sv, v, d1, d2);
+          s0 = g.grid_F[pidx];
+        }
+        R.s1[q] = qf ? s0 - l * v : v;
+        R.s2[q] = 0.0;
+        R.s3[q] = 0.0;
+      }
+    }
+    double gsum, ld, d1, d2;
+    cheb_eval<0>(fix + NPAIR * CHEB_N, 1, sv, gsum, d1, d2);
+    cheb_eval<0>(fix + g.cheb_logdet_off, 1, sv, ld, d1, d2);
+    R.tr1 = (double)g.n - gsum; // sum H = n - sum (1 - H)
+    R.tr2 = 0.0;
+    R.logdet = ld;
+    finish<1>(R, A);
+  }
 };
 
 // any number of covariates (c <= GEN_CMAX): the (c+2) x (c+2) product table is covered by 4 x 4 register
@@ -691,7 +737,20 @@ __device__ __forceinline__ double logf(const SnpCtx<M> &s, double l, Agg &A, int
         }
       }
     }
-    if (have_ld) {
+    bool done = false;
+    if constexpr (M::HAS_CHEB) {
+      if (have_ld && s.g->cheb_final && s.trow) {
+        const int slot = __builtin_amdgcn_readfirstlane(s.cslots[kint]);
+        if (slot >= 0) {
+          const double sv = (log(l) - s.g->cheb_iv[2 * kint]) * s.g->cheb_iv[2 * kint + 1];
+          s.m.eval_cheb(*s.g, s.trow, kint, slot, l, sv, A);
+          done = true;
+        }
+      }
+    }
+    if (done) {
+      // everything came from the series (A.logdet included)
+    } else if (have_ld) {
       s.m.template eval<1, false>(*s.g, s.x, s.y, l, s.lane, A);
       A.logdet = uniform(ldet);
     } else {

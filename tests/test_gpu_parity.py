@@ -979,3 +979,24 @@ def test_kinship_in_other_units(gpu_api, oracle, S):
     ref = oracle.lmm_analyze(4, U, evS, UtW, Uty, X, l_mle_null=l_m, logl_mle_H0=logl_m)
     got = gpu_api.LMM(a_mode=4, l_mle_null=l_m, logl_mle_H0=logl_m).AnalyzeBimbam(U, evS, UtW, Uty, X)
     _cmp_stats(got, ref, 4, "kinship x %g" % S)
+
+
+@pytest.mark.parametrize("n,c", [(500, 1), (402, 3)])
+def test_final_likelihood_from_series_matches_streaming(gpu_api, oracle, monkeypatch, n, c):
+    """Round 3: when a SNP's search ran on the tables, the final LogRL_f / LogL_f at lambda-hat (whose sums also serve
+    CalcRLWald) is assembled from the same series -- no pass over the SNP's row (FixedC::eval_cheb).  Default against
+    GEMMA_HIP_ASSOC_FINAL_SERIES=0 (the streaming pass of round 2) and against the oracle, -lmm 4 so that the REML and the ML
+    likelihood both go through it."""
+    X, U, ev, UtW, _, tr = _synthetic(oracle, n, 300, c, seed=4100 + n)
+    Uty = np.sqrt(0.8 * ev + 1.0) * np.random.default_rng(n).standard_normal(n)  # interior lambda-hat for most SNPs
+    l_mle, logl0 = oracle.calc_lambda_null("L", ev, UtW, Uty)
+    ref = oracle.lmm_analyze(4, U, ev, UtW, Uty, X, l_mle_null=l_mle, logl_mle_H0=logl0)
+    assert np.mean((ref["lambda_remle"] > 1e-4) & (ref["lambda_remle"] < 1e4)) > 0.8
+    res = {}
+    for fs in ("1", "0"):
+        monkeypatch.setenv("GEMMA_HIP_ASSOC_FINAL_SERIES", fs)
+        res[fs] = gpu_api.LMM(a_mode=4, l_mle_null=l_mle, logl_mle_H0=logl0).AnalyzeBimbam(U, ev, UtW, Uty, X)
+        _cmp_stats(res[fs], ref, 4, "n=%d c=%d final likelihood from series=%s" % (n, c, fs))
+    for k in ("beta", "se", "p_wald", "p_lrt", "logl_H1"):
+        ok = np.isfinite(res["1"][k]) & np.isfinite(res["0"][k])
+        np.testing.assert_allclose(res["1"][k][ok], res["0"][k][ok], rtol=2e-7, err_msg=k)
