@@ -107,14 +107,19 @@ __device__ __forceinline__ i32x4 s2_expand(int bits) {
   return v;
 }
 
-__global__ __launch_bounds__(512, 2) void i8gemm_sparse2_kernel(Sparse2Args g) {
+// NI: 32-row blocks per wavefront.  NI = 2: wavefronts 4 (rows) x 2 (columns), 2 x 2 blocks each (the first form of the kernel).
+// NI = 1: wavefronts 8 x 1, one row block x four column blocks each: every record is unpacked by ONE wavefront instead of two
+// (42 instead of 84 VALU per K-tile and wavefront) at the price of 18 instead of 12 ds_read_b128 (the LDS pipe has room).
+template <int NI>
+__global__ __launch_bounds__(512, 2) void i8gemm_sparse2_kernel_t(Sparse2Args g) {
+  constexpr int NJ = 4 / NI;
   extern __shared__ __attribute__((aligned(1024))) int8_t i8lds[];
   int tm, tn;
   {
     const int nwg = gridDim.x, b = blockIdx.x;
     const int q = nwg >> 3, r = nwg & 7, x = b & 7, o = b >> 3;
     const int L = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + o;
-    const int GM = g.gm > 0 ? g.gm : 4;
+    const int GM = g.gm > 0 ? g.gm : 8;
     const int per_group = GM * g.tiles_n;
     const int grp = L / per_group;
     const int first_m = grp * GM;
@@ -129,7 +134,7 @@ __global__ __launch_bounds__(512, 2) void i8gemm_sparse2_kernel(Sparse2Args g) {
   const int nd = (g.fuse && !(odd && plane == 0)) ? 2 : 1;
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-  const int wm = wave >> 1, wn = wave & 1; // rows wm*64, cols wn*64
+  const int wm = NI == 2 ? wave >> 1 : wave, wn = NI == 2 ? wave & 1 : 0; // rows wm * 32 NI, columns wn * 32 NJ
   const int r32 = lane & 31, h = lane >> 5;
 
   // LDS-DMA: a stage is 16 record pieces (piece q: rows 16 q .. 16 q + 15, lane l -> row l / 4, chunk l % 4) and 16 digit pieces
@@ -154,26 +159,26 @@ __global__ __launch_bounds__(512, 2) void i8gemm_sparse2_kernel(Sparse2Args g) {
   // fragment byte offsets inside a stage
   int amo[2], fb[4];
   {
-    const int row = wm * 64 + r32; // block 1: + 32 rows = + 2048 bytes, same swizzle
+    const int row = wm * 32 * NI + r32; // block 1: + 32 rows = + 2048 bytes, same swizzle
 #pragma unroll
     for (int p = 0; p < 2; ++p) amo[p] = row * 64 + (((2 * p + h) ^ ((row >> 2) & 3)) << 4);
-    const int col = wn * 64 + r32; // block 1: + 32 columns = + 4096 bytes
+    const int col = wn * 32 * NJ + r32; // block j: + 32 j columns = + 4096 j bytes (same swizzle)
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) fb[ks] = S2_AMB + col * 128 + (((2 * ks + h) ^ ((col >> 1) & 7)) << 4);
   }
 
-  i32x16 accg[2][2], accm[2][2];
+  i32x16 accg[NI][NJ], accm[NI][NJ];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < NI; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < NJ; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) { accg[i][j][r] = 0; accm[i][j][r] = 0; }
 
-  i32x4 am[2][2]; // records [pair parity][row block]
-  i32x4 ga[2][2]; // genotype operands [K-step parity][row block]
-  i32x4 bb[2][2]; // digit fragments [K-step parity][column block]
-  i32x4 ms[2];    // sparse operand values of the current pair [row block]
+  i32x4 am[2][NI]; // records [pair parity][row block]
+  i32x4 ga[2][NI]; // genotype operands [K-step parity][row block]
+  i32x4 bb[2][NJ]; // digit fragments [K-step parity][column block]
+  i32x4 ms[NI];    // sparse operand values of the current pair [row block]
 
 #define S2_DMA_A(j, SOFF)                                                                                         \
   do {                                                                                                            \
@@ -245,6 +250,46 @@ __global__ __launch_bounds__(512, 2) void i8gemm_sparse2_kernel(Sparse2Args g) {
     S2_G(3, 1, 1); GEMMA_SB();                                                                                    \
   } while (0)
 
+// The same K-tile for NI = 1 (one row block x four column blocks): groups G(0) | S(P0) | G(1) | G(2) | S(P1) | G(3) over the
+// column blocks j = 0..3; the eight digit-fragment reads of a pair of steps go two per slot behind the first two instructions
+// of a group (no read younger than two matrix instructions at the next group's wait).
+#define S2_KTILE_81(SC, SN, SD, MORE, LOAD3, VMW)                                                                 \
+  do {                                                                                                            \
+    S2_G(0, 0, 0); S2_RB(SC, 1, 0); S2_RB(SC, 1, 1); GEMMA_SB();                                                  \
+    S2_G(0, 0, 1); S2_RB(SC, 1, 2); S2_RB(SC, 1, 3); GEMMA_SB();                                                  \
+    S2_G(0, 0, 2); S2_EXP(0, 0); if ((LOAD3) && S2_LOOPDMA) S2_DMA_A(0, SD); GEMMA_SB();                          \
+    S2_G(0, 0, 3); GEMMA_SB();                                                                                    \
+    S2_S(0, 0, 0); S2_RAM(SC, 1, 0); GEMMA_SB();                                                                  \
+    S2_S(0, 0, 1); S2_UNP(1, 0); GEMMA_SB();                                                                      \
+    S2_S(0, 0, 2); if ((LOAD3) && S2_LOOPDMA) S2_DMA_A(1, SD); GEMMA_SB();                                        \
+    S2_S(0, 0, 3); GEMMA_SB();                                                                                    \
+    S2_G(1, 0, 0); S2_UNP(2, 0); GEMMA_SB(); S2_RB(SC, 2, 0); S2_RB(SC, 2, 1); GEMMA_SB();                        \
+    S2_G(1, 0, 1); S2_RB(SC, 2, 2); S2_RB(SC, 2, 3); GEMMA_SB();                                                  \
+    S2_G(1, 0, 2); if ((LOAD3) && S2_LOOPDMA) S2_DMA_B(0, SD); GEMMA_SB();                                        \
+    S2_G(1, 0, 3); if ((LOAD3) && S2_LOOPDMA) S2_DMA_B(1, SD); GEMMA_SB();                                        \
+    S2_G(2, 0, 0); S2_RB(SC, 3, 0); S2_RB(SC, 3, 1); GEMMA_SB();                                                  \
+    S2_G(2, 0, 1); S2_RB(SC, 3, 2); S2_RB(SC, 3, 3); GEMMA_SB();                                                  \
+    asm volatile("s_waitcnt vmcnt(" #VMW ")" ::: "memory");                                                       \
+    __builtin_amdgcn_s_barrier();                                                                                 \
+    GEMMA_SB();                                                                                                   \
+    S2_G(2, 0, 2); S2_EXP(1, 0); GEMMA_SB();                                                                      \
+    S2_G(2, 0, 3); GEMMA_SB();                                                                                    \
+    S2_S(1, 0, 0); if (MORE) S2_RAM(SN, 0, 0); GEMMA_SB();                                                        \
+    S2_S(1, 0, 1); S2_UNP(3, 0); GEMMA_SB();                                                                      \
+    S2_S(1, 0, 2); GEMMA_SB();                                                                                    \
+    S2_S(1, 0, 3); GEMMA_SB();                                                                                    \
+    S2_G(3, 0, 0); if (MORE) S2_UNP(0, 0); GEMMA_SB();                                                            \
+    if (MORE) { S2_RB(SN, 0, 0); S2_RB(SN, 0, 1); } GEMMA_SB();                                                   \
+    S2_G(3, 0, 1); if (MORE) { S2_RB(SN, 0, 2); S2_RB(SN, 0, 3); } GEMMA_SB();                                    \
+    S2_G(3, 0, 2); GEMMA_SB();                                                                                    \
+    S2_G(3, 0, 3); GEMMA_SB();                                                                                    \
+  } while (0)
+#define S2_TILE(SC, SN, SD, MORE, LOAD3, VMW)                                                                     \
+  do {                                                                                                            \
+    if constexpr (NI == 2) S2_KTILE(SC, SN, SD, MORE, LOAD3, VMW);                                                \
+    else S2_KTILE_81(SC, SN, SD, MORE, LOAD3, VMW);                                                               \
+  } while (0)
+
   // the second-dispatched half of the workgroup loses every issue arbitration on age; one static priority step evens it out
   // (MI355X_MICROARCH.md, two waves per SIMD, item 4): 57.2 -> 56.2-56.9 ms (profiles/r03_i8_sparse_ablation.txt)
   if (wave >= 4) __builtin_amdgcn_s_setprio(1);
@@ -253,9 +298,9 @@ __global__ __launch_bounds__(512, 2) void i8gemm_sparse2_kernel(Sparse2Args g) {
     if (dd > 0) { // second digit of a fused pair: acc = 256 * C_hi, then accumulate C_lo on top
       asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < NI; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NJ; ++j)
 #pragma unroll
           for (int r = 0; r < 16; ++r) { accg[i][j][r] <<= 8; accm[i][j][r] <<= 8; }
     }
@@ -278,25 +323,29 @@ __global__ __launch_bounds__(512, 2) void i8gemm_sparse2_kernel(Sparse2Args g) {
     }
     __builtin_amdgcn_s_barrier();
     GEMMA_SB();
-    S2_RAM(0, 0, 0); S2_RAM(0, 0, 1); S2_RB(0, 0, 0); S2_RB(0, 0, 1);
-    S2_UNP(0, 0); S2_UNP(0, 1);
+#pragma unroll
+    for (int i = 0; i < NI; ++i) S2_RAM(0, 0, i);
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) S2_RB(0, 0, j);
+#pragma unroll
+    for (int i = 0; i < NI; ++i) S2_UNP(0, i);
     GEMMA_SB();
 
     int sc = 0, sn = S2_STAGE, s2 = 2 * S2_STAGE, sd = 3 * S2_STAGE; // stage byte offsets: tiles t, t+1, t+2, DMA target
     int kt = 0;
     for (; kt + 3 < nk; ++kt) {
-      S2_KTILE(sc, sn, sd, true, true, 8);
+      S2_TILE(sc, sn, sd, true, true, 8);
       const int tmp = sc; sc = sn; sn = s2; s2 = sd; sd = tmp;
     }
     if (nk >= 3) {
-      S2_KTILE(sc, sn, sd, true, false, 4);
+      S2_TILE(sc, sn, sd, true, false, 4);
       const int tmp = sc; sc = sn; sn = s2; s2 = sd; sd = tmp;
     }
     if (nk >= 2) {
-      S2_KTILE(sc, sn, sd, true, false, 0);
+      S2_TILE(sc, sn, sd, true, false, 0);
       const int tmp = sc; sc = sn; sn = s2; s2 = sd; sd = tmp;
     }
-    S2_KTILE(sc, sn, sd, false, false, 0);
+    S2_TILE(sc, sn, sd, false, false, 0);
   }
 #undef S2_INIT_SRC
 #undef S2_DMA_A
@@ -308,21 +357,29 @@ __global__ __launch_bounds__(512, 2) void i8gemm_sparse2_kernel(Sparse2Args g) {
 #undef S2_G
 #undef S2_S
 #undef S2_KTILE
+#undef S2_KTILE_81
+#undef S2_TILE
 
   asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
   int *Cg = g.C + (long)plane * g.strideC;
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < NI; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const long col = (long)tn * S2_BN + wn * 64 + j * 32 + r32;
+    for (int j = 0; j < NJ; ++j) {
+      const long col = (long)tn * S2_BN + wn * 32 * NJ + j * 32 + r32;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const long row = (long)tm * S2_BM + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        const long row = (long)tm * S2_BM + wm * 32 * NI + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
         Cg[row * g.ldc + col] = accg[i][j][r];
         Cg[(g.m_row0 + row) * g.ldc + col] = accm[i][j][r];
       }
     }
 }
+
+// the shipped form: wavefronts 8 x 1 (54.4-55.0 ms against 56.5 for 4 x 2 in the same session, profiles/r03_i8_sparse_ablation.txt)
+#ifndef S2_DEFAULT_NI
+#define S2_DEFAULT_NI 1
+#endif
+static constexpr auto i8gemm_sparse2_kernel = i8gemm_sparse2_kernel_t<S2_DEFAULT_NI>;
 
 } // namespace gemma_hip

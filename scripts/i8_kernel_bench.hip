@@ -3,7 +3,8 @@
 // Seconds per run instead of the minute a Python session costs -- the development loop for kernel variants.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -Igemma_amd/csrc scripts/i8_kernel_bench.hip -o /tmp/i8_kernel_bench
 //   /tmp/i8_kernel_bench [n] [B] [variant] [gm]    variant 0 = dense mask product, 1 = sparse mask operand (i8gemm_sparse.hip.h),
-//                                                  2 = records + 256 x 128 tiles (i8gemm_sparse2.hip.h)
+//                                                  2 = records + 256 x 128 tiles (i8gemm_sparse2.hip.h), 3 = the same with
+//                                                  wavefronts 8 x 1 instead of 4 x 2
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -66,7 +67,7 @@ int main(int argc, char **argv) {
   const int variant = argc > 3 ? atoi(argv[3]) : 0;
   const int digits = 6, fuse = 1, nplanes = 3;
   const long ldk = (n + I8_BK - 1) / I8_BK * I8_BK, npad = (n + I8_BN - 1) / I8_BN * I8_BN;
-  const long rowtile = variant == 2 ? 256 : I8P_BM;
+  const long rowtile = variant >= 2 ? 256 : I8P_BM;
   const long lpad = (B + rowtile - 1) / rowtile * rowtile, mrows = 2 * lpad;
   const int gm = argc > 4 ? atoi(argv[4]) : 0;
   int8_t *A, *Bt;
@@ -96,7 +97,7 @@ int main(int argc, char **argv) {
   uint4 *AM = nullptr;
   int *rsur = nullptr;
   dim3 grid2;
-  if (variant == 2) {
+  if (variant >= 2) {
     const long total = lpad * (ldk / I8_BK) * 4;
     CK(hipMalloc(&AM, (size_t)total * sizeof(uint4)));
     CK(hipMalloc(&rsur, lpad * sizeof(int)));
@@ -114,14 +115,20 @@ int main(int argc, char **argv) {
     g2.m_row0 = lpad; g2.tiles_m = (int)(lpad / S2_BM); g2.tiles_n = (int)(npad / S2_BN); g2.nk = (int)(ldk / I8_BK);
     g2.gm = gm; g2.fuse = fuse; g2.digits = digits;
     grid2 = dim3((unsigned)(g2.tiles_m * g2.tiles_n), (unsigned)nplanes);
-    CK(hipFuncSetAttribute(reinterpret_cast<const void *>(i8gemm_sparse2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+    CK(hipFuncSetAttribute(reinterpret_cast<const void *>(i8gemm_sparse2_kernel_t<2>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                           S2_NST * S2_STAGE));
+    CK(hipFuncSetAttribute(reinterpret_cast<const void *>(i8gemm_sparse2_kernel_t<1>), hipFuncAttributeMaxDynamicSharedMemorySize,
                            S2_NST * S2_STAGE));
   }
 #endif
   auto launch = [&]() {
 #if HAVE_SPARSE2
     if (variant == 2) {
-      hipLaunchKernelGGL(i8gemm_sparse2_kernel, grid2, dim3(512), S2_NST * S2_STAGE, 0, g2);
+      hipLaunchKernelGGL(i8gemm_sparse2_kernel_t<2>, grid2, dim3(512), S2_NST * S2_STAGE, 0, g2);
+      return;
+    }
+    if (variant == 3) { // wavefronts 8 x 1
+      hipLaunchKernelGGL(i8gemm_sparse2_kernel_t<1>, grid2, dim3(512), S2_NST * S2_STAGE, 0, g2);
       return;
     }
 #endif
