@@ -839,12 +839,22 @@ extern "C" int gemma_hip_kin_loco_d(const double *K_all_d, size_t ns_all, double
   return GEMMA_HIP_OK;
 }
 
+// more than GEN_CMAX covariates: the wide kernels (one wavefront per workgroup, six tables of gen_ni_for(c) doubles in
+// dynamic LDS)
+static size_t wide_lds_bytes(size_t c) { return (size_t)6 * gen_ni_for((int)c) * 8; }
+template <class K>
+static int wide_attr(K kernel) {
+  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                             (int)wide_lds_bytes(GEN_CMAX_WIDE)));
+  return GEMMA_HIP_OK;
+}
+
 // ------------------------------------------------------------------------------ LMM
 static int lmm_common_setup(const gemma_lmm_cfg *cfg) {
   if (!cfg) return fail(GEMMA_HIP_EINVAL, "lmm_setup: null cfg");
   if (cfg->n == 0 || cfg->n_cvt == 0) return fail(GEMMA_HIP_EINVAL, "lmm_setup: n=%zu n_cvt=%zu", cfg->n, cfg->n_cvt);
-  if (cfg->n_cvt > (size_t)GEN_CMAX)
-    return fail(GEMMA_HIP_EINVAL, "lmm_setup: n_cvt=%zu not supported by this build (1..%d)", cfg->n_cvt, GEN_CMAX);
+  if (cfg->n_cvt > (size_t)GEN_CMAX_WIDE)
+    return fail(GEMMA_HIP_EINVAL, "lmm_setup: n_cvt=%zu not supported by this build (1..%d)", cfg->n_cvt, GEN_CMAX_WIDE);
   if (!(cfg->a_mode == 1 || cfg->a_mode == 2 || cfg->a_mode == 3 || cfg->a_mode == 4 || cfg->a_mode == 9))
     return fail(GEMMA_HIP_EINVAL, "lmm_setup: a_mode %d", cfg->a_mode);
   if (!(cfg->l_max > cfg->l_min) || cfg->n_region == 0 || cfg->n_region > (size_t)ASSOC_MAX_REGION)
@@ -1297,7 +1307,14 @@ static int launch_assoc(const double *UtX, size_t l, size_t ld, gemma_sumstat *o
     case 3: hipLaunchKernelGGL(lmm_assoc_kernel<3>, dim3(grid), dim3(256), 0, s, a); break;
     case 4: hipLaunchKernelGGL(lmm_assoc_kernel<4>, dim3(grid), dim3(256), 0, s, a); break;
     default: // more covariates: register-tiled multi-pass path
-      hipLaunchKernelGGL(lmm_assoc_generic_kernel, dim3(grid), dim3(256), 0, s, a, (int)g_ctx.cfg.n_cvt);
+      if (g_ctx.cfg.n_cvt > (size_t)GEN_CMAX) {
+        int rcw = wide_attr(lmm_assoc_wide_kernel);
+        if (rcw) return rcw;
+        hipLaunchKernelGGL(lmm_assoc_wide_kernel, dim3((unsigned)l), dim3(64), wide_lds_bytes(g_ctx.cfg.n_cvt), s, a,
+                           (int)g_ctx.cfg.n_cvt);
+      } else {
+        hipLaunchKernelGGL(lmm_assoc_generic_kernel, dim3(grid), dim3(256), 0, s, a, (int)g_ctx.cfg.n_cvt);
+      }
       break;
     }
     HIPCHK(hipGetLastError());
@@ -1762,7 +1779,15 @@ extern "C" int gemma_hip_lmm_gene_batch_d(const double *Y_d, size_t l, size_t ld
     case 2: hipLaunchKernelGGL(lmm_gene_kernel<2>, dim3(grid), dim3(256), 0, s, a); break;
     case 3: hipLaunchKernelGGL(lmm_gene_kernel<3>, dim3(grid), dim3(256), 0, s, a); break;
     case 4: hipLaunchKernelGGL(lmm_gene_kernel<4>, dim3(grid), dim3(256), 0, s, a); break;
-    default: hipLaunchKernelGGL(lmm_gene_generic_kernel, dim3(grid), dim3(256), 0, s, a, (int)c); break;
+    default:
+      if (c > (size_t)GEN_CMAX) {
+        int rcw = wide_attr(lmm_gene_wide_kernel);
+        if (rcw) return rcw;
+        hipLaunchKernelGGL(lmm_gene_wide_kernel, dim3((unsigned)l), dim3(64), wide_lds_bytes(c), s, a, (int)c);
+      } else {
+        hipLaunchKernelGGL(lmm_gene_generic_kernel, dim3(grid), dim3(256), 0, s, a, (int)c);
+      }
+      break;
     }
     HIPCHK(hipGetLastError());
   }
@@ -1988,8 +2013,8 @@ extern "C" int gemma_hip_lmm_set_env(const double *env) {
   if (!g_ctx.lmm_active) return fail(GEMMA_HIP_ESTATE, "lmm_set_env before lmm_setup");
   if (!env) return fail(GEMMA_HIP_EINVAL, "lmm_set_env: null pointer");
   const size_t n = g_ctx.cfg.n, c = g_ctx.cfg.n_cvt;
-  if (c + 2 > (size_t)GEN_CMAX)
-    return fail(GEMMA_HIP_EINVAL, "lmm_set_env: n_cvt + 2 = %zu covariates not supported (<= %d)", c + 2, GEN_CMAX);
+  if (c + 2 > (size_t)GEN_CMAX_WIDE)
+    return fail(GEMMA_HIP_EINVAL, "lmm_set_env: n_cvt + 2 = %zu covariates not supported (<= %d)", c + 2, GEN_CMAX_WIDE);
   if (n <= c + 3) return fail(GEMMA_HIP_EINVAL, "lmm_set_env: n <= n_cvt + 3");
   if (g_ctx.gxe_env.reserve(n * 8) || g_ctx.gxe_UtWt.reserve((c + 1) * n * 8))
     return fail(GEMMA_HIP_ENOMEM, "lmm_set_env: buffers");
@@ -2061,7 +2086,15 @@ extern "C" int gemma_hip_lmm_gxe_batch_d(int kind, const void *geno, size_t l, s
     switch (c + 2) {
     case 3: hipLaunchKernelGGL(lmm_gxe_kernel<3>, dim3(grid), dim3(256), 0, s, a); break;
     case 4: hipLaunchKernelGGL(lmm_gxe_kernel<4>, dim3(grid), dim3(256), 0, s, a); break;
-    default: hipLaunchKernelGGL(lmm_gxe_generic_kernel, dim3(grid), dim3(256), 0, s, a, (int)(c + 2)); break;
+    default:
+      if (c + 2 > (size_t)GEN_CMAX) {
+        int rcw = wide_attr(lmm_gxe_wide_kernel);
+        if (rcw) return rcw;
+        hipLaunchKernelGGL(lmm_gxe_wide_kernel, dim3((unsigned)l), dim3(64), wide_lds_bytes(c + 2), s, a, (int)(c + 2));
+      } else {
+        hipLaunchKernelGGL(lmm_gxe_generic_kernel, dim3(grid), dim3(256), 0, s, a, (int)(c + 2));
+      }
+      break;
     }
     HIPCHK(hipGetLastError());
   }
@@ -2256,8 +2289,8 @@ extern "C" int gemma_hip_lmm_null(size_t n, size_t n_cvt, const double *eval, co
                                   const double *Uty, double l_min, double l_max, size_t n_region,
                                   double trace_G, double *out8) {
   NEED_INIT();
-  if (!eval || !UtW || !Uty || !out8 || n == 0 || n_cvt == 0 || n_cvt > (size_t)GEN_CMAX + 1)
-    return fail(GEMMA_HIP_EINVAL, "lmm_null: bad arguments (n_cvt 1..%d)", GEN_CMAX + 1);
+  if (!eval || !UtW || !Uty || !out8 || n == 0 || n_cvt == 0 || n_cvt > (size_t)GEN_CMAX_WIDE + 1)
+    return fail(GEMMA_HIP_EINVAL, "lmm_null: bad arguments (n_cvt 1..%d)", GEN_CMAX_WIDE + 1);
   if (!(l_max > l_min) || n_region == 0 || n_region > (size_t)ASSOC_MAX_REGION || n <= n_cvt)
     return fail(GEMMA_HIP_EINVAL, "lmm_null: l_min/l_max/n_region/n");
   DevBuf dE, dW, dWt, dY, dO;
@@ -2287,7 +2320,15 @@ extern "C" int gemma_hip_lmm_null(size_t n, size_t n_cvt, const double *eval, co
     case 3: hipLaunchKernelGGL(lmm_null_kernel<2>, dim3(1), dim3(64), 0, 0, a, o); break;
     case 4: hipLaunchKernelGGL(lmm_null_kernel<3>, dim3(1), dim3(64), 0, 0, a, o); break;
     case 5: hipLaunchKernelGGL(lmm_null_kernel<4>, dim3(1), dim3(64), 0, 0, a, o); break;
-    default: hipLaunchKernelGGL(lmm_null_generic_kernel, dim3(1), dim3(64), 0, 0, a, (int)n_cvt - 1, o); break;
+    default:
+      if (n_cvt - 1 > (size_t)GEN_CMAX) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(lmm_null_wide_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)wide_lds_bytes(GEN_CMAX_WIDE));
+        hipLaunchKernelGGL(lmm_null_wide_kernel, dim3(1), dim3(64), wide_lds_bytes(n_cvt - 1), 0, a, (int)n_cvt - 1, o);
+      } else {
+        hipLaunchKernelGGL(lmm_null_generic_kernel, dim3(1), dim3(64), 0, 0, a, (int)n_cvt - 1, o);
+      }
+      break;
     }
     e = hipGetLastError();
   }

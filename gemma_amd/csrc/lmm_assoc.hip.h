@@ -483,6 +483,12 @@ struct FixedC {
 constexpr int GEN_CMAX = 16;
 constexpr int GEN_NI = (GEN_CMAX + 3) * (GEN_CMAX + 2) / 2;
 constexpr int GEN_LDS_PER_WAVE = 6 * GEN_NI;
+// Beyond 16 covariates (20 principal components + age + sex is an everyday GWAS model; the reference is generic in n_cvt,
+// src/lmm.cpp:283-357) the same code runs with ONE wavefront per workgroup and its six tables in dynamic LDS:
+// 6 (c + 3)(c + 2) / 2 doubles = 106 KiB at c = 64.  "wide" kernels below; slow (the product table takes (c + 2)^2 / 32 passes
+// per evaluation) but complete.
+constexpr int GEN_CMAX_WIDE = 64;
+__host__ __device__ inline int gen_ni_for(int c) { return (c + 3) * (c + 2) / 2; }
 
 __device__ __forceinline__ int ab_index_rt(int a, int b, int c) {
   const int cols = c + 2;
@@ -496,7 +502,8 @@ struct GenericC {
   static constexpr bool HAS_CHEB = false;
   static constexpr int CC = 1; // unused
   int cc;
-  double *L; // this wave's LDS scratch, GEN_LDS_PER_WAVE doubles
+  double *L; // this wave's LDS scratch: 6 tables of `ni` doubles
+  int ni = GEN_NI; // table stride: GEN_NI in the 4-wavefront kernels, gen_ni_for(c) in the wide ones
   const double *wlast = nullptr; // non-null: the last covariate is this per-SNP vector (GXE)
   __device__ __forceinline__ int c() const { return cc; }
 
@@ -505,7 +512,7 @@ struct GenericC {
                        int lane, Agg &A) const {
     const int c = cc, nv = c + 2, n = g.n;
     constexpr int EO = (ORDER == 0) ? 1 : ORDER;
-    double *s1 = L, *s2 = L + GEN_NI, *s3 = L + 2 * GEN_NI;
+    double *s1 = L, *s2 = L + ni, *s3 = L + 2 * ni;
     double tr1 = 0.0, tr2 = 0.0, ld = 0.0;
     const int nblk = (nv + 3) >> 2;
     for (int bi = 0; bi < nblk; ++bi) {
@@ -579,7 +586,7 @@ struct GenericC {
     A.logdet = LOGDET ? wave_sum(ld) : 0.0;
     // projection recursion (src/lmm.cpp:326-349, :385-407, :445-474), one lane per (a,b) pair
     double *cur1 = s1, *cur2 = s2, *cur3 = s3;
-    double *nx1 = L + 3 * GEN_NI, *nx2 = L + 4 * GEN_NI, *nx3 = L + 5 * GEN_NI;
+    double *nx1 = L + 3 * ni, *nx2 = L + 4 * ni, *nx3 = L + 5 * ni;
     const int iyy = ab_index_rt(c + 2, c + 2, c), ixx = ab_index_rt(c + 1, c + 1, c),
               ixy = ab_index_rt(c + 2, c + 1, c);
     double tp = A.tr1, tpp = A.tr2, sl = 0.0;
@@ -989,6 +996,18 @@ __global__ __launch_bounds__(256) void lmm_assoc_generic_kernel(AssocArgs g, int
   assoc_one_snp(g, m, snp, lane);
 }
 
+// more than GEN_CMAX covariates: one wavefront per workgroup, tables in dynamic LDS (6 * gen_ni_for(c) doubles)
+__global__ __launch_bounds__(64) void lmm_assoc_wide_kernel(AssocArgs g, int c) {
+  extern __shared__ double wide_lds[];
+  const long snp = blockIdx.x;
+  if (snp >= g.l) return;
+  GenericC m;
+  m.cc = c;
+  m.L = wide_lds;
+  m.ni = gen_ni_for(c);
+  assoc_one_snp(g, m, snp, threadIdx.x & 63);
+}
+
 // ------------------------------------------------------------------ AnalyzeGene (src/lmm.cpp:1365-1471)
 // The roles are swapped: every row is a PHENOTYPE (a gene's expression over the analysed individuals, rotated:
 // U^T y_g), the tested variable x is one fixed vector (g.Uty holds U^T x here).  Per row, as the reference:
@@ -1070,6 +1089,20 @@ __global__ __launch_bounds__(256) void lmm_gene_generic_kernel(AssocArgs g, int 
   mn.cc = c - 1;
   mn.L = m.L; // the two fits run one after the other
   gene_one_row(g, m, mn, row, lane);
+}
+
+__global__ __launch_bounds__(64) void lmm_gene_wide_kernel(AssocArgs g, int c) {
+  extern __shared__ double wide_lds[];
+  const long row = blockIdx.x;
+  if (row >= g.l) return;
+  GenericC m, mn;
+  m.cc = c;
+  m.L = wide_lds;
+  m.ni = gen_ni_for(c);
+  mn.cc = c - 1;
+  mn.L = m.L; // the two fits run one after the other
+  mn.ni = m.ni;
+  gene_one_row(g, m, mn, row, threadIdx.x & 63);
 }
 
 // ------------------------------------------------------------------ GXE (src/lmm.cpp:2283-2608)
@@ -1213,6 +1246,27 @@ __device__ __forceinline__ void null_model(const AssocArgs &g, const M &model, i
   if (lane == 0) *out = o;
 }
 
+__global__ __launch_bounds__(64) void lmm_gxe_wide_kernel(AssocArgs g, int ct) {
+  extern __shared__ double wide_lds[];
+  const long snp = blockIdx.x;
+  if (snp >= g.l) return;
+  GenericC m, mn;
+  m.cc = ct;
+  m.L = wide_lds;
+  m.ni = gen_ni_for(ct);
+  mn.cc = ct - 1;
+  mn.L = m.L;
+  mn.ni = m.ni;
+  gxe_one_snp(g, m, mn, snp, threadIdx.x & 63);
+}
+__global__ __launch_bounds__(64) void lmm_null_wide_kernel(AssocArgs g, int cp, NullOut *out) {
+  extern __shared__ double wide_lds[];
+  GenericC m;
+  m.cc = cp;
+  m.L = wide_lds;
+  m.ni = gen_ni_for(cp);
+  null_model(g, m, cp, threadIdx.x & 63, out);
+}
 template <int CP>
 __global__ __launch_bounds__(64) void lmm_null_kernel(AssocArgs g, NullOut *out) {
   null_model(g, FixedC<CP>(), CP, threadIdx.x & 63, out);

@@ -473,7 +473,7 @@ def test_generic_kernel_on_bxd(gpu_api, bxd, monkeypatch):
 
 def test_too_many_covariates_is_rejected(gpu_api):
     from gemma_amd import _lib as L
-    n, c = 64, 17
+    n, c = 96, 65  # up to 64 run (round 3: the wide kernels, test_more_than_sixteen_covariates)
     with pytest.raises(L.GemmaHipError) as e:
         gpu_api.LMM(a_mode=1).setup(np.eye(n), np.ones(n), np.ones((n, c)), np.ones(n))
     assert e.value.code == L.EINVAL
@@ -1000,3 +1000,23 @@ def test_final_likelihood_from_series_matches_streaming(gpu_api, oracle, monkeyp
     for k in ("beta", "se", "p_wald", "p_lrt", "logl_H1"):
         ok = np.isfinite(res["1"][k]) & np.isfinite(res["0"][k])
         np.testing.assert_allclose(res["1"][k][ok], res["0"][k][ok], rtol=2e-7, err_msg=k)
+
+
+@pytest.mark.parametrize("c", [20, 33])
+def test_more_than_sixteen_covariates(gpu_api, oracle, c):
+    """The reference is generic in n_cvt (src/lmm.cpp:283-357); rounds 1-2 stopped at 16.  20 principal components + age + sex
+    is an everyday model: c = 20 and c = 33 through the wide kernels (one wavefront per workgroup, tables in dynamic LDS),
+    null model and -lmm 4 against the oracle."""
+    rng = np.random.default_rng(7000 + c)
+    X, U, ev, _, _, tr = _synthetic(oracle, 360, 64, 1, seed=7100 + c)
+    n = 360
+    W = np.hstack([rng.standard_normal((n, c - 1)), np.ones((n, 1))])
+    y = np.sqrt(0.7) * (U @ (np.sqrt(np.maximum(ev, 0)) * rng.standard_normal(n))) + rng.standard_normal(n) + W[:, :3] @ [0.4, -0.3, 0.2]
+    UtW, Uty = U.T @ W, U.T @ y
+    l_r, logl_r = oracle.calc_lambda_null("R", ev, UtW, Uty)
+    l_m, logl_m = oracle.calc_lambda_null("L", ev, UtW, Uty)
+    nm = gpu_api.CalcLambdaNull(ev, UtW, Uty, trace_G=tr)
+    assert nm["l_remle_null"] == pytest.approx(l_r, rel=1e-3) and nm["logl_mle_H0"] == pytest.approx(logl_m, rel=1e-9)
+    ref = oracle.lmm_analyze(4, U, ev, UtW, Uty, X, l_mle_null=l_m, logl_mle_H0=logl_m)
+    got = gpu_api.LMM(a_mode=4, l_mle_null=l_m, logl_mle_H0=logl_m).AnalyzeBimbam(U, ev, UtW, Uty, X)
+    _cmp_stats(got, ref, 4, "c=%d covariates (wide kernels)" % c)
