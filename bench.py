@@ -75,8 +75,8 @@ def parse():
                     help="measurement aid: keep the setup's result (U, eval, UtW, Uty, null scalars) in this file -- written "
                          "when absent, loaded when present -- so that a profiler run (rocprofv3 --pmc crashes inside the "
                          "eigensolver's ~80 000 launches) can start at the timed region")
-    ap.add_argument("--e2e-snps", type=int, default=0,
-                    help="opt-in end-to-end leg after the timed region: a synthetic PLINK set of this many SNPs on disk -> "
+    ap.add_argument("--e2e-snps", type=int, default=200000,
+                    help="end-to-end leg after the timed region (0 = skip; 1000000 = BASELINE config 3 in full): a synthetic PLINK set of this many SNPs on disk -> "
                          "tests/cpp/gemma_file_driver -inproc (first pass, kinship, eigen, -lmm, .assoc.txt), wall seconds "
                          "per stage reported under \"e2e\" (0 = skip)")
     return ap.parse_args()
