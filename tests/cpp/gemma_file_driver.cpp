@@ -130,11 +130,24 @@ int main(int argc, char **argv) {
         if (done < 0) { bad = 1; break; }
         if (!WIFEXITED(st) || WEXITSTATUS(st) != 0) {
           bad = 1;
+          // a failure every rank meets (no device, unreadable input) ends them all by itself: two seconds of grace so that
+          // each can say why, then the ones still waiting in a collective are ended
+          std::vector<pid_t> left_kids;
           for (pid_t k : kids)
-            if (k != done) kill(k, SIGKILL);
-          for (pid_t k : kids) {
+            if (k != done) left_kids.push_back(k);
+          for (int tick = 0; tick < 100 && !left_kids.empty(); ++tick) {
+            for (size_t q = 0; q < left_kids.size();) {
+              int s2 = 0;
+              const pid_t r = waitpid(left_kids[q], &s2, WNOHANG);
+              if (r == left_kids[q] || r < 0) left_kids.erase(left_kids.begin() + (long)q);
+              else ++q;
+            }
+            if (!left_kids.empty()) usleep(20000);
+          }
+          for (pid_t k : left_kids) kill(k, SIGKILL);
+          for (pid_t k : left_kids) {
             int s2 = 0;
-            if (k != done) waitpid(k, &s2, 0);
+            waitpid(k, &s2, 0);
           }
           break;
         }
