@@ -689,7 +689,7 @@ def finish_cpu_setup(args, cs, t_bench0, setup_info):
         res = json.load(open(cs["out"]))
     except Exception:
         pass
-    out = {"kind": "reference", "where": "child process beside the GPU legs, host cores of this box",
+    out = {"kind": "reference", "where": "child process after the GPU legs, host cores of this box",
            "threads": res.get("threads"), "never_in_value": True}
     if "plink_kin" in res:
         pk = res["plink_kin"]
