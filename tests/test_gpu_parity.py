@@ -1020,3 +1020,38 @@ def test_more_than_sixteen_covariates(gpu_api, oracle, c):
     ref = oracle.lmm_analyze(4, U, ev, UtW, Uty, X, l_mle_null=l_m, logl_mle_H0=logl_m)
     got = gpu_api.LMM(a_mode=4, l_mle_null=l_m, logl_mle_H0=logl_m).AnalyzeBimbam(U, ev, UtW, Uty, X)
     _cmp_stats(got, ref, 4, "c=%d covariates (wide kernels)" % c)
+
+
+@pytest.mark.parametrize("n,l", [(100, 5), (200, 257), (330, 64), (129, 300), (517, 513)])
+def test_records_kernel_short_k_loops_and_ragged_tiles(gpu_api, oracle, monkeypatch, n, l):
+    """i8gemm_sparse2_kernel at the sizes where its prologue / tail K-tiles are all there is: nk = ceil(n / 128) = 1, 2, 3, 5 K-tiles
+    (the main loop runs nk - 3 times), fewer rows than one 256-row tile and one row more than a tile; 10 % missingness so that the
+    dropped-call lists are exercised too.  Against a long-double product and against the round-2 sparse kernel and the dense mask
+    product (GEMMA_HIP_I8_SPARSE = 1, 0)."""
+    from gemma_amd import _lib as L
+    rng = np.random.default_rng(31 * n + l)
+    ind = np.ones(n, dtype=np.int32)
+    codes = rng.choice([0, 1, 2, 3], size=(l, n), p=[0.25, 0.10, 0.35, 0.30]).astype(np.uint8)
+    nb = (n + 3) // 4
+    pad = np.zeros((l, nb * 4), dtype=np.uint8)
+    pad[:, :n] = codes
+    raw = (pad[:, 0::4] | (pad[:, 1::4] << 2) | (pad[:, 2::4] << 4) | (pad[:, 3::4] << 6)).astype(np.uint8)
+    Q, _ = np.linalg.qr(rng.standard_normal((n, n)))
+    ev = np.sort(rng.uniform(0.0, 3.0, n))
+    Xn = oracle.bed_decode(raw, n)
+    Xi = np.where(np.isnan(Xn), np.nan_to_num(np.nanmean(Xn, axis=1))[:, None], Xn)
+    exact = (Xi.astype(np.longdouble) @ Q.astype(np.longdouble)).astype(np.float64)
+    scale = np.maximum(np.abs(Xi) @ np.abs(Q), 1e-300)
+    out = {}
+    for sp in ("2", "1", "0"):
+        monkeypatch.setenv("GEMMA_HIP_I8_SPARSE", sp)
+        lmm = gpu_api.LMM(a_mode=1)
+        lmm.setup(Q, ev, Q.T @ np.ones((n, 1)), Q.T @ rng.standard_normal(n), plink=True)
+        lmm.set_indicator(ind)
+        try:
+            out[sp] = lmm.dbg_utx(raw, L.GENO_PLINK_2BIT, 1)
+        finally:
+            lmm.finish()
+        err = np.max(np.abs(out[sp] - exact) / scale)
+        assert err < 8 * 2.3e-16, (sp, err)
+    assert np.max(np.abs(out["2"] - out["0"]) / scale) < 2 * 2.3e-16
