@@ -14,21 +14,22 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_bench_gpus2_launches_its_own_ranks(gpu_api):
+@pytest.mark.parametrize("world", [2, 4])
+def test_bench_gpus_n_launches_its_own_ranks(gpu_api, world):
     env = dict(os.environ)
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     env.update({"BENCH_FORCE_DEVICE": "0", "BENCH_DIST_BACKEND": "gloo", "GEMMA_HIP_COMM": "shm"})
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "2", "--warmup", "1",
                         "--individuals", "3000", "--batch", "3000", "--kin-snps", "6000", "--cpu-sample", "0",
                         "--fp64-steps", "0"], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-2000:])
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["scaling"] == "weak"
+    assert d["n_gpus"] == world and d["scaling"] == "weak"
     assert d["config"]["setup"]["broadcast"].startswith("native:"), d["config"]["setup"]["broadcast"]
-    assert d["config"]["parallelism"] == "snp-shard x2"
+    assert d["config"]["parallelism"] == "snp-shard x%d" % world
     assert d["value"] > 0 and d["config"]["nan_p_wald"] == 0
     am = d["amdahl"]
     assert set(am["projected_total_s"]) == {"1", "2", "4", "8"} and am["projected_total_s"]["8"] < am["projected_total_s"]["1"]
