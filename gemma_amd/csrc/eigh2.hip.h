@@ -390,7 +390,11 @@ struct BcArgs {
   double *V2, *tau2; // V2[(k n + j) 128 + i], tau2[k n + j]
 };
 constexpr int BC_LD = E2_B + 1; // padded column stride of the 128 x 128 block in LDS: row sums and column sums both conflict-free
-constexpr int BC_LDS_DOUBLES = E2_B * BC_LD + 8 * E2_B + 16;
+constexpr int BC_NH = 2;        // column parts per row: 128 BC_NH threads per task.  4 (512 threads) was measured in round 3: 0.90 s
+                                // against 0.86 s at n = 20000 -- the task is bound by the latency of its global loads and of the store
+                                // drain before the flag (6.5 + 6.4 us of 27 with stamps), not by its per-thread loops
+constexpr int BC_THREADS = E2_B * BC_NH;
+constexpr int BC_LDS_DOUBLES = E2_B * BC_LD + (4 + 2 * BC_NH) * E2_B + 32;
 // task (j, k): the caller guarantees that it exists (j <= n - 3, j + 1 + 128 k < n) and that (j, k-1) and (j-1, k+1) are done
 #define BC_STAMP(i)                                                  \
   do {                                                               \
@@ -402,68 +406,83 @@ __device__ __forceinline__ double bc_bcast(double x, int l) {
   const int hi = __builtin_amdgcn_readlane(__double2hiint(x), l);
   return __hiloint2double(hi, lo);
 }
+// block sum over the BC_THREADS threads of a chase workgroup; red: 2 BC_NH doubles
+__device__ __forceinline__ double bc_bsum(double v, double *red) {
+  v = eig_wsum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  double s = 0.0;
+#pragma unroll
+  for (int w = 0; w < 2 * BC_NH; ++w) s += red[w];
+  return s;
+}
 // task (j, k): the caller guarantees that it exists (j <= n - 3, j + 1 + 128 k < n) and that (j, k-1) and (j-1, k+1) are done.
-// Thread (a, h) owns row a of the 128 x 128 blocks and the 64 columns cb = 64 h ..; its 64 entries of E and of the diagonal
-// block's lower triangle stay in REGISTERS from the global load to the global store.  Row sums (E v_p, D v) run on those
-// registers with the vector's entries broadcast by readlane; only the column sums (v^T E, the transposed half of D v) need
-// the block in LDS: one store pass and one read pass per block (the stage is bound by the LDS pipe, not by HBM or flops:
-// the first version, which kept E in LDS for every step, spent 18 of its 29 us per task there).
+// Thread (a, h) owns row a of the 128 x 128 blocks and the CW = 128 / BC_NH columns cb = CW h ..; its CW entries of E and of the
+// diagonal block's lower triangle stay in REGISTERS from the global load to the global store.  Row sums (E v_p, D v) run on
+// those registers with the vector's entries broadcast by readlane; only the column sums (v^T E, the transposed half of D v) need
+// the block in LDS: one store pass and one read pass per block.  The chase is a chain of 2 n dependent tasks, so the task's
+// latency is the stage's time (BC_NH = 4, four column quarters on 512 threads, halves every per-thread loop and was NOT faster:
+// see BC_NH).
 template <bool DBG>
 __device__ __forceinline__ void bc_task(double *__restrict__ B, long n, long j, long k, double *__restrict__ V2g,
                                         double *__restrict__ tau2g, double *e2sm, long long *dbg = nullptr) {
+  constexpr int CW = E2_B / BC_NH;
   BC_STAMP(0);
   double *E = e2sm; // E[c][a] (column stride 129): the block whose column sums are being formed
   double *vp = e2sm + E2_B * BC_LD, *v = vp + E2_B, *zc = v + E2_B, *wv = zc + E2_B;
-  double *ybuf = wv + E2_B, *zbuf = ybuf + 2 * E2_B, *red = zbuf + 2 * E2_B;
-  const int t = threadIdx.x, a = t & (E2_B - 1), h = t >> 7, lane = t & 63;
+  double *ybuf = wv + E2_B, *zbuf = ybuf + BC_NH * E2_B, *red = zbuf + BC_NH * E2_B;
+  const int t = threadIdx.x, a = t & (E2_B - 1), h = t >> 7, lane = t & 63, lc = lane & (CW - 1);
   const long r = j + 1 + k * E2_B;
   const int L = (int)((n - r < E2_B) ? (n - r) : E2_B);
-  const int cb = h * 64;
-  double er[64], dr[64];
+  const int cb = h * CW;
+  double er[CW], dr[CW];
   double xa, ya = 0.0, taup = 0.0, vph = 0.0;
   if (k > 0) {
     // v_p and tau_p first: the counter retires in order, so whoever waits for E has them too and nothing later in the E phase
     // has to wait behind the diagonal block's loads
-    vph = V2g[((size_t)(k - 1) * n + j) * E2_B + cb + lane]; // v_p of this wavefront's columns, one per lane
+    vph = V2g[((size_t)(k - 1) * n + j) * E2_B + cb + lc]; // v_p of this thread group's columns, entry c in lane c (c < CW)
     taup = tau2g[(k - 1) * n + j];
     const double *src = B + (r - E2_B + cb) * E2_LDB + E2_B + a - cb;
 #pragma unroll
-    for (int c = 0; c < 64; ++c) er[c] = src[c * (E2_LDB - 1)]; // rows past n: slots of the band storage that stay zero
+    for (int c = 0; c < CW; ++c) er[c] = src[c * (E2_LDB - 1)]; // rows past n: slots of the band storage that stay zero
   } else {
     // first task of a sweep: the "block" is column j alone (there is no previous reflector: v_p = 0, tau_p = 0); the code below
     // is the same, which keeps every global load of the task in front of the first barrier
 #pragma unroll
-    for (int c = 0; c < 64; ++c) er[c] = 0.0;
+    for (int c = 0; c < CW; ++c) er[c] = 0.0;
     if (h == 0) er[0] = B[j * E2_LDB + 1 + a]; // rows past n: zero slots
   }
 #pragma unroll
-  for (int c = 0; c < 64; ++c) E[(cb + c) * BC_LD + a] = er[c];
+  for (int c = 0; c < CW; ++c) E[(cb + c) * BC_LD + a] = er[c];
   {
-    // the diagonal block's 64 loads go out once E has arrived (a wavefront tracks at most 63 vector-memory operations, more
-    // would only stall the issue) and stay in flight behind the whole E phase
-    // unconditional as well (a select on the loaded value would be placed right behind the load and wait for it): columns
-    // past n lie in the zeroed slack of the band storage, rows past n in slots that stay zero; above the diagonal (a < column)
-    // the address falls into the previous column and the value is masked where it is used
+    // the diagonal block's loads go out once E has arrived and stay in flight behind the whole E phase; unconditional (a select
+    // on the loaded value would be placed right behind the load and wait for it): columns past n lie in the zeroed slack of the
+    // band storage, rows past n in slots that stay zero; above the diagonal (a < column) the address falls into the previous
+    // column and the value is masked where it is used
     const double *srd = B + (r + cb) * E2_LDB + a - cb;
 #pragma unroll
-    for (int c = 0; c < 64; ++c) dr[c] = srd[c * (E2_LDB - 1)];
+    for (int c = 0; c < CW; ++c) dr[c] = srd[c * (E2_LDB - 1)];
   }
   {
     double ys = 0.0;
 #pragma unroll
-    for (int c = 0; c < 64; ++c) ys += er[c] * bc_bcast(vph, c);
+    for (int c = 0; c < CW; ++c) ys += er[c] * bc_bcast(vph, c);
     ybuf[h * E2_B + a] = ys;
-    if ((t & 64) == 0) vp[cb + lane] = vph; // waves 0 and 2 publish v_p (needed by column index below)
+    if ((t & 64) == 0 && lane < CW) vp[cb + lane] = vph; // the first wavefront of every quarter publishes its part of v_p
     __syncthreads();
     BC_STAMP(1);
-    ya = taup * (ybuf[a] + ybuf[E2_B + a]);
+    double ysum = 0.0;
+#pragma unroll
+    for (int q = 0; q < BC_NH; ++q) ysum += ybuf[q * E2_B + a];
+    ya = taup * ysum;
     xa = E[a] - ya * vp[0]; // first column of E (I - tau_p v_p v_p^T)
   }
   BC_STAMP(2);
-  if (t == 0) red[8] = xa;
-  const double xnorm2 = e2_bsum256((h == 0 && a >= 1 && a < L) ? xa * xa : 0.0, red);
+  if (t == 0) red[2 * BC_NH] = xa;
+  const double xnorm2 = bc_bsum((h == 0 && a >= 1 && a < L) ? xa * xa : 0.0, red);
   double tau, beta, scale;
-  e2_larfg(red[8], xnorm2, tau, beta, scale);
+  e2_larfg(red[2 * BC_NH], xnorm2, tau, beta, scale);
   const double va = (a == 0) ? 1.0 : ((a < L) ? scale * xa : 0.0);
   if (h == 0) {
     v[a] = va;
@@ -471,23 +490,28 @@ __device__ __forceinline__ void bc_task(double *__restrict__ B, long n, long j, 
   }
   if (t == 0) tau2g[k * n + j] = tau;
   // s = v . y (the right-hand reflector's share of z = v^T E (I - tau_p v_p v_p^T))
-  const double sdot = e2_bsum256((h == 0) ? va * ya : 0.0, red); // includes the barrier that publishes v
+  const double sdot = bc_bsum((h == 0) ? va * ya : 0.0, red); // includes the barrier that publishes v
   BC_STAMP(3);
   if (k > 0) {
-    // z0_c = sum_q v_q E[c][q]: thread = column a, rows 64 h ..
-    const double vrow = v[cb + lane];
+    // z0_c = sum_q v_q E[c][q]: thread = column a, rows cb ..
+    const double vrow = v[cb + lc];
     double zs = 0.0;
 #pragma unroll
-    for (int q = 0; q < 64; ++q) zs += E[a * BC_LD + cb + q] * bc_bcast(vrow, q);
+    for (int q = 0; q < CW; ++q) zs += E[a * BC_LD + cb + q] * bc_bcast(vrow, q);
     zbuf[h * E2_B + a] = zs;
     __syncthreads();
-    if (h == 0) zc[a] = (zbuf[a] + zbuf[E2_B + a]) - sdot * vp[a];
+    if (h == 0) {
+      double zsum = 0.0;
+#pragma unroll
+      for (int q = 0; q < BC_NH; ++q) zsum += zbuf[q * E2_B + a];
+      zc[a] = zsum - sdot * vp[a];
+    }
     __syncthreads();
-    const double zch = zc[cb + lane];
+    const double zch = zc[cb + lc];
     const double tva = tau * va;
     double *dst = B + (r - E2_B + cb) * E2_LDB + E2_B + a - cb;
 #pragma unroll
-    for (int c = 0; c < 64; ++c) {
+    for (int c = 0; c < CW; ++c) {
       double e = er[c] - ya * bc_bcast(vph, c) - tva * bc_bcast(zch, c);
       if (cb + c == 0) e = (a == 0) ? beta : 0.0;
       if (a < L) dst[c * (E2_LDB - 1)] = e;
@@ -500,10 +524,10 @@ __device__ __forceinline__ void bc_task(double *__restrict__ B, long n, long j, 
   // diagonal block (lower triangle dr, diagonal included): p = tau D v = tau (L v + strict(L)^T v),
   // w = p - (tau/2)(v.p) v, D -= v w^T + w v^T
   __syncthreads(); // the column sums above are done with E
-  const double vh = v[cb + lane];
+  const double vh = v[cb + lc];
   double p1 = 0.0;
 #pragma unroll
-  for (int c = 0; c < 64; ++c) {
+  for (int c = 0; c < CW; ++c) {
     E[(cb + c) * BC_LD + a] = (a > cb + c) ? dr[c] : 0.0; // strictly lower part for the transposed product
     p1 += ((a >= cb + c) ? dr[c] : 0.0) * bc_bcast(vh, c);
   }
@@ -513,27 +537,30 @@ __device__ __forceinline__ void bc_task(double *__restrict__ B, long n, long j, 
   {
     double p2 = 0.0;
 #pragma unroll
-    for (int q = 0; q < 64; ++q) p2 += E[a * BC_LD + cb + q] * bc_bcast(vh, q); // column a, rows cb + q; vh = v of those rows
+    for (int q = 0; q < CW; ++q) p2 += E[a * BC_LD + cb + q] * bc_bcast(vh, q); // column a, rows cb + q; vh = v of those rows
     zbuf[h * E2_B + a] = p2;
   }
   __syncthreads();
-  const double pa = tau * ((ybuf[a] + ybuf[E2_B + a]) + (zbuf[a] + zbuf[E2_B + a]));
-  const double gamma = e2_bsum256((h == 0) ? va * pa : 0.0, red);
+  double psum = 0.0;
+#pragma unroll
+  for (int q = 0; q < BC_NH; ++q) psum += ybuf[q * E2_B + a] + zbuf[q * E2_B + a];
+  const double pa = tau * psum;
+  const double gamma = bc_bsum((h == 0) ? va * pa : 0.0, red);
   const double wa = pa - 0.5 * tau * gamma * va;
   if (h == 0) wv[a] = wa;
   __syncthreads();
   BC_STAMP(6);
   {
-    const double wh = wv[cb + lane];
+    const double wh = wv[cb + lc];
     double *dst = B + (r + cb) * E2_LDB + a - cb;
 #pragma unroll
-    for (int c = 0; c < 64; ++c)
+    for (int c = 0; c < CW; ++c)
       if (a >= cb + c && a < L) dst[c * (E2_LDB - 1)] = dr[c] - va * bc_bcast(wh, c) - wa * bc_bcast(vh, c);
   }
   BC_STAMP(7);
 }
 
-__global__ __launch_bounds__(256) void bc_step_kernel(BcArgs g) {
+__global__ __launch_bounds__(BC_THREADS) void bc_step_kernel(BcArgs g) {
   extern __shared__ double e2sm[];
   const long n = g.n, j = g.jlo + blockIdx.x, k = g.t - 2 * j;
   if (k < 0 || j > n - 3 || j + 1 + k * E2_B >= n) return;
@@ -563,7 +590,7 @@ __device__ __forceinline__ bool bc_wait(int *p, int target, int *err) {
 }
 template <bool DBG> // DBG: wall-clock stamps of workgroup 1's tasks (compiled out otherwise: a conditional store in the task
                     // makes the compiler wait for every load in flight at the join)
-__global__ __launch_bounds__(256) void bc_persist_kernel(BcPersistArgs g) {
+__global__ __launch_bounds__(BC_THREADS) void bc_persist_kernel(BcPersistArgs g) {
   extern __shared__ double e2sm[];
   __shared__ int s_ok;
   const long n = g.n;
@@ -947,8 +974,8 @@ static inline int eig2_sb2st(long n, EigWs &ws, Eig2Ws &w2, hipStream_t s, std::
         (void)hipMemsetAsync(dbg_d, 0, 512 * 16 * 8, s);
         pa.dbg = dbg_d;
       }
-      if (dbg_d) hipLaunchKernelGGL(bc_persist_kernel<true>, dim3((unsigned)nwg), dim3(256), BC_LDS_DOUBLES * 8, s, pa);
-      else hipLaunchKernelGGL(bc_persist_kernel<false>, dim3((unsigned)nwg), dim3(256), BC_LDS_DOUBLES * 8, s, pa);
+      if (dbg_d) hipLaunchKernelGGL(bc_persist_kernel<true>, dim3((unsigned)nwg), dim3(BC_THREADS), BC_LDS_DOUBLES * 8, s, pa);
+      else hipLaunchKernelGGL(bc_persist_kernel<false>, dim3((unsigned)nwg), dim3(BC_THREADS), BC_LDS_DOUBLES * 8, s, pa);
       EIG_HIP(hipGetLastError());
       if (dbg_d) {
         std::vector<long long> hs(512 * 16);
@@ -993,7 +1020,7 @@ static inline int eig2_sb2st(long n, EigWs &ws, Eig2Ws &w2, hipStream_t s, std::
     if (jlo > jhi) continue;
     a.t = t;
     a.jlo = jlo;
-    hipLaunchKernelGGL(bc_step_kernel, dim3((unsigned)(jhi - jlo + 1)), dim3(256), BC_LDS_DOUBLES * 8, s, a);
+    hipLaunchKernelGGL(bc_step_kernel, dim3((unsigned)(jhi - jlo + 1)), dim3(BC_THREADS), BC_LDS_DOUBLES * 8, s, a);
     if ((t & 1023) == 0) EIG_HIP(hipGetLastError());
   }
   hipLaunchKernelGGL(sb_band_de_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, w2.Bd, n, ws.d, ws.e);
