@@ -366,11 +366,13 @@ struct PackF64Args {
                  // in [0, 2], plus the missing marker: NaN, or with nan_missing = 0 one repeated other value); [2] ... with 2
                  // decimals (k / 100); [3] set when any row has a missing entry
 };
-// v is k / 1000 for an integer 0 <= k <= 2000 (to the rounding of the decimal-to-double conversion); *q = k
+// v is EXACTLY the double a decimal "d.ddd" parses to: the correctly rounded k / 1000 for an integer 0 <= k <= 2000 (IEEE
+// division is correctly rounded, as is atof); *q = k.  A value that merely lies close to the grid is not a dosage and keeps
+// the batch on the fp64 GEMM.
 __device__ __forceinline__ bool dosage_on_grid(double v, int *q) {
-  const double t = v * 1000.0, r = rint(t);
+  const double r = rint(v * 1000.0);
   *q = (int)r;
-  return fabs(t - r) <= 1e-6 && r >= 0.0 && r <= 2000.0;
+  return r >= 0.0 && r <= 2000.0 && v == r / 1000.0;
 }
 __global__ __launch_bounds__(256) void pack_f64_kernel(PackF64Args g) {
   const int lane = threadIdx.x & 63;

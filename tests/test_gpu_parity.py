@@ -900,11 +900,12 @@ def test_utx_int8_dosage_product_is_exact(gpu_api, oracle, decimals, miss, want)
         Xi = oracle.impute_mean(X)
         c = lmm.dbg_utx(np.ascontiguousarray(Xi.T), L.GENO_F64_IDV_MAJOR, 1)
         assert gpu_api.last_utx_path() in (want, 3)  # an imputed mean may itself need the finer grid: still the int8 pipe
-        # one value off both grids: the batch belongs to the fp64 GEMM
-        Xo = X.copy()
-        Xo[11, 17] = 0.123456
-        lmm.dbg_utx(Xo, L.GENO_F64_SNP_MAJOR, 1)
-        assert gpu_api.last_utx_path() == 0
+        # one value off both grids -- or merely next to a grid point -- and the batch belongs to the fp64 GEMM
+        for off in (0.123456, np.nextafter(0.98, 1.0), 0.9999999999):
+            Xo = X.copy()
+            Xo[11, 17] = off
+            lmm.dbg_utx(Xo, L.GENO_F64_SNP_MAJOR, 1)
+            assert gpu_api.last_utx_path() == 0, off
     finally:
         lmm.finish()
     exact = (Xi.astype(np.longdouble) @ Q.astype(np.longdouble)).astype(np.float64)
