@@ -263,15 +263,19 @@ def main():
             # single roofline for the stage; the per-kernel split is in profiles/r02_kin_i8_stats.csv.  "equiv" is the
             # GEMM-form fp64 rate the stage replaces (SURVEY 8d's 2 n^2 p), comparable with the fp64 SYRK's figure.
             setup_info["roofline_kinship"] = {
-                "kernel": "kin_i8 stage: i8gemm_packed_kernel_t<false> (G^T G) + kin_i8_accum_kernel + kin_i8_corr_kernel",
-                "bound": "valu (kin_i8_corr_kernel, ~60 % of the stage: 6 VALU per (missing call, individual) pair) / mfma int8 (G^T G, ~25 %)",
+                "kernel": "kin_i8 stage: i8gemm_packed_kernel_t<false> (G^T G, tiles meeting the upper triangle) + kin_i8_accum_kernel + "
+                          "lists of the missing calls (count / scan / fill) + kin_i8_corr2_kernel",
+                "bound": "valu + latency (kin_i8_corr2_kernel, ~55 % of the stage: extract, convert, FMA per (missing call, individual) "
+                         "pair from a 2-bit copy of the block; the both-missing term as integer LDS atomics over per-SNP lists) / "
+                         "mfma int8 (G^T G, ~25 %)",
                 "launch_ms_total": round(kin_ms, 3), "blocks": kin_n,
                 "equiv_fp64_tflops": setup_info["kinship_gemm_tflops"],
                 "equiv_fp64_ratio": round(setup_info["kinship_gemm_tflops"] / 78.6, 4),
                 "equiv_note": "GEMM-form fp64 rate the stage replaces (SURVEY 8d: 2 n^2 p) over the fp64 MFMA peak -- a ratio of two "
                               "different arithmetics, NOT a roofline fraction (exact integers; K agrees with the fp64 SYRK to 1e-14)",
-                "gtg_int8": "G^T G alone: 7.3 ms per 20000-SNP block at n = 20000 = 2.19 POP/s = 0.44 of the dense int8 peak "
-                            "(profiles/r02_kin_i8_stats.csv; the per-kernel split is not measured inside bench.py)"}
+                "gtg_int8": "per 20000-SNP block at n = 20000 (profiles/r03_kin_i8_lists_kernel_stats.csv): G^T G 3.66 ms on the 6319 "
+                            "of 12403 tiles that meet the upper triangle = 2.26 POP/s = 0.45 of the dense int8 peak; correction 7.9 ms "
+                            "(round 2: 7.3 + 17.5 ms); the per-kernel split is not measured inside bench.py"}
         elif kin_ms:
             # K = Xc Xc^T as a SYRK: only the 128 x 128 tiles with tile_n >= tile_m are launched (dgemm_mfma.hip.h), so the
             # flops EXECUTED are tiles * 2 * 128^2 * p; SURVEY 8(d)'s GEMM-form figure 2 n^2 p (what the reference's

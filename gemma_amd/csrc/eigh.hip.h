@@ -1048,6 +1048,7 @@ static inline bool eig_two_stage(long n) {
 static inline int eigh_device_core(double *G, long n, double *U, double *eval, hipStream_t s, std::string &msg) {
   EigWs ws;
   ws.n = n;
+  const double t_enter = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
   const size_t nn = (size_t)n * n;
   bool ok = ws.get(ws.VT, nn) && ws.get(ws.WT, (size_t)EIG_NB * n) && ws.get(ws.xcol, n + 2) && ws.get(ws.p, n) &&
             ws.get(ws.ab, 2 * EIG_NB) && ws.get(ws.ssbuf, n / TD_ROWS + 2) && ws.get(ws.dotbuf, n / TD_ROWS + 2) &&
@@ -1181,7 +1182,10 @@ static inline int eigh_device_core(double *G, long n, double *U, double *eval, h
       fprintf(stderr, "gemma_hip_eigh n=%ld: tridiagonalisation %.3f s, divide&conquer %.3f s, back-transform %.3f s, "
                       "sort+transpose %.3f s\n", n, t1 - t0, t2 - t1, t3 - t2, now() - t3);
   }
+  const double t_rel = timing ? now() : 0.0;
   ws.release();
+  if (timing && rc == 0 && n > 1)
+    fprintf(stderr, "gemma_hip_eigh n=%ld: workspace allocation %.3f s, release %.3f s\n", n, t0 - t_enter, now() - t_rel);
   return rc;
 }
 

@@ -80,6 +80,9 @@ struct Ctx {
   DevBuf U_even;            // odd n: U copied to an even leading dimension for the fp64 GEMM's aligned path
   const double *U_even_of = nullptr; // the U that copy was made from
   DevBuf kin_GtG, kin_S, kin_a, kin_At, kin_Gt;
+  DevBuf kin_A2, kin_cnt, kin_off, kin_listS, kin_listJ, kin_sub, kin_cj, kin_flag; // lists of the missing calls of a block
+  DevBuf kin_tmap;                    // tiles of G^T G that meet the upper triangle
+  int kin_tmap_tm = 0, kin_tmap_tn = 0, kin_tmap_count = 0;
 
   // lmm state
   bool lmm_active = false;
@@ -387,7 +390,34 @@ extern "C" int gemma_hip_kin_begin(size_t n_total, int k_mode) {
 
 static void kin_i8_release() {
   g_ctx.kin_GtG.release(); g_ctx.kin_S.release(); g_ctx.kin_a.release(); g_ctx.kin_At.release(); g_ctx.kin_Gt.release();
+  g_ctx.kin_A2.release(); g_ctx.kin_cnt.release(); g_ctx.kin_off.release(); g_ctx.kin_listS.release();
+  g_ctx.kin_listJ.release(); g_ctx.kin_sub.release(); g_ctx.kin_cj.release(); g_ctx.kin_flag.release();
+  g_ctx.kin_tmap.release();
+  g_ctx.kin_tmap_tm = g_ctx.kin_tmap_tn = g_ctx.kin_tmap_count = 0;
   g_ctx.kin_i8_used = false;
+}
+
+// (tile_m, tile_n) of the 128 x 256 tiles of G^T G that hold an entry with column >= row, in the order the kernel's raster
+// would visit them (groups of eight tile rows, columns outside, rows inside: one L2 patch per XCD)
+static int kin_i8_tile_map(int tiles_m, int tiles_n) {
+  if (g_ctx.kin_tmap_tm == tiles_m && g_ctx.kin_tmap_tn == tiles_n && g_ctx.kin_tmap.p) return GEMMA_HIP_OK;
+  std::vector<int> map;
+  const int GM = 8;
+  for (int first = 0; first < tiles_m; first += GM) {
+    const int gsz = std::min(GM, tiles_m - first);
+    for (int tn = first >> 1; tn < tiles_n; ++tn)
+      for (int tm = first; tm < first + gsz; ++tm)
+        if (tn >= (tm >> 1)) { // columns 256 tn .. + 255 reach row 128 tm
+          map.push_back(tm);
+          map.push_back(tn);
+        }
+  }
+  if (g_ctx.kin_tmap.reserve(map.size() * sizeof(int))) return fail(GEMMA_HIP_ENOMEM, "kin_add: tile map");
+  HIPCHK(hipMemcpy(g_ctx.kin_tmap.p, map.data(), map.size() * sizeof(int), hipMemcpyHostToDevice));
+  g_ctx.kin_tmap_tm = tiles_m;
+  g_ctx.kin_tmap_tn = tiles_n;
+  g_ctx.kin_tmap_count = (int)(map.size() / 2);
+  return GEMMA_HIP_OK;
 }
 
 // one PLINK block through the integer path: packed rows, transposed operands, G^T G (int32, exact), accumulators
@@ -439,7 +469,18 @@ static int kin_add_i8(const void *geno, size_t l, size_t ld, hipStream_t s) {
     g.tiles_m = (int)(rows_a / I8P_BM); g.tiles_n = (int)(rows_b / I8_BN);
     g.nk = (int)(ldl / I8_BK);
     g.gm = 0; g.fuse = 0; g.digits = 1;
-    hipLaunchKernelGGL(i8gemm_packed_kernel_t<false>, dim3((unsigned)(g.tiles_m * g.tiles_n), 1), dim3(512), 3 * I8P_STAGE, s, g);
+    unsigned ntiles = (unsigned)(g.tiles_m * g.tiles_n);
+    {
+      // the product is symmetric and kin_i8_fold_kernel reads its upper triangle only: the tiles below it are not formed
+      // (GEMMA_HIP_KIN_UPPER=0: all of them, as in round 2)
+      const char *eu = getenv("GEMMA_HIP_KIN_UPPER");
+      if (!(eu && eu[0] == '0')) {
+        if (int rc = kin_i8_tile_map(g.tiles_m, g.tiles_n)) return rc;
+        g.tile_map = g_ctx.kin_tmap.as<int>();
+        ntiles = (unsigned)g_ctx.kin_tmap_count;
+      }
+    }
+    hipLaunchKernelGGL(i8gemm_packed_kernel_t<false>, dim3(ntiles, 1), dim3(512), 3 * I8P_STAGE, s, g);
     HIPCHK(hipGetLastError());
     hipLaunchKernelGGL(kin_i8_accum_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)std::min<size_t>(n, 32768)), dim3(256), 0, s,
                        g_ctx.i8_C.as<int>(), (long)rows_b, (long)n, g_ctx.kin_GtG.as<double>());
@@ -448,7 +489,56 @@ static int kin_add_i8(const void *geno, size_t l, size_t ld, hipStream_t s) {
     c.A = g_ctx.i8_A.as<int8_t>(); c.At = g_ctx.kin_At.as<int8_t>(); c.mean = g_ctx.i8_mean.as<double>();
     c.l = (long)l; c.ldk = (long)ldk; c.ldl = (long)ldl; c.n = (long)n;
     c.S = g_ctx.kin_S.as<double>(); c.a = g_ctx.kin_a.as<double>(); c.smu2 = g_ctx.kin_a.as<double>() + n;
-    hipLaunchKernelGGL(kin_i8_corr_kernel, dim3((unsigned)n, (unsigned)((n + KI8_SEG - 1) / KI8_SEG)), dim3(256), 0, s, c);
+    c.lists_ok = nullptr;
+    // the correction on lists of the missing calls (kin_i8.hip.h, round 3); GEMMA_HIP_KIN_LISTS=0 keeps the round-2 kernel,
+    // GEMMA_HIP_KIN_LIST_CAP=<entries> overrides the list capacity (tests: forces the on-device fall-back)
+    const char *el = getenv("GEMMA_HIP_KIN_LISTS");
+    const bool lists = !(el && el[0] == '0') && l < ((size_t)1 << 18);
+    const unsigned nseg = (unsigned)((n + KI8_SEG - 1) / KI8_SEG);
+    if (lists) {
+      size_t cap = std::max<size_t>(l * n / 16, (size_t)1 << 20);
+      if (const char *ec = getenv("GEMMA_HIP_KIN_LIST_CAP")) cap = std::max<size_t>((size_t)atoll(ec), 1);
+      cap = std::min<size_t>(cap, (size_t)1 << 30);
+      const size_t ld2 = (size_t)256 * nseg; // dwords per row of the 2-bit copy (kin_i8_pack2_kernel)
+      if (g_ctx.kin_A2.reserve(l * ld2 * 4) || g_ctx.kin_cnt.reserve((l + n) * 4) || g_ctx.kin_off.reserve((l + n + 2) * 4) ||
+          g_ctx.kin_listS.reserve(cap * 4) || g_ctx.kin_listJ.reserve(cap * 4) ||
+          g_ctx.kin_sub.reserve(l * (size_t)(nseg + 1) * 4) || g_ctx.kin_cj.reserve(n * 8) || g_ctx.kin_flag.reserve(16))
+        return fail(GEMMA_HIP_ENOMEM, "kin_add: lists of the missing calls");
+      int *cntS = g_ctx.kin_cnt.as<int>(), *cntJ = cntS + l, *offS = g_ctx.kin_off.as<int>(), *offJ = offS + l + 1;
+      int *ok = g_ctx.kin_flag.as<int>();
+      hipLaunchKernelGGL(kin_i8_pack2_kernel, dim3((unsigned)l, nseg), dim3(256), 0, s, g_ctx.i8_A.as<int8_t>(), (long)l,
+                         (long)ldk, (int)nseg, g_ctx.kin_A2.as<unsigned>());
+      hipLaunchKernelGGL(kin_i8_count_kernel, dim3((unsigned)((l + 3) / 4)), dim3(256), 0, s, g_ctx.i8_A.as<int8_t>(), (long)l,
+                         (long)ldk, (long)ldk, cntS);
+      hipLaunchKernelGGL(kin_i8_count_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s, g_ctx.kin_At.as<int8_t>(), (long)n,
+                         (long)ldl, (long)ldl, cntJ);
+      KinScanArgs sc;
+      sc.cntS = cntS; sc.cntJ = cntJ; sc.offS = offS; sc.offJ = offJ; sc.l = (long)l; sc.n = (long)n; sc.cap = (long)cap;
+      sc.ok = ok; sc.mean = g_ctx.i8_mean.as<double>(); sc.smu2 = g_ctx.kin_a.as<double>() + n;
+      hipLaunchKernelGGL(kin_i8_scan_kernel, dim3(1), dim3(1024), 0, s, sc);
+      hipLaunchKernelGGL(kin_i8_fill_kernel<false>, dim3((unsigned)((l + 3) / 4)), dim3(256), 0, s, g_ctx.i8_A.as<int8_t>(),
+                         (long)l, (long)ldk, (long)ldk, offS, g_ctx.kin_listS.as<int>(), ok, (const double *)nullptr, (long)l,
+                         (double *)nullptr, (double *)nullptr);
+      hipLaunchKernelGGL(kin_i8_fill_kernel<true>, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s, g_ctx.kin_At.as<int8_t>(),
+                         (long)n, (long)ldl, (long)ldl, offJ, g_ctx.kin_listJ.as<int>(), ok, g_ctx.i8_mean.as<double>(), (long)l,
+                         g_ctx.kin_a.as<double>(), g_ctx.kin_cj.as<double>());
+      hipLaunchKernelGGL(kin_i8_sub_kernel, dim3((unsigned)((l * (nseg + 1) + 255) / 256)), dim3(256), 0, s, offS,
+                         g_ctx.kin_listS.as<int>(), (long)l, (int)nseg, ok, g_ctx.kin_sub.as<int>());
+      KinCorr2Args c2;
+      c2.A2 = g_ctx.kin_A2.as<unsigned>(); c2.ld2 = (long)ld2; c2.mean = g_ctx.i8_mean.as<double>(); c2.n = (long)n;
+      c2.offJ = offJ; c2.listJ = g_ctx.kin_listJ.as<int>(); c2.offS = offS; c2.listS = g_ctx.kin_listS.as<int>();
+      c2.sub = g_ctx.kin_sub.as<int>(); c2.nseg = (int)nseg; c2.cj = g_ctx.kin_cj.as<double>();
+      c2.S = g_ctx.kin_S.as<double>(); c2.ok = ok;
+      {
+        const char *ed = getenv("GEMMA_HIP_KIN_DBG");
+        c2.dbg_skip_pairs = (ed && ed[0] == '1') ? 1 : 0;
+        c2.dbg_skip_main = (ed && ed[0] == '2') ? 1 : 0;
+      }
+      hipLaunchKernelGGL(kin_i8_corr2_kernel, dim3((unsigned)n, nseg), dim3(256), 0, s, c2);
+      HIPCHK(hipGetLastError());
+      c.lists_ok = ok;
+    }
+    hipLaunchKernelGGL(kin_i8_corr_kernel, dim3((unsigned)n, nseg), dim3(256), 0, s, c);
     HIPCHK(hipGetLastError());
   }
   g_ctx.kin_ns += l;

@@ -63,6 +63,8 @@ struct I8PackArgs {
   int fuse;          // 1: two digits per output plane (needs n * 2 * 128 * 257 < 2^31): 7 digits -> planes {0}, {2,1},
                      // {4,3}, {6,5}; 6 digits -> {1,0}, {3,2}, {5,4};  0: one plane per digit
   int digits;        // 6 or 7
+  const int *tile_map = nullptr; // (tile_m, tile_n) per linear tile index when only some tiles are wanted (the symmetric
+                                 // product of kin_i8.hip.h: tiles that meet the upper triangle); the grid has that many blocks
 };
 constexpr int I8P_BM = 128;
 constexpr int I8P_STAGE = 49152;
@@ -86,6 +88,10 @@ __global__ __launch_bounds__(512, 2) void i8gemm_packed_kernel_t(I8PackArgs g) {
     const int in = L - grp * per_group;
     tm = first_m + in % gsz;
     tn = in / gsz;
+    if (g.tile_map) {
+      tm = g.tile_map[2 * L];
+      tn = g.tile_map[2 * L + 1];
+    }
   }
   // output plane q: fused pairs of digits when g.fuse (256 * C_{d+1} + C_d still fits int32): planes
   // {0}, {2,1}, {4,3}, {6,5}; otherwise one digit per plane

@@ -223,6 +223,17 @@ def test_kinship_integer_path(gpu_api, oracle, monkeypatch):
     assert np.array_equal(K1, K1.T) and np.abs(K1[17]).max() < 1e-13 * scale  # a never-called individual: centred row of zeros
     _record("kinship -gk 1 PLINK n=%d p=%d: integer path %.2e, fp64 SYRK %.2e (max abs err / max |K|)"
             % (n, p, np.abs(K1 - ref).max() / scale, np.abs(K0 - ref).max() / scale))
+    # round 3: the correction runs on lists of the missing calls and G^T G on the tiles that meet the upper triangle; the round-2
+    # kernels (switches off), and the on-device fall-back when the lists would not fit their buffers, give the same matrix
+    for env in ({"GEMMA_HIP_KIN_LISTS": "0"}, {"GEMMA_HIP_KIN_UPPER": "0"}, {"GEMMA_HIP_KIN_LIST_CAP": "1000"},
+                {"GEMMA_HIP_KIN_LISTS": "0", "GEMMA_HIP_KIN_UPPER": "0"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        Kv = gpu_api.CalcKin(raw, L.GENO_PLINK_2BIT, n, 1, batch=300)
+        for k in env:
+            monkeypatch.delenv(k)
+        assert np.abs(Kv - ref).max() / scale < 2e-14 and np.abs(Kv - K1).max() / scale < 4e-15, env
+        assert np.array_equal(Kv, Kv.T)
     # mixed run: 400 SNPs as PLINK blocks (integer accumulators) + 300 as an fp64 individual-major block (SYRK), one kin_end
     monkeypatch.setenv("GEMMA_HIP_KIN_I8", "1")
     Xc = oracle.kin_prepare(G[400:], 1)
