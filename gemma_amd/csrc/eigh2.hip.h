@@ -683,35 +683,71 @@ struct Q2ApplyArgs {
   const double *pack;
   const long *goff;
   int nJ, kmaxall;
+  // dynamic schedule (sync != nullptr): tasks (segment of chase steps k, block of 64 rows), segment-major; sync[0] = next task,
+  // sync[1] = error flag, sync[2 + rb] = segments done for row block rb; kseg[0 .. nseg] = first chase step of every segment
+  int *sync;
+  const int *kseg;
+  int nseg, nrb;
 };
 // 4 wavefronts x 16 rows of Z^T per workgroup.  Lane l = (li = l & 15, lk = l >> 4) holds
 // x[4 ct + r] = Z^T[row0 + li][c0 + 16 ct + lk + 4 r]: tile ct of X^T in the MFMA accumulator layout, and at the same
 // time the operand fragment of k-step 4 ct + r.
 constexpr int Q2_MAXJ = 2048; // sweep blocks the kernel can index (n <= 65 536)
+constexpr int Q2_MAXSEG = 64;  // segments of chase steps of the dynamic schedule
+// Balance (round 3): a row block is one wavefront per SIMD for the whole launch, and n / 64 row blocks on 2 x 256 workgroup
+// slots leave the CUs that got two of them with twice the work (n = 20 000: 313 blocks, 0.57 s = the time of the 57 CUs with
+// two; one block alone on a CU runs 1.5 x faster than each of two, so the rest idle for a third of the launch).  The window of
+// Z^T is loaded at the first group of a chase step k and stored at its last one, so the steps of a row block can be handed from
+// one workgroup to another between any two k: the launch is 2 x CUs persistent workgroups that draw tasks (segment of k, row
+// block) from a counter in segment-major order; a task waits for the previous segment of its row block (claimed earlier, hence
+// running: no deadlock; bounded wait and an error flag as in the chase) with agent-scope release / acquire around the hand-over.
 __global__ __launch_bounds__(256, 2) void q2_apply_kernel(Q2ApplyArgs g) {
   __shared__ double Ls[E2_PACK];
   __shared__ int sgoff[Q2_MAXJ]; // first group of every sweep block: looked up through LDS so that the lookup never waits on
                                  // the vector-memory counter behind the window loads in flight
+  __shared__ int s_task;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, li = lane & 15, lk = lane >> 4;
   const long n = g.n;
-  const long row = (long)blockIdx.x * 64 + wave * 16 + li;
-  const bool rok = row < n;
-  double *zrow = g.ZT + (rok ? row : 0) * n;
   for (int i = t; i < g.nJ; i += 256) sgoff[i] = (int)g.goff[i];
   __syncthreads();
   constexpr int NT = E2_WIN / 16; // 10 window tiles
   constexpr int PK_N = (E2_PACK / 2 + 255) / 256; // 16-byte pieces of a pack per thread
   double x[4 * NT];
   e2_v2 pk[PK_N];
+  const bool dyn = g.sync != nullptr;
+ for (;;) {
+  int rb = blockIdx.x, kfirst = 0, kend = g.kmaxall, segi = 0;
+  if (dyn) {
+    if (t == 0) {
+      int task = atomicAdd(g.sync, 1);
+      if (task < g.nseg * g.nrb) {
+        const int sg = task / g.nrb;
+        if (sg > 0 && !bc_wait(g.sync + 2 + (task - sg * g.nrb), sg, g.sync + 1)) task = 0x7fffffff;
+      }
+      s_task = task;
+    }
+    __syncthreads();
+    const int task = s_task;
+    __syncthreads();
+    if (task >= g.nseg * g.nrb) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    segi = task / g.nrb;
+    rb = task - segi * g.nrb;
+    kfirst = g.kseg[segi];
+    kend = g.kseg[segi + 1];
+  }
+  const long row = (long)rb * 64 + wave * 16 + li;
+  const bool rok = row < n;
+  double *zrow = g.ZT + (rok ? row : 0) * n;
   {
-    const long lim0 = n - 2; // first group: k = 0, the last sweep block
+    const long lim0 = n - 2 - (long)kfirst * E2_B; // first group of this task: step kfirst, its last sweep block
     const long Jb0 = (lim0 / E2_NB < g.nJ - 1) ? lim0 / E2_NB : g.nJ - 1;
-    const e2_v2 *src = reinterpret_cast<const e2_v2 *>(g.pack + (size_t)(sgoff[Jb0]) * E2_PACK);
+    const e2_v2 *src = reinterpret_cast<const e2_v2 *>(g.pack + (size_t)(sgoff[Jb0 < 0 ? 0 : Jb0] + kfirst) * E2_PACK);
 #pragma unroll
     for (int q = 0; q < PK_N; ++q)
       if (t + 256 * q < E2_PACK / 2) pk[q] = src[t + 256 * q];
   }
-  for (int k = 0; k < g.kmaxall; ++k) {
+  for (int k = kfirst; k < kend; ++k) {
     const long lim = n - 2 - (long)k * E2_B; // sweep blocks with J0 <= lim have a task at step k
     if (lim < 0) break;
     long Jbmax = lim / E2_NB;
@@ -785,7 +821,7 @@ __global__ __launch_bounds__(256, 2) void q2_apply_kernel(Q2ApplyArgs g) {
         if (nJb < 0) {
           nk = k + 1;
           const long nlim = n - 2 - nk * E2_B;
-          nJb = (nk < g.kmaxall && nlim >= 0) ? (nlim / E2_NB < g.nJ - 1 ? nlim / E2_NB : g.nJ - 1) : -1;
+          nJb = (nk < kend && nlim >= 0) ? (nlim / E2_NB < g.nJ - 1 ? nlim / E2_NB : g.nJ - 1) : -1;
         }
         if (nJb >= 0) {
           const e2_v2 *src = reinterpret_cast<const e2_v2 *>(g.pack + (size_t)(sgoff[nJb] + nk) * E2_PACK);
@@ -823,6 +859,11 @@ __global__ __launch_bounds__(256, 2) void q2_apply_kernel(Q2ApplyArgs g) {
       }
     }
   }
+  if (!dyn) return;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+  __syncthreads();
+  if (t == 0) __hip_atomic_store(g.sync + 2 + rb, segi + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+ }
 }
 
 // ---------------------------------------------------------------- host orchestration
@@ -832,6 +873,7 @@ struct Eig2Ws {
   long *goff = nullptr;
   double *P256 = nullptr, *Tpair = nullptr; // Q1 applied two panels at a time: three n x 256 buffers, one 256 x 256 factor
   int *prog = nullptr; // progress counters of the persistent bulge chase (+ the error flag)
+  int *q2sync = nullptr; // q2_apply_kernel's task counter, error flag, per-row-block progress; then the segment table
   long ngroups = 0, kmaxall = 0, nJ = 0;
 };
 
@@ -1033,8 +1075,65 @@ static inline int eig2_apply_q2(double *ZT, long n, Eig2Ws &w2, hipStream_t s, s
   Q2PackArgs pa{w2.V2, w2.tau2, n, w2.goff, w2.pack};
   hipLaunchKernelGGL(q2_pack_kernel, dim3((unsigned)w2.nJ, (unsigned)w2.kmaxall), dim3(256), 0, s, pa);
   EIG_HIP(hipGetLastError());
-  Q2ApplyArgs aa{ZT, n, w2.pack, w2.goff, (int)w2.nJ, (int)w2.kmaxall};
-  hipLaunchKernelGGL(q2_apply_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, s, aa);
+  Q2ApplyArgs aa{ZT, n, w2.pack, w2.goff, (int)w2.nJ, (int)w2.kmaxall, nullptr, nullptr, 0, 0};
+  const int nrb = (int)((n + 63) / 64);
+  int cus = 0;
+  {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+      cus = 0;
+    (void)hipGetLastError();
+  }
+  // GEMMA_HIP_EIGH_Q2_DYNAMIC=0: one workgroup per row block for the whole launch (round 2); =1: the dynamic schedule even
+  // where it cannot help (tests: small n); GEMMA_HIP_EIGH_Q2_WORKERS / _SEGMENTS override the persistent grid and the cut
+  const char *ed = getenv("GEMMA_HIP_EIGH_Q2_DYNAMIC");
+  // one workgroup alone on a CU does 1.07 units of work per unit of time, two do 1.41 together (measured: n = 16 384 / 32 768);
+  // with C row blocks on 2 x CUs slots only C are ever runnable and they sit where the hardware put them, so below
+  // C = 1.29 CUs (where 2 p (1 - p) 1.07 + p^2 1.41 = 1.07, p = C / (2 CUs)) one workgroup per CU is the better grid
+  // (n = 20 000: 0.478 s against 0.512 s; one workgroup per row block: 0.570 s)
+  int workers = (100L * nrb >= 129L * cus) ? 2 * cus : cus;
+  if (const char *ew = getenv("GEMMA_HIP_EIGH_Q2_WORKERS")) workers = std::max(1, atoi(ew));
+  const bool force = ed && ed[0] == '1';
+  if (!(ed && ed[0] == '0') && cus > 0 && (force || (nrb > cus && nrb % workers != 0))) {
+    // segments of chase steps with about the same number of groups each, ~24 tasks per persistent workgroup
+    std::vector<long> groups((size_t)w2.kmaxall, 0);
+    long total = 0;
+    for (long k = 0; k < w2.kmaxall; ++k) {
+      const long lim = n - 2 - k * E2_B;
+      if (lim < 0) break;
+      groups[k] = std::min<long>(lim / E2_NB, w2.nJ - 1) + 1;
+      total += groups[k];
+    }
+    int nseg = (int)std::min<long>(std::min<long>(Q2_MAXSEG, w2.kmaxall), (24L * workers + nrb - 1) / nrb);
+    if (const char *es = getenv("GEMMA_HIP_EIGH_Q2_SEGMENTS")) nseg = std::max(1, std::min<int>(atoi(es), std::min<long>(Q2_MAXSEG, w2.kmaxall)));
+    std::vector<int> hs((size_t)nrb + 2, 0), kseg;
+    kseg.push_back(0);
+    long acc = 0;
+    for (long k = 0; k < w2.kmaxall && (int)kseg.size() < nseg; ++k) {
+      acc += groups[k];
+      if (acc * nseg >= total * (long)kseg.size() && k + 1 < w2.kmaxall) kseg.push_back((int)(k + 1));
+    }
+    nseg = (int)kseg.size();
+    kseg.push_back((int)w2.kmaxall);
+    EIG_HIP(hipMemsetAsync(w2.q2sync, 0, ((size_t)nrb + 2) * sizeof(int), s));
+    EIG_HIP(hipMemcpyAsync(w2.q2sync + nrb + 2, kseg.data(), kseg.size() * sizeof(int), hipMemcpyHostToDevice, s));
+    EIG_HIP(hipStreamSynchronize(s)); // kseg is a local
+    aa.sync = w2.q2sync;
+    aa.kseg = w2.q2sync + nrb + 2;
+    aa.nseg = nseg;
+    aa.nrb = nrb;
+    hipLaunchKernelGGL(q2_apply_kernel, dim3((unsigned)std::min(workers, nseg * nrb)), dim3(256), 0, s, aa);
+    EIG_HIP(hipGetLastError());
+    int flag = 0;
+    EIG_HIP(hipMemcpyAsync(&flag, w2.q2sync + 1, sizeof(int), hipMemcpyDeviceToHost, s));
+    EIG_HIP(hipStreamSynchronize(s));
+    if (flag) {
+      msg = "stage-2 back-transformation: a task waited too long for its predecessor";
+      return 4;
+    }
+    return 0;
+  }
+  hipLaunchKernelGGL(q2_apply_kernel, dim3((unsigned)nrb), dim3(256), 0, s, aa);
   EIG_HIP(hipGetLastError());
   return 0;
 }
@@ -1084,6 +1183,9 @@ static inline int eig2_apply_q1(double *ZT, long n, EigWs &ws, Eig2Ws &w2, hipSt
   return 0;
 }
 
+// (Round 3 tried to allocate the buffers stage 1 does not touch -- Delta, Wk, V2, pack: 76 GB at n = 50 000 -- on a helper thread
+// beside stage 1: hipMalloc costs 0.5-2.9 s for the same sizes from box to box, but the runtime serialises it with the kernel
+// launches of the other thread; stage 1 took exactly as much longer as the helper spent in hipMalloc.)
 static inline bool eig2_alloc(long n, EigWs &ws, Eig2Ws &w2) {
   const long nsweep = n - 2;
   w2.kmaxall = (n - 1 + E2_B - 1) / E2_B;
@@ -1100,7 +1202,7 @@ static inline bool eig2_alloc(long n, EigWs &ws, Eig2Ws &w2) {
             ws.get(w2.V2, (size_t)w2.kmaxall * n * E2_B) && ws.get(w2.tau2, (size_t)w2.kmaxall * n) &&
             ws.get(w2.pack, (size_t)w2.ngroups * E2_PACK) && ws.get(w2.goff, (size_t)w2.nJ + 1) &&
             ws.get(w2.prog, (size_t)w2.kmaxall + 4) && ws.get(w2.P256, (size_t)3 * n * 2 * E2_B) &&
-            ws.get(w2.Tpair, (size_t)4 * E2_B * E2_B);
+            ws.get(w2.Tpair, (size_t)4 * E2_B * E2_B) && ws.get(w2.q2sync, (size_t)(n + 63) / 64 + 2 + Q2_MAXSEG + 2);
   if (!ok) return false;
   return hipMemcpy(w2.goff, goff.data(), goff.size() * sizeof(long), hipMemcpyHostToDevice) == hipSuccess;
 }

@@ -257,6 +257,25 @@ def test_eigh_two_stage_end_to_end(gpu_api, n, kind, chase, monkeypatch):
     assert np.abs(w - w1).max() <= 30 * n * EPS * max(np.abs(w1).max(), 1e-300)
 
 
+@pytest.mark.parametrize("n,segments,workers", [(1538, "5", "7"), (2050, "64", "512"), (1000, "1", "3")])
+def test_stage2_backtransform_dynamic_schedule(gpu_api, n, segments, workers, monkeypatch):
+    """q2_apply_kernel as persistent workgroups drawing (segment of chase steps, row block) tasks (round 3; by default only where
+    n / 64 row blocks do not fill 2 x CUs slots evenly) applies the same reflectors to the same rows in the same order as one
+    workgroup per row block: eigenvectors identical bit for bit; more workers than tasks, one segment, fewer workers than row
+    blocks (every hand-over between workgroups goes through the progress flags)."""
+    monkeypatch.setenv("GEMMA_HIP_EIGH_STAGES", "2")
+    A = _sym(n, 5 * n + 1, "kinship")
+    monkeypatch.setenv("GEMMA_HIP_EIGH_Q2_DYNAMIC", "0")
+    U0, w0 = np.zeros((n, n)), np.zeros(n)
+    gpu_api.EigenDecomp_Zeroed(A.copy(), U0, w0)
+    monkeypatch.setenv("GEMMA_HIP_EIGH_Q2_DYNAMIC", "1")
+    monkeypatch.setenv("GEMMA_HIP_EIGH_Q2_SEGMENTS", segments)
+    monkeypatch.setenv("GEMMA_HIP_EIGH_Q2_WORKERS", workers)
+    U1, w1 = np.zeros((n, n)), np.zeros(n)
+    gpu_api.EigenDecomp_Zeroed(A.copy(), U1, w1)
+    assert np.array_equal(w0, w1) and np.array_equal(U0, U1)
+
+
 def test_eigh_two_stage_4096_device(gpu_api, monkeypatch):
     import torch
     monkeypatch.setenv("GEMMA_HIP_EIGH_STAGES", "2")
