@@ -56,7 +56,7 @@ class MvNull(C.Structure):
 
 class MvOpt(C.Structure):
     _fields_ = [("em_iter", C.c_size_t), ("nr_iter", C.c_size_t), ("em_prec", C.c_double), ("nr_prec", C.c_double),
-                ("p_nr", C.c_double)]
+                ("p_nr", C.c_double), ("crt", C.c_size_t)]
 
 
 class GemmaHipError(RuntimeError):

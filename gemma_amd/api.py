@@ -498,19 +498,20 @@ class LM:
 
 class MVLMM:
     """Mirror of class MVLMM (src/mvlmm.h:32-104): the fields CopyFromParam fills (src/mvlmm.cpp:51-90) and
-    AnalyzeBimbam / AnalyzePlink (:2972-3899) with crt = 0.  sumStat is a dict of arrays with MPHSUMSTAT's fields
+    AnalyzeBimbam / AnalyzePlink (:2972-3899); crt = 1 is the reference's -crt (CalcCRT / PCRT).  sumStat is a dict of arrays with MPHSUMSTAT's fields
     (src/param.h:68-77): beta (l x d), Vbeta / Vg / Ve (l x d(d+1)/2, upper triangles row by row), p_wald, p_lrt, p_score."""
 
     def __init__(self, a_mode=1, l_min=1e-5, l_max=1e5, n_region=10, em_iter=10000, nr_iter=100, em_prec=1e-4,
-                 nr_prec=1e-4, p_nr=1e-3):
+                 nr_prec=1e-4, p_nr=1e-3, crt=0):
         self.a_mode = a_mode
+        self.crt = crt
         self.l_min, self.l_max, self.n_region = l_min, l_max, n_region
         self.em_iter, self.nr_iter, self.em_prec, self.nr_prec, self.p_nr = em_iter, nr_iter, em_prec, nr_prec, p_nr
         self.sumStat = {}
         self.null = None
 
     def _opt(self):
-        return L.MvOpt(self.em_iter, self.nr_iter, self.em_prec, self.nr_prec, self.p_nr)
+        return L.MvOpt(self.em_iter, self.nr_iter, self.em_prec, self.nr_prec, self.p_nr, self.crt)
 
     def fit_null(self, eval_, UtW, UtY):
         """The null block (src/mvlmm.cpp:3056-3208) -> dict with Vg/Ve/B/logl for 'remle' and 'mle'; also fills the

@@ -1920,6 +1920,7 @@ static void mv_default_opt(gemma_mvlmm_opt &o, const gemma_mvlmm_opt *opt) {
   o.em_prec = 1e-4;
   o.nr_prec = 1e-4;
   o.p_nr = 1e-3;
+  o.crt = 0;
 }
 
 // rows x cols (row-major, host) -> cols x rows on the device
@@ -2041,6 +2042,7 @@ extern "C" int gemma_hip_mvlmm_set(size_t d, const double *UtY, const gemma_mvlm
   a.nr_iter = (int)(o.nr_iter / 10);   // :3321,3344
   a.nr_prec = o.nr_prec * 10;
   a.p_nr = o.p_nr;
+  a.crt = o.crt == 1 ? 1 : 0;       // :3302,3329,3349 test crt == 1
   a.stride = (int)(d + 3 * (d * (d + 1) / 2) + 3);
   g_ctx.mv_d = d;
   g_ctx.mv_ready = true;

@@ -40,6 +40,7 @@ struct MvArgs {
   double p_nr;
   double *out;         // l x stride: beta[d], Vbeta[v], Vg[v], Ve[v], p_wald, p_lrt, p_score
   int stride;
+  int crt;             // -crt: Edgeworth-corrected p values (CalcCRT / PCRT) for the SNPs that reach the Newton-Raphson stage
 };
 
 #ifdef __HIPCC__
@@ -202,6 +203,79 @@ MV_HD double mv_chisq_Q(double x, int nu) {
     term *= y / (k + 0.5);
   }
   return erfc(sqrt(y)) + exp(-y) * sum;
+}
+
+// gsl_cdf_ugaussian_Qinv to ~1e-9 (Acklam's rational approximation) + one Newton step on erfc: only the start value of the
+// iteration below
+MV_HD double mv_ugaussian_Qinv(double Q) {
+  const double a[6] = {-3.969683028665376e+01, 2.209460984245205e+02, -2.759285104469687e+02,
+                       1.383577518672690e+02, -3.066479806614716e+01, 2.506628277459239e+00};
+  const double b[5] = {-5.447609879822406e+01, 1.615858368580409e+02, -1.556989798598866e+02,
+                       6.680131188771972e+01, -1.328068155288572e+01};
+  const double c[6] = {-7.784894002430293e-03, -3.223964580411365e-01, -2.400758277161838e+00,
+                       -2.549732539343734e+00, 4.374664141464968e+00, 2.938163982698783e+00};
+  const double d[4] = {7.784695709041462e-03, 3.224671290700398e-01, 2.445134137142996e+00, 3.754408661907416e+00};
+  const double p = 1.0 - Q;
+  double x;
+  if (p < 0.02425) {
+    const double q = sqrt(-2.0 * log(p));
+    x = (((((c[0] * q + c[1]) * q + c[2]) * q + c[3]) * q + c[4]) * q + c[5]) / ((((d[0] * q + d[1]) * q + d[2]) * q + d[3]) * q + 1.0);
+  } else if (p <= 1.0 - 0.02425) {
+    const double q = p - 0.5, r = q * q;
+    x = (((((a[0] * r + a[1]) * r + a[2]) * r + a[3]) * r + a[4]) * r + a[5]) * q /
+        (((((b[0] * r + b[1]) * r + b[2]) * r + b[3]) * r + b[4]) * r + 1.0);
+  } else {
+    const double q = sqrt(-2.0 * log(1.0 - p));
+    x = -(((((c[0] * q + c[1]) * q + c[2]) * q + c[3]) * q + c[4]) * q + c[5]) / ((((d[0] * q + d[1]) * q + d[2]) * q + d[3]) * q + 1.0);
+  }
+  const double e = 0.5 * erfc(x * 0.70710678118654752440) - Q;
+  return x + e / (exp(-0.5 * x * x) * 0.39894228040143267794);
+}
+
+// gsl_cdf_chisq_Qinv(Q, nu) = 2 gsl_cdf_gamma_Qinv(Q, nu / 2, 1) (GSL cdf/gammainv.c): start value by range of Q, then its
+// Lagrange-corrected Newton step until |step| <= 1e-10 x (at most 33 rounds)
+MV_HD double mv_chisq_Qinv(double Q, int nu) {
+  const double a = 0.5 * (double)nu;
+  if (Q == 1.0) return 0.0;
+  if (Q == 0.0) return 1.0 / 0.0;
+  const double lg = lgamma(a);
+  double x;
+  if (Q < 0.05) x = -log(Q) + lg;
+  else if (Q > 0.95) x = exp((lg + log1p(-Q)) / a);
+  else {
+    const double xg = mv_ugaussian_Qinv(Q);
+    x = (xg < -0.5 * sqrt(a)) ? a : sqrt(a) * xg + a;
+  }
+  for (int n = 0;;) {
+    const double dQ = Q - mv_chisq_Q(2.0 * x, nu);
+    const double phi = exp((a - 1.0) * log(x) - x - lg);
+    if (dQ == 0.0 || n++ > 32) break;
+    const double lambda = -dQ / fmax(2.0 * fabs(dQ / x), phi);
+    const double step0 = lambda, step1 = -((a - 1.0) / x - 1.0) * lambda * lambda / 4.0;
+    double step = step0;
+    if (fabs(step1) < 0.5 * fabs(step0)) step += step1;
+    if (x + step > 0) x += step;
+    else x /= 2.0;
+    if (!(fabs(step0) > 1e-10 * x)) break;
+  }
+  return 2.0 * x;
+}
+
+// PCRT (src/mvlmm.cpp:2952-2970): mode 1 Wald, 2 LRT, 3 score
+MV_HD double mv_pcrt(int mode, int d, double p_value, const double (&crt)[3]) {
+  const double q = (double)d;
+  const double chisq = mv_chisq_Qinv(p_value, d);
+  double chisq_crt;
+  if (mode == 1) {
+    const double a = crt[2] / (2.0 * q * (q + 2.0)), b = 1.0 + (crt[0] + crt[1]) / (2.0 * q);
+    const double rad = b * b + 4.0 * a * chisq;
+    chisq_crt = (-1.0 * b + (rad >= 0.0 ? sqrt(rad) : (0.0 / 0.0))) / (2.0 * a); // safe_sqrt: NaN below zero
+  } else if (mode == 2) {
+    chisq_crt = chisq / (1.0 + crt[0] / (2.0 * q));
+  } else {
+    chisq_crt = chisq;
+  }
+  return mv_chisq_Q(chisq_crt, d);
 }
 
 // ---------------------------------------------------------------- per-SNP state
@@ -614,7 +688,8 @@ template <int D, int C> struct MvNrScratch {
   static constexpr int W1 = 0, UU = W1 + 2 * D, R = UU + 2 * TD, S = R + 2 * C * D * D, WW = S + 2 * TD * T;
   static constexpr int Y3 = WW + 3 * TD, S3 = Y3 + 3 * D * TD, DT = S3 + 3 * D * D * T; // DT: rotated directions
   static constexpr int QI = DT + VS * D * D, GRAD = QI + D * C * C, HESS = GRAD + H2, HINV = HESS + H2 * H2;
-  static constexpr int LU = HINV + H2 * H2, DOUBLES = LU + H2 * H2;
+  // LU: the elimination scratch of invert_hessian, afterwards the 8 d x d tables of crt_factors
+  static constexpr int LU = HINV + H2 * H2, LUSZ = (H2 * H2 > 8 * D * D) ? H2 * H2 : 8 * D * D, DOUBLES = LU + LUSZ;
 };
 
 MV_HD void mv_lane_fence() {
@@ -929,6 +1004,100 @@ template <int D, int C, class Lanes> struct MvNr {
     }
   }
 
+  // CalcCRT (src/mvlmm.cpp:2054-2331) at the point of the last eval(..., true) + invert_hessian(): Rothenberg's Edgeworth
+  // correction factors.  The reference forms dense dc x dc products of Qi, xHiDHix (M) and xHiDHiDHix (MM) and takes traces of
+  // their SNP blocks against the inverse of Qi's SNP block; every one of those traces is invariant under the rotation that
+  // makes H_k diagonal, and there Qi is block-separable per component l (QI[l], c x c), its SNP block is diag(q_l),
+  // q_l = QI[l][z][z] (z = c - 1), M_v[(i,l1),(j,l2)] = Dt_v[l1][l2] S[a][l1,l2][i,j] and the diagonal blocks of MM are
+  // sum_q Dt_1[l][q] Dt_2[q][l] S3[s][l][q][i,j] -- the tables the Hessian already uses.  With
+  //   r^a[l1][l2][j] = sum_i QI[l1][z][i] S[a][l1,l2][i][j]
+  //   g^a[l1][l2]    = sum_j r^a[l1][l2][j] QI[l2][j][z]                         (SNP block of Qi M Qi = Dt o g^a)
+  //   h^{ab}[l][q]   = sum_ij r^a[l][q][i] QI[q][i][j] r^b[l][q][j]              (diagonal of the SNP block of Qi M Qi M Qi)
+  //   k^s[l][q]      = sum_ij QI[l][z][i] S3[s][l][q][i][j] QI[l][j][z]          (diagonal of the SNP block of Qi MM Qi)
+  // the reference's trC, trCC, trB follow as sums over (l, q); B, C, D and crt_a, b, c as written there (:2303-2331).
+  double crt[3] = {0.0, 0.0, 0.0};
+  MV_HD void crt_factors() {
+    constexpr int z = C - 1, DD = D * D;
+    const double *QI = lds + SC::QI, *DT = lds + SC::DT, *Hi = lds + SC::HINV;
+    double *gt = lds + SC::LU, *ht = gt + 2 * DD, *kt = ht + 3 * DD; // g[a], h[gg, ge, ee], k[ee, ge, gg]
+    for (int l1 = 0; l1 < D; ++l1)
+      for (int l2 = 0; l2 < D; ++l2) {
+        double r[2][C];
+        for (int a = 0; a < 2; ++a) {
+          const double *Sa = lds + SC::S + (a * TD + mv_tri(l1, l2, D)) * T;
+          for (int j = 0; j < C; ++j) {
+            double t = 0.0;
+            for (int i = 0; i < C; ++i) t += QI[l1 * C * C + z * C + i] * symget(Sa, i, j);
+            r[a][j] = t;
+          }
+          double gg = 0.0;
+          for (int j = 0; j < C; ++j) gg += r[a][j] * QI[l2 * C * C + j * C + z];
+          gt[a * DD + l1 * D + l2] = gg;
+        }
+        double hgg = 0.0, hge = 0.0, hee = 0.0;
+        for (int i = 0; i < C; ++i)
+          for (int j = 0; j < C; ++j) {
+            const double qq = QI[l2 * C * C + i * C + j];
+            hgg += r[1][i] * qq * r[1][j];
+            hge += r[1][i] * qq * r[0][j];
+            hee += r[0][i] * qq * r[0][j];
+          }
+        ht[0 * DD + l1 * D + l2] = hgg;
+        ht[1 * DD + l1 * D + l2] = 2.0 * hge; // Qi M_g Qi M_e Qi + Qi M_e Qi M_g Qi: equal on this diagonal (QI symmetric)
+        ht[2 * DD + l1 * D + l2] = hee;
+        for (int sI = 0; sI < 3; ++sI) {
+          const double *S3 = lds + SC::S3 + ((sI * D + l1) * D + l2) * T;
+          double t = 0.0;
+          for (int i = 0; i < C; ++i)
+            for (int j = 0; j < C; ++j) t += QI[l1 * C * C + z * C + i] * symget(S3, i, j) * QI[l1 * C * C + j * C + z];
+          kt[sI * DD + l1 * D + l2] = t;
+        }
+      }
+    mv_lane_fence();
+    double qinv[D];
+    for (int l = 0; l < D; ++l) qinv[l] = 1.0 / QI[l * C * C + z * C + z];
+    double Bs = 0.0, Cs = 0.0, Ds = 0.0;
+    for (int v1 = 0; v1 < VS; ++v1) {
+      const double *D1 = DT + v1 * DD;
+      double trCg1 = 0.0, trCe1 = 0.0;
+      for (int l = 0; l < D; ++l) {
+        trCg1 -= D1[l * D + l] * gt[DD + l * D + l] * qinv[l];
+        trCe1 -= D1[l * D + l] * gt[l * D + l] * qinv[l];
+      }
+      for (int v2 = v1; v2 < VS; ++v2) {
+        const double *D2 = DT + v2 * DD;
+        double trCg2 = 0.0, trCe2 = 0.0, trCC_gg = 0.0, trCC_ge = 0.0, trCC_ee = 0.0, trB_gg = 0.0, trB_ge = 0.0, trB_ee = 0.0;
+        for (int l = 0; l < D; ++l) {
+          trCg2 -= D2[l * D + l] * gt[DD + l * D + l] * qinv[l];
+          trCe2 -= D2[l * D + l] * gt[l * D + l] * qinv[l];
+        }
+        for (int l1 = 0; l1 < D; ++l1)
+          for (int l2 = 0; l2 < D; ++l2) {
+            const double dd = D1[l1 * D + l2] * D2[l2 * D + l1];
+            const double w12 = dd * qinv[l1] * qinv[l2];
+            const double g1 = gt[DD + l1 * D + l2], g0 = gt[l1 * D + l2], g1t = gt[DD + l2 * D + l1], g0t = gt[l2 * D + l1];
+            trCC_gg += w12 * g1 * g1t;
+            trCC_ge += w12 * (g1 * g0t + g0 * g1t);
+            trCC_ee += w12 * g0 * g0t;
+            const double wl = dd * qinv[l1]; // (l, q) = (l1, l2)
+            trB_gg += wl * (kt[2 * DD + l1 * D + l2] - ht[0 * DD + l1 * D + l2]);
+            trB_ge += wl * (2.0 * kt[1 * DD + l1 * D + l2] - ht[1 * DD + l1 * D + l2]);
+            trB_ee += wl * (kt[0 * DD + l1 * D + l2] - ht[2 * DD + l1 * D + l2]);
+          }
+        const double trD_gg = 2.0 * trB_gg, trD_ge = 2.0 * trB_ge, trD_ee = 2.0 * trB_ee;
+        const double h_gg = -Hi[v1 * H2 + v2], h_ge = -Hi[v1 * H2 + v2 + VS], h_ee = -Hi[(v1 + VS) * H2 + v2 + VS];
+        const double f = (v1 != v2) ? 2.0 : 1.0;
+        Bs += f * (h_gg * trB_gg + h_ge * trB_ge + h_ee * trB_ee);
+        Cs += f * (h_gg * (trCC_gg + 0.5 * trCg1 * trCg2) + h_ge * (trCC_ge + 0.5 * trCg1 * trCe2 + 0.5 * trCe1 * trCg2) +
+                   h_ee * (trCC_ee + 0.5 * trCe1 * trCe2));
+        Ds += f * (h_gg * (trCC_gg + 0.5 * trD_gg) + h_ge * (trCC_ge + 0.5 * trD_ge) + h_ee * (trCC_ee + 0.5 * trD_ee));
+      }
+    }
+    crt[0] = 2.0 * Ds - Cs;
+    crt[1] = 2.0 * Bs;
+    crt[2] = Cs;
+  }
+
   MV_HD static bool is_pd(const double (&V)[D * D]) {
     double w[D], Z[D * D];
     mv_jacobi<D>(V, w, Z);
@@ -939,7 +1108,8 @@ template <int D, int C, class Lanes> struct MvNr {
   }
 
   // MphNR with the per-SNP limits (nr_iter / 10, nr_prec * 10); returns logl_H1
-  MV_HD double operator()(bool reml, double lndet_xxt, double (&Vg)[D * D], double (&Ve)[D * D]) {
+  // max_iter < 0: g.nr_iter.  With g.crt the factors of the LAST CalcDev call stay in crt[] (:2522-2530, for 'R' and 'L' alike)
+  MV_HD double operator()(bool reml, double lndet_xxt, double (&Vg)[D * D], double (&Ve)[D * D], int max_iter = -1) {
     constexpr double LOG2PI = 1.8378770664093454836;
     const int n = g.n;
     const double logl_const = reml ? -0.5 * (double)(n - C) * (double)D * LOG2PI + 0.5 * (double)D * lndet_xxt
@@ -947,7 +1117,9 @@ template <int D, int C, class Lanes> struct MvNr {
     double Vg_save[D * D], Ve_save[D * D];
     double logl_old = 0.0, logl_new = 0.0;
     const double *Hi = lds + SC::HINV, *grad = lds + SC::GRAD;
-    for (int t = 0; t < g.nr_iter; ++t) {
+    const int iters = max_iter < 0 ? g.nr_iter : max_iter;
+    crt[0] = crt[1] = crt[2] = 0.0;
+    for (int t = 0; t < iters; ++t) {
 #pragma unroll
       for (int i = 0; i < D * D; ++i) {
         Vg_save[i] = Vg[i];
@@ -997,12 +1169,16 @@ template <int D, int C, class Lanes> struct MvNr {
       eval(reml, logl_const, Vg, Ve, true);
       invert_hessian();
       mv_lane_fence();
+      if (g.crt && C > 1) {
+        crt_factors();
+        mv_lane_fence();
+      }
     }
     return logl_new;
   }
 };
 
-// One SNP: the body of the loop at src/mvlmm.cpp:3287-3374 (crt = 0).  nr: callable (reml) -> logl_H1 that refines
+// One SNP: the body of the loop at src/mvlmm.cpp:3287-3374 (with -crt: PCRT on the SNPs that reach MphNR).  nr: callable (reml) -> logl_H1 that refines
 // Vg, Ve by Newton-Raphson, or a no-op returning NaN when the stage is not compiled in.
 template <int D, int C, class Lanes, class NR>
 MV_HD void mv_one_snp(const MvArgs &g, long s, NR &&nr) {
@@ -1024,7 +1200,13 @@ MV_HD void mv_one_snp(const MvArgs &g, long s, NR &&nr) {
   }
   const double lndet_xxt = mv_xxt<C, Lanes>(g, x, XXti);
   double p_wald = 0.0, p_lrt = 0.0, p_score = 0.0;
-  if (g.a_mode == 3 || g.a_mode == 4) p_score = mv_calcp<D, C, Lanes>(g, x, Vg0, Ve0, beta, Vbeta);
+  if (g.a_mode == 3 || g.a_mode == 4) {
+    p_score = mv_calcp<D, C, Lanes>(g, x, Vg0, Ve0, beta, Vbeta);
+    if (p_score < g.p_nr && g.crt == 1) { // :3302-3306: one CalcDev at the null estimates
+      nr(true, lndet_xxt, Vg, Ve, 1);
+      p_score = mv_pcrt(3, D, p_score, nr.crt);
+    }
+  }
   if (g.a_mode == 2 || g.a_mode == 4) {
     double logl_H1 = mv_em<D, C, Lanes>(g, x, false, g.em_iter, g.em_prec, lndet_xxt, XXti, Vg, Ve, B);
     mv_calcp<D, C, Lanes>(g, x, Vg, Ve, beta, Vbeta);
@@ -1033,6 +1215,7 @@ MV_HD void mv_one_snp(const MvArgs &g, long s, NR &&nr) {
       logl_H1 = nr(false, lndet_xxt, Vg, Ve);
       mv_calcp<D, C, Lanes>(g, x, Vg, Ve, beta, Vbeta);
       p_lrt = mv_chisq_Q(2.0 * (logl_H1 - g.logl_H0), D);
+      if (g.crt == 1) p_lrt = mv_pcrt(2, D, p_lrt, nr.crt);
     }
   }
   if (g.a_mode == 1 || g.a_mode == 4) {
@@ -1041,6 +1224,7 @@ MV_HD void mv_one_snp(const MvArgs &g, long s, NR &&nr) {
     if (p_wald < g.p_nr) {
       nr(true, lndet_xxt, Vg, Ve);
       p_wald = mv_calcp<D, C, Lanes>(g, x, Vg, Ve, beta, Vbeta);
+      if (g.crt == 1) p_wald = mv_pcrt(1, D, p_wald, nr.crt);
     }
   }
   if (Lanes::lane() == 0) {

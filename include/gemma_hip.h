@@ -208,17 +208,18 @@ int gemma_hip_lmm_finish(double *time_UtX_min, double *time_opt_min);
 
 /* ---- multivariate LMM (-lmm 1..4 -n a b c ...) ------------------------------------ */
 /* MVLMM::AnalyzeBimbam / AnalyzePlink, src/mvlmm.cpp:2972-3416 / :3418-3899.  d phenotypes (1..5), n_cvt covariates
- * (1..3); crt = 0 (the Edgeworth correction CalcCRT / PCRT, :2054-2358 / :2952-2970, is not built).
+ * (1..3); opt->crt = 1 applies the Edgeworth correction (CalcCRT / PCRT, :2054-2358 / :2952-2970) as -crt does.
  * gemma_mvlmm_null holds what the null-model block (:3056-3208) leaves behind: V_g, V_e (d x d row-major, leading
  * dimension d), B (d x n_cvt) and the log-likelihood, for the REMLE and the MLE fit. */
 typedef struct {
   double Vg_remle[25], Ve_remle[25], B_remle[20], logl_remle_H0;
   double Vg_mle[25], Ve_mle[25], B_mle[20], logl_mle_H0;
 } gemma_mvlmm_null;
-/* PARAM defaults (src/param.cpp:94-107): em_iter 10000, em_prec 1e-4, nr_iter 100, nr_prec 1e-4, p_nr 1e-3 */
+/* PARAM defaults (src/param.cpp:94-107): em_iter 10000, em_prec 1e-4, nr_iter 100, nr_prec 1e-4, p_nr 1e-3, crt 0 */
 typedef struct {
   size_t em_iter, nr_iter;
   double em_prec, nr_prec, p_nr;
+  size_t crt; /* PARAM::crt (-crt, src/gemma.cpp:1398-1399): 1 = PCRT on the SNPs that reach MphNR (:3302-3306,3329-3331,3349-3351) */
 } gemma_mvlmm_opt;
 /* The null block: MphInitial (:2763-2948; one univariate REML fit per trait, and for d > 4 one two-trait fit per pair),
  * MphEM + MphNR + MphCalcBeta for 'R', then for 'L' starting from the REMLE fit.  Host pointers: eval (n), UtW (n x

@@ -892,7 +892,7 @@ private:
 };
 
 // class MVLMM, src/mvlmm.h:32-104 -- multivariate LMM (`-lmm m -n a b c ...`): the members CopyFromParam fills
-// (src/mvlmm.cpp:51-90), AnalyzePlink / AnalyzeBimbam rows (:3418-3899 / :2972-3416, crt = 0) and WriteFiles (:117-210).
+// (src/mvlmm.cpp:51-90), AnalyzePlink / AnalyzeBimbam rows (:3418-3899 / :2972-3416; crt as -crt sets it) and WriteFiles (:117-210).
 // sumStat holds MPHSUMSTAT (src/param.h:68-77) flat: per SNP beta[d], Vbeta[v], Vg[v], Ve[v], p_wald, p_lrt, p_score
 // with v = d (d + 1) / 2 -- the record gemma_hip_mvlmm_batch writes.
 class MVLMM {
@@ -903,6 +903,7 @@ public:
   size_t n_region = 10;
   size_t em_iter = 10000, nr_iter = 100; // src/param.cpp:94-107
   double em_prec = 1e-4, nr_prec = 1e-4, p_nr = 1e-3;
+  size_t crt = 0; // PARAM::crt (-crt, src/gemma.cpp:1398-1399)
   size_t ni_total = 0, ni_test = 0, n_cvt = 1, n_ph = 0;
   double logl_remle_H0 = 0.0, logl_mle_H0 = 0.0, time_UtX = 0.0, time_opt = 0.0;
   gemma_mvlmm_null null_fit;
@@ -1023,7 +1024,7 @@ private:
     ni_test = U->size1;
     n_cvt = UtW->size2;
     n_ph = UtY->size2;
-    const gemma_mvlmm_opt opt = {em_iter, nr_iter, em_prec, nr_prec, p_nr};
+    const gemma_mvlmm_opt opt = {em_iter, nr_iter, em_prec, nr_prec, p_nr, crt};
     enforce_hip(gemma_hip_mvlmm_null(ni_test, n_cvt, n_ph, eval->data, UtW->data, UtY->data, l_min, l_max, n_region, &opt,
                                      &null_fit),
                 "MVLMM (null model)");

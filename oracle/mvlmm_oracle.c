@@ -214,6 +214,78 @@ double orc_cdf_chisq_Q(double x, double nu) {
   return erfc(sqrt(y)) + exp(-y) * sum;
 }
 
+/* gsl_cdf_chisq_Qinv(Q, nu) = 2 gsl_cdf_gamma_Qinv(Q, nu/2, 1) (GSL cdf/chisqinv.c -> cdf/gammainv.c): a start value by range of
+ * Q, then the Lagrange-corrected Newton step of gammainv.c until |step| <= 1e-10 x (at most 33 rounds).  The start value in the
+ * middle range uses the normal quantile; GSL's rational approximation of it is replaced by Acklam's (relative error 1e-9)
+ * polished by one Newton step on erfc -- the iteration converges to the same root to its 1e-10 tolerance either way. */
+static double mv_ugaussian_Qinv(double Q) {
+  static const double a[6] = {-3.969683028665376e+01, 2.209460984245205e+02, -2.759285104469687e+02,
+                              1.383577518672690e+02, -3.066479806614716e+01, 2.506628277459239e+00};
+  static const double b[5] = {-5.447609879822406e+01, 1.615858368580409e+02, -1.556989798598866e+02,
+                              6.680131188771972e+01, -1.328068155288572e+01};
+  static const double cc[6] = {-7.784894002430293e-03, -3.223964580411365e-01, -2.400758277161838e+00,
+                               -2.549732539343734e+00, 4.374664141464968e+00, 2.938163982698783e+00};
+  static const double dd[4] = {7.784695709041462e-03, 3.224671290700398e-01, 2.445134137142996e+00, 3.754408661907416e+00};
+  const double p = 1.0 - Q; /* lower tail */
+  double x;
+  if (p < 0.02425) {
+    const double q = sqrt(-2.0 * log(p));
+    x = (((((cc[0] * q + cc[1]) * q + cc[2]) * q + cc[3]) * q + cc[4]) * q + cc[5]) / ((((dd[0] * q + dd[1]) * q + dd[2]) * q + dd[3]) * q + 1.0);
+  } else if (p <= 1.0 - 0.02425) {
+    const double q = p - 0.5, r = q * q;
+    x = (((((a[0] * r + a[1]) * r + a[2]) * r + a[3]) * r + a[4]) * r + a[5]) * q /
+        (((((b[0] * r + b[1]) * r + b[2]) * r + b[3]) * r + b[4]) * r + 1.0);
+  } else {
+    const double q = sqrt(-2.0 * log(1.0 - p));
+    x = -(((((cc[0] * q + cc[1]) * q + cc[2]) * q + cc[3]) * q + cc[4]) * q + cc[5]) / ((((dd[0] * q + dd[1]) * q + dd[2]) * q + dd[3]) * q + 1.0);
+  }
+  const double e = 0.5 * erfc(x / sqrt(2.0)) - Q; /* Q(x) - Q; dQ/dx = -phi(x) */
+  return x + e / (exp(-0.5 * x * x) / sqrt(2.0 * M_PI));
+}
+
+double orc_cdf_chisq_Qinv(double Q, double nu) {
+  const double a = 0.5 * nu;
+  if (Q == 1.0) return 0.0;
+  if (Q == 0.0) return INFINITY;
+  double x;
+  if (Q < 0.05) x = -log(Q) + lgamma(a);
+  else if (Q > 0.95) x = exp((lgamma(a) + log1p(-Q)) / a);
+  else {
+    const double xg = mv_ugaussian_Qinv(Q);
+    x = (xg < -0.5 * sqrt(a)) ? a : sqrt(a) * xg + a;
+  }
+  for (unsigned n = 0;;) {
+    const double dQ = Q - orc_cdf_chisq_Q(2.0 * x, nu);
+    const double phi = exp((a - 1.0) * log(x) - x - lgamma(a)); /* gsl_ran_gamma_pdf(x, a, 1) */
+    if (dQ == 0.0 || n++ > 32) break;
+    const double lambda = -dQ / fmax(2.0 * fabs(dQ / x), phi);
+    const double step0 = lambda, step1 = -((a - 1.0) / x - 1.0) * lambda * lambda / 4.0;
+    double step = step0;
+    if (fabs(step1) < 0.5 * fabs(step0)) step += step1;
+    if (x + step > 0) x += step;
+    else x /= 2.0;
+    if (!(fabs(step0) > 1e-10 * x)) break;
+  }
+  return 2.0 * x;
+}
+
+/* PCRT (src/mvlmm.cpp:2952-2970): mode 1 Wald, 2 LRT, 3 score */
+double orc_pcrt(int mode, size_t d, double p_value, double crt_a, double crt_b, double crt_c) {
+  const double q = (double)d;
+  const double chisq = orc_cdf_chisq_Qinv(p_value, q);
+  double chisq_crt;
+  if (mode == 1) {
+    const double a = crt_c / (2.0 * q * (q + 2.0)), b = 1.0 + (crt_a + crt_b) / (2.0 * q);
+    const double rad = b * b + 4.0 * a * chisq;
+    chisq_crt = (-1.0 * b + (rad >= 0.0 ? sqrt(rad) : NAN)) / (2.0 * a); /* safe_sqrt: NaN for a negative argument */
+  } else if (mode == 2) {
+    chisq_crt = chisq / (1.0 + crt_a / (2.0 * q));
+  } else {
+    chisq_crt = chisq;
+  }
+  return orc_cdf_chisq_Q(chisq_crt, q);
+}
+
 /* ------------------------------------------------------------------ EigenProc, CalcQi */
 /* src/mvlmm.cpp:213-282 */
 static double mv_eigen_proc(size_t d, const double *Vg, const double *Ve, double *Dl, double *UltVeh, double *UltVehi) {
@@ -490,7 +562,111 @@ typedef struct {
   double logl;                       /* log (restricted) likelihood at (Vg, Ve) */
   double grad[2 * MV_MAXV];          /* d logl / d (Vg_v), then d logl / d (Ve_v) */
   double hess[4 * MV_MAXV * MV_MAXV]; /* the matrix CalcDev builds (before inversion), 2v x 2v */
+  double hinv[4 * MV_MAXV * MV_MAXV]; /* its LU inverse (:2510-2518) */
+  double crt[3];                     /* crt_a, crt_b, crt_c of CalcCRT at this point (c > 1; else 0) */
 } mv_dev;
+
+/* CalcCRT (src/mvlmm.cpp:2054-2331), Rothenberg's Edgeworth correction factors, in the reference's own dense form: Hinv the
+ * inverse of CalcDev's Hessian (g block first), Qi (dc x dc), QM[a][v] = Qi xHiDHix (a = 1: V_g weight), M12[s][v1][v2] =
+ * xHiDHiDHix (s = 0 ee, 1 ge, 2 gg; filled for v1 <= v2, which is all that is read).  Qi_s is the d x d block of the LAST
+ * covariate -- the SNP. */
+static double mv_sub_trace(size_t d, size_t c, const double *Mdc, const double *Qsi) { /* tr(sub(M) Qsi) */
+  const size_t dc = d * c, o = (c - 1) * d;
+  double t = 0.0;
+  for (size_t i = 0; i < d; ++i)
+    for (size_t k = 0; k < d; ++k) t += Mdc[(o + i) * dc + o + k] * Qsi[k * d + i];
+  return t;
+}
+static void mv_sub_times(size_t d, size_t c, const double *Mdc, const double *Qsi, double *out) { /* sub(M) Qsi, d x d */
+  const size_t dc = d * c, o = (c - 1) * d;
+  for (size_t i = 0; i < d; ++i)
+    for (size_t j = 0; j < d; ++j) {
+      double t = 0.0;
+      for (size_t k = 0; k < d; ++k) t += Mdc[(o + i) * dc + o + k] * Qsi[k * d + j];
+      out[i * d + j] = t;
+    }
+}
+static double mv_tr_prod(size_t d, const double *A, const double *B) {
+  double t = 0.0;
+  for (size_t i = 0; i < d; ++i)
+    for (size_t k = 0; k < d; ++k) t += A[i * d + k] * B[k * d + i];
+  return t;
+}
+static void mv_calc_crt(size_t d, size_t c, const double *Hinv, const double *Qi, const double *QM, const double *M12,
+                        double *crt) {
+  const size_t dc = d * c, m2 = dc * dc, vs = d * (d + 1) / 2, H2 = 2 * vs, o = (c - 1) * d;
+  double Qs[MV_MAXD * MV_MAXD], Qsi[MV_MAXD * MV_MAXD];
+  for (size_t i = 0; i < d; ++i)
+    for (size_t j = 0; j < d; ++j) Qs[i * d + j] = Qi[(o + i) * dc + o + j];
+  mv_lu_invert(Qs, d, Qsi);
+  double *buf = (double *)malloc(11 * m2 * sizeof(double));
+  double *QMQ_g1 = buf, *QMQ_e1 = buf + m2, *QMQ_g2 = buf + 2 * m2, *QMQ_e2 = buf + 3 * m2, *P_gg = buf + 4 * m2,
+         *P_ge = buf + 5 * m2, *P_ee = buf + 6 * m2, *T1 = buf + 7 * m2, *T2 = buf + 8 * m2, *T3 = buf + 9 * m2,
+         *T4 = buf + 10 * m2;
+  double B = 0.0, Cc = 0.0, D = 0.0;
+  for (size_t v1 = 0; v1 < vs; ++v1) {
+    const double *QM_g1 = QM + (1 * vs + v1) * m2, *QM_e1 = QM + (0 * vs + v1) * m2;
+    double A_g1[MV_MAXD * MV_MAXD], A_e1[MV_MAXD * MV_MAXD];
+    mv_mm(0, dc, dc, dc, QM_g1, Qi, QMQ_g1);
+    mv_mm(0, dc, dc, dc, QM_e1, Qi, QMQ_e1);
+    mv_sub_times(d, c, QMQ_g1, Qsi, A_g1);
+    mv_sub_times(d, c, QMQ_e1, Qsi, A_e1);
+    double trCg1 = 0.0, trCe1 = 0.0;
+    for (size_t k = 0; k < d; ++k) {
+      trCg1 -= A_g1[k * d + k];
+      trCe1 -= A_e1[k * d + k];
+    }
+    for (size_t v2 = v1; v2 < vs; ++v2) {
+      const double *QM_g2 = QM + (1 * vs + v2) * m2, *QM_e2 = QM + (0 * vs + v2) * m2;
+      double A_g2[MV_MAXD * MV_MAXD], A_e2[MV_MAXD * MV_MAXD];
+      mv_mm(0, dc, dc, dc, QM_g2, Qi, QMQ_g2);
+      mv_mm(0, dc, dc, dc, QM_e2, Qi, QMQ_e2);
+      mv_sub_times(d, c, QMQ_g2, Qsi, A_g2);
+      mv_sub_times(d, c, QMQ_e2, Qsi, A_e2);
+      double trCg2 = 0.0, trCe2 = 0.0;
+      for (size_t k = 0; k < d; ++k) {
+        trCg2 -= A_g2[k * d + k];
+        trCe2 -= A_e2[k * d + k];
+      }
+      const double trCC_gg = mv_tr_prod(d, A_g1, A_g2);
+      const double trCC_ge = mv_tr_prod(d, A_g1, A_e2) + mv_tr_prod(d, A_e1, A_g2);
+      const double trCC_ee = mv_tr_prod(d, A_e1, A_e2);
+      /* Qi M Qi M Qi */
+      mv_mm(0, dc, dc, dc, QM_g1, QMQ_g2, P_gg);
+      mv_mm(0, dc, dc, dc, QM_g1, QMQ_e2, P_ge);
+      mv_mm(0, dc, dc, dc, QM_e1, QMQ_g2, T1);
+      for (size_t i = 0; i < m2; ++i) P_ge[i] += T1[i];
+      mv_mm(0, dc, dc, dc, QM_e1, QMQ_e2, P_ee);
+      double trB_gg = -mv_sub_trace(d, c, P_gg, Qsi), trB_ge = -mv_sub_trace(d, c, P_ge, Qsi),
+             trB_ee = -mv_sub_trace(d, c, P_ee, Qsi);
+      /* Qi (xHiDHiDHix) Qi */
+      const double *MM_ee = M12 + ((0 * vs + v1) * vs + v2) * m2, *MM_ge = M12 + ((1 * vs + v1) * vs + v2) * m2,
+                   *MM_gg = M12 + ((2 * vs + v1) * vs + v2) * m2;
+      mv_mm(0, dc, dc, dc, Qi, MM_gg, T1);
+      mv_mm(0, dc, dc, dc, T1, Qi, T2);
+      trB_gg += mv_sub_trace(d, c, T2, Qsi);
+      mv_mm(0, dc, dc, dc, Qi, MM_ge, T1);
+      mv_mm(0, dc, dc, dc, T1, Qi, T3);
+      trB_ge += 2.0 * mv_sub_trace(d, c, T3, Qsi);
+      mv_mm(0, dc, dc, dc, Qi, MM_ee, T1);
+      mv_mm(0, dc, dc, dc, T1, Qi, T4);
+      trB_ee += mv_sub_trace(d, c, T4, Qsi);
+      const double trD_gg = 2.0 * trB_gg, trD_ge = 2.0 * trB_ge, trD_ee = 2.0 * trB_ee;
+      const double h_gg = -Hinv[v1 * H2 + v2], h_ge = -Hinv[v1 * H2 + v2 + vs], h_ee = -Hinv[(v1 + vs) * H2 + v2 + vs];
+      const int times = v1 != v2 ? 2 : 1;
+      for (int r = 0; r < times; ++r) {
+        B += h_gg * trB_gg + h_ge * trB_ge + h_ee * trB_ee;
+        Cc += h_gg * (trCC_gg + 0.5 * trCg1 * trCg2) + h_ge * (trCC_ge + 0.5 * trCg1 * trCe2 + 0.5 * trCe1 * trCg2) +
+              h_ee * (trCC_ee + 0.5 * trCe1 * trCe2);
+        D += h_gg * (trCC_gg + 0.5 * trD_gg) + h_ge * (trCC_ge + 0.5 * trD_ge) + h_ee * (trCC_ee + 0.5 * trD_ee);
+      }
+    }
+  }
+  free(buf);
+  crt[0] = 2.0 * D - Cc;
+  crt[1] = 2.0 * B;
+  crt[2] = Cc;
+}
 
 /* One evaluation at (Vg, Ve): CalcHiQi :942-1012, the logl of :2697-2713 and, if want_dev, CalcDev :2360-2554.
  *
@@ -690,6 +866,9 @@ static int mv_eval(int reml, size_t n, size_t d, size_t c, const double *eval, c
       out->hess[v2 * H2 + v1 + vs] = out->hess[(v1 + vs) * H2 + v2] = dev2[1];
     }
   }
+  mv_lu_invert(out->hess, H2, out->hinv);
+  out->crt[0] = out->crt[1] = out->crt[2] = 0.0;
+  if (c > 1) mv_calc_crt(d, c, out->hinv, Qi, QM, M12, out->crt); /* :2522-2530: for 'R' and 'L' alike */
   free(QM);
   free(acc);
   free(G);
@@ -705,8 +884,8 @@ static int mv_is_pd(size_t d, const double *V) {
 }
 
 /* Hessian_inv receives MINUS the inverse of the last Hessian (the variance matrix, :2742-2744); 2v x 2v */
-double orc_mph_nr(char func, size_t max_iter, double max_prec, size_t n, size_t d, size_t c, const double *eval,
-                  const double *X, const double *Y, double *Vg, double *Ve, double *Hessian_inv) {
+double orc_mph_nr_crt(char func, size_t max_iter, double max_prec, size_t n, size_t d, size_t c, const double *eval,
+                      const double *X, const double *Y, double *Vg, double *Ve, double *Hessian_inv, double *crt /* 3 or NULL */) {
   const int reml = (func == 'R' || func == 'r');
   const size_t vs = d * (d + 1) / 2, H2 = 2 * vs;
   const double lndet_xxt = mv_lndet_xxt(n, c, X, NULL);
@@ -714,7 +893,7 @@ double orc_mph_nr(char func, size_t max_iter, double max_prec, size_t n, size_t 
                                  : -0.5 * (double)n * (double)d * log(2.0 * M_PI);
   mv_dev *ev = (mv_dev *)malloc(sizeof(mv_dev));
   double Vg_save[MV_MAXD * MV_MAXD], Ve_save[MV_MAXD * MV_MAXD], Hi[4 * MV_MAXV * MV_MAXV], grad[2 * MV_MAXV];
-  double logl_old = 0.0, logl_new = 0.0;
+  double logl_old = 0.0, logl_new = 0.0, crt_last[3] = {0.0, 0.0, 0.0};
   memset(Hi, 0, sizeof(Hi));
   memset(grad, 0, sizeof(grad));
   for (size_t t = 0; t < max_iter; ++t) {
@@ -758,12 +937,18 @@ double orc_mph_nr(char func, size_t max_iter, double max_prec, size_t n, size_t 
     logl_old = logl_new;
     mv_eval(reml, n, d, c, eval, X, Y, Vg, Ve, logl_const, 1, ev);
     memcpy(grad, ev->grad, H2 * sizeof(double));
-    mv_lu_invert(ev->hess, H2, Hi);
+    memcpy(Hi, ev->hinv, H2 * H2 * sizeof(double));
+    memcpy(crt_last, ev->crt, sizeof(crt_last)); /* the factors of the LAST CalcDev call are what MphNR hands back */
   }
   if (Hessian_inv)
     for (size_t i = 0; i < H2 * H2; ++i) Hessian_inv[i] = -Hi[i];
+  if (crt) memcpy(crt, crt_last, sizeof(crt_last));
   free(ev);
   return logl_new;
+}
+double orc_mph_nr(char func, size_t max_iter, double max_prec, size_t n, size_t d, size_t c, const double *eval,
+                  const double *X, const double *Y, double *Vg, double *Ve, double *Hessian_inv) {
+  return orc_mph_nr_crt(func, max_iter, max_prec, n, d, c, eval, X, Y, Vg, Ve, Hessian_inv, NULL);
 }
 
 /* test hook: logl, gradient and the CalcDev Hessian at a point (finite-difference checks) */
@@ -857,6 +1042,7 @@ void orc_mph_initial(size_t em_iter, double em_prec, size_t nr_iter, double nr_p
 typedef struct {
   size_t em_iter, nr_iter, n_region;
   double em_prec, nr_prec, l_min, l_max, p_nr;
+  size_t crt; /* -crt: Edgeworth-corrected p values (PCRT) for the SNPs that reach the Newton-Raphson stage */
 } orc_mv_cfg;
 
 /* The null-model block of MVLMM::AnalyzeBimbam, src/mvlmm.cpp:3056-3208.  W: cw x n.  Outputs the REMLE and MLE fits
@@ -902,23 +1088,32 @@ void orc_mvlmm_batch(int a_mode, const orc_mv_cfg *cfg, size_t n, size_t d, size
       for (size_t j = 0; j < cw; ++j) B[i * c + j] = B_null[i * cw + j];
       B[i * c + cw] = 0.0;
     }
-    if (a_mode == 3 || a_mode == 4) p_score = orc_mph_calcp(n, d, cw, eval, x, W, Y, Vg_null, Ve_null, beta, Vbeta);
+    double crt[3] = {0.0, 0.0, 0.0};
+    if (a_mode == 3 || a_mode == 4) {
+      p_score = orc_mph_calcp(n, d, cw, eval, x, W, Y, Vg_null, Ve_null, beta, Vbeta);
+      if (p_score < cfg->p_nr && cfg->crt == 1) { /* :3302-3306: one CalcDev at the null estimates, PCRT mode 3 */
+        logl_H1 = orc_mph_nr_crt('R', 1, cfg->nr_prec * 10, n, d, c, eval, X, Y, Vg, Ve, NULL, crt);
+        p_score = orc_pcrt(3, d, p_score, crt[0], crt[1], crt[2]);
+      }
+    }
     if (a_mode == 2 || a_mode == 4) {
       logl_H1 = orc_mph_em('L', cfg->em_iter / 10, cfg->em_prec * 10, n, d, c, eval, X, Y, Vg, Ve, B);
       orc_mph_calcp(n, d, cw, eval, x, W, Y, Vg, Ve, beta, Vbeta);
       p_lrt = orc_cdf_chisq_Q(2.0 * (logl_H1 - logl_H0), (double)d);
       if (p_lrt < cfg->p_nr) {
-        logl_H1 = orc_mph_nr('L', cfg->nr_iter / 10, cfg->nr_prec * 10, n, d, c, eval, X, Y, Vg, Ve, NULL);
+        logl_H1 = orc_mph_nr_crt('L', cfg->nr_iter / 10, cfg->nr_prec * 10, n, d, c, eval, X, Y, Vg, Ve, NULL, crt);
         orc_mph_calcp(n, d, cw, eval, x, W, Y, Vg, Ve, beta, Vbeta);
         p_lrt = orc_cdf_chisq_Q(2.0 * (logl_H1 - logl_H0), (double)d);
+        if (cfg->crt == 1) p_lrt = orc_pcrt(2, d, p_lrt, crt[0], crt[1], crt[2]);
       }
     }
     if (a_mode == 1 || a_mode == 4) {
       orc_mph_em('R', cfg->em_iter / 10, cfg->em_prec * 10, n, d, c, eval, X, Y, Vg, Ve, B);
       p_wald = orc_mph_calcp(n, d, cw, eval, x, W, Y, Vg, Ve, beta, Vbeta);
       if (p_wald < cfg->p_nr) {
-        orc_mph_nr('R', cfg->nr_iter / 10, cfg->nr_prec * 10, n, d, c, eval, X, Y, Vg, Ve, NULL);
+        orc_mph_nr_crt('R', cfg->nr_iter / 10, cfg->nr_prec * 10, n, d, c, eval, X, Y, Vg, Ve, NULL, crt);
         p_wald = orc_mph_calcp(n, d, cw, eval, x, W, Y, Vg, Ve, beta, Vbeta);
+        if (cfg->crt == 1) p_wald = orc_pcrt(1, d, p_wald, crt[0], crt[1], crt[2]);
       }
     }
     double *o = out + s * stride;

@@ -39,11 +39,12 @@ SUMSTAT_DTYPE = np.dtype([(k, "f8") for k in
 class MvCfg(C.Structure):
     """orc_mv_cfg: the MVLMM members CopyFromParam fills (src/mvlmm.cpp:51-90) with PARAM's defaults"""
     _fields_ = [("em_iter", C.c_size_t), ("nr_iter", C.c_size_t), ("n_region", C.c_size_t), ("em_prec", C.c_double),
-                ("nr_prec", C.c_double), ("l_min", C.c_double), ("l_max", C.c_double), ("p_nr", C.c_double)]
+                ("nr_prec", C.c_double), ("l_min", C.c_double), ("l_max", C.c_double), ("p_nr", C.c_double),
+                ("crt", C.c_size_t)]
 
 
-def mv_cfg(em_iter=10000, nr_iter=100, em_prec=1e-4, nr_prec=1e-4, l_min=1e-5, l_max=1e5, n_region=10, p_nr=1e-3):
-    return MvCfg(em_iter, nr_iter, n_region, em_prec, nr_prec, l_min, l_max, p_nr)
+def mv_cfg(em_iter=10000, nr_iter=100, em_prec=1e-4, nr_prec=1e-4, l_min=1e-5, l_max=1e5, n_region=10, p_nr=1e-3, crt=0):
+    return MvCfg(em_iter, nr_iter, n_region, em_prec, nr_prec, l_min, l_max, p_nr, crt)
 
 
 def build():
@@ -97,6 +98,12 @@ def lib():
         L.orc_mph_em.argtypes = [C.c_char, sz, cd, sz, sz, sz, dp, dp, dp, dp, dp, dp]
         L.orc_mph_nr.restype = cd
         L.orc_mph_nr.argtypes = [C.c_char, sz, cd, sz, sz, sz, dp, dp, dp, dp, dp, dp]
+        L.orc_mph_nr_crt.restype = cd
+        L.orc_mph_nr_crt.argtypes = [C.c_char, sz, cd, sz, sz, sz, dp, dp, dp, dp, dp, dp, dp]
+        L.orc_cdf_chisq_Qinv.restype = cd
+        L.orc_cdf_chisq_Qinv.argtypes = [cd, cd]
+        L.orc_pcrt.restype = cd
+        L.orc_pcrt.argtypes = [C.c_int, sz, cd, cd, cd, cd]
         L.orc_mph_calcp.restype = cd
         L.orc_mph_calcp.argtypes = [sz, sz, sz, dp, dp, dp, dp, dp, dp, dp, dp]
         L.orc_mph_dev.restype = cd
@@ -635,6 +642,25 @@ def mph_nr(func, max_iter, max_prec, ev, X, Y, Vg, Ve):
     ll = lib().orc_mph_nr(func.encode(), max_iter, max_prec, n, d, X.shape[0], _dp(ev), _dp(X), _dp(Y), _dp(Vg), _dp(Ve),
                           _dp(Hi))
     return ll, Hi
+
+
+def mph_nr_crt(func, max_iter, max_prec, ev, X, Y, Vg, Ve):
+    """MphNR with the Edgeworth correction factors (crt_a, crt_b, crt_c) of its last CalcDev call (src/mvlmm.cpp:2054-2331)"""
+    d, n = Y.shape
+    Hi = np.zeros((d * (d + 1), d * (d + 1)))
+    crt = np.zeros(3)
+    ll = lib().orc_mph_nr_crt(func.encode(), max_iter, max_prec, n, d, X.shape[0], _dp(ev), _dp(X), _dp(Y), _dp(Vg), _dp(Ve),
+                              _dp(Hi), _dp(crt))
+    return ll, Hi, crt
+
+
+def chisq_Qinv(q, nu):
+    return lib().orc_cdf_chisq_Qinv(float(q), float(nu))
+
+
+def pcrt(mode, d, p, crt):
+    """PCRT (src/mvlmm.cpp:2952-2970): mode 1 Wald, 2 LRT, 3 score"""
+    return lib().orc_pcrt(int(mode), int(d), float(p), float(crt[0]), float(crt[1]), float(crt[2]))
 
 
 def mph_calcp(ev, x, W, Y, Vg, Ve):

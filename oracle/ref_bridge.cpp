@@ -33,6 +33,8 @@ double MphCalcP(const gsl_vector *eval, const gsl_vector *x_vec, const gsl_matri
 double MphNR(const char func_name, const size_t max_iter, const double max_prec, const gsl_vector *eval, const gsl_matrix *X,
              const gsl_matrix *Y, gsl_matrix *Hi_all, gsl_matrix *xHi_all, gsl_matrix *Hiy_all, gsl_matrix *V_g,
              gsl_matrix *V_e, gsl_matrix *Hessian_inv, double &crt_a, double &crt_b, double &crt_c);
+// src/mvlmm.cpp:2952-2953
+double PCRT(const size_t mode, const size_t d_size, const double p_value, const double crt_a, const double crt_b, const double crt_c);
 // src/mvlmm.cpp:213-214
 double EigenProc(const gsl_matrix *V_g, const gsl_matrix *V_e, gsl_vector *D_l, gsl_matrix *UltVeh, gsl_matrix *UltVehi);
 
@@ -67,6 +69,21 @@ double ref_MphNR(char func, size_t max_iter, double max_prec, size_t n, size_t d
   gsl_matrix_free(Hi_all); gsl_matrix_free(xHi_all); gsl_matrix_free(Hiy_all);
   return l;
 }
+
+// the same call, also handing back crt_a, crt_b, crt_c of the last CalcDev (src/mvlmm.cpp:2054-2331, :2522-2530)
+double ref_MphNR_crt(char func, size_t max_iter, double max_prec, size_t n, size_t d, size_t c, const double *eval, const double *X,
+                     const double *Y, double *Vg, double *Ve, double *Hessian_inv, double *crt /* 3 */) {
+  gsl_vector_view ev = vview(eval, n);
+  gsl_matrix_view Xm = mview(X, c, n), Ym = mview(Y, d, n), Vgm = mview(Vg, d, d), Vem = mview(Ve, d, d);
+  gsl_matrix_view Hm = mview(Hessian_inv, d * (d + 1), d * (d + 1));
+  gsl_matrix *Hi_all = gsl_matrix_alloc(d, d * n), *xHi_all = gsl_matrix_alloc(d * c, d * n), *Hiy_all = gsl_matrix_alloc(d, n);
+  double l = MphNR(func, max_iter, max_prec, &ev.vector, &Xm.matrix, &Ym.matrix, Hi_all, xHi_all, Hiy_all, &Vgm.matrix, &Vem.matrix,
+                   &Hm.matrix, crt[0], crt[1], crt[2]);
+  gsl_matrix_free(Hi_all); gsl_matrix_free(xHi_all); gsl_matrix_free(Hiy_all);
+  return l;
+}
+
+double ref_PCRT(size_t mode, size_t d, double p, double a, double b, double c) { return PCRT(mode, d, p, a, b, c); }
 
 double ref_MphCalcP(size_t n, size_t d, size_t cw, const double *eval, const double *x, const double *W /* cw x n */,
                     const double *Y, const double *Vg, const double *Ve, double *beta, double *Vbeta) {

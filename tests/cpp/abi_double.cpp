@@ -52,6 +52,7 @@ void orc_CalcPve(size_t n, size_t c, const double *eval, const double *UtW, cons
 typedef struct {
   size_t em_iter, nr_iter, n_region;
   double em_prec, nr_prec, l_min, l_max, p_nr;
+  size_t crt;
 } orc_mv_cfg;
 void orc_mvlmm_null(const orc_mv_cfg *cfg, size_t n, size_t d, size_t cw, const double *eval, const double *W,
                     const double *Y, double *Vg_remle, double *Ve_remle, double *B_remle, double *logl_remle,
@@ -435,7 +436,7 @@ int gemma_hip_lmm_finish(double *t_utx, double *t_opt) {
 // ---- multivariate LMM over oracle/mvlmm_oracle.c ----------------------------------------------------------------
 int gemma_hip_mvlmm_null(size_t n, size_t c, size_t d, const double *eval, const double *UtW, const double *UtY, double l_min,
                          double l_max, size_t n_region, const gemma_mvlmm_opt *opt, gemma_mvlmm_null *out) {
-  const orc_mv_cfg cfg = {opt->em_iter, opt->nr_iter, n_region, opt->em_prec, opt->nr_prec, l_min, l_max, opt->p_nr};
+  const orc_mv_cfg cfg = {opt->em_iter, opt->nr_iter, n_region, opt->em_prec, opt->nr_prec, l_min, l_max, opt->p_nr, opt->crt};
   const std::vector<double> Wt = transposed(UtW, n, c), Yt = transposed(UtY, n, d);
   memset(out, 0, sizeof(*out));
   orc_mvlmm_null(&cfg, n, d, c, eval, Wt.data(), Yt.data(), out->Vg_remle, out->Ve_remle, out->B_remle, &out->logl_remle_H0,
@@ -450,7 +451,7 @@ int gemma_hip_mvlmm_set(size_t d, const double *UtY, const gemma_mvlmm_null *nul
   g_lmm.Wt = transposed(g_lmm.UtW.data(), n, c);
   g_lmm.mv_null = *null_fit;
   const orc_mv_cfg cfg = {opt->em_iter, opt->nr_iter, g_lmm.cfg.n_region, opt->em_prec, opt->nr_prec, g_lmm.cfg.l_min,
-                          g_lmm.cfg.l_max, opt->p_nr};
+                          g_lmm.cfg.l_max, opt->p_nr, opt->crt};
   g_lmm.mv_cfg = cfg;
   return GEMMA_HIP_OK;
 }

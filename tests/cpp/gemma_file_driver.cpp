@@ -40,6 +40,7 @@ int main(int argc, char **argv) {
   std::string loco, file_gxe, file_gene, file_snps;
   int km = 1, gpus = 1, rank = 0, device = 0;
   bool samegpu = false;
+  size_t crt = 0;
   std::string file_geno, file_pheno, file_anno, file_bfile, file_cvt, file_kin, file_kd, file_ku, file_out = "result",
                                                                                                   path_out = "./output";
   std::vector<size_t> p_column;
@@ -78,6 +79,7 @@ int main(int argc, char **argv) {
     else if (a == "-km" && has) km = atoi(argv[++i]);
     else if (a == "-gpus" && has) gpus = atoi(argv[++i]);
     else if (a == "-samegpu") samegpu = true;
+    else if (a == "-crt") crt = 1; // src/gemma.cpp:1398-1399
     else if (a == "-notsnp") qc.maf_level = -1; // src/gemma.cpp:1116-1117
     else if (a == "-maf" && has) qc.maf_level = atof(argv[++i]);
     else if (a == "-miss" && has) qc.miss_level = atof(argv[++i]);
@@ -376,6 +378,7 @@ int main(int argc, char **argv) {
       MVLMM cMv;
       cMv.file_geno = file_geno;
       cMv.a_mode = a_mode;
+      cMv.crt = crt;
       cMv.file_bfile = file_bfile;
       cMv.path_out = path_out;
       cMv.file_out = file_out;

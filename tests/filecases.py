@@ -216,14 +216,21 @@ def loco_workflow(exe, out, chrs=(2,), modes=(1,)):
                     assert (rel <= STAT_TOL).all(), (tag, name, np.nanmax(rel))
 
 
-def mvlmm_workflow(exe, out, modes=(1, 4), bimbam=False):
+def mvlmm_workflow(exe, out, modes=(1, 4), bimbam=False, crt=False):
     """`-lmm m -n 1 2` (multivariate LMM, class MVLMM) from PLINK files: the reference's test/data/issue243 set (1000
     individuals, 2 traits, first 800 SNPs) rebuilt from tests/golden/ref_mv.npz, -gk then -k ... -lmm, against the
     reference's .assoc.txt columns.  An EM that stops one iteration earlier or later moves the estimates by ~1e-4:
-    >= 97 % of the SNPs to the printed digits, all within 5e-3 (the criterion of tests/test_gpu_mvlmm.py)."""
+    >= 97 % of the SNPs to the printed digits, all within 5e-3 (the criterion of tests/test_gpu_mvlmm.py).
+    crt: the same runs with -crt against tests/golden/ref_mv_crt.npz (the reference with -crt: the SNP that reaches MphNR gets
+    PCRT's corrected p_wald / p_lrt; its corrected value must come out, not the uncorrected one)."""
     import refcases as R
     out = str(out)
     fx = np.load(os.path.join(ROOT, "tests", "golden", "ref_mv.npz"))
+    fx_plain = fx
+    if crt:
+        fc = np.load(os.path.join(ROOT, "tests", "golden", "ref_mv_crt.npz"))
+        fx = dict(fx)
+        fx.update({k.replace("a_crt_", "a_", 1): fc[k] for k in fc.files if k.startswith("a_crt_m")})
     Y = fx["a_pheno"]
     n_total = Y.shape[0]
     nb = (n_total + 3) // 4
@@ -251,7 +258,7 @@ def mvlmm_workflow(exe, out, modes=(1, 4), bimbam=False):
     drive(exe, *base, "-gk", "-o", "mv2")
     cxx = os.path.join(out, "mv2.cXX.txt")
     for m in modes:
-        kv = drive(exe, *base, "-k", cxx, "-lmm", m, "-n", 1, 2, "-o", "mv2_m%d" % m)
+        kv = drive(exe, *base, "-k", cxx, "-lmm", m, "-n", 1, 2, *(("-crt",) if crt else ()), "-o", "mv2_m%d" % m)
         assert abs(float(kv["logl_remle_H0"]) - fx["a_logl_null"][0]) <= 2e-6 * abs(fx["a_logl_null"][0])
         assert abs(float(kv["logl_mle_H0"]) - fx["a_logl_null"][1]) <= 2e-6 * abs(fx["a_logl_null"][1])
         hdr, rows = read_assoc(os.path.join(out, "mv2_m%d.assoc.txt" % m))
@@ -267,6 +274,15 @@ def mvlmm_workflow(exe, out, modes=(1, 4), bimbam=False):
                 got[c] = col[c]
         err = R.mv_row_err(got, R.mv_ref_table(fx, "a", m, 2))
         assert np.mean(err <= STAT_TOL) >= 0.97 and err.max() <= 5e-3, (m, float(np.mean(err <= STAT_TOL)), float(err.max()))
+        if crt:  # the rows -crt changes in the reference: the corrected value, to the digits the EM's stopping point allows
+            for c in ("p_wald", "p_lrt"):
+                key = "a_m%d_%s" % (m, c)
+                if c in got:
+                    rows_c = np.flatnonzero(fx[key] != fx_plain[key])
+                    assert rows_c.size >= 1
+                    for r in rows_c:
+                        corrected, plain = fx[key][r], fx_plain[key][r]
+                        assert abs(got[c][r] - corrected) <= 5e-3 * corrected < abs(got[c][r] - plain), (c, r, got[c][r], corrected, plain)
 
 
 def perl_checksum(path):

@@ -18,6 +18,7 @@ Fixtures:
   ref_gene.npz      -gene (LMM::AnalyzeGene): 40 simulated expression rows over issue188's individuals, -lmm 1 and 4
   ref_mv.npz        multivariate LMM: issue243 (first 800 SNPs, 2 traits) and issue188 genotypes with 3 simulated
                     traits, -lmm 1..4 (-n 1 2 [3])
+  ref_mv_crt.npz    fixture (a) of ref_mv.npz with -crt (run `make_ref_fixtures.py mv_crt`; not part of the default list)
 """
 import os
 import re
@@ -331,6 +332,42 @@ def mv(tmp, raw188, fam188, bim188):
     print("ref_mv.npz:", len(d["a_snp"]), "+", len(d["b_snp"]), "+", len(d["c_snp"]), "SNPs")
 
 
+def mv_crt(tmp):
+    """-crt (PARAM::crt, src/gemma.cpp:1398-1399): the Edgeworth-corrected p values of the SNPs that reach MphNR, on fixture (a)
+    of ref_mv.npz (its PLINK files are rebuilt from the stored .bed bytes and phenotypes) and on (b); written to its own file so
+    that ref_mv.npz stays byte for byte what it was."""
+    fx = np.load(os.path.join(OUT, "ref_mv.npz"))
+    d = {}
+    Y = fx["a_pheno"]
+    n_total = Y.shape[0]
+    nb = (n_total + 3) // 4
+    ns = (fx["a_bed"].size - 3) // nb
+    pre = os.path.join(tmp, "mvc")
+    open(pre + ".bed", "wb").write(fx["a_bed"].tobytes())
+    with open(pre + ".bim", "w") as f:
+        for t in range(ns):
+            f.write("1\trs%d\t0\t%d\tA\tG\n" % (t, t + 1))
+    with open(pre + ".fam", "w") as f:
+        for i in range(n_total):
+            f.write("f%d i%d 0 0 1 %r %r\n" % (i, i, float(Y[i, 0]), float(Y[i, 1])))
+    gemma(tmp, "-bfile", "mvc", "-gk", 1, "-o", "mvc")
+    kfile = os.path.join(tmp, "output", "mvc.cXX.txt")
+    bim = ["1\trs%d\t0\t%d\tA\tG\n" % (t, t + 1) for t in range(ns)]
+    mv_run(tmp, "mvc", "a", kfile, (1, 2), d, bim, extra=("-crt",))
+    changed = {}
+    for m in (1, 2, 3, 4):
+        for c in MV_COLS_EXTRA:
+            k = "a_m%d_%s" % (m, c)
+            if k in d:
+                assert np.array_equal(d["a_snp"], fx["a_snp"])
+                changed[k] = int((d[k] != fx[k]).sum())
+    assert changed["a_m1_p_wald"] >= 1 and changed["a_m2_p_lrt"] >= 1, changed
+    out = {k.replace("a_", "a_crt_", 1): v for k, v in d.items() if k.startswith("a_m") or k == "a_snp"}
+    out["a_crt_rows_changed"] = np.array([changed.get("a_m1_p_wald", 0), changed.get("a_m2_p_lrt", 0), changed.get("a_m3_p_score", 0)])
+    np.savez_compressed(os.path.join(OUT, "ref_mv_crt.npz"), **out)
+    print("ref_mv_crt.npz:", len(d["a_snp"]), "SNPs; rows that -crt changes:", changed)
+
+
 def main():
     if not os.path.exists(GEMMA):
         subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "ref"])
@@ -346,6 +383,8 @@ def main():
             raw, fam, bim = copy_plink(REF + "/test/data/issue188/2000", os.path.join(tmp, "p188"))
         if "mv" in which:
             mv(tmp, raw, fam, bim)
+        if "mv_crt" in which:
+            mv_crt(tmp)
         if "loco" in which:
             loco(tmp, raw, fam, bim)
         if "gene" in which:

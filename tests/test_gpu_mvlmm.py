@@ -26,8 +26,8 @@ def _compare(got, ref, tag, tight=1e-6, loose=5e-3, frac=0.97):
     assert bad.mean() <= 1 - frac, (tag, bad.mean())
 
 
-def _oracle_run(oracle, c, a_mode, X=None):
-    cfg = oracle.mv_cfg()
+def _oracle_run(oracle, c, a_mode, X=None, **cfg_kw):
+    cfg = oracle.mv_cfg(**cfg_kw)
     null = oracle.mvlmm_null(cfg, c["ev"], c["UtW"], c["UtY"])
     UtX = c["UtX"] if X is None else np.ascontiguousarray(X @ c["U"])
     return null, oracle.mvlmm_batch(a_mode, cfg, c["ev"], c["UtW"], c["UtY"], UtX, null)
@@ -63,6 +63,23 @@ def test_analyze_bimbam(gpu_api, oracle, n, d, cw, p, seed, a_mode):
     if a_mode in (1, 4):
         assert (ref["p_wald"] < 1e-3).sum() >= 1  # Newton-Raphson refinement taken
     _compare(got, ref, "bimbam d=%d" % d)
+
+
+@pytest.mark.parametrize("n,d,cw,p,seed,p_nr", [(300, 3, 1, 120, 5, 1e-3), (257, 2, 2, 96, 6, 0.5), (400, 4, 1, 40, 8, 0.5),
+                                                (350, 3, 3, 48, 10, 0.5), (600, 5, 2, 16, 9, 0.5)])
+def test_analyze_bimbam_with_crt(gpu_api, oracle, n, d, cw, p, seed, p_nr):
+    """-crt (src/mvlmm.cpp:2054-2331 CalcCRT, :2952-2970 PCRT): the SNPs that reach MphNR get Edgeworth-corrected p values.  The
+    kernel takes the correction factors from its moment tables in the rotated basis (MvNr::crt_factors), the oracle from dense
+    products as the reference does (its crt_a, b, c are pinned on the reference's in tests/test_reference_pin.py).  p_nr = 0.5
+    sends about half of the SNPs down that road, in all three modes (score: one CalcDev at the null estimates)."""
+    c = make_case(n, d, cw, p, seed)
+    null, ref = _oracle_run(oracle, c, 4, X=c["G"], crt=1, p_nr=p_nr)
+    _, plain = _oracle_run(oracle, c, 4, X=c["G"], crt=0, p_nr=p_nr)
+    changed = sum(int((np.abs(ref[k] - plain[k]) > 1e-9 * plain[k]).sum()) for k in ("p_wald", "p_lrt", "p_score"))
+    assert changed >= (1 if p_nr < 0.1 else p // 2)  # the correction is not a no-op on this case
+    mv = gpu_api.MVLMM(a_mode=4, crt=1, p_nr=p_nr)
+    got = mv.AnalyzeBimbam(c["U"], c["ev"], np.ascontiguousarray(c["UtW"].T), np.ascontiguousarray(c["UtY"].T), c["G"])
+    _compare(got, ref, "crt d=%d" % d)
 
 
 def test_analyze_plink(gpu_api, oracle):

@@ -55,6 +55,11 @@ def test_snps_notsnp_km2_to_reference_outputs(driver, tmp_path):
     fc.selection_options_workflow(driver, tmp_path)
 
 
+def test_mvlmm_crt_option_reference_outputs(driver, tmp_path):
+    """gemma ... -lmm m -n 1 2 -crt: PCRT's corrected p values (MvNr::crt_factors on the device) against the reference's"""
+    fc.mvlmm_workflow(driver, tmp_path, modes=(1, 2, 4), crt=True)
+
+
 def test_mvlmm_bimbam_text_to_reference_outputs(driver, tmp_path):
     fc.mvlmm_workflow(driver, tmp_path, modes=(1, 3), bimbam=True)
 

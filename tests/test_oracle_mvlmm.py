@@ -130,7 +130,8 @@ class MvArgs(C.Structure):
     _fields_ = [("UtX", dp), ("ld", C.c_long), ("l", C.c_long), ("n", C.c_int), ("eval", dp), ("Wt", dp), ("Yt", dp),
                 ("Vg_null", C.c_double * 25), ("Ve_null", C.c_double * 25), ("B_null", C.c_double * 20),
                 ("logl_H0", C.c_double), ("a_mode", C.c_int), ("em_iter", C.c_int), ("em_prec", C.c_double),
-                ("nr_iter", C.c_int), ("nr_prec", C.c_double), ("p_nr", C.c_double), ("out", dp), ("stride", C.c_int)]
+                ("nr_iter", C.c_int), ("nr_prec", C.c_double), ("p_nr", C.c_double), ("out", dp), ("stride", C.c_int),
+                ("crt", C.c_int)]
 
 
 @pytest.fixture(scope="module")
@@ -146,11 +147,20 @@ def harness():
     return H
 
 
-@pytest.mark.parametrize("n,d,cw,p,seed", [(300, 3, 1, 40, 5), (257, 2, 2, 30, 6), (200, 1, 1, 30, 7), (400, 4, 1, 12, 8),
-                                           (600, 5, 2, 6, 9), (350, 3, 3, 10, 10)])
-def test_kernel_source_on_one_lane_matches_the_oracle(harness, n, d, cw, p, seed):
+@pytest.mark.parametrize("n,d,cw,p,seed,crt", [(300, 3, 1, 40, 5, 0), (257, 2, 2, 30, 6, 0), (200, 1, 1, 30, 7, 0), (400, 4, 1, 12, 8, 0),
+                                               (600, 5, 2, 6, 9, 0), (350, 3, 3, 10, 10, 0),
+                                               (300, 3, 1, 40, 5, 1), (257, 2, 2, 30, 6, 1), (200, 1, 1, 30, 7, 1),
+                                               (400, 4, 1, 12, 8, 1), (350, 3, 3, 10, 10, 1),
+                                               (300, 3, 1, 40, 5, 2), (257, 2, 2, 30, 6, 2)])
+def test_kernel_source_on_one_lane_matches_the_oracle(harness, n, d, cw, p, seed, crt):
+    """crt = 1: the reference's -crt.  The kernel source computes CalcCRT's traces in the rotated basis from its moment tables
+    (MvNr::crt_factors), the oracle as the reference does, from dense dc x dc products (pinned on the reference's own crt_a, b, c
+    in tests/test_reference_pin.py): two formulations, same corrected p values."""
     c = make_case(n, d, cw, p, seed)
-    cfg = O.mv_cfg()
+    p_nr = 1e-3
+    if crt == 2: # every second SNP goes through MphNR and PCRT in all three modes (score included)
+        crt, p_nr = 1, 0.5
+    cfg = O.mv_cfg(crt=crt, p_nr=p_nr)
     null = O.mvlmm_null(cfg, c["ev"], c["UtW"], c["UtY"])
     # an interior null fit: on the boundary of the positive-definite cone (an eigenvalue of V_e or V_g ~ 1e-8) every
     # downstream number is conditioned like 1e8 and two correct formulations agree to a few digits only
@@ -170,12 +180,15 @@ def test_kernel_source_on_one_lane_matches_the_oracle(harness, n, d, cw, p, seed
     for i, x in enumerate(null["B_mle"].ravel()):
         a.B_null[i] = x
     a.logl_H0, a.a_mode = null["logl_mle"], 4
-    a.em_iter, a.em_prec, a.nr_iter, a.nr_prec, a.p_nr = 1000, 1e-3, 10, 1e-3, 1e-3
+    a.em_iter, a.em_prec, a.nr_iter, a.nr_prec, a.p_nr = 1000, 1e-3, 10, 1e-3, p_nr
     a.out, a.stride = P(out), stride
+    a.crt = crt
     assert harness.mvh_batch(d, cw + 1, C.byref(a)) == 0
     got = {"beta": out[:, :d], "Vbeta": out[:, d:d + v], "Vg": out[:, d + v:d + 2 * v], "Ve": out[:, d + 2 * v:d + 3 * v],
            "p_wald": out[:, d + 3 * v], "p_lrt": out[:, d + 3 * v + 1], "p_score": out[:, d + 3 * v + 2]}
     assert (ref["p_wald"] < 1e-3).sum() >= 1  # the Newton-Raphson branch is exercised
+    if p_nr > 0.1:
+        assert (ref["p_score"] < p_nr).sum() >= 5
     for k in got:
         rel = np.abs(got[k] - ref[k]) / np.maximum(np.abs(ref[k]), 1e-300)
         assert rel.max() < 1e-8, (k, rel.max())

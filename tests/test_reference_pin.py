@@ -220,6 +220,11 @@ def _refso():
     so.ref_MphNR.argtypes = [C.c_char, C.c_size_t, C.c_double, C.c_size_t, C.c_size_t, C.c_size_t] + [P] * 6
     so.ref_MphCalcP.restype = C.c_double
     so.ref_MphCalcP.argtypes = [C.c_size_t, C.c_size_t, C.c_size_t] + [P] * 8
+    if hasattr(so, "ref_MphNR_crt"):
+        so.ref_MphNR_crt.restype = C.c_double
+        so.ref_MphNR_crt.argtypes = [C.c_char, C.c_size_t, C.c_double, C.c_size_t, C.c_size_t, C.c_size_t] + [P] * 7
+        so.ref_PCRT.restype = C.c_double
+        so.ref_PCRT.argtypes = [C.c_size_t, C.c_size_t] + [C.c_double] * 4
     so.ref_EigenProc.restype = C.c_double
     so.ref_EigenProc.argtypes = [C.c_size_t] + [P] * 5
     return so
@@ -283,6 +288,39 @@ def test_reference_mph_nr_and_calcp_functions(oracle, mvcases, func):
                               _dp(beta_r), _dp(Vb_r))
         assert p_o == pytest.approx(p_r, rel=1e-8)
         assert np.abs(beta_o - beta_r).max() < 1e-9 and np.abs(Vb_o - Vb_r).max() < 1e-9
+
+
+@pytest.mark.parametrize("func", ["R", "L"])
+def test_reference_crt_factors_and_pcrt(oracle, mvcases, func):
+    """-crt (src/mvlmm.cpp:2054-2331 CalcCRT, :2952-2970 PCRT): the Edgeworth correction factors crt_a, crt_b, crt_c that the
+    reference's MphNR hands back from its last CalcDev call against the restatement's dense CalcCRT (same point, same Hessian
+    inverse), for the REML and the ML likelihood, on both mvLMM fixtures; then PCRT in its three modes (its chi-square
+    quantile is an iteration converged to 1e-10)."""
+    so = _refso()
+    if not hasattr(so, "ref_MphNR_crt"):
+        pytest.skip("oracle/_ref/libgemma_ref.so predates the crt bridge (make -C oracle ref)")
+    for key in ("a", "b"):
+        c = mvcases[key]
+        n, d = c["ev"].size, c["d"]
+        for s in (7, 3, 250, 11):
+            if s >= c["UtX"].shape[0]:
+                continue
+            Xs, _ = _snp_design(c, s)
+            a = [c["null"]["Vg_mle"].copy(), c["null"]["Ve_mle"].copy()]
+            b = [x.copy() for x in a]
+            for iters in (1, 10):
+                lo, Hi, crt_o = oracle.mph_nr_crt(func, iters, 1e-3, c["ev"], Xs, c["UtY"], a[0], a[1])
+                Hr, crt_r = np.zeros((d * (d + 1), d * (d + 1))), np.zeros(3)
+                lr = so.ref_MphNR_crt(func.encode(), iters, 1e-3, n, d, Xs.shape[0], _dp(c["ev"]), _dp(Xs), _dp(c["UtY"]), _dp(b[0]),
+                                      _dp(b[1]), _dp(Hr), _dp(crt_r))
+                assert lo == pytest.approx(lr, rel=1e-10)
+                assert np.all(np.isfinite(crt_r)) and np.abs(crt_r).max() > 0
+                assert np.abs(crt_o - crt_r).max() <= 1e-6 * np.abs(crt_r).max(), (key, s, iters, crt_o, crt_r)
+                for mode in (1, 2, 3):
+                    for pv in (3e-4, 1e-7, 2e-12):
+                        pr = so.ref_PCRT(mode, d, pv, crt_r[0], crt_r[1], crt_r[2])
+                        po = oracle.pcrt(mode, d, pv, crt_r)
+                        assert po == pytest.approx(pr, rel=1e-8), (mode, pv)
 
 
 def test_reference_eigenproc_basis_is_unstable(mvcases):
