@@ -482,8 +482,10 @@ def main():
     if rank == 0:
         total_snps = B * args.steps * world
         value = total_snps / elapsed
-        gemm_avg_s = gemm_ms * 1e-3 / max(1, gemm_n)
-        assoc_avg_s = assoc_ms * 1e-3 / max(1, assoc_n)
+        # the product of a step may be launched in row chunks (gemma_hip.hip: lmm_batch_plink_chunked): price the step's total
+        gemm_avg_s = gemm_ms * 1e-3 / max(1, args.steps)
+        gemm_launches_per_step = gemm_n / max(1, args.steps)
+        assoc_avg_s = assoc_ms * 1e-3 / max(1, args.steps)  # per step (the stage may run once per row chunk)
         if i8_path:
             # D digits of U x {genotype, missing mask}: 2 D int8 products of 2 n^2 ops per SNP (2 n^2 per SNP);
             # D = 7, or 6 from n = 16384 up (csrc/i8gemm.hip.h)
@@ -510,8 +512,8 @@ def main():
                     "logical_frac_of_dense_peak": round(logical / INT8_MFMA_PEAK_TOPS, 4),
                     "note": "achieved = dense-equivalent work of the matrix pipe (a 2:4 sparse instruction counted as the dense one it "
                             "takes the time of); logical_top_s = the 2 D products as written" if sparse else "dense int8 MFMA",
-                    "traffic": None, "launches": gemm_n,
-                    "avg_launch_ms": round(gemm_avg_s * 1e3, 3),
+                    "traffic": None, "launches": gemm_n, "launches_per_step": gemm_launches_per_step,
+                    "avg_launch_ms": round(gemm_ms / max(1, gemm_n), 3), "ms_per_step": round(gemm_avg_s * 1e3, 3),
                     # the same launch priced as the fp64 product it replaces (2 n^2 flop per SNP)
                     "equiv_fp64_tflops": round(2.0 * B * n * n / gemm_avg_s / 1e12, 1)}
         else:
@@ -542,7 +544,11 @@ def main():
                                "avg_launch_ms": round(assoc_avg_s * 1e3, 3)},
             "stage_ms_per_step": {"ingest": round(ing_ms / max(1, args.steps), 3), "utx_gemm": round(gemm_ms / max(1, args.steps), 3),
                                   "utx_post": round(post_ms / max(1, args.steps), 3),
-                                  "assoc": round(assoc_ms / max(1, args.steps), 3)},
+                                  "assoc": round(assoc_ms / max(1, args.steps), 3),
+                                  "overlap": ("utx_post and assoc of row chunk c run on a side stream beside utx_gemm of chunk c + 1 "
+                                              "(%d chunks per step): the stage times overlap and do not add up to ms_per_step"
+                                              % int(round(gemm_launches_per_step))) if i8_path and gemm_launches_per_step > 1.5 else
+                                             "none: one stream, the stage times add up to ms_per_step"},
         }
         # Amdahl statement for the BASELINE config of this n (SNP-sharded run over N GPUs: setup once, then p / N SNPs per
         # rank with no collective): every term measured in THIS run; the N > 1 rows are projections from the per-GPU rate,

@@ -82,6 +82,10 @@ struct Ctx {
   DevBuf kin_GtG, kin_S, kin_a, kin_At, kin_Gt;
   DevBuf kin_A2, kin_cnt, kin_off, kin_listS, kin_listJ, kin_sub, kin_cj, kin_flag; // lists of the missing calls of a block
   DevBuf kin_tmap;                    // tiles of G^T G that meet the upper triangle
+  // lmm_batch_d on PLINK blocks in row chunks: the digit combine and the per-SNP stage of chunk c on a side stream beside the
+  // int8 product of chunk c + 1 (overlap_*)
+  hipStream_t ov_stream = nullptr;
+  hipEvent_t ov_ready[16] = {}, ov_done = nullptr;
   int kin_tmap_tm = 0, kin_tmap_tn = 0, kin_tmap_count = 0;
 
   // lmm state
@@ -274,6 +278,15 @@ extern "C" void gemma_hip_shutdown(void) {
   g_ctx.table_P.release(); g_ctx.U_even.release();
   g_ctx.U_even_of = nullptr;
   pipe_release(); // pinned slots, copy stream and events of the pipelined host-block path
+  if (g_ctx.ov_stream) {
+    (void)hipStreamDestroy(g_ctx.ov_stream);
+    for (auto &e : g_ctx.ov_ready)
+      if (e) (void)hipEventDestroy(e);
+    if (g_ctx.ov_done) (void)hipEventDestroy(g_ctx.ov_done);
+    g_ctx.ov_stream = nullptr;
+    for (auto &e : g_ctx.ov_ready) e = nullptr;
+    g_ctx.ov_done = nullptr;
+  }
   g_ctx.kin_active = g_ctx.lmm_active = false;
   g_ctx.kept_K.release(); g_ctx.kept_UE.release();
   g_ctx.kept_K_n = g_ctx.kept_n = 0;
@@ -1504,109 +1517,127 @@ static int i8_begin(size_t l, I8Dims *d, hipStream_t s) {
   return GEMMA_HIP_OK;
 }
 
-// UtX (l x ldx) from the packed left factor in g_ctx.i8_A and the per-SNP means in g_ctx.i8_mean
-static int i8_product(size_t l, const I8Dims &d, double *UtX, size_t ldx, hipStream_t s) {
+// The int8 product in three pieces, each over the SNP rows [row0, row0 + rows) of the packed block (rows, row0 multiples of the
+// kernel's tile height except for the last piece of a block): mask words / records, the matrix product, the digit combine.
+static int i8_meta_build(const I8Dims &d, hipStream_t s) {
+  const int mode = i8_sparse_mode();
+  if (mode == 0) return GEMMA_HIP_OK;
+  ProfScope ps(GEMMA_STAGE_INGEST, s);
+  const size_t nk = d.ldk / I8_BK, total = d.lpad * nk * (mode == 2 ? 4 : 2);
+  if (g_ctx.i8_meta.reserve(total * sizeof(uint4)) || g_ctx.i8_rowsur.reserve(d.lpad * sizeof(int)))
+    return fail(GEMMA_HIP_ENOMEM, "lmm_batch: mask words of the sparse product");
+  HIPCHK(hipMemsetAsync(g_ctx.i8_rowsur.p, 0, d.lpad * sizeof(int), s));
+  if (mode == 2)
+    hipLaunchKernelGGL(sparse2_meta_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, g_ctx.i8_A.as<int8_t>(),
+                       (long)d.lpad, (long)d.ldk, g_ctx.i8_meta.as<uint4>(), g_ctx.i8_rowsur.as<int>());
+  else
+    hipLaunchKernelGGL(sparse_meta_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, g_ctx.i8_A.as<int8_t>(),
+                       (long)d.lpad, (long)d.ldk, g_ctx.i8_meta.as<uint4>(), g_ctx.i8_rowsur.as<int>());
+  HIPCHK(hipGetLastError());
+  return GEMMA_HIP_OK;
+}
+
+// rows_pad: padded rows of this piece (a multiple of the tile height; row0 too).  Pieces other than the whole block are taken
+// by the records kernel only (mode 2).
+static int i8_gemm_rows(const I8Dims &d, size_t row0, size_t rows_pad, hipStream_t s) {
   // GEMMA_HIP_I8_SPARSE=0: the mask product on dense MFMAs (i8gemm_packed_kernel_t); default: on the 2:4 sparse MFMA
-  // (i8gemm_sparse.hip.h) -- one word per (row, 32 individuals) describes the operand, rows that lose calls to the 2-of-4
-  // limit are completed in fp64 after the digits are combined
+  // (i8gemm_sparse2.hip.h) -- rows that lose calls to the 2-of-4 limit are completed in fp64 after the digits are combined
   const int mode = i8_sparse_mode();
   const bool sparse = mode != 0;
+  ProfScope ps(GEMMA_STAGE_UTX_GEMM, s);
+  static bool attr_set = false;
+  if (!attr_set) {
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(i8gemm_packed_kernel_t<true>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 3 * I8P_STAGE));
+    attr_set = true;
+  }
+  I8PackArgs g;
+  g.A = g_ctx.i8_A.as<int8_t>();
+  g.Bt = g_ctx.i8_Bt.as<int8_t>();
+  g.C = g_ctx.i8_C.as<int>();
+  g.ldk = (long)d.ldk; g.ldc = (long)d.npad;
+  g.strideB = (long)(d.npad * d.ldk); g.strideC = (long)(d.mrows * d.npad);
+  g.m_row0 = (long)d.lpad;
+  g.tiles_m = (int)(d.lpad / I8P_BM); g.tiles_n = (int)(d.npad / I8_BN);
+  g.nk = (int)(d.ldk / I8_BK);
+  const char *e = getenv("GEMMA_HIP_I8_GM");
+  g.gm = e ? atoi(e) : 0;
+  g.fuse = d.fuse;
+  g.digits = d.digits;
+  const dim3 grid((unsigned)(g.tiles_m * g.tiles_n), (unsigned)d.nplanes);
+  if (mode == 2) {
+    static bool attr3 = false;
+    if (!attr3) {
+      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(i8gemm_sparse2_kernel),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, S2_NST * S2_STAGE));
+      attr3 = true;
+    }
+    Sparse2Args g2;
+    // records: [tile_m][ktile][row % 256][chunk]; planes: G rows at row, M rows at lpad + row
+    g2.AM = g_ctx.i8_meta.as<uint4>() + (row0 / S2_BM) * (size_t)g.nk * S2_BM * 4;
+    g2.Bt = g.Bt; g2.C = g.C + row0 * (size_t)g.ldc; g2.ldk = g.ldk; g2.ldc = g.ldc; g2.strideB = g.strideB; g2.strideC = g.strideC;
+    g2.m_row0 = g.m_row0;
+    g2.tiles_m = (int)(rows_pad / S2_BM); g2.tiles_n = (int)(d.npad / S2_BN);
+    g2.nk = g.nk; g2.gm = g.gm; g2.fuse = g.fuse; g2.digits = g.digits;
+    hipLaunchKernelGGL(i8gemm_sparse2_kernel, dim3((unsigned)(g2.tiles_m * g2.tiles_n), (unsigned)d.nplanes), dim3(512),
+                       S2_NST * S2_STAGE, s, g2);
+  } else if (sparse) {
+    static bool attr2 = false;
+    if (!attr2) {
+      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(i8gemm_sparse_kernel),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 3 * SP_STAGE));
+      attr2 = true;
+    }
+    SparseMeta sm;
+    sm.m4 = g_ctx.i8_meta.as<uint4>();
+    sm.row_surplus = g_ctx.i8_rowsur.as<int>();
+    sm.ntiles = (long)g.nk;
+    hipLaunchKernelGGL(i8gemm_sparse_kernel, grid, dim3(512), 3 * SP_STAGE, s, g, sm);
+  } else {
+    hipLaunchKernelGGL(i8gemm_packed_kernel_t<true>, grid, dim3(512), 3 * I8P_STAGE, s, g);
+  }
+  HIPCHK(hipGetLastError());
+  return GEMMA_HIP_OK;
+}
+
+// digits -> fp64 for the rows [row0, row0 + rows) of a block of l SNPs
+static int i8_post_rows(size_t l, const I8Dims &d, size_t row0, size_t rows, double *UtX, size_t ldx, hipStream_t s) {
+  const bool sparse = i8_sparse_mode() != 0;
+  ProfScope ps(GEMMA_STAGE_UTX_POST, s);
+  // the calls the sparse mask operand dropped (groups of four with 3-4 missing calls): rows with up to SUR_MAX of them are
+  // completed inside the digit combine from a short per-row list, the rare rows with more by the fp64 fix-up pass
+  int *sur_cnt = nullptr, *sur_list = nullptr;
+  const int8_t *Arow = g_ctx.i8_A.as<int8_t>() + row0 * d.ldk;
   if (sparse) {
-    ProfScope ps(GEMMA_STAGE_INGEST, s);
-    const size_t nk = d.ldk / I8_BK, total = d.lpad * nk * (mode == 2 ? 4 : 2);
-    if (g_ctx.i8_meta.reserve(total * sizeof(uint4)) || g_ctx.i8_rowsur.reserve(d.lpad * sizeof(int)))
-      return fail(GEMMA_HIP_ENOMEM, "lmm_batch: mask words of the sparse product");
-    HIPCHK(hipMemsetAsync(g_ctx.i8_rowsur.p, 0, d.lpad * sizeof(int), s));
-    if (mode == 2)
-      hipLaunchKernelGGL(sparse2_meta_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, g_ctx.i8_A.as<int8_t>(),
-                         (long)d.lpad, (long)d.ldk, g_ctx.i8_meta.as<uint4>(), g_ctx.i8_rowsur.as<int>());
-    else
-      hipLaunchKernelGGL(sparse_meta_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, g_ctx.i8_A.as<int8_t>(),
-                         (long)d.lpad, (long)d.ldk, g_ctx.i8_meta.as<uint4>(), g_ctx.i8_rowsur.as<int>());
+    if (g_ctx.i8_surlist.reserve(l * (SUR_MAX + 1) * sizeof(int)))
+      return fail(GEMMA_HIP_ENOMEM, "lmm_batch: dropped-call lists");
+    sur_cnt = g_ctx.i8_surlist.as<int>() + row0;
+    sur_list = g_ctx.i8_surlist.as<int>() + l + row0 * SUR_MAX;
+    hipLaunchKernelGGL(i8_surplus_list_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, Arow, (long)d.ldk,
+                       g_ctx.i8_rowsur.as<int>() + row0, (long)rows, sur_cnt, sur_list);
     HIPCHK(hipGetLastError());
   }
-  {
-    ProfScope ps(GEMMA_STAGE_UTX_GEMM, s);
-    static bool attr_set = false;
-    if (!attr_set) {
-      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(i8gemm_packed_kernel_t<true>),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, 3 * I8P_STAGE));
-      attr_set = true;
-    }
-    I8PackArgs g;
-    g.A = g_ctx.i8_A.as<int8_t>();
-    g.Bt = g_ctx.i8_Bt.as<int8_t>();
-    g.C = g_ctx.i8_C.as<int>();
-    g.ldk = (long)d.ldk; g.ldc = (long)d.npad;
-    g.strideB = (long)(d.npad * d.ldk); g.strideC = (long)(d.mrows * d.npad);
-    g.m_row0 = (long)d.lpad;
-    g.tiles_m = (int)(d.lpad / I8P_BM); g.tiles_n = (int)(d.npad / I8_BN);
-    g.nk = (int)(d.ldk / I8_BK);
-    const char *e = getenv("GEMMA_HIP_I8_GM");
-    g.gm = e ? atoi(e) : 0;
-    g.fuse = d.fuse;
-    g.digits = d.digits;
-    const dim3 grid((unsigned)(g.tiles_m * g.tiles_n), (unsigned)d.nplanes);
-    if (mode == 2) {
-      static bool attr3 = false;
-      if (!attr3) {
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(i8gemm_sparse2_kernel),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, S2_NST * S2_STAGE));
-        attr3 = true;
-      }
-      Sparse2Args g2;
-      g2.AM = g_ctx.i8_meta.as<uint4>();
-      g2.Bt = g.Bt; g2.C = g.C; g2.ldk = g.ldk; g2.ldc = g.ldc; g2.strideB = g.strideB; g2.strideC = g.strideC;
-      g2.m_row0 = g.m_row0;
-      g2.tiles_m = (int)(d.lpad / S2_BM); g2.tiles_n = (int)(d.npad / S2_BN);
-      g2.nk = g.nk; g2.gm = g.gm; g2.fuse = g.fuse; g2.digits = g.digits;
-      hipLaunchKernelGGL(i8gemm_sparse2_kernel, dim3((unsigned)(g2.tiles_m * g2.tiles_n), (unsigned)d.nplanes), dim3(512),
-                         S2_NST * S2_STAGE, s, g2);
-    } else if (sparse) {
-      static bool attr2 = false;
-      if (!attr2) {
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(i8gemm_sparse_kernel),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, 3 * SP_STAGE));
-        attr2 = true;
-      }
-      SparseMeta sm;
-      sm.m4 = g_ctx.i8_meta.as<uint4>();
-      sm.row_surplus = g_ctx.i8_rowsur.as<int>();
-      sm.ntiles = (long)g.nk;
-      hipLaunchKernelGGL(i8gemm_sparse_kernel, grid, dim3(512), 3 * SP_STAGE, s, g, sm);
-    } else {
-      hipLaunchKernelGGL(i8gemm_packed_kernel_t<true>, grid, dim3(512), 3 * I8P_STAGE, s, g);
-    }
+  hipLaunchKernelGGL(i8_combine_kernel, dim3((unsigned)((d.n + 255) / 256), (unsigned)std::min<size_t>(rows, 65535)),
+                     dim3(256), 0, s,
+                     g_ctx.i8_C.as<int>() + row0 * d.npad, (long)d.npad, (long)(d.mrows * d.npad), (long)d.lpad,
+                     g_ctx.i8_mean.as<double>() + row0, g_ctx.i8_ej.as<int>(), (long)rows, (long)d.n, UtX + row0 * ldx, (long)ldx,
+                     1.0, d.fuse, d.digits, sur_cnt, sur_list, g_ctx.U, (long)d.n);
+  HIPCHK(hipGetLastError());
+  if (sparse) {
+    hipLaunchKernelGGL(i8_surplus_fix_kernel, dim3((unsigned)rows), dim3(256), 0, s, Arow, (long)d.ldk,
+                       g_ctx.i8_rowsur.as<int>() + row0, g_ctx.i8_mean.as<double>() + row0, g_ctx.U, (long)d.n, (long)d.n,
+                       (long)rows, UtX + row0 * ldx, (long)ldx, SUR_MAX);
     HIPCHK(hipGetLastError());
-  }
-  {
-    ProfScope ps(GEMMA_STAGE_UTX_POST, s);
-    // the calls the sparse mask operand dropped (groups of four with 3-4 missing calls): rows with up to SUR_MAX of them are
-    // completed inside the digit combine from a short per-row list, the rare rows with more by the fp64 fix-up pass
-    int *sur_cnt = nullptr, *sur_list = nullptr;
-    if (sparse) {
-      if (g_ctx.i8_surlist.reserve(l * (SUR_MAX + 1) * sizeof(int)))
-        return fail(GEMMA_HIP_ENOMEM, "lmm_batch: dropped-call lists");
-      sur_cnt = g_ctx.i8_surlist.as<int>();
-      sur_list = sur_cnt + l;
-      hipLaunchKernelGGL(i8_surplus_list_kernel, dim3((unsigned)((l + 3) / 4)), dim3(256), 0, s, g_ctx.i8_A.as<int8_t>(),
-                         (long)d.ldk, g_ctx.i8_rowsur.as<int>(), (long)l, sur_cnt, sur_list);
-      HIPCHK(hipGetLastError());
-    }
-    hipLaunchKernelGGL(i8_combine_kernel, dim3((unsigned)((d.n + 255) / 256), (unsigned)std::min<size_t>(l, 65535)),
-                       dim3(256), 0, s,
-                       g_ctx.i8_C.as<int>(), (long)d.npad, (long)(d.mrows * d.npad), (long)d.lpad,
-                       g_ctx.i8_mean.as<double>(), g_ctx.i8_ej.as<int>(), (long)l, (long)d.n, UtX, (long)ldx, 1.0, d.fuse,
-                       d.digits, sur_cnt, sur_list, g_ctx.U, (long)d.n);
-    HIPCHK(hipGetLastError());
-    if (sparse) {
-      hipLaunchKernelGGL(i8_surplus_fix_kernel, dim3((unsigned)l), dim3(256), 0, s, g_ctx.i8_A.as<int8_t>(), (long)d.ldk,
-                         g_ctx.i8_rowsur.as<int>(), g_ctx.i8_mean.as<double>(), g_ctx.U, (long)d.n, (long)d.n, (long)l, UtX,
-                         (long)ldx, SUR_MAX);
-      HIPCHK(hipGetLastError());
-    }
   }
   return GEMMA_HIP_OK;
+}
+
+// UtX (l x ldx) from the packed left factor in g_ctx.i8_A and the per-SNP means in g_ctx.i8_mean
+static int i8_product(size_t l, const I8Dims &d, double *UtX, size_t ldx, hipStream_t s) {
+  int rc = i8_meta_build(d, s);
+  if (!rc) rc = i8_gemm_rows(d, 0, d.lpad, s);
+  if (!rc) rc = i8_post_rows(l, d, 0, l, UtX, ldx, s);
+  return rc;
 }
 
 // PLINK 2-bit batch
@@ -1819,6 +1850,74 @@ static int check_batch_args(const char *who, int kind, const void *geno, size_t 
   return GEMMA_HIP_OK;
 }
 
+// PLINK blocks on the records kernel, in row chunks on two streams.  The int8 product is bound by the matrix pipe (and by
+// power), the digit combine and the per-SNP stage by HBM and latency: 6 of a step's 64 ms at n = B = 20 000 that leave the
+// matrix pipe idle.  The block is cut into `chunks` pieces of whole 256-row tiles; the caller's stream runs ingest + records for
+// the block and then the products of the chunks back to back, the side stream runs combine + association of chunk c as soon as
+// its product is done -- beside the product of chunk c + 1 (a product workgroup leaves 32 KiB of LDS and 24 wavefront slots per
+// CU free).  Every buffer is partitioned by SNP rows (planes, UtX, records, lists, the output), the per-SNP stage's scratch is
+// reused chunk after chunk in side-stream order, and the caller's stream waits for the side stream before the call returns
+// control of it: the call has the semantics it had.
+// MEASURED (round 3, n = B = 20 000, profiles/r03_overlap_two_streams.txt): it does not pay.  One stream 62.7 ms per step
+// (product 55.7, combine 2.8, per-SNP stage 3.2); four chunks on two streams 64.2 ms -- the product takes 61.1 ms with the side
+// stream's kernels among its workgroups (every CU slot and every watt they take is the product's), the per-SNP stage 10.5 ms;
+// two chunks 63.3, eight 64.0.  The chip is at its power limit under the product alone, so concurrency is a zero-sum game
+// here.  The path stays behind GEMMA_HIP_OVERLAP=1 (GEMMA_HIP_OVERLAP_CHUNKS, default 4), off by default, with its test.
+static int overlap_chunks(size_t l) {
+  const char *e = getenv("GEMMA_HIP_OVERLAP");
+  if (!(e && e[0] == '1')) return 1;
+  if (utx_i8_mode() != 1 || i8_sparse_mode() != 2) return 1;
+  int q = 4;
+  if (const char *ec = getenv("GEMMA_HIP_OVERLAP_CHUNKS")) q = atoi(ec);
+  q = std::max(1, std::min(q, 16));
+  while (q > 1 && l < (size_t)q * 2 * S2_BM) --q; // at least two tile rows per chunk
+  return q;
+}
+static int overlap_init() {
+  if (g_ctx.ov_stream) return GEMMA_HIP_OK;
+  HIPCHK(hipStreamCreateWithFlags(&g_ctx.ov_stream, hipStreamNonBlocking));
+  for (auto &e : g_ctx.ov_ready) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  HIPCHK(hipEventCreateWithFlags(&g_ctx.ov_done, hipEventDisableTiming));
+  return GEMMA_HIP_OK;
+}
+static int lmm_batch_plink_chunked(const void *geno, size_t l, size_t ld, gemma_sumstat *out_d, int chunks, hipStream_t s) {
+  const size_t n = g_ctx.cfg.n;
+  const size_t ldx = (n + 1) & ~(size_t)1;
+  int rc = overlap_init();
+  if (rc) return rc;
+  if (g_ctx.UtX.reserve(l * ldx * 8)) return fail(GEMMA_HIP_ENOMEM, "lmm_batch: cannot allocate %zu bytes", l * ldx * 8);
+  double *UtX = g_ctx.UtX.as<double>();
+  g_ctx.last_utx_path = 1;
+  I8Dims d;
+  if ((rc = i8_begin(l, &d, s))) return rc;
+  {
+    ProfScope ps(GEMMA_STAGE_INGEST, s);
+    IngestI8Args a;
+    a.src = reinterpret_cast<const unsigned char *>(geno); a.ld = (long)ld; a.l = (long)l;
+    a.idx_map = g_ctx.have_map ? g_ctx.idx_map.as<int>() : nullptr;
+    a.n = (int)d.n; a.A = g_ctx.i8_A.as<int8_t>(); a.ldk = (long)d.ldk;
+    a.mean = g_ctx.i8_mean.as<double>();
+    hipLaunchKernelGGL(ingest_i8_kernel, dim3((unsigned)((l + 3) / 4)), dim3(256), 0, s, a);
+    HIPCHK(hipGetLastError());
+  }
+  if ((rc = i8_meta_build(d, s))) return rc;
+  const size_t per = round_up((l + chunks - 1) / chunks, (size_t)S2_BM);
+  hipStream_t side = g_ctx.ov_stream;
+  int c = 0;
+  for (size_t row0 = 0; row0 < l; row0 += per, ++c) {
+    const size_t rows = std::min(per, l - row0), rows_pad = std::min(per, d.lpad - row0);
+    if ((rc = i8_gemm_rows(d, row0, rows_pad, s))) break;
+    HIPCHK(hipEventRecord(g_ctx.ov_ready[c], s));
+    HIPCHK(hipStreamWaitEvent(side, g_ctx.ov_ready[c], 0));
+    if ((rc = i8_post_rows(l, d, row0, rows, UtX, ldx, side))) break;
+    if ((rc = launch_assoc(UtX + row0 * ldx, rows, ldx, out_d + row0, side))) break;
+  }
+  // whatever happened, the caller's stream is ordered behind the side stream again before this call hands it back
+  (void)hipEventRecord(g_ctx.ov_done, side);
+  (void)hipStreamWaitEvent(s, g_ctx.ov_done, 0);
+  return rc;
+}
+
 extern "C" int gemma_hip_lmm_batch_d(int kind, const void *geno, size_t l, size_t ld, gemma_sumstat *out_d,
                                      void *stream) {
   NEED_INIT();
@@ -1827,6 +1926,10 @@ extern "C" int gemma_hip_lmm_batch_d(int kind, const void *geno, size_t l, size_
   int rc = check_batch_args("lmm_batch", kind, geno, l, ld, out_d);
   if (rc) return rc;
   hipStream_t s = S(stream);
+  if (kind == GEMMA_GENO_PLINK_2BIT) {
+    const int chunks = overlap_chunks(l);
+    if (chunks > 1) return lmm_batch_plink_chunked(geno, l, ld, out_d, chunks, s);
+  }
   double *UtX;
   size_t ldx;
   rc = compute_utx(kind, geno, l, ld, -1, &UtX, &ldx, s);

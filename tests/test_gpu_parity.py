@@ -630,6 +630,46 @@ def test_utx_int8_more_rows_than_a_grid_dimension(gpu_api, oracle):
     np.testing.assert_allclose(b, a, rtol=0, atol=1e-13 * np.abs(a).max())
 
 
+def test_lmm_plink_block_in_chunks_on_two_streams(gpu_api, oracle, monkeypatch):
+    """With GEMMA_HIP_OVERLAP=1 gemma_hip_lmm_batch on a PLINK block runs the int8 product of row chunk c + 1 on the caller's stream
+    beside the digit combine and the per-SNP stage of chunk c on a side stream (round 3; off by default: measured, it does not pay
+    on a power-limited product -- gemma_hip.hip: overlap_chunks).  Every buffer is partitioned by SNP rows, so the records must be
+    the ones a single stream writes, bit for bit: 2500 SNPs (chunks of 768, 768, 768, 196 rows; then seven chunks; then one
+    stream), -lmm 4, missing calls and the NaN-carry rule of the PLINK loop (which crosses chunk boundaries in SNP order), and
+    the call repeated on the same state (the side stream of one call against the ingest of the next)."""
+    import gemma_amd._lib as L
+    rng = np.random.default_rng(31)
+    ni_total, p = 640, 2500
+    ind, raw = _plink_case(oracle, rng, ni_total, p, miss=0.03)
+    raw[1500:1503] = 0x55  # three SNPs nobody is called at: NaN rows in the middle of a chunk, carried forward
+    n = int(ind.sum())
+    Kg = oracle.bed_decode(raw[:600], ni_total)[:, ind == 1]
+    U, ev, _ = oracle.eigen_decomp_zeroed(oracle.center_matrix(oracle.calc_kin(Kg, 1)))
+    y = rng.standard_normal(n)
+    UtW, Uty = U.T @ np.ones((n, 1)), U.T @ y
+    outs = {}
+    for tag, env in (("one stream", {}), ("four chunks", {"GEMMA_HIP_OVERLAP": "1"}),
+                     ("seven chunks", {"GEMMA_HIP_OVERLAP": "1", "GEMMA_HIP_OVERLAP_CHUNKS": "7"})):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        lmm = gpu_api.LMM(a_mode=4)
+        lmm.setup(U, ev, UtW, Uty, plink=True)
+        lmm.set_indicator(ind)
+        try:
+            a = lmm.batch(raw, L.GENO_PLINK_2BIT).copy()
+            b = lmm.batch(raw[::-1].copy(), L.GENO_PLINK_2BIT).copy()
+        finally:
+            lmm.finish()
+        for k in env:
+            monkeypatch.delenv(k)
+        outs[tag] = (a, b)
+    ref = outs["one stream"]
+    assert np.isfinite(ref[0]["p_wald"]).sum() > 2400
+    for tag in ("four chunks", "seven chunks"):
+        for x, r in zip(outs[tag], ref):
+            assert x.tobytes() == r.tobytes(), tag
+
+
 @pytest.mark.parametrize("i8", ["1", "0"])
 def test_lmm_plink_through_int8_digit_product(gpu_api, oracle, monkeypatch, i8):
     """The whole PLINK association path through the int8-digit product (default) and through the fp64 GEMM
