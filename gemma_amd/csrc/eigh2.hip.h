@@ -1016,8 +1016,24 @@ static inline int eig2_sb2st(long n, EigWs &ws, Eig2Ws &w2, hipStream_t s, std::
         (void)hipMemsetAsync(dbg_d, 0, 512 * 16 * 8, s);
         pa.dbg = dbg_d;
       }
-      if (dbg_d) hipLaunchKernelGGL(bc_persist_kernel<true>, dim3((unsigned)nwg), dim3(BC_THREADS), BC_LDS_DOUBLES * 8, s, pa);
-      else hipLaunchKernelGGL(bc_persist_kernel<false>, dim3((unsigned)nwg), dim3(BC_THREADS), BC_LDS_DOUBLES * 8, s, pa);
+      if (dbg_d) {
+        hipLaunchKernelGGL(bc_persist_kernel<true>, dim3((unsigned)nwg), dim3(BC_THREADS), BC_LDS_DOUBLES * 8, s, pa);
+      } else {
+        // a COOPERATIVE launch: the runtime starts the grid only with every workgroup resident, which is what the progress
+        // counters assume (a kernel of another stream holding a few CUs would otherwise leave some workgroups waiting for
+        // neighbours that have not started: bounded waits, then the slow per-step fall-back below).  GEMMA_HIP_EIGH_BC_COOP=0 or a
+        // refusal by the runtime: the plain launch, as in round 2
+        const char *ec = getenv("GEMMA_HIP_EIGH_BC_COOP");
+        bool launched = false;
+        if (!(ec && ec[0] == '0')) {
+          void *kargs[] = {reinterpret_cast<void *>(&pa)};
+          launched = hipLaunchCooperativeKernel(reinterpret_cast<const void *>(bc_persist_kernel<false>), dim3((unsigned)nwg),
+                                                dim3(BC_THREADS), kargs, (unsigned)(BC_LDS_DOUBLES * 8), s) == hipSuccess;
+          if (!launched) (void)hipGetLastError();
+        }
+        if (!launched)
+          hipLaunchKernelGGL(bc_persist_kernel<false>, dim3((unsigned)nwg), dim3(BC_THREADS), BC_LDS_DOUBLES * 8, s, pa);
+      }
       EIG_HIP(hipGetLastError());
       if (dbg_d) {
         std::vector<long long> hs(512 * 16);
