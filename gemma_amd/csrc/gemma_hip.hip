@@ -1352,6 +1352,11 @@ extern "C" int gemma_hip_lmm_set_indicator(const int *indicator_idv, size_t ni_t
   if (map.size() != g_ctx.cfg.n)
     return fail(GEMMA_HIP_EINVAL, "lmm_set_indicator: %zu analysed individuals, cfg.n = %zu", map.size(),
                 g_ctx.cfg.n);
+  if (map.size() == ni_total) { // everybody is analysed: the identity needs no mapping (and PLINK rows take the word-wise ingest)
+    g_ctx.have_map = false;
+    g_ctx.ni_total = 0;
+    return GEMMA_HIP_OK;
+  }
   if (g_ctx.idx_map.reserve(map.size() * sizeof(int))) return fail(GEMMA_HIP_ENOMEM, "idx_map");
   HIPCHK(hipMemcpy(g_ctx.idx_map.p, map.data(), map.size() * sizeof(int), hipMemcpyHostToDevice));
   g_ctx.have_map = true;
@@ -1617,7 +1622,7 @@ static int i8_post_rows(size_t l, const I8Dims &d, size_t row0, size_t rows, dou
                        g_ctx.i8_rowsur.as<int>() + row0, (long)rows, sur_cnt, sur_list);
     HIPCHK(hipGetLastError());
   }
-  hipLaunchKernelGGL(i8_combine_kernel, dim3((unsigned)((d.n + 255) / 256), (unsigned)std::min<size_t>(rows, 65535)),
+  hipLaunchKernelGGL(i8_combine_kernel, dim3((unsigned)((d.n + 1023) / 1024), (unsigned)std::min<size_t>(rows, 65535)),
                      dim3(256), 0, s,
                      g_ctx.i8_C.as<int>() + row0 * d.npad, (long)d.npad, (long)(d.mrows * d.npad), (long)d.lpad,
                      g_ctx.i8_mean.as<double>() + row0, g_ctx.i8_ej.as<int>(), (long)rows, (long)d.n, UtX + row0 * ldx, (long)ldx,

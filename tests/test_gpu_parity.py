@@ -608,6 +608,42 @@ def test_utx_int8_sparse_mask_operand_and_surplus_rows(gpu_api, oracle, monkeypa
     assert e_dense < 8 * 2.3e-16 and e_sparse < 8 * 2.3e-16
 
 
+@pytest.mark.parametrize("ni_total", [777, 800, 1003])
+def test_plink_ingest_word_path_matches_the_byte_path(gpu_api, oracle, ni_total):
+    """ingest_i8_kernel turns a 32-bit word of a .bed row (16 calls) into one 16-byte store when no indicator mapping is set and
+    the row starts on a 4-byte boundary (round 3), byte per lane otherwise: 777 individuals = 195 bytes per row (every fourth row
+    aligned, last word ragged), 800 = all rows aligned, 1003 = 251 bytes.  Against the fp64 path (its own ingest kernel), and with
+    an all-ones indicator (the identity: no mapping is kept) -- identical products and means."""
+    from gemma_amd import _lib as L
+    rng = np.random.default_rng(ni_total)
+    p = 130
+    codes = rng.choice([0, 1, 2, 3], size=(p, ni_total), p=[0.3, 0.05, 0.35, 0.3]).astype(np.uint8)
+    codes[5] = 1   # nobody called
+    codes[6] = 3
+    nb = (ni_total + 3) // 4
+    pad = np.zeros((p, nb * 4), dtype=np.uint8)
+    pad[:, :ni_total] = codes
+    pad[:, ni_total:] = 1  # padding bits of the last byte must not be read as calls
+    raw = (pad[:, 0::4] | (pad[:, 1::4] << 2) | (pad[:, 2::4] << 4) | (pad[:, 3::4] << 6)).astype(np.uint8)
+    A = rng.standard_normal((ni_total, ni_total))
+    U, ev, _ = oracle.eigen_decomp_zeroed(oracle.center_matrix(A @ A.T / ni_total))
+    outs = {}
+    for tag in ("word", "mapped"):
+        lmm = gpu_api.LMM(a_mode=1)
+        lmm.setup(U, ev, U.T @ np.ones((ni_total, 1)), U.T @ rng.standard_normal(ni_total), plink=True)
+        if tag == "mapped":
+            lmm.set_indicator(np.ones(ni_total, dtype=np.int32))
+        try:
+            outs[tag] = (lmm.dbg_utx(raw, L.GENO_PLINK_2BIT, 1), lmm.dbg_utx(raw, L.GENO_PLINK_2BIT, 0))
+        finally:
+            lmm.finish()
+    ok = np.ones(p, dtype=bool)
+    ok[5] = False  # mean 0 / 0
+    assert np.array_equal(outs["word"][0][ok], outs["mapped"][0][ok])
+    np.testing.assert_allclose(outs["word"][0][ok], outs["word"][1][ok], rtol=0, atol=1e-13 * np.abs(outs["word"][1][ok]).max())
+    assert np.isnan(outs["word"][0][5]).all() == np.isnan(outs["mapped"][0][5]).all()
+
+
 def test_utx_int8_more_rows_than_a_grid_dimension(gpu_api, oracle):
     """70 000 SNPs in one block: more rows than a HIP grid's y extent (65 535) -- the digit-combine pass sweeps."""
     from gemma_amd import _lib as L
