@@ -438,8 +438,14 @@ def main():
     # fp64 MFMA GEMM on the same block as the check; outside the timed region, single GPU only
     dosage_path = None
     if world == 1 and i8_path and args.dosage_steps > 0:
-        Xd = [torch.randint(0, 201, (B, n), device=dev, generator=gen, dtype=torch.int32).to(torch.float64).div_(100.0)
+        # k / 100 as a text parser produces it: the correctly rounded quotient.  (tensor / python scalar is a multiplication by
+        # the reciprocal in torch -- k * 0.01 is not the double "0.37" parses to, and the library's dosage detection is exact.)
+        hundred = torch.tensor([100.0], device=dev, dtype=torch.float64)
+        Xd = [torch.randint(0, 201, (B, n), device=dev, generator=gen, dtype=torch.int32).to(torch.float64).div_(hundred)
               for _ in range(2)]
+        probe = Xd[0][:4].cpu().numpy()
+        assert np.array_equal(probe, np.rint(probe * 100.0) / 100.0), "synthetic dosages are not the parsed decimals"
+        del probe
         outd = torch.empty((B, 8), dtype=torch.float64, device=dev)
         lmm.batch(Xd[0], L.GENO_F64_SNP_MAJOR, out=outd)
         torch.cuda.synchronize()

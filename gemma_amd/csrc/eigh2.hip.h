@@ -1019,13 +1019,17 @@ static inline int eig2_sb2st(long n, EigWs &ws, Eig2Ws &w2, hipStream_t s, std::
       if (dbg_d) {
         hipLaunchKernelGGL(bc_persist_kernel<true>, dim3((unsigned)nwg), dim3(BC_THREADS), BC_LDS_DOUBLES * 8, s, pa);
       } else {
-        // a COOPERATIVE launch: the runtime starts the grid only with every workgroup resident, which is what the progress
-        // counters assume (a kernel of another stream holding a few CUs would otherwise leave some workgroups waiting for
-        // neighbours that have not started: bounded waits, then the slow per-step fall-back below).  GEMMA_HIP_EIGH_BC_COOP=0 or a
-        // refusal by the runtime: the plain launch, as in round 2
+        // GEMMA_HIP_EIGH_BC_COOP=1: a COOPERATIVE launch -- the runtime starts the grid only with every workgroup resident, which
+        // is what the progress counters assume (a kernel of another stream holding a few CUs would otherwise leave some
+        // workgroups waiting for neighbours that have not started: bounded waits, then the slow per-step fall-back below).
+        // NOT the default (round 3, measured): the chase itself runs as fast either way (0.86 s at n = 20 000), but a process
+        // that has made one cooperative launch keeps a cooperative queue, and from then on ANOTHER process on the same device
+        // runs at half speed while the first merely exists (bench.py's end-to-end child: 7.8 s instead of 4.3 s, its
+        // eigensolver 5.5 s instead of 2.7 s; back to 4.35 s with the plain launch in the parent).  Ranks that share a device
+        // -- the tests, the shm transport -- must not pay that.
         const char *ec = getenv("GEMMA_HIP_EIGH_BC_COOP");
         bool launched = false;
-        if (!(ec && ec[0] == '0')) {
+        if (ec && ec[0] == '1') {
           void *kargs[] = {reinterpret_cast<void *>(&pa)};
           launched = hipLaunchCooperativeKernel(reinterpret_cast<const void *>(bc_persist_kernel<false>), dim3((unsigned)nwg),
                                                 dim3(BC_THREADS), kargs, (unsigned)(BC_LDS_DOUBLES * 8), s) == hipSuccess;
