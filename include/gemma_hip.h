@@ -32,7 +32,8 @@
 extern "C" {
 #endif
 
-#define GEMMA_HIP_ABI_VERSION 2
+/* 3: gemma_mvlmm_opt gained `crt` (round 3); 2: the round-2 entry points */
+#define GEMMA_HIP_ABI_VERSION 3
 
 enum {
   GEMMA_HIP_OK = 0,
