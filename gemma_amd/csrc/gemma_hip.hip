@@ -2013,8 +2013,10 @@ extern "C" int gemma_hip_mvlmm_null_launch_(const MvNullArgs *a, int d, int c, h
 
 static int mv_check_dims(const char *who, size_t d, size_t c) {
   if (d < 1 || d > (size_t)MV_DMAX) return fail(GEMMA_HIP_EINVAL, "%s: %zu phenotypes not supported (1..%d)", who, d, MV_DMAX);
-  if (c < 1 || c + 1 > (size_t)MV_CMAX)
-    return fail(GEMMA_HIP_EINVAL, "%s: %zu covariates not supported (1..%d)", who, c, MV_CMAX - 1);
+  // kernels are built for d <= 5 with up to 3 covariates and for d <= 3 with up to MV_CMAX - 1 = 6 (mvlmm_kernels.hip)
+  const size_t cmax = d <= 3 ? (size_t)MV_CMAX - 1 : 3;
+  if (c < 1 || c > cmax)
+    return fail(GEMMA_HIP_EINVAL, "%s: %zu covariates not supported with %zu phenotypes (1..%zu)", who, c, d, cmax);
   return GEMMA_HIP_OK;
 }
 

@@ -21,7 +21,8 @@
 namespace gemma_hip {
 
 constexpr int MV_DMAX = 5;  // phenotypes
-constexpr int MV_CMAX = 4;  // covariates + the SNP
+constexpr int MV_CMAX = 7;  // covariates + the SNP (d <= 3: up to 6 covariates; d = 4, 5: up to 3 -- the kernels that are built)
+constexpr int MV_BMAX = 20; // entries of B (d x covariates): 5 x 3, 3 x 6
 
 struct MvArgs {
   const double *UtX;  // l x ld, SNP-major
@@ -30,7 +31,7 @@ struct MvArgs {
   const double *eval;  // n
   const double *Wt;    // (c - 1) x n : U^T W transposed
   const double *Yt;    // d x n       : U^T Y transposed
-  double Vg_null[MV_DMAX * MV_DMAX], Ve_null[MV_DMAX * MV_DMAX], B_null[MV_DMAX * MV_CMAX]; // B_null: d x (c - 1)
+  double Vg_null[MV_DMAX * MV_DMAX], Ve_null[MV_DMAX * MV_DMAX], B_null[MV_BMAX]; // B_null: d x (c - 1)
   double logl_H0;      // MLE null log-likelihood (the LRT reference, :3317)
   int a_mode;
   int em_iter;         // per-SNP cap (the caller passes em_iter / 10, :3310)

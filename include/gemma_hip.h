@@ -209,7 +209,7 @@ int gemma_hip_lmm_finish(double *time_UtX_min, double *time_opt_min);
 
 /* ---- multivariate LMM (-lmm 1..4 -n a b c ...) ------------------------------------ */
 /* MVLMM::AnalyzeBimbam / AnalyzePlink, src/mvlmm.cpp:2972-3416 / :3418-3899.  d phenotypes (1..5), n_cvt covariates
- * (1..3); opt->crt = 1 applies the Edgeworth correction (CalcCRT / PCRT, :2054-2358 / :2952-2970) as -crt does.
+ * (1..3; 1..6 for d <= 3); opt->crt = 1 applies the Edgeworth correction (CalcCRT / PCRT, :2054-2358 / :2952-2970) as -crt does.
  * gemma_mvlmm_null holds what the null-model block (:3056-3208) leaves behind: V_g, V_e (d x d row-major, leading
  * dimension d), B (d x n_cvt) and the log-likelihood, for the REMLE and the MLE fit. */
 typedef struct {

@@ -27,6 +27,7 @@ extern "C" int mvh_batch(int d, int c, const MvArgs *g) {
   CASE(1, 2) CASE(2, 2) CASE(3, 2) CASE(4, 2) CASE(5, 2)
   CASE(1, 3) CASE(2, 3) CASE(3, 3) CASE(4, 3) CASE(5, 3)
   CASE(1, 4) CASE(2, 4) CASE(3, 4) CASE(4, 4) CASE(5, 4)
+  CASE(1, 5) CASE(2, 5) CASE(3, 5) CASE(1, 6) CASE(2, 6) CASE(3, 6) CASE(1, 7) CASE(2, 7) CASE(3, 7)
 #undef CASE
   return 1;
 }

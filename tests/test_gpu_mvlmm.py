@@ -33,7 +33,8 @@ def _oracle_run(oracle, c, a_mode, X=None, **cfg_kw):
     return null, oracle.mvlmm_batch(a_mode, cfg, c["ev"], c["UtW"], c["UtY"], UtX, null)
 
 
-@pytest.mark.parametrize("n,d,cw,seed", [(300, 3, 1, 5), (257, 2, 2, 6), (200, 1, 1, 7), (400, 4, 1, 8), (600, 5, 2, 9),
+@pytest.mark.parametrize("n,d,cw,seed", [(320, 2, 4, 21), (350, 3, 6, 22), (300, 1, 5, 23),  # four to six covariates: d <= 3 (round 3)
+                                        (300, 3, 1, 5), (257, 2, 2, 6), (200, 1, 1, 7), (400, 4, 1, 8), (600, 5, 2, 9),
                                          (350, 3, 3, 10)])
 def test_null_model_block(gpu_api, oracle, n, d, cw, seed):
     """MphInitial + MphEM + MphNR + MphCalcBeta for 'R' then 'L' (src/mvlmm.cpp:3056-3208); d = 5 takes the two-trait
@@ -50,7 +51,8 @@ def test_null_model_block(gpu_api, oracle, n, d, cw, seed):
 
 @pytest.mark.parametrize("n,d,cw,p,seed,a_mode", [(300, 3, 1, 300, 5, 4), (257, 2, 2, 130, 6, 4), (200, 1, 1, 70, 7, 4),
                                                   (400, 4, 1, 40, 8, 1), (600, 5, 2, 24, 9, 2), (350, 3, 3, 50, 10, 3),
-                                                  (300, 3, 1, 64, 15, 1), (300, 3, 2, 64, 16, 2)])
+                                                  (300, 3, 1, 64, 15, 1), (300, 3, 2, 64, 16, 2),
+                                                  (320, 2, 4, 48, 21, 4), (350, 3, 6, 24, 22, 4), (340, 3, 5, 24, 28, 1)])
 def test_analyze_bimbam(gpu_api, oracle, n, d, cw, p, seed, a_mode):
     c = make_case(n, d, cw, p, seed)
     G = c["G"].copy()
@@ -109,5 +111,8 @@ def test_state_and_argument_errors(gpu_api, oracle):
         mv.fit_null(c["ev"], np.ones((120, 1)), np.zeros((120, 6)))  # six phenotypes
     assert e.value.code == L.EINVAL
     with pytest.raises(L.GemmaHipError) as e:
-        mv.fit_null(c["ev"], np.ones((120, 4)), np.zeros((120, 2)))  # four covariates
+        mv.fit_null(c["ev"], np.ones((120, 7)), np.zeros((120, 2)))  # seven covariates (d <= 3: up to six)
+    assert e.value.code == L.EINVAL
+    with pytest.raises(L.GemmaHipError) as e:
+        mv.fit_null(c["ev"], np.ones((120, 4)), np.zeros((120, 4)))  # four covariates with four phenotypes (d > 3: up to three)
     assert e.value.code == L.EINVAL

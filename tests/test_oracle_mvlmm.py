@@ -151,7 +151,8 @@ def harness():
                                                (600, 5, 2, 6, 9, 0), (350, 3, 3, 10, 10, 0),
                                                (300, 3, 1, 40, 5, 1), (257, 2, 2, 30, 6, 1), (200, 1, 1, 30, 7, 1),
                                                (400, 4, 1, 12, 8, 1), (350, 3, 3, 10, 10, 1),
-                                               (300, 3, 1, 40, 5, 2), (257, 2, 2, 30, 6, 2)])
+                                               (300, 3, 1, 40, 5, 2), (257, 2, 2, 30, 6, 2),
+                                               (320, 2, 4, 16, 21, 0), (350, 3, 6, 10, 22, 0), (300, 1, 5, 12, 23, 2), (340, 3, 5, 10, 28, 1)])
 def test_kernel_source_on_one_lane_matches_the_oracle(harness, n, d, cw, p, seed, crt):
     """crt = 1: the reference's -crt.  The kernel source computes CalcCRT's traces in the rotated basis from its moment tables
     (MvNr::crt_factors), the oracle as the reference does, from dense dc x dc products (pinned on the reference's own crt_a, b, c
