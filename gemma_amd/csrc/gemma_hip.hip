@@ -1912,8 +1912,10 @@ static int lmm_batch_plink_chunked(const void *geno, size_t l, size_t ld, gemma_
   for (size_t row0 = 0; row0 < l; row0 += per, ++c) {
     const size_t rows = std::min(per, l - row0), rows_pad = std::min(per, d.lpad - row0);
     if ((rc = i8_gemm_rows(d, row0, rows_pad, s))) break;
-    HIPCHK(hipEventRecord(g_ctx.ov_ready[c], s));
-    HIPCHK(hipStreamWaitEvent(side, g_ctx.ov_ready[c], 0));
+    if (hipEventRecord(g_ctx.ov_ready[c], s) != hipSuccess || hipStreamWaitEvent(side, g_ctx.ov_ready[c], 0) != hipSuccess) {
+      rc = fail(GEMMA_HIP_ERUNTIME, "lmm_batch: %s", hipGetErrorString(hipGetLastError())); // and join below, as on every path
+      break;
+    }
     if ((rc = i8_post_rows(l, d, row0, rows, UtX, ldx, side))) break;
     if ((rc = launch_assoc(UtX + row0 * ldx, rows, ldx, out_d + row0, side))) break;
   }
