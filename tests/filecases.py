@@ -454,13 +454,19 @@ def hwe_workflow(exe, out):
     compare_assoc(os.path.join(out, "Hhwe.assoc.txt"), os.path.join(TXT, "Hhwe.assoc.txt.gz"))
 
 
-def mvlmm3_workflow(exe, out, modes=(1, 3)):
+def mvlmm3_workflow(exe, out, modes=(1, 3), crt=False):
     """Three traits with missing phenotypes (fixture `b` of ref_mv.npz: issue188 genotypes, simulated correlated traits, 25 NA
     entries): the `-gk` run selects individuals by trait 1 alone, the `-lmm m -n 1 2 3` run by all three -- as the reference
-    does; REML and score modes (the reference's ML EM for d >= 3 is basis-unstable)."""
+    does; REML and score modes (the reference's ML EM for d >= 3 is basis-unstable).
+    crt: with -crt against tests/golden/ref_mv_crt.npz -- the reference corrects the p_wald of 52 SNPs here."""
     import refcases as R
     out = str(out)
     fx = np.load(os.path.join(ROOT, "tests", "golden", "ref_mv.npz"))
+    fx_plain = fx
+    if crt:
+        fc = np.load(os.path.join(ROOT, "tests", "golden", "ref_mv_crt.npz"))
+        fx = dict(fx)
+        fx.update({k.replace("b_crt_", "b_", 1): fc[k] for k in fc.files if k.startswith("b_crt_m")})
     f188 = np.load(os.path.join(ROOT, "tests", "golden", "ref_issue188.npz"))
     txt = fx["b_pheno_txt"]
     n_total = txt.shape[0]
@@ -478,7 +484,7 @@ def mvlmm3_workflow(exe, out, modes=(1, 3)):
     drive(exe, *base, "-gk", "-o", "mv3")
     cxx = os.path.join(out, "mv3.cXX.txt")
     for m in modes:
-        kv = drive(exe, *base, "-k", cxx, "-lmm", m, "-n", 1, 2, 3, "-o", "mv3_m%d" % m)
+        kv = drive(exe, *base, "-k", cxx, "-lmm", m, "-n", 1, 2, 3, *(("-crt",) if crt else ()), "-o", "mv3_m%d" % m)
         assert int(kv["ni_test"]) == int((np.array([["NA" in r for r in txt]]) == 0).sum())
         assert abs(float(kv["logl_remle_H0"]) - fx["b_logl_null"][0]) <= 2e-6 * abs(fx["b_logl_null"][0])
         hdr, rows = read_assoc(os.path.join(out, "mv3_m%d.assoc.txt" % m))
@@ -491,6 +497,13 @@ def mvlmm3_workflow(exe, out, modes=(1, 3)):
                 got[c] = col[c]
         err = R.mv_row_err(got, R.mv_ref_table(fx, "b", m, 3))
         assert np.mean(err <= STAT_TOL) >= 0.97 and err.max() <= 5e-3, (m, float(np.mean(err <= STAT_TOL)), float(err.max()))
+        if crt and "p_wald" in got:  # the rows the reference's -crt changes: the corrected value, and not the uncorrected one
+            key = "b_m%d_p_wald" % m
+            rows_c = np.flatnonzero(fx[key] != fx_plain[key])
+            assert rows_c.size >= 40
+            dc = np.abs(got["p_wald"][rows_c] - fx[key][rows_c]) / fx[key][rows_c]
+            dp = np.abs(got["p_wald"][rows_c] - fx_plain[key][rows_c]) / fx_plain[key][rows_c]
+            assert dc.max() <= 5e-3 and np.mean(dc <= STAT_TOL) >= 0.9 and np.all(dc < dp), (float(dc.max()), float(np.mean(dc <= STAT_TOL)))
 
 
 def standardised_kinship_workflow(exe, out):

@@ -364,8 +364,34 @@ def mv_crt(tmp):
     assert changed["a_m1_p_wald"] >= 1 and changed["a_m2_p_lrt"] >= 1, changed
     out = {k.replace("a_", "a_crt_", 1): v for k, v in d.items() if k.startswith("a_m") or k == "a_snp"}
     out["a_crt_rows_changed"] = np.array([changed.get("a_m1_p_wald", 0), changed.get("a_m2_p_lrt", 0), changed.get("a_m3_p_score", 0)])
+    # (b) three traits with missing phenotypes (issue188 genotypes from ref_issue188.npz, phenotypes from ref_mv.npz), REML and
+    #     score modes as in ref_mv.npz
+    f188 = np.load(os.path.join(OUT, "ref_issue188.npz"))
+    txt = fx["b_pheno_txt"]
+    n3 = txt.shape[0]
+    nb3 = (n3 + 3) // 4
+    ns3 = (f188["bed"].size - 3) // nb3
+    pre3 = os.path.join(tmp, "mvc3")
+    open(pre3 + ".bed", "wb").write(f188["bed"].tobytes())
+    bim3 = ["1\trs%d\t0\t%d\tA\tG\n" % (t, t + 1) for t in range(ns3)]
+    open(pre3 + ".bim", "w").writelines(bim3)
+    with open(pre3 + ".fam", "w") as f:
+        for i in range(n3):
+            f.write("f%d i%d 0 0 1 %s\n" % (i, i, " ".join(txt[i])))
+    gemma(tmp, "-bfile", "mvc3", "-gk", 1, "-o", "mvc3")
+    d3 = {}
+    mv_run(tmp, "mvc3", "b", os.path.join(tmp, "output", "mvc3.cXX.txt"), (1, 2, 3), d3, bim3, modes=(1, 3), extra=("-crt",))
+    assert np.array_equal(d3["b_snp"], fx["b_snp"])
+    changed_b = {}
+    for m in (1, 3):
+        for c in MV_COLS_EXTRA:
+            k = "b_m%d_%s" % (m, c)
+            if k in d3:
+                changed_b[k] = int((d3[k] != fx[k]).sum())
+    assert changed_b["b_m1_p_wald"] >= 1, changed_b
+    out.update({k.replace("b_", "b_crt_", 1): v for k, v in d3.items() if k.startswith("b_m") or k == "b_snp"})
     np.savez_compressed(os.path.join(OUT, "ref_mv_crt.npz"), **out)
-    print("ref_mv_crt.npz:", len(d["a_snp"]), "SNPs; rows that -crt changes:", changed)
+    print("ref_mv_crt.npz:", len(d["a_snp"]), "+", len(d3["b_snp"]), "SNPs; rows that -crt changes:", changed, changed_b)
 
 
 def main():

@@ -74,6 +74,17 @@ def test_mvlmm_crt_option_reference_outputs(driver, tmp_path, monkeypatch):
     fc.mvlmm_workflow(driver, tmp_path, modes=(4,), crt=True)
 
 
+def test_mvlmm_crt_three_traits_reference_outputs(driver, tmp_path, monkeypatch):
+    """-crt with three traits and missing phenotypes: 52 SNPs reach MphNR and get PCRT's corrected p_wald in the reference"""
+    import glob
+    import scipy
+    libs = glob.glob(os.path.join(os.path.dirname(os.path.dirname(scipy.__file__)), "scipy.libs", "libscipy_openblas*.so"))
+    if libs:
+        monkeypatch.setenv("GEMMA_DOUBLE_LAPACK", libs[0])
+    monkeypatch.setenv("GEMMA_HIP_IO_BLOCK", "700")
+    fc.mvlmm3_workflow(driver, tmp_path, modes=(1,), crt=True)
+
+
 def test_mvlmm_three_traits_missing_phenotypes(driver, tmp_path, monkeypatch):
     import glob
     import scipy

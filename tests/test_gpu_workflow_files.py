@@ -60,6 +60,11 @@ def test_mvlmm_crt_option_reference_outputs(driver, tmp_path):
     fc.mvlmm_workflow(driver, tmp_path, modes=(1, 2, 4), crt=True)
 
 
+def test_mvlmm_crt_three_traits_reference_outputs(driver, tmp_path):
+    """-crt with three traits and missing phenotypes: the 52 SNPs whose p_wald the reference corrects"""
+    fc.mvlmm3_workflow(driver, tmp_path, modes=(1,), crt=True)
+
+
 def test_mvlmm_bimbam_text_to_reference_outputs(driver, tmp_path):
     fc.mvlmm_workflow(driver, tmp_path, modes=(1, 3), bimbam=True)
 
