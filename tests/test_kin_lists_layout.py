@@ -108,3 +108,46 @@ def test_upper_triangle_tile_map_covers_what_the_fold_reads():
             for i in (0, min(n, 256 * (bx + 1)) - 1):
                 assert (i // 128, bx) in have
         assert len(tiles) < 0.52 * tiles_m * tiles_n + tiles_m + tiles_n
+
+
+def test_word_wise_plink_ingest_lut_and_ragged_tail(oracle):
+    """ingest_i8_kernel's word path (gemma_amd/csrc/i8gemm.hip.h): code c of a .bed word -> packed byte (0x00011002 >> 8 c) & 0xFF
+    = g | m << 4 with g = 2, 0 (missing), 1, 0 for c = 0, 1, 2, 3; calls past n inside the last word are ignored; the mean is
+    sum g / (n - missing).  Against the oracle's bed_decode (the reference's PLINK convention, src/gemma_io.cpp:1665-1682)."""
+    rng = np.random.default_rng(5)
+    for n in (777, 800, 1003, 16, 17):
+        p = 40
+        codes = rng.choice([0, 1, 2, 3], size=(p, n), p=[0.3, 0.06, 0.34, 0.3]).astype(np.uint8)
+        nb = (n + 3) // 4
+        pad = np.ones((p, nb * 4), dtype=np.uint8)      # padding bits set to "missing": must not be counted
+        pad[:, :n] = codes
+        raw = (pad[:, 0::4] | (pad[:, 1::4] << 2) | (pad[:, 2::4] << 4) | (pad[:, 3::4] << 6)).astype(np.uint8)
+        X = oracle.bed_decode(raw, n)                    # NaN where missing
+        ldk = (n + 127) // 128 * 128
+        A = np.zeros((p, ldk), dtype=np.uint8)
+        mean = np.zeros(p)
+        for s in range(p):
+            itot = imiss = 0
+            for k in range(ldk // 16):                   # one lane = one 32-bit word = 16 calls
+                i0 = 16 * k
+                if i0 >= n:
+                    continue
+                nvalid = min(16, n - i0)
+                w = 0
+                for b in range(4):
+                    if i0 // 4 + b < nb:
+                        w |= int(raw[s, i0 // 4 + b]) << (8 * b)
+                for q in range(nvalid):
+                    c = (w >> (2 * q)) & 3
+                    byte = (0x00011002 >> (8 * c)) & 0xFF
+                    A[s, i0 + q] = byte
+                    itot += byte & 3
+                    imiss += byte >> 4
+            mean[s] = itot / (n - imiss) if n > imiss else np.nan
+        g = (A & 3).astype(np.float64)[:, :n]
+        m = (A >> 4)[:, :n].astype(bool)
+        assert np.array_equal(m, np.isnan(X)) and np.array_equal(g[~m], X[~m]) and not g[m].any()
+        assert not A[:, n:].any()
+        with np.errstate(invalid="ignore"):
+            ref_mean = np.nansum(X, axis=1) / (~np.isnan(X)).sum(1)
+        assert np.array_equal(mean, ref_mean)
