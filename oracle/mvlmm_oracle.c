@@ -15,6 +15,9 @@
  * is not reproducible by anything but the same binary on the same machine; there the test bounds the likelihood instead.
  * tests/test_oracle_mvlmm.py keeps the independent legs: the univariate oracle at d = 1 and finite differences of the
  * log-likelihood for the gradient and Hessian.
+ * -crt (round 3): CalcCRT is restated in the reference's own dense form (mv_calc_crt) and PCRT with GSL's chi-square quantile
+ * iteration; pinned on the reference's crt_a, crt_b, crt_c handed back by its MphNR for 'R' and 'L' (ref_MphNR_crt, 1e-6), on its
+ * PCRT in the three modes (1e-8) and on its -crt output for both fixtures (tests/golden/ref_mv_crt.npz).
  *
  * Where the reference expands  P = H^-1 - H^-1 X Q^-1 X^T H^-1  into eight products of precomputed tables
  * (src/mvlmm.cpp:1863-2049), this file evaluates the same quantities from u_k = (P y)_k directly; the algebra is
