@@ -68,6 +68,14 @@ def parse():
                          "run measures a block and cites the full-n measurement)")
     ap.add_argument("--cpu-setup-budget", type=float, default=600.0,
                     help="seconds after which the host eigendecomposition is abandoned and reported as unfinished")
+    ap.add_argument("--setup-parity", type=int, default=1,
+                    help="1: verify the setup stages at the bench's own size (setup_parity in the JSON line): residual and orthogonality of "
+                         "the n x n eigendecomposition through the library's GEMM, its eigenvalues against rocSOLVER's, and -- with "
+                         "--cpu-setup -- the kinship of one .bed batch and the eigenvalues of the --cpu-setup-n block against the reference's "
+                         "PlinkKin / dsyevr outputs (0 = skip)")
+    ap.add_argument("--digits7-steps", type=int, default=2,
+                    help="extra untimed-region steps with GEMMA_HIP_I8_DIGITS=7 (U kept to 7 base-256 digits = 2^-55 of each column's maximum, "
+                         "below fp64's own rounding) beside the timed region's 6 digits at n >= 16384 (0 = skip)")
     ap.add_argument("--child", default="", help=argparse.SUPPRESS)
     ap.add_argument("--child-spec", default="", help=argparse.SUPPRESS)
     ap.add_argument("--seed", type=int, default=20000)
@@ -138,6 +146,19 @@ def run_child(args):
             K = O.ref_plink_kin(spec["bed"], n, spec["bed_snps"], 1)
             res["plink_kin"] = {"seconds": round(time.perf_counter() - t0, 2), "snps": spec["bed_snps"],
                                 "checksum": float(np.abs(K).sum())}
+            if spec.get("K_gpu") and os.path.exists(spec["K_gpu"]):
+                # the GPU's kinship of the SAME .bed batch (written by the parent): every entry against the reference's
+                Kg = np.load(spec["K_gpu"], mmap_mode="r")
+                kmax, dmax, rmax = float(np.abs(K).max()), 0.0, 0.0
+                for r0 in range(0, n, 1024):
+                    a, b = K[r0:r0 + 1024], np.asarray(Kg[r0:r0 + 1024])
+                    d = np.abs(a - b)
+                    dmax = max(dmax, float(d.max()))
+                    big = np.abs(a) > 1e-3 * kmax  # entrywise relative error where the entry is not a cancellation residue
+                    if big.any():
+                        rmax = max(rmax, float((d[big] / np.abs(a[big])).max()))
+                res["plink_kin"].update({"kin_max_abs_diff_over_max": dmax / kmax, "kin_max_rel_entries_above_1e-3_max": rmax,
+                                         "kin_entries_compared": int(n) * int(n), "kin_max_abs": kmax})
             json.dump(res, open(spec["out"], "w"))
             del K
         G = np.load(spec["G"])
@@ -145,6 +166,7 @@ def run_child(args):
         U, ev, tr = O.ref_eigen_decomp_zeroed(G)
         res["eigen"] = {"seconds": round(time.perf_counter() - t0, 2), "n": n, "n_block": int(G.shape[0]), "eval_sum": float(ev.sum()),
                         "eval_max": float(ev.max())}
+        np.save(spec["out"] + ".eval.npy", np.asarray(ev, dtype=np.float64))  # the parent compares the GPU's eigenvalues of the same block
         json.dump(res, open(spec["out"], "w"))
     else:
         raise SystemExit("unknown --child " + args.child)
@@ -317,6 +339,36 @@ def main():
         torch.cuda.synchronize()
         setup_info["eigen"] = eig
         setup_info["eigen_s"] = round(time.time() - t0, 3)
+        if args.setup_parity:
+            # (U, eval) of THIS run, at this n, through the path the library chose: backward error and orthogonality through the
+            # library's own fp64 GEMM, in units of n eps (LAPACK's dsyevr test ratios; bars of tests/test_gpu_eigh.py: 30), and
+            # the eigenvalues against an independent solver (rocSOLVER behind torch.linalg.eigvalsh) -- src/lapack.cpp:260-291
+            try:
+                t1 = time.time()
+                eps = 2.0 ** -52
+                knorm = float(ev.abs().max())
+                R = torch.empty_like(K)
+                api.fast_dgemm("N", "N", 1.0, K, U, 0.0, R)
+                R.sub_(U * ev[None, :])
+                sp = {"n": n, "eigh_resid": round(float(torch.linalg.matrix_norm(R)) / (n * eps * knorm), 4)}
+                api.fast_dgemm("T", "N", 1.0, U, U, 0.0, R)
+                R.diagonal().sub_(1.0)
+                sp["eigh_orth"] = round(float(torch.linalg.matrix_norm(R)) / (n * eps), 4)
+                del R
+                sp["eigh_what"] = ("||K U - U diag(eval)||_F / (n eps ||K||_2) and ||U^T U - I||_F / (n eps) of this run's n x n "
+                                   "eigendecomposition (%s), products on the library's fp64 MFMA GEMM" % eig)
+                try:
+                    wr = torch.linalg.eigvalsh(K)
+                    wr = torch.where(wr < 1e-10, torch.zeros_like(wr), wr)
+                    sp["eval_vs_rocsolver_max_rel"] = float((torch.sort(ev)[0] - wr).abs().max()) / knorm
+                    del wr
+                except Exception as e:  # an out-of-memory workspace at large n must not take the bench down
+                    sp["eval_vs_rocsolver_error"] = repr(e)[:120]
+                torch.cuda.synchronize()
+                sp["seconds"] = round(time.time() - t1, 2)
+                setup_info["setup_parity"] = sp
+            except Exception as e:
+                setup_info["setup_parity"] = {"error": repr(e)[:300]}
         del K
         # UtW = U^T 1, Uty = U^T y through the library's GEMM (CalcUtX, src/mathfunc.cpp:504-506)
         ones = torch.ones((n, 1), dtype=torch.float64, device=dev)
@@ -528,12 +580,15 @@ def main():
             roof = {"kernel": "dgemm_mfma_glds_kernel (UtX = X*U)", "bound": "mfma", "achieved": round(achieved, 2),
                     "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / FP64_MFMA_PEAK_TFLOPS, 4),
                     "traffic": None, "launches": gemm_n, "avg_launch_ms": round(gemm_avg_s * 1e3, 3)}
+        dgd_ = ctypes_digits(L, n) if i8_path else 0
         line = {
             "metric": "SNPs/s (-lmm 1 Wald) at n=20k on 1/2/4/8 MI355X; U^T x HBM GB/s vs roofline",
             "value": round(value, 1), "unit": "SNPs/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f64 (U^T x as exact int8-digit MFMA products, int32 accumulate)" if i8_path else "f64",
+            "dtype": ("f64 (U^T x as int8-digit MFMA products with exact int32 accumulation; U rounded to %d base-256 digits = 2^-%d of each "
+                      "column's maximum%s)" % (dgd_, 8 * dgd_ - 1, ", below fp64's own entry rounding" if dgd_ >= 7 else
+                                               " -- fp64 keeps 2^-53 per entry; digits7_leg and fp64_gemm_path carry the unrounded operand")) if i8_path else "f64",
             "data": "synthetic",
             "config": {"workload": "%ssynthetic n=%d, -lmm %d, %d SNPs per step per GPU (PLINK 2-bit, "
                                    "%g%% missing, Balding-Nichols Fst 0.05), c=1" % (
@@ -601,7 +656,49 @@ def main():
                                                 null=(float(null[0]), float(null[1])))
         if cpu_setup is not None and "cpu_baseline" in line:
             line["cpu_baseline"]["setup"] = setup_cpu
+        if args.setup_parity:
+            # one object for the at-size checks of the setup stages: (U, eval) of this run (residual, orthogonality, eigenvalues vs
+            # rocSOLVER -- measured in the setup above) and K / eval against the REFERENCE's outputs (the ref_setup child)
+            sp = dict(setup_info.pop("setup_parity", {}) or {})
+            if cpu_setup is not None and isinstance(setup_cpu, dict):
+                sp.update(setup_cpu.pop("setup_parity", {}) or {})
+            line["setup_parity"] = sp
         lmm.finish()
+        dg_timed = ctypes_digits(L, n) if i8_path else None
+        if world == 1 and i8_path and args.digits7_steps > 0 and dg_timed != 7:
+            # the bit-faithful mode beside the timed one: U kept to 7 base-256 digits (2^-55 of each column's maximum: below the
+            # 2^-53 of an fp64 entry in the column's top binade) -- the same blocks, a fresh setup (the digits are cut once per setup)
+            os.environ["GEMMA_HIP_I8_DIGITS"] = "7"
+            try:
+                lmm7 = api.LMM(a_mode=args.a_mode, l_mle_null=float(null[0]), logl_mle_H0=float(null[1]))
+                lmm7.setup(U, ev, UtW, Uty, plink=True)
+                out7 = torch.empty((B, 8), dtype=torch.float64, device=dev)
+                lmm7.batch(blocks[0], L.GENO_PLINK_2BIT, out=out7)
+                torch.cuda.synchronize()
+                api.profile_read(L.STAGE_UTX_GEMM, reset=True)
+                t1 = time.perf_counter()
+                for i in range(args.digits7_steps):
+                    lmm7.batch(blocks[(args.warmup + args.steps - args.digits7_steps + i) % len(blocks)], L.GENO_PLINK_2BIT, out=out7)
+                torch.cuda.synchronize()
+                el7 = time.perf_counter() - t1
+                g7_ms, _ = api.profile_read(L.STAGE_UTX_GEMM)
+                r7 = out7.cpu().numpy()  # the last block of the leg is the last timed block: res holds its 6-digit results
+                cols_used = {1: [0, 1, 4, 7], 2: [5, 7], 3: [0, 1, 6], 4: [0, 1, 4, 5, 6, 7], 9: [0, 1, 5, 6, 7]}[args.a_mode]
+                okm = np.isfinite(r7) & np.isfinite(res) & (r7 != 0)
+                line["digits7_leg"] = {
+                    "digits": 7, "steps": args.digits7_steps, "ms_per_step": round(el7 / args.digits7_steps * 1e3, 3),
+                    "value": round(B * args.digits7_steps / el7, 1), "unit": "SNPs/s",
+                    "utx_gemm_ms_per_step": round(g7_ms / args.digits7_steps, 3),
+                    "what": "GEMMA_HIP_I8_DIGITS=7: U cut to 7 balanced base-256 digits (error <= 2^-55 of each column's maximum, i.e. U "
+                            "reproduced to its last bit in the column's top binade); 14 int8 products instead of the timed region's 12",
+                    "timed_region_vs_7_digits_max_rel_diff": max(float(np.max(np.abs(res[:, c][okm[:, c]] - r7[:, c][okm[:, c]]) / np.abs(r7[:, c][okm[:, c]])))
+                                                                 for c in cols_used),
+                    "lambda_max_rel_diff": float(np.nanmax(np.abs(res[:, 2] - r7[:, 2]) / np.maximum(np.abs(r7[:, 2]), 1e-300))) if args.a_mode in (1, 4) else None}
+                lmm7.finish()
+                del out7
+            except Exception as e:
+                line["digits7_leg"] = {"error": repr(e)[:300]}
+            os.environ.pop("GEMMA_HIP_I8_DIGITS", None)
         if world == 1 and i8_path and args.lowh2_leg > 0 and args.a_mode in (1, 4):
             # The same trait on a kinship measured in other units: eigenvalues times S moves every lambda-hat to lambda-hat / S
             # (only lambda * delta enters the likelihood), so with S = lambda_null / lambda0 the brackets of the whole block sit
@@ -675,12 +772,44 @@ def start_cpu_setup(args, np, torch, Kc, n, B, dev):
         with open(bed, "wb") as f:
             f.write(bytes([0x6C, 0x1B, 0x01]))
             f.write(blk.cpu().numpy().tobytes())
-        del blk
         spec = {"n": n, "G": os.path.join(d, "G.npy"), "bed": bed, "bed_snps": B, "out": os.path.join(d, "setup.json")}
+        gpu = {}
+        if args.setup_parity:
+            # what the child compares its outputs with: this library's kinship of the SAME .bed batch (every entry) ...
+            from gemma_amd import api
+            from gemma_amd import _lib as L
+            Kb = torch.empty((n, n), dtype=torch.float64, device=dev)
+            api.kin_begin(n, 1)
+            api.kin_add(blk, L.GENO_PLINK_2BIT)
+            api.kin_end(Kb)
+            torch.cuda.synchronize()
+            try:
+                np.save(os.path.join(d, "K_gpu.npy"), Kb.cpu().numpy())
+                spec["K_gpu"] = os.path.join(d, "K_gpu.npy")
+            except OSError as e:  # a small /dev/shm: the comparison is dropped, the timing leg stays
+                gpu["kin_error"] = repr(e)[:200]
+            del Kb
+            # ... and this library's eigenvalues of the SAME leading block, through both reductions
+            Gb = Kc[:ne, :ne].contiguous()
+            Ub = torch.empty_like(Gb)
+            prev = os.environ.get("GEMMA_HIP_EIGH_STAGES")
+            for stages in ("1", "2"):
+                if stages == "2" and (ne < 384 or ne % 2):
+                    continue
+                os.environ["GEMMA_HIP_EIGH_STAGES"] = stages
+                evb = torch.empty(ne, dtype=torch.float64, device=dev)
+                api.EigenDecomp_Zeroed(Gb.clone(), Ub, evb)
+                gpu["eval_stages" + stages] = evb.cpu().numpy()
+            if prev is None:
+                os.environ.pop("GEMMA_HIP_EIGH_STAGES", None)
+            else:
+                os.environ["GEMMA_HIP_EIGH_STAGES"] = prev
+            del Gb, Ub
+        del blk
         json.dump(spec, open(os.path.join(d, "spec.json"), "w"))
         env = dict(os.environ)
         env.pop("RANK", None); env.pop("WORLD_SIZE", None)
-        return {"dir": d, "out": spec["out"], "spec": os.path.join(d, "spec.json"), "env": env, "n_eig": ne}
+        return {"dir": d, "out": spec["out"], "spec": os.path.join(d, "spec.json"), "env": env, "n_eig": ne, "gpu": gpu}
     except Exception as e:  # a reported baseline must never take the bench down
         return {"error": repr(e)[:300]}
 
@@ -707,14 +836,36 @@ def finish_cpu_setup(args, cs, t_bench0, setup_info):
         pass
     out = {"kind": "reference", "where": "child process after the GPU legs, host cores of this box",
            "threads": res.get("threads"), "never_in_value": True}
+    gpu = cs.get("gpu", {})
+    parity = {}
     if "plink_kin" in res:
         pk = res["plink_kin"]
+        if "kin_max_abs_diff_over_max" in pk:
+            parity["kin_max_rel"] = pk["kin_max_abs_diff_over_max"]
+            parity["kin_max_rel_entrywise"] = pk["kin_max_rel_entries_above_1e-3_max"]
+            parity["kin_what"] = ("this library's kinship (kin_begin / kin_add / kin_end, -gk 1) of one %d-SNP .bed batch at n = %d against the "
+                                  "reference's PlinkKin (src/gemma_io.cpp:1599-1738) on the same file, all %d entries: max |dK| / max |K|; "
+                                  "entrywise relative error over the entries above 1e-3 max |K|" % (pk["snps"], res.get("eigen", {}).get("n", 0) or args.n, pk["kin_entries_compared"]))
+        elif gpu.get("kin_error"):
+            parity["kin_error"] = gpu["kin_error"]
         out["plink_kin"] = {"seconds_per_batch": pk["seconds"], "snps": pk["snps"],
                             "what": "the reference's PlinkKin (src/gemma_io.cpp:1599-1738) on one .bed batch: per-SNP decode / impute / "
                                     "centre + cblas_dgemm(Xlarge Xlarge^T)",
                             "gpu_seconds_per_batch": round(setup_info.get("kinship_s", 0.0) / max(1, (args.kin_snps + pk["snps"] - 1) // pk["snps"]), 4)}
     if "eigen" in res:
         ne = cs["n_eig"]
+        try:
+            import numpy as np
+            ev_ref = np.sort(np.load(cs["out"] + ".eval.npy"))
+            knorm = float(np.abs(ev_ref).max())
+            for k in ("eval_stages1", "eval_stages2"):
+                if k in gpu:
+                    parity["eval_max_rel" + ("" if k.endswith("1") else "_two_stage")] = float(np.abs(np.sort(gpu[k]) - ev_ref).max() / knorm)
+            parity["eval_what"] = ("eigenvalues of the leading %d x %d block of this run's centred kinship: gemma_hip_eigh (one-stage; '_two_stage': "
+                                   "GEMMA_HIP_EIGH_STAGES=2) against the reference's EigenDecomp_Zeroed (src/lapack.cpp:260-291, dsyevr): "
+                                   "max |d eval| / ||K||_2" % (ne, ne))
+        except Exception as e:
+            parity["eval_error"] = repr(e)[:200]
         out["eigen"] = {"seconds": res["eigen"]["seconds"], "n": ne,
                         "what": "the reference's EigenDecomp_Zeroed (src/lapack.cpp:260-291 -> dsyevr_) on the leading %d x %d block of this "
                                 "run's centred kinship" % (ne, ne),
@@ -733,6 +884,7 @@ def finish_cpu_setup(args, cs, t_bench0, setup_info):
     else:
         out["error"] = (pr.stderr.read().decode(errors="replace")[-300:] if pr.stderr else "no result")
     shutil.rmtree(cs["dir"], ignore_errors=True)
+    out["setup_parity"] = parity
     return out
 
 
@@ -817,6 +969,20 @@ def cpu_baseline(args, np, torch, block, U, ev, UtW, Uty, gpu_res, n, B, null=(0
         for k in lams:
             e = rel_err(r, k)
             out[k] = {"frac_within_1e-6": round(float(np.mean(e <= 1e-6)), 5), "max_rel_err": float(e.max()), "n": int(e.size)}
+            # second tier (tests/test_gpu_parity.py _classify_lambda): every value outside 1e-6 must be a flipped Brent / Newton trip
+            # count -- the reference's own stopping rule holds at the GPU's value, or the likelihood there equals the reference's
+            g = gpu_res[:len(r[k]), cols[k]]
+            okm = np.isfinite(r[k]) & np.isfinite(g)
+            with np.errstate(divide="ignore", invalid="ignore"):
+                outl = np.flatnonzero(okm & (np.abs(g - r[k]) > 1e-6 * np.abs(r[k])))
+            if len(outl):
+                fn = "R" if k == "lambda_remle" else "L"
+                sg, lg = O.newton_step_rel(fn, evh, UtWh, Utyh, UtX[outl], g[outl])
+                _, lr = O.newton_step_rel(fn, evh, UtWh, Utyh, UtX[outl], r[k][outl])
+                flipped = (sg < 1e-5) | (np.abs(lg - lr) <= 2e-12 * np.abs(lr))
+                out[k].update({"outside_1e-6": int(len(outl)), "flipped_trip_counts": int(flipped.sum()), "wrong": int((~flipped).sum())})
+            else:
+                out[k].update({"outside_1e-6": 0, "flipped_trip_counts": 0, "wrong": 0})
         g_nan = ~np.isfinite(gpu_res[:len(r["logl_H1"]), 7])
         out["failed_search_flips"] = int((g_nan != ~np.isfinite(r["logl_H1"])).sum()) if args.a_mode != 3 else 0
         return out

@@ -6,8 +6,17 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libgemma_hip.so")
-SOURCES = ["gemma_hip.hip", "mvlmm_kernels.hip", "mvlmm_kernels_wide.hip"]  # one object each, compiled concurrently
-HEADERS = ["dgemm_mfma.hip.h", "lmm_grid.hip.h", "i8gemm.hip.h", "i8gemm_sparse.hip.h", "i8gemm_sparse2.hip.h", "lmm_assoc.hip.h", "lmm_search.hip.h", "comm.hip.h", "comm_shm.hpp", "kin_i8.hip.h", "ingest.hip.h", "eigh.hip.h", "eigh2.hip.h", "qc.hip.h", "lm_assoc.hip.h", "mvlmm.hip.h", "mvlmm_kernels.hip.h"]
+# one object per source, compiled concurrently; the headers each one depends on (staleness by mtime)
+UNITS = {
+    "gemma_hip.hip": ["dgemm_mfma.hip.h", "lmm_grid.hip.h", "i8gemm.hip.h", "i8gemm_sparse.hip.h", "i8gemm_sparse2.hip.h", "lmm_assoc.hip.h",
+                      "lmm_search.hip.h", "comm.hip.h", "comm_shm.hpp", "kin_i8.hip.h", "ingest.hip.h", "qc.hip.h", "lm_assoc.hip.h", "mvlmm.hip.h",
+                      "mvlmm_kernels.hip.h", "eigh_tu.h"],
+    "eigh_tu.hip": ["dgemm_mfma.hip.h", "eigh.hip.h", "eigh2.hip.h", "eigh_tu.h"],  # the eigensolver: its own object file
+    "mvlmm_kernels.hip": ["mvlmm.hip.h", "mvlmm_kernels.hip.h"],
+    "mvlmm_kernels_wide.hip": ["mvlmm.hip.h", "mvlmm_kernels.hip.h"],
+}
+SOURCES = list(UNITS)
+HEADERS = sorted({h for hs in UNITS.values() for h in hs})
 
 
 def hipcc():
@@ -37,7 +46,7 @@ def build(force=False, verbose=False):
     for src in SOURCES:
         obj = os.path.join(objdir, src.replace(".hip", ".o"))
         objs.append(obj)
-        hdrs = HEADERS if src == "gemma_hip.hip" else ["mvlmm.hip.h", "mvlmm_kernels.hip.h"]
+        hdrs = UNITS[src]
         deps = [os.path.join(CSRC, f) for f in [src] + hdrs] + [os.path.join(HERE, "..", "include", "gemma_hip.h")]
         if not force and os.path.exists(obj) and all(os.path.getmtime(d) <= os.path.getmtime(obj) for d in deps):
             continue

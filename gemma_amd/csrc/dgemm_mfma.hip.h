@@ -615,7 +615,7 @@ __global__ __launch_bounds__(256, 2) void dgemm_mfma_glds_kernel(GemmArgs g) {
 
 // mirror the strict upper triangle into the lower one and scale everything (kinship epilogue:
 // K *= 1/ns_test, GEMMA src/gemma_io.cpp:1570, and the symmetric fill of :1724-1729)
-__global__ void symm_fill_scale_kernel(double *K, long n, long ld, double scale) {
+static __global__ void symm_fill_scale_kernel(double *K, long n, long ld, double scale) {
   __shared__ double tile[32][33];
   // blocks cover the upper-triangular 32x32 tile pairs (bx >= by)
   const int bx = blockIdx.x, by = blockIdx.y;

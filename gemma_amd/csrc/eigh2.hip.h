@@ -32,6 +32,8 @@
 
 namespace gemma_hip {
 
+typedef double e2_v4 __attribute__((ext_vector_type(4)));
+typedef double e2_v2 __attribute__((ext_vector_type(2)));
 constexpr int E2_B = EIG_NB;             // half-bandwidth after stage 1 (= the back-transform block of eigh.hip.h)
 constexpr int E2_LDB = 2 * E2_B;         // doubles per column of the band storage: Bd[j * E2_LDB + (i - j)] = B(i, j), i >= j
 constexpr int E2_NB = 32;                // sweeps per block reflector of the stage-2 back-transformation
@@ -62,6 +64,29 @@ __device__ __forceinline__ void e2_larfg(double alpha, double xnorm2, double &ta
   tau = (b - alpha) / b;
   scale = 1.0 / (alpha - b);
   beta = b;
+}
+
+// Bounded by WALL CLOCK (the constant 100 MHz counter), not by a poll count: several processes can time-slice one device (ranks
+// that share it in the tests, bench.py's children), and a predecessor that is merely descheduled must not turn into a failure.
+// BC_WAIT_TICKS: the chase, whose co-residency is assumed, not guaranteed -- a real dead-lock is possible there and the per-step
+// fall-back takes over; Q2_WAIT_TICKS: the stage-2 back-transformation, where the awaited task was claimed earlier and is running
+// by construction, so the bound only has to outlast any descheduling.
+constexpr long long BC_WAIT_TICKS = 400000000LL;   // 4 s
+constexpr long long Q2_WAIT_TICKS = 6000000000LL;  // 60 s
+__device__ __forceinline__ bool bc_wait(int *p, int target, int *err, long long max_ticks = BC_WAIT_TICKS) {
+  long long t0 = 0;
+  for (long it = 0;; ++it) {
+    if (__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) return true;
+    if ((it & 63) == 63) {
+      if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return false;
+      const long long now = (long long)wall_clock64();
+      if (t0 == 0) t0 = now;
+      else if (now - t0 > max_ticks) break;
+    }
+    __builtin_amdgcn_s_sleep(1);
+  }
+  __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return false;
 }
 
 // ---------------------------------------------------------------- stage 1: panel QR
@@ -193,6 +218,230 @@ __global__ __launch_bounds__(256) void sb_panel_kernel(SbPanelArgs g) {
   if (more) {
     __syncthreads();
     if (t < E2_B && t >= c) g.part[(size_t)(c & 1) * g.nwg * E2_B + (size_t)blockIdx.x * E2_B + t] = sred[t];
+  }
+}
+
+// ---------------------------------------------------------------- stage 1: panel QR, ONE launch per panel (round 4)
+// The launches above are a chain of 129 dependent kernels per panel (n in total: 0.29 s of the 0.80 s of stage 1 at n = 20 000,
+// 14.5 us each: launch + the panel re-read from L2 / MALL + its write-back at every kernel boundary).  Here the panel stays in
+// REGISTERS for all 129 steps: a workgroup owns 128 NCH columns, thread (q, h) row q and the columns 32 (4 k + h) .. + 31 of
+// chunk k -- 32 NCH doubles.  A step applies reflector c - 1 to the thread's row (rank-1 update with v broadcast from LDS),
+// publishes row c as x_c, and forms the thread's share of x_c . y_q: 32 NCH serial fused multiply-adds, no shuffles; the four
+// column parts meet in LDS.  Between steps only the (128 - c) partial sums per workgroup and the head column's entries go
+// through memory, in self-validating slots (see SbPersistArgs; wall-clock-bounded polls, error flag -> the host repeats the
+// panel with the per-column launches: A is written only at the very end).  The
+// arithmetic is the per-column kernel's except for the grouping of the partial sums (128 NCH columns per workgroup, summed in
+// workgroup order).  Needs every workgroup resident: nwg <= number of CUs (NCH = 2 from 128 x CUs columns up: n <= 65 536).
+// data exchanged between workgroups of one launch (partial sums, head entries): relaxed atomics at agent scope -- on gfx950 a
+// store with sc1 (written through to the memory side) and a load with sc1 (served from there, not from the XCD's L2)
+__device__ __forceinline__ double sp_ld(const double *p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void sp_st(double *p, double v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+struct SbPersistArgs {
+  double *A;
+  long n, j0;
+  int kk, nwg;
+  double *VT, *tau, *betas;
+  double *part; // [step c][workgroup][row q]: partial sums of step c, filled with SP_EMPTY before the launch
+  double *heads; // [step c][row q]: the head column's entries of step c, likewise
+  int *err;
+};
+// What one workgroup hands to the others is SELF-VALIDATING: the buffers hold one slot per (step, workgroup, row), the host fills
+// them with a NaN pattern no computation produces (all ones) before the launch, and a consumer polls the slots it needs until
+// none of them is empty.  No counter, no grid barrier, no wait for a store's acknowledgement: the latency of a step is one store
+// on its way out plus one load round trip (the barrier version: store + acknowledgement, arrival, poll, loads -- 10.4 us per
+// column, this one: see DESIGN 3.5).  The sums are formed in workgroup order once every slot is there: deterministic.
+constexpr long long SP_EMPTY = -1LL;
+__device__ __forceinline__ bool sp_have(double x) { return __double_as_longlong(x) != SP_EMPTY; }
+constexpr int SP_NH = 4;                 // column parts per row: thread (q, h), 128 SP_NH threads per workgroup
+constexpr int SP_CW = 128 / SP_NH;       // columns of one part of one 128-column chunk
+constexpr int SP_THREADS = E2_B * SP_NH;
+template <int NCH>
+__global__ __launch_bounds__(SP_THREADS) void sb_panel_persist_kernel(SbPersistArgs g) {
+  constexpr int W = 128 * NCH; // columns of this workgroup
+  constexpr int NY = SP_CW * NCH;
+  __shared__ __attribute__((aligned(16))) double xs[W], vs[W];
+  __shared__ double hsum[SP_NH][E2_B], sred[E2_B];
+  __shared__ int s_bad;
+  const int t = threadIdx.x, q = t & (E2_B - 1), h = t >> 7;
+  const long n = g.n, j0 = g.j0, r0 = j0 + E2_B;
+  const long cb = r0 + (long)blockIdx.x * W; // first column of the workgroup (even; n is even: 16-byte aligned rows)
+  const bool full = cb + W <= n;             // only the last workgroup has columns past n (they hold zeros throughout)
+  if (t == 0) s_bad = 0;
+  double y[NY];
+  {
+    const double *row = g.A + (j0 + q) * n + cb;
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+      const int l0 = SP_CW * (SP_NH * k + h);
+      if (full) {
+#pragma unroll
+        for (int j = 0; j < SP_CW; j += 2) {
+          const e2_v2 v2 = *reinterpret_cast<const e2_v2 *>(row + l0 + j);
+          y[SP_CW * k + j] = v2[0];
+          y[SP_CW * k + j + 1] = v2[1];
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < SP_CW; ++j) y[SP_CW * k + j] = (cb + l0 + j < n) ? row[l0 + j] : 0.0;
+      }
+    }
+  }
+  const int nwg = g.nwg;
+  const int wq = (nwg + SP_NH - 1) / SP_NH, wlo = min(h * wq, nwg), whi = min(wlo + wq, nwg);
+  const int hl0 = (blockIdx.x == 0) ? 0 : -(1 << 20); // local index of head column r0 + c is c + hl0: negative outside workgroup 0
+  __syncthreads();
+  for (int c = 0; c <= g.kk; ++c) {
+    const int prev = c - 1;
+    const bool more = c < g.kk;
+    if (c > 0) {
+      // the sums of step c - 1 over all workgroups, in workgroup order (SP_NH ranges, then their sum in order): poll until every
+      // slot this thread needs is there (wall-clock bound, error flag: the host then repeats the panel with the per-column launches)
+      const double *pp = g.part + (size_t)prev * nwg * E2_B + q;
+      const double *hp = g.heads + (size_t)prev * E2_B;
+      double sacc = 0.0, alpha = 0.0, myhead = 0.0;
+      long long t0 = 0;
+      for (long it = 0;; ++it) {
+        bool all = true;
+        alpha = sp_ld(hp + prev);
+        all = all && sp_have(alpha);
+        if (q > prev) {
+          myhead = sp_ld(hp + q);
+          all = all && sp_have(myhead);
+        }
+        if (q >= prev) {
+          double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+          int w = wlo;
+          for (; w + 3 < whi; w += 4) {
+            const double x0 = sp_ld(pp + (size_t)w * E2_B), x1 = sp_ld(pp + (size_t)(w + 1) * E2_B);
+            const double x2 = sp_ld(pp + (size_t)(w + 2) * E2_B), x3 = sp_ld(pp + (size_t)(w + 3) * E2_B);
+            all = all && sp_have(x0) && sp_have(x1) && sp_have(x2) && sp_have(x3);
+            a0 += x0; a1 += x1; a2 += x2; a3 += x3;
+          }
+          for (; w < whi; ++w) {
+            const double x0 = sp_ld(pp + (size_t)w * E2_B);
+            all = all && sp_have(x0);
+            a0 += x0;
+          }
+          sacc = (a0 + a1) + (a2 + a3);
+        }
+        if (all) break;
+        if ((it & 15) == 15) {
+          const long long now = (long long)wall_clock64();
+          if (t0 == 0) t0 = now;
+          if (now - t0 > BC_WAIT_TICKS || __hip_atomic_load(g.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+            __hip_atomic_store(g.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_bad = 1;
+            break;
+          }
+        }
+        __builtin_amdgcn_s_sleep(1);
+      }
+      hsum[h][q] = sacc;
+      __syncthreads();
+      if (s_bad) return; // A untouched
+      if (h == 0) {
+        double sm = 0.0;
+#pragma unroll
+        for (int p = 0; p < SP_NH; ++p) sm += hsum[p][q];
+        sred[q] = sm;
+      }
+      __syncthreads();
+      double tau, beta, scale;
+      e2_larfg(alpha, sred[prev], tau, beta, scale);
+      if (t == 0 && blockIdx.x == 0) {
+        g.tau[j0 + prev] = tau;
+        g.betas[j0 + prev] = beta;
+      }
+      const double f = q > prev ? tau * (myhead + scale * sred[q]) : 0.0;
+      // v of the workgroup's columns from x_{c-1} (xs: published in the previous step, zero at and left of the head and past
+      // n), by the threads of ONE row: into LDS for the update and into row j0 + prev of VT
+      if (q == (c & (E2_B - 1))) {
+        const int hl = prev + hl0; // local index of the head column, negative outside workgroup 0
+        double *vrow = g.VT + (j0 + prev) * n + cb;
+#pragma unroll
+        for (int k = 0; k < NCH; ++k)
+#pragma unroll
+          for (int j = 0; j < SP_CW; ++j) {
+            const int lc = SP_CW * (SP_NH * k + h) + j;
+            const double v = lc == hl ? 1.0 : scale * xs[lc];
+            vs[lc] = v;
+            if (lc >= hl && (full || cb + lc < n)) vrow[lc] = v;
+          }
+      }
+      __syncthreads();
+      if (q > prev) {
+#pragma unroll
+        for (int k = 0; k < NCH; ++k)
+#pragma unroll
+          for (int j = 0; j < SP_CW; j += 2) {
+            const e2_v2 v2 = *reinterpret_cast<const e2_v2 *>(vs + SP_CW * (SP_NH * k + h) + j);
+            y[SP_CW * k + j] -= f * v2[0];
+            y[SP_CW * k + j + 1] -= f * v2[1];
+          }
+      }
+    }
+    if (!more) break;
+    if (q == c) {
+      const int hl = c + hl0;
+#pragma unroll
+      for (int k = 0; k < NCH; ++k)
+#pragma unroll
+        for (int j = 0; j < SP_CW; ++j) {
+          const int lc = SP_CW * (SP_NH * k + h) + j;
+          xs[lc] = (lc > hl) ? y[SP_CW * k + j] : 0.0; // columns past n hold zeros already
+        }
+    }
+    if (blockIdx.x == 0 && q >= c && h == (c / SP_CW)) {
+      // the head column r0 + c is local column c of workgroup 0 (chunk 0): the entries the next reflector needs from every row
+      double hv = 0.0;
+#pragma unroll
+      for (int j = 0; j < SP_CW; ++j) hv = (j == (c & (SP_CW - 1))) ? y[j] : hv;
+      sp_st(g.heads + (size_t)c * E2_B + q, hv);
+    }
+    __syncthreads();
+    double pr = 0.0;
+    if (q >= c) {
+      double p0 = 0.0, p1 = 0.0;
+#pragma unroll
+      for (int k = 0; k < NCH; ++k)
+#pragma unroll
+        for (int j = 0; j < SP_CW; j += 2) {
+          const e2_v2 x2 = *reinterpret_cast<const e2_v2 *>(xs + SP_CW * (SP_NH * k + h) + j);
+          p0 += x2[0] * y[SP_CW * k + j];
+          p1 += x2[1] * y[SP_CW * k + j + 1];
+        }
+      pr = p0 + p1;
+    }
+    hsum[h][q] = pr;
+    __syncthreads();
+    if (h == 0 && q >= c) {
+      double sm = 0.0;
+#pragma unroll
+      for (int p = 0; p < SP_NH; ++p) sm += hsum[p][q];
+      sp_st(g.part + ((size_t)c * nwg + blockIdx.x) * E2_B + q, sm);
+    }
+  }
+  {
+    double *row = g.A + (j0 + q) * n + cb;
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+      const int l0 = SP_CW * (SP_NH * k + h);
+      if (full) {
+#pragma unroll
+        for (int j = 0; j < SP_CW; j += 2) {
+          e2_v2 v2 = {y[SP_CW * k + j], y[SP_CW * k + j + 1]};
+          *reinterpret_cast<e2_v2 *>(row + l0 + j) = v2;
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < SP_CW; ++j)
+          if (cb + l0 + j < n) row[l0 + j] = y[SP_CW * k + j];
+      }
+    }
   }
 }
 
@@ -424,9 +673,21 @@ __device__ __forceinline__ double bc_bsum(double v, double *red) {
 // the block in LDS: one store pass and one read pass per block.  The chase is a chain of 2 n dependent tasks, so the task's
 // latency is the stage's time (BC_NH = 4, four column quarters on 512 threads, halves every per-thread loop and was NOT faster:
 // see BC_NH).
-template <bool DBG>
+template <bool SC1> __device__ __forceinline__ double bc_ld(const double *p) {
+  if constexpr (SC1) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else return *p;
+}
+template <bool SC1> __device__ __forceinline__ void bc_st(double *p, double v) {
+  if constexpr (SC1) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else *p = v;
+}
+// SC1 (round 4): everything a task exchanges with its neighbours -- the two band blocks, v and tau -- moves with agent-scope
+// relaxed atomics (sp_ld / sp_st: loads that bypass the XCD's L2, stores written through), so that the persistent kernel needs
+// no acquire / release FENCE around a task: at agent scope those are an invalidate and a write-back of the XCD's whole L2, and
+// the stamps of round 3 showed 6.4 us of a 19 us task in front of the release alone.
+template <bool DBG, bool SC1, bool EARLY = false>
 __device__ __forceinline__ void bc_task(double *__restrict__ B, long n, long j, long k, double *__restrict__ V2g,
-                                        double *__restrict__ tau2g, double *e2sm, long long *dbg = nullptr) {
+                                        double *__restrict__ tau2g, double *e2sm, long long *dbg = nullptr, int *vflag = nullptr) {
   constexpr int CW = E2_B / BC_NH;
   BC_STAMP(0);
   double *E = e2sm; // E[c][a] (column stride 129): the block whose column sums are being formed
@@ -441,17 +702,17 @@ __device__ __forceinline__ void bc_task(double *__restrict__ B, long n, long j, 
   if (k > 0) {
     // v_p and tau_p first: the counter retires in order, so whoever waits for E has them too and nothing later in the E phase
     // has to wait behind the diagonal block's loads
-    vph = V2g[((size_t)(k - 1) * n + j) * E2_B + cb + lc]; // v_p of this thread group's columns, entry c in lane c (c < CW)
-    taup = tau2g[(k - 1) * n + j];
+    vph = bc_ld<SC1>(V2g + ((size_t)(k - 1) * n + j) * E2_B + cb + lc); // v_p of this thread group's columns, entry c in lane c (c < CW)
+    taup = bc_ld<SC1>(tau2g + (k - 1) * n + j);
     const double *src = B + (r - E2_B + cb) * E2_LDB + E2_B + a - cb;
 #pragma unroll
-    for (int c = 0; c < CW; ++c) er[c] = src[c * (E2_LDB - 1)]; // rows past n: slots of the band storage that stay zero
+    for (int c = 0; c < CW; ++c) er[c] = bc_ld<SC1>(src + c * (E2_LDB - 1)); // rows past n: slots of the band storage that stay zero
   } else {
     // first task of a sweep: the "block" is column j alone (there is no previous reflector: v_p = 0, tau_p = 0); the code below
     // is the same, which keeps every global load of the task in front of the first barrier
 #pragma unroll
     for (int c = 0; c < CW; ++c) er[c] = 0.0;
-    if (h == 0) er[0] = B[j * E2_LDB + 1 + a]; // rows past n: zero slots
+    if (h == 0) er[0] = bc_ld<SC1>(B + j * E2_LDB + 1 + a); // rows past n: zero slots
   }
 #pragma unroll
   for (int c = 0; c < CW; ++c) E[(cb + c) * BC_LD + a] = er[c];
@@ -462,7 +723,7 @@ __device__ __forceinline__ void bc_task(double *__restrict__ B, long n, long j, 
     // column and the value is masked where it is used
     const double *srd = B + (r + cb) * E2_LDB + a - cb;
 #pragma unroll
-    for (int c = 0; c < CW; ++c) dr[c] = srd[c * (E2_LDB - 1)];
+    for (int c = 0; c < CW; ++c) dr[c] = bc_ld<SC1>(srd + c * (E2_LDB - 1));
   }
   {
     double ys = 0.0;
@@ -486,11 +747,15 @@ __device__ __forceinline__ void bc_task(double *__restrict__ B, long n, long j, 
   const double va = (a == 0) ? 1.0 : ((a < L) ? scale * xa : 0.0);
   if (h == 0) {
     v[a] = va;
-    V2g[((size_t)k * n + j) * E2_B + a] = va;
+    bc_st<SC1>(V2g + ((size_t)k * n + j) * E2_B + a, va);
   }
-  if (t == 0) tau2g[k * n + j] = tau;
+  if (t == 0) bc_st<SC1>(tau2g + k * n + j, tau);
   // s = v . y (the right-hand reflector's share of z = v^T E (I - tau_p v_p v_p^T))
+  if (EARLY) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // v and tau have left the chip's caches (and the diagonal block has landed)
   const double sdot = bc_bsum((h == 0) ? va * ya : 0.0, red); // includes the barrier that publishes v
+  // EARLY: the next position of this sweep needs nothing else from this task -- its blocks are disjoint from this task's -- so it
+  // may start now, 6 us into an 18 us task (bc_persist1_kernel)
+  if (EARLY && t == 0) __hip_atomic_store(vflag, (int)(j + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   BC_STAMP(3);
   if (k > 0) {
     // z0_c = sum_q v_q E[c][q]: thread = column a, rows cb ..
@@ -514,10 +779,10 @@ __device__ __forceinline__ void bc_task(double *__restrict__ B, long n, long j, 
     for (int c = 0; c < CW; ++c) {
       double e = er[c] - ya * bc_bcast(vph, c) - tva * bc_bcast(zch, c);
       if (cb + c == 0) e = (a == 0) ? beta : 0.0;
-      if (a < L) dst[c * (E2_LDB - 1)] = e;
+      if (a < L) bc_st<SC1>(dst + c * (E2_LDB - 1), e);
     }
   } else if (h == 0 && a < L) {
-    B[j * E2_LDB + 1 + a] = (a == 0) ? beta : 0.0;
+    bc_st<SC1>(B + j * E2_LDB + 1 + a, (a == 0) ? beta : 0.0);
   }
   BC_STAMP(4);
   if (tau == 0.0) return; // H = I (uniform over the block)
@@ -555,7 +820,7 @@ __device__ __forceinline__ void bc_task(double *__restrict__ B, long n, long j, 
     double *dst = B + (r + cb) * E2_LDB + a - cb;
 #pragma unroll
     for (int c = 0; c < CW; ++c)
-      if (a >= cb + c && a < L) dst[c * (E2_LDB - 1)] = dr[c] - va * bc_bcast(wh, c) - wa * bc_bcast(vh, c);
+      if (a >= cb + c && a < L) bc_st<SC1>(dst + c * (E2_LDB - 1), dr[c] - va * bc_bcast(wh, c) - wa * bc_bcast(vh, c));
   }
   BC_STAMP(7);
 }
@@ -564,7 +829,7 @@ __global__ __launch_bounds__(BC_THREADS) void bc_step_kernel(BcArgs g) {
   extern __shared__ double e2sm[];
   const long n = g.n, j = g.jlo + blockIdx.x, k = g.t - 2 * j;
   if (k < 0 || j > n - 3 || j + 1 + k * E2_B >= n) return;
-  bc_task<false>(g.Bd, n, j, k, g.V2, g.tau2, e2sm);
+  bc_task<false, false>(g.Bd, n, j, k, g.V2, g.tau2, e2sm);
 }
 
 // The same chase as ONE launch: workgroup w owns the chase positions k = 2 w and 2 w + 1 and walks the sweeps j = 0, 1, ...;
@@ -579,17 +844,8 @@ struct BcPersistArgs {
   int *prog, *err;
   long long *dbg; // GEMMA_HIP_EIGH_BC_DBG=1: wall-clock stamps (100 MHz) of workgroup 1's first tasks, 16 per task
 };
-__device__ __forceinline__ bool bc_wait(int *p, int target, int *err) {
-  for (long it = 0; it < (1L << 22); ++it) {
-    if (__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) return true;
-    if ((it & 63) == 63 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return false;
-    __builtin_amdgcn_s_sleep(1);
-  }
-  __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  return false;
-}
-template <bool DBG> // DBG: wall-clock stamps of workgroup 1's tasks (compiled out otherwise: a conditional store in the task
-                    // makes the compiler wait for every load in flight at the join)
+template <bool DBG, bool SC1> // DBG: wall-clock stamps of workgroup 1's tasks (compiled out otherwise: a conditional store in the task
+                              // makes the compiler wait for every load in flight at the join); SC1: see bc_task
 __global__ __launch_bounds__(BC_THREADS) void bc_persist_kernel(BcPersistArgs g) {
   extern __shared__ double e2sm[];
   __shared__ int s_ok;
@@ -608,15 +864,58 @@ __global__ __launch_bounds__(BC_THREADS) void bc_persist_kernel(BcPersistArgs g)
       }
       __syncthreads();
       if (!s_ok) return;
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      if (!SC1) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
       long long *dbg = (DBG && g.dbg && blockIdx.x == 1 && sidx == 0 && j < 512) ? g.dbg + 16 * j : nullptr;
-      if (DBG && dbg) bc_task<true>(g.Bd, n, j, k, g.V2, g.tau2, e2sm, dbg);
-      else bc_task<false>(g.Bd, n, j, k, g.V2, g.tau2, e2sm);
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      if (DBG && dbg) bc_task<true, SC1>(g.Bd, n, j, k, g.V2, g.tau2, e2sm, dbg);
+      else bc_task<false, SC1>(g.Bd, n, j, k, g.V2, g.tau2, e2sm);
+      if (SC1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this thread's write-through stores have left the chip's caches
+      else __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
       __syncthreads();
       if (threadIdx.x == 0) __hip_atomic_store(g.prog + k, (int)(j + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (DBG && dbg && threadIdx.x == 0) dbg[8] = (long long)wall_clock64();
     }
+  }
+}
+
+// One chase position per workgroup, the reflector handed on EARLY (round 4).  With the hand-over at the end of a task the chain
+// (j, k) -> (j, k + 1) -> (j + 1, k) costs two task times T per sweep whatever the number of workgroups.  But task (j, k + 1)
+// needs only v and tau of (j, k) -- the blocks the two tasks touch are disjoint -- and those exist a = 6 us into the T = 18 us
+// task: with start(j, k) >= start(j, k - 1) + a and start(j, k) >= end(j - 1, k + 1) the sweep period drops from 2 T to a + T.
+// vprog[k] = sweeps whose reflector position k has published, prog[k] = sweeps it has finished.  Needs positions <= CUs
+// (n <= 32 768 + 128 on 256 CUs); beyond that bc_persist_kernel (two positions per workgroup) stays.
+struct BcPersist1Args {
+  double *Bd;
+  long n;
+  double *V2, *tau2;
+  int *prog, *vprog, *err;
+  long long *dbg;
+};
+template <bool DBG>
+__global__ __launch_bounds__(BC_THREADS) void bc_persist1_kernel(BcPersist1Args g) {
+  extern __shared__ double e2sm[];
+  __shared__ int s_ok;
+  const long n = g.n, k = blockIdx.x;
+  for (long j = 0; j <= n - 3; ++j) {
+    if (j + 1 + k * E2_B >= n) break;
+    if (threadIdx.x == 0) {
+      bool ok = true;
+      if (k > 0) ok = bc_wait(g.vprog + (k - 1), (int)(j + 1), g.err);
+      if (ok && j >= 1 && j + (k + 1) * E2_B < n) ok = bc_wait(g.prog + (k + 1), (int)j, g.err);
+      s_ok = ok ? 1 : 0;
+    }
+    __syncthreads();
+    if (!s_ok) return;
+    long long *dbg = (DBG && g.dbg && blockIdx.x == 2 && j < 512) ? g.dbg + 16 * j : nullptr;
+    if (DBG && dbg) bc_task<true, true, true>(g.Bd, n, j, k, g.V2, g.tau2, e2sm, dbg, g.vprog + k);
+    else bc_task<false, true, true>(g.Bd, n, j, k, g.V2, g.tau2, e2sm, nullptr, g.vprog + k);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this thread's write-through stores have left the chip's caches
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      // a task that returned early (tau = 0: H = I) has not published through the EARLY path's flag store?  it has: the flag
+      // store sits before that return
+      __hip_atomic_store(g.prog + k, (int)(j + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (DBG && dbg && threadIdx.x == 0) dbg[8] = (long long)wall_clock64();
   }
 }
 
@@ -674,8 +973,6 @@ __global__ __launch_bounds__(256) void q2_pack_kernel(Q2PackArgs g) {
   }
 }
 
-typedef double e2_v4 __attribute__((ext_vector_type(4)));
-typedef double e2_v2 __attribute__((ext_vector_type(2)));
 
 struct Q2ApplyArgs {
   double *ZT;
@@ -722,7 +1019,7 @@ __global__ __launch_bounds__(256, 2) void q2_apply_kernel(Q2ApplyArgs g) {
       int task = atomicAdd(g.sync, 1);
       if (task < g.nseg * g.nrb) {
         const int sg = task / g.nrb;
-        if (sg > 0 && !bc_wait(g.sync + 2 + (task - sg * g.nrb), sg, g.sync + 1)) task = 0x7fffffff;
+        if (sg > 0 && !bc_wait(g.sync + 2 + (task - sg * g.nrb), sg, g.sync + 1, Q2_WAIT_TICKS)) task = 0x7fffffff;
       }
       s_task = task;
     }
@@ -873,6 +1170,8 @@ struct Eig2Ws {
   long *goff = nullptr;
   double *P256 = nullptr, *Tpair = nullptr; // Q1 applied two panels at a time: three n x 256 buffers, one 256 x 256 factor
   int *prog = nullptr; // progress counters of the persistent bulge chase (+ the error flag)
+  int *pbar = nullptr; // error flag of the persistent panel kernel ([1])
+  double *ppart = nullptr, *pheads = nullptr; // its self-validating slots: [step][workgroup][row], [step][row]
   int *q2sync = nullptr; // q2_apply_kernel's task counter, error flag, per-row-block progress; then the segment table
   long ngroups = 0, kmaxall = 0, nJ = 0;
 };
@@ -902,6 +1201,83 @@ static inline int eig2_dgemm_split2(char ta, char tb, long M, long N, long K, do
   return 0;
 }
 
+// The same cut FOUR ways (round 4): at n = 20 000 a half of the skinny product V^T A22 is 60-150 workgroups with a K loop of
+// thousands of steps each -- the two halves together left half of the chip idle (1.74 ms for 0.76 ms of matrix work at
+// m = 14 752).  Four K ranges on four streams (the caller's, the GEMM side stream, two more created on first use); the parts
+// land in four buffers and e2_sum4_kernel adds them in a fixed order.  Falls back to the two-way cut when the extra streams
+// cannot be created or K is short.
+struct Eig2Streams {
+  hipStream_t st[2] = {nullptr, nullptr};
+  hipEvent_t ready = nullptr, done[2] = {nullptr, nullptr};
+  bool tried = false;
+};
+static Eig2Streams g_e2s;
+static inline bool eig2_streams_init() {
+  if (g_e2s.tried) return g_e2s.st[1] != nullptr;
+  g_e2s.tried = true;
+  bool ok = hipEventCreateWithFlags(&g_e2s.ready, hipEventDisableTiming) == hipSuccess;
+  for (int i = 0; i < 2 && ok; ++i)
+    ok = hipStreamCreateWithFlags(&g_e2s.st[i], hipStreamNonBlocking) == hipSuccess &&
+         hipEventCreateWithFlags(&g_e2s.done[i], hipEventDisableTiming) == hipSuccess;
+  if (!ok) {
+    (void)hipGetLastError();
+    g_e2s.st[0] = g_e2s.st[1] = nullptr;
+  }
+  return ok;
+}
+static inline void eig2_streams_destroy() {
+  for (int i = 0; i < 2; ++i) {
+    if (g_e2s.st[i]) (void)hipStreamDestroy(g_e2s.st[i]);
+    if (g_e2s.done[i]) (void)hipEventDestroy(g_e2s.done[i]);
+  }
+  if (g_e2s.ready) (void)hipEventDestroy(g_e2s.ready);
+  g_e2s = Eig2Streams();
+}
+// D[r][c] = A[r][c] + B[r][c] + C[r][c] + E[r][c] (rows x cols, common leading dimension ld), in that order
+__global__ void e2_sum4_kernel(double *D, const double *A, const double *__restrict__ B,
+                               const double *__restrict__ C, const double *__restrict__ E, long cols, long ld) {
+  const long c = ((long)blockIdx.x * 256 + threadIdx.x) * 2, r = blockIdx.y;
+  if (c >= cols) return;
+  const long o = r * ld + c;
+  if (c + 1 < cols) {
+    const e2_v2 a = *reinterpret_cast<const e2_v2 *>(A + o), b = *reinterpret_cast<const e2_v2 *>(B + o);
+    const e2_v2 cc = *reinterpret_cast<const e2_v2 *>(C + o), e = *reinterpret_cast<const e2_v2 *>(E + o);
+    e2_v2 d = {((a[0] + b[0]) + cc[0]) + e[0], ((a[1] + b[1]) + cc[1]) + e[1]};
+    *reinterpret_cast<e2_v2 *>(D + o) = d;
+  } else {
+    D[o] = ((A[o] + B[o]) + C[o]) + E[o];
+  }
+}
+// C[0] + C[1] + C[2] + C[3] = alpha op(A) op(B); returns 4 when it ran four ways, 2 when it fell back to the two-way cut
+// (C[0], C[1] then hold the halves), < 0 on error (msg set)
+static inline int eig2_dgemm_split4(char ta, char tb, long M, long N, long K, double alpha, const double *A, long lda,
+                                    const double *B, long ldb, double *const C[4], long ldc, hipStream_t s, std::string &msg) {
+  const long Kq = (K / 4) / GEMM_BK * GEMM_BK;
+  const char *e4 = getenv("GEMMA_HIP_EIGH_SPLIT4"); // 0: the two-way cut of rounds 2-3
+  if ((e4 && e4[0] == '0') || !g_gemm_aux.stream || Kq < 4 * GEMM_BK || !eig2_streams_init()) {
+    const int rc = eig2_dgemm_split2(ta, tb, M, N, K, alpha, A, lda, B, ldb, C[0], C[1], ldc, s, msg);
+    return rc ? -1 : 2;
+  }
+  const bool tA = (ta == 'T'), tB = (tb == 'T');
+  hipStream_t st[4] = {s, g_gemm_aux.stream, g_e2s.st[0], g_e2s.st[1]};
+  hipEvent_t dn[4] = {nullptr, g_gemm_aux.done, g_e2s.done[0], g_e2s.done[1]};
+  auto chk = [&](hipError_t e, const char *what) {
+    if (e != hipSuccess) msg = std::string(what) + ": " + hipGetErrorString(e);
+    return e == hipSuccess;
+  };
+  if (!chk(hipEventRecord(g_e2s.ready, s), "split4 record")) return -1;
+  for (int i = 3; i >= 0; --i) { // the caller's stream last: its part runs beside the others
+    const long k0 = i * Kq, kn = (i == 3) ? K - 3 * Kq : Kq;
+    const double *Ai = tA ? A + k0 * lda : A + k0, *Bi = tB ? B + k0 : B + k0 * ldb;
+    if (i > 0 && !chk(hipStreamWaitEvent(st[i], g_e2s.ready, 0), "split4 wait")) return -1;
+    if (!chk(launch_dgemm(ta, tb, M, N, kn, alpha, Ai, lda, Bi, ldb, 0.0, C[i], ldc, false, false, st[i]), "split4 gemm")) return -1;
+    if (i > 0 && !chk(hipEventRecord(dn[i], st[i]), "split4 record")) return -1;
+  }
+  for (int i = 1; i < 4; ++i)
+    if (!chk(hipStreamWaitEvent(s, dn[i], 0), "split4 join")) return -1;
+  return 4;
+}
+
 static inline int eig2_gram(const double *X, const double *Y, long ld, long K, double *P, double *S, hipStream_t s,
                             std::string &msg) {
   const int nwg = (int)((K + GR_CH - 1) / GR_CH);
@@ -929,17 +1305,52 @@ static inline int eig2_sy2sb(double *A, long n, EigWs &ws, Eig2Ws &w2, hipStream
   }
   const char *etf = getenv("GEMMA_HIP_EIGH_TFACTOR"); // "serial": the 128-step recurrence
   const bool tf_blocked = !(etf && etf[0] == 's');
+  // GEMMA_HIP_EIGH_PANEL=launch: one launch per panel column (rounds 2-3); default: one persistent launch per panel
+  // (sb_panel_persist_kernel) wherever all of its workgroups fit on the chip at once
+  const char *epn = getenv("GEMMA_HIP_EIGH_PANEL");
+  bool persist = !(epn && epn[0] == 'l');
+  static int ncu = 0;
+  if (!ncu) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ncu = prop.multiProcessorCount;
+    if (ncu <= 0) ncu = 1;
+  }
+  if (persist) EIG_HIP(hipMemsetAsync(w2.pbar, 0, 4 * sizeof(int), s));
   for (long j0 = 0;; j0 += E2_B) {
     const long r0 = j0 + E2_B, m = n - r0;
     if (m < 2) break;
     const int kk = (int)std::min<long>(E2_B, m - 1);
-    const int nwg = (int)((m + SB_COLS - 1) / SB_COLS);
-    SbPanelArgs pa{A, n, j0, 0, kk, nwg, ws.VT, w2.part, w2.heads, ws.tau, w2.betas};
-    for (int c = 0; c <= kk; ++c) {
-      pa.c = c;
-      hipLaunchKernelGGL(sb_panel_kernel, dim3(nwg), dim3(256), 0, s, pa);
+    bool done = false;
+    if (persist) {
+      const int nch = (m + 127) / 128 <= ncu ? 1 : 2;
+      const int nwgp = (int)((m + 128 * nch - 1) / (128 * nch));
+      if (nwgp <= ncu) {
+        EIG_HIP(hipMemsetAsync(w2.ppart, 0xFF, (size_t)kk * nwgp * E2_B * 8, s));
+        EIG_HIP(hipMemsetAsync(w2.pheads, 0xFF, (size_t)kk * E2_B * 8, s));
+        SbPersistArgs pp{A, n, j0, kk, nwgp, ws.VT, ws.tau, w2.betas, w2.ppart, w2.pheads, w2.pbar + 1};
+        if (nch == 1) hipLaunchKernelGGL(sb_panel_persist_kernel<1>, dim3(nwgp), dim3(SP_THREADS), 0, s, pp);
+        else hipLaunchKernelGGL(sb_panel_persist_kernel<2>, dim3(nwgp), dim3(SP_THREADS), 0, s, pp);
+        EIG_HIP(hipGetLastError());
+        int err = 0;
+        EIG_HIP(hipMemcpyAsync(&err, w2.pbar + 1, sizeof(int), hipMemcpyDeviceToHost, s));
+        EIG_HIP(hipStreamSynchronize(s));
+        if (!err) {
+          done = true;
+        } else {
+          persist = false; // a workgroup waited too long (the chip was shared): A is untouched, per-column launches from here on
+        }
+      }
     }
-    EIG_HIP(hipGetLastError());
+    if (!done) {
+      const int nwg = (int)((m + SB_COLS - 1) / SB_COLS);
+      SbPanelArgs pa{A, n, j0, 0, kk, nwg, ws.VT, w2.part, w2.heads, ws.tau, w2.betas};
+      for (int c = 0; c <= kk; ++c) {
+        pa.c = c;
+        hipLaunchKernelGGL(sb_panel_kernel, dim3(nwg), dim3(256), 0, s, pa);
+      }
+      EIG_HIP(hipGetLastError());
+    }
     const long p = j0 / E2_B;
     const double *Vr = ws.VT + j0 * n + r0;
     double *A22 = A + r0 * n + r0;
@@ -954,10 +1365,21 @@ static inline int eig2_sy2sb(double *A, long n, EigWs &ws, Eig2Ws &w2, hipStream
     // Z1 = V^T A22 (128 x m), Y^T = T^T Z1
     double *SA = w2.YT, *SB = w2.YT + (size_t)2 * E2_B * n; // stacked operands [V; W] and [W; V], 256 x m each (ld n)
     double *Wr = SA + (size_t)E2_B * n;
-    rc = eig2_dgemm_split2('N', 'N', E2_B, m, m, 1.0, Vr, n, A22, n, ws.WT, SB, n, s, msg);
-    if (rc) return rc;
-    EIG_HIP(launch_dgemm('T', 'N', E2_B, m, E2_B, 1.0, T, E2_B, ws.WT, n, 0.0, Wr, n, false, false, s));
-    EIG_HIP(launch_dgemm('T', 'N', E2_B, m, E2_B, 1.0, T, E2_B, SB, n, 1.0, Wr, n, false, false, s));
+    {
+      // four K ranges of V^T A22 into WT, SB, SB + 128 n and the (still unused) first half of SA
+      double *const parts[4] = {ws.WT, SB, SB + (size_t)E2_B * n, SA};
+      const int ways = eig2_dgemm_split4('N', 'N', E2_B, m, m, 1.0, Vr, n, A22, n, parts, n, s, msg);
+      if (ways < 0) return 4;
+      if (ways == 4) {
+        hipLaunchKernelGGL(e2_sum4_kernel, dim3((unsigned)((m / 2 + 255) / 256 + 1), (unsigned)E2_B), dim3(256), 0, s, ws.WT, ws.WT, SB,
+                           SB + (size_t)E2_B * n, SA, m, n);
+        EIG_HIP(hipGetLastError());
+        EIG_HIP(launch_dgemm('T', 'N', E2_B, m, E2_B, 1.0, T, E2_B, ws.WT, n, 0.0, Wr, n, false, false, s));
+      } else {
+        EIG_HIP(launch_dgemm('T', 'N', E2_B, m, E2_B, 1.0, T, E2_B, ws.WT, n, 0.0, Wr, n, false, false, s));
+        EIG_HIP(launch_dgemm('T', 'N', E2_B, m, E2_B, 1.0, T, E2_B, SB, n, 1.0, Wr, n, false, false, s));
+      }
+    }
     // W^T = Y^T - (Mid^T T / 2) V^T,  Mid = V^T Y
     rc = eig2_gram(Vr, Wr, n, m, w2.gramP, ws.S, s, msg);
     if (rc) return rc;
@@ -999,15 +1421,19 @@ static inline int eig2_sb2st(long n, EigWs &ws, Eig2Ws &w2, hipStream_t s, std::
       hipDeviceProp_t prop;
       if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ncu = prop.multiProcessorCount;
       if (ncu <= 0) ncu = 1;
-      EIG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(bc_persist_kernel<false>),
+      EIG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(bc_persist_kernel<false, true>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, BC_LDS_DOUBLES * 8));
-      EIG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(bc_persist_kernel<true>),
+      EIG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(bc_persist_kernel<true, true>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, BC_LDS_DOUBLES * 8));
+      EIG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(bc_persist_kernel<false, false>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, BC_LDS_DOUBLES * 8));
+      EIG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(bc_persist_kernel<true, false>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, BC_LDS_DOUBLES * 8));
     }
     const char *eb = getenv("GEMMA_HIP_EIGH_BC");
     const long nwg = (w2.kmaxall + 1) / 2;
     if (!(eb && eb[0] == 's') && nwg <= ncu) {
-      EIG_HIP(hipMemsetAsync(w2.prog, 0, (size_t)(w2.kmaxall + 2) * sizeof(int), s));
+      EIG_HIP(hipMemsetAsync(w2.prog, 0, (size_t)(2 * w2.kmaxall + 4) * sizeof(int), s));
       EIG_HIP(hipMemcpyAsync(w2.Bd0, w2.Bd, (size_t)(n + E2_B) * E2_LDB * 8, hipMemcpyDeviceToDevice, s));
       BcPersistArgs pa{w2.Bd, n, w2.V2, w2.tau2, w2.prog, w2.prog + w2.kmaxall + 1, nullptr};
       const char *ed = getenv("GEMMA_HIP_EIGH_BC_DBG");
@@ -1016,8 +1442,26 @@ static inline int eig2_sb2st(long n, EigWs &ws, Eig2Ws &w2, hipStream_t s, std::
         (void)hipMemsetAsync(dbg_d, 0, 512 * 16 * 8, s);
         pa.dbg = dbg_d;
       }
-      if (dbg_d) {
-        hipLaunchKernelGGL(bc_persist_kernel<true>, dim3((unsigned)nwg), dim3(BC_THREADS), BC_LDS_DOUBLES * 8, s, pa);
+      const char *esc = getenv("GEMMA_HIP_EIGH_BC_SC1"); // 0: acquire / release fences around every task (rounds 2-3)
+      const bool sc1 = !(esc && esc[0] == '0');
+      // GEMMA_HIP_EIGH_BC_PIPE=0: two positions per workgroup, hand-over at the end of a task (rounds 2-3)
+      const char *epi = getenv("GEMMA_HIP_EIGH_BC_PIPE");
+      const bool pipe1 = sc1 && !(epi && epi[0] == '0') && w2.kmaxall <= ncu;
+      if (pipe1) {
+        static bool attr1 = false;
+        if (!attr1) {
+          EIG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(bc_persist1_kernel<false>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, BC_LDS_DOUBLES * 8));
+          EIG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(bc_persist1_kernel<true>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, BC_LDS_DOUBLES * 8));
+          attr1 = true;
+        }
+        BcPersist1Args p1{w2.Bd, n, w2.V2, w2.tau2, w2.prog, w2.prog + w2.kmaxall + 2, w2.prog + w2.kmaxall + 1, dbg_d};
+        if (dbg_d) hipLaunchKernelGGL(bc_persist1_kernel<true>, dim3((unsigned)w2.kmaxall), dim3(BC_THREADS), BC_LDS_DOUBLES * 8, s, p1);
+        else hipLaunchKernelGGL(bc_persist1_kernel<false>, dim3((unsigned)w2.kmaxall), dim3(BC_THREADS), BC_LDS_DOUBLES * 8, s, p1);
+      } else if (dbg_d) {
+        if (sc1) hipLaunchKernelGGL((bc_persist_kernel<true, true>), dim3((unsigned)nwg), dim3(BC_THREADS), BC_LDS_DOUBLES * 8, s, pa);
+        else hipLaunchKernelGGL((bc_persist_kernel<true, false>), dim3((unsigned)nwg), dim3(BC_THREADS), BC_LDS_DOUBLES * 8, s, pa);
       } else {
         // GEMMA_HIP_EIGH_BC_COOP=1: a COOPERATIVE launch -- the runtime starts the grid only with every workgroup resident, which
         // is what the progress counters assume (a kernel of another stream holding a few CUs would otherwise leave some
@@ -1031,12 +1475,15 @@ static inline int eig2_sb2st(long n, EigWs &ws, Eig2Ws &w2, hipStream_t s, std::
         bool launched = false;
         if (ec && ec[0] == '1') {
           void *kargs[] = {reinterpret_cast<void *>(&pa)};
-          launched = hipLaunchCooperativeKernel(reinterpret_cast<const void *>(bc_persist_kernel<false>), dim3((unsigned)nwg),
+          launched = hipLaunchCooperativeKernel(sc1 ? reinterpret_cast<const void *>(bc_persist_kernel<false, true>)
+                                                    : reinterpret_cast<const void *>(bc_persist_kernel<false, false>), dim3((unsigned)nwg),
                                                 dim3(BC_THREADS), kargs, (unsigned)(BC_LDS_DOUBLES * 8), s) == hipSuccess;
           if (!launched) (void)hipGetLastError();
         }
-        if (!launched)
-          hipLaunchKernelGGL(bc_persist_kernel<false>, dim3((unsigned)nwg), dim3(BC_THREADS), BC_LDS_DOUBLES * 8, s, pa);
+        if (!launched) {
+          if (sc1) hipLaunchKernelGGL((bc_persist_kernel<false, true>), dim3((unsigned)nwg), dim3(BC_THREADS), BC_LDS_DOUBLES * 8, s, pa);
+          else hipLaunchKernelGGL((bc_persist_kernel<false, false>), dim3((unsigned)nwg), dim3(BC_THREADS), BC_LDS_DOUBLES * 8, s, pa);
+        }
       }
       EIG_HIP(hipGetLastError());
       if (dbg_d) {
@@ -1217,11 +1664,11 @@ static inline bool eig2_alloc(long n, EigWs &ws, Eig2Ws &w2) {
   }
   w2.ngroups = goff[w2.nJ];
   const size_t nwg_panel = (size_t)(n + SB_COLS - 1) / SB_COLS, nwg_gram = (size_t)(n + GR_CH - 1) / GR_CH;
-  bool ok = ws.get(w2.Bd, (size_t)(n + E2_B) * E2_LDB) && ws.get(w2.Bd0, (size_t)(n + E2_B) * E2_LDB) && ws.get(w2.part, 2 * nwg_panel * E2_B) && ws.get(w2.heads, 2 * E2_B) &&
+  bool ok = ws.get(w2.Bd, (size_t)(n + E2_B) * E2_LDB) && ws.get(w2.Bd0, (size_t)(n + E2_B) * E2_LDB) && ws.get(w2.part, 2 * std::max(nwg_panel, (size_t)(n + E2_B - 1) / E2_B) * E2_B) && ws.get(w2.pbar, 4) && ws.get(w2.ppart, (size_t)E2_B * std::min<size_t>((size_t)(n + E2_B - 1) / E2_B, 1024) * E2_B) && ws.get(w2.pheads, (size_t)E2_B * E2_B) && ws.get(w2.heads, 2 * E2_B) &&
             ws.get(w2.betas, n) && ws.get(w2.gramP, nwg_gram * E2_B * E2_B) && ws.get(w2.YT, (size_t)4 * E2_B * n) &&
             ws.get(w2.V2, (size_t)w2.kmaxall * n * E2_B) && ws.get(w2.tau2, (size_t)w2.kmaxall * n) &&
             ws.get(w2.pack, (size_t)w2.ngroups * E2_PACK) && ws.get(w2.goff, (size_t)w2.nJ + 1) &&
-            ws.get(w2.prog, (size_t)w2.kmaxall + 4) && ws.get(w2.P256, (size_t)3 * n * 2 * E2_B) &&
+            ws.get(w2.prog, 2 * (size_t)w2.kmaxall + 8) && ws.get(w2.P256, (size_t)3 * n * 2 * E2_B) &&
             ws.get(w2.Tpair, (size_t)4 * E2_B * E2_B) && ws.get(w2.q2sync, (size_t)(n + 63) / 64 + 2 + Q2_MAXSEG + 2);
   if (!ok) return false;
   return hipMemcpy(w2.goff, goff.data(), goff.size() * sizeof(long), hipMemcpyHostToDevice) == hipSuccess;

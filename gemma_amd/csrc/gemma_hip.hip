@@ -13,7 +13,7 @@
 
 #include "../../include/gemma_hip.h"
 #include "dgemm_mfma.hip.h"
-#include "eigh.hip.h"
+#include "eigh_tu.h"
 #include "ingest.hip.h"
 #include "lm_assoc.hip.h"
 #include "lmm_assoc.hip.h"
@@ -110,6 +110,8 @@ struct Ctx {
   MvArgs mv_proto;
   DevBuf i8_Bt, i8_ej, i8_cmax, i8_A, i8_C, i8_mean; // exact int8-digit U^T x (i8gemm.hip.h)
   unsigned long long cheb_qmask = 0; // bit k: tabulated interval k is in Q form (ends at or below lambda = 1e-3)
+  DevBuf i8_raster;            // (tile_m, tile_n) per workgroup of the records kernel: the cross-XCD raster (i8gemm_sparse2.hip.h)
+  int i8_raster_tm = 0, i8_raster_tn = 0, i8_raster_rb = 0;
   DevBuf i8_surlist;           // per row: count + up to SUR_MAX individuals the sparse mask operand dropped
   DevBuf i8_colsum;            // column sums of U from its digit planes (fixed-point dosage path)
   bool i8_colsum_ready = false;
@@ -273,6 +275,7 @@ extern "C" void gemma_hip_shutdown(void) {
   g_ctx.UtWt.release(); g_ctx.idx_map.release(); g_ctx.X.release(); g_ctx.UtX.release();
   g_ctx.stage_in.release(); g_ctx.stage_out.release(); g_ctx.carry.release(); g_ctx.scratch.release();
   g_ctx.i8_Bt.release(); g_ctx.i8_ej.release(); g_ctx.i8_cmax.release(); g_ctx.i8_A.release(); g_ctx.i8_C.release();
+  g_ctx.i8_raster.release(); g_ctx.i8_raster_tm = g_ctx.i8_raster_tn = g_ctx.i8_raster_rb = 0;
   g_ctx.i8_mean.release(); g_ctx.i8_meta.release(); g_ctx.i8_rowsur.release(); g_ctx.i8_colsum.release(); g_ctx.i8_surlist.release();
   g_ctx.i8_ready = g_ctx.i8_colsum_ready = false;
   g_ctx.table_P.release(); g_ctx.U_even.release();
@@ -292,6 +295,7 @@ extern "C" void gemma_hip_shutdown(void) {
   g_ctx.kept_K_n = g_ctx.kept_n = 0;
   g_ctx.comm.finalize();
   gemm_aux_destroy();
+  eigh_tu_shutdown();
   g_ctx.inited = false;
 }
 
@@ -506,17 +510,23 @@ static int kin_add_i8(const void *geno, size_t l, size_t ld, hipStream_t s) {
     // the correction on lists of the missing calls (kin_i8.hip.h, round 3); GEMMA_HIP_KIN_LISTS=0 keeps the round-2 kernel,
     // GEMMA_HIP_KIN_LIST_CAP=<entries> overrides the list capacity (tests: forces the on-device fall-back)
     const char *el = getenv("GEMMA_HIP_KIN_LISTS");
-    const bool lists = !(el && el[0] == '0') && l < ((size_t)1 << 18);
+    bool lists = !(el && el[0] == '0') && l < ((size_t)1 << 18);
     const unsigned nseg = (unsigned)((n + KI8_SEG - 1) / KI8_SEG);
+    size_t cap = std::max<size_t>(l * n / 16, (size_t)1 << 20);
+    if (const char *ec = getenv("GEMMA_HIP_KIN_LIST_CAP")) cap = std::max<size_t>((size_t)atoll(ec), 1);
+    cap = std::min<size_t>(cap, (size_t)1 << 30);
+    const size_t ld2 = (size_t)256 * nseg; // dwords per row of the 2-bit copy (kin_i8_pack2_kernel)
+    // the list buffers are an optimisation: when they do not fit (GEMMA_HIP_KIN_LISTS_OOM=1 simulates it) the round-2 kernel,
+    // which needs none of them, takes the whole correction -- as launch_assoc degrades when its tables do not fit
+    const char *eo = getenv("GEMMA_HIP_KIN_LISTS_OOM");
+    if (lists && ((eo && eo[0] == '1') ||
+                  g_ctx.kin_A2.reserve(l * ld2 * 4) || g_ctx.kin_cnt.reserve((l + n) * 4) || g_ctx.kin_off.reserve((l + n + 2) * 4) ||
+                  g_ctx.kin_listS.reserve(cap * 4) || g_ctx.kin_listJ.reserve(cap * 4) ||
+                  g_ctx.kin_sub.reserve(l * (size_t)(nseg + 1) * 4) || g_ctx.kin_cj.reserve(n * 8) || g_ctx.kin_flag.reserve(16))) {
+      (void)hipGetLastError();
+      lists = false;
+    }
     if (lists) {
-      size_t cap = std::max<size_t>(l * n / 16, (size_t)1 << 20);
-      if (const char *ec = getenv("GEMMA_HIP_KIN_LIST_CAP")) cap = std::max<size_t>((size_t)atoll(ec), 1);
-      cap = std::min<size_t>(cap, (size_t)1 << 30);
-      const size_t ld2 = (size_t)256 * nseg; // dwords per row of the 2-bit copy (kin_i8_pack2_kernel)
-      if (g_ctx.kin_A2.reserve(l * ld2 * 4) || g_ctx.kin_cnt.reserve((l + n) * 4) || g_ctx.kin_off.reserve((l + n + 2) * 4) ||
-          g_ctx.kin_listS.reserve(cap * 4) || g_ctx.kin_listJ.reserve(cap * 4) ||
-          g_ctx.kin_sub.reserve(l * (size_t)(nseg + 1) * 4) || g_ctx.kin_cj.reserve(n * 8) || g_ctx.kin_flag.reserve(16))
-        return fail(GEMMA_HIP_ENOMEM, "kin_add: lists of the missing calls");
       int *cntS = g_ctx.kin_cnt.as<int>(), *cntJ = cntS + l, *offS = g_ctx.kin_off.as<int>(), *offJ = offS + l + 1;
       int *ok = g_ctx.kin_flag.as<int>();
       hipLaunchKernelGGL(kin_i8_pack2_kernel, dim3((unsigned)l, nseg), dim3(256), 0, s, g_ctx.i8_A.as<int8_t>(), (long)l,
@@ -542,11 +552,14 @@ static int kin_add_i8(const void *geno, size_t l, size_t ld, hipStream_t s) {
       c2.offJ = offJ; c2.listJ = g_ctx.kin_listJ.as<int>(); c2.offS = offS; c2.listS = g_ctx.kin_listS.as<int>();
       c2.sub = g_ctx.kin_sub.as<int>(); c2.nseg = (int)nseg; c2.cj = g_ctx.kin_cj.as<double>();
       c2.S = g_ctx.kin_S.as<double>(); c2.ok = ok;
+      c2.dbg_skip_pairs = c2.dbg_skip_main = 0;
+#ifdef GEMMA_HIP_KIN_TIMING_SWITCHES // timing experiments only (results wrong): never in the shipped library
       {
         const char *ed = getenv("GEMMA_HIP_KIN_DBG");
         c2.dbg_skip_pairs = (ed && ed[0] == '1') ? 1 : 0;
         c2.dbg_skip_main = (ed && ed[0] == '2') ? 1 : 0;
       }
+#endif
       hipLaunchKernelGGL(kin_i8_corr2_kernel, dim3((unsigned)n, nseg), dim3(256), 0, s, c2);
       HIPCHK(hipGetLastError());
       c.lists_ok = ok;
@@ -724,7 +737,7 @@ extern "C" int gemma_hip_eigh_d(double *G, size_t n, double *U, double *eval, do
   hipStream_t s = S(stream);
   ProfScope ps(GEMMA_STAGE_EIGH, s);
   std::string msg;
-  int rc = eigh_device(G, (long)n, U, eval, s, msg);
+  int rc = eigh_device_x(G, (long)n, U, eval, s, msg);
   if (rc != GEMMA_HIP_OK) return fail(rc, "eigh: %s", msg.c_str());
   // EigenDecomp_Zeroed: eval < 1e-10 -> 0, trace = mean(eval)
   if (g_ctx.scratch.reserve(8)) return fail(GEMMA_HIP_ENOMEM, "eigh: scratch");
@@ -756,109 +769,25 @@ extern "C" int gemma_hip_eigh(double *G, size_t n, double *U, double *eval, doub
   return rc;
 }
 
-// ---- diagnostics for the eigensolver stages (used by tests/test_gpu_eigh.py) ----
-// Householder tridiagonalisation only: G (host, n x n) -> d[n], e[n-1], tau[n], VT (n x n, row j = u_j)
+// ---- diagnostics for the eigensolver stages (used by tests/test_gpu_eigh.py); bodies in eigh_tu.hip ----
 extern "C" int gemma_hip_dbg_tridiag(const double *G, size_t n, double *d, double *e, double *tau, double *VT) {
   NEED_INIT();
-  EigWs ws;
-  DevBuf dG;
-  const size_t nn = n * n;
-  if (dG.reserve(nn * 8)) return fail(GEMMA_HIP_ENOMEM, "dbg_tridiag");
-  bool ok = ws.get(ws.VT, nn) && ws.get(ws.WT, (size_t)EIG_NB * n) && ws.get(ws.xcol, n + 2) && ws.get(ws.p, n) &&
-            ws.get(ws.ab, 2 * EIG_NB) && ws.get(ws.ssbuf, n / TD_ROWS + 2) && ws.get(ws.dotbuf, n / TD_ROWS + 2) &&
-            ws.get(ws.wtmp, n) && ws.get(ws.d, n) && ws.get(ws.e, n) && ws.get(ws.tau, n);
-  {
-    const char *e = getenv("GEMMA_HIP_EIGH_SYMV");
-    if (ok && (n & 1) == 0 && !(e && e[0] == '0')) {
-      const size_t nseg = (n + TS_SEG_MIN - 1) / TS_SEG_MIN, nstrip = (n + TS_STRIP - 1) / TS_STRIP;
-      ok = ws.get(ws.rowP, nseg * n) && ws.get(ws.colP, nstrip * n);
-    }
-  }
   std::string msg;
-  int rc = ok ? 0 : GEMMA_HIP_ENOMEM;
-  if (!rc && hipMemcpy(dG.p, G, nn * 8, hipMemcpyHostToDevice) != hipSuccess) rc = GEMMA_HIP_ERUNTIME;
-  if (!rc) rc = eig_tridiagonalize(dG.as<double>(), (long)n, ws, 0, msg);
-  if (!rc && hipDeviceSynchronize() != hipSuccess) rc = GEMMA_HIP_ERUNTIME;
-  if (!rc) {
-    (void)hipMemcpy(d, ws.d, n * 8, hipMemcpyDeviceToHost);
-    if (n > 1) (void)hipMemcpy(e, ws.e, (n - 1) * 8, hipMemcpyDeviceToHost);
-    (void)hipMemcpy(tau, ws.tau, n * 8, hipMemcpyDeviceToHost);
-    if (VT) (void)hipMemcpy(VT, ws.VT, nn * 8, hipMemcpyDeviceToHost);
-  }
-  ws.release();
-  dG.release();
+  const int rc = dbg_tridiag_x(G, n, d, e, tau, VT, msg);
   if (rc) return fail(rc, "dbg_tridiag: %s", msg.c_str());
   return GEMMA_HIP_OK;
 }
-
-// two-stage reduction only (eigh2.hip.h): G (host, n x n, n even, n >= 384) -> band after stage 1 (n x 129: row j holds
-// B(j .. j+128, j)) and the tridiagonal d[n], e[n-1] after the bulge chase
 extern "C" int gemma_hip_dbg_eigh2(const double *G, size_t n, double *band, double *d, double *e) {
   NEED_INIT();
-  if (n < 3 * (size_t)E2_B || (n & 1)) return fail(GEMMA_HIP_EINVAL, "dbg_eigh2: n must be even and >= %d", 3 * E2_B);
-  EigWs ws;
-  Eig2Ws w2;
-  DevBuf dG;
-  const size_t nn = n * n;
-  if (dG.reserve(nn * 8)) return fail(GEMMA_HIP_ENOMEM, "dbg_eigh2");
-  bool ok = ws.get(ws.VT, nn) && ws.get(ws.WT, (size_t)EIG_NB * n) && ws.get(ws.d, n) && ws.get(ws.e, n) &&
-            ws.get(ws.tau, n) && ws.get(ws.S, (size_t)EIG_NB * EIG_NB) && ws.get(ws.T, (size_t)EIG_NB * EIG_NB) &&
-            ws.get(ws.Tall, ((n + EIG_NB - 1) / EIG_NB) * EIG_NB * EIG_NB) && eig2_alloc((long)n, ws, w2);
   std::string msg;
-  int rc = ok ? 0 : GEMMA_HIP_ENOMEM;
-  if (!rc && hipMemcpy(dG.p, G, nn * 8, hipMemcpyHostToDevice) != hipSuccess) rc = GEMMA_HIP_ERUNTIME;
-  if (!rc) rc = eig2_sy2sb(dG.as<double>(), (long)n, ws, w2, 0, msg);
-  if (!rc && hipDeviceSynchronize() != hipSuccess) rc = GEMMA_HIP_ERUNTIME;
-  if (!rc && band &&
-      hipMemcpy2D(band, (E2_B + 1) * 8, w2.Bd, E2_LDB * 8, (E2_B + 1) * 8, n, hipMemcpyDeviceToHost) != hipSuccess)
-    rc = GEMMA_HIP_ERUNTIME;
-  if (!rc) rc = eig2_sb2st((long)n, ws, w2, 0, msg);
-  if (!rc && hipDeviceSynchronize() != hipSuccess) rc = GEMMA_HIP_ERUNTIME;
-  if (!rc) {
-    (void)hipMemcpy(d, ws.d, n * 8, hipMemcpyDeviceToHost);
-    (void)hipMemcpy(e, ws.e, (n - 1) * 8, hipMemcpyDeviceToHost);
-  }
-  ws.release();
-  dG.release();
-  if (rc) return fail(rc, "dbg_eigh2: %s (%s)", msg.c_str(), hipGetErrorString(hipGetLastError()));
+  const int rc = dbg_eigh2_x(G, n, band, d, e, msg);
+  if (rc) return fail(rc, "dbg_eigh2: %s", msg.c_str());
   return GEMMA_HIP_OK;
 }
-
-// divide-and-conquer on a symmetric tridiagonal (host d[n], e[n-1]) -> w[n] ascending, ZT (n x n, row k =
-// eigenvector k)
 extern "C" int gemma_hip_dbg_stedc(const double *d, const double *e, size_t n, double *w, double *ZT) {
   NEED_INIT();
-  EigWs ws;
-  const size_t nn = n * n;
-  double *QA = nullptr, *QB = nullptr;
-  bool ok = ws.get(QA, nn) && ws.get(QB, nn) && ws.get(ws.d, n) && ws.get(ws.e, n) && ws.get(ws.Delta, nn) &&
-            ws.get(ws.Wk, nn) && ws.get(ws.zbuf, n) && ws.get(ws.dl, n) && ws.get(ws.w, n) && ws.get(ws.lam, n) &&
-            ws.get(ws.zhat, n) && ws.get(ws.dphys, n) && ws.get(ws.ibuf, 2 * n + 64) && ws.get(ws.info, 1) &&
-            ws.get(ws.rot, n);
   std::string msg;
-  int rc = ok ? 0 : GEMMA_HIP_ENOMEM;
-  std::vector<double> hd(d, d + n), he(e, e + (n > 1 ? n - 1 : 0)), dphys;
-  if (he.empty()) he.push_back(0.0);
-  double *Z = nullptr;
-  if (!rc && n == 1) {
-    w[0] = d[0];
-    ZT[0] = 1.0;
-    ws.release();
-    return GEMMA_HIP_OK;
-  }
-  if (!rc) rc = eig_stedc((long)n, hd, he, QA, QB, ws, 0, &Z, dphys, msg);
-  if (!rc) {
-    std::vector<int> perm(n);
-    for (size_t i = 0; i < n; ++i) perm[i] = (int)i;
-    std::stable_sort(perm.begin(), perm.end(), [&](int a, int c) { return dphys[a] < dphys[c]; });
-    std::vector<double> tmp(nn);
-    if (hipMemcpy(tmp.data(), Z, nn * 8, hipMemcpyDeviceToHost) != hipSuccess) rc = GEMMA_HIP_ERUNTIME;
-    for (size_t t = 0; t < n && !rc; ++t) {
-      w[t] = dphys[perm[t]];
-      memcpy(ZT + t * n, tmp.data() + (size_t)perm[t] * n, n * 8);
-    }
-  }
-  ws.release();
+  const int rc = dbg_stedc_x(d, e, n, w, ZT, msg);
   if (rc) return fail(rc, "dbg_stedc: %s", msg.c_str());
   return GEMMA_HIP_OK;
 }
@@ -1015,7 +944,7 @@ static int make_cheb(hipStream_t s) {
   const int nreg = (int)g_ctx.cfg.n_region;
   const double width = log(g_ctx.cfg.l_max / g_ctx.cfg.l_min) / (double)nreg;
   if (c < 1 || c > 4 || width > 2.31 || nreg > 62) return GEMMA_HIP_OK;
-  // Intervals that end at or below lambda = 1e-3 are tabulated in Q form (series of sum a b delta H, the constant sum a b from
+  // Intervals that start below lambda = 1e-3 are tabulated in Q form (series of sum a b delta H, the constant sum a b from
   // the fixed-lambda table) -- low-heritability traits stay on the table path; GEMMA_HIP_CHEB_LOWLAMBDA=0 leaves them to the
   // streaming evaluations as in round 2.
   int j0 = 0;
@@ -1057,7 +986,10 @@ static int make_cheb(hipStream_t s) {
     g_ctx.cheb_inv_half[q] = 1.0 / iv.half;
     ChebNodes nd;
     for (int m = 0; m < CHEB_N; ++m) nd.lam[m] = exp(cheb_node(iv, m));
-    const int qform = a.lam_grid[j0 + q + 1] <= CHEB_MIN_LAMBDA * (1.0 + 1e-9) ? 1 : 0;
+    // Q form by the interval's LOWER end: an interval of a non-default grid that straddles 1e-3 (e.g. [10^-3.5, 10^-2.5]) in
+    // plain S form would carry 1e-13 / lambda of relative error in dS/dt at its low end; S0 - lambda Q stays well conditioned up
+    // to the interval's upper end (<= a decade above, lambda <= 1e-2).  The default grid's nodes fall on 1e-3 either way.
+    const int qform = a.lam_grid[j0 + q] < CHEB_MIN_LAMBDA * (1.0 - 1e-9) ? 1 : 0;
     if (qform) g_ctx.cheb_qmask |= 1ull << q;
     double *G2k = g_ctx.cheb_Gk.as<double>() + n * CHEB_N;
     hipLaunchKernelGGL(cheb_coeff_kernel, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, s, g_ctx.eval, (int)n, nd,
@@ -1584,6 +1516,24 @@ static int i8_gemm_rows(const I8Dims &d, size_t row0, size_t rows_pad, hipStream
     g2.m_row0 = g.m_row0;
     g2.tiles_m = (int)(rows_pad / S2_BM); g2.tiles_n = (int)(d.npad / S2_BN);
     g2.nk = g.nk; g2.gm = g.gm; g2.fuse = g.fuse; g2.digits = g.digits;
+    {
+      // GEMMA_HIP_I8_RASTER: 0 = every XCD sweeps its own tile rows (round 3); 1 / 2 / 4 / 8 = row blocks of the super-patch the
+      // eight XCDs share (s2_build_raster)
+      const char *er = getenv("GEMMA_HIP_I8_RASTER");
+      const int rb = er ? atoi(er) : S2_DEFAULT_RASTER;
+      if (rb > 0) {
+        if (g_ctx.i8_raster_tm != g2.tiles_m || g_ctx.i8_raster_tn != g2.tiles_n || g_ctx.i8_raster_rb != rb) {
+          std::vector<int2> map;
+          s2_build_raster(g2.tiles_m, g2.tiles_n, rb, map);
+          if (g_ctx.i8_raster.reserve(map.size() * sizeof(int2)))
+            return fail(GEMMA_HIP_ENOMEM, "lmm_batch: tile raster (%zu bytes)", map.size() * sizeof(int2));
+          HIPCHK(hipStreamSynchronize(s)); // a previous launch may still read the old map
+          HIPCHK(hipMemcpy(g_ctx.i8_raster.p, map.data(), map.size() * sizeof(int2), hipMemcpyHostToDevice));
+          g_ctx.i8_raster_tm = g2.tiles_m; g_ctx.i8_raster_tn = g2.tiles_n; g_ctx.i8_raster_rb = rb;
+        }
+        g2.tile_map = g_ctx.i8_raster.as<int2>();
+      }
+    }
     hipLaunchKernelGGL(i8gemm_sparse2_kernel, dim3((unsigned)(g2.tiles_m * g2.tiles_n), (unsigned)d.nplanes), dim3(512),
                        S2_NST * S2_STAGE, s, g2);
   } else if (sparse) {
@@ -2572,6 +2522,7 @@ extern "C" int gemma_hip_lmm_finish(double *time_UtX_min, double *time_opt_min) 
   g_ctx.cheb_list.release(); g_ctx.cheb_count.release(); g_ctx.cheb_D.release(); g_ctx.cheb_Ck.release();
   g_ctx.cheb_Gk.release(); g_ctx.cheb_Lk.release(); g_ctx.cheb_iv.release(); g_ctx.cheb_dends.release(); g_ctx.cheb_res.release();
   g_ctx.i8_Bt.release(); g_ctx.i8_ej.release(); g_ctx.i8_cmax.release(); g_ctx.i8_A.release(); g_ctx.i8_C.release();
+  g_ctx.i8_raster.release(); g_ctx.i8_raster_tm = g_ctx.i8_raster_tn = g_ctx.i8_raster_rb = 0;
   g_ctx.i8_mean.release(); g_ctx.i8_meta.release(); g_ctx.i8_rowsur.release(); g_ctx.i8_colsum.release(); g_ctx.i8_surlist.release();
   g_ctx.i8_ready = false;
   g_ctx.i8_colsum_ready = false;

@@ -30,6 +30,8 @@ typedef int i32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int I8_BM = 256, I8_BN = 256, I8_BK = 128;
 constexpr int I8_DIGITS = 7;      // most digits a build handles (buffers are sized for it)
+constexpr int SUR_MAX = 16;       // calls per row the sparse mask operand may drop before the row goes to the fp64 fix-up: the stride of
+                                  // the dropped-call lists, shared by the list kernel (i8gemm_sparse.hip.h), the combine below and the host
 constexpr int I8_SCALE_BITS = 54;  // with 7 digits; D digits scale to 8 D - 2 bits (|V| <= 2^(8D-2) < 128 * 256^(D-1))
 // Digits actually used (host: i8_digits_for): 7 reproduce U to its last bit in the column's top binade (error elsewhere
 // <= 2^-55 of the column maximum).  From n = 16384 up 6 digits are used: U is then rounded at 2^-47 of the column maximum,
@@ -635,7 +637,7 @@ __global__ __launch_bounds__(256) void i8_combine_kernel(const int *__restrict__
       if (cnt > 0) {
         double acc[4] = {0.0, 0.0, 0.0, 0.0};
         for (int e = 0; e < cnt; ++e) {
-          const double *ur = U + (long)sur_list[s * 16 + e] * ldu + j;
+          const double *ur = U + (long)sur_list[s * SUR_MAX + e] * ldu + j;
 #pragma unroll
           for (int c = 0; c < 4; ++c)
             if (c < nv) acc[c] += ur[c];

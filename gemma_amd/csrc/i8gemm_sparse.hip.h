@@ -134,7 +134,7 @@ __global__ __launch_bounds__(256) void i8_surplus_fix_kernel(const int8_t *__res
 // per row with row_surplus > 0 scans the row's groups of four in order and writes the first SUR_MAX dropped individuals to
 // sur_list[row][..] (group order: deterministic), the count to sur_cnt[row]; a row with more (a SNP missing for most
 // individuals) keeps cnt = -1 and is left to i8_surplus_fix_kernel.
-constexpr int SUR_MAX = 16;
+static_assert(SUR_MAX >= 2, "SUR_MAX (i8gemm.hip.h) is the list stride of this kernel, of i8_combine_kernel and of the host's buffers");
 __global__ __launch_bounds__(256) void i8_surplus_list_kernel(const int8_t *__restrict__ A, long ldk, const int *__restrict__ row_surplus,
                                                              long l, int *__restrict__ sur_cnt, int *__restrict__ sur_list) {
   const int lane = threadIdx.x & 63;

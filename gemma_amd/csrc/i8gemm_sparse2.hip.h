@@ -22,6 +22,8 @@
 //     MFMA-to-VALU distance before the accumulators are shifted / stored (s_nop 15; s_nop 7).
 // Layout of the sparse operand, surplus calls (groups of four with more than two missing calls): as i8gemm_sparse.hip.h.
 #pragma once
+#include <algorithm>
+#include <vector>
 #include "i8gemm_sparse.hip.h"
 
 namespace gemma_hip {
@@ -43,7 +45,16 @@ struct Sparse2Args {
   int *C;           // plane q: (2 lpad) x ldc; rows [0, lpad) = G products, [lpad, 2 lpad) = M products
   long ldk, ldc, strideB, strideC, m_row0;
   int tiles_m, tiles_n, nk, gm, fuse, digits;
+  const int2 *tile_map = nullptr; // (tile_m, tile_n) of workgroup blockIdx.x: the cross-XCD raster of s2_build_raster; nullptr:
+                                  // the per-XCD ranges of round 3 (every XCD sweeps its own tile rows)
 };
+// Tried in round 4 and dropped: one digit fewer for the MASK product (the mask product sums only the row's missing calls, so
+// five digits keep its worst-case error at the level of the six-digit genotype product: -1/18 of the matrix instructions).  The
+// lowest digit's pass then runs without the sparse instructions; as a second copy of the K loop it made the register allocator
+// spill -- and a scratch access is a vector-memory operation the counted s_waitcnt vmcnt of the LDS-DMA pipeline does not know
+// about: wrong results --, behind scalar branches in one loop the compiler treats the flag as divergent and puts an
+// s_waitcnt lgkmcnt(0) in front of every sparse instruction.  Measured gain of the (broken) two-loop form: 1.8-3.5 %, the pass
+// without the mask product being short of matrix work to hide its operand movement (profiles/r04_i8_raster_mask.txt).
 
 // packed bytes g | m << 4 (lpad x ldk, lpad a multiple of 256) -> records; one thread per (row, K-tile, chunk)
 __global__ __launch_bounds__(256) void sparse2_meta_kernel(const int8_t *__restrict__ A, long lpad, long ldk,
@@ -107,6 +118,51 @@ __device__ __forceinline__ i32x4 s2_expand(int bits) {
   return v;
 }
 
+// Cross-XCD raster (round 4).  Workgroup b runs on XCD b % 8 and an XCD takes its workgroups in order, 32 at a time (one per
+// CU: 128 KiB of LDS each).  Round 3 gave every XCD its own contiguous range of tiles -- eight disjoint sweeps: each record
+// panel (2.56 MB per tile row) comes from HBM once per 4-column step of its XCD (39 times per plane) and each digit panel once per
+// 8-row group (10 times), 71 GB per launch behind the L2s.  Here the eight XCDs work on ONE super-patch of rb x 8 tile rows by
+// (8 / rb) x 4 tile columns at a time (XCD x: row block x % rb, column block x / rb; its 32 tiles rows inside, columns outside as
+// before, so the per-XCD L2 patch is unchanged) and the super-patches sweep the columns of a band of rb x 8 tile rows before the
+// next band starts: the band's record panels (rb x 20 MB at n = 20 000) stay in the 256 MiB Infinity Cache for the whole
+// sweep and a digit panel is fetched from HBM once per band and shared by the rb XCDs that need it at the same time.  HBM reads
+// per launch: records once per plane (1.2 GB), digits once per band (24 / rb GB) instead of 71 GB; what the L2s request is
+// unchanged.  Ragged bands / column steps give the XCDs sequences of different lengths: tiles are moved from the tails of the
+// long ones to the short ones until every XCD has exactly the number of workgroups the hardware will hand it.
+static inline void s2_build_raster(int tiles_m, int tiles_n, int rb, std::vector<int2> &map, int PR = 8) {
+  const int NX = 8, PC = 32 / PR; // PR x PC = the 32 tiles an XCD works on at a time (8 x 4 unless an experiment says otherwise)
+  if (rb != 1 && rb != 2 && rb != 4 && rb != 8) rb = 2;
+  const int cbs = NX / rb; // column blocks per super-patch
+  std::vector<std::vector<int2>> seq(NX);
+  for (int band0 = 0, band = 0; band0 < tiles_m; band0 += rb * PR, ++band)
+    for (int col0 = 0; col0 < tiles_n; col0 += cbs * PC)
+      for (int xx = 0; xx < NX; ++xx) {
+        const int x = (xx + band) % NX; // the XCDs that get the short blocks of a ragged last column step change from band to band
+        const int r0 = band0 + (xx % rb) * PR, c0 = col0 + (xx / rb) * PC;
+        const int nr = std::min(PR, std::min(tiles_m, band0 + rb * PR) - r0), nc = std::min(PC, std::min(tiles_n, col0 + cbs * PC) - c0);
+        if (nr <= 0 || nc <= 0) continue;
+        for (int c = 0; c < nc; ++c)
+          for (int r = 0; r < nr; ++r) seq[x].push_back(make_int2(r0 + r, c0 + c));
+      }
+  const int total = tiles_m * tiles_n;
+  std::vector<int> want(NX);
+  for (int x = 0; x < NX; ++x) want[x] = total / NX + (x < total % NX ? 1 : 0);
+  std::vector<int2> spare;
+  for (int x = 0; x < NX; ++x)
+    while ((int)seq[x].size() > want[x]) {
+      spare.push_back(seq[x].back());
+      seq[x].pop_back();
+    }
+  for (int x = 0; x < NX; ++x)
+    while ((int)seq[x].size() < want[x]) {
+      seq[x].push_back(spare.back());
+      spare.pop_back();
+    }
+  map.assign((size_t)total, make_int2(0, 0));
+  for (int x = 0; x < NX; ++x)
+    for (int o = 0; o < want[x]; ++o) map[(size_t)o * NX + x] = seq[x][o];
+}
+
 // NI: 32-row blocks per wavefront.  NI = 2: wavefronts 4 (rows) x 2 (columns), 2 x 2 blocks each (the first form of the kernel).
 // NI = 1: wavefronts 8 x 1, one row block x four column blocks each: every record is unpacked by ONE wavefront instead of two
 // (42 instead of 84 VALU per K-tile and wavefront) at the price of 18 instead of 12 ds_read_b128 (the LDS pipe has room).
@@ -115,7 +171,11 @@ __global__ __launch_bounds__(512, 2) void i8gemm_sparse2_kernel_t(Sparse2Args g)
   constexpr int NJ = 4 / NI;
   extern __shared__ __attribute__((aligned(1024))) int8_t i8lds[];
   int tm, tn;
-  {
+  if (g.tile_map) {
+    const int2 t2 = g.tile_map[blockIdx.x];
+    tm = __builtin_amdgcn_readfirstlane(t2.x);
+    tn = __builtin_amdgcn_readfirstlane(t2.y);
+  } else {
     const int nwg = gridDim.x, b = blockIdx.x;
     const int q = nwg >> 3, r = nwg & 7, x = b & 7, o = b >> 3;
     const int L = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + o;
@@ -289,7 +349,6 @@ __global__ __launch_bounds__(512, 2) void i8gemm_sparse2_kernel_t(Sparse2Args g)
     if constexpr (NI == 2) S2_KTILE(SC, SN, SD, MORE, LOAD3, VMW);                                                \
     else S2_KTILE_81(SC, SN, SD, MORE, LOAD3, VMW);                                                               \
   } while (0)
-
   // the second-dispatched half of the workgroup loses every issue arbitration on age; one static priority step evens it out
   // (MI355X_MICROARCH.md, two waves per SIMD, item 4): 57.2 -> 56.2-56.9 ms (profiles/r03_i8_sparse_ablation.txt)
   if (wave >= 4) __builtin_amdgcn_s_setprio(1);
@@ -377,6 +436,9 @@ __global__ __launch_bounds__(512, 2) void i8gemm_sparse2_kernel_t(Sparse2Args g)
 }
 
 // the shipped form: wavefronts 8 x 1 (54.4-55.0 ms against 56.5 for 4 x 2 in the same session, profiles/r03_i8_sparse_ablation.txt)
+#ifndef S2_DEFAULT_RASTER
+#define S2_DEFAULT_RASTER 1 // row blocks of the cross-XCD super-patch (0: the per-XCD ranges of round 3)
+#endif
 #ifndef S2_DEFAULT_NI
 #define S2_DEFAULT_NI 1
 #endif

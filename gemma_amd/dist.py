@@ -65,14 +65,18 @@ def broadcast_state(tensors, src=0, group=None, small_limit=1 << 22):
 
 _native_ready = False
 _native_poisoned = False  # a bootstrap thread timed out inside the library: the comm API is off limits for this process
+_native_failed = False    # the AGREED outcome of an earlier attempt was "no": every rank knows it, no rank tries again
 
 
 def native_comm_init(group=None, timeout=180.0):
     """Bootstrap the LIBRARY's own RCCL communicator (csrc/comm.hip.h: ncclGetUniqueId on rank 0, the 128-byte id shipped
     through torch.distributed's store, ncclCommInitRank on every rank's device).  Every rank learns whether ALL ranks
     succeeded (one MIN all-reduce), so that they take the same branch afterwards.  Returns True when the native
-    communicator is usable."""
-    global _native_ready, _native_poisoned
+    communicator is usable.  The function is a collective: a failed attempt is remembered as the result all ranks AGREED on
+    (`_native_failed`, set on every rank by the same all-reduce), so a later call returns False everywhere without any
+    collective -- a per-rank early return (one rank's helper thread timed out, the others' did not) would leave the others
+    waiting in a broadcast the first never joins."""
+    global _native_ready, _native_poisoned, _native_failed
     import ctypes as C
     import torch
     import torch.distributed as dist
@@ -81,11 +85,13 @@ def native_comm_init(group=None, timeout=180.0):
         return False
     if _native_ready:
         return True
-    if _native_poisoned:
+    if _native_failed:
         return False
     rank, world = dist.get_rank(group), dist.get_world_size(group)
     ok = 1
     try:
+        if _native_poisoned:  # cannot happen after an agreed failure; kept so that a poisoned rank still reaches the agreement
+            raise RuntimeError("comm API poisoned")
         ident = C.create_string_buffer(L.COMM_ID_BYTES)
         box = [None]
         if rank == 0:
@@ -122,6 +128,7 @@ def native_comm_init(group=None, timeout=180.0):
     flag = torch.tensor([ok], dtype=torch.int32, device=dev)
     dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
     _native_ready = bool(int(flag[0]) == 1)
+    _native_failed = not _native_ready
     if not _native_ready and ok == 1 and not _native_poisoned:
         L.lib().gemma_hip_comm_finalize()  # this rank could, another could not: drop the communicator, all take the fallback
     return _native_ready

@@ -170,9 +170,14 @@ int gemma_hip_lmm_set_indicator(const int *indicator_idv, size_t ni_total);
  * then per SNP CalcUab, CalcRLScore, CalcLambda('R')+CalcRLWald, CalcLambda('L')+LRT (:1526-1562).
  * out[l] in SNP order. l is not limited to LMM_BATCH_SIZE.
  * U^T X: fp64 MFMA GEMM for real-valued input; for hard calls (GEMMA_GENO_PLINK_2BIT, or fp64 rows holding only
- * 0/1/2 and one missing / imputed value -- detected per batch) the same product as 14 exact int8 MFMA products of
- * {genotype, missing mask} with 7 base-256 digits of U (closer to the exact dot products than the fp64 GEMM;
- * environment GEMMA_HIP_UTX_I8=0 selects the fp64 GEMM always).  The _d form is asynchronous on its stream for
+ * 0/1/2 and one missing / imputed value -- detected per batch) the same product as 2 D int8 MFMA products of
+ * {genotype, missing mask} with D balanced base-256 digits of U, accumulated exactly in int32.  PRECISION OF THE OPERAND:
+ * D = 7 below n = 16384 -- U is then reproduced to 2^-55 of each column's maximum, i.e. to its last bit in the column's top
+ * binade, and the product is closer to the exact dot products than an fp64 GEMM (which rounds every partial sum).  From
+ * n = 16384 up D = 6: U is ROUNDED to 2^-47 of each column's maximum -- narrower than the reference's fp64 operand (2^-53 per
+ * entry); measured at n = 20000 the rms error of U^T x is 10 x that of the fp64 MFMA GEMM, the maximum equal to it
+ * (DESIGN.md 3.1c), eight orders below the 1e-6 bar on the statistics.  GEMMA_HIP_I8_DIGITS=7 forces the bit-faithful operand at
+ * any n (14 products: 7/6 of the time), GEMMA_HIP_UTX_I8=0 selects the fp64 GEMM always.  The _d form is asynchronous on its stream for
  * GEMMA_GENO_PLINK_2BIT; for fp64 input it synchronises the stream once per call (the hard-call verdict is read back). */
 int gemma_hip_lmm_batch(int geno_kind, const void *geno, size_t l, size_t ld, gemma_sumstat *out);
 int gemma_hip_lmm_batch_d(int geno_kind, const void *geno_d, size_t l, size_t ld,
@@ -319,7 +324,8 @@ int gemma_hip_dbg_utx(int geno_kind, const void *geno, size_t l, size_t ld, int 
  * product of hard calls, 2 / 3 int8-digit product of fixed-point dosages k/100 / k/1000 (BIMBAM mean genotypes,
  * doc/manual.tex:398-404) */
 int gemma_hip_dbg_last_utx_path(int *path);
-/* base-256 digits of U the exact int8 product uses at this n (7; 6 from n = 16384 up; GEMMA_HIP_I8_DIGITS overrides) */
+/* base-256 digits of U the int8 product uses at this n: 7 (U to 2^-55 of the column maximum: bit-faithful); 6 from n = 16384 up
+ * (U rounded to 2^-47 of the column maximum -- see gemma_hip_lmm_batch); GEMMA_HIP_I8_DIGITS=6|7 overrides */
 int gemma_hip_dbg_i8_digits(size_t n, int *digits);
 
 #ifdef __cplusplus

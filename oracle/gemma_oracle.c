@@ -907,6 +907,31 @@ void orc_lmm_batch(int a_mode, size_t n, size_t c, const double *eval, const dou
   free(Uab);
 }
 
+/* Test aid for the two-tier lambda criterion: for every SNP row of UtX and a GIVEN lambda, the relative size
+ * of the Newton step CalcLambda's polish would take from there, |f / f'| / |lambda - f / f'| with f = dev1, f' = dev2 of
+ * LogRL ('R') or LogL ('L') (src/lmm.cpp:2064-2078), and logf(lambda).  The reference reports the iterate BEFORE the one that
+ * met |x_new - x_old| < 1e-5 |x_new| (:2073, :2096): a lambda-hat that differs from the reference's because a Brent / Newton
+ * trip count flipped is still a point where this step is below that threshold; a wrong root is not. */
+void orc_newton_step_rel(char func_name, size_t n, size_t c, const double *eval, const double *UtW, const double *Uty,
+                         const double *UtX, size_t l, const double *lambda, double *step_rel, double *logf) {
+  size_t n_index = (c + 3) * (c + 2) / 2;
+  double *Uab = (double *)calloc(n * n_index, sizeof(double));
+  orc_CalcUab_null(n, c, UtW, Uty, Uab);
+  orc_func_param p = {0, n, c, eval, Uab};
+  param_alloc(&p, n, c);
+  char fn = (func_name == 'R' || func_name == 'r') ? 'R' : 'L';
+  for (size_t s = 0; s < l; ++s) {
+    orc_CalcUab_snp(n, c, UtW, Uty, UtX + s * n, Uab);
+    double f, df;
+    f_dev12(fn, lambda[s], &p, &f, &df);
+    double x1 = lambda[s] - f / df;
+    step_rel[s] = fabs(f / df) / fabs(x1);
+    if (logf) logf[s] = f_logf(fn, lambda[s], &p);
+  }
+  free(p.Hi);
+  free(Uab);
+}
+
 /* ---------------- AnalyzeGene --------------------------------------- */
 /* LMM::AnalyzeGene, src/lmm.cpp:1365-1471: every row of UtY (l x n, SNP-major style) is a rotated PHENOTYPE U^T y_g,
  * Utx is the one fixed tested variable.  Per row: Uab from (UtW, Uty_g) with the x columns zero; param0 carries

@@ -76,6 +76,8 @@ def lib():
                                     C.c_double, C.c_double, C.c_size_t, C.c_double, C.c_double, C.c_int,
                                     dp, C.POINTER(SumStat), C.POINTER(C.c_long)]
         L.orc_lm_batch.argtypes = [C.c_int, C.c_size_t, C.c_size_t, dp, dp, dp, dp, C.c_size_t, C.POINTER(SumStat)]
+        L.orc_newton_step_rel.restype = None
+        L.orc_newton_step_rel.argtypes = [C.c_char, C.c_size_t, C.c_size_t, dp, dp, dp, dp, C.c_size_t, dp, dp, dp]
         L.orc_gene_batch.argtypes = [C.c_int, C.c_size_t, C.c_size_t, dp, dp, dp, dp, C.c_size_t, C.c_double, C.c_double,
                                      C.c_size_t, C.POINTER(SumStat)]
         L.orc_gene_batch.restype = None
@@ -221,6 +223,17 @@ def lmm_batch_UtX(a_mode, ev, UtW, Uty, UtX_snpmajor, l_mle_null=0.0, logl_mle_H
                         out.ctypes.data_as(C.POINTER(SumStat)),
                         diag.ctypes.data_as(C.POINTER(C.c_long)) if want_diag else None)
     return (out, diag) if want_diag else out
+
+
+def newton_step_rel(func, ev, UtW, Uty, UtX_snpmajor, lambdas):
+    """(relative Newton step of CalcLambda's polish from lambdas[s], logf(lambdas[s])) per SNP row -- test aid for the
+    two-tier lambda criterion (orc_newton_step_rel)."""
+    ev = _c64(ev); UtW = _c64(UtW); Uty = _c64(Uty); UtX = _c64(UtX_snpmajor); lam = _c64(lambdas)
+    n, c = UtW.shape
+    l = UtX.shape[0]
+    step = np.zeros(l); logf = np.zeros(l)
+    lib().orc_newton_step_rel(func.encode(), n, c, _dp(ev), _dp(UtW), _dp(Uty), _dp(UtX), l, _dp(lam), _dp(step), _dp(logf))
+    return step, logf
 
 
 def gene_analyze(a_mode, U, ev, UtW, Utx, Y, l_min=1e-5, l_max=1e5, n_region=10):

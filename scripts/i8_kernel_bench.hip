@@ -112,6 +112,14 @@ int main(int argc, char **argv) {
     CK(hipEventElapsedTime(&mms, m0, m1));
     printf("sparse2_meta_kernel: %.3f ms\n", mms);
     g2.AM = AM; g2.Bt = Bt; g2.C = C; g2.ldk = ldk; g2.ldc = npad; g2.strideB = npad * ldk; g2.strideC = mrows * npad;
+    if (getenv("RASTER") && atoi(getenv("RASTER")) > 0) { // cross-XCD raster (s2_build_raster): row blocks of the super-patch
+      std::vector<int2> map;
+      s2_build_raster((int)(lpad / S2_BM), (int)(npad / S2_BN), atoi(getenv("RASTER")), map, getenv("RASTER_PR") ? atoi(getenv("RASTER_PR")) : 8);
+      int2 *dmap = nullptr;
+      CK(hipMalloc(&dmap, map.size() * sizeof(int2)));
+      CK(hipMemcpy(dmap, map.data(), map.size() * sizeof(int2), hipMemcpyHostToDevice));
+      g2.tile_map = dmap;
+    }
     g2.m_row0 = lpad; g2.tiles_m = (int)(lpad / S2_BM); g2.tiles_n = (int)(npad / S2_BN); g2.nk = (int)(ldk / I8_BK);
     g2.gm = gm; g2.fuse = fuse; g2.digits = digits;
     grid2 = dim3((unsigned)(g2.tiles_m * g2.tiles_n), (unsigned)nplanes);
@@ -152,7 +160,7 @@ int main(int argc, char **argv) {
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0));
   CK(hipEventCreate(&e1));
-  const int reps = 3;
+  const int reps = getenv("REPS") ? atoi(getenv("REPS")) : 3;
   CK(hipEventRecord(e0));
   for (int i = 0; i < reps; ++i) launch();
   CK(hipEventRecord(e1));

@@ -145,3 +145,66 @@ def test_seed_plink_carry_reproduces_the_unsharded_chain():
                 rows, _ = run(lo, hi, state["carry"])
                 got += rows
             assert got == full
+
+
+class _FakeCommLib:
+    """Stands in for libgemma_hip.so's communicator entry points (no GPU here): comm_init fails on `bad_rank`."""
+
+    def __init__(self, rank, bad_rank):
+        self.rank, self.bad_rank = rank, bad_rank
+        self.inits = self.finalizes = 0
+
+    def gemma_hip_comm_unique_id(self, buf):
+        return 0
+
+    def gemma_hip_comm_init(self, ident, rank, world):
+        self.inits += 1
+        return 4 if rank == self.bad_rank else 0
+
+    def gemma_hip_comm_finalize(self):
+        self.finalizes += 1
+        return 0
+
+
+def _native_init_worker(rank, world, port, outdir):
+    sys.path.insert(0, ROOT)
+    import time
+
+    import torch
+    import torch.distributed as dist
+    from gemma_amd import _lib as L
+    from gemma_amd import dist as gdist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    fake = _FakeCommLib(rank, bad_rank=1)
+    L.lib = lambda: fake
+    L.check = lambda rc, what="": None
+    torch.cuda.current_device = lambda: 0
+    torch.cuda.set_device = lambda d: None
+    first = gdist.native_comm_init(timeout=20.0)
+    # the second call must return at once on EVERY rank, without a collective (rank 1 alone calls it a third time:
+    # a collective inside would hang it, the join below would time out)
+    t0 = time.time()
+    second = gdist.native_comm_init(timeout=20.0)
+    third = gdist.native_comm_init(timeout=20.0) if rank == 1 else False
+    dt = time.time() - t0
+    with open(os.path.join(outdir, "r%d.txt" % rank), "w") as f:
+        f.write("%d %d %d %d %d %.3f" % (first, second, third, fake.inits, fake.finalizes, dt))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_native_comm_init_failure_is_agreed_and_remembered(tmp_path):
+    """one rank's communicator bootstrap fails -> every rank returns False, the rank that could drops its
+    communicator, and later calls return False on all ranks with no collective (gemma_amd/dist.py)."""
+    import torch.multiprocessing as mp
+    port = _free_port()
+    mp.spawn(_native_init_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0 = open(tmp_path / "r0.txt").read().split()
+    r1 = open(tmp_path / "r1.txt").read().split()
+    assert r0[:3] == ["0", "0", "0"] and r1[:3] == ["0", "0", "0"]
+    assert r0[3] == "1" and r1[3] == "1"          # one attempt each, never a second
+    assert r0[4] == "1" and r1[4] == "0"          # the rank that succeeded finalises its communicator
+    assert float(r0[5]) < 1.0 and float(r1[5]) < 1.0

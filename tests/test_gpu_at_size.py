@@ -12,7 +12,7 @@ path at that n: U^T x through the int8-digit product, lambda search, tests).
 import numpy as np
 import pytest
 
-from test_gpu_parity import _cmp_stats, _plink_case, _record
+from test_gpu_parity import _cmp_stats, _plink_case, _problem, _record
 
 pytestmark = pytest.mark.gpu
 
@@ -98,7 +98,7 @@ def test_config2_n5000_lmm4(gpu_api, oracle, c):
     ref = oracle.lmm_analyze(4, Uh, evh, UtWh, Utyh, X, l_mle_null=nm["l_mle_null"], logl_mle_H0=nm["logl_mle_H0"],
                              plink_nan_rule=1)
     assert np.isfinite(got["p_wald"]).mean() > 0.99
-    _cmp_stats(got[sample], ref, 4, "config2 n=5000 c=%d" % c)
+    _cmp_stats(got[sample], ref, 4, "config2 n=5000 c=%d" % c, _problem(Uh, evh, UtWh, Utyh, X))
 
 
 def test_config4_shape_unfused_int8_planes_n33000(gpu_api, oracle):
@@ -142,7 +142,8 @@ def test_config4_shape_unfused_int8_planes_n33000(gpu_api, oracle):
     ref = oracle.lmm_analyze(1, Uh, ev.cpu().numpy(), UtW.cpu().numpy(), Uty.cpu().numpy(), X,
                              plink_nan_rule=1)
     assert np.isfinite(got["p_wald"]).mean() > 0.99
-    _cmp_stats(got[sample], ref, 1, "config4-shape n=33000 (unfused int8 planes)")
+    _cmp_stats(got[sample], ref, 1, "config4-shape n=33000 (unfused int8 planes)",
+               _problem(Uh, ev.cpu().numpy(), UtW.cpu().numpy(), Uty.cpu().numpy(), X))
 
 
 @pytest.mark.parametrize("ni_total,p", [(611, 257), (1301, 300)])
@@ -169,7 +170,7 @@ def test_unfused_int8_planes_forced_small(gpu_api, oracle, monkeypatch, ni_total
         utx[fuse] = lmm.dbg_utx(raw, L.GENO_PLINK_2BIT, 1)
         got = lmm.batch(raw, L.GENO_PLINK_2BIT)
         lmm.finish()
-        _cmp_stats(got, ref, 1, "plink fuse=%s ni_total=%d" % (fuse, ni_total))
+        _cmp_stats(got, ref, 1, "plink fuse=%s ni_total=%d" % (fuse, ni_total), _problem(U, ev, UtW, Uty, Xn))
     assert np.array_equal(utx["0"], utx["1"])
     exact = oracle.impute_mean(Xn) @ U
     assert np.max(np.abs(utx["0"] - exact)) < 1e-12 * np.max(np.abs(exact)) * n

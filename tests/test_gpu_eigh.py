@@ -297,6 +297,47 @@ def test_eigh_two_stage_4096_device(gpu_api, monkeypatch):
     assert float((w - torch.where(wr < 1e-10, torch.zeros_like(wr), wr)).abs().max() / nrm) < 1e-12
 
 
+@pytest.mark.parametrize("n,odd", [(14080, False), (14337, True)])
+def test_eigh_default_path_at_two_stage_size(gpu_api, monkeypatch, n, odd):
+    """The DEFAULT path at the sizes where it is the two-stage reduction (n >= 14 000: eigh.hip.h eig_two_stage; nothing
+    forced): a kinship-like matrix (centred, one zero eigenvalue, population structure), the same residual / orthogonality
+    bars as at n = 4096, eigenvalues against rocSOLVER.  This is the path the headline bench's setup takes at n = 20 000
+    (persistent bulge chase, dynamic stage-2 back-transformation schedule, paired stage-1 panels); the odd size goes through
+    the (n + 1) embedding.  Reference semantics: src/lapack.cpp:149-291 (dsyevr, eval < 1e-10 -> 0)."""
+    import torch
+    monkeypatch.delenv("GEMMA_HIP_EIGH_STAGES", raising=False)
+    g = torch.Generator(device="cuda").manual_seed(11 + n)
+    p = 2 * n
+    maf = torch.empty(p, dtype=torch.float64, device="cuda").uniform_(0.05, 0.5, generator=g)
+    X = (torch.rand((n, p), dtype=torch.float64, device="cuda", generator=g) < maf).to(torch.float64)
+    X += (torch.rand((n, p), dtype=torch.float64, device="cuda", generator=g) < maf).to(torch.float64)
+    X[: n // 2] += (torch.rand((n // 2, p), dtype=torch.float64, device="cuda", generator=g) < 0.2).to(torch.float64)
+    X -= X.mean(0, keepdim=True)
+    A = X @ X.T / p
+    del X
+    A = (A + A.T) / 2
+    A -= A.mean(0, keepdim=True)
+    A -= A.mean(1, keepdim=True)
+    A = (A + A.T) / 2
+    U = torch.empty_like(A)
+    w = torch.empty(n, dtype=torch.float64, device="cuda")
+    gpu_api.EigenDecomp_Zeroed(A.clone(), U, w)
+    torch.cuda.synchronize()
+    wr = torch.linalg.eigvalsh(A)
+    nrm = wr.abs().max()
+    R = A @ U
+    R -= U * w[None, :]
+    res = torch.linalg.matrix_norm(R) / (nrm * n * EPS)
+    R = U.T @ U
+    R.diagonal().sub_(1.0)
+    orth = torch.linalg.matrix_norm(R) / (n * EPS)
+    everr = (w - torch.where(wr < 1e-10, torch.zeros_like(wr), wr)).abs().max() / nrm
+    print("default-path eigh n=%d: resid %.2f orth %.2f (n*eps), max eval err / ||A|| %.2e" % (n, float(res), float(orth), float(everr)))
+    assert bool((w[1:] >= w[:-1]).all()), "eigenvalues not ascending"
+    assert float(res) < 30 and float(orth) < 30
+    assert float(everr) < 1e-12
+
+
 def test_two_stage_degenerate_inputs(gpu_api, monkeypatch):
     """Inputs whose reflectors vanish (tau = 0 everywhere): a diagonal matrix and a block-diagonal one on the two-stage
     path; and a NaN must be reported, not looped on (the bulge-chase kernel's waits are bounded)."""

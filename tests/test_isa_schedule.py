@@ -34,12 +34,17 @@ def test_sparse2_kernel_steady_state_loop_is_as_written(tmp_path):
     lines = _kernel_text(tmp_path, "i8gemm_sparse2_kernel")
     assert lines, "i8gemm_sparse2_kernel not found in the gfx950 code object"
     ops = [ln.split("//")[0].strip() for ln in lines if ln.strip()]
+    # NO scratch access anywhere in the kernel, not only in the loop: a spill is a vector-memory operation, and the counted
+    # s_waitcnt vmcnt of the LDS-DMA pipeline would then wait for the wrong transfers (round 4: a second copy of the K loop made
+    # the allocator spill and the product came out wrong on a fraction of the tiles)
+    assert not any(o.startswith("scratch_") for o in ops), [o for o in ops if o.startswith("scratch_")][:4]
     # the steady-state loop: the backward branch whose body holds the most matrix instructions
     addr = []
     for ln in lines:
         m = re.search(r"//\s*([0-9A-F]{8,16}):", ln)
         addr.append(int(m.group(1), 16) if m else None)
     best = None
+    loops = []
     for i, op in enumerate(ops):
         m = re.match(r"s_cbranch_scc1\s+(\d+)", op)
         if not m or int(m.group(1)) < 32768:  # backward: the 16-bit offset is negative
@@ -48,6 +53,7 @@ def test_sparse2_kernel_steady_state_loop_is_as_written(tmp_path):
         j = next(k for k in range(i) if addr[k] == target)
         body = ops[j:i + 1]
         nm = sum(("v_mfma" in o) or ("v_smfmac" in o) for o in body)
+        loops.append(body)
         if best is None or nm > best[0]:
             best = (nm, body)
     assert best is not None
