@@ -76,6 +76,10 @@ def parse():
     ap.add_argument("--digits7-steps", type=int, default=2,
                     help="extra untimed-region steps with GEMMA_HIP_I8_DIGITS=7 (U kept to 7 base-256 digits = 2^-55 of each column's maximum, "
                          "below fp64's own rounding) beside the timed region's 6 digits at n >= 16384 (0 = skip)")
+    ap.add_argument("--c4-leg", type=int, default=1,
+                    help="1: after everything else, BASELINE config 4's per-GPU piece at its real size in a child process (n = 50000, one "
+                         "20000-SNP block per step, 2 steps, kinship from 40000 SNPs, its own eigendecomposition, 64 SNPs against the "
+                         "oracle / the reference) -- ~80 s, reported under \"c4_leg\", never part of `value` (0 = skip)")
     ap.add_argument("--child", default="", help=argparse.SUPPRESS)
     ap.add_argument("--child-spec", default="", help=argparse.SUPPRESS)
     ap.add_argument("--seed", type=int, default=20000)
@@ -232,6 +236,12 @@ def main():
 
     api.init(local, verbose=0)
     name, n_cu, hbm = api.device_info()
+    # the library's own communicator (RCCL; its shm test transport only when asked for by name, for N ranks on ONE device in
+    # the tests), created before the setup: the eigensolver uses it (collective decomposition, see below)
+    native = False
+    if world > 1:
+        want_native = os.environ.get("BENCH_DIST_BACKEND", "nccl") == "nccl" or os.environ.get("GEMMA_HIP_COMM", "") == "shm"
+        native = bool(want_native and gdist.native_comm_init())
     n, B = args.n, args.batch
     torch.manual_seed(args.seed + rank)
     gen = torch.Generator(device=dev).manual_seed(args.seed + 1000 * rank)
@@ -254,6 +264,8 @@ def main():
             setup_info["state"] = "loaded from " + args.state_file
             loaded = True
         del st
+    sent_go = False
+    shard_eig = False
     if rank == 0 and not loaded:
         t0 = time.time()
         K = torch.empty((n, n), dtype=torch.float64, device=dev)
@@ -315,16 +327,33 @@ def main():
         # (dsyevr at this n "measured once and reported separately", the reference's -gk beside the GPU kinship)
         if world == 1 and args.cpu_setup and args.cpu_sample > 0:
             cpu_setup = start_cpu_setup(args, np, torch, K, n, B, dev)
+        shard_eig = world > 1 and native and args.eigen in ("auto", "gemma") and os.environ.get("GEMMA_HIP_EIGH_SHARD", "1") != "0"
+        if shard_eig:
+            # every rank needs the centred kinship: in the real flow it HAS it (the SNP-sharded kinship ends in an all-reduce,
+            # gemma_hip_kin_end_keep); here rank 0 built K alone from synthetic blocks, so K travels once
+            t0 = time.time()
+            gdist.broadcast_state_native([torch.ones(1, dtype=torch.float64, device=dev)])  # "a collective decomposition follows"
+            sent_go = True
+            gdist.broadcast_state_native([K])
+            setup_info["kinship_bcast_s"] = round(time.time() - t0, 3)
         t0 = time.time()
         eig = args.eigen
+        prev_t = os.environ.get("GEMMA_HIP_EIGH_TIMING")
+        os.environ["GEMMA_HIP_EIGH_TIMING"] = "1"  # stage seconds for the Amdahl block (gemma_hip_dbg_eigh_last); prints to stderr
         if eig in ("auto", "gemma"):
             try:
                 Kc = K.clone()
-                api.EigenDecomp_Zeroed(Kc, U, ev)
+                if shard_eig:
+                    api.EigenDecomp_Zeroed_sharded(Kc, U, ev)
+                else:
+                    api.EigenDecomp_Zeroed(Kc, U, ev)
                 st = os.environ.get("GEMMA_HIP_EIGH_STAGES", "")
                 ne = n + (n & 1) if (n >= 192 and os.environ.get("GEMMA_HIP_EIGH_PAD", "") != "0") else n  # odd n is padded
                 two = (st == "2" and ne >= 384 or st != "1" and ne >= 14000) and ne % 2 == 0  # eigh.hip.h: eig_two_stage
                 eig = "gemma_hip_eigh (%s)" % ("two-stage: dense -> band -> tridiagonal" if two else "one-stage tridiagonalisation")
+                if shard_eig:
+                    eig += ("; collective over %d ranks: reduction and divide & conquer on every rank, back-transformations shared out by "
+                            "eigenvector, slices exchanged once" % world) if two else "; replicated on every rank (one-stage: nothing is exchanged)"
                 del Kc
             except L.GemmaHipError:
                 if eig == "gemma":
@@ -339,6 +368,18 @@ def main():
         torch.cuda.synchronize()
         setup_info["eigen"] = eig
         setup_info["eigen_s"] = round(time.time() - t0, 3)
+        if prev_t is None:
+            os.environ.pop("GEMMA_HIP_EIGH_TIMING", None)
+        else:
+            os.environ["GEMMA_HIP_EIGH_TIMING"] = prev_t
+        if eig.startswith("gemma_hip_eigh"):
+            import ctypes
+            t8 = (ctypes.c_double * 8)()
+            L.lib().gemma_hip_dbg_eigh_last(t8)
+            if int(t8[6]) == n + (n & 1 if n >= 192 else 0) or int(t8[6]) == n:
+                setup_info["eigen_stages_s"] = {"reduction": round(t8[0], 3), "bulge_chase": round(t8[1], 3), "divide_conquer": round(t8[2], 3),
+                                                "backtransform_q2": round(t8[3], 3), "backtransform_q1": round(t8[4], 3),
+                                                "sort_transpose": round(t8[5], 3)}
         if args.setup_parity:
             # (U, eval) of THIS run, at this n, through the path the library chose: backward error and orthogonality through the
             # library's own fp64 GEMM, in units of n eps (LAPACK's dsyevr test ratios; bars of tests/test_gpu_eigh.py: 30), and
@@ -358,6 +399,8 @@ def main():
                 sp["eigh_what"] = ("||K U - U diag(eval)||_F / (n eps ||K||_2) and ||U^T U - I||_F / (n eps) of this run's n x n "
                                    "eigendecomposition (%s), products on the library's fp64 MFMA GEMM" % eig)
                 try:
+                    if n > 30000:
+                        raise RuntimeError("skipped at n > 30000 (rocSOLVER's eigvalsh takes longer than this library's whole decomposition)")
                     wr = torch.linalg.eigvalsh(K)
                     wr = torch.where(wr < 1e-10, torch.zeros_like(wr), wr)
                     sp["eval_vs_rocsolver_max_rel"] = float((torch.sort(ev)[0] - wr).abs().max()) / knorm
@@ -384,18 +427,33 @@ def main():
         api.profile_read(L.STAGE_UTX_GEMM, reset=True)
         if args.state_file:
             torch.save({"U": U, "ev": ev, "UtW": UtW, "Uty": Uty, "null": null}, args.state_file)
+    if world > 1 and native:
+        # do the other ranks take part in a collective decomposition?  (rank 0 decides: a loaded state file or --eigen torch say no)
+        if rank == 0:
+            if not sent_go:
+                gdist.broadcast_state_native([torch.zeros(1, dtype=torch.float64, device=dev)])
+        else:
+            go = torch.zeros(1, dtype=torch.float64, device=dev)
+            gdist.broadcast_state_native([go])
+            if float(go[0]) == 1.0:
+                shard_eig = True
+                Kr = torch.empty((n, n), dtype=torch.float64, device=dev)
+                gdist.broadcast_state_native([Kr])
+                api.EigenDecomp_Zeroed_sharded(Kr, U, ev)  # the same (U, eval) on every rank: nothing of it is broadcast below
+                del Kr
     t0 = time.time()
     # the single broadcast round: ncclBroadcast issued by the library's own RCCL communicator (csrc/comm.hip.h) when every
     # rank could create it, otherwise the same two collectives through torch.distributed (nccl = RCCL as well)
     bpath = "none (1 rank)"
     if world > 1:
-        # the library's own communicator: RCCL, or -- only when asked for by name, for N ranks on ONE device in the tests --
-        # its shared-memory test transport behind the same entry points (csrc/comm_shm.hpp)
-        want_native = os.environ.get("BENCH_DIST_BACKEND", "nccl") == "nccl" or os.environ.get("GEMMA_HIP_COMM", "") == "shm"
-        if want_native and gdist.native_comm_init():
-            gdist.broadcast_state_native([U, ev, UtW, Uty, null])
+        if native:
+            # after a collective decomposition U and eval are everywhere already: only the rotated covariates / phenotype and the
+            # null model's two scalars travel
+            gdist.broadcast_state_native([UtW, Uty, null] if shard_eig else [U, ev, UtW, Uty, null])
             bpath = "native: ncclBroadcast from libgemma_hip.so's communicator" if os.environ.get("GEMMA_HIP_COMM", "") != "shm" \
                 else "native: libgemma_hip.so's communicator over its shm test transport (GEMMA_HIP_COMM=shm)"
+            if shard_eig:
+                bpath += "; (U, eval) from the collective eigensolver (gemma_hip_eigh_sharded_d), not broadcast"
         else:
             gdist.broadcast_state([U, ev, UtW, Uty, null])
             bpath = "torch.distributed broadcast (%s)" % os.environ.get("BENCH_DIST_BACKEND", "nccl")
@@ -617,6 +675,20 @@ def main():
         p_cfg = {20000: 1000000, 50000: 500000, 5000: 100000, 10000: 500000}.get(n, B * args.steps)
         per_gpu = value / world
         setup_once = sum(float(setup_info.get(k) or 0.0) for k in ("kinship_s", "eigen_s", "broadcast_s"))
+        est = setup_info.get("eigen_stages_s")
+        eig_proj = None
+        if est and world == 1:
+            # the collective decomposition (gemma_hip_eigh_sharded_d): the back-transformations divide by N, the rest does not; the
+            # slices of Z^T travel once (n^2 doubles in all, priced at one xGMI link: 7 links x ~153 GB/s per GPU)
+            serial = est["reduction"] + est["bulge_chase"] + est["divide_conquer"] + est["sort_transpose"]
+            bt = est["backtransform_q2"] + est["backtransform_q1"]
+            other = max(0.0, float(setup_info.get("eigen_s") or 0.0) - serial - bt)  # allocation, copies
+            xchg = 8.0 * n * n / 153e9
+            eig_proj = {str(N): round(serial + other + bt / N + (xchg if N > 1 else 0.0), 3) for N in (1, 2, 4, 8)}
+        eig_note = "eigendecomposition runs on one GPU (replicas only for that stage); ranks idle during it"
+        if shard_eig:
+            eig_note = ("eigendecomposition is a collective (gemma_hip_eigh_sharded_d): reduction + divide & conquer on every rank, the "
+                        "back-transformations shared out by eigenvector; eigen_s above was measured with %d rank(s)" % world)
         line["amdahl"] = {
             "p_total": p_cfg, "setup_once_s": round(setup_once, 3),
             "setup_terms_s": {k: setup_info.get(k) for k in ("kinship_s", "eigen_s", "broadcast_s")},
@@ -624,7 +696,11 @@ def main():
             "assoc_s_per_rank": {str(N): round(p_cfg / N / per_gpu, 3) for N in (1, 2, 4, 8)},
             "projected_total_s": {str(N): round(setup_once + p_cfg / N / per_gpu, 3) for N in (1, 2, 4, 8)},
             "serial_fraction_at_8": round(setup_once / (setup_once + p_cfg / 8 / per_gpu), 4) if setup_once else None,
-            "note": "eigendecomposition runs on one GPU (replicas only for that stage); ranks idle during it"}
+            "eigen_s_collective_projection": eig_proj,
+            "serial_fraction_at_8_collective_eigen": (round((setup_once - eig_proj["1"] + eig_proj["8"]) /
+                                                            (setup_once - eig_proj["1"] + eig_proj["8"] + p_cfg / 8 / per_gpu), 4)
+                                                      if (eig_proj and setup_once) else None),
+            "note": eig_note}
         if fp64_path:
             line["fp64_gemm_path"] = fp64_path
         if dosage_path:
@@ -742,6 +818,8 @@ def main():
             del blocks, out, U
             torch.cuda.empty_cache()
             line["e2e"] = e2e_files(args, n)
+        if world == 1 and args.c4_leg and n == 20000 and args.cpu_sample > 0:
+            line["c4_leg"] = c4_leg(args, t_bench0)
         print(json.dumps(line), flush=True)
     else:
         lmm.finish()
@@ -886,6 +964,39 @@ def finish_cpu_setup(args, cs, t_bench0, setup_info):
     shutil.rmtree(cs["dir"], ignore_errors=True)
     out["setup_parity"] = parity
     return out
+
+
+def c4_leg(args, t_bench0):
+    """BASELINE config 4 (n = 50 000, SNP-sharded over 8 GPUs) is one rank's piece per GPU: this bench itself at n = 50 000 in a
+    child process (the parent's tensors are gone by now), every optional leg off, a 64-SNP sample against the oracle and the
+    reference.  Driver-run evidence of the shape the GPU suite only covers at n = 33 000."""
+    import subprocess
+    if time.time() - t_bench0 > 400.0:
+        return {"skipped": "the bench had already run for %.0f s" % (time.time() - t_bench0)}
+    cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--individuals", "50000", "--batch", "20000", "--steps", "2",
+           "--warmup", "1", "--kin-snps", "40000", "--cpu-sample", "64", "--ref-procs", "1", "--cpu-setup", "0", "--setup-parity", "1",
+           "--fp64-steps", "0", "--dosage-steps", "0", "--miss-leg", "0", "--lowh2-leg", "0", "--digits7-steps", "0", "--e2e-snps", "0",
+           "--c4-leg", "0", "--seed", str(args.seed + 4)]
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    t0 = time.time()
+    try:
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=420)
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        if r.returncode != 0 or not lines:
+            return {"error": (r.stderr or r.stdout)[-300:], "seconds": round(time.time() - t0, 1)}
+        d = json.loads(lines[-1])
+        cb = d.get("cpu_baseline", {})
+        return {"workload": d["config"]["workload"], "value": d["value"], "unit": "SNPs/s per GPU", "ms_per_step": d["ms_per_step"],
+                "steps": d["steps"], "stage_ms_per_step": d["stage_ms_per_step"], "roofline_frac": d["roofline"]["frac"],
+                "utx_digits_note": d["dtype"], "setup": {k: d["config"]["setup"].get(k) for k in ("kinship_s", "eigen_s", "eigen", "eigen_stages_s")},
+                "setup_parity": d.get("setup_parity"),
+                "parity": {k: cb.get(k) for k in ("kind", "sample", "gpu_vs_reference_max_rel_err", "gpu_vs_reference_lambda",
+                                                   "gpu_vs_oracle_max_rel_err", "gpu_vs_oracle_lambda") if k in cb},
+                "projected_8gpu_snps_per_s": round(8 * d["value"], 1), "seconds": round(time.time() - t0, 1)}
+    except Exception as e:  # a reported leg must never take the bench line down
+        return {"error": repr(e)[:300], "seconds": round(time.time() - t0, 1)}
 
 
 def e2e_files(args, n):

@@ -12,7 +12,7 @@ SYMBOLS = [
     "gemma_hip_last_error", "gemma_hip_device_info", "gemma_hip_dgemm", "gemma_hip_dgemm_d",
     "gemma_hip_kin_begin", "gemma_hip_kin_add", "gemma_hip_kin_add_d", "gemma_hip_kin_end",
     "gemma_hip_kin_end_d", "gemma_hip_kin_loco_d", "gemma_hip_snp_qc", "gemma_hip_center", "gemma_hip_center_d", "gemma_hip_eigh",
-    "gemma_hip_eigh_d", "gemma_hip_calc_utx", "gemma_hip_lmm_setup", "gemma_hip_lmm_setup_d",
+    "gemma_hip_eigh_d", "gemma_hip_dbg_eigh_last", "gemma_hip_eigh_sharded_d", "gemma_hip_eigh_kept_K_sharded", "gemma_hip_calc_utx", "gemma_hip_lmm_setup", "gemma_hip_lmm_setup_d",
     "gemma_hip_lmm_null", "gemma_hip_lmm_set_indicator", "gemma_hip_lmm_batch", "gemma_hip_lmm_batch_d",
     "gemma_hip_lmm_assoc_d", "gemma_hip_lmm_finish", "gemma_hip_lm_setup", "gemma_hip_lm_batch", "gemma_hip_lm_batch_d",
     "gemma_hip_lm_finish", "gemma_hip_profile_enable",
@@ -105,6 +105,8 @@ def lib():
     L.gemma_hip_center_d.argtypes = [dp, sz, vp]
     L.gemma_hip_eigh.argtypes = [dp, sz, dp, dp, C.POINTER(cd)]
     L.gemma_hip_eigh_d.argtypes = [dp, sz, dp, dp, C.POINTER(cd), vp]
+    L.gemma_hip_eigh_sharded_d.argtypes = [dp, sz, dp, dp, C.POINTER(cd), vp]
+    L.gemma_hip_dbg_eigh_last.argtypes = [dp]
     L.gemma_hip_calc_utx.argtypes = [dp, dp, sz, sz, dp]
     L.gemma_hip_lmm_setup.argtypes = [C.POINTER(LmmCfg), dp, dp, dp, dp]
     L.gemma_hip_lmm_setup_d.argtypes = [C.POINTER(LmmCfg), dp, dp, dp, dp, vp]
@@ -135,6 +137,7 @@ def lib():
     L.gemma_hip_kin_end_keep.argtypes = [C.POINTER(sz), ci]
     L.gemma_hip_kept_K_get.argtypes = [dp]
     L.gemma_hip_eigh_kept_K.argtypes = [vp, sz, dp, C.POINTER(cd)]
+    L.gemma_hip_eigh_kept_K_sharded.argtypes = [vp, sz, dp, C.POINTER(cd)]
     L.gemma_hip_eigh_keep.argtypes = [dp, sz, dp, C.POINTER(cd)]
     L.gemma_hip_kept_n.argtypes = [C.POINTER(sz)]
     L.gemma_hip_kept_bcast.argtypes = [ci, C.POINTER(cd)]

@@ -150,6 +150,18 @@ def EigenDecomp_Zeroed(G, U, eval_):
     return tr.value
 
 
+def EigenDecomp_Zeroed_sharded(G, U, eval_):
+    """EigenDecomp_Zeroed as a COLLECTIVE over the library's communicator (gemma_amd.dist.native_comm_init): every rank passes
+    the same device matrix G (destroyed) and receives the same (U, eval_); the two back-transformations are shared out by
+    eigenvector.  torch tensors on the device only."""
+    n = G.shape[0]
+    tr = C.c_double()
+    rc = L.lib().gemma_hip_eigh_sharded_d(C.c_void_p(G.data_ptr()), n, C.c_void_p(U.data_ptr()),
+                                          C.c_void_p(eval_.data_ptr()), C.byref(tr), _stream())
+    L.check(rc, "EigenDecomp_Zeroed_sharded")
+    return tr.value
+
+
 def CalcUtX(U, X):
     """UtX = U^T X (src/mathfunc.cpp:504-506).  X: n x m (or n,) numpy."""
     X2 = np.ascontiguousarray(X.reshape(X.shape[0], -1), dtype=np.float64)

@@ -52,7 +52,23 @@ struct GemmArgs {
   int clamp;       // glds kernel: shift ragged last tiles back inside the matrix (needs beta == 0)
   int ablate;      // timing experiments only (GEMMA_HIP_GEMM_ABLATE): 1 = no global loads / LDS stores after
                    // the first K-tile, 2 = no barrier, 4 = fragments read once (results are then wrong)
+  // K slices in ONE launch (round 4; launch_dgemm_ksliced): blockIdx.y = slice, slice ks multiplies K range
+  // [ks * kslice, min(K, (ks + 1) * kslice)) into C + ks * cslice.  Skinny products (128 x m x m: m / 128 output tiles for 256
+  // CUs) fill the chip this way without extra streams -- whose number of hardware queues the library does not control.
+  int kslices = 1;
+  long kslice = 0, cslice = 0;
 };
+template <bool A_KM, bool B_KN>
+__device__ __forceinline__ void gemm_take_slice(GemmArgs &g) {
+  if (g.kslices > 1) {
+    const long ks = blockIdx.y, k0 = ks * g.kslice;
+    const long kn = (g.K - k0 < g.kslice) ? g.K - k0 : g.kslice;
+    g.A += A_KM ? k0 * g.lda : k0;
+    g.B += B_KN ? k0 * g.ldb : k0;
+    g.C += ks * g.cslice;
+    g.K = kn;
+  }
+}
 
 // 16-byte global load of two consecutive doubles with element-wise bounds; `vec_ok` says the
 // address is 16-byte aligned and both elements are in range.
@@ -182,6 +198,7 @@ __device__ __forceinline__ void tile_of_block(const GemmArgs &g, int &tm, int &t
 // unaligned views, element-wise bounds on every access.
 template <bool A_KM, bool B_KN, int NW, bool FULL>
 __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : 2)) void dgemm_mfma_kernel(GemmArgs g) {
+  gemm_take_slice<A_KM, B_KN>(g);
   constexpr int NT = NW * 64;
   constexpr int NLD = 1024 / NT;
   constexpr int WN = NW / 2;        // waves along N (2 along M)
@@ -294,6 +311,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : 2)) void dgemm_mfma_kernel(
 #define GEMMA_SB() __builtin_amdgcn_sched_barrier(0)
 template <bool A_KM, bool B_KN>
 __global__ __launch_bounds__(256, 2) void dgemm_mfma_pipe_kernel(GemmArgs g) {
+  gemm_take_slice<A_KM, B_KN>(g);
   constexpr int NT = 256;
   constexpr int NLD = 4;
   __shared__ __attribute__((aligned(16))) double lds[4 * GEMM_TILE_DOUBLES];
@@ -436,6 +454,7 @@ typedef __attribute__((address_space(3))) void *gemma_lptr_t;
 
 template <bool A_KM, bool B_KN>
 __global__ __launch_bounds__(256, 2) void dgemm_mfma_glds_kernel(GemmArgs g) {
+  gemm_take_slice<A_KM, B_KN>(g);
   __shared__ __attribute__((aligned(1024))) double lds[4 * GEMM_TILE_DOUBLES];
   int tm, tn;
   tile_of_block(g, tm, tn);
@@ -680,13 +699,13 @@ static inline hipError_t launch_dgemm_grid(const GemmArgs &g, hipStream_t s) {
     nblocks = g.tiles_m * g.tiles_n;
   if (nblocks <= 0) return hipSuccess;
   if (FULL && gemm_pipe() == 2 && !g.square_a)
-    hipLaunchKernelGGL((dgemm_mfma_glds_kernel<A_KM, B_KN>), dim3(nblocks), dim3(256), 0, s, g);
+    hipLaunchKernelGGL((dgemm_mfma_glds_kernel<A_KM, B_KN>), dim3(nblocks, g.kslices), dim3(256), 0, s, g);
   else if (FULL && gemm_pipe())
-    hipLaunchKernelGGL((dgemm_mfma_pipe_kernel<A_KM, B_KN>), dim3(nblocks), dim3(256), 0, s, g);
+    hipLaunchKernelGGL((dgemm_mfma_pipe_kernel<A_KM, B_KN>), dim3(nblocks, g.kslices), dim3(256), 0, s, g);
   else if (gemm_waves() == 8)
-    hipLaunchKernelGGL((dgemm_mfma_kernel<A_KM, B_KN, 8, FULL>), dim3(nblocks), dim3(512), 0, s, g);
+    hipLaunchKernelGGL((dgemm_mfma_kernel<A_KM, B_KN, 8, FULL>), dim3(nblocks, g.kslices), dim3(512), 0, s, g);
   else
-    hipLaunchKernelGGL((dgemm_mfma_kernel<A_KM, B_KN, 4, FULL>), dim3(nblocks), dim3(256), 0, s, g);
+    hipLaunchKernelGGL((dgemm_mfma_kernel<A_KM, B_KN, 4, FULL>), dim3(nblocks, g.kslices), dim3(256), 0, s, g);
   return hipGetLastError();
 }
 
@@ -829,6 +848,46 @@ static inline hipError_t launch_dgemm(char ta, char tb, long M, long N, long K, 
   if (tA && tB) return launch_dgemm_t<true, false>(g, s);
   if (!tA && !tB) return launch_dgemm_t<false, true>(g, s);
   return launch_dgemm_t<false, false>(g, s);
+}
+
+// C_ks (ks = 0 .. *nslices - 1, at C + ks * cslice) = alpha op(A) op(B) over the K range of slice ks, ONE launch per kernel
+// variant (interior tiles / edge strips) with the slice in blockIdx.y; the caller adds the slices.  want = slices asked for; the
+// number used (returned in *nslices) keeps every slice at least four K-tiles long.  A K that is not a multiple of the K-tile
+// leaves its last < 16 columns to one extra bounds-checked launch that accumulates into slice 0.
+static inline hipError_t launch_dgemm_ksliced(char ta, char tb, long M, long N, long K, double alpha, const double *A, long lda,
+                                              const double *B, long ldb, double *C, long ldc, long cslice, int want,
+                                              int *nslices, hipStream_t s) {
+  const bool tA = (ta == 'T' || ta == 't'), tB = (tb == 'T' || tb == 't');
+  const long K0 = (K / GEMM_BK) * GEMM_BK, K1 = K - K0;
+  int ns = want < 1 ? 1 : want;
+  while (ns > 1 && K0 / ns < 4 * GEMM_BK) --ns;
+  *nslices = ns;
+  if (ns <= 1 || K0 == 0) {
+    *nslices = 1;
+    return launch_dgemm(ta, tb, M, N, K, alpha, A, lda, B, ldb, 0.0, C, ldc, false, false, s);
+  }
+  const long kt = K0 / GEMM_BK, pt = (kt + ns - 1) / ns; // K-tiles in all, per slice
+  ns = (int)((kt + pt - 1) / pt);                        // slices that are not empty: (ns - 1) pt < kt <= ns pt
+  *nslices = ns;
+  const long per = pt * GEMM_BK;
+  GemmArgs g;
+  g.A = A; g.B = B; g.C = C;
+  g.M = M; g.N = N; g.K = K0;
+  g.lda = lda; g.ldb = ldb; g.ldc = ldc;
+  g.alpha = alpha; g.beta = 0.0;
+  g.tiles_m = g.tiles_n = 0;
+  g.tm0 = g.tn0 = 0;
+  g.syrk_upper = 0; g.clamp = 0; g.square_a = 0; g.ablate = 0; g.gm = 0;
+  g.kslices = ns; g.kslice = per; g.cslice = cslice;
+  hipError_t e;
+  // op(A) = A^T  <=> A stored [k][m]  (KM image);  op(B) = B <=> B stored [k][n] (KN image)
+  if (tA && !tB) e = launch_dgemm_t<true, true>(g, s);
+  else if (tA && tB) e = launch_dgemm_t<true, false>(g, s);
+  else if (!tA && !tB) e = launch_dgemm_t<false, true>(g, s);
+  else e = launch_dgemm_t<false, false>(g, s);
+  if (e != hipSuccess || K1 == 0) return e;
+  const double *A1 = tA ? A + K0 * lda : A + K0, *B1 = tB ? B + K0 : B + K0 * ldb;
+  return launch_dgemm(ta, tb, M, N, K1, alpha, A1, lda, B1, ldb, 1.0, C, ldc, false, false, s);
 }
 
 } // namespace gemma_hip

@@ -32,6 +32,7 @@
 #include <vector>
 
 #include "dgemm_mfma.hip.h"
+#include "eigh_tu.h" // EighShard
 
 namespace gemma_hip {
 
@@ -1044,8 +1045,26 @@ static inline bool eig_two_stage(long n) {
   return n >= 14000;
 }
 
+// Several ranks, one decomposition (round 4).  The eigenvectors are independent through both back-transformations
+// (a row of Z^T never meets another row), and those are 0.8 of 2.3 s at n = 20 000 and 10 of 19 s at n = 50 000.  Every rank
+// runs the reduction and the divide & conquer on its own copy of the matrix -- the same code on the same bits: the results
+// agree bit for bit, which is CHECKED (a hash of the tridiagonal matrix and of the eigenvalues is compared with rank 0's; on
+// any difference rank 0 alone finishes and broadcasts U) --, applies Q2 and Q1 to its own slice of Z^T (whole 64-row blocks),
+// and the slices travel once (one broadcast per rank: an all-gather on the library's two collectives).  One-stage solves
+// (n < 14 000) are replicated whole: nothing to send.
+static double g_eig_last[8] = {0, 0, 0, 0, 0, 0, 0, 0}; // stage seconds of the last solve with GEMMA_HIP_EIGH_TIMING=1
+static inline unsigned long long eig_fnv(unsigned long long h, const void *p, size_t bytes) {
+  const unsigned char *c = static_cast<const unsigned char *>(p);
+  for (size_t i = 0; i < bytes; ++i) {
+    h ^= c[i];
+    h *= 1099511628211ULL;
+  }
+  return h;
+}
+
 // G (n x n symmetric, device, destroyed) -> U (row-major, eigenvector k in column k), eval ascending.
-static inline int eigh_device_core(double *G, long n, double *U, double *eval, hipStream_t s, std::string &msg) {
+static inline int eigh_device_core(double *G, long n, double *U, double *eval, hipStream_t s, std::string &msg,
+                                   const EighShard *sh = nullptr) {
   EigWs ws;
   ws.n = n;
   const double t_enter = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
@@ -1141,15 +1160,84 @@ static inline int eigh_device_core(double *G, long n, double *U, double *eval, h
     rc = eig_stedc(n, hd, he, G, U, ws, s, &Z, dphys, msg);
     if (rc) break;
     if (timing) t2 = now();
+    long row0 = 0, rows = n;
+    bool sharded = false, root_only = false;
+    if (two && sh && sh->world > 1 && sh->bcast && sh->allreduce_sum) {
+      // do all ranks hold the same tridiagonal matrix and the same eigenvalues, bit for bit?
+      unsigned long long hsh = 1469598103934665603ULL;
+      hsh = eig_fnv(hsh, hd.data(), hd.size() * 8);
+      hsh = eig_fnv(hsh, he.data(), he.size() * 8);
+      hsh = eig_fnv(hsh, dphys.data(), dphys.size() * 8);
+      double hv[2] = {(double)(hsh & 0xffffffffULL), (double)(hsh >> 32)}, h0[2] = {0.0, 0.0};
+      if (hipMemcpyAsync(ws.zbuf, hv, 16, hipMemcpyHostToDevice, s) != hipSuccess || sh->bcast(sh->ctx, ws.zbuf, 16, 0, s) ||
+          hipMemcpyAsync(h0, ws.zbuf, 16, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) {
+        msg = "sharded back-transformation: agreement broadcast failed";
+        rc = 4;
+        break;
+      }
+      double differ = (h0[0] != hv[0] || h0[1] != hv[1]) ? 1.0 : 0.0;
+      if (hipMemcpyAsync(ws.zbuf, &differ, 8, hipMemcpyHostToDevice, s) != hipSuccess || sh->allreduce_sum(sh->ctx, ws.zbuf, 1, s) ||
+          hipMemcpyAsync(&differ, ws.zbuf, 8, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) {
+        msg = "sharded back-transformation: agreement all-reduce failed";
+        rc = 4;
+        break;
+      }
+      const char *efd = getenv("GEMMA_HIP_EIGH_SHARD_FORCE_DIFFER"); // tests: take the fall-back branch
+      if (efd && efd[0] == '1') differ = 1.0;
+      if (differ == 0.0) {
+        const long nrb = (n + 63) / 64;
+        const long b0 = nrb * sh->rank / sh->world, b1 = nrb * (sh->rank + 1) / sh->world;
+        row0 = 64 * b0;
+        rows = std::min<long>(n, 64 * b1) - row0;
+        sharded = true;
+      } else {
+        root_only = true; // rank 0 finishes alone and broadcasts (U, eval)
+      }
+    }
     if (two) {
-      rc = eig2_apply_q2(Z, n, w2, s, msg);
-      if (timing) t2a = now();
-      if (!rc) rc = eig2_apply_q1(Z, n, ws, w2, s, msg);
+      if (!(root_only && sh->rank != 0) && rows > 0) {
+        rc = eig2_apply_q2(Z + row0 * n, n, rows, w2, s, msg);
+        if (timing) t2a = now();
+        if (!rc) rc = eig2_apply_q1(Z + row0 * n, n, rows, ws, w2, s, msg);
+      }
     } else {
       rc = eig_backtransform(Z, n, ws, s, msg);
     }
+    if (sharded) {
+      // every rank tells the others how its slice went before anybody waits for it
+      double bad = rc ? 1.0 : 0.0;
+      if (hipMemcpyAsync(ws.zbuf, &bad, 8, hipMemcpyHostToDevice, s) != hipSuccess || sh->allreduce_sum(sh->ctx, ws.zbuf, 1, s) ||
+          hipMemcpyAsync(&bad, ws.zbuf, 8, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) {
+        if (!rc) { msg = "sharded back-transformation: status all-reduce failed"; rc = 4; }
+        break;
+      }
+      if (bad != 0.0) {
+        if (!rc) { msg = "sharded back-transformation: another rank failed"; rc = 4; }
+        break;
+      }
+      const long nrb = (n + 63) / 64;
+      for (int r = 0; r < sh->world && !rc; ++r) {
+        const long b0 = nrb * r / sh->world, b1 = nrb * (r + 1) / sh->world;
+        const long r0 = 64 * b0, rr = std::min<long>(n, 64 * b1) - r0;
+        if (rr > 0 && sh->bcast(sh->ctx, Z + r0 * n, (size_t)rr * n * 8, r, s)) {
+          msg = "sharded back-transformation: slice broadcast failed";
+          rc = 4;
+        }
+      }
+    }
     if (rc) break;
     if (timing) t3 = now();
+    if (timing && sharded)
+      fprintf(stderr, "gemma_hip_eigh n=%ld: rank %d of %d back-transformed rows %ld .. %ld of Z^T\n", n, sh->rank, sh->world, row0,
+              row0 + rows);
+    if (root_only && sh->rank != 0) {
+      // rank 0's result arrives as it is (U, then eval)
+      if (sh->bcast(sh->ctx, U, nn * 8, 0, s) || sh->bcast(sh->ctx, eval, (size_t)n * 8, 0, s) || hipStreamSynchronize(s) != hipSuccess) {
+        msg = "sharded back-transformation: fall-back broadcast failed";
+        rc = 4;
+      }
+      break;
+    }
     std::vector<int> perm(n);
     for (long i = 0; i < n; ++i) perm[i] = (int)i;
     std::stable_sort(perm.begin(), perm.end(), [&](int a, int c) { return dphys[a] < dphys[c]; });
@@ -1171,9 +1259,20 @@ static inline int eigh_device_core(double *G, long n, double *U, double *eval, h
       msg = "final transpose failed";
       rc = 4;
     }
+    if (!rc && root_only && (sh->bcast(sh->ctx, U, nn * 8, 0, s) || sh->bcast(sh->ctx, eval, (size_t)n * 8, 0, s) ||
+                             hipStreamSynchronize(s) != hipSuccess)) {
+      msg = "sharded back-transformation: fall-back broadcast failed";
+      rc = 4;
+    }
   } while (0);
   (void)hipStreamSynchronize(s);
   if (timing && rc == 0 && n > 1) {
+    // kept for gemma_hip_dbg_eigh_last: {reduction to band / tridiagonal, bulge chase, divide & conquer, Q2, Q1 (one-stage: the
+    // whole back-transformation), sort + transpose}
+    const double tend = now();
+    g_eig_last[0] = two ? t1a - t0 : t1 - t0; g_eig_last[1] = two ? t1 - t1a : 0.0; g_eig_last[2] = t2 - t1;
+    g_eig_last[3] = two ? t2a - t2 : 0.0; g_eig_last[4] = two ? t3 - t2a : t3 - t2; g_eig_last[5] = tend - t3;
+    g_eig_last[6] = (double)n; g_eig_last[7] = two ? 2.0 : 1.0;
     if (two)
       fprintf(stderr, "gemma_hip_eigh n=%ld (two-stage): dense->band %.3f s, band->tridiagonal %.3f s, divide&conquer %.3f s, "
                       "back-transform Q2 %.3f s, Q1 %.3f s, sort+transpose %.3f s\n", n, t1a - t0, t1 - t1a, t2 - t1,
@@ -1207,9 +1306,10 @@ __global__ void eig_unpad_kernel(const double *__restrict__ Up, const double *__
     if (i == 0) eval[k] = evp[ks];
   }
 }
-static inline int eigh_device(double *G, long n, double *U, double *eval, hipStream_t s, std::string &msg) {
+static inline int eigh_device(double *G, long n, double *U, double *eval, hipStream_t s, std::string &msg,
+                              const EighShard *sh = nullptr) {
   const char *ep = getenv("GEMMA_HIP_EIGH_PAD"); // 0: odd n on the unaligned paths (tests)
-  if ((n & 1) == 0 || n < 192 || (ep && ep[0] == '0')) return eigh_device_core(G, n, U, eval, s, msg);
+  if ((n & 1) == 0 || n < 192 || (ep && ep[0] == '0')) return eigh_device_core(G, n, U, eval, s, msg, sh);
   const long m = n + 1;
   double *Gp = nullptr, *Up = nullptr, *evp = nullptr;
   auto cleanup = [&]() {
@@ -1222,7 +1322,7 @@ static inline int eigh_device(double *G, long n, double *U, double *eval, hipStr
       hipMalloc(reinterpret_cast<void **>(&evp), (size_t)m * 8) != hipSuccess) {
     (void)hipGetLastError();
     cleanup();
-    return eigh_device_core(G, n, U, eval, s, msg); // not enough room for the padded copy: the slower unaligned path
+    return eigh_device_core(G, n, U, eval, s, msg, sh); // not enough room for the padded copy: the slower unaligned path
   }
   std::vector<double> hdiag((size_t)n);
   if (hipMemcpy2DAsync(hdiag.data(), 8, G, (size_t)(n + 1) * 8, 8, (size_t)n, hipMemcpyDeviceToHost, s) != hipSuccess ||
@@ -1235,7 +1335,7 @@ static inline int eigh_device(double *G, long n, double *U, double *eval, hipStr
   for (long i = 0; i < n; ++i) sigma += hdiag[i];
   sigma /= (double)n;
   hipLaunchKernelGGL(eig_pad_kernel, dim3((unsigned)m), dim3(256), 0, s, G, n, Gp, sigma);
-  int rc = eigh_device_core(Gp, m, Up, evp, s, msg);
+  int rc = eigh_device_core(Gp, m, Up, evp, s, msg, sh);
   if (rc) {
     cleanup();
     return rc;
@@ -1252,7 +1352,7 @@ static inline int eigh_device(double *G, long n, double *U, double *eval, hipStr
     if (std::fabs(last[k]) > std::fabs(last[kdrop])) kdrop = k;
   if (!(std::fabs(last[kdrop]) > 1.0 - 1e-9)) { // cannot happen for an exactly decoupled entry; never guess
     cleanup();
-    return eigh_device_core(G, n, U, eval, s, msg);
+    return eigh_device_core(G, n, U, eval, s, msg, sh);
   }
   hipLaunchKernelGGL(eig_unpad_kernel, dim3((unsigned)n), dim3(256), 0, s, Up, evp, n, kdrop, U, eval);
   const bool ok = hipGetLastError() == hipSuccess && hipStreamSynchronize(s) == hipSuccess;

@@ -525,38 +525,53 @@ __global__ __launch_bounds__(256) void sb_tfactor_kernel(const double *__restric
 // recurrence (one wavefront each, side by side: 32 steps instead of 128), then two levels of two small products.  ~25 us
 // instead of 370 us per panel.
 constexpr int TF_LD = 65;
-constexpr int TF_LDS_DOUBLES = 3 * 64 * TF_LD;
+constexpr int TF_LDS_DOUBLES = 4 * 64 * TF_LD;
+// Round 4: every block of S a phase multiplies with is staged in LDS first (Sb) -- the recurrences and the small products read
+// S from global memory inside their inner loops before: 134 us per panel, not the 25 the arithmetic needs.
 __global__ __launch_bounds__(256) void sb_tfactor_blocked_kernel(const double *__restrict__ S,
                                                                  const double *__restrict__ tau, double *__restrict__ T) {
   extern __shared__ double e2sm[];
   double *A0 = e2sm, *A1 = e2sm + 64 * TF_LD, *X = e2sm + 2 * 64 * TF_LD; // A0, A1: the 64 x 64 diagonal blocks of T
+  double *Sb = e2sm + 3 * 64 * TF_LD;
+  __shared__ double stau[E2_B];
   const int t = threadIdx.x;
-  for (int idx = t; idx < TF_LDS_DOUBLES; idx += 256) e2sm[idx] = 0.0;
+  for (int idx = t; idx < 3 * 64 * TF_LD; idx += 256) e2sm[idx] = 0.0;
+  if (t < E2_B) stau[t] = tau[t];
+  // the four 32 x 32 diagonal blocks of S: Sb[(b * 32 + r) * 33 + c] = S[32 b + r][32 b + c]
+  for (int idx = t; idx < 4 * 32 * 32; idx += 256) {
+    const int b = idx >> 10, r = (idx >> 5) & 31, c = idx & 31;
+    Sb[(b * 32 + r) * 33 + c] = S[(32 * b + r) * E2_B + 32 * b + c];
+  }
   __syncthreads();
   {
     const int b = t >> 6, l = t & 63; // block b: rows / columns 32 b .. 32 b + 31 of T
     double *Ab = (b >> 1) ? A1 : A0;
     const int o = 32 * (b & 1), g0 = 32 * b;
+    const double *Sd = Sb + b * 32 * 33;
     for (int i = 0; i < 32; ++i) {
-      const double ti = tau[g0 + i];
+      const double ti = stau[g0 + i];
       if (l < i) {
         double acc = 0.0;
-        for (int c = l; c < i; ++c) acc += Ab[(o + l) * TF_LD + o + c] * S[(g0 + c) * E2_B + g0 + i];
+        for (int c = l; c < i; ++c) acc += Ab[(o + l) * TF_LD + o + c] * Sd[c * 33 + i];
         Ab[(o + l) * TF_LD + o + i] = -ti * acc;
       }
       if (l == i) Ab[(o + i) * TF_LD + o + i] = ti;
       __syncthreads();
     }
   }
-  { // level 1: inside each 64-block, T01 = -T00 (S01 T11) with 32 x 32 blocks
+  { // level 1: inside each 64-block, T01 = -T00 (S01 T11) with 32 x 32 blocks; Sb[(p * 32 + r) * 33 + k] = S[64 p + r][64 p + 32 + k]
+    for (int idx = t; idx < 2 * 32 * 32; idx += 256) {
+      const int p = idx >> 10, r = (idx >> 5) & 31, k = idx & 31;
+      Sb[(p * 32 + r) * 33 + k] = S[(64 * p + r) * E2_B + 64 * p + 32 + k];
+    }
+    __syncthreads();
     const int p = t >> 7;
     double *Ap = p ? A1 : A0;
-    const int gp = 64 * p;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       const int idx = (t & 127) * 8 + e, r = idx >> 5, c = idx & 31;
       double acc = 0.0;
-      for (int k = 0; k <= c; ++k) acc += S[(gp + r) * E2_B + gp + 32 + k] * Ap[(32 + k) * TF_LD + 32 + c];
+      for (int k = 0; k <= c; ++k) acc += Sb[(p * 32 + r) * 33 + k] * Ap[(32 + k) * TF_LD + 32 + c];
       X[(p * 32 + r) * TF_LD + c] = acc;
     }
     __syncthreads();
@@ -569,11 +584,16 @@ __global__ __launch_bounds__(256) void sb_tfactor_blocked_kernel(const double *_
     }
     __syncthreads();
   }
-  { // level 2: T[0:64, 64:128] = -T00 (S[0:64, 64:128] T11)
+  { // level 2: T[0:64, 64:128] = -T00 (S[0:64, 64:128] T11); Sb[r * 65 + k] = S[r][64 + k]
+    for (int idx = t; idx < 64 * 64; idx += 256) {
+      const int r = idx >> 6, k = idx & 63;
+      Sb[r * TF_LD + k] = S[r * E2_B + 64 + k];
+    }
+    __syncthreads();
     const int r = t >> 2, c0 = (t & 3) * 16;
     for (int c = c0; c < c0 + 16; ++c) {
       double acc = 0.0;
-      for (int k = 0; k <= c; ++k) acc += S[r * E2_B + 64 + k] * A1[k * TF_LD + c];
+      for (int k = 0; k <= c; ++k) acc += Sb[r * TF_LD + k] * A1[k * TF_LD + c];
       X[r * TF_LD + c] = acc;
     }
     __syncthreads();
@@ -976,6 +996,7 @@ __global__ __launch_bounds__(256) void q2_pack_kernel(Q2PackArgs g) {
 
 struct Q2ApplyArgs {
   double *ZT;
+  long nrows; // rows of Z^T (eigenvectors) this launch transforms: n, or one rank's slice (eigenvectors are independent)
   long n;
   const double *pack;
   const long *goff;
@@ -1034,7 +1055,7 @@ __global__ __launch_bounds__(256, 2) void q2_apply_kernel(Q2ApplyArgs g) {
     kend = g.kseg[segi + 1];
   }
   const long row = (long)rb * 64 + wave * 16 + li;
-  const bool rok = row < n;
+  const bool rok = row < g.nrows;
   double *zrow = g.ZT + (rok ? row : 0) * n;
   {
     const long lim0 = n - 2 - (long)kfirst * E2_B; // first group of this task: step kfirst, its last sweep block
@@ -1171,6 +1192,7 @@ struct Eig2Ws {
   double *P256 = nullptr, *Tpair = nullptr; // Q1 applied two panels at a time: three n x 256 buffers, one 256 x 256 factor
   int *prog = nullptr; // progress counters of the persistent bulge chase (+ the error flag)
   int *pbar = nullptr; // error flag of the persistent panel kernel ([1])
+  double *ZS = nullptr; // K slices of V^T A22: E2_MAXSLICE x 128 x n
   double *ppart = nullptr, *pheads = nullptr; // its self-validating slots: [step][workgroup][row], [step][row]
   int *q2sync = nullptr; // q2_apply_kernel's task counter, error flag, per-row-block progress; then the segment table
   long ngroups = 0, kmaxall = 0, nJ = 0;
@@ -1201,82 +1223,32 @@ static inline int eig2_dgemm_split2(char ta, char tb, long M, long N, long K, do
   return 0;
 }
 
-// The same cut FOUR ways (round 4): at n = 20 000 a half of the skinny product V^T A22 is 60-150 workgroups with a K loop of
+// K SLICES IN ONE LAUNCH (round 4): at n = 20 000 a half of the skinny product V^T A22 is 60-150 workgroups with a K loop of
 // thousands of steps each -- the two halves together left half of the chip idle (1.74 ms for 0.76 ms of matrix work at
-// m = 14 752).  Four K ranges on four streams (the caller's, the GEMM side stream, two more created on first use); the parts
-// land in four buffers and e2_sum4_kernel adds them in a fixed order.  Falls back to the two-way cut when the extra streams
-// cannot be created or K is short.
-struct Eig2Streams {
-  hipStream_t st[2] = {nullptr, nullptr};
-  hipEvent_t ready = nullptr, done[2] = {nullptr, nullptr};
-  bool tried = false;
-};
-static Eig2Streams g_e2s;
-static inline bool eig2_streams_init() {
-  if (g_e2s.tried) return g_e2s.st[1] != nullptr;
-  g_e2s.tried = true;
-  bool ok = hipEventCreateWithFlags(&g_e2s.ready, hipEventDisableTiming) == hipSuccess;
-  for (int i = 0; i < 2 && ok; ++i)
-    ok = hipStreamCreateWithFlags(&g_e2s.st[i], hipStreamNonBlocking) == hipSuccess &&
-         hipEventCreateWithFlags(&g_e2s.done[i], hipEventDisableTiming) == hipSuccess;
-  if (!ok) {
-    (void)hipGetLastError();
-    g_e2s.st[0] = g_e2s.st[1] = nullptr;
-  }
-  return ok;
-}
-static inline void eig2_streams_destroy() {
-  for (int i = 0; i < 2; ++i) {
-    if (g_e2s.st[i]) (void)hipStreamDestroy(g_e2s.st[i]);
-    if (g_e2s.done[i]) (void)hipEventDestroy(g_e2s.done[i]);
-  }
-  if (g_e2s.ready) (void)hipEventDestroy(g_e2s.ready);
-  g_e2s = Eig2Streams();
-}
-// D[r][c] = A[r][c] + B[r][c] + C[r][c] + E[r][c] (rows x cols, common leading dimension ld), in that order
-__global__ void e2_sum4_kernel(double *D, const double *A, const double *__restrict__ B,
-                               const double *__restrict__ C, const double *__restrict__ E, long cols, long ld) {
+// m = 14 752).  The GEMM takes the slice from blockIdx.y (dgemm_mfma.hip.h: launch_dgemm_ksliced), so that ~2 workgroups per
+// CU exist whatever m is; the slices land in w2.ZS and e2_sumk_kernel adds them in slice order (fixed: deterministic).  A first
+// version put four K ranges on four streams: two of them shared a hardware queue (the runtime hands out four per process) and
+// ran one after the other.
+// D[r][c] = sum_k P[k * stride + r * ld + c] (rows x cols), k ascending
+__global__ void e2_sumk_kernel(double *__restrict__ D, const double *__restrict__ P, int ns, long stride, long cols, long ld) {
   const long c = ((long)blockIdx.x * 256 + threadIdx.x) * 2, r = blockIdx.y;
   if (c >= cols) return;
   const long o = r * ld + c;
   if (c + 1 < cols) {
-    const e2_v2 a = *reinterpret_cast<const e2_v2 *>(A + o), b = *reinterpret_cast<const e2_v2 *>(B + o);
-    const e2_v2 cc = *reinterpret_cast<const e2_v2 *>(C + o), e = *reinterpret_cast<const e2_v2 *>(E + o);
-    e2_v2 d = {((a[0] + b[0]) + cc[0]) + e[0], ((a[1] + b[1]) + cc[1]) + e[1]};
-    *reinterpret_cast<e2_v2 *>(D + o) = d;
+    e2_v2 acc = *reinterpret_cast<const e2_v2 *>(P + o);
+    for (int k = 1; k < ns; ++k) {
+      const e2_v2 x = *reinterpret_cast<const e2_v2 *>(P + (long)k * stride + o);
+      acc[0] += x[0];
+      acc[1] += x[1];
+    }
+    *reinterpret_cast<e2_v2 *>(D + o) = acc;
   } else {
-    D[o] = ((A[o] + B[o]) + C[o]) + E[o];
+    double acc = P[o];
+    for (int k = 1; k < ns; ++k) acc += P[(long)k * stride + o];
+    D[o] = acc;
   }
 }
-// C[0] + C[1] + C[2] + C[3] = alpha op(A) op(B); returns 4 when it ran four ways, 2 when it fell back to the two-way cut
-// (C[0], C[1] then hold the halves), < 0 on error (msg set)
-static inline int eig2_dgemm_split4(char ta, char tb, long M, long N, long K, double alpha, const double *A, long lda,
-                                    const double *B, long ldb, double *const C[4], long ldc, hipStream_t s, std::string &msg) {
-  const long Kq = (K / 4) / GEMM_BK * GEMM_BK;
-  const char *e4 = getenv("GEMMA_HIP_EIGH_SPLIT4"); // 0: the two-way cut of rounds 2-3
-  if ((e4 && e4[0] == '0') || !g_gemm_aux.stream || Kq < 4 * GEMM_BK || !eig2_streams_init()) {
-    const int rc = eig2_dgemm_split2(ta, tb, M, N, K, alpha, A, lda, B, ldb, C[0], C[1], ldc, s, msg);
-    return rc ? -1 : 2;
-  }
-  const bool tA = (ta == 'T'), tB = (tb == 'T');
-  hipStream_t st[4] = {s, g_gemm_aux.stream, g_e2s.st[0], g_e2s.st[1]};
-  hipEvent_t dn[4] = {nullptr, g_gemm_aux.done, g_e2s.done[0], g_e2s.done[1]};
-  auto chk = [&](hipError_t e, const char *what) {
-    if (e != hipSuccess) msg = std::string(what) + ": " + hipGetErrorString(e);
-    return e == hipSuccess;
-  };
-  if (!chk(hipEventRecord(g_e2s.ready, s), "split4 record")) return -1;
-  for (int i = 3; i >= 0; --i) { // the caller's stream last: its part runs beside the others
-    const long k0 = i * Kq, kn = (i == 3) ? K - 3 * Kq : Kq;
-    const double *Ai = tA ? A + k0 * lda : A + k0, *Bi = tB ? B + k0 : B + k0 * ldb;
-    if (i > 0 && !chk(hipStreamWaitEvent(st[i], g_e2s.ready, 0), "split4 wait")) return -1;
-    if (!chk(launch_dgemm(ta, tb, M, N, kn, alpha, Ai, lda, Bi, ldb, 0.0, C[i], ldc, false, false, st[i]), "split4 gemm")) return -1;
-    if (i > 0 && !chk(hipEventRecord(dn[i], st[i]), "split4 record")) return -1;
-  }
-  for (int i = 1; i < 4; ++i)
-    if (!chk(hipStreamWaitEvent(s, dn[i], 0), "split4 join")) return -1;
-  return 4;
-}
+constexpr int E2_MAXSLICE = 8;
 
 static inline int eig2_gram(const double *X, const double *Y, long ld, long K, double *P, double *S, hipStream_t s,
                             std::string &msg) {
@@ -1366,16 +1338,26 @@ static inline int eig2_sy2sb(double *A, long n, EigWs &ws, Eig2Ws &w2, hipStream
     double *SA = w2.YT, *SB = w2.YT + (size_t)2 * E2_B * n; // stacked operands [V; W] and [W; V], 256 x m each (ld n)
     double *Wr = SA + (size_t)E2_B * n;
     {
-      // four K ranges of V^T A22 into WT, SB, SB + 128 n and the (still unused) first half of SA
-      double *const parts[4] = {ws.WT, SB, SB + (size_t)E2_B * n, SA};
-      const int ways = eig2_dgemm_split4('N', 'N', E2_B, m, m, 1.0, Vr, n, A22, n, parts, n, s, msg);
-      if (ways < 0) return 4;
-      if (ways == 4) {
-        hipLaunchKernelGGL(e2_sum4_kernel, dim3((unsigned)((m / 2 + 255) / 256 + 1), (unsigned)E2_B), dim3(256), 0, s, ws.WT, ws.WT, SB,
-                           SB + (size_t)E2_B * n, SA, m, n);
-        EIG_HIP(hipGetLastError());
-        EIG_HIP(launch_dgemm('T', 'N', E2_B, m, E2_B, 1.0, T, E2_B, ws.WT, n, 0.0, Wr, n, false, false, s));
+      // Z1 = V^T A22 in K slices (about two workgroups per CU), summed into WT; GEMMA_HIP_EIGH_KSLICES=1: the two-way cut on two
+      // streams of rounds 2-3
+      const char *eks = getenv("GEMMA_HIP_EIGH_KSLICES");
+      const long tiles = (m + GEMM_BN - 1) / GEMM_BN;
+      int want = eks ? atoi(eks) : (int)std::min<long>(E2_MAXSLICE, std::max<long>(1, (2L * ncu + tiles - 1) / tiles));
+      if (want > E2_MAXSLICE) want = E2_MAXSLICE;
+      if (want >= 2 && w2.ZS) {
+        int ns = 1;
+        EIG_HIP(launch_dgemm_ksliced('N', 'N', E2_B, m, m, 1.0, Vr, n, A22, n, w2.ZS, n, (long)E2_B * n, want, &ns, s));
+        if (ns > 1) {
+          hipLaunchKernelGGL(e2_sumk_kernel, dim3((unsigned)((m / 2 + 255) / 256 + 1), (unsigned)E2_B), dim3(256), 0, s, ws.WT, w2.ZS, ns,
+                             (long)E2_B * n, m, n);
+          EIG_HIP(hipGetLastError());
+          EIG_HIP(launch_dgemm('T', 'N', E2_B, m, E2_B, 1.0, T, E2_B, ws.WT, n, 0.0, Wr, n, false, false, s));
+        } else {
+          EIG_HIP(launch_dgemm('T', 'N', E2_B, m, E2_B, 1.0, T, E2_B, w2.ZS, n, 0.0, Wr, n, false, false, s));
+        }
       } else {
+        rc = eig2_dgemm_split2('N', 'N', E2_B, m, m, 1.0, Vr, n, A22, n, ws.WT, SB, n, s, msg);
+        if (rc) return rc;
         EIG_HIP(launch_dgemm('T', 'N', E2_B, m, E2_B, 1.0, T, E2_B, ws.WT, n, 0.0, Wr, n, false, false, s));
         EIG_HIP(launch_dgemm('T', 'N', E2_B, m, E2_B, 1.0, T, E2_B, SB, n, 1.0, Wr, n, false, false, s));
       }
@@ -1538,12 +1520,12 @@ static inline int eig2_sb2st(long n, EigWs &ws, Eig2Ws &w2, hipStream_t s, std::
 }
 
 // Z^T <- Z^T Q2^T (the reflectors of the bulge chase)
-static inline int eig2_apply_q2(double *ZT, long n, Eig2Ws &w2, hipStream_t s, std::string &msg) {
+static inline int eig2_apply_q2(double *ZT, long n, long nrows, Eig2Ws &w2, hipStream_t s, std::string &msg) {
   Q2PackArgs pa{w2.V2, w2.tau2, n, w2.goff, w2.pack};
   hipLaunchKernelGGL(q2_pack_kernel, dim3((unsigned)w2.nJ, (unsigned)w2.kmaxall), dim3(256), 0, s, pa);
   EIG_HIP(hipGetLastError());
-  Q2ApplyArgs aa{ZT, n, w2.pack, w2.goff, (int)w2.nJ, (int)w2.kmaxall, nullptr, nullptr, 0, 0};
-  const int nrb = (int)((n + 63) / 64);
+  Q2ApplyArgs aa{ZT, nrows, n, w2.pack, w2.goff, (int)w2.nJ, (int)w2.kmaxall, nullptr, nullptr, 0, 0};
+  const int nrb = (int)((nrows + 63) / 64);
   int cus = 0;
   {
     int dev = 0;
@@ -1606,7 +1588,7 @@ static inline int eig2_apply_q2(double *ZT, long n, Eig2Ws &w2, hipStream_t s, s
 }
 
 // Z^T <- Z^T Q1^T (stage-1 panels, compact WY: three GEMMs per panel as in eig_backtransform)
-static inline int eig2_apply_q1(double *ZT, long n, EigWs &ws, Eig2Ws &w2, hipStream_t s, std::string &msg) {
+static inline int eig2_apply_q1(double *ZT, long n, long nrows, EigWs &ws, Eig2Ws &w2, hipStream_t s, std::string &msg) {
   const long nb2 = (long)E2_B * E2_B;
   long npan = 0;
   for (long j0 = 0; n - (j0 + E2_B) >= 2; j0 += E2_B) ++npan;
@@ -1640,11 +1622,11 @@ static inline int eig2_apply_q1(double *ZT, long n, EigWs &ws, Eig2Ws &w2, hipSt
     }
     double *P = two ? w2.P256 : ws.P, *P2 = two ? w2.P256 + (size_t)n * kp : ws.P2;
     double *Pb = two ? w2.P256 + (size_t)2 * n * kp : w2.YT;
-    int rc = eig2_dgemm_split2('N', 'T', n, kp, Kc, 1.0, ZT + c0, n, Y, n, P, Pb, kp, s, msg);
+    int rc = eig2_dgemm_split2('N', 'T', nrows, kp, Kc, 1.0, ZT + c0, n, Y, n, P, Pb, kp, s, msg);
     if (rc) return rc;
-    EIG_HIP(launch_dgemm('N', 'T', n, kp, kp, 1.0, P, kp, T, kp, 0.0, P2, kp, false, false, s));
-    EIG_HIP(launch_dgemm('N', 'T', n, kp, kp, 1.0, Pb, kp, T, kp, 1.0, P2, kp, false, false, s));
-    EIG_HIP(launch_dgemm('N', 'N', n, Kc, kp, -1.0, P2, kp, Y, n, 1.0, ZT + c0, n, false, false, s));
+    EIG_HIP(launch_dgemm('N', 'T', nrows, kp, kp, 1.0, P, kp, T, kp, 0.0, P2, kp, false, false, s));
+    EIG_HIP(launch_dgemm('N', 'T', nrows, kp, kp, 1.0, Pb, kp, T, kp, 1.0, P2, kp, false, false, s));
+    EIG_HIP(launch_dgemm('N', 'N', nrows, Kc, kp, -1.0, P2, kp, Y, n, 1.0, ZT + c0, n, false, false, s));
     pnl = pa - 1;
   }
   return 0;
@@ -1664,7 +1646,7 @@ static inline bool eig2_alloc(long n, EigWs &ws, Eig2Ws &w2) {
   }
   w2.ngroups = goff[w2.nJ];
   const size_t nwg_panel = (size_t)(n + SB_COLS - 1) / SB_COLS, nwg_gram = (size_t)(n + GR_CH - 1) / GR_CH;
-  bool ok = ws.get(w2.Bd, (size_t)(n + E2_B) * E2_LDB) && ws.get(w2.Bd0, (size_t)(n + E2_B) * E2_LDB) && ws.get(w2.part, 2 * std::max(nwg_panel, (size_t)(n + E2_B - 1) / E2_B) * E2_B) && ws.get(w2.pbar, 4) && ws.get(w2.ppart, (size_t)E2_B * std::min<size_t>((size_t)(n + E2_B - 1) / E2_B, 1024) * E2_B) && ws.get(w2.pheads, (size_t)E2_B * E2_B) && ws.get(w2.heads, 2 * E2_B) &&
+  bool ok = ws.get(w2.Bd, (size_t)(n + E2_B) * E2_LDB) && ws.get(w2.Bd0, (size_t)(n + E2_B) * E2_LDB) && ws.get(w2.part, 2 * std::max(nwg_panel, (size_t)(n + E2_B - 1) / E2_B) * E2_B) && ws.get(w2.pbar, 4) && ws.get(w2.ppart, (size_t)E2_B * std::min<size_t>((size_t)(n + E2_B - 1) / E2_B, 1024) * E2_B) && ws.get(w2.pheads, (size_t)E2_B * E2_B) && ws.get(w2.ZS, (size_t)E2_MAXSLICE * E2_B * n) && ws.get(w2.heads, 2 * E2_B) &&
             ws.get(w2.betas, n) && ws.get(w2.gramP, nwg_gram * E2_B * E2_B) && ws.get(w2.YT, (size_t)4 * E2_B * n) &&
             ws.get(w2.V2, (size_t)w2.kmaxall * n * E2_B) && ws.get(w2.tau2, (size_t)w2.kmaxall * n) &&
             ws.get(w2.pack, (size_t)w2.ngroups * E2_PACK) && ws.get(w2.goff, (size_t)w2.nJ + 1) &&

@@ -30,13 +30,16 @@ struct TuBuf { // device scratch of a diagnostic call
 };
 } // namespace
 
-int eigh_device_x(double *G, long n, double *U, double *eval, hipStream_t s, std::string &msg) {
+int eigh_device_x(double *G, long n, double *U, double *eval, hipStream_t s, std::string &msg, const EighShard *sh) {
   gemm_aux_init();
-  return eigh_device(G, n, U, eval, s, msg);
+  return eigh_device(G, n, U, eval, s, msg, sh);
+}
+
+void eigh_last_stages(double *t8) {
+  for (int i = 0; i < 8; ++i) t8[i] = g_eig_last[i];
 }
 
 void eigh_tu_shutdown() {
-  eig2_streams_destroy();
   gemm_aux_destroy();
 }
 

@@ -730,14 +730,31 @@ extern "C" int gemma_hip_center(double *G, size_t n) {
   return rc;
 }
 
-extern "C" int gemma_hip_eigh_d(double *G, size_t n, double *U, double *eval, double *trace_G,
-                                void *stream) {
+// The communicator's two collectives as the eigensolver's unit sees them (eigh_tu.h: EighShard)
+static int shard_bcast(void *, void *buf_d, size_t bytes, int root, hipStream_t s) {
+  std::string err;
+  return g_ctx.comm.bcast(buf_d, bytes, root, s, err) ? 1 : 0;
+}
+static int shard_allreduce(void *, double *buf_d, size_t count, hipStream_t s) {
+  std::string err;
+  return g_ctx.comm.allreduce_sum(buf_d, count, s, err) ? 1 : 0;
+}
+static int eigh_d_impl(double *G, size_t n, double *U, double *eval, double *trace_G, void *stream, bool sharded) {
   NEED_INIT();
   if (!G || !U || !eval || n == 0) return fail(GEMMA_HIP_EINVAL, "eigh: null/empty argument");
   hipStream_t s = S(stream);
   ProfScope ps(GEMMA_STAGE_EIGH, s);
   std::string msg;
-  int rc = eigh_device_x(G, (long)n, U, eval, s, msg);
+  EighShard sh;
+  const char *es = getenv("GEMMA_HIP_EIGH_SHARD"); // 0: every rank decomposes on its own (replicas), nothing is exchanged
+  const bool use = sharded && g_ctx.comm.active && g_ctx.comm.world > 1 && !(es && es[0] == '0');
+  if (use) {
+    sh.rank = g_ctx.comm.rank;
+    sh.world = g_ctx.comm.world;
+    sh.bcast = shard_bcast;
+    sh.allreduce_sum = shard_allreduce;
+  }
+  int rc = eigh_device_x(G, (long)n, U, eval, s, msg, use ? &sh : nullptr);
   if (rc != GEMMA_HIP_OK) return fail(rc, "eigh: %s", msg.c_str());
   // EigenDecomp_Zeroed: eval < 1e-10 -> 0, trace = mean(eval)
   if (g_ctx.scratch.reserve(8)) return fail(GEMMA_HIP_ENOMEM, "eigh: scratch");
@@ -748,6 +765,20 @@ extern "C" int gemma_hip_eigh_d(double *G, size_t n, double *U, double *eval, do
   HIPCHK(hipMemcpyAsync(&tr, g_ctx.scratch.p, 8, hipMemcpyDeviceToHost, s));
   HIPCHK(hipStreamSynchronize(s));
   if (trace_G) *trace_G = tr;
+  return GEMMA_HIP_OK;
+}
+extern "C" int gemma_hip_eigh_d(double *G, size_t n, double *U, double *eval, double *trace_G, void *stream) {
+  return eigh_d_impl(G, n, U, eval, trace_G, stream, false);
+}
+// COLLECTIVE over the library's communicator (gemma_hip_comm_init): every rank passes the same G and receives the same
+// (U, eval); the back-transformations are shared out (csrc/eigh.hip.h "Several ranks").  One rank: gemma_hip_eigh_d.
+extern "C" int gemma_hip_eigh_sharded_d(double *G, size_t n, double *U, double *eval, double *trace_G, void *stream) {
+  return eigh_d_impl(G, n, U, eval, trace_G, stream, true);
+}
+
+extern "C" int gemma_hip_dbg_eigh_last(double *t8) {
+  if (!t8) return fail(GEMMA_HIP_EINVAL, "dbg_eigh_last: null argument");
+  eigh_last_stages(t8);
   return GEMMA_HIP_OK;
 }
 
@@ -2602,11 +2633,11 @@ static int kept_alloc_ue(size_t n) {
   return GEMMA_HIP_OK;
 }
 
-static int kept_eigh_of(double *G_d, size_t n, double *eval, double *trace_G) {
+static int kept_eigh_of(double *G_d, size_t n, double *eval, double *trace_G, bool sharded = false) {
   int rc = kept_alloc_ue(n);
   if (rc) return rc;
   double tr = 0.0;
-  rc = gemma_hip_eigh_d(G_d, n, kept_U(), kept_eval(), &tr, nullptr);
+  rc = eigh_d_impl(G_d, n, kept_U(), kept_eval(), &tr, nullptr, sharded);
   if (rc) {
     g_ctx.kept_n = 0;
     return rc;
@@ -2617,7 +2648,16 @@ static int kept_eigh_of(double *G_d, size_t n, double *eval, double *trace_G) {
   return GEMMA_HIP_OK;
 }
 
+static int eigh_kept_K_impl(const int *indicator_idv, size_t ni_total, double *eval, double *trace_G, bool sharded);
 extern "C" int gemma_hip_eigh_kept_K(const int *indicator_idv, size_t ni_total, double *eval, double *trace_G) {
+  return eigh_kept_K_impl(indicator_idv, ni_total, eval, trace_G, false);
+}
+// COLLECTIVE: every rank holds the same kept K (kin_end_keep with the all-reduce) and ends with the same kept (U, eval) --
+// no gemma_hip_kept_bcast afterwards
+extern "C" int gemma_hip_eigh_kept_K_sharded(const int *indicator_idv, size_t ni_total, double *eval, double *trace_G) {
+  return eigh_kept_K_impl(indicator_idv, ni_total, eval, trace_G, true);
+}
+static int eigh_kept_K_impl(const int *indicator_idv, size_t ni_total, double *eval, double *trace_G, bool sharded) {
   NEED_INIT();
   if (!g_ctx.kept_K_n) return fail(GEMMA_HIP_ESTATE, "eigh_kept_K: no kept K (kin_end_keep first)");
   if (ni_total != g_ctx.kept_K_n) return fail(GEMMA_HIP_EINVAL, "eigh_kept_K: ni_total=%zu, kept K is %zu", ni_total, g_ctx.kept_K_n);
@@ -2640,7 +2680,7 @@ extern "C" int gemma_hip_eigh_kept_K(const int *indicator_idv, size_t ni_total, 
     e = hipGetLastError();
   }
   if (e == hipSuccess) rc = gemma_hip_center_d(G.as<double>(), n, nullptr);
-  if (e == hipSuccess && rc == GEMMA_HIP_OK) rc = kept_eigh_of(G.as<double>(), n, eval, trace_G);
+  if (e == hipSuccess && rc == GEMMA_HIP_OK) rc = kept_eigh_of(G.as<double>(), n, eval, trace_G, sharded);
   G.release(); dmap.release();
   if (e != hipSuccess) return fail(GEMMA_HIP_ERUNTIME, "eigh_kept_K: %s", hipGetErrorString(e));
   return rc;

@@ -132,6 +132,11 @@ int gemma_hip_center_d(double *G_d, size_t n, void *stream);
 int gemma_hip_eigh(double *G, size_t n, double *U, double *eval, double *trace_G);
 int gemma_hip_eigh_d(double *G_d, size_t n, double *U_d, double *eval_d, double *trace_G,
                      void *stream);
+/* The same as a COLLECTIVE over the library's communicator (gemma_hip_comm_init): every rank passes the same G and
+ * receives the same (U, eval).  The reduction and the divide & conquer run on every rank (same code, same bits -- checked),
+ * the two back-transformations are shared out by eigenvector (rows of Z^T) and the slices exchanged once; with one rank, or
+ * GEMMA_HIP_EIGH_SHARD=0, it is gemma_hip_eigh_d. */
+int gemma_hip_eigh_sharded_d(double *G_d, size_t n, double *U_d, double *eval_d, double *trace_G, void *stream);
 /* CalcUtX(U,X,UtX), src/mathfunc.cpp:504-506: UtX (n x m) = U^T X (X n x m row-major) */
 int gemma_hip_calc_utx(const double *U, const double *X, size_t n, size_t m, double *UtX);
 
@@ -275,6 +280,9 @@ int gemma_hip_eigh_kept_K(const int *indicator_idv /* NULL: all */, size_t ni_to
 int gemma_hip_eigh_keep(const double *G /* n^2, already centred; not modified */, size_t n, double *eval /* may be NULL */,
                         double *trace_G);
 int gemma_hip_kept_n(size_t *n /* order of the kept U, 0 = none */);
+/* gemma_hip_eigh_kept_K as a collective (every rank holds the same kept K after the all-reduce of kin_end_keep): every rank ends
+ * with the same kept (U, eval); gemma_hip_kept_bcast is then not needed */
+int gemma_hip_eigh_kept_K_sharded(const int *indicator_idv, size_t ni_total, double *eval, double *trace_G);
 int gemma_hip_kept_bcast(int root, double *trace_G /* out on every rank: mean(eval) of the root's decomposition; may be NULL */);
 int gemma_hip_kept_U_get(double *U /* n^2, may be NULL */, double *eval /* n, may be NULL */);
 int gemma_hip_calc_utx_kept(const double *X, size_t n, size_t m, double *UtX);
@@ -315,6 +323,9 @@ int gemma_hip_dbg_stedc(const double *d, const double *e, size_t n, double *w, d
 /* two-stage reduction of the eigensolver alone (n even, >= 384): band (n x 129, row j = B(j..j+128, j)) after the dense ->
  * band stage, d[n], e[n-1] after the bulge chase */
 int gemma_hip_dbg_eigh2(const double *G, size_t n, double *band, double *d, double *e);
+/* stage seconds of the last eigendecomposition that ran with GEMMA_HIP_EIGH_TIMING=1 in the environment: t8 = {reduction (to band /
+ * to tridiagonal), bulge chase, divide & conquer, back-transformation Q2, Q1 (one-stage: all of it), sort + transpose, n, 1|2 stages} */
+int gemma_hip_dbg_eigh_last(double *t8);
 /* the U^T x stage of gemma_hip_lmm_batch alone (after lmm_setup; host pointers): UtX is l x n row-major, row s =
  * (U^T x_s)^T of the mean-imputed SNP s (the column fast_dgemm("T","N",U,Xlarge) produces, GEMMA src/lmm.cpp:1521).
  * path 0: fp64 MFMA GEMM; path 1: exact int8-digit product where the input allows it (PLINK 2-bit; fp64 rows of hard calls;

@@ -276,6 +276,15 @@ inline double EigenDecompKept(const std::vector<int> &indicator_idv, Vector *eva
   enforce_hip(gemma_hip_eigh_kept_K(indicator_idv.data(), indicator_idv.size(), eval->data, &tr), "EigenDecomp_Zeroed (kept K)");
   return tr;
 }
+// The same as a COLLECTIVE of all ranks (each holds the same kept K after the all-reduce): the back-transformations of the
+// eigensolver are shared out by eigenvector and every rank ends with the same kept (U, eval) -- no broadcast afterwards
+// (csrc/eigh.hip.h "Several ranks")
+inline double EigenDecompKeptSharded(const std::vector<int> &indicator_idv, Vector *eval) {
+  double tr = 0.0;
+  enforce_hip(gemma_hip_eigh_kept_K_sharded(indicator_idv.data(), indicator_idv.size(), eval->data, &tr),
+              "EigenDecomp_Zeroed (kept K, sharded)");
+  return tr;
+}
 // CalcUtX on the kept U
 inline void CalcUtXKept(const Matrix *X, Matrix *UtX) {
   if (X->tda != X->size2 || UtX->tda != UtX->size2 || UtX->size1 != X->size1 || UtX->size2 != X->size2)

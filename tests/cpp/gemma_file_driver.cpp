@@ -289,7 +289,7 @@ int main(int argc, char **argv) {
     // With -inproc, and with -k on several GPUs, U and eval stay on the device (the library's kept chain): U is then an
     // empty view and cLmm.kept_U says so; only -eigen copies them out.
     std::vector<double> Ub, evalb(ni_test);
-    bool kept = false;
+    bool kept = false, eig_sharded = false;
     double trace_G = 0.0;
     bool error = false;
     Vector eval = vector_view(evalb.data(), ni_test);
@@ -301,7 +301,12 @@ int main(int argc, char **argv) {
                                          : PlinkKin(file_bfile + ".bed", indicator_snp, inproc, 0, &K, kk);
       if (!ok) return 4;
       std::cout << " t_kinship=" << lap();
-      if (rank == 0) trace_G = EigenDecompKept(cp.indicator_idv, &eval); // sub-selection, centring, eigendecomposition
+      // sub-selection, centring, eigendecomposition.  Several ranks: every one holds the all-reduced K, so the decomposition is
+      // a collective whose back-transformations are shared out (GEMMA_HIP_EIGH_SHARD=0: rank 0 alone, then the broadcast below)
+      const char *esh = getenv("GEMMA_HIP_EIGH_SHARD");
+      eig_sharded = gpus > 1 && !(esh && esh[0] == '0');
+      if (eig_sharded) trace_G = EigenDecompKeptSharded(cp.indicator_idv, &eval);
+      else if (rank == 0) trace_G = EigenDecompKept(cp.indicator_idv, &eval);
       kept = true;
       std::cout << " t_eigen=" << lap();
     } else if (!file_kin.empty() && gpus > 1) {
@@ -342,7 +347,7 @@ int main(int argc, char **argv) {
       std::cerr << "need -gk, -inproc, -k or -d/-u" << std::endl;
       return 2;
     }
-    if (kept && gpus > 1) { // the ONE broadcast of (U, eval); the other ranks then fetch eval (n doubles) for the null model
+    if (kept && gpus > 1 && !eig_sharded) { // the ONE broadcast of (U, eval); the other ranks then fetch eval (n doubles) for the null model
       enforce_hip(gemma_hip_kept_bcast(0, &trace_G), "kept_bcast");
       if (rank != 0) enforce_hip(gemma_hip_kept_U_get(nullptr, evalb.data()), "kept_U_get");
     }

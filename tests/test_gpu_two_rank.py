@@ -104,3 +104,58 @@ def test_two_hip_ranks_on_one_device_equal_single_rank(gpu_api, oracle, tmp_path
     got = np.load(tmp_path / "gathered.npy")
     assert got.shape == single.shape
     assert np.array_equal(got, single, equal_nan=True)
+
+
+def _eigh_worker(rank, world, port, case_path, outdir, env):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    os.environ["GEMMA_HIP_COMM"] = "shm"  # RCCL refuses two ranks on one device: the library's shm test transport
+    os.environ.update(env)
+    import torch
+    import torch.distributed as dist
+    from gemma_amd import api
+    from gemma_amd import dist as gdist
+
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    api.init(0, verbose=0)
+    assert gdist.native_comm_init(), "the library's communicator (shm transport) did not come up"
+    K = torch.from_numpy(np.load(case_path)).to(dev)
+    n = K.shape[0]
+    U = torch.empty_like(K)
+    ev = torch.empty(n, dtype=torch.float64, device=dev)
+    tr = api.EigenDecomp_Zeroed_sharded(K.clone(), U, ev)
+    torch.cuda.synchronize()
+    np.savez(os.path.join(outdir, "eig_rank%d.npz" % rank), U=U.cpu().numpy(), ev=ev.cpu().numpy(), tr=tr)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n,world,env", [(1538, 2, {}), (1090, 3, {}), (1538, 2, {"GEMMA_HIP_EIGH_SHARD_FORCE_DIFFER": "1"}),
+                                         (1538, 2, {"GEMMA_HIP_EIGH_SHARD": "0"})])
+def test_sharded_backtransformation_equals_single_rank(gpu_api, tmp_path, monkeypatch, n, world, env):
+    """gemma_hip_eigh_sharded_d -- every rank reduces and runs the divide & conquer on its own copy, the two
+    back-transformations are shared out by eigenvector (rows of Z^T, whole 64-row blocks), the slices are exchanged once.  Two
+    / three ranks on ONE device over the library's shm test transport (the two-stage path forced at this small n): every
+    rank's (U, eval) must equal the single-rank result BIT FOR BIT -- also when the ranks' agreement check is made to fail
+    (rank 0 then finishes alone and broadcasts) and with the sharing switched off (replicas)."""
+    import torch.multiprocessing as mp
+    from test_gpu_eigh import _sym
+    monkeypatch.setenv("GEMMA_HIP_EIGH_STAGES", "2")
+    A = _sym(n, 77 + n, "kinship")
+    case = tmp_path / "K.npy"
+    np.save(case, A)
+    U1, w1 = np.zeros((n, n)), np.zeros(n)
+    tr1 = gpu_api.EigenDecomp_Zeroed(A.copy(), U1, w1)
+    mp.spawn(_eigh_worker, args=(world, _free_port(), str(case), str(tmp_path), dict(env, GEMMA_HIP_EIGH_STAGES="2")),
+             nprocs=world, join=True)
+    for r in range(world):
+        d = np.load(tmp_path / ("eig_rank%d.npz" % r))
+        assert np.array_equal(d["ev"], w1), "rank %d eigenvalues" % r
+        assert np.array_equal(d["U"], U1), "rank %d eigenvectors differ from the single-rank solve" % r
+        assert float(d["tr"]) == tr1
+    resid = np.linalg.norm(A @ U1 - U1 * w1[None, :]) / (np.linalg.norm(A, 2) * n * np.finfo(float).eps)
+    assert resid < 30

@@ -88,6 +88,13 @@ def test_two_ranks_on_one_device_kinship_allreduce_eigen_broadcast(driver, tmp_p
     fc.sharded_inproc_workflow(driver, tmp_path, world=2, samegpu=True)
 
 
+def test_two_ranks_rank0_eigensolver_and_broadcast(driver, tmp_path, monkeypatch):
+    """The same with GEMMA_HIP_EIGH_SHARD=0: rank 0 alone decomposes and (U, eval) travel in ONE broadcast (rounds 2-3); the
+    default since round 4 is the collective eigensolver above (every rank decomposes, back-transformations shared out)."""
+    monkeypatch.setenv("GEMMA_HIP_EIGH_SHARD", "0")
+    fc.sharded_inproc_workflow(driver, tmp_path, world=2, samegpu=True)
+
+
 def test_rccl_entry_points_single_rank(driver):
     """ncclGetUniqueId / ncclCommInitRank / ncclBroadcast / ncclAllReduce through the library on the one device there is:
     a communicator of one rank over the real librccl (dlopen), broadcast and all-reduce are then the identity."""
