@@ -349,7 +349,7 @@ def main():
                     api.EigenDecomp_Zeroed(Kc, U, ev)
                 st = os.environ.get("GEMMA_HIP_EIGH_STAGES", "")
                 ne = n + (n & 1) if (n >= 192 and os.environ.get("GEMMA_HIP_EIGH_PAD", "") != "0") else n  # odd n is padded
-                two = (st == "2" and ne >= 384 or st != "1" and ne >= 14000) and ne % 2 == 0  # eigh.hip.h: eig_two_stage
+                two = (st == "2" and ne >= 384 or st != "1" and ne >= 8000) and ne % 2 == 0  # eigh.hip.h: eig_two_stage
                 eig = "gemma_hip_eigh (%s)" % ("two-stage: dense -> band -> tridiagonal" if two else "one-stage tridiagonalisation")
                 if shard_eig:
                     eig += ("; collective over %d ranks: reduction and divide & conquer on every rank, back-transformations shared out by "

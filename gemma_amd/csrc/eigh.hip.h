@@ -1033,7 +1033,7 @@ static inline int eig_backtransform(double *ZT, long n, EigWs &ws, hipStream_t s
 namespace gemma_hip {
 
 // GEMMA_HIP_EIGH_STAGES: 1 = one-stage tridiagonalisation (HBM-bound SYMV per column), 2 = two-stage (dense -> band ->
-// tridiagonal, eigh2.hip.h) whenever the matrix has at least one stage-1 panel; unset: two-stage from n = 14000 (measured:
+// tridiagonal, eigh2.hip.h) whenever the matrix has at least one stage-1 panel; unset: two-stage from n = 8000 (rounds 2-3: 14000; measured then:
 // n = 8192 0.50 s one-stage / 0.70 s two-stage, n = 20000 4.46 / 3.09 s -- the n sequential panel launches and the 2 n
 // dependent chase steps are latency, the SYMV they replace is bandwidth: a n + b n^3 fits through the two sizes cross at 14000).  Odd n stays on the one-stage path (the panel
 // GEMMs want even leading dimensions).
@@ -1042,7 +1042,7 @@ static inline bool eig_two_stage(long n) {
   if (e && e[0] == '1') return false;
   if (n < 3 * E2_B || (n & 1) || (n - 2 + E2_NB - 1) / E2_NB > Q2_MAXJ) return false; // q2_apply_kernel's LDS table: n <= 65 536
   if (e && e[0] == '2') return true;
-  return n >= 14000;
+  return n >= 8000; // round 4: with the panel in one launch and the pipelined chase n = 8192 takes 0.48 s two-stage, 0.52 s one-stage
 }
 
 // Several ranks, one decomposition (round 4).  The eigenvectors are independent through both back-transformations

@@ -237,7 +237,7 @@ def test_two_stage_reduction_stages(gpu_api, n, kind):
 @pytest.mark.parametrize("n,kind,chase", [(384, "random", "persist"), (640, "kinship", "persist"), (1000, "kinship", "steps"),
                                           (1538, "clustered", "persist"), (2050, "lowrank", "persist")])
 def test_eigh_two_stage_end_to_end(gpu_api, n, kind, chase, monkeypatch):
-    """The whole solver on the two-stage path (forced: by default it starts at n = 14000), with the bounds of
+    """The whole solver on the two-stage path (forced: by default it starts at n = 8000), with the bounds of
     test_eigh_end_to_end; `steps` runs the bulge chase as one launch per time step instead of the persistent kernel."""
     monkeypatch.setenv("GEMMA_HIP_EIGH_STAGES", "2")
     monkeypatch.setenv("GEMMA_HIP_EIGH_BC", chase)
@@ -299,7 +299,7 @@ def test_eigh_two_stage_4096_device(gpu_api, monkeypatch):
 
 @pytest.mark.parametrize("n,odd", [(14080, False), (14337, True)])
 def test_eigh_default_path_at_two_stage_size(gpu_api, monkeypatch, n, odd):
-    """The DEFAULT path at the sizes where it is the two-stage reduction (n >= 14 000: eigh.hip.h eig_two_stage; nothing
+    """The DEFAULT path at the sizes where it is the two-stage reduction (n >= 8 000 since round 4: eigh.hip.h eig_two_stage; nothing
     forced): a kinship-like matrix (centred, one zero eigenvalue, population structure), the same residual / orthogonality
     bars as at n = 4096, eigenvalues against rocSOLVER.  This is the path the headline bench's setup takes at n = 20 000
     (persistent bulge chase, dynamic stage-2 back-transformation schedule, paired stage-1 panels); the odd size goes through
