@@ -656,6 +656,15 @@ __global__ void dc_gather_rows_kernel(const double *__restrict__ src, long n, in
   dst[(long)t * ld_dst + c] = src[(long)(lo + rows[t]) * n + col0 + c];
 }
 
+// dst[j][p] = src[j][cols[p]] (src k x k with leading dimension k, dst k x count)
+__global__ void dc_gather_cols_kernel(const double *__restrict__ src, int k, const int *__restrict__ cols, int count,
+                                      double *__restrict__ dst, long ld_dst) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  const int j = blockIdx.y;
+  if (p >= ld_dst || j >= k) return;
+  dst[(long)j * ld_dst + p] = p < count ? src[(long)j * k + cols[p]] : 0.0; // the padding column of an odd count
+}
+
 // ---------------------------------------------------------------- 3. back-transformation
 // forward compact-WY factor (LAPACK dlarft, columnwise): T(i,i) = tau_i,
 // T(0:i,i) = -tau_i T(0:i,0:i) S(0:i,i) with S = Y^T Y.  One workgroup per panel (blockIdx.x): the panels' factors are
@@ -726,6 +735,7 @@ struct EigWs {
   double *Sall = nullptr; // per panel: strict upper triangle of Y Y^T, collected by the tridiagonalisation (ld EIG_NB)
   double *zbuf = nullptr, *dl = nullptr, *w = nullptr, *lam = nullptr, *zhat = nullptr, *dphys = nullptr;
   int *ibuf = nullptr, *info = nullptr;
+  int *ibuf2 = nullptr; // structured merges of the divide & conquer: row / column lists of the two children (4 n ints); optional
   GivensRot *rot = nullptr;
   std::vector<void *> owned;
   template <class Tp> bool get(Tp *&ptr, size_t count) {
@@ -870,7 +880,7 @@ static inline int eig_stedc(long n, std::vector<double> &hd, std::vector<double>
   double *Qc = QA, *Qn = QB;
   const double EPS = 2.220446049250313e-16;
   std::vector<double> z, dl, wv, lam;
-  std::vector<int> order, keep, defl;
+  std::vector<int> order, keep, defl, ctype, l13, l23, hb;
   std::vector<GivensRot> rots;
   for (int L = levels; L >= 1; --L) {
     const std::vector<int> &bl = bounds[L];
@@ -903,6 +913,10 @@ static inline int eig_stedc(long n, std::vector<double> &hd, std::vector<double>
       keep.clear();
       defl.clear();
       rots.clear();
+      // which child's columns a row of the children's eigenvector matrix occupies: 1, 2, or 3 = both (a Givens rotation of the
+      // deflation below has mixed a row of each child) -- LAPACK's dlaed2 column types; used by the structured product below
+      ctype.assign(ns, 1);
+      for (int i = n1; i < ns; ++i) ctype[i] = 2;
       if (rho * zmax <= tol) {
         for (int i = 0; i < ns; ++i) defl.push_back(order[i]);
       } else {
@@ -926,6 +940,7 @@ static inline int eig_stedc(long n, std::vector<double> &hd, std::vector<double>
             z[i] = tau;
             z[pj] = 0.0;
             rots.push_back(GivensRot{pj, i, cs, sn});
+            if (ctype[pj] != ctype[i]) ctype[pj] = ctype[i] = 3;
             const double tt = dd[pj] * cs * cs + dd[i] * sn * sn;
             dd[i] = dd[pj] * sn * sn + dd[i] * cs * cs;
             dd[pj] = tt;
@@ -960,12 +975,47 @@ static inline int eig_stedc(long n, std::vector<double> &hd, std::vector<double>
                            ws.Delta);
         hipLaunchKernelGGL(dc_zhat_kernel, dim3((k + 3) / 4), dim3(256), 0, s, ws.dl, ws.w, ws.Delta, k, ws.zhat);
         hipLaunchKernelGGL(dc_eigvec_kernel, dim3((k + 3) / 4), dim3(256), 0, s, ws.Delta, ws.zhat, k);
-        hipLaunchKernelGGL(dc_gather_rows_kernel, dim3((ns + 255) / 256, k), dim3(256), 0, s, Qc, n, lo, ws.ibuf,
-                           k, lo, ns, ws.Wk, (long)ns);
-        EIG_HIP(hipGetLastError());
-        // new eigenvector rows lo .. lo+k-1 of Qn:  R = Uk (k x k, row j = vector j) * Wk (k x ns)
-        EIG_HIP(launch_dgemm('N', 'N', k, ns, k, 1.0, ws.Delta, k, ws.Wk, ns, 0.0, Qn + (long)lo * n + lo, n, false,
-                             false, s));
+        // new eigenvector rows lo .. lo+k-1 of Qn:  R = Uk (k x k, row j = vector j) * Wk (k x ns), Wk = the kept rows of the
+        // children's matrix.  A row of child 1 is zero in child 2's columns and vice versa, so the product is two of half the size
+        // (round 4; LAPACK's dlaed3 does the same): R[:, 0:n1] = Uk[:, types 1,3] * W[types 1,3][0:n1], R[:, n1:] likewise.  The
+        // column subsets of Uk and the row subsets of W are gathered into Wk (order kept: the sums run over the same non-zero terms
+        // in the same order).  Small merges, merges whose gathers would not fit Wk, and GEMMA_HIP_EIGH_DC_STRUCT=0 take the dense form.
+        static const bool dc_struct = !(getenv("GEMMA_HIP_EIGH_DC_STRUCT") && getenv("GEMMA_HIP_EIGH_DC_STRUCT")[0] == '0');
+        l13.clear();
+        l23.clear();
+        for (int t = 0; t < k; ++t) {
+          if (ctype[keep[t]] != 2) l13.push_back(t);
+          if (ctype[keep[t]] != 1) l23.push_back(t);
+        }
+        const int k13 = (int)l13.size(), k23 = (int)l23.size(), n2 = ns - n1;
+        // even leading dimensions (the GEMM's aligned path); the padding column of Uk multiplies nothing (K = the true count)
+        const long ld13 = k13 + (k13 & 1), ld23 = k23 + (k23 & 1), ldn1 = n1 + (n1 & 1), ldn2 = n2 + (n2 & 1);
+        const size_t need = std::max((size_t)k * ld13 + (size_t)k13 * ldn1, (size_t)k * ld23 + (size_t)k23 * ldn2);
+        if (dc_struct && ws.ibuf2 && k >= 256 && need <= (size_t)n * n && (size_t)2 * k + 2 * k <= 4 * (size_t)n) {
+          // ibuf2: [0, k13) positions t of types 1,3; [k, k + k13) their rows keep[t]; [2k, ..) and [3k, ..) the same for types 2,3
+          hb.assign((size_t)4 * k, 0); // lives until the stream synchronisation at the end of this merge
+          for (int p = 0; p < k13; ++p) { hb[p] = l13[p]; hb[(size_t)k + p] = keep[l13[p]]; }
+          for (int p = 0; p < k23; ++p) { hb[(size_t)2 * k + p] = l23[p]; hb[(size_t)3 * k + p] = keep[l23[p]]; }
+          EIG_HIP(hipMemcpyAsync(ws.ibuf2, hb.data(), hb.size() * sizeof(int), hipMemcpyHostToDevice, s));
+          for (int half = 0; half < 2; ++half) {
+            const int kk = half ? k23 : k13, nc = half ? n2 : n1, c0 = half ? n1 : 0;
+            const long ldu = half ? ld23 : ld13, ldw = half ? ldn2 : ldn1;
+            if (kk == 0 || nc == 0) continue;
+            double *Uc = ws.Wk, *Wc = ws.Wk + (size_t)k * ldu;
+            hipLaunchKernelGGL(dc_gather_cols_kernel, dim3((unsigned)((ldu + 255) / 256), k), dim3(256), 0, s, ws.Delta, k,
+                               ws.ibuf2 + (size_t)(2 * half) * k, kk, Uc, ldu);
+            hipLaunchKernelGGL(dc_gather_rows_kernel, dim3((nc + 255) / 256, kk), dim3(256), 0, s, Qc, n, lo,
+                               ws.ibuf2 + (size_t)(2 * half + 1) * k, kk, lo + c0, nc, Wc, ldw);
+            EIG_HIP(hipGetLastError());
+            EIG_HIP(launch_dgemm('N', 'N', k, nc, kk, 1.0, Uc, ldu, Wc, ldw, 0.0, Qn + (long)lo * n + lo + c0, n, false, false, s));
+          }
+        } else {
+          hipLaunchKernelGGL(dc_gather_rows_kernel, dim3((ns + 255) / 256, k), dim3(256), 0, s, Qc, n, lo, ws.ibuf,
+                             k, lo, ns, ws.Wk, (long)ns);
+          EIG_HIP(hipGetLastError());
+          EIG_HIP(launch_dgemm('N', 'N', k, ns, k, 1.0, ws.Delta, k, ws.Wk, ns, 0.0, Qn + (long)lo * n + lo, n, false,
+                               false, s));
+        }
         lam.resize(k);
         EIG_HIP(hipMemcpyAsync(lam.data(), ws.lam, k * 8, hipMemcpyDeviceToHost, s));
       }
@@ -1075,7 +1125,7 @@ static inline int eigh_device_core(double *G, long n, double *U, double *eval, h
             ws.get(ws.Delta, nn) && ws.get(ws.Wk, nn) && ws.get(ws.P, (size_t)n * EIG_NB) &&
             ws.get(ws.P2, (size_t)n * EIG_NB) && ws.get(ws.S, (size_t)EIG_NB * EIG_NB) &&
             ws.get(ws.T, (size_t)EIG_NB * EIG_NB) && ws.get(ws.zbuf, n) && ws.get(ws.dl, n) && ws.get(ws.w, n) &&
-            ws.get(ws.lam, n) && ws.get(ws.zhat, n) && ws.get(ws.dphys, n) && ws.get(ws.ibuf, 2 * (size_t)n + 64) &&
+            ws.get(ws.lam, n) && ws.get(ws.zhat, n) && ws.get(ws.dphys, n) && ws.get(ws.ibuf, 2 * (size_t)n + 64) && ws.get(ws.ibuf2, 4 * (size_t)n + 64) &&
             ws.get(ws.info, 1) && ws.get(ws.rot, n);
   {
     // panel Gram matrices from the tridiagonalisation; GEMMA_HIP_EIGH_PANEL_S=0 recomputes them as GEMMs

@@ -116,7 +116,7 @@ int dbg_stedc_x(const double *d, const double *e, size_t n, double *w, double *Z
   double *QA = nullptr, *QB = nullptr;
   bool ok = ws.get(QA, nn) && ws.get(QB, nn) && ws.get(ws.d, n) && ws.get(ws.e, n) && ws.get(ws.Delta, nn) &&
             ws.get(ws.Wk, nn) && ws.get(ws.zbuf, n) && ws.get(ws.dl, n) && ws.get(ws.w, n) && ws.get(ws.lam, n) &&
-            ws.get(ws.zhat, n) && ws.get(ws.dphys, n) && ws.get(ws.ibuf, 2 * n + 64) && ws.get(ws.info, 1) &&
+            ws.get(ws.zhat, n) && ws.get(ws.dphys, n) && ws.get(ws.ibuf, 2 * n + 64) && ws.get(ws.ibuf2, 4 * n + 64) && ws.get(ws.info, 1) &&
             ws.get(ws.rot, n);
   int rc = ok ? 0 : GEMMA_HIP_ENOMEM;
   std::vector<double> hd(d, d + n), he(e, e + (n > 1 ? n - 1 : 0)), dphys;

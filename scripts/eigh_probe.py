@@ -6,8 +6,11 @@ from gemma_amd import api
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 20000
 api.init(0)
 g = torch.Generator(device="cuda").manual_seed(3)
-X = torch.randn((n, n // 2), dtype=torch.float64, device="cuda", generator=g)
-A = X @ X.T / (n // 2)
+# default: rank n / 2 (half of the spectrum is zero: the divide & conquer deflates heavily); "kin" as 2nd argument: full rank with a
+# Marchenko-Pastur bulk, like a kinship of 2 n SNPs (next to no deflation: the merges are full-size products)
+kin = len(sys.argv) > 2 and sys.argv[2] == "kin"
+X = torch.randn((n, 2 * n if kin else n // 2), dtype=torch.float64, device="cuda", generator=g)
+A = X @ X.T / X.shape[1]
 del X
 A = (A + A.T) / 2
 A0 = A.clone() if n <= 8192 else None
@@ -19,7 +22,7 @@ t0 = time.time()
 api.EigenDecomp_Zeroed(A, U, w)
 torch.cuda.synchronize()
 dt = time.time() - t0
-msg = "eigh n=%d: %.2f s" % (n, dt)
+msg = "eigh n=%d%s: %.2f s" % (n, " (kin)" if kin else "", dt)
 if A0 is not None:
     nrm = torch.linalg.matrix_norm(A0, 2)
     res = torch.linalg.matrix_norm(A0 @ U - U * w[None, :]) / (nrm * n * 2.2e-16)
