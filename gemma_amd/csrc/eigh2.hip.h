@@ -1649,9 +1649,16 @@ static inline bool eig2_alloc(long n, EigWs &ws, Eig2Ws &w2) {
   bool ok = ws.get(w2.Bd, (size_t)(n + E2_B) * E2_LDB) && ws.get(w2.Bd0, (size_t)(n + E2_B) * E2_LDB) && ws.get(w2.part, 2 * std::max(nwg_panel, (size_t)(n + E2_B - 1) / E2_B) * E2_B) && ws.get(w2.pbar, 4) && ws.get(w2.ppart, (size_t)E2_B * std::min<size_t>((size_t)(n + E2_B - 1) / E2_B, 1024) * E2_B) && ws.get(w2.pheads, (size_t)E2_B * E2_B) && ws.get(w2.ZS, (size_t)E2_MAXSLICE * E2_B * n) && ws.get(w2.heads, 2 * E2_B) &&
             ws.get(w2.betas, n) && ws.get(w2.gramP, nwg_gram * E2_B * E2_B) && ws.get(w2.YT, (size_t)4 * E2_B * n) &&
             ws.get(w2.V2, (size_t)w2.kmaxall * n * E2_B) && ws.get(w2.tau2, (size_t)w2.kmaxall * n) &&
-            ws.get(w2.pack, (size_t)w2.ngroups * E2_PACK) && ws.get(w2.goff, (size_t)w2.nJ + 1) &&
+            ws.get(w2.goff, (size_t)w2.nJ + 1) &&
             ws.get(w2.prog, 2 * (size_t)w2.kmaxall + 8) && ws.get(w2.P256, (size_t)3 * n * 2 * E2_B) &&
             ws.get(w2.Tpair, (size_t)4 * E2_B * E2_B) && ws.get(w2.q2sync, (size_t)(n + 63) / 64 + 2 + Q2_MAXSEG + 2);
+  // the packed groups of the stage-2 back-transformation (0.8 n^2 doubles) are written after the divide & conquer and dead before
+  // the final transpose: they live in the divide & conquer's Delta buffer (n^2), which is free in between (round 4: 16 GB less
+  // to allocate at n = 50 000); a caller without that buffer (the stage diagnostics) or a pack that would not fit gets its own
+  if (ok) {
+    if (ws.Delta && (size_t)w2.ngroups * E2_PACK <= (size_t)n * n) w2.pack = ws.Delta;
+    else ok = ws.get(w2.pack, (size_t)w2.ngroups * E2_PACK);
+  }
   if (!ok) return false;
   return hipMemcpy(w2.goff, goff.data(), goff.size() * sizeof(long), hipMemcpyHostToDevice) == hipSuccess;
 }

@@ -636,6 +636,11 @@ int gemma_hip_eigh_kept_K(const int *indicator_idv, size_t ni_total, double *eva
   orc_CenterMatrix(G.data(), n);
   return kept_eigh_of(G, n, eval, trace_G);
 }
+// the collective form: on this CPU double every rank decomposes its (identical, all-reduced) kept K itself -- LAPACK on the host
+// is deterministic, so all ranks end with the same (U, eval), which is the entry point's contract
+int gemma_hip_eigh_kept_K_sharded(const int *indicator_idv, size_t ni_total, double *eval, double *trace_G) {
+  return gemma_hip_eigh_kept_K(indicator_idv, ni_total, eval, trace_G);
+}
 int gemma_hip_eigh_keep(const double *G, size_t n, double *eval, double *trace_G) {
   std::vector<double> Gc(G, G + n * n);
   return kept_eigh_of(Gc, n, eval, trace_G);
