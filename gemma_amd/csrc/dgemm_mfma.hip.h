@@ -850,6 +850,21 @@ static inline hipError_t launch_dgemm(char ta, char tb, long M, long N, long K, 
   return launch_dgemm_t<false, false>(g, s);
 }
 
+// How K is cut for launch_dgemm_ksliced: K0 = the part that is whole K-tiles, `per` = length of a slice (a multiple of the K-tile),
+// return = number of slices: every slice is non-empty ((ns - 1) per < K0 <= ns per) and -- when more than one -- at least four K-tiles
+// long except possibly the last.  1 means "do not slice".  (tests/cpp/raster_slices_check.hip runs this for every K <= 40 000.)
+static inline int gemm_kslice_plan(long K, int want, long *K0, long *per) {
+  *K0 = (K / GEMM_BK) * GEMM_BK;
+  *per = *K0;
+  int ns = want < 1 ? 1 : want;
+  while (ns > 1 && *K0 / ns < 4 * GEMM_BK) --ns;
+  if (ns <= 1 || *K0 == 0) return 1;
+  const long kt = *K0 / GEMM_BK, pt = (kt + ns - 1) / ns; // K-tiles in all, per slice
+  ns = (int)((kt + pt - 1) / pt);
+  *per = pt * GEMM_BK;
+  return ns;
+}
+
 // C_ks (ks = 0 .. *nslices - 1, at C + ks * cslice) = alpha op(A) op(B) over the K range of slice ks, ONE launch per kernel
 // variant (interior tiles / edge strips) with the slice in blockIdx.y; the caller adds the slices.  want = slices asked for; the
 // number used (returned in *nslices) keeps every slice at least four K-tiles long.  A K that is not a multiple of the K-tile
@@ -858,18 +873,11 @@ static inline hipError_t launch_dgemm_ksliced(char ta, char tb, long M, long N, 
                                               const double *B, long ldb, double *C, long ldc, long cslice, int want,
                                               int *nslices, hipStream_t s) {
   const bool tA = (ta == 'T' || ta == 't'), tB = (tb == 'T' || tb == 't');
-  const long K0 = (K / GEMM_BK) * GEMM_BK, K1 = K - K0;
-  int ns = want < 1 ? 1 : want;
-  while (ns > 1 && K0 / ns < 4 * GEMM_BK) --ns;
+  long K0, per;
+  const int ns = gemm_kslice_plan(K, want, &K0, &per);
+  const long K1 = K - K0;
   *nslices = ns;
-  if (ns <= 1 || K0 == 0) {
-    *nslices = 1;
-    return launch_dgemm(ta, tb, M, N, K, alpha, A, lda, B, ldb, 0.0, C, ldc, false, false, s);
-  }
-  const long kt = K0 / GEMM_BK, pt = (kt + ns - 1) / ns; // K-tiles in all, per slice
-  ns = (int)((kt + pt - 1) / pt);                        // slices that are not empty: (ns - 1) pt < kt <= ns pt
-  *nslices = ns;
-  const long per = pt * GEMM_BK;
+  if (ns <= 1) return launch_dgemm(ta, tb, M, N, K, alpha, A, lda, B, ldb, 0.0, C, ldc, false, false, s);
   GemmArgs g;
   g.A = A; g.B = B; g.C = C;
   g.M = M; g.N = N; g.K = K0;
