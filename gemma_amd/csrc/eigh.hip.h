@@ -1148,12 +1148,32 @@ static inline int eigh_device_core(double *G, long n, double *U, double *eval, h
     if (!ws.Tall) ok = ws.get(ws.Tall, (size_t)((n + EIG_NB - 1) / EIG_NB) * EIG_NB * EIG_NB);
     ok = ok && eig2_alloc(n, ws, w2);
   }
-  if (!ok) {
+  // Collective runs: a rank that fails on its own (allocation, a non-finite entry, a leaf that does not converge) must not leave
+  // the others waiting inside a collective it never reaches -- before the first exchange the ranks agree, with one all-reduce of
+  // a status word in a buffer of its own, that every one of them got that far; if any did not, all of them return an error.
+  const bool coll = two && sh && sh->world > 1 && sh->bcast && sh->allreduce_sum;
+  double *agree_d = nullptr;
+  if (coll && hipMalloc(reinterpret_cast<void **>(&agree_d), 16) != hipSuccess) {
+    (void)hipGetLastError();
+    agree_d = nullptr; // the agreement itself then fails on this rank: it reports 'bad' through the host value below
+  }
+  auto anyone_failed = [&](bool mine) -> bool {
+    if (!coll) return mine;
+    double v = mine ? 1.0 : 0.0;
+    if (!agree_d) return true; // cannot take part: the others time out in the collective -- an allocation of 16 bytes failing is the end anyway
+    if (hipMemcpyAsync(agree_d, &v, 8, hipMemcpyHostToDevice, s) != hipSuccess || sh->allreduce_sum(sh->ctx, agree_d, 1, s) ||
+        hipMemcpyAsync(&v, agree_d, 8, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess)
+      return true;
+    return v != 0.0;
+  };
+  if (anyone_failed(!ok)) {
     ws.release();
-    msg = "cannot allocate the eigensolver workspace (about 3 n^2 doubles)";
+    if (agree_d) (void)hipFree(agree_d);
+    msg = ok ? "another rank could not allocate its eigensolver workspace" : "cannot allocate the eigensolver workspace (about 5 n^2 doubles)";
     return 3;
   }
   int rc = 0;
+  bool reached_agreement = false;
   std::vector<double> hd(n), he(std::max<long>(n - 1, 1)), dphys;
   double *Z = nullptr;
   const char *tenv = getenv("GEMMA_HIP_EIGH_TIMING");
@@ -1208,7 +1228,11 @@ static inline int eigh_device_core(double *G, long n, double *U, double *eval, h
     for (long i = 0; i + 1 < n; ++i) he[i] /= scale;
     // G (dead after the reduction) and U serve as the two eigenvector-row buffers
     rc = eig_stedc(n, hd, he, G, U, ws, s, &Z, dphys, msg);
-    if (rc) break;
+    if (coll) reached_agreement = true;
+    if (anyone_failed(rc != 0)) {
+      if (!rc) { msg = "another rank failed in the reduction or the divide & conquer"; rc = 4; }
+      break;
+    }
     if (timing) t2 = now();
     long row0 = 0, rows = n;
     bool sharded = false, root_only = false;
@@ -1315,6 +1339,8 @@ static inline int eigh_device_core(double *G, long n, double *U, double *eval, h
       rc = 4;
     }
   } while (0);
+  if (coll && !reached_agreement) (void)anyone_failed(true); // left the loop before the agreement: tell the others
+  if (agree_d) (void)hipFree(agree_d);
   (void)hipStreamSynchronize(s);
   if (timing && rc == 0 && n > 1) {
     // kept for gemma_hip_dbg_eigh_last: {reduction to band / tridiagonal, bulge chase, divide & conquer, Q2, Q1 (one-stage: the
