@@ -231,7 +231,9 @@ __global__ __launch_bounds__(256) void sb_panel_kernel(SbPanelArgs g) {
 // through memory, in self-validating slots (see SbPersistArgs; wall-clock-bounded polls, error flag -> the host repeats the
 // panel with the per-column launches: A is written only at the very end).  The
 // arithmetic is the per-column kernel's except for the grouping of the partial sums (128 NCH columns per workgroup, summed in
-// workgroup order).  Needs every workgroup resident: nwg <= number of CUs (NCH = 2 from 128 x CUs columns up: n <= 65 536).
+// workgroup order).  Needs every workgroup resident: nwg <= number of CUs.  Only NCH = 1 (128 columns per workgroup) is used:
+// with 256 columns per workgroup the kernel spills and loses to the launches (measured at n = 50 000), so panels wider than
+// 128 x CUs columns keep the per-column launches until the trailing matrix has shrunk.
 // data exchanged between workgroups of one launch (partial sums, head entries): relaxed atomics at agent scope -- on gfx950 a
 // store with sc1 (written through to the memory side) and a load with sc1 (served from there, not from the XCD's L2)
 __device__ __forceinline__ double sp_ld(const double *p) {
@@ -1295,14 +1297,15 @@ static inline int eig2_sy2sb(double *A, long n, EigWs &ws, Eig2Ws &w2, hipStream
     const int kk = (int)std::min<long>(E2_B, m - 1);
     bool done = false;
     if (persist) {
-      const int nch = (m + 127) / 128 <= ncu ? 1 : 2;
-      const int nwgp = (int)((m + 128 * nch - 1) / (128 * nch));
+      // 128 columns per workgroup, every workgroup resident: panels up to 128 x CUs columns.  (256 columns per workgroup -- the
+      // NCH = 2 instantiation -- spills, and measured at n = 50 000 it is slower than the per-column launches it would replace:
+      // dense -> band 4.82 s against 4.72 s; wider panels therefore keep the launches.)
+      const int nwgp = (int)((m + 127) / 128);
       if (nwgp <= ncu) {
         EIG_HIP(hipMemsetAsync(w2.ppart, 0xFF, (size_t)kk * nwgp * E2_B * 8, s));
         EIG_HIP(hipMemsetAsync(w2.pheads, 0xFF, (size_t)kk * E2_B * 8, s));
         SbPersistArgs pp{A, n, j0, kk, nwgp, ws.VT, ws.tau, w2.betas, w2.ppart, w2.pheads, w2.pbar + 1};
-        if (nch == 1) hipLaunchKernelGGL(sb_panel_persist_kernel<1>, dim3(nwgp), dim3(SP_THREADS), 0, s, pp);
-        else hipLaunchKernelGGL(sb_panel_persist_kernel<2>, dim3(nwgp), dim3(SP_THREADS), 0, s, pp);
+        hipLaunchKernelGGL(sb_panel_persist_kernel<1>, dim3(nwgp), dim3(SP_THREADS), 0, s, pp);
         EIG_HIP(hipGetLastError());
         int err = 0;
         EIG_HIP(hipMemcpyAsync(&err, w2.pbar + 1, sizeof(int), hipMemcpyDeviceToHost, s));
