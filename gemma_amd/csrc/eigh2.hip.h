@@ -707,9 +707,18 @@ template <bool SC1> __device__ __forceinline__ void bc_st(double *p, double v) {
 // relaxed atomics (sp_ld / sp_st: loads that bypass the XCD's L2, stores written through), so that the persistent kernel needs
 // no acquire / release FENCE around a task: at agent scope those are an invalidate and a write-back of the XCD's whole L2, and
 // the stamps of round 3 showed 6.4 us of a 19 us task in front of the release alone.
+// EARLY (bc_persist1_kernel): three hand-overs instead of one at the end of the task --
+//   vflag  : v and tau are out (6 us into the task): the next position of this sweep may start;
+//   eflag  : the left block is stored (its row 0 is the last row of the diagonal block of task (j + 1, k - 1), its (0, 0) entry that
+//            task's last left-block entry): the previous position may start its next sweep;
+//   cbox_out: the updated (0, 0) entry of the diagonal block -- the only entry of this task's D phase the task (j + 1, k - 1) needs
+//            (the corner of ITS diagonal block) -- travels in a self-validating slot (all-ones NaN = empty) that the reader
+//            empties again; cbox_in is the slot of task (j - 1, k + 1) this task reads its own corner from (nullptr: no such task).
 template <bool DBG, bool SC1, bool EARLY = false>
 __device__ __forceinline__ void bc_task(double *__restrict__ B, long n, long j, long k, double *__restrict__ V2g,
-                                        double *__restrict__ tau2g, double *e2sm, long long *dbg = nullptr, int *vflag = nullptr) {
+                                        double *__restrict__ tau2g, double *e2sm, long long *dbg = nullptr, int *vflag = nullptr,
+                                        int *eflag = nullptr, double *cbox_in = nullptr, double *cbox_out = nullptr,
+                                        int *err = nullptr) {
   constexpr int CW = E2_B / BC_NH;
   BC_STAMP(0);
   double *E = e2sm; // E[c][a] (column stride 129): the block whose column sums are being formed
@@ -807,7 +816,29 @@ __device__ __forceinline__ void bc_task(double *__restrict__ B, long n, long j, 
     bc_st<SC1>(B + j * E2_LDB + 1 + a, (a == 0) ? beta : 0.0);
   }
   BC_STAMP(4);
-  if (tau == 0.0) return; // H = I (uniform over the block)
+  // EARLY: the corner of this diagonal block, D(127, 127), is the (0, 0) entry of the diagonal block of task (j - 1, k + 1), which may
+  // still be running: thread (127, last column part) requests it from that task's slot now and uses it after the second product
+  const bool corner_late = EARLY && cbox_in != nullptr;
+  const bool corner_mine = corner_late && t == BC_THREADS - 1;
+  double cslot = 0.0;
+  if (corner_mine) cslot = bc_ld<true>(cbox_in);
+  if (tau == 0.0) { // H = I (uniform over the block): nothing to do to D, but the hand-overs must still happen
+    if (EARLY) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (t == 0) {
+        __hip_atomic_store(eflag, (int)(j + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (cbox_out) bc_st<true>(cbox_out, dr[0]); // D(0, 0) unchanged
+      }
+      if (corner_mine) { // the slot is emptied by its reader, and its value has no other way into the band
+        for (long it = 0; __double_as_longlong(cslot) == -1LL && it < (1L << 22); ++it) cslot = bc_ld<true>(cbox_in);
+        if (__double_as_longlong(cslot) == -1LL) __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        bc_st<true>(cbox_in, __longlong_as_double(-1LL));
+        bc_st<SC1>(B + (r + E2_B - 1) * E2_LDB, cslot);
+      }
+    }
+    return;
+  }
   // diagonal block (lower triangle dr, diagonal included): p = tau D v = tau (L v + strict(L)^T v),
   // w = p - (tau/2)(v.p) v, D -= v w^T + w v^T
   __syncthreads(); // the column sums above are done with E
@@ -816,10 +847,13 @@ __device__ __forceinline__ void bc_task(double *__restrict__ B, long n, long j, 
 #pragma unroll
   for (int c = 0; c < CW; ++c) {
     E[(cb + c) * BC_LD + a] = (a > cb + c) ? dr[c] : 0.0; // strictly lower part for the transposed product
-    p1 += ((a >= cb + c) ? dr[c] : 0.0) * bc_bcast(vh, c);
+    const bool late = corner_mine && c == CW - 1;           // the corner's product is added below, once the slot has been read
+    p1 += ((a >= cb + c && !late) ? dr[c] : 0.0) * bc_bcast(vh, c);
   }
   ybuf[h * E2_B + a] = p1;
+  if (EARLY) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the left block's stores (issued a product ago) have left the chip
   __syncthreads();
+  if (EARLY && t == 0) __hip_atomic_store(eflag, (int)(j + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   BC_STAMP(5);
   {
     double p2 = 0.0;
@@ -827,10 +861,28 @@ __device__ __forceinline__ void bc_task(double *__restrict__ B, long n, long j, 
     for (int q = 0; q < CW; ++q) p2 += E[a * BC_LD + cb + q] * bc_bcast(vh, q); // column a, rows cb + q; vh = v of those rows
     zbuf[h * E2_B + a] = p2;
   }
+  if (corner_mine) {
+    long long t0 = 0;
+    for (long it = 0; __double_as_longlong(cslot) == -1LL; ++it) { // normally there long ago: the slot was requested two products back
+      cslot = bc_ld<true>(cbox_in);
+      if ((it & 63) == 63) {
+        const long long now = (long long)wall_clock64();
+        if (t0 == 0) t0 = now;
+        if (now - t0 > BC_WAIT_TICKS || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+          __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          cslot = 0.0;
+        }
+      }
+    }
+    bc_st<true>(cbox_in, __longlong_as_double(-1LL)); // empty again for the sweep after next
+    dr[CW - 1] = cslot;
+    red[2 * BC_NH + 1] = cslot * v[E2_B - 1];
+  }
   __syncthreads();
   double psum = 0.0;
 #pragma unroll
   for (int q = 0; q < BC_NH; ++q) psum += ybuf[q * E2_B + a] + zbuf[q * E2_B + a];
+  if (corner_late && a == E2_B - 1) psum += red[2 * BC_NH + 1];
   const double pa = tau * psum;
   const double gamma = bc_bsum((h == 0) ? va * pa : 0.0, red);
   const double wa = pa - 0.5 * tau * gamma * va;
@@ -841,8 +893,14 @@ __device__ __forceinline__ void bc_task(double *__restrict__ B, long n, long j, 
     const double wh = wv[cb + lc];
     double *dst = B + (r + cb) * E2_LDB + a - cb;
 #pragma unroll
-    for (int c = 0; c < CW; ++c)
-      if (a >= cb + c && a < L) bc_st<SC1>(dst + c * (E2_LDB - 1), dr[c] - va * bc_bcast(wh, c) - wa * bc_bcast(vh, c));
+    for (int c = 0; c < CW; ++c) {
+      const double dnew = dr[c] - va * bc_bcast(wh, c) - wa * bc_bcast(vh, c);
+      // D(0, 0) is the corner of task (j + 1, k - 1)'s diagonal block: when that task exists the value goes into its slot ONLY (the
+      // reader stores its own update of it to the band; a store from here could land after that one)
+      const bool handed = EARLY && c == 0 && t == 0 && cbox_out != nullptr;
+      if (handed) bc_st<true>(cbox_out, dnew);
+      else if (a >= cb + c && a < L) bc_st<SC1>(dst + c * (E2_LDB - 1), dnew);
+    }
   }
   BC_STAMP(7);
 }
@@ -905,11 +963,17 @@ __global__ __launch_bounds__(BC_THREADS) void bc_persist_kernel(BcPersistArgs g)
 // task: with start(j, k) >= start(j, k - 1) + a and start(j, k) >= end(j - 1, k + 1) the sweep period drops from 2 T to a + T.
 // vprog[k] = sweeps whose reflector position k has published, prog[k] = sweeps it has finished.  Needs positions <= CUs
 // (n <= 32 768 + 128 on 256 CUs); beyond that bc_persist_kernel (two positions per workgroup) stays.
+// Round 4, second step: of the previous sweep's neighbour only the LEFT block has to be stored (eprog, published a third into its
+// diagonal-block phase); the one entry of its diagonal block this task needs comes through a slot (cbox, see bc_task), so
+// start(j, k) >= left_block_done(j - 1, k + 1) and the period is a + (that offset) instead of a + T.  GEMMA_HIP_EIGH_BC_PIPE=1
+// keeps the whole-task hand-over (handshake = 0).
 struct BcPersist1Args {
   double *Bd;
   long n;
   double *V2, *tau2;
-  int *prog, *vprog, *err;
+  int *prog, *vprog, *eprog, *err;
+  double *cbox; // [position][sweep parity]
+  int handshake;
   long long *dbg;
 };
 template <bool DBG>
@@ -919,17 +983,20 @@ __global__ __launch_bounds__(BC_THREADS) void bc_persist1_kernel(BcPersist1Args 
   const long n = g.n, k = blockIdx.x;
   for (long j = 0; j <= n - 3; ++j) {
     if (j + 1 + k * E2_B >= n) break;
+    const bool has_right = j >= 1 && j + (k + 1) * E2_B < n; // task (j - 1, k + 1) exists
     if (threadIdx.x == 0) {
       bool ok = true;
       if (k > 0) ok = bc_wait(g.vprog + (k - 1), (int)(j + 1), g.err);
-      if (ok && j >= 1 && j + (k + 1) * E2_B < n) ok = bc_wait(g.prog + (k + 1), (int)j, g.err);
+      if (ok && has_right) ok = bc_wait((g.handshake ? g.eprog : g.prog) + (k + 1), (int)j, g.err);
       s_ok = ok ? 1 : 0;
     }
     __syncthreads();
     if (!s_ok) return;
     long long *dbg = (DBG && g.dbg && blockIdx.x == 2 && j < 512) ? g.dbg + 16 * j : nullptr;
-    if (DBG && dbg) bc_task<true, true, true>(g.Bd, n, j, k, g.V2, g.tau2, e2sm, dbg, g.vprog + k);
-    else bc_task<false, true, true>(g.Bd, n, j, k, g.V2, g.tau2, e2sm, nullptr, g.vprog + k);
+    double *cin = (g.handshake && has_right) ? g.cbox + 2 * (k + 1) + ((j - 1) & 1) : nullptr;
+    double *cout = (g.handshake && k >= 1 && j + 1 <= n - 3) ? g.cbox + 2 * k + (j & 1) : nullptr;
+    if (DBG && dbg) bc_task<true, true, true>(g.Bd, n, j, k, g.V2, g.tau2, e2sm, dbg, g.vprog + k, g.eprog + k, cin, cout, g.err);
+    else bc_task<false, true, true>(g.Bd, n, j, k, g.V2, g.tau2, e2sm, nullptr, g.vprog + k, g.eprog + k, cin, cout, g.err);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this thread's write-through stores have left the chip's caches
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -1441,7 +1508,14 @@ static inline int eig2_sb2st(long n, EigWs &ws, Eig2Ws &w2, hipStream_t s, std::
                                       hipFuncAttributeMaxDynamicSharedMemorySize, BC_LDS_DOUBLES * 8));
           attr1 = true;
         }
-        BcPersist1Args p1{w2.Bd, n, w2.V2, w2.tau2, w2.prog, w2.prog + w2.kmaxall + 2, w2.prog + w2.kmaxall + 1, dbg_d};
+        // ints: prog [0, kmaxall], err, vprog from kmaxall + 2, eprog from 2 kmaxall + 4; then the corner slots (doubles, all-ones = empty)
+        const size_t cbox_off = ((size_t)3 * w2.kmaxall + 8 + 1) & ~(size_t)1;
+        double *cbox = reinterpret_cast<double *>(w2.prog + cbox_off);
+        EIG_HIP(hipMemsetAsync(w2.prog + w2.kmaxall + 2, 0, (cbox_off - w2.kmaxall - 2) * sizeof(int), s));
+        EIG_HIP(hipMemsetAsync(cbox, 0xFF, (size_t)2 * (w2.kmaxall + 2) * sizeof(double), s));
+        const bool handshake = !(epi && epi[0] == '1');
+        BcPersist1Args p1{w2.Bd,   n,    w2.V2, w2.tau2, w2.prog, w2.prog + w2.kmaxall + 2, w2.prog + 2 * w2.kmaxall + 4, w2.prog + w2.kmaxall + 1,
+                          cbox, handshake ? 1 : 0, dbg_d};
         if (dbg_d) hipLaunchKernelGGL(bc_persist1_kernel<true>, dim3((unsigned)w2.kmaxall), dim3(BC_THREADS), BC_LDS_DOUBLES * 8, s, p1);
         else hipLaunchKernelGGL(bc_persist1_kernel<false>, dim3((unsigned)w2.kmaxall), dim3(BC_THREADS), BC_LDS_DOUBLES * 8, s, p1);
       } else if (dbg_d) {
@@ -1653,7 +1727,7 @@ static inline bool eig2_alloc(long n, EigWs &ws, Eig2Ws &w2) {
             ws.get(w2.betas, n) && ws.get(w2.gramP, nwg_gram * E2_B * E2_B) && ws.get(w2.YT, (size_t)4 * E2_B * n) &&
             ws.get(w2.V2, (size_t)w2.kmaxall * n * E2_B) && ws.get(w2.tau2, (size_t)w2.kmaxall * n) &&
             ws.get(w2.goff, (size_t)w2.nJ + 1) &&
-            ws.get(w2.prog, 2 * (size_t)w2.kmaxall + 8) && ws.get(w2.P256, (size_t)3 * n * 2 * E2_B) &&
+            ws.get(w2.prog, 8 * (size_t)w2.kmaxall + 32) && ws.get(w2.P256, (size_t)3 * n * 2 * E2_B) &&
             ws.get(w2.Tpair, (size_t)4 * E2_B * E2_B) && ws.get(w2.q2sync, (size_t)(n + 63) / 64 + 2 + Q2_MAXSEG + 2);
   // the packed groups of the stage-2 back-transformation (0.8 n^2 doubles) are written after the divide & conquer and dead before
   // the final transpose: they live in the divide & conquer's Delta buffer (n^2), which is free in between (round 4: 16 GB less
