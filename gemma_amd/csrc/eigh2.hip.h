@@ -718,7 +718,7 @@ template <bool DBG, bool SC1, bool EARLY = false>
 __device__ __forceinline__ void bc_task(double *__restrict__ B, long n, long j, long k, double *__restrict__ V2g,
                                         double *__restrict__ tau2g, double *e2sm, long long *dbg = nullptr, int *vflag = nullptr,
                                         int *eflag = nullptr, double *cbox_in = nullptr, double *cbox_out = nullptr,
-                                        int *err = nullptr) {
+                                        int *err = nullptr, int *vwait = nullptr) {
   constexpr int CW = E2_B / BC_NH;
   BC_STAMP(0);
   double *E = e2sm; // E[c][a] (column stride 129): the block whose column sums are being formed
@@ -730,11 +730,17 @@ __device__ __forceinline__ void bc_task(double *__restrict__ B, long n, long j, 
   const int cb = h * CW;
   double er[CW], dr[CW];
   double xa, ya = 0.0, taup = 0.0, vph = 0.0;
+  // vwait (EARLY with the left-block hand-over): neither block depends on the previous position of THIS sweep -- only v_p and
+  // tau_p do -- so both blocks are requested first and the wait for that position's reflector comes behind them: the blocks'
+  // memory latency leaves the chain of dependent tasks
+  const bool late_v = EARLY && vwait != nullptr;
   if (k > 0) {
     // v_p and tau_p first: the counter retires in order, so whoever waits for E has them too and nothing later in the E phase
     // has to wait behind the diagonal block's loads
-    vph = bc_ld<SC1>(V2g + ((size_t)(k - 1) * n + j) * E2_B + cb + lc); // v_p of this thread group's columns, entry c in lane c (c < CW)
-    taup = bc_ld<SC1>(tau2g + (k - 1) * n + j);
+    if (!late_v) {
+      vph = bc_ld<SC1>(V2g + ((size_t)(k - 1) * n + j) * E2_B + cb + lc); // v_p of this thread group's columns, entry c in lane c (c < CW)
+      taup = bc_ld<SC1>(tau2g + (k - 1) * n + j);
+    }
     const double *src = B + (r - E2_B + cb) * E2_LDB + E2_B + a - cb;
 #pragma unroll
     for (int c = 0; c < CW; ++c) er[c] = bc_ld<SC1>(src + c * (E2_LDB - 1)); // rows past n: slots of the band storage that stay zero
@@ -745,8 +751,10 @@ __device__ __forceinline__ void bc_task(double *__restrict__ B, long n, long j, 
     for (int c = 0; c < CW; ++c) er[c] = 0.0;
     if (h == 0) er[0] = bc_ld<SC1>(B + j * E2_LDB + 1 + a); // rows past n: zero slots
   }
+  if (!late_v) {
 #pragma unroll
-  for (int c = 0; c < CW; ++c) E[(cb + c) * BC_LD + a] = er[c];
+    for (int c = 0; c < CW; ++c) E[(cb + c) * BC_LD + a] = er[c];
+  }
   {
     // the diagonal block's loads go out once E has arrived and stay in flight behind the whole E phase; unconditional (a select
     // on the loaded value would be placed right behind the load and wait for it): columns past n lie in the zeroed slack of the
@@ -755,6 +763,15 @@ __device__ __forceinline__ void bc_task(double *__restrict__ B, long n, long j, 
     const double *srd = B + (r + cb) * E2_LDB + a - cb;
 #pragma unroll
     for (int c = 0; c < CW; ++c) dr[c] = bc_ld<SC1>(srd + c * (E2_LDB - 1));
+  }
+  if (late_v) {
+#pragma unroll
+    for (int c = 0; c < CW; ++c) E[(cb + c) * BC_LD + a] = er[c];
+    if (t == 0) red[2 * BC_NH + 2] = bc_wait(vwait, (int)(j + 1), err) ? 1.0 : 0.0;
+    __syncthreads();
+    if (red[2 * BC_NH + 2] == 0.0) return; // the error flag is up: every workgroup leaves at its next wait
+    vph = bc_ld<SC1>(V2g + ((size_t)(k - 1) * n + j) * E2_B + cb + lc);
+    taup = bc_ld<SC1>(tau2g + (k - 1) * n + j);
   }
   {
     double ys = 0.0;
@@ -986,7 +1003,7 @@ __global__ __launch_bounds__(BC_THREADS) void bc_persist1_kernel(BcPersist1Args 
     const bool has_right = j >= 1 && j + (k + 1) * E2_B < n; // task (j - 1, k + 1) exists
     if (threadIdx.x == 0) {
       bool ok = true;
-      if (k > 0) ok = bc_wait(g.vprog + (k - 1), (int)(j + 1), g.err);
+      if (k > 0 && !g.handshake) ok = bc_wait(g.vprog + (k - 1), (int)(j + 1), g.err); // handshake: inside the task, behind its loads
       if (ok && has_right) ok = bc_wait((g.handshake ? g.eprog : g.prog) + (k + 1), (int)j, g.err);
       s_ok = ok ? 1 : 0;
     }
@@ -995,8 +1012,9 @@ __global__ __launch_bounds__(BC_THREADS) void bc_persist1_kernel(BcPersist1Args 
     long long *dbg = (DBG && g.dbg && blockIdx.x == 2 && j < 512) ? g.dbg + 16 * j : nullptr;
     double *cin = (g.handshake && has_right) ? g.cbox + 2 * (k + 1) + ((j - 1) & 1) : nullptr;
     double *cout = (g.handshake && k >= 1 && j + 1 <= n - 3) ? g.cbox + 2 * k + (j & 1) : nullptr;
-    if (DBG && dbg) bc_task<true, true, true>(g.Bd, n, j, k, g.V2, g.tau2, e2sm, dbg, g.vprog + k, g.eprog + k, cin, cout, g.err);
-    else bc_task<false, true, true>(g.Bd, n, j, k, g.V2, g.tau2, e2sm, nullptr, g.vprog + k, g.eprog + k, cin, cout, g.err);
+    int *vwait = (g.handshake && k > 0) ? g.vprog + (k - 1) : nullptr;
+    if (DBG && dbg) bc_task<true, true, true>(g.Bd, n, j, k, g.V2, g.tau2, e2sm, dbg, g.vprog + k, g.eprog + k, cin, cout, g.err, vwait);
+    else bc_task<false, true, true>(g.Bd, n, j, k, g.V2, g.tau2, e2sm, nullptr, g.vprog + k, g.eprog + k, cin, cout, g.err, vwait);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this thread's write-through stores have left the chip's caches
     __syncthreads();
     if (threadIdx.x == 0) {
