@@ -62,6 +62,30 @@ __global__ void fill_B(int8_t *Bt, long total, long ldk, long n) {
   Bt[i] = (c < n) ? (int8_t)((int)(hash32((unsigned)(i * 40503u + 977u)) & 255) - 128) : (int8_t)0;
 }
 
+// stand-ins for the stages behind U^T x (CU_SPLIT experiment): grid-stride streaming kernels
+__global__ __launch_bounds__(256) void side_combine_kernel(const int *__restrict__ C, size_t strideC, size_t moff, double *__restrict__ out,
+                                                           size_t total) {
+  for (size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4; i < total; i += (size_t)gridDim.x * 1024) {
+    double acc[4] = {0, 0, 0, 0};
+    for (int p = 0; p < 3; ++p) {
+      const int4 a = *reinterpret_cast<const int4 *>(C + p * strideC + i), b = *reinterpret_cast<const int4 *>(C + p * strideC + moff + i);
+      acc[0] = acc[0] * 65536.0 + a.x + 0.5 * b.x;
+      acc[1] = acc[1] * 65536.0 + a.y + 0.5 * b.y;
+      acc[2] = acc[2] * 65536.0 + a.z + 0.5 * b.z;
+      acc[3] = acc[3] * 65536.0 + a.w + 0.5 * b.w;
+    }
+    *reinterpret_cast<double4 *>(out + i) = make_double4(acc[0], acc[1], acc[2], acc[3]);
+  }
+}
+__global__ __launch_bounds__(256) void side_read_kernel(const double *__restrict__ in, size_t total, double *__restrict__ sink) {
+  double s = 0.0;
+  for (size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 2; i + 1 < total; i += (size_t)gridDim.x * 512) {
+    const double2 v = *reinterpret_cast<const double2 *>(in + i);
+    s += v.x * v.y;
+  }
+  if (s == 1.2345e-300) *sink = s;
+}
+
 int main(int argc, char **argv) {
   const long n = argc > 1 ? atol(argv[1]) : 20000, B = argc > 2 ? atol(argv[2]) : 20000;
   const int variant = argc > 3 ? atoi(argv[3]) : 0;
@@ -129,10 +153,29 @@ int main(int argc, char **argv) {
                            S2_NST * S2_STAGE));
   }
 #endif
+  // CU_SPLIT=k (experiment): the product runs on a stream whose CU mask leaves k CUs out, and on exactly those a streaming kernel
+  // with the traffic of the stages that follow U^T x in a step (combine: 3 + 3 int32 planes in, fp64 out; then two reads of it) runs at
+  // the same time.  CU_MODE=0: the k lowest mask bits, 1: every (256 / k)-th bit.
+  hipStream_t mstream = 0, sstream = 0;
+  const int cu_split = getenv("CU_SPLIT") ? atoi(getenv("CU_SPLIT")) : 0;
+  double *side_out = nullptr;
+  if (cu_split > 0) {
+    const int mode = getenv("CU_MODE") ? atoi(getenv("CU_MODE")) : 0;
+    unsigned mm[8], sm_[8];
+    for (int w = 0; w < 8; ++w) { mm[w] = 0xFFFFFFFFu; sm_[w] = 0; }
+    for (int q = 0; q < cu_split; ++q) {
+      const int bit = mode == 0 ? q : q * (256 / cu_split);
+      mm[bit >> 5] &= ~(1u << (bit & 31));
+      sm_[bit >> 5] |= 1u << (bit & 31);
+    }
+    CK(hipExtStreamCreateWithCUMask(&mstream, 8, mm));
+    CK(hipExtStreamCreateWithCUMask(&sstream, 8, sm_));
+    CK(hipMalloc(&side_out, (size_t)lpad * npad * 8));
+  }
   auto launch = [&]() {
 #if HAVE_SPARSE2
     if (variant == 2) {
-      hipLaunchKernelGGL(i8gemm_sparse2_kernel_t<2>, grid2, dim3(512), S2_NST * S2_STAGE, 0, g2);
+      hipLaunchKernelGGL(i8gemm_sparse2_kernel_t<2>, grid2, dim3(512), S2_NST * S2_STAGE, mstream, g2);
       return;
     }
     if (variant == 3) { // wavefronts 8 x 1
@@ -161,12 +204,33 @@ int main(int argc, char **argv) {
   CK(hipEventCreate(&e0));
   CK(hipEventCreate(&e1));
   const int reps = getenv("REPS") ? atoi(getenv("REPS")) : 3;
-  CK(hipEventRecord(e0));
-  for (int i = 0; i < reps; ++i) launch();
-  CK(hipEventRecord(e1));
+  hipEvent_t s0, s1;
+  CK(hipEventCreate(&s0));
+  CK(hipEventCreate(&s1));
+  CK(hipEventRecord(e0, mstream));
+  if (cu_split > 0) CK(hipEventRecord(s0, sstream));
+  for (int i = 0; i < reps; ++i) {
+    launch();
+    if (cu_split > 0) {
+      const size_t tot = (size_t)lpad * npad;
+      hipLaunchKernelGGL(side_combine_kernel, dim3((unsigned)(cu_split * 8)), dim3(256), 0, sstream, C, (size_t)mrows * npad, (size_t)lpad * npad,
+                         side_out, tot);
+      hipLaunchKernelGGL(side_read_kernel, dim3((unsigned)(cu_split * 8)), dim3(256), 0, sstream, side_out, tot, side_out + tot - 1);
+      hipLaunchKernelGGL(side_read_kernel, dim3((unsigned)(cu_split * 8)), dim3(256), 0, sstream, side_out, tot, side_out + tot - 1);
+    }
+  }
+  CK(hipEventRecord(e1, mstream));
+  if (cu_split > 0) CK(hipEventRecord(s1, sstream));
   CK(hipEventSynchronize(e1));
   float ms = 0;
   CK(hipEventElapsedTime(&ms, e0, e1));
+  if (cu_split > 0) {
+    CK(hipEventSynchronize(s1));
+    float sms = 0;
+    CK(hipEventElapsedTime(&sms, s0, s1));
+    printf("CU_SPLIT=%d mode %s: side stream (combine-like + 2 reads, %.1f GB per step) %.3f ms per step\n", cu_split,
+           getenv("CU_MODE") ? getenv("CU_MODE") : "0", ((double)nplanes * mrows * npad * 4 + 3.0 * lpad * npad * 8) / 1e9, sms / reps);
+  }
   // sampled check: rows and columns spread over the tiles, all planes
   std::vector<int8_t> hrow(ldk), hcol((size_t)digits * ldk);
   long bad = 0, checked = 0, surplus_rows = 0;
