@@ -49,14 +49,14 @@ class QcCfg(C.Structure):
 
 class MvNull(C.Structure):
     """gemma_mvlmm_null: V_g, V_e (d x d, leading dimension d), B (d x n_cvt), logl for the REMLE and the MLE null fit"""
-    _fields_ = [("Vg_remle", C.c_double * 25), ("Ve_remle", C.c_double * 25), ("B_remle", C.c_double * 20),
-                ("logl_remle_H0", C.c_double), ("Vg_mle", C.c_double * 25), ("Ve_mle", C.c_double * 25),
-                ("B_mle", C.c_double * 20), ("logl_mle_H0", C.c_double)]
+    _fields_ = [("Vg_remle", C.c_double * 64), ("Ve_remle", C.c_double * 64), ("B_remle", C.c_double * 96),  # GEMMA_MV_DMAX 8, _CMAX 12
+                ("logl_remle_H0", C.c_double), ("Vg_mle", C.c_double * 64), ("Ve_mle", C.c_double * 64),
+                ("B_mle", C.c_double * 96), ("logl_mle_H0", C.c_double)]
 
 
 class MvOpt(C.Structure):
     _fields_ = [("em_iter", C.c_size_t), ("nr_iter", C.c_size_t), ("em_prec", C.c_double), ("nr_prec", C.c_double),
-                ("p_nr", C.c_double), ("crt", C.c_size_t)]
+                ("p_nr", C.c_double), ("crt", C.c_size_t), ("gxe", C.c_size_t)]
 
 
 class GemmaHipError(RuntimeError):

@@ -522,8 +522,8 @@ class MVLMM:
         self.sumStat = {}
         self.null = None
 
-    def _opt(self):
-        return L.MvOpt(self.em_iter, self.nr_iter, self.em_prec, self.nr_prec, self.p_nr, self.crt)
+    def _opt(self, gxe=0):
+        return L.MvOpt(self.em_iter, self.nr_iter, self.em_prec, self.nr_prec, self.p_nr, self.crt, gxe)
 
     def fit_null(self, eval_, UtW, UtY):
         """The null block (src/mvlmm.cpp:3056-3208) -> dict with Vg/Ve/B/logl for 'remle' and 'mle'; also fills the
@@ -544,10 +544,18 @@ class MVLMM:
         self.logl_remle_H0, self.logl_mle_H0 = nf.logl_remle_H0, nf.logl_mle_H0
         return self.null
 
-    def Analyze(self, U, eval_, UtW, UtY, geno, geno_kind, indicator_idv=None, batch=LMM_BATCH_SIZE):
+    def Analyze(self, U, eval_, UtW, UtY, geno, geno_kind, indicator_idv=None, batch=LMM_BATCH_SIZE, env=None):
+        """env (over the analysed individuals): the interaction test of AnalyzeBimbamGXE / AnalyzePlinkGXE (src/mvlmm.cpp:3970-4870):
+        the null model is fitted on (W, env) (:4046-4070), per SNP x o env is tested with (W, env, x) as covariates."""
         UtY = np.ascontiguousarray(UtY, dtype=np.float64)
         n, d = UtY.shape
-        self.fit_null(eval_, UtW, UtY)
+        UtW = np.ascontiguousarray(UtW, dtype=np.float64).reshape(n, -1)
+        if env is not None:
+            env = np.ascontiguousarray(env, dtype=np.float64)
+            Ute = np.ascontiguousarray(U, dtype=np.float64).T @ env  # gsl_blas_dgemv(CblasTrans, U, env), :4047
+            self.fit_null(eval_, np.column_stack([UtW, Ute]), UtY)
+        else:
+            self.fit_null(eval_, UtW, UtY)
         lmm = LMM(a_mode=self.a_mode, l_min=self.l_min, l_max=self.l_max, n_region=self.n_region)
         lmm.setup(U, eval_, UtW, np.ascontiguousarray(UtY[:, 0]), plink=(geno_kind == L.GENO_PLINK_2BIT))
         v = d * (d + 1) // 2
@@ -556,7 +564,9 @@ class MVLMM:
         try:
             if indicator_idv is not None:
                 lmm.set_indicator(indicator_idv)
-            opt = self._opt()
+            if env is not None:
+                L.check(L.lib().gemma_hip_lmm_set_env(_ptr(env)), "MVLMM.set_env")
+            opt = self._opt(gxe=1 if env is not None else 0)
             L.check(L.lib().gemma_hip_mvlmm_set(d, _ptr(UtY), C.byref(self._null_struct), C.byref(opt)), "MVLMM.set")
             geno = np.ascontiguousarray(geno)
             for s0 in range(0, geno.shape[0], batch):
@@ -582,6 +592,16 @@ class MVLMM:
         """src/mvlmm.cpp:3418-3899"""
         return self.Analyze(U, eval_, UtW, UtY, np.ascontiguousarray(bed_rows, dtype=np.uint8), L.GENO_PLINK_2BIT,
                             indicator_idv=indicator_idv, batch=batch)
+
+    def AnalyzeBimbamGXE(self, U, eval_, UtW, UtY, env, X_snpmajor, batch=LMM_BATCH_SIZE):
+        """src/mvlmm.cpp:3970-4414"""
+        return self.Analyze(U, eval_, UtW, UtY, np.ascontiguousarray(X_snpmajor, dtype=np.float64), L.GENO_F64_SNP_MAJOR,
+                            batch=batch, env=env)
+
+    def AnalyzePlinkGXE(self, U, eval_, UtW, UtY, env, bed_rows, indicator_idv, batch=LMM_BATCH_SIZE):
+        """src/mvlmm.cpp:4416-4870"""
+        return self.Analyze(U, eval_, UtW, UtY, np.ascontiguousarray(bed_rows, dtype=np.uint8), L.GENO_PLINK_2BIT,
+                            indicator_idv=indicator_idv, batch=batch, env=env)
 
     def WriteFiles(self, path, snp_info):
         """MVLMM::WriteFiles (src/mvlmm.cpp:117-210)"""

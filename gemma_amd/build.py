@@ -14,6 +14,7 @@ UNITS = {
     "eigh_tu.hip": ["dgemm_mfma.hip.h", "eigh.hip.h", "eigh2.hip.h", "eigh_tu.h"],  # the eigensolver: its own object file
     "mvlmm_kernels.hip": ["mvlmm.hip.h", "mvlmm_kernels.hip.h"],
     "mvlmm_kernels_wide.hip": ["mvlmm.hip.h", "mvlmm_kernels.hip.h"],
+    "mvlmm_kernels_rt.hip": ["mvlmm.hip.h", "mvlmm_kernels.hip.h"],  # the run-time (d, c) instance
 }
 PUBLIC_HEADER_USERS = ("gemma_hip.hip", "eigh_tu.hip")
 SOURCES = list(UNITS)

@@ -105,7 +105,8 @@ struct Ctx {
   bool gxe_ready = false;
   double gxe_lnbeta = 0.0;
   DevBuf mv_Yt, mv_out; // multivariate LMM: U^T Y transposed (d x n)
-  bool mv_ready = false;
+  DevBuf mv_scratch;    // Newton-Raphson tables of the run-time kernel, one slab per workgroup
+  bool mv_ready = false, mv_gxe = false;
   size_t mv_d = 0;
   MvArgs mv_proto;
   DevBuf i8_Bt, i8_ej, i8_cmax, i8_A, i8_C, i8_mean; // exact int8-digit U^T x (i8gemm.hip.h)
@@ -1993,14 +1994,25 @@ extern "C" int gemma_hip_lmm_gene_batch(const double *Y, size_t l, size_t ld, ge
 // ---- multivariate LMM: MVLMM::AnalyzeBimbam / AnalyzePlink, src/mvlmm.cpp:2972-3899 (kernels in mvlmm_kernels.hip)
 extern "C" int gemma_hip_mvlmm_launch_(const MvArgs *g, int d, int c, hipStream_t s);
 extern "C" int gemma_hip_mvlmm_null_launch_(const MvNullArgs *a, int d, int c, hipStream_t s);
+// mvlmm_kernels_rt.hip: the run-time (d, c) kernel
+extern "C" size_t gemma_hip_mvlmm_rt_scratch_(int d, int c);
+extern "C" int gemma_hip_mvlmm_launch_rt_(const MvArgs *g, unsigned grid, hipStream_t s);
+extern "C" int gemma_hip_mvlmm_null_launch_rt_(const MvNullArgs *a, hipStream_t s);
 
-static int mv_check_dims(const char *who, size_t d, size_t c) {
+// c = covariates of the model the caller names; extra = the rows of X on top of them (1: the SNP; 3: env, SNP, interaction)
+static int mv_check_dims(const char *who, size_t d, size_t c, size_t extra = 1) {
   if (d < 1 || d > (size_t)MV_DMAX) return fail(GEMMA_HIP_EINVAL, "%s: %zu phenotypes not supported (1..%d)", who, d, MV_DMAX);
-  // kernels are built for d <= 5 with up to 3 covariates and for d <= 3 with up to MV_CMAX - 1 = 6 (mvlmm_kernels.hip)
-  const size_t cmax = d <= 3 ? (size_t)MV_CMAX - 1 : 3;
+  // fixed kernels: d <= 5 with up to 3 covariates, d <= 3 with up to 6 (mvlmm_kernels*.hip); everything else up to MV_DMAX phenotypes
+  // and MV_CMAX rows of X runs on the run-time kernel (mvlmm_kernels_rt.hip)
+  const size_t cmax = (size_t)MV_CMAX - extra;
   if (c < 1 || c > cmax)
-    return fail(GEMMA_HIP_EINVAL, "%s: %zu covariates not supported with %zu phenotypes (1..%zu)", who, c, d, cmax);
+    return fail(GEMMA_HIP_EINVAL, "%s: %zu covariates not supported (1..%zu)", who, c, cmax);
   return GEMMA_HIP_OK;
+}
+// GEMMA_HIP_MVLMM_RT=1: the run-time kernel also where a fixed one exists (tests)
+static bool mv_force_rt() {
+  const char *e = getenv("GEMMA_HIP_MVLMM_RT");
+  return e && e[0] == '1';
 }
 
 static void mv_default_opt(gemma_mvlmm_opt &o, const gemma_mvlmm_opt *opt) {
@@ -2014,6 +2026,7 @@ static void mv_default_opt(gemma_mvlmm_opt &o, const gemma_mvlmm_opt *opt) {
   o.nr_prec = 1e-4;
   o.p_nr = 1e-3;
   o.crt = 0;
+  o.gxe = 0;
 }
 
 // rows x cols (row-major, host) -> cols x rows on the device
@@ -2042,7 +2055,13 @@ extern "C" int gemma_hip_mvlmm_null(size_t n, size_t n_cvt, size_t d, const doub
     DevBuf *b[5];
     ~Rel() { for (DevBuf *x : b) x->release(); }
   } rel{{&d_eval, &d_Wt, &d_Yt, &d_Ypair, &d_out}};
-  if (d_eval.reserve(n * 8) || d_out.reserve(2 * (2 * 25 + 20 + 1) * 8)) return fail(GEMMA_HIP_ENOMEM, "mvlmm_null: buffers");
+  constexpr size_t RES_MAX = 2 * (2 * MV_DMAX * MV_DMAX + MV_BMAX + 1);
+  DevBuf d_scr;
+  struct Rel2 {
+    DevBuf *b;
+    ~Rel2() { b->release(); }
+  } rel2{&d_scr};
+  if (d_eval.reserve(n * 8) || d_out.reserve(RES_MAX * 8)) return fail(GEMMA_HIP_ENOMEM, "mvlmm_null: buffers");
   HIPCHK(hipMemcpy(d_eval.p, eval, n * 8, hipMemcpyHostToDevice));
   if ((rc = mv_upload_transposed(UtW, n, c, d_Wt)) || (rc = mv_upload_transposed(UtY, n, d, d_Yt))) return rc;
   // MphInitial :2780-2797: the diagonals from one univariate REML fit per trait
@@ -2071,14 +2090,20 @@ extern "C" int gemma_hip_mvlmm_null(size_t n, size_t n_cvt, size_t d, const doub
       a.Ve0[i] = ve0[i];
     }
     a.out = d_out.as<double>();
-    const int lrc = gemma_hip_mvlmm_null_launch_(&a, (int)dd, (int)c, 0);
-    if (lrc < 0) return fail(GEMMA_HIP_EINVAL, "mvlmm_null: no kernel for d=%zu, n_cvt=%zu", dd, c);
+    int lrc = mv_force_rt() ? -1 : gemma_hip_mvlmm_null_launch_(&a, (int)dd, (int)c, 0);
+    if (lrc < 0) { // no fixed kernel for this shape
+      a.g.d = (int)dd;
+      a.g.c = (int)c;
+      if (d_scr.reserve(gemma_hip_mvlmm_rt_scratch_((int)dd, (int)c) * 8)) return fail(GEMMA_HIP_ENOMEM, "mvlmm_null: scratch");
+      a.g.scratch = d_scr.as<double>();
+      lrc = gemma_hip_mvlmm_null_launch_rt_(&a, 0);
+    }
     if (lrc) return fail(GEMMA_HIP_ERUNTIME, "mvlmm_null launch: %s", hipGetErrorString((hipError_t)lrc));
     HIPCHK(hipDeviceSynchronize());
     HIPCHK(hipMemcpy(host_out, d_out.p, 2 * (2 * dd * dd + dd * c + 1) * 8, hipMemcpyDeviceToHost));
     return GEMMA_HIP_OK;
   };
-  std::vector<double> res(2 * (2 * 25 + 20 + 1));
+  std::vector<double> res(RES_MAX);
   if (d > 4) { // :2805-2884: off-diagonals from two-trait REML fits
     if (d_Ypair.reserve(2 * n * 8)) return fail(GEMMA_HIP_ENOMEM, "mvlmm_null: pair buffer");
     for (size_t i = 0; i < d; ++i)
@@ -2113,12 +2138,15 @@ extern "C" int gemma_hip_mvlmm_set(size_t d, const double *UtY, const gemma_mvlm
   NEED_INIT();
   if (!g_ctx.lmm_active) return fail(GEMMA_HIP_ESTATE, "mvlmm_set before lmm_setup");
   if (!UtY || !nf) return fail(GEMMA_HIP_EINVAL, "mvlmm_set: null pointer");
-  const size_t n = g_ctx.cfg.n, c = g_ctx.cfg.n_cvt;
-  int rc = mv_check_dims("mvlmm_set", d, c);
-  if (rc) return rc;
-  if (g_ctx.cfg.a_mode < 1 || g_ctx.cfg.a_mode > 4) return fail(GEMMA_HIP_EINVAL, "mvlmm_set: a_mode %d (1..4)", g_ctx.cfg.a_mode);
   gemma_mvlmm_opt o;
   mv_default_opt(o, opt);
+  const bool gxe = o.gxe == 1;
+  if (gxe && !g_ctx.gxe_ready) return fail(GEMMA_HIP_ESTATE, "mvlmm_set with gxe before lmm_set_env");
+  // gxe: the null fit is the one of (W, env) -- c covariates here; the per-SNP models add the SNP and its interaction row
+  const size_t n = g_ctx.cfg.n, c = g_ctx.cfg.n_cvt + (gxe ? 1 : 0);
+  int rc = mv_check_dims("mvlmm_set", d, c, gxe ? 2 : 1);
+  if (rc) return rc;
+  if (g_ctx.cfg.a_mode < 1 || g_ctx.cfg.a_mode > 4) return fail(GEMMA_HIP_EINVAL, "mvlmm_set: a_mode %d (1..4)", g_ctx.cfg.a_mode);
   if ((rc = mv_upload_transposed(UtY, n, d, g_ctx.mv_Yt))) return rc;
   MvArgs &a = g_ctx.mv_proto;
   memset(&a, 0, sizeof a);
@@ -2138,8 +2166,73 @@ extern "C" int gemma_hip_mvlmm_set(size_t d, const double *UtY, const gemma_mvlm
   a.crt = o.crt == 1 ? 1 : 0;       // :3302,3329,3349 test crt == 1
   a.stride = (int)(d + 3 * (d * (d + 1) / 2) + 3);
   g_ctx.mv_d = d;
+  g_ctx.mv_gxe = gxe;
   g_ctx.mv_ready = true;
   return GEMMA_HIP_OK;
+}
+
+// launches the per-SNP kernel: the fixed instance of (d, rows) if there is one, else the run-time kernel
+static int mv_launch(MvArgs &a, size_t d, size_t rows, hipStream_t s) {
+  int lrc = (a.UtX2 || mv_force_rt()) ? -1 : gemma_hip_mvlmm_launch_(&a, (int)d, (int)rows, s);
+  if (lrc < 0) {
+    a.d = (int)d;
+    a.c = (int)rows;
+    const unsigned grid = (unsigned)std::min<size_t>((size_t)a.l, 1024);
+    const size_t per = gemma_hip_mvlmm_rt_scratch_(a.d, a.c);
+    if (g_ctx.mv_scratch.reserve((size_t)grid * per * 8)) return fail(GEMMA_HIP_ENOMEM, "mvlmm_batch: %zu bytes of scratch", (size_t)grid * per * 8);
+    a.scratch = g_ctx.mv_scratch.as<double>();
+    lrc = gemma_hip_mvlmm_launch_rt_(&a, grid, s);
+  }
+  if (lrc) return fail(GEMMA_HIP_ERUNTIME, "mvlmm_batch launch: %s", hipGetErrorString((hipError_t)lrc));
+  return GEMMA_HIP_OK;
+}
+
+// MVLMM::AnalyzeBimbamGXE / AnalyzePlinkGXE (src/mvlmm.cpp:3970-4414 / :4416-4870): x, x o env and the allele flip as in the
+// univariate GXE path (ingest_gxe_kernel), both rotated by fp64 GEMMs
+static int mvlmm_gxe_batch_d(int kind, const void *geno, size_t l, size_t ld, double *out_d, hipStream_t s) {
+  if (kind == GEMMA_GENO_F64_IDV_MAJOR) return fail(GEMMA_HIP_EINVAL, "mvlmm_batch (gxe): SNP-major input only");
+  const size_t n = g_ctx.cfg.n, c = g_ctx.cfg.n_cvt;
+  const size_t ldx = (n + 1) & ~(size_t)1;
+  if (g_ctx.X.reserve(l * ldx * 8) || g_ctx.UtX.reserve(l * ldx * 8) || g_ctx.gxe_Z.reserve(l * ldx * 8) ||
+      g_ctx.gxe_UtZ.reserve(l * ldx * 8) || g_ctx.gxe_flip.reserve(l * sizeof(int)))
+    return fail(GEMMA_HIP_ENOMEM, "mvlmm_batch (gxe): cannot allocate 4 x %zu bytes", l * ldx * 8);
+  double *X = g_ctx.X.as<double>(), *UtX = g_ctx.UtX.as<double>();
+  double *Z = g_ctx.gxe_Z.as<double>(), *UtZ = g_ctx.gxe_UtZ.as<double>();
+  {
+    ProfScope ps(GEMMA_STAGE_INGEST, s);
+    IngestGxeArgs ia;
+    ia.src = geno; ia.ld = (long)ld; ia.l = (long)l;
+    ia.idx_map = g_ctx.have_map ? g_ctx.idx_map.as<int>() : nullptr;
+    ia.n = (int)n; ia.env = g_ctx.gxe_env.as<double>(); ia.X = X; ia.Z = Z; ia.ldo = (long)ldx;
+    ia.flip = g_ctx.gxe_flip.as<int>();
+    const unsigned grid = (unsigned)((l + 3) / 4);
+    if (kind == GEMMA_GENO_PLINK_2BIT)
+      hipLaunchKernelGGL(ingest_gxe_kernel<true>, dim3(grid), dim3(256), 0, s, ia);
+    else
+      hipLaunchKernelGGL(ingest_gxe_kernel<false>, dim3(grid), dim3(256), 0, s, ia);
+    HIPCHK(hipGetLastError());
+  }
+  {
+    ProfScope ps(GEMMA_STAGE_UTX_GEMM, s);
+    const double *Ug;
+    long ldu;
+    int rcu = gemm_U(&Ug, &ldu, s);
+    if (rcu) return rcu;
+    HIPCHK(launch_dgemm('N', 'N', (long)l, (long)n, (long)n, 1.0, X, (long)ldx, Ug, ldu, 0.0, UtX, (long)ldx, false, false, s));
+    HIPCHK(launch_dgemm('N', 'N', (long)l, (long)n, (long)n, 1.0, Z, (long)ldx, Ug, ldu, 0.0, UtZ, (long)ldx, false, false, s));
+  }
+  MvArgs a = g_ctx.mv_proto;
+  a.UtX = UtX;
+  a.UtX2 = UtZ;
+  a.flip = g_ctx.gxe_flip.as<int>();
+  a.ld = (long)ldx;
+  a.l = (long)l;
+  a.eval = g_ctx.eval;
+  a.Wt = g_ctx.gxe_UtWt.as<double>(); // W then U^T env
+  a.Yt = g_ctx.mv_Yt.as<double>();
+  a.out = out_d;
+  ProfScope ps(GEMMA_STAGE_ASSOC, s);
+  return mv_launch(a, g_ctx.mv_d, c + 3, s);
 }
 
 extern "C" int gemma_hip_mvlmm_batch_d(int kind, const void *geno, size_t l, size_t ld, double *out_d, void *stream) {
@@ -2149,6 +2242,7 @@ extern "C" int gemma_hip_mvlmm_batch_d(int kind, const void *geno, size_t l, siz
   int rc = check_batch_args("mvlmm_batch", kind, geno, l, ld, out_d);
   if (rc) return rc;
   hipStream_t s = S(stream);
+  if (g_ctx.mv_gxe) return mvlmm_gxe_batch_d(kind, geno, l, ld, out_d, s);
   double *UtX;
   size_t ldx;
   rc = compute_utx(kind, geno, l, ld, -1, &UtX, &ldx, s);
@@ -2161,13 +2255,8 @@ extern "C" int gemma_hip_mvlmm_batch_d(int kind, const void *geno, size_t l, siz
   a.Wt = g_ctx.UtWt.as<double>();
   a.Yt = g_ctx.mv_Yt.as<double>();
   a.out = out_d;
-  {
-    ProfScope ps(GEMMA_STAGE_ASSOC, s);
-    const int lrc = gemma_hip_mvlmm_launch_(&a, (int)g_ctx.mv_d, (int)g_ctx.cfg.n_cvt + 1, s);
-    if (lrc < 0) return fail(GEMMA_HIP_EINVAL, "mvlmm_batch: no kernel for d=%zu, n_cvt=%zu", g_ctx.mv_d, g_ctx.cfg.n_cvt);
-    if (lrc) return fail(GEMMA_HIP_ERUNTIME, "mvlmm_batch launch: %s", hipGetErrorString((hipError_t)lrc));
-  }
-  return GEMMA_HIP_OK;
+  ProfScope ps(GEMMA_STAGE_ASSOC, s);
+  return mv_launch(a, g_ctx.mv_d, g_ctx.cfg.n_cvt + 1, s);
 }
 
 extern "C" int gemma_hip_mvlmm_batch(int kind, const void *geno, size_t l, size_t ld, double *out) {
@@ -2558,7 +2647,7 @@ extern "C" int gemma_hip_lmm_finish(double *time_UtX_min, double *time_opt_min) 
   g_ctx.i8_ready = false;
   g_ctx.i8_colsum_ready = false;
   g_ctx.gxe_env.release(); g_ctx.gxe_UtWt.release(); g_ctx.gxe_Z.release(); g_ctx.gxe_UtZ.release();
-  g_ctx.mv_Yt.release(); g_ctx.mv_out.release();
+  g_ctx.mv_Yt.release(); g_ctx.mv_out.release(); g_ctx.mv_scratch.release();
   g_ctx.mv_ready = false;
   g_ctx.gxe_flip.release();
   g_ctx.gxe_ready = false;

@@ -17,12 +17,40 @@
 #ifndef MV_HD
 #define MV_HD __device__ __forceinline__
 #endif
+// the run-time instance calls its large pieces instead of inlining them: one copy of each, and private-memory frames that overlap
+// (inlined, the 21 call sites of one SNP summed to 120 KB of scratch per lane and 8 minutes of compile time)
+#ifndef MV_OUTLINE
+#define MV_OUTLINE __device__ __noinline__
+#endif
 
 namespace gemma_hip {
 
-constexpr int MV_DMAX = 5;  // phenotypes
-constexpr int MV_CMAX = 7;  // covariates + the SNP (d <= 3: up to 6 covariates; d = 4, 5: up to 3 -- the kernels that are built)
-constexpr int MV_BMAX = 20; // entries of B (d x covariates): 5 x 3, 3 x 6
+// Every function below exists in two forms from one source: FIXED (template arguments DT phenotypes, CT rows of X = covariates + the
+// SNP: loops unroll, the small matrices live in registers -- the kernels of mvlmm_kernels*.hip) and RUN-TIME (DT = CT = 0: d and c
+// come from MvRt, arrays are sized by the caps below and indexed with the run-time strides -- one kernel for every other (d, c),
+// and the only one that takes a second SNP row, the gene-environment interaction of MVLMM::AnalyzeBimbamGXE, src/mvlmm.cpp:3970).
+constexpr int MV_DMAX = 8;   // phenotypes
+constexpr int MV_CMAX = 12;  // rows of X: covariates (+ the environment) + the SNP (+ its interaction row)
+constexpr int MV_BMAX = MV_DMAX * MV_CMAX; // entries of B
+template <int DT> constexpr int mv_dk = DT > 0 ? DT : MV_DMAX; // array extents of the two forms
+template <int CT> constexpr int mv_ck = CT > 0 ? CT : MV_CMAX;
+template <int MT> constexpr int mv_mk = MT > 0 ? MT : -MT;     // small dense algebra: MT > 0 fixed order, MT < 0 run-time order <= -MT
+template <int XT, int CAP> constexpr int mv_mt = XT > 0 ? XT : -CAP;
+
+// run-time shape (read by the DT = CT = 0 instance only) and the second SNP row of the interaction test
+struct MvRt {
+  int d = 0, c = 0;
+  const double *x2 = nullptr; // GXE: row c - 2 of X is the SNP (the `x` argument), row c - 1 this one (U^T (x o env))
+};
+#define MV_SHAPE(rt_)                                                                                                      \
+  [[maybe_unused]] constexpr int DK = mv_dk<DT>, CK = mv_ck<CT>, TK = CK * (CK + 1) / 2, TDK = DK * (DK + 1) / 2, VSK = TDK, \
+                                 H2K = 2 * VSK;                                                                            \
+  [[maybe_unused]] const int D = DT > 0 ? DT : (rt_).d, C = CT > 0 ? CT : (rt_).c, T = C * (C + 1) / 2,                     \
+                             TD = D * (D + 1) / 2, VS = TD, H2 = 2 * VS
+#define MV_DD (mv_dk<DT> * mv_dk<DT>)
+#define MV_DC (mv_dk<DT> * mv_ck<CT>)
+#define MV_CC (mv_ck<CT> * mv_ck<CT>)
+#define MV_D1 (mv_dk<DT>)
 
 struct MvArgs {
   const double *UtX;  // l x ld, SNP-major
@@ -42,6 +70,11 @@ struct MvArgs {
   double *out;         // l x stride: beta[d], Vbeta[v], Vg[v], Ve[v], p_wald, p_lrt, p_score
   int stride;
   int crt;             // -crt: Edgeworth-corrected p values (CalcCRT / PCRT) for the SNPs that reach the Newton-Raphson stage
+  // run-time instance only
+  int d = 0, c = 0;    // phenotypes; rows of X of the alternative model (covariates + SNP [+ interaction])
+  const double *UtX2 = nullptr; // GXE: U^T (x o env), l x ld like UtX; Wt then ends with the U^T env row
+  const int *flip = nullptr;    // GXE: SNPs whose allele was switched (x_mean > 1: x <- 2 - x, :4232-4236): beta changes sign (:4331-4333)
+  double *scratch = nullptr;    // MvNrLayout(d, c).DOUBLES doubles per workgroup (the Newton-Raphson tables: too large for LDS at the caps)
 };
 
 #ifdef __HIPCC__
@@ -61,8 +94,11 @@ struct MvWaveLanes {
 // largest magnitude is positive.  The ML EM subtracts the PREVIOUS iteration's U_l^T V_e^-1/2 B X from this
 // iteration's rotated phenotypes (UltVehiBX is not refreshed before UpdateU, src/mvlmm.cpp:679-686), so the component
 // order and signs must not jump between two nearly equal matrices.
-template <int M> MV_HD void mv_jacobi(const double (&A)[M * M], double (&w)[M], double (&V)[M * M]) {
-  double a[M * M];
+template <int MT>
+MV_HD void mv_jacobi(const double (&A)[mv_mk<MT> * mv_mk<MT>], double (&w)[mv_mk<MT>], double (&V)[mv_mk<MT> * mv_mk<MT>], int m) {
+  constexpr int MK = mv_mk<MT>;
+  const int M = MT > 0 ? MT : m;
+  double a[MK * MK];
 #pragma unroll
   for (int i = 0; i < M * M; ++i) a[i] = A[i];
 #pragma unroll
@@ -143,8 +179,10 @@ template <int M> MV_HD void mv_jacobi(const double (&A)[M * M], double (&w)[M], 
 
 // inverse and log-determinant of a symmetric positive definite M x M matrix (Cholesky); a non-positive pivot
 // propagates NaN like the reference's LU of a singular Q propagates inf/NaN
-template <int M> MV_HD double mv_spd_inverse(const double (&A)[M * M], double (&Ai)[M * M]) {
-  double L[M * M], Li[M * M];
+template <int MT> MV_HD double mv_spd_inverse(const double (&A)[mv_mk<MT> * mv_mk<MT>], double (&Ai)[mv_mk<MT> * mv_mk<MT>], int m) {
+  constexpr int MK = mv_mk<MT>;
+  const int M = MT > 0 ? MT : m;
+  double L[MK * MK], Li[MK * MK];
   double lndet = 0.0;
 #pragma unroll
   for (int j = 0; j < M; ++j) {
@@ -280,11 +318,13 @@ MV_HD double mv_pcrt(int mode, int d, double p_value, const double (&crt)[3]) {
 }
 
 // ---------------------------------------------------------------- per-SNP state
-template <int D> struct MvBasis { // EigenProc, src/mvlmm.cpp:213-282
-  double Dl[D], UltVeh[D * D], UltVehi[D * D], logdet_Ve;
-  MV_HD void build(const double (&Vg)[D * D], const double (&Ve)[D * D]) {
-    double w[D], Ul[D * D], Veh[D * D], Vehi[D * D], T1[D * D], Lam[D * D];
-    mv_jacobi<D>(Ve, w, Ul);
+template <int DT> struct MvBasis { // EigenProc, src/mvlmm.cpp:213-282
+  static constexpr int DK = mv_dk<DT>;
+  double Dl[DK], UltVeh[DK * DK], UltVehi[DK * DK], logdet_Ve;
+  MV_HD void build(const double (&Vg)[MV_DD], const double (&Ve)[MV_DD], int d) {
+    const int D = DT > 0 ? DT : d;
+    double w[DK], Ul[DK * DK], Veh[DK * DK], Vehi[DK * DK], T1[DK * DK], Lam[DK * DK];
+    mv_jacobi<mv_mt<DT, MV_DMAX>>(Ve, w, Ul, D);
     logdet_Ve = 0.0;
 #pragma unroll
     for (int i = 0; i < D * D; ++i) Veh[i] = Vehi[i] = 0.0;
@@ -324,7 +364,7 @@ template <int D> struct MvBasis { // EigenProc, src/mvlmm.cpp:213-282
     for (int a = 0; a < D; ++a)
 #pragma unroll
       for (int b = a + 1; b < D; ++b) Lam[a * D + b] = Lam[b * D + a] = 0.5 * (Lam[a * D + b] + Lam[b * D + a]);
-    mv_jacobi<D>(Lam, Dl, Ul);
+    mv_jacobi<mv_mt<DT, MV_DMAX>>(Lam, Dl, Ul, D);
 #pragma unroll
     for (int i = 0; i < D; ++i)
       if (Dl[i] < 0) Dl[i] = 0;
@@ -346,14 +386,31 @@ template <int D> struct MvBasis { // EigenProc, src/mvlmm.cpp:213-282
 
 // the sums of one pass over the individuals at a fixed basis: per component l the c x c block Q_l (upper triangle),
 // xHiy (c per component) and the scalar part of MphCalcLogL (:571-581)
-template <int D, int C> struct MvMoments {
-  static constexpr int T = C * (C + 1) / 2;
-  double Q[D * T], xHiy[D * C], ll;
+template <int DT, int CT> struct MvMoments {
+  static constexpr int DK = mv_dk<DT>, CK = mv_ck<CT>, TK = CK * (CK + 1) / 2;
+  double Q[DK * TK], xHiy[DK * CK], ll;
 };
 
-template <int D, int C, class Lanes>
-MV_HD void mv_pass_moments(const MvArgs &g, const double *__restrict__ x, const MvBasis<D> &bs, MvMoments<D, C> &m) {
-  constexpr int T = C * (C + 1) / 2;
+// row k of X^T: the covariates from Wt, then the SNP (fixed form: always one row; run-time form with rt.x2: the SNP and its
+// interaction row)
+template <int CT>
+MV_HD void mv_load_x(const MvArgs &g, const MvRt &rt, const double *__restrict__ x, int k, double (&xv)[mv_ck<CT>]) {
+  const int C = CT > 0 ? CT : rt.c;
+  const bool two = CT == 0 && rt.x2 != nullptr;
+  const int nw = two ? C - 2 : C - 1;
+#pragma unroll
+  for (int j = 0; j < nw; ++j) xv[j] = g.Wt[(long)j * g.n + k];
+  if (two) {
+    xv[C - 2] = x[k];
+    xv[C - 1] = rt.x2[k];
+  } else {
+    xv[C - 1] = x[k];
+  }
+}
+
+template <int DT, int CT, class Lanes>
+MV_HD void mv_pass_moments(const MvArgs &g, const MvRt &rt, const double *__restrict__ x, const MvBasis<DT> &bs, MvMoments<DT, CT> &m) {
+  MV_SHAPE(rt);
 #pragma unroll
   for (int i = 0; i < D * T; ++i) m.Q[i] = 0.0;
 #pragma unroll
@@ -361,10 +418,8 @@ MV_HD void mv_pass_moments(const MvArgs &g, const double *__restrict__ x, const 
   m.ll = 0.0;
   for (int k = Lanes::lane(); k < g.n; k += Lanes::N) {
     const double delta = g.eval[k];
-    double xv[C], yv[D];
-#pragma unroll
-    for (int j = 0; j < C - 1; ++j) xv[j] = g.Wt[(long)j * g.n + k];
-    xv[C - 1] = x[k];
+    double xv[CK], yv[DK];
+    mv_load_x<CT>(g, rt, x, k, xv);
 #pragma unroll
     for (int i = 0; i < D; ++i) yv[i] = g.Yt[(long)i * g.n + k];
 #pragma unroll
@@ -391,7 +446,8 @@ MV_HD void mv_pass_moments(const MvArgs &g, const double *__restrict__ x, const 
   m.ll = Lanes::sum(m.ll);
 }
 
-template <int C> MV_HD void mv_unpack_sym(const double *tri, double (&A)[C * C]) {
+template <int CT> MV_HD void mv_unpack_sym(const double *tri, double (&A)[MV_CC], int c) {
+  const int C = CT > 0 ? CT : c;
   int t = 0;
 #pragma unroll
   for (int a = 0; a < C; ++a)
@@ -400,17 +456,16 @@ template <int C> MV_HD void mv_unpack_sym(const double *tri, double (&A)[C * C])
 }
 
 // log|X X^T| and (X X^T)^-1 over the c covariate rows (:631-649)
-template <int C, class Lanes>
-MV_HD double mv_xxt(const MvArgs &g, const double *__restrict__ x, double (&XXti)[C * C]) {
-  constexpr int T = C * (C + 1) / 2;
-  double tri[T];
+template <int CT, class Lanes>
+MV_HD double mv_xxt(const MvArgs &g, const MvRt &rt, const double *__restrict__ x, double (&XXti)[MV_CC]) {
+  constexpr int CK = mv_ck<CT>, TK = CK * (CK + 1) / 2;
+  const int C = CT > 0 ? CT : rt.c, T = C * (C + 1) / 2;
+  double tri[TK];
 #pragma unroll
   for (int i = 0; i < T; ++i) tri[i] = 0.0;
   for (int k = Lanes::lane(); k < g.n; k += Lanes::N) {
-    double xv[C];
-#pragma unroll
-    for (int j = 0; j < C - 1; ++j) xv[j] = g.Wt[(long)j * g.n + k];
-    xv[C - 1] = x[k];
+    double xv[CK];
+    mv_load_x<CT>(g, rt, x, k, xv);
     int t = 0;
 #pragma unroll
     for (int a = 0; a < C; ++a)
@@ -419,37 +474,37 @@ MV_HD double mv_xxt(const MvArgs &g, const double *__restrict__ x, double (&XXti
   }
 #pragma unroll
   for (int i = 0; i < T; ++i) tri[i] = Lanes::sum(tri[i]);
-  double XXt[C * C];
-  mv_unpack_sym<C>(tri, XXt);
-  return mv_spd_inverse<C>(XXt, XXti);
+  double XXt[CK * CK];
+  mv_unpack_sym<CT>(tri, XXt, C);
+  return mv_spd_inverse<mv_mt<CT, MV_CMAX>>(XXt, XXti, C);
 }
 
 // MphEM, src/mvlmm.cpp:599-724.  Vg, Ve (d x d) and B (d x c) are updated in place; returns the last logl.
-template <int D, int C, class Lanes>
-MV_HD double mv_em(const MvArgs &g, const double *__restrict__ x, bool reml, int max_iter, double max_prec,
-                   double lndet_xxt, const double (&XXti)[C * C], double (&Vg)[D * D], double (&Ve)[D * D],
-                   double (&B)[D * C]) {
-  constexpr int T = C * (C + 1) / 2;
+template <int DT, int CT, class Lanes>
+MV_HD double mv_em(const MvArgs &g, const MvRt &rt, const double *__restrict__ x, bool reml, int max_iter, double max_prec,
+                   double lndet_xxt, const double (&XXti)[MV_CC], double (&Vg)[MV_DD], double (&Ve)[MV_DD],
+                   double (&B)[MV_DC]) {
+  MV_SHAPE(rt);
   constexpr double LOG2PI = 1.8378770664093454836;
   const int n = g.n;
   const double logl_const = reml ? -0.5 * (double)(n - C) * (double)D * LOG2PI + 0.5 * (double)D * lndet_xxt
                                  : -0.5 * (double)n * (double)D * LOG2PI;
-  double UltVehiB[D * C]; // component-major: [l][j]
+  double UltVehiB[DK * CK]; // component-major: [l][j]
 #pragma unroll
   for (int i = 0; i < D * C; ++i) UltVehiB[i] = 0.0;
   double logl_old = 0.0, logl_new = 0.0;
-  MvBasis<D> bs;
-  MvMoments<D, C> m;
-  double Qi[D][C * C];
+  MvBasis<DT> bs;
+  MvMoments<DT, CT> m;
+  double Qi[DK][CK * CK];
   for (int t = 0; t < max_iter; ++t) {
-    bs.build(Vg, Ve);
-    mv_pass_moments<D, C, Lanes>(g, x, bs, m);
-    double logdet_Q = 0.0, quad = 0.0, bl[D * C];
+    bs.build(Vg, Ve, D);
+    mv_pass_moments<DT, CT, Lanes>(g, rt, x, bs, m);
+    double logdet_Q = 0.0, quad = 0.0, bl[DK * CK];
 #pragma unroll
     for (int l = 0; l < D; ++l) {
-      double Ql[C * C];
-      mv_unpack_sym<C>(m.Q + l * T, Ql);
-      logdet_Q += mv_spd_inverse<C>(Ql, Qi[l]);
+      double Ql[CK * CK];
+      mv_unpack_sym<CT>(m.Q + l * T, Ql, C);
+      logdet_Q += mv_spd_inverse<mv_mt<CT, MV_CMAX>>(Ql, Qi[l], C);
 #pragma unroll
       for (int a = 0; a < C; ++a) {
         double s = 0.0;
@@ -478,19 +533,17 @@ MV_HD double mv_em(const MvArgs &g, const double *__restrict__ x, bool reml, int
           UltVehiB[l * C + j] = s;
         }
     }
-    double Bnew[D * C]; // UltVehiB after UpdateL_B (ML) -- equal to UltVehiB for REML
+    double Bnew[DK * CK]; // UltVehiB after UpdateL_B (ML) -- equal to UltVehiB for REML
 #pragma unroll
     for (int i = 0; i < D * C; ++i) Bnew[i] = UltVehiB[i];
     if (!reml) { // UpdateL_B :402-418: (UltVehiY - UltVehiU) X^T (X X^T)^-1
-      double YUX[D * C];
+      double YUX[DK * CK];
 #pragma unroll
       for (int i = 0; i < D * C; ++i) YUX[i] = 0.0;
       for (int k = Lanes::lane(); k < n; k += Lanes::N) {
         const double delta = g.eval[k];
-        double xv[C], yv[D];
-#pragma unroll
-        for (int j = 0; j < C - 1; ++j) xv[j] = g.Wt[(long)j * n + k];
-        xv[C - 1] = x[k];
+        double xv[CK], yv[DK];
+        mv_load_x<CT>(g, rt, x, k, xv);
 #pragma unroll
         for (int i = 0; i < D; ++i) yv[i] = g.Yt[(long)i * n + k];
 #pragma unroll
@@ -519,18 +572,15 @@ MV_HD double mv_em(const MvArgs &g, const double *__restrict__ x, bool reml, int
         }
     }
     // U_hat, E_hat, Sigma (UpdateU / UpdateE / CalcSigma / UpdateV :686-708)
-    constexpr int TD = D * (D + 1) / 2;
-    double VgS[TD], VeS[TD], Suu[D], See[D];
+    double VgS[TDK], VeS[TDK], Suu[DK], See[DK];
 #pragma unroll
     for (int i = 0; i < TD; ++i) VgS[i] = VeS[i] = 0.0;
 #pragma unroll
     for (int i = 0; i < D; ++i) Suu[i] = See[i] = 0.0;
     for (int k = Lanes::lane(); k < n; k += Lanes::N) {
       const double delta = g.eval[k];
-      double xv[C], yv[D], Uv[D], Ev[D];
-#pragma unroll
-      for (int j = 0; j < C - 1; ++j) xv[j] = g.Wt[(long)j * n + k];
-      xv[C - 1] = x[k];
+      double xv[CK], yv[DK], Uv[DK], Ev[DK];
+      mv_load_x<CT>(g, rt, x, k, xv);
 #pragma unroll
       for (int i = 0; i < D; ++i) yv[i] = g.Yt[(long)i * n + k];
 #pragma unroll
@@ -559,7 +609,7 @@ MV_HD double mv_em(const MvArgs &g, const double *__restrict__ x, bool reml, int
         Suu[l] += su;
         See[l] += se;
       }
-      double Uh[D], Eh[D];
+      double Uh[DK], Eh[DK];
 #pragma unroll
       for (int a = 0; a < D; ++a) {
         double s1 = 0.0, s2 = 0.0;
@@ -621,28 +671,42 @@ MV_HD double mv_em(const MvArgs &g, const double *__restrict__ x, bool reml, int
   return logl_new;
 }
 
+template <int DT, int CT, class Lanes>
+MV_OUTLINE double mv_em_out(const MvArgs &g, const MvRt &rt, const double *__restrict__ x, bool reml, int max_iter, double max_prec,
+                            double lndet_xxt, const double (&XXti)[MV_CC], double (&Vg)[MV_DD], double (&Ve)[MV_DD], double (&B)[MV_DC]) {
+  return mv_em<DT, CT, Lanes>(g, rt, x, reml, max_iter, max_prec, lndet_xxt, XXti, Vg, Ve, B);
+}
+template <int DT, int CT, class Lanes>
+MV_HD double mv_em_sel(const MvArgs &g, const MvRt &rt, const double *__restrict__ x, bool reml, int max_iter, double max_prec,
+                       double lndet_xxt, const double (&XXti)[MV_CC], double (&Vg)[MV_DD], double (&Ve)[MV_DD], double (&B)[MV_DC]) {
+  if constexpr (DT == 0) return mv_em_out<0, 0, Lanes>(g, rt, x, reml, max_iter, max_prec, lndet_xxt, XXti, Vg, Ve, B);
+  else return mv_em<DT, CT, Lanes>(g, rt, x, reml, max_iter, max_prec, lndet_xxt, XXti, Vg, Ve, B);
+}
+
 // MphCalcP, src/mvlmm.cpp:727-831: the covariates are the first C - 1 rows, the SNP the last; beta (d), Vbeta (d x d)
-template <int D, int C, class Lanes>
-MV_HD double mv_calcp(const MvArgs &g, const double *__restrict__ x, const double (&Vg)[D * D], const double (&Ve)[D * D],
-                      double (&beta)[D], double (&Vbeta)[D * D]) {
-  constexpr int T = C * (C + 1) / 2, CW = C - 1;
-  MvBasis<D> bs;
-  MvMoments<D, C> m;
-  bs.build(Vg, Ve);
-  mv_pass_moments<D, C, Lanes>(g, x, bs, m);
-  double sol[D], vinv[D], stat = 0.0;
+template <int DT, int CT, class Lanes>
+MV_HD double mv_calcp(const MvArgs &g, const MvRt &rt, const double *__restrict__ x, const double (&Vg)[MV_DD], const double (&Ve)[MV_DD],
+                      double (&beta)[MV_D1], double (&Vbeta)[MV_DD]) {
+  MV_SHAPE(rt);
+  constexpr int CWT = CT > 0 ? (CT > 1 ? CT - 1 : 1) : -MV_CMAX, CWK = mv_mk<CWT>; // the covariate block: order c - 1
+  const int CW = C - 1;
+  MvBasis<DT> bs;
+  MvMoments<DT, CT> m;
+  bs.build(Vg, Ve, D);
+  mv_pass_moments<DT, CT, Lanes>(g, rt, x, bs, m);
+  double sol[DK], vinv[DK], stat = 0.0;
 #pragma unroll
   for (int l = 0; l < D; ++l) {
-    double Ql[C * C];
-    mv_unpack_sym<C>(m.Q + l * T, Ql);
+    double Ql[CK * CK];
+    mv_unpack_sym<CT>(m.Q + l * T, Ql, C);
     double xPx = Ql[(C - 1) * C + (C - 1)], xPy = m.xHiy[l * C + (C - 1)];
     if (CW > 0) {
-      double QW[(CW > 0 ? CW : 1) * (CW > 0 ? CW : 1)], QWi[(CW > 0 ? CW : 1) * (CW > 0 ? CW : 1)];
+      double QW[CWK * CWK], QWi[CWK * CWK];
 #pragma unroll
       for (int a = 0; a < CW; ++a)
 #pragma unroll
         for (int b = 0; b < CW; ++b) QW[a * CW + b] = Ql[a * C + b];
-      mv_spd_inverse<(CW > 0 ? CW : 1)>(QW, QWi);
+      mv_spd_inverse<CWT>(QW, QWi, CW);
 #pragma unroll
       for (int a = 0; a < CW; ++a) {
         double s = 0.0;
@@ -673,7 +737,23 @@ MV_HD double mv_calcp(const MvArgs &g, const double *__restrict__ x, const doubl
   return mv_chisq_Q(stat, D);
 }
 
+template <int DT, int CT, class Lanes>
+MV_OUTLINE double mv_calcp_out(const MvArgs &g, const MvRt &rt, const double *__restrict__ x, const double (&Vg)[MV_DD],
+                               const double (&Ve)[MV_DD], double (&beta)[MV_D1], double (&Vbeta)[MV_DD]) {
+  return mv_calcp<DT, CT, Lanes>(g, rt, x, Vg, Ve, beta, Vbeta);
+}
+template <int DT, int CT, class Lanes>
+MV_HD double mv_calcp_sel(const MvArgs &g, const MvRt &rt, const double *__restrict__ x, const double (&Vg)[MV_DD],
+                          const double (&Ve)[MV_DD], double (&beta)[MV_D1], double (&Vbeta)[MV_DD]) {
+  if constexpr (DT == 0) return mv_calcp_out<0, 0, Lanes>(g, rt, x, Vg, Ve, beta, Vbeta);
+  else return mv_calcp<DT, CT, Lanes>(g, rt, x, Vg, Ve, beta, Vbeta);
+}
+
 // ---------------------------------------------------------------- MphNR (src/mvlmm.cpp:2608-2760)
+template <class NR, int N2> MV_OUTLINE double mv_nr_out(NR &nr, bool reml, double lndet_xxt, double (&Vg)[N2], double (&Ve)[N2], int max_iter) {
+  return nr.run(reml, lndet_xxt, Vg, Ve, max_iter);
+}
+
 // index of the pair (a <= b) in a packed upper triangle of order N (GetIndex :1093-1109)
 MV_HD constexpr int mv_tri(int a, int b, int N) { return a <= b ? (2 * N - a + 1) * a / 2 + b - a : (2 * N - b + 1) * b / 2 + a - b; }
 
@@ -684,13 +764,16 @@ MV_HD constexpr int mv_tri(int a, int b, int N) { return a <= b ? (2 * N - a + 1
 //   R[a][j][l][q]     sum x_j w_l u_q              S[a][l1<=l2][j1<=j2]  sum x_j1 x_j2 w_l1 w_l2
 //   WW[s][l1<=l2]     sum w_l1 w_l2                Y3[s][q][p<=r]        sum u_p w_q u_r
 //   S3[s][l][q][j1<=j2] sum x_j1 x_j2 w_l^2 w_q
-template <int D, int C> struct MvNrScratch {
-  static constexpr int T = C * (C + 1) / 2, TD = D * (D + 1) / 2, VS = TD, H2 = 2 * VS;
-  static constexpr int W1 = 0, UU = W1 + 2 * D, R = UU + 2 * TD, S = R + 2 * C * D * D, WW = S + 2 * TD * T;
-  static constexpr int Y3 = WW + 3 * TD, S3 = Y3 + 3 * D * TD, DT = S3 + 3 * D * D * T; // DT: rotated directions
-  static constexpr int QI = DT + VS * D * D, GRAD = QI + D * C * C, HESS = GRAD + H2, HINV = HESS + H2 * H2;
-  // LU: the elimination scratch of invert_hessian, afterwards the 8 d x d tables of crt_factors
-  static constexpr int LU = HINV + H2 * H2, LUSZ = (H2 * H2 > 8 * D * D) ? H2 * H2 : 8 * D * D, DOUBLES = LU + LUSZ;
+struct MvNrLayout {
+  int T, TD, VS, H2, W1, UU, R, S, WW, Y3, S3, DT, QI, GRAD, HESS, HINV, LU, LUSZ, DOUBLES;
+  // DT: rotated directions; LU: the elimination scratch of invert_hessian, afterwards the 8 d x d tables of crt_factors
+  constexpr MvNrLayout(int D, int C)
+      : T(C * (C + 1) / 2), TD(D * (D + 1) / 2), VS(TD), H2(2 * VS), W1(0), UU(W1 + 2 * D), R(UU + 2 * TD), S(R + 2 * C * D * D),
+        WW(S + 2 * TD * T), Y3(WW + 3 * TD), S3(Y3 + 3 * D * TD), DT(S3 + 3 * D * D * T), QI(DT + VS * D * D), GRAD(QI + D * C * C),
+        HESS(GRAD + H2), HINV(HESS + H2 * H2), LU(HINV + H2 * H2), LUSZ((H2 * H2 > 8 * D * D) ? H2 * H2 : 8 * D * D), DOUBLES(LU + LUSZ) {}
+};
+template <int D, int C> struct MvNrScratch { // the fixed kernels' LDS array
+  static constexpr int DOUBLES = MvNrLayout(D, C).DOUBLES;
 };
 
 MV_HD void mv_lane_fence() {
@@ -700,26 +783,29 @@ MV_HD void mv_lane_fence() {
 #endif
 }
 
-template <int D, int C, class Lanes> struct MvNr {
-  using SC = MvNrScratch<D, C>;
-  static constexpr int T = SC::T, TD = SC::TD, VS = SC::VS, H2 = SC::H2;
+template <int DT, int CT, class Lanes> struct MvNr {
   const MvArgs &g;
-  double *lds;            // SC::DOUBLES doubles owned by this wavefront
+  double *lds;            // sc.DOUBLES doubles owned by this wavefront (LDS for the fixed kernels, global memory for the run-time one)
+  const MvRt rt;
+  const MvNrLayout sc;
   const double *x = nullptr;
+  MV_HD MvNr(const MvArgs &g_, double *lds_, const MvRt &rt_ = MvRt())
+      : g(g_), lds(lds_), rt(rt_), sc(DT > 0 ? DT : rt_.d, CT > 0 ? CT : rt_.c) {}
 
   // logl at (Vg, Ve) and, if want_dev, gradient + CalcDev's Hessian in lds[GRAD], lds[HESS]
-  MV_HD double eval(bool reml, double logl_const, const double (&Vg)[D * D], const double (&Ve)[D * D], bool want_dev) {
+  MV_HD double eval(bool reml, double logl_const, const double (&Vg)[MV_DD], const double (&Ve)[MV_DD], bool want_dev) {
+    MV_SHAPE(rt);
     const int n = g.n;
-    MvBasis<D> bs;
-    MvMoments<D, C> m;
-    bs.build(Vg, Ve);
-    mv_pass_moments<D, C, Lanes>(g, x, bs, m);
-    double logdet_Q = 0.0, quad = 0.0, Bt[D * C], Qi[D][C * C];
+    MvBasis<DT> bs;
+    MvMoments<DT, CT> m;
+    bs.build(Vg, Ve, D);
+    mv_pass_moments<DT, CT, Lanes>(g, rt, x, bs, m);
+    double logdet_Q = 0.0, quad = 0.0, Bt[DK * CK], Qi[DK][CK * CK];
 #pragma unroll
     for (int l = 0; l < D; ++l) {
-      double Ql[C * C];
-      mv_unpack_sym<C>(m.Q + l * T, Ql);
-      logdet_Q += mv_spd_inverse<C>(Ql, Qi[l]);
+      double Ql[CK * CK];
+      mv_unpack_sym<CT>(m.Q + l * T, Ql, C);
+      logdet_Q += mv_spd_inverse<mv_mt<CT, MV_CMAX>>(Ql, Qi[l], C);
 #pragma unroll
       for (int a = 0; a < C; ++a) {
         double s = 0.0;
@@ -737,7 +823,7 @@ template <int D, int C, class Lanes> struct MvNr {
     for (int s = 0; s < 3; ++s)
 #pragma unroll
       for (int l1 = 0; l1 < D; ++l1) {
-        double aW1 = 0.0, aUU[TD], aR[C * D], aS[D * T], aWW[D], aY3[TD], aS3[D * T];
+        double aW1 = 0.0, aUU[TDK], aR[CK * DK], aS[DK * TK], aWW[DK], aY3[TDK], aS3[DK * TK];
 #pragma unroll
         for (int i = 0; i < TD; ++i) aUU[i] = aY3[i] = 0.0;
 #pragma unroll
@@ -749,10 +835,8 @@ template <int D, int C, class Lanes> struct MvNr {
         for (int k = Lanes::lane(); k < n; k += Lanes::N) {
           const double delta = g.eval[k];
           const double ws = (s == 0) ? 1.0 : (s == 1 ? delta : delta * delta);
-          double xv[C], yv[D], w[D], u[D];
-#pragma unroll
-          for (int j = 0; j < C - 1; ++j) xv[j] = g.Wt[(long)j * n + k];
-          xv[C - 1] = x[k];
+          double xv[CK], yv[DK], w[DK], u[DK];
+          mv_load_x<CT>(g, rt, x, k, xv);
 #pragma unroll
           for (int i = 0; i < D; ++i) yv[i] = g.Yt[(long)i * n + k];
 #pragma unroll
@@ -804,44 +888,44 @@ template <int D, int C, class Lanes> struct MvNr {
         const bool wr = Lanes::lane() == 0;
         if (s < 2) {
           const double v = Lanes::sum(aW1);
-          if (wr) lds[SC::W1 + s * D + l1] = v;
+          if (wr) lds[sc.W1 + s * D + l1] = v;
           if (l1 == 0)
 #pragma unroll
             for (int i = 0; i < TD; ++i) {
               const double v2 = Lanes::sum(aUU[i]);
-              if (wr) lds[SC::UU + s * TD + i] = v2;
+              if (wr) lds[sc.UU + s * TD + i] = v2;
             }
 #pragma unroll
           for (int j = 0; j < C; ++j)
 #pragma unroll
             for (int q = 0; q < D; ++q) {
               const double v2 = Lanes::sum(aR[j * D + q]);
-              if (wr) lds[SC::R + ((s * C + j) * D + l1) * D + q] = v2;
+              if (wr) lds[sc.R + ((s * C + j) * D + l1) * D + q] = v2;
             }
 #pragma unroll
           for (int l2 = l1; l2 < D; ++l2)
 #pragma unroll
             for (int t = 0; t < T; ++t) {
               const double v2 = Lanes::sum(aS[l2 * T + t]);
-              if (wr) lds[SC::S + (s * TD + mv_tri(l1, l2, D)) * T + t] = v2;
+              if (wr) lds[sc.S + (s * TD + mv_tri(l1, l2, D)) * T + t] = v2;
             }
         }
 #pragma unroll
         for (int l2 = l1; l2 < D; ++l2) {
           const double v2 = Lanes::sum(aWW[l2]);
-          if (wr) lds[SC::WW + s * TD + mv_tri(l1, l2, D)] = v2;
+          if (wr) lds[sc.WW + s * TD + mv_tri(l1, l2, D)] = v2;
         }
 #pragma unroll
         for (int i = 0; i < TD; ++i) {
           const double v2 = Lanes::sum(aY3[i]);
-          if (wr) lds[SC::Y3 + (s * D + l1) * TD + i] = v2;
+          if (wr) lds[sc.Y3 + (s * D + l1) * TD + i] = v2;
         }
 #pragma unroll
         for (int q = 0; q < D; ++q)
 #pragma unroll
           for (int t = 0; t < T; ++t) {
             const double v2 = Lanes::sum(aS3[q * T + t]);
-            if (wr) lds[SC::S3 + ((s * D + l1) * D + q) * T + t] = v2;
+            if (wr) lds[sc.S3 + ((s * D + l1) * D + q) * T + t] = v2;
           }
       }
     // rotated directions and the Q blocks
@@ -856,13 +940,13 @@ template <int D, int C, class Lanes> struct MvNr {
 #pragma unroll
             for (int q = 0; q < D; ++q) {
               const double a = bs.UltVehi[p * D + i] * bs.UltVehi[q * D + j];
-              lds[SC::DT + (v * D + p) * D + q] = (i == j) ? a : a + bs.UltVehi[p * D + j] * bs.UltVehi[q * D + i];
+              lds[sc.DT + (v * D + p) * D + q] = (i == j) ? a : a + bs.UltVehi[p * D + j] * bs.UltVehi[q * D + i];
             }
         }
 #pragma unroll
       for (int l = 0; l < D; ++l)
 #pragma unroll
-        for (int t = 0; t < C * C; ++t) lds[SC::QI + l * C * C + t] = Qi[l][t];
+        for (int t = 0; t < C * C; ++t) lds[sc.QI + l * C * C + t] = Qi[l][t];
     }
     mv_lane_fence();
     contract(reml);
@@ -871,22 +955,23 @@ template <int D, int C, class Lanes> struct MvNr {
   }
 
   // symmetric c x c block stored as a packed triangle
-  MV_HD double symget(const double *tri, int a, int b) const { return tri[mv_tri(a, b, C)]; }
+  MV_HD double symget(const double *tri, int a, int b) const { return tri[mv_tri(a, b, CT > 0 ? CT : rt.c)]; }
 
   // gradient and Hessian from the tables (every lane computes the same values; plain loops over LDS)
   MV_HD void contract(bool reml) {
-    const double *DT = lds + SC::DT, *QI = lds + SC::QI;
-    double *grad = lds + SC::GRAD, *hess = lds + SC::HESS;
+    MV_SHAPE(rt);
+    const double *Dtab = lds + sc.DT, *QI = lds + sc.QI;
+    double *grad = lds + sc.GRAD, *hess = lds + sc.HESS;
     for (int v = 0; v < VS; ++v) {
-      const double *Dv = DT + v * D * D;
+      const double *Dv = Dtab + v * D * D;
       for (int a = 0; a < 2; ++a) {
         double yPDPy = 0.0, trHiD = 0.0, trQM = 0.0;
         for (int p = 0; p < D; ++p)
-          for (int q = 0; q < D; ++q) yPDPy += Dv[p * D + q] * lds[SC::UU + a * TD + mv_tri(p, q, D)];
+          for (int q = 0; q < D; ++q) yPDPy += Dv[p * D + q] * lds[sc.UU + a * TD + mv_tri(p, q, D)];
         for (int l = 0; l < D; ++l) {
-          trHiD += Dv[l * D + l] * lds[SC::W1 + a * D + l];
+          trHiD += Dv[l * D + l] * lds[sc.W1 + a * D + l];
           if (reml) {
-            const double *Sl = lds + SC::S + (a * TD + mv_tri(l, l, D)) * T;
+            const double *Sl = lds + sc.S + (a * TD + mv_tri(l, l, D)) * T;
             double t = 0.0;
             for (int j1 = 0; j1 < C; ++j1)
               for (int j2 = 0; j2 < C; ++j2) t += QI[l * C * C + j1 * C + j2] * symget(Sl, j1, j2);
@@ -899,23 +984,23 @@ template <int D, int C, class Lanes> struct MvNr {
     for (int i = 0; i < H2 * H2; ++i) hess[i] = 0.0;
     for (int v1 = 0; v1 < VS; ++v1)
       for (int v2 = v1; v2 < VS; ++v2) {
-        const double *D1 = DT + v1 * D * D, *D2 = DT + v2 * D * D;
+        const double *D1 = Dtab + v1 * D * D, *D2 = Dtab + v2 * D * D;
         double dev2[3];
         for (int sI = 0; sI < 3; ++sI) { // ee, ge (D1 = V_g direction, D2 = V_e direction), gg
           const int a1 = sI >= 1, a2 = sI == 2;
           double yy = 0.0, trHH = 0.0, t2 = 0.0, t4 = 0.0, rQr = 0.0;
           for (int q = 0; q < D; ++q) {
-            const double *Y3q = lds + SC::Y3 + (sI * D + q) * TD;
+            const double *Y3q = lds + sc.Y3 + (sI * D + q) * TD;
             for (int p = 0; p < D; ++p)
               for (int r = 0; r < D; ++r) yy += D1[q * D + p] * D2[q * D + r] * Y3q[mv_tri(p, r, D)];
           }
           for (int l = 0; l < D; ++l) {
-            double r1[C], r2[C];
+            double r1[CK], r2[CK];
             for (int j = 0; j < C; ++j) {
               double s1 = 0.0, s2 = 0.0;
               for (int q = 0; q < D; ++q) {
-                s1 += D1[l * D + q] * lds[SC::R + ((a1 * C + j) * D + l) * D + q];
-                s2 += D2[l * D + q] * lds[SC::R + ((a2 * C + j) * D + l) * D + q];
+                s1 += D1[l * D + q] * lds[sc.R + ((a1 * C + j) * D + l) * D + q];
+                s2 += D2[l * D + q] * lds[sc.R + ((a2 * C + j) * D + l) * D + q];
               }
               r1[j] = s1;
               r2[j] = s2;
@@ -926,15 +1011,15 @@ template <int D, int C, class Lanes> struct MvNr {
           for (int l1 = 0; l1 < D; ++l1)
             for (int l2 = 0; l2 < D; ++l2) {
               const double dd = D1[l1 * D + l2] * D2[l2 * D + l1];
-              trHH += dd * lds[SC::WW + sI * TD + mv_tri(l1, l2, D)];
+              trHH += dd * lds[sc.WW + sI * TD + mv_tri(l1, l2, D)];
               if (reml) {
-                const double *S3 = lds + SC::S3 + ((sI * D + l1) * D + l2) * T; // q = l2
+                const double *S3 = lds + sc.S3 + ((sI * D + l1) * D + l2) * T; // q = l2
                 double t = 0.0;
                 for (int j1 = 0; j1 < C; ++j1)
                   for (int j2 = 0; j2 < C; ++j2) t += QI[l1 * C * C + j1 * C + j2] * symget(S3, j1, j2);
                 t2 += dd * t;
-                const double *A = lds + SC::S + (a1 * TD + mv_tri(l1, l2, D)) * T;
-                const double *Bm = lds + SC::S + (a2 * TD + mv_tri(l1, l2, D)) * T;
+                const double *A = lds + sc.S + (a1 * TD + mv_tri(l1, l2, D)) * T;
+                const double *Bm = lds + sc.S + (a2 * TD + mv_tri(l1, l2, D)) * T;
                 double tr = 0.0; // tr(Qi_l1 A Qi_l2 B)
                 for (int i1 = 0; i1 < C; ++i1)
                   for (int i2 = 0; i2 < C; ++i2) {
@@ -961,10 +1046,11 @@ template <int D, int C, class Lanes> struct MvNr {
 
   // Hinv = HESS^-1 by LU with partial pivoting (LUDecomp / LUInvert :2510-2518), in scratch
   MV_HD void invert_hessian() {
-    double *lu = lds + SC::LU, *Hi = lds + SC::HINV;
-    const double *H = lds + SC::HESS;
+    MV_SHAPE(rt);
+    double *lu = lds + sc.LU, *Hi = lds + sc.HINV;
+    const double *H = lds + sc.HESS;
     for (int i = 0; i < H2 * H2; ++i) lu[i] = H[i];
-    int perm[H2];
+    int perm[H2K];
     for (int i = 0; i < H2; ++i) perm[i] = i;
     for (int j = 0; j < H2; ++j) {
       int ip = j;
@@ -993,7 +1079,7 @@ template <int D, int C, class Lanes> struct MvNr {
         }
     }
     for (int col = 0; col < H2; ++col) {
-      double xs[H2];
+      double xs[H2K];
       for (int i = 0; i < H2; ++i) xs[i] = (perm[i] == col) ? 1.0 : 0.0;
       for (int i = 0; i < H2; ++i)
         for (int k = 0; k < i; ++k) xs[i] -= lu[i * H2 + k] * xs[k];
@@ -1018,14 +1104,15 @@ template <int D, int C, class Lanes> struct MvNr {
   // the reference's trC, trCC, trB follow as sums over (l, q); B, C, D and crt_a, b, c as written there (:2303-2331).
   double crt[3] = {0.0, 0.0, 0.0};
   MV_HD void crt_factors() {
-    constexpr int z = C - 1, DD = D * D;
-    const double *QI = lds + SC::QI, *DT = lds + SC::DT, *Hi = lds + SC::HINV;
-    double *gt = lds + SC::LU, *ht = gt + 2 * DD, *kt = ht + 3 * DD; // g[a], h[gg, ge, ee], k[ee, ge, gg]
+    MV_SHAPE(rt);
+    const int z = C - 1, DD = D * D;
+    const double *QI = lds + sc.QI, *Dtab = lds + sc.DT, *Hi = lds + sc.HINV;
+    double *gt = lds + sc.LU, *ht = gt + 2 * DD, *kt = ht + 3 * DD; // g[a], h[gg, ge, ee], k[ee, ge, gg]
     for (int l1 = 0; l1 < D; ++l1)
       for (int l2 = 0; l2 < D; ++l2) {
-        double r[2][C];
+        double r[2][CK];
         for (int a = 0; a < 2; ++a) {
-          const double *Sa = lds + SC::S + (a * TD + mv_tri(l1, l2, D)) * T;
+          const double *Sa = lds + sc.S + (a * TD + mv_tri(l1, l2, D)) * T;
           for (int j = 0; j < C; ++j) {
             double t = 0.0;
             for (int i = 0; i < C; ++i) t += QI[l1 * C * C + z * C + i] * symget(Sa, i, j);
@@ -1047,7 +1134,7 @@ template <int D, int C, class Lanes> struct MvNr {
         ht[1 * DD + l1 * D + l2] = 2.0 * hge; // Qi M_g Qi M_e Qi + Qi M_e Qi M_g Qi: equal on this diagonal (QI symmetric)
         ht[2 * DD + l1 * D + l2] = hee;
         for (int sI = 0; sI < 3; ++sI) {
-          const double *S3 = lds + SC::S3 + ((sI * D + l1) * D + l2) * T;
+          const double *S3 = lds + sc.S3 + ((sI * D + l1) * D + l2) * T;
           double t = 0.0;
           for (int i = 0; i < C; ++i)
             for (int j = 0; j < C; ++j) t += QI[l1 * C * C + z * C + i] * symget(S3, i, j) * QI[l1 * C * C + j * C + z];
@@ -1055,18 +1142,18 @@ template <int D, int C, class Lanes> struct MvNr {
         }
       }
     mv_lane_fence();
-    double qinv[D];
+    double qinv[DK];
     for (int l = 0; l < D; ++l) qinv[l] = 1.0 / QI[l * C * C + z * C + z];
     double Bs = 0.0, Cs = 0.0, Ds = 0.0;
     for (int v1 = 0; v1 < VS; ++v1) {
-      const double *D1 = DT + v1 * DD;
+      const double *D1 = Dtab + v1 * DD;
       double trCg1 = 0.0, trCe1 = 0.0;
       for (int l = 0; l < D; ++l) {
         trCg1 -= D1[l * D + l] * gt[DD + l * D + l] * qinv[l];
         trCe1 -= D1[l * D + l] * gt[l * D + l] * qinv[l];
       }
       for (int v2 = v1; v2 < VS; ++v2) {
-        const double *D2 = DT + v2 * DD;
+        const double *D2 = Dtab + v2 * DD;
         double trCg2 = 0.0, trCe2 = 0.0, trCC_gg = 0.0, trCC_ge = 0.0, trCC_ee = 0.0, trB_gg = 0.0, trB_ge = 0.0, trB_ee = 0.0;
         for (int l = 0; l < D; ++l) {
           trCg2 -= D2[l * D + l] * gt[DD + l * D + l] * qinv[l];
@@ -1099,9 +1186,11 @@ template <int D, int C, class Lanes> struct MvNr {
     crt[2] = Cs;
   }
 
-  MV_HD static bool is_pd(const double (&V)[D * D]) {
-    double w[D], Z[D * D];
-    mv_jacobi<D>(V, w, Z);
+  MV_HD static bool is_pd(const double (&V)[MV_DD], int d) {
+    constexpr int DK = mv_dk<DT>;
+    const int D = DT > 0 ? DT : d;
+    double w[DK], Z[DK * DK];
+    mv_jacobi<mv_mt<DT, MV_DMAX>>(V, w, Z, D);
     bool ok = true;
 #pragma unroll
     for (int i = 0; i < D; ++i) ok = ok && (w[i] > 0);
@@ -1110,14 +1199,19 @@ template <int D, int C, class Lanes> struct MvNr {
 
   // MphNR with the per-SNP limits (nr_iter / 10, nr_prec * 10); returns logl_H1
   // max_iter < 0: g.nr_iter.  With g.crt the factors of the LAST CalcDev call stay in crt[] (:2522-2530, for 'R' and 'L' alike)
-  MV_HD double operator()(bool reml, double lndet_xxt, double (&Vg)[D * D], double (&Ve)[D * D], int max_iter = -1) {
+  MV_HD double operator()(bool reml, double lndet_xxt, double (&Vg)[MV_DD], double (&Ve)[MV_DD], int max_iter = -1) {
+    if constexpr (DT == 0) return mv_nr_out(*this, reml, lndet_xxt, Vg, Ve, max_iter);
+    else return run(reml, lndet_xxt, Vg, Ve, max_iter);
+  }
+  MV_HD double run(bool reml, double lndet_xxt, double (&Vg)[MV_DD], double (&Ve)[MV_DD], int max_iter) {
+    MV_SHAPE(rt);
     constexpr double LOG2PI = 1.8378770664093454836;
     const int n = g.n;
     const double logl_const = reml ? -0.5 * (double)(n - C) * (double)D * LOG2PI + 0.5 * (double)D * lndet_xxt
                                    : -0.5 * (double)n * (double)D * LOG2PI;
-    double Vg_save[D * D], Ve_save[D * D];
+    double Vg_save[DK * DK], Ve_save[DK * DK];
     double logl_old = 0.0, logl_new = 0.0;
-    const double *Hi = lds + SC::HINV, *grad = lds + SC::GRAD;
+    const double *Hi = lds + sc.HINV, *grad = lds + sc.GRAD;
     const int iters = max_iter < 0 ? g.nr_iter : max_iter;
     crt[0] = crt[1] = crt[2] = 0.0;
     for (int t = 0; t < iters; ++t) {
@@ -1150,7 +1244,7 @@ template <int D, int C, class Lanes> struct MvNr {
               Ve[i * D + j] = Ve[j * D + i] = Ve_save[i * D + j] - step_scale * se;
             }
         }
-        flag_pd = is_pd(Ve) && is_pd(Vg);
+        flag_pd = is_pd(Ve, D) && is_pd(Vg, D);
         if (flag_pd) logl_new = eval(reml, logl_const, Vg, Ve, false);
         step_scale /= 2.0;
         step_iter++;
@@ -1181,93 +1275,21 @@ template <int D, int C, class Lanes> struct MvNr {
 
 // One SNP: the body of the loop at src/mvlmm.cpp:3287-3374 (with -crt: PCRT on the SNPs that reach MphNR).  nr: callable (reml) -> logl_H1 that refines
 // Vg, Ve by Newton-Raphson, or a no-op returning NaN when the stage is not compiled in.
-template <int D, int C, class Lanes, class NR>
-MV_HD void mv_one_snp(const MvArgs &g, long s, NR &&nr) {
-  constexpr int CW = C - 1;
-  const double *__restrict__ x = g.UtX + s * g.ld;
-  double Vg[D * D], Ve[D * D], Vg0[D * D], Ve0[D * D], B[D * C], beta[D], Vbeta[D * D], XXti[C * C];
-#pragma unroll
-  for (int i = 0; i < D * D; ++i) {
-    Vg[i] = Vg0[i] = g.Vg_null[i];
-    Ve[i] = Ve0[i] = g.Ve_null[i];
-    Vbeta[i] = 0.0;
-  }
-#pragma unroll
-  for (int i = 0; i < D; ++i) {
-    beta[i] = 0.0;
-#pragma unroll
-    for (int j = 0; j < CW; ++j) B[i * C + j] = g.B_null[i * CW + j];
-    B[i * C + CW] = 0.0;
-  }
-  const double lndet_xxt = mv_xxt<C, Lanes>(g, x, XXti);
-  double p_wald = 0.0, p_lrt = 0.0, p_score = 0.0;
-  if (g.a_mode == 3 || g.a_mode == 4) {
-    p_score = mv_calcp<D, C, Lanes>(g, x, Vg0, Ve0, beta, Vbeta);
-    if (p_score < g.p_nr && g.crt == 1) { // :3302-3306: one CalcDev at the null estimates
-      nr(true, lndet_xxt, Vg, Ve, 1);
-      p_score = mv_pcrt(3, D, p_score, nr.crt);
-    }
-  }
-  if (g.a_mode == 2 || g.a_mode == 4) {
-    double logl_H1 = mv_em<D, C, Lanes>(g, x, false, g.em_iter, g.em_prec, lndet_xxt, XXti, Vg, Ve, B);
-    mv_calcp<D, C, Lanes>(g, x, Vg, Ve, beta, Vbeta);
-    p_lrt = mv_chisq_Q(2.0 * (logl_H1 - g.logl_H0), D);
-    if (p_lrt < g.p_nr) {
-      logl_H1 = nr(false, lndet_xxt, Vg, Ve);
-      mv_calcp<D, C, Lanes>(g, x, Vg, Ve, beta, Vbeta);
-      p_lrt = mv_chisq_Q(2.0 * (logl_H1 - g.logl_H0), D);
-      if (g.crt == 1) p_lrt = mv_pcrt(2, D, p_lrt, nr.crt);
-    }
-  }
-  if (g.a_mode == 1 || g.a_mode == 4) {
-    mv_em<D, C, Lanes>(g, x, true, g.em_iter, g.em_prec, lndet_xxt, XXti, Vg, Ve, B);
-    p_wald = mv_calcp<D, C, Lanes>(g, x, Vg, Ve, beta, Vbeta);
-    if (p_wald < g.p_nr) {
-      nr(true, lndet_xxt, Vg, Ve);
-      p_wald = mv_calcp<D, C, Lanes>(g, x, Vg, Ve, beta, Vbeta);
-      if (g.crt == 1) p_wald = mv_pcrt(1, D, p_wald, nr.crt);
-    }
-  }
-  if (Lanes::lane() == 0) {
-    constexpr int V = D * (D + 1) / 2;
-    double *o = g.out + s * g.stride;
-#pragma unroll
-    for (int i = 0; i < D; ++i) o[i] = beta[i];
-    int q = 0;
-#pragma unroll
-    for (int i = 0; i < D; ++i)
-#pragma unroll
-      for (int j = i; j < D; ++j, ++q) {
-        o[D + q] = Vbeta[i * D + j];
-        o[D + V + q] = Vg[i * D + j];
-        o[D + 2 * V + q] = Ve[i * D + j];
-      }
-    o[D + 3 * V] = p_wald;
-    o[D + 3 * V + 1] = p_lrt;
-    o[D + 3 * V + 2] = p_score;
-  }
-}
-
-} // namespace gemma_hip
-
-// ---------------------------------------------------------------- null model (src/mvlmm.cpp:3056-3208)
-namespace gemma_hip {
-
 // B = GLS estimate of the fixed effects at (Vg, Ve): what MphCalcBeta (:835-935) leaves in B
-template <int D, int C, class Lanes>
-MV_HD void mv_gls_B(const MvArgs &g, const double *__restrict__ x, const double (&Vg)[D * D], const double (&Ve)[D * D],
-                    double (&B)[D * C]) {
-  constexpr int T = C * (C + 1) / 2;
-  MvBasis<D> bs;
-  MvMoments<D, C> m;
-  bs.build(Vg, Ve);
-  mv_pass_moments<D, C, Lanes>(g, x, bs, m);
-  double bl[D * C];
+template <int DT, int CT, class Lanes>
+MV_HD void mv_gls_B(const MvArgs &g, const MvRt &rt, const double *__restrict__ x, const double (&Vg)[MV_DD], const double (&Ve)[MV_DD],
+                    double (&B)[MV_DC]) {
+  MV_SHAPE(rt);
+  MvBasis<DT> bs;
+  MvMoments<DT, CT> m;
+  bs.build(Vg, Ve, D);
+  mv_pass_moments<DT, CT, Lanes>(g, rt, x, bs, m);
+  double bl[DK * CK];
 #pragma unroll
   for (int l = 0; l < D; ++l) {
-    double Ql[C * C], Qi[C * C];
-    mv_unpack_sym<C>(m.Q + l * T, Ql);
-    mv_spd_inverse<C>(Ql, Qi);
+    double Ql[CK * CK], Qi[CK * CK];
+    mv_unpack_sym<CT>(m.Q + l * T, Ql, C);
+    mv_spd_inverse<mv_mt<CT, MV_CMAX>>(Ql, Qi, C);
 #pragma unroll
     for (int a = 0; a < C; ++a) {
       double s = 0.0;
@@ -1287,19 +1309,189 @@ MV_HD void mv_gls_B(const MvArgs &g, const double *__restrict__ x, const double 
     }
 }
 
+// the record of one SNP: beta[d], Vbeta[v], Vg[v], Ve[v], p_wald, p_lrt, p_score (MPHSUMSTAT, src/param.h:68-77)
+template <int DT>
+MV_HD void mv_store_snp(const MvArgs &g, long s, int D, const double (&beta)[MV_D1], const double (&Vbeta)[MV_DD],
+                        const double (&Vg)[MV_DD], const double (&Ve)[MV_DD], double p_wald, double p_lrt, double p_score) {
+  const int V = D * (D + 1) / 2;
+  double *o = g.out + s * g.stride;
+#pragma unroll
+  for (int i = 0; i < D; ++i) o[i] = beta[i];
+  int q = 0;
+#pragma unroll
+  for (int i = 0; i < D; ++i)
+#pragma unroll
+    for (int j = i; j < D; ++j, ++q) {
+      o[D + q] = Vbeta[i * D + j];
+      o[D + V + q] = Vg[i * D + j];
+      o[D + 2 * V + q] = Ve[i * D + j];
+    }
+  o[D + 3 * V] = p_wald;
+  o[D + 3 * V + 1] = p_lrt;
+  o[D + 3 * V + 2] = p_score;
+}
+
+template <int DT, int CT, class Lanes, class NR>
+MV_HD void mv_one_snp(const MvArgs &g, long s, NR &&nr) {
+  const MvRt &rt = nr.rt;
+  MV_SHAPE(rt);
+  const int CW = C - 1;
+  const double *__restrict__ x = g.UtX + s * g.ld;
+  double Vg[DK * DK], Ve[DK * DK], Vg0[DK * DK], Ve0[DK * DK], B[DK * CK], beta[DK], Vbeta[DK * DK], XXti[CK * CK];
+#pragma unroll
+  for (int i = 0; i < D * D; ++i) {
+    Vg[i] = Vg0[i] = g.Vg_null[i];
+    Ve[i] = Ve0[i] = g.Ve_null[i];
+    Vbeta[i] = 0.0;
+  }
+#pragma unroll
+  for (int i = 0; i < D; ++i) {
+    beta[i] = 0.0;
+#pragma unroll
+    for (int j = 0; j < CW; ++j) B[i * C + j] = g.B_null[i * CW + j];
+    B[i * C + CW] = 0.0;
+  }
+  const double lndet_xxt = mv_xxt<CT, Lanes>(g, rt, x, XXti);
+  double p_wald = 0.0, p_lrt = 0.0, p_score = 0.0;
+  if (g.a_mode == 3 || g.a_mode == 4) {
+    p_score = mv_calcp_sel<DT, CT, Lanes>(g, rt, x, Vg0, Ve0, beta, Vbeta);
+    if (p_score < g.p_nr && g.crt == 1) { // :3302-3306: one CalcDev at the null estimates
+      nr(true, lndet_xxt, Vg, Ve, 1);
+      p_score = mv_pcrt(3, D, p_score, nr.crt);
+    }
+  }
+  if (g.a_mode == 2 || g.a_mode == 4) {
+    double logl_H1 = mv_em_sel<DT, CT, Lanes>(g, rt, x, false, g.em_iter, g.em_prec, lndet_xxt, XXti, Vg, Ve, B);
+    mv_calcp_sel<DT, CT, Lanes>(g, rt, x, Vg, Ve, beta, Vbeta);
+    p_lrt = mv_chisq_Q(2.0 * (logl_H1 - g.logl_H0), D);
+    if (p_lrt < g.p_nr) {
+      logl_H1 = nr(false, lndet_xxt, Vg, Ve);
+      mv_calcp_sel<DT, CT, Lanes>(g, rt, x, Vg, Ve, beta, Vbeta);
+      p_lrt = mv_chisq_Q(2.0 * (logl_H1 - g.logl_H0), D);
+      if (g.crt == 1) p_lrt = mv_pcrt(2, D, p_lrt, nr.crt);
+    }
+  }
+  if (g.a_mode == 1 || g.a_mode == 4) {
+    mv_em_sel<DT, CT, Lanes>(g, rt, x, true, g.em_iter, g.em_prec, lndet_xxt, XXti, Vg, Ve, B);
+    p_wald = mv_calcp_sel<DT, CT, Lanes>(g, rt, x, Vg, Ve, beta, Vbeta);
+    if (p_wald < g.p_nr) {
+      nr(true, lndet_xxt, Vg, Ve);
+      p_wald = mv_calcp_sel<DT, CT, Lanes>(g, rt, x, Vg, Ve, beta, Vbeta);
+      if (g.crt == 1) p_wald = mv_pcrt(1, D, p_wald, nr.crt);
+    }
+  }
+  if (Lanes::lane() == 0) mv_store_snp<DT>(g, s, D, beta, Vbeta, Vg, Ve, p_wald, p_lrt, p_score);
+}
+
+// One SNP of the gene-environment interaction test, the loop body at src/mvlmm.cpp:4259-4353 (AnalyzeBimbamGXE; AnalyzePlinkGXE
+// :4416 is the same after the read): X = (W, env, x, x o env) with c rows, tested row = the interaction.  The NULL of the test
+// holds the SNP's main effect, so it is fitted per SNP on the first c - 1 rows (REML for the score / Wald statistics, ML for the
+// LRT reference, each EM + Newton-Raphson with the per-SNP limits and carrying V_g, V_e on from one fit to the next as the
+// reference's loop does); g.B_null is d x (c - 2), the columns of the global null fit.  Run-time instance only.
+template <class Lanes>
+MV_HD void mv_one_snp_gxe(const MvArgs &g, long s, double *scratch) {
+  constexpr int DT = 0, CT = 0;
+  MvRt rt1, rt0;                  // alternative (c rows, two SNP rows), per-SNP null (c - 1 rows, the SNP last)
+  rt1.d = rt0.d = g.d;
+  rt1.c = g.c;
+  rt0.c = g.c - 1;
+  const double *__restrict__ x = g.UtX + s * g.ld;
+  rt1.x2 = g.UtX2 + s * g.ld;
+  MV_SHAPE(rt1);
+  const int C0 = C - 1, CW = C - 2;
+  MvNr<0, 0, Lanes> nr1(g, scratch, rt1), nr0(g, scratch, rt0);
+  nr1.x = nr0.x = x;
+  double Vg[DK * DK], Ve[DK * DK], Vg0[DK * DK], Ve0[DK * DK], B[DK * CK], B0[DK * CK], beta[DK], Vbeta[DK * DK], XXti[CK * CK], XXti0[CK * CK];
+  for (int i = 0; i < D * D; ++i) {
+    Vg[i] = Vg0[i] = g.Vg_null[i];
+    Ve[i] = Ve0[i] = g.Ve_null[i];
+    Vbeta[i] = 0.0;
+  }
+  for (int i = 0; i < D; ++i) {
+    beta[i] = 0.0;
+    for (int j = 0; j < CW; ++j) B[i * C + j] = g.B_null[i * CW + j];
+    B[i * C + CW] = B[i * C + CW + 1] = 0.0;
+  }
+  // B_sub2 is a view of B (d x (c + 1) storage in the reference): the per-SNP null fit and the alternative share its columns
+  auto to_sub = [&]() {
+    for (int i = 0; i < D; ++i)
+      for (int j = 0; j < C0; ++j) B0[i * C0 + j] = B[i * C + j];
+  };
+  auto from_sub = [&]() {
+    for (int i = 0; i < D; ++i)
+      for (int j = 0; j < C0; ++j) B[i * C + j] = B0[i * C0 + j];
+  };
+  const double lndet_xxt = mv_xxt<0, Lanes>(g, rt1, x, XXti), lndet_xxt0 = mv_xxt<0, Lanes>(g, rt0, x, XXti0);
+  double p_wald = 0.0, p_lrt = 0.0, p_score = 0.0, logl_H0 = 0.0;
+  if (g.a_mode == 3 || g.a_mode == 4) { // :4262-4272
+    to_sub();
+    mv_em_sel<0, 0, Lanes>(g, rt0, x, true, g.em_iter, g.em_prec, lndet_xxt0, XXti0, Vg, Ve, B0);
+    nr0(true, lndet_xxt0, Vg, Ve);
+    mv_gls_B<0, 0, Lanes>(g, rt0, x, Vg, Ve, B0); // MphCalcBeta leaves the GLS estimate in B_sub2
+    from_sub();
+  }
+  if (g.a_mode == 2 || g.a_mode == 4) { // :4274-4284
+    to_sub();
+    mv_em_sel<0, 0, Lanes>(g, rt0, x, false, g.em_iter, g.em_prec, lndet_xxt0, XXti0, Vg, Ve, B0);
+    logl_H0 = nr0(false, lndet_xxt0, Vg, Ve);
+    mv_gls_B<0, 0, Lanes>(g, rt0, x, Vg, Ve, B0);
+    from_sub();
+  }
+  if (g.a_mode == 3 || g.a_mode == 4) {
+    p_score = mv_calcp_sel<0, 0, Lanes>(g, rt1, x, Vg0, Ve0, beta, Vbeta);
+    if (p_score < g.p_nr && g.crt == 1) {
+      nr1(true, lndet_xxt, Vg, Ve, 1);
+      p_score = mv_pcrt(3, D, p_score, nr1.crt);
+    }
+  }
+  if (g.a_mode == 2 || g.a_mode == 4) {
+    double logl_H1 = mv_em_sel<0, 0, Lanes>(g, rt1, x, false, g.em_iter, g.em_prec, lndet_xxt, XXti, Vg, Ve, B);
+    mv_calcp_sel<0, 0, Lanes>(g, rt1, x, Vg, Ve, beta, Vbeta);
+    p_lrt = mv_chisq_Q(2.0 * (logl_H1 - logl_H0), D);
+    if (p_lrt < g.p_nr) {
+      logl_H1 = nr1(false, lndet_xxt, Vg, Ve);
+      mv_calcp_sel<0, 0, Lanes>(g, rt1, x, Vg, Ve, beta, Vbeta);
+      p_lrt = mv_chisq_Q(2.0 * (logl_H1 - logl_H0), D);
+      if (g.crt == 1) p_lrt = mv_pcrt(2, D, p_lrt, nr1.crt);
+    }
+  }
+  if (g.a_mode == 1 || g.a_mode == 4) {
+    mv_em_sel<0, 0, Lanes>(g, rt1, x, true, g.em_iter, g.em_prec, lndet_xxt, XXti, Vg, Ve, B);
+    p_wald = mv_calcp_sel<0, 0, Lanes>(g, rt1, x, Vg, Ve, beta, Vbeta);
+    if (p_wald < g.p_nr) {
+      nr1(true, lndet_xxt, Vg, Ve);
+      p_wald = mv_calcp_sel<0, 0, Lanes>(g, rt1, x, Vg, Ve, beta, Vbeta);
+      if (g.crt == 1) p_wald = mv_pcrt(1, D, p_wald, nr1.crt);
+    }
+  }
+  if (g.flip && g.flip[s])
+    for (int i = 0; i < D; ++i) beta[i] = -beta[i];
+  if (Lanes::lane() == 0) mv_store_snp<0>(g, s, D, beta, Vbeta, Vg, Ve, p_wald, p_lrt, p_score);
+}
+
+} // namespace gemma_hip
+
+// ---------------------------------------------------------------- null model (src/mvlmm.cpp:3056-3208)
+namespace gemma_hip {
+
 struct MvNullArgs {
   MvArgs g;            // eval, Wt (all c covariate rows: the last one plays the "x" row), Yt, n; nr_iter / nr_prec
   int em_iter;
   double em_prec;
   double Vg0[MV_DMAX * MV_DMAX], Ve0[MV_DMAX * MV_DMAX]; // MphInitial's starting point
   double *out;         // 2 x (d*d + d*d + d*c + 1): REMLE then MLE block: Vg, Ve, B (d x c), logl
+  // run-time instance: g.d, g.c = the phenotypes and the covariates of THIS fit (c counts the last covariate, which plays the x row)
 };
 
 // EM + NR for REML, then for ML starting from the REML fit; one "lane group" does the whole fit
-template <int D, int C, class Lanes> MV_HD void mv_null_fit(const MvNullArgs &a, double *scratch) {
+template <int DT, int CT, class Lanes> MV_HD void mv_null_fit(const MvNullArgs &a, double *scratch) {
   const MvArgs &g = a.g;
+  MvRt rt;
+  rt.d = g.d;
+  rt.c = g.c;
+  MV_SHAPE(rt);
   const double *x = g.Wt + (long)(C - 1) * g.n;
-  double Vg[D * D], Ve[D * D], B[D * C], XXti[C * C];
+  double Vg[DK * DK], Ve[DK * DK], B[DK * CK], XXti[CK * CK];
 #pragma unroll
   for (int i = 0; i < D * D; ++i) {
     Vg[i] = a.Vg0[i];
@@ -1307,15 +1499,15 @@ template <int D, int C, class Lanes> MV_HD void mv_null_fit(const MvNullArgs &a,
   }
 #pragma unroll
   for (int i = 0; i < D * C; ++i) B[i] = 0.0;
-  const double lndet_xxt = mv_xxt<C, Lanes>(g, x, XXti);
-  MvNr<D, C, Lanes> nr{g, scratch};
+  const double lndet_xxt = mv_xxt<CT, Lanes>(g, rt, x, XXti);
+  MvNr<DT, CT, Lanes> nr(g, scratch, rt);
   nr.x = x;
-  constexpr int BLK = 2 * D * D + D * C + 1;
+  const int BLK = 2 * D * D + D * C + 1;
   for (int pass = 0; pass < 2; ++pass) {
     const bool reml = pass == 0;
-    mv_em<D, C, Lanes>(g, x, reml, a.em_iter, a.em_prec, lndet_xxt, XXti, Vg, Ve, B);
+    mv_em_sel<DT, CT, Lanes>(g, rt, x, reml, a.em_iter, a.em_prec, lndet_xxt, XXti, Vg, Ve, B);
     const double logl = nr(reml, lndet_xxt, Vg, Ve);
-    mv_gls_B<D, C, Lanes>(g, x, Vg, Ve, B);
+    mv_gls_B<DT, CT, Lanes>(g, rt, x, Vg, Ve, B);
     if (Lanes::lane() == 0) {
       double *o = a.out + pass * BLK;
 #pragma unroll

@@ -32,8 +32,9 @@
 extern "C" {
 #endif
 
-/* 3: gemma_mvlmm_opt gained `crt` (round 3); 2: the round-2 entry points */
-#define GEMMA_HIP_ABI_VERSION 3
+/* 4: gemma_mvlmm_null sized for 8 phenotypes / 11 covariates, gemma_mvlmm_opt gained `gxe` (round 4); 3: gemma_mvlmm_opt gained
+ * `crt` (round 3); 2: the round-2 entry points */
+#define GEMMA_HIP_ABI_VERSION 4
 
 enum {
   GEMMA_HIP_OK = 0,
@@ -218,19 +219,29 @@ int gemma_hip_lmm_assoc_d(const double *UtX_d, size_t l, size_t ld_utx, gemma_su
 int gemma_hip_lmm_finish(double *time_UtX_min, double *time_opt_min);
 
 /* ---- multivariate LMM (-lmm 1..4 -n a b c ...) ------------------------------------ */
-/* MVLMM::AnalyzeBimbam / AnalyzePlink, src/mvlmm.cpp:2972-3416 / :3418-3899.  d phenotypes (1..5), n_cvt covariates
- * (1..3; 1..6 for d <= 3); opt->crt = 1 applies the Edgeworth correction (CalcCRT / PCRT, :2054-2358 / :2952-2970) as -crt does.
+/* MVLMM::AnalyzeBimbam / AnalyzePlink, src/mvlmm.cpp:2972-3416 / :3418-3899, and with opt->gxe the interaction test of
+ * AnalyzeBimbamGXE / AnalyzePlinkGXE (:3970-4414 / :4416-4870).  d phenotypes (1..GEMMA_MV_DMAX), n_cvt covariates with
+ * n_cvt + 1 <= GEMMA_MV_CMAX rows of X (gxe: n_cvt + 3): register-resident kernels for d <= 5 with up to 3 covariates and d <= 3
+ * with up to 6, one run-time-shaped kernel (slower) for every other shape and for gxe.  opt->crt = 1 applies the Edgeworth
+ * correction (CalcCRT / PCRT, :2054-2358 / :2952-2970) as -crt does.
  * gemma_mvlmm_null holds what the null-model block (:3056-3208) leaves behind: V_g, V_e (d x d row-major, leading
  * dimension d), B (d x n_cvt) and the log-likelihood, for the REMLE and the MLE fit. */
+#define GEMMA_MV_DMAX 8
+#define GEMMA_MV_CMAX 12
 typedef struct {
-  double Vg_remle[25], Ve_remle[25], B_remle[20], logl_remle_H0;
-  double Vg_mle[25], Ve_mle[25], B_mle[20], logl_mle_H0;
+  double Vg_remle[GEMMA_MV_DMAX * GEMMA_MV_DMAX], Ve_remle[GEMMA_MV_DMAX * GEMMA_MV_DMAX], B_remle[GEMMA_MV_DMAX * GEMMA_MV_CMAX],
+      logl_remle_H0;
+  double Vg_mle[GEMMA_MV_DMAX * GEMMA_MV_DMAX], Ve_mle[GEMMA_MV_DMAX * GEMMA_MV_DMAX], B_mle[GEMMA_MV_DMAX * GEMMA_MV_CMAX], logl_mle_H0;
 } gemma_mvlmm_null;
 /* PARAM defaults (src/param.cpp:94-107): em_iter 10000, em_prec 1e-4, nr_iter 100, nr_prec 1e-4, p_nr 1e-3, crt 0 */
 typedef struct {
   size_t em_iter, nr_iter;
   double em_prec, nr_prec, p_nr;
   size_t crt; /* PARAM::crt (-crt, src/gemma.cpp:1398-1399): 1 = PCRT on the SNPs that reach MphNR (:3302-3306,3329-3331,3349-3351) */
+  size_t gxe; /* 1 (-gxe with several phenotypes, src/gemma.cpp:2840-2851): after gemma_hip_lmm_set_env; mvlmm_set then takes the null
+               * fit of (W, env) -- gemma_hip_mvlmm_null called with U^T env appended to UtW as covariate n_cvt + 1 (:4046-4070) --
+               * and mvlmm_batch tests x o env per SNP with (W, env, x) as covariates; SNP-major input only; beta changes sign with
+               * the allele switch of :4232-4236 */
 } gemma_mvlmm_opt;
 /* The null block: MphInitial (:2763-2948; one univariate REML fit per trait, and for d > 4 one two-trait fit per pair),
  * MphEM + MphNR + MphCalcBeta for 'R', then for 'L' starting from the REMLE fit.  Host pointers: eval (n), UtW (n x

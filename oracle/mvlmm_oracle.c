@@ -31,7 +31,7 @@
 #include <string.h>
 
 #define MV_MAXD 8
-#define MV_MAXC 8
+#define MV_MAXC 12
 #define MV_MAXDC (MV_MAXD * MV_MAXC)
 #define MV_MAXV (MV_MAXD * (MV_MAXD + 1) / 2)
 
@@ -1116,6 +1116,88 @@ void orc_mvlmm_batch(int a_mode, const orc_mv_cfg *cfg, size_t n, size_t d, size
       if (p_wald < cfg->p_nr) {
         orc_mph_nr_crt('R', cfg->nr_iter / 10, cfg->nr_prec * 10, n, d, c, eval, X, Y, Vg, Ve, NULL, crt);
         p_wald = orc_mph_calcp(n, d, cw, eval, x, W, Y, Vg, Ve, beta, Vbeta);
+        if (cfg->crt == 1) p_wald = orc_pcrt(1, d, p_wald, crt[0], crt[1], crt[2]);
+      }
+    }
+    double *o = out + s * stride;
+    for (size_t i = 0; i < d; ++i) o[i] = beta[i];
+    size_t q = 0;
+    for (size_t i = 0; i < d; ++i)
+      for (size_t j = i; j < d; ++j, ++q) {
+        o[d + q] = Vbeta[i * d + j];
+        o[d + vs + q] = Vg[i * d + j];
+        o[d + 2 * vs + q] = Ve[i * d + j];
+      }
+    o[d + 3 * vs] = p_wald;
+    o[d + 3 * vs + 1] = p_lrt;
+    o[d + 3 * vs + 2] = p_score;
+  }
+  free(X);
+}
+
+/* The per-SNP block of MVLMM::AnalyzeBimbamGXE, src/mvlmm.cpp:4253-4348 (AnalyzePlinkGXE :4700-4795 is the same).  W: cw x n, its
+ * last row U^T env (X_sub1 of the reference); UtX, UtX2: l x n, the rotated SNP and its product with env (X_row1, X_row2).
+ * Per SNP the null of the test, X_sub2 = (W, x), is fitted first -- REML for modes 3 / 4 (:4262-4272), then ML for modes 2 / 4
+ * (:4274-4284) -- with V_g, V_e and B carried from one fit to the next exactly as the reference's variables are; the tested row
+ * is x o env with X_sub2 as covariates.  B_null: d x cw.  The allele switch of :4232-4236 (and beta's sign, :4331-4333) is the
+ * caller's.  out as orc_mvlmm_batch. */
+void orc_mvlmm_batch_gxe(int a_mode, const orc_mv_cfg *cfg, size_t n, size_t d, size_t cw, const double *eval, const double *W,
+                         const double *Y, const double *UtX, const double *UtX2, size_t l, const double *Vg_null,
+                         const double *Ve_null, const double *B_null, double *out) {
+  const size_t c2 = cw + 1, c = cw + 2, vs = d * (d + 1) / 2, stride = 3 * vs + d + 3; /* rows of X_sub2, of X */
+  double *X = (double *)malloc(c * n * sizeof(double));
+  memcpy(X, W, cw * n * sizeof(double));
+  for (size_t s = 0; s < l; ++s) {
+    const double *x = UtX + s * n, *x2 = UtX2 + s * n;
+    memcpy(X + cw * n, x, n * sizeof(double));
+    memcpy(X + c2 * n, x2, n * sizeof(double));
+    double Vg[MV_MAXD * MV_MAXD], Ve[MV_MAXD * MV_MAXD], B[MV_MAXD * MV_MAXC], B2[MV_MAXD * MV_MAXC], beta[MV_MAXD], Vbeta[MV_MAXD * MV_MAXD];
+    double p_wald = 0, p_lrt = 0, p_score = 0, logl_H1, logl_H0 = 0.0;
+    memset(beta, 0, sizeof(beta));
+    memset(Vbeta, 0, sizeof(Vbeta));
+    memcpy(Vg, Vg_null, d * d * sizeof(double));
+    memcpy(Ve, Ve_null, d * d * sizeof(double));
+    for (size_t i = 0; i < d; ++i) { /* B = B_null: the global null's columns, zeros for the SNP and the interaction (:4056-4059) */
+      for (size_t j = 0; j < cw; ++j) B[i * c + j] = B_null[i * cw + j];
+      B[i * c + cw] = B[i * c + cw + 1] = 0.0;
+    }
+    double crt[3] = {0.0, 0.0, 0.0};
+    for (int pass = 0; pass < 2; ++pass) { /* the per-SNP null on X_sub2: 'R' then 'L' */
+      const char f = pass == 0 ? 'R' : 'L';
+      if (pass == 0 && !(a_mode == 3 || a_mode == 4)) continue;
+      if (pass == 1 && !(a_mode == 2 || a_mode == 4)) continue;
+      for (size_t i = 0; i < d; ++i)
+        for (size_t j = 0; j < c2; ++j) B2[i * c2 + j] = B[i * c + j]; /* B_sub2: a view of B's first c2 columns */
+      logl_H0 = orc_mph_em(f, cfg->em_iter / 10, cfg->em_prec * 10, n, d, c2, eval, X, Y, Vg, Ve, B2);
+      logl_H0 = orc_mph_nr(f, cfg->nr_iter / 10, cfg->nr_prec * 10, n, d, c2, eval, X, Y, Vg, Ve, NULL);
+      mv_gls_B(n, d, c2, eval, X, Y, Vg, Ve, B2); /* MphCalcBeta */
+      for (size_t i = 0; i < d; ++i)
+        for (size_t j = 0; j < c2; ++j) B[i * c + j] = B2[i * c2 + j];
+    }
+    if (a_mode == 3 || a_mode == 4) {
+      p_score = orc_mph_calcp(n, d, c2, eval, x2, X, Y, Vg_null, Ve_null, beta, Vbeta);
+      if (p_score < cfg->p_nr && cfg->crt == 1) {
+        logl_H1 = orc_mph_nr_crt('R', 1, cfg->nr_prec * 10, n, d, c, eval, X, Y, Vg, Ve, NULL, crt);
+        p_score = orc_pcrt(3, d, p_score, crt[0], crt[1], crt[2]);
+      }
+    }
+    if (a_mode == 2 || a_mode == 4) {
+      logl_H1 = orc_mph_em('L', cfg->em_iter / 10, cfg->em_prec * 10, n, d, c, eval, X, Y, Vg, Ve, B);
+      orc_mph_calcp(n, d, c2, eval, x2, X, Y, Vg, Ve, beta, Vbeta);
+      p_lrt = orc_cdf_chisq_Q(2.0 * (logl_H1 - logl_H0), (double)d);
+      if (p_lrt < cfg->p_nr) {
+        logl_H1 = orc_mph_nr_crt('L', cfg->nr_iter / 10, cfg->nr_prec * 10, n, d, c, eval, X, Y, Vg, Ve, NULL, crt);
+        orc_mph_calcp(n, d, c2, eval, x2, X, Y, Vg, Ve, beta, Vbeta);
+        p_lrt = orc_cdf_chisq_Q(2.0 * (logl_H1 - logl_H0), (double)d);
+        if (cfg->crt == 1) p_lrt = orc_pcrt(2, d, p_lrt, crt[0], crt[1], crt[2]);
+      }
+    }
+    if (a_mode == 1 || a_mode == 4) {
+      orc_mph_em('R', cfg->em_iter / 10, cfg->em_prec * 10, n, d, c, eval, X, Y, Vg, Ve, B);
+      p_wald = orc_mph_calcp(n, d, c2, eval, x2, X, Y, Vg, Ve, beta, Vbeta);
+      if (p_wald < cfg->p_nr) {
+        orc_mph_nr_crt('R', cfg->nr_iter / 10, cfg->nr_prec * 10, n, d, c, eval, X, Y, Vg, Ve, NULL, crt);
+        p_wald = orc_mph_calcp(n, d, c2, eval, x2, X, Y, Vg, Ve, beta, Vbeta);
         if (cfg->crt == 1) p_wald = orc_pcrt(1, d, p_wald, crt[0], crt[1], crt[2]);
       }
     }

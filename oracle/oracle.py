@@ -112,6 +112,8 @@ def lib():
         L.orc_mph_dev.argtypes = [C.c_char, sz, sz, sz, dp, dp, dp, dp, dp, dp, dp]
         L.orc_mvlmm_null.restype = None
         L.orc_mvlmm_null.argtypes = [C.POINTER(MvCfg), sz, sz, sz, dp, dp, dp] + [dp] * 8
+        L.orc_mvlmm_batch_gxe.restype = None
+        L.orc_mvlmm_batch_gxe.argtypes = [C.c_int, C.POINTER(MvCfg), sz, sz, sz, dp, dp, dp, dp, dp, sz, dp, dp, dp, dp]
         L.orc_mvlmm_batch.restype = None
         L.orc_mvlmm_batch.argtypes = [C.c_int, C.POINTER(MvCfg), sz, sz, sz, dp, dp, dp, dp, sz, dp, dp, dp, cd, dp]
         _LIB = L
@@ -715,5 +717,19 @@ def mvlmm_batch(a_mode, cfg, ev, W, Y, UtX_snpmajor, null):
     X = _c64(UtX_snpmajor)
     lib().orc_mvlmm_batch(a_mode, C.byref(cfg), n, d, W.shape[0], _dp(ev), _dp(W), _dp(Y), _dp(X), l, _dp(null["Vg_mle"]),
                           _dp(null["Ve_mle"]), _dp(null["B_mle"]), null["logl_mle"], _dp(out))
+    return {"beta": out[:, :d], "Vbeta": out[:, d:d + v], "Vg": out[:, d + v:d + 2 * v], "Ve": out[:, d + 2 * v:d + 3 * v],
+            "p_wald": out[:, d + 3 * v], "p_lrt": out[:, d + 3 * v + 1], "p_score": out[:, d + 3 * v + 2]}
+
+
+def mvlmm_batch_gxe(a_mode, cfg, ev, W_env, Y, UtX_snpmajor, UtX2_snpmajor, null):
+    """Per-SNP block of MVLMM::AnalyzeBimbamGXE (src/mvlmm.cpp:4253-4348): W_env = the covariate rows with U^T env last, null = the
+    fit of (W, env); UtX2 = the rotated x o env rows."""
+    d, n = Y.shape
+    l = UtX_snpmajor.shape[0]
+    v = d * (d + 1) // 2
+    out = np.zeros((l, 3 * v + d + 3))
+    X, X2 = _c64(UtX_snpmajor), _c64(UtX2_snpmajor)
+    lib().orc_mvlmm_batch_gxe(a_mode, C.byref(cfg), n, d, W_env.shape[0], _dp(ev), _dp(W_env), _dp(Y), _dp(X), _dp(X2), l,
+                              _dp(null["Vg_mle"]), _dp(null["Ve_mle"]), _dp(null["B_mle"]), _dp(out))
     return {"beta": out[:, :d], "Vbeta": out[:, d:d + v], "Vg": out[:, d + v:d + 2 * v], "Ve": out[:, d + 2 * v:d + 3 * v],
             "p_wald": out[:, d + 3 * v], "p_lrt": out[:, d + 3 * v + 1], "p_score": out[:, d + 3 * v + 2]}

@@ -19,6 +19,7 @@ Fixtures:
   ref_mv.npz        multivariate LMM: issue243 (first 800 SNPs, 2 traits) and issue188 genotypes with 3 simulated
                     traits, -lmm 1..4 (-n 1 2 [3])
   ref_mv_crt.npz    fixture (a) of ref_mv.npz with -crt (run `make_ref_fixtures.py mv_crt`; not part of the default list)
+  ref_mv_wide.npz   multivariate -gxe (2 traits) and six traits with three covariates (`make_ref_fixtures.py mv_wide`)
 """
 import os
 import re
@@ -394,6 +395,63 @@ def mv_crt(tmp):
     print("ref_mv_crt.npz:", len(d["a_snp"]), "+", len(d3["b_snp"]), "SNPs; rows that -crt changes:", changed, changed_b)
 
 
+def mv_wide(tmp):
+    """ref_mv_wide.npz: what the fixed multivariate kernels do not cover.
+    (g) -gxe with two traits (MVLMM::AnalyzePlinkGXE, src/mvlmm.cpp:4416-4870): fixture (a) of ref_mv.npz (issue243 genotypes and
+        phenotypes, rebuilt from the stored bytes), a simulated environment variable, every 5th SNP, -lmm 1..4;
+    (w) six traits and two covariates besides the intercept on the issue188 genotypes, every 16th SNP, REML and score modes (the
+        reference's ML EM is not reproducible from d = 3 on, see tests/test_reference_pin.py)."""
+    fx = np.load(os.path.join(OUT, "ref_mv.npz"))
+    d = {}
+    Y = fx["a_pheno"]
+    n_total = Y.shape[0]
+    nb = (n_total + 3) // 4
+    ns = (fx["a_bed"].size - 3) // nb
+    pre = os.path.join(tmp, "mvg")
+    open(pre + ".bed", "wb").write(fx["a_bed"].tobytes())
+    bim = ["1\trs%d\t0\t%d\tA\tG\n" % (t, t + 1) for t in range(ns)]
+    open(pre + ".bim", "w").writelines(bim)
+    with open(pre + ".fam", "w") as f:
+        for i in range(n_total):
+            f.write("f%d i%d 0 0 1 %r %r\n" % (i, i, float(Y[i, 0]), float(Y[i, 1])))
+    rng = np.random.default_rng(4416)
+    env = np.round(rng.standard_normal(n_total), 6)
+    np.savetxt(os.path.join(tmp, "envg.txt"), env, fmt="%.6f")
+    with open(os.path.join(tmp, "snpsg.txt"), "w") as f:
+        f.writelines("rs%d\n" % t for t in range(0, ns, 5))
+    d["g_env"] = env
+    d["g_snps_listed"] = np.arange(0, ns, 5)
+    gemma(tmp, "-bfile", "mvg", "-gk", 1, "-o", "mvg")
+    mv_run(tmp, "mvg", "g", os.path.join(tmp, "output", "mvg.cXX.txt"), (1, 2), d, bim,
+           extra=("-gxe", "envg.txt", "-snps", "snpsg.txt"))
+    # (w)
+    raw188, fam188, bim188 = copy_plink(REF + "/test/data/issue188/2000", os.path.join(tmp, "p188w"))
+    n188 = len(fam188)
+    nb188 = (n188 + 3) // 4
+    codes = np.unpackbits(raw188[3:].reshape(-1, nb188)[:400], axis=1, bitorder="little").reshape(400, -1, 2)[:, :n188]
+    g = (codes[:, :, 0] + codes[:, :, 1]).astype(float)
+    g = (g - g.mean(1, keepdims=True)) / (g.std(1, keepdims=True) + 1e-9)
+    A6 = np.triu(rng.uniform(0.2, 0.8, (6, 6)))
+    E6 = np.triu(rng.uniform(0.1, 0.4, (6, 6))) + 0.8 * np.eye(6)
+    Y6 = (g.T @ rng.standard_normal((400, 6)) / np.sqrt(400)) @ A6 + rng.standard_normal((n188, 6)) @ E6
+    cov = np.column_stack([np.ones(n188), rng.standard_normal(n188), rng.binomial(1, 0.4, n188).astype(float)])
+    Y6 += 0.3 * cov[:, 1:2] * rng.standard_normal((1, 6)) + 0.4 * g[11][:, None] * rng.standard_normal((1, 6))
+    txt6 = [["%.8g" % v for v in row] for row in Y6]
+    fam_lines = [" ".join(l.split()[:5] + t) + "\n" for l, t in zip(fam188, txt6)]
+    copy_plink(REF + "/test/data/issue188/2000", os.path.join(tmp, "mv6"), fam_lines=fam_lines)
+    np.savetxt(os.path.join(tmp, "cov6.txt"), cov, fmt="%.10g")
+    with open(os.path.join(tmp, "snps6.txt"), "w") as f:
+        f.writelines(l.split()[1] + "\n" for l in bim188[::16])
+    d["w_pheno"] = np.array([[float(x) for x in row] for row in txt6])
+    d["w_cov"] = np.loadtxt(os.path.join(tmp, "cov6.txt"))
+    d["w_snps_listed"] = np.arange(0, len(bim188), 16)
+    gemma(tmp, "-bfile", "mv6", "-gk", 1, "-o", "mv6")
+    mv_run(tmp, "mv6", "w", os.path.join(tmp, "output", "mv6.cXX.txt"), (1, 2, 3, 4, 5, 6), d, bim188, modes=(1, 3),
+           extra=("-c", "cov6.txt", "-snps", "snps6.txt"))
+    np.savez_compressed(os.path.join(OUT, "ref_mv_wide.npz"), **d)
+    print("ref_mv_wide.npz:", len(d["g_snp"]), "+", len(d["w_snp"]), "SNPs")
+
+
 def main():
     if not os.path.exists(GEMMA):
         subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "ref"])
@@ -411,6 +469,8 @@ def main():
             mv(tmp, raw, fam, bim)
         if "mv_crt" in which:
             mv_crt(tmp)
+        if "mv_wide" in which:
+            mv_wide(tmp)
         if "loco" in which:
             loco(tmp, raw, fam, bim)
         if "gene" in which:

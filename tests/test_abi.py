@@ -25,7 +25,7 @@ def test_header_symbols_exported():
         assert hasattr(lib, name), name
     from gemma_amd import _lib
     assert sorted(_lib.SYMBOLS) == declared
-    assert _lib.lib().gemma_hip_abi_version() == 3
+    assert _lib.lib().gemma_hip_abi_version() == 4
 
 
 def test_struct_layouts_match_header():

@@ -108,11 +108,82 @@ def test_state_and_argument_errors(gpu_api, oracle):
     c = make_case(120, 2, 1, 2, 3)
     mv = gpu_api.MVLMM()
     with pytest.raises(L.GemmaHipError) as e:
-        mv.fit_null(c["ev"], np.ones((120, 1)), np.zeros((120, 6)))  # six phenotypes
+        mv.fit_null(c["ev"], np.ones((120, 1)), np.zeros((120, 9)))  # nine phenotypes (GEMMA_MV_DMAX = 8)
     assert e.value.code == L.EINVAL
     with pytest.raises(L.GemmaHipError) as e:
-        mv.fit_null(c["ev"], np.ones((120, 7)), np.zeros((120, 2)))  # seven covariates (d <= 3: up to six)
+        mv.fit_null(c["ev"], np.ones((120, 12)), np.zeros((120, 2)))  # twelve covariates (+ the SNP > GEMMA_MV_CMAX = 12 rows)
     assert e.value.code == L.EINVAL
-    with pytest.raises(L.GemmaHipError) as e:
-        mv.fit_null(c["ev"], np.ones((120, 4)), np.zeros((120, 4)))  # four covariates with four phenotypes (d > 3: up to three)
-    assert e.value.code == L.EINVAL
+
+
+# ------------------------------------------------------------------ the run-time kernel (mvlmm_kernels_rt.hip)
+@pytest.mark.parametrize("n,d,cw,p,seed,crt", [(300, 3, 1, 48, 5, 1), (257, 2, 2, 40, 6, 0), (350, 3, 6, 16, 22, 0)])
+def test_run_time_kernel_equals_the_fixed_kernel(gpu_api, oracle, monkeypatch, n, d, cw, p, seed, crt):
+    """GEMMA_HIP_MVLMM_RT=1 sends a shape that has a fixed kernel through the run-time one: same source (mvlmm.hip.h), same
+    operation order per lane, different code generation (loops instead of unrolled register code: the compiler may contract
+    other multiply-add pairs), so: equal to 1e-9 where both take the same number of EM iterations."""
+    c = make_case(n, d, cw, p, seed)
+    args = (c["U"], c["ev"], np.ascontiguousarray(c["UtW"].T), np.ascontiguousarray(c["UtY"].T), c["G"])
+    a = gpu_api.MVLMM(a_mode=4, crt=crt, p_nr=0.5)
+    fixed = a.AnalyzeBimbam(*args)
+    monkeypatch.setenv("GEMMA_HIP_MVLMM_RT", "1")
+    b = gpu_api.MVLMM(a_mode=4, crt=crt, p_nr=0.5)
+    rt = b.AnalyzeBimbam(*args)
+    for k in ("Vg_mle", "Ve_mle", "B_mle", "Vg_remle"):
+        assert np.abs(a.null[k] - b.null[k]).max() < 1e-9 * np.abs(a.null[k]).max(), k
+    _compare(rt, fixed, "rt vs fixed d=%d" % d, tight=1e-9)
+
+
+@pytest.mark.parametrize("n,d,cw,p,seed,a_mode,crt", [(500, 6, 1, 24, 31, 4, 0), (420, 4, 5, 24, 32, 4, 1), (380, 2, 9, 32, 33, 4, 0),
+                                                      (600, 7, 2, 12, 34, 1, 0), (450, 5, 4, 16, 35, 3, 1), (640, 8, 1, 8, 36, 1, 0)])
+def test_analyze_beyond_the_fixed_kernels(gpu_api, oracle, n, d, cw, p, seed, a_mode, crt):
+    """Shapes no fixed kernel is built for (d > 5; more than three covariates with d = 4, 5; more than six with d <= 3): the
+    reference takes any (src/mvlmm.cpp:2972-3416); here the run-time kernel does, null block included (d > 4: pairwise
+    two-trait initialisation)."""
+    c = make_case(n, d, cw, p, seed)
+    null, ref = _oracle_run(oracle, c, a_mode, X=c["G"], crt=crt, p_nr=0.5)
+    mv = gpu_api.MVLMM(a_mode=a_mode, crt=crt, p_nr=0.5)
+    got = mv.AnalyzeBimbam(c["U"], c["ev"], np.ascontiguousarray(c["UtW"].T), np.ascontiguousarray(c["UtY"].T), c["G"])
+    for k in ("Vg_remle", "Ve_remle", "B_remle", "Vg_mle", "Ve_mle", "B_mle"):
+        assert np.abs(mv.null[k] - null[k]).max() < 1e-6 * np.abs(null[k]).max(), k
+    assert mv.null["logl_mle"] == pytest.approx(null["logl_mle"], rel=1e-10)
+    _compare(got, ref, "rt d=%d c=%d" % (d, cw))
+
+
+@pytest.mark.parametrize("n,d,cw,p,seed,a_mode,crt,plink", [(300, 2, 1, 40, 41, 4, 0, False), (320, 3, 2, 24, 42, 4, 1, False),
+                                                            (280, 2, 1, 32, 43, 1, 0, True), (300, 1, 1, 32, 44, 4, 0, False)])
+def test_analyze_gxe(gpu_api, oracle, n, d, cw, p, seed, a_mode, crt, plink):
+    """MVLMM::AnalyzeBimbamGXE / AnalyzePlinkGXE (src/mvlmm.cpp:3970-4870) against orc_mvlmm_batch_gxe (pinned on the reference's
+    own -gxe output in tests/test_reference_pin.py): null fit on (W, env), per-SNP null on (W, env, x), tested row x o env, alleles
+    switched where the mean exceeds 1 (beta changes sign)."""
+    c = make_case(n, d, cw, p, seed)
+    rng = np.random.default_rng(seed + 100)
+    env = rng.standard_normal(n)
+    U = c["U"]
+    G = c["G"].copy()
+    G[::3] = 2.0 - G[::3]  # a third of the SNPs with the other allele counted: mean > 1 -> the switch of :4232-4236
+    G[rng.random(G.shape) < 0.02] = np.nan
+    if plink:
+        G = np.where(np.isnan(G), np.nan, np.round(G))
+    X = oracle.impute_mean(G)
+    flip = X.mean(1) > 1
+    X[flip] = 2.0 - X[flip]
+    W_env = np.ascontiguousarray(np.vstack([c["UtW"], (U.T @ env)[None, :]]))
+    cfg = oracle.mv_cfg(crt=crt, p_nr=0.5)
+    null = oracle.mvlmm_null(cfg, c["ev"], W_env, c["UtY"])
+    ref = oracle.mvlmm_batch_gxe(a_mode, cfg, c["ev"], W_env, c["UtY"], np.ascontiguousarray(X @ U),
+                                 np.ascontiguousarray((X * env[None, :]) @ U), null)
+    ref["beta"][flip] *= -1.0
+    assert flip.sum() >= 3
+    mv = gpu_api.MVLMM(a_mode=a_mode, crt=crt, p_nr=0.5)
+    UtW, UtY = np.ascontiguousarray(c["UtW"].T), np.ascontiguousarray(c["UtY"].T)
+    if plink:
+        # .bed codes per individual (src/lmm.cpp:1797-1812): 0 -> 2, 1 -> NA, 2 -> 1, 3 -> 0
+        codes = np.where(np.isnan(G), 1, np.where(G == 2, 0, np.where(G == 1, 2, 3))).astype(np.uint8)
+        pad = np.zeros((p, (n + 3) // 4 * 4), dtype=np.uint8)
+        pad[:, :n] = codes
+        raw = (pad[:, 0::4] | (pad[:, 1::4] << 2) | (pad[:, 2::4] << 4) | (pad[:, 3::4] << 6)).astype(np.uint8)
+        assert np.array_equal(np.nan_to_num(oracle.bed_decode(raw, n), nan=-1), np.nan_to_num(G, nan=-1))
+        got = mv.AnalyzePlinkGXE(U, c["ev"], UtW, UtY, env, raw, np.ones(n, dtype=np.int32))
+    else:
+        got = mv.AnalyzeBimbamGXE(U, c["ev"], UtW, UtY, env, G)
+    _compare(got, ref, "gxe d=%d" % d)

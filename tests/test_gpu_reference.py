@@ -173,6 +173,26 @@ def test_mvlmm_vs_reference_output(gpu_api, mvprep, tag, mode):
     assert mv.null["logl_mle"] == pytest.approx(c["fx"][tag + "_logl_null"][1], rel=2e-6)
 
 
+@pytest.mark.parametrize("mode", [1, 2, 3, 4])
+def test_mvlmm_gxe_vs_reference_output(gpu_api, mvprep, mode):
+    """`-gxe` with two traits: the reference's own output (MVLMM::AnalyzePlinkGXE, src/mvlmm.cpp:4416-4870; fixture `g` of
+    ref_mv_wide.npz: issue243, a simulated environment, every 5th SNP) against the run-time kernel's interaction test.  Same
+    criterion as the plain multivariate runs above (an EM that stops an iteration apart moves the estimates by ~1e-4)."""
+    fw = R.load("ref_mv_wide.npz")
+    c = mvprep["a"]
+    listed = np.zeros(c["raw"].shape[0], dtype=bool)
+    listed[fw["g_snps_listed"]] = True
+    sel = (c["isnp"] == 1) & listed
+    assert np.array_equal(np.flatnonzero(sel), fw["g_snp"])
+    mv = gpu_api.MVLMM(a_mode=mode)
+    got = mv.AnalyzePlinkGXE(c["U"], c["ev"], c["UtW"], c["UtY"], fw["g_env"], np.ascontiguousarray(c["raw"][sel]), c["ind"])
+    ref = R.mv_ref_table(fw, "g", mode, 2)
+    err = R.mv_row_err(got, ref)
+    assert np.mean(err <= R.PRINT_TOL) >= 0.97 and err.max() <= 5e-3, (float(np.mean(err <= R.PRINT_TOL)), float(err.max()))
+    assert mv.null["logl_remle"] == pytest.approx(fw["g_logl_null"][0], rel=2e-6)
+    assert mv.null["logl_mle"] == pytest.approx(fw["g_logl_null"][1], rel=2e-6)
+
+
 @pytest.mark.parametrize("mode", [2, 4])
 def test_mvlmm_ml_em_three_traits(gpu_api, mvprep, mode):
     """d = 3, ML: the reference's trajectory depends on LAPACK's eigenvector signs (tests/test_reference_pin.py::

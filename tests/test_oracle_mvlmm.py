@@ -128,10 +128,10 @@ def test_one_trait_reduces_to_the_univariate_lmm():
 class MvArgs(C.Structure):
     dp = C.POINTER(C.c_double)
     _fields_ = [("UtX", dp), ("ld", C.c_long), ("l", C.c_long), ("n", C.c_int), ("eval", dp), ("Wt", dp), ("Yt", dp),
-                ("Vg_null", C.c_double * 25), ("Ve_null", C.c_double * 25), ("B_null", C.c_double * 20),
+                ("Vg_null", C.c_double * 64), ("Ve_null", C.c_double * 64), ("B_null", C.c_double * 96),  # MV_DMAX = 8, MV_CMAX = 12
                 ("logl_H0", C.c_double), ("a_mode", C.c_int), ("em_iter", C.c_int), ("em_prec", C.c_double),
                 ("nr_iter", C.c_int), ("nr_prec", C.c_double), ("p_nr", C.c_double), ("out", dp), ("stride", C.c_int),
-                ("crt", C.c_int)]
+                ("crt", C.c_int), ("d", C.c_int), ("c", C.c_int), ("UtX2", dp), ("flip", C.POINTER(C.c_int)), ("scratch", dp)]
 
 
 @pytest.fixture(scope="module")
@@ -190,6 +190,84 @@ def test_kernel_source_on_one_lane_matches_the_oracle(harness, n, d, cw, p, seed
     assert (ref["p_wald"] < 1e-3).sum() >= 1  # the Newton-Raphson branch is exercised
     if p_nr > 0.1:
         assert (ref["p_score"] < p_nr).sum() >= 5
+    for k in got:
+        rel = np.abs(got[k] - ref[k]) / np.maximum(np.abs(ref[k]), 1e-300)
+        assert rel.max() < 1e-8, (k, rel.max())
+
+
+def _harness_batch(harness, c, null, d, cw, p_nr, crt, fixed, a_mode=4, utx2=None, w=None):
+    n, p = c["UtX"].shape[1], c["UtX"].shape[0]
+    v = d * (d + 1) // 2
+    stride = 3 * v + d + 3
+    out = np.zeros((p, stride))
+    P = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
+    W = c["UtW"] if w is None else w
+    a = MvArgs()
+    a.UtX, a.ld, a.l, a.n = P(c["UtX"]), n, p, n
+    a.eval, a.Wt, a.Yt = P(c["ev"]), P(W), P(c["UtY"])
+    for i, x in enumerate(null["Vg_mle"].ravel()):
+        a.Vg_null[i] = x
+    for i, x in enumerate(null["Ve_mle"].ravel()):
+        a.Ve_null[i] = x
+    for i, x in enumerate(null["B_mle"].ravel()):
+        a.B_null[i] = x
+    a.logl_H0, a.a_mode = null["logl_mle"], a_mode
+    a.em_iter, a.em_prec, a.nr_iter, a.nr_prec, a.p_nr = 1000, 1e-3, 10, 1e-3, p_nr
+    a.out, a.stride = P(out), stride
+    a.crt = crt
+    rows = W.shape[0] + 1
+    if utx2 is not None:
+        a.UtX2 = P(utx2)
+        rows += 1
+    assert harness.mvh_batch2(d, rows, C.byref(a), fixed) == 0
+    return {"beta": out[:, :d], "Vbeta": out[:, d:d + v], "Vg": out[:, d + v:d + 2 * v], "Ve": out[:, d + 2 * v:d + 3 * v],
+            "p_wald": out[:, d + 3 * v], "p_lrt": out[:, d + 3 * v + 1], "p_score": out[:, d + 3 * v + 2]}
+
+
+@pytest.mark.parametrize("n,d,cw,p,seed,crt", [(300, 3, 1, 24, 5, 1), (257, 2, 2, 20, 6, 0), (400, 4, 1, 8, 8, 1), (350, 3, 6, 8, 22, 0)])
+def test_run_time_instance_is_the_fixed_instance_bit_for_bit(harness, n, d, cw, p, seed, crt):
+    """One source, two forms (mvlmm.hip.h: DT, CT > 0 fixed, 0 run-time): on one CPU lane and without fused multiply-adds the same
+    operations run in the same order, so where a fixed instance exists the run-time one must return the same bits."""
+    c = make_case(n, d, cw, p, seed)
+    null = O.mvlmm_null(O.mv_cfg(crt=crt, p_nr=0.5), c["ev"], c["UtW"], c["UtY"])
+    a = _harness_batch(harness, c, null, d, cw, 0.5, crt, 1)
+    b = _harness_batch(harness, c, null, d, cw, 0.5, crt, 0)
+    for k in a:
+        assert np.array_equal(a[k], b[k], equal_nan=True), k
+
+
+@pytest.mark.parametrize("n,d,cw,p,seed,crt", [(500, 6, 1, 6, 31, 0), (420, 4, 5, 8, 32, 1), (380, 2, 9, 10, 33, 0), (600, 7, 2, 4, 34, 0),
+                                               (450, 5, 4, 6, 35, 1)])
+def test_run_time_instance_matches_the_oracle_beyond_the_fixed_kernels(harness, n, d, cw, p, seed, crt):
+    """(d, c) for which no fixed kernel is built (d > 5, or more covariates than 3 for d = 4, 5 / 6 for d <= 3): the reference takes
+    any (src/mvlmm.cpp:2972-3416)."""
+    c = make_case(n, d, cw, p, seed)
+    cfg = O.mv_cfg(crt=crt, p_nr=0.5)
+    null = O.mvlmm_null(cfg, c["ev"], c["UtW"], c["UtY"])
+    assert min(np.linalg.eigvalsh(null["Ve_mle"]).min(), np.linalg.eigvalsh(null["Vg_mle"]).min()) > 1e-3
+    ref = O.mvlmm_batch(4, cfg, c["ev"], c["UtW"], c["UtY"], c["UtX"], null)
+    got = _harness_batch(harness, c, null, d, cw, 0.5, crt, 0)
+    for k in got:
+        rel = np.abs(got[k] - ref[k]) / np.maximum(np.abs(ref[k]), 1e-300)
+        assert rel.max() < 1e-8, (k, rel.max())
+
+
+@pytest.mark.parametrize("n,d,cw,p,seed,a_mode,crt", [(300, 2, 1, 10, 41, 4, 0), (320, 3, 2, 8, 42, 4, 1), (280, 2, 1, 12, 43, 1, 0),
+                                                      (300, 1, 1, 10, 44, 4, 0)])
+def test_gxe_on_one_lane_matches_the_oracle(harness, n, d, cw, p, seed, a_mode, crt):
+    """The interaction test (MVLMM::AnalyzeBimbamGXE, src/mvlmm.cpp:3970-4414): per-SNP null fits on (W, env, x), tested row x o env;
+    kernel source (mv_one_snp_gxe, run-time instance) against the oracle's restatement of the reference's loop."""
+    c = make_case(n, d, cw, p, seed)
+    rng = np.random.default_rng(seed + 100)
+    env = rng.standard_normal(n)
+    U = c["U"]
+    W_env = np.ascontiguousarray(np.vstack([c["UtW"], (U.T @ env)[None, :]]))
+    Gs = c["G"]
+    UtX2 = np.ascontiguousarray((Gs * env[None, :]) @ U)
+    cfg = O.mv_cfg(crt=crt, p_nr=0.5)
+    null = O.mvlmm_null(cfg, c["ev"], W_env, c["UtY"])
+    ref = O.mvlmm_batch_gxe(a_mode, cfg, c["ev"], W_env, c["UtY"], c["UtX"], UtX2, null)
+    got = _harness_batch(harness, c, null, d, cw + 1, 0.5, crt, 0, a_mode=a_mode, utx2=UtX2, w=W_env)
     for k in got:
         rel = np.abs(got[k] - ref[k]) / np.maximum(np.abs(ref[k]), 1e-300)
         assert rel.max() < 1e-8, (k, rel.max())

@@ -498,3 +498,86 @@ def test_reference_setup_stages_through_the_bridge(oracle, tmp_path):
     U2, ev2, tr2 = oracle.eigen_decomp_zeroed(G)
     assert np.allclose(ev, ev2, rtol=0, atol=1e-12) and tr == pytest.approx(tr2, rel=1e-12)
     assert np.max(np.abs(U @ np.diag(ev) @ U.T - G)) < 1e-11
+
+
+# ----------------------------------------------------------------------------- multivariate -gxe, six traits (ref_mv_wide.npz)
+@pytest.fixture(scope="module")
+def mvgxe(oracle):
+    fw, fx = R.load("ref_mv_wide.npz"), R.load("ref_mv.npz")
+    raw, n_total, Yall, ind_all, _ = R.mv_case_inputs(fx, None, "a")
+    G = oracle.bed_decode(raw, n_total)
+    ind, W = oracle.process_cvt_phen(ind_all)
+    isnp = oracle.qc_snps_bed(G, W)
+    K10 = oracle.round10(oracle.calc_kin(G[isnp == 1], 1))
+    U, ev, _ = oracle.eigen_decomp_zeroed(oracle.center_matrix(K10))
+    listed = np.zeros(G.shape[0], dtype=bool)
+    listed[fw["g_snps_listed"]] = True
+    sel = (isnp == 1) & listed
+    env = fw["g_env"]
+    X = oracle.impute_mean(G[sel])
+    flip = X.mean(1) > 1  # src/mvlmm.cpp:4232-4236 (the mean over the called genotypes = the mean after imputation)
+    X[flip] = 2.0 - X[flip]
+    W_env = np.ascontiguousarray(np.vstack([(U.T @ W).T, (U.T @ env)[None, :]]))
+    UtY = np.ascontiguousarray((U.T @ Yall).T)
+    cfg = oracle.mv_cfg()
+    return dict(fw=fw, sel=sel, ev=ev, W_env=W_env, UtY=UtY, UtX=np.ascontiguousarray(X @ U),
+                UtX2=np.ascontiguousarray((X * env[None, :]) @ U), flip=flip, cfg=cfg, null=oracle.mvlmm_null(cfg, ev, W_env, UtY))
+
+
+@pytest.mark.parametrize("mode", [1, 2, 3, 4])
+def test_mvlmm_gxe_per_snp_every_digit(oracle, mvgxe, mode):
+    """`-gxe` with two traits (MVLMM::AnalyzePlinkGXE, src/mvlmm.cpp:4416-4870) in every mode: the per-SNP null fits on (W, env, x),
+    the interaction row as the tested variable, the allele switch and beta's sign -- every SNP to the printed digits.  This pins
+    orc_mvlmm_batch_gxe, which the kernel source is compared with in test_oracle_mvlmm.py / test_gpu_mvlmm.py."""
+    c = mvgxe
+    assert np.array_equal(np.flatnonzero(c["sel"]), c["fw"]["g_snp"])
+    got = oracle.mvlmm_batch_gxe(mode, c["cfg"], c["ev"], c["W_env"], c["UtY"], c["UtX"], c["UtX2"], c["null"])
+    got["beta"][c["flip"]] *= -1.0
+    ref = R.mv_ref_table(c["fw"], "g", mode, 2)
+    err = R.mv_row_err(got, ref)
+    assert err.max() <= R.PRINT_TOL, (mode, float(err.max()), int(err.argmax()))
+    assert c["flip"].sum() >= 5
+
+
+def test_mvlmm_six_traits_null_and_per_snp(oracle):
+    """d = 6 with three covariates: beyond the fixed kernels (d <= 5) -- the shape the run-time kernel exists for.  As with five
+    traits the REML null fit follows the reference's log at its 6 digits and the per-SNP output as far as the reference's own
+    (basis-unstable) ML null fit defines its starting point."""
+    fw, f188 = R.load("ref_mv_wide.npz"), R.load("ref_issue188.npz")
+    Yall = fw["w_pheno"]
+    n_total = Yall.shape[0]
+    nb = (n_total + 3) // 4
+    G = oracle.bed_decode(np.ascontiguousarray(f188["bed"][3:].reshape(-1, nb)), n_total)
+    ones = np.ones(n_total, dtype=np.int32)
+    _, W = oracle.process_cvt_phen(ones, fw["w_cov"], ones)
+    _, W1 = oracle.process_cvt_phen(ones)
+    K10 = oracle.round10(oracle.calc_kin(G[oracle.qc_snps_bed(G, W1) == 1], 1))
+    listed = np.zeros(G.shape[0], dtype=bool)
+    listed[fw["w_snps_listed"]] = True
+    sel = (oracle.qc_snps_bed(G, W) == 1) & listed
+    assert np.array_equal(np.flatnonzero(sel), fw["w_snp"])
+    U, ev, _ = oracle.eigen_decomp_zeroed(oracle.center_matrix(K10))
+    UtW, UtY = np.ascontiguousarray((U.T @ W).T), np.ascontiguousarray((U.T @ Yall).T)
+    cfg = oracle.mv_cfg()
+    null = oracle.mvlmm_null(cfg, ev, UtW, UtY)
+    assert null["logl_remle"] == pytest.approx(fw["w_logl_null"][0], rel=2e-6)
+    # the ML null fit: the reference's EM stalls below the maximum here (its rotated fixed effects lag one basis behind,
+    # test_mvlmm_ml_em_three_traits above): the restatement's likelihood is the higher one
+    assert fw["w_logl_null"][1] - 1e-3 <= null["logl_mle"] <= fw["w_logl_null"][1] + 1.0
+    print("six traits, ML null logl: restatement %.4f, reference %.4f" % (null["logl_mle"], fw["w_logl_null"][1]))
+    lo = np.tril_indices(6)
+    np.testing.assert_allclose(null["Vg_remle"][lo], fw["w_log_REMLE_estimate_for_Vg_in_the_null_model"], rtol=5e-5, atol=1e-8)
+    np.testing.assert_allclose(null["Ve_remle"][lo], fw["w_log_REMLE_estimate_for_Ve_in_the_null_model"], rtol=5e-5)
+    UtX = np.ascontiguousarray(oracle.impute_mean(G[sel]) @ U)
+    # the per-SNP loop starts from the ML null estimates (:3291-3293): from the REFERENCE's own (its log prints them to 6 digits), so
+    # that the per-SNP arithmetic at d = 6 is compared and not the two ML null fits
+    start = dict(null)
+    start["Vg_mle"] = np.ascontiguousarray(fw["w_log_MLE_estimate_for_Vg_in_the_null_model"].reshape(6, 6))
+    start["Ve_mle"] = np.ascontiguousarray(fw["w_log_MLE_estimate_for_Ve_in_the_null_model"].reshape(6, 6))
+    start["B_mle"] = np.ascontiguousarray(fw["w_log_estimate_for_B_d_by_c_in_the_null_model_columns_correspond_t"].reshape(6, -1))
+    start["logl_mle"] = float(fw["w_logl_null"][1])
+    for mode in (1, 3):
+        got = oracle.mvlmm_batch(mode, cfg, ev, UtW, UtY, UtX, start)
+        err = R.mv_row_err(got, R.mv_ref_table(fw, "w", mode, 6))
+        print("six traits, mode %d: median %.2e max %.2e" % (mode, float(np.median(err)), float(err.max())))
+        assert np.median(err) < 1e-4 and err.max() < 5e-3, (mode, float(np.median(err)), float(err.max()))
