@@ -934,7 +934,6 @@ public:
     std::ifstream infile(file_bed.c_str(), std::ios::binary);
     if (!infile) throw std::runtime_error("error reading genotype (.bed) file");
     setup(U, eval, UtW, UtY, 1);
-    enforce_hip(gemma_hip_lmm_set_indicator(indicator_idv.data(), indicator_idv.size()), "MVLMM::AnalyzePlink");
     const size_t n_bit = (ni_total + 3) / 4, B = io_block_rows(LMM_BATCH_SIZE);
     std::vector<double> out(B * stride());
     size_t t_next = 0;
@@ -951,6 +950,36 @@ public:
       sumStat.insert(sumStat.end(), out.begin(), out.begin() + l * stride());
     }
     enforce_hip(gemma_hip_lmm_finish(&time_UtX, &time_opt), "MVLMM::AnalyzePlink");
+  }
+
+  // MVLMM::AnalyzePlinkGXE, src/mvlmm.cpp:4416-4870 (`-gxe` with several phenotypes, src/gemma.cpp:2840-2846): the null model is
+  // fitted on (W, env) -- UtWe = UtW with U^T env appended as its last column (:4492-4516) --, per SNP x o env is tested with
+  // (W, env, x) as covariates.  env over the analysed individuals.
+  void AnalyzePlinkGXE(const Matrix *U, const Vector *eval, const Matrix *UtW, const Matrix *UtWe, const Matrix *UtY, const Vector *env) {
+    const std::string file_bed = file_bfile + ".bed";
+    std::ifstream infile(file_bed.c_str(), std::ios::binary);
+    if (!infile) throw std::runtime_error("error reading genotype (.bed) file");
+    if (UtWe->size2 != UtW->size2 + 1 || UtWe->tda != UtWe->size2 || env->size != U->size1)
+      throw HipError(GEMMA_HIP_EINVAL, "MVLMM::AnalyzePlinkGXE: UtWe must be UtW plus the U^T env column, env over the analysed individuals");
+    std::vector<double> e(env->size);
+    for (size_t i = 0; i < env->size; ++i) e[i] = env->data[i * env->stride];
+    setup(U, eval, UtW, UtY, 1, UtWe, e.data());
+    const size_t n_bit = (ni_total + 3) / 4, B = io_block_rows(LMM_BATCH_SIZE);
+    std::vector<double> out(B * stride());
+    size_t t_next = 0;
+    const std::vector<int> keep = analysed_snps();
+    BlockPrefetch pf(B * n_bit, [&](void *slot, int) {
+      return read_bed_rows(infile, keep, t_next, n_bit, static_cast<unsigned char *>(slot), B);
+    });
+    for (;;) {
+      void *slot = nullptr;
+      const size_t l = pf.next(slot);
+      if (l == (size_t)-1) throw std::runtime_error("error reading genotype (.bed) file (truncated)");
+      if (l == 0) break;
+      enforce_hip(gemma_hip_mvlmm_batch(GEMMA_GENO_PLINK_2BIT, slot, l, n_bit, out.data()), "MVLMM::AnalyzePlinkGXE");
+      sumStat.insert(sumStat.end(), out.begin(), out.begin() + l * stride());
+    }
+    enforce_hip(gemma_hip_lmm_finish(&time_UtX, &time_opt), "MVLMM::AnalyzePlinkGXE");
   }
 
   // pull-style block source as in LMM::AnalyzeFeed (rows = analysed SNPs over the analysed individuals, NaN = missing):
@@ -1027,14 +1056,17 @@ public:
 
 private:
   // the null block (src/mvlmm.cpp:3056-3208) and the per-SNP loop's state
-  void setup(const Matrix *U, const Vector *eval, const Matrix *UtW, const Matrix *UtY, int plink) {
+  // UtWe, env: the interaction test (the null model then has UtWe's covariates)
+  void setup(const Matrix *U, const Vector *eval, const Matrix *UtW, const Matrix *UtY, int plink, const Matrix *UtWe = nullptr,
+             const double *env = nullptr) {
     if ((!kept_U && U->tda != U->size2) || UtW->tda != UtW->size2 || UtY->tda != UtY->size2 || eval->stride != 1)
       throw HipError(GEMMA_HIP_EINVAL, "MVLMM: contiguous U/UtW/UtY/eval required");
     ni_test = U->size1;
     n_cvt = UtW->size2;
     n_ph = UtY->size2;
-    const gemma_mvlmm_opt opt = {em_iter, nr_iter, em_prec, nr_prec, p_nr, crt};
-    enforce_hip(gemma_hip_mvlmm_null(ni_test, n_cvt, n_ph, eval->data, UtW->data, UtY->data, l_min, l_max, n_region, &opt,
+    const gemma_mvlmm_opt opt = {em_iter, nr_iter, em_prec, nr_prec, p_nr, crt, (size_t)(env ? 1 : 0)};
+    const Matrix *Wn = env ? UtWe : UtW;
+    enforce_hip(gemma_hip_mvlmm_null(ni_test, Wn->size2, n_ph, eval->data, Wn->data, UtY->data, l_min, l_max, n_region, &opt,
                                      &null_fit),
                 "MVLMM (null model)");
     logl_remle_H0 = null_fit.logl_remle_H0;
@@ -1048,6 +1080,8 @@ private:
       enforce_hip(gemma_hip_lmm_setup_kept(&cfg, UtW->data, y0.data()), "MVLMM::Analyze");
     else
       enforce_hip(gemma_hip_lmm_setup(&cfg, U->data, eval->data, UtW->data, y0.data()), "MVLMM::Analyze");
+    if (plink) enforce_hip(gemma_hip_lmm_set_indicator(indicator_idv.data(), indicator_idv.size()), "MVLMM::Analyze");
+    if (env) enforce_hip(gemma_hip_lmm_set_env(env), "MVLMM::Analyze (gxe)");
     enforce_hip(gemma_hip_mvlmm_set(n_ph, UtY->data, &null_fit, &opt), "MVLMM::Analyze");
     sumStat.clear();
   }

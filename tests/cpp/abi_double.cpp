@@ -60,6 +60,9 @@ void orc_mvlmm_null(const orc_mv_cfg *cfg, size_t n, size_t d, size_t cw, const 
 void orc_mvlmm_batch(int a_mode, const orc_mv_cfg *cfg, size_t n, size_t d, size_t cw, const double *eval, const double *W,
                      const double *Y, const double *UtX, size_t l, const double *Vg_null, const double *Ve_null,
                      const double *B_null, double logl_H0, double *out);
+void orc_mvlmm_batch_gxe(int a_mode, const orc_mv_cfg *cfg, size_t n, size_t d, size_t cw, const double *eval, const double *W,
+                         const double *Y, const double *UtX, const double *UtX2, size_t l, const double *Vg_null,
+                         const double *Ve_null, const double *B_null, double *out);
 void orc_CalcLmmVgVeBeta(size_t n, size_t c, const double *eval, const double *UtW, const double *Uty, double lambda,
                          double *vg, double *ve, double *beta, double *se_beta);
 }
@@ -89,6 +92,7 @@ struct Lmm {
   std::vector<double> Yt, Wt;
   gemma_mvlmm_null mv_null;
   orc_mv_cfg mv_cfg;
+  bool mv_gxe = false;
 } g_lmm;
 
 struct Lm {
@@ -428,6 +432,7 @@ int gemma_hip_lmm_batch_collect(gemma_sumstat *out, size_t *l) {
 int gemma_hip_lmm_finish(double *t_utx, double *t_opt) {
   g_pipe.clear();
   g_lmm.on = false;
+  g_lmm.mv_gxe = false;
   if (t_utx) *t_utx = 0.0;
   if (t_opt) *t_opt = 0.0;
   return GEMMA_HIP_OK;
@@ -453,6 +458,11 @@ int gemma_hip_mvlmm_set(size_t d, const double *UtY, const gemma_mvlmm_null *nul
   const orc_mv_cfg cfg = {opt->em_iter, opt->nr_iter, g_lmm.cfg.n_region, opt->em_prec, opt->nr_prec, g_lmm.cfg.l_min,
                           g_lmm.cfg.l_max, opt->p_nr, opt->crt};
   g_lmm.mv_cfg = cfg;
+  g_lmm.mv_gxe = opt->gxe == 1;
+  if (g_lmm.mv_gxe) {
+    if (g_lmm.env.empty()) return fail(GEMMA_HIP_ESTATE, "mvlmm_set with gxe before lmm_set_env");
+    g_lmm.Wt = transposed(g_lmm.UtWe.data(), n, c + 1); // (W, env)
+  }
   return GEMMA_HIP_OK;
 }
 int gemma_hip_mvlmm_batch(int kind, const void *geno, size_t l, size_t ld, double *out) {
@@ -463,6 +473,32 @@ int gemma_hip_mvlmm_batch(int kind, const void *geno, size_t l, size_t ld, doubl
     decode(kind, geno, l, ld, g_lmm.ind.empty() ? nullptr : g_lmm.ind.data(), g_lmm.ind.empty() ? n : g_lmm.ind.size(), n, X);
   else
     decode(kind, geno, l, ld, nullptr, n, n, X);
+  if (g_lmm.mv_gxe) { // MVLMM::AnalyzePlinkGXE, src/mvlmm.cpp:4416-4870
+    std::vector<int> flip(l, 0);
+    for (size_t s = 0; s < l; ++s) {
+      double tot = 0.0;
+      size_t cnt = 0;
+      for (size_t i = 0; i < n; ++i)
+        if (X[s * n + i] == X[s * n + i]) { tot += X[s * n + i]; ++cnt; }
+      flip[s] = cnt && tot / (double)cnt > 1.0;
+    }
+    orc_impute_mean(X.data(), l, n);
+    std::vector<double> Z(l * n), UtX(l * n), UtZ(l * n);
+    for (size_t s = 0; s < l; ++s)
+      for (size_t i = 0; i < n; ++i) {
+        if (flip[s]) X[s * n + i] = 2.0 - X[s * n + i];
+        Z[s * n + i] = X[s * n + i] * g_lmm.env[i];
+      }
+    gemma_hip_dgemm('N', 'N', l, n, n, 1.0, X.data(), n, g_lmm.U.data(), n, 0.0, UtX.data(), n);
+    gemma_hip_dgemm('N', 'N', l, n, n, 1.0, Z.data(), n, g_lmm.U.data(), n, 0.0, UtZ.data(), n);
+    orc_mvlmm_batch_gxe(g_lmm.cfg.a_mode, &g_lmm.mv_cfg, n, g_lmm.d, c + 1, g_lmm.eval.data(), g_lmm.Wt.data(), g_lmm.Yt.data(),
+                        UtX.data(), UtZ.data(), l, g_lmm.mv_null.Vg_mle, g_lmm.mv_null.Ve_mle, g_lmm.mv_null.B_mle, out);
+    const size_t d = g_lmm.d, stride = d + 3 * (d * (d + 1) / 2) + 3;
+    for (size_t s = 0; s < l; ++s)
+      if (flip[s])
+        for (size_t i = 0; i < d; ++i) out[s * stride + i] = -out[s * stride + i];
+    return GEMMA_HIP_OK;
+  }
   orc_impute_mean(X.data(), l, n);
   std::vector<double> UtX(l * n);
   gemma_hip_dgemm('N', 'N', l, n, n, 1.0, X.data(), n, g_lmm.U.data(), n, 0.0, UtX.data(), n);

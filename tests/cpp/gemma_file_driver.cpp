@@ -395,7 +395,26 @@ int main(int argc, char **argv) {
       cMv.shard_world = gpus;
       cMv.kept_U = kept;
       const double t_a0 = lap();
-      if (!file_bfile.empty()) cMv.AnalyzePlink(&U, &eval, &UtW, &UtY);
+      if (!file_gxe.empty()) { // src/gemma.cpp:2840-2851
+        if (file_bfile.empty()) {
+          std::cerr << "-gxe takes -bfile input" << std::endl;
+          return 2;
+        }
+        std::vector<double> envb;
+        cp.CopyGxe(envb);
+        Vector env = vector_view(envb.data(), envb.size());
+        // U^T env as covariate n_cvt + 1 of the null model (src/mvlmm.cpp:4492-4494)
+        std::vector<double> Uteb(ni_test), UtWeb(ni_test * (n_cvt + 1));
+        Matrix E = matrix_view(envb.data(), ni_test, 1), UtE = matrix_view(Uteb.data(), ni_test, 1);
+        if (kept) CalcUtXKept(&E, &UtE);
+        else CalcUtX(&U, &E, &UtE);
+        for (size_t i = 0; i < ni_test; ++i) {
+          for (size_t j = 0; j < n_cvt; ++j) UtWeb[i * (n_cvt + 1) + j] = UtWb[i * n_cvt + j];
+          UtWeb[i * (n_cvt + 1) + n_cvt] = Uteb[i];
+        }
+        Matrix UtWe = matrix_view(UtWeb.data(), ni_test, n_cvt + 1);
+        cMv.AnalyzePlinkGXE(&U, &eval, &UtW, &UtWe, &UtY, &env);
+      } else if (!file_bfile.empty()) cMv.AnalyzePlink(&U, &eval, &UtW, &UtY);
       else AnalyzeBimbam(cMv, &U, &eval, &UtW, &UtY);
       const double t_a1 = lap();
       cMv.WriteFiles();

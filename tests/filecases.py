@@ -216,17 +216,29 @@ def loco_workflow(exe, out, chrs=(2,), modes=(1,)):
                     assert (rel <= STAT_TOL).all(), (tag, name, np.nanmax(rel))
 
 
-def mvlmm_workflow(exe, out, modes=(1, 4), bimbam=False, crt=False):
+def mvlmm_workflow(exe, out, modes=(1, 4), bimbam=False, crt=False, gxe=False):
     """`-lmm m -n 1 2` (multivariate LMM, class MVLMM) from PLINK files: the reference's test/data/issue243 set (1000
     individuals, 2 traits, first 800 SNPs) rebuilt from tests/golden/ref_mv.npz, -gk then -k ... -lmm, against the
     reference's .assoc.txt columns.  An EM that stops one iteration earlier or later moves the estimates by ~1e-4:
     >= 97 % of the SNPs to the printed digits, all within 5e-3 (the criterion of tests/test_gpu_mvlmm.py).
     crt: the same runs with -crt against tests/golden/ref_mv_crt.npz (the reference with -crt: the SNP that reaches MphNR gets
-    PCRT's corrected p_wald / p_lrt; its corrected value must come out, not the uncorrected one)."""
+    PCRT's corrected p_wald / p_lrt; its corrected value must come out, not the uncorrected one).
+    gxe: `-gxe env.txt -snps list` on the same files against fixture `g` of tests/golden/ref_mv_wide.npz (the reference's
+    MVLMM::AnalyzePlinkGXE, src/mvlmm.cpp:4416-4870, on every 5th SNP)."""
     import refcases as R
     out = str(out)
     fx = np.load(os.path.join(ROOT, "tests", "golden", "ref_mv.npz"))
     fx_plain = fx
+    tag, extra = "a", ()
+    if gxe:
+        fw = np.load(os.path.join(ROOT, "tests", "golden", "ref_mv_wide.npz"))
+        fx = dict(fx)
+        fx.update({k: fw[k] for k in fw.files if k.startswith("g_")})
+        tag = "g"
+        np.savetxt(os.path.join(out, "envg.txt"), fw["g_env"], fmt="%.6f")
+        with open(os.path.join(out, "snpsg.txt"), "w") as f:
+            f.writelines("rs%d\n" % t for t in fw["g_snps_listed"])
+        extra = ("-gxe", os.path.join(out, "envg.txt"), "-snps", os.path.join(out, "snpsg.txt"))
     if crt:
         fc = np.load(os.path.join(ROOT, "tests", "golden", "ref_mv_crt.npz"))
         fx = dict(fx)
@@ -258,21 +270,21 @@ def mvlmm_workflow(exe, out, modes=(1, 4), bimbam=False, crt=False):
     drive(exe, *base, "-gk", "-o", "mv2")
     cxx = os.path.join(out, "mv2.cXX.txt")
     for m in modes:
-        kv = drive(exe, *base, "-k", cxx, "-lmm", m, "-n", 1, 2, *(("-crt",) if crt else ()), "-o", "mv2_m%d" % m)
-        assert abs(float(kv["logl_remle_H0"]) - fx["a_logl_null"][0]) <= 2e-6 * abs(fx["a_logl_null"][0])
-        assert abs(float(kv["logl_mle_H0"]) - fx["a_logl_null"][1]) <= 2e-6 * abs(fx["a_logl_null"][1])
+        kv = drive(exe, *base, "-k", cxx, "-lmm", m, "-n", 1, 2, *(("-crt",) if crt else ()), *extra, "-o", "mv2_m%d" % m)
+        assert abs(float(kv["logl_remle_H0"]) - fx[tag + "_logl_null"][0]) <= 2e-6 * abs(fx[tag + "_logl_null"][0])
+        assert abs(float(kv["logl_mle_H0"]) - fx[tag + "_logl_null"][1]) <= 2e-6 * abs(fx[tag + "_logl_null"][1])
         hdr, rows = read_assoc(os.path.join(out, "mv2_m%d.assoc.txt" % m))
         want_hdr = ["chr", "rs", "ps", "n_miss", "allele1", "allele0", "af", "beta_1", "beta_2", "Vbeta_1_1", "Vbeta_1_2",
                     "Vbeta_2_2"] + {1: ["p_wald"], 2: ["p_lrt"], 3: ["p_score"], 4: ["p_wald", "p_lrt", "p_score"]}[m]
         assert hdr == want_hdr
-        assert [r[1] for r in rows] == ["rs%d" % t for t in fx["a_snp"]]
+        assert [r[1] for r in rows] == ["rs%d" % t for t in fx[tag + "_snp"]]
         col = {name: np.array([float(r[j]) for r in rows]) for j, name in enumerate(hdr) if j >= 7}
         got = {"beta": np.column_stack([col["beta_1"], col["beta_2"]]),
                "Vbeta": np.column_stack([col["Vbeta_1_1"], col["Vbeta_1_2"], col["Vbeta_2_2"]])}
         for c in ("p_wald", "p_lrt", "p_score"):
             if c in col:
                 got[c] = col[c]
-        err = R.mv_row_err(got, R.mv_ref_table(fx, "a", m, 2))
+        err = R.mv_row_err(got, R.mv_ref_table(fx, tag, m, 2))
         assert np.mean(err <= STAT_TOL) >= 0.97 and err.max() <= 5e-3, (m, float(np.mean(err <= STAT_TOL)), float(err.max()))
         if crt:  # the rows -crt changes in the reference: the corrected value, to the digits the EM's stopping point allows
             for c in ("p_wald", "p_lrt"):

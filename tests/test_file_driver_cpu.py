@@ -63,6 +63,18 @@ def test_mvlmm_plink_files_to_reference_outputs(driver, tmp_path, monkeypatch):
     fc.mvlmm_workflow(driver, tmp_path, modes=(1, 4))
 
 
+def test_mvlmm_gxe_plink_files_to_reference_outputs(driver, tmp_path, monkeypatch):
+    """-gxe with two phenotypes through the host layer (MVLMM::AnalyzePlinkGXE: null fit on (W, env), gemma_mvlmm_opt.gxe) against
+    the reference's own -gxe run"""
+    import glob
+    import scipy
+    libs = glob.glob(os.path.join(os.path.dirname(os.path.dirname(scipy.__file__)), "scipy.libs", "libscipy_openblas*.so"))
+    if libs:
+        monkeypatch.setenv("GEMMA_DOUBLE_LAPACK", libs[0])
+    monkeypatch.setenv("GEMMA_HIP_IO_BLOCK", "60")
+    fc.mvlmm_workflow(driver, tmp_path, modes=(4,), gxe=True)
+
+
 def test_mvlmm_crt_option_reference_outputs(driver, tmp_path, monkeypatch):
     """-crt through the host layer (PARAM::crt -> gemma_mvlmm_opt.crt) against the reference run with -crt"""
     import glob

@@ -39,6 +39,11 @@ def test_mvlmm_plink_files_to_reference_outputs(driver, tmp_path):
     fc.mvlmm_workflow(driver, tmp_path, modes=(1, 2, 3, 4))
 
 
+def test_mvlmm_gxe_plink_files_to_reference_outputs(driver, tmp_path):
+    """-gxe with two phenotypes, files to .assoc.txt, against the reference's own run (tests/golden/ref_mv_wide.npz)"""
+    fc.mvlmm_workflow(driver, tmp_path, modes=(1, 2, 3, 4), gxe=True)
+
+
 def test_lm_files_to_reference_outputs_and_golden_checksum(driver, tmp_path):
     fc.lm_workflow(driver, tmp_path)
 
