@@ -257,6 +257,30 @@ def test_eigh_two_stage_end_to_end(gpu_api, n, kind, chase, monkeypatch):
     assert np.abs(w - w1).max() <= 30 * n * EPS * max(np.abs(w1).max(), 1e-300)
 
 
+@pytest.mark.parametrize("n,kind", [(1538, "kinship"), (2307, "random"), (1000, "lowrank")])
+def test_bulge_chase_hand_over_variants_are_bit_identical(gpu_api, n, kind, monkeypatch):
+    """The persistent chase kernels differ only in WHEN a task may start (round 4: two positions per workgroup with whole-task
+    hand-over, GEMMA_HIP_EIGH_BC_PIPE=0; one position per workgroup with the reflector handed on early, =1; default: also the
+    left-block hand-over with the shared diagonal entry in a slot, both blocks requested ahead of the reflector): the arithmetic of
+    a task is the same, so (U, eval) must be the same bits; a lost update or a stale block would show here."""
+    monkeypatch.setenv("GEMMA_HIP_EIGH_STAGES", "2")
+    A = _sym(n, 5 * n + 1, kind)
+    res = {}
+    for pipe in ("default", "1", "0"):
+        if pipe == "default":
+            monkeypatch.delenv("GEMMA_HIP_EIGH_BC_PIPE", raising=False)
+        else:
+            monkeypatch.setenv("GEMMA_HIP_EIGH_BC_PIPE", pipe)
+        U, w = np.zeros((n, n)), np.zeros(n)
+        gpu_api.EigenDecomp_Zeroed(A.copy(), U, w)
+        res[pipe] = (U, w)
+    for pipe in ("1", "0"):
+        assert np.array_equal(res[pipe][1], res["default"][1]), pipe
+        assert np.array_equal(res[pipe][0], res["default"][0]), pipe
+    U, w = res["default"]
+    assert np.linalg.norm(U.T @ U - np.eye(n)) < 50 * n * EPS
+
+
 @pytest.mark.parametrize("n,segments,workers", [(1538, "5", "7"), (2050, "64", "512"), (1000, "1", "3")])
 def test_stage2_backtransform_dynamic_schedule(gpu_api, n, segments, workers, monkeypatch):
     """q2_apply_kernel as persistent workgroups drawing (segment of chase steps, row block) tasks (round 3; by default only where
