@@ -893,13 +893,15 @@ __device__ __forceinline__ void bc_task(double *__restrict__ B, long n, long j, 
     }
     bc_st<true>(cbox_in, __longlong_as_double(-1LL)); // empty again for the sweep after next
     dr[CW - 1] = cslot;
-    red[2 * BC_NH + 1] = cslot * v[E2_B - 1];
+    // the corner's term is the LAST of this thread's first product: added here it is the sum the loop above forms when the corner
+    // comes with the block (the hand-over variants return the same bits: test_bulge_chase_hand_over_variants_are_bit_identical)
+    p1 += cslot * v[E2_B - 1]; // same source form as the loop's update: the same contraction into a fused multiply-add
+    ybuf[h * E2_B + a] = p1;
   }
   __syncthreads();
   double psum = 0.0;
 #pragma unroll
   for (int q = 0; q < BC_NH; ++q) psum += ybuf[q * E2_B + a] + zbuf[q * E2_B + a];
-  if (corner_late && a == E2_B - 1) psum += red[2 * BC_NH + 1];
   const double pa = tau * psum;
   const double gamma = bc_bsum((h == 0) ? va * pa : 0.0, red);
   const double wa = pa - 0.5 * tau * gamma * va;
