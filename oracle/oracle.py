@@ -651,6 +651,20 @@ def mph_em(func, max_iter, max_prec, ev, X, Y, Vg, Ve, B):
                             _dp(B))
 
 
+def mph_initial(cfg, ev, X, Y):
+    """MphInitial (src/mvlmm.cpp:2763-2948): the starting point of the null block -> (Vg, Ve, B)"""
+    d, n = Y.shape
+    c = X.shape[0]
+    Vg, Ve, B = np.zeros((d, d)), np.zeros((d, d)), np.zeros((d, c))
+    L = lib()
+    sz, dp, cd = C.c_size_t, C.POINTER(C.c_double), C.c_double
+    L.orc_mph_initial.restype = None
+    L.orc_mph_initial.argtypes = [sz, cd, sz, cd, sz, sz, sz, dp, dp, dp, cd, cd, sz, dp, dp, dp]
+    L.orc_mph_initial(cfg.em_iter, cfg.em_prec, cfg.nr_iter, cfg.nr_prec, n, d, c, _dp(ev), _dp(_c64(X)), _dp(_c64(Y)), cfg.l_min,
+                      cfg.l_max, cfg.n_region, _dp(Vg), _dp(Ve), _dp(B))
+    return Vg, Ve, B
+
+
 def mph_nr(func, max_iter, max_prec, ev, X, Y, Vg, Ve):
     d, n = Y.shape
     Hi = np.zeros((d * (d + 1), d * (d + 1)))

@@ -271,3 +271,39 @@ def test_gxe_on_one_lane_matches_the_oracle(harness, n, d, cw, p, seed, a_mode, 
     for k in got:
         rel = np.abs(got[k] - ref[k]) / np.maximum(np.abs(ref[k]), 1e-300)
         assert rel.max() < 1e-8, (k, rel.max())
+
+
+class MvNullArgs(C.Structure):
+    _fields_ = [("g", MvArgs), ("em_iter", C.c_int), ("em_prec", C.c_double), ("Vg0", C.c_double * 64), ("Ve0", C.c_double * 64),
+                ("out", C.POINTER(C.c_double))]
+
+
+@pytest.mark.parametrize("n,d,cw,seed", [(260, 6, 2, 51), (240, 3, 8, 52), (300, 2, 1, 53)])
+def test_null_fit_of_the_run_time_instance_matches_the_oracle(harness, n, d, cw, seed):
+    """mv_null_fit<0, 0> (EM + Newton-Raphson for REML, then ML from the REML fit, GLS B) on one CPU lane from the oracle's own
+    starting point (MphInitial) against orc_mph_em / orc_mph_nr: the null block of shapes that have no fixed kernel."""
+    c = make_case(n, d, cw, 2, seed)
+    cfg = O.mv_cfg()
+    ref = O.mvlmm_null(cfg, c["ev"], c["UtW"], c["UtY"])
+    Vg0, Ve0, _ = O.mph_initial(cfg, c["ev"], c["UtW"], c["UtY"])
+    harness.mvh_null_args_size.restype = C.c_size_t
+    assert harness.mvh_null_args_size() == C.sizeof(MvNullArgs)
+    P = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
+    a = MvNullArgs()
+    a.g.n, a.g.eval, a.g.Wt, a.g.Yt = n, P(c["ev"]), P(c["UtW"]), P(c["UtY"])
+    a.g.nr_iter, a.g.nr_prec, a.g.d, a.g.c = cfg.nr_iter, cfg.nr_prec, d, cw
+    a.em_iter, a.em_prec = cfg.em_iter, cfg.em_prec
+    for i, x in enumerate(np.asarray(Vg0).ravel()):
+        a.Vg0[i] = x
+    for i, x in enumerate(np.asarray(Ve0).ravel()):
+        a.Ve0[i] = x
+    blk = 2 * d * d + d * cw + 1
+    out = np.zeros(2 * blk)
+    a.out = P(out)
+    assert harness.mvh_null_rt(C.byref(a)) == 0
+    for p, tag in ((0, "remle"), (1, "mle")):
+        o = out[p * blk:(p + 1) * blk]
+        assert np.abs(o[:d * d].reshape(d, d) - ref["Vg_" + tag]).max() < 1e-7 * np.abs(ref["Vg_" + tag]).max()
+        assert np.abs(o[d * d:2 * d * d].reshape(d, d) - ref["Ve_" + tag]).max() < 1e-7 * np.abs(ref["Ve_" + tag]).max()
+        assert np.abs(o[2 * d * d:2 * d * d + d * cw].reshape(d, cw) - ref["B_" + tag]).max() < 1e-7 * np.abs(ref["B_" + tag]).max()
+        assert o[-1] == pytest.approx(ref["logl_" + tag], rel=1e-10)
