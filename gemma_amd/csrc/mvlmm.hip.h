@@ -6,10 +6,11 @@
 // direct sum of d blocks of size c x c (its entries couple (covariate i, component l) with (covariate j, component l)
 // only), so "LU-invert Q" becomes d small SPD inversions, the REML part of CalcSigma (:517-548) and the x P x of
 // MphCalcP are diagonal, and the whole EM iteration is two passes (REML; three for ML) over the n individuals with
-// < 50 running sums, which the 64 lanes of a wavefront stride over and butterfly-reduce.  Small matrices live in
-// registers (D, C are template parameters, every loop over them unrolls); all lanes carry the same copy.
+// < 50 running sums, which the 64 lanes of a wavefront stride over and butterfly-reduce.  In the fixed form (template extents
+// DT, CT > 0) the small matrices live in registers and every loop over them unrolls; in the run-time form (DT = CT = 0, see
+// below) they live in private memory.  All lanes carry the same copy.
 //
-// The lane policy makes the same source run on one CPU "lane" in tests/host_mvlmm_harness.cpp (test infrastructure:
+// The lane policy makes the same source run on one CPU "lane" in tests/host/mvlmm_harness.cpp (test infrastructure:
 // the shipped library has no CPU path).
 #pragma once
 #include <math.h>
