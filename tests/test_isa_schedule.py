@@ -68,3 +68,38 @@ def test_sparse2_kernel_steady_state_loop_is_as_written(tmp_path):
     assert len(mats) == 24 and all(a != b for a, b in zip(mats, mats[1:] + mats[:1])), mats
     # every accumulator block is visited the same number of times: 4 genotype + 4 mask accumulators
     assert sorted(mats.count(a) for a in set(mats)) == [2] * 4 + [4] * 4
+
+
+@pytest.mark.skipif(not (os.path.exists(LIB) and os.path.exists(OBJDUMP)), reason="needs the built library and llvm-objdump")
+def test_run_time_mvlmm_kernel_private_memory_budget(tmp_path):
+    """The run-time multivariate kernel (mvlmm_kernels_rt.hip) keeps its small matrices in private memory; its large pieces are
+    CALLED (MV_OUTLINE), not inlined: 60 KB per lane.  Fully inlined it was 120 KB per lane and eight minutes of compile time, close
+    to the 128 KB a wavefront's scratch can address: a change that inlines them again must not pass silently.  The fixed kernels
+    stay register-resident (no more than a few hundred bytes of spill space for the largest shapes)."""
+    readelf = os.path.join(os.path.dirname(OBJDUMP), "llvm-readelf")
+    if not os.path.exists(readelf):
+        pytest.skip("llvm-readelf not found")
+    work = tmp_path / "o"
+    work.mkdir()
+    shutil.copy(LIB, work / "lib.so")
+    subprocess.run([OBJDUMP, "--offloading", "lib.so"], cwd=work, check=True, capture_output=True)
+    found = {}
+    for f in sorted(os.listdir(work)):
+        if "gfx950" not in f:
+            continue
+        notes = subprocess.run([readelf, "--notes", f], cwd=work, check=True, capture_output=True, text=True).stdout
+        name = None
+        for ln in notes.splitlines():
+            m = re.search(r"\.name:\s+(\S+)", ln)
+            if m:
+                name = m.group(1)
+            m = re.search(r"\.private_segment_fixed_size:\s+(\d+)", ln)
+            if m and name:
+                found[name] = int(m.group(1))
+    rt = {k: v for k, v in found.items() if "mvlmm_rt_kernel" in k or "mvlmm_null_rt_kernel" in k}
+    assert len(rt) == 2, sorted(found)[:5]
+    for k, v in rt.items():
+        assert 0 < v <= 72 * 1024, (k, v)
+    fixed = {k: v for k, v in found.items() if "12mvlmm_kernelILi" in k}
+    assert len(fixed) >= 24
+    assert max(fixed.values()) <= 4096, max(fixed.items(), key=lambda kv: kv[1])
