@@ -287,6 +287,17 @@ def test_snp_sharded_ranks_lm_and_multivariate(driver, tmp_path, monkeypatch):
     fc.drive(driver, *h2, "-k", cxx, "-lmm", 1, "-n", 1, 2, "-gpus", 2, "-o", "mv2")
     assert open(os.path.join(out, "mv2.assoc.txt"), "rb").read() == open(os.path.join(out, "mv1.assoc.txt"), "rb").read()
     assert len(open(os.path.join(out, "mv1.assoc.txt")).read().strip().split("\n")) == 601
+    # the multivariate -gxe (MVLMM::AnalyzePlinkGXE) shards the same way: an environment column over all individuals
+    import numpy as np
+    rng = np.random.default_rng(7)
+    np.savetxt(os.path.join(out, "env.txt"), np.round(rng.standard_normal(len(fam)), 5), fmt="%.5f")
+    with open(os.path.join(out, "few.txt"), "w") as f:
+        f.writelines(l.split()[1] + "\n" for l in list(open(os.path.join(T, "H.bim")))[::10])
+    gx = ["-k", cxx, "-lmm", 4, "-n", 1, 2, "-gxe", os.path.join(out, "env.txt"), "-snps", os.path.join(out, "few.txt")]
+    fc.drive(driver, *h2, *gx, "-o", "gx1")
+    fc.drive(driver, *h2, *gx, "-gpus", 2, "-o", "gx2")
+    assert open(os.path.join(out, "gx2.assoc.txt"), "rb").read() == open(os.path.join(out, "gx1.assoc.txt"), "rb").read()
+    assert len(open(os.path.join(out, "gx1.assoc.txt")).read().strip().split("\n")) >= 50
 
 
 @pytest.mark.parametrize("world", [2, 3])
