@@ -23,6 +23,8 @@
 #define HAVE_SPARSE2 0
 #endif
 
+#include "i8gemm_dense2_proto.hip.h" // scripts/: an experiment, not part of the library
+
 using namespace gemma_hip;
 
 #define CK(x)                                                                          \
@@ -172,7 +174,30 @@ int main(int argc, char **argv) {
     CK(hipExtStreamCreateWithCUMask(&sstream, 8, sm_));
     CK(hipMalloc(&side_out, (size_t)lpad * npad * 8));
   }
+  // variant 4: the dense byte-plane product on 256 x 256 x 64 tiles (i8gemm_dense2.hip.h): A's bytes as they are, one plane per digit;
+  // variant 5: the kernel it replaces for dosages (i8gemm_packed_kernel_t<false, true>) on the same operands
+  Dense2Args gd;
+  gd.A = A; gd.Bt = Bt; gd.C = C; gd.ldk = ldk; gd.ldc = npad; gd.strideB = npad * ldk; gd.strideC = lpad * npad;
+  gd.tiles_m = (int)(lpad / D2_BM); gd.tiles_n = (int)(npad / D2_BN); gd.nk = (int)(ldk / D2_BK); gd.gm = gm;
+  if (variant == 4)
+    CK(hipFuncSetAttribute(reinterpret_cast<const void *>(i8gemm_dense2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                           D2_NST * D2_STAGE));
+  if (variant == 5)
+    CK(hipFuncSetAttribute(reinterpret_cast<const void *>(i8gemm_packed_kernel_t<false, true>),
+                           hipFuncAttributeMaxDynamicSharedMemorySize, 3 * I8P_STAGE));
   auto launch = [&]() {
+    if (variant == 4) {
+      hipLaunchKernelGGL(i8gemm_dense2_kernel, dim3((unsigned)(gd.tiles_m * gd.tiles_n), (unsigned)digits), dim3(512),
+                         D2_NST * D2_STAGE, mstream, gd);
+      return;
+    }
+    if (variant == 5) {
+      I8PackArgs g5 = g;
+      g5.strideC = lpad * npad; g5.m_row0 = 0; g5.fuse = 0;
+      hipLaunchKernelGGL((i8gemm_packed_kernel_t<false, true>), dim3((unsigned)(g5.tiles_m * g5.tiles_n), (unsigned)digits), dim3(512),
+                         3 * I8P_STAGE, mstream, g5);
+      return;
+    }
 #if HAVE_SPARSE2
     if (variant == 2) {
       hipLaunchKernelGGL(i8gemm_sparse2_kernel_t<2>, grid2, dim3(512), S2_NST * S2_STAGE, mstream, g2);
@@ -255,6 +280,17 @@ int main(int argc, char **argv) {
       const long c = (long)((sc * 104729L + 101) % n);
       for (int d = 0; d < digits; ++d)
         CK(hipMemcpy(hcol.data() + (size_t)d * ldk, Bt + (size_t)d * npad * ldk + c * ldk, ldk, hipMemcpyDeviceToHost));
+      if (variant >= 4) { // one plane per digit, A's bytes as signed values
+        for (int d = 0; d < digits; ++d) {
+          long e = 0;
+          for (long k = 0; k < ldk; ++k) e += (long)hrow[k] * hcol[(size_t)d * ldk + k];
+          int got;
+          CK(hipMemcpy(&got, C + (size_t)d * lpad * npad + r * npad + c, 4, hipMemcpyDeviceToHost));
+          bad += got != (int)e;
+          ++checked;
+        }
+        continue;
+      }
       for (int pl = 0; pl < nplanes; ++pl) {
         long eg = 0, em = 0; // fused pair: 256 * C_{2 pl + 1} + C_{2 pl}
         for (int dd = 1; dd >= 0; --dd) {
