@@ -646,7 +646,9 @@ def main():
                     "frac": round(achieved / INT8_MFMA_PEAK_TOPS, 4), "logical_top_s": round(logical, 1),
                     "logical_frac_of_dense_peak": round(logical / INT8_MFMA_PEAK_TOPS, 4),
                     "note": "achieved = dense-equivalent work of the matrix pipe (a 2:4 sparse instruction counted as the dense one it "
-                            "takes the time of); logical_top_s = the 2 D products as written" if sparse else "dense int8 MFMA",
+                            "takes the time of); logical_top_s = the 2 D products as written; the kernel is power-limited: the same binary "
+                            "with an all-zero digit operand takes 38.65 ms where full-range digits take 55.95 "
+                            "(profiles/r04_i8_operand_value_power.txt, DESIGN 3.1c)" if sparse else "dense int8 MFMA",
                     "traffic": None, "launches": gemm_n, "launches_per_step": gemm_launches_per_step,
                     "avg_launch_ms": round(gemm_ms / max(1, gemm_n), 3), "ms_per_step": round(gemm_avg_s * 1e3, 3),
                     # the same launch priced as the fp64 product it replaces (2 n^2 flop per SNP)

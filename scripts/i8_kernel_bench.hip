@@ -57,11 +57,19 @@ __global__ void fill_A(int8_t *A, long lpad, long ldk, long l, long n) {
   }
   A[i] = v;
 }
-__global__ void fill_B(int8_t *Bt, long total, long ldk, long n) {
+// B_MODE (experiment: how much of the power-limited kernel time is operand toggling): 0 digits uniform in [-128, 127] (what real
+// digits of U look like), 1 all zero, 2 uniform in [0, 15], 3 uniform in [-8, 7], 4 uniform in [0, 127]
+__global__ void fill_B(int8_t *Bt, long total, long ldk, long n, int mode) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   if (i >= total) return;
   const long c = i % ldk;
-  Bt[i] = (c < n) ? (int8_t)((int)(hash32((unsigned)(i * 40503u + 977u)) & 255) - 128) : (int8_t)0;
+  const int hv = (int)(hash32((unsigned)(i * 40503u + 977u)) & 255);
+  int v = hv - 128;
+  if (mode == 1) v = 0;
+  if (mode == 2) v = hv & 15;
+  if (mode == 3) v = (hv & 15) - 8;
+  if (mode == 4) v = hv & 127;
+  Bt[i] = (c < n) ? (int8_t)v : (int8_t)0;
 }
 
 // stand-ins for the stages behind U^T x (CU_SPLIT experiment): grid-stride streaming kernels
@@ -103,7 +111,7 @@ int main(int argc, char **argv) {
   CK(hipMalloc(&C, (size_t)nplanes * mrows * npad * 4));
   hipLaunchKernelGGL(fill_A, dim3((unsigned)((lpad * ldk + 255) / 256)), dim3(256), 0, 0, A, lpad, ldk, B, n);
   hipLaunchKernelGGL(fill_B, dim3((unsigned)(((size_t)digits * npad * ldk + 255) / 256)), dim3(256), 0, 0, Bt,
-                     (long)digits * npad * ldk, ldk, n);
+                     (long)digits * npad * ldk, ldk, n, getenv("B_MODE") ? atoi(getenv("B_MODE")) : 0);
   CK(hipDeviceSynchronize());
   I8PackArgs g;
   g.A = A; g.Bt = Bt; g.C = C;
