@@ -24,6 +24,7 @@
 #endif
 
 #include "i8gemm_dense2_proto.hip.h" // scripts/: an experiment, not part of the library
+#include "i8gemm_sparse2_g16_proto.hip.h" // scripts/: the records kernel with its genotype product on 16x16x64 (variant 6)
 
 using namespace gemma_hip;
 
@@ -161,6 +162,8 @@ int main(int argc, char **argv) {
                            S2_NST * S2_STAGE));
     CK(hipFuncSetAttribute(reinterpret_cast<const void *>(i8gemm_sparse2_kernel_t<1>), hipFuncAttributeMaxDynamicSharedMemorySize,
                            S2_NST * S2_STAGE));
+    CK(hipFuncSetAttribute(reinterpret_cast<const void *>(i8gemm_sparse2_g16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                           S2_NST * S2_STAGE));
   }
 #endif
   // CU_SPLIT=k (experiment): the product runs on a stream whose CU mask leaves k CUs out, and on exactly those a streaming kernel
@@ -207,6 +210,10 @@ int main(int argc, char **argv) {
       return;
     }
 #if HAVE_SPARSE2
+    if (variant == 6) {
+      hipLaunchKernelGGL(i8gemm_sparse2_g16_kernel, grid2, dim3(512), S2_NST * S2_STAGE, mstream, g2);
+      return;
+    }
     if (variant == 2) {
       hipLaunchKernelGGL(i8gemm_sparse2_kernel_t<2>, grid2, dim3(512), S2_NST * S2_STAGE, mstream, g2);
       return;
@@ -288,7 +295,7 @@ int main(int argc, char **argv) {
       const long c = (long)((sc * 104729L + 101) % n);
       for (int d = 0; d < digits; ++d)
         CK(hipMemcpy(hcol.data() + (size_t)d * ldk, Bt + (size_t)d * npad * ldk + c * ldk, ldk, hipMemcpyDeviceToHost));
-      if (variant >= 4) { // one plane per digit, A's bytes as signed values
+      if (variant == 4 || variant == 5) { // one plane per digit, A's bytes as signed values
         for (int d = 0; d < digits; ++d) {
           long e = 0;
           for (long k = 0; k < ldk; ++k) e += (long)hrow[k] * hcol[(size_t)d * ldk + k];
