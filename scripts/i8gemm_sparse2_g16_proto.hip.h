@@ -94,8 +94,10 @@ __global__ __launch_bounds__(512, 2) void i8gemm_sparse2_g16_kernel(Sparse2Args 
   i32x4 am[2];        // records in the sparse instruction's lane layout [pair parity]
   i32x4 ar[2];        // records in the 16x16x64 lane layout [group of 16 rows] (next pair's, until unpacked)
   i32x4 ga[2];        // genotype operands [group]
-  i32x4 bx[5], by[5]; // digit fragments [32-column block]; block 3 alternates between slots 3 and 4 with the pair's parity (its
-                      // last reader is the last instruction of a pair: the next pair's fragment is requested a pair ahead)
+  i32x8 bxy[5];       // digit fragments [32-column block]: X (columns 32 j + c16) in elements 0..3, Y (+ 16) in 4..7 -- eight
+                      // consecutive registers, which after the lane swap ARE the sparse instruction's operand; block 3 alternates
+                      // between slots 3 and 4 with the pair's parity (its last reader is the last instruction of a pair: the next
+                      // pair's fragment is requested a pair ahead)
   i32x4 ms[2];        // expanded kept bits [pair parity]
 
 #define G16_DMA_A(j, SOFF)                                                                                        \
@@ -115,8 +117,10 @@ __global__ __launch_bounds__(512, 2) void i8gemm_sparse2_g16_kernel(Sparse2Args 
 // block j of pair P into register slot SL (SL = j for j < 3, 3 + (P & 1) for block 3)
 #define G16_RB(SOFF, P, j, SL)                                                                                    \
   do {                                                                                                            \
-    bx[SL] = *reinterpret_cast<const i32x4 *>(i8lds + (SOFF) + fbx[(P)&1] + (j) * 4096);                          \
-    by[SL] = *reinterpret_cast<const i32x4 *>(i8lds + (SOFF) + fbx[(P)&1] + (j) * 4096 + 2048);                   \
+    const i32x4 x_ = *reinterpret_cast<const i32x4 *>(i8lds + (SOFF) + fbx[(P)&1] + (j) * 4096);                  \
+    const i32x4 y_ = *reinterpret_cast<const i32x4 *>(i8lds + (SOFF) + fbx[(P)&1] + (j) * 4096 + 2048);           \
+    bxy[SL] = __builtin_shufflevector(__builtin_shufflevector(x_, x_, 0, 1, 2, 3, 0, 1, 2, 3), bxy[SL], 0, 1, 2, 3, 12, 13, 14, 15); \
+    bxy[SL] = __builtin_shufflevector(bxy[SL], __builtin_shufflevector(y_, y_, 0, 1, 2, 3, 0, 1, 2, 3), 0, 1, 2, 3, 8, 9, 10, 11);   \
   } while (0)
 // (the empty asm keeps all four registers of the record alive up to here: otherwise the unused halves of ar[0] and ar[1] share
 // registers and the second read has to wait for the first)
@@ -128,20 +132,21 @@ __global__ __launch_bounds__(512, 2) void i8gemm_sparse2_g16_kernel(Sparse2Args 
 #define G16_EXP(P) ms[(P)&1] = s2_expand(am[(P)&1][3])
 // dense 16x16x64: group i of rows, sub-block 2 j (X) or 2 j + 1 (Y)
 #define G16_DX(i, j, SL)                                                                                          \
-  asm volatile("s_nop 1\n\tv_mfma_i32_16x16x64_i8 %0, %1, %2, %0" : "+v"(acc16[i][2 * (j)]) : "v"(ga[i]), "v"(bx[SL]))
+  asm volatile("s_nop 1\n\tv_mfma_i32_16x16x64_i8 %0, %1, %2, %0"                                                \
+               : "+v"(acc16[i][2 * (j)]) : "v"(ga[i]), "v"(__builtin_shufflevector(bxy[SL], bxy[SL], 0, 1, 2, 3)))
 #define G16_DY(i, j, SL)                                                                                          \
-  asm volatile("s_nop 1\n\tv_mfma_i32_16x16x64_i8 %0, %1, %2, %0" : "+v"(acc16[i][2 * (j) + 1]) : "v"(ga[i]), "v"(by[SL]))
+  asm volatile("s_nop 1\n\tv_mfma_i32_16x16x64_i8 %0, %1, %2, %0"                                                \
+               : "+v"(acc16[i][2 * (j) + 1]) : "v"(ga[i]), "v"(__builtin_shufflevector(bxy[SL], bxy[SL], 4, 5, 6, 7)))
 // X, Y of block j -> the two halves of the sparse instruction's digit operand (in place)
 #define G16_SWAP(SL)                                                                                              \
   do {                                                                                                            \
     _Pragma("unroll") for (int w_ = 0; w_ < 4; ++w_)                                                              \
-      asm volatile("v_permlane16_swap_b32 %0, %1" : "+v"(bx[SL][w_]), "+v"(by[SL][w_]));                          \
+      asm volatile("v_permlane16_swap_b32 %0, %1" : "+v"(bxy[SL][w_]), "+v"(bxy[SL][4 + w_]));                    \
   } while (0)
 #define G16_S(P, j, SL)                                                                                           \
   do {                                                                                                            \
-    const i32x8 bp_ = __builtin_shufflevector(bx[SL], by[SL], 0, 1, 2, 3, 4, 5, 6, 7);                             \
     asm volatile("s_nop 1\n\tv_smfmac_i32_32x32x64_i8 %0, %1, %2, %3"                                            \
-                 : "+v"(accm[j]) : "v"(ms[(P)&1]), "v"(bp_), "v"(am[(P)&1][2]));                                   \
+                 : "+v"(accm[j]) : "v"(ms[(P)&1]), "v"(bxy[SL]), "v"(am[(P)&1][2]));                               \
   } while (0)
 // All the work of pair P (parity known at compile time) from registers.  HEAD: the next pair's record reads and its block-3 fragment
 // (other slot); RB0, RB12: its other digit-fragment reads, issued behind the sparse instruction that was the last reader of those
@@ -149,28 +154,29 @@ __global__ __launch_bounds__(512, 2) void i8gemm_sparse2_g16_kernel(Sparse2Args 
 // instruction).  No read is younger than one sparse instruction and four lane swaps when the next pair starts.
 #define G16_PAIR(P, HEAD, RB0, RB12, MID0, MID1, TAIL)                                                            \
   do {                                                                                                            \
-    G16_DX(0, 0, 0); HEAD; GEMMA_SB();                                                                            \
-    G16_DY(0, 0, 0); GEMMA_SB();                                                                                  \
+    G16_DX(0, 0, 0); MID0; GEMMA_SB();                                                                            \
+    G16_DY(0, 0, 0); MID1; GEMMA_SB();                                                                            \
     G16_DX(1, 0, 0); GEMMA_SB();                                                                                  \
     G16_DY(1, 0, 0); GEMMA_SB();                                                                                  \
-    G16_DX(0, 1, 1); MID0; GEMMA_SB();                                                                            \
+    G16_DX(0, 1, 1); GEMMA_SB();                                                                                  \
     G16_DY(0, 1, 1); GEMMA_SB();                                                                                  \
-    G16_DX(1, 1, 1); MID1; GEMMA_SB();                                                                            \
+    G16_DX(1, 1, 1); GEMMA_SB();                                                                                  \
     G16_DY(1, 1, 1); G16_SWAP(0); GEMMA_SB();                                                                     \
-    G16_DX(0, 2, 2); GEMMA_SB();                                                                                  \
+    G16_DX(0, 2, 2); HEAD; GEMMA_SB();                                                                            \
     G16_DY(0, 2, 2); GEMMA_SB();                                                                                  \
-    G16_S(P, 0, 0); GEMMA_SB();                                                                                   \
+    G16_S(P, 0, 0); RB0; GEMMA_SB();                                                                              \
     G16_DX(1, 2, 2); GEMMA_SB();                                                                                  \
     G16_DY(1, 2, 2); G16_SWAP(1); GEMMA_SB();                                                                     \
     G16_DX(0, 3, 3 + ((P)&1)); GEMMA_SB();                                                                        \
     G16_DY(0, 3, 3 + ((P)&1)); GEMMA_SB();                                                                        \
-    G16_S(P, 1, 1); RB0; GEMMA_SB();                                                                              \
+    G16_S(P, 1, 1); GEMMA_SB();                                                                                   \
     G16_DX(1, 3, 3 + ((P)&1)); GEMMA_SB();                                                                        \
     G16_DY(1, 3, 3 + ((P)&1)); G16_SWAP(2); GEMMA_SB();                                                           \
     TAIL; GEMMA_SB();                                                                                             \
     G16_S(P, 2, 2); RB12; GEMMA_SB();                                                                             \
     G16_SWAP(3 + ((P)&1)); GEMMA_SB();                                                                            \
     G16_S(P, 3, 3 + ((P)&1)); GEMMA_SB();                                                                         \
+    asm volatile("" ::"v"(am[(P)&1])); /* all four registers of the record alive up to here (see G16_UNP) */     \
   } while (0)
 // one K-tile from stage SC (MORE: tile t+1 in stage SN; LOAD3: tile t+3 goes to stage SD; VMW as in i8gemm_sparse2.hip.h).  Every
 // read of stage SC is issued before the rendezvous in the middle; the reads of stage SN come behind it.
