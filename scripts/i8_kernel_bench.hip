@@ -25,6 +25,7 @@
 
 #include "i8gemm_dense2_proto.hip.h" // scripts/: an experiment, not part of the library
 #include "i8gemm_sparse2_g16_proto.hip.h" // scripts/: the records kernel with its genotype product on 16x16x64 (variant 6)
+#include "i8gemm_sparse2_g16s_proto.hip.h" // scripts/: both products on the 16-row forms, no lane swaps (variant 7)
 
 using namespace gemma_hip;
 
@@ -164,6 +165,8 @@ int main(int argc, char **argv) {
                            S2_NST * S2_STAGE));
     CK(hipFuncSetAttribute(reinterpret_cast<const void *>(i8gemm_sparse2_g16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                            S2_NST * S2_STAGE));
+    CK(hipFuncSetAttribute(reinterpret_cast<const void *>(i8gemm_sparse2_g16s_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                           S2_NST * S2_STAGE));
   }
 #endif
   // CU_SPLIT=k (experiment): the product runs on a stream whose CU mask leaves k CUs out, and on exactly those a streaming kernel
@@ -212,6 +215,10 @@ int main(int argc, char **argv) {
 #if HAVE_SPARSE2
     if (variant == 6) {
       hipLaunchKernelGGL(i8gemm_sparse2_g16_kernel, grid2, dim3(512), S2_NST * S2_STAGE, mstream, g2);
+      return;
+    }
+    if (variant == 7) {
+      hipLaunchKernelGGL(i8gemm_sparse2_g16s_kernel, grid2, dim3(512), S2_NST * S2_STAGE, mstream, g2);
       return;
     }
     if (variant == 2) {
