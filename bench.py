@@ -632,7 +632,10 @@ def main():
             smode = os.environ.get("GEMMA_HIP_I8_SPARSE", "2")[:1]
             smode = smode if smode in ("0", "1", "2") else "2"
             sparse = smode != "0"
-            kfn = {"0": "i8gemm_packed_kernel", "1": "i8gemm_sparse_kernel", "2": "i8gemm_sparse2_kernel"}[smode]
+            rows16 = os.environ.get("GEMMA_HIP_I8_ROWS", "16").strip() != "32"
+            kfn = {"0": "i8gemm_packed_kernel", "1": "i8gemm_sparse_kernel",
+                   "2": "i8gemm_sparse2_r16_kernel (records kernel on v_mfma_i32_16x16x64_i8 + v_smfmac_i32_16x16x128_i8)" if rows16
+                        else "i8gemm_sparse2_kernel (32-row matrix instructions)"}[smode]
             # With the mask product on the 2:4 sparse MFMA (csrc/i8gemm_sparse.hip.h) a pair of K-steps issues 8 dense + 4 sparse
             # matrix instructions instead of 16 dense ones, and a sparse instruction holds the pipe as long as a dense one
             # (profiles/r02_smfmac_i8_rate.txt): the pipe does 12/16 of the dense work.  `achieved` / `frac` price what the pipe
@@ -646,9 +649,9 @@ def main():
                     "frac": round(achieved / INT8_MFMA_PEAK_TOPS, 4), "logical_top_s": round(logical, 1),
                     "logical_frac_of_dense_peak": round(logical / INT8_MFMA_PEAK_TOPS, 4),
                     "note": "achieved = dense-equivalent work of the matrix pipe (a 2:4 sparse instruction counted as the dense one it "
-                            "takes the time of); logical_top_s = the 2 D products as written; the kernel is power-limited: the same binary "
-                            "with an all-zero digit operand takes 38.65 ms where full-range digits take 55.95 "
-                            "(profiles/r04_i8_operand_value_power.txt, DESIGN 3.1c)" if sparse else "dense int8 MFMA",
+                            "takes the time of); logical_top_s = the 2 D products as written; the kernel is power-limited: with an all-zero digit "
+                            "operand the 32-row kernel takes 38.65 ms where full-range digits take 55.95, the 16-row kernel 40.8 / 49.8 "
+                            "(profiles/r04_i8_operand_value_power.txt, r04_i8_g16s_prototype.txt, DESIGN 3.1c)" if sparse else "dense int8 MFMA",
                     "traffic": None, "launches": gemm_n, "launches_per_step": gemm_launches_per_step,
                     "avg_launch_ms": round(gemm_ms / max(1, gemm_n), 3), "ms_per_step": round(gemm_avg_s * 1e3, 3),
                     # the same launch priced as the fp64 product it replaces (2 n^2 flop per SNP)

@@ -1,24 +1,33 @@
-// EXPERIMENT (end of round 4; not part of the library): the records kernel of i8gemm_sparse2.hip.h on the 16-row matrix
-// instructions -- genotype product on v_mfma_i32_16x16x64_i8, mask product on v_smfmac_i32_16x16x128_i8 -- with NO lane swaps:
-// same records, same digit planes, same int32 planes out, same LDS stages and LDS-DMA pipeline; wavefronts 8 x 1.
+// The records kernel (i8gemm_sparse2.hip.h: same records, same digit planes, same int32 planes out, same LDS stages and LDS-DMA
+// pipeline, wavefronts 8 x 1) on the 16-ROW matrix instructions: genotype product on v_mfma_i32_16x16x64_i8, mask product on
+// v_smfmac_i32_16x16x128_i8.  The shipped form since the end of round 4 (GEMMA_HIP_I8_ROWS=32 selects the 32-row kernel).
+//
+// Why: the kernel is power-limited, and how much clock the chip gives up depends on the instruction and on the VALUES it multiplies
+// (DESIGN.md 3.1c).  With operands in registers and nothing else running v_mfma_i32_32x32x32_i8 sustains 3.70 POP/s on full-range
+// digit values and the 16x16x64 form 4.72 (profiles/r04_mfma_power_probe.txt); this kernel needs 40.8 ms of schedule (all-zero
+// digits; the 32-row kernel 38.7) and 49.8 ms with real digits where the 32-row kernel needs 54.6 on the same box
+// (profiles/r04_i8_g16s_prototype.txt).  Every entry of every plane equals the 32-row kernel's on ten shapes -- 2 454 061 056 entries
+// at n = 20 000, odd digit counts, unfused planes, K loops of 1 - 3 tiles, ragged tiles (profiles/r04_i8_r16_full_compare.txt,
+// scripts/i8_kernel_bench.hip variant 7 with FULLCMP=1).
 //
 // Layouts (profiles/r04_mfma16_layout_probe.txt, r04_smfmac16_layout_probe.txt).  Lane l = (r16 = l % 16, q = l / 16).
 //   dense 16x16x64, pair P of K-steps: lane q multiplies the 16 K bytes 64 P + 16 q .. of row / column r16 -- K-step 2 P + (q >> 1),
 //     half q & 1: left operand = word q >> 1 of the record chunk 2 P + (q & 1) of the row, right operand F[P] = chunk 4 P + q of the
 //     digit row;
 //   sparse 16x16x128, the whole K-tile: lane quarter q of the left operand covers the 32 logical K bytes of K-step q (kept slots
-//     0..7 its first 16, 8..15 its second 16) = index word and kept bits of the record chunk q of the row -- which the existing
-//     records already hold; its right operand in lane (c16, qb) is (F[0], F[1]) of the SAME lane: chunk beta of quarter qb
-//     multiplies quarter qa = (qb >> 1) + 2 beta, slots 8 (qb & 1) ..: K bytes 64 beta + 16 qb .. = F[beta] of lane qb.  So one
-//     8-register tuple per 16-column sub-block serves two dense and one sparse instruction per group of 16 rows.
-// Per K-tile and lane: record chunks q & 1 and 2 + (q & 1) of both row groups (4 ds_read_b128), 16 digit reads, 32 dense + 16
-// sparse instructions, 4 LDS-DMA pieces.
+//     0..7 its first 16, 8..15 its second 16) = index word and kept bits of the record chunk q of the row -- which the records
+//     already hold; its right operand in lane (c16, qb) is (F[0], F[1]) of the SAME lane: chunk beta of quarter qb multiplies
+//     quarter qa = (qb >> 1) + 2 beta, slots 8 (qb & 1) ..: K bytes 64 beta + 16 qb .. = F[beta] of lane qb.  So one 8-register
+//     tuple per 16-column sub-block serves two dense and one sparse instruction per group of 16 rows: no lane exchange, no second
+//     set of LDS reads.
+// Per K-tile and wavefront: 4 record reads + 16 digit reads (ds_read_b128), 32 dense + 16 sparse instructions, 4 LDS-DMA pieces, one
+// counted s_waitcnt vmcnt(8) + one s_barrier; tests/test_isa_schedule.py holds the built loop to that.
 #pragma once
 #include "i8gemm_sparse2.hip.h"
 
 namespace gemma_hip {
 
-__global__ __launch_bounds__(512, 2) void i8gemm_sparse2_g16s_kernel(Sparse2Args g) {
+__global__ __launch_bounds__(512, 2) void i8gemm_sparse2_r16_kernel(Sparse2Args g) {
   extern __shared__ __attribute__((aligned(1024))) int8_t i8lds[];
   int tm, tn;
   if (g.tile_map) {

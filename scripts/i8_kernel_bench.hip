@@ -25,7 +25,7 @@
 
 #include "i8gemm_dense2_proto.hip.h" // scripts/: an experiment, not part of the library
 #include "i8gemm_sparse2_g16_proto.hip.h" // scripts/: the records kernel with its genotype product on 16x16x64 (variant 6)
-#include "i8gemm_sparse2_g16s_proto.hip.h" // scripts/: both products on the 16-row forms, no lane swaps (variant 7)
+#include "i8gemm_sparse2_r16.hip.h" // the shipped 16-row kernel (variant 7)
 
 using namespace gemma_hip;
 
@@ -98,10 +98,18 @@ __global__ __launch_bounds__(256) void side_read_kernel(const double *__restrict
   if (s == 1.2345e-300) *sink = s;
 }
 
+__global__ void count_diff_kernel(const int *a, const int *b, size_t total, unsigned long long *cnt) {
+  unsigned long long c = 0;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) c += a[i] != b[i];
+  if (c) atomicAdd(cnt, c);
+}
+
 int main(int argc, char **argv) {
   const long n = argc > 1 ? atol(argv[1]) : 20000, B = argc > 2 ? atol(argv[2]) : 20000;
   const int variant = argc > 3 ? atoi(argv[3]) : 0;
-  const int digits = 6, fuse = 1, nplanes = 3;
+  // DIGITS / FUSE (variants 3, 6, 7): an odd digit count leaves the first plane with one digit; FUSE=0: one plane per digit
+  const int digits = getenv("DIGITS") ? atoi(getenv("DIGITS")) : 6, fuse = getenv("FUSE") ? atoi(getenv("FUSE")) : 1;
+  const int nplanes = fuse ? (digits + 1) / 2 : digits;
   const long ldk = (n + I8_BK - 1) / I8_BK * I8_BK, npad = (n + I8_BN - 1) / I8_BN * I8_BN;
   const long rowtile = variant >= 2 ? 256 : I8P_BM;
   const long lpad = (B + rowtile - 1) / rowtile * rowtile, mrows = 2 * lpad;
@@ -165,7 +173,7 @@ int main(int argc, char **argv) {
                            S2_NST * S2_STAGE));
     CK(hipFuncSetAttribute(reinterpret_cast<const void *>(i8gemm_sparse2_g16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                            S2_NST * S2_STAGE));
-    CK(hipFuncSetAttribute(reinterpret_cast<const void *>(i8gemm_sparse2_g16s_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+    CK(hipFuncSetAttribute(reinterpret_cast<const void *>(i8gemm_sparse2_r16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                            S2_NST * S2_STAGE));
   }
 #endif
@@ -218,7 +226,7 @@ int main(int argc, char **argv) {
       return;
     }
     if (variant == 7) {
-      hipLaunchKernelGGL(i8gemm_sparse2_g16s_kernel, grid2, dim3(512), S2_NST * S2_STAGE, mstream, g2);
+      hipLaunchKernelGGL(i8gemm_sparse2_r16_kernel, grid2, dim3(512), S2_NST * S2_STAGE, mstream, g2);
       return;
     }
     if (variant == 2) {
@@ -277,6 +285,28 @@ int main(int argc, char **argv) {
     CK(hipEventElapsedTime(&sms, s0, s1));
     printf("CU_SPLIT=%d mode %s: side stream (combine-like + 2 reads, %.1f GB per step) %.3f ms per step\n", cu_split,
            getenv("CU_MODE") ? getenv("CU_MODE") : "0", ((double)nplanes * mrows * npad * 4 + 3.0 * lpad * npad * 8) / 1e9, sms / reps);
+  }
+  // FULLCMP=1 (variants 6, 7): EVERY entry of every plane against the shipped kernel (variant 3) run on the same operands
+  if (getenv("FULLCMP") && atoi(getenv("FULLCMP")) && (variant == 6 || variant == 7)) {
+    const size_t total = (size_t)nplanes * mrows * npad;
+    int *C2 = nullptr;
+    unsigned long long *dcnt = nullptr, hcnt = 0;
+    CK(hipMalloc(&C2, total * 4));
+    CK(hipMalloc(&dcnt, 8));
+    CK(hipMemset(dcnt, 0, 8));
+    CK(hipMemcpy(C2, C, total * 4, hipMemcpyDeviceToDevice));
+    CK(hipMemset(C, 0xAB, total * 4));
+    hipLaunchKernelGGL(i8gemm_sparse2_kernel_t<1>, grid2, dim3(512), S2_NST * S2_STAGE, 0, g2);
+    CK(hipGetLastError());
+    hipLaunchKernelGGL(count_diff_kernel, dim3(4096), dim3(256), 0, 0, C, C2, total, dcnt);
+    CK(hipMemcpy(&hcnt, dcnt, 8, hipMemcpyDeviceToHost));
+    printf("FULLCMP variant %d vs shipped kernel, digits %d fuse %d, n = %ld, B = %ld: %llu of %zu plane entries differ\n", variant, digits, fuse,
+           n, B, hcnt, total);
+    if (hcnt) return 3;
+  }
+  if (digits != 6 || fuse != 1) { // the sampled check below knows the default plane layout only
+    printf("variant %d, n = %ld, B = %ld, digits %d fuse %d: %.2f ms per launch (%d planes)\n", variant, n, B, digits, fuse, ms / reps, nplanes);
+    return 0;
   }
   // sampled check: rows and columns spread over the tiles, all planes
   std::vector<int8_t> hrow(ldk), hcol((size_t)digits * ldk);

@@ -70,6 +70,53 @@ def test_sparse2_kernel_steady_state_loop_is_as_written(tmp_path):
     assert sorted(mats.count(a) for a in set(mats)) == [2] * 4 + [4] * 4
 
 
+def _steady_loop(lines):
+    """ops of the backward-branch loop that holds the most matrix instructions"""
+    ops = [ln.split("//")[0].strip() for ln in lines if ln.strip()]
+    addr = []
+    for ln in lines:
+        if not ln.strip():
+            continue
+        m = re.search(r"//\s*([0-9A-F]{8,16}):", ln)
+        addr.append(int(m.group(1), 16) if m else None)
+    best = None
+    for i, op in enumerate(ops):
+        m = re.match(r"s_cbranch_scc1\s+(\d+)", op)
+        if not m or int(m.group(1)) < 32768:
+            continue
+        target = addr[i] + 4 + 4 * (int(m.group(1)) - 65536)
+        j = next(k for k in range(i) if addr[k] == target)
+        body = ops[j:i + 1]
+        nm = sum(("v_mfma" in o) or ("v_smfmac" in o) for o in body)
+        if best is None or nm > best[0]:
+            best = (nm, body)
+    return ops, (best[1] if best else None)
+
+
+@pytest.mark.skipif(not (os.path.exists(LIB) and os.path.exists(OBJDUMP)), reason="needs the built library and llvm-objdump")
+def test_sixteen_row_records_kernel_steady_state_loop_is_as_written(tmp_path):
+    """i8gemm_sparse2_r16_kernel (the shipped form of the records kernel since the end of round 4: v_mfma_i32_16x16x64_i8 +
+    v_smfmac_i32_16x16x128_i8): per K-tile and wavefront 32 dense + 16 sparse instructions, 4 LDS-DMA pieces, 20 ds_read_b128 (4
+    records, 16 digit fragments), one barrier, ONE counted s_waitcnt vmcnt(8) and no vmcnt(0), no lane exchange, no register copy,
+    and no scratch access anywhere in the kernel (a spill is a vector-memory operation the counted wait does not know about)."""
+    lines = _kernel_text(tmp_path, "i8gemm_sparse2_r16_kernel")
+    assert lines, "i8gemm_sparse2_r16_kernel not found in the gfx950 code object"
+    ops, body = _steady_loop(lines)
+    assert not any(o.startswith("scratch_") for o in ops), [o for o in ops if o.startswith("scratch_")][:4]
+    assert body is not None
+    cnt = lambda pat: sum(bool(re.match(pat, o)) for o in body)
+    assert cnt(r"v_mfma_i32_16x16x64_i8") == 32 and cnt(r"v_smfmac_i32_16x16x128_i8") == 16
+    assert cnt(r"global_load_lds_dwordx4") == 4 and cnt(r"ds_read_b128") == 20 and cnt(r"ds_read") == 20
+    assert cnt(r"s_barrier") == 1
+    assert cnt(r"s_waitcnt vmcnt\(8\)") == 1 and cnt(r"s_waitcnt vmcnt\(0\)") == 0, [o for o in body if "vmcnt" in o]
+    assert cnt(r"v_permlane") == 0 and cnt(r"v_mov_b32") == 0
+    assert not any(o.startswith(("scratch_", "buffer_store", "buffer_load_dword ")) for o in body)
+    mats = [re.match(r"v_s?mfmac?\w*\s+(v\[\d+:\d+\])", o).group(1) for o in body if re.match(r"v_s?mfma", o)]
+    # 16 genotype accumulators visited twice (two pairs of K-steps), 16 mask accumulators once; never the same one twice in a row
+    assert len(mats) == 48 and all(a != b for a, b in zip(mats, mats[1:] + mats[:1])), mats
+    assert sorted(mats.count(a) for a in set(mats)) == [1] * 16 + [2] * 16
+
+
 @pytest.mark.skipif(not (os.path.exists(LIB) and os.path.exists(OBJDUMP)), reason="needs the built library and llvm-objdump")
 def test_run_time_mvlmm_kernel_private_memory_budget(tmp_path):
     """The run-time multivariate kernel (mvlmm_kernels_rt.hip) keeps its small matrices in private memory; its large pieces are
