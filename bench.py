@@ -201,6 +201,101 @@ def self_launch(args):
     return subprocess.call(cmd, env=env)
 
 
+def setup_multi_rank(args, np, torch, dist, api, L, gdist, rank, world, dev, gen, n, B, setup_info, null, UtW, Uty):
+    """The setup of an N-rank run as the real flow has it (tests/cpp/gemma_file_driver.cpp -gpus N): every rank adds ITS
+    share of the kinship SNPs, gemma_hip_kin_end_keep(allreduce) is the ONE ncclAllReduce of the n^2 sums, the decomposition is the
+    collective gemma_hip_eigh_kept_K_sharded (K, U and eval never leave the device), every rank rotates the covariates and the
+    phenotype on its kept U, and ONE small ncclBroadcast makes rank 0's (UtW, Uty, null model) everybody's.  Every clock is this
+    rank's wall time around synchronised library calls; rank 0's go into the line, the slowest rank's beside them."""
+    wa = torch.ones((64, 64), dtype=torch.float64, device=dev)
+    api.fast_dgemm("N", "N", 1.0, wa, wa, 0.0, torch.empty_like(wa))  # the library's code object is loaded before any clock starts
+    del wa
+    lo, hi = gdist.shard_range(args.kin_snps, rank, world)
+    torch.cuda.synchronize()
+    t_kin = 0.0
+    t0 = time.time()
+    api.kin_begin(n, 1)
+    torch.cuda.synchronize()
+    t_kin += time.time() - t0
+    done = lo
+    while done < hi:
+        l = min(B, hi - done)
+        blk = synth_block(torch, n, l, gen, dev)
+        torch.cuda.synchronize()
+        t0 = time.time()
+        api.kin_add(blk, L.GENO_PLINK_2BIT)
+        torch.cuda.synchronize()
+        t_kin += time.time() - t0
+        done += l
+        del blk
+    dist.barrier()
+    t0 = time.time()
+    ns = api.kin_end_keep(allreduce=True)
+    torch.cuda.synchronize()
+    t_all = time.time() - t0
+    prev_t = os.environ.get("GEMMA_HIP_EIGH_TIMING")
+    os.environ["GEMMA_HIP_EIGH_TIMING"] = "1"
+    t0 = time.time()
+    evh, trace = api.EigenDecomp_kept_K(n, None, sharded=True)
+    torch.cuda.synchronize()
+    t_eig = time.time() - t0
+    if prev_t is None:
+        os.environ.pop("GEMMA_HIP_EIGH_TIMING", None)
+    else:
+        os.environ["GEMMA_HIP_EIGH_TIMING"] = prev_t
+    import ctypes
+    t8 = (ctypes.c_double * 8)()
+    L.lib().gemma_hip_dbg_eigh_last(t8)
+    # phenotype: 50 causal SNPs + noise from a generator seeded alike on every rank; rank 0's rotation is the one that counts (below)
+    gc = torch.Generator(device=dev).manual_seed(args.seed + 77)
+    cb = synth_block(torch, n, 50, gc, dev)
+    codes = (cb.unsqueeze(2) >> torch.tensor([0, 2, 4, 6], device=dev, dtype=torch.uint8)) & 3
+    codes = codes.reshape(50, -1)[:, :n]
+    gv = torch.where(codes == 0, 2.0, torch.where(codes == 2, 1.0, 0.0)).to(torch.float64)
+    y = gv.T @ (torch.randn(50, dtype=torch.float64, device=dev, generator=gc) * 0.15)
+    y += torch.randn(n, dtype=torch.float64, device=dev, generator=gc) * y.std().clamp_min(1e-3)
+    UtWh = api.CalcUtX_kept(np.ones((n, 1)))
+    Utyh = api.CalcUtX_kept(y.cpu().numpy())
+    nm = api.CalcLambdaNull(evh, UtWh, Utyh, trace_G=trace)
+    UtW.copy_(torch.from_numpy(UtWh)); Uty.copy_(torch.from_numpy(Utyh))
+    null[0], null[1] = nm["l_mle_null"], nm["logl_mle_H0"]
+    torch.cuda.synchronize()
+    t0 = time.time()
+    gdist.broadcast_state_native([UtW, Uty, null])  # ONE ncclBroadcast: rank 0's rotated covariates / phenotype / null model
+    torch.cuda.synchronize()
+    t_bc = time.time() - t0
+    # the slowest rank's clocks beside rank 0's (one SUM all-reduce of a world x 4 table)
+    tab = torch.zeros((world, 4), dtype=torch.float64, device=dev)
+    tab[rank] = torch.tensor([t_kin, t_all, t_eig, t_bc], dtype=torch.float64, device=dev)
+    dist.all_reduce(tab, op=dist.ReduceOp.SUM)
+    tab = tab.cpu().numpy()
+    transport = api.comm_info()[2]
+    two = int(t8[7]) == 2
+    setup_info.update({
+        "flow": "every rank: kin_add of its %d-SNP share -> gemma_hip_kin_end_keep(allreduce=1) -> gemma_hip_eigh_kept_K_sharded -> "
+                "calc_utx_kept -> ONE broadcast of (UtW, Uty, null) -> lmm_setup_kept" % (hi - lo),
+        "kinship_s": round(t_kin, 3), "kinship_snps_per_rank": [int(gdist.shard_range(args.kin_snps, r, world)[1] -
+                                                                      gdist.shard_range(args.kin_snps, r, world)[0]) for r in range(world)],
+        "kinship_snps_all_ranks": int(ns),
+        "allreduce_s": round(t_all, 3),
+        "allreduce": "%s of the n^2 kinship sums + the SNP count, issued by libgemma_hip.so (gemma_hip_kin_end_keep); %.2f GB per rank"
+                     % ("ncclAllReduce" if transport == 1 else "shm test transport's all-reduce", 8.0 * n * n / 1e9),
+        "eigen_s": round(t_eig, 3),
+        "eigen": "gemma_hip_eigh_kept_K_sharded (%s)" % (
+            "two-stage; collective over %d ranks: reduction and divide & conquer on every rank, back-transformations shared out by "
+            "eigenvector, slices exchanged once" % world if two else "one-stage: replicated on every rank, nothing is exchanged"),
+        "eigen_stages_s": {"reduction": round(t8[0], 3), "bulge_chase": round(t8[1], 3), "divide_conquer": round(t8[2], 3),
+                           "backtransform_q2": round(t8[3], 3), "backtransform_q1": round(t8[4], 3), "sort_transpose": round(t8[5], 3)},
+        "broadcast_s": round(t_bc, 3),
+        "slowest_rank_s": {"kinship_s": round(float(tab[:, 0].max()), 3), "allreduce_s": round(float(tab[:, 1].max()), 3),
+                           "eigen_s": round(float(tab[:, 2].max()), 3), "broadcast_s": round(float(tab[:, 3].max()), 3)},
+        "null": {k: nm[k] for k in ("l_remle_null", "pve")}})
+    api.profile_read(L.STAGE_UTX_GEMM, reset=True)
+    return {"broadcast": ("native: ncclBroadcast from libgemma_hip.so's communicator" if transport == 1 else
+                          "native: libgemma_hip.so's communicator over its shm test transport (GEMMA_HIP_COMM=shm)") +
+                         "; (U, eval) from the collective eigensolver on the all-reduced kept K, not broadcast"}
+
+
 def main():
     args = parse()
     if args.child:
@@ -242,6 +337,11 @@ def main():
     if world > 1:
         want_native = os.environ.get("BENCH_DIST_BACKEND", "nccl") == "nccl" or os.environ.get("GEMMA_HIP_COMM", "") == "shm"
         native = bool(want_native and gdist.native_comm_init())
+        if want_native and not native:
+            # no silent fall-back: N ranks on N devices go through the library's own RCCL communicator or the
+            # run says why not.  BENCH_DIST_BACKEND=gloo (without GEMMA_HIP_COMM=shm) is the explicit torch.distributed-only route.
+            raise SystemExit("bench.py: the library's communicator (librccl via gemma_hip_comm_init) did not come up on all %d ranks; "
+                             "set BENCH_DIST_BACKEND=gloo to run the torch.distributed-only setup instead" % world)
     n, B = args.n, args.batch
     torch.manual_seed(args.seed + rank)
     gen = torch.Generator(device=dev).manual_seed(args.seed + 1000 * rank)
@@ -266,7 +366,14 @@ def main():
         del st
     sent_go = False
     shard_eig = False
-    if rank == 0 and not loaded:
+    multi_real = world > 1 and native and args.eigen in ("auto", "gemma") and not args.state_file
+    kept_state = None
+    if multi_real:
+        kept_state = setup_multi_rank(args, np, torch, dist, api, L, gdist, rank, world, dev, gen, n, B, setup_info, null, UtW, Uty)
+        shard_eig = True
+        del U  # (U, eval) are the library's kept buffers in this flow (gemma_hip_eigh_kept_K_sharded); nothing of them is a torch tensor
+        U = None
+    if rank == 0 and not loaded and not multi_real:
         # kinship_s / eigen_s are the LIBRARY's stages: the synthetic blocks (torch kernels, loaded lazily on their first use: seconds
         # on a box with a cold page cache) and the load of the library's own code object (first launch) stay outside the clocks
         wa = torch.ones((64, 64), dtype=torch.float64, device=dev)
@@ -446,7 +553,7 @@ def main():
         api.profile_read(L.STAGE_UTX_GEMM, reset=True)
         if args.state_file:
             torch.save({"U": U, "ev": ev, "UtW": UtW, "Uty": Uty, "null": null}, args.state_file)
-    if world > 1 and native:
+    if world > 1 and native and not multi_real:
         # do the other ranks take part in a collective decomposition?  (rank 0 decides: a loaded state file or --eigen torch say no)
         if rank == 0:
             if not sent_go:
@@ -464,7 +571,9 @@ def main():
     # the single broadcast round: ncclBroadcast issued by the library's own RCCL communicator (csrc/comm.hip.h) when every
     # rank could create it, otherwise the same two collectives through torch.distributed (nccl = RCCL as well)
     bpath = "none (1 rank)"
-    if world > 1:
+    if multi_real:
+        bpath = kept_state["broadcast"]
+    elif world > 1:
         if native:
             # after a collective decomposition U and eval are everywhere already: only the rotated covariates / phenotype and the
             # null model's two scalars travel
@@ -477,13 +586,17 @@ def main():
             gdist.broadcast_state([U, ev, UtW, Uty, null])
             bpath = "torch.distributed broadcast (%s)" % os.environ.get("BENCH_DIST_BACKEND", "nccl")
     torch.cuda.synchronize()
-    setup_info["broadcast_s"] = round(time.time() - t0, 3)
+    if not multi_real:
+        setup_info["broadcast_s"] = round(time.time() - t0, 3)
     setup_info["broadcast"] = bpath
 
     blocks = [synth_block(torch, n, B, gen, dev, miss=args.miss) for _ in range(args.steps + args.warmup)]
     out = torch.empty((B, 8), dtype=torch.float64, device=dev)
     lmm = api.LMM(a_mode=args.a_mode, l_mle_null=float(null[0]), logl_mle_H0=float(null[1]))
-    lmm.setup(U, ev, UtW, Uty, plink=True)
+    if multi_real:
+        lmm.setup_kept(UtW.cpu().numpy(), Uty.cpu().numpy(), plink=True)  # lmm_setup on the kept (U, eval): nothing crosses PCIe
+    else:
+        lmm.setup(U, ev, UtW, Uty, plink=True)
     torch.cuda.synchronize()
     setup_info["setup_total_s"] = round(time.time() - t_setup, 1)
 
@@ -506,7 +619,13 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    per_rank_s = [elapsed]
     if world > 1:
+        # every rank's own clock (one SUM all-reduce of a vector with one slot per rank), then the contract's MAX over ranks
+        tv = torch.zeros(world, dtype=torch.float64, device=dev)
+        tv[rank] = elapsed
+        dist.all_reduce(tv, op=dist.ReduceOp.SUM)
+        per_rank_s = [float(x) for x in tv.cpu()]
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt[0])
@@ -517,11 +636,13 @@ def main():
     res = out.cpu().numpy()
     n_nan = int(np.isnan(res[:, 4]).sum())
     i8_path = os.environ.get("GEMMA_HIP_UTX_I8", "1") != "0"
+    timed_kernel = api.last_utx_kernel()  # the matrix kernel the timed steps launched, as the library's launch site recorded it
 
     # the fp64 MFMA GEMM path on the same blocks, outside the contract's timed region (single GPU only)
     fp64_path = None
     if world == 1 and i8_path and args.fp64_steps > 0:
         os.environ["GEMMA_HIP_UTX_I8"] = "0"
+        api.reload_env()  # the library reads its switches once per setup, not per launch
         lmm.batch(blocks[0], L.GENO_PLINK_2BIT, out=out)
         torch.cuda.synchronize()
         api.profile_read(L.STAGE_UTX_GEMM, reset=True)
@@ -532,6 +653,7 @@ def main():
         el64 = time.perf_counter() - t1
         g64_ms, g64_n = api.profile_read(L.STAGE_UTX_GEMM)
         os.environ["GEMMA_HIP_UTX_I8"] = "1"
+        api.reload_env()
         g64_s = g64_ms * 1e-3 / max(1, g64_n)
         tf = 2.0 * B * n * n / g64_s / 1e12
         fp64_path = {"value": round(B * args.fp64_steps / el64, 1), "unit": "SNPs/s", "steps": args.fp64_steps,
@@ -591,9 +713,11 @@ def main():
         id_ms, _ = api.profile_read(L.STAGE_INGEST)
         res_i8 = outd.cpu().numpy().copy()
         os.environ["GEMMA_HIP_UTX_DOSAGE_I8"] = "0"
+        api.reload_env()
         lmm.batch(Xd[(args.dosage_steps - 1) % 2], L.GENO_F64_SNP_MAJOR, out=outd)
         torch.cuda.synchronize()
         os.environ.pop("GEMMA_HIP_UTX_DOSAGE_I8")
+        api.reload_env()
         res_64 = outd.cpu().numpy()
         okm = np.isfinite(res_i8) & np.isfinite(res_64) & (res_64 != 0)
         cols_used = {1: [0, 1, 4, 7], 2: [5, 7], 3: [0, 1, 6], 4: [0, 1, 4, 5, 6, 7], 9: [0, 1, 5, 6, 7]}[args.a_mode]
@@ -629,13 +753,11 @@ def main():
             L.lib().gemma_hip_dbg_i8_digits(n, ctypes.byref(dg))
             ops_per_launch = 2.0 * dg.value * 2.0 * B * n * n
             logical = ops_per_launch / gemm_avg_s / 1e12
-            smode = os.environ.get("GEMMA_HIP_I8_SPARSE", "2")[:1]
-            smode = smode if smode in ("0", "1", "2") else "2"
-            sparse = smode != "0"
-            rows16 = os.environ.get("GEMMA_HIP_I8_ROWS", "16").strip() != "32"
-            kfn = {"0": "i8gemm_packed_kernel", "1": "i8gemm_sparse_kernel",
-                   "2": "i8gemm_sparse2_r16_kernel (records kernel on v_mfma_i32_16x16x64_i8 + v_smfmac_i32_16x16x128_i8)" if rows16
-                        else "i8gemm_sparse2_kernel (32-row matrix instructions)"}[smode]
+            # the kernel's name comes from the library's launch site (gemma_hip_dbg_last_utx_kernel), not from the environment
+            kv = timed_kernel["variant"]
+            sparse = kv in (L.UTX_KERNEL_SPARSE_BYTES, L.UTX_KERNEL_RECORDS_R32, L.UTX_KERNEL_RECORDS_R16)
+            kfn = timed_kernel["name"] + {L.UTX_KERNEL_RECORDS_R16: " (records kernel on v_mfma_i32_16x16x64_i8 + v_smfmac_i32_16x16x128_i8)",
+                                          L.UTX_KERNEL_RECORDS_R32: " (records kernel on the 32-row matrix instructions)"}.get(kv, "")
             # With the mask product on the 2:4 sparse MFMA (csrc/i8gemm_sparse.hip.h) a pair of K-steps issues 8 dense + 4 sparse
             # matrix instructions instead of 16 dense ones, and a sparse instruction holds the pipe as long as a dense one
             # (profiles/r02_smfmac_i8_rate.txt): the pipe does 12/16 of the dense work.  `achieved` / `frac` price what the pipe
@@ -652,6 +774,7 @@ def main():
                             "takes the time of); logical_top_s = the 2 D products as written; the kernel is power-limited: with an all-zero digit "
                             "operand the 32-row kernel takes 38.65 ms where full-range digits take 55.95, the 16-row kernel 40.8 / 49.8 "
                             "(profiles/r04_i8_operand_value_power.txt, r04_i8_g16s_prototype.txt, DESIGN 3.1c)" if sparse else "dense int8 MFMA",
+                    "kernel_symbol": timed_kernel["name"], "kernel_variant": {k: timed_kernel[k] for k in ("variant", "rows", "digits", "fuse", "raster")},
                     "traffic": None, "launches": gemm_n, "launches_per_step": gemm_launches_per_step,
                     "avg_launch_ms": round(gemm_ms / max(1, gemm_n), 3), "ms_per_step": round(gemm_avg_s * 1e3, 3),
                     # the same launch priced as the fp64 product it replaces (2 n^2 flop per SNP)
@@ -677,6 +800,12 @@ def main():
                                        "configs[2] (headline): " if (n == 20000 and args.a_mode == 1) else "", n, args.a_mode, B, 100.0 * args.miss),
                        "n": n, "snps_per_step": B, "kinship_snps": args.kin_snps, "parallelism": "snp-shard x%d" % world,
                        "device": name, "cus": n_cu, "utx_path": "int8-digit" if i8_path else "fp64-gemm",
+                       "ranks_seen": sum(1 for x in per_rank_s if x > 0),
+                       "per_rank": {"seconds": [round(x, 4) for x in per_rank_s],
+                                    "value": [round(B * args.steps / x, 1) if x > 0 else None for x in per_rank_s], "unit": "SNPs/s"},
+                       "comm": (dict(zip(("rank", "world", "transport"), api.comm_info()),
+                                     transport_names={"0": "none", "1": "RCCL (librccl, ncclAllReduce / ncclBroadcast)",
+                                                      "2": "shm test transport (GEMMA_HIP_COMM=shm)"}) if world > 1 else None),
                        "setup": setup_info, "nan_p_wald": n_nan},
             "roofline": roof,
             "roofline_assoc": {"kernel": "per-SNP stage: fixed-lambda table + bracket scan + interval series tables (fp64 MFMA) + series-driven "
@@ -710,12 +839,14 @@ def main():
             xchg = 8.0 * n * n / 153e9
             eig_proj = {str(N): round(serial + other + bt / N + (xchg if N > 1 else 0.0), 3) for N in (1, 2, 4, 8)}
         eig_note = "eigendecomposition runs on one GPU (replicas only for that stage); ranks idle during it"
+        if multi_real:
+            setup_once = sum(float(setup_info.get(k) or 0.0) for k in ("kinship_s", "allreduce_s", "eigen_s", "broadcast_s"))
         if shard_eig:
             eig_note = ("eigendecomposition is a collective (gemma_hip_eigh_sharded_d): reduction + divide & conquer on every rank, the "
                         "back-transformations shared out by eigenvector; eigen_s above was measured with %d rank(s)" % world)
         line["amdahl"] = {
             "p_total": p_cfg, "setup_once_s": round(setup_once, 3),
-            "setup_terms_s": {k: setup_info.get(k) for k in ("kinship_s", "eigen_s", "broadcast_s")},
+            "setup_terms_s": {k: setup_info.get(k) for k in ("kinship_s", "allreduce_s", "eigen_s", "broadcast_s")},
             "kinship_note": "kinship_s covers %d SNPs here; over all p SNPs it shards with the SNPs (one ncclAllReduce of n^2 sums)" % args.kin_snps,
             "assoc_s_per_rank": {str(N): round(p_cfg / N / per_gpu, 3) for N in (1, 2, 4, 8)},
             "projected_total_s": {str(N): round(setup_once + p_cfg / N / per_gpu, 3) for N in (1, 2, 4, 8)},
@@ -741,10 +872,20 @@ def main():
                     line["roofline"]["traffic_source"] = line["roofline_assoc"]["traffic_source"] = \
                         "static profile: profiles/pmc_traffic.json (rocprofv3 --pmc passes, %s)" % pj.get("collected", "round 1")
                     line["roofline_assoc"]["traffic"] = pj.get("assoc_hbm_bytes_per_launch")
-                    line["roofline"]["traffic"] = pj.get("i8gemm_hbm_bytes_per_launch" if i8_path
-                                                         else "utx_gemm_hbm_bytes_per_launch")
-                    if i8_path and pj.get("i8gemm_note"):
-                        line["roofline"]["traffic_note"] = pj["i8gemm_note"]
+                    # counters of ANOTHER kernel are not this kernel's traffic: the file names the kernel its passes instrumented
+                    # and the library names the one the timed steps launched -- they must agree
+                    counted = str(pj.get("i8gemm_kernel", "")).split("::")[-1].split("(")[0].strip()
+                    if not i8_path:
+                        line["roofline"]["traffic"] = pj.get("utx_gemm_hbm_bytes_per_launch")
+                    elif counted == timed_kernel["name"]:
+                        line["roofline"]["traffic"] = pj.get("i8gemm_hbm_bytes_per_launch")
+                        line["roofline"]["traffic_kernel"] = pj.get("i8gemm_kernel")
+                        if pj.get("i8gemm_note"):
+                            line["roofline"]["traffic_note"] = pj["i8gemm_note"]
+                    else:
+                        line["roofline"]["traffic"] = None
+                        line["roofline"]["traffic_source"] = ("refused: profiles/pmc_traffic.json holds the counters of %r, the timed steps "
+                                                              "launched %r" % (pj.get("i8gemm_kernel"), timed_kernel["name"]))
                     if fp64_path:
                         fp64_path["roofline"]["traffic"] = pj.get("utx_gemm_hbm_bytes_per_launch")
             except Exception:
@@ -799,6 +940,7 @@ def main():
             except Exception as e:
                 line["digits7_leg"] = {"error": repr(e)[:300]}
             os.environ.pop("GEMMA_HIP_I8_DIGITS", None)
+            api.reload_env()
         if world == 1 and i8_path and args.lowh2_leg > 0 and args.a_mode in (1, 4):
             # The same trait on a kinship measured in other units: eigenvalues times S moves every lambda-hat to lambda-hat / S
             # (only lambda * delta enters the likelihood), so with S = lambda_null / lambda0 the brackets of the whole block sit

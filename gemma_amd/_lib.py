@@ -23,6 +23,7 @@ SYMBOLS = [
     "gemma_hip_kept_bcast", "gemma_hip_kept_U_get", "gemma_hip_calc_utx_kept", "gemma_hip_lmm_setup_kept", "gemma_hip_kept_release",
     "gemma_hip_comm_unique_id", "gemma_hip_comm_init", "gemma_hip_comm_info", "gemma_hip_comm_bcast_d",
     "gemma_hip_comm_allreduce_sum_d", "gemma_hip_comm_finalize", "gemma_hip_dbg_i8_digits", "gemma_hip_dbg_last_utx_path", "gemma_hip_lmm_batch_submit", "gemma_hip_lmm_batch_collect",
+    "gemma_hip_dbg_last_utx_kernel", "gemma_hip_reload_env",
 ]
 COMM_ID_BYTES = 128
 
@@ -40,6 +41,16 @@ class LmmCfg(C.Structure):
     _fields_ = [("a_mode", C.c_int), ("n", C.c_size_t), ("n_cvt", C.c_size_t), ("l_min", C.c_double),
                 ("l_max", C.c_double), ("n_region", C.c_size_t), ("l_mle_null", C.c_double),
                 ("logl_mle_H0", C.c_double), ("plink_nan_rule", C.c_int)]
+
+
+class UtxKernelInfo(C.Structure):
+    """gemma_utx_kernel_info: the matrix kernel the last U^T x launched, as the library's launch site recorded it"""
+    _fields_ = [("variant", C.c_int), ("rows", C.c_int), ("digits", C.c_int), ("fuse", C.c_int), ("raster", C.c_int),
+                ("launches", C.c_long), ("name", C.c_char * 64)]
+
+
+UTX_KERNEL_DGEMM_F64, UTX_KERNEL_DENSE_I8, UTX_KERNEL_SPARSE_BYTES, UTX_KERNEL_RECORDS_R32, UTX_KERNEL_RECORDS_R16, \
+    UTX_KERNEL_DOSAGE_I8 = range(6)
 
 
 class QcCfg(C.Structure):
@@ -146,6 +157,8 @@ def lib():
     L.gemma_hip_lmm_setup_kept.argtypes = [C.POINTER(LmmCfg), dp, dp]
     L.gemma_hip_dbg_i8_digits.argtypes = [sz, C.POINTER(ci)]
     L.gemma_hip_dbg_last_utx_path.argtypes = [C.POINTER(ci)]
+    L.gemma_hip_dbg_last_utx_kernel.argtypes = [C.POINTER(UtxKernelInfo)]
+    L.gemma_hip_reload_env.argtypes = []
     L.gemma_hip_lmm_batch_submit.argtypes = [ci, vp, sz, sz]
     L.gemma_hip_lmm_batch_collect.argtypes = [vp, C.POINTER(sz)]
     L.gemma_hip_comm_unique_id.argtypes = [vp]

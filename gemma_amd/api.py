@@ -92,6 +92,20 @@ def last_utx_path():
     return p.value
 
 
+def last_utx_kernel():
+    """The matrix kernel the last U^T x launched (gemma_hip_dbg_last_utx_kernel): dict(variant, rows, digits, fuse, raster,
+    launches, name) -- name is the kernel symbol as rocprofv3 prints it."""
+    k = L.UtxKernelInfo()
+    L.check(L.lib().gemma_hip_dbg_last_utx_kernel(C.byref(k)), "dbg_last_utx_kernel")
+    return {"variant": k.variant, "rows": k.rows, "digits": k.digits, "fuse": k.fuse, "raster": k.raster,
+            "launches": k.launches, "name": k.name.decode()}
+
+
+def reload_env():
+    """Have the library re-read its GEMMA_HIP_* switches (it reads them once per setup, never per launch)."""
+    L.check(L.lib().gemma_hip_reload_env(), "reload_env")
+
+
 # ----------------------------------------------------------------------------- B2
 def fast_dgemm(TransA, TransB, alpha, A, B, beta, Cm):
     """C = alpha*op(A)*op(B) + beta*C (row-major).  Shape mismatch -> GemmaHipError(EINVAL), the
@@ -199,6 +213,49 @@ def kin_end(K=None):
     else:
         L.check(L.lib().gemma_hip_kin_end(_ptr(K) if K is not None else None, C.byref(ns)), "kin_end")
     return ns.value
+
+
+# ---- the device-resident chain (include/gemma_hip.h "kept"): K, U, eval never leave the device; with a communicator of several
+# ranks kin_end_keep(allreduce=True) is the ONE ncclAllReduce of the SNP-sharded kinship and EigenDecomp_kept_K(sharded=True) the
+# collective decomposition -- the flow of tests/cpp/gemma_file_driver.cpp -gpus N and of bench.py --gpus N
+def kin_end_keep(allreduce=False):
+    """Ends kin_begin / kin_add and KEEPS K on the device; allreduce: sum the ranks' partial kinships first (every rank then holds
+    the kinship of all SNPs).  Returns the SNP count (of all ranks with allreduce)."""
+    ns = C.c_size_t()
+    L.check(L.lib().gemma_hip_kin_end_keep(C.byref(ns), 1 if allreduce else 0), "kin_end_keep")
+    return ns.value
+
+
+def EigenDecomp_kept_K(ni_total, indicator_idv=None, sharded=False):
+    """Sub-select (ReadFile_kin's indicator), CenterMatrix, EigenDecomp_Zeroed of the kept K, all on the device; U and eval stay
+    there (lmm setup_kept / CalcUtX_kept use them).  sharded: the collective form (every rank holds the same kept K).  Returns
+    (eval numpy, trace_G)."""
+    ind = None if indicator_idv is None else np.ascontiguousarray(indicator_idv, dtype=np.int32)
+    n = int(ni_total if ind is None else int((ind != 0).sum()))
+    ev = np.zeros(n)
+    tr = C.c_double()
+    fn = L.lib().gemma_hip_eigh_kept_K_sharded if sharded else L.lib().gemma_hip_eigh_kept_K
+    L.check(fn(_ptr(ind) if ind is not None else None, ni_total, _ptr(ev), C.byref(tr)), "EigenDecomp_kept_K")
+    return ev, tr.value
+
+
+def CalcUtX_kept(X):
+    """U^T X on the kept U (host X: n x m or n,; returns numpy of the same shape)."""
+    X2 = np.ascontiguousarray(np.asarray(X, dtype=np.float64).reshape(len(X), -1))
+    out = np.zeros_like(X2)
+    L.check(L.lib().gemma_hip_calc_utx_kept(_ptr(X2), X2.shape[0], X2.shape[1], _ptr(out)), "CalcUtX_kept")
+    return out.reshape(np.asarray(X).shape)
+
+
+def kept_release():
+    L.check(L.lib().gemma_hip_kept_release(), "kept_release")
+
+
+def comm_info():
+    """(rank, world, transport) of the library's communicator: transport 0 none, 1 RCCL, 2 the shm test transport."""
+    r, w, t = C.c_int(), C.c_int(), C.c_int()
+    L.check(L.lib().gemma_hip_comm_info(C.byref(r), C.byref(w), C.byref(t)), "comm_info")
+    return r.value, w.value, t.value
 
 
 def CalcKin(geno, geno_kind, n_total, k_mode=1, batch=K_BATCH_SIZE):
@@ -329,6 +386,16 @@ class LMM:
             rc = L.lib().gemma_hip_lmm_setup(C.byref(cfg), _ptr(U_c), _ptr(ev_c), _ptr(UtW), _ptr(Uty_c))
         L.check(rc, "LMM.setup")
         self.ni_test, self.n_cvt = n, c
+        self._active = True
+
+    def setup_kept(self, UtW, Uty, plink=False):
+        """lmm_setup on the kept (U, eval) of EigenDecomp_kept_K (host UtW n x c, Uty n)."""
+        n = len(Uty)
+        UtW = np.ascontiguousarray(UtW, dtype=np.float64).reshape(n, -1)
+        Uty_c = np.ascontiguousarray(Uty, dtype=np.float64)
+        cfg = self._cfg(n, UtW.shape[1], plink)
+        L.check(L.lib().gemma_hip_lmm_setup_kept(C.byref(cfg), _ptr(UtW), _ptr(Uty_c)), "LMM.setup_kept")
+        self.ni_test, self.n_cvt = n, UtW.shape[1]
         self._active = True
 
     def set_indicator(self, indicator_idv):
@@ -552,7 +619,7 @@ class MVLMM:
         UtW = np.ascontiguousarray(UtW, dtype=np.float64).reshape(n, -1)
         if env is not None:
             env = np.ascontiguousarray(env, dtype=np.float64)
-            Ute = np.ascontiguousarray(U, dtype=np.float64).T @ env  # gsl_blas_dgemv(CblasTrans, U, env), :4047
+            Ute = CalcUtX(np.ascontiguousarray(U, dtype=np.float64), env)  # gsl_blas_dgemv(CblasTrans, U, env), :4047 -- on the library's GEMM
             self.fit_null(eval_, np.column_stack([UtW, Ute]), UtY)
         else:
             self.fit_null(eval_, UtW, UtY)

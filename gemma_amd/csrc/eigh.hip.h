@@ -1095,13 +1095,35 @@ static inline bool eig_two_stage(long n) {
   return n >= 8000; // round 4: with the panel in one launch and the pipelined chase n = 8192 takes 0.48 s two-stage, 0.52 s one-stage
 }
 
+// The order the core runs at: an odd n >= 192 is embedded in n + 1 (eigh_device) unless GEMMA_HIP_EIGH_PAD=0.
+static inline long eig_effective_n(long n) {
+  const char *ep = getenv("GEMMA_HIP_EIGH_PAD");
+  return ((n & 1) == 0 || n < 192 || (ep && ep[0] == '0')) ? n : n + 1;
+}
+// a rank of a collective solve that cannot even start -- it failed to allocate its copy of the matrix, its padded copy,
+// its slot of the kept (U, eval) -- must not leave the others waiting in the core's first all-reduce.  It takes part in exactly
+// that agreement (eigh_device_core: anyone_failed(!ok), one all-reduce of one double) with "failed", so that every rank returns an
+// error.  n = the caller's order; no-op where the solve at that order exchanges nothing (one-stage: replicas).
+static inline void eigh_collective_abort(long n, hipStream_t s, const EighShard *sh) {
+  if (!(sh && sh->world > 1 && sh->bcast && sh->allreduce_sum) || !eig_two_stage(eig_effective_n(n))) return;
+  double *d = nullptr;
+  if (hipMalloc(reinterpret_cast<void **>(&d), 16) != hipSuccess) {
+    (void)hipGetLastError();
+    return; // cannot take part (16 bytes refused): the others' collective times out -- the end anyway
+  }
+  const double v = 1.0;
+  if (hipMemcpyAsync(d, &v, 8, hipMemcpyHostToDevice, s) == hipSuccess) (void)sh->allreduce_sum(sh->ctx, d, 1, s);
+  (void)hipStreamSynchronize(s);
+  (void)hipFree(d);
+}
+
 // Several ranks, one decomposition (round 4).  The eigenvectors are independent through both back-transformations
 // (a row of Z^T never meets another row), and those are 0.8 of 2.3 s at n = 20 000 and 10 of 19 s at n = 50 000.  Every rank
 // runs the reduction and the divide & conquer on its own copy of the matrix -- the same code on the same bits: the results
 // agree bit for bit, which is CHECKED (a hash of the tridiagonal matrix and of the eigenvalues is compared with rank 0's; on
 // any difference rank 0 alone finishes and broadcasts U) --, applies Q2 and Q1 to its own slice of Z^T (whole 64-row blocks),
 // and the slices travel once (one broadcast per rank: an all-gather on the library's two collectives).  One-stage solves
-// (n < 14 000) are replicated whole: nothing to send.
+// (n < 8 000) are replicated whole: nothing to send.
 static double g_eig_last[8] = {0, 0, 0, 0, 0, 0, 0, 0}; // stage seconds of the last solve with GEMMA_HIP_EIGH_TIMING=1
 static inline unsigned long long eig_fnv(unsigned long long h, const void *p, size_t bytes) {
   const unsigned char *c = static_cast<const unsigned char *>(p);
@@ -1174,6 +1196,7 @@ static inline int eigh_device_core(double *G, long n, double *U, double *eval, h
   }
   int rc = 0;
   bool reached_agreement = false;
+  bool fallback_pending = false; // root-only fall-back: the agreement before its broadcasts is still owed by this rank
   std::vector<double> hd(n), he(std::max<long>(n - 1, 1)), dphys;
   double *Z = nullptr;
   const char *tenv = getenv("GEMMA_HIP_EIGH_TIMING");
@@ -1266,6 +1289,7 @@ static inline int eigh_device_core(double *G, long n, double *U, double *eval, h
         sharded = true;
       } else {
         root_only = true; // rank 0 finishes alone and broadcasts (U, eval)
+        fallback_pending = true;
       }
     }
     if (two) {
@@ -1276,6 +1300,10 @@ static inline int eigh_device_core(double *G, long n, double *U, double *eval, h
       }
     } else {
       rc = eig_backtransform(Z, n, ws, s, msg);
+    }
+    if (root_only && sh->rank == 0) {
+      const char *eff = getenv("GEMMA_HIP_EIGH_FAIL_FALLBACK"); // tests: rank 0 fails in the fall-back it runs alone
+      if (eff && eff[0] == '1') { msg = "failure injected into the root-only fall-back (GEMMA_HIP_EIGH_FAIL_FALLBACK)"; rc = 4; }
     }
     if (sharded) {
       // every rank tells the others how its slice went before anybody waits for it
@@ -1305,7 +1333,14 @@ static inline int eigh_device_core(double *G, long n, double *U, double *eval, h
       fprintf(stderr, "gemma_hip_eigh n=%ld: rank %d of %d back-transformed rows %ld .. %ld of Z^T\n", n, sh->rank, sh->world, row0,
               row0 + rows);
     if (root_only && sh->rank != 0) {
-      // rank 0's result arrives as it is (U, then eval)
+      // rank 0's result arrives as it is (U, then eval) -- once rank 0 has said that it HAS one (a rank 0 that failed in its
+      // back-transformation left the loop before its broadcasts and the others waited for ever)
+      fallback_pending = false;
+      if (anyone_failed(false)) {
+        msg = "sharded back-transformation: rank 0 failed in the fall-back";
+        rc = 4;
+        break;
+      }
       if (sh->bcast(sh->ctx, U, nn * 8, 0, s) || sh->bcast(sh->ctx, eval, (size_t)n * 8, 0, s) || hipStreamSynchronize(s) != hipSuccess) {
         msg = "sharded back-transformation: fall-back broadcast failed";
         rc = 4;
@@ -1333,6 +1368,13 @@ static inline int eigh_device_core(double *G, long n, double *U, double *eval, h
       msg = "final transpose failed";
       rc = 4;
     }
+    if (root_only) {
+      fallback_pending = false;
+      if (anyone_failed(rc != 0)) {
+        if (!rc) { msg = "sharded back-transformation: fall-back agreement failed"; rc = 4; }
+        break;
+      }
+    }
     if (!rc && root_only && (sh->bcast(sh->ctx, U, nn * 8, 0, s) || sh->bcast(sh->ctx, eval, (size_t)n * 8, 0, s) ||
                              hipStreamSynchronize(s) != hipSuccess)) {
       msg = "sharded back-transformation: fall-back broadcast failed";
@@ -1340,6 +1382,7 @@ static inline int eigh_device_core(double *G, long n, double *U, double *eval, h
     }
   } while (0);
   if (coll && !reached_agreement) (void)anyone_failed(true); // left the loop before the agreement: tell the others
+  if (coll && fallback_pending) (void)anyone_failed(true);   // rank 0 left the fall-back before its broadcasts: the others are told
   if (agree_d) (void)hipFree(agree_d);
   (void)hipStreamSynchronize(s);
   if (timing && rc == 0 && n > 1) {
@@ -1398,6 +1441,13 @@ static inline int eigh_device(double *G, long n, double *U, double *eval, hipStr
       hipMalloc(reinterpret_cast<void **>(&evp), (size_t)m * 8) != hipSuccess) {
     (void)hipGetLastError();
     cleanup();
+    if (sh && sh->world > 1 && eig_two_stage(m)) {
+      // a collective solve: the other ranks run the padded, two-stage, exchanging form -- this rank cannot quietly take the
+      // replicated odd-n path instead.  It reports the failure through the core's first agreement.
+      eigh_collective_abort(n, s, sh);
+      msg = "cannot allocate the padded copy of an odd-order matrix in a collective solve";
+      return 3;
+    }
     return eigh_device_core(G, n, U, eval, s, msg, sh); // not enough room for the padded copy: the slower unaligned path
   }
   std::vector<double> hdiag((size_t)n);

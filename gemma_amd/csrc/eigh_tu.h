@@ -22,6 +22,11 @@ struct EighShard {
 // With sh (world > 1) the call is a COLLECTIVE: every rank passes the same matrix and receives the same (U, eval).
 int eigh_device_x(double *G, long n, double *U, double *eval, hipStream_t s, std::string &msg, const EighShard *sh = nullptr);
 
+// A rank that fails BEFORE eigh_device_x in a collective solve of order n (its own allocations) calls this instead: it takes part in
+// the solver's first agreement with "failed", so that the other ranks return an error instead of waiting (no-op where a solve of
+// that order exchanges nothing).
+void eigh_abort_x(long n, hipStream_t s, const EighShard *sh);
+
 // stage diagnostics behind gemma_hip_dbg_tridiag / _dbg_eigh2 / _dbg_stedc (host pointers; tests/test_gpu_eigh.py)
 int dbg_tridiag_x(const double *G, size_t n, double *d, double *e, double *tau, double *VT, std::string &msg);
 int dbg_eigh2_x(const double *G, size_t n, double *band, double *d, double *e, std::string &msg);

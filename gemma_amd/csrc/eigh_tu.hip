@@ -35,6 +35,8 @@ int eigh_device_x(double *G, long n, double *U, double *eval, hipStream_t s, std
   return eigh_device(G, n, U, eval, s, msg, sh);
 }
 
+void eigh_abort_x(long n, hipStream_t s, const EighShard *sh) { eigh_collective_abort(n, s, sh); }
+
 void eigh_last_stages(double *t8) {
   for (int i = 0; i < 8; ++i) t8[i] = g_eig_last[i];
 }

@@ -60,8 +60,70 @@ struct StageProf {
   long launches = 0;
 };
 
+// Environment switches of the batch path.  Read ONCE per setup -- gemma_hip_init, every lmm_setup* / lm_setup / mvlmm_set,
+// kin_begin and gemma_hip_reload_env -- never on a launch path (a getenv per launch walks the whole environment block under
+// libc's lock; round 4 had three of them on every records-kernel launch).  Tests and bench legs that flip a switch between
+// two batches of one setup call gemma_hip_reload_env().
+struct Knobs {
+  int utx_i8 = 1;          // GEMMA_HIP_UTX_I8: 1 = hard-call batches through the exact int8-digit product, 0 = always the fp64 GEMM
+  int i8_digits = 0;       // GEMMA_HIP_I8_DIGITS: 6 | 7 forces the digit count (0: by n)
+  int i8_sparse = 2;       // GEMMA_HIP_I8_SPARSE: 0 dense mask product, 1 sparse MFMA on byte genotypes, 2 records kernel
+  int i8_fuse = 1;         // GEMMA_HIP_I8_FUSE: 0 = one int32 plane per digit
+  int i8_gm = 0;           // GEMMA_HIP_I8_GM: tile rows per L2 patch of the non-rastered launch
+  int i8_raster = S2_DEFAULT_RASTER; // GEMMA_HIP_I8_RASTER
+  int i8_rows = 16;        // GEMMA_HIP_I8_ROWS: 32 = the records kernel on the 32-row matrix instructions
+  int dosage_i8 = 1;       // GEMMA_HIP_UTX_DOSAGE_I8
+  int overlap = 0;         // GEMMA_HIP_OVERLAP
+  int overlap_chunks = 4;  // GEMMA_HIP_OVERLAP_CHUNKS
+  int table_v2 = 1;        // GEMMA_HIP_TABLE_V2
+  int table_pf = 0;        // GEMMA_HIP_TABLE_PF
+  int force_generic = 0;   // GEMMA_HIP_FORCE_GENERIC
+  int assoc_variant = 44;  // GEMMA_HIP_ASSOC_VARIANT
+  int mvlmm_rt = 0;        // GEMMA_HIP_MVLMM_RT
+  int kin_i8 = 1, kin_upper = 1, kin_lists = 1, kin_lists_oom = 0; // GEMMA_HIP_KIN_I8 / _UPPER / _LISTS / _LISTS_OOM
+  long long kin_list_cap = 0;                                       // GEMMA_HIP_KIN_LIST_CAP (0: by block size)
+  static int geti(const char *name, int dflt) {
+    const char *e = getenv(name);
+    return (e && *e) ? atoi(e) : dflt;
+  }
+  void load() {
+    utx_i8 = geti("GEMMA_HIP_UTX_I8", 1);
+    const int dg = geti("GEMMA_HIP_I8_DIGITS", 0);
+    i8_digits = (dg == 6 || dg == 7) ? dg : 0;
+    const char *es = getenv("GEMMA_HIP_I8_SPARSE");
+    i8_sparse = (es && es[0] >= '0' && es[0] <= '2') ? es[0] - '0' : 2;
+    const char *ef = getenv("GEMMA_HIP_I8_FUSE");
+    i8_fuse = (ef && ef[0] == '0') ? 0 : 1;
+    i8_gm = geti("GEMMA_HIP_I8_GM", 0);
+    i8_raster = geti("GEMMA_HIP_I8_RASTER", S2_DEFAULT_RASTER);
+    i8_rows = geti("GEMMA_HIP_I8_ROWS", 16) == 32 ? 32 : 16;
+    const char *ed = getenv("GEMMA_HIP_UTX_DOSAGE_I8");
+    dosage_i8 = (ed && ed[0] == '0') ? 0 : 1;
+    const char *eo = getenv("GEMMA_HIP_OVERLAP");
+    overlap = (eo && eo[0] == '1') ? 1 : 0;
+    overlap_chunks = geti("GEMMA_HIP_OVERLAP_CHUNKS", 4);
+    const char *et = getenv("GEMMA_HIP_TABLE_V2");
+    table_v2 = (et && et[0] == '0') ? 0 : 1;
+    const char *ep = getenv("GEMMA_HIP_TABLE_PF");
+    table_pf = (ep && ep[0] == '1') ? 1 : 0;
+    const char *eg = getenv("GEMMA_HIP_FORCE_GENERIC");
+    force_generic = (eg && eg[0] == '1') ? 1 : 0;
+    assoc_variant = geti("GEMMA_HIP_ASSOC_VARIANT", 44);
+    const char *er = getenv("GEMMA_HIP_MVLMM_RT");
+    mvlmm_rt = (er && er[0] == '1') ? 1 : 0;
+    const char *k1 = getenv("GEMMA_HIP_KIN_I8"), *k2 = getenv("GEMMA_HIP_KIN_UPPER"), *k3 = getenv("GEMMA_HIP_KIN_LISTS");
+    const char *k4 = getenv("GEMMA_HIP_KIN_LISTS_OOM"), *k5 = getenv("GEMMA_HIP_KIN_LIST_CAP");
+    kin_i8 = (k1 && k1[0] == '0') ? 0 : 1;
+    kin_upper = (k2 && k2[0] == '0') ? 0 : 1;
+    kin_lists = (k3 && k3[0] == '0') ? 0 : 1;
+    kin_lists_oom = (k4 && k4[0] == '1') ? 1 : 0;
+    kin_list_cap = (k5 && *k5) ? atoll(k5) : 0;
+  }
+};
+
 struct Ctx {
   bool inited = false;
+  Knobs knobs;
   int device = -1;
   int verbose = 0;
   std::string last_error;
@@ -112,12 +174,22 @@ struct Ctx {
   MvArgs mv_proto;
   DevBuf i8_Bt, i8_ej, i8_cmax, i8_A, i8_C, i8_mean; // exact int8-digit U^T x (i8gemm.hip.h)
   unsigned long long cheb_qmask = 0; // bit k: tabulated interval k is in Q form (ends at or below lambda = 1e-3)
-  DevBuf i8_raster;            // (tile_m, tile_n) per workgroup of the records kernel: the cross-XCD raster (i8gemm_sparse2.hip.h)
-  int i8_raster_tm = 0, i8_raster_tn = 0, i8_raster_rb = 0;
+  // (tile_m, tile_n) per workgroup of the records kernel: the cross-XCD raster (i8gemm_sparse2.hip.h).  One map per launch shape,
+  // each in its OWN buffer, built once (a block cut into row chunks has two shapes -- full chunks and the last one -- and
+  // a single slot was rebuilt, with a stream synchronisation and a blocking copy, twice per batch; a map in use by a kernel on
+  // another stream could be overwritten).  The host copy stays alive for the asynchronous upload.
+  struct RasterSlot {
+    DevBuf dev;
+    std::vector<int2> host;
+    int tm = 0, tn = 0, rb = 0, xcds = 8;
+    unsigned long long used = 0;
+  } i8_raster[6];
+  unsigned long long i8_raster_clock = 0;
   DevBuf i8_surlist;           // per row: count + up to SUR_MAX individuals the sparse mask operand dropped
   DevBuf i8_colsum;            // column sums of U from its digit planes (fixed-point dosage path)
   bool i8_colsum_ready = false;
   int last_utx_path = 0;       // what the last U^T x took: 0 fp64 GEMM, 1 int8 hard calls, 2 int8 dosages k/100, 3 int8 dosages k/1000
+  gemma_utx_kernel_info last_utx_kernel = {}; // the matrix kernel that product launched (gemma_hip_dbg_last_utx_kernel)
   bool i8_ready = false;
   size_t i8_ldk = 0, i8_npad = 0;
   int i8_digits = I8_DIGITS;
@@ -220,6 +292,14 @@ inline hipStream_t S(void *s) { return reinterpret_cast<hipStream_t>(s); }
 } // namespace
 
 static void pipe_release(); // pipelined host-block path, defined with lmm_batch_submit
+static void raster_release() {
+  for (auto &r : g_ctx.i8_raster) {
+    r.dev.release();
+    r.host.clear();
+    r.tm = r.tn = r.rb = 0;
+    r.used = 0;
+  }
+}
 static void kin_i8_release(); // integer kinship path, defined with kin_begin
 
 // ------------------------------------------------------------------------------ lifetime
@@ -259,6 +339,7 @@ extern "C" int gemma_hip_init(int device, int verbose) {
                 g_ctx.prop.gcnArchName);
   g_ctx.device = cur;
   g_ctx.inited = true;
+  g_ctx.knobs.load();
   gemm_aux_init();
   if (verbose)
     fprintf(stderr, "gemma_hip: device %d %s (%s), %d CUs, %.1f GB\n", cur, g_ctx.prop.name,
@@ -277,7 +358,9 @@ extern "C" void gemma_hip_shutdown(void) {
   g_ctx.UtWt.release(); g_ctx.idx_map.release(); g_ctx.X.release(); g_ctx.UtX.release();
   g_ctx.stage_in.release(); g_ctx.stage_out.release(); g_ctx.carry.release(); g_ctx.scratch.release();
   g_ctx.i8_Bt.release(); g_ctx.i8_ej.release(); g_ctx.i8_cmax.release(); g_ctx.i8_A.release(); g_ctx.i8_C.release();
-  g_ctx.i8_raster.release(); g_ctx.i8_raster_tm = g_ctx.i8_raster_tn = g_ctx.i8_raster_rb = 0;
+  raster_release();
+  g_ctx.mv_Yt.release(); g_ctx.mv_out.release(); g_ctx.mv_scratch.release(); // shutdown without lmm_finish leaked these
+  g_ctx.mv_ready = g_ctx.mv_gxe = false;
   g_ctx.i8_mean.release(); g_ctx.i8_meta.release(); g_ctx.i8_rowsur.release(); g_ctx.i8_colsum.release(); g_ctx.i8_surlist.release();
   g_ctx.i8_ready = g_ctx.i8_colsum_ready = false;
   g_ctx.table_P.release(); g_ctx.U_even.release();
@@ -401,8 +484,8 @@ extern "C" int gemma_hip_kin_begin(size_t n_total, int k_mode) {
   g_ctx.kin_ns = 0;
   // -gk 1 on PLINK 2-bit blocks: G^T G as an exact int8 product + a sparse pass over the missing calls (kin_i8.hip.h);
   // GEMMA_HIP_KIN_I8=0 keeps every block on the fp64 SYRK
-  const char *e = getenv("GEMMA_HIP_KIN_I8");
-  g_ctx.kin_i8 = (k_mode == 1) && !(e && e[0] == '0');
+  g_ctx.knobs.load();
+  g_ctx.kin_i8 = (k_mode == 1) && g_ctx.knobs.kin_i8;
   g_ctx.kin_i8_used = false;
   return GEMMA_HIP_OK;
 }
@@ -492,8 +575,7 @@ static int kin_add_i8(const void *geno, size_t l, size_t ld, hipStream_t s) {
     {
       // the product is symmetric and kin_i8_fold_kernel reads its upper triangle only: the tiles below it are not formed
       // (GEMMA_HIP_KIN_UPPER=0: all of them, as in round 2)
-      const char *eu = getenv("GEMMA_HIP_KIN_UPPER");
-      if (!(eu && eu[0] == '0')) {
+      if (g_ctx.knobs.kin_upper) {
         if (int rc = kin_i8_tile_map(g.tiles_m, g.tiles_n)) return rc;
         g.tile_map = g_ctx.kin_tmap.as<int>();
         ntiles = (unsigned)g_ctx.kin_tmap_count;
@@ -511,17 +593,15 @@ static int kin_add_i8(const void *geno, size_t l, size_t ld, hipStream_t s) {
     c.lists_ok = nullptr;
     // the correction on lists of the missing calls (kin_i8.hip.h, round 3); GEMMA_HIP_KIN_LISTS=0 keeps the round-2 kernel,
     // GEMMA_HIP_KIN_LIST_CAP=<entries> overrides the list capacity (tests: forces the on-device fall-back)
-    const char *el = getenv("GEMMA_HIP_KIN_LISTS");
-    bool lists = !(el && el[0] == '0') && l < ((size_t)1 << 18);
+    bool lists = g_ctx.knobs.kin_lists && l < ((size_t)1 << 18);
     const unsigned nseg = (unsigned)((n + KI8_SEG - 1) / KI8_SEG);
     size_t cap = std::max<size_t>(l * n / 16, (size_t)1 << 20);
-    if (const char *ec = getenv("GEMMA_HIP_KIN_LIST_CAP")) cap = std::max<size_t>((size_t)atoll(ec), 1);
+    if (g_ctx.knobs.kin_list_cap) cap = std::max<size_t>((size_t)g_ctx.knobs.kin_list_cap, 1);
     cap = std::min<size_t>(cap, (size_t)1 << 30);
     const size_t ld2 = (size_t)256 * nseg; // dwords per row of the 2-bit copy (kin_i8_pack2_kernel)
     // the list buffers are an optimisation: when they do not fit (GEMMA_HIP_KIN_LISTS_OOM=1 simulates it) the round-2 kernel,
     // which needs none of them, takes the whole correction -- as launch_assoc degrades when its tables do not fit
-    const char *eo = getenv("GEMMA_HIP_KIN_LISTS_OOM");
-    if (lists && ((eo && eo[0] == '1') ||
+    if (lists && (g_ctx.knobs.kin_lists_oom ||
                   g_ctx.kin_A2.reserve(l * ld2 * 4) || g_ctx.kin_cnt.reserve((l + n) * 4) || g_ctx.kin_off.reserve((l + n + 2) * 4) ||
                   g_ctx.kin_listS.reserve(cap * 4) || g_ctx.kin_listJ.reserve(cap * 4) ||
                   g_ctx.kin_sub.reserve(l * (size_t)(nseg + 1) * 4) || g_ctx.kin_cj.reserve(n * 8) || g_ctx.kin_flag.reserve(16))) {
@@ -741,13 +821,8 @@ static int shard_allreduce(void *, double *buf_d, size_t count, hipStream_t s) {
   std::string err;
   return g_ctx.comm.allreduce_sum(buf_d, count, s, err) ? 1 : 0;
 }
-static int eigh_d_impl(double *G, size_t n, double *U, double *eval, double *trace_G, void *stream, bool sharded) {
-  NEED_INIT();
-  if (!G || !U || !eval || n == 0) return fail(GEMMA_HIP_EINVAL, "eigh: null/empty argument");
-  hipStream_t s = S(stream);
-  ProfScope ps(GEMMA_STAGE_EIGH, s);
-  std::string msg;
-  EighShard sh;
+// the collective form of the eigensolver is in force for this call: fills sh
+static bool eigh_shard_in_force(bool sharded, EighShard &sh) {
   const char *es = getenv("GEMMA_HIP_EIGH_SHARD"); // 0: every rank decomposes on its own (replicas), nothing is exchanged
   const bool use = sharded && g_ctx.comm.active && g_ctx.comm.world > 1 && !(es && es[0] == '0');
   if (use) {
@@ -755,6 +830,30 @@ static int eigh_d_impl(double *G, size_t n, double *U, double *eval, double *tra
     sh.world = g_ctx.comm.world;
     sh.bcast = shard_bcast;
     sh.allreduce_sum = shard_allreduce;
+  }
+  return use;
+}
+// a rank whose OWN setup fails before the collective solver (its copy of the matrix, its slot of the kept (U, eval))
+// tells the others through the solver's first agreement instead of leaving them in it (eigh.hip.h: eigh_collective_abort)
+static void eigh_abort_if_sharded(bool sharded, size_t n, hipStream_t s) {
+  EighShard sh;
+  if (eigh_shard_in_force(sharded, sh)) eigh_abort_x((long)n, s, &sh);
+}
+static int eigh_d_impl(double *G, size_t n, double *U, double *eval, double *trace_G, void *stream, bool sharded) {
+  NEED_INIT();
+  if (!G || !U || !eval || n == 0) return fail(GEMMA_HIP_EINVAL, "eigh: null/empty argument");
+  hipStream_t s = S(stream);
+  ProfScope ps(GEMMA_STAGE_EIGH, s);
+  std::string msg;
+  EighShard sh;
+  const bool use = eigh_shard_in_force(sharded, sh);
+  if (use) {
+    // tests (tests/test_gpu_two_rank.py): GEMMA_HIP_EIGH_FAIL_RANK=<r> makes rank r fail as if its own allocations had, before the solver
+    const char *efr = getenv("GEMMA_HIP_EIGH_FAIL_RANK");
+    if (efr && *efr && atoi(efr) == g_ctx.comm.rank) {
+      eigh_abort_x((long)n, s, &sh);
+      return fail(GEMMA_HIP_ENOMEM, "eigh: allocation failure injected on rank %d (GEMMA_HIP_EIGH_FAIL_RANK)", g_ctx.comm.rank);
+    }
   }
   int rc = eigh_device_x(G, (long)n, U, eval, s, msg, use ? &sh : nullptr);
   if (rc != GEMMA_HIP_OK) return fail(rc, "eigh: %s", msg.c_str());
@@ -927,6 +1026,7 @@ static int lmm_common_setup(const gemma_lmm_cfg *cfg) {
   if (cfg->n <= cfg->n_cvt + 1) return fail(GEMMA_HIP_EINVAL, "lmm_setup: n <= n_cvt + 1");
   if (cfg->n > 0x7fffffffUL) return fail(GEMMA_HIP_EINVAL, "lmm_setup: n too large");
   g_ctx.cfg = *cfg;
+  g_ctx.knobs.load(); // the environment switches of the batch path: once per setup
   AssocArgs &a = g_ctx.assoc_proto;
   memset(&a, 0, sizeof a);
   a.n = (int)cfg->n;
@@ -1098,10 +1198,7 @@ static int make_grid(hipStream_t s) {
 
 // table_v2_kernel + table_reduce_kernel (lmm_grid.hip.h): T = [X.X | X] * R with RG * 16 rows per wave and the K range cut
 // into slices; tg == nullptr: the dense fixed-lambda table of all l rows, else the per-interval gather tables
-static bool table_v2_enabled() {
-  const char *e = getenv("GEMMA_HIP_TABLE_V2");
-  return !(e && e[0] == '0');
-}
+static bool table_v2_enabled() { return g_ctx.knobs.table_v2 != 0; }
 template <int NBX, int NBA, int RG>
 static int launch_table_v2_t(const GridGeom &gg, const double *UtX, size_t l, size_t ld, const double *R, double *T,
                              const TableGather *tg, int nint, hipStream_t s) {
@@ -1120,8 +1217,7 @@ static int launch_table_v2_t(const GridGeom &gg, const double *UtX, size_t l, si
   a.P = g_ctx.table_P.as<double>(); a.cap = (long)l;
   if (tg) a.tg = *tg; else a.tg = TableGather();
   const long total = (long)l * NB16;
-  const char *epf = getenv("GEMMA_HIP_TABLE_PF");
-  const bool pf = epf && epf[0] == '1';
+  const bool pf = g_ctx.knobs.table_pf != 0;
   if (tg) {
     if (pf) hipLaunchKernelGGL((table_v2_kernel<NBX, NBA, RG, true, true>), dim3((unsigned)bx, (unsigned)ksplit, (unsigned)nint), dim3(256), 0, s, a);
     else hipLaunchKernelGGL((table_v2_kernel<NBX, NBA, RG, true, false>), dim3((unsigned)bx, (unsigned)ksplit, (unsigned)nint), dim3(256), 0, s, a);
@@ -1342,8 +1438,7 @@ static int launch_assoc(const double *UtX, size_t l, size_t ld, gemma_sumstat *o
   {
     ProfScope ps(GEMMA_STAGE_ASSOC, s);
     // GEMMA_HIP_FORCE_GENERIC=1 routes every covariate count through the multi-pass kernel (tests)
-    const char *fg = getenv("GEMMA_HIP_FORCE_GENERIC");
-    const size_t sel = (fg && fg[0] == '1') ? 99 : g_ctx.cfg.n_cvt;
+    const size_t sel = g_ctx.knobs.force_generic ? 99 : g_ctx.cfg.n_cvt;
     a.grid_T = nullptr;
     if (a.have_grid && sel <= 4 && (ld & 1) == 0 && (reinterpret_cast<uintptr_t>(UtX) & 15) == 0 &&
         a.a_mode != 3) { // mode 3 (score only) never searches lambda
@@ -1366,8 +1461,7 @@ static int launch_assoc(const double *UtX, size_t l, size_t ld, gemma_sumstat *o
     case 1: {
       // streaming-loop unroll / wavefronts per SIMD of the c = 1 kernel; measured at n = 20000 (ms per 20000 SNPs):
       // 2/3: 14.3, 4/3: 14.1, 8/3: 13.9, 2/4: 12.9, 4/4: 12.8 (default), 4/2: 14.2
-      const char *ev = getenv("GEMMA_HIP_ASSOC_VARIANT");
-      const int var = ev ? atoi(ev) : 44;
+      const int var = g_ctx.knobs.assoc_variant;
       if (var == 43) hipLaunchKernelGGL((lmm_assoc1_variant_kernel<4, 3>), dim3(grid), dim3(256), 0, s, a);
       else if (var == 83) hipLaunchKernelGGL((lmm_assoc1_variant_kernel<8, 3>), dim3(grid), dim3(256), 0, s, a);
       else if (var == 24) hipLaunchKernelGGL((lmm_assoc1_variant_kernel<2, 4>), dim3(grid), dim3(256), 0, s, a);
@@ -1415,9 +1509,20 @@ extern "C" int gemma_hip_lmm_assoc_d(const double *UtX_d, size_t l, size_t ld_ut
 // GEMMA_HIP_UTX_I8: 1 (default) = hard-call batches (PLINK 2-bit; fp64 input whose rows hold only 0/1/2 and one
 // missing / imputed value) go through the exact int8-digit product (i8gemm.hip.h), 0 = always the fp64 MFMA GEMM.
 // Real-valued dosages always take the fp64 GEMM.
-static int utx_i8_mode() {
-  const char *e = getenv("GEMMA_HIP_UTX_I8");
-  return e ? atoi(e) : 1;
+static int utx_i8_mode() { return g_ctx.knobs.utx_i8; }
+
+// which matrix kernel the product of the batch launched (gemma_hip_dbg_last_utx_kernel): bench.py labels its roofline from this,
+// not from the environment
+static void note_utx_kernel(int variant, int digits, int fuse, int raster) {
+  static const char *const names[GEMMA_UTX_KERNEL_COUNT] = {
+      "dgemm_mfma_glds_kernel", "i8gemm_packed_kernel_t<true>", "i8gemm_sparse_kernel", "i8gemm_sparse2_kernel",
+      "i8gemm_sparse2_r16_kernel", "i8gemm_packed_kernel_t<false, true>"};
+  gemma_utx_kernel_info &k = g_ctx.last_utx_kernel;
+  k.variant = variant;
+  k.rows = variant == GEMMA_UTX_KERNEL_RECORDS_R16 ? 16 : (variant == GEMMA_UTX_KERNEL_DGEMM_F64 ? 0 : 32);
+  k.digits = digits; k.fuse = fuse; k.raster = raster;
+  k.launches += 1;
+  snprintf(k.name, sizeof k.name, "%s", names[variant]);
 }
 
 static size_t round_up(size_t v, size_t m) { return (v + m - 1) / m * m; }
@@ -1425,8 +1530,7 @@ static size_t round_up(size_t v, size_t m) { return (v + m - 1) / m * m; }
 // digits of U in the exact int8 product (i8gemm.hip.h): 7, or 6 from n = 16384 up where the 2^-47 rounding of U stays at
 // the level of an fp64 GEMM's own rounding; GEMMA_HIP_I8_DIGITS=6|7 forces either
 static int i8_digits_for(size_t n) {
-  const char *e = getenv("GEMMA_HIP_I8_DIGITS");
-  if (e && (atoi(e) == 6 || atoi(e) == 7)) return atoi(e);
+  if (g_ctx.knobs.i8_digits) return g_ctx.knobs.i8_digits;
   return n >= 16384 ? 6 : 7;
 }
 
@@ -1465,19 +1569,14 @@ struct I8Dims {
 // GEMMA_HIP_I8_SPARSE: 0 = the mask product on dense MFMAs (i8gemm_packed_kernel_t), 1 = on the 2:4 sparse MFMA with byte-wise
 // genotypes and separate mask words (i8gemm_sparse.hip.h), 2 (default) = sparse MFMA, left factor as 16-byte records of 2-bit
 // genotypes + mask words, 256 x 128 tiles (i8gemm_sparse2.hip.h)
-static int i8_sparse_mode() {
-  const char *e = getenv("GEMMA_HIP_I8_SPARSE");
-  if (e && e[0] >= '0' && e[0] <= '2') return e[0] - '0';
-  return 2;
-}
+static int i8_sparse_mode() { return g_ctx.knobs.i8_sparse; }
 static int i8_begin(size_t l, I8Dims *d, hipStream_t s) {
   int rc = i8_prepare_u(s);
   if (rc) return rc;
   d->n = g_ctx.cfg.n; d->ldk = g_ctx.i8_ldk; d->npad = g_ctx.i8_npad;
   d->lpad = round_up(l, i8_sparse_mode() == 2 ? (size_t)S2_BM : (size_t)I8P_BM); d->mrows = 2 * d->lpad;
   // two digits per int32 output plane while 256 * C_hi + C_lo cannot overflow: n * 2 * 128 * 257 < 2^31
-  const char *ef = getenv("GEMMA_HIP_I8_FUSE");
-  d->fuse = (!(ef && ef[0] == '0') && (double)d->n * 2.0 * 128.0 * 257.0 < 2147483648.0) ? 1 : 0;
+  d->fuse = (g_ctx.knobs.i8_fuse && (double)d->n * 2.0 * 128.0 * 257.0 < 2147483648.0) ? 1 : 0;
   d->digits = g_ctx.i8_digits;
   d->nplanes = d->fuse ? (d->digits + 1) / 2 : d->digits;
   const size_t c_elems = (size_t)d->nplanes * d->mrows * d->npad;
@@ -1507,6 +1606,31 @@ static int i8_meta_build(const I8Dims &d, hipStream_t s) {
   return GEMMA_HIP_OK;
 }
 
+// The raster of a launch shape: found in the cache or built into the least recently used slot.  A slot is only recycled when more
+// than six shapes are alive (a block in row chunks has two); then the device is synchronised first, since a kernel on ANY stream may
+// still read the map that goes.
+static int raster_for(int tiles_m, int tiles_n, int rb, hipStream_t s, const int2 **map_d) {
+  Ctx::RasterSlot *lru = &g_ctx.i8_raster[0];
+  for (auto &r : g_ctx.i8_raster) {
+    if (r.tm == tiles_m && r.tn == tiles_n && r.rb == rb && r.dev.p) {
+      r.used = ++g_ctx.i8_raster_clock;
+      *map_d = r.dev.as<int2>();
+      return GEMMA_HIP_OK;
+    }
+    if (r.used < lru->used) lru = &r;
+  }
+  if (lru->dev.p) HIPCHK(hipDeviceSynchronize()); // recycling a map some launch may still read
+  s2_build_raster(tiles_m, tiles_n, rb, lru->host);
+  lru->tm = lru->tn = lru->rb = 0;
+  if (lru->dev.reserve(lru->host.size() * sizeof(int2)))
+    return fail(GEMMA_HIP_ENOMEM, "lmm_batch: tile raster (%zu bytes)", lru->host.size() * sizeof(int2));
+  HIPCHK(hipMemcpyAsync(lru->dev.p, lru->host.data(), lru->host.size() * sizeof(int2), hipMemcpyHostToDevice, s));
+  lru->tm = tiles_m; lru->tn = tiles_n; lru->rb = rb;
+  lru->used = ++g_ctx.i8_raster_clock;
+  *map_d = lru->dev.as<int2>();
+  return GEMMA_HIP_OK;
+}
+
 // rows_pad: padded rows of this piece (a multiple of the tile height; row0 too).  Pieces other than the whole block are taken
 // by the records kernel only (mode 2).
 static int i8_gemm_rows(const I8Dims &d, size_t row0, size_t rows_pad, hipStream_t s) {
@@ -1530,8 +1654,7 @@ static int i8_gemm_rows(const I8Dims &d, size_t row0, size_t rows_pad, hipStream
   g.m_row0 = (long)d.lpad;
   g.tiles_m = (int)(d.lpad / I8P_BM); g.tiles_n = (int)(d.npad / I8_BN);
   g.nk = (int)(d.ldk / I8_BK);
-  const char *e = getenv("GEMMA_HIP_I8_GM");
-  g.gm = e ? atoi(e) : 0;
+  g.gm = g_ctx.knobs.i8_gm;
   g.fuse = d.fuse;
   g.digits = d.digits;
   const dim3 grid((unsigned)(g.tiles_m * g.tiles_n), (unsigned)d.nplanes);
@@ -1551,28 +1674,24 @@ static int i8_gemm_rows(const I8Dims &d, size_t row0, size_t rows_pad, hipStream
     g2.m_row0 = g.m_row0;
     g2.tiles_m = (int)(rows_pad / S2_BM); g2.tiles_n = (int)(d.npad / S2_BN);
     g2.nk = g.nk; g2.gm = g.gm; g2.fuse = g.fuse; g2.digits = g.digits;
+    int raster_rb = 0;
     {
       // GEMMA_HIP_I8_RASTER: 0 = every XCD sweeps its own tile rows (round 3); 1 / 2 / 4 / 8 = row blocks of the super-patch the
       // eight XCDs share (s2_build_raster)
-      const char *er = getenv("GEMMA_HIP_I8_RASTER");
-      const int rb = er ? atoi(er) : S2_DEFAULT_RASTER;
+      const int rb = g_ctx.knobs.i8_raster;
       if (rb > 0) {
-        if (g_ctx.i8_raster_tm != g2.tiles_m || g_ctx.i8_raster_tn != g2.tiles_n || g_ctx.i8_raster_rb != rb) {
-          std::vector<int2> map;
-          s2_build_raster(g2.tiles_m, g2.tiles_n, rb, map);
-          if (g_ctx.i8_raster.reserve(map.size() * sizeof(int2)))
-            return fail(GEMMA_HIP_ENOMEM, "lmm_batch: tile raster (%zu bytes)", map.size() * sizeof(int2));
-          HIPCHK(hipStreamSynchronize(s)); // a previous launch may still read the old map
-          HIPCHK(hipMemcpy(g_ctx.i8_raster.p, map.data(), map.size() * sizeof(int2), hipMemcpyHostToDevice));
-          g_ctx.i8_raster_tm = g2.tiles_m; g_ctx.i8_raster_tn = g2.tiles_n; g_ctx.i8_raster_rb = rb;
-        }
-        g2.tile_map = g_ctx.i8_raster.as<int2>();
+        const int2 *map_d = nullptr;
+        int rc_map = raster_for(g2.tiles_m, g2.tiles_n, rb, s, &map_d);
+        if (rc_map) return rc_map;
+        g2.tile_map = map_d;
+        raster_rb = rb;
       }
     }
     // GEMMA_HIP_I8_ROWS=32: the kernel of rounds 3-4 on the 32-row matrix instructions; default: the same product on the 16-row
     // forms (i8gemm_sparse2_r16.hip.h: same records, same planes, every entry equal; 9 % faster under the power limit)
-    const char *e16 = getenv("GEMMA_HIP_I8_ROWS");
-    if (e16 && atoi(e16) == 32)
+    note_utx_kernel(g_ctx.knobs.i8_rows == 32 ? GEMMA_UTX_KERNEL_RECORDS_R32 : GEMMA_UTX_KERNEL_RECORDS_R16, d.digits, d.fuse,
+                    raster_rb);
+    if (g_ctx.knobs.i8_rows == 32)
       hipLaunchKernelGGL(i8gemm_sparse2_kernel, dim3((unsigned)(g2.tiles_m * g2.tiles_n), (unsigned)d.nplanes), dim3(512),
                          S2_NST * S2_STAGE, s, g2);
     else
@@ -1589,8 +1708,10 @@ static int i8_gemm_rows(const I8Dims &d, size_t row0, size_t rows_pad, hipStream
     sm.m4 = g_ctx.i8_meta.as<uint4>();
     sm.row_surplus = g_ctx.i8_rowsur.as<int>();
     sm.ntiles = (long)g.nk;
+    note_utx_kernel(GEMMA_UTX_KERNEL_SPARSE_BYTES, d.digits, d.fuse, 0);
     hipLaunchKernelGGL(i8gemm_sparse_kernel, grid, dim3(512), 3 * SP_STAGE, s, g, sm);
   } else {
+    note_utx_kernel(GEMMA_UTX_KERNEL_DENSE_I8, d.digits, d.fuse, 0);
     hipLaunchKernelGGL(i8gemm_packed_kernel_t<true>, grid, dim3(512), 3 * I8P_STAGE, s, g);
   }
   HIPCHK(hipGetLastError());
@@ -1657,10 +1778,7 @@ static int utx_plink_i8(const void *geno, size_t l, size_t ld, double *UtX, size
 
 // Fixed-point dosage rows (i8gemm.hip.h: pack_dosage_kernel): byte planes a0 [, a1] [, mask] x the digits of U on the dense int8
 // kernel, one int32 plane per (byte plane, digit); GEMMA_HIP_UTX_DOSAGE_I8=0 keeps such batches on the fp64 GEMM.
-static bool dosage_i8_enabled() {
-  const char *e = getenv("GEMMA_HIP_UTX_DOSAGE_I8");
-  return !(e && e[0] == '0');
-}
+static bool dosage_i8_enabled() { return g_ctx.knobs.dosage_i8 != 0; }
 static int utx_dosage_i8(const double *src, size_t l, size_t ld, bool nan_missing, bool two, bool have_m, const I8Dims &d,
                          double *UtX, size_t ldx, hipStream_t s) {
   const int np = (two ? 2 : 1) + (have_m ? 1 : 0);
@@ -1704,10 +1822,10 @@ static int utx_dosage_i8(const double *src, size_t l, size_t ld, bool nan_missin
       g.m_row0 = 0;
       g.tiles_m = (int)(d.lpad / I8P_BM); g.tiles_n = (int)(d.npad / I8_BN);
       g.nk = (int)(d.ldk / I8_BK);
-      const char *e = getenv("GEMMA_HIP_I8_GM");
-      g.gm = e ? atoi(e) : 0;
+      g.gm = g_ctx.knobs.i8_gm;
       g.fuse = 0;
       g.digits = d.digits;
+      note_utx_kernel(GEMMA_UTX_KERNEL_DOSAGE_I8, d.digits, 0, 0);
       hipLaunchKernelGGL((i8gemm_packed_kernel_t<false, true>), dim3((unsigned)(g.tiles_m * g.tiles_n), (unsigned)d.digits),
                          dim3(512), 3 * I8P_STAGE, s, g);
       HIPCHK(hipGetLastError());
@@ -1832,6 +1950,7 @@ static int compute_utx(int kind, const void *geno, size_t l, size_t ld, int path
     long ldu;
     int rcu = gemm_U(&Ug, &ldu, s);
     if (rcu) return rcu;
+    note_utx_kernel(GEMMA_UTX_KERNEL_DGEMM_F64, 0, 0, 0);
     HIPCHK(launch_dgemm('N', 'N', (long)l, (long)n, (long)n, 1.0, X, (long)ldx, Ug, ldu, 0.0, UtX,
                         (long)ldx, false, false, s));
   }
@@ -1861,11 +1980,9 @@ static int check_batch_args(const char *who, int kind, const void *geno, size_t 
 // two chunks 63.3, eight 64.0.  The chip is at its power limit under the product alone, so concurrency is a zero-sum game
 // here.  The path stays behind GEMMA_HIP_OVERLAP=1 (GEMMA_HIP_OVERLAP_CHUNKS, default 4), off by default, with its test.
 static int overlap_chunks(size_t l) {
-  const char *e = getenv("GEMMA_HIP_OVERLAP");
-  if (!(e && e[0] == '1')) return 1;
+  if (!g_ctx.knobs.overlap) return 1;
   if (utx_i8_mode() != 1 || i8_sparse_mode() != 2) return 1;
-  int q = 4;
-  if (const char *ec = getenv("GEMMA_HIP_OVERLAP_CHUNKS")) q = atoi(ec);
+  int q = g_ctx.knobs.overlap_chunks;
   q = std::max(1, std::min(q, 16));
   while (q > 1 && l < (size_t)q * 2 * S2_BM) --q; // at least two tile rows per chunk
   return q;
@@ -2020,10 +2137,7 @@ static int mv_check_dims(const char *who, size_t d, size_t c, size_t extra = 1) 
   return GEMMA_HIP_OK;
 }
 // GEMMA_HIP_MVLMM_RT=1: the run-time kernel also where a fixed one exists (tests)
-static bool mv_force_rt() {
-  const char *e = getenv("GEMMA_HIP_MVLMM_RT");
-  return e && e[0] == '1';
-}
+static bool mv_force_rt() { return g_ctx.knobs.mvlmm_rt != 0; }
 
 static void mv_default_opt(gemma_mvlmm_opt &o, const gemma_mvlmm_opt *opt) {
   if (opt) {
@@ -2053,6 +2167,7 @@ extern "C" int gemma_hip_mvlmm_null(size_t n, size_t n_cvt, size_t d, const doub
                                     const double *UtY, double l_min, double l_max, size_t n_region,
                                     const gemma_mvlmm_opt *opt, gemma_mvlmm_null *out) {
   NEED_INIT();
+  g_ctx.knobs.load();
   if (!eval || !UtW || !UtY || !out) return fail(GEMMA_HIP_EINVAL, "mvlmm_null: null pointer");
   int rc = mv_check_dims("mvlmm_null", d, n_cvt);
   if (rc) return rc;
@@ -2146,6 +2261,7 @@ extern "C" int gemma_hip_mvlmm_null(size_t n, size_t n_cvt, size_t d, const doub
 
 extern "C" int gemma_hip_mvlmm_set(size_t d, const double *UtY, const gemma_mvlmm_null *nf, const gemma_mvlmm_opt *opt) {
   NEED_INIT();
+  g_ctx.knobs.load();
   if (!g_ctx.lmm_active) return fail(GEMMA_HIP_ESTATE, "mvlmm_set before lmm_setup");
   if (!UtY || !nf) return fail(GEMMA_HIP_EINVAL, "mvlmm_set: null pointer");
   gemma_mvlmm_opt o;
@@ -2444,6 +2560,7 @@ extern "C" int gemma_hip_lmm_batch(int kind, const void *geno, size_t l, size_t 
 // ------------------------------------------------------------------------------ linear model (-lm)
 extern "C" int gemma_hip_lm_setup(int a_mode, size_t n, size_t n_cvt, const double *W, const double *y) {
   NEED_INIT();
+  g_ctx.knobs.load();
   if (g_ctx.lmm_active) return fail(GEMMA_HIP_ESTATE, "lm_setup while an LMM run is active");
   if (a_mode < 51 || a_mode > 54) return fail(GEMMA_HIP_EINVAL, "lm_setup: a_mode %d (51..54)", a_mode);
   if (!W || !y || n == 0 || n_cvt == 0 || n_cvt > (size_t)LM_CMAX || n <= n_cvt + 1 || n > 0x7fffffffUL)
@@ -2652,13 +2769,13 @@ extern "C" int gemma_hip_lmm_finish(double *time_UtX_min, double *time_opt_min) 
   g_ctx.cheb_list.release(); g_ctx.cheb_count.release(); g_ctx.cheb_D.release(); g_ctx.cheb_Ck.release();
   g_ctx.cheb_Gk.release(); g_ctx.cheb_Lk.release(); g_ctx.cheb_iv.release(); g_ctx.cheb_dends.release(); g_ctx.cheb_res.release();
   g_ctx.i8_Bt.release(); g_ctx.i8_ej.release(); g_ctx.i8_cmax.release(); g_ctx.i8_A.release(); g_ctx.i8_C.release();
-  g_ctx.i8_raster.release(); g_ctx.i8_raster_tm = g_ctx.i8_raster_tn = g_ctx.i8_raster_rb = 0;
+  raster_release();
   g_ctx.i8_mean.release(); g_ctx.i8_meta.release(); g_ctx.i8_rowsur.release(); g_ctx.i8_colsum.release(); g_ctx.i8_surlist.release();
   g_ctx.i8_ready = false;
   g_ctx.i8_colsum_ready = false;
   g_ctx.gxe_env.release(); g_ctx.gxe_UtWt.release(); g_ctx.gxe_Z.release(); g_ctx.gxe_UtZ.release();
   g_ctx.mv_Yt.release(); g_ctx.mv_out.release(); g_ctx.mv_scratch.release();
-  g_ctx.mv_ready = false;
+  g_ctx.mv_ready = g_ctx.mv_gxe = false;
   g_ctx.gxe_flip.release();
   g_ctx.gxe_ready = false;
   g_ctx.U = g_ctx.eval = g_ctx.Uty = nullptr;
@@ -2734,7 +2851,10 @@ static int kept_alloc_ue(size_t n) {
 
 static int kept_eigh_of(double *G_d, size_t n, double *eval, double *trace_G, bool sharded = false) {
   int rc = kept_alloc_ue(n);
-  if (rc) return rc;
+  if (rc) {
+    eigh_abort_if_sharded(sharded, n, nullptr);
+    return rc;
+  }
   double tr = 0.0;
   rc = eigh_d_impl(G_d, n, kept_U(), kept_eval(), &tr, nullptr, sharded);
   if (rc) {
@@ -2768,6 +2888,7 @@ static int eigh_kept_K_impl(const int *indicator_idv, size_t ni_total, double *e
   DevBuf G, dmap;
   if (G.reserve(n * n * 8) || dmap.reserve(n * sizeof(int))) {
     G.release(); dmap.release();
+    eigh_abort_if_sharded(sharded, n, nullptr);
     return fail(GEMMA_HIP_ENOMEM, "eigh_kept_K: %zu bytes", n * n * 8);
   }
   int rc = GEMMA_HIP_OK;
@@ -2780,6 +2901,7 @@ static int eigh_kept_K_impl(const int *indicator_idv, size_t ni_total, double *e
   }
   if (e == hipSuccess) rc = gemma_hip_center_d(G.as<double>(), n, nullptr);
   if (e == hipSuccess && rc == GEMMA_HIP_OK) rc = kept_eigh_of(G.as<double>(), n, eval, trace_G, sharded);
+  else eigh_abort_if_sharded(sharded, n, nullptr); // sub-selection or centring failed on this rank alone
   G.release(); dmap.release();
   if (e != hipSuccess) return fail(GEMMA_HIP_ERUNTIME, "eigh_kept_K: %s", hipGetErrorString(e));
   return rc;
@@ -3024,6 +3146,17 @@ extern "C" int gemma_hip_comm_finalize(void) {
   return GEMMA_HIP_OK;
 }
 
+
+extern "C" int gemma_hip_dbg_last_utx_kernel(gemma_utx_kernel_info *info) {
+  if (!info) return fail(GEMMA_HIP_EINVAL, "dbg_last_utx_kernel: null");
+  *info = g_ctx.last_utx_kernel;
+  return GEMMA_HIP_OK;
+}
+
+extern "C" int gemma_hip_reload_env(void) {
+  g_ctx.knobs.load();
+  return GEMMA_HIP_OK;
+}
 
 extern "C" int gemma_hip_dbg_last_utx_path(int *path) {
   if (path) *path = g_ctx.last_utx_path;

@@ -346,6 +346,31 @@ int gemma_hip_dbg_utx(int geno_kind, const void *geno, size_t l, size_t ld, int 
  * product of hard calls, 2 / 3 int8-digit product of fixed-point dosages k/100 / k/1000 (BIMBAM mean genotypes,
  * doc/manual.tex:398-404) */
 int gemma_hip_dbg_last_utx_path(int *path);
+/* the MATRIX KERNEL that product launched, as the library's own launch site recorded it (bench.py labels `roofline.kernel` from this
+ * and refuses counter files taken on another kernel -- VERDICT r4 #1b).  `name` is the kernel's symbol as rocprofv3 prints it;
+ * `launches` counts launches since the library was loaded. */
+enum {
+  GEMMA_UTX_KERNEL_DGEMM_F64 = 0,    /* dgemm_mfma_glds_kernel: src/lmm.cpp:1521 as one fp64 MFMA product */
+  GEMMA_UTX_KERNEL_DENSE_I8 = 1,     /* i8gemm_packed_kernel_t<true>: digit products, mask product dense (GEMMA_HIP_I8_SPARSE=0) */
+  GEMMA_UTX_KERNEL_SPARSE_BYTES = 2, /* i8gemm_sparse_kernel: mask product on the 2:4 sparse MFMA, byte genotypes (=1) */
+  GEMMA_UTX_KERNEL_RECORDS_R32 = 3,  /* i8gemm_sparse2_kernel: records, 32-row matrix instructions (GEMMA_HIP_I8_ROWS=32) */
+  GEMMA_UTX_KERNEL_RECORDS_R16 = 4,  /* i8gemm_sparse2_r16_kernel: records, v_mfma_i32_16x16x64_i8 + v_smfmac_i32_16x16x128_i8 (default) */
+  GEMMA_UTX_KERNEL_DOSAGE_I8 = 5,    /* i8gemm_packed_kernel_t<false, true>: byte planes of fixed-point dosages */
+  GEMMA_UTX_KERNEL_COUNT = 6
+};
+typedef struct {
+  int variant;  /* GEMMA_UTX_KERNEL_* */
+  int rows;     /* rows of the matrix instruction: 16 | 32 (0: fp64) */
+  int digits;   /* base-256 digits of U in the product (0: fp64) */
+  int fuse;     /* 1: two digits per int32 plane */
+  int raster;   /* row blocks of the cross-XCD raster (0: per-XCD ranges) */
+  long launches;
+  char name[64];
+} gemma_utx_kernel_info;
+int gemma_hip_dbg_last_utx_kernel(gemma_utx_kernel_info *info);
+/* re-read the GEMMA_HIP_* switches of the batch path.  The library reads them once per setup (gemma_hip_init, lmm_setup*, lm_setup,
+ * mvlmm_null / mvlmm_set, kin_begin), never per launch; a caller that changes one between two batches of ONE setup calls this. */
+int gemma_hip_reload_env(void);
 /* base-256 digits of U the int8 product uses at this n: 7 (U to 2^-55 of the column maximum: bit-faithful); 6 from n = 16384 up
  * (U rounded to 2^-47 of the column maximum -- see gemma_hip_lmm_batch); GEMMA_HIP_I8_DIGITS=6|7 overrides */
 int gemma_hip_dbg_i8_digits(size_t n, int *digits);

@@ -5,6 +5,7 @@ hundred sampled SNPs of that block (the oracle is handed the device's U / eval, 
 path at that n: U^T x through the int8-digit product, lambda search, tests).
 
   config 2  n = 5 000, -lmm 4 (Wald + LRT + score), c = 1 and c = 3     src/lmm.cpp:1526-1562
+  config 3  n = 20 000, -lmm 1: the headline size (one full 20 000-SNP block; oracle on 256 SNPs, the reference on 64)
   config 4  n = 33 000 > 32 640: the UNFUSED 7-plane int8-digit product (256 C_hi + C_lo would overflow int32);
             also forced at small n with GEMMA_HIP_I8_FUSE=0
   config 5  n = 10 000, three phenotypes, -lmm 4 multivariate            src/mvlmm.cpp:3218-3375
@@ -99,6 +100,53 @@ def test_config2_n5000_lmm4(gpu_api, oracle, c):
                              plink_nan_rule=1)
     assert np.isfinite(got["p_wald"]).mean() > 0.99
     _cmp_stats(got[sample], ref, 4, "config2 n=5000 c=%d" % c, _problem(Uh, evh, UtWh, Utyh, X))
+
+
+def test_config3_n20000_lmm1(gpu_api, oracle):
+    """BASELINE config 3 -- THE HEADLINE SIZE -- as a gate, not a bench leg: n = 20 000, K from 20 000
+    SNPs, -lmm 1, one full PLINK 2-bit block of 20 000 SNPs through gemma_hip_lmm_batch_d (6-digit int8 product on the records
+    kernel, the tables, the series-driven search); 256 sampled SNPs against the oracle, 64 of them also against the reference's own
+    LMM::Analyze (oracle/_ref/libgemma_ref.so) when that library travelled with the repo.  The library must report the 16-row
+    records kernel with 6 fused digits: what bench.py times."""
+    import torch
+    import bench
+    from gemma_amd import _lib as L
+    n, B, S, SR = 20000, 20000, 256, 64
+    ch = _device_chain(gpu_api, n, 20000, seed=20000)
+    U, ev, UtW, Uty = ch["U"], ch["ev"], ch["UtW"], ch["UtY"][:, 0].contiguous()
+    blk = bench.synth_block(torch, n, B, ch["gen"], ch["dev"])
+    lmm = gpu_api.LMM(a_mode=1)
+    lmm.setup(U, ev, UtW, Uty, plink=True)
+    out = lmm.batch(blk, L.GENO_PLINK_2BIT)
+    torch.cuda.synchronize()
+    k = gpu_api.last_utx_kernel()
+    lmm.finish()
+    assert (k["name"], k["rows"], k["digits"], k["fuse"]) == ("i8gemm_sparse2_r16_kernel", 16, 6, 1), k
+    got = _sumstat(gpu_api, out)
+    assert np.isfinite(got["p_wald"]).mean() > 0.99
+    sample = np.sort(np.random.default_rng(3).choice(B, S, replace=False))
+    X = oracle.bed_decode(blk[torch.from_numpy(sample).to(ch["dev"])].cpu().numpy(), n)
+    Uh, evh, UtWh, Utyh = U.cpu().numpy(), ev.cpu().numpy(), UtW.cpu().numpy(), Uty.cpu().numpy()
+    del U, blk, out, ch
+    torch.cuda.empty_cache()
+    ref = oracle.lmm_analyze(1, Uh, evh, UtWh, Utyh, X, plink_nan_rule=1)
+    _cmp_stats(got[sample], ref, 1, "config3 n=20000 -lmm 1 vs oracle", _problem(Uh, evh, UtWh, Utyh, X))
+    if oracle.ref_lib() is None:
+        _record("parity[config3 n=20000 vs reference] skipped: oracle/_ref/libgemma_ref.so did not travel")
+        return
+    # the reference's own loop: no PLINK NaN-carry (LMM::Analyze is the BIMBAM loop); compare where the search succeeded
+    rr = oracle.ref_lmm_analyze(1, Uh, evh, UtWh, Utyh, X[:SR])
+    g = got[sample][:SR]
+    ok = np.isfinite(rr["logl_H1"]) & np.isfinite(g["logl_H1"])
+    assert ok.sum() >= SR - 2
+    worst = {}
+    for name in ("beta", "se", "logl_H1", "p_wald"):
+        worst[name] = float(np.max(np.abs(g[name][ok] - rr[name][ok]) / np.abs(rr[name][ok])))
+    lam = np.abs(g["lambda_remle"][ok] - rr["lambda_remle"][ok]) / np.abs(rr["lambda_remle"][ok])
+    _record("parity[config3 n=20000 -lmm 1 vs the reference's LMM::Analyze, %d SNPs] %s; lambda_remle max rel %.3e, within 1e-6: %.4f"
+            % (int(ok.sum()), ", ".join("%s %.3e" % kv for kv in worst.items()), float(lam.max()), float(np.mean(lam <= 1e-6))))
+    assert max(worst.values()) < 1e-6, worst
+    assert np.mean(lam <= 1e-6) >= 0.98
 
 
 def test_config4_shape_unfused_int8_planes_n33000(gpu_api, oracle):

@@ -22,6 +22,30 @@ def _problem(U, ev, UtW, Uty, X, l_min=1e-5, l_max=1e5):
     return {"U": U, "ev": ev, "UtW": UtW, "Uty": Uty, "X": X, "l_min": l_min, "l_max": l_max}
 
 
+def _problem_gene(oracle, U, ev, UtW, Utx, Y):
+    """LMM::AnalyzeGene (src/lmm.cpp:1365-1471) as per-row problems for the lambda classification: row g has its own phenotype
+    U^T y_g, the covariates and the tested vector U^T x are fixed."""
+    U = np.asarray(U, dtype=np.float64)
+    return {"ev": ev, "per_row": lambda g: (UtW, np.asarray(Y, dtype=np.float64)[g] @ U, Utx)}
+
+
+def _problem_gxe(oracle, U, ev, UtW, Uty, env, X):
+    """The GXE loop (src/lmm.cpp:2283-2608) as per-row problems: SNP s is imputed, recoded 2 - x where its mean exceeds 1, and
+    enters the COVARIATES [W, env, x_s]; the tested vector is x_s . env (the feeder part of oracle.gxe_analyze, row by row)."""
+    U = np.asarray(U, dtype=np.float64)
+    Ute = U.T @ env
+
+    def row(s):
+        xs = np.asarray(X, dtype=np.float64)[s:s + 1]
+        with np.errstate(invalid="ignore"):
+            xm = np.nanmean(xs)
+        x = oracle.impute_mean(xs)[0]
+        if xm > 1:
+            x = 2.0 - x
+        return np.ascontiguousarray(np.column_stack([UtW, Ute, x @ U])), Uty, (x * env) @ U
+    return {"ev": ev, "per_row": row}
+
+
 def _classify_lambda(problem, func, idx, lam_g, lam_r):
     """For SNPs whose lambda-hat differs by more than 1e-6: did a Brent / Newton trip count flip, or is the value wrong?
     The reference reports the Newton iterate BEFORE the one that met |x_new - x_old| < 1e-5 |x_new| (src/lmm.cpp:2071-2073,
@@ -32,6 +56,14 @@ def _classify_lambda(problem, func, idx, lam_g, lam_r):
     builds show).  Measured detection power (tests/test_lambda_criterion.py): on a well-conditioned problem (n = 500) a
     lambda-hat moved by 1e-4 is rejected on 299 of 300 SNPs, by 3e-4 on all -- the blanket bound this replaces was 1e-3."""
     from oracle import oracle as O
+    if "per_row" in problem:  # gene / GXE callers: covariates, phenotype or tested vector change from row to row
+        sg, lg, lr = np.zeros(len(idx)), np.zeros(len(idx)), np.zeros(len(idx))
+        for j, i in enumerate(idx):
+            W_i, y_i, x_i = problem["per_row"](int(i))
+            a, b = O.newton_step_rel(func, problem["ev"], W_i, y_i, np.ascontiguousarray(x_i)[None, :], np.array([lam_g[j]]))
+            _, c = O.newton_step_rel(func, problem["ev"], W_i, y_i, np.ascontiguousarray(x_i)[None, :], np.array([lam_r[j]]))
+            sg[j], lg[j], lr[j] = a[0], b[0], c[0]
+        return (sg < 1e-5) | (np.abs(lg - lr) <= 2e-12 * np.abs(lr)), sg, np.abs(lg - lr) / np.abs(lr)
     if "UtX" in problem:
         UtX = np.ascontiguousarray(np.asarray(problem["UtX"])[idx])
     else:
@@ -47,8 +79,9 @@ def _cmp_stats(got, ref, mode, tag="", problem=None):
     """beta/se/logl/p: <= 1e-6 relative on every SNP.  lambda-hat (two tiers): within 1e-6 on >= 98 % of the
     SNPs; every other SNP must be a FLIPPED TRIP COUNT, not a wrong value -- with `problem` (see _problem) each of them is
     classified through the oracle (_classify_lambda: the reference's own stopping rule holds at the GPU's value, or the
-    likelihood there equals the reference's to 1e-11) and any unclassifiable one fails the test whatever its size; without
-    `problem` (callers whose covariate structure the helper does not model: gene / GXE) the blanket bound 1e-3 stays."""
+    likelihood there equals the reference's to 2e-12) and any unclassifiable one fails the test whatever its size -- the gene and
+    GXE callers hand in per-row problems (_problem_gene, _problem_gxe: round 5); only a caller without `problem` keeps the
+    blanket bound 1e-3."""
     used = {1: ["beta", "se", "logl_H1", "lambda_remle", "p_wald"],
             2: ["logl_H1", "lambda_mle", "p_lrt"],
             3: ["beta", "se", "p_score"],
@@ -88,7 +121,7 @@ def _cmp_stats(got, ref, mode, tag="", problem=None):
         report.append("%s: max rel %.3e at %d (%r vs %r), #>1e-6: %d of %d (frac <=1e-6: %.5f)" % (
             k, rel[w], w, g[w], r[w], int((rel > 1e-6).sum()), len(rel), float(np.mean(rel <= 1e-6)) if len(rel) else 1.0))
         if k.startswith("lambda"):
-            if rel.max() > 1e-3 or np.mean(rel <= 1e-6) < 0.98:
+            if (problem is None and rel.max() > 1e-3) or np.mean(rel <= 1e-6) < 0.98:
                 bad.append(report[-1])
             out = np.flatnonzero(rel > 1e-6)
             if problem is not None and len(out):
@@ -498,7 +531,7 @@ def test_lmm_other_region_counts_stream(gpu_api, oracle, n_region):
     ref = oracle.lmm_analyze(4, U, ev, UtW, Uty, X, l_mle_null=l_mle, logl_mle_H0=logl0, n_region=n_region)
     lmm = gpu_api.LMM(a_mode=4, n_region=n_region, l_mle_null=l_mle, logl_mle_H0=logl0)
     got = lmm.AnalyzeBimbam(U, ev, UtW, Uty, X)
-    _cmp_stats(got, ref, 4, "n_region=%d" % n_region)
+    _cmp_stats(got, ref, 4, "n_region=%d" % n_region, _problem(U, ev, UtW, Uty, X))
 
 
 @pytest.mark.parametrize("n,c", [(310, 5), (288, 7), (350, 11), (400, 16)])
@@ -571,7 +604,7 @@ def test_lmm_plink_path_with_dropped_individuals(gpu_api, oracle):
     ref = oracle.lmm_analyze(1, U, ev, UtW, Uty, Xn, plink_nan_rule=1)
     lmm = gpu_api.LMM(a_mode=1)
     got = lmm.AnalyzePlink(U, ev, UtW, Uty, raw, ind)
-    _cmp_stats(got, ref, 1, "plink")
+    _cmp_stats(got, ref, 1, "plink", _problem(U, ev, UtW, Uty, Xn))
 
 
 def _plink_case(oracle, rng, ni_total, p, drop=0.2, miss=0.03):
@@ -767,7 +800,7 @@ def test_lmm_plink_through_int8_digit_product(gpu_api, oracle, monkeypatch, i8):
     monkeypatch.setenv("GEMMA_HIP_UTX_I8", i8)
     lmm = gpu_api.LMM(a_mode=1)
     got = lmm.AnalyzePlink(U, ev, UtW, Uty, raw, ind)
-    _cmp_stats(got, ref, 1, "plink-int8=%s" % i8)
+    _cmp_stats(got, ref, 1, "plink-int8=%s" % i8, _problem(U, ev, UtW, Uty, Xn))
 
 
 def test_hard_call_detection_picks_the_product(gpu_api, oracle, monkeypatch):
@@ -791,24 +824,24 @@ def test_hard_call_detection_picks_the_product(gpu_api, oracle, monkeypatch):
 
     a, na = run(X, L.GENO_F64_SNP_MAJOR)                       # hard calls with NaN
     assert na == 1
-    _cmp_stats(a, ref, 1, "bimbam-hardcall")
+    _cmp_stats(a, ref, 1, "bimbam-hardcall", _problem(U, ev, UtW, Uty, X))
     Xi = oracle.impute_mean(X)
     b, nb = run(np.ascontiguousarray(Xi.T), L.GENO_F64_IDV_MAJOR)  # the reference's mean-imputed Xlarge
     assert nb == 1
-    _cmp_stats(b, ref, 1, "xlarge-hardcall")
+    _cmp_stats(b, ref, 1, "xlarge-hardcall", _problem(U, ev, UtW, Uty, X))
     Xd = X.copy()
     Xd[3, 5] = 0.37                                            # a fixed-point dosage k/100: the int8-digit dosage planes (round 3)
     c, nc = run(Xd, L.GENO_F64_SNP_MAJOR)
     assert nc == 1 and gpu_api.last_utx_path() == 2
-    _cmp_stats(c, oracle.lmm_analyze(1, U, ev, UtW, Uty, Xd), 1, "bimbam-dosage-k/100")
+    _cmp_stats(c, oracle.lmm_analyze(1, U, ev, UtW, Uty, Xd), 1, "bimbam-dosage-k/100", _problem(U, ev, UtW, Uty, Xd.copy()))
     Xd[3, 5] = 0.123456                                        # one value off both grids: the whole batch takes the fp64 GEMM
     c, nc = run(Xd, L.GENO_F64_SNP_MAJOR)
     assert nc == 0 and gpu_api.last_utx_path() == 0
-    _cmp_stats(c, oracle.lmm_analyze(1, U, ev, UtW, Uty, Xd), 1, "bimbam-dosage")
+    _cmp_stats(c, oracle.lmm_analyze(1, U, ev, UtW, Uty, Xd), 1, "bimbam-dosage", _problem(U, ev, UtW, Uty, Xd.copy()))
     monkeypatch.setenv("GEMMA_HIP_UTX_I8", "0")
     d, nd = run(X, L.GENO_F64_SNP_MAJOR)
     assert nd == 0
-    _cmp_stats(d, ref, 1, "bimbam-hardcall-fp64")
+    _cmp_stats(d, ref, 1, "bimbam-hardcall-fp64", _problem(U, ev, UtW, Uty, X))
     for k in ("beta", "se", "p_wald"):
         ok = ~(np.isnan(a[k]) | np.isnan(d[k]))
         np.testing.assert_allclose(a[k][ok], d[k][ok], rtol=1e-8, err_msg=k)
@@ -830,7 +863,7 @@ def test_lmm_reference_xlarge_layout_and_batching(gpu_api, oracle):
     for k in a.dtype.names:
         assert np.array_equal(a[k], b[k], equal_nan=True), k  # bit-identical per SNP
     ref = oracle.lmm_analyze(1, U, ev, UtW, Uty, X)
-    _cmp_stats(a, ref, 1, "xlarge")
+    _cmp_stats(a, ref, 1, "xlarge", _problem(U, ev, UtW, Uty, X))
 
 
 @pytest.mark.parametrize("n,c", [(260, 1), (301, 3), (288, 6)])
@@ -846,7 +879,7 @@ def test_analyze_gene(gpu_api, oracle, n, c):
     for mode in (1, 2, 3, 4, 9):
         ref = oracle.gene_analyze(mode, U, ev, UtW, Utx, Y)
         got = gpu_api.LMM(a_mode=mode).AnalyzeGene(U, ev, UtW, Utx, Y, batch=64)
-        _cmp_stats(got, ref, mode, "gene n=%d c=%d" % (n, c))
+        _cmp_stats(got, ref, mode, "gene n=%d c=%d" % (n, c), _problem_gene(oracle, U, ev, UtW, Utx, Y))
 
 
 @pytest.mark.parametrize("n,c", [(280, 1), (300, 2), (310, 4)])
@@ -862,7 +895,7 @@ def test_analyze_gxe(gpu_api, oracle, n, c):
     for mode in (1, 2, 3, 4, 9):
         ref = oracle.gxe_analyze(mode, U, ev, UtW, Uty, env, X, l_mle_null=l_mle)
         got = gpu_api.LMM(a_mode=mode, l_mle_null=l_mle, logl_mle_H0=logl0).AnalyzeGXE(U, ev, UtW, Uty, env, X, batch=50)
-        _cmp_stats(got, ref, mode, "gxe n=%d c=%d" % (n, c))
+        _cmp_stats(got, ref, mode, "gxe n=%d c=%d" % (n, c), _problem_gxe(oracle, U, ev, UtW, Uty, env, X))
 
 
 def test_analyze_gxe_plink(gpu_api, oracle):
@@ -882,7 +915,7 @@ def test_analyze_gxe_plink(gpu_api, oracle):
     ref = oracle.gxe_analyze(4, U, ev, UtW, Uty, env, Xn, l_mle_null=l_mle)
     got = gpu_api.LMM(a_mode=4, l_mle_null=l_mle, logl_mle_H0=logl0).AnalyzeGXE(
         U, ev, UtW, Uty, env, raw, geno_kind=L.GENO_PLINK_2BIT, indicator_idv=ind)
-    _cmp_stats(got, ref, 4, "gxe-plink")
+    _cmp_stats(got, ref, 4, "gxe-plink", _problem_gxe(oracle, U, ev, UtW, Uty, env, Xn))
 
 
 def test_lmm_eigenvector_sign_invariance(gpu_api, oracle):
@@ -991,7 +1024,7 @@ def test_lmm_medium_size_device_path(gpu_api, oracle):
     got.view(np.float64).reshape(-1, 8)[:] = out.cpu().numpy()
     sample = np.random.default_rng(0).choice(4096, 192, replace=False)
     ref = oracle.lmm_analyze(1, U, ev, UtW, Uty, X[sample])
-    _cmp_stats(got[sample], ref, 1, "n=2000")
+    _cmp_stats(got[sample], ref, 1, "n=2000", _problem(U, ev, UtW, Uty, X[sample]))
     assert np.isfinite(got["p_wald"]).all()
 
 
@@ -1068,7 +1101,7 @@ def test_lmm_bimbam_dosages_match_the_oracle(gpu_api, oracle):
         finally:
             os.environ.pop("GEMMA_HIP_UTX_DOSAGE_I8", None)
     for mode, got in outs.items():
-        _cmp_stats(got, ref, 4, "bimbam dosage k/100 DOSAGE_I8=%s" % mode)
+        _cmp_stats(got, ref, 4, "bimbam dosage k/100 DOSAGE_I8=%s" % mode, _problem(U, ev, UtW, Uty, X))
 
 
 @pytest.mark.parametrize("c,lam0", [(1, 3e-4), (2, 6e-5)])
@@ -1131,7 +1164,7 @@ def test_kinship_in_other_units(gpu_api, oracle, S):
     assert nm["logl_mle_H0"] == pytest.approx(logl_m, rel=1e-9)
     ref = oracle.lmm_analyze(4, U, evS, UtW, Uty, X, l_mle_null=l_m, logl_mle_H0=logl_m)
     got = gpu_api.LMM(a_mode=4, l_mle_null=l_m, logl_mle_H0=logl_m).AnalyzeBimbam(U, evS, UtW, Uty, X)
-    _cmp_stats(got, ref, 4, "kinship x %g" % S)
+    _cmp_stats(got, ref, 4, "kinship x %g" % S, _problem(U, evS, UtW, Uty, X))
 
 
 @pytest.mark.parametrize("n,c", [(500, 1), (402, 3)])
@@ -1172,7 +1205,7 @@ def test_more_than_sixteen_covariates(gpu_api, oracle, c):
     assert nm["l_remle_null"] == pytest.approx(l_r, rel=1e-3) and nm["logl_mle_H0"] == pytest.approx(logl_m, rel=1e-9)
     ref = oracle.lmm_analyze(4, U, ev, UtW, Uty, X, l_mle_null=l_m, logl_mle_H0=logl_m)
     got = gpu_api.LMM(a_mode=4, l_mle_null=l_m, logl_mle_H0=logl_m).AnalyzeBimbam(U, ev, UtW, Uty, X)
-    _cmp_stats(got, ref, 4, "c=%d covariates (wide kernels)" % c)
+    _cmp_stats(got, ref, 4, "c=%d covariates (wide kernels)" % c, _problem(U, ev, UtW, Uty, X))
 
 
 @pytest.mark.parametrize("n,l", [(100, 5), (200, 257), (330, 64), (129, 300), (517, 513)])
@@ -1208,3 +1241,80 @@ def test_records_kernel_short_k_loops_and_ragged_tiles(gpu_api, oracle, monkeypa
         err = np.max(np.abs(out[sp] - exact) / scale)
         assert err < 8 * 2.3e-16, (sp, err)
     assert np.max(np.abs(out["2"] - out["0"]) / scale) < 2 * 2.3e-16
+
+
+@pytest.mark.parametrize("n,l", [(300, 700), (517, 513), (1301, 300)])
+def test_records_kernel_variants_agree_bit_for_bit_and_the_library_says_which_ran(gpu_api, oracle, monkeypatch, n, l):
+    """the records kernel of the library in every combination of GEMMA_HIP_I8_ROWS = {16, 32} x GEMMA_HIP_I8_RASTER =
+    {0, 1, 2} x {fused planes, one plane per digit} x {7, 6 digits (odd / even plane counts)} through gemma_hip_dbg_utx: the int32
+    planes are exact integer sums, so U^T x must be the SAME BITS in all of them -- and gemma_hip_dbg_last_utx_kernel must name the
+    kernel the switch selects (bench.py labels its roofline from that report, not from the environment)."""
+    from gemma_amd import _lib as L
+    rng = np.random.default_rng(7 * n + l)
+    ind = np.ones(n, dtype=np.int32)
+    codes = rng.choice([0, 1, 2, 3], size=(l, n), p=[0.25, 0.06, 0.35, 0.34]).astype(np.uint8)
+    nb = (n + 3) // 4
+    pad = np.zeros((l, nb * 4), dtype=np.uint8)
+    pad[:, :n] = codes
+    raw = (pad[:, 0::4] | (pad[:, 1::4] << 2) | (pad[:, 2::4] << 4) | (pad[:, 3::4] << 6)).astype(np.uint8)
+    Q, _ = np.linalg.qr(rng.standard_normal((n, n)))
+    ev = np.sort(rng.uniform(0.0, 3.0, n))
+    UtW, Uty = Q.T @ np.ones((n, 1)), Q.T @ rng.standard_normal(n)
+    ref = {}
+    for digits in ("7", "6"):
+        monkeypatch.setenv("GEMMA_HIP_I8_DIGITS", digits)
+        for fuse in ("1", "0"):
+            monkeypatch.setenv("GEMMA_HIP_I8_FUSE", fuse)
+            for rows in ("16", "32"):
+                monkeypatch.setenv("GEMMA_HIP_I8_ROWS", rows)
+                for raster in ("0", "1", "2"):
+                    monkeypatch.setenv("GEMMA_HIP_I8_RASTER", raster)
+                    lmm = gpu_api.LMM(a_mode=1)
+                    lmm.setup(Q, ev, UtW, Uty, plink=True)
+                    lmm.set_indicator(ind)
+                    try:
+                        got = lmm.dbg_utx(raw, L.GENO_PLINK_2BIT, 1)
+                    finally:
+                        lmm.finish()
+                    k = gpu_api.last_utx_kernel()
+                    tag = (digits, fuse, rows, raster)
+                    assert k["variant"] == (L.UTX_KERNEL_RECORDS_R16 if rows == "16" else L.UTX_KERNEL_RECORDS_R32), (tag, k)
+                    assert k["name"] == ("i8gemm_sparse2_r16_kernel" if rows == "16" else "i8gemm_sparse2_kernel"), (tag, k)
+                    assert (k["rows"], k["digits"], k["fuse"], k["raster"]) == (int(rows), int(digits), int(fuse), int(raster)), (tag, k)
+                    if digits not in ref:
+                        ref[digits] = got
+                    else:
+                        assert got.tobytes() == ref[digits].tobytes(), tag
+    # 6 digits against 7: different roundings of U, so not the same bits -- but inside the 2^-47 model (tests/test_gpu_at_size.py)
+    ej = np.frexp(np.abs(Q).max(axis=0))[1].astype(np.float64)  # column maximum < 2^ej
+    bound = np.full(l, 2.0 * n)[:, None] * (np.exp2(ej - 47) + np.exp2(ej - 55))[None, :]  # |x_k| <= 2
+    diff = np.abs(ref["6"] - ref["7"])
+    assert diff.max() > 0 and np.all(diff <= 1.01 * bound + 1e-300)
+
+
+def test_reload_env_switches_the_product_between_two_batches_of_one_setup(gpu_api, oracle, monkeypatch):
+    """The library reads its GEMMA_HIP_* switches once per setup (no getenv on a launch path -- VERDICT r4 #11): a changed switch takes
+    effect at the next setup or at gemma_hip_reload_env(), not silently in the middle of a run."""
+    from gemma_amd import _lib as L
+    rng = np.random.default_rng(5)
+    ni_total, p = 400, 120
+    ind, raw = _plink_case(oracle, rng, ni_total, p)
+    n = int(ind.sum())
+    Q, _ = np.linalg.qr(rng.standard_normal((n, n)))
+    ev = np.sort(rng.uniform(0.0, 3.0, n))
+    lmm = gpu_api.LMM(a_mode=1)
+    lmm.setup(Q, ev, Q.T @ np.ones((n, 1)), Q.T @ rng.standard_normal(n), plink=True)
+    lmm.set_indicator(ind)
+    try:
+        lmm.batch(raw, L.GENO_PLINK_2BIT)
+        assert gpu_api.last_utx_path() == 1 and gpu_api.last_utx_kernel()["variant"] == L.UTX_KERNEL_RECORDS_R16
+        monkeypatch.setenv("GEMMA_HIP_UTX_I8", "0")
+        lmm.batch(raw, L.GENO_PLINK_2BIT)
+        assert gpu_api.last_utx_path() == 1  # not re-read per launch
+        gpu_api.reload_env()
+        lmm.batch(raw, L.GENO_PLINK_2BIT)
+        assert gpu_api.last_utx_path() == 0 and gpu_api.last_utx_kernel()["variant"] == L.UTX_KERNEL_DGEMM_F64
+    finally:
+        monkeypatch.delenv("GEMMA_HIP_UTX_I8")
+        gpu_api.reload_env()
+        lmm.finish()

@@ -159,3 +159,62 @@ def test_sharded_backtransformation_equals_single_rank(gpu_api, tmp_path, monkey
         assert float(d["tr"]) == tr1
     resid = np.linalg.norm(A @ U1 - U1 * w1[None, :]) / (np.linalg.norm(A, 2) * n * np.finfo(float).eps)
     assert resid < 30
+
+
+def _eigh_fail_worker(rank, world, port, case_path, outdir, env):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    os.environ["GEMMA_HIP_COMM"] = "shm"
+    os.environ.update(env)
+    import torch
+    import torch.distributed as dist
+    from gemma_amd import api
+    from gemma_amd import dist as gdist
+    from gemma_amd._lib import GemmaHipError
+
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    api.init(0, verbose=0)
+    assert gdist.native_comm_init()
+    K = torch.from_numpy(np.load(case_path)).to(dev)
+    n = K.shape[0]
+    U = torch.empty_like(K)
+    ev = torch.empty(n, dtype=torch.float64, device=dev)
+    verdict = "returned a result"
+    try:
+        api.EigenDecomp_Zeroed_sharded(K.clone(), U, ev)
+    except GemmaHipError as e:
+        verdict = "error: %s" % e
+    with open(os.path.join(outdir, "fail_rank%d.txt" % rank), "w") as f:
+        f.write(verdict)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("env", [{"GEMMA_HIP_EIGH_FAIL_RANK": "1"},
+                                 {"GEMMA_HIP_EIGH_SHARD_FORCE_DIFFER": "1", "GEMMA_HIP_EIGH_FAIL_FALLBACK": "1"}])
+def test_collective_eigensolver_ranks_agree_on_a_failure_outside_the_core(gpu_api, tmp_path, monkeypatch, env):
+    """(1) a rank that fails BEFORE the collective solver (its own allocations) and (2) a rank 0 that fails inside the
+    root-only fall-back used to leave the other ranks waiting in a collective for ever.  Now every rank takes part in the solver's
+    agreement and ALL of them return an error -- the spawn below would time out otherwise."""
+    import torch.multiprocessing as mp
+    from test_gpu_eigh import _sym
+    n = 1538
+    A = _sym(n, 77 + n, "kinship")
+    case = tmp_path / "K.npy"
+    np.save(case, A)
+    ctx = mp.spawn(_eigh_fail_worker, args=(2, _free_port(), str(case), str(tmp_path), dict(env, GEMMA_HIP_EIGH_STAGES="2")),
+                   nprocs=2, join=False)
+    import time
+    t0 = time.time()
+    while not ctx.join(timeout=5):
+        if time.time() - t0 > 150:
+            for p in ctx.processes:
+                p.kill()
+            pytest.fail("the ranks of a collective solve with one failing rank did not return: they wait for each other")
+    for r in range(2):
+        v = (tmp_path / ("fail_rank%d.txt" % r)).read_text()
+        assert v.startswith("error:"), "rank %d %s" % (r, v)
