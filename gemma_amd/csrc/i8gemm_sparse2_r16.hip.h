@@ -25,6 +25,10 @@
 #pragma once
 #include "i8gemm_sparse2.hip.h"
 
+#ifndef S2_R16_PREP_SPREAD
+#define S2_R16_PREP_SPREAD 0
+#endif
+
 namespace gemma_hip {
 
 __global__ __launch_bounds__(512, 2) void i8gemm_sparse2_r16_kernel(Sparse2Args g) {
@@ -122,6 +126,16 @@ __global__ __launch_bounds__(512, 2) void i8gemm_sparse2_r16_kernel(Sparse2Args 
     ms[i] = s2_expand((q >> 1) ? rec[i][1][3] : rec[i][0][3]);                                                    \
     asm volatile("" ::"v"(rec[i][0]), "v"(rec[i][1]));                                                            \
   } while (0)
+// the same in pieces (S2_R16_PREP_SPREAD): each operand register is rebuilt right behind the LAST matrix instruction of the K-tile
+// that reads it (step 7: D(0,P0) D(1,P0) D(0,P1) D(1,P1) S(0) S(1)), so the 66 VALU instructions of the preparation sit between
+// the step's matrix instructions instead of behind them
+#define GS_PREP_G(i, P) ga[i][P] = s2_unpack_g((q >> 1) ? rec[i][P][1] : rec[i][P][0])
+#define GS_PREP_M(i)                                                                                              \
+  do {                                                                                                            \
+    ix[i] = (q >> 1) ? rec[i][1][2] : rec[i][0][2];                                                               \
+    ms[i] = s2_expand((q >> 1) ? rec[i][1][3] : rec[i][0][3]);                                                    \
+    asm volatile("" ::"v"(rec[i][0]), "v"(rec[i][1]));                                                            \
+  } while (0)
 #define GS_D(i, SB, P, SL)                                                                                        \
   asm volatile("s_nop 1\n\tv_mfma_i32_16x16x64_i8 %0, %1, %2, %0"                                                 \
                : "+v"(accg[i][SB])                                                                                \
@@ -154,9 +168,19 @@ __global__ __launch_bounds__(512, 2) void i8gemm_sparse2_r16_kernel(Sparse2Args 
     GS_STEP(5, 1, { if (MORE) { GS_RREC(SN, 0, 0); GS_RREC(SN, 0, 1); GS_RREC(SN, 1, 0); GS_RREC(SN, 1, 1);       \
                                 GS_RT(SN, 0, 0); } });                                                             \
     GS_STEP(6, 2, { if (MORE) { GS_RT(SN, 1, 1); } });                                                             \
-    GS_STEP(7, 3, { if (MORE) { GS_RT(SN, 2, 2); } });                                                             \
-    if (MORE) { GS_PREP(0); GS_PREP(1); }                                                                         \
-    GEMMA_SB();                                                                                                   \
+    if (S2_R16_PREP_SPREAD && (MORE)) {                                                                           \
+      GS_D(0, 7, 0, 3); GEMMA_SB();                                                                               \
+      GS_D(1, 7, 0, 3); { GS_RT(SN, 2, 2); GS_PREP_G(0, 0); } GEMMA_SB();                                          \
+      GS_D(0, 7, 1, 3); { GS_PREP_G(1, 0); } GEMMA_SB();                                                           \
+      GS_D(1, 7, 1, 3); { GS_PREP_G(0, 1); } GEMMA_SB();                                                           \
+      GS_S(0, 7, 3); { GS_PREP_G(1, 1); } GEMMA_SB();                                                              \
+      GS_S(1, 7, 3); { GS_PREP_M(0); } GEMMA_SB();                                                                 \
+      { GS_PREP_M(1); } GEMMA_SB();                                                                                \
+    } else {                                                                                                      \
+      GS_STEP(7, 3, { if (MORE) { GS_RT(SN, 2, 2); } });                                                           \
+      if (MORE) { GS_PREP(0); GS_PREP(1); }                                                                       \
+      GEMMA_SB();                                                                                                 \
+    }                                                                                                             \
   } while (0)
 
   if (wave >= 4) __builtin_amdgcn_s_setprio(1);
@@ -234,6 +258,8 @@ __global__ __launch_bounds__(512, 2) void i8gemm_sparse2_r16_kernel(Sparse2Args 
 #undef GS_RREC
 #undef GS_RT
 #undef GS_PREP
+#undef GS_PREP_G
+#undef GS_PREP_M
 #undef GS_D
 #undef GS_S
 #undef GS_STEP
