@@ -26,6 +26,7 @@
 #include "i8gemm_dense2_proto.hip.h" // scripts/: an experiment, not part of the library
 #include "i8gemm_sparse2_g16_proto.hip.h" // scripts/: the records kernel with its genotype product on 16x16x64 (variant 6)
 #include "i8gemm_sparse2_r16.hip.h" // the shipped 16-row kernel (variant 7)
+#include "i8gemm_sparse2_r16_persist_proto.hip.h" // scripts/: persistent workgroups / spread operand preparation (variants 8, 9)
 
 using namespace gemma_hip;
 
@@ -175,6 +176,8 @@ int main(int argc, char **argv) {
                            S2_NST * S2_STAGE));
     CK(hipFuncSetAttribute(reinterpret_cast<const void *>(i8gemm_sparse2_r16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                            S2_NST * S2_STAGE));
+    CK(hipFuncSetAttribute(reinterpret_cast<const void *>(i8gemm_sparse2_r16p_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                           S2_NST * S2_STAGE));
   }
 #endif
   // CU_SPLIT=k (experiment): the product runs on a stream whose CU mask leaves k CUs out, and on exactly those a streaming kernel
@@ -227,6 +230,21 @@ int main(int argc, char **argv) {
     }
     if (variant == 7) {
       hipLaunchKernelGGL(i8gemm_sparse2_r16_kernel, grid2, dim3(512), S2_NST * S2_STAGE, mstream, g2);
+      return;
+    }
+    if (variant == 8) { // the same kernel, PERSISTENT workgroups: PERSIST_WGS (default 256 = one per CU) walk the (plane, tile) list
+      Sparse2ArgsP gp;
+      static_cast<Sparse2Args &>(gp) = g2;
+      gp.persist = 1;
+      gp.nplanes = (int)grid2.y;
+      const int wgs = getenv("PERSIST_WGS") ? atoi(getenv("PERSIST_WGS")) : 256;
+      hipLaunchKernelGGL(i8gemm_sparse2_r16p_kernel, dim3((unsigned)wgs, 1), dim3(512), S2_NST * S2_STAGE, mstream, gp);
+      return;
+    }
+    if (variant == 9) { // the prototype's non-persistent form (S2_R16_PREP_SPREAD decides what it differs in)
+      Sparse2ArgsP gp;
+      static_cast<Sparse2Args &>(gp) = g2;
+      hipLaunchKernelGGL(i8gemm_sparse2_r16p_kernel, grid2, dim3(512), S2_NST * S2_STAGE, mstream, gp);
       return;
     }
     if (variant == 2) {
@@ -287,7 +305,7 @@ int main(int argc, char **argv) {
            getenv("CU_MODE") ? getenv("CU_MODE") : "0", ((double)nplanes * mrows * npad * 4 + 3.0 * lpad * npad * 8) / 1e9, sms / reps);
   }
   // FULLCMP=1 (variants 6, 7): EVERY entry of every plane against the shipped kernel (variant 3) run on the same operands
-  if (getenv("FULLCMP") && atoi(getenv("FULLCMP")) && (variant == 6 || variant == 7)) {
+  if (getenv("FULLCMP") && atoi(getenv("FULLCMP")) && (variant == 6 || variant == 7 || variant == 8 || variant == 9)) {
     const size_t total = (size_t)nplanes * mrows * npad;
     int *C2 = nullptr;
     unsigned long long *dcnt = nullptr, hcnt = 0;
