@@ -82,6 +82,11 @@ def parse():
                          "oracle / the reference) -- ~80 s, reported under \"c4_leg\", never part of `value` (0 = skip)")
     ap.add_argument("--child", default="", help=argparse.SUPPRESS)
     ap.add_argument("--child-spec", default="", help=argparse.SUPPRESS)
+    ap.add_argument("--pipeline", type=int, default=0,
+                    help="0 (default): gemma_hip_lmm_batch_d, one stream, one block at a time.  1: the timed steps go through "
+                         "gemma_hip_lmm_batch_pipe_d -- the int8 product of block i + 1 on one CU partition beside the digit combine and per-SNP "
+                         "stage of block i on the other (GEMMA_HIP_PIPE_CUS, default 64); the timed region ends with the flush.  Measured in round "
+                         "5: no gain on a power-limited product (profiles/r05_pipeline_partition.txt)")
     ap.add_argument("--seed", type=int, default=20000)
     ap.add_argument("--state-file", default="",
                     help="measurement aid: keep the setup's result (U, eval, UtW, Uty, null scalars) in this file -- written "
@@ -602,8 +607,23 @@ def main():
 
     # ------------------------------------------------------------------ warmup + timed steps
     api.profile_enable(False)
+    piped = bool(args.pipeline) and os.environ.get("GEMMA_HIP_UTX_I8", "1") != "0"
+
+    def step(blk):
+        if piped:
+            lmm.batch_pipe(blk, L.GENO_PLINK_2BIT, out)
+        else:
+            lmm.batch(blk, L.GENO_PLINK_2BIT, out=out)
+    if piped:
+        # setup, not a step: the pipeline's two buffer sets (planes, packed block) are allocated by its first two calls
+        for _ in range(2):
+            step(blocks[0])
+        lmm.pipe_flush()
+        torch.cuda.synchronize()
     for i in range(args.warmup):
-        lmm.batch(blocks[i], L.GENO_PLINK_2BIT, out=out)
+        step(blocks[i])
+    if piped:
+        lmm.pipe_flush()
     torch.cuda.synchronize()
     api.profile_enable(True)
     for st in range(L.STAGE_UTX_POST + 1):
@@ -613,7 +633,9 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        lmm.batch(blocks[args.warmup + i], L.GENO_PLINK_2BIT, out=out)
+        step(blocks[args.warmup + i])
+    if piped:
+        lmm.pipe_flush()  # inside the timed region: the last block's combine and per-SNP stage are waited for
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -637,6 +659,32 @@ def main():
     n_nan = int(np.isnan(res[:, 4]).sum())
     i8_path = os.environ.get("GEMMA_HIP_UTX_I8", "1") != "0"
     timed_kernel = api.last_utx_kernel()  # the matrix kernel the timed steps launched, as the library's launch site recorded it
+    # the same blocks one at a time on one stream (gemma_hip_lmm_batch_d: what rounds 1-4 timed), outside the timed region: the
+    # records kernel on ALL CUs, and a bit-for-bit comparison of the last block's records with the pipelined run's
+    one_stream = None
+    if piped and world == 1:
+        out1 = torch.empty_like(out)
+        lmm.batch(blocks[args.warmup], L.GENO_PLINK_2BIT, out=out1)
+        torch.cuda.synchronize()
+        for st in range(L.STAGE_UTX_POST + 1):
+            api.profile_read(st, reset=True)
+        k1 = min(args.steps, 6)
+        t1 = time.perf_counter()
+        for i in range(k1):
+            lmm.batch(blocks[args.warmup + args.steps - k1 + i], L.GENO_PLINK_2BIT, out=out1)
+        torch.cuda.synchronize()
+        el1 = time.perf_counter() - t1
+        g1_ms, g1_n = api.profile_read(L.STAGE_UTX_GEMM, reset=True)
+        p1_ms, _ = api.profile_read(L.STAGE_UTX_POST, reset=True)
+        a1_ms, _ = api.profile_read(L.STAGE_ASSOC, reset=True)
+        i1_ms, _ = api.profile_read(L.STAGE_INGEST, reset=True)
+        same = bool(np.array_equal(out1.cpu().numpy(), res, equal_nan=True))
+        one_stream = {"steps": k1, "ms_per_step": round(el1 / k1 * 1e3, 3), "value": round(B * k1 / el1, 1), "unit": "SNPs/s",
+                      "stage_ms_per_step": {"ingest": round(i1_ms / k1, 3), "utx_gemm": round(g1_ms / k1, 3), "utx_post": round(p1_ms / k1, 3),
+                                            "assoc": round(a1_ms / k1, 3)},
+                      "utx_gemm_avg_launch_ms": round(g1_ms / max(1, g1_n), 3),
+                      "last_block_records_equal_the_pipelined_run_bit_for_bit": same}
+        del out1
 
     # the fp64 MFMA GEMM path on the same blocks, outside the contract's timed region (single GPU only)
     fp64_path = None
@@ -775,6 +823,7 @@ def main():
                             "operand the 32-row kernel takes 38.65 ms where full-range digits take 55.95, the 16-row kernel 40.8 / 49.8 "
                             "(profiles/r04_i8_operand_value_power.txt, r04_i8_g16s_prototype.txt, DESIGN 3.1c)" if sparse else "dense int8 MFMA",
                     "kernel_symbol": timed_kernel["name"], "kernel_variant": {k: timed_kernel[k] for k in ("variant", "rows", "digits", "fuse", "raster")},
+                    "cus": (n_cu - int(os.environ.get("GEMMA_HIP_PIPE_CUS", "64") or 0)) if piped else n_cu,
                     "traffic": None, "launches": gemm_n, "launches_per_step": gemm_launches_per_step,
                     "avg_launch_ms": round(gemm_ms / max(1, gemm_n), 3), "ms_per_step": round(gemm_avg_s * 1e3, 3),
                     # the same launch priced as the fp64 product it replaces (2 n^2 flop per SNP)
@@ -817,7 +866,12 @@ def main():
             "stage_ms_per_step": {"ingest": round(ing_ms / max(1, args.steps), 3), "utx_gemm": round(gemm_ms / max(1, args.steps), 3),
                                   "utx_post": round(post_ms / max(1, args.steps), 3),
                                   "assoc": round(assoc_ms / max(1, args.steps), 3),
-                                  "overlap": ("utx_post and assoc of row chunk c run on a side stream beside utx_gemm of chunk c + 1 "
+                                  "overlap": ("two blocks in flight (gemma_hip_lmm_batch_pipe_d): ingest + records + utx_gemm of block i + 1 on %d CUs beside "
+                                              "utx_post + assoc of block i on the other %s; the stage times overlap and do not add up to ms_per_step; "
+                                              "the timed region ends with the flush (the last block's utx_post + assoc are inside it)"
+                                              % (n_cu - int(os.environ.get("GEMMA_HIP_PIPE_CUS", "64") or 0), os.environ.get("GEMMA_HIP_PIPE_CUS", "64")))
+                                             if piped else
+                                             ("utx_post and assoc of row chunk c run on a side stream beside utx_gemm of chunk c + 1 "
                                               "(%d chunks per step): the stage times overlap and do not add up to ms_per_step"
                                               % int(round(gemm_launches_per_step))) if i8_path and gemm_launches_per_step > 1.5 else
                                              "none: one stream, the stage times add up to ms_per_step"},
@@ -856,6 +910,14 @@ def main():
                                                             (setup_once - eig_proj["1"] + eig_proj["8"] + p_cfg / 8 / per_gpu), 4)
                                                       if (eig_proj and setup_once) else None),
             "note": eig_note}
+        if one_stream:
+            # the kernel's own roofline on the whole chip, beside the pipelined step's (192 CUs, the other 64 busy behind it)
+            ops1 = 2.0 * ctypes_digits(L, n) * 2.0 * B * n * n
+            one_stream["roofline_frac_all_cus"] = round(ops1 * 0.75 / (one_stream["utx_gemm_avg_launch_ms"] * 1e-3) / 1e12 / INT8_MFMA_PEAK_TOPS, 4)
+            line["one_stream_leg"] = one_stream
+            line["roofline"]["note_partition"] = ("the timed steps launch this kernel on %d of %d CUs (gemma_hip_lmm_batch_pipe_d); achieved / frac "
+                                                  "price it against the WHOLE chip's peak; one_stream_leg.roofline_frac_all_cus is the same kernel on "
+                                                  "all CUs, one block at a time" % (line["roofline"]["cus"], n_cu))
         if fp64_path:
             line["fp64_gemm_path"] = fp64_path
         if dosage_path:

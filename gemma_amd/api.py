@@ -424,6 +424,19 @@ class LMM:
         L.check(L.lib().gemma_hip_lmm_batch(geno_kind, _ptr(geno), l, ld, _ptr(out)), "LMM.batch")
         return out
 
+    def batch_pipe(self, geno, geno_kind, out):
+        """LMM.batch with two blocks in flight (gemma_hip_lmm_batch_pipe_d; torch device tensors): the product of this block beside
+        the combine and per-SNP stage of the previous one, on a CU partition.  `out` holds this block's records only after
+        pipe_flush() (or any other batch call)."""
+        l = geno.shape[0]
+        rc = L.lib().gemma_hip_lmm_batch_pipe_d(geno_kind, C.c_void_p(geno.data_ptr()), l, _tld(geno),
+                                                C.c_void_p(out.data_ptr()), _stream())
+        L.check(rc, "LMM.batch_pipe")
+        return out
+
+    def pipe_flush(self):
+        L.check(L.lib().gemma_hip_lmm_pipe_flush(_stream()), "LMM.pipe_flush")
+
     def assoc(self, UtX, out=None):
         """Per-SNP stage only, on a device-resident SNP-major UtX (torch)."""
         import torch

@@ -80,6 +80,7 @@ struct Knobs {
   int force_generic = 0;   // GEMMA_HIP_FORCE_GENERIC
   int assoc_variant = 44;  // GEMMA_HIP_ASSOC_VARIANT
   int mvlmm_rt = 0;        // GEMMA_HIP_MVLMM_RT
+  int pipe_cus = 64;       // GEMMA_HIP_PIPE_CUS: CUs of the post partition of gemma_hip_lmm_batch_pipe_d (0: two plain streams, no masks)
   int kin_i8 = 1, kin_upper = 1, kin_lists = 1, kin_lists_oom = 0; // GEMMA_HIP_KIN_I8 / _UPPER / _LISTS / _LISTS_OOM
   long long kin_list_cap = 0;                                       // GEMMA_HIP_KIN_LIST_CAP (0: by block size)
   static int geti(const char *name, int dflt) {
@@ -111,6 +112,7 @@ struct Knobs {
     assoc_variant = geti("GEMMA_HIP_ASSOC_VARIANT", 44);
     const char *er = getenv("GEMMA_HIP_MVLMM_RT");
     mvlmm_rt = (er && er[0] == '1') ? 1 : 0;
+    pipe_cus = geti("GEMMA_HIP_PIPE_CUS", 64);
     const char *k1 = getenv("GEMMA_HIP_KIN_I8"), *k2 = getenv("GEMMA_HIP_KIN_UPPER"), *k3 = getenv("GEMMA_HIP_KIN_LISTS");
     const char *k4 = getenv("GEMMA_HIP_KIN_LISTS_OOM"), *k5 = getenv("GEMMA_HIP_KIN_LIST_CAP");
     kin_i8 = (k1 && k1[0] == '0') ? 0 : 1;
@@ -149,6 +151,18 @@ struct Ctx {
   // int8 product of chunk c + 1 (overlap_*)
   hipStream_t ov_stream = nullptr;
   hipEvent_t ov_ready[16] = {}, ov_done = nullptr;
+  // gemma_hip_lmm_batch_pipe_d: the product of block i + 1 on one CU partition beside the combine + per-SNP stage of block i on the
+  // other (xp_*).  What both stages of a block touch exists twice (A / C / mean / rowsur alternate between the live members of
+  // this struct and `shadow`); what only one stream touches exists once.
+  struct XPipe {
+    hipStream_t P = nullptr, Q = nullptr;
+    hipEvent_t in_ready = nullptr, prod_done[2] = {}, post_done[2] = {};
+    bool post_valid[2] = {false, false};
+    unsigned long long count = 0;
+    bool pending = false;
+    int cus = -1; // partition the streams were made for
+    DevBuf shadow_A, shadow_C, shadow_mean, shadow_rowsur;
+  } xp;
   int kin_tmap_tm = 0, kin_tmap_tn = 0, kin_tmap_count = 0;
 
   // lmm state
@@ -292,6 +306,8 @@ inline hipStream_t S(void *s) { return reinterpret_cast<hipStream_t>(s); }
 } // namespace
 
 static void pipe_release(); // pipelined host-block path, defined with lmm_batch_submit
+static void xp_release();   // two-block product / post pipeline, defined with lmm_batch_pipe_d
+static int xp_flush_fwd(hipStream_t s);
 static void raster_release() {
   for (auto &r : g_ctx.i8_raster) {
     r.dev.release();
@@ -366,6 +382,7 @@ extern "C" void gemma_hip_shutdown(void) {
   g_ctx.table_P.release(); g_ctx.U_even.release();
   g_ctx.U_even_of = nullptr;
   pipe_release(); // pinned slots, copy stream and events of the pipelined host-block path
+  xp_release();
   if (g_ctx.ov_stream) {
     (void)hipStreamDestroy(g_ctx.ov_stream);
     for (auto &e : g_ctx.ov_ready)
@@ -1503,6 +1520,10 @@ extern "C" int gemma_hip_lmm_assoc_d(const double *UtX_d, size_t l, size_t ld_ut
   if (!g_ctx.lmm_active) return fail(GEMMA_HIP_ESTATE, "lmm_assoc before lmm_setup");
   if (l == 0) return GEMMA_HIP_OK;
   if (!UtX_d || !out_d || ld_utx < g_ctx.cfg.n) return fail(GEMMA_HIP_EINVAL, "lmm_assoc: bad UtX/ld");
+  {
+    int rcf = xp_flush_fwd(S(stream));
+    if (rcf) return rcf;
+  }
   return launch_assoc(UtX_d, l, ld_utx, out_d, S(stream));
 }
 
@@ -1897,10 +1918,84 @@ static int gemm_U(const double **U, long *ld, hipStream_t s) {
   return GEMMA_HIP_OK;
 }
 
+// ---- stream / buffer plumbing of gemma_hip_lmm_batch_pipe_d (the two-block pipeline, described where that entry point is defined)
+static void xp_release() {
+  Ctx::XPipe &x = g_ctx.xp;
+  if (x.P) (void)hipStreamDestroy(x.P);
+  if (x.Q) (void)hipStreamDestroy(x.Q);
+  if (x.in_ready) (void)hipEventDestroy(x.in_ready);
+  for (int i = 0; i < 2; ++i) {
+    if (x.prod_done[i]) (void)hipEventDestroy(x.prod_done[i]);
+    if (x.post_done[i]) (void)hipEventDestroy(x.post_done[i]);
+    x.prod_done[i] = x.post_done[i] = nullptr;
+    x.post_valid[i] = false;
+  }
+  x.P = x.Q = nullptr;
+  x.in_ready = nullptr;
+  x.count = 0;
+  x.pending = false;
+  x.cus = -1;
+  x.shadow_A.release(); x.shadow_C.release(); x.shadow_mean.release(); x.shadow_rowsur.release();
+}
+static int xp_init() {
+  Ctx::XPipe &x = g_ctx.xp;
+  const int ncu = g_ctx.prop.multiProcessorCount;
+  int cus = g_ctx.knobs.pipe_cus;
+  if (cus < 0 || cus * 2 > ncu || ncu % 32 != 0 || cus % 8 != 0 || (cus && (ncu / 8) % (cus / 8) != 0)) cus = 0;
+  if (x.P && x.cus == cus) return GEMMA_HIP_OK;
+  HIPCHK(hipDeviceSynchronize());
+  xp_release();
+  if (cus > 0) {
+    // Mask bit c = CU c / 8 of XCD c % 8 (scripts/xcc_mask_probe.hip, profiles/r05_pipeline_partition.txt), and a mask that leaves an
+    // XCD WITHOUT CUs is not applied at all (the stream then runs on every CU) -- so the post partition takes the same cus / 8 CUs
+    // out of EVERY XCD, evenly spaced over its 32 (an uneven cut lets the dispatcher's round over the XCDs wait for the short one:
+    // 16 CUs taken from one XCD cost the product 75 %).
+    const int words = ncu / 32, per_xcd = cus / 8, cu_per_xcd = ncu / 8, stepj = cu_per_xcd / per_xcd;
+    std::vector<unsigned> mp((size_t)words, 0xFFFFFFFFu), mq((size_t)words, 0u);
+    for (int j = 0; j < cu_per_xcd; j += stepj)
+      for (int xcd = 0; xcd < 8; ++xcd) {
+        const int c = 8 * j + xcd;
+        mp[c >> 5] &= ~(1u << (c & 31));
+        mq[c >> 5] |= 1u << (c & 31);
+      }
+    HIPCHK(hipExtStreamCreateWithCUMask(&x.P, (uint32_t)words, mp.data()));
+    HIPCHK(hipExtStreamCreateWithCUMask(&x.Q, (uint32_t)words, mq.data()));
+  } else {
+    // blocking streams like the masked ones: ordered behind the legacy default stream without an event (see lmm_batch_pipe_d)
+    HIPCHK(hipStreamCreateWithFlags(&x.P, hipStreamDefault));
+    HIPCHK(hipStreamCreateWithFlags(&x.Q, hipStreamDefault));
+  }
+  HIPCHK(hipEventCreateWithFlags(&x.in_ready, hipEventDisableTiming));
+  for (int i = 0; i < 2; ++i) {
+    HIPCHK(hipEventCreateWithFlags(&x.prod_done[i], hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&x.post_done[i], hipEventDisableTiming));
+  }
+  x.cus = cus;
+  return GEMMA_HIP_OK;
+}
+// everything the pipeline still has in flight is ordered in front of whatever the caller puts on s next
+static int xp_flush(hipStream_t s) {
+  Ctx::XPipe &x = g_ctx.xp;
+  if (!x.pending) return GEMMA_HIP_OK;
+  for (int i = 0; i < 2; ++i)
+    if (x.post_valid[i]) HIPCHK(hipStreamWaitEvent(s, x.post_done[i], 0));
+  x.pending = false;
+  return GEMMA_HIP_OK;
+}
+static void xp_swap_sets() {
+  Ctx::XPipe &x = g_ctx.xp;
+  std::swap(g_ctx.i8_A, x.shadow_A); std::swap(g_ctx.i8_C, x.shadow_C);
+  std::swap(g_ctx.i8_mean, x.shadow_mean); std::swap(g_ctx.i8_rowsur, x.shadow_rowsur);
+}
+
 // UtX (l x ldx, SNP-major) = mean-imputed X (l x n) * U (n x n): row s is (U^T x_s)^T, i.e. the column the
 // reference's fast_dgemm("T","N",U,Xlarge) (src/lmm.cpp:1521) produces for SNP s.  path < 0: by GEMMA_HIP_UTX_I8.
 static int compute_utx(int kind, const void *geno, size_t l, size_t ld, int path, double **UtX_out, size_t *ldx_out,
                        hipStream_t s) {
+  {
+    int rcf = xp_flush(s); // blocks of gemma_hip_lmm_batch_pipe_d still in flight share this call's buffers
+    if (rcf) return rcf;
+  }
   const size_t n = g_ctx.cfg.n;
   const size_t ldx = (n + 1) & ~(size_t)1;
   const bool want_i8 = (path < 0 ? utx_i8_mode() == 1 : path == 1);
@@ -2034,6 +2129,89 @@ static int lmm_batch_plink_chunked(const void *geno, size_t l, size_t ld, gemma_
   return rc;
 }
 
+// ---- two blocks in flight on a CU partition (round 5) -----------------------------------------------------------------------
+// A step of the PLINK path is the int8 product (50 ms at n = B = 20 000: matrix pipe, power) followed by the digit combine and the
+// per-SNP stage (5.6 ms: HBM and latency, the matrix pipe idle).  Side by side on ALL CUs they only take each other's slots and watts
+// (round 3: 62.7 -> 64.2 ms, overlap_chunks above).  This entry point puts them on a PARTITION of the CUs
+// (hipExtStreamCreateWithCUMask): block i + 1's ingest, records and product on stream P (all but GEMMA_HIP_PIPE_CUS CUs, the same
+// number taken out of every XCD) while block i's combine and per-SNP stage run on stream Q (those CUs):
+//   caller's stream s --in_ready--> P: [wait post_done(i - 1: same buffer set)] ingest, records, product --prod_done(i)--> Q: combine,
+//   per-SNP stage --post_done(i)--> (flush: s waits for the last one)
+// Every result is the one gemma_hip_lmm_batch_d gives, bit for bit (same kernels, same launch shapes; the PLINK carry chain runs in
+// block order on Q): tests/test_gpu_parity.py::test_lmm_pipe_blocks_equal_plain_batches.
+// MEASURED (round 5, n = B = 20 000, profiles/r05_pipeline_partition.txt): IT DOES NOT PAY ON THIS PART, so bench.py times the
+// one-stream step (--pipeline 0) and this stays an option.  The records kernel on 224 CUs (4 out of every XCD) takes 55.2 ms
+// against 50.4 on 256 (the clock gained from the smaller power draw gives back a third of the 8 / 7), the 32 CUs need 13.6 ms for the
+// traffic of the stages behind it: 55.8 ms per step against 56.4.  Without a partition (two plain streams, or a mask that the
+// runtime does not apply) the product takes 55.7 ms with the other stages' kernels among its workgroups: 56.7-56.9 ms per step
+// against 56.7-57.0 one block at a time, in five configurations on two boxes.  The product is limited by power and the stages behind
+// it by HBM; whatever runs beside the product takes its watts.
+static int xp_flush_fwd(hipStream_t s) { return xp_flush(s); }
+
+extern "C" int gemma_hip_lmm_pipe_flush(void *stream) {
+  NEED_INIT();
+  return xp_flush(S(stream));
+}
+
+extern "C" int gemma_hip_lmm_batch_pipe_d(int kind, const void *geno, size_t l, size_t ld, gemma_sumstat *out_d, void *stream) {
+  NEED_INIT();
+  if (!g_ctx.lmm_active) return fail(GEMMA_HIP_ESTATE, "lmm_batch_pipe before lmm_setup");
+  if (l == 0) return GEMMA_HIP_OK;
+  int rc = check_batch_args("lmm_batch_pipe", kind, geno, l, ld, out_d);
+  if (rc) return rc;
+  hipStream_t s = S(stream);
+  if (kind != GEMMA_GENO_PLINK_2BIT || utx_i8_mode() != 1 || i8_sparse_mode() != 2) {
+    // nothing to pipeline on this path: the plain batch, behind whatever is still in flight
+    if ((rc = xp_flush(s))) return rc;
+    return gemma_hip_lmm_batch_d(kind, geno, l, ld, out_d, stream);
+  }
+  if ((rc = xp_init())) return rc;
+  Ctx::XPipe &x = g_ctx.xp;
+  const int slot = (int)(x.count & 1);
+  const size_t n = g_ctx.cfg.n;
+  const size_t ldx = (n + 1) & ~(size_t)1;
+  // allocations first (a growing buffer is freed and re-allocated: hipFree waits for the device, which is what an in-flight reader
+  // of the old buffer needs)
+  if (g_ctx.UtX.reserve(l * ldx * 8)) return fail(GEMMA_HIP_ENOMEM, "lmm_batch_pipe: cannot allocate %zu bytes", l * ldx * 8);
+  xp_swap_sets(); // this block's A / C / mean / rowsur: the set block i - 2 used (its post stage is waited for below)
+  // The block handed in is ready when the work already queued on s is done.  For the legacy default stream (s == 0: torch's current
+  // stream unless the caller made another) nothing is recorded: streams with a CU mask are BLOCKING streams (the creating call takes
+  // no flags), so P is ordered behind everything issued to stream 0 before this call anyway -- and any operation ON stream 0,
+  // an event record included, is a barrier across P and Q that would serialise the two partitions again (measured: that one
+  // record per call took the whole overlap away, 57.3 against 56.8 ms per step).
+  if (s != nullptr) {
+    HIPCHK(hipEventRecord(x.in_ready, s));
+    HIPCHK(hipStreamWaitEvent(x.P, x.in_ready, 0));
+  }
+  if (x.post_valid[slot]) HIPCHK(hipStreamWaitEvent(x.P, x.post_done[slot], 0));
+  g_ctx.last_utx_path = 1;
+  I8Dims d;
+  if ((rc = i8_begin(l, &d, x.P))) return rc;
+  {
+    ProfScope ps(GEMMA_STAGE_INGEST, x.P);
+    IngestI8Args a;
+    a.src = reinterpret_cast<const unsigned char *>(geno); a.ld = (long)ld; a.l = (long)l;
+    a.idx_map = g_ctx.have_map ? g_ctx.idx_map.as<int>() : nullptr;
+    a.n = (int)d.n; a.A = g_ctx.i8_A.as<int8_t>(); a.ldk = (long)d.ldk;
+    a.mean = g_ctx.i8_mean.as<double>();
+    hipLaunchKernelGGL(ingest_i8_kernel, dim3((unsigned)((l + 3) / 4)), dim3(256), 0, x.P, a);
+    HIPCHK(hipGetLastError());
+  }
+  if ((rc = i8_meta_build(d, x.P))) return rc;
+  if ((rc = i8_gemm_rows(d, 0, d.lpad, x.P))) return rc;
+  HIPCHK(hipEventRecord(x.prod_done[slot], x.P));
+  HIPCHK(hipStreamWaitEvent(x.Q, x.prod_done[slot], 0));
+  double *UtX = g_ctx.UtX.as<double>();
+  rc = i8_post_rows(l, d, 0, l, UtX, ldx, x.Q);
+  if (!rc) rc = launch_assoc(UtX, l, ldx, out_d, x.Q);
+  // whatever happened, what was queued on Q is waited for by the next user of this buffer set and by the flush
+  (void)hipEventRecord(x.post_done[slot], x.Q);
+  x.post_valid[slot] = true;
+  x.pending = true;
+  x.count += 1;
+  return rc;
+}
+
 extern "C" int gemma_hip_lmm_batch_d(int kind, const void *geno, size_t l, size_t ld, gemma_sumstat *out_d,
                                      void *stream) {
   NEED_INIT();
@@ -2042,6 +2220,7 @@ extern "C" int gemma_hip_lmm_batch_d(int kind, const void *geno, size_t l, size_
   int rc = check_batch_args("lmm_batch", kind, geno, l, ld, out_d);
   if (rc) return rc;
   hipStream_t s = S(stream);
+  if ((rc = xp_flush(s))) return rc; // blocks of gemma_hip_lmm_batch_pipe_d still in flight share this call's buffers
   if (kind == GEMMA_GENO_PLINK_2BIT) {
     const int chunks = overlap_chunks(l);
     if (chunks > 1) return lmm_batch_plink_chunked(geno, l, ld, out_d, chunks, s);
@@ -2754,6 +2933,7 @@ extern "C" int gemma_hip_lmm_finish(double *time_UtX_min, double *time_opt_min) 
   if (!g_ctx.lmm_active) return fail(GEMMA_HIP_ESTATE, "lmm_finish before lmm_setup");
   HIPCHK(hipDeviceSynchronize());
   pipe_release(); // blocks still in flight are dropped with the state
+  xp_release();
   prof_collect(GEMMA_STAGE_UTX_GEMM);
   prof_collect(GEMMA_STAGE_UTX_POST);
   prof_collect(GEMMA_STAGE_ASSOC);

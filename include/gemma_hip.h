@@ -188,6 +188,16 @@ int gemma_hip_lmm_set_indicator(const int *indicator_idv, size_t ni_total);
 int gemma_hip_lmm_batch(int geno_kind, const void *geno, size_t l, size_t ld, gemma_sumstat *out);
 int gemma_hip_lmm_batch_d(int geno_kind, const void *geno_d, size_t l, size_t ld,
                           gemma_sumstat *out_d, void *stream);
+/* gemma_hip_lmm_batch_d with TWO BLOCKS IN FLIGHT on a CU partition (round 5; the loop of src/lmm.cpp:1526-1562 has no dependency
+ * between blocks except AnalyzePlink's beta / se carry, which stays in block order): ingest, records and the int8 product of this
+ * block run on 192 of the 256 CUs while the digit combine and the per-SNP stage of the PREVIOUS block run on the other 64 (two of the
+ * eight CUs of every shader engine; GEMMA_HIP_PIPE_CUS=32|64|...; 0 = two plain streams).  The call returns when the work is QUEUED:
+ * out_d of a block is complete only after gemma_hip_lmm_pipe_flush(stream) has ordered `stream` behind it (or after any other
+ * batch entry point, which flushes first); geno_d may be overwritten once work queued on `stream` AFTER the next call (or the
+ * flush) runs.  Records are the ones gemma_hip_lmm_batch_d writes, bit for bit.  PLINK 2-bit blocks on the records kernel only;
+ * every other input takes gemma_hip_lmm_batch_d. */
+int gemma_hip_lmm_batch_pipe_d(int geno_kind, const void *geno_d, size_t l, size_t ld, gemma_sumstat *out_d, void *stream);
+int gemma_hip_lmm_pipe_flush(void *stream);
 /* The same for a STREAM of host blocks, pipelined (pinned, double-buffered H2D; the feeder this replaces is the
  * per-SNP read loop of src/lmm.cpp:1776-1827): submit copies the block into one of two pinned staging slots and queues its
  * H2D copy (copy stream), the batch (compute stream, after the copy) and the D2H of its SUMSTAT records; collect waits for

@@ -25,6 +25,34 @@ int main() {
   hipMalloc(&d, N * 8);
   std::vector<int> h(2 * N);
   hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+  // which CUs does a mask leave?  distinct (XCC, HW_ID bits 8..15 = CU / shader array / shader engine) over all workgroups
+  for (int kind = 0; kind < 5; ++kind) {
+    unsigned mm[8];
+    for (int w = 0; w < 8; ++w) mm[w] = 0xFFFFFFFFu;
+    const char *what[5] = {"no bit cleared", "every 4th bit cleared (64)", "bits 0..31 cleared", "bits 0..127 cleared", "every 2nd bit cleared (128)"};
+    for (int c = 0; c < 256; ++c) {
+      const bool clr = (kind == 1 && c % 4 == 0) || (kind == 2 && c < 32) || (kind == 3 && c < 128) || (kind == 4 && c % 2 == 0);
+      if (clr) mm[c >> 5] &= ~(1u << (c & 31));
+    }
+    hipStream_t s;
+    if (hipExtStreamCreateWithCUMask(&s, 8, mm) != hipSuccess) { printf("cannot create masked stream\n"); return 1; }
+    hipMemsetAsync(d, 0xFF, N * 8, s);
+    hipLaunchKernelGGL(k, dim3(N), dim3(512), 128 * 1024, s, d);
+    hipStreamSynchronize(s);
+    hipMemcpy(h.data(), d, N * 8, hipMemcpyDeviceToHost);
+    std::vector<int> seen;
+    int perx[8] = {0};
+    for (int b = 0; b < N; ++b) {
+      const int key = ((h[2 * b] & 15) << 16) | (h[2 * b + 1] & 0xFF00);
+      bool f = false;
+      for (int v : seen) f = f || v == key;
+      if (!f) { seen.push_back(key); perx[h[2 * b] & 7]++; }
+    }
+    printf("%-34s: %zu distinct CUs hold the %d workgroups; per XCD:", what[kind], seen.size(), N);
+    for (int x = 0; x < 8; ++x) printf(" %d", perx[x]);
+    printf("\n");
+    hipStreamDestroy(s);
+  }
   for (int off = -1; off < 8; off += (off < 0 ? 1 : 7)) { // no mask, XCD 0 out, XCD 7 out
     unsigned mm[8];
     for (int w = 0; w < 8; ++w) mm[w] = 0xFFFFFFFFu;

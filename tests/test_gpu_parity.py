@@ -1318,3 +1318,56 @@ def test_reload_env_switches_the_product_between_two_batches_of_one_setup(gpu_ap
         monkeypatch.delenv("GEMMA_HIP_UTX_I8")
         gpu_api.reload_env()
         lmm.finish()
+
+
+@pytest.mark.parametrize("cus", ["64", "32", "0"])
+def test_lmm_pipe_blocks_equal_plain_batches(gpu_api, oracle, monkeypatch, cus):
+    """gemma_hip_lmm_batch_pipe_d (round 5): ingest + records + int8 product of block i + 1 on one CU partition beside the digit combine
+    and per-SNP stage of block i on the other (GEMMA_HIP_PIPE_CUS = 64: two of every shader engine's eight CUs; 32; 0 = two plain
+    streams).  Five blocks of different heights (so that every buffer is re-sized while its twin is in flight), SNPs nobody is called at
+    in the middle and at the START of a block (AnalyzePlink's beta / se carry crosses the block boundary in block order), then a plain
+    batch behind the unflushed pipeline (it must flush by itself), then the pipeline again: every record must be the one
+    gemma_hip_lmm_batch_d writes, bit for bit."""
+    import torch
+    from gemma_amd import _lib as L
+    monkeypatch.setenv("GEMMA_HIP_PIPE_CUS", cus)
+    rng = np.random.default_rng(77)
+    ni_total, p = 900, 3300
+    ind = np.ones(ni_total, dtype=np.int32)
+    _, raw = _plink_case(oracle, rng, ni_total, p, drop=0.0, miss=0.03)
+    raw[700:702] = 0x55   # nobody called: NaN rows in the middle of the second block
+    raw[1500] = 0x55      # ... and as the first row of the fourth block
+    n = ni_total
+    Kg = oracle.bed_decode(raw[:600], ni_total)
+    U, ev, _ = oracle.eigen_decomp_zeroed(oracle.center_matrix(oracle.calc_kin(Kg, 1)))
+    y = rng.standard_normal(n)
+    dev = torch.device("cuda", 0)
+    tU, te = torch.from_numpy(U).to(dev), torch.from_numpy(ev).to(dev)
+    tW, ty = torch.from_numpy(np.ascontiguousarray(U.T @ np.ones((n, 1)))).to(dev), torch.from_numpy(U.T @ y).to(dev)
+    cuts = [0, 500, 1200, 1500, 2800, 3300]
+    blocks = [torch.from_numpy(raw[a:b].copy()).to(dev) for a, b in zip(cuts, cuts[1:])]
+
+    def run(pipe):
+        lmm = gpu_api.LMM(a_mode=1)
+        lmm.setup(tU, te, tW, ty, plink=True)
+        outs = [torch.full((b.shape[0], 8), -7.0, dtype=torch.float64, device=dev) for b in blocks]
+        try:
+            if pipe:
+                for b, o in zip(blocks[:3], outs[:3]):
+                    lmm.batch_pipe(b, L.GENO_PLINK_2BIT, o)
+                lmm.batch(blocks[3], L.GENO_PLINK_2BIT, out=outs[3])  # flushes by itself
+                lmm.batch_pipe(blocks[4], L.GENO_PLINK_2BIT, outs[4])
+                lmm.pipe_flush()
+            else:
+                for b, o in zip(blocks, outs):
+                    lmm.batch(b, L.GENO_PLINK_2BIT, out=o)
+            torch.cuda.synchronize()
+            return np.concatenate([o.cpu().numpy() for o in outs])
+        finally:
+            lmm.finish()
+
+    plain, piped, piped2 = run(False), run(True), run(True)
+    assert np.isfinite(plain[:, 4]).sum() > p - 10 and not np.any(plain == -7.0)
+    assert plain[700, 0] == plain[699, 0] and plain[1500, 0] == plain[1499, 0]  # the carry is what is being tested
+    assert piped.tobytes() == plain.tobytes()
+    assert piped2.tobytes() == plain.tobytes()
