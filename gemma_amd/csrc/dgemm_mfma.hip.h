@@ -57,6 +57,11 @@ struct GemmArgs {
   // CUs) fill the chip this way without extra streams -- whose number of hardware queues the library does not control.
   int kslices = 1;
   long kslice = 0, cslice = 0;
+  // round 5: every off-diagonal tile ALSO stores its transpose at C[col][row] (symmetric results formed on the upper-triangle tiles
+  // only -- the eigensolver's rank-256 update of the trailing matrix: the separate mirror pass, a read and a write of half the
+  // matrix per panel, goes away).  Lane (l15, l4) holds rows l4 + 4 r of column l15 of a 16 x 16 block: for one r the four lane
+  // groups write four consecutive doubles of a transposed row, the four r together its whole 128-byte line.
+  int mirror = 0;
 };
 template <bool A_KM, bool B_KN>
 __device__ __forceinline__ void gemm_take_slice(GemmArgs &g) {
@@ -292,6 +297,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 ? 4 : 2)) void dgemm_mfma_kernel(
           double v = alpha * acc[i][j][r];
           if (beta != 0.0) v += beta * (*c);
           *c = v;
+          if (g.mirror && tm != tn) g.C[col * g.ldc + row] = v;
         }
       }
     }
@@ -427,6 +433,7 @@ __global__ __launch_bounds__(256, 2) void dgemm_mfma_pipe_kernel(GemmArgs g) {
         double v = alpha * acc[i][j][r];
         if (beta != 0.0) v += beta * (*c);
         *c = v;
+        if (g.mirror && tm != tn) g.C[col * g.ldc + row] = v;
       }
     }
   }
@@ -627,6 +634,7 @@ __global__ __launch_bounds__(256, 2) void dgemm_mfma_glds_kernel(GemmArgs g) {
         double v = alpha * acc[i][j][r];
         if (beta != 0.0) v += beta * (*c);
         *c = v;
+        if (g.mirror && tm != tn) g.C[col * g.ldc + row] = v;
       }
     }
   }
@@ -813,12 +821,14 @@ static inline hipError_t launch_dgemm_t(GemmArgs g, hipStream_t s) {
   return hipSuccess;
 }
 
-// ta/tb in {'N','T'} with the cblas row-major meaning
+// ta/tb in {'N','T'} with the cblas row-major meaning; mirror (with syrk_upper, M == N): the lower triangle is written too, as the
+// transpose of the upper tiles (GemmArgs::mirror)
 static inline hipError_t launch_dgemm(char ta, char tb, long M, long N, long K, double alpha,
                                       const double *A, long lda, const double *B, long ldb,
                                       double beta, double *C, long ldc, bool syrk_upper,
-                                      bool square_a, hipStream_t s) {
+                                      bool square_a, hipStream_t s, bool mirror = false) {
   GemmArgs g;
+  g.mirror = (mirror && syrk_upper && M == N) ? 1 : 0;
   g.A = A; g.B = B; g.C = C;
   g.M = M; g.N = N; g.K = K;
   g.lda = lda; g.ldb = ldb; g.ldc = ldc;

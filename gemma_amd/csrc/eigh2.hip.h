@@ -1378,6 +1378,8 @@ static inline int eig2_sy2sb(double *A, long n, EigWs &ws, Eig2Ws &w2, hipStream
     if (ncu <= 0) ncu = 1;
   }
   if (persist) EIG_HIP(hipMemsetAsync(w2.pbar, 0, 4 * sizeof(int), s));
+  const char *emi = getenv("GEMMA_HIP_EIGH_MIRROR");
+  const bool fused_mirror = !(emi && emi[0] == 'p');
   for (long j0 = 0;; j0 += E2_B) {
     const long r0 = j0 + E2_B, m = n - r0;
     if (m < 2) break;
@@ -1462,8 +1464,11 @@ static inline int eig2_sy2sb(double *A, long n, EigWs &ws, Eig2Ws &w2, hipStream
     EIG_HIP(hipMemcpy2DAsync(SA, n * 8, Vr, n * 8, m * 8, E2_B, hipMemcpyDeviceToDevice, s));
     EIG_HIP(hipMemcpy2DAsync(SB, n * 8, Wr, n * 8, m * 8, E2_B, hipMemcpyDeviceToDevice, s));
     EIG_HIP(hipMemcpy2DAsync(SB + (size_t)E2_B * n, n * 8, Vr, n * 8, m * 8, E2_B, hipMemcpyDeviceToDevice, s));
-    EIG_HIP(launch_dgemm('T', 'N', m, m, 2 * E2_B, -1.0, SA, n, SB, n, 1.0, A22, n, true, false, s));
-    {
+    // round 5: the product's epilogue writes the transposed tiles itself (GemmArgs::mirror) -- the mirror pass was 0.51 s of the
+    // 4.56 s of this stage at n = 50 000 (390 launches, a read and a write of half the trailing matrix each);
+    // GEMMA_HIP_EIGH_MIRROR=pass restores it
+    EIG_HIP(launch_dgemm('T', 'N', m, m, 2 * E2_B, -1.0, SA, n, SB, n, 1.0, A22, n, true, false, s, fused_mirror));
+    if (!fused_mirror) {
       const unsigned nb32 = (unsigned)((m + 31) / 32);
       hipLaunchKernelGGL(e2_mirror_upper_kernel, dim3(nb32, nb32), dim3(32, 8), 0, s, A22, m, n);
     }
