@@ -756,6 +756,7 @@ def main():
             lmm.batch(Xd[i % 2], L.GENO_F64_SNP_MAJOR, out=outd)
         torch.cuda.synchronize()
         eld = time.perf_counter() - t1
+        dos_kernel = api.last_utx_kernel()  # the library's launch site says which kernel the planes ran on
         gd_ms, gd_n = api.profile_read(L.STAGE_UTX_GEMM)
         pd_ms, _ = api.profile_read(L.STAGE_UTX_POST)
         id_ms, _ = api.profile_read(L.STAGE_INGEST)
@@ -779,7 +780,8 @@ def main():
                        "utx_path": api.UTX_PATHS.get(took, str(took)),
                        "stage_ms_per_step": {"ingest_and_pack": round(id_ms / args.dosage_steps, 3), "utx_gemm": round(gd_ms / args.dosage_steps, 3),
                                              "utx_post": round(pd_ms / args.dosage_steps, 3)},
-                       "roofline": {"kernel": "i8gemm_packed_kernel_t<false, true> (one signed byte plane x %d digits of U, dense int8 MFMA)" % dgd,
+                       "roofline": {"kernel": "%s (one signed byte plane x %d digits of U, dense int8 MFMA)" % (dos_kernel["name"], dgd),
+                                    "kernel_variant": {k: dos_kernel[k] for k in ("variant", "rows", "digits")},
                                     "bound": "mfma", "achieved": round(dgd * 2.0 * B * n * n / gd_s / 1e12, 1), "peak": INT8_MFMA_PEAK_TOPS,
                                     "unit": "TOP/s", "frac": round(dgd * 2.0 * B * n * n / gd_s / 1e12 / INT8_MFMA_PEAK_TOPS, 4),
                                     "launches_per_step": 1, "ms_per_step": round(gd_s * 1e3, 3)},

@@ -50,7 +50,7 @@ class UtxKernelInfo(C.Structure):
 
 
 UTX_KERNEL_DGEMM_F64, UTX_KERNEL_DENSE_I8, UTX_KERNEL_SPARSE_BYTES, UTX_KERNEL_RECORDS_R32, UTX_KERNEL_RECORDS_R16, \
-    UTX_KERNEL_DOSAGE_I8 = range(6)
+    UTX_KERNEL_DOSAGE_I8, UTX_KERNEL_DOSAGE_I8_R16 = range(7)
 
 
 class QcCfg(C.Structure):

@@ -8,7 +8,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libgemma_hip.so")
 # one object per source, compiled concurrently; the headers each one depends on (staleness by mtime)
 UNITS = {
-    "gemma_hip.hip": ["dgemm_mfma.hip.h", "lmm_grid.hip.h", "i8gemm.hip.h", "i8gemm_sparse.hip.h", "i8gemm_sparse2.hip.h", "i8gemm_sparse2_r16.hip.h", "lmm_assoc.hip.h",
+    "gemma_hip.hip": ["dgemm_mfma.hip.h", "lmm_grid.hip.h", "i8gemm.hip.h", "i8gemm_sparse.hip.h", "i8gemm_sparse2.hip.h", "i8gemm_sparse2_r16.hip.h", "i8gemm_dense16.hip.h", "lmm_assoc.hip.h",
                       "lmm_search.hip.h", "comm.hip.h", "comm_shm.hpp", "kin_i8.hip.h", "ingest.hip.h", "qc.hip.h", "lm_assoc.hip.h", "mvlmm.hip.h",
                       "mvlmm_kernels.hip.h", "eigh_tu.h"],
     "eigh_tu.hip": ["dgemm_mfma.hip.h", "eigh.hip.h", "eigh2.hip.h", "eigh_tu.h"],  # the eigensolver: its own object file

@@ -22,6 +22,7 @@
 #include "i8gemm_sparse.hip.h"
 #include "i8gemm_sparse2.hip.h"
 #include "i8gemm_sparse2_r16.hip.h"
+#include "i8gemm_dense16.hip.h"
 #include "qc.hip.h"
 #include "mvlmm.hip.h"
 #include "comm.hip.h"
@@ -73,6 +74,7 @@ struct Knobs {
   int i8_raster = S2_DEFAULT_RASTER; // GEMMA_HIP_I8_RASTER
   int i8_rows = 16;        // GEMMA_HIP_I8_ROWS: 32 = the records kernel on the 32-row matrix instructions
   int dosage_i8 = 1;       // GEMMA_HIP_UTX_DOSAGE_I8
+  int dosage_rows = 16;    // GEMMA_HIP_DOSAGE_ROWS: 32 = the dosage planes on the 32-row dense kernel (rounds 3-4)
   int overlap = 0;         // GEMMA_HIP_OVERLAP
   int overlap_chunks = 4;  // GEMMA_HIP_OVERLAP_CHUNKS
   int table_v2 = 1;        // GEMMA_HIP_TABLE_V2
@@ -100,6 +102,7 @@ struct Knobs {
     i8_rows = geti("GEMMA_HIP_I8_ROWS", 16) == 32 ? 32 : 16;
     const char *ed = getenv("GEMMA_HIP_UTX_DOSAGE_I8");
     dosage_i8 = (ed && ed[0] == '0') ? 0 : 1;
+    dosage_rows = geti("GEMMA_HIP_DOSAGE_ROWS", 16) == 32 ? 32 : 16;
     const char *eo = getenv("GEMMA_HIP_OVERLAP");
     overlap = (eo && eo[0] == '1') ? 1 : 0;
     overlap_chunks = geti("GEMMA_HIP_OVERLAP_CHUNKS", 4);
@@ -1537,10 +1540,11 @@ static int utx_i8_mode() { return g_ctx.knobs.utx_i8; }
 static void note_utx_kernel(int variant, int digits, int fuse, int raster) {
   static const char *const names[GEMMA_UTX_KERNEL_COUNT] = {
       "dgemm_mfma_glds_kernel", "i8gemm_packed_kernel_t<true>", "i8gemm_sparse_kernel", "i8gemm_sparse2_kernel",
-      "i8gemm_sparse2_r16_kernel", "i8gemm_packed_kernel_t<false, true>"};
+      "i8gemm_sparse2_r16_kernel", "i8gemm_packed_kernel_t<false, true>", "i8gemm_dense16_kernel_t<true>"};
   gemma_utx_kernel_info &k = g_ctx.last_utx_kernel;
   k.variant = variant;
-  k.rows = variant == GEMMA_UTX_KERNEL_RECORDS_R16 ? 16 : (variant == GEMMA_UTX_KERNEL_DGEMM_F64 ? 0 : 32);
+  k.rows = (variant == GEMMA_UTX_KERNEL_RECORDS_R16 || variant == GEMMA_UTX_KERNEL_DOSAGE_I8_R16) ? 16
+                                                                                                   : (variant == GEMMA_UTX_KERNEL_DGEMM_F64 ? 0 : 32);
   k.digits = digits; k.fuse = fuse; k.raster = raster;
   k.launches += 1;
   snprintf(k.name, sizeof k.name, "%s", names[variant]);
@@ -1831,6 +1835,8 @@ static int utx_dosage_i8(const double *src, size_t l, size_t ld, bool nan_missin
     if (!attr_set) {
       HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(i8gemm_packed_kernel_t<false, true>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 3 * I8P_STAGE));
+      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(i8gemm_dense16_kernel_t<true>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 3 * I8P_STAGE));
       attr_set = true;
     }
     for (int a = 0; a < np; ++a) {
@@ -1846,9 +1852,17 @@ static int utx_dosage_i8(const double *src, size_t l, size_t ld, bool nan_missin
       g.gm = g_ctx.knobs.i8_gm;
       g.fuse = 0;
       g.digits = d.digits;
-      note_utx_kernel(GEMMA_UTX_KERNEL_DOSAGE_I8, d.digits, 0, 0);
-      hipLaunchKernelGGL((i8gemm_packed_kernel_t<false, true>), dim3((unsigned)(g.tiles_m * g.tiles_n), (unsigned)d.digits),
-                         dim3(512), 3 * I8P_STAGE, s, g);
+      // round 5: the byte planes on v_mfma_i32_16x16x64_i8 (i8gemm_dense16.hip.h: same tiles, same LDS images, every plane entry equal;
+      // 44.5 against 46.8 ms for six planes at n = B = 20 000 under the power limit); GEMMA_HIP_DOSAGE_ROWS=32: the 32-row kernel
+      if (g_ctx.knobs.dosage_rows == 32) {
+        note_utx_kernel(GEMMA_UTX_KERNEL_DOSAGE_I8, d.digits, 0, 0);
+        hipLaunchKernelGGL((i8gemm_packed_kernel_t<false, true>), dim3((unsigned)(g.tiles_m * g.tiles_n), (unsigned)d.digits),
+                           dim3(512), 3 * I8P_STAGE, s, g);
+      } else {
+        note_utx_kernel(GEMMA_UTX_KERNEL_DOSAGE_I8_R16, d.digits, 0, 0);
+        hipLaunchKernelGGL((i8gemm_dense16_kernel_t<true>), dim3((unsigned)(g.tiles_m * g.tiles_n), (unsigned)d.digits),
+                           dim3(512), 3 * I8P_STAGE, s, g);
+      }
       HIPCHK(hipGetLastError());
     }
   }

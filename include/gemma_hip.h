@@ -365,8 +365,9 @@ enum {
   GEMMA_UTX_KERNEL_SPARSE_BYTES = 2, /* i8gemm_sparse_kernel: mask product on the 2:4 sparse MFMA, byte genotypes (=1) */
   GEMMA_UTX_KERNEL_RECORDS_R32 = 3,  /* i8gemm_sparse2_kernel: records, 32-row matrix instructions (GEMMA_HIP_I8_ROWS=32) */
   GEMMA_UTX_KERNEL_RECORDS_R16 = 4,  /* i8gemm_sparse2_r16_kernel: records, v_mfma_i32_16x16x64_i8 + v_smfmac_i32_16x16x128_i8 (default) */
-  GEMMA_UTX_KERNEL_DOSAGE_I8 = 5,    /* i8gemm_packed_kernel_t<false, true>: byte planes of fixed-point dosages */
-  GEMMA_UTX_KERNEL_COUNT = 6
+  GEMMA_UTX_KERNEL_DOSAGE_I8 = 5,    /* i8gemm_packed_kernel_t<false, true>: byte planes of fixed-point dosages, 32-row instructions (GEMMA_HIP_DOSAGE_ROWS=32) */
+  GEMMA_UTX_KERNEL_DOSAGE_I8_R16 = 6, /* i8gemm_dense16_kernel_t<true>: the same planes on v_mfma_i32_16x16x64_i8 (default) */
+  GEMMA_UTX_KERNEL_COUNT = 7
 };
 typedef struct {
   int variant;  /* GEMMA_UTX_KERNEL_* */

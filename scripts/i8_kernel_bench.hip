@@ -26,6 +26,7 @@
 #include "i8gemm_dense2_proto.hip.h" // scripts/: an experiment, not part of the library
 #include "i8gemm_sparse2_g16_proto.hip.h" // scripts/: the records kernel with its genotype product on 16x16x64 (variant 6)
 #include "i8gemm_sparse2_r16.hip.h" // the shipped 16-row kernel (variant 7)
+#include "i8gemm_dense16.hip.h" // the dense byte-plane product on v_mfma_i32_16x16x64_i8 (variant 10; 11 = its genotype-masked form)
 #include "i8gemm_sparse2_r16_persist_proto.hip.h" // scripts/: persistent workgroups / spread operand preparation (variants 8, 9)
 
 using namespace gemma_hip;
@@ -72,6 +73,7 @@ __global__ void fill_B(int8_t *Bt, long total, long ldk, long n, int mode) {
   if (mode == 2) v = hv & 15;
   if (mode == 3) v = (hv & 15) - 8;
   if (mode == 4) v = hv & 127;
+  if (mode == 5) v = (int)(hash32((unsigned)(i * 2654435761u + 12345u)) % 201u) - 100;
   Bt[i] = (c < n) ? (int8_t)v : (int8_t)0;
 }
 
@@ -207,9 +209,20 @@ int main(int argc, char **argv) {
   if (variant == 4)
     CK(hipFuncSetAttribute(reinterpret_cast<const void *>(i8gemm_dense2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                            D2_NST * D2_STAGE));
-  if (variant == 5)
+  if (variant == 5 || variant == 10 || variant == 11 || variant == 12) {
     CK(hipFuncSetAttribute(reinterpret_cast<const void *>(i8gemm_packed_kernel_t<false, true>),
                            hipFuncAttributeMaxDynamicSharedMemorySize, 3 * I8P_STAGE));
+    CK(hipFuncSetAttribute(reinterpret_cast<const void *>(i8gemm_packed_kernel_t<false, false>),
+                           hipFuncAttributeMaxDynamicSharedMemorySize, 3 * I8P_STAGE));
+    CK(hipFuncSetAttribute(reinterpret_cast<const void *>(i8gemm_dense16_kernel_t<true>),
+                           hipFuncAttributeMaxDynamicSharedMemorySize, 3 * I8P_STAGE));
+    CK(hipFuncSetAttribute(reinterpret_cast<const void *>(i8gemm_dense16_kernel_t<false>),
+                           hipFuncAttributeMaxDynamicSharedMemorySize, 3 * I8P_STAGE));
+  }
+  if (getenv("A_MODE") && atoi(getenv("A_MODE")) == 1) { // dosage-like left factor: signed bytes uniform in [-100, 100]
+    hipLaunchKernelGGL(fill_B, dim3((unsigned)((lpad * ldk + 255) / 256)), dim3(256), 0, 0, A, lpad * ldk, ldk, n, 5);
+    CK(hipDeviceSynchronize());
+  }
   auto launch = [&]() {
     if (variant == 4) {
       hipLaunchKernelGGL(i8gemm_dense2_kernel, dim3((unsigned)(gd.tiles_m * gd.tiles_n), (unsigned)digits), dim3(512),
@@ -221,6 +234,24 @@ int main(int argc, char **argv) {
       g5.strideC = lpad * npad; g5.m_row0 = 0; g5.fuse = 0;
       hipLaunchKernelGGL((i8gemm_packed_kernel_t<false, true>), dim3((unsigned)(g5.tiles_m * g5.tiles_n), (unsigned)digits), dim3(512),
                          3 * I8P_STAGE, mstream, g5);
+      return;
+    }
+    if (variant == 12) { // the 32-row dense kernel on genotype-masked bytes (what G^T G of the integer kinship launched up to round 4)
+      I8PackArgs g5 = g;
+      g5.strideC = lpad * npad; g5.m_row0 = 0; g5.fuse = 0;
+      hipLaunchKernelGGL((i8gemm_packed_kernel_t<false, false>), dim3((unsigned)(g5.tiles_m * g5.tiles_n), (unsigned)digits), dim3(512),
+                         3 * I8P_STAGE, mstream, g5);
+      return;
+    }
+    if (variant == 10 || variant == 11) { // the same product on v_mfma_i32_16x16x64_i8 (10: raw bytes, 11: genotype-masked bytes)
+      I8PackArgs g5 = g;
+      g5.strideC = lpad * npad; g5.m_row0 = 0; g5.fuse = 0;
+      if (variant == 10)
+        hipLaunchKernelGGL((i8gemm_dense16_kernel_t<true>), dim3((unsigned)(g5.tiles_m * g5.tiles_n), (unsigned)digits), dim3(512),
+                           3 * I8P_STAGE, mstream, g5);
+      else
+        hipLaunchKernelGGL((i8gemm_dense16_kernel_t<false>), dim3((unsigned)(g5.tiles_m * g5.tiles_n), (unsigned)digits), dim3(512),
+                           3 * I8P_STAGE, mstream, g5);
       return;
     }
 #if HAVE_SPARSE2
@@ -322,6 +353,31 @@ int main(int argc, char **argv) {
            n, B, hcnt, total);
     if (hcnt) return 3;
   }
+  if (getenv("FULLCMP") && atoi(getenv("FULLCMP")) && (variant == 10 || variant == 11)) {
+    const size_t total = (size_t)digits * lpad * npad;
+    int *C2 = nullptr;
+    unsigned long long *dcnt = nullptr, hcnt = 0;
+    CK(hipMalloc(&C2, total * 4));
+    CK(hipMalloc(&dcnt, 8));
+    CK(hipMemset(dcnt, 0, 8));
+    CK(hipMemcpy(C2, C, total * 4, hipMemcpyDeviceToDevice));
+    CK(hipMemset(C, 0xAB, total * 4));
+    I8PackArgs g5 = g;
+    g5.strideC = lpad * npad; g5.m_row0 = 0; g5.fuse = 0;
+    if (variant == 10)
+      hipLaunchKernelGGL((i8gemm_packed_kernel_t<false, true>), dim3((unsigned)(g5.tiles_m * g5.tiles_n), (unsigned)digits), dim3(512), 3 * I8P_STAGE, 0, g5);
+    else
+      hipLaunchKernelGGL((i8gemm_packed_kernel_t<false, false>), dim3((unsigned)(g5.tiles_m * g5.tiles_n), (unsigned)digits), dim3(512), 3 * I8P_STAGE, 0, g5);
+    CK(hipGetLastError());
+    hipLaunchKernelGGL(count_diff_kernel, dim3(4096), dim3(256), 0, 0, C, C2, total, dcnt);
+    CK(hipMemcpy(&hcnt, dcnt, 8, hipMemcpyDeviceToHost));
+    printf("FULLCMP variant %d vs the 32-row dense kernel, digits %d, n = %ld, B = %ld: %llu of %zu plane entries differ\n", variant, digits, n, B, hcnt, total);
+    if (hcnt) return 3;
+  }
+  if (variant == 11 || variant == 12) { // genotype-masked bytes: the sampled check below does not model this variant
+    printf("variant %d, n = %ld, B = %ld, digits %d: %.2f ms per launch\n", variant, n, B, digits, ms / reps);
+    return 0;
+  }
   if (digits != 6 || fuse != 1) { // the sampled check below knows the default plane layout only
     printf("variant %d, n = %ld, B = %ld, digits %d fuse %d: %.2f ms per launch (%d planes)\n", variant, n, B, digits, fuse, ms / reps, nplanes);
     return 0;
@@ -350,7 +406,7 @@ int main(int argc, char **argv) {
       const long c = (long)((sc * 104729L + 101) % n);
       for (int d = 0; d < digits; ++d)
         CK(hipMemcpy(hcol.data() + (size_t)d * ldk, Bt + (size_t)d * npad * ldk + c * ldk, ldk, hipMemcpyDeviceToHost));
-      if (variant == 4 || variant == 5) { // one plane per digit, A's bytes as signed values
+      if (variant == 4 || variant == 5 || variant == 10) { // one plane per digit, A's bytes as signed values
         for (int d = 0; d < digits; ++d) {
           long e = 0;
           for (long k = 0; k < ldk; ++k) e += (long)hrow[k] * hcol[(size_t)d * ldk + k];

@@ -1371,3 +1371,33 @@ def test_lmm_pipe_blocks_equal_plain_batches(gpu_api, oracle, monkeypatch, cus):
     assert plain[700, 0] == plain[699, 0] and plain[1500, 0] == plain[1499, 0]  # the carry is what is being tested
     assert piped.tobytes() == plain.tobytes()
     assert piped2.tobytes() == plain.tobytes()
+
+
+@pytest.mark.parametrize("n,p,decimals,miss", [(645, 300, 2, 0.02), (1290, 513, 3, 0.01), (130, 129, 2, 0.0)])
+def test_dosage_planes_on_the_16_row_instruction_equal_the_32_row_kernel(gpu_api, oracle, monkeypatch, n, p, decimals, miss):
+    """Round 5: the byte planes of fixed-point dosages run on v_mfma_i32_16x16x64_i8 (i8gemm_dense16_kernel_t<true>) by default,
+    GEMMA_HIP_DOSAGE_ROWS=32 selects the 32-row dense kernel of rounds 3-4.  Exact integer sums either way: U^T x must be the same
+    bits, and the library must name the kernel it launched (K loops of 2, 6 and 11 tiles; one / two byte planes; with and without
+    the mask plane; ragged tiles)."""
+    from gemma_amd import _lib as L
+    rng = np.random.default_rng(977 + n)
+    X = _dosage_case(rng, n, p, decimals, miss)
+    Q, _ = np.linalg.qr(rng.standard_normal((n, n)))
+    ev = np.sort(rng.uniform(0.0, 3.0, n))
+    out = {}
+    for rows, variant, name in (("16", L.UTX_KERNEL_DOSAGE_I8_R16, "i8gemm_dense16_kernel_t<true>"),
+                                ("32", L.UTX_KERNEL_DOSAGE_I8, "i8gemm_packed_kernel_t<false, true>")):
+        monkeypatch.setenv("GEMMA_HIP_DOSAGE_ROWS", rows)
+        lmm = gpu_api.LMM(a_mode=1)
+        lmm.setup(Q, ev, Q.T @ np.ones((n, 1)), Q.T @ rng.standard_normal(n))
+        try:
+            out[rows] = lmm.dbg_utx(X, L.GENO_F64_SNP_MAJOR, 1)
+            k = gpu_api.last_utx_kernel()
+            assert gpu_api.last_utx_path() == (2 if decimals == 2 else 3)
+            assert (k["variant"], k["name"], k["rows"]) == (variant, name, int(rows)), k
+        finally:
+            lmm.finish()
+    assert out["16"].tobytes() == out["32"].tobytes()
+    Xi = oracle.impute_mean(X)
+    exact = (Xi.astype(np.longdouble) @ Q.astype(np.longdouble)).astype(np.float64)
+    assert np.max(np.abs(out["16"] - exact) / np.maximum(np.abs(Xi) @ np.abs(Q), 1e-300)) < 8 * 2.3e-16
