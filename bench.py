@@ -92,8 +92,8 @@ def parse():
                     help="measurement aid: keep the setup's result (U, eval, UtW, Uty, null scalars) in this file -- written "
                          "when absent, loaded when present -- so that a profiler run (rocprofv3 --pmc crashes inside the "
                          "eigensolver's ~80 000 launches) can start at the timed region")
-    ap.add_argument("--e2e-snps", type=int, default=200000,
-                    help="end-to-end leg after the timed region (0 = skip; 1000000 = BASELINE config 3 in full): a synthetic PLINK set of this many SNPs on disk -> "
+    ap.add_argument("--e2e-snps", type=int, default=1000000,
+                    help="end-to-end leg after the timed region (0 = skip; default 1000000 = BASELINE config 3 in full since round 5): a synthetic PLINK set of this many SNPs on disk -> "
                          "tests/cpp/gemma_file_driver -inproc (first pass, kinship, eigen, -lmm, .assoc.txt), wall seconds "
                          "per stage reported under \"e2e\" (0 = skip)")
     return ap.parse_args()
@@ -1246,8 +1246,10 @@ def e2e_files(args, n):
         subprocess.check_call(["g++", "-std=c++11", "-O2", "-I" + inc, os.path.join(ROOT, "tests", "cpp", "gemma_file_driver.cpp"),
                                "-L" + libdir, "-lgemma_hip", "-Wl,-rpath," + libdir, "-lz", "-pthread", "-o", drv])
         prefix = os.path.join(tmp, "S")
+        tg = time.perf_counter()
         subprocess.check_call([gen, "plinkgen", prefix, str(n), str(args.e2e_snps), str(min(64, os.cpu_count() or 8))],
                               stdout=subprocess.DEVNULL)
+        gen_s = time.perf_counter() - tg
         t0 = time.perf_counter()
         r = subprocess.run([drv, "-bfile", prefix, "-inproc", "1", "-lmm", str(args.a_mode), "-outdir", tmp, "-o", "e2e"],
                            capture_output=True, text=True)
@@ -1257,7 +1259,7 @@ def e2e_files(args, n):
         kv = dict(t.split("=", 1) for t in r.stdout.split() if "=" in t)
         f = lambda k: float(kv[k]) if k in kv else None
         return {"workload": "PLINK files n=%d p=%d -> .assoc.txt, -lmm %d, one process, files in the page cache" % (n, args.e2e_snps, args.a_mode),
-                "wall_s": round(wall, 2), "snps": int(kv.get("snps", 0)), "ni_test": int(kv.get("ni_test", 0)),
+                "wall_s": round(wall, 2), "synthetic_set_written_in_s": round(gen_s, 2), "snps": int(kv.get("snps", 0)), "ni_test": int(kv.get("ni_test", 0)),
                 "ns_test": int(kv.get("ns_test", 0)),
                 "stage_end_s": {k: f(k) for k in ("t_first_pass", "t_kinship", "t_eigen", "t_null", "t_assoc", "t_written")},
                 "assoc_snps_per_s": f("assoc_snps_per_s"), "whole_run_snps_per_s": round(int(kv.get("snps", 0)) / wall, 1)}

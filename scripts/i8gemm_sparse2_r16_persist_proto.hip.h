@@ -37,6 +37,9 @@
 #ifndef S2_R16_PREP_SPREAD
 #define S2_R16_PREP_SPREAD 0
 #endif
+#ifndef S2_R16_ABLATE
+#define S2_R16_ABLATE 0
+#endif
 
 namespace gemma_hip {
 
@@ -136,11 +139,16 @@ __global__ __launch_bounds__(512, 2) void i8gemm_sparse2_r16p_kernel(Sparse2Args
   } while (0)
 #define GS_RREC(SOFF, i, P) rec[i][P] = *reinterpret_cast<const i32x4 *>(i8lds + (SOFF) + ro[P] + (i) * 1024)
 // sub-block SB of the stage into ring slot SL
+// S2_R16_ABLATE (timing experiment only, results wrong): 1 = the digit fragments of the odd sub-blocks are not read (the ring slot keeps
+// what it held: 12 instead of 20 ds_read_b128 per K-tile and wavefront), 2 = only sub-block 0 is read (6 of 20) -- is the loop bound by
+// the LDS pipe?
 #define GS_RT(SOFF, SB, SL)                                                                                       \
   do {                                                                                                            \
-    const i32x4 x_ = *reinterpret_cast<const i32x4 *>(i8lds + (SOFF) + fo[0] + (SB) * 2048);                      \
-    const i32x4 y_ = *reinterpret_cast<const i32x4 *>(i8lds + (SOFF) + fo[1] + (SB) * 2048);                      \
-    T[SL] = __builtin_shufflevector(x_, y_, 0, 1, 2, 3, 4, 5, 6, 7);                                              \
+    if (!(S2_R16_ABLATE == 1 && ((SB)&1)) && !(S2_R16_ABLATE == 2 && (SB) != 0)) {                                 \
+      const i32x4 x_ = *reinterpret_cast<const i32x4 *>(i8lds + (SOFF) + fo[0] + (SB) * 2048);                    \
+      const i32x4 y_ = *reinterpret_cast<const i32x4 *>(i8lds + (SOFF) + fo[1] + (SB) * 2048);                    \
+      T[SL] = __builtin_shufflevector(x_, y_, 0, 1, 2, 3, 4, 5, 6, 7);                                            \
+    }                                                                                                             \
   } while (0)
 // operands of a K-tile from its records: genotype word q >> 1 of (pair P, half q & 1); index word and kept bits of K-step q = the
 // record of pair q >> 1 (its half is q & 1 by construction)

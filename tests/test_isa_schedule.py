@@ -150,3 +150,23 @@ def test_run_time_mvlmm_kernel_private_memory_budget(tmp_path):
     fixed = {k: v for k, v in found.items() if "12mvlmm_kernelILi" in k}
     assert len(fixed) >= 24
     assert max(fixed.values()) <= 4096, max(fixed.items(), key=lambda kv: kv[1])
+
+
+@pytest.mark.skipif(not (os.path.exists(LIB) and os.path.exists(OBJDUMP)), reason="needs the built library and llvm-objdump")
+def test_dense_sixteen_row_kernel_steady_state_loop(tmp_path):
+    """i8gemm_dense16_kernel_t<true> (round 5: the dosage byte planes on v_mfma_i32_16x16x64_i8): per K-tile and wavefront 32 matrix
+    instructions on 16 accumulators (each visited twice: the two pairs of K-steps), 16 ds_read_b128 (one per block and pair), 6 LDS-DMA
+    pieces, one barrier, ONE counted s_waitcnt vmcnt(6) and no vmcnt(0), no scratch anywhere in the kernel."""
+    lines = _kernel_text(tmp_path, r"i8gemm_dense16_kernel_tILb1")
+    assert lines, "i8gemm_dense16_kernel_t<true> not found in the gfx950 code object"
+    ops, body = _steady_loop(lines)
+    assert not any(o.startswith("scratch_") for o in ops), [o for o in ops if o.startswith("scratch_")][:4]
+    assert body is not None
+    cnt = lambda pat: sum(bool(re.match(pat, o)) for o in body)
+    assert cnt(r"v_mfma_i32_16x16x64_i8") == 32 and cnt(r"v_mfma_i32_32x32x32_i8") == 0
+    assert cnt(r"global_load_lds_dwordx4") == 6 and cnt(r"ds_read_b128") == 16 and cnt(r"ds_read") == 16
+    assert cnt(r"s_barrier") == 1
+    assert cnt(r"s_waitcnt vmcnt\(6\)") == 1 and cnt(r"s_waitcnt vmcnt\(0\)") == 0, [o for o in body if "vmcnt" in o]
+    mats = [re.match(r"v_mfma\w*\s+(v\[\d+:\d+\])", o).group(1) for o in body if re.match(r"v_mfma", o)]
+    assert len(set(mats)) == 16 and all(mats.count(a) == 2 for a in set(mats)), mats
+    assert all(a != b for a, b in zip(mats, mats[1:])), mats
