@@ -27,6 +27,7 @@
 #include "i8gemm_sparse2_g16_proto.hip.h" // scripts/: the records kernel with its genotype product on 16x16x64 (variant 6)
 #include "i8gemm_sparse2_r16.hip.h" // the shipped 16-row kernel (variant 7)
 #include "i8gemm_dense16.hip.h" // the dense byte-plane product on v_mfma_i32_16x16x64_i8 (variant 10; 11 = its genotype-masked form)
+#include "i8gemm_dense16w.hip.h" // the same with 128 x 128 per wavefront, 256 x 256 x 64 tiles (variant 13; 14 = genotype-masked)
 #include "i8gemm_sparse2_r16_persist_proto.hip.h" // scripts/: persistent workgroups / spread operand preparation (variants 8, 9)
 
 using namespace gemma_hip;
@@ -209,7 +210,7 @@ int main(int argc, char **argv) {
   if (variant == 4)
     CK(hipFuncSetAttribute(reinterpret_cast<const void *>(i8gemm_dense2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                            D2_NST * D2_STAGE));
-  if (variant == 5 || variant == 10 || variant == 11 || variant == 12) {
+  if (variant == 5 || variant == 10 || variant == 11 || variant == 12 || variant == 13 || variant == 14) {
     CK(hipFuncSetAttribute(reinterpret_cast<const void *>(i8gemm_packed_kernel_t<false, true>),
                            hipFuncAttributeMaxDynamicSharedMemorySize, 3 * I8P_STAGE));
     CK(hipFuncSetAttribute(reinterpret_cast<const void *>(i8gemm_packed_kernel_t<false, false>),
@@ -218,6 +219,10 @@ int main(int argc, char **argv) {
                            hipFuncAttributeMaxDynamicSharedMemorySize, 3 * I8P_STAGE));
     CK(hipFuncSetAttribute(reinterpret_cast<const void *>(i8gemm_dense16_kernel_t<false>),
                            hipFuncAttributeMaxDynamicSharedMemorySize, 3 * I8P_STAGE));
+    CK(hipFuncSetAttribute(reinterpret_cast<const void *>(i8gemm_dense16w_kernel_t<true>),
+                           hipFuncAttributeMaxDynamicSharedMemorySize, DW_NST * DW_STAGE));
+    CK(hipFuncSetAttribute(reinterpret_cast<const void *>(i8gemm_dense16w_kernel_t<false>),
+                           hipFuncAttributeMaxDynamicSharedMemorySize, DW_NST * DW_STAGE));
   }
   if (getenv("A_MODE") && atoi(getenv("A_MODE")) == 1) { // dosage-like left factor: signed bytes uniform in [-100, 100]
     hipLaunchKernelGGL(fill_B, dim3((unsigned)((lpad * ldk + 255) / 256)), dim3(256), 0, 0, A, lpad * ldk, ldk, n, 5);
@@ -234,6 +239,18 @@ int main(int argc, char **argv) {
       g5.strideC = lpad * npad; g5.m_row0 = 0; g5.fuse = 0;
       hipLaunchKernelGGL((i8gemm_packed_kernel_t<false, true>), dim3((unsigned)(g5.tiles_m * g5.tiles_n), (unsigned)digits), dim3(512),
                          3 * I8P_STAGE, mstream, g5);
+      return;
+    }
+    if (variant == 13 || variant == 14) {
+      DenseWArgs gw;
+      gw.A = A; gw.Bt = Bt; gw.C = C; gw.ldk = ldk; gw.ldc = npad; gw.strideB = npad * ldk; gw.strideC = lpad * npad;
+      gw.tiles_m = (int)(lpad / DW_BM); gw.tiles_n = (int)(npad / DW_BN); gw.nk = (int)(ldk / DW_BK); gw.gm = gm;
+      if (variant == 13)
+        hipLaunchKernelGGL((i8gemm_dense16w_kernel_t<true>), dim3((unsigned)(gw.tiles_m * gw.tiles_n), (unsigned)digits), dim3(256),
+                           DW_NST * DW_STAGE, mstream, gw);
+      else
+        hipLaunchKernelGGL((i8gemm_dense16w_kernel_t<false>), dim3((unsigned)(gw.tiles_m * gw.tiles_n), (unsigned)digits), dim3(256),
+                           DW_NST * DW_STAGE, mstream, gw);
       return;
     }
     if (variant == 12) { // the 32-row dense kernel on genotype-masked bytes (what G^T G of the integer kinship launched up to round 4)
@@ -353,7 +370,7 @@ int main(int argc, char **argv) {
            n, B, hcnt, total);
     if (hcnt) return 3;
   }
-  if (getenv("FULLCMP") && atoi(getenv("FULLCMP")) && (variant == 10 || variant == 11)) {
+  if (getenv("FULLCMP") && atoi(getenv("FULLCMP")) && (variant == 10 || variant == 11 || variant == 13 || variant == 14)) {
     const size_t total = (size_t)digits * lpad * npad;
     int *C2 = nullptr;
     unsigned long long *dcnt = nullptr, hcnt = 0;
@@ -364,7 +381,7 @@ int main(int argc, char **argv) {
     CK(hipMemset(C, 0xAB, total * 4));
     I8PackArgs g5 = g;
     g5.strideC = lpad * npad; g5.m_row0 = 0; g5.fuse = 0;
-    if (variant == 10)
+    if (variant == 10 || variant == 13)
       hipLaunchKernelGGL((i8gemm_packed_kernel_t<false, true>), dim3((unsigned)(g5.tiles_m * g5.tiles_n), (unsigned)digits), dim3(512), 3 * I8P_STAGE, 0, g5);
     else
       hipLaunchKernelGGL((i8gemm_packed_kernel_t<false, false>), dim3((unsigned)(g5.tiles_m * g5.tiles_n), (unsigned)digits), dim3(512), 3 * I8P_STAGE, 0, g5);
@@ -374,7 +391,7 @@ int main(int argc, char **argv) {
     printf("FULLCMP variant %d vs the 32-row dense kernel, digits %d, n = %ld, B = %ld: %llu of %zu plane entries differ\n", variant, digits, n, B, hcnt, total);
     if (hcnt) return 3;
   }
-  if (variant == 11 || variant == 12) { // genotype-masked bytes: the sampled check below does not model this variant
+  if (variant == 11 || variant == 12 || variant == 14) { // genotype-masked bytes: the sampled check below does not model this variant
     printf("variant %d, n = %ld, B = %ld, digits %d: %.2f ms per launch\n", variant, n, B, digits, ms / reps);
     return 0;
   }
@@ -406,7 +423,7 @@ int main(int argc, char **argv) {
       const long c = (long)((sc * 104729L + 101) % n);
       for (int d = 0; d < digits; ++d)
         CK(hipMemcpy(hcol.data() + (size_t)d * ldk, Bt + (size_t)d * npad * ldk + c * ldk, ldk, hipMemcpyDeviceToHost));
-      if (variant == 4 || variant == 5 || variant == 10) { // one plane per digit, A's bytes as signed values
+      if (variant == 4 || variant == 5 || variant == 10 || variant == 13) { // one plane per digit, A's bytes as signed values
         for (int d = 0; d < digits; ++d) {
           long e = 0;
           for (long k = 0; k < ldk; ++k) e += (long)hrow[k] * hcol[(size_t)d * ldk + k];
