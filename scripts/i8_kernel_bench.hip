@@ -27,7 +27,7 @@
 #include "i8gemm_sparse2_g16_proto.hip.h" // scripts/: the records kernel with its genotype product on 16x16x64 (variant 6)
 #include "i8gemm_sparse2_r16.hip.h" // the shipped 16-row kernel (variant 7)
 #include "i8gemm_dense16.hip.h" // the dense byte-plane product on v_mfma_i32_16x16x64_i8 (variant 10; 11 = its genotype-masked form)
-#include "i8gemm_dense16w.hip.h" // the same with 128 x 128 per wavefront, 256 x 256 x 64 tiles (variant 13; 14 = genotype-masked)
+#include "i8gemm_dense16w_proto.hip.h" // scripts/: the same with 128 x 128 per wavefront, 256 x 256 x 64 tiles (variant 13; 14 = genotype-masked): slower, dropped
 #include "i8gemm_sparse2_r16_persist_proto.hip.h" // scripts/: persistent workgroups / spread operand preparation (variants 8, 9)
 
 using namespace gemma_hip;

@@ -1,4 +1,11 @@
-// The dense byte-plane product on v_mfma_i32_16x16x64_i8 with a 128 x 128 tile PER WAVEFRONT (round 5, second step after
+// PROTOTYPE, NOT SHIPPED (round 5; scripts/i8_kernel_bench.hip variants 13 / 14; profiles/r05_i8_dense16w_prototype.txt).  Measured:
+// SLOWER than the 64 x 64-per-wavefront kernel it was meant to replace -- 49.2 against 44.1 ms for six dosage planes at n = B = 20 000,
+// 47.5 against 40.8 ms with all-zero digits: one wavefront per SIMD does not keep the matrix pipe fed (a K-tile of 64 bytes is 1 024
+// cycles, the LDS-DMA three tiles ahead is 1.3 us of lead) -- and its planes DIFFER from the reference kernel's on three small shapes
+// whose padded K is a power of two (n = 100, 200, 500; equal on six others incl. every plane entry at n = 20 000): not investigated,
+// the form was dropped on the timing.  Kept for the next attempt at the dense kernel.
+//
+// The dense byte-plane product on v_mfma_i32_16x16x64_i8 with a 128 x 128 tile PER WAVEFRONT (second step after
 // i8gemm_dense16.hip.h): 256 x 256 x 64 tiles, FOUR wavefronts (2 x 2, one per SIMD, up to 512 registers each), four 32 KiB LDS
 // stages, LDS-DMA three K-tiles ahead with one counted s_waitcnt vmcnt and one s_barrier per K-tile.
 //
