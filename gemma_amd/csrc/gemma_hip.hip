@@ -2256,6 +2256,7 @@ extern "C" int gemma_hip_lmm_gene_batch_d(const double *Y_d, size_t l, size_t ld
   if (!Y_d || !out_d || ld < n) return fail(GEMMA_HIP_EINVAL, "lmm_gene_batch: ld=%zu < n=%zu", ld, n);
   hipStream_t s = S(stream);
   const size_t ldx = (n + 1) & ~(size_t)1;
+  if (int rcf = xp_flush(S(stream))) return rcf; // blocks of the two-block pipeline still in flight share these buffers
   if (g_ctx.UtX.reserve(l * ldx * 8)) return fail(GEMMA_HIP_ENOMEM, "lmm_gene_batch: %zu bytes", l * ldx * 8);
   double *UtY = g_ctx.UtX.as<double>();
   {
@@ -2512,6 +2513,7 @@ static int mvlmm_gxe_batch_d(int kind, const void *geno, size_t l, size_t ld, do
   if (kind == GEMMA_GENO_F64_IDV_MAJOR) return fail(GEMMA_HIP_EINVAL, "mvlmm_batch (gxe): SNP-major input only");
   const size_t n = g_ctx.cfg.n, c = g_ctx.cfg.n_cvt;
   const size_t ldx = (n + 1) & ~(size_t)1;
+  if (int rcf = xp_flush(s)) return rcf; // blocks of the two-block pipeline still in flight share these buffers
   if (g_ctx.X.reserve(l * ldx * 8) || g_ctx.UtX.reserve(l * ldx * 8) || g_ctx.gxe_Z.reserve(l * ldx * 8) ||
       g_ctx.gxe_UtZ.reserve(l * ldx * 8) || g_ctx.gxe_flip.reserve(l * sizeof(int)))
     return fail(GEMMA_HIP_ENOMEM, "mvlmm_batch (gxe): cannot allocate 4 x %zu bytes", l * ldx * 8);
@@ -2634,6 +2636,7 @@ extern "C" int gemma_hip_lmm_gxe_batch_d(int kind, const void *geno, size_t l, s
   hipStream_t s = S(stream);
   const size_t n = g_ctx.cfg.n, c = g_ctx.cfg.n_cvt;
   const size_t ldx = (n + 1) & ~(size_t)1;
+  if (int rcf = xp_flush(s)) return rcf; // blocks of the two-block pipeline still in flight share these buffers
   if (g_ctx.X.reserve(l * ldx * 8) || g_ctx.UtX.reserve(l * ldx * 8) || g_ctx.gxe_Z.reserve(l * ldx * 8) ||
       g_ctx.gxe_UtZ.reserve(l * ldx * 8) || g_ctx.gxe_flip.reserve(l * sizeof(int)))
     return fail(GEMMA_HIP_ENOMEM, "lmm_gxe_batch: cannot allocate 4 x %zu bytes", l * ldx * 8);
