@@ -210,7 +210,7 @@ int main(int argc, char **argv) {
   if (variant == 4)
     CK(hipFuncSetAttribute(reinterpret_cast<const void *>(i8gemm_dense2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                            D2_NST * D2_STAGE));
-  if (variant == 5 || variant == 10 || variant == 11 || variant == 12 || variant == 13 || variant == 14) {
+  if (variant == 5 || (variant >= 10 && variant <= 16)) {
     CK(hipFuncSetAttribute(reinterpret_cast<const void *>(i8gemm_packed_kernel_t<false, true>),
                            hipFuncAttributeMaxDynamicSharedMemorySize, 3 * I8P_STAGE));
     CK(hipFuncSetAttribute(reinterpret_cast<const void *>(i8gemm_packed_kernel_t<false, false>),
@@ -370,7 +370,7 @@ int main(int argc, char **argv) {
            n, B, hcnt, total);
     if (hcnt) return 3;
   }
-  if (getenv("FULLCMP") && atoi(getenv("FULLCMP")) && (variant == 10 || variant == 11 || variant == 13 || variant == 14)) {
+  if (getenv("FULLCMP") && atoi(getenv("FULLCMP")) && (variant == 10 || variant == 11 || (variant >= 13 && variant <= 16))) {
     const size_t total = (size_t)digits * lpad * npad;
     int *C2 = nullptr;
     unsigned long long *dcnt = nullptr, hcnt = 0;
@@ -381,7 +381,7 @@ int main(int argc, char **argv) {
     CK(hipMemset(C, 0xAB, total * 4));
     I8PackArgs g5 = g;
     g5.strideC = lpad * npad; g5.m_row0 = 0; g5.fuse = 0;
-    if (variant == 10 || variant == 13)
+    if (variant == 10 || variant == 13 || variant == 15)
       hipLaunchKernelGGL((i8gemm_packed_kernel_t<false, true>), dim3((unsigned)(g5.tiles_m * g5.tiles_n), (unsigned)digits), dim3(512), 3 * I8P_STAGE, 0, g5);
     else
       hipLaunchKernelGGL((i8gemm_packed_kernel_t<false, false>), dim3((unsigned)(g5.tiles_m * g5.tiles_n), (unsigned)digits), dim3(512), 3 * I8P_STAGE, 0, g5);
@@ -391,7 +391,7 @@ int main(int argc, char **argv) {
     printf("FULLCMP variant %d vs the 32-row dense kernel, digits %d, n = %ld, B = %ld: %llu of %zu plane entries differ\n", variant, digits, n, B, hcnt, total);
     if (hcnt) return 3;
   }
-  if (variant == 11 || variant == 12 || variant == 14) { // genotype-masked bytes: the sampled check below does not model this variant
+  if (variant == 11 || variant == 12 || variant == 14 || variant == 16) { // genotype-masked bytes: the sampled check below does not model this variant
     printf("variant %d, n = %ld, B = %ld, digits %d: %.2f ms per launch\n", variant, n, B, digits, ms / reps);
     return 0;
   }
@@ -423,7 +423,7 @@ int main(int argc, char **argv) {
       const long c = (long)((sc * 104729L + 101) % n);
       for (int d = 0; d < digits; ++d)
         CK(hipMemcpy(hcol.data() + (size_t)d * ldk, Bt + (size_t)d * npad * ldk + c * ldk, ldk, hipMemcpyDeviceToHost));
-      if (variant == 4 || variant == 5 || variant == 10 || variant == 13) { // one plane per digit, A's bytes as signed values
+      if (variant == 4 || variant == 5 || variant == 10 || variant == 13 || variant == 15) { // one plane per digit, A's bytes as signed values
         for (int d = 0; d < digits; ++d) {
           long e = 0;
           for (long k = 0; k < ldk; ++k) e += (long)hrow[k] * hcol[(size_t)d * ldk + k];
