@@ -15,6 +15,8 @@ UNITS = {
     "mvlmm_kernels.hip": ["mvlmm.hip.h", "mvlmm_kernels.hip.h"],
     "mvlmm_kernels_wide.hip": ["mvlmm.hip.h", "mvlmm_kernels.hip.h"],
     "mvlmm_kernels_rt.hip": ["mvlmm.hip.h", "mvlmm_kernels.hip.h"],  # the run-time (d, c) instance
+    "mvlmm_kernels_d6.hip": ["mvlmm.hip.h", "mvlmm_kernels.hip.h"],  # six phenotypes, fixed form (two wavefronts per workgroup)
+    "mvlmm_kernels_d7.hip": ["mvlmm.hip.h", "mvlmm_kernels.hip.h"],  # seven phenotypes (one wavefront per workgroup)
 }
 PUBLIC_HEADER_USERS = ("gemma_hip.hip", "eigh_tu.hip")
 SOURCES = list(UNITS)

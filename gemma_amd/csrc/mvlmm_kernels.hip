@@ -9,10 +9,14 @@ using namespace gemma_hip;
 #define MV_FOR_D(F, C) F(1, C) F(2, C) F(3, C) F(4, C) F(5, C)
 
 extern "C" int gemma_hip_mvlmm_launch_wide_(const MvArgs *g, int d, int c, hipStream_t s);      // mvlmm_kernels_wide.hip
+extern "C" int gemma_hip_mvlmm_launch_d6_(const MvArgs *g, int c, hipStream_t s);               // mvlmm_kernels_d6.hip
+extern "C" int gemma_hip_mvlmm_launch_d7_(const MvArgs *g, int c, hipStream_t s);               // mvlmm_kernels_d7.hip
 extern "C" int gemma_hip_mvlmm_null_launch_wide_(const MvNullArgs *a, int d, int c, hipStream_t s);
 
 // c = covariates + 1 (the SNP row).  Returns 0, a hipError_t, or -1 for an unsupported (d, c).
 extern "C" int gemma_hip_mvlmm_launch_(const MvArgs *g, int d, int c, hipStream_t s) {
+  if (d == 6) return gemma_hip_mvlmm_launch_d6_(g, c, s); // six / seven phenotypes, up to three covariates: fixed kernels with two / one
+  if (d == 7) return gemma_hip_mvlmm_launch_d7_(g, c, s); // wavefronts per workgroup (round 5)
   const unsigned grid = (unsigned)((g->l + 3) / 4);
 #define MV_CASE(DD, CC)                                                                        \
   if (d == DD && c == CC) {                                                                    \
