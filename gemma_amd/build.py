@@ -17,6 +17,7 @@ UNITS = {
     "mvlmm_kernels_rt.hip": ["mvlmm.hip.h", "mvlmm_kernels.hip.h"],  # the run-time (d, c) instance
     "mvlmm_kernels_d6.hip": ["mvlmm.hip.h", "mvlmm_kernels.hip.h"],  # six phenotypes, fixed form (two wavefronts per workgroup)
     "mvlmm_kernels_d7.hip": ["mvlmm.hip.h", "mvlmm_kernels.hip.h"],  # seven phenotypes (one wavefront per workgroup)
+    "mvlmm_kernels_d8.hip": ["mvlmm.hip.h", "mvlmm_kernels.hip.h"],  # eight phenotypes, one covariate
 }
 PUBLIC_HEADER_USERS = ("gemma_hip.hip", "eigh_tu.hip")
 SOURCES = list(UNITS)

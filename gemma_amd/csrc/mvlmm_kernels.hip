@@ -11,12 +11,14 @@ using namespace gemma_hip;
 extern "C" int gemma_hip_mvlmm_launch_wide_(const MvArgs *g, int d, int c, hipStream_t s);      // mvlmm_kernels_wide.hip
 extern "C" int gemma_hip_mvlmm_launch_d6_(const MvArgs *g, int c, hipStream_t s);               // mvlmm_kernels_d6.hip
 extern "C" int gemma_hip_mvlmm_launch_d7_(const MvArgs *g, int c, hipStream_t s);               // mvlmm_kernels_d7.hip
+extern "C" int gemma_hip_mvlmm_launch_d8_(const MvArgs *g, int c, hipStream_t s);               // mvlmm_kernels_d8.hip (c = 2 only)
 extern "C" int gemma_hip_mvlmm_null_launch_wide_(const MvNullArgs *a, int d, int c, hipStream_t s);
 
 // c = covariates + 1 (the SNP row).  Returns 0, a hipError_t, or -1 for an unsupported (d, c).
 extern "C" int gemma_hip_mvlmm_launch_(const MvArgs *g, int d, int c, hipStream_t s) {
   if (d == 6) return gemma_hip_mvlmm_launch_d6_(g, c, s); // six / seven phenotypes, up to three covariates: fixed kernels with two / one
   if (d == 7) return gemma_hip_mvlmm_launch_d7_(g, c, s); // wavefronts per workgroup (round 5)
+  if (d == 8) return gemma_hip_mvlmm_launch_d8_(g, c, s); // one covariate only (156.8 KB of tables)
   const unsigned grid = (unsigned)((g->l + 3) / 4);
 #define MV_CASE(DD, CC)                                                                        \
   if (d == DD && c == CC) {                                                                    \
