@@ -3,7 +3,9 @@
 // 47.5 against 40.8 ms with all-zero digits: one wavefront per SIMD does not keep the matrix pipe fed (a K-tile of 64 bytes is 1 024
 // cycles, the LDS-DMA three tiles ahead is 1.3 us of lead) -- and its planes DIFFER from the reference kernel's on three small shapes
 // whose padded K is a power of two (n = 100, 200, 500; equal on six others incl. every plane entry at n = 20 000): not investigated,
-// the form was dropped on the timing.  Kept for the next attempt at the dense kernel.
+// the form was dropped on the timing.  Its PREMISE below ("bound by the LDS pipe") was also wrong: counters taken afterwards show the
+// LDS pipe active 0.31 of the cycles in the shipped kernel, which runs at 1.66 GHz with the matrix pipe busy 0.63 on these operands
+// (profiles/r05_i8_dense_pmc.txt).  Kept for the next attempt at the dense kernel.
 //
 // The dense byte-plane product on v_mfma_i32_16x16x64_i8 with a 128 x 128 tile PER WAVEFRONT (second step after
 // i8gemm_dense16.hip.h): 256 x 256 x 64 tiles, FOUR wavefronts (2 x 2, one per SIMD, up to 512 registers each), four 32 KiB LDS
