@@ -12,7 +12,7 @@ SYMBOLS = [
     "gemma_hip_last_error", "gemma_hip_device_info", "gemma_hip_dgemm", "gemma_hip_dgemm_d",
     "gemma_hip_kin_begin", "gemma_hip_kin_add", "gemma_hip_kin_add_d", "gemma_hip_kin_end",
     "gemma_hip_kin_end_d", "gemma_hip_kin_loco_d", "gemma_hip_snp_qc", "gemma_hip_center", "gemma_hip_center_d", "gemma_hip_eigh",
-    "gemma_hip_eigh_d", "gemma_hip_dbg_eigh_last", "gemma_hip_eigh_sharded_d", "gemma_hip_eigh_kept_K_sharded", "gemma_hip_calc_utx", "gemma_hip_lmm_setup", "gemma_hip_lmm_setup_d",
+    "gemma_hip_eigh_d", "gemma_hip_eigh_reserve", "gemma_hip_eigh_release", "gemma_hip_dbg_eigh_last", "gemma_hip_eigh_sharded_d", "gemma_hip_eigh_kept_K_sharded", "gemma_hip_calc_utx", "gemma_hip_lmm_setup", "gemma_hip_lmm_setup_d",
     "gemma_hip_lmm_null", "gemma_hip_lmm_set_indicator", "gemma_hip_lmm_batch", "gemma_hip_lmm_batch_d",
     "gemma_hip_lmm_assoc_d", "gemma_hip_lmm_finish", "gemma_hip_lm_setup", "gemma_hip_lm_batch", "gemma_hip_lm_batch_d",
     "gemma_hip_lm_finish", "gemma_hip_profile_enable",
@@ -22,7 +22,7 @@ SYMBOLS = [
     "gemma_hip_kin_end_keep", "gemma_hip_kept_K_get", "gemma_hip_eigh_kept_K", "gemma_hip_eigh_keep", "gemma_hip_kept_n",
     "gemma_hip_kept_bcast", "gemma_hip_kept_U_get", "gemma_hip_calc_utx_kept", "gemma_hip_lmm_setup_kept", "gemma_hip_kept_release",
     "gemma_hip_comm_unique_id", "gemma_hip_comm_init", "gemma_hip_comm_info", "gemma_hip_comm_bcast_d",
-    "gemma_hip_comm_allreduce_sum_d", "gemma_hip_comm_finalize", "gemma_hip_dbg_i8_digits", "gemma_hip_dbg_last_utx_path", "gemma_hip_lmm_batch_submit", "gemma_hip_lmm_batch_collect",
+    "gemma_hip_comm_allreduce_sum_d", "gemma_hip_comm_finalize", "gemma_hip_comm_selftest", "gemma_hip_comm_stats", "gemma_hip_dbg_i8_digits", "gemma_hip_dbg_last_utx_path", "gemma_hip_lmm_batch_submit", "gemma_hip_lmm_batch_collect",
     "gemma_hip_dbg_last_utx_kernel", "gemma_hip_reload_env", "gemma_hip_lmm_batch_pipe_d", "gemma_hip_lmm_pipe_flush",
 ]
 COMM_ID_BYTES = 128
@@ -51,6 +51,12 @@ class UtxKernelInfo(C.Structure):
 
 UTX_KERNEL_DGEMM_F64, UTX_KERNEL_DENSE_I8, UTX_KERNEL_SPARSE_BYTES, UTX_KERNEL_RECORDS_R32, UTX_KERNEL_RECORDS_R16, \
     UTX_KERNEL_DOSAGE_I8, UTX_KERNEL_DOSAGE_I8_R16 = range(7)
+
+
+class CommStats(C.Structure):
+    """gemma_comm_stats: calls / pieces / bytes (and, with GEMMA_HIP_COMM_TIMING=1, seconds) of the library's collectives"""
+    _fields_ = [("allreduce_calls", C.c_long), ("allreduce_pieces", C.c_long), ("bcast_calls", C.c_long), ("bcast_pieces", C.c_long),
+                ("allreduce_bytes", C.c_double), ("bcast_bytes", C.c_double), ("allreduce_s", C.c_double), ("bcast_s", C.c_double)]
 
 
 class QcCfg(C.Structure):
@@ -118,6 +124,8 @@ def lib():
     L.gemma_hip_eigh_d.argtypes = [dp, sz, dp, dp, C.POINTER(cd), vp]
     L.gemma_hip_eigh_sharded_d.argtypes = [dp, sz, dp, dp, C.POINTER(cd), vp]
     L.gemma_hip_dbg_eigh_last.argtypes = [dp]
+    L.gemma_hip_eigh_reserve.argtypes = [sz]
+    L.gemma_hip_eigh_release.argtypes = [C.POINTER(sz)]
     L.gemma_hip_calc_utx.argtypes = [dp, dp, sz, sz, dp]
     L.gemma_hip_lmm_setup.argtypes = [C.POINTER(LmmCfg), dp, dp, dp, dp]
     L.gemma_hip_lmm_setup_d.argtypes = [C.POINTER(LmmCfg), dp, dp, dp, dp, vp]
@@ -168,6 +176,8 @@ def lib():
     L.gemma_hip_comm_info.argtypes = [C.POINTER(ci), C.POINTER(ci), C.POINTER(ci)]
     L.gemma_hip_comm_bcast_d.argtypes = [vp, sz, ci, vp]
     L.gemma_hip_comm_allreduce_sum_d.argtypes = [dp, sz, vp]
+    L.gemma_hip_comm_selftest.argtypes = [vp]
+    L.gemma_hip_comm_stats.argtypes = [C.POINTER(CommStats)]
     for s in SYMBOLS:
         getattr(L, s)  # AttributeError if the library does not export what the header declares
     _lib = L

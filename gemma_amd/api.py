@@ -164,6 +164,19 @@ def EigenDecomp_Zeroed(G, U, eval_):
     return tr.value
 
 
+def eigh_reserve(n):
+    """gemma_hip_eigh_reserve: allocate the eigensolver's workspace of order n ahead of the solve and keep the buffers of every later
+    solve in the library's pool (csrc/eigh.hip.h, EigPool) until eigh_release()."""
+    L.check(L.lib().gemma_hip_eigh_reserve(int(n)), "eigh_reserve")
+
+
+def eigh_release():
+    """gemma_hip_eigh_release: hand the pool's idle buffers back; returns the bytes freed."""
+    b = C.c_size_t()
+    L.check(L.lib().gemma_hip_eigh_release(C.byref(b)), "eigh_release")
+    return b.value
+
+
 def EigenDecomp_Zeroed_sharded(G, U, eval_):
     """EigenDecomp_Zeroed as a COLLECTIVE over the library's communicator (gemma_amd.dist.native_comm_init): every rank passes
     the same device matrix G (destroyed) and receives the same (U, eval_); the two back-transformations are shared out by
@@ -256,6 +269,14 @@ def comm_info():
     r, w, t = C.c_int(), C.c_int(), C.c_int()
     L.check(L.lib().gemma_hip_comm_info(C.byref(r), C.byref(w), C.byref(t)), "comm_info")
     return r.value, w.value, t.value
+
+
+def comm_stats():
+    """gemma_hip_comm_stats as a dict: calls, 1-GiB pieces and bytes per collective since comm_init (seconds only with
+    GEMMA_HIP_COMM_TIMING=1 in the environment)."""
+    st = L.CommStats()
+    L.check(L.lib().gemma_hip_comm_stats(C.byref(st)), "comm_stats")
+    return {k: getattr(st, k) for k, _ in L.CommStats._fields_}
 
 
 def CalcKin(geno, geno_kind, n_total, k_mode=1, batch=K_BATCH_SIZE):

@@ -17,9 +17,11 @@
 #pragma once
 #include <dlfcn.h>
 
+#include <chrono>
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <vector>
 
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
@@ -64,6 +66,18 @@ struct RcclApi {
   }
 };
 
+// One collective never carries more than this many bytes: the n^2 kinship sums of config 4 (n = 50 000) are 20 GB, and a single
+// ncclAllReduce / ncclBroadcast of that size has never run on this library's communicator (round 6).  The pieces
+// are issued back to back on the caller's stream (stream order = piece order on every rank).
+constexpr size_t COMM_PIECE_BYTES = size_t(1) << 30;
+
+// what the communicator has carried since it was created (gemma_hip_comm_stats); the seconds are host wall time around a
+// synchronised call and are only taken when GEMMA_HIP_COMM_TIMING=1 (a synchronisation per collective otherwise costs overlap)
+struct CommStats {
+  long allreduce_calls = 0, allreduce_pieces = 0, bcast_calls = 0, bcast_pieces = 0;
+  double allreduce_bytes = 0, bcast_bytes = 0, allreduce_s = 0, bcast_s = 0;
+};
+
 struct Comm {
   int rank = 0, world = 1;
   bool active = false;
@@ -72,6 +86,19 @@ struct Comm {
   ncclComm_t nccl = nullptr;
   ShmTransport tr;        // test transport
   void *pinned = nullptr; // COMM_SHM_CHUNK staging for it
+  CommStats stats;
+
+  // failure injection for the tests of the callers' fall-backs (tests/test_gpu_bench_launch.py, tests/test_dist_gloo.py):
+  // GEMMA_HIP_COMM_FAIL=init | selftest | allreduce | bcast makes that entry point return an error on EVERY rank; allreduce_large /
+  // bcast_large only from 1 MiB up (a collective that fails AFTER a passed self-test)
+  static bool fail_at(const char *what) {
+    const char *e = getenv("GEMMA_HIP_COMM_FAIL");
+    return e && strcmp(e, what) == 0;
+  }
+  static bool timing() {
+    const char *e = getenv("GEMMA_HIP_COMM_TIMING");
+    return e && atoi(e) != 0;
+  }
 
   static bool want_shm() {
     const char *e = getenv("GEMMA_HIP_COMM");
@@ -110,6 +137,11 @@ struct Comm {
       err = "comm_init: world > 1 needs the id of rank 0";
       return 1;
     }
+    if (fail_at("init")) {
+      err = "comm_init: failure injected (GEMMA_HIP_COMM_FAIL=init)";
+      return 1;
+    }
+    stats = CommStats();
     if (want_shm()) {
       if (!tr.open(id, rank, world, err)) return 1;
       if (hipHostMalloc(&pinned, COMM_SHM_CHUNK, hipHostMallocDefault) != hipSuccess) {
@@ -136,11 +168,29 @@ struct Comm {
   // in place on buf_d (device), bytes from `root` to everyone
   int bcast(void *buf_d, size_t bytes, int root, hipStream_t s, std::string &err) {
     if (!active || world == 1 || bytes == 0) return 0;
+    if (fail_at("bcast") || (bytes >= (size_t(1) << 20) && fail_at("bcast_large"))) {
+      err = "comm bcast: failure injected (GEMMA_HIP_COMM_FAIL)";
+      return 1;
+    }
+    const bool tm = timing();
+    if (tm && hipStreamSynchronize(s) != hipSuccess) { err = "comm bcast: stream"; return 1; }
+    const auto t0 = std::chrono::steady_clock::now();
+    stats.bcast_calls += 1;
+    stats.bcast_bytes += (double)bytes;
     if (!shm) {
-      const ncclResult_t r = api.Broadcast(buf_d, buf_d, bytes, ncclUint8, root, nccl, s);
-      if (r != ncclSuccess) {
-        err = std::string("ncclBroadcast: ") + api.GetErrorString(r);
-        return 1;
+      for (size_t off = 0; off < bytes; off += COMM_PIECE_BYTES) {
+        const size_t len = bytes - off < COMM_PIECE_BYTES ? bytes - off : COMM_PIECE_BYTES;
+        char *d = static_cast<char *>(buf_d) + off;
+        const ncclResult_t r = api.Broadcast(d, d, len, ncclUint8, root, nccl, s);
+        if (r != ncclSuccess) {
+          err = std::string("ncclBroadcast: ") + api.GetErrorString(r);
+          return 1;
+        }
+        stats.bcast_pieces += 1;
+      }
+      if (tm) {
+        if (hipStreamSynchronize(s) != hipSuccess) { err = "comm bcast: stream"; return 1; }
+        stats.bcast_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
       }
       return 0;
     }
@@ -151,18 +201,38 @@ struct Comm {
       if (rank == root && hipMemcpy(pinned, d, len, hipMemcpyDeviceToHost) != hipSuccess) { err = "comm bcast: D2H"; return 1; }
       tr.bcast_chunk(pinned, len, root);
       if (rank != root && hipMemcpy(d, pinned, len, hipMemcpyHostToDevice) != hipSuccess) { err = "comm bcast: H2D"; return 1; }
+      stats.bcast_pieces += 1;
     }
+    if (tm) stats.bcast_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     return 0;
   }
 
   // in place sum over ranks of `count` doubles on the device (the shm transport adds in rank order on every rank)
   int allreduce_sum(double *buf_d, size_t count, hipStream_t s, std::string &err) {
     if (!active || world == 1 || count == 0) return 0;
+    if (fail_at("allreduce") || (count >= (size_t(1) << 17) && fail_at("allreduce_large"))) {
+      err = "comm allreduce: failure injected (GEMMA_HIP_COMM_FAIL)";
+      return 1;
+    }
+    const bool tm = timing();
+    if (tm && hipStreamSynchronize(s) != hipSuccess) { err = "comm allreduce: stream"; return 1; }
+    const auto t0 = std::chrono::steady_clock::now();
+    stats.allreduce_calls += 1;
+    stats.allreduce_bytes += 8.0 * (double)count;
     if (!shm) {
-      const ncclResult_t r = api.AllReduce(buf_d, buf_d, count, ncclFloat64, ncclSum, nccl, s);
-      if (r != ncclSuccess) {
-        err = std::string("ncclAllReduce: ") + api.GetErrorString(r);
-        return 1;
+      const size_t piece = COMM_PIECE_BYTES / sizeof(double);
+      for (size_t off = 0; off < count; off += piece) {
+        const size_t len = count - off < piece ? count - off : piece;
+        const ncclResult_t r = api.AllReduce(buf_d + off, buf_d + off, len, ncclFloat64, ncclSum, nccl, s);
+        if (r != ncclSuccess) {
+          err = std::string("ncclAllReduce: ") + api.GetErrorString(r);
+          return 1;
+        }
+        stats.allreduce_pieces += 1;
+      }
+      if (tm) {
+        if (hipStreamSynchronize(s) != hipSuccess) { err = "comm allreduce: stream"; return 1; }
+        stats.allreduce_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
       }
       return 0;
     }
@@ -173,8 +243,53 @@ struct Comm {
       if (hipMemcpy(pinned, buf_d + off, len * 8, hipMemcpyDeviceToHost) != hipSuccess) { err = "comm allreduce: D2H"; return 1; }
       tr.allreduce_chunk(static_cast<double *>(pinned), len);
       if (hipMemcpy(buf_d + off, pinned, len * 8, hipMemcpyHostToDevice) != hipSuccess) { err = "comm allreduce: H2D"; return 1; }
+      stats.allreduce_pieces += 1;
     }
+    if (tm) stats.allreduce_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     return 0;
+  }
+
+  // The first contact of a new communicator: ONE KiB through both collectives before anything n^2 is trusted
+  // to them -- an all-reduce of (rank + 1) in 128 doubles, a broadcast of a pattern from rank 0 and one from the last rank, every
+  // value checked on every rank.  Synchronous; the caller runs it under its own wall-clock deadline (a bootstrap that hangs in
+  // here costs that deadline, not the run).
+  int selftest(hipStream_t s, std::string &err) {
+    if (!active || world == 1) return 0;
+    if (fail_at("selftest")) {
+      err = "comm selftest: failure injected (GEMMA_HIP_COMM_FAIL=selftest)";
+      return 1;
+    }
+    const size_t cnt = 128;
+    double *d = nullptr;
+    if (hipMalloc(&d, cnt * sizeof(double)) != hipSuccess) { err = "comm selftest: device buffer"; return 1; }
+    std::vector<double> h(cnt);
+    int rc = 0;
+    do {
+      for (size_t i = 0; i < cnt; ++i) h[i] = (double)(rank + 1) * (double)(i + 1);
+      if (hipMemcpyAsync(d, h.data(), cnt * 8, hipMemcpyHostToDevice, s) != hipSuccess) { err = "comm selftest: H2D"; rc = 1; break; }
+      if (allreduce_sum(d, cnt, s, err)) { rc = 1; break; }
+      if (hipMemcpyAsync(h.data(), d, cnt * 8, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) {
+        err = "comm selftest: D2H after the all-reduce"; rc = 1; break;
+      }
+      const double want = 0.5 * world * (world + 1);
+      for (size_t i = 0; i < cnt; ++i)
+        if (h[i] != want * (double)(i + 1)) { err = "comm selftest: the all-reduce returned a wrong sum"; rc = 1; break; }
+      if (rc) break;
+      const int roots[2] = {0, world - 1};
+      for (int k = 0; k < 2 && !rc; ++k) {
+        const int root = roots[k];
+        for (size_t i = 0; i < cnt; ++i) h[i] = rank == root ? 1000.0 * (root + 1) + (double)i : -1.0;
+        if (hipMemcpyAsync(d, h.data(), cnt * 8, hipMemcpyHostToDevice, s) != hipSuccess) { err = "comm selftest: H2D"; rc = 1; break; }
+        if (bcast(d, cnt * 8, root, s, err)) { rc = 1; break; }
+        if (hipMemcpyAsync(h.data(), d, cnt * 8, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) {
+          err = "comm selftest: D2H after the broadcast"; rc = 1; break;
+        }
+        for (size_t i = 0; i < cnt; ++i)
+          if (h[i] != 1000.0 * (root + 1) + (double)i) { err = "comm selftest: the broadcast delivered wrong bytes"; rc = 1; break; }
+      }
+    } while (0);
+    (void)hipFree(d);
+    return rc;
   }
 
   void finalize() {

@@ -722,6 +722,79 @@ __global__ void eig_scale_kernel(double *v, long n, double s) {
 }
 
 // ---------------------------------------------------------------- host orchestration
+// The workspace of a solve is ~5 n^2 doubles in thirty-odd buffers, and hipMalloc / hipFree of such sizes cost 25-50 ms per GB
+// (profiles/r05_alloc_probe.txt): 0.1-0.2 s of a 1.9 s solve at n = 20 000, 1.0-2.2 s of 19 s at n = 50 000 -- per call, because the
+// buffers were freed on the way out.  Round 6: the buffers of one solve can stay in a pool between calls.
+// Off unless asked for -- gemma_hip_eigh_reserve(n) (allocates the workspace of order n ahead of the solve: a caller that knows its n
+// does this while it reads files) or GEMMA_HIP_EIGH_CACHE=1 (every solve leaves its buffers behind) -- and gemma_hip_eigh_release()
+// hands the memory back; lmm_setup* drops a pool that holds more than a quarter of the device.  A request is served by the smallest
+// idle block of at least its size and at most 9/8 of it (the same n again: exact fits in the order of allocation).
+struct EigPool {
+  struct Blk { void *p; size_t bytes; bool used; };
+  std::vector<Blk> blks;
+  bool keep = false;
+  static bool env_keep() {
+    const char *e = getenv("GEMMA_HIP_EIGH_CACHE");
+    return e && e[0] == '1';
+  }
+  void *take(size_t bytes) {
+    long best = -1;
+    for (size_t i = 0; i < blks.size(); ++i)
+      if (!blks[i].used && blks[i].bytes >= bytes && blks[i].bytes <= bytes + bytes / 8 + 4096 &&
+          (best < 0 || blks[i].bytes < blks[(size_t)best].bytes))
+        best = (long)i;
+    if (best >= 0) {
+      blks[(size_t)best].used = true;
+      return blks[(size_t)best].p;
+    }
+    void *q = nullptr;
+    if (hipMalloc(&q, bytes) != hipSuccess) {
+      (void)hipGetLastError();
+      // idle blocks of other sizes may be what stands in the way: hand them back and try once more
+      if (drop_idle() == 0) return nullptr;
+      if (hipMalloc(&q, bytes) != hipSuccess) {
+        (void)hipGetLastError();
+        return nullptr;
+      }
+    }
+    blks.push_back({q, bytes, true});
+    return q;
+  }
+  void give(void *q) {
+    for (size_t i = 0; i < blks.size(); ++i)
+      if (blks[i].p == q) {
+        if (keep || env_keep()) {
+          blks[i].used = false;
+        } else {
+          (void)hipFree(q);
+          blks.erase(blks.begin() + (long)i);
+        }
+        return;
+      }
+    (void)hipFree(q); // not ours (cannot happen): still the caller's to free
+  }
+  size_t idle_bytes() const {
+    size_t b = 0;
+    for (const Blk &k : blks)
+      if (!k.used) b += k.bytes;
+    return b;
+  }
+  size_t drop_idle() {
+    size_t freed = 0;
+    for (size_t i = blks.size(); i-- > 0;)
+      if (!blks[i].used) {
+        (void)hipFree(blks[i].p);
+        freed += blks[i].bytes;
+        blks.erase(blks.begin() + (long)i);
+      }
+    return freed;
+  }
+};
+static inline EigPool &eig_pool() {
+  static EigPool pool;
+  return pool;
+}
+
 struct EigWs {
   long n = 0;
   double *VT = nullptr, *WT = nullptr, *xcol = nullptr, *p = nullptr, *ab = nullptr;
@@ -739,17 +812,14 @@ struct EigWs {
   GivensRot *rot = nullptr;
   std::vector<void *> owned;
   template <class Tp> bool get(Tp *&ptr, size_t count) {
-    void *q = nullptr;
-    if (hipMalloc(&q, std::max<size_t>(count, 1) * sizeof(Tp)) != hipSuccess) {
-      (void)hipGetLastError();
-      return false;
-    }
+    void *q = eig_pool().take(std::max<size_t>(count, 1) * sizeof(Tp));
+    if (!q) return false;
     owned.push_back(q);
     ptr = reinterpret_cast<Tp *>(q);
     return true;
   }
   void release() {
-    for (void *q : owned) (void)hipFree(q);
+    for (void *q : owned) eig_pool().give(q);
     owned.clear();
   }
 };
@@ -1134,12 +1204,8 @@ static inline unsigned long long eig_fnv(unsigned long long h, const void *p, si
   return h;
 }
 
-// G (n x n symmetric, device, destroyed) -> U (row-major, eigenvector k in column k), eval ascending.
-static inline int eigh_device_core(double *G, long n, double *U, double *eval, hipStream_t s, std::string &msg,
-                                   const EighShard *sh = nullptr) {
-  EigWs ws;
-  ws.n = n;
-  const double t_enter = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+// every buffer a solve of order n takes (eigh_device_core; gemma_hip_eigh_reserve runs this alone and hands the blocks to the pool)
+static inline bool eig_alloc_all(long n, EigWs &ws, Eig2Ws &w2) {
   const size_t nn = (size_t)n * n;
   bool ok = ws.get(ws.VT, nn) && ws.get(ws.WT, (size_t)EIG_NB * n) && ws.get(ws.xcol, n + 2) && ws.get(ws.p, n) &&
             ws.get(ws.ab, 2 * EIG_NB) && ws.get(ws.ssbuf, n / TD_ROWS + 2) && ws.get(ws.dotbuf, n / TD_ROWS + 2) &&
@@ -1164,12 +1230,23 @@ static inline int eigh_device_core(double *G, long n, double *U, double *eval, h
       ok = ws.get(ws.rowP, nseg * (size_t)n) && ws.get(ws.colP, nstrip * (size_t)n);
     }
   }
-  const bool two = eig_two_stage(n);
-  Eig2Ws w2;
-  if (ok && two) {
+  if (ok && eig_two_stage(n)) {
     if (!ws.Tall) ok = ws.get(ws.Tall, (size_t)((n + EIG_NB - 1) / EIG_NB) * EIG_NB * EIG_NB);
     ok = ok && eig2_alloc(n, ws, w2);
   }
+  return ok;
+}
+
+// G (n x n symmetric, device, destroyed) -> U (row-major, eigenvector k in column k), eval ascending.
+static inline int eigh_device_core(double *G, long n, double *U, double *eval, hipStream_t s, std::string &msg,
+                                   const EighShard *sh = nullptr) {
+  EigWs ws;
+  ws.n = n;
+  const double t_enter = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+  const size_t nn = (size_t)n * n;
+  Eig2Ws w2;
+  const bool two = eig_two_stage(n);
+  bool ok = eig_alloc_all(n, ws, w2);
   // Collective runs: a rank that fails on its own (allocation, a non-finite entry, a leaf that does not converge) must not leave
   // the others waiting inside a collective it never reaches -- before the first exchange the ranks agree, with one all-reduce of
   // a status word in a buffer of its own, that every one of them got that far; if any did not, all of them return an error.

@@ -36,6 +36,12 @@ int dbg_stedc_x(const double *d, const double *e, size_t n, double *w, double *Z
 // one-stage back-transformation, sort + transpose, n, stages}
 void eigh_last_stages(double *t8);
 
-void eigh_tu_shutdown(); // side stream / events of this unit's GEMM launcher
+// The solver's workspace pool (eigh.hip.h, EigPool): reserve = allocate every buffer a solve of order n takes and leave them idle in
+// the pool (which from then on keeps the buffers of every solve); release = hand all idle buffers back; bytes = what sits idle.
+int eigh_reserve_x(long n, std::string &msg);
+size_t eigh_release_x();
+size_t eigh_pool_idle_bytes_x();
+
+void eigh_tu_shutdown(); // side stream / events of this unit's GEMM launcher; the workspace pool
 
 } // namespace gemma_hip

@@ -43,7 +43,35 @@ void eigh_last_stages(double *t8) {
 
 void eigh_tu_shutdown() {
   gemm_aux_destroy();
+  eig_pool().keep = false;
+  (void)eig_pool().drop_idle();
 }
+
+int eigh_reserve_x(long n, std::string &msg) {
+  if (n < 1) {
+    msg = "eigh_reserve: n < 1";
+    return GEMMA_HIP_EINVAL;
+  }
+  const long ne = eig_effective_n(n); // an odd order runs embedded in n + 1
+  eig_pool().keep = true;
+  EigWs ws;
+  ws.n = ne;
+  Eig2Ws w2;
+  const bool ok = eig_alloc_all(ne, ws, w2);
+  ws.release(); // into the pool (keep is on); a partial set stays too: the solve reports the shortage itself
+  if (!ok) {
+    msg = "eigh_reserve: cannot allocate the eigensolver workspace (about 5 n^2 doubles)";
+    return GEMMA_HIP_ENOMEM;
+  }
+  return 0;
+}
+
+size_t eigh_release_x() {
+  eig_pool().keep = false;
+  return eig_pool().drop_idle();
+}
+
+size_t eigh_pool_idle_bytes_x() { return eig_pool().idle_bytes(); }
 
 // Householder tridiagonalisation only: G (host, n x n) -> d[n], e[n-1], tau[n], VT (n x n, row j = u_j)
 int dbg_tridiag_x(const double *G, size_t n, double *d, double *e, double *tau, double *VT, std::string &msg) {

@@ -897,6 +897,21 @@ extern "C" int gemma_hip_eigh_sharded_d(double *G, size_t n, double *U, double *
   return eigh_d_impl(G, n, U, eval, trace_G, stream, true);
 }
 
+// The eigensolver's workspace (~5 n^2 doubles) ahead of the solve, kept between solves (csrc/eigh.hip.h, EigPool).
+extern "C" int gemma_hip_eigh_reserve(size_t n) {
+  NEED_INIT();
+  std::string msg;
+  const int rc = eigh_reserve_x((long)n, msg);
+  if (rc) return fail(rc, "%s", msg.c_str());
+  return GEMMA_HIP_OK;
+}
+
+extern "C" int gemma_hip_eigh_release(size_t *bytes_freed) {
+  const size_t b = eigh_release_x();
+  if (bytes_freed) *bytes_freed = b;
+  return GEMMA_HIP_OK;
+}
+
 extern "C" int gemma_hip_dbg_eigh_last(double *t8) {
   if (!t8) return fail(GEMMA_HIP_EINVAL, "dbg_eigh_last: null argument");
   eigh_last_stages(t8);
@@ -1046,6 +1061,12 @@ static int lmm_common_setup(const gemma_lmm_cfg *cfg) {
   if (cfg->n <= cfg->n_cvt + 1) return fail(GEMMA_HIP_EINVAL, "lmm_setup: n <= n_cvt + 1");
   if (cfg->n > 0x7fffffffUL) return fail(GEMMA_HIP_EINVAL, "lmm_setup: n too large");
   g_ctx.cfg = *cfg;
+  {
+    // the eigensolver's workspace pool (gemma_hip_eigh_reserve / GEMMA_HIP_EIGH_CACHE): a pool that holds more than a quarter of
+    // the device would stand in the way of this setup's own buffers (n = 50 000: 100+ GB idle beside 70 GB of digit planes)
+    size_t mf = 0, mt = 0;
+    if (eigh_pool_idle_bytes_x() > 0 && hipMemGetInfo(&mf, &mt) == hipSuccess && eigh_pool_idle_bytes_x() > mt / 4) (void)eigh_release_x();
+  }
   g_ctx.knobs.load(); // the environment switches of the batch path: once per setup
   AssocArgs &a = g_ctx.assoc_proto;
   memset(&a, 0, sizeof a);
@@ -1689,7 +1710,7 @@ static int i8_gemm_rows(const I8Dims &d, size_t row0, size_t rows_pad, hipStream
       HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(i8gemm_sparse2_kernel),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, S2_NST * S2_STAGE));
       HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(i8gemm_sparse2_r16_kernel),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, S2_NST * S2_STAGE));
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, S2_R16_LDS));
       attr3 = true;
     }
     Sparse2Args g2;
@@ -1721,7 +1742,7 @@ static int i8_gemm_rows(const I8Dims &d, size_t row0, size_t rows_pad, hipStream
                          S2_NST * S2_STAGE, s, g2);
     else
       hipLaunchKernelGGL(i8gemm_sparse2_r16_kernel, dim3((unsigned)(g2.tiles_m * g2.tiles_n), (unsigned)d.nplanes), dim3(512),
-                         S2_NST * S2_STAGE, s, g2);
+                         S2_R16_LDS, s, g2);
   } else if (sparse) {
     static bool attr2 = false;
     if (!attr2) {
@@ -3340,6 +3361,27 @@ extern "C" int gemma_hip_comm_allreduce_sum_d(double *buf_d, size_t count, void 
 
 extern "C" int gemma_hip_comm_finalize(void) {
   g_ctx.comm.finalize();
+  return GEMMA_HIP_OK;
+}
+
+extern "C" int gemma_hip_comm_selftest(void *stream) {
+  NEED_INIT();
+  std::string err;
+  if (g_ctx.comm.selftest(S(stream), err)) return fail(GEMMA_HIP_ERUNTIME, "%s", err.c_str());
+  return GEMMA_HIP_OK;
+}
+
+extern "C" int gemma_hip_comm_stats(gemma_comm_stats *out) {
+  if (!out) return fail(GEMMA_HIP_EINVAL, "comm_stats: null");
+  const CommStats &st = g_ctx.comm.stats;
+  out->allreduce_calls = st.allreduce_calls;
+  out->allreduce_pieces = st.allreduce_pieces;
+  out->bcast_calls = st.bcast_calls;
+  out->bcast_pieces = st.bcast_pieces;
+  out->allreduce_bytes = st.allreduce_bytes;
+  out->bcast_bytes = st.bcast_bytes;
+  out->allreduce_s = st.allreduce_s;
+  out->bcast_s = st.bcast_s;
   return GEMMA_HIP_OK;
 }
 

@@ -28,8 +28,25 @@
 #ifndef S2_R16_PREP_SPREAD
 #define S2_R16_PREP_SPREAD 0
 #endif
+// timing experiments only (scripts/i8_kernel_bench.hip, round 6 power table): the sparse (mask) / the dense (genotype) matrix
+// instructions compiled out -- results wrong, everything else of the loop (LDS reads, LDS-DMA, operand preparation) unchanged
+// LDS stages of the K pipeline (S2_STAGE = 32 KiB each): LDS-DMA runs S2_R16_NST - 1 K-tiles ahead.  4 = rounds 3-5; 5 fills the
+// CU's 160 KiB exactly: 128 instead of 96 KiB of operands in flight per CU.  Round 6: the loop's data side is bound by
+// (bytes in flight) / (latency of an L2 miss served across the fabric) -- profiles/r06_power_table.txt: with the dense matrix
+// instructions compiled out the same loop still takes 29 ms for its 382 GB of LDS-DMA = 53 GB/s per CU = 96 KiB per ~1.8 us.
+#ifndef S2_R16_NST
+#define S2_R16_NST 4
+#endif
+#ifndef S2_R16_ABL_NO_S
+#define S2_R16_ABL_NO_S 0
+#endif
+#ifndef S2_R16_ABL_NO_D
+#define S2_R16_ABL_NO_D 0
+#endif
 
 namespace gemma_hip {
+
+constexpr int S2_R16_LDS = S2_R16_NST * S2_STAGE; // dynamic LDS of a launch
 
 __global__ __launch_bounds__(512, 2) void i8gemm_sparse2_r16_kernel(Sparse2Args g) {
   extern __shared__ __attribute__((aligned(1024))) int8_t i8lds[];
@@ -137,11 +154,17 @@ __global__ __launch_bounds__(512, 2) void i8gemm_sparse2_r16_kernel(Sparse2Args 
     asm volatile("" ::"v"(rec[i][0]), "v"(rec[i][1]));                                                            \
   } while (0)
 #define GS_D(i, SB, P, SL)                                                                                        \
-  asm volatile("s_nop 1\n\tv_mfma_i32_16x16x64_i8 %0, %1, %2, %0"                                                 \
-               : "+v"(accg[i][SB])                                                                                \
-               : "v"(ga[i][P]), "v"(__builtin_shufflevector(T[SL], T[SL], 4 * (P), 4 * (P) + 1, 4 * (P) + 2, 4 * (P) + 3)))
+  do {                                                                                                            \
+    if (!S2_R16_ABL_NO_D)                                                                                         \
+      asm volatile("s_nop 1\n\tv_mfma_i32_16x16x64_i8 %0, %1, %2, %0"                                             \
+                   : "+v"(accg[i][SB])                                                                            \
+                   : "v"(ga[i][P]), "v"(__builtin_shufflevector(T[SL], T[SL], 4 * (P), 4 * (P) + 1, 4 * (P) + 2, 4 * (P) + 3))); \
+  } while (0)
 #define GS_S(i, SB, SL)                                                                                           \
-  asm volatile("s_nop 1\n\tv_smfmac_i32_16x16x128_i8 %0, %1, %2, %3" : "+v"(accm[i][SB]) : "v"(ms[i]), "v"(T[SL]), "v"(ix[i]))
+  do {                                                                                                            \
+    if (!S2_R16_ABL_NO_S)                                                                                         \
+      asm volatile("s_nop 1\n\tv_smfmac_i32_16x16x128_i8 %0, %1, %2, %3" : "+v"(accm[i][SB]) : "v"(ms[i]), "v"(T[SL]), "v"(ix[i])); \
+  } while (0)
 // the six matrix instructions of sub-block SB (ring slot SL); X: statements issued behind the first two
 #define GS_STEP(SB, SL, X)                                                                                        \
   do {                                                                                                            \
@@ -196,6 +219,7 @@ __global__ __launch_bounds__(512, 2) void i8gemm_sparse2_r16_kernel(Sparse2Args 
           for (int r = 0; r < 4; ++r) { accg[i][j][r] <<= 8; accm[i][j][r] <<= 8; }
     }
     GS_INIT_SRC(d_first - dd);
+    // prologue: tiles 0 .. NST - 2 in flight, tile 0 landed
 #pragma unroll
     for (int j = 0; j < 2; ++j) { GS_DMA_A(j, 0); GS_DMA_B(j, 0); }
     if (nk > 1) {
@@ -205,6 +229,12 @@ __global__ __launch_bounds__(512, 2) void i8gemm_sparse2_r16_kernel(Sparse2Args 
     if (nk > 2) {
 #pragma unroll
       for (int j = 0; j < 2; ++j) { GS_DMA_A(j, 2 * S2_STAGE); GS_DMA_B(j, 2 * S2_STAGE); }
+    }
+    if (S2_R16_NST == 5 && nk > 3) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) { GS_DMA_A(j, 3 * S2_STAGE); GS_DMA_B(j, 3 * S2_STAGE); }
+      asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    } else if (nk > 2) {
       asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     } else if (nk > 1) {
       asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
@@ -221,21 +251,41 @@ __global__ __launch_bounds__(512, 2) void i8gemm_sparse2_r16_kernel(Sparse2Args 
     GS_PREP(1);
     GEMMA_SB();
 
-    int sc = 0, sn = S2_STAGE, s2 = 2 * S2_STAGE, sd = 3 * S2_STAGE;
+    // stage byte offsets: tile t, t + 1, ..., the LDS-DMA target (the stage tile t - 1 was read from)
+    int sc = 0, sn = S2_STAGE, s2 = 2 * S2_STAGE, s3 = 3 * S2_STAGE, sd = (S2_R16_NST - 1) * S2_STAGE;
+#define GS_ROTATE()                                                                                               \
+  do {                                                                                                            \
+    const int tmp = sc;                                                                                           \
+    sc = sn; sn = s2;                                                                                             \
+    if (S2_R16_NST == 5) { s2 = s3; s3 = sd; } else { s2 = sd; }                                                  \
+    sd = tmp;                                                                                                     \
+  } while (0)
     int kt = 0;
-    for (; kt + 3 < nk; ++kt) {
-      GS_KTILE(sc, sn, sd, true, true, 8);
-      const int tmp = sc; sc = sn; sn = s2; s2 = sd; sd = tmp;
+    if (S2_R16_NST == 5) {
+      for (; kt + 4 < nk; ++kt) {
+        GS_KTILE(sc, sn, sd, true, true, 12);
+        GS_ROTATE();
+      }
+      if (nk >= 4) {
+        GS_KTILE(sc, sn, sd, true, false, 8);
+        GS_ROTATE();
+      }
+    } else {
+      for (; kt + 3 < nk; ++kt) {
+        GS_KTILE(sc, sn, sd, true, true, 8);
+        GS_ROTATE();
+      }
     }
     if (nk >= 3) {
       GS_KTILE(sc, sn, sd, true, false, 4);
-      const int tmp = sc; sc = sn; sn = s2; s2 = sd; sd = tmp;
+      GS_ROTATE();
     }
     if (nk >= 2) {
       GS_KTILE(sc, sn, sd, true, false, 0);
-      const int tmp = sc; sc = sn; sn = s2; s2 = sd; sd = tmp;
+      GS_ROTATE();
     }
     GS_KTILE(sc, sn, sd, false, false, 0);
+#undef GS_ROTATE
   }
 
   asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");

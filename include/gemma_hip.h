@@ -133,6 +133,14 @@ int gemma_hip_center_d(double *G_d, size_t n, void *stream);
 int gemma_hip_eigh(double *G, size_t n, double *U, double *eval, double *trace_G);
 int gemma_hip_eigh_d(double *G_d, size_t n, double *U_d, double *eval_d, double *trace_G,
                      void *stream);
+/* The solver's device workspace is ~5 n^2 doubles in thirty-odd buffers, and hipMalloc / hipFree of such sizes cost 25-50 ms per GB
+ * (0.1-0.2 s of a 1.9 s solve at n = 20 000, 1-2 s of 19 s at n = 50 000).  gemma_hip_eigh_reserve(n) allocates the workspace of order n
+ * ahead of the solve (a caller that knows its n does this while it reads its files) and from then on every solve leaves its buffers in a
+ * pool for the next one (LOCO: one decomposition per chromosome); gemma_hip_eigh_release hands the idle buffers back (lmm_setup* does
+ * so by itself when the pool holds more than a quarter of the device).  GEMMA_HIP_EIGH_CACHE=1 keeps every solve's buffers without a
+ * reserve call.  Without either the solver allocates and frees per call, as before. */
+int gemma_hip_eigh_reserve(size_t n);
+int gemma_hip_eigh_release(size_t *bytes_freed /* may be NULL */);
 /* The same as a COLLECTIVE over the library's communicator (gemma_hip_comm_init): every rank passes the same G and
  * receives the same (U, eval).  The reduction and the divide & conquer run on every rank (same code, same bits -- checked),
  * the two back-transformations are shared out by eigenvector (rows of Z^T) and the slices exchanged once; with one rank, or
@@ -325,6 +333,20 @@ int gemma_hip_comm_info(int *rank, int *world, int *transport /* 0 none, 1 RCCL,
 int gemma_hip_comm_bcast_d(void *buf_d, size_t bytes, int root, void *stream);
 int gemma_hip_comm_allreduce_sum_d(double *buf_d, size_t count, void *stream);
 int gemma_hip_comm_finalize(void);
+/* The first contact of a new communicator: ONE KiB through both collectives (an all-reduce of rank + 1, a broadcast from rank 0 and one
+ * from the last rank; every value checked on every rank) before anything n^2 is trusted to them.  Synchronous; a caller that cannot
+ * afford a hang runs it under its own wall-clock deadline (bench.py: a helper thread).  Every collective above is cut into pieces of at
+ * most 1 GiB issued back to back on the caller's stream.  GEMMA_HIP_COMM_FAIL=init|selftest|allreduce|bcast|allreduce_large|bcast_large
+ * makes that entry point fail on every rank (the *_large forms only from 1 MiB up, i.e. after a passed self-test): failure injection
+ * for the callers' fall-backs. */
+int gemma_hip_comm_selftest(void *stream);
+/* what the communicator has carried since gemma_hip_comm_init; the seconds are host wall time around synchronised collectives and stay
+ * zero unless GEMMA_HIP_COMM_TIMING=1 is in the environment */
+typedef struct {
+  long allreduce_calls, allreduce_pieces, bcast_calls, bcast_pieces;
+  double allreduce_bytes, bcast_bytes, allreduce_s, bcast_s;
+} gemma_comm_stats;
+int gemma_hip_comm_stats(gemma_comm_stats *out);
 
 /* ---- measurement -------------------------------------------------------- */
 enum { GEMMA_STAGE_INGEST = 0, GEMMA_STAGE_UTX_GEMM = 1, GEMMA_STAGE_ASSOC = 2,

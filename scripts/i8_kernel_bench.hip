@@ -10,6 +10,7 @@
 #include <cstdlib>
 #include <vector>
 #include "i8gemm.hip.h"
+#include "smi_sampler.hpp" // scripts/: socket power / clock / power-limit residency over the timed loop (SMI=1)
 #if __has_include("i8gemm_sparse.hip.h")
 #include "i8gemm_sparse.hip.h"
 #define HAVE_SPARSE 1
@@ -178,7 +179,7 @@ int main(int argc, char **argv) {
     CK(hipFuncSetAttribute(reinterpret_cast<const void *>(i8gemm_sparse2_g16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                            S2_NST * S2_STAGE));
     CK(hipFuncSetAttribute(reinterpret_cast<const void *>(i8gemm_sparse2_r16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                           S2_NST * S2_STAGE));
+                           S2_R16_LDS));
     CK(hipFuncSetAttribute(reinterpret_cast<const void *>(i8gemm_sparse2_r16p_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                            S2_NST * S2_STAGE));
   }
@@ -277,7 +278,7 @@ int main(int argc, char **argv) {
       return;
     }
     if (variant == 7) {
-      hipLaunchKernelGGL(i8gemm_sparse2_r16_kernel, grid2, dim3(512), S2_NST * S2_STAGE, mstream, g2);
+      hipLaunchKernelGGL(i8gemm_sparse2_r16_kernel, grid2, dim3(512), S2_R16_LDS, mstream, g2);
       return;
     }
     if (variant == 8) { // the same kernel, PERSISTENT workgroups: PERSIST_WGS (default 256 = one per CU) walk the (plane, tile) list
@@ -328,6 +329,9 @@ int main(int argc, char **argv) {
   hipEvent_t s0, s1;
   CK(hipEventCreate(&s0));
   CK(hipEventCreate(&s1));
+  SmiSampler smi;
+  const bool use_smi = getenv("SMI") && atoi(getenv("SMI")) && smi.open();
+  if (use_smi) smi.start();
   CK(hipEventRecord(e0, mstream));
   if (cu_split > 0) CK(hipEventRecord(s0, sstream));
   for (int i = 0; i < reps; ++i) {
@@ -343,6 +347,13 @@ int main(int argc, char **argv) {
   CK(hipEventRecord(e1, mstream));
   if (cu_split > 0) CK(hipEventRecord(s1, sstream));
   CK(hipEventSynchronize(e1));
+  if (use_smi) {
+    char tag[64];
+    snprintf(tag, sizeof tag, "variant %d B_MODE %s", variant, getenv("B_MODE") ? getenv("B_MODE") : "0");
+    smi.stop(tag);
+  } else if (getenv("SMI") && atoi(getenv("SMI"))) {
+    printf("[smi] unavailable on this box\n");
+  }
   float ms = 0;
   CK(hipEventElapsedTime(&ms, e0, e1));
   if (cu_split > 0) {

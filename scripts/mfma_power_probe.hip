@@ -10,6 +10,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
+#include "smi_sampler.hpp" // SMI=1: socket power / clock / power-limit residency per run (use iters >= 400000)
 
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v8i __attribute__((ext_vector_type(8)));
@@ -49,7 +50,7 @@ template <int NW> __device__ inline void fill(int (&w)[NW], unsigned seed, int m
 }
 
 // KIND 0: i8 32x32x32; 1: i8 16x16x64; 2: sparse i8 32x32x64; 3: fp8 32x32x64
-template <int KIND> __global__ __launch_bounds__(512) void probe(int iters, int mode, int *sink) {
+template <int KIND> __global__ __launch_bounds__(512) void probe(int iters, int mode, int *sink, int a_zero) {
   const unsigned seed = blockIdx.x * 512u + threadIdx.x;
   int a4[4], b4[4], a8[8], b8[8];
   fill<4>(a4, seed, mode, true, false);
@@ -58,6 +59,11 @@ template <int KIND> __global__ __launch_bounds__(512) void probe(int iters, int 
   fill<8>(b8, seed + 7919u, mode, false, KIND == 3);
   v4i A4 = {a4[0], a4[1], a4[2], a4[3]}, B4 = {b4[0], b4[1], b4[2], b4[3]};
   v8i A8 = {a8[0], a8[1], a8[2], a8[3], a8[4], a8[5], a8[6], a8[7]}, B8 = {b8[0], b8[1], b8[2], b8[3], b8[4], b8[5], b8[6], b8[7]};
+  if (a_zero) { // A_ZERO=1: the left operand of the real mask product -- kept values almost all zero (one lane in 16 holds a single 1)
+    const int one = (threadIdx.x & 15) == 3 ? 1 : 0;
+    A4 = (v4i){one, 0, 0, 0};
+    A8 = (v8i){one, 0, 0, 0, 0, 0, 0, 0};
+  }
   const int idx = 0x44444444;
   v16i c[8];
   v16f f[8];
@@ -98,15 +104,25 @@ __global__ void fp8_check(float *out) {
 
 template <int KIND> static double run(int iters, int mode, int *sink, double ops_per_instr) {
   const int grid = 2048; // 8 wavefronts per workgroup
-  hipLaunchKernelGGL(probe<KIND>, dim3(grid), dim3(512), 0, 0, iters / 8, mode, sink);
+  const int a_zero = getenv("A_ZERO") ? atoi(getenv("A_ZERO")) : 0;
+  hipLaunchKernelGGL(probe<KIND>, dim3(grid), dim3(512), 0, 0, iters / 8, mode, sink, a_zero);
   hipDeviceSynchronize();
+  static SmiSampler smi;
+  static int smi_state = -1;
+  if (smi_state < 0) smi_state = (getenv("SMI") && atoi(getenv("SMI")) && smi.open()) ? 1 : 0;
+  if (smi_state) smi.start();
   hipEvent_t e0, e1;
   hipEventCreate(&e0);
   hipEventCreate(&e1);
   hipEventRecord(e0);
-  hipLaunchKernelGGL(probe<KIND>, dim3(grid), dim3(512), 0, 0, iters, mode, sink);
+  hipLaunchKernelGGL(probe<KIND>, dim3(grid), dim3(512), 0, 0, iters, mode, sink, a_zero);
   hipEventRecord(e1);
   hipEventSynchronize(e1);
+  if (smi_state) {
+    char tag[64];
+    snprintf(tag, sizeof tag, "kind %d digits-mode %d a_zero %d", KIND, mode, a_zero);
+    smi.stop(tag);
+  }
   float ms = 0;
   hipEventElapsedTime(&ms, e0, e1);
   return (double)grid * 8 * iters * 8 * ops_per_instr / (ms * 1e-3) / 1e12;
