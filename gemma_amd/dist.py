@@ -23,7 +23,7 @@ def _staged(t, group):
     """gloo (CPU tests, and the same-device 2-rank GPU test) moves host memory: device tensors are staged through a
     host copy there; with nccl (= RCCL, the real multi-GPU runs) tensors are used in place."""
     import torch.distributed as dist
-    return t.is_cuda and dist.get_backend(group) != "nccl"
+    return t.is_cuda and "nccl" not in str(dist.get_backend(group))  # "nccl", or the mixed "cpu:gloo,cuda:nccl" of bench.py
 
 
 def broadcast_state(tensors, src=0, group=None, small_limit=1 << 22):
@@ -124,14 +124,140 @@ def native_comm_init(group=None, timeout=180.0):
             ok = 0
     except Exception:  # the other ranks must still reach the agreement below
         ok = 0
-    dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
-    flag = torch.tensor([ok], dtype=torch.int32, device=dev)
-    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
-    _native_ready = bool(int(flag[0]) == 1)
+    _native_ready = agree(ok == 1, group)
     _native_failed = not _native_ready
     if not _native_ready and ok == 1 and not _native_poisoned:
         L.lib().gemma_hip_comm_finalize()  # this rank could, another could not: drop the communicator, all take the fallback
+    if not _native_ready:
+        try:
+            _native_error[0] = ("bootstrap timed out after %.0f s" % timeout) if _native_poisoned else \
+                (L.lib().gemma_hip_last_error().decode() or "another rank could not create the communicator")
+        except Exception:  # noqa: BLE001
+            pass
     return _native_ready
+
+
+_native_error = [""]
+
+
+def native_comm_error():
+    """why the last native_comm_init / native_comm_selftest said no on THIS rank ('' when it did not)"""
+    return _native_error[0]
+
+
+def ctl_device(group=None):
+    """Where the small control-plane tensors live: the CPU whenever the process group has a CPU backend (gloo; bench.py's default
+    group is "cpu:gloo,cuda:nccl"), so that agreements, barriers and clock exchanges never depend on the device transport whose
+    health they are about; the current device for a pure-nccl group."""
+    import torch
+    import torch.distributed as dist
+    b = str(dist.get_backend(group))
+    return torch.device("cpu") if ("gloo" in b or b == "undefined") else torch.device("cuda", torch.cuda.current_device())
+
+
+def agree(ok, group=None):
+    """True on every rank iff `ok` is true on every rank (one MIN all-reduce of one int on the control plane)."""
+    import torch
+    import torch.distributed as dist
+    flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=ctl_device(group))
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+    return bool(int(flag[0]) == 1)
+
+
+def ctl_barrier(group=None):
+    """A barrier on the control plane (an all-reduce of one int; dist.barrier() of a mixed-backend group may pick the device backend)."""
+    agree(True, group)
+
+
+def ctl_allreduce(values, op="sum", group=None):
+    """All-reduce a short list of floats on the control plane; returns a list."""
+    import torch
+    import torch.distributed as dist
+    t = torch.tensor([float(v) for v in values], dtype=torch.float64, device=ctl_device(group))
+    dist.all_reduce(t, op={"sum": dist.ReduceOp.SUM, "max": dist.ReduceOp.MAX, "min": dist.ReduceOp.MIN}[op], group=group)
+    return [float(x) for x in t.cpu()]
+
+
+def _with_deadline(fn, timeout):
+    """Run fn() on a helper thread; (finished, result or exception repr).  A call that never returns costs `timeout`, not the run."""
+    import threading
+    import torch
+    box = {}
+    dev_index = torch.cuda.current_device() if torch.cuda.is_available() else None
+
+    def _run():
+        try:
+            if dev_index is not None:
+                torch.cuda.set_device(dev_index)
+            box["v"] = fn()
+        except Exception as e:  # noqa: BLE001
+            box["e"] = repr(e)
+
+    th = threading.Thread(target=_run, daemon=True)
+    th.start()
+    th.join(timeout)
+    if th.is_alive():
+        return False, "no answer within %.0f s" % timeout
+    if "e" in box:
+        return True, box["e"]
+    return True, box.get("v")
+
+
+def native_comm_selftest(group=None, timeout=60.0):
+    """The staged start of the library's communicator: gemma_hip_comm_selftest -- ONE KiB through ncclAllReduce
+    and ncclBroadcast, every value checked -- under a wall-clock deadline, BEFORE anything n^2 goes through it.  A collective like
+    native_comm_init: every rank learns whether all ranks passed; after a "no" the communicator is finalised where that is safe and
+    native_comm_init answers False from then on."""
+    global _native_ready, _native_poisoned, _native_failed
+    import ctypes as C
+    import torch
+    from . import _lib as L
+    if not _native_ready:
+        return False
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    finished, res = _with_deadline(lambda: L.lib().gemma_hip_comm_selftest(stream), timeout)
+    ok = bool(finished and res == 0)
+    if not ok:
+        if not finished:
+            _native_poisoned = True
+            _native_error[0] = "comm self-test: " + str(res)
+        else:
+            try:
+                _native_error[0] = L.lib().gemma_hip_last_error().decode() if isinstance(res, int) else str(res)
+            except Exception:  # noqa: BLE001
+                _native_error[0] = str(res)
+    all_ok = agree(ok, group)
+    if not all_ok:
+        _native_ready = False
+        _native_failed = True
+        if not _native_poisoned:
+            L.lib().gemma_hip_comm_finalize()
+        if not _native_error[0]:
+            _native_error[0] = "another rank failed the communicator's self-test"
+    return all_ok
+
+
+def torch_device_selftest(group=None, timeout=60.0):
+    """The same first contact for torch.distributed's DEVICE backend (nccl = RCCL; lazily initialised in a mixed-backend group): a
+    tiny all-reduce and broadcast of device tensors under a deadline.  Returns (ok on every rank, this rank's error text)."""
+    import torch
+    import torch.distributed as dist
+
+    def _probe():
+        dev = torch.device("cuda", torch.cuda.current_device())
+        t = torch.full((128,), float(dist.get_rank(group) + 1), dtype=torch.float64, device=dev)
+        dist.all_reduce(t, group=group)
+        w = dist.get_world_size(group)
+        b = torch.arange(128, dtype=torch.float64, device=dev) + (1000.0 if dist.get_rank(group) == 0 else -1.0)
+        dist.broadcast(b, src=0, group=group)
+        torch.cuda.synchronize()
+        good = bool((t == 0.5 * w * (w + 1)).all()) and bool((b == torch.arange(128, dtype=torch.float64, device=dev) + 1000.0).all())
+        return 0 if good else "torch.distributed device self-test: wrong values"
+
+    finished, res = _with_deadline(_probe, timeout)
+    ok = bool(finished and res == 0)
+    err = "" if ok else str(res)
+    return agree(ok, group), err
 
 
 def broadcast_state_native(tensors, src=0, small_limit=1 << 22):
