@@ -73,9 +73,11 @@ def parse():
                          "the n x n eigendecomposition through the library's GEMM, its eigenvalues against rocSOLVER's, and -- with "
                          "--cpu-setup -- the kinship of one .bed batch and the eigenvalues of the --cpu-setup-n block against the reference's "
                          "PlinkKin / dsyevr outputs (0 = skip)")
-    ap.add_argument("--digits7-steps", type=int, default=2,
-                    help="extra untimed-region steps with GEMMA_HIP_I8_DIGITS=7 (U kept to 7 base-256 digits = 2^-55 of each column's maximum, "
-                         "below fp64's own rounding) beside the timed region's 6 digits at n >= 16384 (0 = skip)")
+    ap.add_argument("--digits7-steps", type=int, default=-1,
+                    help="steps of the STRICT-precision leg beside the timed region's 6 digits at n >= 16384: GEMMA_HIP_I8_FORM=7g6m -- seven "
+                         "base-256 digits of U for the genotype product (2^-56 of each column's maximum), the mask product on the upper six: "
+                         "U^T x at or below the fp64 GEMM's own rounding error (tests/test_gpu_at_size.py).  -1 (default): as many steps "
+                         "as the timed region, the same blocks; reported as value_strict at equal standing (0 = skip)")
     ap.add_argument("--c4-leg", type=int, default=1,
                     help="1: after everything else, BASELINE config 4's per-GPU piece at its real size in a child process (n = 50000, one "
                          "20000-SNP block per step, 2 steps, kinship from 40000 SNPs, its own eigendecomposition, 64 SNPs against the "
@@ -87,6 +89,10 @@ def parse():
                          "gemma_hip_lmm_batch_pipe_d -- the int8 product of block i + 1 on one CU partition beside the digit combine and per-SNP "
                          "stage of block i on the other (GEMMA_HIP_PIPE_CUS, default 64); the timed region ends with the flush.  Measured in round "
                          "5: no gain on a power-limited product (profiles/r05_pipeline_partition.txt)")
+    ap.add_argument("--config", type=int, default=0,
+                    help="4: BASELINE config 4 with one flag -- n = 50000, p = 500000 SNPs, -gk + -lmm 1, the SNPs (kinship AND association) "
+                         "split over the ranks: steps / batch / kin-snps are derived (ceil(p / ranks / 20000) steps of equal blocks per rank), "
+                         "scaling is 'strong', the optional legs are off.  0 (default): the headline config (configs[2])")
     ap.add_argument("--seed", type=int, default=20000)
     ap.add_argument("--state-file", default="",
                     help="measurement aid: keep the setup's result (U, eval, UtW, Uty, null scalars) in this file -- written "
@@ -233,7 +239,7 @@ def setup_multi_rank(args, np, torch, dist, api, L, gdist, rank, world, dev, gen
         t_kin += time.time() - t0
         done += l
         del blk
-    dist.barrier()
+    gdist.ctl_barrier()
     t0 = time.time()
     ns = api.kin_end_keep(allreduce=True)
     torch.cuda.synchronize()
@@ -241,9 +247,17 @@ def setup_multi_rank(args, np, torch, dist, api, L, gdist, rank, world, dev, gen
     prev_t = os.environ.get("GEMMA_HIP_EIGH_TIMING")
     os.environ["GEMMA_HIP_EIGH_TIMING"] = "1"
     t0 = time.time()
+    try:
+        api.eigh_reserve(n)  # the solver's workspace ahead of its clock (a stage of its own: eigen_workspace_reserve_s)
+    except L.GemmaHipError:
+        pass
+    torch.cuda.synchronize()
+    t_res = time.time() - t0
+    t0 = time.time()
     evh, trace = api.EigenDecomp_kept_K(n, None, sharded=True)
     torch.cuda.synchronize()
     t_eig = time.time() - t0
+    api.eigh_release()
     if prev_t is None:
         os.environ.pop("GEMMA_HIP_EIGH_TIMING", None)
     else:
@@ -270,10 +284,9 @@ def setup_multi_rank(args, np, torch, dist, api, L, gdist, rank, world, dev, gen
     torch.cuda.synchronize()
     t_bc = time.time() - t0
     # the slowest rank's clocks beside rank 0's (one SUM all-reduce of a world x 4 table)
-    tab = torch.zeros((world, 4), dtype=torch.float64, device=dev)
-    tab[rank] = torch.tensor([t_kin, t_all, t_eig, t_bc], dtype=torch.float64, device=dev)
-    dist.all_reduce(tab, op=dist.ReduceOp.SUM)
-    tab = tab.cpu().numpy()
+    flat = [0.0] * (4 * world)
+    flat[4 * rank:4 * rank + 4] = [t_kin, t_all, t_eig, t_bc]
+    tab = np.array(gdist.ctl_allreduce(flat, "sum")).reshape(world, 4)
     transport = api.comm_info()[2]
     two = int(t8[7]) == 2
     setup_info.update({
@@ -285,6 +298,7 @@ def setup_multi_rank(args, np, torch, dist, api, L, gdist, rank, world, dev, gen
         "allreduce_s": round(t_all, 3),
         "allreduce": "%s of the n^2 kinship sums + the SNP count, issued by libgemma_hip.so (gemma_hip_kin_end_keep); %.2f GB per rank"
                      % ("ncclAllReduce" if transport == 1 else "shm test transport's all-reduce", 8.0 * n * n / 1e9),
+        "eigen_workspace_reserve_s": round(t_res, 3),
         "eigen_s": round(t_eig, 3),
         "eigen": "gemma_hip_eigh_kept_K_sharded (%s)" % (
             "two-stage; collective over %d ranks: reduction and divide & conquer on every rank, back-transformations shared out by "
@@ -299,6 +313,29 @@ def setup_multi_rank(args, np, torch, dist, api, L, gdist, rank, world, dev, gen
     return {"broadcast": ("native: ncclBroadcast from libgemma_hip.so's communicator" if transport == 1 else
                           "native: libgemma_hip.so's communicator over its shm test transport (GEMMA_HIP_COMM=shm)") +
                          "; (U, eval) from the collective eigensolver on the all-reduced kept K, not broadcast"}
+
+
+def apply_config(args, world):
+    """--config 4 (BASELINE configs[3]): n = 50 000, p = 500 000 SNPs split over the ranks -- kinship shares and association blocks."""
+    if args.config == 0:
+        return None
+    if args.config != 4:
+        raise SystemExit("bench.py: --config %d is not a bench workload (0 = headline, 4 = BASELINE config 4)" % args.config)
+    p_total = 500000
+    args.n = 50000
+    per_rank = (p_total + world - 1) // world
+    args.steps = max(1, (per_rank + 19999) // 20000)
+    args.batch = (per_rank + args.steps - 1) // args.steps
+    args.kin_snps = p_total
+    args.warmup = min(args.warmup, 1)
+    args.fp64_steps = args.dosage_steps = args.digits7_steps = 0
+    args.miss_leg = args.lowh2_leg = 0.0
+    args.e2e_snps = 0
+    args.c4_leg = 0
+    args.cpu_setup = 0
+    args.cpu_sample = min(args.cpu_sample, 64)
+    args.ref_procs = 1
+    return {"config": 4, "p_total": p_total, "snps_per_rank": args.batch * args.steps}
 
 
 def main():
@@ -322,9 +359,14 @@ def main():
         local = int(os.environ["BENCH_FORCE_DEVICE"])
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    preset = apply_config(args, world)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")
+        # Control plane on gloo (CPU tensors: agreements, barriers, the clocks' exchange), device tensors on nccl = RCCL, whose
+        # communicator torch creates lazily at the first device collective -- under the staged start below, not here.  A pure
+        # "nccl" group (BENCH_DIST_BACKEND=nccl) initialises eagerly, a pure "gloo" one stages device tensors through the host
+        # (the tests' N-ranks-on-one-device route).
+        backend = os.environ.get("BENCH_DIST_BACKEND", "cpu:gloo,cuda:nccl")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
@@ -336,17 +378,45 @@ def main():
 
     api.init(local, verbose=0)
     name, n_cu, hbm = api.device_info()
-    # the library's own communicator (RCCL; its shm test transport only when asked for by name, for N ranks on ONE device in
-    # the tests), created before the setup: the eigensolver uses it (collective decomposition, see below)
+    # ---- staged start of the transports: this run must come back with a line whatever the fabric does.
+    #   native      libgemma_hip.so's own communicator (librccl: ncclCommInitRank under a deadline, then ONE KiB through ncclAllReduce /
+    #               ncclBroadcast under a deadline) -- the real flow: sharded kinship, one all-reduce, collective eigensolver
+    #   torch       rank 0 runs the setup alone, (U, eval, UtW, Uty, null) travel over torch.distributed (its own first contact under a
+    #               deadline as well) -- LABELLED as such
+    #   replicated  no device transport at all: every rank runs the setup itself; the timed region is communication-free anyway
+    # Every decision is an agreement on the control plane, so all ranks take the same branch.
     native = False
+    comm_log = {"tried": []}
+    setup_mode = "single"
     if world > 1:
-        want_native = os.environ.get("BENCH_DIST_BACKEND", "nccl") == "nccl" or os.environ.get("GEMMA_HIP_COMM", "") == "shm"
-        native = bool(want_native and gdist.native_comm_init())
+        pure_gloo = os.environ.get("BENCH_DIST_BACKEND", "") == "gloo"
+        want_native = (not pure_gloo) or os.environ.get("GEMMA_HIP_COMM", "") == "shm"
+        if want_native:
+            t0 = time.time()
+            native = bool(gdist.native_comm_init(timeout=float(os.environ.get("BENCH_COMM_DEADLINE", "180"))))
+            comm_log["tried"].append({"stage": "libgemma_hip.so communicator: init", "ok": native, "seconds": round(time.time() - t0, 2),
+                                      "error": None if native else gdist.native_comm_error()})
+            if native:
+                t0 = time.time()
+                native = bool(gdist.native_comm_selftest(timeout=float(os.environ.get("BENCH_COMM_DEADLINE", "180")) / 3))
+                comm_log["tried"].append({"stage": "libgemma_hip.so communicator: 1 KiB all-reduce + broadcast", "ok": native,
+                                          "seconds": round(time.time() - t0, 2), "error": None if native else gdist.native_comm_error()})
+        if native:
+            setup_mode = "native"
+        else:
+            t0 = time.time()
+            if pure_gloo:
+                ok_t, err_t = True, ""
+            else:
+                ok_t, err_t = gdist.torch_device_selftest(timeout=float(os.environ.get("BENCH_COMM_DEADLINE", "180")) / 3)
+            comm_log["tried"].append({"stage": "torch.distributed device collectives (%s): 1 KiB all-reduce + broadcast"
+                                               % os.environ.get("BENCH_DIST_BACKEND", "cpu:gloo,cuda:nccl"),
+                                      "ok": bool(ok_t), "seconds": round(time.time() - t0, 2), "error": err_t or None})
+            setup_mode = "torch" if ok_t else "replicated"
         if want_native and not native:
-            # no silent fall-back: N ranks on N devices go through the library's own RCCL communicator or the
-            # run says why not.  BENCH_DIST_BACKEND=gloo (without GEMMA_HIP_COMM=shm) is the explicit torch.distributed-only route.
-            raise SystemExit("bench.py: the library's communicator (librccl via gemma_hip_comm_init) did not come up on all %d ranks; "
-                             "set BENCH_DIST_BACKEND=gloo to run the torch.distributed-only setup instead" % world)
+            comm_log["error"] = "; ".join("%s: %s" % (t["stage"], t["error"]) for t in comm_log["tried"] if not t["ok"])
+        comm_log["setup_mode"] = setup_mode
+    replicated = setup_mode == "replicated"
     n, B = args.n, args.batch
     torch.manual_seed(args.seed + rank)
     gen = torch.Generator(device=dev).manual_seed(args.seed + 1000 * rank)
@@ -374,11 +444,47 @@ def main():
     multi_real = world > 1 and native and args.eigen in ("auto", "gemma") and not args.state_file
     kept_state = None
     if multi_real:
-        kept_state = setup_multi_rank(args, np, torch, dist, api, L, gdist, rank, world, dev, gen, n, B, setup_info, null, UtW, Uty)
-        shard_eig = True
-        del U  # (U, eval) are the library's kept buffers in this flow (gemma_hip_eigh_kept_K_sharded); nothing of them is a torch tensor
-        U = None
-    if rank == 0 and not loaded and not multi_real:
+        # the real flow, under a deadline and an agreement: a collective that FAILS after the passed self-test (or never returns) must
+        # cost this run its native setup, not its line
+        fin, res = gdist._with_deadline(lambda: setup_multi_rank(args, np, torch, dist, api, L, gdist, rank, world, dev, gen, n, B, setup_info,
+                                                                 null, UtW, Uty),
+                                        float(os.environ.get("BENCH_SETUP_DEADLINE", str(600 + 900 * (n / 50000.0) ** 3))))
+        ok_here = bool(fin and isinstance(res, dict))
+        if gdist.agree(ok_here):
+            kept_state = res
+            shard_eig = True
+            del U  # (U, eval) are the library's kept buffers in this flow (gemma_hip_eigh_kept_K_sharded); nothing of them is a torch tensor
+            U = None
+        else:
+            why = ("no answer within the setup deadline" if not fin else str(res))
+            comm_log["tried"].append({"stage": "native multi-rank setup (sharded kinship -> ncclAllReduce -> collective eigensolver -> ncclBroadcast)",
+                                      "ok": False, "error": why if not ok_here else "another rank failed"})
+            comm_log["error"] = (comm_log.get("error", "") + "; " if comm_log.get("error") else "") + "native setup: " + \
+                                (why if not ok_here else "another rank failed")
+            multi_real = False
+            native = False
+            replicated = True
+            setup_mode = comm_log["setup_mode"] = "replicated"
+            setup_info.clear()
+            if not fin:
+                # the helper thread is still inside the library, its stream may never drain: everything from here on runs on a new stream
+                torch.cuda.set_stream(torch.cuda.Stream(device=dev))
+            else:
+                try:
+                    api.kept_release()
+                except Exception:  # noqa: BLE001
+                    pass
+                try:
+                    L.lib().gemma_hip_comm_finalize()
+                except Exception:  # noqa: BLE001
+                    pass
+            torch.manual_seed(args.seed + rank)
+            gen = torch.Generator(device=dev).manual_seed(args.seed + 1000 * rank)
+    if replicated:
+        # every rank builds the SAME setup from the seeds rank 0 uses; its own blocks of the timed region are drawn afterwards
+        torch.manual_seed(args.seed)
+        gen = torch.Generator(device=dev).manual_seed(args.seed)
+    if (rank == 0 or replicated) and not loaded and not multi_real:
         # kinship_s / eigen_s are the LIBRARY's stages: the synthetic blocks (torch kernels, loaded lazily on their first use: seconds
         # on a box with a cold page cache) and the load of the library's own code object (first launch) stay outside the clocks
         wa = torch.ones((64, 64), dtype=torch.float64, device=dev)
@@ -456,7 +562,8 @@ def main():
         # (dsyevr at this n "measured once and reported separately", the reference's -gk beside the GPU kinship)
         if world == 1 and args.cpu_setup and args.cpu_sample > 0:
             cpu_setup = start_cpu_setup(args, np, torch, K, n, B, dev)
-        shard_eig = world > 1 and native and args.eigen in ("auto", "gemma") and os.environ.get("GEMMA_HIP_EIGH_SHARD", "1") != "0"
+        shard_eig = (world > 1 and native and not replicated and args.eigen in ("auto", "gemma") and
+                     os.environ.get("GEMMA_HIP_EIGH_SHARD", "1") != "0")
         if shard_eig:
             # every rank needs the centred kinship: in the real flow it HAS it (the SNP-sharded kinship ends in an all-reduce,
             # gemma_hip_kin_end_keep); here rank 0 built K alone from synthetic blocks, so K travels once
@@ -472,7 +579,16 @@ def main():
         if eig in ("auto", "gemma"):
             try:
                 Kc = K.clone()  # the solver destroys its input; the copy is not part of the stage
+                # the solver's ~5 n^2 doubles of workspace ahead of the clock (gemma_hip_eigh_reserve: a stage of its own, reported and
+                # counted in amdahl.setup_once_s; the file driver issues it while it reads the genotype files)
                 torch.cuda.synchronize()
+                t0 = time.time()
+                try:
+                    api.eigh_reserve(n)
+                except L.GemmaHipError:
+                    pass  # the solve below reports the shortage itself
+                torch.cuda.synchronize()
+                setup_info["eigen_workspace_reserve_s"] = round(time.time() - t0, 3)
                 t0 = time.time()
                 if shard_eig:
                     api.EigenDecomp_Zeroed_sharded(Kc, U, ev)
@@ -499,6 +615,7 @@ def main():
         torch.cuda.synchronize()
         setup_info["eigen"] = eig
         setup_info["eigen_s"] = round(time.time() - t0, 3)
+        setup_info["eigen_workspace_released_gb"] = round(api.eigh_release() / 1e9, 1)
         if prev_t is None:
             os.environ.pop("GEMMA_HIP_EIGH_TIMING", None)
         else:
@@ -558,7 +675,10 @@ def main():
         api.profile_read(L.STAGE_UTX_GEMM, reset=True)
         if args.state_file:
             torch.save({"U": U, "ev": ev, "UtW": UtW, "Uty": Uty, "null": null}, args.state_file)
-    if world > 1 and native and not multi_real:
+    if replicated:
+        torch.manual_seed(args.seed + rank)
+        gen = torch.Generator(device=dev).manual_seed(args.seed + 1000 * rank + 1)
+    if world > 1 and native and not multi_real and not replicated:
         # do the other ranks take part in a collective decomposition?  (rank 0 decides: a loaded state file or --eigen torch say no)
         if rank == 0:
             if not sent_go:
@@ -578,6 +698,8 @@ def main():
     bpath = "none (1 rank)"
     if multi_real:
         bpath = kept_state["broadcast"]
+    elif replicated:
+        bpath = "none: no device transport came up -- every rank ran the whole setup itself (see config.comm.error)"
     elif world > 1:
         if native:
             # after a collective decomposition U and eval are everywhere already: only the rotated covariates / phenotype and the
@@ -629,28 +751,28 @@ def main():
     for st in range(L.STAGE_UTX_POST + 1):
         api.profile_read(st, reset=True)
     if world > 1:
-        dist.barrier()
+        gdist.ctl_barrier()  # the contract's barrier: an all-reduce on the control plane (gloo) -- no device transport in or around the timed region
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    t_own0 = t0
     for i in range(args.steps):
         step(blocks[args.warmup + i])
     if piped:
         lmm.pipe_flush()  # inside the timed region: the last block's combine and per-SNP stage are waited for
     torch.cuda.synchronize()
+    own = time.perf_counter() - t_own0  # this rank's own steps, before it waits for the others
     if world > 1:
-        dist.barrier()
+        gdist.ctl_barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    per_rank_s = [elapsed]
+    per_rank_s = [own]
     if world > 1:
-        # every rank's own clock (one SUM all-reduce of a vector with one slot per rank), then the contract's MAX over ranks
-        tv = torch.zeros(world, dtype=torch.float64, device=dev)
-        tv[rank] = elapsed
-        dist.all_reduce(tv, op=dist.ReduceOp.SUM)
-        per_rank_s = [float(x) for x in tv.cpu()]
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt[0])
+        # every rank's own clock (one SUM all-reduce of a vector with one slot per rank), then the contract's MAX over ranks of the
+        # barrier-to-barrier time
+        tv = [0.0] * world
+        tv[rank] = own
+        per_rank_s = gdist.ctl_allreduce(tv, "sum")
+        elapsed = gdist.ctl_allreduce([elapsed], "max")[0]
     gemm_ms, gemm_n = api.profile_read(L.STAGE_UTX_GEMM)
     post_ms, post_n = api.profile_read(L.STAGE_UTX_POST)
     assoc_ms, assoc_n = api.profile_read(L.STAGE_ASSOC)
@@ -838,16 +960,20 @@ def main():
                     "traffic": None, "launches": gemm_n, "avg_launch_ms": round(gemm_avg_s * 1e3, 3)}
         dgd_ = ctypes_digits(L, n) if i8_path else 0
         line = {
-            "metric": "SNPs/s (-lmm 1 Wald) at n=20k on 1/2/4/8 MI355X; U^T x HBM GB/s vs roofline",
+            "metric": ("SNPs/s (-lmm 1 Wald) at n=20k on 1/2/4/8 MI355X; U^T x HBM GB/s vs roofline" if not preset else
+                       "SNPs/s of the association stage, BASELINE config 4: n=50k, p=500k SNPs SNP-sharded over %d MI355X (-gk + -lmm 1)" % world),
             "value": round(value, 1), "unit": "SNPs/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": ("f64 (U^T x as int8-digit MFMA products with exact int32 accumulation; U rounded to %d base-256 digits = 2^-%d of each "
-                      "column's maximum%s)" % (dgd_, 8 * dgd_ - 1, ", below fp64's own entry rounding" if dgd_ >= 7 else
-                                               " -- fp64 keeps 2^-53 per entry; digits7_leg and fp64_gemm_path carry the unrounded operand")) if i8_path else "f64",
+            "higher_is_better": True, "scaling": "strong" if preset else "weak", "vs_baseline": None,
+            "dtype": ("f64 (U^T x as int8-digit MFMA products with exact int32 accumulation; every column of U scaled by its exact maximum and "
+                      "rounded to %d base-256 digits = 2^-%d of that maximum%s)" % (dgd_, 8 * dgd_, ", below fp64's own entry rounding" if dgd_ >= 7 else
+                                               " -- fp64 keeps 2^-53 per entry; value_strict / strict_leg (7g6m: U^T x at or below the fp64 GEMM's own error) "
+                                               "and fp64_gemm_path carry the unrounded operand")) if i8_path else "f64",
             "data": "synthetic",
             "config": {"workload": "%ssynthetic n=%d, -lmm %d, %d SNPs per step per GPU (PLINK 2-bit, "
                                    "%g%% missing, Balding-Nichols Fst 0.05), c=1" % (
+                                       ("configs[3] (--config 4: p = %d SNPs over %d rank(s), %d steps each; kinship from all of them, "
+                                        "sharded the same way): " % (B * args.steps * world, world, args.steps)) if preset else
                                        "configs[2] (headline): " if (n == 20000 and args.a_mode == 1) else "", n, args.a_mode, B, 100.0 * args.miss),
                        "n": n, "snps_per_step": B, "kinship_snps": args.kin_snps, "parallelism": "snp-shard x%d" % world,
                        "device": name, "cus": n_cu, "utx_path": "int8-digit" if i8_path else "fp64-gemm",
@@ -856,7 +982,17 @@ def main():
                                     "value": [round(B * args.steps / x, 1) if x > 0 else None for x in per_rank_s], "unit": "SNPs/s"},
                        "comm": (dict(zip(("rank", "world", "transport"), api.comm_info()),
                                      transport_names={"0": "none", "1": "RCCL (librccl, ncclAllReduce / ncclBroadcast)",
-                                                      "2": "shm test transport (GEMMA_HIP_COMM=shm)"}) if world > 1 else None),
+                                                      "2": "shm test transport (GEMMA_HIP_COMM=shm)"},
+                                     setup_mode=setup_mode,
+                                     setup_transport={"native": "libgemma_hip.so's own communicator (see transport)",
+                                                      "torch": "torch.distributed (%s): rank 0 ran the setup, one broadcast round of (U, eval, UtW, Uty, null)"
+                                                               % os.environ.get("BENCH_DIST_BACKEND", "cpu:gloo,cuda:nccl"),
+                                                      "replicated": "none: every rank ran the whole setup itself"}.get(setup_mode),
+                                     control_plane=str(dist.get_backend()),
+                                     error=comm_log.get("error"), staged_start=comm_log.get("tried"),
+                                     collectives=(api.comm_stats() if setup_mode == "native" else None),
+                                     timed_region="communication-free: every rank analyses its own blocks; barrier + clock exchange on the control plane")
+                                if world > 1 else None),
                        "setup": setup_info, "nan_p_wald": n_nan},
             "roofline": roof,
             "roofline_assoc": {"kernel": "per-SNP stage: fixed-lambda table + bracket scan + interval series tables (fp64 MFMA) + series-driven "
@@ -883,7 +1019,7 @@ def main():
         # the driver's SCALE run is the measurement
         p_cfg = {20000: 1000000, 50000: 500000, 5000: 100000, 10000: 500000}.get(n, B * args.steps)
         per_gpu = value / world
-        setup_once = sum(float(setup_info.get(k) or 0.0) for k in ("kinship_s", "eigen_s", "broadcast_s"))
+        setup_once = sum(float(setup_info.get(k) or 0.0) for k in ("kinship_s", "eigen_workspace_reserve_s", "eigen_s", "broadcast_s"))
         est = setup_info.get("eigen_stages_s")
         eig_proj = None
         if est and world == 1:
@@ -896,13 +1032,13 @@ def main():
             eig_proj = {str(N): round(serial + other + bt / N + (xchg if N > 1 else 0.0), 3) for N in (1, 2, 4, 8)}
         eig_note = "eigendecomposition runs on one GPU (replicas only for that stage); ranks idle during it"
         if multi_real:
-            setup_once = sum(float(setup_info.get(k) or 0.0) for k in ("kinship_s", "allreduce_s", "eigen_s", "broadcast_s"))
+            setup_once = sum(float(setup_info.get(k) or 0.0) for k in ("kinship_s", "allreduce_s", "eigen_workspace_reserve_s", "eigen_s", "broadcast_s"))
         if shard_eig:
             eig_note = ("eigendecomposition is a collective (gemma_hip_eigh_sharded_d): reduction + divide & conquer on every rank, the "
                         "back-transformations shared out by eigenvector; eigen_s above was measured with %d rank(s)" % world)
         line["amdahl"] = {
             "p_total": p_cfg, "setup_once_s": round(setup_once, 3),
-            "setup_terms_s": {k: setup_info.get(k) for k in ("kinship_s", "allreduce_s", "eigen_s", "broadcast_s")},
+            "setup_terms_s": {k: setup_info.get(k) for k in ("kinship_s", "allreduce_s", "eigen_workspace_reserve_s", "eigen_s", "broadcast_s")},
             "kinship_note": "kinship_s covers %d SNPs here; over all p SNPs it shards with the SNPs (one ncclAllReduce of n^2 sums)" % args.kin_snps,
             "assoc_s_per_rank": {str(N): round(p_cfg / N / per_gpu, 3) for N in (1, 2, 4, 8)},
             "projected_total_s": {str(N): round(setup_once + p_cfg / N / per_gpu, 3) for N in (1, 2, 4, 8)},
@@ -970,40 +1106,53 @@ def main():
             line["setup_parity"] = sp
         lmm.finish()
         dg_timed = ctypes_digits(L, n) if i8_path else None
-        if world == 1 and i8_path and args.digits7_steps > 0 and dg_timed != 7:
-            # the bit-faithful mode beside the timed one: U kept to 7 base-256 digits (2^-55 of each column's maximum: below the
-            # 2^-53 of an fp64 entry in the column's top binade) -- the same blocks, a fresh setup (the digits are cut once per setup)
-            os.environ["GEMMA_HIP_I8_DIGITS"] = "7"
+        n_strict = args.steps if args.digits7_steps < 0 else args.digits7_steps
+        if world == 1 and i8_path and n_strict > 0 and dg_timed != 7:
+            # The strict-precision form at equal standing: seven digits for the genotype product, the mask product
+            # on the upper six ("7g6m": 13 int8 products = 10 dense equivalents instead of 12 = 9) -- U^T x at or below the fp64 GEMM's own
+            # rounding error, rms and maximum.  The SAME blocks as the timed region, the same number of steps, the same barrier-free
+            # single-rank clock; a fresh setup (the digits are cut once per setup).
+            os.environ["GEMMA_HIP_I8_FORM"] = "7g6m"
             try:
                 lmm7 = api.LMM(a_mode=args.a_mode, l_mle_null=float(null[0]), logl_mle_H0=float(null[1]))
                 lmm7.setup(U, ev, UtW, Uty, plink=True)
                 out7 = torch.empty((B, 8), dtype=torch.float64, device=dev)
-                lmm7.batch(blocks[0], L.GENO_PLINK_2BIT, out=out7)
+                for i in range(max(1, min(args.warmup, 2))):
+                    lmm7.batch(blocks[i % len(blocks)], L.GENO_PLINK_2BIT, out=out7)
                 torch.cuda.synchronize()
-                api.profile_read(L.STAGE_UTX_GEMM, reset=True)
+                for st in range(L.STAGE_UTX_POST + 1):
+                    api.profile_read(st, reset=True)
                 t1 = time.perf_counter()
-                for i in range(args.digits7_steps):
-                    lmm7.batch(blocks[(args.warmup + args.steps - args.digits7_steps + i) % len(blocks)], L.GENO_PLINK_2BIT, out=out7)
+                for i in range(n_strict):
+                    lmm7.batch(blocks[(args.warmup + args.steps - n_strict + i) % len(blocks)], L.GENO_PLINK_2BIT, out=out7)
                 torch.cuda.synchronize()
                 el7 = time.perf_counter() - t1
-                g7_ms, _ = api.profile_read(L.STAGE_UTX_GEMM)
+                g7_ms, g7_n = api.profile_read(L.STAGE_UTX_GEMM)
+                k7 = api.last_utx_kernel()
                 r7 = out7.cpu().numpy()  # the last block of the leg is the last timed block: res holds its 6-digit results
                 cols_used = {1: [0, 1, 4, 7], 2: [5, 7], 3: [0, 1, 6], 4: [0, 1, 4, 5, 6, 7], 9: [0, 1, 5, 6, 7]}[args.a_mode]
                 okm = np.isfinite(r7) & np.isfinite(res) & (r7 != 0)
-                line["digits7_leg"] = {
-                    "digits": 7, "steps": args.digits7_steps, "ms_per_step": round(el7 / args.digits7_steps * 1e3, 3),
-                    "value": round(B * args.digits7_steps / el7, 1), "unit": "SNPs/s",
-                    "utx_gemm_ms_per_step": round(g7_ms / args.digits7_steps, 3),
-                    "what": "GEMMA_HIP_I8_DIGITS=7: U cut to 7 balanced base-256 digits (error <= 2^-55 of each column's maximum, i.e. U "
-                            "reproduced to its last bit in the column's top binade); 14 int8 products instead of the timed region's 12",
-                    "timed_region_vs_7_digits_max_rel_diff": max(float(np.max(np.abs(res[:, c][okm[:, c]] - r7[:, c][okm[:, c]]) / np.abs(r7[:, c][okm[:, c]])))
-                                                                 for c in cols_used),
+                g7_s = g7_ms * 1e-3 / max(1, n_strict)
+                line["value_strict"] = round(B * n_strict / el7, 1)
+                line["strict_leg"] = {
+                    "form": "7g6m", "steps": n_strict, "ms_per_step": round(el7 / n_strict * 1e3, 3),
+                    "value": round(B * n_strict / el7, 1), "unit": "SNPs/s",
+                    "utx_gemm_ms_per_step": round(g7_ms / n_strict, 3), "launches_per_step": g7_n / max(1, n_strict),
+                    "roofline_frac": round(10.0 * 2.0 * B * n * n / g7_s / 1e12 / INT8_MFMA_PEAK_TOPS, 4),
+                    "kernel": k7["name"] + " (planes {2,1} {4,3} {6,5}) + i8gemm_sparse2_r16_g_kernel (digit 0, genotype product alone)",
+                    "what": "GEMMA_HIP_I8_FORM=7g6m: U cut to 7 balanced base-256 digits against each column's exact maximum (rounded at 2^-56 of it); "
+                            "genotype product on all seven, mask product on the upper six (its term is sqrt(n / missing calls) smaller): 13 int8 "
+                            "products = 10 dense equivalents where the timed region runs 12 = 9.  U^T x then carries no more error than the "
+                            "reference's cblas_dgemm on fp64 operands (src/fastblas.cpp:202): at or below the fp64 MFMA GEMM's rms and maximum "
+                            "error against long-double products (tests/test_gpu_at_size.py::test_six_digit_rounding_of_U_is_what_the_model_says)",
+                    "timed_region_vs_strict_max_rel_diff": max(float(np.max(np.abs(res[:, c][okm[:, c]] - r7[:, c][okm[:, c]]) / np.abs(r7[:, c][okm[:, c]])))
+                                                               for c in cols_used),
                     "lambda_max_rel_diff": float(np.nanmax(np.abs(res[:, 2] - r7[:, 2]) / np.maximum(np.abs(r7[:, 2]), 1e-300))) if args.a_mode in (1, 4) else None}
                 lmm7.finish()
                 del out7
             except Exception as e:
-                line["digits7_leg"] = {"error": repr(e)[:300]}
-            os.environ.pop("GEMMA_HIP_I8_DIGITS", None)
+                line["strict_leg"] = {"error": repr(e)[:300]}
+            os.environ.pop("GEMMA_HIP_I8_FORM", None)
             api.reload_env()
         if world == 1 and i8_path and args.lowh2_leg > 0 and args.a_mode in (1, 4):
             # The same trait on a kinship measured in other units: eigenvalues times S moves every lambda-hat to lambda-hat / S
@@ -1054,6 +1203,14 @@ def main():
     else:
         lmm.finish()
     if world > 1:
+        hung = gdist._native_poisoned or any((t.get("error") or "").startswith("no answer within") for t in comm_log.get("tried", []))
+        gdist.ctl_barrier()  # rank 0's line is out before anybody tears the group down
+        if hung or setup_mode == "replicated":
+            # a helper thread may still sit inside a collective that never returns (or torch's device backend is in an error state):
+            # leave without the tear-down that would wait for it
+            sys.stdout.flush()
+            sys.stderr.flush()
+            os._exit(0)
         dist.destroy_process_group()
 
 
@@ -1220,7 +1377,7 @@ def c4_leg(args, t_bench0):
         cb = d.get("cpu_baseline", {})
         return {"workload": d["config"]["workload"], "value": d["value"], "unit": "SNPs/s per GPU", "ms_per_step": d["ms_per_step"],
                 "steps": d["steps"], "stage_ms_per_step": d["stage_ms_per_step"], "roofline_frac": d["roofline"]["frac"],
-                "utx_digits_note": d["dtype"], "setup": {k: d["config"]["setup"].get(k) for k in ("kinship_s", "eigen_s", "eigen", "eigen_stages_s")},
+                "utx_digits_note": d["dtype"], "setup": {k: d["config"]["setup"].get(k) for k in ("kinship_s", "eigen_workspace_reserve_s", "eigen_s", "eigen", "eigen_stages_s")},
                 "setup_parity": d.get("setup_parity"),
                 "parity": {k: cb.get(k) for k in ("kind", "sample", "gpu_vs_reference_max_rel_err", "gpu_vs_reference_lambda",
                                                    "gpu_vs_oracle_max_rel_err", "gpu_vs_oracle_lambda") if k in cb},

@@ -73,6 +73,8 @@ struct Knobs {
   int i8_gm = 0;           // GEMMA_HIP_I8_GM: tile rows per L2 patch of the non-rastered launch
   int i8_raster = S2_DEFAULT_RASTER; // GEMMA_HIP_I8_RASTER
   int i8_rows = 16;        // GEMMA_HIP_I8_ROWS: 32 = the records kernel on the 32-row matrix instructions
+  int i8_scale_max = 1;    // GEMMA_HIP_I8_SCALE: "pow2" = columns of U scaled by a power of two (rounds 1-5); default: by their exact maximum
+  int i8_mdrop = 0;        // GEMMA_HIP_I8_FORM=7g6m: seven digits for the genotype product, the mask product on the upper six
   int dosage_i8 = 1;       // GEMMA_HIP_UTX_DOSAGE_I8
   int dosage_rows = 16;    // GEMMA_HIP_DOSAGE_ROWS: 32 = the dosage planes on the 32-row dense kernel (rounds 3-4)
   int overlap = 0;         // GEMMA_HIP_OVERLAP
@@ -100,6 +102,11 @@ struct Knobs {
     i8_gm = geti("GEMMA_HIP_I8_GM", 0);
     i8_raster = geti("GEMMA_HIP_I8_RASTER", S2_DEFAULT_RASTER);
     i8_rows = geti("GEMMA_HIP_I8_ROWS", 16) == 32 ? 32 : 16;
+    const char *esc = getenv("GEMMA_HIP_I8_SCALE");
+    i8_scale_max = (esc && strcmp(esc, "pow2") == 0) ? 0 : 1;
+    const char *efm = getenv("GEMMA_HIP_I8_FORM");
+    i8_mdrop = (efm && strcmp(efm, "7g6m") == 0) ? 1 : 0;
+    if (i8_mdrop) i8_digits = 7;
     const char *ed = getenv("GEMMA_HIP_UTX_DOSAGE_I8");
     dosage_i8 = (ed && ed[0] == '0') ? 0 : 1;
     dosage_rows = geti("GEMMA_HIP_DOSAGE_ROWS", 16) == 32 ? 32 : 16;
@@ -160,6 +167,8 @@ struct Ctx {
   struct XPipe {
     hipStream_t P = nullptr, Q = nullptr;
     hipEvent_t in_ready = nullptr, prod_done[2] = {}, post_done[2] = {};
+    hipEvent_t ingest_done = nullptr; // recorded on P behind the ingest of the last block handed in (the caller's stream waits for it)
+    bool ingest_valid = false;
     bool post_valid[2] = {false, false};
     unsigned long long count = 0;
     bool pending = false;
@@ -189,7 +198,7 @@ struct Ctx {
   bool mv_ready = false, mv_gxe = false;
   size_t mv_d = 0;
   MvArgs mv_proto;
-  DevBuf i8_Bt, i8_ej, i8_cmax, i8_A, i8_C, i8_mean; // exact int8-digit U^T x (i8gemm.hip.h)
+  DevBuf i8_Bt, i8_q, i8_qinv, i8_cmax, i8_A, i8_C, i8_mean; // exact int8-digit U^T x (i8gemm.hip.h)
   unsigned long long cheb_qmask = 0; // bit k: tabulated interval k is in Q form (ends at or below lambda = 1e-3)
   // (tile_m, tile_n) per workgroup of the records kernel: the cross-XCD raster (i8gemm_sparse2.hip.h).  One map per launch shape,
   // each in its OWN buffer, built once (a block cut into row chunks has two shapes -- full chunks and the last one -- and
@@ -376,7 +385,7 @@ extern "C" void gemma_hip_shutdown(void) {
   g_ctx.own_U.release(); g_ctx.own_eval.release(); g_ctx.own_Uty.release(); g_ctx.own_UtW.release();
   g_ctx.UtWt.release(); g_ctx.idx_map.release(); g_ctx.X.release(); g_ctx.UtX.release();
   g_ctx.stage_in.release(); g_ctx.stage_out.release(); g_ctx.carry.release(); g_ctx.scratch.release();
-  g_ctx.i8_Bt.release(); g_ctx.i8_ej.release(); g_ctx.i8_cmax.release(); g_ctx.i8_A.release(); g_ctx.i8_C.release();
+  g_ctx.i8_Bt.release(); g_ctx.i8_q.release(); g_ctx.i8_qinv.release(); g_ctx.i8_cmax.release(); g_ctx.i8_A.release(); g_ctx.i8_C.release();
   raster_release();
   g_ctx.mv_Yt.release(); g_ctx.mv_out.release(); g_ctx.mv_scratch.release(); // shutdown without lmm_finish leaked these
   g_ctx.mv_ready = g_ctx.mv_gxe = false;
@@ -1586,7 +1595,7 @@ static int i8_prepare_u(hipStream_t s) {
   const size_t n = g_ctx.cfg.n;
   const size_t ldk = round_up(n, I8_BK), npad = round_up(n, I8_BN);
   g_ctx.i8_digits = i8_digits_for(n);
-  if (g_ctx.i8_Bt.reserve((size_t)I8_DIGITS * npad * ldk) || g_ctx.i8_ej.reserve(n * sizeof(int)) ||
+  if (g_ctx.i8_Bt.reserve((size_t)I8_DIGITS * npad * ldk) || g_ctx.i8_q.reserve(n * 8) || g_ctx.i8_qinv.reserve(n * 8) ||
       g_ctx.i8_cmax.reserve(n * 8))
     return fail(GEMMA_HIP_ENOMEM, "lmm_batch: int8 digits of U (%zu bytes)", (size_t)I8_DIGITS * npad * ldk);
   HIPCHK(hipMemsetAsync(g_ctx.i8_Bt.p, 0, (size_t)I8_DIGITS * npad * ldk, s));
@@ -1594,11 +1603,12 @@ static int i8_prepare_u(hipStream_t s) {
   hipLaunchKernelGGL(u_colmax_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)((n + 1023) / 1024)), dim3(256), 0, s,
                      g_ctx.U, (long)n, (long)n, g_ctx.i8_cmax.as<unsigned long long>());
   HIPCHK(hipGetLastError());
-  hipLaunchKernelGGL(u_exponent_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s,
-                     g_ctx.i8_cmax.as<unsigned long long>(), (long)n, g_ctx.i8_ej.as<int>());
+  hipLaunchKernelGGL(u_scale_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s,
+                     g_ctx.i8_cmax.as<unsigned long long>(), (long)n, g_ctx.i8_digits, g_ctx.knobs.i8_scale_max,
+                     g_ctx.i8_q.as<double>(), g_ctx.i8_qinv.as<double>());
   HIPCHK(hipGetLastError());
   hipLaunchKernelGGL(u_digits_kernel, dim3((unsigned)((n + 31) / 32), (unsigned)((n + 31) / 32)), dim3(256), 0, s,
-                     g_ctx.U, (long)n, (long)n, g_ctx.i8_ej.as<int>(), g_ctx.i8_Bt.as<int8_t>(), (long)ldk,
+                     g_ctx.U, (long)n, (long)n, g_ctx.i8_q.as<double>(), g_ctx.i8_Bt.as<int8_t>(), (long)ldk,
                      (long)(npad * ldk), g_ctx.i8_digits);
   HIPCHK(hipGetLastError());
   g_ctx.i8_ldk = ldk;
@@ -1611,6 +1621,7 @@ static int i8_prepare_u(hipStream_t s) {
 struct I8Dims {
   size_t n, ldk, npad, lpad, mrows;
   int fuse, digits, nplanes;
+  int mdrop; // 1: the 7g6m form -- plane 0 (digit 0 alone) carries the genotype product only
 };
 // GEMMA_HIP_I8_SPARSE: 0 = the mask product on dense MFMAs (i8gemm_packed_kernel_t), 1 = on the 2:4 sparse MFMA with byte-wise
 // genotypes and separate mask words (i8gemm_sparse.hip.h), 2 (default) = sparse MFMA, left factor as 16-byte records of 2-bit
@@ -1625,6 +1636,8 @@ static int i8_begin(size_t l, I8Dims *d, hipStream_t s) {
   d->fuse = (g_ctx.knobs.i8_fuse && (double)d->n * 2.0 * 128.0 * 257.0 < 2147483648.0) ? 1 : 0;
   d->digits = g_ctx.i8_digits;
   d->nplanes = d->fuse ? (d->digits + 1) / 2 : d->digits;
+  // the 7g6m form needs plane 0 to be digit 0 alone (odd count, fused planes) and the 16-row records kernel
+  d->mdrop = (g_ctx.knobs.i8_mdrop && d->fuse && d->digits == 7 && i8_sparse_mode() == 2 && g_ctx.knobs.i8_rows == 16) ? 1 : 0;
   const size_t c_elems = (size_t)d->nplanes * d->mrows * d->npad;
   if (g_ctx.i8_A.reserve(d->lpad * d->ldk) || g_ctx.i8_C.reserve(c_elems * 4) || g_ctx.i8_mean.reserve(l * 8))
     return fail(GEMMA_HIP_ENOMEM, "lmm_batch: int8 product buffers (%zu bytes)", d->lpad * d->ldk + c_elems * 4);
@@ -1670,7 +1683,10 @@ static int raster_for(int tiles_m, int tiles_n, int rb, hipStream_t s, const int
   lru->tm = lru->tn = lru->rb = 0;
   if (lru->dev.reserve(lru->host.size() * sizeof(int2)))
     return fail(GEMMA_HIP_ENOMEM, "lmm_batch: tile raster (%zu bytes)", lru->host.size() * sizeof(int2));
+  // once per launch shape, and synchronous: a later cache hit hands the same map to a launch on ANY stream, and nothing
+  // would order that launch behind an upload still queued on this one
   HIPCHK(hipMemcpyAsync(lru->dev.p, lru->host.data(), lru->host.size() * sizeof(int2), hipMemcpyHostToDevice, s));
+  HIPCHK(hipStreamSynchronize(s));
   lru->tm = tiles_m; lru->tn = tiles_n; lru->rb = rb;
   lru->used = ++g_ctx.i8_raster_clock;
   *map_d = lru->dev.as<int2>();
@@ -1711,6 +1727,8 @@ static int i8_gemm_rows(const I8Dims &d, size_t row0, size_t rows_pad, hipStream
                                  hipFuncAttributeMaxDynamicSharedMemorySize, S2_NST * S2_STAGE));
       HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(i8gemm_sparse2_r16_kernel),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, S2_R16_LDS));
+      HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(i8gemm_sparse2_r16_g_kernel),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, S2_R16_LDS));
       attr3 = true;
     }
     Sparse2Args g2;
@@ -1737,12 +1755,20 @@ static int i8_gemm_rows(const I8Dims &d, size_t row0, size_t rows_pad, hipStream
     // forms (i8gemm_sparse2_r16.hip.h: same records, same planes, every entry equal; 9 % faster under the power limit)
     note_utx_kernel(g_ctx.knobs.i8_rows == 32 ? GEMMA_UTX_KERNEL_RECORDS_R32 : GEMMA_UTX_KERNEL_RECORDS_R16, d.digits, d.fuse,
                     raster_rb);
-    if (g_ctx.knobs.i8_rows == 32)
+    if (g_ctx.knobs.i8_rows == 32) {
       hipLaunchKernelGGL(i8gemm_sparse2_kernel, dim3((unsigned)(g2.tiles_m * g2.tiles_n), (unsigned)d.nplanes), dim3(512),
                          S2_NST * S2_STAGE, s, g2);
-    else
+    } else if (d.mdrop) {
+      // 7g6m: planes 1..3 (digit pairs {2,1} {4,3} {6,5}) with both products, then plane 0 (digit 0) with the genotype product alone
+      g2.plane0 = 1;
+      hipLaunchKernelGGL(i8gemm_sparse2_r16_kernel, dim3((unsigned)(g2.tiles_m * g2.tiles_n), (unsigned)(d.nplanes - 1)), dim3(512),
+                         S2_R16_LDS, s, g2);
+      g2.plane0 = 0;
+      hipLaunchKernelGGL(i8gemm_sparse2_r16_g_kernel, dim3((unsigned)(g2.tiles_m * g2.tiles_n), 1u), dim3(512), S2_R16_LDS, s, g2);
+    } else {
       hipLaunchKernelGGL(i8gemm_sparse2_r16_kernel, dim3((unsigned)(g2.tiles_m * g2.tiles_n), (unsigned)d.nplanes), dim3(512),
                          S2_R16_LDS, s, g2);
+    }
   } else if (sparse) {
     static bool attr2 = false;
     if (!attr2) {
@@ -1784,8 +1810,8 @@ static int i8_post_rows(size_t l, const I8Dims &d, size_t row0, size_t rows, dou
   hipLaunchKernelGGL(i8_combine_kernel, dim3((unsigned)((d.n + 1023) / 1024), (unsigned)std::min<size_t>(rows, 65535)),
                      dim3(256), 0, s,
                      g_ctx.i8_C.as<int>() + row0 * d.npad, (long)d.npad, (long)(d.mrows * d.npad), (long)d.lpad,
-                     g_ctx.i8_mean.as<double>() + row0, g_ctx.i8_ej.as<int>(), (long)rows, (long)d.n, UtX + row0 * ldx, (long)ldx,
-                     1.0, d.fuse, d.digits, sur_cnt, sur_list, g_ctx.U, (long)d.n);
+                     g_ctx.i8_mean.as<double>() + row0, g_ctx.i8_qinv.as<double>(), (long)rows, (long)d.n, UtX + row0 * ldx, (long)ldx,
+                     1.0, d.fuse, d.digits, sur_cnt, sur_list, g_ctx.U, (long)d.n, d.mdrop);
   HIPCHK(hipGetLastError());
   if (sparse) {
     hipLaunchKernelGGL(i8_surplus_fix_kernel, dim3((unsigned)rows), dim3(256), 0, s, Arow, (long)d.ldk,
@@ -1844,7 +1870,7 @@ static int utx_dosage_i8(const double *src, size_t l, size_t ld, bool nan_missin
     HIPCHK(hipGetLastError());
     if (!g_ctx.i8_colsum_ready) {
       hipLaunchKernelGGL(u_digit_colsum_kernel, dim3((unsigned)((d.n + 3) / 4)), dim3(256), 0, s, g_ctx.i8_Bt.as<int8_t>(),
-                         (long)d.ldk, (long)(d.npad * d.ldk), g_ctx.i8_ej.as<int>(), (long)d.n, d.digits,
+                         (long)d.ldk, (long)(d.npad * d.ldk), g_ctx.i8_qinv.as<double>(), (long)d.n, d.digits,
                          g_ctx.i8_colsum.as<double>());
       HIPCHK(hipGetLastError());
       g_ctx.i8_colsum_ready = true;
@@ -1891,7 +1917,7 @@ static int utx_dosage_i8(const double *src, size_t l, size_t ld, bool nan_missin
     ProfScope ps(GEMMA_STAGE_UTX_POST, s);
     hipLaunchKernelGGL(i8_combine_dosage_kernel, dim3((unsigned)((d.n + 255) / 256), (unsigned)std::min<size_t>(l, 65535)),
                        dim3(256), 0, s, g_ctx.i8_C.as<int>(), (long)d.npad, (long)plane_c, g_ctx.i8_mean.as<double>(),
-                       g_ctx.i8_ej.as<int>(), g_ctx.i8_colsum.as<double>(), (long)l, (long)d.n, UtX, (long)ldx, d.digits,
+                       g_ctx.i8_qinv.as<double>(), g_ctx.i8_colsum.as<double>(), (long)l, (long)d.n, UtX, (long)ldx, d.digits,
                        two ? 1 : 0, have_m ? 1 : 0, two ? 1000.0 : 100.0);
     HIPCHK(hipGetLastError());
   }
@@ -1959,6 +1985,9 @@ static void xp_release() {
   if (x.P) (void)hipStreamDestroy(x.P);
   if (x.Q) (void)hipStreamDestroy(x.Q);
   if (x.in_ready) (void)hipEventDestroy(x.in_ready);
+  if (x.ingest_done) (void)hipEventDestroy(x.ingest_done);
+  x.ingest_done = nullptr;
+  x.ingest_valid = false;
   for (int i = 0; i < 2; ++i) {
     if (x.prod_done[i]) (void)hipEventDestroy(x.prod_done[i]);
     if (x.post_done[i]) (void)hipEventDestroy(x.post_done[i]);
@@ -2001,6 +2030,7 @@ static int xp_init() {
     HIPCHK(hipStreamCreateWithFlags(&x.Q, hipStreamDefault));
   }
   HIPCHK(hipEventCreateWithFlags(&x.in_ready, hipEventDisableTiming));
+  HIPCHK(hipEventCreateWithFlags(&x.ingest_done, hipEventDisableTiming));
   for (int i = 0; i < 2; ++i) {
     HIPCHK(hipEventCreateWithFlags(&x.prod_done[i], hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&x.post_done[i], hipEventDisableTiming));
@@ -2015,13 +2045,26 @@ static int xp_flush(hipStream_t s) {
   for (int i = 0; i < 2; ++i)
     if (x.post_valid[i]) HIPCHK(hipStreamWaitEvent(s, x.post_done[i], 0));
   x.pending = false;
+  x.ingest_valid = false; // every block's post stage (behind its ingest on P, through prod_done) is now in front of s
   return GEMMA_HIP_OK;
+}
+// A pipelined call that fails after it has switched buffer sets leaves the slot parity and the set parity out of step:
+// wait for everything in flight and start the pipeline over (slot 0, nothing to wait for); the error is the caller's to report.
+static int xp_abort(int rc) {
+  Ctx::XPipe &x = g_ctx.xp;
+  (void)hipDeviceSynchronize(); // both buffer sets are idle from here on: which of them is "live" no longer matters
+  x.count = 0;
+  x.post_valid[0] = x.post_valid[1] = false;
+  x.pending = false;
+  x.ingest_valid = false;
+  return rc;
 }
 static void xp_swap_sets() {
   Ctx::XPipe &x = g_ctx.xp;
   std::swap(g_ctx.i8_A, x.shadow_A); std::swap(g_ctx.i8_C, x.shadow_C);
   std::swap(g_ctx.i8_mean, x.shadow_mean); std::swap(g_ctx.i8_rowsur, x.shadow_rowsur);
 }
+
 
 // UtX (l x ldx, SNP-major) = mean-imputed X (l x n) * U (n x n): row s is (U^T x_s)^T, i.e. the column the
 // reference's fast_dgemm("T","N",U,Xlarge) (src/lmm.cpp:1521) produces for SNP s.  path < 0: by GEMMA_HIP_UTX_I8.
@@ -2208,6 +2251,11 @@ extern "C" int gemma_hip_lmm_batch_pipe_d(int kind, const void *geno, size_t l, 
   // allocations first (a growing buffer is freed and re-allocated: hipFree waits for the device, which is what an in-flight reader
   // of the old buffer needs)
   if (g_ctx.UtX.reserve(l * ldx * 8)) return fail(GEMMA_HIP_ENOMEM, "lmm_batch_pipe: cannot allocate %zu bytes", l * ldx * 8);
+  // The header's contract: the previous block's genotype buffer may be overwritten by work queued on `stream` AFTER this call.  Its
+  // ingest runs on P, possibly still behind the product before it -- so the caller's stream is put behind that ingest here (ADVICE r5:
+  // without this a double-buffering caller on a non-default stream could overwrite block i before ingest(i) had read it; on the legacy
+  // default stream P is a blocking stream and the order held by itself -- no operation is issued on stream 0 here either, see below).
+  if (s != nullptr && x.ingest_valid) HIPCHK(hipStreamWaitEvent(s, x.ingest_done, 0));
   xp_swap_sets(); // this block's A / C / mean / rowsur: the set block i - 2 used (its post stage is waited for below)
   // The block handed in is ready when the work already queued on s is done.  For the legacy default stream (s == 0: torch's current
   // stream unless the caller made another) nothing is recorded: streams with a CU mask are BLOCKING streams (the creating call takes
@@ -2221,7 +2269,7 @@ extern "C" int gemma_hip_lmm_batch_pipe_d(int kind, const void *geno, size_t l, 
   if (x.post_valid[slot]) HIPCHK(hipStreamWaitEvent(x.P, x.post_done[slot], 0));
   g_ctx.last_utx_path = 1;
   I8Dims d;
-  if ((rc = i8_begin(l, &d, x.P))) return rc;
+  if ((rc = i8_begin(l, &d, x.P))) return xp_abort(rc);
   {
     ProfScope ps(GEMMA_STAGE_INGEST, x.P);
     IngestI8Args a;
@@ -2230,10 +2278,12 @@ extern "C" int gemma_hip_lmm_batch_pipe_d(int kind, const void *geno, size_t l, 
     a.n = (int)d.n; a.A = g_ctx.i8_A.as<int8_t>(); a.ldk = (long)d.ldk;
     a.mean = g_ctx.i8_mean.as<double>();
     hipLaunchKernelGGL(ingest_i8_kernel, dim3((unsigned)((l + 3) / 4)), dim3(256), 0, x.P, a);
-    HIPCHK(hipGetLastError());
+    if (hipGetLastError() != hipSuccess) return xp_abort(fail(GEMMA_HIP_ERUNTIME, "lmm_batch_pipe: ingest launch"));
   }
-  if ((rc = i8_meta_build(d, x.P))) return rc;
-  if ((rc = i8_gemm_rows(d, 0, d.lpad, x.P))) return rc;
+  if (hipEventRecord(x.ingest_done, x.P) != hipSuccess) return xp_abort(fail(GEMMA_HIP_ERUNTIME, "lmm_batch_pipe: event"));
+  x.ingest_valid = true;
+  if ((rc = i8_meta_build(d, x.P))) return xp_abort(rc);
+  if ((rc = i8_gemm_rows(d, 0, d.lpad, x.P))) return xp_abort(rc);
   HIPCHK(hipEventRecord(x.prod_done[slot], x.P));
   HIPCHK(hipStreamWaitEvent(x.Q, x.prod_done[slot], 0));
   double *UtX = g_ctx.UtX.as<double>();
@@ -2986,7 +3036,7 @@ extern "C" int gemma_hip_lmm_finish(double *time_UtX_min, double *time_opt_min) 
   g_ctx.cheb_R.release(); g_ctx.cheb_F.release(); g_ctx.cheb_T.release(); g_ctx.cheb_slots.release();
   g_ctx.cheb_list.release(); g_ctx.cheb_count.release(); g_ctx.cheb_D.release(); g_ctx.cheb_Ck.release();
   g_ctx.cheb_Gk.release(); g_ctx.cheb_Lk.release(); g_ctx.cheb_iv.release(); g_ctx.cheb_dends.release(); g_ctx.cheb_res.release();
-  g_ctx.i8_Bt.release(); g_ctx.i8_ej.release(); g_ctx.i8_cmax.release(); g_ctx.i8_A.release(); g_ctx.i8_C.release();
+  g_ctx.i8_Bt.release(); g_ctx.i8_q.release(); g_ctx.i8_qinv.release(); g_ctx.i8_cmax.release(); g_ctx.i8_A.release(); g_ctx.i8_C.release();
   raster_release();
   g_ctx.i8_mean.release(); g_ctx.i8_meta.release(); g_ctx.i8_rowsur.release(); g_ctx.i8_colsum.release(); g_ctx.i8_surlist.release();
   g_ctx.i8_ready = false;
@@ -3393,7 +3443,12 @@ extern "C" int gemma_hip_dbg_last_utx_kernel(gemma_utx_kernel_info *info) {
 }
 
 extern "C" int gemma_hip_reload_env(void) {
+  const int digits0 = i8_digits_for(g_ctx.cfg.n), scale0 = g_ctx.knobs.i8_scale_max;
   g_ctx.knobs.load();
+  // switches the digit planes of U were cut under: a change of the digit count or of the column scaling makes the next
+  // batch cut them again instead of multiplying planes of the old form
+  if (g_ctx.i8_ready && (i8_digits_for(g_ctx.cfg.n) != digits0 || g_ctx.knobs.i8_scale_max != scale0))
+    g_ctx.i8_ready = g_ctx.i8_colsum_ready = false;
   return GEMMA_HIP_OK;
 }
 

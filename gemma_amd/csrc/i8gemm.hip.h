@@ -291,19 +291,35 @@ __global__ __launch_bounds__(256) void u_colmax_kernel(const double *__restrict_
   atomicMax(colmax_bits + j, m);
 }
 
-// colmax_bits[j] -> e_j with max|u| < 2^e_j (0 for an all-zero column); in place as int
-__global__ void u_exponent_kernel(const unsigned long long *__restrict__ colmax_bits, long n, int *__restrict__ ej) {
+// colmax_bits[j] -> the column's fixed-point scale: V = llrint(U * q_j) is cut into `digits` balanced base-256 digits and an integer
+// sum over a column is worth qinv_j in U's units.
+//   exact_max = 0 (rounds 1-5, GEMMA_HIP_I8_SCALE=pow2): q_j = 2^(8 D - 2 - e_j) with max|u| < 2^e_j -- |V| <= 2^(8 D - 2), half of what
+//     the digits can hold, and up to another factor of two lost between the maximum and the next power of two;
+//   exact_max = 1 (round 6, default): q_j = 0.99 * 2^(8 D - 1) / max|u| -- the largest entry of the column sits at 0.99 of the largest
+//     magnitude D balanced digits represent (127/255 * (256^D - 1) = 0.996 * 2^(8 D - 1)): U is rounded at 1.01 * 2^(-8 D) of each
+//     column's maximum instead of 2^(-8 D + 1) .. 2^(-8 D + 2) of it -- one to two bits for nothing but a multiplication by a
+//     non-power-of-two when the integer sums are turned back into doubles (one more rounding at 2^-53, relative).
+__global__ void u_scale_kernel(const unsigned long long *__restrict__ colmax_bits, long n, int digits, int exact_max,
+                               double *__restrict__ q, double *__restrict__ qinv) {
   const long j = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= n) return;
   const double m = __longlong_as_double((long long)colmax_bits[j]);
-  int e = 0;
-  if (m > 0.0 && m <= DBL_MAX) (void)frexp(m, &e);
-  ej[j] = e;
+  const bool finite_pos = m > 0.0 && m <= DBL_MAX;
+  if (exact_max && finite_pos) {
+    const double L = 0.99 * ldexp(1.0, 8 * digits - 1);
+    q[j] = L / m;
+    qinv[j] = m / L;
+  } else {
+    int e = 0;
+    if (finite_pos) (void)frexp(m, &e);
+    q[j] = ldexp(1.0, i8_scale_bits(digits) - e);
+    qinv[j] = ldexp(1.0, e - i8_scale_bits(digits));
+  }
 }
 
 // 32 x 32 tile of U (rows k, cols j) -> digit tiles [j][k]
 __global__ __launch_bounds__(256) void u_digits_kernel(const double *__restrict__ U, long n, long ld,
-                                                       const int *__restrict__ ej, int8_t *__restrict__ Bt, long ldk,
+                                                       const double *__restrict__ q, int8_t *__restrict__ Bt, long ldk,
                                                        long strideB, int digits) {
   __shared__ long long tile[32][33];
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5; // 32 x 8
@@ -311,7 +327,7 @@ __global__ __launch_bounds__(256) void u_digits_kernel(const double *__restrict_
   for (int r = ty; r < 32; r += 8) {
     const long k = k0 + r, j = j0 + tx;
     long long v = 0;
-    if (k < n && j < n) v = llrint(ldexp(U[k * ld + j], i8_scale_bits(digits) - ej[j]));
+    if (k < n && j < n) v = llrint(U[k * ld + j] * q[j]); // q a power of two: exactly the ldexp of rounds 1-5
     tile[r][tx] = v;
   }
   __syncthreads();
@@ -547,10 +563,10 @@ __global__ __launch_bounds__(256) void pack_dosage_kernel(PackDosageArgs g) {
   if (lane == 0) g.mean[s] = g.nan_missing ? tot / cnt : other;
 }
 
-// colsum[j] = 2^(e_j - scale_bits) * sum_d 256^d sum_k D_d[j][k]: the column sums of U as the digit planes hold it; one
+// colsum[j] = qinv_j * sum_d 256^d sum_k D_d[j][k]: the column sums of U as the digit planes hold it; one
 // wavefront per column
 __global__ __launch_bounds__(256) void u_digit_colsum_kernel(const int8_t *__restrict__ Bt, long ldk, long strideB,
-                                                             const int *__restrict__ ej, long n, int digits,
+                                                             const double *__restrict__ qinv, long n, int digits,
                                                              double *__restrict__ colsum) {
   const int lane = threadIdx.x & 63;
   const long j = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -563,20 +579,20 @@ __global__ __launch_bounds__(256) void u_digit_colsum_kernel(const int8_t *__res
     for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
     t = t * 256.0 + (double)acc;
   }
-  if (lane == 0) colsum[j] = ldexp(t, ej[j] - i8_scale_bits(digits));
+  if (lane == 0) colsum[j] = t * qinv[j];
 }
 
-// UtX[s][j] = 2^(e_j - scale_bits) * ( T0 / S + (mean_s - 1) TM ) + colsum[j],  T0 = sum_d 256^d (C0_d + 256 C1_d),
+// UtX[s][j] = qinv_j * ( T0 / S + (mean_s - 1) TM ) + colsum[j],  T0 = sum_d 256^d (C0_d + 256 C1_d),
 // TM = sum_d 256^d CM_d; planes: digit d of byte plane a at C + (a * digits + d) * strideC (a = 0: a0, 1: a1 if two, last: mask
 // if have_m)
 __global__ __launch_bounds__(256) void i8_combine_dosage_kernel(const int *__restrict__ C, long ldc, long strideC,
-                                                                const double *__restrict__ mean, const int *__restrict__ ej,
+                                                                const double *__restrict__ mean, const double *__restrict__ qinv,
                                                                 const double *__restrict__ colsum, long l, long n,
                                                                 double *__restrict__ UtX, long ldx, int digits, int two,
                                                                 int have_m, double inv_scale_is_S) {
   const long j = (long)blockIdx.x * 256 + threadIdx.x;
   if (j >= n) return;
-  const int e = ej[j] - i8_scale_bits(digits);
+  const double qi = qinv[j];
   const double cs = colsum[j];
   const int *Cm = C + (long)((two ? 2 : 1) * digits) * strideC;
   for (long s = blockIdx.y; s < l; s += gridDim.y) {
@@ -588,11 +604,11 @@ __global__ __launch_bounds__(256) void i8_combine_dosage_kernel(const int *__res
     }
     double v = (t0 + 256.0 * t1) / inv_scale_is_S;
     if (have_m) v = fma(mean[s] - 1.0, tm, v);
-    UtX[s * ldx + j] = ldexp(v, e) + cs;
+    UtX[s * ldx + j] = v * qi + cs;
   }
 }
 
-// UtX[s][j] = 2^(e_j - scale_bits) * sum_d 256^d (CG_d[s][j] + mean_s * CM_d[s][j]);  planes: one per digit (fuse = 0) or
+// UtX[s][j] = qinv_j * sum_d 256^d (CG_d[s][j] + mean_s * CM_d[s][j]);  planes: one per digit (fuse = 0) or
 // two digits per plane with 256 * C_{d+1} + C_d (fuse = 1; with an odd digit count plane 0 holds digit 0 alone)
 // sur_cnt / sur_list (may be null): the calls the 2:4 sparse mask operand dropped, per row (i8gemm_sparse.hip.h:
 // i8_surplus_list_kernel); rows with 1 .. 16 of them get mean_s * sum_e U[i_e][j] added here, in list order
@@ -600,27 +616,29 @@ __global__ __launch_bounds__(256) void i8_combine_dosage_kernel(const int *__res
 // pass is a plain HBM stream (9.6 GB of planes in, 3.2 GB out at n = B = 20 000) and was short of bytes in flight with one column
 // per thread (2.8 ms = 4.6 TB/s).  Needs ldc % 4 == 0 and 16-byte aligned planes / UtX rows (ldx even): the library's buffers.
 __global__ __launch_bounds__(256) void i8_combine_kernel(const int *__restrict__ C, long ldc, long strideC, long m_row0,
-                                                         const double *__restrict__ mean, const int *__restrict__ ej,
+                                                         const double *__restrict__ mean, const double *__restrict__ qinv,
                                                          long l, long n, double *__restrict__ UtX, long ldx,
                                                          double m_scale, int fuse, int digits,
                                                          const int *__restrict__ sur_cnt = nullptr,
                                                          const int *__restrict__ sur_list = nullptr,
-                                                         const double *__restrict__ U = nullptr, long ldu = 0) {
+                                                         const double *__restrict__ U = nullptr, long ldu = 0,
+                                                         int m_skip0 = 0 /* 1: plane 0 carries no mask product (7g6m) */) {
   const long j = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
   if (j >= n) return;
   const int nplanes = fuse ? (digits + 1) / 2 : digits;
   const int odd = digits & 1;
   const int nv = (n - j < 4) ? (int)(n - j) : 4; // columns of this thread inside the row (the planes are padded past n)
-  int e4[4];
+  double qi4[4];
 #pragma unroll
-  for (int c = 0; c < 4; ++c) e4[c] = ej[c < nv ? j + c : j] - i8_scale_bits(digits);
+  for (int c = 0; c < 4; ++c) qi4[c] = qinv[c < nv ? j + c : j];
   for (long s = blockIdx.y; s < l; s += gridDim.y) { // gridDim.y is capped at 65535 rows per sweep
     double tg[4] = {0.0, 0.0, 0.0, 0.0}, tmk[4] = {0.0, 0.0, 0.0, 0.0};
     for (int q = nplanes - 1; q >= 0; --q) {
       // fused: plane q sits two digits above plane q - 1, except that an odd count leaves plane 0 one digit wide
       const double w = fuse ? ((q == 0 && odd) ? 256.0 : 65536.0) : 256.0;
       const int4 cg = *reinterpret_cast<const int4 *>(C + (long)q * strideC + s * ldc + j);
-      const int4 cm = *reinterpret_cast<const int4 *>(C + (long)q * strideC + (m_row0 + s) * ldc + j);
+      const int4 cm = (m_skip0 && q == 0) ? make_int4(0, 0, 0, 0)
+                                          : *reinterpret_cast<const int4 *>(C + (long)q * strideC + (m_row0 + s) * ldc + j);
       const int g4[4] = {cg.x, cg.y, cg.z, cg.w}, m4[4] = {cm.x, cm.y, cm.z, cm.w};
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
@@ -631,7 +649,7 @@ __global__ __launch_bounds__(256) void i8_combine_kernel(const int *__restrict__
     const double ms = mean[s] * m_scale; // m_scale: exact power of two
     double v[4];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) v[c] = ldexp(fma(ms, tmk[c], tg[c]), e4[c]);
+    for (int c = 0; c < 4; ++c) v[c] = fma(ms, tmk[c], tg[c]) * qi4[c];
     if (sur_cnt) {
       const int cnt = sur_cnt[s]; // uniform over the block: no divergence
       if (cnt > 0) {

@@ -45,6 +45,7 @@ struct Sparse2Args {
   int *C;           // plane q: (2 lpad) x ldc; rows [0, lpad) = G products, [lpad, 2 lpad) = M products
   long ldk, ldc, strideB, strideC, m_row0;
   int tiles_m, tiles_n, nk, gm, fuse, digits;
+  int plane0 = 0; // first plane of this launch (i8gemm_sparse2_r16.hip.h: the 7g6m form launches plane 0 and planes 1.. separately)
   const int2 *tile_map = nullptr; // (tile_m, tile_n) of workgroup blockIdx.x: the cross-XCD raster of s2_build_raster; nullptr:
                                   // the per-XCD ranges of round 3 (every XCD sweeps its own tile rows)
 };

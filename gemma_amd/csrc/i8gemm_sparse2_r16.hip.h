@@ -48,8 +48,13 @@ namespace gemma_hip {
 
 constexpr int S2_R16_LDS = S2_R16_NST * S2_STAGE; // dynamic LDS of a launch
 
-__global__ __launch_bounds__(512, 2) void i8gemm_sparse2_r16_kernel(Sparse2Args g) {
+// WITH_S = false: the genotype product alone (round 6, the "7g6m" form: the lowest of seven digits is multiplied with the genotypes
+// only -- its mask term is below the rounding of the other six): no sparse instruction, no mask accumulators, no M rows
+// written.  The same loop otherwise; one source so that the two cannot drift apart.
+template <bool WITH_S>
+__device__ __forceinline__ void s2_r16_body(const Sparse2Args &g) {
   extern __shared__ __attribute__((aligned(1024))) int8_t i8lds[];
+  constexpr bool NO_S = !WITH_S || S2_R16_ABL_NO_S;
   int tm, tn;
   if (g.tile_map) {
     const int2 t2 = g.tile_map[blockIdx.x];
@@ -68,7 +73,7 @@ __global__ __launch_bounds__(512, 2) void i8gemm_sparse2_r16_kernel(Sparse2Args 
     tm = first_m + in % gsz;
     tn = in / gsz;
   }
-  const int plane = blockIdx.y;
+  const int plane = blockIdx.y + g.plane0;
   const int odd = g.digits & 1;
   const int d_first = g.fuse ? (odd ? (plane == 0 ? 0 : 2 * plane) : 2 * plane + 1) : plane;
   const int nd = (g.fuse && !(odd && plane == 0)) ? 2 : 1;
@@ -162,7 +167,7 @@ __global__ __launch_bounds__(512, 2) void i8gemm_sparse2_r16_kernel(Sparse2Args 
   } while (0)
 #define GS_S(i, SB, SL)                                                                                           \
   do {                                                                                                            \
-    if (!S2_R16_ABL_NO_S)                                                                                         \
+    if (!NO_S)                                                                                                    \
       asm volatile("s_nop 1\n\tv_smfmac_i32_16x16x128_i8 %0, %1, %2, %3" : "+v"(accm[i][SB]) : "v"(ms[i]), "v"(T[SL]), "v"(ix[i])); \
   } while (0)
 // the six matrix instructions of sub-block SB (ring slot SL); X: statements issued behind the first two
@@ -216,7 +221,10 @@ __global__ __launch_bounds__(512, 2) void i8gemm_sparse2_r16_kernel(Sparse2Args 
 #pragma unroll
         for (int j = 0; j < 8; ++j)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) { accg[i][j][r] <<= 8; accm[i][j][r] <<= 8; }
+          for (int r = 0; r < 4; ++r) {
+            accg[i][j][r] <<= 8;
+            if (WITH_S) accm[i][j][r] <<= 8;
+          }
     }
     GS_INIT_SRC(d_first - dd);
     // prologue: tiles 0 .. NST - 2 in flight, tile 0 landed
@@ -299,7 +307,7 @@ __global__ __launch_bounds__(512, 2) void i8gemm_sparse2_r16_kernel(Sparse2Args 
       for (int r = 0; r < 4; ++r) {
         const long row = (long)tm * S2_BM + wave * 32 + 16 * i + 4 * q + r;
         Cg[row * g.ldc + col] = accg[i][sb][r];
-        Cg[(g.m_row0 + row) * g.ldc + col] = accm[i][sb][r];
+        if (WITH_S) Cg[(g.m_row0 + row) * g.ldc + col] = accm[i][sb][r];
       }
     }
 #undef GS_INIT_SRC
@@ -315,5 +323,9 @@ __global__ __launch_bounds__(512, 2) void i8gemm_sparse2_r16_kernel(Sparse2Args 
 #undef GS_STEP
 #undef GS_KTILE
 }
+
+__global__ __launch_bounds__(512, 2) void i8gemm_sparse2_r16_kernel(Sparse2Args g) { s2_r16_body<true>(g); }
+// the genotype product alone (plane 0 of the 7g6m form)
+__global__ __launch_bounds__(512, 2) void i8gemm_sparse2_r16_g_kernel(Sparse2Args g) { s2_r16_body<false>(g); }
 
 } // namespace gemma_hip

@@ -24,8 +24,8 @@ try:
     print("kernel %s  frac %.4f  avg_launch_ms %.3f  traffic %s" % (r.get("kernel_symbol"), r["frac"], r["avg_launch_ms"], r.get("traffic")))
     s = l["config"]["setup"]
     print("setup: kinship_s %s eigen_s %s stages %s" % (s.get("kinship_s"), s.get("eigen_s"), s.get("eigen_stages_s")))
-    for k in ("dosage_path", "digits7_leg", "fp64_gemm_path"):
-        if k in l: print(k, l[k].get("value"), l[k].get("ms_per_step"), (l[k].get("roofline") or {}).get("frac"))
+    for k in ("dosage_path", "strict_leg", "fp64_gemm_path"):
+        if k in l: print(k, l[k].get("value"), l[k].get("ms_per_step"), (l[k].get("roofline") or {}).get("frac") or l[k].get("roofline_frac"), l[k].get("error"))
     if "c4_leg" in l: print("c4_leg", l["c4_leg"].get("value"), (l["c4_leg"].get("setup") or {}).get("eigen_s"), (l["c4_leg"].get("setup") or {}).get("eigen_stages_s"))
     if "e2e" in l: print("e2e", {k: l["e2e"].get(k) for k in ("snps", "wall_s")})
     if "cpu_baseline" in l: print("vs reference", l["cpu_baseline"].get("gpu_vs_reference_max_rel_err"), l["cpu_baseline"].get("gpu_vs_reference_lambda"))

@@ -208,3 +208,89 @@ def test_native_comm_init_failure_is_agreed_and_remembered(tmp_path):
     assert r0[3] == "1" and r1[3] == "1"          # one attempt each, never a second
     assert r0[4] == "1" and r1[4] == "0"          # the rank that succeeded finalises its communicator
     assert float(r0[5]) < 1.0 and float(r1[5]) < 1.0
+
+
+class _FakeSelftestLib:
+    """The communicator's first contact (gemma_hip_comm_selftest) on a CPU box: `mode` decides what rank 1 does with it."""
+
+    def __init__(self, rank, mode):
+        self.rank, self.mode = rank, mode
+        self.finalizes = 0
+
+    def gemma_hip_comm_selftest(self, stream):
+        import time
+        if self.rank == 1 and self.mode == "fail":
+            return 4
+        if self.rank == 1 and self.mode == "hang":
+            time.sleep(30.0)
+        return 0
+
+    def gemma_hip_last_error(self):
+        return b"comm selftest: the all-reduce returned a wrong sum"
+
+    def gemma_hip_comm_finalize(self):
+        self.finalizes += 1
+        return 0
+
+
+def _selftest_worker(rank, world, port, outdir, mode):
+    sys.path.insert(0, ROOT)
+    import time
+    import types
+
+    import torch
+    import torch.distributed as dist
+    from gemma_amd import _lib as L
+    from gemma_amd import dist as gdist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    fake = _FakeSelftestLib(rank, mode)
+    L.lib = lambda: fake
+    torch.cuda.current_stream = lambda: types.SimpleNamespace(cuda_stream=0)
+    torch.cuda.is_available = lambda: False
+    gdist._native_ready = True  # as after a successful native_comm_init
+    t0 = time.time()
+    ok = gdist.native_comm_selftest(timeout=2.0)
+    dt = time.time() - t0
+    # the control plane the bench uses around its timed region: agreement, barrier, clock exchange -- CPU tensors on gloo
+    assert gdist.ctl_device().type == "cpu"
+    assert gdist.agree(True) and not gdist.agree(rank == 0)
+    gdist.ctl_barrier()
+    tv = [0.0, 0.0]
+    tv[rank] = 1.5 + rank
+    assert gdist.ctl_allreduce(tv, "sum") == [1.5, 2.5]
+    assert gdist.ctl_allreduce([float(rank)], "max") == [1.0]
+    fin, res = gdist._with_deadline(lambda: 7, 1.0)
+    assert fin and res == 7
+    fin, res = gdist._with_deadline(lambda: 1 / 0, 1.0)
+    assert fin and "ZeroDivisionError" in res
+    with open(os.path.join(outdir, "s%d.txt" % rank), "w") as f:
+        f.write("%d %d %d %d %.3f %s" % (ok, gdist._native_ready, gdist._native_poisoned, fake.finalizes, dt,
+                                         gdist.native_comm_error().replace(" ", "_")))
+    gdist.ctl_barrier()
+    if mode == "hang":
+        os._exit(0)  # rank 1's helper thread is still asleep inside the fake library
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode", ["pass", "fail", "hang"])
+def test_comm_selftest_is_an_agreement_under_a_deadline(tmp_path, mode):
+    """The staged start (round 6): the communicator's 1 KiB self-test runs under a wall-clock deadline and its outcome is AGREED --
+    one rank that fails (or never answers) makes every rank drop the native transport; a rank whose helper is stuck inside the library
+    never touches the comm API again (no finalize)."""
+    import torch.multiprocessing as mp
+    port = _free_port()
+    mp.spawn(_selftest_worker, args=(2, port, str(tmp_path), mode), nprocs=2, join=True)
+    r0 = open(tmp_path / "s0.txt").read().split()
+    r1 = open(tmp_path / "s1.txt").read().split()
+    if mode == "pass":
+        assert r0[:4] == ["1", "1", "0", "0"] and r1[:4] == ["1", "1", "0", "0"]
+    elif mode == "fail":
+        assert r0[:4] == ["0", "0", "0", "1"] and r1[:4] == ["0", "0", "0", "1"]
+        assert "wrong_sum" in r1[5] and "another_rank" in r0[5]
+    else:
+        assert r0[:4] == ["0", "0", "0", "1"]      # the healthy rank finalises
+        assert r1[:4] == ["0", "0", "1", "0"]      # the stuck one is poisoned and leaves the API alone
+        assert 1.9 < float(r1[4]) < 10.0 and "no_answer" in r1[5]
