@@ -257,7 +257,10 @@ def setup_multi_rank(args, np, torch, dist, api, L, gdist, rank, world, dev, gen
     evh, trace = api.EigenDecomp_kept_K(n, None, sharded=True)
     torch.cuda.synchronize()
     t_eig = time.time() - t0
+    t0 = time.time()
     api.eigh_release()
+    torch.cuda.synchronize()
+    t_rel = time.time() - t0
     if prev_t is None:
         os.environ.pop("GEMMA_HIP_EIGH_TIMING", None)
     else:
@@ -298,7 +301,7 @@ def setup_multi_rank(args, np, torch, dist, api, L, gdist, rank, world, dev, gen
         "allreduce_s": round(t_all, 3),
         "allreduce": "%s of the n^2 kinship sums + the SNP count, issued by libgemma_hip.so (gemma_hip_kin_end_keep); %.2f GB per rank"
                      % ("ncclAllReduce" if transport == 1 else "shm test transport's all-reduce", 8.0 * n * n / 1e9),
-        "eigen_workspace_reserve_s": round(t_res, 3),
+        "eigen_workspace_reserve_s": round(t_res, 3), "eigen_workspace_release_s": round(t_rel, 3),
         "eigen_s": round(t_eig, 3),
         "eigen": "gemma_hip_eigh_kept_K_sharded (%s)" % (
             "two-stage; collective over %d ranks: reduction and divide & conquer on every rank, back-transformations shared out by "
@@ -615,7 +618,10 @@ def main():
         torch.cuda.synchronize()
         setup_info["eigen"] = eig
         setup_info["eigen_s"] = round(time.time() - t0, 3)
+        t0r = time.time()
         setup_info["eigen_workspace_released_gb"] = round(api.eigh_release() / 1e9, 1)
+        torch.cuda.synchronize()
+        setup_info["eigen_workspace_release_s"] = round(time.time() - t0r, 3)
         if prev_t is None:
             os.environ.pop("GEMMA_HIP_EIGH_TIMING", None)
         else:
@@ -1019,7 +1025,7 @@ def main():
         # the driver's SCALE run is the measurement
         p_cfg = {20000: 1000000, 50000: 500000, 5000: 100000, 10000: 500000}.get(n, B * args.steps)
         per_gpu = value / world
-        setup_once = sum(float(setup_info.get(k) or 0.0) for k in ("kinship_s", "eigen_workspace_reserve_s", "eigen_s", "broadcast_s"))
+        setup_once = sum(float(setup_info.get(k) or 0.0) for k in ("kinship_s", "eigen_workspace_reserve_s", "eigen_workspace_release_s", "eigen_s", "broadcast_s"))
         est = setup_info.get("eigen_stages_s")
         eig_proj = None
         if est and world == 1:
@@ -1032,13 +1038,13 @@ def main():
             eig_proj = {str(N): round(serial + other + bt / N + (xchg if N > 1 else 0.0), 3) for N in (1, 2, 4, 8)}
         eig_note = "eigendecomposition runs on one GPU (replicas only for that stage); ranks idle during it"
         if multi_real:
-            setup_once = sum(float(setup_info.get(k) or 0.0) for k in ("kinship_s", "allreduce_s", "eigen_workspace_reserve_s", "eigen_s", "broadcast_s"))
+            setup_once = sum(float(setup_info.get(k) or 0.0) for k in ("kinship_s", "allreduce_s", "eigen_workspace_reserve_s", "eigen_workspace_release_s", "eigen_s", "broadcast_s"))
         if shard_eig:
             eig_note = ("eigendecomposition is a collective (gemma_hip_eigh_sharded_d): reduction + divide & conquer on every rank, the "
                         "back-transformations shared out by eigenvector; eigen_s above was measured with %d rank(s)" % world)
         line["amdahl"] = {
             "p_total": p_cfg, "setup_once_s": round(setup_once, 3),
-            "setup_terms_s": {k: setup_info.get(k) for k in ("kinship_s", "allreduce_s", "eigen_workspace_reserve_s", "eigen_s", "broadcast_s")},
+            "setup_terms_s": {k: setup_info.get(k) for k in ("kinship_s", "allreduce_s", "eigen_workspace_reserve_s", "eigen_workspace_release_s", "eigen_s", "broadcast_s")},
             "kinship_note": "kinship_s covers %d SNPs here; over all p SNPs it shards with the SNPs (one ncclAllReduce of n^2 sums)" % args.kin_snps,
             "assoc_s_per_rank": {str(N): round(p_cfg / N / per_gpu, 3) for N in (1, 2, 4, 8)},
             "projected_total_s": {str(N): round(setup_once + p_cfg / N / per_gpu, 3) for N in (1, 2, 4, 8)},
@@ -1377,7 +1383,7 @@ def c4_leg(args, t_bench0):
         cb = d.get("cpu_baseline", {})
         return {"workload": d["config"]["workload"], "value": d["value"], "unit": "SNPs/s per GPU", "ms_per_step": d["ms_per_step"],
                 "steps": d["steps"], "stage_ms_per_step": d["stage_ms_per_step"], "roofline_frac": d["roofline"]["frac"],
-                "utx_digits_note": d["dtype"], "setup": {k: d["config"]["setup"].get(k) for k in ("kinship_s", "eigen_workspace_reserve_s", "eigen_s", "eigen", "eigen_stages_s")},
+                "utx_digits_note": d["dtype"], "setup": {k: d["config"]["setup"].get(k) for k in ("kinship_s", "eigen_workspace_reserve_s", "eigen_workspace_release_s", "eigen_s", "eigen", "eigen_stages_s")},
                 "setup_parity": d.get("setup_parity"),
                 "parity": {k: cb.get(k) for k in ("kind", "sample", "gpu_vs_reference_max_rel_err", "gpu_vs_reference_lambda",
                                                    "gpu_vs_oracle_max_rel_err", "gpu_vs_oracle_lambda") if k in cb},
@@ -1552,11 +1558,14 @@ def cpu_baseline(args, np, torch, block, U, ev, UtW, Uty, gpu_res, n, B, null=(0
         port["reference_error"] = repr(e)[:300]
         return port
     one = float(np.median(per_proc))
-    return {"value": round(S1 / one, 2), "unit": "SNPs/s", "cores": threads, "kind": "reference",
+    # value = the WHOLE-HOST rate of this leg (all processes side by side: what a reader expects under `value`); the rate
+    # of one process beside it
+    return {"value": round(P * S1 / wall, 2), "unit": "SNPs/s", "cores": threads * P, "kind": "reference",
+            "value_one_process": round(S1 / one, 2), "threads_per_process": threads,
             "sample": "%d SNPs of the last timed block through the reference's own LMM::Analyze (oracle/_ref/libgemma_ref.so = "
                       "/root/reference/src compiled unchanged, GSL API from oracle/gslshim): %d independent processes x %d SNPs side by "
-                      "side, %.2f s wall, %.2f s median per process; value = the rate of ONE process (its OpenBLAS dgemm on %d threads + "
-                      "its serial per-SNP loop, incl. its 2 x n x 20000 batch buffers)" % (P * S1, P, S1, wall, one, threads),
+                      "side, %.2f s wall, %.2f s median per process; value = all %d processes together (each: OpenBLAS dgemm on %d threads + "
+                      "its serial per-SNP loop, incl. its 2 x n x 20000 batch buffers); value_one_process = one of them" % (P * S1, P, S1, wall, one, P, threads),
             "processes": P, "aggregate_snps_per_s": round(P * S1 / wall, 2), "host_threads": cores,
             "threads_note": "the reference's OpenBLAS build caps its pool at %d threads; the box has %d" % (O.ref_blas_threads(), cores),
             "gpu_vs_reference_max_rel_err": worst_err(rr), "gpu_vs_reference_lambda": lambda_err(rr),

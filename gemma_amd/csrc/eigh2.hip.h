@@ -1284,6 +1284,8 @@ struct Eig2Ws {
   double *ZS = nullptr; // K slices of V^T A22: E2_MAXSLICE x 128 x n
   double *ppart = nullptr, *pheads = nullptr; // its self-validating slots: [step][workgroup][row], [step][row]
   int *q2sync = nullptr; // q2_apply_kernel's task counter, error flag, per-row-block progress; then the segment table
+  double *Qg = nullptr;  // eig2_apply_q1 with groups of panels: Gram of the group's reflectors, its compact-WY factor, scratch, K slices
+  long q1_kpmax = 0;     // widest block reflector the buffers above (and P256) were sized for
   long ngroups = 0, kmaxall = 0, nJ = 0;
 };
 
@@ -1689,6 +1691,86 @@ static inline int eig2_apply_q2(double *ZT, long n, long nrows, Eig2Ws &w2, hipS
   return 0;
 }
 
+// Panels per block reflector of the stage-1 back-transformation (round 6).  The rank-k update Z^T -= (Z^T Y^T T^T) Y reads and writes
+// the touched part of Z^T once per block reflector: with two panels (k = 256, round 4) it moves 16 n Kc bytes per 1024 n Kc flop --
+// 64 flop per byte, 1.1 TB/s at the GEMM's 73 TFLOP/s, and the update ran at 56; with four panels (k = 512) the traffic halves again.
+// GEMMA_HIP_EIGH_Q1_GROUP = 1 | 2 | 4 | 8 (default 4); 2 takes the pair code of round 4.
+constexpr int Q1_SLICES = 16;
+static inline int eig2_q1_group() {
+  const char *e = getenv("GEMMA_HIP_EIGH_Q1_GROUP");
+  const int g = e ? atoi(e) : 4;
+  return (g == 1 || g == 2 || g == 4 || g == 8) ? g : 4;
+}
+static inline long eig2_q1_kp(long n) {
+  long kp = (long)eig2_q1_group() * E2_B;
+  while (kp > 2 * E2_B && kp > n / 2) kp /= 2; // no wider than makes sense for a small matrix
+  return kp;
+}
+
+// D (rows x cols, ld ldd) = 0 except: copies of `nblk` diagonal blocks T_i (E2_B x E2_B, ld E2_B) from Tsrc + i * E2_B^2
+__global__ void q1_tdiag_kernel(double *__restrict__ D, long kp, const double *__restrict__ Tsrc, int nblk) {
+  const long i = (long)blockIdx.y, j = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= kp || j >= kp) return;
+  const long bi = i / E2_B, bj = j / E2_B;
+  D[i * kp + j] = (bi == bj && bi < nblk) ? Tsrc[bi * (long)E2_B * E2_B + (i % E2_B) * E2_B + (j % E2_B)] : 0.0;
+}
+
+// The compact-WY factor of g consecutive panels pa .. pa + g - 1 (g a power of two) in TG (kp x kp, kp = g * 128):
+//   (I - Va Ta Va^T)(I - Vb Tb Vb^T) = I - [Va Vb] [[Ta, -Ta (Va^T Vb) Tb], [0, Tb]] [Va Vb]^T, applied level by level;
+// every Va^T Vb is a block of ONE Gram matrix Y Y^T of the group's reflectors (the later panels' rows are zero in front of their own
+// first column, so the common column range changes nothing).
+static inline int eig2_q1_group_T(const double *Y, long n, long Kc, int g, const double *Tpanels, Eig2Ws &w2, hipStream_t s,
+                                  std::string &msg) {
+  const long kp = (long)g * E2_B;
+  double *Sg = w2.Qg, *TG = w2.Qg + kp * kp, *W = w2.Qg + 2 * kp * kp, *SL = w2.Qg + 3 * kp * kp;
+  int ns = 1;
+  EIG_HIP(launch_dgemm_ksliced('N', 'T', kp, kp, Kc, 1.0, Y, n, Y, n, SL, kp, kp * kp, Q1_SLICES, &ns, s));
+  hipLaunchKernelGGL(e2_sumk_kernel, dim3((unsigned)((kp / 2 + 255) / 256), (unsigned)kp), dim3(256), 0, s, Sg, SL, ns, kp * kp, kp, kp);
+  hipLaunchKernelGGL(q1_tdiag_kernel, dim3((unsigned)((kp + 255) / 256), (unsigned)kp), dim3(256), 0, s, TG, kp, Tpanels, g);
+  EIG_HIP(hipGetLastError());
+  for (int h = 1; h < g; h *= 2) {
+    const long m = (long)h * E2_B;
+    for (int i = 0; i + 2 * h <= g; i += 2 * h) {
+      const long a0 = (long)i * E2_B, b0 = a0 + m;
+      // W = Ta * S_ab ; T_ab = -W * Tb
+      EIG_HIP(launch_dgemm('N', 'N', m, m, m, 1.0, TG + a0 * kp + a0, kp, Sg + a0 * kp + b0, kp, 0.0, W, m, false, false, s));
+      EIG_HIP(launch_dgemm('N', 'N', m, m, m, -1.0, W, m, TG + b0 * kp + b0, kp, 0.0, TG + a0 * kp + b0, kp, false, false, s));
+    }
+  }
+  return 0;
+}
+
+static inline int eig2_apply_q1_grouped(double *ZT, long n, long nrows, EigWs &ws, Eig2Ws &w2, int G, hipStream_t s, std::string &msg) {
+  const long nb2 = (long)E2_B * E2_B;
+  long npan = 0;
+  for (long j0 = 0; n - (j0 + E2_B) >= 2; j0 += E2_B) ++npan;
+  long pnl = npan - 1;
+  while (pnl >= 0) {
+    int g = G;
+    while (g > 1 && (g > pnl + 1 || (long)g * E2_B > w2.q1_kpmax)) g /= 2; // groups counted from the last panel; what is left over in smaller ones
+    const long pa = pnl - g + 1;
+    const long j0 = pa * E2_B, c0 = j0 + E2_B, Kc = n - c0;
+    const long kp = (long)g * E2_B;
+    const double *Y = ws.VT + j0 * n + c0;
+    const double *T = ws.Tall + pa * nb2;
+    long ldt = E2_B;
+    if (g > 1) {
+      int rc = eig2_q1_group_T(Y, n, Kc, g, ws.Tall + pa * nb2, w2, s, msg);
+      if (rc) return rc;
+      T = w2.Qg + kp * kp;
+      ldt = kp;
+    }
+    double *P = w2.P256, *P2 = w2.P256 + (size_t)n * kp, *Pb = w2.P256 + (size_t)2 * n * kp;
+    int rc = eig2_dgemm_split2('N', 'T', nrows, kp, Kc, 1.0, ZT + c0, n, Y, n, P, Pb, kp, s, msg);
+    if (rc) return rc;
+    EIG_HIP(launch_dgemm('N', 'T', nrows, kp, kp, 1.0, P, kp, T, ldt, 0.0, P2, kp, false, false, s));
+    EIG_HIP(launch_dgemm('N', 'T', nrows, kp, kp, 1.0, Pb, kp, T, ldt, 1.0, P2, kp, false, false, s));
+    EIG_HIP(launch_dgemm('N', 'N', nrows, Kc, kp, -1.0, P2, kp, Y, n, 1.0, ZT + c0, n, false, false, s));
+    pnl = pa - 1;
+  }
+  return 0;
+}
+
 // Z^T <- Z^T Q1^T (stage-1 panels, compact WY: three GEMMs per panel as in eig_backtransform)
 static inline int eig2_apply_q1(double *ZT, long n, long nrows, EigWs &ws, Eig2Ws &w2, hipStream_t s, std::string &msg) {
   const long nb2 = (long)E2_B * E2_B;
@@ -1698,8 +1780,12 @@ static inline int eig2_apply_q1(double *ZT, long n, long nrows, EigWs &ws, Eig2W
   //   (I - V1 T1 V1^T)(I - V2 T2 V2^T) = I - [V1 V2] [[T1, -T1 (V1^T V2) T2], [0, T2]] [V1 V2]^T:
   // the rank-k update of Z^T has K = 256 (its reads and writes of Z^T halve) and the skinny product Z^T Y^T has two tile
   // columns.  GEMMA_HIP_EIGH_Q1_PAIR=0: panel by panel.
+  {
+    const int G = eig2_q1_group();
+    if (G >= 4 && w2.Qg && w2.q1_kpmax >= 4 * E2_B) return eig2_apply_q1_grouped(ZT, n, nrows, ws, w2, G, s, msg);
+  }
   const char *ep = getenv("GEMMA_HIP_EIGH_Q1_PAIR");
-  const bool pair = !(ep && ep[0] == '0') && w2.P256 != nullptr;
+  const bool pair = !(ep && ep[0] == '0') && w2.P256 != nullptr && eig2_q1_group() != 1;
   long pnl = npan - 1;
   while (pnl >= 0) {
     const bool two = pair && pnl >= 1 && ((npan - 1 - pnl) % 2 == 0); // pairs (pnl-1, pnl) counted from the last panel
@@ -1752,7 +1838,8 @@ static inline bool eig2_alloc(long n, EigWs &ws, Eig2Ws &w2) {
             ws.get(w2.betas, n) && ws.get(w2.gramP, nwg_gram * E2_B * E2_B) && ws.get(w2.YT, (size_t)4 * E2_B * n) &&
             ws.get(w2.V2, (size_t)w2.kmaxall * n * E2_B) && ws.get(w2.tau2, (size_t)w2.kmaxall * n) &&
             ws.get(w2.goff, (size_t)w2.nJ + 1) &&
-            ws.get(w2.prog, 8 * (size_t)w2.kmaxall + 32) && ws.get(w2.P256, (size_t)3 * n * 2 * E2_B) &&
+            ws.get(w2.prog, 8 * (size_t)w2.kmaxall + 32) && ws.get(w2.P256, (size_t)3 * n * std::max<long>(2 * E2_B, eig2_q1_kp(n))) &&
+            ws.get(w2.Qg, (size_t)eig2_q1_kp(n) * eig2_q1_kp(n) * (2 + 1 + Q1_SLICES)) &&
             ws.get(w2.Tpair, (size_t)4 * E2_B * E2_B) && ws.get(w2.q2sync, (size_t)(n + 63) / 64 + 2 + Q2_MAXSEG + 2);
   // the packed groups of the stage-2 back-transformation (0.8 n^2 doubles) are written after the divide & conquer and dead before
   // the final transpose: they live in the divide & conquer's Delta buffer (n^2), which is free in between (round 4: 16 GB less
@@ -1762,6 +1849,7 @@ static inline bool eig2_alloc(long n, EigWs &ws, Eig2Ws &w2) {
     else ok = ws.get(w2.pack, (size_t)w2.ngroups * E2_PACK);
   }
   if (!ok) return false;
+  w2.q1_kpmax = eig2_q1_kp(n);
   return hipMemcpy(w2.goff, goff.data(), goff.size() * sizeof(long), hipMemcpyHostToDevice) == hipSuccess;
 }
 

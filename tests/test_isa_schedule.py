@@ -118,6 +118,27 @@ def test_sixteen_row_records_kernel_steady_state_loop_is_as_written(tmp_path):
 
 
 @pytest.mark.skipif(not (os.path.exists(LIB) and os.path.exists(OBJDUMP)), reason="needs the built library and llvm-objdump")
+def test_sixteen_row_genotype_only_instance_of_the_records_kernel(tmp_path):
+    """i8gemm_sparse2_r16_g_kernel (round 6: the lowest digit of the 7g6m form -- genotype product alone, the SAME source as the shipped
+    kernel with the sparse instructions, the mask accumulators and the M rows compiled out): 32 dense matrix instructions and no sparse
+    one per K-tile and wavefront, the same 4 LDS-DMA pieces and 20 ds_read_b128, the same single counted wait, no scratch."""
+    lines = _kernel_text(tmp_path, "i8gemm_sparse2_r16_g_kernel")
+    assert lines, "i8gemm_sparse2_r16_g_kernel not found in the gfx950 code object"
+    ops, body = _steady_loop(lines)
+    assert not any(o.startswith("scratch_") for o in ops), [o for o in ops if o.startswith("scratch_")][:4]
+    assert not any("v_smfmac" in o for o in ops)
+    assert body is not None
+    cnt = lambda pat: sum(bool(re.match(pat, o)) for o in body)
+    assert cnt(r"v_mfma_i32_16x16x64_i8") == 32
+    assert cnt(r"global_load_lds_dwordx4") == 4 and cnt(r"ds_read_b128") == 20 and cnt(r"ds_read") == 20
+    assert cnt(r"s_barrier") == 1
+    assert cnt(r"s_waitcnt vmcnt\(8\)") == 1 and cnt(r"s_waitcnt vmcnt\(0\)") == 0, [o for o in body if "vmcnt" in o]
+    mats = [re.match(r"v_mfma\w*\s+(v\[\d+:\d+\])", o).group(1) for o in body if re.match(r"v_mfma", o)]
+    assert len(mats) == 32 and sorted(mats.count(a) for a in set(mats)) == [2] * 16
+    assert all(a != b for a, b in zip(mats, mats[1:] + mats[:1])), mats
+
+
+@pytest.mark.skipif(not (os.path.exists(LIB) and os.path.exists(OBJDUMP)), reason="needs the built library and llvm-objdump")
 def test_run_time_mvlmm_kernel_private_memory_budget(tmp_path):
     """The run-time multivariate kernel (mvlmm_kernels_rt.hip) keeps its small matrices in private memory; its large pieces are
     CALLED (MV_OUTLINE), not inlined: 60 KB per lane.  Fully inlined it was 120 KB per lane and eight minutes of compile time, close
