@@ -44,7 +44,8 @@ def parse():
     ap.add_argument("--eigen", default="auto", choices=["auto", "gemma", "torch"])
     ap.add_argument("--cpu-sample", type=int, default=2560, help="SNPs in the CPU baseline sample (0 = skip)")
     ap.add_argument("--a-mode", type=int, default=1)
-    ap.add_argument("--fp64-steps", type=int, default=2, help="extra untimed-region steps through the fp64 GEMM path (0 = skip)")
+    ap.add_argument("--fp64-steps", type=int, default=-1,
+                    help="steps of the fp64 MFMA GEMM path beside the timed region, on the same blocks (-1, default: min(--steps, 10); 0 = skip)")
     ap.add_argument("--dosage-steps", type=int, default=2,
                     help="extra untimed-region steps on BIMBAM-style fixed-point dosages (k/100, fp64 input): the int8-digit "
                          "dosage path, checked against the fp64 GEMM path on the same block (0 = skip)")
@@ -816,6 +817,8 @@ def main():
 
     # the fp64 MFMA GEMM path on the same blocks, outside the contract's timed region (single GPU only)
     fp64_path = None
+    if args.fp64_steps < 0:
+        args.fp64_steps = min(args.steps, 10)
     if world == 1 and i8_path and args.fp64_steps > 0:
         os.environ["GEMMA_HIP_UTX_I8"] = "0"
         api.reload_env()  # the library reads its switches once per setup, not per launch
