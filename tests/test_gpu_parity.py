@@ -860,8 +860,17 @@ def test_lmm_reference_xlarge_layout_and_batching(gpu_api, oracle):
     a = lmm.batch(Xlarge[:, :200], L.GENO_F64_IDV_MAJOR)  # view with tda 256
     b = np.concatenate([lmm.batch(X[s:s + 64], L.GENO_F64_SNP_MAJOR) for s in range(0, 200, 64)])
     lmm.finish()
+    # bit-identical per SNP -- except where the row's mean IS a genotype value (0, 1, 2): after the reference's imputation such a row's
+    # missing calls cannot be told from called ones, so the imputed layout multiplies them in the genotype product and the NaN layout in
+    # the mask product: the same x_s, assembled through two different roundings of the 7-digit Horner sum (1 ulp of U^T x; round 6: with the
+    # exact-maximum column scale that ulp moved one beta's last bit, with the power-of-two scale of rounds 1-5 it had not)
+    with np.errstate(invalid="ignore"):
+        mu = np.nanmean(X, axis=1)
+    amb = np.isnan(X).any(axis=1) & np.isin(mu, (0.0, 1.0, 2.0))
+    assert amb.sum() <= 3
     for k in a.dtype.names:
-        assert np.array_equal(a[k], b[k], equal_nan=True), k  # bit-identical per SNP
+        assert np.array_equal(a[k][~amb], b[k][~amb], equal_nan=True), k
+        np.testing.assert_allclose(a[k][amb], b[k][amb], rtol=1e-12, equal_nan=True, err_msg=k)
     ref = oracle.lmm_analyze(1, U, ev, UtW, Uty, X)
     _cmp_stats(a, ref, 1, "xlarge", _problem(U, ev, UtW, Uty, X))
 
