@@ -53,6 +53,9 @@ int eigh_reserve_x(long n, std::string &msg) {
     return GEMMA_HIP_EINVAL;
   }
   const long ne = eig_effective_n(n); // an odd order runs embedded in n + 1
+  static long reserved_for = 0;
+  if (reserved_for != ne) (void)eig_pool().drop_idle(); // another order: its blocks would only sit beside the new ones
+  reserved_for = ne;
   eig_pool().keep = true;
   EigWs ws;
   ws.n = ne;

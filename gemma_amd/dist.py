@@ -97,7 +97,9 @@ def native_comm_init(group=None, timeout=180.0):
         if rank == 0:
             L.check(L.lib().gemma_hip_comm_unique_id(ident), "comm_unique_id")
             box[0] = ident.raw
-        dist.broadcast_object_list(box, src=0, group=group)
+        # on the control plane explicitly: a mixed-backend group would otherwise be free to serialise the object onto the device and
+        # make torch's own (lazy) RCCL communicator the first thing to come up -- outside any deadline
+        dist.broadcast_object_list(box, src=0, group=group, device=ctl_device(group))
         ident = C.create_string_buffer(box[0], L.COMM_ID_BYTES)
         # ncclCommInitRank is itself a collective: run it on a helper thread with a deadline, so that a bootstrap that
         # never completes costs a delay and the agreed fallback below, not the run

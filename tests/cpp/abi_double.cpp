@@ -748,4 +748,15 @@ int gemma_hip_comm_finalize(void) {
   g_comm.world = 1;
   return GEMMA_HIP_OK;
 }
+int gemma_hip_comm_selftest(void *) { return GEMMA_HIP_OK; }
+int gemma_hip_comm_stats(gemma_comm_stats *out) {
+  if (out) memset(out, 0, sizeof *out);
+  return GEMMA_HIP_OK;
+}
+// the eigensolver's device workspace: nothing to reserve on the host double
+int gemma_hip_eigh_reserve(size_t) { return GEMMA_HIP_OK; }
+int gemma_hip_eigh_release(size_t *bytes_freed) {
+  if (bytes_freed) *bytes_freed = 0;
+  return GEMMA_HIP_OK;
+}
 }

@@ -29,6 +29,7 @@
 #include <sys/wait.h>
 #include <unistd.h>
 #include <string>
+#include <thread>
 #include <utility>
 #include <vector>
 
@@ -219,6 +220,16 @@ int main(int argc, char **argv) {
     cp.CopyCvtPhen(Wb, Yb);
     const size_t ni_total = cp.indicator_idv.size(), ni_test = cp.ni_test, n_cvt = cp.n_cvt;
     Matrix W = matrix_view(Wb.data(), ni_test, n_cvt);
+    // -inproc: the order of the eigendecomposition is known from here on.  Its device workspace (~5 n^2 doubles; hipMalloc of such sizes
+    // costs 25-50 ms per GB) is reserved on a helper thread while the first pass reads the genotype file (gemma_hip_eigh_reserve touches
+    // only the solver's own pool: the one entry point of the library that may run beside another one); joined before the kinship stage.
+    std::thread reserve_thr;
+    if (inproc && k_mode == 0 && a_mode != 0 && lm_mode == 0 && ni_test >= 8000 && getenv("GEMMA_DRIVER_NO_RESERVE") == nullptr)
+      reserve_thr = std::thread([ni_test] { (void)gemma_hip_eigh_reserve(ni_test); });
+    struct JoinGuard {
+      std::thread &t;
+      ~JoinGuard() { if (t.joinable()) t.join(); }
+    } reserve_guard{reserve_thr};
     size_t ng_total = 0;
     if (!file_gene.empty()) {
       if (!ReadFile_gene(file_gene, snpInfo, ng_total)) return 3;
@@ -238,6 +249,7 @@ int main(int argc, char **argv) {
       LOCO_set_Snps(setKSnps, setGWASnps, mapRS2chr, loco);
       std::cout << " ksnps=" << setKSnps.size() << " gwasnps=" << setGWASnps.size();
     }
+    if (reserve_thr.joinable()) reserve_thr.join();
     if (inproc) std::cout << " t_first_pass=" << lap();
     log.ni_total = ni_total; log.ni_test = ni_test; log.n_cvt = n_cvt; log.n_ph = n_ph;
     log.ns_total = indicator_snp.size(); log.ns_test = ns_test;
