@@ -400,3 +400,57 @@ def test_eigh_odd_n_is_padded(gpu_api, n, stages, monkeypatch):
     U0, w0 = np.zeros((n, n)), np.zeros(n)
     gpu_api.EigenDecomp_Zeroed(A.copy(), U0, w0)
     assert np.abs(w - w0).max() <= 30 * n * EPS * np.abs(w0).max()
+
+
+@pytest.mark.parametrize("n,kind", [(1538, "kinship"), (2307, "random"), (1280, "lowrank"), (700, "kinship")])
+def test_stage1_backtransform_panel_groups_agree(gpu_api, n, kind, monkeypatch):
+    """Round 6: the stage-1 back-transformation applies 1, 2, 4 or 8 stage-1 panels as ONE block reflector (GEMMA_HIP_EIGH_Q1_GROUP;
+    default 4, K = 512: the compact-WY factor of the group is built level by level from ONE Gram matrix of its reflectors).  Every group
+    size is the same orthogonal transformation: eigenvalues bit-identical (they do not pass through it), eigenvectors equal to rounding,
+    residual and orthogonality inside the bars of the end-to-end tests.  Sizes whose panel count is not a multiple of the group (a
+    leftover group of 1 / 2 / 3 panels at the top) included."""
+    monkeypatch.setenv("GEMMA_HIP_EIGH_STAGES", "2")
+    A = _sym(n, 11 * n + 5, kind)
+    nrm = max(np.linalg.norm(A, 2), 1e-300)
+    res = {}
+    for G in ("1", "2", "4", "8"):
+        monkeypatch.setenv("GEMMA_HIP_EIGH_Q1_GROUP", G)
+        U, w = np.zeros((n, n)), np.zeros(n)
+        gpu_api.EigenDecomp_Zeroed(A.copy(), U, w)
+        w_raw = np.where(w == 0.0, np.einsum("ij,ij->j", U, A @ U), w)
+        assert np.linalg.norm(U.T @ U - np.eye(n)) < 50 * n * EPS, G
+        assert np.linalg.norm(A @ U - U * w_raw[None, :]) / nrm < 50 * n * EPS, G
+        res[G] = (U, w)
+    for G in ("2", "4", "8"):
+        assert np.array_equal(res[G][1], res["1"][1]), G
+        if kind != "lowrank":  # (a degenerate eigenspace may come back in another basis)
+            assert np.abs(np.abs(res[G][0]) - np.abs(res["1"][0])).max() < 1e-9, G
+
+
+def test_eigensolver_workspace_pool(gpu_api, monkeypatch):
+    """Round 6: gemma_hip_eigh_reserve(n) allocates the solver's workspace ahead of the solve and keeps every later solve's buffers in a
+    pool; gemma_hip_eigh_release hands them back.  Same bits with and without the pool, a second solve of the same order allocates
+    nothing new, another order (and an odd one: embedded in n + 1) still works, release frees what was reserved."""
+    monkeypatch.setenv("GEMMA_HIP_EIGH_STAGES", "2")
+    n = 1026
+    A = _sym(n, 99, "kinship")
+    U0, w0 = np.zeros((n, n)), np.zeros(n)
+    gpu_api.EigenDecomp_Zeroed(A.copy(), U0, w0)
+    assert gpu_api.eigh_release() == 0  # nothing is kept unless asked for
+    gpu_api.eigh_reserve(n)
+    U1, w1 = np.zeros((n, n)), np.zeros(n)
+    gpu_api.EigenDecomp_Zeroed(A.copy(), U1, w1)
+    U2, w2 = np.zeros((n, n)), np.zeros(n)
+    gpu_api.EigenDecomp_Zeroed(A.copy(), U2, w2)
+    assert np.array_equal(w0, w1) and np.array_equal(U0, U1) and np.array_equal(U1, U2)
+    m = 769  # odd: runs embedded in 770; the pool holds blocks of another order
+    B = _sym(m, 5, "random")
+    Ub, wb = np.zeros((m, m)), np.zeros(m)
+    gpu_api.EigenDecomp_Zeroed(B.copy(), Ub, wb)
+    _check(B, Ub, wb, "pooled, another order")
+    freed = gpu_api.eigh_release()
+    assert freed > 5 * n * n * 8 // 2
+    assert gpu_api.eigh_release() == 0
+    U3, w3 = np.zeros((n, n)), np.zeros(n)
+    gpu_api.EigenDecomp_Zeroed(A.copy(), U3, w3)
+    assert np.array_equal(U0, U3) and gpu_api.eigh_release() == 0

@@ -1382,6 +1382,94 @@ def test_lmm_pipe_blocks_equal_plain_batches(gpu_api, oracle, monkeypatch, cus):
     assert piped2.tobytes() == plain.tobytes()
 
 
+@pytest.mark.parametrize("ni_total,p,miss", [(500, 300, 0.02), (1333, 700, 0.01), (260, 64, 0.10)])
+def test_strict_form_7g6m_statistics(gpu_api, oracle, monkeypatch, ni_total, p, miss):
+    """Round 6: GEMMA_HIP_I8_FORM=7g6m -- seven digits of U for the genotype product, the mask product on the upper six; plane 0 (digit 0
+    alone) is a launch of its own on the genotype-only instance of the records kernel, the digit combine reads no mask rows for it.
+    PLINK blocks with dropped individuals and ragged tiles: the statistics against the oracle at the usual bar, U^T x within 1e-13 of the
+    exact product, NOT identical to the 7-digit run (the lowest mask digit is really gone) yet closer than 2^-40 to it; the library names
+    the kernels it launched; 10 % missingness puts surplus rows through the fp64 fix-up of the combine as well."""
+    from gemma_amd import _lib as L
+    rng = np.random.default_rng(ni_total + p)
+    ind, raw = _plink_case(oracle, rng, ni_total, p, miss=miss)
+    n = int(ind.sum())
+    Xn = oracle.bed_decode(raw, ni_total, ind)
+    Kg = oracle.bed_decode(raw, ni_total)[:, ind == 1]
+    U, ev, _ = oracle.eigen_decomp_zeroed(oracle.center_matrix(oracle.calc_kin(Kg, 1)))
+    y = rng.standard_normal(n)
+    UtW, Uty = U.T @ np.ones((n, 1)), U.T @ y
+    ref = oracle.lmm_analyze(1, U, ev, UtW, Uty, Xn, plink_nan_rule=1)
+    utx = {}
+    for form in ("7g6m", "7"):
+        monkeypatch.delenv("GEMMA_HIP_I8_FORM", raising=False)
+        monkeypatch.delenv("GEMMA_HIP_I8_DIGITS", raising=False)
+        if form == "7g6m":
+            monkeypatch.setenv("GEMMA_HIP_I8_FORM", "7g6m")
+        else:
+            monkeypatch.setenv("GEMMA_HIP_I8_DIGITS", "7")
+        lmm = gpu_api.LMM(a_mode=1)
+        lmm.setup(U, ev, UtW, Uty, plink=True)
+        lmm.set_indicator(ind)
+        utx[form] = lmm.dbg_utx(raw, L.GENO_PLINK_2BIT, 1)
+        got = lmm.batch(raw, L.GENO_PLINK_2BIT)
+        k = gpu_api.last_utx_kernel()
+        lmm.finish()
+        assert k["variant"] == L.UTX_KERNEL_RECORDS_R16 and k["digits"] == 7
+        _cmp_stats(got, ref, 1, "plink form=%s ni_total=%d" % (form, ni_total), _problem(U, ev, UtW, Uty, Xn))
+    monkeypatch.delenv("GEMMA_HIP_I8_FORM", raising=False)
+    monkeypatch.delenv("GEMMA_HIP_I8_DIGITS", raising=False)
+    exact = oracle.impute_mean(Xn) @ U
+    scale = np.abs(oracle.impute_mean(Xn)) @ np.abs(U)
+    assert np.max(np.abs(utx["7g6m"] - exact) / scale) < 1e-13
+    d = np.abs(utx["7g6m"] - utx["7"])
+    assert d.max() > 0 and np.max(d / scale) < 2.0 ** -40
+
+
+def test_lmm_pipe_on_a_side_stream_with_two_staging_buffers(gpu_api, oracle, monkeypatch):
+    """include/gemma_hip.h lets a caller overwrite the genotype buffer of block i with work queued on ITS stream
+    after the call for block i + 1 -- a double-buffering feeder.  On a non-default stream nothing used to order that overwrite behind
+    ingest(i), which runs on the pipeline's own stream and may still sit behind the product of block i - 1: round 6 records an event
+    behind every ingest and makes the caller's stream wait for it at the next call.  Eight blocks through TWO staging buffers on a
+    torch side stream, each refilled right after the next call: every record must be the plain batch's, bit for bit."""
+    import torch
+    from gemma_amd import _lib as L
+    monkeypatch.setenv("GEMMA_HIP_PIPE_CUS", "0")
+    rng = np.random.default_rng(78)
+    ni_total, p = 3000, 8 * 1400
+    _, raw = _plink_case(oracle, rng, ni_total, p, drop=0.0, miss=0.02)
+    n = ni_total
+    Kg = oracle.bed_decode(raw[:800], ni_total)
+    U, ev, _ = oracle.eigen_decomp_zeroed(oracle.center_matrix(oracle.calc_kin(Kg, 1)))
+    y = rng.standard_normal(n)
+    dev = torch.device("cuda", 0)
+    tU, te = torch.from_numpy(U).to(dev), torch.from_numpy(ev).to(dev)
+    tW, ty = torch.from_numpy(np.ascontiguousarray(U.T @ np.ones((n, 1)))).to(dev), torch.from_numpy(U.T @ y).to(dev)
+    master = [torch.from_numpy(raw[1400 * i:1400 * (i + 1)].copy()).to(dev) for i in range(8)]
+    lmm = gpu_api.LMM(a_mode=1)
+    lmm.setup(tU, te, tW, ty, plink=True)
+    plain = [lmm.batch(b, L.GENO_PLINK_2BIT).cpu().numpy().copy() for b in master]
+    lmm.finish()
+    lmm = gpu_api.LMM(a_mode=1)
+    lmm.setup(tU, te, tW, ty, plink=True)
+    try:
+        side = torch.cuda.Stream(device=dev)
+        outs = [torch.full((1400, 8), -7.0, dtype=torch.float64, device=dev) for _ in master]
+        stage = [torch.empty_like(master[0]) for _ in range(2)]
+        torch.cuda.synchronize()
+        with torch.cuda.stream(side):
+            stage[0].copy_(master[0])
+            for i in range(8):
+                if i + 1 < 8:
+                    stage[(i + 1) % 2].copy_(master[i + 1])  # queued on the side stream after the call for block i: refills block i - 1's buffer
+                lmm.batch_pipe(stage[i % 2], L.GENO_PLINK_2BIT, outs[i])
+            lmm.pipe_flush()
+        torch.cuda.synchronize()
+        for i in range(8):
+            assert outs[i].cpu().numpy().tobytes() == plain[i].tobytes(), i
+    finally:
+        lmm.finish()
+
+
 @pytest.mark.parametrize("n,p,decimals,miss", [(645, 300, 2, 0.02), (1290, 513, 3, 0.01), (130, 129, 2, 0.0)])
 def test_dosage_planes_on_the_16_row_instruction_equal_the_32_row_kernel(gpu_api, oracle, monkeypatch, n, p, decimals, miss):
     """Round 5: the byte planes of fixed-point dosages run on v_mfma_i32_16x16x64_i8 (i8gemm_dense16_kernel_t<true>) by default,

@@ -123,12 +123,20 @@ def _eigh_worker(rank, world, port, case_path, outdir, env):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     api.init(0, verbose=0)
     assert gdist.native_comm_init(), "the library's communicator (shm transport) did not come up"
+    # round 6: the staged start -- ONE KiB through the all-reduce and the broadcast (from rank 0 and from the last rank), every value
+    # checked on every rank, before anything n^2 goes through the communicator
+    assert gdist.native_comm_selftest(timeout=60.0), gdist.native_comm_error()
+    st0 = api.comm_stats()
+    assert st0["allreduce_calls"] == 1 and st0["bcast_calls"] == 2 and st0["allreduce_bytes"] == 1024.0 and st0["bcast_bytes"] == 2048.0
     K = torch.from_numpy(np.load(case_path)).to(dev)
     n = K.shape[0]
     U = torch.empty_like(K)
     ev = torch.empty(n, dtype=torch.float64, device=dev)
     tr = api.EigenDecomp_Zeroed_sharded(K.clone(), U, ev)
     torch.cuda.synchronize()
+    st1 = api.comm_stats()  # the collective solve's agreements, and -- when the back-transformations were shared out -- one slice per rank
+    assert st1["allreduce_calls"] + st1["bcast_calls"] > st0["allreduce_calls"] + st0["bcast_calls"]
+    assert st1["bcast_pieces"] >= st1["bcast_calls"] and st1["allreduce_pieces"] >= st1["allreduce_calls"]
     np.savez(os.path.join(outdir, "eig_rank%d.npz" % rank), U=U.cpu().numpy(), ev=ev.cpu().numpy(), tr=tr)
     dist.barrier()
     dist.destroy_process_group()
