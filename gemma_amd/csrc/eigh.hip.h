@@ -745,6 +745,10 @@ struct EigPool {
         best = (long)i;
     if (best >= 0) {
       blks[(size_t)best].used = true;
+      // A recycled block carries the previous solve's bytes.  The solver reads nothing it has not written: GEMMA_HIP_EIGH_POISON=1
+      // (diagnostics) fills every block, fresh ones too, with NaN bit patterns, and every stage returns the same bits
+      // (scripts/exp/r6_dbg2.py: one- and two-stage paths, the stage diagnostics).
+      if (poison() && hipMemset(blks[(size_t)best].p, 0xFF, blks[(size_t)best].bytes) != hipSuccess) (void)hipGetLastError();
       return blks[(size_t)best].p;
     }
     void *q = nullptr;
@@ -757,8 +761,13 @@ struct EigPool {
         return nullptr;
       }
     }
+    if (poison() && hipMemset(q, 0xFF, bytes) != hipSuccess) (void)hipGetLastError();
     blks.push_back({q, bytes, true});
     return q;
+  }
+  static bool poison() {
+    const char *e = getenv("GEMMA_HIP_EIGH_POISON");
+    return e && e[0] == '1';
   }
   void give(void *q) {
     for (size_t i = 0; i < blks.size(); ++i)

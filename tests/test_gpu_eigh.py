@@ -444,10 +444,12 @@ def test_eigensolver_workspace_pool(gpu_api, monkeypatch):
     gpu_api.EigenDecomp_Zeroed(A.copy(), U2, w2)
     assert np.array_equal(w0, w1) and np.array_equal(U0, U1) and np.array_equal(U1, U2)
     m = 769  # odd: runs embedded in 770; the pool holds blocks of another order
-    B = _sym(m, 5, "random")
+    B = _sym(m, 5, "kinship") + 0.5 * np.eye(m)  # positive definite: EigenDecomp_Zeroed leaves every eigenvalue as it is
     Ub, wb = np.zeros((m, m)), np.zeros(m)
+    monkeypatch.setenv("GEMMA_HIP_EIGH_POISON", "1")  # every block handed out, recycled or fresh, is filled with NaN patterns first
     gpu_api.EigenDecomp_Zeroed(B.copy(), Ub, wb)
-    _check(B, Ub, wb, "pooled, another order")
+    monkeypatch.delenv("GEMMA_HIP_EIGH_POISON")
+    _check(B, Ub, wb, "pooled, another order, poisoned blocks")
     freed = gpu_api.eigh_release()
     assert freed > 5 * n * n * 8 // 2
     assert gpu_api.eigh_release() == 0

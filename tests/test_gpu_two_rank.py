@@ -135,7 +135,8 @@ def _eigh_worker(rank, world, port, case_path, outdir, env):
     tr = api.EigenDecomp_Zeroed_sharded(K.clone(), U, ev)
     torch.cuda.synchronize()
     st1 = api.comm_stats()  # the collective solve's agreements, and -- when the back-transformations were shared out -- one slice per rank
-    assert st1["allreduce_calls"] + st1["bcast_calls"] > st0["allreduce_calls"] + st0["bcast_calls"]
+    if os.environ.get("GEMMA_HIP_EIGH_SHARD", "1") != "0":  # (=0: replicas, nothing is exchanged)
+        assert st1["allreduce_calls"] + st1["bcast_calls"] > st0["allreduce_calls"] + st0["bcast_calls"]
     assert st1["bcast_pieces"] >= st1["bcast_calls"] and st1["allreduce_pieces"] >= st1["allreduce_calls"]
     np.savez(os.path.join(outdir, "eig_rank%d.npz" % rank), U=U.cpu().numpy(), ev=ev.cpu().numpy(), tr=tr)
     dist.barrier()
