@@ -83,10 +83,17 @@ def test_two_ranks_on_one_device_without_any_test_hook_still_yield_a_line(gpu_ap
     assert d["config"]["ranks_seen"] == 2
 
 
-def test_native_flow_reports_its_collectives(gpu_api):
-    """the healthy path: staged start passed, the line carries bytes and 1-GiB pieces per collective of the library's communicator"""
-    d = _run_bench({"BENCH_DIST_BACKEND": "gloo", "GEMMA_HIP_COMM": "shm", "GEMMA_HIP_COMM_TIMING": "1"})
+@pytest.mark.parametrize("backend", ["gloo", None])
+def test_native_flow_reports_its_collectives(gpu_api, backend):
+    """the healthy path: staged start passed, the line carries bytes and 1-GiB pieces per collective of the library's communicator.
+    backend None = the process group the driver's run gets (control plane gloo, device collectives RCCL -- which is never touched when the
+    library's own communicator carries the setup: torch's lazy RCCL communicator is not even created, so this also runs on one device)."""
+    env = {"GEMMA_HIP_COMM": "shm", "GEMMA_HIP_COMM_TIMING": "1"}
+    if backend:
+        env["BENCH_DIST_BACKEND"] = backend
+    d = _run_bench(env)
     cm = d["config"]["comm"]
+    assert cm["control_plane"] == ("gloo" if backend else "cpu:gloo,cuda:nccl") or "gloo" in cm["control_plane"]
     assert cm["setup_mode"] == "native" and cm["error"] is None
     assert all(t["ok"] for t in cm["staged_start"]) and len(cm["staged_start"]) == 2
     st = cm["collectives"]
