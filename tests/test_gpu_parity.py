@@ -1458,10 +1458,12 @@ def test_lmm_pipe_on_a_side_stream_with_two_staging_buffers(gpu_api, oracle, mon
         torch.cuda.synchronize()
         with torch.cuda.stream(side):
             stage[0].copy_(master[0])
+            stage[1].copy_(master[1])
             for i in range(8):
-                if i + 1 < 8:
-                    stage[(i + 1) % 2].copy_(master[i + 1])  # queued on the side stream after the call for block i: refills block i - 1's buffer
                 lmm.batch_pipe(stage[i % 2], L.GENO_PLINK_2BIT, outs[i])
+                # the header's contract: block i - 1's buffer may be overwritten by work queued on this stream AFTER the call for block i
+                if i >= 1 and i + 1 < 8:
+                    stage[(i + 1) % 2].copy_(master[i + 1])
             lmm.pipe_flush()
         torch.cuda.synchronize()
         for i in range(8):
