@@ -10,7 +10,10 @@ LIB = os.path.join(HERE, "libgemma_hip.so")
 UNITS = {
     "gemma_hip.hip": ["dgemm_mfma.hip.h", "lmm_grid.hip.h", "i8gemm.hip.h", "i8gemm_sparse.hip.h", "i8gemm_sparse2.hip.h", "i8gemm_sparse2_r16.hip.h", "i8gemm_dense16.hip.h", "lmm_assoc.hip.h",
                       "lmm_search.hip.h", "comm.hip.h", "comm_shm.hpp", "kin_i8.hip.h", "ingest.hip.h", "qc.hip.h", "lm_assoc.hip.h", "mvlmm.hip.h",
-                      "mvlmm_kernels.hip.h", "eigh_tu.h"],
+                      "mvlmm_kernels.hip.h", "eigh_tu.h",
+                      # the stages of the C ABI: textual parts of gemma_hip.hip (one translation unit around g_ctx)
+                      "abi_kinship.inc.h", "abi_eigen_qc.inc.h", "abi_lmm_stage.inc.h", "abi_utx.inc.h", "abi_lmm_batch.inc.h",
+                      "abi_mvlmm.inc.h", "abi_gxe_lm.inc.h", "abi_kept_comm.inc.h"],
     "eigh_tu.hip": ["dgemm_mfma.hip.h", "eigh.hip.h", "eigh2.hip.h", "eigh_tu.h"],  # the eigensolver: its own object file
     "mvlmm_kernels.hip": ["mvlmm.hip.h", "mvlmm_kernels.hip.h"],
     "mvlmm_kernels_wide.hip": ["mvlmm.hip.h", "mvlmm_kernels.hip.h"],

@@ -3,9 +3,9 @@
 // A PLINK genotype row after GEMMA's mean imputation (src/lmm.cpp:1797-1827) is  x_s = g_s + mean_s * m_s  with
 // g in {0,1,2} (0 where the call is missing) and m the 0/1 missing mask, so
 //     (U^T x_s)[j] = sum_k g_sk U[k][j] + mean_s * sum_k m_sk U[k][j].
-// Both sums have an EXACTLY representable small-integer left factor.  U's column j is scaled by a power of two and
-// rounded to a 55-bit integer (|V| <= 2^54: every entry in the column's top binade is exact, absolute error elsewhere
-// <= 2^-55 of the column maximum), written in balanced base 256: V = sum_d 256^d D_d, D_d in [-128,127], d = 0..6.
+// Both sums have an EXACTLY representable small-integer left factor.  U's column j is scaled (round 6: by 0.99 * 2^(8 D - 1) over its
+// exact maximum, u_scale_kernel below; rounds 1-5: by a power of two) and rounded to an integer of D balanced base-256 digits:
+// V = sum_d 256^d D_d, D_d in [-128,127], d = 0..D-1 (absolute error <= 1.01 * 2^(-8 D) of the column maximum).
 // Each digit product  [G; M] (int8) x D_d (int8)  accumulates exactly in int32 (|sum| <= 20000*2*128 < 2^23), i.e.
 // v_mfma_i32_32x32x32_i8 work at ~64x the fp64 MFMA rate; 7 digits x 2 left factors = 14 products replace the one
 // fp64 product.  The fp64 result is assembled once per element (Horner over the digits, <= 2 roundings), which is
@@ -33,11 +33,11 @@ constexpr int I8_DIGITS = 7;      // most digits a build handles (buffers are si
 constexpr int SUR_MAX = 16;       // calls per row the sparse mask operand may drop before the row goes to the fp64 fix-up: the stride of
                                   // the dropped-call lists, shared by the list kernel (i8gemm_sparse.hip.h), the combine below and the host
 constexpr int I8_SCALE_BITS = 54;  // with 7 digits; D digits scale to 8 D - 2 bits (|V| <= 2^(8D-2) < 128 * 256^(D-1))
-// Digits actually used (host: i8_digits_for): 7 reproduce U to its last bit in the column's top binade (error elsewhere
-// <= 2^-55 of the column maximum).  From n = 16384 up 6 digits are used: U is then rounded at 2^-47 of the column maximum,
-// which perturbs a dot product by ~2^-47 cmax |x|_2 / sqrt(12) -- in the units of the accuracy test (sum_k |x_k||u_k|)
-// about 1.3e-14 / sqrt(n), i.e. <= 1e-16 typical and ~5e-16 at the worst of 4e8 outputs at n = 20000: the level of the
-// fp64 MFMA GEMM's own rounding (5e-16), an order below the test's bar -- for 6/7 of the matrix-pipe cycles.
+// Digits actually used (host: i8_digits_for): 7 round U at 2^-56 of each column's maximum.  From n = 16384 up 6 digits are used: U is
+// then rounded at 2^-48 of the column maximum, which perturbs a dot product by cmax |x|_2 / (0.99 * 2^47 * sqrt(12)) -- measured against
+// long-double products 1.66e-16 rms in units of sum_k |x_k||u_k| (the fp64 MFMA GEMM: 3.6e-17), 4.6 x the GEMM's, for 6/7 of the
+// matrix-pipe cycles; GEMMA_HIP_I8_FORM=7g6m (seven digits for the genotype product, six for the mask product) is below the GEMM's
+// (tests/test_gpu_at_size.py::test_six_digit_rounding_of_U_is_what_the_model_says).  i8_scale_bits: the power-of-two scale of rounds 1-5.
 __host__ __device__ inline int i8_scale_bits(int digits) { return 8 * digits - 2; }
 
 // ---------------------------------------------------------------------------------------------------------------

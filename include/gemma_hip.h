@@ -185,12 +185,14 @@ int gemma_hip_lmm_set_indicator(const int *indicator_idv, size_t ni_total);
  * out[l] in SNP order. l is not limited to LMM_BATCH_SIZE.
  * U^T X: fp64 MFMA GEMM for real-valued input; for hard calls (GEMMA_GENO_PLINK_2BIT, or fp64 rows holding only
  * 0/1/2 and one missing / imputed value -- detected per batch) the same product as 2 D int8 MFMA products of
- * {genotype, missing mask} with D balanced base-256 digits of U, accumulated exactly in int32.  PRECISION OF THE OPERAND:
- * D = 7 below n = 16384 -- U is then reproduced to 2^-55 of each column's maximum, i.e. to its last bit in the column's top
- * binade, and the product is closer to the exact dot products than an fp64 GEMM (which rounds every partial sum).  From
- * n = 16384 up D = 6: U is ROUNDED to 2^-47 of each column's maximum -- narrower than the reference's fp64 operand (2^-53 per
- * entry); measured at n = 20000 the rms error of U^T x is 10 x that of the fp64 MFMA GEMM, the maximum equal to it
- * (DESIGN.md 3.1c), eight orders below the 1e-6 bar on the statistics.  GEMMA_HIP_I8_DIGITS=7 forces the bit-faithful operand at
+ * {genotype, missing mask} with D balanced base-256 digits of U, accumulated exactly in int32.  PRECISION OF THE OPERAND (round 6):
+ * every column of U is scaled by its exact maximum and rounded at 1.01 * 2^(-8 D) of it.  D = 7 below n = 16384: 2^-56 of the column
+ * maximum, below an fp64 entry's own rounding in the column's top binades, and the product is closer to the exact dot products than an
+ * fp64 GEMM (which rounds every partial sum).  From n = 16384 up D = 6: U is ROUNDED to 2^-48 of each column's maximum -- narrower than
+ * the reference's fp64 operand (2^-53 per entry); measured against long-double products the rms error of U^T x is 4.6 x that of the fp64
+ * MFMA GEMM, the maximum 4.4 x, eight orders below the 1e-6 bar on the statistics.  GEMMA_HIP_I8_FORM=7g6m is the strict
+ * form -- seven digits for the genotype product, the mask product (whose term is sqrt(n / missing calls) smaller) on the upper six:
+ * rms and maximum error a quarter / an eighth of the fp64 GEMM's for 10/9 of the matrix work; GEMMA_HIP_I8_DIGITS=7 seven digits for both at
  * any n (14 products: 7/6 of the time), GEMMA_HIP_UTX_I8=0 selects the fp64 GEMM always.  The _d form is asynchronous on its stream for
  * GEMMA_GENO_PLINK_2BIT; for fp64 input it synchronises the stream once per call (the hard-call verdict is read back). */
 int gemma_hip_lmm_batch(int geno_kind, const void *geno, size_t l, size_t ld, gemma_sumstat *out);
@@ -404,8 +406,8 @@ int gemma_hip_dbg_last_utx_kernel(gemma_utx_kernel_info *info);
 /* re-read the GEMMA_HIP_* switches of the batch path.  The library reads them once per setup (gemma_hip_init, lmm_setup*, lm_setup,
  * mvlmm_null / mvlmm_set, kin_begin), never per launch; a caller that changes one between two batches of ONE setup calls this. */
 int gemma_hip_reload_env(void);
-/* base-256 digits of U the int8 product uses at this n: 7 (U to 2^-55 of the column maximum: bit-faithful); 6 from n = 16384 up
- * (U rounded to 2^-47 of the column maximum -- see gemma_hip_lmm_batch); GEMMA_HIP_I8_DIGITS=6|7 overrides */
+/* base-256 digits of U the int8 product uses at this n: 7 (U to 2^-56 of the column maximum); 6 from n = 16384 up
+ * (U rounded to 2^-48 of the column maximum -- see gemma_hip_lmm_batch); GEMMA_HIP_I8_DIGITS=6|7 and GEMMA_HIP_I8_FORM=7g6m override */
 int gemma_hip_dbg_i8_digits(size_t n, int *digits);
 
 #ifdef __cplusplus
