@@ -1078,7 +1078,9 @@ __global__ __launch_bounds__(256) void q2_pack_kernel(Q2PackArgs g) {
   }
   for (int idx = t; idx < E2_NB * E2_VLD; idx += 256) {
     const int p = idx / E2_VLD, q = idx % E2_VLD;
-    dst[E2_WIN * E2_VLD + idx] = (q < E2_NB) ? Tt[p][q] : 0.0;
+    // stored NEGATED (round 6): the apply kernel then forms -T W^T in its second product and adds V (-W2^T) in its third -- the same bits as
+    // subtracting V W2^T, without a sign flip of every V operand in front of the third product's matrix instructions
+    dst[E2_WIN * E2_VLD + idx] = (q < E2_NB) ? -Tt[p][q] : 0.0;
   }
 }
 
@@ -1238,21 +1240,33 @@ __global__ __launch_bounds__(256, 2) void q2_apply_kernel(Q2ApplyArgs g) {
         }
       }
       __builtin_amdgcn_sched_barrier(0);
-      // X^T tile ct -= V[16 ct .., :] W2^T
+      // X^T tile ct += V[16 ct .., :] (-W2^T)   (the pack holds -T: w20 / w21 are -W2^T).  Round 6: TWO window tiles at a time, their
+      // matrix instructions alternating -- a tile's eight instructions are one dependent chain on its accumulator, and back to back each
+      // waited for the one before it; the other tile's fill those slots (every chain keeps its own order: the same bits)
 #pragma unroll
-      for (int ct = 0; ct < NT; ++ct) {
-        e2_v4 acc = {x[4 * ct], x[4 * ct + 1], x[4 * ct + 2], x[4 * ct + 3]};
+      for (int ct = 0; ct < NT; ct += 2) {
+        e2_v4 acc0 = {x[4 * ct], x[4 * ct + 1], x[4 * ct + 2], x[4 * ct + 3]};
+        e2_v4 acc1 = {x[4 * ct + 4], x[4 * ct + 5], x[4 * ct + 6], x[4 * ct + 7]};
 #pragma unroll
         for (int ks = 0; ks < E2_NB / 4; ++ks) {
-          if ((ct == 0 && ks >= 4) || (ct == NT - 1 && ks < 4)) continue; // zero corners of the parallelogram
-          const double a = -Vd[(16 * ct + li) * E2_VLD + 4 * ks + lk];
           const double b = (ks < 4) ? w20[ks & 3] : w21[ks & 3];
-          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+          if (!(ct == 0 && ks >= 4)) { // zero corners of the parallelogram: tile 0 has no sweeps 16..31, tile NT - 1 no sweeps 0..15
+            const double a0 = Vd[(16 * ct + li) * E2_VLD + 4 * ks + lk];
+            acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b, acc0, 0, 0, 0);
+          }
+          if (!(ct + 1 == NT - 1 && ks < 4)) {
+            const double a1 = Vd[(16 * (ct + 1) + li) * E2_VLD + 4 * ks + lk];
+            acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b, acc1, 0, 0, 0);
+          }
         }
-        x[4 * ct] = acc[0];
-        x[4 * ct + 1] = acc[1];
-        x[4 * ct + 2] = acc[2];
-        x[4 * ct + 3] = acc[3];
+        x[4 * ct] = acc0[0];
+        x[4 * ct + 1] = acc0[1];
+        x[4 * ct + 2] = acc0[2];
+        x[4 * ct + 3] = acc0[3];
+        x[4 * ct + 4] = acc1[0];
+        x[4 * ct + 5] = acc1[1];
+        x[4 * ct + 6] = acc1[2];
+        x[4 * ct + 7] = acc1[3];
         __builtin_amdgcn_sched_barrier(0); // keep the operand reads of later tiles from being hoisted (register pressure)
       }
       if (Jb == 0) {
