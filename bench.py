@@ -452,7 +452,7 @@ def main():
         # cost this run its native setup, not its line
         fin, res = gdist._with_deadline(lambda: setup_multi_rank(args, np, torch, dist, api, L, gdist, rank, world, dev, gen, n, B, setup_info,
                                                                  null, UtW, Uty),
-                                        float(os.environ.get("BENCH_SETUP_DEADLINE", str(600 + 900 * (n / 50000.0) ** 3))))
+                                        float(os.environ.get("BENCH_SETUP_DEADLINE", str(90 + 300 * (n / 50000.0) ** 3))))  # ~20 x what the stage takes
         ok_here = bool(fin and isinstance(res, dict))
         if gdist.agree(ok_here):
             kept_state = res
