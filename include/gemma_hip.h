@@ -138,7 +138,9 @@ int gemma_hip_eigh_d(double *G_d, size_t n, double *U_d, double *eval_d, double 
  * ahead of the solve (a caller that knows its n does this while it reads its files) and from then on every solve leaves its buffers in a
  * pool for the next one (LOCO: one decomposition per chromosome); gemma_hip_eigh_release hands the idle buffers back (lmm_setup* does
  * so by itself when the pool holds more than a quarter of the device).  GEMMA_HIP_EIGH_CACHE=1 keeps every solve's buffers without a
- * reserve call.  Without either the solver allocates and frees per call, as before. */
+ * reserve call.  Without either the solver allocates and frees per call, as before.  gemma_hip_eigh_reserve touches nothing but the solver's
+ * own pool: after gemma_hip_init it is the ONE entry point that may run on a second thread beside another call of the library (the file
+ * driver issues it while the first pass reads the genotype file); join it before the first gemma_hip_eigh* call. */
 int gemma_hip_eigh_reserve(size_t n);
 int gemma_hip_eigh_release(size_t *bytes_freed /* may be NULL */);
 /* The same as a COLLECTIVE over the library's communicator (gemma_hip_comm_init): every rank passes the same G and
