@@ -100,6 +100,11 @@ extern "C" int gemma_hip_eigh_sharded_d(double *G, size_t n, double *U, double *
 // The eigensolver's workspace (~5 n^2 doubles) ahead of the solve, kept between solves (csrc/eigh.hip.h, EigPool).
 extern "C" int gemma_hip_eigh_reserve(size_t n) {
   NEED_INIT();
+  // may run on a thread of its own (include/gemma_hip.h): HIP's current device is per thread, and a fresh thread starts on device 0
+  if (g_ctx.device >= 0 && hipSetDevice(g_ctx.device) != hipSuccess) {
+    (void)hipGetLastError();
+    return fail(GEMMA_HIP_ERUNTIME, "eigh_reserve: cannot select device %d", g_ctx.device);
+  }
   std::string msg;
   const int rc = eigh_reserve_x((long)n, msg);
   if (rc) return fail(rc, "%s", msg.c_str());
