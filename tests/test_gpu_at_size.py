@@ -317,11 +317,12 @@ def test_six_digit_rounding_of_U_is_what_the_model_says(gpu_api, oracle, monkeyp
     assert rms["7"] <= rms["7g6m"] * 1.05 and rms["7"] <= rms["gemm"]
 
 
-@pytest.mark.parametrize("n,stages", [(4096, "2"), (5003, "")])
+@pytest.mark.parametrize("n,stages", [(4096, "2"), (5003, ""), (8200, "")])
 def test_whole_chain_against_the_reference_built_here(gpu_api, oracle, monkeypatch, tmp_path, n, stages):
     """end-to-end parity with the REFERENCE -- raw genotypes -> kinship -> centring -> eigendecomposition -> U^T W, U^T y ->
     null model -> association -- stopped at n = 1 008 (BXD, issue188); at size the oracle was handed the device's (U, eval).  Here the whole
-    chain runs twice from the same .bed bytes at n = 4 096 (two-stage eigensolver forced) and n = 5 003 (odd: embedded; one-stage):
+    chain runs twice from the same .bed bytes at n = 4 096 (two-stage eigensolver forced), n = 5 003 (odd: embedded; one-stage) and
+    n = 8 200 (the DEFAULT two-stage path; the reference's dsyevr needs half a minute there):
       reference side, on the CPU: the reference's own PlinkKin, its own EigenDecomp_Zeroed (dsyevr) and its own LMM::Analyze
         (oracle/_ref/libgemma_ref.so = /root/reference/src compiled unchanged), centring and null model through the pinned restatement;
       device side: gemma_hip_kin_* -> center -> eigh -> calc_utx -> lmm_null -> lmm_batch through the C ABI.
