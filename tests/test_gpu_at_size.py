@@ -317,8 +317,8 @@ def test_six_digit_rounding_of_U_is_what_the_model_says(gpu_api, oracle, monkeyp
     assert rms["7"] <= rms["7g6m"] * 1.05 and rms["7"] <= rms["gemm"]
 
 
-@pytest.mark.parametrize("n,stages", [(4096, "2"), (5003, ""), (8200, "")])
-def test_whole_chain_against_the_reference_built_here(gpu_api, oracle, monkeypatch, tmp_path, n, stages):
+@pytest.mark.parametrize("n,stages,mode,c", [(4096, "2", 1, 1), (5003, "", 4, 3), (8200, "", 1, 1)])
+def test_whole_chain_against_the_reference_built_here(gpu_api, oracle, monkeypatch, tmp_path, n, stages, mode, c):
     """end-to-end parity with the REFERENCE -- raw genotypes -> kinship -> centring -> eigendecomposition -> U^T W, U^T y ->
     null model -> association -- stopped at n = 1 008 (BXD, issue188); at size the oracle was handed the device's (U, eval).  Here the whole
     chain runs twice from the same .bed bytes at n = 4 096 (two-stage eigensolver forced), n = 5 003 (odd: embedded; one-stage) and
@@ -327,7 +327,8 @@ def test_whole_chain_against_the_reference_built_here(gpu_api, oracle, monkeypat
         (oracle/_ref/libgemma_ref.so = /root/reference/src compiled unchanged), centring and null model through the pinned restatement;
       device side: gemma_hip_kin_* -> center -> eigh -> calc_utx -> lmm_null -> lmm_batch through the C ABI.
     The two eigenbases differ (any orthonormal basis of a cluster is as good as another), the statistics must not: beta, se, logl, p within
-    1e-6 on every SNP, lambda-hat by the two-tier criterion."""
+    1e-6 on every SNP, lambda-hat by the two-tier criterion.  The n = 5 003 case is BASELINE config 2's analysis (-lmm 4: Wald + LRT + score)
+    with three covariates."""
     import torch
     import bench
     from oracle import oracle as O
@@ -349,14 +350,16 @@ def test_whole_chain_against_the_reference_built_here(gpu_api, oracle, monkeypat
     rng = np.random.default_rng(n)
     Xc = O.impute_mean(O.bed_decode(test_raw[:20], n))
     y = Xc.T @ (rng.standard_normal(20) * 0.2) + rng.standard_normal(n)
-    W = np.ones((n, 1))
+    W = np.ones((n, 1)) if c == 1 else np.hstack([rng.standard_normal((n, c - 1)), np.ones((n, 1))])
+    if c > 1:
+        y = y + W[:, :c - 1] @ rng.standard_normal(c - 1)
     # ---- the reference's chain
     K_ref = O.ref_plink_kin(str(bed), n, pk, 1)
     U_r, ev_r, tr_r = O.ref_eigen_decomp_zeroed(O.center_matrix(K_ref))
     UtW_r, Uty_r = U_r.T @ W, U_r.T @ y
     l_mle_r, logl0_r = O.calc_lambda_null("L", ev_r, UtW_r, Uty_r)
     X_test = O.bed_decode(test_raw, n)
-    ref = O.ref_lmm_analyze(1, U_r, ev_r, UtW_r, Uty_r, X_test, l_mle_null=l_mle_r, logl_mle_H0=logl0_r)
+    ref = O.ref_lmm_analyze(mode, U_r, ev_r, UtW_r, Uty_r, X_test, l_mle_null=l_mle_r, logl_mle_H0=logl0_r)
     # ---- the device's chain, through the C ABI
     K_d = gpu_api.CalcKin(kin_raw, L.GENO_PLINK_2BIT, n, 1)
     assert np.abs(K_d - K_ref).max() <= 1e-13 * np.abs(K_ref).max()
@@ -367,7 +370,7 @@ def test_whole_chain_against_the_reference_built_here(gpu_api, oracle, monkeypat
     UtW_d, Uty_d = gpu_api.CalcUtX(U_d, W), gpu_api.CalcUtX(U_d, y)
     nm = gpu_api.CalcLambdaNull(ev_d, UtW_d, Uty_d, trace_G=tr_d)
     assert nm["l_mle_null"] == pytest.approx(l_mle_r, rel=1e-6) and nm["logl_mle_H0"] == pytest.approx(logl0_r, rel=1e-9)
-    lmm = gpu_api.LMM(a_mode=1, l_mle_null=nm["l_mle_null"], logl_mle_H0=nm["logl_mle_H0"])
+    lmm = gpu_api.LMM(a_mode=mode, l_mle_null=nm["l_mle_null"], logl_mle_H0=nm["logl_mle_H0"])
     got = lmm.AnalyzePlink(U_d, ev_d, UtW_d, Uty_d, test_raw, np.ones(n, dtype=np.int32))
-    _cmp_stats(got, ref, 1, "whole chain vs the reference's own PlinkKin + dsyevr + LMM::Analyze, n=%d" % n,
+    _cmp_stats(got, ref, mode, "whole chain vs the reference's own PlinkKin + dsyevr + LMM::Analyze, n=%d c=%d" % (n, c),
                _problem(U_r, ev_r, UtW_r, Uty_r, X_test))
