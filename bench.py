@@ -53,6 +53,10 @@ def parse():
     ap.add_argument("--miss-leg", type=float, default=0.05,
                     help="extra untimed-region steps at this missing-call rate (GEMMA's default -miss ceiling is 0.05): every row then "
                          "has groups of four with 3-4 missing calls, which the sparse mask operand hands to the fp64 fix-up (0 = skip)")
+    ap.add_argument("--complete-steps", type=int, default=4,
+                    help="extra untimed-region steps on blocks WITHOUT a missing call (hard calls of an imputed panel): the library "
+                         "notices on the device and takes the genotype product alone (include/gemma_hip.h: "
+                         "gemma_hip_dbg_last_block_missing); 0 = skip")
     ap.add_argument("--lowh2-leg", type=float, default=3e-4,
                     help="extra untimed-region steps on a second phenotype whose variance ratio lambda is this value (next to no "
                          "heritability: lambda-hat in the decades below 1e-3, the common case in human GWAS) -- the per-SNP stage must "
@@ -334,6 +338,7 @@ def apply_config(args, world):
     args.warmup = min(args.warmup, 1)
     args.fp64_steps = args.dosage_steps = args.digits7_steps = 0
     args.miss_leg = args.lowh2_leg = 0.0
+    args.complete_steps = 0
     args.e2e_snps = 0
     args.c4_leg = 0
     args.cpu_setup = 0
@@ -864,6 +869,40 @@ def main():
                     "nan_p_wald": int(np.isnan(out.cpu().numpy()[:, 4]).sum())}
         del mb
 
+    # blocks without a missing call: the mask product is identically zero and the library drops it (device-side choice between the two
+    # forms of the records kernel, same bits); outside the timed region, single GPU only.  NOT the headline: `value` keeps 1 % missing.
+    complete_leg = None
+    if world == 1 and i8_path and args.complete_steps > 0:
+        ks = args.complete_steps
+        cb = [synth_block(torch, n, B, gen, dev, miss=0.0) for _ in range(2)]
+        lmm.batch(cb[0], L.GENO_PLINK_2BIT, out=out)
+        flag = api.last_block_missing()
+        torch.cuda.synchronize()
+        for st in range(L.STAGE_UTX_POST + 1):
+            api.profile_read(st, reset=True)
+        t1 = time.perf_counter()
+        for i in range(ks):
+            lmm.batch(cb[i % 2], L.GENO_PLINK_2BIT, out=out)
+        torch.cuda.synchronize()
+        elc = time.perf_counter() - t1
+        got_c = out.cpu().numpy().copy()
+        complete_leg = {"input": "the same synthetic PLINK blocks with no missing call (miss = 0)", "steps": ks,
+                        "any_missing_flag": flag, "ms_per_step": round(elc / ks * 1e3, 3), "value": round(B * ks / elc, 1), "unit": "SNPs/s",
+                        "ratio_to_timed_step": round(elc / ks / (elapsed / args.steps), 4),
+                        "stage_ms_per_step": {"ingest": round(api.profile_read(L.STAGE_INGEST)[0] / ks, 3),
+                                              "utx_gemm (genotype product alone)": round(api.profile_read(L.STAGE_UTX_GEMM)[0] / ks, 3),
+                                              "utx_post": round(api.profile_read(L.STAGE_UTX_POST)[0] / ks, 3),
+                                              "assoc": round(api.profile_read(L.STAGE_ASSOC)[0] / ks, 3)}}
+        # the same block through both products (GEMMA_HIP_I8_COMPLETE=0): must be the same records, bit for bit
+        os.environ["GEMMA_HIP_I8_COMPLETE"] = "0"
+        api.reload_env()
+        lmm.batch(cb[(ks - 1) % 2], L.GENO_PLINK_2BIT, out=out)
+        torch.cuda.synchronize()
+        complete_leg["records_bit_equal_to_both_products"] = bool(out.cpu().numpy().tobytes() == got_c.tobytes())
+        del os.environ["GEMMA_HIP_I8_COMPLETE"]
+        api.reload_env()
+        del cb
+
     # fixed-point dosages (BIMBAM mean genotypes, doc/manual.tex:398-404) as fp64 input: int8-digit dosage planes, then the
     # fp64 MFMA GEMM on the same block as the check; outside the timed region, single GPU only
     dosage_path = None
@@ -1071,6 +1110,8 @@ def main():
             line["dosage_path"] = dosage_path
         if miss_leg:
             line["miss_leg"] = miss_leg
+        if complete_leg:
+            line["complete_leg"] = complete_leg
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc):
             try:

@@ -23,7 +23,7 @@ SYMBOLS = [
     "gemma_hip_kept_bcast", "gemma_hip_kept_U_get", "gemma_hip_calc_utx_kept", "gemma_hip_lmm_setup_kept", "gemma_hip_kept_release",
     "gemma_hip_comm_unique_id", "gemma_hip_comm_init", "gemma_hip_comm_info", "gemma_hip_comm_bcast_d",
     "gemma_hip_comm_allreduce_sum_d", "gemma_hip_comm_finalize", "gemma_hip_comm_selftest", "gemma_hip_comm_stats", "gemma_hip_dbg_i8_digits", "gemma_hip_dbg_last_utx_path", "gemma_hip_lmm_batch_submit", "gemma_hip_lmm_batch_collect",
-    "gemma_hip_dbg_last_utx_kernel", "gemma_hip_reload_env", "gemma_hip_lmm_batch_pipe_d", "gemma_hip_lmm_pipe_flush",
+    "gemma_hip_dbg_last_utx_kernel", "gemma_hip_dbg_last_block_missing", "gemma_hip_reload_env", "gemma_hip_lmm_batch_pipe_d", "gemma_hip_lmm_pipe_flush",
 ]
 COMM_ID_BYTES = 128
 
@@ -166,6 +166,7 @@ def lib():
     L.gemma_hip_dbg_i8_digits.argtypes = [sz, C.POINTER(ci)]
     L.gemma_hip_dbg_last_utx_path.argtypes = [C.POINTER(ci)]
     L.gemma_hip_dbg_last_utx_kernel.argtypes = [C.POINTER(UtxKernelInfo)]
+    L.gemma_hip_dbg_last_block_missing.argtypes = [C.POINTER(ci)]
     L.gemma_hip_reload_env.argtypes = []
     L.gemma_hip_lmm_batch_pipe_d.argtypes = [ci, vp, sz, sz, vp, vp]
     L.gemma_hip_lmm_pipe_flush.argtypes = [vp]

@@ -101,6 +101,14 @@ def last_utx_kernel():
             "launches": k.launches, "name": k.name.decode()}
 
 
+def last_block_missing():
+    """gemma_hip_dbg_last_block_missing: 1 / 0 = the last records product's block held / did not hold a missing call (a block without
+    one takes the genotype product alone); -1 = the complete-block form is off or no such product ran."""
+    a = C.c_int()
+    L.check(L.lib().gemma_hip_dbg_last_block_missing(C.byref(a)), "dbg_last_block_missing")
+    return a.value
+
+
 def reload_env():
     """Have the library re-read its GEMMA_HIP_* switches (it reads them once per setup, never per launch)."""
     L.check(L.lib().gemma_hip_reload_env(), "reload_env")

@@ -390,6 +390,18 @@ extern "C" int gemma_hip_dbg_last_utx_kernel(gemma_utx_kernel_info *info) {
   return GEMMA_HIP_OK;
 }
 
+// the any-missing flag sparse2_meta_kernel left for the last records product of a plain (not pipelined) batch: 1 / 0, -1 when the
+// complete-block form is off or no such product ran.  Synchronises the device.
+extern "C" int gemma_hip_dbg_last_block_missing(int *any) {
+  NEED_INIT();
+  if (!any) return fail(GEMMA_HIP_EINVAL, "dbg_last_block_missing: null");
+  *any = -1;
+  if (g_ctx.i8_flag_at < 0 || !g_ctx.i8_rowsur.p) return GEMMA_HIP_OK;
+  HIPCHK(hipDeviceSynchronize());
+  HIPCHK(hipMemcpy(any, g_ctx.i8_rowsur.as<int>() + g_ctx.i8_flag_at, sizeof(int), hipMemcpyDeviceToHost));
+  return GEMMA_HIP_OK;
+}
+
 extern "C" int gemma_hip_reload_env(void) {
   const int digits0 = i8_digits_for(g_ctx.cfg.n), scale0 = g_ctx.knobs.i8_scale_max;
   g_ctx.knobs.load();

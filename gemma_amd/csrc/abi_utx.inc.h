@@ -7,7 +7,10 @@ struct I8Dims {
   size_t n, ldk, npad, lpad, mrows;
   int fuse, digits, nplanes;
   int mdrop; // 1: the 7g6m form -- plane 0 (digit 0 alone) carries the genotype product only
+  int complete; // 1: sparse2_meta_kernel flags the block's missing calls (the int after the row counters) and a block without one
+                // takes the genotype product alone (Sparse2Args::anymiss): same planes, same U^T x, bit for bit
 };
+static const int *i8_anymiss(const I8Dims &d) { return d.complete ? g_ctx.i8_rowsur.as<int>() + d.lpad : nullptr; }
 // GEMMA_HIP_I8_SPARSE: 0 = the mask product on dense MFMAs (i8gemm_packed_kernel_t), 1 = on the 2:4 sparse MFMA with byte-wise
 // genotypes and separate mask words (i8gemm_sparse.hip.h), 2 (default) = sparse MFMA, left factor as 16-byte records of 2-bit
 // genotypes + mask words, 256 x 128 tiles (i8gemm_sparse2.hip.h)
@@ -23,6 +26,7 @@ static int i8_begin(size_t l, I8Dims *d, hipStream_t s) {
   d->nplanes = d->fuse ? (d->digits + 1) / 2 : d->digits;
   // the 7g6m form needs plane 0 to be digit 0 alone (odd count, fused planes) and the 16-row records kernel
   d->mdrop = (g_ctx.knobs.i8_mdrop && d->fuse && d->digits == 7 && i8_sparse_mode() == 2 && g_ctx.knobs.i8_rows == 16) ? 1 : 0;
+  d->complete = (g_ctx.knobs.i8_complete && i8_sparse_mode() == 2 && g_ctx.knobs.i8_rows == 16) ? 1 : 0;
   const size_t c_elems = (size_t)d->nplanes * d->mrows * d->npad;
   if (g_ctx.i8_A.reserve(d->lpad * d->ldk) || g_ctx.i8_C.reserve(c_elems * 4) || g_ctx.i8_mean.reserve(l * 8))
     return fail(GEMMA_HIP_ENOMEM, "lmm_batch: int8 product buffers (%zu bytes)", d->lpad * d->ldk + c_elems * 4);
@@ -37,16 +41,18 @@ static int i8_meta_build(const I8Dims &d, hipStream_t s) {
   if (mode == 0) return GEMMA_HIP_OK;
   ProfScope ps(GEMMA_STAGE_INGEST, s);
   const size_t nk = d.ldk / I8_BK, total = d.lpad * nk * (mode == 2 ? 4 : 2);
-  if (g_ctx.i8_meta.reserve(total * sizeof(uint4)) || g_ctx.i8_rowsur.reserve(d.lpad * sizeof(int)))
+  if (g_ctx.i8_meta.reserve(total * sizeof(uint4)) || g_ctx.i8_rowsur.reserve((d.lpad + 1) * sizeof(int)))
     return fail(GEMMA_HIP_ENOMEM, "lmm_batch: mask words of the sparse product");
-  HIPCHK(hipMemsetAsync(g_ctx.i8_rowsur.p, 0, d.lpad * sizeof(int), s));
+  HIPCHK(hipMemsetAsync(g_ctx.i8_rowsur.p, 0, (d.lpad + 1) * sizeof(int), s)); // dropped calls per row, then the block's any-missing flag
   if (mode == 2)
     hipLaunchKernelGGL(sparse2_meta_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, g_ctx.i8_A.as<int8_t>(),
-                       (long)d.lpad, (long)d.ldk, g_ctx.i8_meta.as<uint4>(), g_ctx.i8_rowsur.as<int>());
+                       (long)d.lpad, (long)d.ldk, g_ctx.i8_meta.as<uint4>(), g_ctx.i8_rowsur.as<int>(),
+                       const_cast<int *>(i8_anymiss(d)));
   else
     hipLaunchKernelGGL(sparse_meta_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, g_ctx.i8_A.as<int8_t>(),
                        (long)d.lpad, (long)d.ldk, g_ctx.i8_meta.as<uint4>(), g_ctx.i8_rowsur.as<int>());
   HIPCHK(hipGetLastError());
+  g_ctx.i8_flag_at = (mode == 2 && d.complete) ? (long)d.lpad : -1;
   return GEMMA_HIP_OK;
 }
 
@@ -143,16 +149,21 @@ static int i8_gemm_rows(const I8Dims &d, size_t row0, size_t rows_pad, hipStream
     if (g_ctx.knobs.i8_rows == 32) {
       hipLaunchKernelGGL(i8gemm_sparse2_kernel, dim3((unsigned)(g2.tiles_m * g2.tiles_n), (unsigned)d.nplanes), dim3(512),
                          S2_NST * S2_STAGE, s, g2);
-    } else if (d.mdrop) {
-      // 7g6m: planes 1..3 (digit pairs {2,1} {4,3} {6,5}) with both products, then plane 0 (digit 0) with the genotype product alone
-      g2.plane0 = 1;
-      hipLaunchKernelGGL(i8gemm_sparse2_r16_kernel, dim3((unsigned)(g2.tiles_m * g2.tiles_n), (unsigned)(d.nplanes - 1)), dim3(512),
-                         S2_R16_LDS, s, g2);
-      g2.plane0 = 0;
-      hipLaunchKernelGGL(i8gemm_sparse2_r16_g_kernel, dim3((unsigned)(g2.tiles_m * g2.tiles_n), 1u), dim3(512), S2_R16_LDS, s, g2);
     } else {
-      hipLaunchKernelGGL(i8gemm_sparse2_r16_kernel, dim3((unsigned)(g2.tiles_m * g2.tiles_n), (unsigned)d.nplanes), dim3(512),
-                         S2_R16_LDS, s, g2);
+      // 7g6m: planes 1..3 (digit pairs {2,1} {4,3} {6,5}) with both products, then plane 0 (digit 0) with the genotype product alone
+      const unsigned wgs = (unsigned)(g2.tiles_m * g2.tiles_n), first = d.mdrop ? 1u : 0u;
+      g2.anymiss = i8_anymiss(d);
+      g2.plane0 = (int)first;
+      g2.run_if = g2.anymiss ? 1 : 0; // both products: always, or (complete-block form) only when the block has a missing call
+      hipLaunchKernelGGL(i8gemm_sparse2_r16_kernel, dim3(wgs, (unsigned)d.nplanes - first), dim3(512), S2_R16_LDS, s, g2);
+      if (g2.anymiss) { // the same planes from the genotype product alone when it has none (the other launch returned at once)
+        g2.run_if = 2;
+        hipLaunchKernelGGL(i8gemm_sparse2_r16_g_kernel, dim3(wgs, (unsigned)d.nplanes - first), dim3(512), S2_R16_LDS, s, g2);
+      }
+      if (d.mdrop) {
+        g2.plane0 = 0; g2.run_if = 0;
+        hipLaunchKernelGGL(i8gemm_sparse2_r16_g_kernel, dim3(wgs, 1u), dim3(512), S2_R16_LDS, s, g2);
+      }
     }
   } else if (sparse) {
     static bool attr2 = false;
@@ -196,7 +207,7 @@ static int i8_post_rows(size_t l, const I8Dims &d, size_t row0, size_t rows, dou
                      dim3(256), 0, s,
                      g_ctx.i8_C.as<int>() + row0 * d.npad, (long)d.npad, (long)(d.mrows * d.npad), (long)d.lpad,
                      g_ctx.i8_mean.as<double>() + row0, g_ctx.i8_qinv.as<double>(), (long)rows, (long)d.n, UtX + row0 * ldx, (long)ldx,
-                     1.0, d.fuse, d.digits, sur_cnt, sur_list, g_ctx.U, (long)d.n, d.mdrop);
+                     1.0, d.fuse, d.digits, sur_cnt, sur_list, g_ctx.U, (long)d.n, d.mdrop, i8_anymiss(d));
   HIPCHK(hipGetLastError());
   if (sparse) {
     hipLaunchKernelGGL(i8_surplus_fix_kernel, dim3((unsigned)rows), dim3(256), 0, s, Arow, (long)d.ldk,

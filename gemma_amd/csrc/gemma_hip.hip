@@ -75,6 +75,7 @@ struct Knobs {
   int i8_rows = 16;        // GEMMA_HIP_I8_ROWS: 32 = the records kernel on the 32-row matrix instructions
   int i8_scale_max = 1;    // GEMMA_HIP_I8_SCALE: "pow2" = columns of U scaled by a power of two (rounds 1-5); default: by their exact maximum
   int i8_mdrop = 0;        // GEMMA_HIP_I8_FORM=7g6m: seven digits for the genotype product, the mask product on the upper six
+  int i8_complete = 1;     // GEMMA_HIP_I8_COMPLETE: 0 = blocks without a missing call take the mask product like any other block
   int dosage_i8 = 1;       // GEMMA_HIP_UTX_DOSAGE_I8
   int dosage_rows = 16;    // GEMMA_HIP_DOSAGE_ROWS: 32 = the dosage planes on the 32-row dense kernel (rounds 3-4)
   int overlap = 0;         // GEMMA_HIP_OVERLAP
@@ -107,6 +108,8 @@ struct Knobs {
     const char *efm = getenv("GEMMA_HIP_I8_FORM");
     i8_mdrop = (efm && strcmp(efm, "7g6m") == 0) ? 1 : 0;
     if (i8_mdrop) i8_digits = 7;
+    const char *ecp = getenv("GEMMA_HIP_I8_COMPLETE");
+    i8_complete = (ecp && ecp[0] == '0') ? 0 : 1;
     const char *ed = getenv("GEMMA_HIP_UTX_DOSAGE_I8");
     dosage_i8 = (ed && ed[0] == '0') ? 0 : 1;
     dosage_rows = geti("GEMMA_HIP_DOSAGE_ROWS", 16) == 32 ? 32 : 16;
@@ -216,6 +219,7 @@ struct Ctx {
   bool i8_colsum_ready = false;
   int last_utx_path = 0;       // what the last U^T x took: 0 fp64 GEMM, 1 int8 hard calls, 2 int8 dosages k/100, 3 int8 dosages k/1000
   gemma_utx_kernel_info last_utx_kernel = {}; // the matrix kernel that product launched (gemma_hip_dbg_last_utx_kernel)
+  long i8_flag_at = -1;                       // int index of the any-missing flag of the last records product in i8_rowsur (-1: none)
   bool i8_ready = false;
   size_t i8_ldk = 0, i8_npad = 0;
   int i8_digits = I8_DIGITS;

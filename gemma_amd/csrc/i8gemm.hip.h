@@ -622,9 +622,12 @@ __global__ __launch_bounds__(256) void i8_combine_kernel(const int *__restrict__
                                                          const int *__restrict__ sur_cnt = nullptr,
                                                          const int *__restrict__ sur_list = nullptr,
                                                          const double *__restrict__ U = nullptr, long ldu = 0,
-                                                         int m_skip0 = 0 /* 1: plane 0 carries no mask product (7g6m) */) {
+                                                         int m_skip0 = 0 /* 1: plane 0 carries no mask product (7g6m) */,
+                                                         const int *__restrict__ anymiss = nullptr /* Sparse2Args::anymiss: 0 = no
+                                                         plane of this block carries one (their M rows were not written) */) {
   const long j = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
   if (j >= n) return;
+  const bool no_mask = anymiss != nullptr && *anymiss == 0; // uniform; a mask product of zeros adds +0.0: the same doubles
   const int nplanes = fuse ? (digits + 1) / 2 : digits;
   const int odd = digits & 1;
   const int nv = (n - j < 4) ? (int)(n - j) : 4; // columns of this thread inside the row (the planes are padded past n)
@@ -637,7 +640,7 @@ __global__ __launch_bounds__(256) void i8_combine_kernel(const int *__restrict__
       // fused: plane q sits two digits above plane q - 1, except that an odd count leaves plane 0 one digit wide
       const double w = fuse ? ((q == 0 && odd) ? 256.0 : 65536.0) : 256.0;
       const int4 cg = *reinterpret_cast<const int4 *>(C + (long)q * strideC + s * ldc + j);
-      const int4 cm = (m_skip0 && q == 0) ? make_int4(0, 0, 0, 0)
+      const int4 cm = (no_mask || (m_skip0 && q == 0)) ? make_int4(0, 0, 0, 0)
                                           : *reinterpret_cast<const int4 *>(C + (long)q * strideC + (m_row0 + s) * ldc + j);
       const int g4[4] = {cg.x, cg.y, cg.z, cg.w}, m4[4] = {cm.x, cm.y, cm.z, cm.w};
 #pragma unroll

@@ -48,6 +48,12 @@ struct Sparse2Args {
   int plane0 = 0; // first plane of this launch (i8gemm_sparse2_r16.hip.h: the 7g6m form launches plane 0 and planes 1.. separately)
   const int2 *tile_map = nullptr; // (tile_m, tile_n) of workgroup blockIdx.x: the cross-XCD raster of s2_build_raster; nullptr:
                                   // the per-XCD ranges of round 3 (every XCD sweeps its own tile rows)
+  // Blocks without a missing call (round 6): sparse2_meta_kernel leaves *anymiss = 0 for them and the mask product is identically
+  // zero.  The launch site then queues BOTH forms of the 16-row kernel and each one returns at once unless the flag is its own
+  // (run_if 1: only when *anymiss != 0, 2: only when *anymiss == 0, 0: always) -- the choice is made on the device, so the
+  // asynchronous pipeline needs no read-back, and neither K loop changes.
+  const int *anymiss = nullptr;
+  int run_if = 0;
 };
 // Tried in round 4 and dropped: one digit fewer for the MASK product (the mask product sums only the row's missing calls, so
 // five digits keep its worst-case error at the level of the six-digit genotype product: -1/18 of the matrix instructions).  The
@@ -59,7 +65,8 @@ struct Sparse2Args {
 
 // packed bytes g | m << 4 (lpad x ldk, lpad a multiple of 256) -> records; one thread per (row, K-tile, chunk)
 __global__ __launch_bounds__(256) void sparse2_meta_kernel(const int8_t *__restrict__ A, long lpad, long ldk,
-                                                           uint4 *__restrict__ AM, int *__restrict__ row_surplus) {
+                                                           uint4 *__restrict__ AM, int *__restrict__ row_surplus,
+                                                           int *anymiss = nullptr /* set to 1 when the block holds a missing call */) {
   const long nk = ldk / I8_BK;
   const long id = (long)blockIdx.x * 256 + threadIdx.x;
   if (id >= lpad * nk * 4) return;
@@ -100,6 +107,8 @@ __global__ __launch_bounds__(256) void sparse2_meta_kernel(const int8_t *__restr
     w[2] = idx;
     w[3] = bits;
     if (surplus) atomicAdd(row_surplus + row, surplus);
+    // every writer stores the same value (a wavefront's lanes coalesce into one write), and only while the flag still reads 0
+    if (anymiss && bits != 0 && *reinterpret_cast<volatile int *>(anymiss) == 0) *reinterpret_cast<volatile int *>(anymiss) = 1;
   }
   AM[id] = make_uint4(w[0], w[1], w[2], w[3]);
 }

@@ -55,6 +55,10 @@ template <bool WITH_S>
 __device__ __forceinline__ void s2_r16_body(const Sparse2Args &g) {
   extern __shared__ __attribute__((aligned(1024))) int8_t i8lds[];
   constexpr bool NO_S = !WITH_S || S2_R16_ABL_NO_S;
+  if (g.run_if) { // Sparse2Args::anymiss: the form that is not this block's returns before it touches anything
+    const int any = __builtin_amdgcn_readfirstlane(*g.anymiss);
+    if ((g.run_if == 1) != (any != 0)) return;
+  }
   int tm, tn;
   if (g.tile_map) {
     const int2 t2 = g.tile_map[blockIdx.x];

@@ -405,6 +405,13 @@ typedef struct {
   char name[64];
 } gemma_utx_kernel_info;
 int gemma_hip_dbg_last_utx_kernel(gemma_utx_kernel_info *info);
+/* Blocks WITHOUT a missing call (round 6).  With x = g + mean * m the mask product U^T (mean * m) is identically zero for them; the
+ * records path notices on the device -- the kernel that builds the records sets a flag when it meets a missing call -- and the launch
+ * site queues both forms of the 16-row kernel, of which the one that is not the block's returns at once: complete blocks take the
+ * genotype product alone (i8gemm_sparse2_r16_g_kernel) and the digit combine reads no mask rows.  U^T x is the same, bit for bit (a
+ * mask product of zeros adds +0.0); GEMMA_HIP_I8_COMPLETE=0 sends every block through both products.  *any: that flag for the last
+ * records product of a plain batch (1 / 0; -1: form off or no such product yet).  Synchronises the device. */
+int gemma_hip_dbg_last_block_missing(int *any);
 /* re-read the GEMMA_HIP_* switches of the batch path.  The library reads them once per setup (gemma_hip_init, lmm_setup*, lm_setup,
  * mvlmm_null / mvlmm_set, kin_begin), never per launch; a caller that changes one between two batches of ONE setup calls this. */
 int gemma_hip_reload_env(void);

@@ -1425,6 +1425,70 @@ def test_strict_form_7g6m_statistics(gpu_api, oracle, monkeypatch, ni_total, p, 
     assert d.max() > 0 and np.max(d / scale) < 2.0 ** -40
 
 
+@pytest.mark.parametrize("ni_total,p,form", [(1333, 700, ""), (2600, 515, ""), (900, 300, "7g6m")])
+def test_complete_blocks_take_the_genotype_product_alone(gpu_api, oracle, monkeypatch, ni_total, p, form):
+    """Round 6: a block WITHOUT a missing call among the analysed individuals has an identically zero mask product.  The kernel that
+    builds the records flags missing calls on the device, the launch site queues both forms of the 16-row kernel and the one that is
+    not the block's returns at once; the digit combine then reads no mask rows.  U^T x and the statistics must be the SAME BITS as with
+    GEMMA_HIP_I8_COMPLETE=0 (every block through both products) -- for a complete block, for the same block with ONE missing call put
+    in (flag 1), with dropped individuals carrying the only missing calls (flag 0: they are not analysed), and through the pipelined
+    entry point."""
+    import torch
+    from gemma_amd import _lib as L
+    rng = np.random.default_rng(ni_total * 3 + p)
+    ind, raw0 = _plink_case(oracle, rng, ni_total, p, drop=0.15, miss=0.0)
+    n = int(ind.sum())
+    assert not np.isnan(oracle.bed_decode(raw0, ni_total)).any()
+    kept, dropped = np.flatnonzero(ind == 1), np.flatnonzero(ind == 0)
+
+    def with_missing(raw, s, i):  # PLINK code 01 = missing at (SNP s, individual i)
+        r = raw.copy()
+        r[s, i // 4] = (r[s, i // 4] & ~np.uint8(3 << (2 * (i % 4)))) | np.uint8(1 << (2 * (i % 4)))
+        return r
+    cases = {"complete": (raw0, 0), "one missing call": (with_missing(raw0, p // 2, int(kept[7])), 1),
+             "missing only where dropped": (with_missing(with_missing(raw0, 3, int(dropped[0])), p - 1, int(dropped[-1])), 0)}
+    Kg = oracle.bed_decode(raw0, ni_total)[:, ind == 1]
+    U, ev, _ = oracle.eigen_decomp_zeroed(oracle.center_matrix(oracle.calc_kin(Kg, 1)))
+    y = rng.standard_normal(n)
+    UtW, Uty = U.T @ np.ones((n, 1)), U.T @ y
+    if form:
+        monkeypatch.setenv("GEMMA_HIP_I8_FORM", form)
+    res = {}
+    for knob in ("1", "0"):
+        monkeypatch.setenv("GEMMA_HIP_I8_COMPLETE", knob)
+        lmm = gpu_api.LMM(a_mode=1)
+        lmm.setup(U, ev, UtW, Uty, plink=True)
+        lmm.set_indicator(ind)
+        try:
+            for name, (raw, flag) in cases.items():
+                utx = lmm.dbg_utx(raw, L.GENO_PLINK_2BIT, 1)
+                assert gpu_api.last_block_missing() == (flag if knob == "1" else -1), (name, knob)
+                stats = np.array(lmm.batch(raw, L.GENO_PLINK_2BIT))
+                assert gpu_api.last_utx_kernel()["variant"] == L.UTX_KERNEL_RECORDS_R16
+                res[name, knob] = (utx, stats)
+            if knob == "1":  # the pipelined entry point: two complete blocks, then one with a missing call, then a complete one
+                dev = torch.device("cuda", 0)
+                seq = ["complete", "complete", "one missing call", "complete"]
+                blocks = [torch.from_numpy(cases[k][0]).to(dev) for k in seq]
+                outs = [torch.zeros((p, 8), dtype=torch.float64, device=dev) for _ in seq]
+                for b, o in zip(blocks, outs):
+                    lmm.batch_pipe(b, L.GENO_PLINK_2BIT, o)
+                lmm.pipe_flush()
+                torch.cuda.synchronize()
+                for k, o in zip(seq, outs):
+                    assert o.cpu().numpy().tobytes() == res[k, "1"][1].tobytes(), k
+        finally:
+            lmm.finish()
+    for name in cases:
+        assert res[name, "1"][0].tobytes() == res[name, "0"][0].tobytes(), name
+        assert res[name, "1"][1].tobytes() == res[name, "0"][1].tobytes(), name
+    # and the complete block against the exact product
+    Xn = oracle.bed_decode(raw0, ni_total, ind)
+    exact = (Xn.astype(np.longdouble) @ U.astype(np.longdouble)).astype(np.float64)
+    scale = np.abs(Xn) @ np.abs(U)
+    assert np.max(np.abs(res["complete", "1"][0] - exact) / scale) < 1e-13
+
+
 def test_lmm_pipe_on_a_side_stream_with_two_staging_buffers(gpu_api, oracle, monkeypatch):
     """include/gemma_hip.h lets a caller overwrite the genotype buffer of block i with work queued on ITS stream
     after the call for block i + 1 -- a double-buffering feeder.  On a non-default stream nothing used to order that overwrite behind
