@@ -62,7 +62,7 @@ def test_tridiagonalisation_stage(gpu_api, n):
     T = np.diag(d) + np.diag(e[: n - 1], 1) + np.diag(e[: n - 1], -1)
     Q = np.eye(n)
     for j in range(n):  # Q = H_0 H_1 ...
-        Q = Q @ (np.eye(n) - tau[j] * np.outer(VT[j], VT[j]))
+        Q -= tau[j] * np.outer(Q @ VT[j], VT[j])  # Q (I - tau v v^T) as a rank-1 update
     nrm = np.linalg.norm(A, 2)
     assert np.linalg.norm(Q.T @ Q - np.eye(n)) < 50 * n * EPS
     assert np.linalg.norm(Q @ T @ Q.T - A) / nrm < 50 * n * EPS
@@ -87,7 +87,7 @@ def test_symmetric_symv_path(gpu_api, n, seg, monkeypatch):
     if n <= 1100:
         Q = np.eye(n)
         for j in range(n):
-            Q = Q @ (np.eye(n) - tau[j] * np.outer(VT[j], VT[j]))
+            Q -= tau[j] * np.outer(Q @ VT[j], VT[j])  # Q (I - tau v v^T) as a rank-1 update
         assert np.linalg.norm(Q.T @ Q - np.eye(n)) < 50 * n * EPS
         assert np.linalg.norm(Q @ T @ Q.T - A) / nrm < 50 * n * EPS
 
