@@ -3,7 +3,7 @@
 # FETCH_SIZE and WRITE_SIZE do not fit one pass), restricted to the kernels of the timed region by name so that the
 # eigensolver's ~80 000 setup launches are not instrumented.  Usage (GPU box): scripts/pmc_bench.sh <outdir> [bench args]
 OUT=${1:-gpurun_out/pmc_r04}; shift
-ARGS=${@:---steps 2 --warmup 1 --cpu-sample 0 --fp64-steps 0 --dosage-steps 0 --miss-leg 0 --lowh2-leg 0 --digits7-steps 0 --setup-parity 0 --c4-leg 0 --e2e-snps 0 --kin-snps 20000 --state-file /tmp/bench_state.pt}
+ARGS=${@:---steps 2 --warmup 1 --cpu-sample 0 --fp64-steps 0 --dosage-steps 0 --miss-leg 0 --lowh2-leg 0 --digits7-steps 0 --setup-parity 0 --c4-leg 0 --e2e-snps 0 --complete-steps 0 --kin-snps 20000 --state-file /tmp/bench_state.pt}
 RX='i8gemm_sparse2|sparse2_meta|i8gemm_packed|i8_combine|i8_surplus|table_v2|table_reduce|lmm_assoc1|cheb_scan|cheb_search|ingest_i8'
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 mkdir -p "$OUT"
