@@ -828,7 +828,8 @@ static inline hipError_t launch_dgemm(char ta, char tb, long M, long N, long K, 
                                       double beta, double *C, long ldc, bool syrk_upper,
                                       bool square_a, hipStream_t s, bool mirror = false) {
   GemmArgs g;
-  g.mirror = (mirror && syrk_upper && M == N) ? 1 : 0;
+  g.mirror = (mirror && (syrk_upper ? M == N : M <= N)) ? 1 : 0; // without syrk_upper: a row strip of such an update (tiles (0, j) of C: the
+                                                                 // eigensolver's look-ahead); every tile off the diagonal is also written transposed
   g.A = A; g.B = B; g.C = C;
   g.M = M; g.N = N; g.K = K;
   g.lda = lda; g.ldb = ldb; g.ldc = ldc;

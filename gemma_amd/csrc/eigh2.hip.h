@@ -1396,9 +1396,9 @@ static inline int eig2_sy2sb(double *A, long n, EigWs &ws, Eig2Ws &w2, hipStream
   if (persist) EIG_HIP(hipMemsetAsync(w2.pbar, 0, 4 * sizeof(int), s));
   const char *emi = getenv("GEMMA_HIP_EIGH_MIRROR");
   const bool fused_mirror = !(emi && emi[0] == 'p');
-  for (long j0 = 0;; j0 += E2_B) {
+  // the Householder QR of one panel (columns j0 .. j0 + 127 below the band) on stream ps; nonzero: a HIP error
+  auto factor_panel = [&](long j0, hipStream_t ps) -> int {
     const long r0 = j0 + E2_B, m = n - r0;
-    if (m < 2) break;
     const int kk = (int)std::min<long>(E2_B, m - 1);
     bool done = false;
     if (persist) {
@@ -1407,14 +1407,14 @@ static inline int eig2_sy2sb(double *A, long n, EigWs &ws, Eig2Ws &w2, hipStream
       // dense -> band 4.82 s against 4.72 s; wider panels therefore keep the launches.)
       const int nwgp = (int)((m + 127) / 128);
       if (nwgp <= ncu) {
-        EIG_HIP(hipMemsetAsync(w2.ppart, 0xFF, (size_t)kk * nwgp * E2_B * 8, s));
-        EIG_HIP(hipMemsetAsync(w2.pheads, 0xFF, (size_t)kk * E2_B * 8, s));
+        EIG_HIP(hipMemsetAsync(w2.ppart, 0xFF, (size_t)kk * nwgp * E2_B * 8, ps));
+        EIG_HIP(hipMemsetAsync(w2.pheads, 0xFF, (size_t)kk * E2_B * 8, ps));
         SbPersistArgs pp{A, n, j0, kk, nwgp, ws.VT, ws.tau, w2.betas, w2.ppart, w2.pheads, w2.pbar + 1};
-        hipLaunchKernelGGL(sb_panel_persist_kernel<1>, dim3(nwgp), dim3(SP_THREADS), 0, s, pp);
+        hipLaunchKernelGGL(sb_panel_persist_kernel<1>, dim3(nwgp), dim3(SP_THREADS), 0, ps, pp);
         EIG_HIP(hipGetLastError());
         int err = 0;
-        EIG_HIP(hipMemcpyAsync(&err, w2.pbar + 1, sizeof(int), hipMemcpyDeviceToHost, s));
-        EIG_HIP(hipStreamSynchronize(s));
+        EIG_HIP(hipMemcpyAsync(&err, w2.pbar + 1, sizeof(int), hipMemcpyDeviceToHost, ps));
+        EIG_HIP(hipStreamSynchronize(ps));
         if (!err) {
           done = true;
         } else {
@@ -1427,10 +1427,48 @@ static inline int eig2_sy2sb(double *A, long n, EigWs &ws, Eig2Ws &w2, hipStream
       SbPanelArgs pa{A, n, j0, 0, kk, nwg, ws.VT, w2.part, w2.heads, ws.tau, w2.betas};
       for (int c = 0; c <= kk; ++c) {
         pa.c = c;
-        hipLaunchKernelGGL(sb_panel_kernel, dim3(nwg), dim3(256), 0, s, pa);
+        hipLaunchKernelGGL(sb_panel_kernel, dim3(nwg), dim3(256), 0, ps, pa);
       }
       EIG_HIP(hipGetLastError());
     }
+    return 0;
+  };
+  // LOOK-AHEAD (round 6).  Where the panel is wider than 128 x CUs columns its QR is a chain of 129 launches (2.5 ms) during which most
+  // of the chip idles, and the trailing update that precedes it is the stage's largest product.  There the update is issued in two
+  // pieces -- the first tile row (with its mirror: the next panel's columns), then the rest -- and the NEXT panel is factored on a
+  // second, high-priority stream beside the second piece.  Same tiles, same K order: the reduced matrix is bit-identical either way.
+  // Panels that fit the one-launch kernel are NOT looked ahead: its workgroups poll each other, and on a chip they share with the
+  // update the chain slows down by more than the product hides (measured, profiles/r06_eigh_lookahead.txt: looking ahead at every
+  // panel n = 20 000 loses 0.03 s and n = 33 000 0.06 s; n = 50 000 gains 0.13 s, and 0.19 s with the launches only).
+  // GEMMA_HIP_EIGH_LOOKAHEAD=0: never; =1: at every panel (the bit-identity tests).
+  static hipStream_t la_stream = nullptr;
+  static hipEvent_t la_ready = nullptr, la_done = nullptr;
+  const char *ela = getenv("GEMMA_HIP_EIGH_LOOKAHEAD");
+  const int la_mode = (ela && ela[0] == '0') ? 0 : (ela && ela[0] == '1') ? 1 : 2; // 2: panels on the launch path only
+  bool lookahead = la_mode > 0 && fused_mirror;
+  auto la_streams = [&]() -> bool { // created at the first use
+    if (la_stream) return true;
+    int lo = 0, hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+    if (hipStreamCreateWithPriority(&la_stream, hipStreamNonBlocking, hi) != hipSuccess ||
+        hipEventCreateWithFlags(&la_ready, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&la_done, hipEventDisableTiming) != hipSuccess) {
+      (void)hipGetLastError();
+      la_stream = nullptr;
+      lookahead = false;
+      return false;
+    }
+    return true;
+  };
+  bool have_panel = false; // the panel of this j0 was factored beside the previous update
+  for (long j0 = 0;; j0 += E2_B) {
+    const long r0 = j0 + E2_B, m = n - r0;
+    if (m < 2) break;
+    if (!have_panel) {
+      const int rcp = factor_panel(j0, s);
+      if (rcp) return rcp;
+    }
+    have_panel = false;
     const long p = j0 / E2_B;
     const double *Vr = ws.VT + j0 * n + r0;
     double *A22 = A + r0 * n + r0;
@@ -1483,6 +1521,20 @@ static inline int eig2_sy2sb(double *A, long n, EigWs &ws, Eig2Ws &w2, hipStream
     // round 5: the product's epilogue writes the transposed tiles itself (GemmArgs::mirror) -- the mirror pass was 0.51 s of the
     // 4.56 s of this stage at n = 50 000 (390 launches, a read and a write of half the trailing matrix each);
     // GEMMA_HIP_EIGH_MIRROR=pass restores it
+    const long m2 = m - E2_B; // rows below the next panel's band block
+    if (lookahead && m2 >= 2 && (la_mode == 1 || !persist || (m2 + 127) / 128 > ncu) && la_streams()) {
+      EIG_HIP(launch_dgemm('T', 'N', E2_B, m, 2 * E2_B, -1.0, SA, n, SB, n, 1.0, A22, n, false, false, s, true));
+      EIG_HIP(hipEventRecord(la_ready, s));
+      EIG_HIP(hipStreamWaitEvent(la_stream, la_ready, 0));
+      EIG_HIP(launch_dgemm('T', 'N', m2, m2, 2 * E2_B, -1.0, SA + E2_B, n, SB + E2_B, n, 1.0, A22 + (size_t)E2_B * n + E2_B, n, true, false, s,
+                           true));
+      const int rcp = factor_panel(r0, la_stream);
+      if (rcp) return rcp;
+      EIG_HIP(hipEventRecord(la_done, la_stream));
+      EIG_HIP(hipStreamWaitEvent(s, la_done, 0));
+      have_panel = true;
+      continue;
+    }
     EIG_HIP(launch_dgemm('T', 'N', m, m, 2 * E2_B, -1.0, SA, n, SB, n, 1.0, A22, n, true, false, s, fused_mirror));
     if (!fused_mirror) {
       const unsigned nb32 = (unsigned)((m + 31) / 32);

@@ -427,6 +427,35 @@ def test_stage1_backtransform_panel_groups_agree(gpu_api, n, kind, monkeypatch):
             assert np.abs(np.abs(res[G][0]) - np.abs(res["1"][0])).max() < 1e-9, G
 
 
+@pytest.mark.parametrize("n,kind,panel", [(1538, "kinship", ""), (2307, "random", ""), (1411, "kinship", "launch"), (700, "lowrank", "launch")])
+def test_stage1_lookahead_is_bit_identical(gpu_api, n, kind, panel, monkeypatch):
+    """Round 6: the dense -> band reduction may issue the trailing update in two pieces (first tile row + its mirror, then the rest) and
+    factor the NEXT panel on a second stream beside the second piece (by default only where the panel QR is a chain of launches, i.e.
+    beyond 32 768 rows; GEMMA_HIP_EIGH_LOOKAHEAD=1: at every panel, =0: never).  Same tiles, same K order: eigenvalues and eigenvectors
+    must be the same BITS -- with the one-launch panel kernel and with the per-column launches (GEMMA_HIP_EIGH_PANEL=launch)."""
+    monkeypatch.setenv("GEMMA_HIP_EIGH_STAGES", "2")
+    if panel:
+        monkeypatch.setenv("GEMMA_HIP_EIGH_PANEL", panel)
+    A = _sym(n, 7 * n + 1, kind)
+    res = {}
+    for la in ("1", "0", ""):
+        if la:
+            monkeypatch.setenv("GEMMA_HIP_EIGH_LOOKAHEAD", la)
+        else:
+            monkeypatch.delenv("GEMMA_HIP_EIGH_LOOKAHEAD")
+        U, w = np.zeros((n, n)), np.zeros(n)
+        gpu_api.EigenDecomp_Zeroed(A.copy(), U, w)
+        res[la] = (U, w)
+    for la in ("1", ""):
+        assert res[la][1].tobytes() == res["0"][1].tobytes(), la
+        assert res[la][0].tobytes() == res["0"][0].tobytes(), la
+    nrm = max(np.linalg.norm(A, 2), 1e-300)
+    U, w = res["1"]
+    w_raw = np.where(w == 0.0, np.einsum("ij,ij->j", U, A @ U), w)
+    assert np.linalg.norm(U.T @ U - np.eye(n)) < 50 * n * EPS
+    assert np.linalg.norm(A @ U - U * w_raw[None, :]) / nrm < 50 * n * EPS
+
+
 def test_eigensolver_workspace_pool(gpu_api, monkeypatch):
     """Round 6: gemma_hip_eigh_reserve(n) allocates the solver's workspace ahead of the solve and keeps every later solve's buffers in a
     pool; gemma_hip_eigh_release hands them back.  Same bits with and without the pool, a second solve of the same order allocates
