@@ -200,7 +200,7 @@ extern "C" int gemma_hip_snp_qc(int kind, const void *geno, size_t l, size_t ld,
   if (!invert_small(WtW, c)) return fail(GEMMA_HIP_EINVAL, "snp_qc: W^T W is singular");
   const size_t esz = (kind == GEMMA_GENO_PLINK_2BIT) ? 1 : 8;
   const size_t ncol = QC_NSTAT + n_cvt;
-  DevBuf dG, dM, dW, dO;
+  DevBuf &dG = g_ctx.qc_G, &dM = g_ctx.qc_M, &dW = g_ctx.qc_W, &dO = g_ctx.qc_O; // kept for the next block of the pass
   auto cleanup = [&]() { dG.release(); dM.release(); dW.release(); dO.release(); };
   if (dG.reserve(l * ld * esz) || dM.reserve(n * sizeof(int)) || dW.reserve(Wt.size() * 8) || dO.reserve(l * ncol * 8)) {
     cleanup();
@@ -223,8 +223,10 @@ extern "C" int gemma_hip_snp_qc(int kind, const void *geno, size_t l, size_t ld,
     e = hipGetLastError();
   }
   if (e == hipSuccess) e = hipMemcpy(stats.data(), dO.p, stats.size() * 8, hipMemcpyDeviceToHost);
-  cleanup();
-  if (e != hipSuccess) return fail(GEMMA_HIP_ERUNTIME, "snp_qc: %s", hipGetErrorString(e));
+  if (e != hipSuccess) {
+    cleanup();
+    return fail(GEMMA_HIP_ERUNTIME, "snp_qc: %s", hipGetErrorString(e));
+  }
   QcCfgHost q = {cfg->maf_level, cfg->miss_level, cfg->hwe_level, cfg->r2_level};
   snp_qc_finish(stats.data(), l, (int)n, c, WtW.data(), kind == GEMMA_GENO_PLINK_2BIT, q, indicator_snp, maf, n_miss);
   return GEMMA_HIP_OK;

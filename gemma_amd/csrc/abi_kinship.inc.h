@@ -7,6 +7,8 @@ extern "C" int gemma_hip_kin_begin(size_t n_total, int k_mode) {
   NEED_INIT();
   if (n_total == 0) return fail(GEMMA_HIP_EINVAL, "kin_begin: n_total == 0");
   if (k_mode != 1 && k_mode != 2) return fail(GEMMA_HIP_EINVAL, "kin_begin: k_mode %d", k_mode);
+  g_ctx.qc_G.release(); g_ctx.qc_M.release(); g_ctx.qc_W.release(); g_ctx.qc_O.release(); // the first pass is over
+  g_ctx.kin_ingested_valid = false;
   if (g_ctx.kin_K.reserve(n_total * n_total * 8))
     return fail(GEMMA_HIP_ENOMEM, "kin_begin: cannot allocate K (%zu bytes)", n_total * n_total * 8);
   HIPCHK(hipMemsetAsync(g_ctx.kin_K.p, 0, n_total * n_total * 8, 0));
@@ -80,6 +82,10 @@ static int kin_add_i8(const void *geno, size_t l, size_t ld, hipStream_t s) {
     a.n = (int)n; a.A = g_ctx.i8_A.as<int8_t>(); a.ldk = (long)ldk; a.mean = g_ctx.i8_mean.as<double>();
     hipLaunchKernelGGL(ingest_i8_kernel, dim3((unsigned)((l + 3) / 4)), dim3(256), 0, s, a);
     HIPCHK(hipGetLastError());
+    if (g_ctx.kin_host_call) { // ingest_i8_kernel was the only reader of gemma_hip_kin_add's staging buffer
+      HIPCHK(hipEventRecord(g_ctx.kin_ingested, s));
+      g_ctx.kin_ingested_valid = true;
+    }
     hipLaunchKernelGGL(kin_i8_transpose_kernel, dim3((unsigned)((ldl + 63) / 64), (unsigned)((rows_t + 63) / 64)), dim3(256), 0,
                        s, g_ctx.i8_A.as<int8_t>(), (long)l, (long)ldk, (long)n, g_ctx.kin_At.as<int8_t>(),
                        g_ctx.kin_Gt.as<int8_t>(), (long)ldl, (long)rows_t);
@@ -240,6 +246,10 @@ extern "C" int gemma_hip_kin_add_d(int kind, const void *geno, size_t l, size_t 
     }
     HIPCHK(hipGetLastError());
   }
+  if (g_ctx.kin_host_call) { // the staging buffer of gemma_hip_kin_add is free again from here on
+    HIPCHK(hipEventRecord(g_ctx.kin_ingested, s));
+    g_ctx.kin_ingested_valid = true;
+  }
   {
     // K(upper tiles) += X^T X : A = X as [k = snp][m = individual]  -> ('T','N')
     ProfScope ps(GEMMA_STAGE_KIN_GEMM, s);
@@ -261,11 +271,34 @@ extern "C" int gemma_hip_kin_add(int kind, const void *geno, size_t l, size_t ld
   const size_t rows = (kind == GEMMA_GENO_F64_IDV_MAJOR) ? n : l;
   const size_t esz = (kind == GEMMA_GENO_PLINK_2BIT) ? 1 : 8;
   const size_t bytes = rows * ld * esz;
+  if (bytes > g_ctx.kin_stage.cap) g_ctx.kin_ingested_valid = false; // (the hipFree inside reserve waits for the device)
   if (g_ctx.kin_stage.reserve(bytes)) return fail(GEMMA_HIP_ENOMEM, "kin_add: staging %zu bytes", bytes);
   // last row may be shorter than ld in the caller's buffer
   const size_t width = need * esz;
-  HIPCHK(hipMemcpy2D(g_ctx.kin_stage.p, ld * esz, geno, ld * esz, width, rows, hipMemcpyHostToDevice));
-  return gemma_hip_kin_add_d(kind, g_ctx.kin_stage.p, l, ld, nullptr);
+  if (!g_ctx.kin_copy) { // created once; without it the upload stays on the null stream (behind the previous block's kernels)
+    if (hipStreamCreateWithFlags(&g_ctx.kin_copy, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&g_ctx.kin_copied, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&g_ctx.kin_ingested, hipEventDisableTiming) != hipSuccess) {
+      (void)hipGetLastError();
+      if (g_ctx.kin_copy) (void)hipStreamDestroy(g_ctx.kin_copy);
+      g_ctx.kin_copy = nullptr;
+    }
+  }
+  if (!g_ctx.kin_copy) {
+    HIPCHK(hipMemcpy2D(g_ctx.kin_stage.p, ld * esz, geno, ld * esz, width, rows, hipMemcpyHostToDevice));
+    return gemma_hip_kin_add_d(kind, g_ctx.kin_stage.p, l, ld, nullptr);
+  }
+  // the upload beside the previous block's kernels: behind that block's ingest (the staging buffer's only reader), in front of
+  // this block's kernels on the null stream; the caller's buffer is consumed when the call returns
+  if (g_ctx.kin_ingested_valid) HIPCHK(hipStreamWaitEvent(g_ctx.kin_copy, g_ctx.kin_ingested, 0));
+  HIPCHK(hipMemcpy2DAsync(g_ctx.kin_stage.p, ld * esz, geno, ld * esz, width, rows, hipMemcpyHostToDevice, g_ctx.kin_copy));
+  HIPCHK(hipEventRecord(g_ctx.kin_copied, g_ctx.kin_copy));
+  HIPCHK(hipStreamWaitEvent(nullptr, g_ctx.kin_copied, 0));
+  g_ctx.kin_host_call = true;
+  const int rc = gemma_hip_kin_add_d(kind, g_ctx.kin_stage.p, l, ld, nullptr);
+  g_ctx.kin_host_call = false;
+  HIPCHK(hipEventSynchronize(g_ctx.kin_copied));
+  return rc;
 }
 
 extern "C" int gemma_hip_kin_end_d(double *K_d, size_t *ns_used, void *stream) {

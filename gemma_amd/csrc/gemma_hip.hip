@@ -152,6 +152,13 @@ struct Ctx {
   int kin_mode = 1;
   size_t kin_ns = 0;
   DevBuf kin_K, kin_X, kin_stage;
+  // gemma_hip_kin_add (host blocks): the upload of block k + 1 runs on its own stream beside the kernels of block k (round 6); it
+  // waits for the ingest of block k -- the only reader of the staging buffer -- and the null stream waits for the upload
+  hipStream_t kin_copy = nullptr;
+  hipEvent_t kin_copied = nullptr, kin_ingested = nullptr;
+  bool kin_ingested_valid = false, kin_host_call = false;
+  DevBuf qc_G, qc_M, qc_W, qc_O; // gemma_hip_snp_qc: block, index map, W^T, statistics -- kept between the calls of a first pass (round 6:
+                                 // four hipMalloc + hipFree per 100 MB block were a fifth of the pass), released by kin_begin / shutdown
   // exact-integer path of the centred kinship of hard calls (kin_i8.hip.h)
   bool kin_i8 = false, kin_i8_used = false;
   DevBuf i8_meta, i8_rowsur; // sparse mask operand: the words of the packed block, dropped calls per row
@@ -385,6 +392,7 @@ extern "C" void gemma_hip_shutdown(void) {
   (void)hipDeviceSynchronize();
   for (int s = 0; s < GEMMA_STAGE_COUNT; ++s) prof_collect(s);
   g_ctx.kin_K.release(); g_ctx.kin_X.release(); g_ctx.kin_stage.release();
+  g_ctx.qc_G.release(); g_ctx.qc_M.release(); g_ctx.qc_W.release(); g_ctx.qc_O.release();
   kin_i8_release();
   g_ctx.own_U.release(); g_ctx.own_eval.release(); g_ctx.own_Uty.release(); g_ctx.own_UtW.release();
   g_ctx.UtWt.release(); g_ctx.idx_map.release(); g_ctx.X.release(); g_ctx.UtX.release();
@@ -407,6 +415,14 @@ extern "C" void gemma_hip_shutdown(void) {
     g_ctx.ov_stream = nullptr;
     for (auto &e : g_ctx.ov_ready) e = nullptr;
     g_ctx.ov_done = nullptr;
+  }
+  if (g_ctx.kin_copy) {
+    (void)hipStreamDestroy(g_ctx.kin_copy);
+    if (g_ctx.kin_copied) (void)hipEventDestroy(g_ctx.kin_copied);
+    if (g_ctx.kin_ingested) (void)hipEventDestroy(g_ctx.kin_ingested);
+    g_ctx.kin_copy = nullptr;
+    g_ctx.kin_copied = g_ctx.kin_ingested = nullptr;
+    g_ctx.kin_ingested_valid = false;
   }
   g_ctx.kin_active = g_ctx.lmm_active = false;
   g_ctx.kept_K.release(); g_ctx.kept_UE.release();
