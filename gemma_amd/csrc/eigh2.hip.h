@@ -1366,6 +1366,18 @@ static inline int eig2_gram(const double *X, const double *Y, long ld, long K, d
 
 // A (n x n, both triangles) -> band in w2.Bd; reflectors in ws.VT (row j0 + c: reflector c of the panel at j0, head at
 // column j0 + 128 + c), their compact-WY factors in ws.Tall.  A is destroyed.
+// the look-ahead's second stream and its two events (eig2_sy2sb); destroyed by eigh_tu_shutdown
+struct Eig2LookAhead {
+  hipStream_t stream = nullptr;
+  hipEvent_t ready = nullptr, done = nullptr;
+};
+static Eig2LookAhead g_eig2_la;
+static inline void eig2_lookahead_destroy() {
+  if (g_eig2_la.stream) (void)hipStreamDestroy(g_eig2_la.stream);
+  if (g_eig2_la.ready) (void)hipEventDestroy(g_eig2_la.ready);
+  if (g_eig2_la.done) (void)hipEventDestroy(g_eig2_la.done);
+  g_eig2_la = Eig2LookAhead();
+}
 static inline int eig2_sy2sb(double *A, long n, EigWs &ws, Eig2Ws &w2, hipStream_t s, std::string &msg) {
   const long nb2 = (long)E2_B * E2_B;
   EIG_HIP(hipMemsetAsync(ws.VT, 0, (size_t)n * n * 8, s));
@@ -1441,8 +1453,8 @@ static inline int eig2_sy2sb(double *A, long n, EigWs &ws, Eig2Ws &w2, hipStream
   // update the chain slows down by more than the product hides (measured, profiles/r06_eigh_lookahead.txt: looking ahead at every
   // panel n = 20 000 loses 0.03 s and n = 33 000 0.06 s; n = 50 000 gains 0.13 s, and 0.19 s with the launches only).
   // GEMMA_HIP_EIGH_LOOKAHEAD=0: never; =1: at every panel (the bit-identity tests).
-  static hipStream_t la_stream = nullptr;
-  static hipEvent_t la_ready = nullptr, la_done = nullptr;
+  hipStream_t &la_stream = g_eig2_la.stream;
+  hipEvent_t &la_ready = g_eig2_la.ready, &la_done = g_eig2_la.done;
   const char *ela = getenv("GEMMA_HIP_EIGH_LOOKAHEAD");
   const int la_mode = (ela && ela[0] == '0') ? 0 : (ela && ela[0] == '1') ? 1 : 2; // 2: panels on the launch path only
   bool lookahead = la_mode > 0 && fused_mirror;
@@ -1454,7 +1466,7 @@ static inline int eig2_sy2sb(double *A, long n, EigWs &ws, Eig2Ws &w2, hipStream
         hipEventCreateWithFlags(&la_ready, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&la_done, hipEventDisableTiming) != hipSuccess) {
       (void)hipGetLastError();
-      la_stream = nullptr;
+      eig2_lookahead_destroy();
       lookahead = false;
       return false;
     }

@@ -43,6 +43,7 @@ void eigh_last_stages(double *t8) {
 
 void eigh_tu_shutdown() {
   gemm_aux_destroy();
+  eig2_lookahead_destroy();
   eig_pool().keep = false;
   (void)eig_pool().drop_idle();
 }
