@@ -893,6 +893,13 @@ def main():
                                               "utx_gemm (genotype product alone)": round(api.profile_read(L.STAGE_UTX_GEMM)[0] / ks, 3),
                                               "utx_post": round(api.profile_read(L.STAGE_UTX_POST)[0] / ks, 3),
                                               "assoc": round(api.profile_read(L.STAGE_ASSOC)[0] / ks, 3)}}
+        gc_ms = complete_leg["stage_ms_per_step"]["utx_gemm (genotype product alone)"]
+        if gc_ms > 0:
+            dgc = ctypes_digits(L, n)  # digit products of the genotype operand alone, all on the dense instruction
+            top = dgc * 2.0 * B * n * n / (gc_ms * 1e-3) / 1e12
+            complete_leg["roofline"] = {"kernel": "i8gemm_sparse2_r16_g_kernel", "bound": "mfma", "achieved": round(top, 1), "peak": INT8_MFMA_PEAK_TOPS,
+                                        "unit": "TOP/s", "frac": round(top / INT8_MFMA_PEAK_TOPS, 4), "avg_launch_ms": gc_ms,
+                                        "dense_products": dgc}
         # the same block through both products (GEMMA_HIP_I8_COMPLETE=0): must be the same records, bit for bit
         os.environ["GEMMA_HIP_I8_COMPLETE"] = "0"
         api.reload_env()
