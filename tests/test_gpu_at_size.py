@@ -165,8 +165,8 @@ def test_config4_shape_unfused_int8_planes_n33000(gpu_api, oracle):
     torch.cuda.synchronize()
     sample = np.sort(np.random.default_rng(4).choice(B, S, replace=False))
     raw = blk[torch.from_numpy(sample).to(ch["dev"])].cpu().numpy()
-    utx8 = lmm.dbg_utx(raw[:6], L.GENO_PLINK_2BIT, 1)   # the int8-digit product alone, 6 rows
-    utx64 = lmm.dbg_utx(raw[:6], L.GENO_PLINK_2BIT, 0)  # the fp64 MFMA GEMM on the same rows
+    utx8 = lmm.dbg_utx(raw[:3], L.GENO_PLINK_2BIT, 1)   # the int8-digit product alone, 3 rows (the long-double check is ~5 s per row)
+    utx64 = lmm.dbg_utx(raw[:3], L.GENO_PLINK_2BIT, 0)  # the fp64 MFMA GEMM on the same rows
     lmm.finish()
     got = _sumstat(gpu_api, out)
     X = oracle.bed_decode(raw, n)
@@ -174,7 +174,7 @@ def test_config4_shape_unfused_int8_planes_n33000(gpu_api, oracle):
     # From n = 16384 up the product uses 6 base-256 digits of U (csrc/i8gemm.hip.h): U is rounded at 2^-47 of each column's
     # maximum, which puts its error (units of sum_k |x_k||u_k|, as in test_utx_int8_digit_product_matches_fp64) at the level
     # of the fp64 GEMM's own rounding at this n -- both are measured here; the bar is the one that test sets for the fp64 path.
-    Xi6 = oracle.impute_mean(X[:6])
+    Xi6 = oracle.impute_mean(X[:3])
     exact = (Xi6.astype(np.longdouble) @ Uh.astype(np.longdouble)).astype(np.float64)
     scale = np.abs(Xi6) @ np.abs(Uh)
     err8 = float(np.max(np.abs(utx8 - exact) / scale))
@@ -182,7 +182,7 @@ def test_config4_shape_unfused_int8_planes_n33000(gpu_api, oracle):
     # where the two maxima sit and what the typical error is (the two maxima were the same number)
     e8m, e64m = np.abs(utx8 - exact) / scale, np.abs(utx64 - exact) / scale
     w8, w64 = np.unravel_index(np.argmax(e8m), e8m.shape), np.unravel_index(np.argmax(e64m), e64m.shape)
-    _record("U^T x at n=%d, 6 rows: int8-digit product (6 digits) max err %.2e at %s (rms %.2e), fp64 MFMA GEMM max err %.2e at %s "
+    _record("U^T x at n=%d, 3 rows: int8-digit product (6 digits) max err %.2e at %s (rms %.2e), fp64 MFMA GEMM max err %.2e at %s "
             "(rms %.2e) (units of sum|x||u|; bar 64 x 2.3e-16 = 1.47e-14); at the int8 maximum: exact %.17g int8 %.17g fp64 %.17g, "
             "eigenvalue there %.3e" % (n, err8, w8, float(np.sqrt(np.mean(e8m ** 2))), err64, w64, float(np.sqrt(np.mean(e64m ** 2))),
                                        exact[w8], utx8[w8], utx64[w8], float(ev[w8[1]])))
